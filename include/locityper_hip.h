@@ -1,0 +1,274 @@
+/*
+ * locityper_hip.h — C ABI of liblocityper_hip.so
+ *
+ * MI355X (gfx950) implementation of ONE hot path of Locityper: read -> haplotype
+ * likelihood scoring and genotype pre-filtering / assignment of `locityper genotype`.
+ * Every entry point below names the reference interface it replaces
+ * (paths relative to the reference crate root, tprodanov/locityper v1.7.2).
+ *
+ * Conventions
+ *   - all functions return int32 status (LCTY_OK == 0); the message of the last
+ *     failure on the calling thread is available from lcty_last_error();
+ *     codes mirror the error categories of src/err.rs:11-30;
+ *   - handles are opaque and owned by the library; input buffers are caller-owned
+ *     host memory, only read during the call; output buffers are caller-allocated;
+ *   - distinct handles may be used from distinct threads concurrently;
+ *   - nothing in here falls back to the CPU: without a usable HIP device every
+ *     compute entry point fails with LCTY_ERR_RUNTIME.
+ */
+#ifndef LOCITYPER_HIP_H
+#define LOCITYPER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (src/err.rs:11-30) ---------------------------------- */
+#define LCTY_OK                0
+#define LCTY_ERR_INVALID_INPUT 1   /* Error::InvalidInput */
+#define LCTY_ERR_INVALID_DATA  2   /* Error::InvalidData  */
+#define LCTY_ERR_RUNTIME       3   /* Error::RuntimeError */
+#define LCTY_ERR_SOLVER        4   /* Error::Solver       */
+#define LCTY_ERR_UNSUPPORTED   5   /* shape outside what this build handles (fails loudly, never silently) */
+
+/* ---- constants of the path -------------------------------------------- */
+#define LCTY_GC_BINS        101    /* src/bg/depth.rs:42 */
+#define LCTY_DEPTH_CACHE    256    /* src/model/distr_cache.rs:14 */
+#define LCTY_MAX_ALT_CN     15     /* src/math/distr/bayes.rs:4,16 (alternatives.len() < 16) */
+#define LCTY_MAX_USED_ALNS  10     /* src/model/locs.rs:743 */
+#define LCTY_MAX_UNUSED_ALNS 2     /* src/model/locs.rs:740 */
+#define LCTY_NONE_U32       0xFFFFFFFFu
+
+/* sequencing technology (src/bg/mod.rs:182-268) */
+#define LCTY_TECH_ILLUMINA 0
+#define LCTY_TECH_HIFI     1
+#define LCTY_TECH_PACBIO   2
+#define LCTY_TECH_NANOPORE 3
+
+/* edit-distance threshold kind (src/bg/err_prof.rs:365-399) */
+#define LCTY_EDIT_FRACTION 0
+#define LCTY_EDIT_PVALUE   1
+
+/* read status after AllAlignments::load (src/model/locs.rs:1116-1150, 1255-1286) */
+#define LCTY_READ_GOOD          0  /* goes to AllAlignments::reads */
+#define LCTY_READ_POORLY_MAPPED 1
+#define LCTY_READ_OUT_OF_BOUNDS 2
+#define LCTY_READ_FEW_KMERS     3  /* goes to AllAlignments::unused_reads */
+
+/* alignment record flags: BAM flag bits, plus MATE2 assigned by the loader
+ * (src/model/locs.rs:1119-1131: first primary-led group = ReadEnd::First). */
+#define LCTY_FLAG_UNMAPPED  0x0004u
+#define LCTY_FLAG_REVERSE   0x0010u
+#define LCTY_FLAG_MATE2     0x0080u
+#define LCTY_FLAG_SECONDARY 0x0100u
+#define LCTY_FLAG_SUPPL     0x0800u
+
+/* raw BAM CIGAR op codes accepted on the path (src/seq/cigar.rs:116-129) */
+#define LCTY_CIGAR_M 0u  /* rejected: the path requires --eqx (src/seq/aln.rs:311) */
+#define LCTY_CIGAR_I 1u
+#define LCTY_CIGAR_D 2u
+#define LCTY_CIGAR_S 4u
+#define LCTY_CIGAR_H 5u
+#define LCTY_CIGAR_EQ 7u
+#define LCTY_CIGAR_X 8u
+
+/* ---- plain-data structs crossing the boundary -------------------------- */
+
+/* model::Params (src/model/mod.rs:64-135) — the fields the path consumes. */
+typedef struct lcty_params {
+    uint32_t boundary_size;      /* 200 */
+    int32_t  tweak;              /* -1 = auto (set_tweak_size, model/mod.rs:179-197) */
+    double   lik_skew;           /* 0.85 */
+    double   prob_diff;          /* NaN = auto: |unmapped_penalty| + ln 10 (command/genotype.rs:1294-1296) */
+    double   unmapped_penalty;   /* NaN = auto by technology (model/mod.rs:55-60) */
+    double   poor_compl;         /* 0.5 */
+    double   poor_compl_edit;    /* 0.7 */
+    double   compl_weight_bp;    /* 0.5; <= 0 disables the calculator (None) */
+    double   compl_weight_pow;   /* 4 */
+    double   kmers_weight_bp;    /* 0.2; <= 0 disables */
+    double   kmers_weight_pow;   /* 4 */
+    double   min_weight;         /* 0.001 */
+    double   filt_diff;          /* ln 1e100 */
+    double   prob_thresh;        /* ln 1e-4 */
+    double   alt_cn[LCTY_MAX_ALT_CN]; /* 0.3,2,3,4,5 */
+    uint32_t n_alt_cn;           /* 5 */
+    uint16_t kmer_soft_thresh;   /* 5 */
+    uint16_t kmer_hard_thresh;   /* 1 */
+    uint8_t  complexity_k;       /* 5 */
+    uint8_t  dont_skip;          /* 0 */
+    uint8_t  strict_subset;      /* locs.rs:490: BAM header has fewer contigs than the contig set */
+    uint8_t  _pad0;
+    uint32_t threads;            /* reference `-@` (only enters truncate_ixs / discard thresholds) */
+} lcty_params;
+
+/* bg::BgDistr as loaded from distr.gz (src/bg/mod.rs:147-177) */
+typedef struct lcty_bg {
+    double   op_lnprobs[5];      /* matches, mismatches, insertions, deletions, clipping (bg/err_prof.rs:321-329) */
+    double   edit_alpha;         /* BetaBinomial(alpha, beta) of the error profile */
+    double   edit_beta;
+    double   ins_n;              /* insert-size NBinom(n,p); ignored when !is_paired (bg/insertsz.rs:195-208) */
+    double   ins_p;
+    double   depth_n[LCTY_GC_BINS]; /* bg_depth NBinom per GC bin (bg/depth.rs:400-412) */
+    double   depth_p[LCTY_GC_BINS];
+    double   edit_p1;            /* EditThresh params: Fraction(.03,.06) / PValue(.99,.999) (bg/err_prof.rs:394-399) */
+    double   edit_p2;
+    uint32_t window;             /* bg_depth.window */
+    uint32_t neighb;             /* bg_depth.neighb */
+    int32_t  is_paired;          /* insert_distr defined */
+    int32_t  technology;         /* LCTY_TECH_* */
+    int32_t  edit_kind;          /* LCTY_EDIT_* */
+    uint32_t _pad0;
+} lcty_bg;
+
+/* One BAM record of OUT/loci/<locus>/aln.bam reduced to what the path reads
+ * (src/seq/aln.rs:147-157, src/seq/cigar.rs:203-208). 16 bytes. */
+typedef struct lcty_aln_rec {
+    uint32_t pos;        /* 0-based leftmost reference position (record.pos()) */
+    uint16_t contig;     /* ContigId of the allele */
+    uint16_t flags;      /* LCTY_FLAG_* */
+    uint32_t n_cigar;    /* number of raw CIGAR words */
+    uint32_t cigar_rel;  /* offset of the first CIGAR word relative to the pair's cigar_off */
+} lcty_aln_rec;
+
+/* Host view of a chunk of read pairs (or single reads) with all their records, in
+ * the input-order contract of locs.rs:1116-1150: per pair
+ *   mate-1 primary, mate-1 secondaries..., mate-2 primary, mate-2 secondaries...
+ * Sequences are the primary record's SEQ (BAM orientation), 2-bit packed
+ * (A=0,C=1,G=2,T=3; src/seq/kmers.rs:179-183) with a 1-bit/base "not ACGT" side
+ * channel because kmers() emits UNDEF for such windows (kmers.rs:184-190). */
+typedef struct lcty_reads_host {
+    uint64_t n_pairs;
+    const uint32_t*     mate_len;   /* [2*n_pairs]; 0 = mate absent (single-end data: every odd entry 0) */
+    const uint64_t*     mate_off;   /* [2*n_pairs+1] base offsets, each a multiple of 32 */
+    const uint32_t*     bases2;     /* 16 bases per word, base i of a mate at bit 2*(i%16) of word (off+i)/16 */
+    const uint32_t*     nmask;      /* 32 bases per word, bit set = base is not A/C/G/T */
+    const uint64_t*     aln_off;    /* [n_pairs+1] record offsets */
+    const lcty_aln_rec* recs;
+    const uint64_t*     cigar_off;  /* [n_pairs+1] CIGAR word offsets */
+    const uint32_t*     cigar;      /* raw BAM CIGAR words: len<<4 | op */
+} lcty_reads_host;
+
+/* PairAlignment (src/model/locs.rs:668-676); LCTY_NONE_U32 encodes Option::None. */
+typedef struct lcty_pair_aln {
+    double   ln_prob;    /* already multiplied by the read weight (locs.rs:861-863) */
+    uint32_t ix1;        /* record index inside the pair, or NONE */
+    uint32_t mid1;       /* Interval::middle of the mate-1 alignment, or NONE */
+    uint32_t ix2;
+    uint32_t mid2;
+    uint16_t contig;
+    uint16_t _pad[3];
+} lcty_pair_aln;
+
+typedef struct lcty_ctx   lcty_ctx;
+typedef struct lcty_locus lcty_locus;
+typedef struct lcty_reads lcty_reads;
+
+/* ---- library / context -------------------------------------------------- */
+const char* lcty_last_error(void);
+const char* lcty_version(void);
+/* number of HIP devices visible; 0 when there is none (never an error) */
+int32_t lcty_device_count(void);
+int32_t lcty_ctx_create(int32_t device_id, lcty_ctx** out);
+void    lcty_ctx_destroy(lcty_ctx* ctx);
+int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
+
+/* defaults of model::Params::default (model/mod.rs:108-135) */
+void    lcty_params_default(lcty_params* out);
+/* Resolves the "auto" fields exactly as command/genotype.rs:1282-1296 does:
+ * tweak (model/mod.rs:179-197), unmapped_penalty (55-60), prob_diff. */
+int32_t lcty_params_resolve(lcty_params* params, const lcty_bg* bg);
+
+/* ---- locus: ContigSet + KmerCounts + ContigInfos + UniqueKmers + LUTs ----
+ * Replaces ContigSet::load_with_kmer_counts (src/seq/contigs.rs:295),
+ * ContigInfos::new (src/model/windows.rs:584-615), UniqueKmers::new
+ * (src/model/locs.rs:930-963), InsertDistr::load (src/bg/insertsz.rs:195-208),
+ * EditDistCache::new (src/bg/err_prof.rs:422-428), DistrCache::new
+ * (src/model/distr_cache.rs:61-75).
+ *   seqs       ASCII allele sequences, concatenated; seq_off[n_alleles+1]
+ *   offtarget  off-target k-mer counts (first KmerCounts block), cnt_off[n_alleles+1],
+ *              cnt_off[a+1]-cnt_off[a] == len(a)+1-k                                  */
+int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles,
+                          const uint8_t* seqs, const uint64_t* seq_off,
+                          const uint16_t* offtarget, const uint64_t* cnt_off, uint32_t k,
+                          const lcty_bg* bg, const lcty_params* params, lcty_locus** out);
+void    lcty_locus_destroy(lcty_locus* locus);
+/* number of locus-unique canonical k-mers (the count logged at locs.rs:953) */
+int32_t lcty_locus_n_unique_kmers(const lcty_locus* locus, uint64_t* out);
+/* ContigInfo::new products per allele (windows.rs:386-407): position count = len-neighb+1.
+ * Any output pointer may be NULL. uniq counts / complexity counts are the integer
+ * numerators, the f64 values of the reference are count*mult with
+ *   uniq_kmer_frac = uniq * (1/(neighb+1-k)),  complexity = distinct * (1/min(neighb+1-ck, 4^ck)). */
+int32_t lcty_locus_contig_info(const lcty_locus* locus, uint32_t allele,
+                               uint8_t* gc, uint32_t* uniq_cnt, uint16_t* compl_cnt,
+                               uint32_t* n_windows, uint32_t* reg_start);
+/* EditDistCache::get (bg/err_prof.rs:434-448) */
+int32_t lcty_locus_edit_thresholds(const lcty_locus* locus, uint32_t read_len, uint32_t* good, uint32_t* passable);
+/* InsertDistr::ln_prob / insert_penalty (bg/insertsz.rs:153-175) */
+int32_t lcty_locus_insert_lnprob(const lcty_locus* locus, uint32_t n, const uint32_t* sizes, double* out, double* insert_penalty);
+/* DistrCache: ln P(depth) for gc bin, depth in 0..LCTY_DEPTH_CACHE (distr_cache.rs:61-75; bayes.rs:27-35) */
+int32_t lcty_locus_depth_lut(const lcty_locus* locus, double* out /* [101*256] */);
+
+/* ---- reads: device-resident batch -----------------------------------------
+ * Capacity is fixed at creation so a batch larger than host memory can be
+ * appended chunk by chunk (each append is one set of H2D copies).             */
+int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_bases,
+                          uint64_t cap_recs, uint64_t cap_cigar, lcty_reads** out);
+int32_t lcty_reads_append(lcty_reads* reads, const lcty_reads_host* chunk);
+void    lcty_reads_destroy(lcty_reads* reads);
+int32_t lcty_reads_n_pairs(const lcty_reads* reads, uint64_t* out);
+
+/* AllAlignments::load without alignment recovery (src/model/locs.rs:1085-1185,
+ * 1237-1288 with opt_hap_alns == None): K2 unique k-mers + read weight (968-1002),
+ * K4 op counts + ErrorProfile::ln_prob (aln.rs:301-317, err_prof.rs:212-221),
+ * K5 thresholds / 128-bp dedupe (502-567, 298-344), K7 pairing (746-868 / 873-911)
+ * and K8 the dense row of best_aln_matrix (1203-1212) — one fused launch.
+ * Asynchronous on the context's stream.                                         */
+int32_t lcty_score_reads(lcty_reads* reads);
+
+/* per-pair products of load(): any pointer may be NULL */
+int32_t lcty_reads_get_status(lcty_reads* reads, uint8_t* status, double* weight,
+                              double* unmapped_prob, uint16_t* uniq_kmers /* [2*n_pairs] */);
+/* number of LCTY_READ_GOOD pairs (AllAlignments::reads().len()) */
+int32_t lcty_reads_n_good(lcty_reads* reads, uint64_t* out);
+/* AllAlignments::best_aln_matrix (locs.rs:1203-1212): out[a*n_good + j], j over GOOD
+ * pairs in input order (the order produced with threads == 1, locs.rs:1149). */
+int32_t lcty_best_aln_matrix(lcty_reads* reads, double* out);
+/* GrouppedAlignments::aln_pairs of every GOOD and FEW_KMERS pair, CSR over all input
+ * pairs: off[n_pairs+1]; entries contig-ascending, ln_prob-descending inside a contig
+ * (locs.rs:819-851). Call with out == NULL to obtain only the offsets / total. */
+int32_t lcty_reads_get_pair_alns(lcty_reads* reads, uint64_t* off, lcty_pair_aln* out, uint64_t cap);
+
+/* run_filter (src/solvers/solve.rs:87-122): scores[g] = prior[g] + sum_r max_{a in g} M[a][r].
+ * genotypes == NULL: all multisets of size `ploidy` in the order of
+ * gen_combinations_with_repl (src/ext/vec.rs:298-339), n_genotypes is then checked
+ * against count_combinations_with_repl. priors == NULL: all 0.0.                     */
+int32_t lcty_prefilter(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_genotypes,
+                       uint32_t ploidy, const double* priors, double* scores);
+/* device-only variant used by the timed path: leaves the scores in HBM */
+int32_t lcty_prefilter_async(lcty_reads* reads, uint32_t ploidy);
+int32_t lcty_prefilter_scores(lcty_reads* reads, double* scores, uint64_t n);
+
+/* truncate_ixs (src/solvers/solve.rs:52-84). ixs: in = candidate indices, out = kept,
+ * sorted by (score desc, index asc); returns the kept count in *n_keep.              */
+int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double filt_diff,
+                      uint64_t min_size, uint64_t threads, uint64_t* n_keep);
+
+/* generate_genotypes without priors (src/command/genotype.rs:1120-1126) */
+uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy);
+int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* out, uint64_t cap);
+
+/* ---- measurement hooks (bench.py) -----------------------------------------
+ * HIP-event timing of the launches issued between begin/end on the context's
+ * stream; kernel ids LCTY_K_*.                                                 */
+#define LCTY_K_SCORE     0
+#define LCTY_K_PREFILTER 1
+#define LCTY_K_COUNT     2
+int32_t lcty_timing_reset(lcty_ctx* ctx);
+int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCITYPER_HIP_H */

@@ -1,0 +1,76 @@
+"""Loader of liblocityper_hip.so (the C-ABI product library). Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+from .cdefs import Bg, Params, ReadsHost, PairAln
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblocityper_hip.so")
+_lib = None
+
+I32, U32, U64, D, VP = C.c_int32, C.c_uint32, C.c_uint64, C.c_double, C.c_void_p
+P = C.POINTER
+
+# name -> (restype, argtypes): every symbol declared in include/locityper_hip.h
+SIGNATURES = {
+    "lcty_last_error": (C.c_char_p, []),
+    "lcty_version": (C.c_char_p, []),
+    "lcty_device_count": (I32, []),
+    "lcty_ctx_create": (I32, [I32, P(VP)]),
+    "lcty_ctx_destroy": (None, [VP]),
+    "lcty_ctx_synchronize": (I32, [VP]),
+    "lcty_params_default": (None, [P(Params)]),
+    "lcty_params_resolve": (I32, [P(Params), P(Bg)]),
+    "lcty_locus_create": (I32, [VP, U32, VP, VP, VP, VP, U32, P(Bg), P(Params), P(VP)]),
+    "lcty_locus_destroy": (None, [VP]),
+    "lcty_locus_n_unique_kmers": (I32, [VP, P(U64)]),
+    "lcty_locus_contig_info": (I32, [VP, U32, VP, VP, VP, P(U32), P(U32)]),
+    "lcty_locus_edit_thresholds": (I32, [VP, U32, P(U32), P(U32)]),
+    "lcty_locus_insert_lnprob": (I32, [VP, U32, VP, VP, P(D)]),
+    "lcty_locus_depth_lut": (I32, [VP, VP]),
+    "lcty_reads_create": (I32, [VP, U64, U64, U64, U64, P(VP)]),
+    "lcty_reads_append": (I32, [VP, P(ReadsHost)]),
+    "lcty_reads_destroy": (None, [VP]),
+    "lcty_reads_n_pairs": (I32, [VP, P(U64)]),
+    "lcty_score_reads": (I32, [VP]),
+    "lcty_reads_get_status": (I32, [VP, VP, VP, VP, VP]),
+    "lcty_reads_n_good": (I32, [VP, P(U64)]),
+    "lcty_best_aln_matrix": (I32, [VP, VP]),
+    "lcty_reads_get_pair_alns": (I32, [VP, VP, VP, U64]),
+    "lcty_prefilter": (I32, [VP, VP, U64, U32, VP, VP]),
+    "lcty_prefilter_async": (I32, [VP, U32]),
+    "lcty_prefilter_scores": (I32, [VP, VP, U64]),
+    "lcty_truncate": (I32, [VP, VP, U64, D, U64, U64, P(U64)]),
+    "lcty_count_genotypes": (U64, [U32, U32]),
+    "lcty_generate_genotypes": (I32, [U32, U32, VP, U64]),
+    "lcty_timing_reset": (I32, [VP]),
+    "lcty_timing_get": (I32, [VP, I32, P(U64), P(D)]),
+}
+
+
+class LocityperError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[lcty error {code}] {msg}")
+        self.code = code
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C locityper_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LocityperError(rc, lib().lcty_last_error().decode())

@@ -1,0 +1,242 @@
+"""Thin Python binding of the C ABI (include/locityper_hip.h), used by tests/ and bench.py.
+
+Class and method names follow the reference interface of the path:
+  Locus        ~ ContigSet + KmerCounts + ContigInfos + UniqueKmers (src/model/locs.rs:930-963, windows.rs:584-615)
+  AllAlignments ~ model::locs::AllAlignments (load 1085-1185, best_aln_matrix 1203-1212)
+  run_filter / truncate_ixs ~ src/solvers/solve.rs:52-122
+Everything is computed by liblocityper_hip.so on the GPU; nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import cdefs
+from ._lib import lib, check, VP, U32, U64, D
+from .cdefs import Bg, Params, PAIR_ALN_DTYPE
+
+
+def device_count():
+    return int(lib().lcty_device_count())
+
+
+def default_params():
+    p = Params()
+    lib().lcty_params_default(C.byref(p))
+    return p
+
+
+def resolve_params(p, bg):
+    check(lib().lcty_params_resolve(C.byref(p), C.byref(bg)))
+    return p
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = VP()
+        check(lib().lcty_ctx_create(device, C.byref(self._h)))
+
+    def synchronize(self):
+        check(lib().lcty_ctx_synchronize(self._h))
+
+    def timing_reset(self):
+        check(lib().lcty_timing_reset(self._h))
+
+    def timing(self, kernel):
+        n, ms = U64(), D()
+        check(lib().lcty_timing_get(self._h, kernel, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def close(self):
+        if self._h:
+            lib().lcty_ctx_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+K_SCORE, K_PREFILTER = 0, 1
+
+
+class Locus:
+    def __init__(self, ctx, seqs, seq_off, counts, cnt_off, k, bg, params):
+        self.ctx = ctx
+        self.seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        self.seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        self.counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        self.cnt_off = np.ascontiguousarray(cnt_off, dtype=np.uint64)
+        self.n_alleles = len(self.seq_off) - 1
+        self.k, self.bg, self.params = k, bg, params
+        self._h = VP()
+        check(lib().lcty_locus_create(ctx._h, self.n_alleles, self.seqs.ctypes.data, self.seq_off.ctypes.data,
+                                      self.counts.ctypes.data, self.cnt_off.ctypes.data, k,
+                                      C.byref(bg), C.byref(params), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().lcty_locus_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def n_unique_kmers(self):
+        n = U64()
+        check(lib().lcty_locus_n_unique_kmers(self._h, C.byref(n)))
+        return int(n.value)
+
+    def contig_info(self, a):
+        ln = int(self.seq_off[a + 1] - self.seq_off[a])
+        npos = ln - self.bg.neighb + 1
+        gc = np.zeros(npos, dtype=np.uint8)
+        uniq = np.zeros(npos, dtype=np.uint32)
+        cc = np.zeros(npos, dtype=np.uint16)
+        nw, rs = U32(), U32()
+        check(lib().lcty_locus_contig_info(self._h, a, gc.ctypes.data, uniq.ctypes.data, cc.ctypes.data,
+                                           C.byref(nw), C.byref(rs)))
+        return gc, uniq, cc, nw.value, rs.value
+
+    def edit_thresholds(self, read_len):
+        g, p = U32(), U32()
+        check(lib().lcty_locus_edit_thresholds(self._h, read_len, C.byref(g), C.byref(p)))
+        return g.value, p.value
+
+    def insert_lnprob(self, sizes):
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        out = np.zeros(len(sizes), dtype=np.float64)
+        pen = D()
+        check(lib().lcty_locus_insert_lnprob(self._h, len(sizes), sizes.ctypes.data, out.ctypes.data, C.byref(pen)))
+        return out, pen.value
+
+    def depth_lut(self):
+        out = np.zeros((cdefs.GC_BINS, cdefs.DEPTH_CACHE), dtype=np.float64)
+        check(lib().lcty_locus_depth_lut(self._h, out.ctypes.data))
+        return out
+
+
+class AllAlignments:
+    """Device-resident batch of read pairs and the products of AllAlignments::load."""
+
+    def __init__(self, locus, cap_pairs, cap_bases, cap_recs, cap_cigar):
+        self.locus = locus
+        self._h = VP()
+        check(lib().lcty_reads_create(locus._h, cap_pairs, cap_bases, cap_recs, cap_cigar, C.byref(self._h)))
+        self._scored = False
+
+    @classmethod
+    def load(cls, locus, chunks):
+        """AllAlignments::load: upload `chunks` (ReadsChunk or list of them) and score them."""
+        if not isinstance(chunks, (list, tuple)):
+            chunks = [chunks]
+        self = cls(locus, sum(c.n_pairs for c in chunks), sum(c.n_bases for c in chunks),
+                   sum(len(c.recs) for c in chunks), sum(len(c.cigar) for c in chunks))
+        for c in chunks:
+            self.append(c)
+        self.score()
+        return self
+
+    def append(self, chunk):
+        hs = chunk.host_struct()
+        check(lib().lcty_reads_append(self._h, C.byref(hs)))
+        self._scored = False
+
+    def score(self):
+        check(lib().lcty_score_reads(self._h))
+        self._scored = True
+
+    def close(self):
+        if self._h:
+            lib().lcty_reads_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_pairs(self):
+        n = U64()
+        check(lib().lcty_reads_n_pairs(self._h, C.byref(n)))
+        return int(n.value)
+
+    def n_good(self):
+        n = U64()
+        check(lib().lcty_reads_n_good(self._h, C.byref(n)))
+        return int(n.value)
+
+    def status(self):
+        n = self.n_pairs
+        status = np.zeros(n, dtype=np.uint8)
+        weight = np.zeros(n, dtype=np.float64)
+        unm = np.zeros(n, dtype=np.float64)
+        uniq = np.zeros(2 * n, dtype=np.uint16)
+        check(lib().lcty_reads_get_status(self._h, status.ctypes.data, weight.ctypes.data, unm.ctypes.data, uniq.ctypes.data))
+        return status, weight, unm, uniq
+
+    def best_aln_matrix(self):
+        """[A][n_good] f64 (locs.rs:1203-1212)."""
+        ng = self.n_good()
+        out = np.zeros((self.locus.n_alleles, ng), dtype=np.float64)
+        check(lib().lcty_best_aln_matrix(self._h, out.ctypes.data))
+        return out
+
+    def pair_alns(self):
+        n = self.n_pairs
+        off = np.zeros(n + 1, dtype=np.uint64)
+        check(lib().lcty_reads_get_pair_alns(self._h, off.ctypes.data, None, 0))
+        out = np.zeros(int(off[-1]), dtype=PAIR_ALN_DTYPE)
+        check(lib().lcty_reads_get_pair_alns(self._h, off.ctypes.data, out.ctypes.data, len(out)))
+        return off, out
+
+    # ---- prefilter ----
+    def run_filter(self, genotypes=None, priors=None, ploidy=2):
+        """run_filter scores (solve.rs:101-119). genotypes None = all multisets of `ploidy`."""
+        A = self.locus.n_alleles
+        if genotypes is None:
+            n = count_genotypes(A, ploidy)
+            gptr = None
+        else:
+            genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+            n, ploidy = genotypes.shape
+            gptr = genotypes.ctypes.data
+        scores = np.zeros(n, dtype=np.float64)
+        pr = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+        check(lib().lcty_prefilter(self._h, gptr, n, ploidy, None if pr is None else pr.ctypes.data, scores.ctypes.data))
+        return scores
+
+    def prefilter_async(self, ploidy=2):
+        check(lib().lcty_prefilter_async(self._h, ploidy))
+
+    def prefilter_scores(self):
+        n = count_genotypes(self.locus.n_alleles, 2)
+        scores = np.zeros(n, dtype=np.float64)
+        check(lib().lcty_prefilter_scores(self._h, scores.ctypes.data, n))
+        return scores
+
+
+def count_genotypes(n_alleles, ploidy):
+    return int(lib().lcty_count_genotypes(n_alleles, ploidy))
+
+
+def generate_genotypes(n_alleles, ploidy):
+    n = count_genotypes(n_alleles, ploidy)
+    out = np.zeros((n, ploidy), dtype=np.uint16)
+    check(lib().lcty_generate_genotypes(n_alleles, ploidy, out.ctypes.data, n))
+    return out
+
+
+def truncate_ixs(scores, ixs, filt_diff, min_size, threads):
+    """truncate_ixs (solve.rs:52-84): returns the kept indices sorted by (score desc, index asc)."""
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    ixs = np.ascontiguousarray(ixs, dtype=np.uint64).copy()
+    keep = U64()
+    check(lib().lcty_truncate(scores.ctypes.data, ixs.ctypes.data, len(ixs), filt_diff, min_size, threads, C.byref(keep)))
+    return ixs[:int(keep.value)]

@@ -1,0 +1,226 @@
+"""ctypes mirrors of the plain-data structs in include/locityper_hip.h.
+
+Shared by the product binding (api.py), the synthetic-workload generator (synth.py)
+and — in tests only — the oracle binding. Field order and types must match the header.
+"""
+import ctypes as C
+
+import numpy as np
+
+GC_BINS = 101
+DEPTH_CACHE = 256
+MAX_ALT_CN = 15
+NONE_U32 = 0xFFFFFFFF
+
+OK, ERR_INVALID_INPUT, ERR_INVALID_DATA, ERR_RUNTIME, ERR_SOLVER, ERR_UNSUPPORTED = range(6)
+TECH_ILLUMINA, TECH_HIFI, TECH_PACBIO, TECH_NANOPORE = range(4)
+EDIT_FRACTION, EDIT_PVALUE = 0, 1
+READ_GOOD, READ_POORLY_MAPPED, READ_OUT_OF_BOUNDS, READ_FEW_KMERS = range(4)
+
+FLAG_UNMAPPED = 0x4
+FLAG_REVERSE = 0x10
+FLAG_MATE2 = 0x80
+FLAG_SECONDARY = 0x100
+FLAG_SUPPL = 0x800
+
+CIGAR_M, CIGAR_I, CIGAR_D, CIGAR_S, CIGAR_H, CIGAR_EQ, CIGAR_X = 0, 1, 2, 4, 5, 7, 8
+
+
+class Params(C.Structure):
+    """model::Params (src/model/mod.rs:64-135)."""
+    _fields_ = [
+        ("boundary_size", C.c_uint32),
+        ("tweak", C.c_int32),
+        ("lik_skew", C.c_double),
+        ("prob_diff", C.c_double),
+        ("unmapped_penalty", C.c_double),
+        ("poor_compl", C.c_double),
+        ("poor_compl_edit", C.c_double),
+        ("compl_weight_bp", C.c_double),
+        ("compl_weight_pow", C.c_double),
+        ("kmers_weight_bp", C.c_double),
+        ("kmers_weight_pow", C.c_double),
+        ("min_weight", C.c_double),
+        ("filt_diff", C.c_double),
+        ("prob_thresh", C.c_double),
+        ("alt_cn", C.c_double * MAX_ALT_CN),
+        ("n_alt_cn", C.c_uint32),
+        ("kmer_soft_thresh", C.c_uint16),
+        ("kmer_hard_thresh", C.c_uint16),
+        ("complexity_k", C.c_uint8),
+        ("dont_skip", C.c_uint8),
+        ("strict_subset", C.c_uint8),
+        ("_pad0", C.c_uint8),
+        ("threads", C.c_uint32),
+    ]
+
+
+class Bg(C.Structure):
+    """bg::BgDistr as loaded from distr.gz (src/bg/mod.rs:147-177)."""
+    _fields_ = [
+        ("op_lnprobs", C.c_double * 5),
+        ("edit_alpha", C.c_double),
+        ("edit_beta", C.c_double),
+        ("ins_n", C.c_double),
+        ("ins_p", C.c_double),
+        ("depth_n", C.c_double * GC_BINS),
+        ("depth_p", C.c_double * GC_BINS),
+        ("edit_p1", C.c_double),
+        ("edit_p2", C.c_double),
+        ("window", C.c_uint32),
+        ("neighb", C.c_uint32),
+        ("is_paired", C.c_int32),
+        ("technology", C.c_int32),
+        ("edit_kind", C.c_int32),
+        ("_pad0", C.c_uint32),
+    ]
+
+
+class AlnRec(C.Structure):
+    _fields_ = [
+        ("pos", C.c_uint32),
+        ("contig", C.c_uint16),
+        ("flags", C.c_uint16),
+        ("n_cigar", C.c_uint32),
+        ("cigar_rel", C.c_uint32),
+    ]
+
+
+ALN_REC_DTYPE = np.dtype([("pos", "<u4"), ("contig", "<u2"), ("flags", "<u2"),
+                          ("n_cigar", "<u4"), ("cigar_rel", "<u4")])
+assert ALN_REC_DTYPE.itemsize == C.sizeof(AlnRec) == 16
+
+
+class ReadsHost(C.Structure):
+    _fields_ = [
+        ("n_pairs", C.c_uint64),
+        ("mate_len", C.POINTER(C.c_uint32)),
+        ("mate_off", C.POINTER(C.c_uint64)),
+        ("bases2", C.POINTER(C.c_uint32)),
+        ("nmask", C.POINTER(C.c_uint32)),
+        ("aln_off", C.POINTER(C.c_uint64)),
+        ("recs", C.POINTER(AlnRec)),
+        ("cigar_off", C.POINTER(C.c_uint64)),
+        ("cigar", C.POINTER(C.c_uint32)),
+    ]
+
+
+class PairAln(C.Structure):
+    _fields_ = [
+        ("ln_prob", C.c_double),
+        ("ix1", C.c_uint32),
+        ("mid1", C.c_uint32),
+        ("ix2", C.c_uint32),
+        ("mid2", C.c_uint32),
+        ("contig", C.c_uint16),
+        ("_pad", C.c_uint16 * 3),
+    ]
+
+
+PAIR_ALN_DTYPE = np.dtype([("ln_prob", "<f8"), ("ix1", "<u4"), ("mid1", "<u4"), ("ix2", "<u4"),
+                           ("mid2", "<u4"), ("contig", "<u2"), ("_pad", "<u2", (3,))])
+assert PAIR_ALN_DTYPE.itemsize == C.sizeof(PairAln) == 32
+
+
+def ptr(arr, ctype):
+    """Pointer of `ctype` into a C-contiguous numpy array (kept alive by the caller)."""
+    if arr is None:
+        return C.cast(None, C.POINTER(ctype))
+    assert arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class ReadsChunk:
+    """Numpy-backed lcty_reads_host: a chunk of read pairs with all their records."""
+
+    def __init__(self, mate_len, mate_off, bases2, nmask, aln_off, recs, cigar_off, cigar):
+        self.mate_len = np.ascontiguousarray(mate_len, dtype=np.uint32)
+        self.mate_off = np.ascontiguousarray(mate_off, dtype=np.uint64)
+        self.bases2 = np.ascontiguousarray(bases2, dtype=np.uint32)
+        self.nmask = np.ascontiguousarray(nmask, dtype=np.uint32)
+        self.aln_off = np.ascontiguousarray(aln_off, dtype=np.uint64)
+        self.recs = np.ascontiguousarray(recs, dtype=ALN_REC_DTYPE)
+        self.cigar_off = np.ascontiguousarray(cigar_off, dtype=np.uint64)
+        self.cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        self.n_pairs = len(self.aln_off) - 1
+        assert len(self.mate_len) == 2 * self.n_pairs
+        assert len(self.mate_off) == 2 * self.n_pairs + 1
+        assert len(self.cigar_off) == self.n_pairs + 1
+        assert np.all(self.mate_off % 32 == 0)
+
+    @property
+    def n_bases(self):
+        return int(self.mate_off[-1])
+
+    def host_struct(self):
+        h = ReadsHost()
+        h.n_pairs = self.n_pairs
+        h.mate_len = ptr(self.mate_len, C.c_uint32)
+        h.mate_off = ptr(self.mate_off, C.c_uint64)
+        h.bases2 = ptr(self.bases2, C.c_uint32)
+        h.nmask = ptr(self.nmask, C.c_uint32)
+        h.aln_off = ptr(self.aln_off, C.c_uint64)
+        h.recs = C.cast(self.recs.ctypes.data, C.POINTER(AlnRec))
+        h.cigar_off = ptr(self.cigar_off, C.c_uint64)
+        h.cigar = ptr(self.cigar, C.c_uint32)
+        return h
+
+    # ---- construction from plain Python, for hand-written test cases ----
+    @staticmethod
+    def from_pairs(pairs):
+        """pairs: list of dicts {"seq1": str, "seq2": str|None, "recs": [(contig, pos, flags, cigar_str)]}.
+
+        Records must already be in the input-order contract (mate-1 group then mate-2 group);
+        FLAG_MATE2 is added by the caller. cigar_str uses =XIDSHM letters.
+        """
+        opmap = {"M": 0, "I": 1, "D": 2, "S": 4, "H": 5, "=": 7, "X": 8, "N": 3, "P": 6}
+        mate_len, mate_off, aln_off, cigar_off = [], [0], [0], [0]
+        seqs, recs, cigar = [], [], []
+        for p in pairs:
+            for key in ("seq1", "seq2"):
+                s = p.get(key) or ""
+                mate_len.append(len(s))
+                seqs.append(s)
+                mate_off.append(mate_off[-1] + (len(s) + 31) // 32 * 32)
+            rel = 0
+            for contig, pos, flags, cig in p["recs"]:
+                words = []
+                num = ""
+                for ch in cig:
+                    if ch.isdigit():
+                        num += ch
+                    else:
+                        words.append((int(num) << 4) | opmap[ch])
+                        num = ""
+                recs.append((pos, contig, flags, len(words), rel))
+                cigar.extend(words)
+                rel += len(words)
+            aln_off.append(len(recs))
+            cigar_off.append(len(cigar))
+        nb = mate_off[-1]
+        bases2 = np.zeros(max(nb // 16, 1), dtype=np.uint32)
+        nmask = np.zeros(max(nb // 32, 1), dtype=np.uint32)
+        code = {"A": 0, "C": 1, "G": 2, "T": 3}
+        for m, s in enumerate(seqs):
+            off = mate_off[m]
+            for i, ch in enumerate(s):
+                b = off + i
+                if ch in code:
+                    bases2[b >> 4] |= np.uint32(code[ch] << (2 * (b & 15)))
+                else:
+                    nmask[b >> 5] |= np.uint32(1 << (b & 31))
+        rec_arr = np.array(recs, dtype=ALN_REC_DTYPE) if recs else np.zeros(0, dtype=ALN_REC_DTYPE)
+        return ReadsChunk(mate_len, mate_off, bases2, nmask, aln_off, rec_arr, cigar_off,
+                          np.array(cigar, dtype=np.uint32) if cigar else np.zeros(0, dtype=np.uint32))
+
+    def slice(self, lo, hi):
+        """Sub-chunk of pairs [lo, hi) with rebased offsets."""
+        mo = self.mate_off[2 * lo:2 * hi + 1]
+        ao = self.aln_off[lo:hi + 1]
+        co = self.cigar_off[lo:hi + 1]
+        return ReadsChunk(
+            self.mate_len[2 * lo:2 * hi], mo - mo[0],
+            self.bases2[int(mo[0]) // 16:max(int(mo[-1]) // 16, int(mo[0]) // 16 + 1)],
+            self.nmask[int(mo[0]) // 32:max(int(mo[-1]) // 32, int(mo[0]) // 32 + 1)],
+            ao - ao[0], self.recs[int(ao[0]):int(ao[-1])], co - co[0],
+            self.cigar[int(co[0]):int(co[-1])])

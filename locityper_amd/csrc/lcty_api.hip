@@ -1,0 +1,262 @@
+// lcty_api.hip — context, parameters, prefilter / truncate entry points, timing hooks.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <numeric>
+
+#include "lcty_objects.hpp"
+
+using namespace lcty;
+
+namespace lcty {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace lcty
+
+hipEvent_t lcty_ctx::get_event() {
+    hipEvent_t e;
+    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); return e; }
+    LCTY_HIP(hipEventCreate(&e));
+    return e;
+}
+
+extern "C" {
+
+const char* lcty_last_error(void) { return g_last_error.c_str(); }
+const char* lcty_version(void) { return "locityper_hip 0.1.0 (gfx950)"; }
+
+int32_t lcty_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int32_t lcty_ctx_create(int32_t device_id, lcty_ctx** out) {
+    return guarded([&] {
+        if (!out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+            (void)hipGetLastError();
+            fail(LCTY_ERR_RUNTIME, "no HIP device is visible: liblocityper_hip has no CPU fallback");
+        }
+        if (device_id < 0 || device_id >= n) fail(LCTY_ERR_INVALID_INPUT, "device %d out of range (0..%d)", device_id, n - 1);
+        auto c = std::unique_ptr<lcty_ctx>(new lcty_ctx());
+        c->device = device_id;
+        LCTY_HIP(hipSetDevice(device_id));
+        LCTY_HIP(hipGetDeviceProperties(&c->props, device_id));
+        LCTY_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        *out = c.release();
+    });
+}
+
+void lcty_ctx_destroy(lcty_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t lcty_ctx_synchronize(lcty_ctx* ctx) {
+    return guarded([&] {
+        if (!ctx) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        ctx->activate();
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// model::Params::default — src/model/mod.rs:108-135
+void lcty_params_default(lcty_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->boundary_size = 200;
+    p->tweak = -1;
+    p->lik_skew = 0.85;
+    p->prob_diff = std::numeric_limits<double>::quiet_NaN();
+    p->unmapped_penalty = std::numeric_limits<double>::quiet_NaN();
+    p->poor_compl = 0.5;
+    p->poor_compl_edit = 0.7;
+    p->compl_weight_bp = 0.5; p->compl_weight_pow = 4.0;
+    p->kmers_weight_bp = 0.2; p->kmers_weight_pow = 4.0;
+    p->min_weight = 0.001;
+    p->filt_diff = 100.0 * math::LN10;     // Ln::from_log10(100.0)
+    p->prob_thresh = -4.0 * math::LN10;
+    const double cn[5] = {0.3, 2.0, 3.0, 4.0, 5.0};
+    for (int i = 0; i < 5; i++) p->alt_cn[i] = cn[i];
+    p->n_alt_cn = 5;
+    p->kmer_soft_thresh = 5;
+    p->kmer_hard_thresh = 1;
+    p->complexity_k = 5;
+    p->threads = 8;                         // src/command/genotype.rs:127
+}
+
+// Params::set_tweak_size (model/mod.rs:179-197) + command/genotype.rs:1291-1296 + Params::validate (144-177)
+int32_t lcty_params_resolve(lcty_params* p, const lcty_bg* bg) {
+    return guarded([&] {
+        if (!p || !bg) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (p->boundary_size == 0) fail(LCTY_ERR_INVALID_INPUT, "Boundary size (0) cannot be zero.");
+        if (!(p->lik_skew >= -1.0 + 1e-10 && p->lik_skew <= 1.0 - 1e-10))
+            fail(LCTY_ERR_INVALID_INPUT, "Likelihood skew (%g) must be within (-1, 1)", p->lik_skew);
+        if (!(0.0 <= p->min_weight && p->min_weight <= 0.5))
+            fail(LCTY_ERR_INVALID_INPUT, "Minimal weight (%g) must be within [0, 0.5].", p->min_weight);
+        if (p->tweak < 0) {
+            uint32_t t = static_cast<uint32_t>(std::round(static_cast<double>(bg->window) * 0.5));
+            t = std::min(t, 200u);
+            t = std::min(t, p->boundary_size - 1);
+            p->tweak = static_cast<int32_t>(t);
+        }
+        if (static_cast<uint32_t>(p->tweak) >= p->boundary_size)
+            fail(LCTY_ERR_INVALID_INPUT, "Boundary size (%u) must be greater than tweak size (%d).", p->boundary_size, p->tweak);
+        if (static_cast<uint32_t>(p->tweak) > 65535u / 2 - 1)
+            fail(LCTY_ERR_INVALID_INPUT, "Tweaking size (%d) is too large (max = %u)", p->tweak, 65535u / 2 - 1);
+        if (std::isnan(p->unmapped_penalty))
+            p->unmapped_penalty = (bg->technology == LCTY_TECH_ILLUMINA ? -10.0 : -100.0) * math::LN10;
+        if (std::isnan(p->prob_diff)) p->prob_diff = std::fabs(p->unmapped_penalty) + math::LN10;
+        p->prob_diff = std::fabs(p->prob_diff);
+        if (!(p->filt_diff >= 0.0)) fail(LCTY_ERR_INVALID_INPUT, "Filtering likelihood difference must be non-negative");
+        if (!(p->prob_thresh < 0.0)) fail(LCTY_ERR_INVALID_INPUT, "Probability threshold must be negative");
+    });
+}
+
+uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy) { return count_genotypes(n_alleles, ploidy); }
+
+// gen_combinations_with_repl — src/ext/vec.rs:298-339 (iterative odometer instead of the recursion)
+int32_t lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* out, uint64_t cap) {
+    return guarded([&] {
+        if (!out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (n_alleles == 0 || ploidy == 0) return;
+        if (n_alleles > 65535) fail(LCTY_ERR_INVALID_INPUT, "too many alleles");
+        const uint64_t total = count_genotypes(n_alleles, ploidy);
+        if (cap < total) fail(LCTY_ERR_INVALID_INPUT, "output capacity %llu < %llu genotypes", (unsigned long long)cap, (unsigned long long)total);
+        std::vector<uint32_t> cur(ploidy, 0);
+        for (uint64_t g = 0; g < total; g++) {
+            for (uint32_t t = 0; t < ploidy; t++) out[g * ploidy + t] = static_cast<uint16_t>(cur[t]);
+            // next non-decreasing tuple in lexicographic order
+            int32_t t = static_cast<int32_t>(ploidy) - 1;
+            while (t >= 0 && cur[t] == n_alleles - 1) t--;
+            if (t < 0) break;
+            const uint32_t v = cur[t] + 1;
+            for (uint32_t u = t; u < ploidy; u++) cur[u] = v;
+        }
+    });
+}
+
+static void require_scored(lcty_reads* reads) {
+    if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
+    reads->ctx->activate();
+}
+
+int32_t lcty_prefilter_async(lcty_reads* reads, uint32_t ploidy) {
+    return guarded([&] {
+        require_scored(reads);
+        if (ploidy != 2) fail(LCTY_ERR_UNSUPPORTED, "lcty_prefilter_async handles ploidy 2; use lcty_prefilter for other ploidies");
+        launch_prefilter_diploid(reads);
+    });
+}
+
+int32_t lcty_prefilter_scores(lcty_reads* reads, double* scores, uint64_t n) {
+    return guarded([&] {
+        require_scored(reads);
+        if (!scores) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (n != reads->n_scores) fail(LCTY_ERR_INVALID_INPUT, "expected %llu scores", (unsigned long long)reads->n_scores);
+        reads->check_device_error();
+        reads->d_scores.download(scores, n, reads->ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(reads->ctx->stream));
+    });
+}
+
+int32_t lcty_prefilter(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_genotypes, uint32_t ploidy,
+                       const double* priors, double* scores) {
+    return guarded([&] {
+        require_scored(reads);
+        if (!scores) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "ploidy must be positive");
+        reads->check_device_error();
+        hipStream_t s = reads->ctx->stream;
+        const uint32_t A = reads->locus->n_alleles;
+        if (!genotypes && ploidy == 2) {
+            const uint64_t G = count_genotypes(A, 2);
+            if (n_genotypes != G) fail(LCTY_ERR_INVALID_INPUT, "expected %llu genotypes, got %llu", (unsigned long long)G, (unsigned long long)n_genotypes);
+            launch_prefilter_diploid(reads);
+            reads->d_scores.download(scores, G, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            if (priors) for (uint64_t g = 0; g < G; g++) scores[g] = priors[g] + scores[g];    // prior + sum (solve.rs:114)
+            return;
+        }
+        std::vector<uint16_t> all;
+        if (!genotypes) {
+            const uint64_t G = count_genotypes(A, ploidy);
+            if (n_genotypes != G) fail(LCTY_ERR_INVALID_INPUT, "expected %llu genotypes, got %llu", (unsigned long long)G, (unsigned long long)n_genotypes);
+            all.resize(G * ploidy);
+            if (lcty_generate_genotypes(A, ploidy, all.data(), G) != LCTY_OK) fail(LCTY_ERR_RUNTIME, "%s", lcty_last_error());
+            genotypes = all.data();
+        }
+        for (uint64_t i = 0; i < n_genotypes * ploidy; i++)
+            if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
+        DevBuf<uint16_t> d_gt; DevBuf<double> d_pr, d_sc;
+        d_gt.alloc(n_genotypes * ploidy); d_gt.upload(genotypes, n_genotypes * ploidy, s);
+        if (priors) { d_pr.alloc(n_genotypes); d_pr.upload(priors, n_genotypes, s); }
+        d_sc.alloc(n_genotypes);
+        launch_prefilter_generic(reads, d_gt.p, n_genotypes, ploidy, priors ? d_pr.p : nullptr, d_sc.p);
+        d_sc.download(scores, n_genotypes, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// truncate_ixs — src/solvers/solve.rs:52-84; ties ordered by index ascending
+int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double filt_diff, uint64_t min_size,
+                      uint64_t threads, uint64_t* n_keep) {
+    return guarded([&] {
+        if (!scores || !ixs || !n_keep) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (n == 0) fail(LCTY_ERR_INVALID_INPUT, "no genotypes to filter");
+        std::sort(ixs, ixs + n, [&](uint64_t i, uint64_t j) {
+            if (scores[i] != scores[j]) return scores[i] > scores[j];
+            return i < j;
+        });
+        const double best = scores[ixs[0]], worst = scores[ixs[n - 1]];
+        double thresh = best - filt_diff;
+        if (min_size >= n || worst >= thresh) { *n_keep = n; return; }
+        auto count_ge = [&](double t) {
+            return static_cast<uint64_t>(std::partition_point(ixs, ixs + n, [&](uint64_t i) { return scores[i] >= t; }) - ixs);
+        };
+        uint64_t m = count_ge(thresh);
+        if (m < min_size) { thresh = scores[ixs[min_size - 1]]; m = count_ge(thresh); }
+        m = std::min(std::max(m, threads), n);
+        *n_keep = m;
+    });
+}
+
+int32_t lcty_timing_reset(lcty_ctx* ctx) {
+    return guarded([&] {
+        if (!ctx) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        ctx->activate();
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        for (auto& t : ctx->timers) {
+            for (auto& pr : t.pending) { ctx->event_pool.push_back(pr.first); ctx->event_pool.push_back(pr.second); }
+            t.pending.clear(); t.launches = 0; t.total_ms = 0.0;
+        }
+    });
+}
+
+int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms) {
+    return guarded([&] {
+        if (!ctx || kernel < 0 || kernel >= LCTY_K_COUNT) fail(LCTY_ERR_INVALID_INPUT, "bad argument");
+        ctx->activate();
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        auto& t = ctx->timers[kernel];
+        for (auto& pr : t.pending) {
+            float ms = 0.f;
+            LCTY_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            t.total_ms += ms; t.launches++;
+            ctx->event_pool.push_back(pr.first); ctx->event_pool.push_back(pr.second);
+        }
+        t.pending.clear();
+        if (launches) *launches = t.launches;
+        if (total_ms) *total_ms = t.total_ms;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// lcty_common.hpp — shared host-side plumbing of liblocityper_hip.so:
+// error reporting (mirrors src/err.rs:11-30 categories), HIP checks, device buffers, context.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/locityper_hip.h"
+
+namespace lcty {
+
+// Thread-local message of the last failure (lcty_last_error()).
+void set_last_error(const std::string& msg);
+
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int32_t code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+#define LCTY_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            ::lcty::fail(LCTY_ERR_RUNTIME, "HIP error %s at %s:%d: %s", hipGetErrorName(e__),   \
+                         __FILE__, __LINE__, #expr);                                            \
+    } while (0)
+
+// Wraps a C-ABI body: exceptions -> status code + last-error string.
+template <typename F>
+int32_t guarded(F&& body) {
+    try {
+        body();
+        return LCTY_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("out of host memory");
+        return LCTY_ERR_RUNTIME;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return LCTY_ERR_RUNTIME;
+    }
+}
+
+// Owning device allocation.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) LCTY_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    }
+    void upload(const T* host, size_t count, hipStream_t s, size_t dst_off = 0) {
+        if (dst_off + count > n) fail(LCTY_ERR_RUNTIME, "device buffer overflow (%zu + %zu > %zu)", dst_off, count, n);
+        if (count) LCTY_HIP(hipMemcpyAsync(p + dst_off, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T* host, size_t count, hipStream_t s, size_t src_off = 0) const {
+        if (src_off + count > n) fail(LCTY_ERR_RUNTIME, "device buffer overread");
+        if (count) LCTY_HIP(hipMemcpyAsync(host, p + src_off, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+    void zero(hipStream_t s) {
+        if (n) LCTY_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    }
+};
+
+struct KernelTimer {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace lcty
+
+// One GPU, one stream. All work of a context is issued on `stream`.
+struct lcty_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t props{};
+    lcty::KernelTimer timers[LCTY_K_COUNT];
+    std::vector<hipEvent_t> event_pool;
+
+    hipEvent_t get_event();
+    // records start/stop events around fn() on the stream; resolved lazily in lcty_timing_get
+    template <typename F>
+    void timed(int kernel, F&& fn) {
+        hipEvent_t a = get_event(), b = get_event();
+        LCTY_HIP(hipEventRecord(a, stream));
+        fn();
+        LCTY_HIP(hipEventRecord(b, stream));
+        timers[kernel].pending.emplace_back(a, b);
+    }
+    void activate() const { LCTY_HIP(hipSetDevice(device)); }
+};

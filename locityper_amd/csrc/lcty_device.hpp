@@ -1,0 +1,119 @@
+// lcty_device.hpp — plain views passed by value to the gfx950 kernels, and the
+// device helpers shared between kernels (2-bit k-mer extraction, hash probing).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/locityper_hip.h"
+
+namespace lcty {
+
+constexpr int WAVE = 64;                       // CDNA4 wavefront
+constexpr uint64_t KSET_EMPTY = ~0ull;         // never a valid canonical k-mer for k <= 31
+
+// Device record of one PairAlignment (src/model/locs.rs:668-676), 24 B.
+struct PairAlnDev {
+    double ln_prob;
+    uint32_t mid1, mid2;     // LCTY_NONE_U32 = None
+    uint16_t contig;
+    uint16_t ix1, ix2;       // record index inside the pair, 0xFFFF = None
+    uint16_t _pad;
+};
+static_assert(sizeof(PairAlnDev) == 24, "PairAlnDev layout");
+
+struct LocusView {
+    uint32_t n_alleles, k;
+    const uint32_t* allele_len;     // [A]
+    const uint32_t* ci_off;         // [A+1] offsets into the per-position ContigInfo arrays
+    const uint16_t* compl_cnt;      // linguistic-complexity numerators (src/seq/compl.rs:115-140)
+    double compl_mult;              // 1 / min(neighb+1-ck, 4^ck)
+    uint32_t half_neighb;
+    // UniqueKmers (src/model/locs.rs:915-1003)
+    const uint64_t* kset;           // open addressing, KSET_EMPTY = free
+    uint64_t kset_mask;             // capacity - 1
+    uint32_t undef_in_set;          // UNDEF was inserted (an allele window with N has count 0)
+    double weight_mult, weight_interc;
+    // InsertDistr (src/bg/insertsz.rs)
+    const double* ins_lut;
+    uint32_t ins_lut_size;
+    double ins_n, ins_lnq, ins_lnpmf_const, insert_penalty;
+    // ErrorProfile (src/bg/err_prof.rs:212-221)
+    double lp[5];
+    // EditDistCache (src/bg/err_prof.rs:415-448): (good, passable) per read length
+    const uint2* edit_lut;
+    uint32_t edit_lut_size;
+    // model::Params
+    double unmapped_penalty, prob_diff, min_weight, poor_compl, poor_compl_edit;
+    uint32_t boundary;              // boundary_size - tweak (locs.rs:1099)
+    uint32_t is_paired, short_reads, strict_subset;
+};
+
+struct ReadsView {
+    uint64_t n_pairs;
+    const uint32_t* mate_len;
+    const uint64_t* mate_off;
+    const uint32_t* bases2;
+    const uint32_t* nmask;
+    const uint64_t* aln_off;
+    const lcty_aln_rec* recs;
+    const uint64_t* cigar_off;
+    const uint32_t* cigar;
+    // products of AllAlignments::load
+    uint8_t* status;
+    double* weight;
+    double* unmapped_prob;
+    uint16_t* uniq_kmers;           // [2R]
+    double* matrix;                 // [R][A] read-major; rows of non-GOOD pairs are 0.0
+    PairAlnDev* pa;                 // arena
+    uint64_t pa_cap;
+    unsigned long long* pa_count;   // arena cursor
+    uint64_t* pa_off;               // [R]
+    uint32_t* pa_cnt;               // [R]
+    uint32_t* err_flag;             // first LCTY_ERR_* raised by a kernel
+};
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+#ifdef __HIPCC__
+// Canonical k-mer (src/seq/kmers.rs:192-196) of the window starting at base q of a mate whose
+// 2-bit stream starts at 64-bit word `w64` (mate offsets are multiples of 32 bases).
+// The stream is LSB-first: x = sum enc[q+t] << 2t, hence rv = ~x (masked) and fw = digit-reverse(x).
+__device__ inline uint64_t canonical_kmer_2bit(const uint64_t* w64, uint32_t q, uint32_t k) {
+    const uint32_t word = q >> 5, sh = (q & 31u) * 2u;
+    uint64_t x = w64[word] >> sh;
+    if (sh + 2u * k > 64u) x |= w64[word + 1] << (64u - sh);
+    const uint64_t mask = (1ull << (2u * k)) - 1ull;
+    x &= mask;
+    const uint64_t rv = (~x) & mask;
+    uint64_t y = __brevll(x);
+    y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+    const uint64_t fw = y >> (64u - 2u * k);
+    return rv < fw ? rv : fw;
+}
+
+// any "not ACGT" base inside [q, q+k) of the mate's 1-bit stream starting at 32-bit word `nm`
+__device__ inline bool window_has_n(const uint32_t* nm, uint32_t q, uint32_t k) {
+    const uint32_t w = q >> 5, s = q & 31u;
+    uint32_t bits = nm[w] >> s;
+    if (s + k > 32u) bits |= nm[w + 1] << (32u - s);
+    return (bits & ((1u << k) - 1u)) != 0u;
+}
+
+__device__ inline bool kset_contains(const uint64_t* kset, uint64_t mask, uint64_t key) {
+    uint64_t slot = mix64(key) & mask;
+    while (true) {
+        const uint64_t v = kset[slot];
+        if (v == key) return true;
+        if (v == KSET_EMPTY) return false;
+        slot = (slot + 1) & mask;
+    }
+}
+#endif
+
+}  // namespace lcty

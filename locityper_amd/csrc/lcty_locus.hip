@@ -1,0 +1,405 @@
+// lcty_locus.hip — per-locus preprocessing.
+//   K1  UniqueKmers::new (src/model/locs.rs:930-963): device hash set of locus-unique canonical k-mers
+//   K3  ContigInfo::new  (src/model/windows.rs:362-424): GC / unique-k-mer / complexity moving windows
+//       (host threads in this round; one-off O(A*L) per locus, not on the per-read path)
+//   LUTs: InsertDistr (bg/insertsz.rs:195-208), DistrCache (model/distr_cache.rs:61-75),
+//         EditDistCache (bg/err_prof.rs:415-448)
+#include <algorithm>
+#include <thread>
+
+#include "lcty_objects.hpp"
+
+namespace lcty {
+
+// ---------------------------------------------------------------------------------------------
+// K1: hash-set build. One thread rolls over SEG consecutive k-mer start positions of one allele,
+// restating kmers::kmers::<_, _, CANONICAL> (src/seq/kmers.rs:163-202) on the ASCII sequence.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t KSEG = 64;
+
+__device__ inline void kset_insert(uint64_t* table, uint64_t mask, uint64_t key) {
+    uint64_t slot = mix64(key) & mask;
+    while (true) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot]),
+                                                 static_cast<unsigned long long>(KSET_EMPTY),
+                                                 static_cast<unsigned long long>(key));
+        if (old == KSET_EMPTY || old == key) return;
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ void kset_build_kernel(const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ seq_off,
+                                  const uint16_t* __restrict__ counts, const uint64_t* __restrict__ cnt_off,
+                                  uint32_t k, uint64_t* table, uint64_t mask, uint32_t* undef_flag) {
+    const uint32_t a = blockIdx.y;
+    const uint8_t* seq = seqs + seq_off[a];
+    const uint64_t len = seq_off[a + 1] - seq_off[a];
+    const uint16_t* cnt = counts + cnt_off[a];
+    if (len < k) return;
+    const uint64_t nk = len + 1 - k;
+    const uint64_t s = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * KSEG;
+    if (s >= nk) return;
+    const uint64_t e = min(s + KSEG, nk);
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    const uint32_t rv_shift = 2 * k - 2;
+    uint64_t fw = 0, rv = 0;
+    uint64_t reset = s + k - 1;
+    for (uint64_t i = s; i < e + k - 1; i++) {
+        uint32_t enc;
+        switch (seq[i]) {
+            case 'A': enc = 0; break;
+            case 'C': enc = 1; break;
+            case 'G': enc = 2; break;
+            case 'T': enc = 3; break;
+            default: enc = 4;
+        }
+        if (enc == 4) {
+            reset = i + k;
+            if (i + 1 >= s + k && cnt[i + 1 - k] == 0) atomicOr(undef_flag, 1u);   // UNDEF enters the set (kmers.rs:184-190)
+            continue;
+        }
+        fw = ((fw << 2) | enc) & kmask;
+        rv = (rv >> 2) | (static_cast<uint64_t>(3 - enc) << rv_shift);
+        if (i + 1 >= s + k) {
+            const uint64_t pos = i + 1 - k;
+            if (i >= reset) {
+                if (cnt[pos] == 0) kset_insert(table, mask, rv < fw ? rv : fw);
+            } else if (cnt[pos] == 0) {
+                atomicOr(undef_flag, 1u);
+            }
+        }
+    }
+}
+
+__global__ void kset_count_kernel(const uint64_t* __restrict__ table, uint64_t cap, unsigned long long* out) {
+    uint64_t local = 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < cap;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+        local += table[i] != KSET_EMPTY;
+    for (int off = WAVE / 2; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && local) atomicAdd(out, static_cast<unsigned long long>(local));
+}
+
+__global__ void kset_compact_kernel(const uint64_t* __restrict__ big, uint64_t big_cap, uint64_t* small, uint64_t small_mask) {
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < big_cap;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t key = big[i];
+        if (key != KSET_EMPTY) kset_insert(small, small_mask, key);
+    }
+}
+
+static uint64_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 on host threads: ContigInfo::new (windows.rs:386-407) + linguistic_complexity (compl.rs:115-140)
+// ---------------------------------------------------------------------------------------------
+static void contig_info_host(const uint8_t* seq, uint32_t len, const uint16_t* cnt, uint32_t k, uint32_t neighb,
+                             uint32_t ck, uint8_t* gc, uint32_t* uniq, uint16_t* compl_cnt) {
+    const uint32_t n_pos = len - neighb + 1;
+    // GC content: rolling count over `neighb` bases, rounded percentage (windows.rs:387-391)
+    {
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < neighb; i++) c += (seq[i] == 'C' || seq[i] == 'G');
+        const double mult = 100.0 / static_cast<double>(neighb);
+        for (uint32_t i = 0;; i++) {
+            gc[i] = static_cast<uint8_t>(std::round(mult * static_cast<double>(c)));
+            if (i + 1 == n_pos) break;
+            c += (seq[i + neighb] == 'C' || seq[i + neighb] == 'G');
+            c -= (seq[i] == 'C' || seq[i] == 'G');
+        }
+    }
+    // number of off-target-count == 0 k-mers among the neighb+1-k k-mers of the window (windows.rs:395-403)
+    {
+        const uint32_t span = neighb + 1 - k;
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < span; i++) c += cnt[i] == 0;
+        for (uint32_t i = 0;; i++) {
+            uniq[i] = c;
+            if (i + 1 == n_pos) break;
+            c += cnt[i + span] == 0;
+            c -= cnt[i] == 0;
+        }
+    }
+    // distinct ck-mers (non-canonical; a window with a non-ACGT base is the single value UNDEF) per window
+    {
+        const uint32_t nk = len + 1 - ck, span = neighb + 1 - ck;
+        const uint32_t undef = 1u << (2 * ck);
+        std::vector<uint32_t> code(nk);
+        uint32_t v = 0, bad = 0;     // bad = number of remaining positions poisoned by a non-ACGT base
+        const uint32_t mask = undef - 1;
+        for (uint32_t i = 0; i < len; i++) {
+            uint32_t enc;
+            switch (seq[i]) { case 'A': enc = 0; break; case 'C': enc = 1; break; case 'G': enc = 2; break;
+                              case 'T': enc = 3; break; default: enc = 4; }
+            if (enc == 4) { bad = ck; v = (v << 2) & mask; } else { v = ((v << 2) | enc) & mask; if (bad) bad--; }
+            if (i + 1 >= ck) code[i + 1 - ck] = bad ? undef : v;
+        }
+        std::vector<uint16_t> table(undef + 1, 0);
+        uint32_t distinct = 0;
+        for (uint32_t i = 0; i < span; i++) distinct += table[code[i]]++ == 0;
+        for (uint32_t i = 0;; i++) {
+            compl_cnt[i] = static_cast<uint16_t>(distinct);
+            if (i + 1 == n_pos) break;
+            distinct += table[code[i + span]]++ == 0;
+            distinct -= --table[code[i]] == 0;
+        }
+    }
+}
+
+}  // namespace lcty
+
+using namespace lcty;
+
+LocusView lcty_locus::view() const {
+    LocusView v{};
+    v.n_alleles = n_alleles; v.k = k;
+    v.allele_len = d_allele_len.p; v.ci_off = d_ci_off.p; v.compl_cnt = d_compl_cnt.p;
+    v.compl_mult = compl_mult; v.half_neighb = half_neighb;
+    v.kset = d_kset.p; v.kset_mask = kset_cap - 1; v.undef_in_set = undef_in_set;
+    v.weight_mult = 1.0 / static_cast<double>(prm.kmer_soft_thresh + 1 - prm.kmer_hard_thresh);   // locs.rs:957
+    v.weight_interc = (1.0 - static_cast<double>(prm.kmer_hard_thresh)) * v.weight_mult;           // locs.rs:958
+    v.ins_lut = d_ins_lut.p; v.ins_lut_size = static_cast<uint32_t>(ins_lut.size());
+    v.ins_n = ins.n; v.ins_lnq = ins.lnq; v.ins_lnpmf_const = ins.lnpmf_const; v.insert_penalty = insert_penalty;
+    for (int i = 0; i < 5; i++) v.lp[i] = bg.op_lnprobs[i];
+    v.edit_lut = d_edit_lut.p; v.edit_lut_size = edit_dev_size;
+    v.unmapped_penalty = prm.unmapped_penalty; v.prob_diff = prm.prob_diff; v.min_weight = prm.min_weight;
+    v.poor_compl = prm.poor_compl; v.poor_compl_edit = prm.poor_compl_edit;
+    v.boundary = prm.boundary_size - static_cast<uint32_t>(prm.tweak);
+    v.is_paired = bg.is_paired != 0; v.short_reads = bg.technology == LCTY_TECH_ILLUMINA;
+    v.strict_subset = prm.strict_subset;
+    return v;
+}
+
+void lcty_locus::ensure_edit_thresholds(const uint32_t* lens, size_t n) {
+    std::lock_guard<std::mutex> lock(edit_mutex);
+    uint32_t max_len = 0;
+    for (size_t i = 0; i < n; i++) max_len = std::max(max_len, lens[i]);
+    bool changed = false;
+    if (edit_cache.size() < static_cast<size_t>(max_len) + 1) {
+        edit_cache.resize(static_cast<size_t>(max_len) + 1, make_uint2(~0u, ~0u));
+        changed = true;
+    }
+    for (size_t i = 0; i < n; i++) {
+        uint2& e = edit_cache[lens[i]];
+        if (e.x == ~0u && e.y == ~0u) {
+            uint32_t g, p;
+            math::edit_thresholds(bg, lens[i], &g, &p);
+            e = make_uint2(g, p);
+            changed = true;
+        }
+    }
+    if (changed) {
+        ctx->activate();
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));     // the old table may still be read by a running kernel
+        d_edit_lut.alloc(edit_cache.size());
+        d_edit_lut.upload(edit_cache.data(), edit_cache.size(), ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        edit_dev_size = static_cast<uint32_t>(edit_cache.size());
+    }
+}
+
+extern "C" {
+
+int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs, const uint64_t* seq_off,
+                          const uint16_t* offtarget, const uint64_t* cnt_off, uint32_t k,
+                          const lcty_bg* bg, const lcty_params* params, lcty_locus** out) {
+    return guarded([&] {
+        if (!ctx || !seqs || !seq_off || !offtarget || !cnt_off || !bg || !params || !out)
+            fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_create: null argument");
+        if (n_alleles == 0 || n_alleles > 65535)
+            fail(LCTY_ERR_INVALID_INPUT, "number of alleles (%u) must be in 1..65535 (seq/contigs.rs:96-98)", n_alleles);
+        if (k < 2) fail(LCTY_ERR_INVALID_INPUT, "k-mer size (%u) must be over 1 (locs.rs:937)", k);
+        if (k > 31) fail(LCTY_ERR_UNSUPPORTED, "k = %u: this build stores k-mers in 64 bits (k <= 31)", k);
+        if (params->tweak < 0 || std::isnan(params->prob_diff) || std::isnan(params->unmapped_penalty))
+            fail(LCTY_ERR_INVALID_INPUT, "params have unresolved auto fields: call lcty_params_resolve first");
+        if (static_cast<uint32_t>(params->tweak) >= params->boundary_size)
+            fail(LCTY_ERR_INVALID_INPUT, "boundary size (%u) must be greater than tweak size (%d)", params->boundary_size, params->tweak);
+        if (params->kmer_hard_thresh > params->kmer_soft_thresh)
+            fail(LCTY_ERR_INVALID_INPUT, "hard k-mer threshold must not exceed the soft threshold");
+        if (params->complexity_k == 0 || params->complexity_k > 15)
+            fail(LCTY_ERR_INVALID_INPUT, "complexity k (%u) must be in 1..15", params->complexity_k);
+        if (params->n_alt_cn > LCTY_MAX_ALT_CN) fail(LCTY_ERR_INVALID_INPUT, "too many alternative copy numbers");
+        ctx->activate();
+
+        auto L = std::unique_ptr<lcty_locus>(new lcty_locus());
+        L->ctx = ctx; L->n_alleles = n_alleles; L->k = k; L->bg = *bg; L->prm = *params;
+        const uint32_t neighb = bg->neighb, window = bg->window, ck = params->complexity_k;
+        if (window == 0 || neighb < window) fail(LCTY_ERR_INVALID_DATA, "bg_depth: neighbourhood (%u) < window (%u)", neighb, window);
+        if (neighb + 1 <= k || neighb + 1 <= ck) fail(LCTY_ERR_INVALID_DATA, "neighbourhood size (%u) too small for k = %u", neighb, k);
+        const uint32_t boundary = params->boundary_size - static_cast<uint32_t>(params->tweak);
+
+        L->allele_len.resize(n_alleles);
+        L->ci_off.resize(n_alleles + 1);
+        L->n_windows.resize(n_alleles);
+        L->reg_start.resize(n_alleles);
+        uint64_t total_pos = 0, zero_positions = 0;
+        for (uint32_t a = 0; a < n_alleles; a++) {
+            const uint64_t len64 = seq_off[a + 1] - seq_off[a];
+            if (len64 >= (1ull << 32)) fail(LCTY_ERR_INVALID_DATA, "allele %u is too long", a);
+            const uint32_t len = static_cast<uint32_t>(len64);
+            if (len < window + 2 * params->boundary_size)
+                fail(LCTY_ERR_RUNTIME, "Contig %u is too short (len = %u)", a, len);                       // windows.rs:375-378
+            if (!(len > 2 * boundary)) fail(LCTY_ERR_RUNTIME, "Some contigs are too short (must be over twice boundary size = %u)", 2 * boundary);
+            if (len < neighb) fail(LCTY_ERR_RUNTIME, "Contig %u is shorter than the neighbourhood size", a);
+            if (cnt_off[a + 1] - cnt_off[a] != len64 + 1 - k)
+                fail(LCTY_ERR_INVALID_DATA, "k-mer counts of allele %u do not match its length (locs.rs:944)", a);
+            L->allele_len[a] = len;
+            L->ci_off[a] = static_cast<uint32_t>(total_pos);
+            total_pos += len - neighb + 1;
+            if (total_pos >= (1ull << 32)) fail(LCTY_ERR_UNSUPPORTED, "locus too large for 32-bit window offsets");
+            L->n_windows[a] = (len - 2 * params->boundary_size) / window;                                   // windows.rs:380
+            L->reg_start[a] = (len - L->n_windows[a] * window) / 2;                                         // windows.rs:381-382
+        }
+        L->ci_off[n_alleles] = static_cast<uint32_t>(total_pos);
+        L->left_padding = (neighb - window) / 2;
+        L->half_neighb = neighb / 2;
+        L->uniq_mult = 1.0 / static_cast<double>(neighb + 1 - k);
+        L->compl_mult = 1.0 / static_cast<double>(std::min<uint64_t>(neighb + 1 - ck, 1ull << (2 * ck)));
+
+        // ---- K3 (host threads) ----
+        L->gc.resize(total_pos); L->uniq_cnt.resize(total_pos); L->compl_cnt.resize(total_pos);
+        {
+            unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+            nt = std::min<unsigned>(nt, n_alleles);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([&, t] {
+                    for (uint32_t a = t; a < n_alleles; a += nt)
+                        contig_info_host(seqs + seq_off[a], L->allele_len[a], offtarget + cnt_off[a], k, neighb, ck,
+                                         L->gc.data() + L->ci_off[a], L->uniq_cnt.data() + L->ci_off[a],
+                                         L->compl_cnt.data() + L->ci_off[a]);
+                });
+            for (auto& t : th) t.join();
+        }
+        for (uint64_t i = 0, n = cnt_off[n_alleles]; i < n; i++) zero_positions += offtarget[i] == 0;
+
+        hipStream_t s = ctx->stream;
+        L->d_allele_len.alloc(n_alleles); L->d_allele_len.upload(L->allele_len.data(), n_alleles, s);
+        L->d_ci_off.alloc(n_alleles + 1); L->d_ci_off.upload(L->ci_off.data(), n_alleles + 1, s);
+        L->d_compl_cnt.alloc(total_pos); L->d_compl_cnt.upload(L->compl_cnt.data(), total_pos, s);
+        L->d_gc.alloc(total_pos); L->d_gc.upload(L->gc.data(), total_pos, s);
+        L->d_uniq_cnt.alloc(total_pos); L->d_uniq_cnt.upload(L->uniq_cnt.data(), total_pos, s);
+
+        // ---- K1 (device) ----
+        {
+            DevBuf<uint8_t> d_seqs; DevBuf<uint64_t> d_seq_off, d_cnt_off; DevBuf<uint16_t> d_counts;
+            DevBuf<uint64_t> d_big; DevBuf<uint32_t> d_flag; DevBuf<unsigned long long> d_n;
+            const uint64_t total_seq = seq_off[n_alleles], total_cnt = cnt_off[n_alleles];
+            d_seqs.alloc(total_seq); d_seqs.upload(seqs, total_seq, s);
+            d_seq_off.alloc(n_alleles + 1); d_seq_off.upload(seq_off, n_alleles + 1, s);
+            d_cnt_off.alloc(n_alleles + 1); d_cnt_off.upload(cnt_off, n_alleles + 1, s);
+            d_counts.alloc(total_cnt); d_counts.upload(offtarget, total_cnt, s);
+            const uint64_t big_cap = next_pow2(std::max<uint64_t>(2 * zero_positions, 1024));
+            d_big.alloc(big_cap);
+            LCTY_HIP(hipMemsetAsync(d_big.p, 0xFF, big_cap * sizeof(uint64_t), s));
+            d_flag.alloc(1); d_flag.zero(s);
+            d_n.alloc(1); d_n.zero(s);
+            uint32_t max_len = *std::max_element(L->allele_len.begin(), L->allele_len.end());
+            const uint32_t threads = 128;
+            const uint32_t segs = (max_len + KSEG - 1) / KSEG;
+            dim3 grid((segs + threads - 1) / threads, n_alleles);
+            hipLaunchKernelGGL(kset_build_kernel, grid, dim3(threads), 0, s, d_seqs.p, d_seq_off.p, d_counts.p,
+                               d_cnt_off.p, k, d_big.p, big_cap - 1, d_flag.p);
+            hipLaunchKernelGGL(kset_count_kernel, dim3(1024), dim3(256), 0, s, d_big.p, big_cap, d_n.p);
+            unsigned long long n_distinct = 0; uint32_t flag = 0;
+            LCTY_HIP(hipMemcpyAsync(&n_distinct, d_n.p, sizeof(n_distinct), hipMemcpyDeviceToHost, s));
+            LCTY_HIP(hipMemcpyAsync(&flag, d_flag.p, sizeof(flag), hipMemcpyDeviceToHost, s));
+            LCTY_HIP(hipStreamSynchronize(s));
+            L->undef_in_set = flag;
+            L->n_unique = n_distinct + (flag ? 1 : 0);
+            L->kset_cap = next_pow2(std::max<uint64_t>(4 * n_distinct, 1024));
+            L->d_kset.alloc(L->kset_cap);
+            LCTY_HIP(hipMemsetAsync(L->d_kset.p, 0xFF, L->kset_cap * sizeof(uint64_t), s));
+            hipLaunchKernelGGL(kset_compact_kernel, dim3(1024), dim3(256), 0, s, d_big.p, big_cap, L->d_kset.p, L->kset_cap - 1);
+            LCTY_HIP(hipGetLastError());
+            LCTY_HIP(hipStreamSynchronize(s));
+        }
+
+        // ---- LUTs ----
+        if (bg->is_paired) {
+            if (!(bg->ins_n > 0.0 && bg->ins_p >= 0.0 && bg->ins_p <= 1.0))
+                fail(LCTY_ERR_INVALID_DATA, "Incorrect Negative Binomial parameters n = %g, p = %g", bg->ins_n, bg->ins_p);
+            L->ins = math::NBinom(bg->ins_n, bg->ins_p);
+            const size_t sz = math::insert_cache_size(L->ins);
+            L->ins_lut.resize(sz);
+            for (size_t i = 0; i < sz; i++) L->ins_lut[i] = L->ins.ln_pmf(static_cast<uint32_t>(i));
+            L->insert_penalty = L->ins.ln_pmf(L->ins.mode());
+        } else {
+            L->insert_penalty = std::numeric_limits<double>::quiet_NaN();
+        }
+        L->d_ins_lut.alloc(std::max<size_t>(L->ins_lut.size(), 1));
+        if (!L->ins_lut.empty()) L->d_ins_lut.upload(L->ins_lut.data(), L->ins_lut.size(), s);
+        {
+            std::vector<double> lut(static_cast<size_t>(LCTY_GC_BINS) * LCTY_DEPTH_CACHE);
+            for (uint32_t gc = 0; gc < LCTY_GC_BINS; gc++) {
+                if (!(bg->depth_n[gc] > 0.0)) fail(LCTY_ERR_INVALID_DATA, "bg_depth: invalid NBinom at GC %u", gc);
+                math::DepthDistr dd(*bg, *params, gc);
+                for (uint32_t d = 0; d < LCTY_DEPTH_CACHE; d++) lut[gc * LCTY_DEPTH_CACHE + d] = dd.ln_pmf(d);
+            }
+            L->d_depth_lut.alloc(lut.size());
+            L->d_depth_lut.upload(lut.data(), lut.size(), s);
+            LCTY_HIP(hipStreamSynchronize(s));
+        }
+        LCTY_HIP(hipStreamSynchronize(s));
+        *out = L.release();
+    });
+}
+
+void lcty_locus_destroy(lcty_locus* locus) {
+    if (!locus) return;
+    (void)hipSetDevice(locus->ctx->device);
+    delete locus;
+}
+
+int32_t lcty_locus_n_unique_kmers(const lcty_locus* locus, uint64_t* out) {
+    return guarded([&] {
+        if (!locus || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        *out = locus->n_unique;
+    });
+}
+
+int32_t lcty_locus_contig_info(const lcty_locus* locus, uint32_t allele, uint8_t* gc, uint32_t* uniq_cnt,
+                               uint16_t* compl_cnt, uint32_t* n_windows, uint32_t* reg_start) {
+    return guarded([&] {
+        if (!locus) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (allele >= locus->n_alleles) fail(LCTY_ERR_INVALID_INPUT, "allele index out of range");
+        const size_t o = locus->ci_off[allele], n = locus->ci_off[allele + 1] - o;
+        if (gc) memcpy(gc, locus->gc.data() + o, n);
+        if (uniq_cnt) memcpy(uniq_cnt, locus->uniq_cnt.data() + o, n * sizeof(uint32_t));
+        if (compl_cnt) memcpy(compl_cnt, locus->compl_cnt.data() + o, n * sizeof(uint16_t));
+        if (n_windows) *n_windows = locus->n_windows[allele];
+        if (reg_start) *reg_start = locus->reg_start[allele];
+    });
+}
+
+int32_t lcty_locus_edit_thresholds(const lcty_locus* locus, uint32_t read_len, uint32_t* good, uint32_t* passable) {
+    return guarded([&] {
+        if (!locus || !good || !passable) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        math::edit_thresholds(locus->bg, read_len, good, passable);
+    });
+}
+
+int32_t lcty_locus_insert_lnprob(const lcty_locus* locus, uint32_t n, const uint32_t* sizes, double* out, double* insert_penalty) {
+    return guarded([&] {
+        if (!locus) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (!locus->bg.is_paired) fail(LCTY_ERR_INVALID_INPUT, "insert size distribution is undefined for single-end data");
+        for (uint32_t i = 0; i < n; i++)
+            out[i] = sizes[i] < locus->ins_lut.size() ? locus->ins_lut[sizes[i]] : locus->ins.ln_pmf(sizes[i]);
+        if (insert_penalty) *insert_penalty = locus->insert_penalty;
+    });
+}
+
+int32_t lcty_locus_depth_lut(const lcty_locus* locus, double* out) {
+    return guarded([&] {
+        if (!locus || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        locus->ctx->activate();
+        locus->d_depth_lut.download(out, static_cast<size_t>(LCTY_GC_BINS) * LCTY_DEPTH_CACHE, locus->ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(locus->ctx->stream));
+    });
+}
+
+}  // extern "C"

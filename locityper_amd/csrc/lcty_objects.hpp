@@ -1,0 +1,97 @@
+// lcty_objects.hpp — the opaque handles behind include/locityper_hip.h.
+#pragma once
+
+#include <mutex>
+#include <vector>
+
+#include "lcty_common.hpp"
+#include "lcty_device.hpp"
+#include "lcty_math.hpp"
+
+// ContigSet + KmerCounts + ContigInfos + UniqueKmers + InsertDistr + EditDistCache + DistrCache
+struct lcty_locus {
+    lcty_ctx* ctx = nullptr;
+    uint32_t n_alleles = 0, k = 0;
+    lcty_bg bg{};
+    lcty_params prm{};
+
+    // host copies
+    std::vector<uint32_t> allele_len;
+    std::vector<uint32_t> ci_off;            // [A+1]
+    std::vector<uint8_t> gc;                 // NeighbInfo::gc_content
+    std::vector<uint32_t> uniq_cnt;          // numerator of uniq_kmer_frac
+    std::vector<uint16_t> compl_cnt;         // numerator of complexity
+    std::vector<uint32_t> n_windows, reg_start;
+    double uniq_mult = 0, compl_mult = 0;
+    uint32_t left_padding = 0, half_neighb = 0;
+    uint64_t n_unique = 0;
+    uint32_t undef_in_set = 0;
+
+    lcty::math::NBinom ins;
+    std::vector<double> ins_lut;
+    double insert_penalty = 0;
+
+    std::mutex edit_mutex;
+    std::vector<uint2> edit_cache;           // (good, passable) per read length; (~0,~0) = not computed
+    uint32_t edit_dev_size = 0;
+
+    // device
+    lcty::DevBuf<uint32_t> d_allele_len, d_ci_off;
+    lcty::DevBuf<uint16_t> d_compl_cnt;
+    lcty::DevBuf<uint8_t> d_gc;
+    lcty::DevBuf<uint32_t> d_uniq_cnt;
+    lcty::DevBuf<uint64_t> d_kset;
+    uint64_t kset_cap = 0;
+    lcty::DevBuf<double> d_ins_lut;
+    lcty::DevBuf<uint2> d_edit_lut;
+    lcty::DevBuf<double> d_depth_lut;        // [101][256]
+
+    lcty::LocusView view() const;
+    // makes sure (good, passable) is known on the device for every length in `lens`
+    void ensure_edit_thresholds(const uint32_t* lens, size_t n);
+};
+
+// device-resident batch of read pairs + products of load()
+struct lcty_reads {
+    lcty_locus* locus = nullptr;
+    lcty_ctx* ctx = nullptr;
+    uint64_t cap_pairs = 0, cap_bases = 0, cap_recs = 0, cap_cigar = 0;
+    uint64_t n_pairs = 0, n_bases = 0, n_recs = 0, n_cigar = 0;
+    uint32_t max_recs_per_pair = 0;
+    bool scored = false;
+
+    lcty::DevBuf<uint32_t> d_mate_len;
+    lcty::DevBuf<uint64_t> d_mate_off;
+    lcty::DevBuf<uint32_t> d_bases2, d_nmask;
+    lcty::DevBuf<uint64_t> d_aln_off;
+    lcty::DevBuf<lcty_aln_rec> d_recs;
+    lcty::DevBuf<uint64_t> d_cigar_off;
+    lcty::DevBuf<uint32_t> d_cigar;
+
+    lcty::DevBuf<uint8_t> d_status;
+    lcty::DevBuf<double> d_weight, d_unmapped;
+    lcty::DevBuf<uint16_t> d_uniq;
+    lcty::DevBuf<double> d_matrix;           // [R][A]
+    lcty::DevBuf<lcty::PairAlnDev> d_pa;
+    lcty::DevBuf<unsigned long long> d_pa_count;
+    lcty::DevBuf<uint64_t> d_pa_off;
+    lcty::DevBuf<uint32_t> d_pa_cnt;
+    lcty::DevBuf<uint32_t> d_err;
+
+    // prefilter products
+    lcty::DevBuf<double> d_scores;           // [G]
+    lcty::DevBuf<double> d_partials;         // [splits][G]
+    uint64_t n_scores = 0;
+
+    lcty::ReadsView view() const;
+    void check_device_error();               // throws when a kernel raised LCTY_ERR_*
+};
+
+namespace lcty {
+void launch_score_reads(lcty_reads* reads);
+void launch_prefilter_diploid(lcty_reads* reads);                               // all (i <= j) pairs
+void launch_prefilter_generic(lcty_reads* reads, const uint16_t* d_genotypes, uint64_t n_gt, uint32_t ploidy,
+                              const double* d_priors, double* d_scores);
+void compact_matrix(lcty_reads* reads, double* d_out, uint64_t n_good);         // [A][n_good]
+uint64_t count_genotypes(uint32_t n_alleles, uint32_t ploidy);
+}  // namespace lcty

@@ -1,0 +1,289 @@
+// lcty_reads.hip — device-resident batch of read pairs: creation, chunked append (H2D),
+// and the getters that hand the products of AllAlignments::load back to the host.
+#include <algorithm>
+#include <memory>
+
+#include "lcty_objects.hpp"
+
+using namespace lcty;
+
+namespace lcty {
+
+// out[a * n_good + j] = M[good_ix[j]][a]  (AllAlignments::best_aln_matrix layout, locs.rs:1203-1212)
+__global__ void compact_matrix_kernel(const double* __restrict__ M, const uint64_t* __restrict__ good_ix,
+                                      uint64_t n_good, uint32_t A, double* __restrict__ out) {
+    __shared__ double tile[64][65];
+    const uint64_t j0 = static_cast<uint64_t>(blockIdx.x) * 64;
+    const uint32_t a0 = blockIdx.y * 64;
+    for (uint32_t t = threadIdx.y; t < 64; t += blockDim.y) {
+        const uint64_t j = j0 + t;
+        const uint32_t a = a0 + threadIdx.x;
+        tile[t][threadIdx.x] = (j < n_good && a < A) ? M[good_ix[j] * A + a] : 0.0;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.y; t < 64; t += blockDim.y) {
+        const uint32_t a = a0 + t;
+        const uint64_t j = j0 + threadIdx.x;
+        if (a < A && j < n_good) out[static_cast<uint64_t>(a) * n_good + j] = tile[threadIdx.x][t];
+    }
+}
+
+void compact_matrix(lcty_reads* reads, double* d_out, uint64_t n_good) {
+    lcty_ctx* ctx = reads->ctx;
+    std::vector<uint8_t> status(reads->n_pairs);
+    reads->d_status.download(status.data(), reads->n_pairs, ctx->stream);
+    LCTY_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> good;
+    good.reserve(n_good);
+    for (uint64_t r = 0; r < reads->n_pairs; r++) if (status[r] == LCTY_READ_GOOD) good.push_back(r);
+    if (good.size() != n_good) fail(LCTY_ERR_RUNTIME, "inconsistent number of good reads");
+    if (n_good == 0) return;
+    DevBuf<uint64_t> d_good;
+    d_good.alloc(n_good);
+    d_good.upload(good.data(), n_good, ctx->stream);
+    const uint32_t A = reads->locus->n_alleles;
+    dim3 grid(static_cast<uint32_t>((n_good + 63) / 64), (A + 63) / 64);
+    hipLaunchKernelGGL(compact_matrix_kernel, grid, dim3(64, 4), 0, ctx->stream, reads->d_matrix.p, d_good.p, n_good, A, d_out);
+    LCTY_HIP(hipGetLastError());
+    LCTY_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+}  // namespace lcty
+
+ReadsView lcty_reads::view() const {
+    ReadsView v{};
+    v.n_pairs = n_pairs;
+    v.mate_len = d_mate_len.p; v.mate_off = d_mate_off.p; v.bases2 = d_bases2.p; v.nmask = d_nmask.p;
+    v.aln_off = d_aln_off.p; v.recs = d_recs.p; v.cigar_off = d_cigar_off.p; v.cigar = d_cigar.p;
+    v.status = d_status.p; v.weight = d_weight.p; v.unmapped_prob = d_unmapped.p; v.uniq_kmers = d_uniq.p;
+    v.matrix = d_matrix.p;
+    v.pa = d_pa.p; v.pa_cap = d_pa.n; v.pa_count = d_pa_count.p; v.pa_off = d_pa_off.p; v.pa_cnt = d_pa_cnt.p;
+    v.err_flag = d_err.p;
+    return v;
+}
+
+void lcty_reads::check_device_error() {
+    uint32_t flag = 0;
+    d_err.download(&flag, 1, ctx->stream);
+    LCTY_HIP(hipStreamSynchronize(ctx->stream));
+    if (flag == LCTY_ERR_INVALID_DATA)
+        fail(LCTY_ERR_INVALID_DATA,
+             "alignment table violates the input contract (unsupported CIGAR operation, hard-clipped or empty primary, "
+             "missing mate, contig id out of range) — the reference panics here (aln.rs:311, locs.rs:509-526)");
+    if (flag) fail(static_cast<int32_t>(flag), "pair-alignment arena overflow");
+}
+
+extern "C" {
+
+int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_bases, uint64_t cap_recs,
+                          uint64_t cap_cigar, lcty_reads** out) {
+    return guarded([&] {
+        if (!locus || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (cap_bases % 32) fail(LCTY_ERR_INVALID_INPUT, "cap_bases must be a multiple of 32");
+        lcty_ctx* ctx = locus->ctx;
+        ctx->activate();
+        auto R = std::unique_ptr<lcty_reads>(new lcty_reads());
+        R->locus = locus; R->ctx = ctx;
+        R->cap_pairs = cap_pairs; R->cap_bases = cap_bases; R->cap_recs = cap_recs; R->cap_cigar = cap_cigar;
+        const uint32_t A = locus->n_alleles;
+        R->d_mate_len.alloc(2 * cap_pairs);
+        R->d_mate_off.alloc(2 * cap_pairs + 1);
+        R->d_bases2.alloc(cap_bases / 16 + 4);      // +4 words: the k-mer window loader may touch one 64-bit word past a mate
+        R->d_nmask.alloc(cap_bases / 32 + 2);
+        R->d_aln_off.alloc(cap_pairs + 1);
+        R->d_recs.alloc(std::max<uint64_t>(cap_recs, 1));
+        R->d_cigar_off.alloc(cap_pairs + 1);
+        R->d_cigar.alloc(std::max<uint64_t>(cap_cigar, 1));
+        R->d_status.alloc(std::max<uint64_t>(cap_pairs, 1));
+        R->d_weight.alloc(std::max<uint64_t>(cap_pairs, 1));
+        R->d_unmapped.alloc(std::max<uint64_t>(cap_pairs, 1));
+        R->d_uniq.alloc(std::max<uint64_t>(2 * cap_pairs, 1));
+        R->d_matrix.alloc(std::max<uint64_t>(cap_pairs * A, 1));
+        // every saved record yields at most one (aln, unmapped) entry plus its share of pairs; the kept
+        // list is capped at MAX_USED_ALNS per (pair, contig with records) — bound by 10 per record is loose,
+        // the tight bound is min(10 * contigs_with_records, pairs + alones) <= 2 * recs per typical data.
+        // We allocate 10 per (pair, allele) capped by 2 * records + pairs and report overflow loudly.
+        const uint64_t pa_cap = std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * cap_pairs * A,
+                                                   2 * cap_recs + cap_pairs) + 64;
+        R->d_pa.alloc(pa_cap);
+        R->d_pa_count.alloc(1);
+        R->d_pa_off.alloc(std::max<uint64_t>(cap_pairs, 1));
+        R->d_pa_cnt.alloc(std::max<uint64_t>(cap_pairs, 1));
+        R->d_err.alloc(1);
+        R->d_err.zero(ctx->stream);
+        R->d_pa_count.zero(ctx->stream);
+        const uint64_t zero = 0;
+        R->d_mate_off.upload(&zero, 1, ctx->stream);
+        R->d_aln_off.upload(&zero, 1, ctx->stream);
+        R->d_cigar_off.upload(&zero, 1, ctx->stream);
+        LCTY_HIP(hipMemsetAsync(R->d_bases2.p, 0, R->d_bases2.n * sizeof(uint32_t), ctx->stream));
+        LCTY_HIP(hipMemsetAsync(R->d_nmask.p, 0, R->d_nmask.n * sizeof(uint32_t), ctx->stream));
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        *out = R.release();
+    });
+}
+
+int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
+    return guarded([&] {
+        if (!R || !h) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        lcty_ctx* ctx = R->ctx;
+        ctx->activate();
+        const uint64_t n = h->n_pairs;
+        if (n == 0) return;
+        const uint64_t nb = h->mate_off[2 * n], nr = h->aln_off[n], nc = h->cigar_off[n];
+        if (h->mate_off[0] || h->aln_off[0] || h->cigar_off[0]) fail(LCTY_ERR_INVALID_INPUT, "chunk offsets must start at 0");
+        if (R->n_pairs + n > R->cap_pairs || R->n_bases + nb > R->cap_bases || R->n_recs + nr > R->cap_recs ||
+            R->n_cigar + nc > R->cap_cigar)
+            fail(LCTY_ERR_INVALID_INPUT, "chunk exceeds the capacity given to lcty_reads_create");
+        // host-side validation of the CSR structure (cheap, O(pairs + records))
+        uint32_t max_recs = R->max_recs_per_pair;
+        for (uint64_t m = 0; m < 2 * n; m++) {
+            if (h->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
+            if (h->mate_off[m + 1] < h->mate_off[m] + h->mate_len[m]) fail(LCTY_ERR_INVALID_INPUT, "mate offsets overlap");
+        }
+        for (uint64_t r = 0; r < n; r++) {
+            if (h->aln_off[r + 1] < h->aln_off[r] || h->cigar_off[r + 1] < h->cigar_off[r])
+                fail(LCTY_ERR_INVALID_INPUT, "record / CIGAR offsets must be non-decreasing");
+            const uint64_t cnt = h->aln_off[r + 1] - h->aln_off[r];
+            if (cnt > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many records in one read pair");
+            max_recs = std::max<uint32_t>(max_recs, static_cast<uint32_t>(cnt));
+            const uint64_t cw = h->cigar_off[r + 1] - h->cigar_off[r];
+            for (uint64_t i = h->aln_off[r]; i < h->aln_off[r + 1]; i++)
+                if (static_cast<uint64_t>(h->recs[i].cigar_rel) + h->recs[i].n_cigar > cw)
+                    fail(LCTY_ERR_INVALID_INPUT, "CIGAR of record %llu leaves its pair's CIGAR range", (unsigned long long)i);
+        }
+        R->locus->ensure_edit_thresholds(h->mate_len, 2 * n);
+
+        hipStream_t s = ctx->stream;
+        R->d_mate_len.upload(h->mate_len, 2 * n, s, 2 * R->n_pairs);
+        R->d_bases2.upload(h->bases2, nb / 16, s, R->n_bases / 16);
+        R->d_nmask.upload(h->nmask, nb / 32, s, R->n_bases / 32);
+        R->d_recs.upload(h->recs, nr, s, R->n_recs);
+        R->d_cigar.upload(h->cigar, nc, s, R->n_cigar);
+        // rebased offsets
+        std::vector<uint64_t> mo(2 * n), ao(n), co(n);
+        for (uint64_t m = 0; m < 2 * n; m++) mo[m] = h->mate_off[m + 1] + R->n_bases;
+        for (uint64_t r = 0; r < n; r++) { ao[r] = h->aln_off[r + 1] + R->n_recs; co[r] = h->cigar_off[r + 1] + R->n_cigar; }
+        R->d_mate_off.upload(mo.data(), 2 * n, s, 2 * R->n_pairs + 1);
+        R->d_aln_off.upload(ao.data(), n, s, R->n_pairs + 1);
+        R->d_cigar_off.upload(co.data(), n, s, R->n_pairs + 1);
+        LCTY_HIP(hipStreamSynchronize(s));
+        R->n_pairs += n; R->n_bases += nb; R->n_recs += nr; R->n_cigar += nc;
+        R->max_recs_per_pair = max_recs;
+        R->scored = false;
+    });
+}
+
+void lcty_reads_destroy(lcty_reads* reads) {
+    if (!reads) return;
+    (void)hipSetDevice(reads->ctx->device);
+    delete reads;
+}
+
+int32_t lcty_reads_n_pairs(const lcty_reads* reads, uint64_t* out) {
+    return guarded([&] {
+        if (!reads || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        *out = reads->n_pairs;
+    });
+}
+
+int32_t lcty_score_reads(lcty_reads* reads) {
+    return guarded([&] {
+        if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        reads->ctx->activate();
+        if (reads->n_pairs) launch_score_reads(reads);
+        reads->scored = true;
+    });
+}
+
+static void require_scored(lcty_reads* reads) {
+    if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
+    reads->ctx->activate();
+    reads->check_device_error();
+}
+
+int32_t lcty_reads_get_status(lcty_reads* reads, uint8_t* status, double* weight, double* unmapped_prob, uint16_t* uniq_kmers) {
+    return guarded([&] {
+        require_scored(reads);
+        hipStream_t s = reads->ctx->stream;
+        const uint64_t n = reads->n_pairs;
+        if (status) reads->d_status.download(status, n, s);
+        if (weight) reads->d_weight.download(weight, n, s);
+        if (unmapped_prob) reads->d_unmapped.download(unmapped_prob, n, s);
+        if (uniq_kmers) reads->d_uniq.download(uniq_kmers, 2 * n, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int32_t lcty_reads_n_good(lcty_reads* reads, uint64_t* out) {
+    return guarded([&] {
+        require_scored(reads);
+        if (!out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        std::vector<uint8_t> status(reads->n_pairs);
+        reads->d_status.download(status.data(), reads->n_pairs, reads->ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(reads->ctx->stream));
+        uint64_t g = 0;
+        for (uint8_t v : status) g += v == LCTY_READ_GOOD;
+        *out = g;
+    });
+}
+
+int32_t lcty_best_aln_matrix(lcty_reads* reads, double* out) {
+    return guarded([&] {
+        require_scored(reads);
+        if (!out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        uint64_t n_good = 0;
+        {
+            std::vector<uint8_t> status(reads->n_pairs);
+            reads->d_status.download(status.data(), reads->n_pairs, reads->ctx->stream);
+            LCTY_HIP(hipStreamSynchronize(reads->ctx->stream));
+            for (uint8_t v : status) n_good += v == LCTY_READ_GOOD;
+        }
+        if (!n_good) return;
+        const uint32_t A = reads->locus->n_alleles;
+        DevBuf<double> d_out;
+        d_out.alloc(n_good * A);
+        compact_matrix(reads, d_out.p, n_good);
+        d_out.download(out, n_good * A, reads->ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(reads->ctx->stream));
+    });
+}
+
+int32_t lcty_reads_get_pair_alns(lcty_reads* reads, uint64_t* off, lcty_pair_aln* out, uint64_t cap) {
+    return guarded([&] {
+        require_scored(reads);
+        hipStream_t s = reads->ctx->stream;
+        const uint64_t n = reads->n_pairs;
+        std::vector<uint64_t> dev_off(n);
+        std::vector<uint32_t> cnt(n);
+        reads->d_pa_off.download(dev_off.data(), n, s);
+        reads->d_pa_cnt.download(cnt.data(), n, s);
+        unsigned long long total = 0;
+        LCTY_HIP(hipMemcpyAsync(&total, reads->d_pa_count.p, sizeof(total), hipMemcpyDeviceToHost, s));
+        LCTY_HIP(hipStreamSynchronize(s));
+        uint64_t run = 0;
+        for (uint64_t r = 0; r < n; r++) { if (off) off[r] = run; run += cnt[r]; }
+        if (off) off[n] = run;
+        if (run != total) fail(LCTY_ERR_RUNTIME, "pair-alignment arena is inconsistent (%llu vs %llu)", (unsigned long long)run, total);
+        if (!out) return;
+        if (cap < run) fail(LCTY_ERR_INVALID_INPUT, "output capacity %llu < %llu pair alignments", (unsigned long long)cap, (unsigned long long)run);
+        std::vector<PairAlnDev> arena(total);
+        reads->d_pa.download(arena.data(), total, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        uint64_t w = 0;
+        for (uint64_t r = 0; r < n; r++) {
+            for (uint32_t t = 0; t < cnt[r]; t++) {
+                const PairAlnDev& d = arena[dev_off[r] + t];
+                lcty_pair_aln& o = out[w++];
+                memset(&o, 0, sizeof(o));
+                o.ln_prob = d.ln_prob;
+                o.ix1 = d.ix1 == 0xFFFFu ? LCTY_NONE_U32 : d.ix1;
+                o.ix2 = d.ix2 == 0xFFFFu ? LCTY_NONE_U32 : d.ix2;
+                o.mid1 = d.mid1; o.mid2 = d.mid2; o.contig = d.contig;
+            }
+        }
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""Synthetic workloads of the BASELINE.json shapes (binding of synth/lcty_synth.c).
+
+Bench / test input generator: produces numpy buffers in the lcty_reads_host layout.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import cdefs
+from .cdefs import ALN_REC_DTYPE, Bg, ReadsChunk
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "synth", "liblcty_synth.so")
+_lib = None
+
+# seed of SURVEY.md §8(d) / BASELINE.md; locus l uses SEED + l
+SEED = 0x10C17E9E20250001
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(_LIB_PATH)
+        L.synth_locus_new.restype = C.c_void_p
+        L.synth_locus_new.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64]
+        L.synth_locus_free.argtypes = [C.c_void_p]
+        for name, rt in (("synth_locus_seqs", C.POINTER(C.c_uint8)), ("synth_locus_seq_off", C.POINTER(C.c_uint64)),
+                         ("synth_locus_counts", C.POINTER(C.c_uint16)), ("synth_locus_cnt_off", C.POINTER(C.c_uint64)),
+                         ("synth_locus_bg", C.POINTER(Bg))):
+            getattr(L, name).restype = rt
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.synth_locus_true_genotype.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.synth_reads_sizes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.synth_reads_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 7
+        _lib = L
+    return _lib
+
+
+class SynthLocus:
+    """Alleles + off-target k-mer counts + BgDistr of one synthetic locus."""
+
+    def __init__(self, n_alleles, n_pairs, seed=SEED, base_len=50_000, k=25,
+                 technology=cdefs.TECH_ILLUMINA, read_len=150):
+        L = lib()
+        self._h = L.synth_locus_new(seed, n_alleles, base_len, k, technology, read_len, n_pairs)
+        if not self._h:
+            raise RuntimeError("synth_locus_new failed")
+        self.n_alleles, self.k, self.n_pairs = n_alleles, k, n_pairs
+        self.seq_off = np.ctypeslib.as_array(L.synth_locus_seq_off(self._h), (n_alleles + 1,)).copy()
+        self.seqs = np.ctypeslib.as_array(L.synth_locus_seqs(self._h), (int(self.seq_off[-1]),)).copy()
+        self.cnt_off = np.ctypeslib.as_array(L.synth_locus_cnt_off(self._h), (n_alleles + 1,)).copy()
+        self.counts = np.ctypeslib.as_array(L.synth_locus_counts(self._h), (int(self.cnt_off[-1]),)).copy()
+        self.bg = Bg()
+        C.memmove(C.byref(self.bg), L.synth_locus_bg(self._h), C.sizeof(Bg))
+        gt = (C.c_uint32 * 2)()
+        L.synth_locus_true_genotype(self._h, gt)
+        self.true_genotype = (int(gt[0]), int(gt[1]))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().synth_locus_free(self._h)
+            self._h = None
+
+    def allele(self, a):
+        return bytes(self.seqs[int(self.seq_off[a]):int(self.seq_off[a + 1])])
+
+    def reads(self, first, n):
+        """Read pairs [first, first+n) with all their candidate alignments."""
+        L = lib()
+        mate_len = np.zeros(2 * n, dtype=np.uint32)
+        rec_cnt = np.zeros(n, dtype=np.uint32)
+        cig_cnt = np.zeros(n, dtype=np.uint32)
+        L.synth_reads_sizes(self._h, first, n, mate_len.ctypes.data, rec_cnt.ctypes.data, cig_cnt.ctypes.data)
+        mate_off = np.zeros(2 * n + 1, dtype=np.uint64)
+        np.cumsum((mate_len.astype(np.uint64) + 31) // 32 * 32, out=mate_off[1:])
+        aln_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(rec_cnt, out=aln_off[1:], dtype=np.uint64)
+        cigar_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(cig_cnt, out=cigar_off[1:], dtype=np.uint64)
+        nb = int(mate_off[-1])
+        bases2 = np.zeros(max(nb // 16, 1), dtype=np.uint32)
+        nmask = np.zeros(max(nb // 32, 1), dtype=np.uint32)
+        recs = np.zeros(int(aln_off[-1]), dtype=ALN_REC_DTYPE)
+        cigar = np.zeros(max(int(cigar_off[-1]), 1), dtype=np.uint32)
+        L.synth_reads_fill(self._h, first, n, mate_off.ctypes.data, bases2.ctypes.data, nmask.ctypes.data,
+                           aln_off.ctypes.data, recs.ctypes.data, cigar_off.ctypes.data, cigar.ctypes.data)
+        return ReadsChunk(mate_len, mate_off, bases2, nmask, aln_off, recs, cigar_off,
+                          cigar[:int(cigar_off[-1])])
+
+
+# the five BASELINE.json configurations
+CONFIGS = {
+    1: dict(n_pairs=10_000, n_alleles=8, technology=cdefs.TECH_ILLUMINA, read_len=150),
+    2: dict(n_pairs=1_000_000, n_alleles=256, technology=cdefs.TECH_ILLUMINA, read_len=150),
+    3: dict(n_pairs=1_000_000, n_alleles=256, technology=cdefs.TECH_NANOPORE, read_len=10_000),
+    4: dict(n_pairs=1_000_000, n_alleles=256, technology=cdefs.TECH_ILLUMINA, read_len=150, n_loci=32),
+    5: dict(n_pairs=5_000_000, n_alleles=4096, technology=cdefs.TECH_ILLUMINA, read_len=150),
+}

@@ -1,0 +1,215 @@
+"""ctypes binding of oracle/_build/liblcty_oracle.so — the CPU restatement.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py. The product package (locityper_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from locityper_amd import cdefs
+from locityper_amd.cdefs import Bg, Params, ReadsHost, PAIR_ALN_DTYPE
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_ROOT, "oracle", "_build", "liblcty_oracle.so")
+_lib = None
+
+D, U32, U64, VP = C.c_double, C.c_uint32, C.c_uint64, C.c_void_p
+
+
+class NBinom(C.Structure):
+    _fields_ = [("n", D), ("p", D), ("lnq", D), ("lnpmf_const", D)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} missing: run `make -C oracle`")
+    L = C.CDLL(LIB_PATH)
+
+    def sig(name, restype, *argtypes):
+        f = getattr(L, name)
+        f.restype = restype
+        f.argtypes = list(argtypes)
+
+    sig("orc_ln_gamma", D, D)
+    sig("orc_ln_beta", D, D, D)
+    sig("orc_beta_reg", D, D, D, D)
+    sig("orc_ln_add", D, D, D)
+    sig("orc_ln_sum", D, VP, C.c_size_t)
+    sig("orc_ln_sum_init", D, VP, C.c_size_t, D)
+    sig("orc_nbinom_new", NBinom, D, D)
+    sig("orc_nbinom_ln_pmf", D, C.POINTER(NBinom), U32)
+    sig("orc_nbinom_mode", U32, C.POINTER(NBinom))
+    sig("orc_nbinom_cdf", D, C.POINTER(NBinom), U32)
+    sig("orc_nbinom_quantile", D, C.POINTER(NBinom), D)
+    sig("orc_insert_cache_size", C.c_size_t, C.POINTER(NBinom))
+    sig("orc_betabinom_inv_cdf2", None, D, D, U32, D, D, C.POINTER(U32), C.POINTER(U32))
+    sig("orc_edit_thresholds", None, C.POINTER(Bg), U32, C.POINTER(U32), C.POINTER(U32))
+    sig("orc_depth_ln_pmf", D, C.POINTER(Bg), C.POINTER(Params), U32, U32)
+    sig("orc_students_t_cdf", D, D, D)
+    sig("orc_t_test", D, D, D, D, D, D)
+    sig("orc_t_test_diffsizes", D, D, D, D, D, D, D)
+    sig("orc_params_default", None, C.POINTER(Params))
+    sig("orc_params_resolve", C.c_int, C.POINTER(Params), C.POINTER(Bg))
+    sig("orc_kmers_u128", C.c_size_t, VP, C.c_size_t, U32, C.c_int, VP)
+    sig("orc_kmers_u32", C.c_size_t, VP, C.c_size_t, U32, C.c_int, VP)
+    sig("orc_complexity_counts", C.c_size_t, VP, C.c_size_t, U32, U32, VP)
+    sig("orc_locus_new", VP, U32, VP, VP, VP, VP, U32, C.POINTER(Bg), C.POINTER(Params))
+    sig("orc_locus_free", None, VP)
+    sig("orc_locus_n_unique_kmers", U64, VP)
+    sig("orc_locus_contig_info", C.c_int, VP, U32, VP, VP, VP, C.POINTER(U32), C.POINTER(U32))
+    sig("orc_locus_insert_lnprob", D, VP, U32)
+    sig("orc_locus_insert_penalty", D, VP)
+    sig("orc_load", VP, VP, C.POINTER(ReadsHost), C.POINTER(C.c_int))
+    sig("orc_alns_free", None, VP)
+    sig("orc_alns_n_pairs", U64, VP)
+    sig("orc_alns_n_good", U64, VP)
+    sig("orc_alns_status", None, VP, VP, VP, VP, VP)
+    sig("orc_alns_pair_alns", U64, VP, VP, VP, U64)
+    sig("orc_best_aln_matrix", None, VP, VP)
+    sig("orc_count_genotypes", U64, U32, U32)
+    sig("orc_generate_genotypes", U64, U32, U32, VP)
+    sig("orc_run_filter", None, VP, U32, U64, VP, U64, U32, VP, VP)
+    sig("orc_truncate", U64, VP, VP, U64, D, U64, U64)
+    _lib = L
+    return L
+
+
+def default_params():
+    p = Params()
+    lib().orc_params_default(C.byref(p))
+    return p
+
+
+def resolve_params(p, bg):
+    rc = lib().orc_params_resolve(C.byref(p), C.byref(bg))
+    if rc:
+        raise ValueError(f"orc_params_resolve -> {rc}")
+    return p
+
+
+def kmers(seq: bytes, k: int, canonical=True):
+    """kmers::kmers::<u128> as Python ints."""
+    n = len(seq)
+    out = np.zeros((max(n + 1 - k, 0), 2), dtype=np.uint64)
+    buf = np.frombuffer(seq, dtype=np.uint8)
+    w = lib().orc_kmers_u128(buf.ctypes.data, n, k, int(canonical), out.ctypes.data)
+    return [int(lo) | (int(hi) << 64) for lo, hi in out[:w]]
+
+
+def complexity_counts(seq: bytes, k: int, w: int):
+    n = len(seq)
+    out = np.zeros(n - w + 1, dtype=np.uint16)
+    buf = np.frombuffer(seq, dtype=np.uint8)
+    m = lib().orc_complexity_counts(buf.ctypes.data, n, k, w, out.ctypes.data)
+    assert m == len(out)
+    return out
+
+
+class OracleLocus:
+    def __init__(self, seqs, seq_off, counts, cnt_off, k, bg, params):
+        self.seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        self.seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        self.counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        self.cnt_off = np.ascontiguousarray(cnt_off, dtype=np.uint64)
+        self.n_alleles = len(self.seq_off) - 1
+        self.bg, self.params, self.k = bg, params, k
+        self._h = lib().orc_locus_new(self.n_alleles, self.seqs.ctypes.data, self.seq_off.ctypes.data,
+                                      self.counts.ctypes.data, self.cnt_off.ctypes.data, k,
+                                      C.byref(bg), C.byref(params))
+        if not self._h:
+            raise ValueError("orc_locus_new failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_locus_free(self._h)
+            self._h = None
+
+    def n_unique_kmers(self):
+        return int(lib().orc_locus_n_unique_kmers(self._h))
+
+    def contig_info(self, a):
+        ln = int(self.seq_off[a + 1] - self.seq_off[a])
+        npos = ln - self.bg.neighb + 1
+        gc = np.zeros(npos, dtype=np.uint8)
+        uniq = np.zeros(npos, dtype=np.uint32)
+        cc = np.zeros(npos, dtype=np.uint16)
+        nw, rs = U32(), U32()
+        rc = lib().orc_locus_contig_info(self._h, a, gc.ctypes.data, uniq.ctypes.data, cc.ctypes.data,
+                                         C.byref(nw), C.byref(rs))
+        assert rc == 0
+        return gc, uniq, cc, nw.value, rs.value
+
+    def insert_lnprob(self, sz):
+        return lib().orc_locus_insert_lnprob(self._h, int(sz))
+
+    def insert_penalty(self):
+        return lib().orc_locus_insert_penalty(self._h)
+
+    def load(self, chunk):
+        """AllAlignments::load -> OracleAlns (raises ValueError with the error code on invalid data)."""
+        err = C.c_int(0)
+        hs = chunk.host_struct()
+        h = lib().orc_load(self._h, C.byref(hs), C.byref(err))
+        if not h:
+            raise ValueError(f"orc_load failed: {err.value}")
+        return OracleAlns(h, self.n_alleles)
+
+
+class OracleAlns:
+    def __init__(self, h, n_alleles):
+        self._h = h
+        self.n_alleles = n_alleles
+        L = lib()
+        self.n_pairs = int(L.orc_alns_n_pairs(h))
+        self.n_good = int(L.orc_alns_n_good(h))
+        self.status = np.zeros(self.n_pairs, dtype=np.uint8)
+        self.weight = np.zeros(self.n_pairs, dtype=np.float64)
+        self.unmapped_prob = np.zeros(self.n_pairs, dtype=np.float64)
+        self.uniq_kmers = np.zeros(2 * self.n_pairs, dtype=np.uint16)
+        L.orc_alns_status(h, self.status.ctypes.data, self.weight.ctypes.data, self.unmapped_prob.ctypes.data,
+                          self.uniq_kmers.ctypes.data)
+        self.pa_off = np.zeros(self.n_pairs + 1, dtype=np.uint64)
+        n = int(L.orc_alns_pair_alns(h, self.pa_off.ctypes.data, None, 0))
+        self.pair_alns = np.zeros(n, dtype=PAIR_ALN_DTYPE)
+        L.orc_alns_pair_alns(h, None, self.pair_alns.ctypes.data, n)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_alns_free(self._h)
+            self._h = None
+
+    def best_aln_matrix(self):
+        out = np.zeros((self.n_alleles, self.n_good), dtype=np.float64)
+        lib().orc_best_aln_matrix(self._h, out.ctypes.data)
+        return out
+
+
+def generate_genotypes(n_alleles, ploidy):
+    n = int(lib().orc_count_genotypes(n_alleles, ploidy))
+    out = np.zeros((n, ploidy), dtype=np.uint16)
+    w = lib().orc_generate_genotypes(n_alleles, ploidy, out.ctypes.data)
+    assert w == n
+    return out
+
+
+def run_filter(matrix, genotypes, priors=None):
+    matrix = np.ascontiguousarray(matrix, dtype=np.float64)
+    genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n_gt, ploidy = genotypes.shape
+    scores = np.zeros(n_gt, dtype=np.float64)
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    lib().orc_run_filter(matrix.ctypes.data, matrix.shape[0], matrix.shape[1], genotypes.ctypes.data, n_gt, ploidy,
+                         None if pri is None else pri.ctypes.data, scores.ctypes.data)
+    return scores
+
+
+def truncate(scores, ixs, filt_diff, min_size, threads):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    ixs = np.ascontiguousarray(ixs, dtype=np.uint64).copy()
+    m = lib().orc_truncate(scores.ctypes.data, ixs.ctypes.data, len(ixs), filt_diff, min_size, threads)
+    return ixs[:int(m)]
