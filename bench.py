@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s scored + genotypes/s prefiltered on the BASELINE.json config
+("1M synthetic 150 bp PE reads, 1 locus, 256 alleles, k=25" = configs[1]).
+
+A step = one pass of the hot path over one locus' batch, inputs resident in HBM:
+    lcty_score_reads   (K2+K4+K5+K7+K8: AllAlignments::load -> likelihood matrix + pair alignments)
+    lcty_prefilter     (K9: run_filter over all C(A+1,2) genotypes) + scores D2H
+    lcty_truncate      (K10: truncate_ixs on the host)
+N > 1: one process per GPU, one independent locus per rank (loci are independent in the reference,
+command/genotype.rs:1331-1351) -> weak scaling, no data-path collective; torch.distributed (gloo)
+only carries the barrier and the max-over-ranks of the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from locityper_amd import _lib, api, synth, cdefs  # noqa: E402
+
+# SURVEY.md §8(d) / BASELINE.md algorithmic bytes per read pair scored (config 2, f64 matrix):
+# 75 B packed bases + 2*A*16 B alignment table + 252*8 B k-mer probe slots + A*8 B matrix row
+ALG_BYTES_FIXED = 75 + 2016
+
+
+def survey_bytes_per_pair(n_alleles):
+    return ALG_BYTES_FIXED + 2 * n_alleles * 16 + n_alleles * 8
+
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per locus (BASELINE: 1M)")
+    ap.add_argument("--alleles", type=int, default=256)
+    ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    _lib.lib()      # load the HIP library before anything else can bring another HIP runtime into scope
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist      # gloo: barrier + max-reduce only, no GPU tensors
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+
+    ndev = api.device_count()
+    if ndev < 1:
+        raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
+    ctx = api.Context(local_rank % ndev)
+
+    # ---- synthetic locus + reads (seed + locus index) -> HBM ----
+    t0 = time.time()
+    L = synth.SynthLocus(args.alleles, args.pairs, seed=synth.SEED + rank)
+    params = api.resolve_params(api.default_params(), L.bg)
+    t1 = time.time()
+    loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
+    ctx.synchronize()
+    locus_setup_s = time.time() - t1
+    first = None
+    sizes = []
+    chunks = []
+    # first pass over chunks only to size the device batch would double the generation time; instead
+    # generate chunk by chunk, keep totals, and allocate from the first chunk's density with head-room.
+    n_chunks = (args.pairs + args.chunk - 1) // args.chunk
+    c0 = L.reads(0, min(args.chunk, args.pairs))
+    dens_b = c0.n_bases / c0.n_pairs
+    dens_r = len(c0.recs) / c0.n_pairs
+    dens_c = len(c0.cigar) / c0.n_pairs
+    head = 1.03
+    cap_bases = (int(dens_b * args.pairs * head) + 1024) // 32 * 32 + 32
+    aa = api.AllAlignments(loc, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096,
+                           int(dens_c * args.pairs * head) + 65536)
+    aa.append(c0)
+    tot_recs, tot_cigar, tot_bases = len(c0.recs), len(c0.cigar), c0.n_bases
+    first = c0 if (rank == 0 and world == 1 and args.cpu_sample > 0) else None
+    for ci in range(1, n_chunks):
+        lo = ci * args.chunk
+        ch = L.reads(lo, min(args.chunk, args.pairs - lo))
+        aa.append(ch)
+        tot_recs += len(ch.recs); tot_cigar += len(ch.cigar); tot_bases += ch.n_bases
+        del ch
+    gen_s = time.time() - t0
+    A = args.alleles
+    G = api.count_genotypes(A, 2)
+    all_ixs = np.arange(G, dtype=np.uint64)
+
+    def step():
+        aa.score()
+        aa.prefilter_async()
+        scores = aa.prefilter_scores()
+        keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, params.threads)   # in_size of stage 1 (solve.rs:216-221)
+        return scores, keep
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_reset()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        scores, keep = step()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t_start
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    n_score, ms_score = ctx.timing(api.K_SCORE)
+    n_pref, ms_pref = ctx.timing(api.K_PREFILTER)
+
+    top = int(keep[0])
+    gts = api.generate_genotypes(A, 2)
+    called = tuple(int(x) for x in gts[top])
+
+    if rank != 0:
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    reads_per_s = world * args.pairs * args.steps / elapsed
+    score_ms = ms_score / max(n_score, 1)
+    pref_ms = ms_pref / max(n_pref, 1)
+    alg_bytes = survey_bytes_per_pair(A) * args.pairs
+    layout_bytes = (tot_bases / 4 + tot_bases / 8 + 16 * tot_recs + 4 * tot_cigar + 8 * A * args.pairs
+                    + 8 * 4 * args.pairs)      # what the kernel's inputs/outputs occupy, excl. pair-alignment arena
+    achieved = alg_bytes / (score_ms * 1e-3) / 1e9
+    out = {
+        "metric": "reads/s scored (read pairs -> likelihood-matrix row + all genotypes prefiltered)",
+        "value": reads_per_s,
+        "unit": "read pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.pairs} synthetic 150 bp PE read pairs x {A} alleles, 1 locus per GPU, k=25 "
+                               "(BASELINE.json configs[1])",
+                   "read_pairs": args.pairs, "alleles": A, "genotypes": G, "k": 25,
+                   "records": tot_recs, "cigar_words": tot_cigar, "parallelism": f"loci x{world}"},
+        "genotypes_per_s": world * G * args.steps / elapsed,
+        "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3),
+        "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms},
+        "roofline": {"bound": "hbm", "kernel": "score_reads_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "layout_bytes_per_launch": layout_bytes,
+                     "achieved_layout_GBs": layout_bytes / (score_ms * 1e-3) / 1e9},
+        "roofline_prefilter": {"bound": "valu_f64", "achieved": 2.0 * G * args.pairs / (pref_ms * 1e-3) / 1e12,
+                               "peak": 39.3, "unit": "Tmaxadd/s",
+                               "frac": 2.0 * G * args.pairs / (pref_ms * 1e-3) / 1e12 / 39.3},
+        "called_genotype": called, "true_genotype": L.true_genotype, "kept_after_prefilter": int(len(keep)),
+        "setup_s": {"generate_and_upload": gen_s, "locus_create": locus_setup_s},
+    }
+
+    if first is not None:
+        # ---- CPU baseline: the oracle (C restatement of the reference algorithms, single thread:
+        # AllAlignments::load is a single-threaded BAM loop and run_filter is single-threaded in the
+        # reference) on a bounded sample of the same workload ----
+        from tests import oracle_ffi as O
+        ns = min(args.cpu_sample, first.n_pairs)
+        sample = first.slice(0, ns)
+        ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
+        tc = time.perf_counter()
+        oa = ol.load(sample)
+        Mo = oa.best_aln_matrix()
+        t_load = time.perf_counter() - tc
+        tc = time.perf_counter()
+        so = O.run_filter(Mo, gts)
+        O.truncate(so, all_ixs, params.filt_diff, 5000, params.threads)
+        t_filter = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": ns / (t_load + t_filter), "unit": "read pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"first {ns} read pairs of the same workload x {A} alleles, all {G} genotypes "
+                                         f"(load {t_load:.2f} s + run_filter {t_filter:.2f} s)",
+                               "cpu_count": os.cpu_count()}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

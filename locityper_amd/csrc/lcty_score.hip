@@ -55,10 +55,14 @@ __device__ inline uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t* to
 }
 
 // InsertDistr::ln_prob -> LinearCache::ln_pmf (insertsz.rs:153-155, lincache.rs:41-48)
+// cold path: insert sizes beyond the cached range are evaluated directly (nbinom.rs:128-131)
+__device__ __noinline__ double nbinom_ln_pmf_direct(double n, double lnq, double lnpmf_const, uint32_t sz) {
+    const double x = static_cast<double>(sz);
+    return lnpmf_const + lgamma(n + x) - lgamma(x + 1.0) + x * lnq;
+}
 __device__ inline double insert_lnprob(const LocusView& L, uint32_t sz) {
     if (sz < L.ins_lut_size) return L.ins_lut[sz];
-    const double x = static_cast<double>(sz);
-    return L.ins_lnpmf_const + lgamma(L.ins_n + x) - lgamma(x + 1.0) + x * L.ins_lnq;    // nbinom.rs:128-131
+    return nbinom_ln_pmf_direct(L.ins_n, L.ins_lnq, L.ins_lnpmf_const, sz);
 }
 
 // UniqueKmers::calculate_read_weight for one mate (locs.rs:976-993): count of non-overlapping hits.

@@ -407,32 +407,55 @@ static void make_mate(const synth_locus* L, rng_t* r, uint32_t h, uint32_t h_sta
 }
 
 /* emits the record of mate m (generated from haplotype h) against allele a */
-static void align_to(const synth_locus* L, const mate_t* m, uint32_t h, uint32_t a, uint16_t flags,
+#define MAX_SITES 2048
+typedef struct {
+    uint32_t bs;                   /* base coordinate of the mate start */
+    uint32_t n;
+    uint32_t var[MAX_SITES];       /* variant index */
+    uint32_t q[MAX_SITES];         /* read offset of the site (non-decreasing) */
+    uint8_t ch[MAX_SITES];         /* carried by the source haplotype */
+} mate_sites;
+
+/* variant sites under the mate, computed once per mate and reused for every allele */
+static void prepare_sites(const synth_locus* L, const mate_t* m, uint32_t h, mate_sites* ms) {
+    ms->bs = a2b(L, h, m->h_start);
+    ms->n = 0;
+    uint32_t be = a2b(L, h, m->h_start + m->len);
+    uint32_t lo = 0, hi = L->n_vars;
+    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (L->vars[mid].pos < ms->bs) lo = mid + 1; else hi = mid; }
+    for (uint32_t i = lo; i < L->n_vars && L->vars[i].pos < be && ms->n < MAX_SITES; i++) {
+        const variant* v = &L->vars[i];
+        uint32_t hp = b2a(L, h, v->pos);
+        if (hp < m->h_start) continue;
+        ms->var[ms->n] = i; ms->q[ms->n] = hp - m->h_start; ms->ch[ms->n] = (uint8_t)carries(L, h, v);
+        ms->n++;
+    }
+}
+
+/* emits the record of mate m (generated from haplotype h) against allele a */
+static void align_to(const synth_locus* L, const mate_t* m, const mate_sites* ms, uint32_t h, uint32_t a, uint16_t flags,
                      event* evbuf, cigbuf* cb, pair_out* po) {
     uint32_t n_ev = 0;
-    memcpy(evbuf, m->err, sizeof(event) * m->n_err); n_ev = m->n_err;
-    uint32_t bs = a2b(L, h, m->h_start);
-    if (a != h) {
-        uint32_t be = a2b(L, h, m->h_start + m->len);
-        /* variant sites with base position in [bs, be) carried by exactly one of h, a */
-        uint32_t lo = 0, hi = L->n_vars;
-        while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (L->vars[mid].pos < bs) lo = mid + 1; else hi = mid; }
-        for (uint32_t i = lo; i < L->n_vars && L->vars[i].pos < be && n_ev < MAX_EVENTS; i++) {
-            const variant* v = &L->vars[i];
-            int ch = carries(L, h, v), ca = carries(L, a, v);
+    if (a == h) {
+        memcpy(evbuf, m->err, sizeof(event) * m->n_err); n_ev = m->n_err;
+    } else {
+        /* merge the (sorted) sequencing-error events with the (sorted) variant differences */
+        uint32_t ie = 0;
+        for (uint32_t s = 0; s < ms->n && n_ev < MAX_EVENTS; s++) {
+            const variant* v = &L->vars[ms->var[s]];
+            int ch = ms->ch[s], ca = carries(L, a, v);
             if (ch == ca) continue;
-            uint32_t hp = b2a(L, h, v->pos);
-            if (hp < m->h_start) continue;
-            event* e = &evbuf[n_ev];
-            e->q = hp - m->h_start;
-            if (v->type == 0) { e->op = 1; e->len = 1; }
-            else if ((v->type == 1) == (ch != 0)) { e->op = 2; e->len = v->len; e->q += 1; }   /* read has extra bases */
-            else { e->op = 3; e->len = v->len; e->q += (v->type == 1); }
-            n_ev++;
+            event e;
+            e.q = ms->q[s];
+            if (v->type == 0) { e.op = 1; e.len = 1; }
+            else if ((v->type == 1) == (ch != 0)) { e.op = 2; e.len = v->len; e.q += 1; }   /* read has extra bases */
+            else { e.op = 3; e.len = v->len; e.q += (v->type == 1); }
+            while (ie < m->n_err && m->err[ie].q <= e.q && n_ev < MAX_EVENTS) evbuf[n_ev++] = m->err[ie++];
+            if (n_ev < MAX_EVENTS) evbuf[n_ev++] = e;
         }
-        if (n_ev > m->n_err) qsort(evbuf, n_ev, sizeof(event), cmp_event);
+        while (ie < m->n_err && n_ev < MAX_EVENTS) evbuf[n_ev++] = m->err[ie++];
     }
-    uint32_t pos = b2a(L, a, bs) + m->clip_l;
+    uint32_t pos = b2a(L, a, ms->bs) + m->clip_l;
     build_cigar(evbuf, n_ev, m->len, m->clip_l, m->clip_r, cb);
     uint32_t alen = (uint32_t)(L->seq_off[a + 1] - L->seq_off[a]);
     if (pos >= alen) pos = alen - 1;
@@ -454,7 +477,7 @@ static void emit_variant_rec(const synth_locus* L, rng_t* r, const mate_t* m, ui
 }
 
 typedef struct {
-    event* ev; uint32_t* cig; uint8_t* seq1; uint8_t* seq2; mate_t* m1; mate_t* m2;
+    event* ev; uint32_t* cig; uint8_t* seq1; uint8_t* seq2; mate_t* m1; mate_t* m2; mate_sites* ms;
 } scratch;
 
 static void gen_pair(const synth_locus* L, uint64_t pair, scratch* S, pair_out* po, uint32_t* len_out) {
@@ -515,7 +538,8 @@ static void gen_pair(const synth_locus* L, uint64_t pair, scratch* S, pair_out* 
         mate_t* m = e ? m2 : m1;
         uint16_t ef = e ? LCTY_FLAG_MATE2 : 0;
         /* primary: the source haplotype */
-        align_to(L, m, h, h, ef, S->ev, &cb, po);
+        prepare_sites(L, m, h, S->ms);
+        align_to(L, m, S->ms, h, h, ef, S->ev, &cb, po);
         double u = rng_unif(&r);
         if (u < 0.05) {         /* decoy >= 1 kb away, 2-9 mismatches */
             uint32_t a = rng_below(&r, A);
@@ -528,7 +552,7 @@ static void gen_pair(const synth_locus* L, uint64_t pair, scratch* S, pair_out* 
         }
         for (uint32_t a = 0; a < A; a++) {
             if (a == h) continue;
-            align_to(L, m, h, a, ef | LCTY_FLAG_SECONDARY, S->ev, &cb, po);
+            align_to(L, m, S->ms, h, a, ef | LCTY_FLAG_SECONDARY, S->ev, &cb, po);
         }
     }
 }
@@ -539,9 +563,10 @@ static scratch* scratch_new(uint32_t max_len) {
     S->cig = (uint32_t*)malloc(sizeof(uint32_t) * MAX_CIG);
     S->seq1 = (uint8_t*)malloc(max_len + 8); S->seq2 = (uint8_t*)malloc(max_len + 8);
     S->m1 = (mate_t*)malloc(sizeof(mate_t)); S->m2 = (mate_t*)malloc(sizeof(mate_t));
+    S->ms = (mate_sites*)malloc(sizeof(mate_sites));
     return S;
 }
-static void scratch_free(scratch* S) { free(S->ev); free(S->cig); free(S->seq1); free(S->seq2); free(S->m1); free(S->m2); free(S); }
+static void scratch_free(scratch* S) { free(S->ev); free(S->cig); free(S->seq1); free(S->seq2); free(S->m1); free(S->m2); free(S->ms); free(S); }
 
 static uint32_t max_read_len(const synth_locus* L) {
     return L->bg.is_paired ? L->read_len : (uint32_t)(2.5 * L->read_len) + 8;
