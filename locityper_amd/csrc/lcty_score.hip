@@ -200,7 +200,7 @@ __device__ inline uint32_t sort_dedupe(const RecLds* rec, uint16_t* ord, uint32_
     return kept;
 }
 
-__global__ __launch_bounds__(WAVE) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+__global__ __launch_bounds__(WAVE) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs, const uint32_t dbg) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t A = L.n_alleles;
     RecLds* rec = reinterpret_cast<RecLds*>(smem);
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(WAVE) void score_reads_kernel(const LocusView L, co
             if (b && j2 != NONE32 && j3 == NONE32) j3 = base + static_cast<uint32_t>(__ffsll(static_cast<long long>(b))) - 1u;
         }
         __syncthreads();
+        if (dbg == 1) { if (lane == 0) R.status[p] = static_cast<uint8_t>(j2 + rec[0].edit); continue; }   // ablation (LCTY_DBG)
         // records of this pair: end 0 = [0, j2), end 1 = [j2, n_eff) (locs.rs:1119-1131)
         const uint32_t n_eff = L.is_paired ? min(n, j3) : min(n, j2);
         const uint32_t split = min(j2, n_eff);
@@ -378,12 +379,13 @@ __global__ __launch_bounds__(WAVE) void score_reads_kernel(const LocusView L, co
                 }
             }
             __syncthreads();
+            if (dbg == 2) { if (lane == 0) R.status[p] = static_cast<uint8_t>(order[0]); continue; }          // ablation
 
             // ---------------- K2: unique k-mers -> read weight (locs.rs:968-1002) ----------------
             // (evaluated after the in-bounds test in the reference; it has no side effects, so the
             //  order is irrelevant for the result)
-            const uint32_t uk0 = mate_unique_kmers(L, R, 2 * p, lane);
-            const uint32_t uk1 = L.is_paired && R.mate_len[2 * p + 1] ? mate_unique_kmers(L, R, 2 * p + 1, lane) : 0u;
+            const uint32_t uk0 = dbg == 3 ? 5u : mate_unique_kmers(L, R, 2 * p, lane);
+            const uint32_t uk1 = dbg == 3 ? 5u : (L.is_paired && R.mate_len[2 * p + 1] ? mate_unique_kmers(L, R, 2 * p + 1, lane) : 0u);
             const uint32_t paired_count = (uk0 + uk1) & 0xFFFFu;
             double kw = L.weight_interc + static_cast<double>(paired_count) * L.weight_mult;
             kw = kw < 0.0 ? 0.0 : (kw > 1.0 ? 1.0 : kw);
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(WAVE) void score_reads_kernel(const LocusView L, co
                     uint32_t tot;
                     const uint32_t my_off = run + wave_excl_scan_u32(cnt, lane, &tot);
                     run += tot;
-                    if (cnt && room) {
+                    if (cnt && room && dbg != 4) {
                         const uint32_t s1 = c ? hist[2 * c - 1] : 0u, e1 = hist[2 * c];
                         PairCtx pc{&L, rec, order + s1, order + e1, kk1[c], kk2[c], bl0, bl1, unm_ins_penalty, L.is_paired != 0};
                         PairAlnDev* out = R.pa + pa_base + my_off;
@@ -515,9 +517,11 @@ void launch_score_reads(lcty_reads* reads) {
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
     const uint32_t per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, lds_max / lds)));
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(reads->n_pairs, static_cast<uint64_t>(cus) * per_cu));
+    const char* dbg_env = getenv("LCTY_DBG");      // developer ablation switch; 0 / unset = the real kernel
+    const uint32_t dbg = dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u;
     reads->d_pa_count.zero(ctx->stream);
     ctx->timed(LCTY_K_SCORE, [&] {
-        hipLaunchKernelGGL(score_reads_kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs);
+        hipLaunchKernelGGL(score_reads_kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs, dbg);
     });
     LCTY_HIP(hipGetLastError());
 }

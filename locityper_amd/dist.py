@@ -1,0 +1,85 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed launcher / env contract).
+
+The path shards at two levels:
+  * loci are independent (command/genotype.rs:1331-1351): round-robin over ranks, no collective;
+  * inside one locus reads contribute additively to run_filter scores (solvers/solve.rs:105-119):
+    read shards -> one SUM all-reduce of the G-long f64 score vector.
+torch.distributed is plumbing only (rendezvous, barrier, small host-staged reductions); it is
+imported lazily and only when WORLD_SIZE > 1, after liblocityper_hip.so has been loaded.
+"""
+import os
+
+import numpy as np
+
+_pg = None
+
+
+def env():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend="gloo"):
+    """Initialises the process group when WORLD_SIZE > 1. Returns (rank, local_rank, world)."""
+    global _pg
+    rank, local_rank, world = env()
+    if world > 1 and _pg is None:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        _pg = dist
+    return rank, local_rank, world
+
+
+def finalize():
+    global _pg
+    if _pg is not None:
+        _pg.destroy_process_group()
+        _pg = None
+
+
+def loci_for_rank(n_loci, rank, world):
+    """Round-robin locus assignment: locus l -> rank l % world."""
+    return list(range(rank, n_loci, world))
+
+
+def read_shard(n_pairs, rank, world):
+    """Contiguous read shard [lo, hi) of rank `rank`."""
+    per = (n_pairs + world - 1) // world
+    lo = min(rank * per, n_pairs)
+    return lo, min(lo + per, n_pairs)
+
+
+def barrier():
+    if _pg is not None:
+        _pg.barrier()
+
+
+def max_over_ranks(x):
+    if _pg is None:
+        return float(x)
+    import torch
+    t = torch.tensor([float(x)], dtype=torch.float64)
+    _pg.all_reduce(t, op=_pg.ReduceOp.MAX)
+    return float(t[0])
+
+
+def allreduce_sum_f64(arr):
+    """SUM all-reduce of a small f64 vector (partial run_filter scores of read shards)."""
+    arr = np.ascontiguousarray(arr, dtype=np.float64)
+    if _pg is None:
+        return arr
+    import torch
+    t = torch.from_numpy(arr.copy())
+    _pg.all_reduce(t, op=_pg.ReduceOp.SUM)
+    return t.numpy()
+
+
+def gather_objects(obj):
+    """List of every rank's `obj` on rank 0 (None elsewhere)."""
+    if _pg is None:
+        return [obj]
+    rank, _, world = env()
+    out = [None] * world if rank == 0 else None
+    _pg.gather_object(obj, out, dst=0)
+    return out

@@ -1,0 +1,322 @@
+"""Parity of the HIP path (through the C ABI) against the oracle. All tests need an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from locityper_amd import _lib, api, cdefs, synth
+from locityper_amd.cdefs import ReadsChunk
+from tests import oracle_ffi as O
+from tests.helpers import make_bg, random_alleles, locus_arrays, compare_gpu_to_oracle
+
+pytestmark = pytest.mark.gpu
+
+SEC, REV, M2 = cdefs.FLAG_SECONDARY, cdefs.FLAG_REVERSE, cdefs.FLAG_MATE2
+
+
+def both_loci(ctx, L, **prm):
+    p = api.default_params()
+    for k, v in prm.items():
+        setattr(p, k, v)
+    api.resolve_params(p, L.bg)
+    loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    return loc, ol, p
+
+
+def check_prefilter(aa, Mo, n_alleles, p):
+    gts = O.generate_genotypes(n_alleles, 2)
+    sc = aa.run_filter()
+    so = O.run_filter(Mo, gts)
+    assert np.abs(sc - so).max() <= 1e-9 * max(np.abs(so).max(), 1.0)       # 1e-9 relative on sums
+    assert int(np.argmax(sc)) == int(np.argmax(so))
+    for min_size in (1, 50, 5000):
+        k1 = api.truncate_ixs(sc, np.arange(len(sc)), p.filt_diff, min_size, p.threads)
+        k2 = O.truncate(so, np.arange(len(so)), p.filt_diff, min_size, p.threads)
+        assert set(k1.tolist()) == set(k2.tolist())
+    return sc, so, gts
+
+
+# ------------------------------------------------------------------ locus products
+@pytest.mark.parametrize("n_alleles,tech,rl", [(8, cdefs.TECH_ILLUMINA, 150), (20, cdefs.TECH_NANOPORE, 3000)])
+def test_locus_products(gpu_ctx, n_alleles, tech, rl):
+    L = synth.SynthLocus(n_alleles, 10_000, technology=tech, read_len=rl)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    assert loc.n_unique_kmers() == ol.n_unique_kmers()                       # bit-exact (K1)
+    for a in range(0, n_alleles, 3):
+        for x, y in zip(loc.contig_info(a), ol.contig_info(a)):              # K3: integers, bit-exact
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    g, ps = C.c_uint32(), C.c_uint32()
+    for rl_ in (50, 150, 151, 1000, 2500):
+        O.lib().orc_edit_thresholds(C.byref(L.bg), rl_, C.byref(g), C.byref(ps))
+        assert loc.edit_thresholds(rl_) == (g.value, ps.value)
+    if L.bg.is_paired:
+        sizes = np.array([0, 1, 150, 449, 450, 451, 900, 5000, 70000], dtype=np.uint32)
+        got, pen = loc.insert_lnprob(sizes)
+        want = np.array([ol.insert_lnprob(s) for s in sizes])
+        assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max() and abs(pen - ol.insert_penalty()) < 1e-10
+    lut = loc.depth_lut()
+    for gc in (0, 37, 100):
+        for d in (0, 1, 17, 255):
+            assert abs(lut[gc, d] - O.lib().orc_depth_ln_pmf(C.byref(L.bg), C.byref(p), gc, d)) <= 1e-9 * max(1.0, abs(lut[gc, d]))
+
+
+def test_undef_kmer_quirk(gpu_ctx):
+    """An allele window with N and off-target count 0 puts UNDEF into the unique set; read windows
+    with N then count as hits (kmers.rs:184-190 + locs.rs:946-947, 984)."""
+    alleles = random_alleles(2, 1500, seed=9)
+    alleles[1] = alleles[1][:700] + b"N" + alleles[1][701:]
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    assert loc.n_unique_kmers() == ol.n_unique_kmers()
+    s1 = alleles[0][300:450].decode()
+    s1n = s1[:60] + "N" + s1[61:]
+    s2 = alleles[0][620:770].decode()
+    ch = ReadsChunk.from_pairs([{"seq1": s1n, "seq2": s2, "recs": [(0, 300, 0, "150="), (0, 620, M2 | REV, "150=")]}])
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    compare_gpu_to_oracle(aa, oa)
+    assert oa.uniq_kmers[0] == 6        # the N windows are "hits"
+
+
+# ------------------------------------------------------------------ scoring + prefilter on the synthetic configs
+def test_config1_full(gpu_ctx):
+    """BASELINE configs[0]: 10k PE pairs x 8 alleles (the reference's own CPU-runnable case), complete."""
+    cfg = synth.CONFIGS[1]
+    L = synth.SynthLocus(cfg["n_alleles"], cfg["n_pairs"])
+    loc, ol, p = both_loci(gpu_ctx, L)
+    ch = L.reads(0, cfg["n_pairs"])
+    aa = api.AllAlignments.load(loc, ch)
+    oa = ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    sc, so, gts = check_prefilter(aa, Mo, 8, p)
+    assert tuple(gts[int(np.argmax(sc))]) == L.true_genotype
+    assert aa.n_good() == oa.n_good > 8000
+
+
+@pytest.mark.parametrize("n_alleles,n_pairs", [(256, 2048), (20, 700), (130, 300), (300, 200)])
+def test_config2_shape_sample(gpu_ctx, n_alleles, n_pairs):
+    """configs[1] shape (256 alleles, k=25, 150 bp PE) on a sample the oracle finishes in seconds,
+    plus allele counts that are not multiples of the kernel tiles (8 / 64 / 128)."""
+    L = synth.SynthLocus(n_alleles, 1_000_000)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    ch = L.reads(5000, n_pairs)
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    check_prefilter(aa, Mo, n_alleles, p)
+
+
+def test_config3_ont_single_end(gpu_ctx):
+    """configs[2] shape: single-end long reads (p-value edit thresholds, window 5000-like, SE grouping)."""
+    L = synth.SynthLocus(16, 3000, technology=cdefs.TECH_NANOPORE, read_len=10_000, base_len=60_000)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    ch = L.reads(0, 160)
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    check_prefilter(aa, Mo, 16, p)
+    assert oa.n_good > 100
+
+
+def test_chunked_append_equals_single_upload(gpu_ctx):
+    L = synth.SynthLocus(12, 10_000)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    ch = L.reads(0, 900)
+    a1 = api.AllAlignments.load(loc, ch)
+    a2 = api.AllAlignments.load(loc, [ch.slice(0, 1), ch.slice(1, 400), ch.slice(400, 900)])
+    for x, y in zip(a1.status(), a2.status()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a1.best_aln_matrix(), a2.best_aln_matrix())
+    o1, p1 = a1.pair_alns()
+    o2, p2 = a2.pair_alns()
+    assert np.array_equal(o1, o2) and np.array_equal(p1, p2)
+    assert np.array_equal(a1.run_filter(), a2.run_filter())      # fixed reduction order -> bitwise reproducible
+
+
+# ------------------------------------------------------------------ hand-written edge cases
+def edge_pairs(alleles):
+    a0 = alleles[0]
+    s1, s2 = a0[300:450].decode(), a0[620:770].decode()
+    return [
+        {"seq1": s1, "seq2": s2, "recs": [(0, 0, cdefs.FLAG_UNMAPPED, ""), (0, 620, M2 | REV, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "150="), (0, 0, M2 | cdefs.FLAG_UNMAPPED, "")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "100=12X38="), (1, 300, SEC, "150="), (0, 620, M2 | REV, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "100=6X44="), (0, 620, M2 | REV, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "100=3X47="), (1, 300, SEC, "150="), (2, 302, SEC, "2H148="),
+                                          (0, 620, M2 | REV, "147=3S"), (1, 620, M2 | REV | SEC, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "149=1X"), (0, 301, SEC, "150="), (0, 303, SEC, "150="),
+                                          (0, 390, SEC, "148=2X"),
+                                          (0, 620, M2 | REV, "150="), (0, 621, M2 | REV | SEC, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "150="), (0, 620, M2, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 1, 0, "2S73=1I30=1D44="), (0, 620, M2 | REV, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 0, 0, "150="), (0, 10, M2 | REV, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "150=")] +
+            [(1, 128 * i + 3, SEC | (REV if i % 3 == 0 else 0), "149=1X" if i % 2 else "150=") for i in range(1, 15)] +
+            [(0, 620, M2 | REV, "150=")]},
+        # many alignments of both ends on one contig: 10 x 10 pairing, kept list capped at 10
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "150=")] +
+            [(2, 128 * i + 3, SEC, "150=") for i in range(1, 13)] + [(0, 620, M2 | REV, "150=")] +
+            [(2, 128 * i + 300, M2 | REV | SEC, "149=1X" if i % 4 == 0 else "150=") for i in range(1, 13)]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 300, 0, "150="), (1, 300, SEC, ""), (0, 620, M2 | REV, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 210, 0, "150="), (0, 1040, M2 | REV, "150=")]},
+        {"seq1": s1, "seq2": s2, "recs": [(0, 210, 0, "150="), (0, 2300, M2 | REV, "150=")]},
+        {"seq1": s1[:40] + "N" + s1[41:], "seq2": s2, "recs": [(0, 300, 0, "150="), (0, 620, M2 | REV, "150=")]},
+        # different read lengths, shorter than k, exactly k
+        {"seq1": s1[:24], "seq2": s2[:25], "recs": [(0, 300, 0, "24="), (0, 620, M2 | REV, "25=")]},
+        {"seq1": s1 + s1[:83], "seq2": s2, "recs": [(0, 300, 0, "233="), (0, 620, M2 | REV, "150=")]},
+    ]
+
+
+def test_edge_cases(gpu_ctx):
+    alleles = random_alleles(3, 2600, seed=11)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ch = ReadsChunk.from_pairs(edge_pairs(alleles))
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    assert set(oa.status.tolist()) == {cdefs.READ_GOOD, cdefs.READ_POORLY_MAPPED, cdefs.READ_OUT_OF_BOUNDS}
+    check_prefilter(aa, Mo, 3, p)
+    # generic prefilter: ploidy 1 and 3, explicit genotype list with priors
+    for ploidy in (1, 3):
+        g = O.generate_genotypes(3, ploidy)
+        assert np.abs(aa.run_filter(ploidy=ploidy) - O.run_filter(Mo, g)).max() < 1e-9
+    g2 = O.generate_genotypes(3, 2)[::2]
+    pri = -np.arange(len(g2), dtype=np.float64)
+    assert np.abs(aa.run_filter(g2, pri) - O.run_filter(Mo, g2, pri)).max() < 1e-9
+
+
+def test_few_kmers_reads_and_strict_subset(gpu_ctx):
+    """Reads with few locus-unique k-mers go to unused_reads (MAX_UNUSED_ALNS = 2, locs.rs:1268-1285)."""
+    alleles = random_alleles(3, 2600, seed=11)
+    bg = make_bg()
+    counts = [np.full(len(a) + 1 - 25, 7, dtype=np.uint16) for a in alleles]      # nothing is locus-unique ...
+    for c in counts:
+        c[1000:1003] = 0                                                        # ... except a few k-mers
+    for strict in (0, 1):
+        p = api.default_params()
+        p.strict_subset = strict
+        api.resolve_params(p, bg)
+        seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25, counts)
+        loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+        ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+        pairs = edge_pairs(alleles)
+        a0 = alleles[0]
+        pairs.append({"seq1": a0[900:1050].decode(), "seq2": a0[1200:1350].decode(),
+                      "recs": [(0, 900, 0, "150="), (0, 1200, M2 | REV, "150=")]})
+        pairs.append({"seq1": a0[900:1050].decode(), "seq2": a0[1200:1350].decode(),
+                      "recs": [(0, 900, 0, "144=6X"), (0, 1200, M2 | REV, "150=")]})
+        ch = ReadsChunk.from_pairs(pairs)
+        aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+        compare_gpu_to_oracle(aa, oa)
+        assert cdefs.READ_FEW_KMERS in oa.status.tolist()
+
+
+def test_single_end_illumina(gpu_ctx):
+    alleles = random_alleles(4, 2000, seed=3)
+    bg = make_bg(paired=False)
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    s = alleles[2][400:550].decode()
+    pairs = [{"seq1": s, "seq2": None, "recs": [(2, 400, 0, "150="), (0, 400, SEC, "149=1X"), (1, 400, SEC | REV, "148=2X"),
+                                                (2, 900, SEC, "147=3X"), (2, 1100, SEC, "120=30X")]},
+             {"seq1": s, "seq2": None, "recs": [(2, 400, cdefs.FLAG_UNMAPPED, "")]},
+             {"seq1": s, "seq2": None, "recs": [(3, 500, REV, "10S140=")]}]
+    ch = ReadsChunk.from_pairs(pairs)
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    assert oa.status.tolist()[0] == cdefs.READ_GOOD
+
+
+def test_invalid_inputs_fail_loudly(gpu_ctx):
+    alleles = random_alleles(3, 1200, seed=11)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    s = alleles[0][300:450].decode()
+    bad = [
+        [(0, 300, 0, "150M"), (0, 620, M2 | REV, "150=")],
+        [(0, 300, 0, "3H147="), (0, 620, M2 | REV, "150=")],
+        [(0, 300, 0, "150=")],
+        [(7, 300, 0, "150="), (0, 620, M2 | REV, "150=")],
+        [],
+        [(0, 300, 0, "150="), (0, 620, M2 | REV, "100=3N50=")],
+    ]
+    for recs in bad:
+        ch = ReadsChunk.from_pairs([{"seq1": s, "seq2": s, "recs": recs}])
+        aa = api.AllAlignments.load(loc, ch)
+        with pytest.raises(_lib.LocityperError) as e:
+            aa.status()
+        assert e.value.code == cdefs.ERR_INVALID_DATA
+    # defects in records the reference never examines are harmless
+    ch = ReadsChunk.from_pairs([{"seq1": s, "seq2": s, "recs": [(0, 0, cdefs.FLAG_UNMAPPED, ""), (0, 620, M2 | REV, "150M")]}])
+    assert api.AllAlignments.load(loc, ch).status()[0].tolist() == [cdefs.READ_POORLY_MAPPED]
+    # API misuse
+    aa = api.AllAlignments(loc, 4, 32 * 8, 16, 64)
+    with pytest.raises(_lib.LocityperError):
+        aa.status()                                   # not scored yet
+    with pytest.raises(_lib.LocityperError) as e:
+        api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 40, bg, p)      # k > 31: loud UNSUPPORTED, counts mismatch first
+    assert e.value.code in (cdefs.ERR_UNSUPPORTED, cdefs.ERR_INVALID_DATA)
+
+
+def test_empty_batch(gpu_ctx):
+    L = synth.SynthLocus(4, 100)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    aa = api.AllAlignments.load(loc, ReadsChunk.from_pairs([]))
+    assert aa.n_pairs == 0 and aa.n_good() == 0
+    assert aa.best_aln_matrix().shape == (4, 0)
+    assert np.array_equal(aa.run_filter(), np.zeros(10))
+
+
+# ------------------------------------------------------------------ full BASELINE size: size-independent properties
+def test_full_size_properties(gpu_ctx):
+    """configs[1] at full size (1M pairs x 256 alleles): linearity of run_filter over read shards,
+    run-to-run determinism, zero rows for unused pairs, the called genotype, sortedness of the kept list."""
+    n, A, chunk = 1_000_000, 256, 32768
+    L = synth.SynthLocus(A, n)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    lo = 0
+    c0 = L.reads(0, chunk)
+    est = lambda x: int(x / c0.n_pairs * n * 1.03) + 70000
+    caps = (n, est(c0.n_bases) // 32 * 32 + 32, est(len(c0.recs)), est(len(c0.cigar)))
+    full, half_a, half_b = (api.AllAlignments(loc, *caps) for _ in range(3))      # 288 GB of HBM: capacity is not the issue
+    sample = None
+    while lo < n:
+        ch = c0 if lo == 0 else L.reads(lo, min(chunk, n - lo))
+        full.append(ch)
+        (half_a if lo < n // 2 else half_b).append(ch)
+        if lo == 16 * chunk:
+            sample = (lo, ch)
+        lo += ch.n_pairs
+    for x in (full, half_a, half_b):
+        x.score()
+    st, w, unm, uk = full.status()
+    sc_full = full.run_filter()
+    sc_sum = half_a.run_filter() + half_b.run_filter()
+    assert np.abs(sc_full - sc_sum).max() <= 1e-11 * np.abs(sc_full).max()           # linearity over read shards
+    sa, sb = half_a.status()[0], half_b.status()[0]
+    assert np.array_equal(st, np.concatenate([sa, sb]))
+    # determinism: a second scoring + prefilter pass is bitwise identical
+    full.score()
+    st2, w2, unm2, uk2 = full.status()
+    assert np.array_equal(st, st2) and np.array_equal(w, w2) and np.array_equal(uk, uk2)
+    assert np.array_equal(full.run_filter(), sc_full)
+    # the oracle agrees on a 32k-pair window from the middle of the batch
+    lo_s, ch_s = sample
+    oa = ol.load(ch_s)
+    assert np.array_equal(st[lo_s:lo_s + ch_s.n_pairs], oa.status)
+    assert np.array_equal(uk[2 * lo_s:2 * (lo_s + ch_s.n_pairs)], oa.uniq_kmers)
+    assert np.allclose(w[lo_s:lo_s + ch_s.n_pairs], oa.weight, rtol=0, atol=1e-12)
+    # genotype call and kept list
+    gts = api.generate_genotypes(A, 2)
+    assert tuple(gts[int(np.argmax(sc_full))]) == L.true_genotype
+    keep = api.truncate_ixs(sc_full, np.arange(len(sc_full)), p.filt_diff, 5000, p.threads)
+    assert len(keep) >= 5000 and np.all(np.diff(sc_full[keep]) <= 0)
+    assert 0.85 * n < (st == cdefs.READ_GOOD).sum() <= n

@@ -1,0 +1,84 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header declares,
+host-only entry points agree with the oracle, and compute entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from locityper_amd import _lib, api, cdefs
+from tests import oracle_ffi as O
+from tests.helpers import make_bg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "locityper_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lcty_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/locityper_hip.h but not exported"
+    assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
+    assert b"gfx950" in L.lcty_version()
+
+
+def test_struct_layouts_match_header():
+    # sizes implied by the C declarations (natural alignment)
+    assert C.sizeof(cdefs.AlnRec) == 16 and C.sizeof(cdefs.PairAln) == 32
+    assert C.sizeof(cdefs.Bg) == 8 * (5 + 2 + 2 + 2 * cdefs.GC_BINS + 2) + 4 * 6
+    assert C.sizeof(cdefs.Params) == 8 + 12 * 8 + 15 * 8 + 4 + 2 + 2 + 4 + 4
+
+
+def test_params_default_and_resolve_match_oracle():
+    p, q = api.default_params(), O.default_params()
+    assert bytes(p) == bytes(q) or all(
+        (getattr(p, f) == getattr(q, f)) or (getattr(p, f) != getattr(p, f) and getattr(q, f) != getattr(q, f))
+        for f, _ in cdefs.Params._fields_ if f not in ("alt_cn", "_pad0"))
+    for tech in (cdefs.TECH_ILLUMINA, cdefs.TECH_NANOPORE):
+        bg = make_bg(technology=tech, window=100 if tech == 0 else 3333)
+        p, q = api.resolve_params(api.default_params(), bg), O.resolve_params(O.default_params(), bg)
+        assert (p.tweak, p.unmapped_penalty, p.prob_diff) == (q.tweak, q.unmapped_penalty, q.prob_diff)
+    bad = api.default_params()
+    bad.tweak = 300
+    with pytest.raises(_lib.LocityperError) as e:
+        api.resolve_params(bad, make_bg())
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
+
+
+def test_genotypes_and_truncate_match_oracle():
+    for n, pl in [(1, 2), (5, 1), (7, 2), (4, 3), (3, 4), (256, 2)]:
+        assert np.array_equal(api.generate_genotypes(n, pl), O.generate_genotypes(n, pl))
+        assert api.count_genotypes(n, pl) == len(O.generate_genotypes(n, pl))
+    rng = np.random.default_rng(1)
+    for _ in range(30):
+        n = int(rng.integers(1, 400))
+        s = np.round(rng.normal(-5000, 300, n), 0)       # rounding creates ties
+        fd, ms, th = float(rng.integers(1, 900)), int(rng.integers(1, 450)), int(rng.integers(1, 16))
+        a = api.truncate_ixs(s, np.arange(n), fd, ms, th)
+        b = O.truncate(s, np.arange(n), fd, ms, th)
+        assert np.array_equal(a, b)
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.LocityperError) as e:
+        api.Context(0)
+    assert e.value.code == cdefs.ERR_RUNTIME and "no CPU fallback" in str(e.value)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "locityper_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".c")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_ffi" not in txt and "lcty_oracle" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)
