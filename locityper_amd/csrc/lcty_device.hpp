@@ -59,6 +59,7 @@ struct ReadsView {
     const lcty_aln_rec* recs;
     const uint64_t* cigar_off;
     const uint32_t* cigar;
+    const uint2* pair_meta;         // per pair {index of the mate-2 primary (or n), number of records to look at}
     // products of AllAlignments::load
     uint8_t* status;
     double* weight;

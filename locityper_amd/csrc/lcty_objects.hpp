@@ -58,6 +58,7 @@ struct lcty_reads {
     uint64_t cap_pairs = 0, cap_bases = 0, cap_recs = 0, cap_cigar = 0;
     uint64_t n_pairs = 0, n_bases = 0, n_recs = 0, n_cigar = 0;
     uint32_t max_recs_per_pair = 0;
+    uint32_t max_cigar_per_pair = 0;
     bool scored = false;
 
     lcty::DevBuf<uint32_t> d_mate_len;
@@ -67,6 +68,7 @@ struct lcty_reads {
     lcty::DevBuf<lcty_aln_rec> d_recs;
     lcty::DevBuf<uint64_t> d_cigar_off;
     lcty::DevBuf<uint32_t> d_cigar;
+    lcty::DevBuf<uint2> d_pair_meta;
 
     lcty::DevBuf<uint8_t> d_status;
     lcty::DevBuf<double> d_weight, d_unmapped;

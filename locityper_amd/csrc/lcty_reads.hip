@@ -55,6 +55,7 @@ ReadsView lcty_reads::view() const {
     v.n_pairs = n_pairs;
     v.mate_len = d_mate_len.p; v.mate_off = d_mate_off.p; v.bases2 = d_bases2.p; v.nmask = d_nmask.p;
     v.aln_off = d_aln_off.p; v.recs = d_recs.p; v.cigar_off = d_cigar_off.p; v.cigar = d_cigar.p;
+    v.pair_meta = d_pair_meta.p;
     v.status = d_status.p; v.weight = d_weight.p; v.unmapped_prob = d_unmapped.p; v.uniq_kmers = d_uniq.p;
     v.matrix = d_matrix.p;
     v.pa = d_pa.p; v.pa_cap = d_pa.n; v.pa_count = d_pa_count.p; v.pa_off = d_pa_off.p; v.pa_cnt = d_pa_cnt.p;
@@ -93,7 +94,8 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
         R->d_aln_off.alloc(cap_pairs + 1);
         R->d_recs.alloc(std::max<uint64_t>(cap_recs, 1));
         R->d_cigar_off.alloc(cap_pairs + 1);
-        R->d_cigar.alloc(std::max<uint64_t>(cap_cigar, 1));
+        R->d_cigar.alloc(cap_cigar + 16);            // +16: the CIGAR loader reads 8 words per record unconditionally
+        R->d_pair_meta.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_status.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_weight.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_unmapped.alloc(std::max<uint64_t>(cap_pairs, 1));
@@ -137,10 +139,13 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
             fail(LCTY_ERR_INVALID_INPUT, "chunk exceeds the capacity given to lcty_reads_create");
         // host-side validation of the CSR structure (cheap, O(pairs + records))
         uint32_t max_recs = R->max_recs_per_pair;
+        uint64_t max_cig = R->max_cigar_per_pair;
         for (uint64_t m = 0; m < 2 * n; m++) {
             if (h->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
             if (h->mate_off[m + 1] < h->mate_off[m] + h->mate_len[m]) fail(LCTY_ERR_INVALID_INPUT, "mate offsets overlap");
         }
+        std::vector<uint2> meta(n);
+        const bool paired = R->locus->bg.is_paired != 0;
         for (uint64_t r = 0; r < n; r++) {
             if (h->aln_off[r + 1] < h->aln_off[r] || h->cigar_off[r + 1] < h->cigar_off[r])
                 fail(LCTY_ERR_INVALID_INPUT, "record / CIGAR offsets must be non-decreasing");
@@ -148,9 +153,19 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
             if (cnt > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many records in one read pair");
             max_recs = std::max<uint32_t>(max_recs, static_cast<uint32_t>(cnt));
             const uint64_t cw = h->cigar_off[r + 1] - h->cigar_off[r];
-            for (uint64_t i = h->aln_off[r]; i < h->aln_off[r + 1]; i++)
+            max_cig = std::max(max_cig, cw);
+            // record groups (locs.rs:1119-1131): the second primary starts read end 2, a third one would start
+            // the next read pair
+            uint32_t j2 = static_cast<uint32_t>(cnt), j3 = static_cast<uint32_t>(cnt);
+            for (uint64_t i = h->aln_off[r]; i < h->aln_off[r + 1]; i++) {
                 if (static_cast<uint64_t>(h->recs[i].cigar_rel) + h->recs[i].n_cigar > cw)
                     fail(LCTY_ERR_INVALID_INPUT, "CIGAR of record %llu leaves its pair's CIGAR range", (unsigned long long)i);
+                const uint32_t idx = static_cast<uint32_t>(i - h->aln_off[r]);
+                if (idx > 0 && (h->recs[i].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0) {
+                    if (j2 == cnt) j2 = idx; else if (j3 == cnt) j3 = idx;
+                }
+            }
+            meta[r] = make_uint2(j2, paired ? j3 : j2);
         }
         R->locus->ensure_edit_thresholds(h->mate_len, 2 * n);
 
@@ -167,9 +182,11 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         R->d_mate_off.upload(mo.data(), 2 * n, s, 2 * R->n_pairs + 1);
         R->d_aln_off.upload(ao.data(), n, s, R->n_pairs + 1);
         R->d_cigar_off.upload(co.data(), n, s, R->n_pairs + 1);
+        R->d_pair_meta.upload(meta.data(), n, s, R->n_pairs);
         LCTY_HIP(hipStreamSynchronize(s));
         R->n_pairs += n; R->n_bases += nb; R->n_recs += nr; R->n_cigar += nc;
         R->max_recs_per_pair = max_recs;
+        R->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
         R->scored = false;
     });
 }

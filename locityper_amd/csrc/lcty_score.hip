@@ -1,35 +1,47 @@
 // lcty_score.hip — AllAlignments::load (src/model/locs.rs:1085-1185, 1237-1288, no alignment
 // recovery) as ONE fused gfx950 kernel: one 64-lane wavefront per read pair.
 //
-//   pass 1  lanes over BAM records: CIGAR -> op counts -> ErrorProfile::ln_prob, edit distance
-//           (aln.rs:301-317, err_prof.rs:73-79, 212-221); results parked in LDS (24 B / record)
-//   thresholds  lanes 0/1: EditDistCache + poor-complexity relaxation (locs.rs:529-536)
-//   pass 2  per-end best edit / best ln-prob (wave reductions), saved flag (locs.rs:310-314)
-//   K2      unique k-mers of both mates from the 2-bit stream: wave-parallel hash probes,
-//           ballot, greedy non-overlap walk over the hit mask (locs.rs:968-1002)
-//   sort    LDS counting sort of the saved records by (contig, read end)
-//   pass 3a lane per contig: (ln_prob desc) order, 128-bp dedupe (locs.rs:321-342), in_bounds
-//           (1008-1014), pair enumeration -> best + kept count (746-799) -> matrix row (1203-1212)
-//   pass 3b selection-emit of the kept PairAlignments, contig-ascending, into the arena
+// Each phase is organised as wide, independent memory operations (a naive lane-chases-its-records
+// version is bound by serial global-memory latency):
+//
+//   prologue   both mates' 2-bit words are prefetched into registers (one 64-bit word per lane);
+//              lanes 0/1 score the two primaries and derive the edit thresholds
+//              (EditDistCache + poor-complexity relaxation, locs.rs:529-536). The index of the
+//              mate-2 primary comes from the host (pair_meta), so thresholds are known first.
+//   pass 1     lanes over BAM records in groups of 4x64: 4 record loads, then 4x2 unaligned
+//              dwordx4 CIGAR loads in flight, branch-light op counting (aln.rs:301-317),
+//              ErrorProfile::ln_prob (err_prof.rs:212-221), per-end best edit / ln-prob in
+//              registers. Saved alignments (locs.rs:310-314) go to LDS (16 B each) and are
+//              chained per (contig, read end) with one LDS exchange (no sort, no scan).
+//   K2         unique k-mers (locs.rs:968-1002): windows extracted with cross-lane reads from the
+//              prefetched words, hash probes issued 4 at a time, ballot + greedy ctz walk.
+//   pass 3a    lane per contig. 1x1 groups (the common case) are paired entirely in registers;
+//              anything else takes the general path: (ln_prob desc) order, 128-bp dedupe
+//              (locs.rs:321-342), top-10, full pair enumeration (746-799). Writes the matrix row
+//              (locs.rs:1203-1212) and the per-contig kept count; in_bounds (1008-1014).
+//   pass 3b    PairAlignments emitted contig-ascending into the arena (one atomicAdd per pair).
 //
 // Launch: 64-thread workgroups (one wave), grid-strided over pairs; dynamic LDS sized from the
 // largest record count of any pair in the batch. All LDS traffic is wave-private.
+// (Staging a pair's records + CIGAR words through LDS with all loads in flight was measured: slower —
+//  pass 1 is instruction-issue bound, not latency bound, once the loads are grouped.)
 #include "lcty_objects.hpp"
 
 namespace lcty {
 
-struct RecLds {
-    double ln_prob;
-    uint32_t start, end, edit;
-    uint16_t contig, flags;
-};
-static_assert(sizeof(RecLds) == 24, "RecLds layout");
-
-enum : uint16_t {
-    RF_REVERSE = 1, RF_SAVED = 4, RF_SKIP = 8, RF_UNMAPPED = 16, RF_BAD = 32, RF_PRIMARY = 64,
-};
-
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr uint32_t NONE16 = 0xFFFFu;
+constexpr uint32_t REV_BIT = 0x80000000u;
+constexpr int GR = 4;                         // 64-record chunks whose loads are kept in flight together
+
+// saved alignment in LDS: ln_prob (not yet normalised), start, end | strand<<31
+struct __attribute__((aligned(16))) Rec16 {
+    double ln_prob;
+    uint32_t start, end_rev;
+};
+static_assert(sizeof(Rec16) == 16, "Rec16 layout");
+
+struct __attribute__((packed, aligned(4))) W8 { uint32_t w[8]; };
 
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
     for (int o = WAVE / 2; o > 0; o >>= 1) v = min(v, static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), o)));
@@ -54,86 +66,227 @@ __device__ inline uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t* to
     return x - v;
 }
 
-// InsertDistr::ln_prob -> LinearCache::ln_pmf (insertsz.rs:153-155, lincache.rs:41-48)
 // cold path: insert sizes beyond the cached range are evaluated directly (nbinom.rs:128-131)
 __device__ __noinline__ double nbinom_ln_pmf_direct(double n, double lnq, double lnpmf_const, uint32_t sz) {
     const double x = static_cast<double>(sz);
     return lnpmf_const + lgamma(n + x) - lgamma(x + 1.0) + x * lnq;
 }
-__device__ inline double insert_lnprob(const LocusView& L, uint32_t sz) {
-    if (sz < L.ins_lut_size) return L.ins_lut[sz];
-    return nbinom_ln_pmf_direct(L.ins_n, L.ins_lnq, L.ins_lnpmf_const, sz);
+// InsertDistr::ln_prob -> LinearCache::ln_pmf (insertsz.rs:153-155, lincache.rs:41-48).
+// Held by value: the kernel-argument structs must never be addressed (that would spill them to scratch).
+struct InsLut {
+    const double* lut;
+    uint32_t size;
+    double n, lnq, lnpmf_const;
+    __device__ __forceinline__ double ln_prob(uint32_t sz) const {
+        if (sz < size) return lut[sz];
+        return nbinom_ln_pmf_direct(n, lnq, lnpmf_const, sz);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// CIGAR -> operation counts (count_region_operations_fast, aln.rs:301-317; soft_clipping,
+// cigar.rs:519-527; hard_to_soft, cigar.rs:309-320).
+// ---------------------------------------------------------------------------------------------
+struct OpCounts {
+    uint32_t matches, mism, ins, del, left, right;
+    bool bad;
+};
+
+// One CIGAR word. Clipping is handled by the caller from the first / last word, so here S and H only
+// have to be accepted (H: first / last word only; anywhere else it panics like any unsupported op, aln.rs:311).
+__device__ __forceinline__ void count_op(OpCounts& c, uint32_t w, bool edge) {
+    const uint32_t op = w & 15u;
+    const uint32_t len = w >> 4;
+    c.matches += op == LCTY_CIGAR_EQ ? len : 0u;
+    c.mism += op == LCTY_CIGAR_X ? len : 0u;
+    c.del += op == LCTY_CIGAR_D ? len : 0u;
+    c.ins += op == LCTY_CIGAR_I ? len : 0u;
+    const uint32_t valid = edge ? 0x1B6u : 0x196u;      // I, D, S, =, X (+ H at the ends, turned into S)
+    c.bad |= ((valid >> op) & 1u) == 0u;
 }
 
-// UniqueKmers::calculate_read_weight for one mate (locs.rs:976-993): count of non-overlapping hits.
-__device__ inline uint32_t mate_unique_kmers(const LocusView& L, const ReadsView& R, uint64_t mate, int lane) {
-    const uint32_t len = R.mate_len[mate];
-    const uint32_t k = L.k;
-    if (len < k) return 0;
-    const uint64_t off = R.mate_off[mate];
-    const uint64_t* w64 = reinterpret_cast<const uint64_t*>(R.bases2) + (off >> 5);
-    const uint32_t* nm = R.nmask + (off >> 5);
-    const uint32_t nk = len + 1 - k;
-    uint32_t count = 0, next_allowed = 0;
-    for (uint32_t base = 0; base < nk; base += WAVE) {
-        const uint32_t q = base + lane;
-        bool hit = false;
-        if (q < nk) {
-            if (window_has_n(nm, q, k)) hit = L.undef_in_set != 0;       // UNDEF k-mer (kmers.rs:184-190)
-            else hit = kset_contains(L.kset, L.kset_mask, canonical_kmer_2bit(w64, q, k));
-        }
-        unsigned long long m = __ballot(hit);
-        // greedy walk: take a hit, then skip the next k-1 k-mers (`kmers_iter.nth(k_2)`, locs.rs:988)
+// first 8 words are already in registers; longer CIGARs continue from memory
+__device__ __forceinline__ OpCounts count_ops(const W8& first, const uint32_t* cig, uint32_t nc, bool primary) {
+    OpCounts c{0, 0, 0, 0, 0, 0, false};
+    uint32_t wl = first.w[0];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++)
+        if (i < nc) { count_op(c, first.w[i], i == 0 || i + 1 == nc); wl = first.w[i]; }
+    for (uint32_t i = 8; i < nc; i++) { wl = cig[i]; count_op(c, wl, i + 1 == nc); }
+    // soft_clipping (cigar.rs:519-527) after hard_to_soft (309-320)
+    const uint32_t w0 = first.w[0];
+    const uint32_t op0 = w0 & 15u, opl = wl & 15u;
+    if (op0 == LCTY_CIGAR_S || op0 == LCTY_CIGAR_H) c.left = w0 >> 4;
+    if (opl == LCTY_CIGAR_S || opl == LCTY_CIGAR_H) c.right = wl >> 4;
+    if (primary && (op0 == LCTY_CIGAR_H || opl == LCTY_CIGAR_H)) c.bad = true;   // assert!(!cigar.has_hard_clipping()), locs.rs:526
+    return c;
+}
+
+struct Scored {
+    double ln_prob;
+    uint32_t start, end, edit;
+    bool bad;
+};
+
+__device__ __forceinline__ Scored score_counts(const LocusView& L, const OpCounts& c, uint32_t pos, uint32_t contig_len) {
+    Scored s;
+    const uint32_t ref_len = c.matches + c.mism + c.del;
+    s.start = pos;
+    s.end = pos + ref_len;
+    const uint32_t clip = min(c.left, pos) + min(c.right, contig_len > s.end ? contig_len - s.end : 0u);   // aln.rs:288-296
+    const uint32_t common = c.mism + c.ins + clip;                                                          // err_prof.rs:73-79
+    s.edit = common + c.del;
+    s.ln_prob = L.lp[0] * static_cast<double>(c.matches) + L.lp[1] * static_cast<double>(c.mism)
+              + L.lp[2] * static_cast<double>(c.ins) + L.lp[3] * static_cast<double>(c.del)
+              + L.lp[4] * static_cast<double>(clip);                                                        // err_prof.rs:212-221
+    s.bad = c.bad;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: unique k-mers (locs.rs:976-993).
+// ---------------------------------------------------------------------------------------------
+struct KmerWalk {
+    uint32_t count, next_allowed;
+    __device__ inline void feed(unsigned long long m, uint32_t base, uint32_t k) {
+        // greedy: take a hit, then skip the next k-1 k-mers (`kmers_iter.nth(k_2)`, locs.rs:988)
         if (next_allowed > base) {
             const uint32_t sh = next_allowed - base;
             m = sh >= 64 ? 0ull : (m >> sh) << sh;
         }
         while (m) {
             const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(m))) - 1u;
-            count = count == 0xFFFFu ? count : count + 1;                 // saturating_add
+            count = count == 0xFFFFu ? count : count + 1;         // saturating_add
             next_allowed = base + b + k;
             const uint32_t sh = b + k;
             m = sh >= 64 ? 0ull : (m >> sh) << sh;
         }
     }
-    return count;
+};
+
+// general path: windows straight from global memory (mates longer than 2016 bases)
+__device__ __noinline__ uint32_t mate_unique_kmers_global(const uint64_t* kset, uint64_t kset_mask, uint32_t undef_in_set, uint32_t k,
+                                                         const uint64_t* w64, const uint32_t* nm, uint32_t len, int lane) {
+    if (len < k) return 0;
+    const uint32_t nk = len + 1 - k;
+    KmerWalk walk{0, 0};
+    for (uint32_t base = 0; base < nk; base += WAVE) {
+        const uint32_t q = base + lane;
+        bool hit = false;
+        if (q < nk) {
+            if (window_has_n(nm, q, k)) hit = undef_in_set != 0;         // UNDEF k-mer (kmers.rs:184-190)
+            else hit = kset_contains(kset, kset_mask, canonical_kmer_2bit(w64, q, k));
+        }
+        walk.feed(__ballot(hit), base, k);
+    }
+    return walk.count;
 }
 
+// canonical k-mer (kmers.rs:192-196) of the window that starts `sh`/2 bases into the 32-base word `lo`
+__device__ __forceinline__ uint64_t canon_from_words(uint64_t lo, uint64_t hi, uint32_t sh, uint32_t k) {
+    uint64_t x = lo >> sh;
+    if (sh) x |= hi << (64u - sh);
+    const uint64_t mask = (1ull << (2u * k)) - 1ull;
+    x &= mask;
+    const uint64_t rv = (~x) & mask;
+    uint64_t y = __brevll(x);
+    y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+    const uint64_t fw = y >> (64u - 2u * k);
+    return rv < fw ? rv : fw;
+}
+
+// Both mates at once from register-resident words (lane l holds 64-bit word l and N-mask word l of each
+// mate). Hash probes of up to 4 (mate, 64-window chunk) items are in flight together.
+__device__ __forceinline__ void pair_unique_kmers_regs(const uint64_t* kset, uint64_t kset_mask, uint32_t undef_in_set, uint32_t k,
+                                                       uint32_t len0, uint32_t len1, uint64_t bw0, uint64_t bw1,
+                                                       uint32_t nm0, uint32_t nm1, int lane, uint32_t* uk0, uint32_t* uk1) {
+    const uint32_t nk0 = len0 >= k ? len0 + 1 - k : 0u, nk1 = len1 >= k ? len1 + 1 - k : 0u;
+    const uint32_t nch0 = (nk0 + WAVE - 1) / WAVE, nch1 = (nk1 + WAVE - 1) / WAVE;
+    const uint32_t items = nch0 + nch1;
+    KmerWalk walk0{0, 0}, walk1{0, 0};
+    const uint32_t half = static_cast<uint32_t>(lane) >> 5;
+    const uint32_t sh2 = (lane & 31u) * 2u, sh1 = lane & 31u;
+    for (uint32_t it0 = 0; it0 < items; it0 += 4) {
+        uint64_t key[4], val[4], slot[4];
+        bool live[4], undef[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t it = it0 + j;
+            const bool m = it >= nch0;                    // wave-uniform
+            const uint32_t t = m ? it - nch0 : it;
+            const uint32_t nk = m ? nk1 : nk0;
+            const uint32_t q = t * WAVE + lane;
+            live[j] = it < items && q < nk;
+            // 128-base span of this chunk = words 2t, 2t+1, 2t+2 (wave-uniform indices)
+            const uint64_t src = m ? bw1 : bw0;
+            const uint32_t nsrc = m ? nm1 : nm0;
+            const int wi = static_cast<int>((2 * t) & 63u);
+            const uint64_t wA = __shfl(src, wi), wB = __shfl(src, (wi + 1) & 63), wC = __shfl(src, (wi + 2) & 63);
+            const uint32_t nA = __shfl(nsrc, wi), nB = __shfl(nsrc, (wi + 1) & 63), nC = __shfl(nsrc, (wi + 2) & 63);
+            key[j] = canon_from_words(half ? wB : wA, half ? wC : wB, sh2, k);
+            uint32_t nbits = (half ? nB : nA) >> sh1;
+            if (sh1 + k > 32u) nbits |= (half ? nC : nB) << (32u - sh1);
+            undef[j] = (nbits & ((1u << k) - 1u)) != 0u;  // window contains a non-ACGT base -> UNDEF (kmers.rs:184-190)
+            slot[j] = mix64(key[j]) & kset_mask;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) val[j] = (live[j] && !undef[j]) ? kset[slot[j]] : KSET_EMPTY;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t it = it0 + j;
+            if (it < items) {                             // wave-uniform
+                bool hit = false;
+                if (live[j]) {
+                    if (undef[j]) hit = undef_in_set != 0;
+                    else {
+                        uint64_t v = val[j], s = slot[j];
+                        while (v != key[j] && v != KSET_EMPTY) { s = (s + 1) & kset_mask; v = kset[s]; }
+                        hit = v == key[j];
+                    }
+                }
+                const unsigned long long mask = __ballot(hit);
+                const bool m = it >= nch0;
+                const uint32_t t = m ? it - nch0 : it;
+                if (m) walk1.feed(mask, t * WAVE, k); else walk0.feed(mask, t * WAVE, k);
+            }
+        }
+    }
+    *uk0 = walk0.count;
+    *uk1 = walk1.count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pairing (identify_contig_pair_alns, locs.rs:746-799 / identify_single_end_alignments 873-911)
+// ---------------------------------------------------------------------------------------------
 struct AlnRef {
     double lp;
     uint32_t start, end, idx;
     bool rev;
 };
 
+__device__ __forceinline__ AlnRef load_aln(const Rec16* rec, uint32_t idx, double best_lik) {
+    const Rec16 r = rec[idx];
+    return AlnRef{r.ln_prob - best_lik, r.start, r.end_rev & ~REV_BIT, idx, (r.end_rev & REV_BIT) != 0};   // normalize_probs, locs.rs:358-360
+}
+
 struct PairCtx {
-    const LocusView* L;
-    const RecLds* rec;
+    InsLut ins;
+    const Rec16* rec;
     const uint16_t* ord1;
     const uint16_t* ord2;
     uint32_t k1, k2;
-    double best0, best1;        // best_lik per end (normalize_probs, locs.rs:358-360)
+    double best0, best1;
     double unm_ins_penalty;
     bool paired;
 
-    __device__ inline AlnRef get1(uint32_t i) const {
-        const uint32_t v = ord1[i];
-        const RecLds& r = rec[v];
-        return AlnRef{r.ln_prob - best0, r.start, r.end, v, (r.flags & RF_REVERSE) != 0};
-    }
-    __device__ inline AlnRef get2(uint32_t j) const {
-        const uint32_t v = ord2[j];
-        const RecLds& r = rec[v];
-        return AlnRef{r.ln_prob - best1, r.start, r.end, v, (r.flags & RF_REVERSE) != 0};
-    }
+    __device__ inline AlnRef get1(uint32_t i) const { return load_aln(rec, ord1[i], best0); }
+    __device__ inline AlnRef get2(uint32_t j) const { return load_aln(rec, ord2[j], best1); }
     __device__ inline double pair_prob(const AlnRef& a1, const AlnRef& a2) const {
         // paired_prob (aln.rs:236-238) with furthest_distance (interv.rs:179-185)
         const uint32_t insert = max(a1.end, a2.end) - min(a1.start, a2.start);
-        return a1.lp + a2.lp + insert_lnprob(*L, insert);
+        return a1.lp + a2.lp + ins.ln_prob(insert);
     }
-
-    // Calls f(prob, order, aln1 or idx NONE32, aln2 or idx NONE32) for every PairAlignment pushed by
-    // identify_contig_pair_alns (locs.rs:762-791) in push order, or — single-end — by
-    // identify_single_end_alignments (locs.rs:890-901).
+    // f(prob, order, aln1 | idx NONE32, aln2 | idx NONE32) for every PairAlignment pushed, in push order
     template <typename F>
     __device__ inline void enumerate(F&& f) const {
         const AlnRef none{0.0, 0, 0, NONE32, false};
@@ -170,10 +323,14 @@ struct PairCtx {
     }
 };
 
-// in-place (ln_prob desc, record index asc) insertion sort + 128-bp-bin dedupe of one (contig, end) group.
-// Returns the number of kept alignments, *inb |= any kept alignment inside the central region.
-__device__ inline uint32_t sort_dedupe(const RecLds* rec, uint16_t* ord, uint32_t n, uint32_t boundary,
-                                       uint32_t contig_len, bool* inb) {
+// General path, one (contig, end) group: copy the chain into `ord`, order by (ln_prob desc, record
+// index asc), drop later members of a 128-bp bin (locs.rs:321-342). Returns the kept count;
+// bit 31: some kept alignment lies in the central region (in_bounds, locs.rs:1008-1014).
+__device__ __noinline__ uint32_t gather_sort_dedupe(const Rec16* rec, const uint16_t* nxt, uint32_t head, uint16_t* ord,
+                                                    uint32_t boundary, uint32_t contig_len) {
+    bool inb = false;
+    uint32_t n = 0;
+    for (uint32_t v = head; v != NONE16; v = nxt[v]) ord[n++] = static_cast<uint16_t>(v);
     for (uint32_t i = 1; i < n; i++) {
         const uint16_t v = ord[i];
         const double lpv = rec[v].ln_prob;
@@ -193,285 +350,407 @@ __device__ inline uint32_t sort_dedupe(const RecLds* rec, uint16_t* ord, uint32_
         for (uint32_t u = 0; u < kept; u++) dup |= (rec[ord[u]].start >> 7) == bin;
         if (!dup) {
             ord[kept++] = v;
-            const uint32_t mid = (rec[v].start + rec[v].end) / 2;
-            if (boundary <= mid && mid < contig_len - boundary) *inb = true;    // in_bounds, locs.rs:1008-1014
+            const uint32_t mid = (rec[v].start + (rec[v].end_rev & ~REV_BIT)) / 2;
+            if (boundary <= mid && mid < contig_len - boundary) inb = true;
         }
     }
-    return kept;
+    return kept | (inb ? 0x80000000u : 0u);
 }
 
-__global__ __launch_bounds__(WAVE) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs, const uint32_t dbg) {
+struct ContigResult {
+    double best;
+    uint32_t cnt;
+};
+
+// general path: best + kept count of one contig
+__device__ __noinline__ ContigResult general_count(const PairCtx pc, uint32_t max_alns, double prob_diff) {
+    double best = -INFINITY;
+    pc.enumerate([&](double prob, uint32_t, const AlnRef&, const AlnRef&) { best = fmax(best, prob); });
+    const double thresh = best - prob_diff;                                  // locs.rs:796
+    uint32_t ge = 0;
+    pc.enumerate([&](double prob, uint32_t, const AlnRef&, const AlnRef&) { ge += prob >= thresh; });
+    return ContigResult{best, min(ge, max_alns)};                            // locs.rs:797
+}
+
+// general path: selection-emit of the kept PairAlignments (decreasing ln_prob, ties in push order, locs.rs:795)
+__device__ __noinline__ void general_emit(const PairCtx pc, uint32_t cnt, double weight, uint32_t contig, PairAlnDev* out) {
+    double prev_prob = INFINITY;
+    uint32_t prev_ord = 0;
+    bool first = true;
+    for (uint32_t e = 0; e < cnt; e++) {
+        double bp = -INFINITY; uint32_t bo = NONE32;
+        AlnRef b1{0.0, 0, 0, NONE32, false}, b2 = b1;
+        pc.enumerate([&](double prob, uint32_t ord, const AlnRef& x1, const AlnRef& x2) {
+            const bool after = first || prob < prev_prob || (prob == prev_prob && ord > prev_ord);
+            if (after && (prob > bp || (prob == bp && ord < bo))) { bp = prob; bo = ord; b1 = x1; b2 = x2; }
+        });
+        PairAlnDev o;
+        o.ln_prob = bp * weight;                                              // locs.rs:861-863
+        o.mid1 = b1.idx == NONE32 ? NONE32 : (b1.start + b1.end) / 2;          // Interval::middle, interv.rs:154-156
+        o.mid2 = b2.idx == NONE32 ? NONE32 : (b2.start + b2.end) / 2;
+        o.contig = static_cast<uint16_t>(contig);
+        o.ix1 = b1.idx == NONE32 ? 0xFFFFu : static_cast<uint16_t>(b1.idx);
+        o.ix2 = b2.idx == NONE32 ? 0xFFFFu : static_cast<uint16_t>(b2.idx);
+        o._pad = 0;
+        out[e] = o;
+        prev_prob = bp; prev_ord = bo; first = false;
+    }
+}
+
+// Fast path: at most one saved alignment per read end on this contig. Candidates in push order:
+// 0 = (aln1, aln2), 1 = (aln1, unmapped), 2 = (unmapped, aln2).
+struct Fast3 {
+    double prob[3];
+    bool present[3];
+    AlnRef a1, a2;
+    bool has1, has2;
+};
+
+__device__ __forceinline__ Fast3 fast_candidates(const InsLut& ins, const Rec16* rec, uint32_t h1, uint32_t h2, double best0,
+                                                 double best1, double unm_ins_penalty, bool paired) {
+    Fast3 f;
+    f.has1 = h1 != NONE16; f.has2 = h2 != NONE16;
+    const AlnRef none{0.0, 0, 0, NONE32, false};
+    f.a1 = f.has1 ? load_aln(rec, h1, best0) : none;
+    f.a2 = f.has2 ? load_aln(rec, h2, best1) : none;
+    f.present[0] = f.present[1] = f.present[2] = false;
+    f.prob[0] = f.prob[1] = f.prob[2] = -INFINITY;
+    if (!paired) {                                   // identify_single_end_alignments: one entry (aln, -)
+        if (f.has1) { f.present[1] = true; f.prob[1] = f.a1.lp; }
+        return f;
+    }
+    double m = -INFINITY;
+    if (f.has1 && f.has2 && f.a1.rev != f.a2.rev) {
+        const uint32_t insert = max(f.a1.end, f.a2.end) - min(f.a1.start, f.a2.start);
+        const double prob = f.a1.lp + f.a2.lp + ins.ln_prob(insert);
+        if (isfinite(prob)) { f.present[0] = true; f.prob[0] = prob; m = prob; }
+    }
+    if (f.has1) {
+        const double alone = f.a1.lp + unm_ins_penalty;
+        if (alone >= m) { f.present[1] = true; f.prob[1] = alone; }
+    }
+    if (f.has2) {
+        const double alone = f.a2.lp + unm_ins_penalty;
+        if (alone >= m) { f.present[2] = true; f.prob[2] = alone; }
+    }
+    return f;
+}
+
+__device__ __forceinline__ ContigResult fast_count(const Fast3& f, uint32_t max_alns, double prob_diff) {
+    const double best = fmax(f.prob[0], fmax(f.prob[1], f.prob[2]));
+    const double thresh = best - prob_diff;
+    uint32_t ge = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) ge += f.present[i] && f.prob[i] >= thresh;
+    return ContigResult{best, min(ge, max_alns)};
+}
+
+__device__ __forceinline__ void fast_emit(const Fast3& f, uint32_t cnt, double weight, uint32_t contig, PairAlnDev* out) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (!f.present[i]) continue;
+        uint32_t rank = 0;                               // candidates sorted before i (ln_prob desc, push order)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            rank += j != i && f.present[j] && (f.prob[j] > f.prob[i] || (f.prob[j] == f.prob[i] && j < i));
+        if (rank < cnt) {
+            const bool use1 = i != 2, use2 = i != 1;
+            PairAlnDev o;
+            o.ln_prob = f.prob[i] * weight;
+            o.mid1 = use1 ? (f.a1.start + f.a1.end) / 2 : NONE32;
+            o.mid2 = use2 ? (f.a2.start + f.a2.end) / 2 : NONE32;
+            o.contig = static_cast<uint16_t>(contig);
+            o.ix1 = use1 ? static_cast<uint16_t>(f.a1.idx) : 0xFFFFu;
+            o.ix2 = use2 ? static_cast<uint16_t>(f.a2.idx) : 0xFFFFu;
+            o._pad = 0;
+            out[rank] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
+                                                              const uint32_t dbg) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t A = L.n_alleles;
-    RecLds* rec = reinterpret_cast<RecLds*>(smem);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(rec + max_recs);          // [2A] counts -> offsets -> group ends
-    uint16_t* order = reinterpret_cast<uint16_t*>(hist + 2 * A);           // [max_recs]
-    uint8_t* kk1 = reinterpret_cast<uint8_t*>(order + ((max_recs + 1) & ~1u));   // [A] kept first-end alns (<= 10)
-    uint8_t* kk2 = kk1 + A;                                                // [A]
-    uint8_t* cnt8 = kk2 + A;                                               // [A] emitted PairAlignments (<= 10)
+    const uint32_t mr2 = (max_recs + 1) & ~1u;
+    // region sizes must match score_lds_bytes()
+    Rec16* rec = reinterpret_cast<Rec16*>(smem);                              // [max_recs] saved alignments, by record index
+    uint32_t* head32 = reinterpret_cast<uint32_t*>(rec + max_recs);           // [A] {head(end 0) | head(end 1) << 16}
+    uint32_t* alen = head32 + A;                                              // [A] allele lengths (filled once per workgroup)
+    uint32_t* scratch_cursor = alen + A;                                      // [1]
+    uint16_t* nxt = reinterpret_cast<uint16_t*>(scratch_cursor + 1);          // [max_recs] chain links
+    uint16_t* order = nxt + mr2;                                              // [max_recs] scratch of the general path
+    uint8_t* kk1 = reinterpret_cast<uint8_t*>(order + mr2);                   // [A] general path: kept first-end alns (<= 10)
+    uint8_t* kk2 = kk1 + A;                                                   // [A]
+    uint8_t* cnt8 = kk2 + A;                                                  // [A] emitted PairAlignments (<= 10); bit 7 = general path
     const int lane = threadIdx.x;
+    const bool paired = L.is_paired != 0;
+    const InsLut ins{L.ins_lut, L.ins_lut_size, L.ins_n, L.ins_lnq, L.ins_lnpmf_const};
+    for (uint32_t i = lane; i < A; i += WAVE) alen[i] = L.allele_len[i];
+    __syncthreads();
 
     for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
         const uint64_t a0 = R.aln_off[p];
-        const uint32_t n = static_cast<uint32_t>(R.aln_off[p + 1] - a0);
         const uint32_t* cig = R.cigar + R.cigar_off[p];
-        double* mrow = R.matrix + p * A;
-
-        // ---------------- pass 1: records -> LDS ----------------
-        uint32_t j2 = NONE32, j3 = NONE32;
-        for (uint32_t base = 0; base < n; base += WAVE) {
-            const uint32_t idx = base + lane;
-            bool primary = false;
-            if (idx < n) {
-                const uint4 raw = reinterpret_cast<const uint4*>(R.recs)[a0 + idx];
-                const uint32_t pos = raw.x, contig = raw.y & 0xFFFFu, bflags = raw.y >> 16, nc = raw.z, rel = raw.w;
-                primary = (bflags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0;
-                uint16_t fl = (bflags & LCTY_FLAG_REVERSE) ? RF_REVERSE : 0;
-                if (primary) fl |= RF_PRIMARY;
-                if (bflags & LCTY_FLAG_UNMAPPED) fl |= RF_UNMAPPED;
-                uint32_t matches = 0, mism = 0, ins = 0, del = 0, left = 0, right = 0;
-                if (nc == 0) fl |= RF_SKIP;
-                if (contig >= A) fl |= RF_BAD;
-                for (uint32_t i = 0; i < nc; i++) {
-                    const uint32_t w = cig[rel + i];
-                    uint32_t op = w & 15u;
-                    const uint32_t len = w >> 4;
-                    if (op == LCTY_CIGAR_H && (i == 0 || i + 1 == nc)) {
-                        if (primary) fl |= RF_BAD;              // assert!(!cigar.has_hard_clipping()), locs.rs:526
-                        op = LCTY_CIGAR_S;                       // hard_to_soft, cigar.rs:309-320
-                    }
-                    switch (op) {
-                        case LCTY_CIGAR_EQ: matches += len; break;
-                        case LCTY_CIGAR_X: mism += len; break;
-                        case LCTY_CIGAR_D: del += len; break;
-                        case LCTY_CIGAR_I: ins += len; break;
-                        case LCTY_CIGAR_S:
-                            if (i == 0) left = len;              // soft_clipping, cigar.rs:519-527
-                            if (i + 1 == nc) right = len;
-                            break;
-                        default: fl |= RF_BAD;                   // panic!("Unsupported CIGAR operation"), aln.rs:311
-                    }
-                }
-                const uint32_t ref_len = matches + mism + del;
-                const uint32_t clen = (fl & RF_BAD) ? 0u : L.allele_len[contig];
-                const uint32_t end = pos + ref_len;
-                const uint32_t clip = min(left, pos) + min(right, clen > end ? clen - end : 0u);   // limited_clipping, aln.rs:288-296
-                const uint32_t common = mism + ins + clip;                                          // err_prof.rs:73-79
-                RecLds r;
-                r.ln_prob = L.lp[0] * static_cast<double>(matches) + L.lp[1] * static_cast<double>(mism)
-                          + L.lp[2] * static_cast<double>(ins) + L.lp[3] * static_cast<double>(del)
-                          + L.lp[4] * static_cast<double>(clip);                                    // err_prof.rs:212-221
-                r.start = pos; r.end = end; r.edit = common + del;
-                r.contig = static_cast<uint16_t>(contig); r.flags = fl;
-                rec[idx] = r;
-            }
-            unsigned long long b = __ballot(primary && idx > 0);
-            if (b && j2 == NONE32) {
-                const uint32_t f = static_cast<uint32_t>(__ffsll(static_cast<long long>(b))) - 1u;
-                j2 = base + f;
-                b &= ~((2ull << f) - 1ull);
-            }
-            if (b && j2 != NONE32 && j3 == NONE32) j3 = base + static_cast<uint32_t>(__ffsll(static_cast<long long>(b))) - 1u;
-        }
-        __syncthreads();
-        if (dbg == 1) { if (lane == 0) R.status[p] = static_cast<uint8_t>(j2 + rec[0].edit); continue; }   // ablation (LCTY_DBG)
-        // records of this pair: end 0 = [0, j2), end 1 = [j2, n_eff) (locs.rs:1119-1131)
-        const uint32_t n_eff = L.is_paired ? min(n, j3) : min(n, j2);
+        const uint2 meta = R.pair_meta[p];                 // {index of the mate-2 primary (or n), records to look at}
+        const uint32_t j2 = meta.x, n_eff = meta.y;
         const uint32_t split = min(j2, n_eff);
+        const uint32_t len0 = R.mate_len[2 * p], len1 = paired ? R.mate_len[2 * p + 1] : 0u;
+        double* mrow = R.matrix + p * A;
+        const lcty_aln_rec* recs = R.recs + a0;
 
-        // ---------------- thresholds (lanes 0 / 1) ----------------
-        uint32_t my_good = 0, my_thr = NONE32, my_pass = NONE32, my_state = 0;   // state: 1 examined-ok, 2 primary saved, 4 error
+        // ---------------- prologue: prefetch read bases (consumed by K2) ----------------
+        const bool regs_ok = len0 <= 2016 && len1 <= 2016;
+        uint64_t bw0 = 0, bw1 = 0;
+        uint32_t nm0 = 0, nm1 = 0;
+        if (regs_ok) {
+            const uint64_t off0 = R.mate_off[2 * p], off1 = R.mate_off[2 * p + 1];
+            if (static_cast<uint32_t>(lane) * 32u < len0) {
+                bw0 = (reinterpret_cast<const uint64_t*>(R.bases2) + (off0 >> 5))[lane];
+                nm0 = (R.nmask + (off0 >> 5))[lane];
+            }
+            if (static_cast<uint32_t>(lane) * 32u < len1) {
+                bw1 = (reinterpret_cast<const uint64_t*>(R.bases2) + (off1 >> 5))[lane];
+                nm1 = (R.nmask + (off1 >> 5))[lane];
+            }
+        }
+        for (uint32_t i = lane; i < A; i += WAVE) head32[i] = 0xFFFFFFFFu;
+        if (lane == 0) *scratch_cursor = 0;
+
+        // ---------------- thresholds (lanes 0 / 1 score the primaries) ----------------
+        // state: 1 examined-ok, 2 primary saved, 4 error
+        uint32_t my_good = 0, my_thr = NONE32, my_pass = NONE32, my_state = 0;
         if (lane < 2) {
             const uint32_t e = lane;
             const uint32_t pidx = e ? j2 : 0u;
-            const bool exists = e == 0 ? n_eff > 0 : (L.is_paired && j2 < n_eff);
-            if (e == 1 && !L.is_paired) {
+            const bool exists = e == 0 ? n_eff > 0 : (paired && j2 < n_eff);
+            if (e == 1 && !paired) {
                 my_state = 3;                                   // single-end: second end is vacuously fine
             } else if (!exists) {
                 my_state = 4;                                   // expect("Cannot read any more records"), locs.rs:509
             } else {
-                const RecLds pr = rec[pidx];
-                const uint32_t read_len = R.mate_len[2 * p + e];
-                if (read_len == 0 || !(pr.flags & RF_PRIMARY)) my_state = 4;        // locs.rs:511-517 / LaggedReader assert
-                else if (pr.flags & RF_UNMAPPED) my_state = 0;                      // locs.rs:520-523
-                else if (pr.flags & (RF_BAD | RF_SKIP)) my_state = 4;
+                const lcty_aln_rec pr = recs[pidx];
+                const uint32_t read_len = e ? len1 : len0;
+                const bool is_primary = (pr.flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0;
+                if (read_len == 0 || !is_primary) my_state = 4;                 // locs.rs:511-517 / LaggedReader assert
+                else if (pr.flags & LCTY_FLAG_UNMAPPED) my_state = 0;           // locs.rs:520-523
+                else if (pr.n_cigar == 0 || pr.contig >= A) my_state = 4;
                 else {
-                    const uint2 gp = L.edit_lut[min(read_len, L.edit_lut_size - 1)];
-                    uint32_t good = gp.x, passable = gp.y, thr = good;
-                    double compl_v = 1.0;
-                    if (L.short_reads) {                         // neighb_complexity, windows.rs:447-452, 696-698
-                        const uint32_t mid = (pr.start + pr.end) / 2;
-                        const uint32_t npos = L.ci_off[pr.contig + 1] - L.ci_off[pr.contig];
-                        const uint32_t i = min(mid > L.half_neighb ? mid - L.half_neighb : 0u, npos - 1);
-                        compl_v = static_cast<double>(L.compl_cnt[L.ci_off[pr.contig] + i]) * L.compl_mult;
+                    const W8 w8 = *reinterpret_cast<const W8*>(cig + pr.cigar_rel);
+                    const OpCounts oc = count_ops(w8, cig + pr.cigar_rel, pr.n_cigar, true);
+                    const Scored sc = score_counts(L, oc, pr.pos, L.allele_len[pr.contig]);
+                    if (sc.bad) my_state = 4;
+                    else {
+                        const uint2 gp = L.edit_lut[min(read_len, L.edit_lut_size - 1)];
+                        uint32_t good = gp.x, passable = gp.y, thr = good;
+                        double compl_v = 1.0;
+                        if (L.short_reads) {                     // neighb_complexity, windows.rs:447-452, 696-698
+                            const uint32_t mid = (sc.start + sc.end) / 2;
+                            const uint32_t o = L.ci_off[pr.contig];
+                            const uint32_t npos = L.ci_off[pr.contig + 1] - o;
+                            const uint32_t i = min(mid > L.half_neighb ? mid - L.half_neighb : 0u, npos - 1);
+                            compl_v = static_cast<double>(L.compl_cnt[o + i]) * L.compl_mult;
+                        }
+                        if (compl_v <= L.poor_compl) {           // locs.rs:533-536
+                            thr = max(good, static_cast<uint32_t>(L.poor_compl_edit * static_cast<double>(read_len)));
+                            passable += thr - good;
+                        }
+                        my_good = good; my_thr = thr; my_pass = passable;
+                        my_state = 1u | (sc.edit <= passable ? 2u : 0u);
                     }
-                    if (compl_v <= L.poor_compl) {               // locs.rs:533-536
-                        thr = max(good, static_cast<uint32_t>(L.poor_compl_edit * static_cast<double>(read_len)));
-                        passable += thr - good;
-                    }
-                    my_good = good; my_thr = thr; my_pass = passable;
-                    my_state = 1u | (pr.edit <= passable ? 2u : 0u);
                 }
             }
         }
         const uint32_t good0 = __shfl(my_good, 0), thr0 = __shfl(my_thr, 0), pass0 = __shfl(my_pass, 0), st0 = __shfl(my_state, 0);
         const uint32_t good1 = __shfl(my_good, 1), thr1 = __shfl(my_thr, 1), pass1 = __shfl(my_pass, 1), st1 = __shfl(my_state, 1);
+        __syncthreads();      // head table initialised
 
-        // ---------------- pass 2: per-end best edit / ln-prob, saved flags ----------------
+        // ---------------- pass 1: records -> (best edit, best ln-prob), saved ones -> LDS chains ----------------
         uint32_t be0 = NONE32, be1 = NONE32, bad0 = 0, bad1 = 0;
         double bl0 = -INFINITY, bl1 = -INFINITY;
-        for (uint32_t idx = lane; idx < n_eff; idx += WAVE) {
-            RecLds& r = rec[idx];
-            const uint32_t e = idx >= split ? 1u : 0u;
-            // a record is examined only if its end's primary was pushed (locs.rs:539-558)
-            const bool examined = e == 0 ? (st0 & 3u) == 3u : ((st0 & 3u) == 3u && (st1 & 3u) == 3u && L.is_paired);
-            if (!examined || (r.flags & RF_SKIP)) continue;
-            if (r.flags & RF_BAD) { if (e) bad1 = 1; else bad0 = 1; continue; }
-            if (e == 0) { be0 = min(be0, r.edit); bl0 = fmax(bl0, r.ln_prob); }
-            else { be1 = min(be1, r.edit); bl1 = fmax(bl1, r.ln_prob); }
-            if (r.edit <= (e ? pass1 : pass0)) r.flags |= RF_SAVED;
+        // a pair whose first primary was not pushed is rejected without looking further (locs.rs:539-543)
+        const bool look = (st0 & 3u) == 3u;
+        for (uint32_t base = 0; look && base < n_eff; base += WAVE * GR) {
+            uint4 raw[GR];
+            W8 cw[GR];
+            uint32_t clen[GR];
+#pragma unroll
+            for (int g = 0; g < GR; g++) {
+                const uint32_t idx = base + g * WAVE + lane;
+                raw[g] = idx < n_eff ? reinterpret_cast<const uint4*>(recs)[idx] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < GR; g++) {
+                if (raw[g].z) cw[g] = *reinterpret_cast<const W8*>(cig + raw[g].w);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) cw[g].w[i] = 0;
+                }
+                const uint32_t contig = raw[g].y & 0xFFFFu;
+                clen[g] = contig < A ? alen[contig] : 0u;
+            }
+#pragma unroll
+            for (int g = 0; g < GR; g++) {
+                const uint32_t idx = base + g * WAVE + lane;
+                const uint32_t nc = raw[g].z;
+                const uint32_t pos = raw[g].x, contig = raw[g].y & 0xFFFFu, bflags = raw[g].y >> 16;
+                const bool primary = idx == 0 || idx == j2;
+                // empty CIGAR: skipped with a warning (locs.rs:550-554); unmapped primaries end the pair above
+                if (idx < n_eff && nc != 0 && !(primary && (bflags & LCTY_FLAG_UNMAPPED))) {
+                    const uint32_t e = idx >= split ? 1u : 0u;
+                    const bool cbad = contig >= A;
+                    const OpCounts oc = count_ops(cw[g], cig + raw[g].w, nc, primary);
+                    const Scored sc = score_counts(L, oc, pos, clen[g]);
+                    if (sc.bad || cbad) {
+                        if (!primary) { if (e) bad1 = 1; else bad0 = 1; }   // primaries are judged by lanes 0/1 above
+                    } else {
+                        if (e == 0) { be0 = min(be0, sc.edit); bl0 = fmax(bl0, sc.ln_prob); }
+                        else { be1 = min(be1, sc.edit); bl1 = fmax(bl1, sc.ln_prob); }
+                        if (sc.edit <= (e ? pass1 : pass0)) {              // save (locs.rs:314)
+                            Rec16 r;
+                            r.ln_prob = sc.ln_prob; r.start = sc.start;
+                            r.end_rev = sc.end | ((bflags & LCTY_FLAG_REVERSE) ? REV_BIT : 0u);
+                            rec[idx] = r;
+                            // chain per (contig, end): exchange the 16-bit head inside its 32-bit word
+                            uint32_t* word = &head32[contig];
+                            uint32_t old = *word, assumed;
+                            do {
+                                assumed = old;
+                                const uint32_t repl = e ? ((assumed & 0x0000FFFFu) | (idx << 16)) : ((assumed & 0xFFFF0000u) | idx);
+                                old = atomicCAS(word, assumed, repl);
+                            } while (old != assumed);
+                            nxt[idx] = static_cast<uint16_t>(e ? (old >> 16) : (old & 0xFFFFu));
+                        }
+                    }
+                }
+            }
         }
         be0 = wave_min_u32(be0); be1 = wave_min_u32(be1);
         bl0 = wave_max_f64(bl0); bl1 = wave_max_f64(bl1);
         bad0 = wave_sum_u32(bad0); bad1 = wave_sum_u32(bad1);
-        // end 1 is only looked at when end 0 is well mapped (locs.rs:1125-1132)
-        const bool wm0 = (st0 & 3u) == 3u && be0 <= (L.strict_subset ? pass0 : thr0) && !bad0;
-        const bool err = (st0 & 4u) || bad0 || (wm0 && ((st1 & 4u) || bad1));
-        if (err) {
-            if (lane == 0) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_INVALID_DATA));
-        }
-        const bool wm1 = !L.is_paired || ((st1 & 3u) == 3u && be1 <= (L.strict_subset ? pass1 : thr1));
+        __syncthreads();
+        if (dbg == 1) { if (lane == 0) R.status[p] = static_cast<uint8_t>(be0 + be1); continue; }   // ablation (LCTY_DBG)
+
+        // end 1 is only looked at when end 0 is well mapped (locs.rs:1125-1132); its secondaries only when its
+        // primary was pushed
+        const bool wm0 = look && be0 <= (L.strict_subset ? pass0 : thr0) && !bad0;
+        const bool saved1 = (st1 & 3u) == 3u;
+        const bool err = (st0 & 4u) || (look && bad0) || (wm0 && ((st1 & 4u) || (saved1 && bad1)));
+        if (err && lane == 0) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_INVALID_DATA));
+        const bool wm1 = !paired || (saved1 && be1 <= (L.strict_subset ? pass1 : thr1));
         bool accepted = wm0 && wm1 && !err;
         double weight = 1.0;
         if (accepted) {
             weight *= be0 <= good0 ? 1.0 : sqrt(static_cast<double>(good0) / static_cast<double>(be0));      // locs.rs:565
-            if (L.is_paired) weight *= be1 <= good1 ? 1.0 : sqrt(static_cast<double>(good1) / static_cast<double>(be1));
+            if (paired) weight *= be1 <= good1 ? 1.0 : sqrt(static_cast<double>(good1) / static_cast<double>(be1));
         }
         uint8_t status = LCTY_READ_POORLY_MAPPED;
-        uint32_t total_cnt = 0;
+        uint32_t total_cnt = 0, uk0 = 0, uk1 = 0;
         double unmapped_prob = 0.0;
         uint64_t pa_base = 0;
 
         if (accepted) {
-            // ---------------- counting sort of saved records by (contig, end) ----------------
-            for (uint32_t i = lane; i < 2 * A; i += WAVE) hist[i] = 0;
-            __syncthreads();
-            for (uint32_t idx = lane; idx < n_eff; idx += WAVE) {
-                const RecLds& r = rec[idx];
-                if (r.flags & RF_SAVED) atomicAdd(&hist[2u * r.contig + (idx >= split ? 1u : 0u)], 1u);
-            }
-            __syncthreads();
-            {
-                const uint32_t per = (2 * A + WAVE - 1) / WAVE;
-                const uint32_t lo = min(lane * per, 2 * A), hi = min(lo + per, 2 * A);
-                uint32_t s = 0;
-                for (uint32_t i = lo; i < hi; i++) s += hist[i];
-                uint32_t tot;
-                uint32_t run = wave_excl_scan_u32(s, lane, &tot);
-                for (uint32_t i = lo; i < hi; i++) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
-            }
-            __syncthreads();
-            for (uint32_t idx = lane; idx < n_eff; idx += WAVE) {
-                const RecLds& r = rec[idx];
-                if (r.flags & RF_SAVED) {
-                    const uint32_t pos = atomicAdd(&hist[2u * r.contig + (idx >= split ? 1u : 0u)], 1u);
-                    order[pos] = static_cast<uint16_t>(idx);
-                }
-            }
-            __syncthreads();
-            if (dbg == 2) { if (lane == 0) R.status[p] = static_cast<uint8_t>(order[0]); continue; }          // ablation
-
             // ---------------- K2: unique k-mers -> read weight (locs.rs:968-1002) ----------------
-            // (evaluated after the in-bounds test in the reference; it has no side effects, so the
-            //  order is irrelevant for the result)
-            const uint32_t uk0 = dbg == 3 ? 5u : mate_unique_kmers(L, R, 2 * p, lane);
-            const uint32_t uk1 = dbg == 3 ? 5u : (L.is_paired && R.mate_len[2 * p + 1] ? mate_unique_kmers(L, R, 2 * p + 1, lane) : 0u);
+            // (evaluated after the in-bounds test in the reference; no side effects, order irrelevant)
+            if (dbg == 3) { uk0 = uk1 = 5; }
+            else if (regs_ok) pair_unique_kmers_regs(L.kset, L.kset_mask, L.undef_in_set, L.k, len0, len1, bw0, bw1, nm0, nm1, lane, &uk0, &uk1);
+            else {
+                const uint64_t off0 = R.mate_off[2 * p], off1 = R.mate_off[2 * p + 1];
+                uk0 = mate_unique_kmers_global(L.kset, L.kset_mask, L.undef_in_set, L.k,
+                                               reinterpret_cast<const uint64_t*>(R.bases2) + (off0 >> 5), R.nmask + (off0 >> 5), len0, lane);
+                uk1 = len1 ? mate_unique_kmers_global(L.kset, L.kset_mask, L.undef_in_set, L.k,
+                                                      reinterpret_cast<const uint64_t*>(R.bases2) + (off1 >> 5), R.nmask + (off1 >> 5), len1, lane)
+                           : 0u;
+            }
             const uint32_t paired_count = (uk0 + uk1) & 0xFFFFu;
             double kw = L.weight_interc + static_cast<double>(paired_count) * L.weight_mult;
             kw = kw < 0.0 ? 0.0 : (kw > 1.0 ? 1.0 : kw);
             weight *= kw;
             const uint32_t max_alns = weight >= L.min_weight ? LCTY_MAX_USED_ALNS : LCTY_MAX_UNUSED_ALNS;   // locs.rs:1268
             const double unm_ins_penalty = L.unmapped_penalty + L.insert_penalty;                         // locs.rs:816
-            unmapped_prob = L.is_paired ? weight * (2.0 * L.unmapped_penalty + L.insert_penalty)           // locs.rs:866
-                                        : weight * L.unmapped_penalty;                                     // locs.rs:908
+            unmapped_prob = paired ? weight * (2.0 * L.unmapped_penalty + L.insert_penalty)                // locs.rs:866
+                                   : weight * L.unmapped_penalty;                                          // locs.rs:908
 
-            // ---------------- pass 3a: per contig sort/dedupe, best + count ----------------
+            // ---------------- pass 3a: per contig best + kept count, matrix row ----------------
             bool inb = false;
             for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
                 const uint32_t c = c0 + lane;
+                uint32_t h1 = NONE16, h2 = NONE16;
+                bool general = false;
                 if (c < A) {
-                    const uint32_t s1 = c ? hist[2 * c - 1] : 0u, e1 = hist[2 * c], e2 = hist[2 * c + 1];
-                    const uint32_t clen = L.allele_len[c];
-                    const uint32_t K1 = sort_dedupe(rec, order + s1, e1 - s1, L.boundary, clen, &inb);
-                    const uint32_t K2 = sort_dedupe(rec, order + e1, e2 - e1, L.boundary, clen, &inb);
-                    const uint32_t k1 = min(K1, max_alns), k2 = min(K2, max_alns);       // locs.rs:842-851
-                    kk1[c] = static_cast<uint8_t>(k1); kk2[c] = static_cast<uint8_t>(k2);
-                    double mval = unmapped_prob;
-                    uint32_t cnt = 0;
-                    if (k1 + k2 > 0) {
-                        PairCtx pc{&L, rec, order + s1, order + e1, k1, k2, bl0, bl1, unm_ins_penalty, L.is_paired != 0};
-                        double best = -INFINITY;
-                        pc.enumerate([&](double prob, uint32_t, const AlnRef&, const AlnRef&) { best = fmax(best, prob); });
-                        const double thresh = best - L.prob_diff;                        // locs.rs:796
-                        uint32_t ge = 0;
-                        pc.enumerate([&](double prob, uint32_t, const AlnRef&, const AlnRef&) { ge += prob >= thresh; });
-                        cnt = min(ge, max_alns);                                         // locs.rs:797
-                        if (cnt) mval = best * weight;                                   // locs.rs:861-863, 621-629
+                    const uint32_t hw = head32[c];
+                    h1 = hw & 0xFFFFu; h2 = hw >> 16;
+                    general = (h1 != NONE16 && nxt[h1] != NONE16) || (h2 != NONE16 && nxt[h2] != NONE16);
+                }
+                ContigResult res{-INFINITY, 0};
+                if (c < A && !general) {
+                    const Fast3 f = fast_candidates(ins, rec, h1, h2, bl0, bl1, unm_ins_penalty, paired);
+                    const uint32_t clen = alen[c];
+                    if (f.has1) { const uint32_t mid = (f.a1.start + f.a1.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                    if (f.has2) { const uint32_t mid = (f.a2.start + f.a2.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                    if (f.has1 || f.has2) res = fast_count(f, max_alns, L.prob_diff);
+                    cnt8[c] = static_cast<uint8_t>(res.cnt);
+                }
+                if (__ballot(general)) {                  // some lane needs the general path (wave-uniform branch)
+                    if (general) {
+                        uint32_t n1 = 0, n2 = 0;
+                        for (uint32_t v = h1; v != NONE16; v = nxt[v]) n1++;
+                        for (uint32_t v = h2; v != NONE16; v = nxt[v]) n2++;
+                        const uint32_t o = atomicAdd(scratch_cursor, n1 + n2);
+                        const uint32_t clen = alen[c];
+                        const uint32_t K1 = gather_sort_dedupe(rec, nxt, h1, order + o, L.boundary, clen);
+                        const uint32_t K2 = gather_sort_dedupe(rec, nxt, h2, order + o + n1, L.boundary, clen);
+                        inb |= ((K1 | K2) & 0x80000000u) != 0;
+                        const uint32_t k1 = min(K1 & 0x7FFFFFFFu, max_alns), k2 = min(K2 & 0x7FFFFFFFu, max_alns);   // locs.rs:842-851
+                        kk1[c] = static_cast<uint8_t>(k1); kk2[c] = static_cast<uint8_t>(k2);
+                        head32[c] = (o + n1) | (o << 16);     // chains are consumed: {start of list 2, start of list 1} in `order`
+                        const PairCtx pc{ins, rec, order + o, order + o + n1, k1, k2, bl0, bl1, unm_ins_penalty, paired};
+                        res = general_count(pc, max_alns, L.prob_diff);
+                        cnt8[c] = static_cast<uint8_t>(res.cnt | 0x80u);
                     }
-                    cnt8[c] = static_cast<uint8_t>(cnt);
-                    total_cnt += cnt;
-                    mrow[c] = mval;
+                }
+                if (c < A) {
+                    mrow[c] = res.cnt ? res.best * weight : unmapped_prob;   // locs.rs:861-863, 621-629
+                    total_cnt += res.cnt;
                 }
             }
             const bool any_inb = __ballot(inb) != 0ull;
             total_cnt = wave_sum_u32(total_cnt);
-            const bool edit_good = be0 <= thr0 && (!L.is_paired || be1 <= thr1);          // best_edit_is_good, locs.rs:293-295
+            const bool edit_good = be0 <= thr0 && (!paired || be1 <= thr1);                   // best_edit_is_good, locs.rs:293-295
             if (!any_inb) { status = LCTY_READ_OUT_OF_BOUNDS; accepted = false; }
             else if (!edit_good) { status = LCTY_READ_POORLY_MAPPED; accepted = false; }
             else status = weight >= L.min_weight ? LCTY_READ_GOOD : LCTY_READ_FEW_KMERS;     // locs.rs:1277-1285
+            __syncthreads();
 
             if (accepted) {
                 if (lane == 0) {
                     pa_base = atomicAdd(R.pa_count, static_cast<unsigned long long>(total_cnt));
                     if (pa_base + total_cnt > R.pa_cap) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
-                    R.uniq_kmers[2 * p] = static_cast<uint16_t>(uk0);
-                    R.uniq_kmers[2 * p + 1] = static_cast<uint16_t>(uk1);
                 }
                 pa_base = __shfl(pa_base, 0);
-                const bool room = pa_base + total_cnt <= R.pa_cap;
+                const bool room = pa_base + total_cnt <= R.pa_cap && dbg != 4;
                 // ---------------- pass 3b: emit PairAlignments, contig-ascending ----------------
                 uint32_t run = 0;
                 for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
                     const uint32_t c = c0 + lane;
-                    const uint32_t cnt = c < A ? cnt8[c] : 0u;
+                    const uint32_t craw = c < A ? cnt8[c] : 0u;
+                    const uint32_t cnt = craw & 0x7Fu;
+                    const bool general = (craw & 0x80u) != 0;
                     uint32_t tot;
                     const uint32_t my_off = run + wave_excl_scan_u32(cnt, lane, &tot);
                     run += tot;
-                    if (cnt && room && dbg != 4) {
-                        const uint32_t s1 = c ? hist[2 * c - 1] : 0u, e1 = hist[2 * c];
-                        PairCtx pc{&L, rec, order + s1, order + e1, kk1[c], kk2[c], bl0, bl1, unm_ins_penalty, L.is_paired != 0};
-                        PairAlnDev* out = R.pa + pa_base + my_off;
-                        double prev_prob = INFINITY;
-                        uint32_t prev_ord = 0;
-                        bool first = true;
-                        for (uint32_t e = 0; e < cnt; e++) {
-                            double bp = -INFINITY; uint32_t bo = NONE32;
-                            AlnRef b1{0.0, 0, 0, NONE32, false}, b2 = b1;
-                            // decreasing ln_prob, ties in push order (locs.rs:795)
-                            pc.enumerate([&](double prob, uint32_t ord, const AlnRef& x1, const AlnRef& x2) {
-                                const bool after = first || prob < prev_prob || (prob == prev_prob && ord > prev_ord);
-                                if (after && (prob > bp || (prob == bp && ord < bo))) { bp = prob; bo = ord; b1 = x1; b2 = x2; }
-                            });
-                            PairAlnDev o;
-                            o.ln_prob = bp * weight;
-                            o.mid1 = b1.idx == NONE32 ? NONE32 : (b1.start + b1.end) / 2;   // Interval::middle, interv.rs:154-156
-                            o.mid2 = b2.idx == NONE32 ? NONE32 : (b2.start + b2.end) / 2;
-                            o.contig = static_cast<uint16_t>(c);
-                            o.ix1 = b1.idx == NONE32 ? 0xFFFFu : static_cast<uint16_t>(b1.idx);
-                            o.ix2 = b2.idx == NONE32 ? 0xFFFFu : static_cast<uint16_t>(b2.idx);
-                            o._pad = 0;
-                            out[e] = o;
-                            prev_prob = bp; prev_ord = bo; first = false;
+                    PairAlnDev* out = R.pa + pa_base + my_off;
+                    if (room && cnt && !general) {
+                        const uint32_t hw = head32[c];
+                        const Fast3 f = fast_candidates(ins, rec, hw & 0xFFFFu, hw >> 16, bl0, bl1, unm_ins_penalty, paired);
+                        fast_emit(f, cnt, weight, c, out);
+                    }
+                    if (__ballot(room && general && cnt)) {
+                        if (room && general && cnt) {
+                            const uint32_t hw = head32[c];
+                            const PairCtx pc{ins, rec, order + (hw >> 16), order + (hw & 0xFFFFu), kk1[c], kk2[c], bl0, bl1,
+                                             unm_ins_penalty, paired};
+                            general_emit(pc, cnt, weight, c, out);
                         }
                     }
                 }
@@ -487,15 +766,17 @@ __global__ __launch_bounds__(WAVE) void score_reads_kernel(const LocusView L, co
             R.unmapped_prob[p] = accepted ? unmapped_prob : 0.0;
             R.pa_off[p] = accepted ? pa_base : 0ull;
             R.pa_cnt[p] = accepted ? total_cnt : 0u;
-            if (!accepted) { R.uniq_kmers[2 * p] = 0; R.uniq_kmers[2 * p + 1] = 0; }
+            R.uniq_kmers[2 * p] = accepted ? static_cast<uint16_t>(uk0) : 0;
+            R.uniq_kmers[2 * p + 1] = accepted ? static_cast<uint16_t>(uk1) : 0;
         }
         __syncthreads();
     }
 }
 
 static size_t score_lds_bytes(uint32_t max_recs, uint32_t A) {
-    size_t b = static_cast<size_t>(max_recs) * sizeof(RecLds) + static_cast<size_t>(2) * A * sizeof(uint32_t);
-    b += static_cast<size_t>((max_recs + 1) & ~1u) * sizeof(uint16_t) + static_cast<size_t>(3) * A;
+    const size_t mr2 = (max_recs + 1) & ~1u;
+    size_t b = static_cast<size_t>(max_recs) * sizeof(Rec16) + static_cast<size_t>(A) * 8 + 4;   // rec + head + alen + cursor
+    b += 2 * mr2 * sizeof(uint16_t) + static_cast<size_t>(3) * A;                                // nxt + order + kk1/kk2/cnt8
     return (b + 15) & ~static_cast<size_t>(15);
 }
 
@@ -506,16 +787,16 @@ void launch_score_reads(lcty_reads* reads) {
     const uint32_t max_recs = std::max<uint32_t>(reads->max_recs_per_pair, 1);
     const size_t lds = score_lds_bytes(max_recs, L.n_alleles);
     const size_t lds_max = 160 * 1024;
+    if (max_recs >= 65535) fail(LCTY_ERR_UNSUPPORTED, "more than 65534 records in one read pair");
     if (lds > lds_max)
         fail(LCTY_ERR_UNSUPPORTED,
              "a read pair with %u records on %u alleles needs %zu B of LDS (> %zu): not supported by this build",
              max_recs, L.n_alleles, lds, lds_max);
-    if (max_recs > 65535) fail(LCTY_ERR_UNSUPPORTED, "more than 65535 records in one read pair");
     if (lds > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_reads_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
-    const uint32_t per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, lds_max / lds)));
+    const uint32_t per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(12, lds_max / lds)));
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(reads->n_pairs, static_cast<uint64_t>(cus) * per_cu));
     const char* dbg_env = getenv("LCTY_DBG");      // developer ablation switch; 0 / unset = the real kernel
     const uint32_t dbg = dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u;
