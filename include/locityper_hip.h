@@ -161,6 +161,20 @@ typedef struct lcty_pair_aln {
     uint16_t _pad[3];
 } lcty_pair_aln;
 
+/* Solver of one stage (src/solvers/stoch.rs): Greedy (36-145) or SimAnneal (151-266) with their parameters
+ * (`-S greedy:x0=..,s=..,p=..` / `-S anneal:n=..,p=..,P=..`, SetParams 128-139, 249-260). */
+#define LCTY_SOLVER_GREEDY 0
+#define LCTY_SOLVER_ANNEAL 1
+typedef struct lcty_solver {
+    int32_t  kind;          /* LCTY_SOLVER_* */
+    int32_t  best_start;    /* greedy: 1 = start from the best location of every read (default), 0 = random */
+    uint32_t sample_size;   /* greedy: 10 */
+    uint32_t plato_size;    /* greedy: 100; anneal: 10000 */
+    uint32_t anneal_steps;  /* anneal: 20000 */
+    uint32_t _pad0;
+    double   init_prob;     /* anneal: 0.5 */
+} lcty_solver;
+
 typedef struct lcty_ctx   lcty_ctx;
 typedef struct lcty_locus lcty_locus;
 typedef struct lcty_reads lcty_reads;

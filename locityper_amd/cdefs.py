@@ -76,6 +76,22 @@ class Bg(C.Structure):
     ]
 
 
+SOLVER_GREEDY, SOLVER_ANNEAL = 0, 1
+
+
+class Solver(C.Structure):
+    """One stage's solver (src/solvers/stoch.rs)."""
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("best_start", C.c_int32),
+        ("sample_size", C.c_uint32),
+        ("plato_size", C.c_uint32),
+        ("anneal_steps", C.c_uint32),
+        ("_pad0", C.c_uint32),
+        ("init_prob", C.c_double),
+    ]
+
+
 class AlnRec(C.Structure):
     _fields_ = [
         ("pos", C.c_uint32),

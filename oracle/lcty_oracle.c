@@ -8,6 +8,7 @@
  * that every ordering / tie / rounding decision of the CPU path is reproduced.
  */
 #include "lcty_oracle.h"
+#include "lcty_oracle_internal.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -374,11 +375,6 @@ size_t orc_complexity_counts(const uint8_t* seq, size_t n, uint32_t k, uint32_t 
 }
 
 /* ---- HashSet<u128> for UniqueKmers (locs.rs:919): open addressing ---------- */
-typedef struct {
-    orc_u128* keys;
-    uint8_t* used;
-    size_t cap, len;
-} u128set;
 
 static inline uint64_t mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -422,32 +418,7 @@ static void set_insert(u128set* s, orc_u128 k) {
 /* locus: ContigSet + ContigInfos + UniqueKmers + distributions              */
 /* ======================================================================== */
 
-typedef struct {
-    uint32_t len;
-    uint32_t n_pos;        /* len - neighb + 1 */
-    uint32_t n_windows, reg_start, reg_end;
-    uint8_t*  gc;          /* NeighbInfo::gc_content */
-    uint32_t* uniq_cnt;    /* numerator of uniq_kmer_frac */
-    uint16_t* compl_cnt;   /* numerator of complexity */
-} orc_contig_info;
 
-struct orc_locus {
-    uint32_t n_alleles, k;
-    lcty_bg bg;
-    lcty_params prm;
-    const uint8_t** seqs;     /* borrowed copies */
-    uint8_t* seq_store;
-    uint64_t* seq_off;
-    orc_contig_info* infos;
-    u128set unique;
-    double weight_mult, weight_interc;
-    /* InsertDistr */
-    orc_nbinom ins;
-    double* ins_lut; size_t ins_lut_size; double ins_mode_prob;
-    /* ContigInfo scalars */
-    uint32_t left_padding, half_neighb;
-    double uniq_mult, compl_mult;
-};
 
 const lcty_params* orc_locus_params(const orc_locus* l) { return &l->prm; }
 
@@ -542,6 +513,10 @@ orc_locus* orc_locus_new(uint32_t n_alleles, const uint8_t* seqs, const uint64_t
     } else {
         l->ins_mode_prob = NAN;
     }
+    l->depth_lut = (double*)malloc(sizeof(double) * LCTY_GC_BINS * LCTY_DEPTH_CACHE);
+    for (uint32_t gc = 0; gc < LCTY_GC_BINS; gc++)
+        for (uint32_t d = 0; d < LCTY_DEPTH_CACHE; d++)
+            l->depth_lut[gc * LCTY_DEPTH_CACHE + d] = orc_depth_ln_pmf(&l->bg, &l->prm, gc, d);
     return l;
 }
 
@@ -550,7 +525,7 @@ void orc_locus_free(orc_locus* l) {
     if (l->infos) for (uint32_t a = 0; a < l->n_alleles; a++) {
         free(l->infos[a].gc); free(l->infos[a].uniq_cnt); free(l->infos[a].compl_cnt);
     }
-    free(l->infos); free(l->seqs); free(l->seq_store); free(l->seq_off); free(l->ins_lut);
+    free(l->depth_lut); free(l->infos); free(l->seqs); free(l->seq_store); free(l->seq_off); free(l->ins_lut);
     set_free(&l->unique);
     free(l);
 }
@@ -632,12 +607,6 @@ static void prelim_reset(prelim* p, size_t n_records) {
     }
 }
 
-struct orc_alns {
-    uint64_t n_pairs, n_good;
-    uint32_t n_alleles;
-    uint8_t* status; double* weight; double* unmapped_prob; uint16_t* uniq_kmers;
-    uint64_t* pa_off; lcty_pair_aln* pa; size_t n_pa, cap_pa;
-};
 
 typedef struct {
     const orc_locus* l;

@@ -105,6 +105,79 @@ void     orc_run_filter(const double* matrix, uint32_t n_alleles, uint64_t n_goo
 uint64_t orc_truncate(const double* scores, uint64_t* ixs, uint64_t n, double filt_diff,
                       uint64_t min_size, uint64_t threads);
 
+
+/* ======================================================================================== */
+/* solver stages                                                 */
+/* ======================================================================================== */
+
+/* Xoshiro256PlusPlus::seed_from_u64 (ext/rand.rs:3-22; SplitMix64 expansion), next_u64, jump
+ * (solve.rs:1017), long_jump (genotype.rs:1345): public-domain reference constants. */
+typedef struct { uint64_t s[4]; } orc_rng;
+void     orc_rng_seed(orc_rng* r, uint64_t seed);
+uint64_t orc_rng_next(orc_rng* r);
+void     orc_rng_jump(orc_rng* r);
+void     orc_rng_long_jump(orc_rng* r);
+/* Sampling adaptors. rand ^0.10's own adaptors are not in the reference tree, so these are OUR
+ * documented definitions, shared by oracle and GPU:
+ *   below(n)  = high 64 bits of next_u64() * n          (stands in for random_range(0..n))
+ *   f64()     = (next_u64() >> 11) * 2^-53              (random::<f64>())
+ *   counter(key, i) = SplitMix64 finaliser of key + (i+1) * 0x9e3779b97f4a7c15  (order-free draws of apply_tweak) */
+uint64_t orc_rng_below(orc_rng* r, uint64_t n);
+double   orc_rng_f64(orc_rng* r);
+uint64_t orc_counter_u64(uint64_t key, uint64_t i);
+
+/* WeightCalculator::get (model/windows.rs:163-177) */
+double   orc_weight_calc(double breakpoint, double power, double x);
+/* ContigInfo::neighb_info weight for a window starting at `wstart` (windows.rs:439-445); *gc = NeighbInfo::gc_content */
+double   orc_window_weight(const orc_locus* l, uint32_t allele, uint32_t wstart, uint32_t* gc);
+/* WindowDistr::ln_prob of the depth LUT / direct evaluation (distr_cache.rs:34-39, lincache.rs:41-48) */
+double   orc_depth_ln_prob(const orc_locus* l, uint32_t gc, double weight, uint32_t depth);
+
+/* GenotypeAlignments (model/assgn.rs:16-169) + GenotypeWindows (windows.rs:709-806) */
+typedef struct orc_gt_alns orc_gt_alns;
+orc_gt_alns* orc_gt_alns_new(const orc_locus* l, const orc_alns* a, const uint16_t* ids, uint32_t ploidy);
+void     orc_gt_alns_free(orc_gt_alns* g);
+uint64_t orc_gt_alns_n_reads(const orc_gt_alns* g);
+uint64_t orc_gt_alns_n_alns(const orc_gt_alns* g);
+uint32_t orc_gt_alns_n_windows(const orc_gt_alns* g);
+uint64_t orc_gt_alns_n_nontrivial(const orc_gt_alns* g);
+/* any pointer may be NULL. contig_ix 0xFF = both mates unmapped; mids LCTY_NONE_U32 = None; windows[2*i..] */
+void     orc_gt_alns_get(const orc_gt_alns* g, uint64_t* read_ixs, double* ln_prob, uint8_t* contig_ix,
+                         uint32_t* mid1, uint32_t* mid2, uint32_t* windows, uint64_t* non_trivial);
+/* apply_tweak (assgn.rs:127-151): location i draws counter(key, i); window w of the genotype draws
+ * counter(key ^ 0xD1B54A32D192ED03, w) */
+void     orc_gt_alns_apply_tweak(orc_gt_alns* g, uint64_t key);
+/* per window after apply_tweak: gc and weight (weight 0.0 = WindowDistr::TRIVIAL) */
+void     orc_gt_alns_window_distr(const orc_gt_alns* g, uint8_t* gc, double* weight);
+double   orc_gt_alns_max_aln_lik(const orc_gt_alns* g);
+
+void     orc_solver_default(lcty_solver* s, int32_t kind);
+/* Solver::solve (solvers/mod.rs:57-72) -> ReadAssignment::likelihood() (assgn.rs:235-237);
+ * assgn_out[n_reads] = chosen location per read; lik_parts = {aln_lik, depth_lik} */
+double   orc_solve(const orc_gt_alns* g, const lcty_solver* s, orc_rng* rng, uint16_t* assgn_out, double* lik_parts);
+/* likelihood of an explicit assignment (recalc_likelihood, assgn.rs:346-354) */
+double   orc_assignment_likelihood(const orc_gt_alns* g, const uint16_t* assgn, double* lik_parts);
+
+/* One stage of solve_single_thread (solve.rs:816-843) for genotypes[n_gt][ploidy]: chain (g, attempt) is
+ * driven by chain_seeds[g*attempts + attempt] (tweak key = seed, solver rng = seed_from_u64(seed)).
+ * Outputs lik_mean / lik_var (mean_variance_or_nan, ext/vec.rs:109-116); counts (optional) receives, per
+ * genotype, n_alns(g) u16 values appended; counts_off[n_gt+1]. */
+void     orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                         const double* priors, const lcty_solver* s, uint32_t attempts, const uint64_t* chain_seeds,
+                         double* lik_mean, double* lik_var, double* liks_out);
+
+/* compare_two_likelihoods (solve.rs:319-336) */
+double   orc_compare_two_likelihoods(double mean1, double var1, uint32_t att1, double mean2, double var2, uint32_t att2);
+/* discard_improbable_genotypes (solve.rs:425-480): ixs in/out, returns the new count */
+uint64_t orc_discard_improbable(const double* lik_mean, const double* lik_var, const uint32_t* attempts, uint64_t* ixs,
+                                uint64_t n, double prob_thresh, uint64_t out_size, uint64_t threads);
+/* produce_result (solve.rs:482-535): out_ixs/out_ln_probs sized >= min(n, 50); returns the number of genotypes, *quality */
+uint64_t orc_produce_result(const double* lik_mean, const double* lik_var, const uint32_t* attempts, const uint64_t* ixs,
+                            uint64_t n, double prob_thresh, uint64_t out_bams, uint64_t* out_ixs, double* out_ln_probs,
+                            double* quality);
+/* count_unexplained_reads (solve.rs:718-729) */
+uint32_t orc_count_unexplained(const orc_alns* a, const uint16_t* ids, uint32_t ploidy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,13 +9,17 @@ import os
 import numpy as np
 
 from locityper_amd import cdefs
-from locityper_amd.cdefs import Bg, Params, ReadsHost, PAIR_ALN_DTYPE
+from locityper_amd.cdefs import Bg, Params, ReadsHost, PAIR_ALN_DTYPE, Solver
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_ROOT, "oracle", "_build", "liblcty_oracle.so")
 _lib = None
 
 D, U32, U64, VP = C.c_double, C.c_uint32, C.c_uint64, C.c_void_p
+
+
+class Rng(C.Structure):
+    _fields_ = [("s", C.c_uint64 * 4)]
 
 
 class NBinom(C.Structure):
@@ -75,6 +79,35 @@ def lib():
     sig("orc_generate_genotypes", U64, U32, U32, VP)
     sig("orc_run_filter", None, VP, U32, U64, VP, U64, U32, VP, VP)
     sig("orc_truncate", U64, VP, VP, U64, D, U64, U64)
+    # solver stages
+    sig("orc_rng_seed", None, C.POINTER(Rng), U64)
+    sig("orc_rng_next", U64, C.POINTER(Rng))
+    sig("orc_rng_jump", None, C.POINTER(Rng))
+    sig("orc_rng_long_jump", None, C.POINTER(Rng))
+    sig("orc_rng_below", U64, C.POINTER(Rng), U64)
+    sig("orc_rng_f64", D, C.POINTER(Rng))
+    sig("orc_counter_u64", U64, U64, U64)
+    sig("orc_weight_calc", D, D, D, D)
+    sig("orc_window_weight", D, VP, U32, U32, C.POINTER(U32))
+    sig("orc_depth_ln_prob", D, VP, U32, D, U32)
+    sig("orc_gt_alns_new", VP, VP, VP, VP, U32)
+    sig("orc_gt_alns_free", None, VP)
+    sig("orc_gt_alns_n_reads", U64, VP)
+    sig("orc_gt_alns_n_alns", U64, VP)
+    sig("orc_gt_alns_n_windows", U32, VP)
+    sig("orc_gt_alns_n_nontrivial", U64, VP)
+    sig("orc_gt_alns_get", None, VP, VP, VP, VP, VP, VP, VP, VP)
+    sig("orc_gt_alns_apply_tweak", None, VP, U64)
+    sig("orc_gt_alns_window_distr", None, VP, VP, VP)
+    sig("orc_gt_alns_max_aln_lik", D, VP)
+    sig("orc_solver_default", None, C.POINTER(Solver), C.c_int32)
+    sig("orc_solve", D, VP, C.POINTER(Solver), C.POINTER(Rng), VP, VP)
+    sig("orc_assignment_likelihood", D, VP, VP, VP)
+    sig("orc_solve_stage", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP)
+    sig("orc_compare_two_likelihoods", D, D, D, U32, D, D, U32)
+    sig("orc_discard_improbable", U64, VP, VP, VP, VP, U64, D, U64, U64)
+    sig("orc_produce_result", U64, VP, VP, VP, VP, U64, D, U64, VP, VP, C.POINTER(D))
+    sig("orc_count_unexplained", U32, VP, VP, U32)
     _lib = L
     return L
 
@@ -213,3 +246,113 @@ def truncate(scores, ixs, filt_diff, min_size, threads):
     ixs = np.ascontiguousarray(ixs, dtype=np.uint64).copy()
     m = lib().orc_truncate(scores.ctypes.data, ixs.ctypes.data, len(ixs), filt_diff, min_size, threads)
     return ixs[:int(m)]
+
+
+# ---------------------------------------------------------------- solver stages
+def default_solver(kind):
+    s = Solver()
+    lib().orc_solver_default(C.byref(s), kind)
+    return s
+
+
+def rng_from_seed(seed):
+    r = Rng()
+    lib().orc_rng_seed(C.byref(r), seed)
+    return r
+
+
+class OracleGtAlns:
+    """GenotypeAlignments::new (assgn.rs:41-84) for genotype `ids` over the GOOD reads of `alns`."""
+
+    def __init__(self, locus, alns, ids):
+        self.locus, self.src = locus, alns
+        self.ids = np.ascontiguousarray(ids, dtype=np.uint16)
+        self._h = lib().orc_gt_alns_new(locus._h, alns._h, self.ids.ctypes.data, len(self.ids))
+        if not self._h:
+            raise ValueError("orc_gt_alns_new failed")
+        L = lib()
+        self.n_reads = int(L.orc_gt_alns_n_reads(self._h))
+        self.n_alns = int(L.orc_gt_alns_n_alns(self._h))
+        self.n_windows = int(L.orc_gt_alns_n_windows(self._h))
+        self.n_nontrivial = int(L.orc_gt_alns_n_nontrivial(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_gt_alns_free(self._h)
+            self._h = None
+
+    def arrays(self):
+        read_ixs = np.zeros(self.n_reads + 1, dtype=np.uint64)
+        ln_prob = np.zeros(self.n_alns, dtype=np.float64)
+        contig_ix = np.zeros(self.n_alns, dtype=np.uint8)
+        mid1 = np.zeros(self.n_alns, dtype=np.uint32)
+        mid2 = np.zeros(self.n_alns, dtype=np.uint32)
+        windows = np.zeros((self.n_alns, 2), dtype=np.uint32)
+        nt = np.zeros(self.n_nontrivial, dtype=np.uint64)
+        lib().orc_gt_alns_get(self._h, read_ixs.ctypes.data, ln_prob.ctypes.data, contig_ix.ctypes.data,
+                              mid1.ctypes.data, mid2.ctypes.data, windows.ctypes.data, nt.ctypes.data)
+        return dict(read_ixs=read_ixs, ln_prob=ln_prob, contig_ix=contig_ix, mid1=mid1, mid2=mid2, windows=windows,
+                    non_trivial=nt)
+
+    def apply_tweak(self, key):
+        lib().orc_gt_alns_apply_tweak(self._h, key)
+
+    def window_distr(self):
+        gc = np.zeros(self.n_windows, dtype=np.uint8)
+        w = np.zeros(self.n_windows, dtype=np.float64)
+        lib().orc_gt_alns_window_distr(self._h, gc.ctypes.data, w.ctypes.data)
+        return gc, w
+
+    def max_aln_lik(self):
+        return lib().orc_gt_alns_max_aln_lik(self._h)
+
+    def solve(self, solver, seed):
+        """(likelihood, assignment[n_reads], (aln_lik, depth_lik)) with the solver rng = seed_from_u64(seed)."""
+        rng = rng_from_seed(seed)
+        assgn = np.zeros(self.n_reads, dtype=np.uint16)
+        parts = np.zeros(2, dtype=np.float64)
+        lik = lib().orc_solve(self._h, C.byref(solver), C.byref(rng), assgn.ctypes.data, parts.ctypes.data)
+        return lik, assgn, parts
+
+    def likelihood(self, assgn):
+        assgn = np.ascontiguousarray(assgn, dtype=np.uint16)
+        parts = np.zeros(2, dtype=np.float64)
+        lik = lib().orc_assignment_likelihood(self._h, assgn.ctypes.data, parts.ctypes.data)
+        return lik, parts
+
+
+def solve_stage(locus, alns, genotypes, solver, attempts, chain_seeds, priors=None):
+    genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n, ploidy = genotypes.shape
+    seeds = np.ascontiguousarray(chain_seeds, dtype=np.uint64)
+    assert len(seeds) == n * attempts
+    mean = np.zeros(n)
+    var = np.zeros(n)
+    liks = np.zeros((n, attempts))
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    lib().orc_solve_stage(locus._h, alns._h, genotypes.ctypes.data, n, ploidy, None if pri is None else pri.ctypes.data,
+                          C.byref(solver), attempts, seeds.ctypes.data, mean.ctypes.data, var.ctypes.data, liks.ctypes.data)
+    return mean, var, liks
+
+
+def discard_improbable(lik_mean, lik_var, attempts, ixs, prob_thresh, out_size, threads):
+    lik_mean = np.ascontiguousarray(lik_mean, dtype=np.float64)
+    lik_var = np.ascontiguousarray(lik_var, dtype=np.float64)
+    attempts = np.ascontiguousarray(attempts, dtype=np.uint32)
+    ixs = np.ascontiguousarray(ixs, dtype=np.uint64).copy()
+    m = lib().orc_discard_improbable(lik_mean.ctypes.data, lik_var.ctypes.data, attempts.ctypes.data, ixs.ctypes.data,
+                                     len(ixs), prob_thresh, out_size, threads)
+    return ixs[:int(m)]
+
+
+def produce_result(lik_mean, lik_var, attempts, ixs, prob_thresh, out_bams=0):
+    lik_mean = np.ascontiguousarray(lik_mean, dtype=np.float64)
+    lik_var = np.ascontiguousarray(lik_var, dtype=np.float64)
+    attempts = np.ascontiguousarray(attempts, dtype=np.uint32)
+    ixs = np.ascontiguousarray(ixs, dtype=np.uint64)
+    out_ixs = np.zeros(50, dtype=np.uint64)
+    out_lp = np.zeros(50, dtype=np.float64)
+    q = D()
+    n = lib().orc_produce_result(lik_mean.ctypes.data, lik_var.ctypes.data, attempts.ctypes.data, ixs.ctypes.data, len(ixs),
+                                 prob_thresh, out_bams, out_ixs.ctypes.data, out_lp.ctypes.data, C.byref(q))
+    return out_ixs[:int(n)], out_lp[:int(n)], q.value
