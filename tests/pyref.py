@@ -421,3 +421,64 @@ def gen_combinations_with_repl(n, size):      # ext/vec.rs:298-339
     if n and size:
         rec([0] * size, 0, 0)
     return out
+
+
+# ---------------------------------------------------------------- solver stages (second transliteration)
+def extend_read_gt_alns(pair_alns, unmapped_prob, ids, prob_diff):
+    """GenotypeWindows::extend_read_gt_alns (windows.rs:762-797) for one read.
+
+    pair_alns: [(ln_prob, contig, ix1, mid1, ix2, mid2)] contig-ascending, ln_prob-descending.
+    Returns [(ln_prob, contig_ix or 0xFF, mid1, mid2)] sorted, thresholded."""
+    thresh = unmapped_prob - prob_diff
+    out = []
+    for i, cid in enumerate(ids):
+        alns = [pa for pa in pair_alns if pa[1] == cid]
+        if alns:
+            thresh = max(thresh, alns[0][0] - prob_diff)
+            for pa in alns:
+                if pa[0] >= thresh:
+                    out.append((pa[0], i, pa[3], pa[5]))
+                else:
+                    break
+    if unmapped_prob >= thresh:
+        out.append((unmapped_prob, 0xFF, cdefs.NONE_U32, cdefs.NONE_U32))
+    order = sorted(range(len(out)), key=lambda t: (-out[t][0], t))
+    out = [out[t] for t in order]
+    keep = 0
+    while keep < len(out) and out[keep][0] >= thresh:
+        keep += 1
+    return out[:keep]
+
+
+def window_ix(reg_start, n_windows, window, shift, middle):
+    """get_shifted_window_ix (windows.rs:465-470) + middle_window (62-68)."""
+    if middle == cdefs.NONE_U32:
+        return 0
+    if reg_start <= middle < reg_start + n_windows * window:
+        return (middle - reg_start) // window + shift
+    return 1
+
+
+def depth_lik_diff_counts(w1, w2, w3, w4):
+    """The (window -> depth change) bookkeeping of ReadAssignment::depth_lik_diff (assgn.rs:259-284)."""
+    c1 = -1
+    if w2 == w1:
+        c1 -= 1; c2 = 0
+    else:
+        c2 = -1
+    if w3 == w1:
+        c1 += 1; c3 = 0
+    elif w3 == w2:
+        c2 += 1; c3 = 0
+    else:
+        c3 = 1
+    if w4 == w1:
+        c1 += 1; c4 = 0
+    elif w4 == w2:
+        c2 += 1; c4 = 0
+    elif w4 == w3:
+        c3 += 1; c4 = 0
+    else:
+        c4 = 1
+    assert c1 + c2 + c3 + c4 == 0
+    return [(w1, c1), (w2, c2), (w3, c3), (w4, c4)]
