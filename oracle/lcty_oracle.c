@@ -525,7 +525,7 @@ void orc_locus_free(orc_locus* l) {
     if (l->infos) for (uint32_t a = 0; a < l->n_alleles; a++) {
         free(l->infos[a].gc); free(l->infos[a].uniq_cnt); free(l->infos[a].compl_cnt);
     }
-    free(l->depth_lut); free(l->infos); free(l->seqs); free(l->seq_store); free(l->seq_off); free(l->ins_lut);
+    free(l->depth_lut); free(l->win_weight_inj); free(l->ci_off_inj); free(l->infos); free(l->seqs); free(l->seq_store); free(l->seq_off); free(l->ins_lut);
     set_free(&l->unique);
     free(l);
 }
@@ -1049,6 +1049,23 @@ orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) {
     A->pa_off[R] = pv.n;
     A->pa = pv.v; A->n_pa = pv.n;
     if (err) *err = 0;
+    return A;
+}
+
+/* Test hook: an orc_alns assembled from arrays (e.g. the products of the GPU scoring kernel), so that the solver
+ * stages of oracle and GPU can be compared on bit-identical inputs. */
+orc_alns* orc_alns_from_arrays(uint64_t n_pairs, uint32_t n_alleles, const uint8_t* status, const double* weight,
+                               const double* unmapped_prob, const uint64_t* pa_off, const lcty_pair_aln* pa) {
+    orc_alns* A = (orc_alns*)calloc(1, sizeof(orc_alns));
+    A->n_pairs = n_pairs; A->n_alleles = n_alleles;
+    A->status = (uint8_t*)malloc(n_pairs ? n_pairs : 1); memcpy(A->status, status, n_pairs);
+    A->weight = (double*)malloc(sizeof(double) * (n_pairs ? n_pairs : 1)); memcpy(A->weight, weight, sizeof(double) * n_pairs);
+    A->unmapped_prob = (double*)malloc(sizeof(double) * (n_pairs ? n_pairs : 1)); memcpy(A->unmapped_prob, unmapped_prob, sizeof(double) * n_pairs);
+    A->uniq_kmers = (uint16_t*)calloc(n_pairs ? 2 * n_pairs : 1, sizeof(uint16_t));
+    A->pa_off = (uint64_t*)malloc(sizeof(uint64_t) * (n_pairs + 1)); memcpy(A->pa_off, pa_off, sizeof(uint64_t) * (n_pairs + 1));
+    A->n_pa = pa_off[n_pairs];
+    A->pa = (lcty_pair_aln*)malloc(sizeof(lcty_pair_aln) * (A->n_pa ? A->n_pa : 1)); memcpy(A->pa, pa, sizeof(lcty_pair_aln) * A->n_pa);
+    for (uint64_t r = 0; r < n_pairs; r++) A->n_good += status[r] == LCTY_READ_GOOD;
     return A;
 }
 

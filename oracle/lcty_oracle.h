@@ -85,6 +85,9 @@ typedef struct orc_alns orc_alns;
 /* returns NULL and sets *err (LCTY_ERR_*) on invalid data (the reference panics / errors) */
 orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err);
 void      orc_alns_free(orc_alns* a);
+/* test hook: orc_alns from arrays (status, weight, unmapped_prob [n_pairs], pa_off [n_pairs+1], pa) */
+orc_alns* orc_alns_from_arrays(uint64_t n_pairs, uint32_t n_alleles, const uint8_t* status, const double* weight,
+                               const double* unmapped_prob, const uint64_t* pa_off, const lcty_pair_aln* pa);
 uint64_t  orc_alns_n_pairs(const orc_alns* a);
 uint64_t  orc_alns_n_good(const orc_alns* a);
 void      orc_alns_status(const orc_alns* a, uint8_t* status, double* weight, double* unmapped_prob,
@@ -144,8 +147,9 @@ uint64_t orc_gt_alns_n_nontrivial(const orc_gt_alns* g);
 /* any pointer may be NULL. contig_ix 0xFF = both mates unmapped; mids LCTY_NONE_U32 = None; windows[2*i..] */
 void     orc_gt_alns_get(const orc_gt_alns* g, uint64_t* read_ixs, double* ln_prob, uint8_t* contig_ix,
                          uint32_t* mid1, uint32_t* mid2, uint32_t* windows, uint64_t* non_trivial);
-/* apply_tweak (assgn.rs:127-151): location i draws counter(key, i); window w of the genotype draws
- * counter(key ^ 0xD1B54A32D192ED03, w) */
+/* apply_tweak (assgn.rs:127-151): location t of read rp draws counter(key, rp << 16 | t); window w of the genotype
+ * draws counter(key ^ 0xD1B54A32D192ED03, w); a random initial assignment of read rp draws
+ * counter(key ^ 0x8CB92BA72F3D8DD7, rp) */
 void     orc_gt_alns_apply_tweak(orc_gt_alns* g, uint64_t key);
 /* per window after apply_tweak: gc and weight (weight 0.0 = WindowDistr::TRIVIAL) */
 void     orc_gt_alns_window_distr(const orc_gt_alns* g, uint8_t* gc, double* weight);
@@ -154,7 +158,9 @@ double   orc_gt_alns_max_aln_lik(const orc_gt_alns* g);
 void     orc_solver_default(lcty_solver* s, int32_t kind);
 /* Solver::solve (solvers/mod.rs:57-72) -> ReadAssignment::likelihood() (assgn.rs:235-237);
  * assgn_out[n_reads] = chosen location per read; lik_parts = {aln_lik, depth_lik} */
-double   orc_solve(const orc_gt_alns* g, const lcty_solver* s, orc_rng* rng, uint16_t* assgn_out, double* lik_parts);
+double   orc_solve(const orc_gt_alns* g, const lcty_solver* s, uint64_t seed, uint16_t* assgn_out, double* lik_parts);
+/* test hook: depth_lut[101*256] and/or win_weight (per position, alleles concatenated) replace the oracle's own tables */
+void     orc_locus_inject_tables(orc_locus* l, const double* depth_lut, const double* win_weight);
 /* likelihood of an explicit assignment (recalc_likelihood, assgn.rs:346-354) */
 double   orc_assignment_likelihood(const orc_gt_alns* g, const uint16_t* assgn, double* lik_parts);
 

@@ -35,6 +35,7 @@ struct orc_locus {
     uint32_t left_padding, half_neighb;
     double uniq_mult, compl_mult;
     double* depth_lut;      /* [101][256] LinearCache<BayesCalc> values (distr_cache.rs:61-75) */
+    double* win_weight_inj; uint64_t* ci_off_inj;   /* test hook: injected per-position window weights */
 };
 
 struct orc_alns {

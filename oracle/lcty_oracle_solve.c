@@ -81,6 +81,7 @@ double orc_window_weight(const orc_locus* l, uint32_t allele, uint32_t wstart, u
     const orc_contig_info* ci = &l->infos[allele];
     const uint32_t i = wstart > l->left_padding ? wstart - l->left_padding : 0;
     if (gc) *gc = ci->gc[i];
+    if (l->win_weight_inj) return l->win_weight_inj[l->ci_off_inj[allele] + i];
     const double uniq_frac = (double)ci->uniq_cnt[i] * l->uniq_mult;          /* windows.rs:402 */
     const double complexity = (double)ci->compl_cnt[i] * l->compl_mult;      /* compl.rs:133,138 */
     double w = 1.0;
@@ -227,14 +228,16 @@ static inline uint32_t shifted_window_ix(const orc_contig_info* ci, uint32_t win
 void orc_gt_alns_apply_tweak(orc_gt_alns* g, uint64_t key) {
     const orc_locus* l = g->l;
     const uint32_t tweak = (uint32_t)l->prm.tweak, window = l->bg.window;
-    for (uint64_t i = 0; i < g->n_alns; i++) {
+    for (uint64_t rp = 0; rp < g->n_reads; rp++)
+    for (uint64_t i = g->read_ixs[rp]; i < g->read_ixs[rp + 1]; i++) {
         gt_aln* a = &g->alns[i];
-        if (a->contig_ix == 0xFF) continue;                           /* parent == None: windows stay UNMAPPED */
+        if (a->contig_ix == 0xFF) { a->win[0] = a->win[1] = 0; continue; }   /* parent == None: windows stay UNMAPPED */
         const orc_contig_info* ci = &l->infos[g->ids[a->contig_ix]];
         const uint32_t shift = g->wshifts[a->contig_ix];
         uint32_t t1 = 0, t2 = 0;
         if (tweak != 0) {
-            const uint64_t r = orc_counter_u64(key, i);
+            /* one draw per location, keyed by (read, location index inside the read) */
+            const uint64_t r = orc_counter_u64(key, (rp << 16) | (i - g->read_ixs[rp]));
             t1 = (uint32_t)(r >> 32) % (2 * tweak + 1);
             t2 = (uint32_t)r % (2 * tweak + 1);
         }
@@ -297,14 +300,17 @@ static void recalc_likelihood(rassgn* ra) {
 }
 
 /* try_new — assgn.rs:199-226; init: 0 = best location, 1 = random_range(0..alns.len()) */
-static void rassgn_init(rassgn* ra, const orc_gt_alns* g, int random_init, orc_rng* rng) {
+#define INIT_KEY_XOR 0x8CB92BA72F3D8DD7ULL
+static void rassgn_init(rassgn* ra, const orc_gt_alns* g, int random_init, uint64_t key) {
     ra->g = g;
     ra->assgn = (uint16_t*)calloc(g->n_reads ? g->n_reads : 1, sizeof(uint16_t));
     ra->depth = (uint32_t*)calloc(g->total_windows, sizeof(uint32_t));
     for (uint64_t r = 0; r < g->n_reads; r++) {
         const uint64_t i = g->read_ixs[r], m = g->read_ixs[r + 1] - i;
         uint32_t a = 0;
-        if (m > 1 && random_init) a = (uint32_t)orc_rng_below(rng, m);
+        /* rng.random_range(0..alns.len()) per non-trivial read -> counter draw keyed by the read (order-free) */
+        if (m > 1 && random_init)
+            a = (uint32_t)(((unsigned __int128)orc_counter_u64(key ^ INIT_KEY_XOR, r) * (unsigned __int128)m) >> 64);
         ra->assgn[r] = (uint16_t)a;
         ra->depth[g->alns[i + a].win[0]]++;
         ra->depth[g->alns[i + a].win[1]]++;
@@ -402,10 +408,10 @@ static double max_abs_random(const rassgn* ra, orc_rng* rng, int count) {
 static inline double minimum_allowed_diff(double m) { return fmax(1e-10 * m, 1e-14); }   /* stoch.rs:27-29 */
 
 /* Greedy::solve_nontrivial — stoch.rs:81-120 */
-static void solve_greedy(rassgn* ra, const orc_gt_alns* g, const lcty_solver* s, orc_rng* rng) {
+static void solve_greedy(rassgn* ra, const orc_gt_alns* g, const lcty_solver* s, orc_rng* rng, uint64_t key) {
     const uint64_t nnt = g->n_nontrivial;
     const uint64_t sample_size = MIN((uint64_t)s->sample_size, nnt);
-    rassgn_init(ra, g, !s->best_start, rng);
+    rassgn_init(ra, g, !s->best_start, key);
     const double min_diff = minimum_allowed_diff(max_abs_random(ra, rng, 100));
     uint64_t curr_plato = 0;
     const uint64_t max_iter = MAX((uint64_t)100000, (uint64_t)s->plato_size * 100);
@@ -434,8 +440,8 @@ static void solve_greedy(rassgn* ra, const orc_gt_alns* g, const lcty_solver* s,
 }
 
 /* SimAnneal::solve_nontrivial — stoch.rs:195-245 */
-static void solve_anneal(rassgn* ra, const orc_gt_alns* g, const lcty_solver* s, orc_rng* rng) {
-    rassgn_init(ra, g, 1, rng);
+static void solve_anneal(rassgn* ra, const orc_gt_alns* g, const lcty_solver* s, orc_rng* rng, uint64_t key) {
+    rassgn_init(ra, g, 1, key);
     const double max_abs = max_abs_random(ra, rng, 100);
     const double min_diff = minimum_allowed_diff(max_abs);
     const double start_temp = fmax(-max_abs / log(s->init_prob), 1e-5);
@@ -465,11 +471,12 @@ void orc_solver_default(lcty_solver* s, int32_t kind) {
 }
 
 /* Solver::solve — solvers/mod.rs:57-72 */
-double orc_solve(const orc_gt_alns* g, const lcty_solver* s, orc_rng* rng, uint16_t* assgn_out, double* lik_parts) {
+double orc_solve(const orc_gt_alns* g, const lcty_solver* s, uint64_t seed, uint16_t* assgn_out, double* lik_parts) {
     rassgn ra;
-    if (g->n_nontrivial == 0) rassgn_init(&ra, g, 0, rng);          /* trivial: the only possible assignment */
-    else if (s->kind == LCTY_SOLVER_GREEDY) solve_greedy(&ra, g, s, rng);
-    else solve_anneal(&ra, g, s, rng);
+    orc_rng rng; orc_rng_seed(&rng, seed);
+    if (g->n_nontrivial == 0) rassgn_init(&ra, g, 0, seed);         /* trivial: the only possible assignment */
+    else if (s->kind == LCTY_SOLVER_GREEDY) solve_greedy(&ra, g, s, &rng, seed);
+    else solve_anneal(&ra, g, s, &rng, seed);
     const double lik = rassgn_likelihood(&ra);
     if (assgn_out) memcpy(assgn_out, ra.assgn, sizeof(uint16_t) * g->n_reads);
     if (lik_parts) { lik_parts[0] = ra.aln_lik; lik_parts[1] = ra.depth_lik; }
@@ -504,8 +511,7 @@ void orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* geno
         for (uint32_t at = 0; at < attempts; at++) {
             const uint64_t seed = chain_seeds[gi * attempts + at];
             orc_gt_alns_apply_tweak(g, seed);
-            orc_rng rng; orc_rng_seed(&rng, seed);
-            liks[at] = prior + orc_solve(g, s, &rng, NULL, NULL);
+            liks[at] = prior + orc_solve(g, s, seed, NULL, NULL);
             if (liks_out) liks_out[gi * attempts + at] = liks[at];
         }
         /* mean_variance_or_nan — ext/vec.rs:74-116 */
@@ -622,4 +628,19 @@ uint32_t orc_count_unexplained(const orc_alns* a, const uint16_t* ids, uint32_t 
         unexplained += best < a->unmapped_prob[r] + 1e-8;
     }
     return unexplained;
+}
+
+/* Test hook: make the solver consume externally supplied tables (the ones the GPU built), so that oracle and GPU
+ * chains see bit-identical inputs and their trajectories can be compared exactly. */
+void orc_locus_inject_tables(orc_locus* l, const double* depth_lut, const double* win_weight) {
+    if (depth_lut) memcpy(l->depth_lut, depth_lut, sizeof(double) * LCTY_GC_BINS * LCTY_DEPTH_CACHE);
+    if (win_weight) {
+        uint64_t total = 0;
+        free(l->ci_off_inj); free(l->win_weight_inj);
+        l->ci_off_inj = (uint64_t*)malloc(sizeof(uint64_t) * (l->n_alleles + 1));
+        for (uint32_t a = 0; a < l->n_alleles; a++) { l->ci_off_inj[a] = total; total += l->infos[a].n_pos; }
+        l->ci_off_inj[l->n_alleles] = total;
+        l->win_weight_inj = (double*)malloc(sizeof(double) * (total ? total : 1));
+        memcpy(l->win_weight_inj, win_weight, sizeof(double) * total);
+    }
 }

@@ -70,6 +70,7 @@ def lib():
     sig("orc_locus_insert_penalty", D, VP)
     sig("orc_load", VP, VP, C.POINTER(ReadsHost), C.POINTER(C.c_int))
     sig("orc_alns_free", None, VP)
+    sig("orc_alns_from_arrays", VP, U64, U32, VP, VP, VP, VP, VP)
     sig("orc_alns_n_pairs", U64, VP)
     sig("orc_alns_n_good", U64, VP)
     sig("orc_alns_status", None, VP, VP, VP, VP, VP)
@@ -101,7 +102,8 @@ def lib():
     sig("orc_gt_alns_window_distr", None, VP, VP, VP)
     sig("orc_gt_alns_max_aln_lik", D, VP)
     sig("orc_solver_default", None, C.POINTER(Solver), C.c_int32)
-    sig("orc_solve", D, VP, C.POINTER(Solver), C.POINTER(Rng), VP, VP)
+    sig("orc_solve", D, VP, C.POINTER(Solver), U64, VP, VP)
+    sig("orc_locus_inject_tables", None, VP, VP, VP)
     sig("orc_assignment_likelihood", D, VP, VP, VP)
     sig("orc_solve_stage", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP)
     sig("orc_compare_two_likelihoods", D, D, D, U32, D, D, U32)
@@ -183,6 +185,12 @@ class OracleLocus:
     def insert_penalty(self):
         return lib().orc_locus_insert_penalty(self._h)
 
+    def inject_tables(self, depth_lut=None, win_weight=None):
+        """Test hook: use the tables the GPU built (bit-identical solver inputs)."""
+        dl = None if depth_lut is None else np.ascontiguousarray(depth_lut, dtype=np.float64)
+        ww = None if win_weight is None else np.ascontiguousarray(win_weight, dtype=np.float64)
+        lib().orc_locus_inject_tables(self._h, None if dl is None else dl.ctypes.data, None if ww is None else ww.ctypes.data)
+
     def load(self, chunk):
         """AllAlignments::load -> OracleAlns (raises ValueError with the error code on invalid data)."""
         err = C.c_int(0)
@@ -220,6 +228,18 @@ class OracleAlns:
         out = np.zeros((self.n_alleles, self.n_good), dtype=np.float64)
         lib().orc_best_aln_matrix(self._h, out.ctypes.data)
         return out
+
+
+def alns_from_arrays(n_alleles, status, weight, unmapped_prob, pa_off, pair_alns):
+    """Test hook: OracleAlns over externally produced AllAlignments products (e.g. the GPU's)."""
+    status = np.ascontiguousarray(status, dtype=np.uint8)
+    weight = np.ascontiguousarray(weight, dtype=np.float64)
+    unm = np.ascontiguousarray(unmapped_prob, dtype=np.float64)
+    off = np.ascontiguousarray(pa_off, dtype=np.uint64)
+    pa = np.ascontiguousarray(pair_alns, dtype=PAIR_ALN_DTYPE)
+    h = lib().orc_alns_from_arrays(len(status), n_alleles, status.ctypes.data, weight.ctypes.data, unm.ctypes.data,
+                                   off.ctypes.data, pa.ctypes.data)
+    return OracleAlns(h, n_alleles)
 
 
 def generate_genotypes(n_alleles, ploidy):
@@ -308,10 +328,9 @@ class OracleGtAlns:
 
     def solve(self, solver, seed):
         """(likelihood, assignment[n_reads], (aln_lik, depth_lik)) with the solver rng = seed_from_u64(seed)."""
-        rng = rng_from_seed(seed)
         assgn = np.zeros(self.n_reads, dtype=np.uint16)
         parts = np.zeros(2, dtype=np.float64)
-        lik = lib().orc_solve(self._h, C.byref(solver), C.byref(rng), assgn.ctypes.data, parts.ctypes.data)
+        lik = lib().orc_solve(self._h, C.byref(solver), seed, assgn.ctypes.data, parts.ctypes.data)
         return lik, assgn, parts
 
     def likelihood(self, assgn):
