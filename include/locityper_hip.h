@@ -223,6 +223,9 @@ int32_t lcty_locus_edit_thresholds(const lcty_locus* locus, uint32_t read_len, u
 int32_t lcty_locus_insert_lnprob(const lcty_locus* locus, uint32_t n, const uint32_t* sizes, double* out, double* insert_penalty);
 /* DistrCache: ln P(depth) for gc bin, depth in 0..LCTY_DEPTH_CACHE (distr_cache.rs:61-75; bayes.rs:27-35) */
 int32_t lcty_locus_depth_lut(const lcty_locus* locus, double* out /* [101*256] */);
+/* ContigInfo::neighb_info weight (windows.rs:439-445) of every moving-window position, alleles concatenated
+ * (sum over alleles of len - neighb + 1 values) */
+int32_t lcty_locus_window_weights(const lcty_locus* locus, double* out);
 
 /* ---- reads: device-resident batch -----------------------------------------
  * Capacity is fixed at creation so a batch larger than host memory can be
@@ -273,12 +276,33 @@ int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double fi
 uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy);
 int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* out, uint64_t cap);
 
+/* ---- solver stages (src/solvers/solve.rs:789-850, src/solvers/stoch.rs, src/model/assgn.rs) ----------------
+ * The reference drives these stages from one Xoshiro256++ through rand ^0.10 adaptors that are not in its tree and
+ * whose results already depend on --threads (solve.rs:1017, 1051). Here every (genotype, attempt) chain gets its
+ * own 64-bit seed (lcty_chain_seeds draws them from seed_from_u64(master)); DESIGN.md §7 lists the adaptors. */
+int32_t lcty_solver_default(lcty_solver* out, int32_t kind);                 /* Greedy::default / SimAnneal::default */
+int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out);
+/* One stage over genotypes[n_gt][ploidy] (the body of the stage loop, solve.rs:816-843): per genotype `attempts` x
+ * (apply_tweak -> Solver::solve -> prior + likelihood), then mean_variance_or_nan. chain_seeds[n_gt*attempts];
+ * liks_out (optional) [n_gt*attempts]. Device solver: ploidy <= 4. */
+int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
+                         const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                         double* lik_mean, double* lik_var, double* liks_out);
+/* Predictions::discard_improbable_genotypes (solve.rs:425-480): ixs in/out */
+int32_t lcty_discard_improbable(const double* lik_mean, const double* lik_var, const uint32_t* attempts, uint64_t* ixs, uint64_t n,
+                                double prob_thresh, uint64_t out_size, uint64_t threads, uint64_t* n_keep);
+/* Predictions::produce_result (solve.rs:482-535): out arrays sized >= min(n, 50) */
+int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const uint32_t* attempts, const uint64_t* ixs, uint64_t n,
+                            double prob_thresh, uint64_t out_bams, uint64_t* out_ixs, double* out_ln_probs, uint64_t* n_out,
+                            double* quality);
+
 /* ---- measurement hooks (bench.py) -----------------------------------------
  * HIP-event timing of the launches issued between begin/end on the context's
  * stream; kernel ids LCTY_K_*.                                                 */
 #define LCTY_K_SCORE     0
 #define LCTY_K_PREFILTER 1
-#define LCTY_K_COUNT     2
+#define LCTY_K_SOLVE     2
+#define LCTY_K_COUNT     3
 int32_t lcty_timing_reset(lcty_ctx* ctx);
 int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms);
 

@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 
-from .cdefs import Bg, Params, ReadsHost, PairAln
+from .cdefs import Bg, Params, ReadsHost, PairAln, Solver
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocityper_hip.so")
@@ -43,6 +43,12 @@ SIGNATURES = {
     "lcty_truncate": (I32, [VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_count_genotypes": (U64, [U32, U32]),
     "lcty_generate_genotypes": (I32, [U32, U32, VP, U64]),
+    "lcty_locus_window_weights": (I32, [VP, VP]),
+    "lcty_solver_default": (I32, [P(Solver), I32]),
+    "lcty_chain_seeds": (I32, [U64, U64, VP]),
+    "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
+    "lcty_discard_improbable": (I32, [VP, VP, VP, VP, U64, D, U64, U64, P(U64)]),
+    "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),
     "lcty_timing_reset": (I32, [VP]),
     "lcty_timing_get": (I32, [VP, I32, P(U64), P(D)]),
 }

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import cdefs
 from ._lib import lib, check, VP, U32, U64, D
-from .cdefs import Bg, Params, PAIR_ALN_DTYPE
+from .cdefs import Bg, Params, Solver, PAIR_ALN_DTYPE
 
 
 def device_count():
@@ -58,7 +58,7 @@ class Context:
             pass
 
 
-K_SCORE, K_PREFILTER = 0, 1
+K_SCORE, K_PREFILTER, K_SOLVE = 0, 1, 2
 
 
 class Locus:
@@ -113,6 +113,13 @@ class Locus:
         pen = D()
         check(lib().lcty_locus_insert_lnprob(self._h, len(sizes), sizes.ctypes.data, out.ctypes.data, C.byref(pen)))
         return out, pen.value
+
+    def window_weights(self):
+        """ContigInfo::neighb_info weights of every moving-window position (alleles concatenated)."""
+        n = sum(int(self.seq_off[a + 1] - self.seq_off[a]) - self.bg.neighb + 1 for a in range(self.n_alleles))
+        out = np.zeros(n, dtype=np.float64)
+        check(lib().lcty_locus_window_weights(self._h, out.ctypes.data))
+        return out
 
     def depth_lut(self):
         out = np.zeros((cdefs.GC_BINS, cdefs.DEPTH_CACHE), dtype=np.float64)
@@ -220,6 +227,55 @@ class AllAlignments:
         scores = np.zeros(n, dtype=np.float64)
         check(lib().lcty_prefilter_scores(self._h, scores.ctypes.data, n))
         return scores
+
+
+def default_solver(kind):
+    s = Solver()
+    check(lib().lcty_solver_default(C.byref(s), kind))
+    return s
+
+
+def chain_seeds(master_seed, n):
+    out = np.zeros(n, dtype=np.uint64)
+    check(lib().lcty_chain_seeds(master_seed, n, out.ctypes.data))
+    return out
+
+
+def solve_stage(aa, genotypes, solver, attempts, seeds, priors=None):
+    """One solver stage (solve.rs:816-843) on the GPU: returns (lik_mean, lik_var, liks[n_gt][attempts])."""
+    genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n, ploidy = genotypes.shape
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    assert len(seeds) == n * attempts
+    mean, var, liks = np.zeros(n), np.zeros(n), np.zeros((n, attempts))
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    check(lib().lcty_solve_stage(aa._h, genotypes.ctypes.data, n, ploidy, None if pri is None else pri.ctypes.data,
+                                 C.byref(solver), attempts, seeds.ctypes.data, mean.ctypes.data, var.ctypes.data,
+                                 liks.ctypes.data))
+    return mean, var, liks
+
+
+def discard_improbable(lik_mean, lik_var, attempts, ixs, prob_thresh, out_size, threads):
+    lik_mean = np.ascontiguousarray(lik_mean, dtype=np.float64)
+    lik_var = np.ascontiguousarray(lik_var, dtype=np.float64)
+    attempts = np.ascontiguousarray(attempts, dtype=np.uint32)
+    ixs = np.ascontiguousarray(ixs, dtype=np.uint64).copy()
+    keep = U64()
+    check(lib().lcty_discard_improbable(lik_mean.ctypes.data, lik_var.ctypes.data, attempts.ctypes.data, ixs.ctypes.data,
+                                        len(ixs), prob_thresh, out_size, threads, C.byref(keep)))
+    return ixs[:int(keep.value)]
+
+
+def produce_result(lik_mean, lik_var, attempts, ixs, prob_thresh, out_bams=0):
+    lik_mean = np.ascontiguousarray(lik_mean, dtype=np.float64)
+    lik_var = np.ascontiguousarray(lik_var, dtype=np.float64)
+    attempts = np.ascontiguousarray(attempts, dtype=np.uint32)
+    ixs = np.ascontiguousarray(ixs, dtype=np.uint64)
+    out_ixs, out_lp = np.zeros(50, dtype=np.uint64), np.zeros(50, dtype=np.float64)
+    n, q = U64(), D()
+    check(lib().lcty_produce_result(lik_mean.ctypes.data, lik_var.ctypes.data, attempts.ctypes.data, ixs.ctypes.data, len(ixs),
+                                    prob_thresh, out_bams, out_ixs.ctypes.data, out_lp.ctypes.data, C.byref(n), C.byref(q)))
+    return out_ixs[:int(n.value)], out_lp[:int(n.value)], q.value
 
 
 def count_genotypes(n_alleles, ploidy):

@@ -22,6 +22,14 @@ struct PairAlnDev {
 };
 static_assert(sizeof(PairAlnDev) == 24, "PairAlnDev layout");
 
+// BayesCalc<NBinom, NBinom> of one GC bin (src/model/distr_cache.rs:61-75): null hypothesis + alternatives, for the
+// direct evaluation of depths beyond the 256-entry LinearCache (src/math/distr/lincache.rs:41-48).
+struct DepthNB {
+    double lnq;                                  // ln(1 - p), shared by all hypotheses (NBinom::mul keeps p)
+    double n[LCTY_MAX_ALT_CN + 1];               // [0] = null (cn 1), then the alternatives
+    double lnpmf_const[LCTY_MAX_ALT_CN + 1];     // n ln p - lnGamma(n)
+};
+
 struct LocusView {
     uint32_t n_alleles, k;
     const uint32_t* allele_len;     // [A]
@@ -71,6 +79,7 @@ struct ReadsView {
     unsigned long long* pa_count;   // arena cursor
     uint64_t* pa_off;               // [R]
     uint32_t* pa_cnt;               // [R]
+    uint32_t* pa_idx;               // [R][A]: offset of the contig's entries inside the pair's arena segment | count << 24
     uint32_t* err_flag;             // first LCTY_ERR_* raised by a kernel
 };
 

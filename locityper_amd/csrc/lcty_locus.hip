@@ -88,6 +88,22 @@ __global__ void kset_compact_kernel(const uint64_t* __restrict__ big, uint64_t b
     }
 }
 
+// WeightCalculator::get (src/model/windows.rs:163-177) and ContigInfo::neighb_info (439-445) for every position
+__device__ inline double weight_calc(double breakpoint, double power, double x) {
+    const double const_fct = pow(breakpoint / (1.0 - breakpoint), power);
+    return 1.0 / (1.0 + const_fct * pow((1.0 - x) / x, power));
+}
+__global__ void window_weight_kernel(const uint32_t* __restrict__ uniq_cnt, const uint16_t* __restrict__ compl_cnt, uint64_t n,
+                                     double uniq_mult, double compl_mult, double kmers_bp, double kmers_pow,
+                                     double compl_bp, double compl_pow, double* __restrict__ out) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double w = 1.0;
+    if (kmers_bp > 0.0) w = weight_calc(kmers_bp, kmers_pow, static_cast<double>(uniq_cnt[i]) * uniq_mult);
+    if (compl_bp > 0.0) w = w * weight_calc(compl_bp, compl_pow, static_cast<double>(compl_cnt[i]) * compl_mult);
+    out[i] = w * 1.0;      // explicit weight == 1 (no --weights file)
+}
+
 static uint64_t next_pow2(uint64_t x) {
     uint64_t p = 1;
     while (p < x) p <<= 1;
@@ -283,6 +299,15 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
         L->d_compl_cnt.alloc(total_pos); L->d_compl_cnt.upload(L->compl_cnt.data(), total_pos, s);
         L->d_gc.alloc(total_pos); L->d_gc.upload(L->gc.data(), total_pos, s);
         L->d_uniq_cnt.alloc(total_pos); L->d_uniq_cnt.upload(L->uniq_cnt.data(), total_pos, s);
+        L->d_n_windows.alloc(n_alleles); L->d_n_windows.upload(L->n_windows.data(), n_alleles, s);
+        L->d_reg_start.alloc(n_alleles); L->d_reg_start.upload(L->reg_start.data(), n_alleles, s);
+        L->max_n_windows = *std::max_element(L->n_windows.begin(), L->n_windows.end());
+        L->d_win_weight.alloc(total_pos);
+        hipLaunchKernelGGL(window_weight_kernel, dim3(static_cast<uint32_t>((total_pos + 255) / 256)), dim3(256), 0, s,
+                           L->d_uniq_cnt.p, L->d_compl_cnt.p, total_pos, L->uniq_mult, L->compl_mult,
+                           params->kmers_weight_bp, params->kmers_weight_pow, params->compl_weight_bp, params->compl_weight_pow,
+                           L->d_win_weight.p);
+        LCTY_HIP(hipGetLastError());
 
         // ---- K1 (device) ----
         {
@@ -342,6 +367,16 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
             }
             L->d_depth_lut.alloc(lut.size());
             L->d_depth_lut.upload(lut.data(), lut.size(), s);
+            std::vector<DepthNB> nbs(LCTY_GC_BINS);
+            for (uint32_t gc = 0; gc < LCTY_GC_BINS; gc++) {
+                math::DepthDistr dd(*bg, *params, gc);
+                DepthNB& d = nbs[gc];
+                memset(&d, 0, sizeof(d));
+                d.lnq = dd.cn1.lnq; d.n[0] = dd.cn1.n; d.lnpmf_const[0] = dd.cn1.lnpmf_const;
+                for (size_t i = 0; i < dd.alts.size(); i++) { d.n[i + 1] = dd.alts[i].n; d.lnpmf_const[i + 1] = dd.alts[i].lnpmf_const; }
+            }
+            L->d_depth_nb.alloc(LCTY_GC_BINS);
+            L->d_depth_nb.upload(nbs.data(), LCTY_GC_BINS, s);
             LCTY_HIP(hipStreamSynchronize(s));
         }
         LCTY_HIP(hipStreamSynchronize(s));
@@ -390,6 +425,15 @@ int32_t lcty_locus_insert_lnprob(const lcty_locus* locus, uint32_t n, const uint
         for (uint32_t i = 0; i < n; i++)
             out[i] = sizes[i] < locus->ins_lut.size() ? locus->ins_lut[sizes[i]] : locus->ins.ln_pmf(sizes[i]);
         if (insert_penalty) *insert_penalty = locus->insert_penalty;
+    });
+}
+
+int32_t lcty_locus_window_weights(const lcty_locus* locus, double* out) {
+    return guarded([&] {
+        if (!locus || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        locus->ctx->activate();
+        locus->d_win_weight.download(out, locus->d_win_weight.n, locus->ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(locus->ctx->stream));
     });
 }
 

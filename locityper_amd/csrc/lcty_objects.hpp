@@ -45,6 +45,10 @@ struct lcty_locus {
     lcty::DevBuf<double> d_ins_lut;
     lcty::DevBuf<uint2> d_edit_lut;
     lcty::DevBuf<double> d_depth_lut;        // [101][256]
+    lcty::DevBuf<lcty::DepthNB> d_depth_nb;  // [101]
+    lcty::DevBuf<uint32_t> d_n_windows, d_reg_start;   // [A]
+    lcty::DevBuf<double> d_win_weight;       // per position: ContigInfo::neighb_info weight (windows.rs:439-445)
+    uint32_t max_n_windows = 0;
 
     lcty::LocusView view() const;
     // makes sure (good, passable) is known on the device for every length in `lens`
@@ -78,6 +82,12 @@ struct lcty_reads {
     lcty::DevBuf<unsigned long long> d_pa_count;
     lcty::DevBuf<uint64_t> d_pa_off;
     lcty::DevBuf<uint32_t> d_pa_cnt;
+    lcty::DevBuf<uint32_t> d_pa_idx;         // [R][A]
+    // solver stages: compact list of GOOD pairs (AllAlignments::reads order), built lazily after scoring
+    lcty::DevBuf<uint32_t> d_good_ix;
+    uint64_t n_good_cached = 0;
+    bool good_valid = false;
+    void ensure_good_index();
     lcty::DevBuf<uint32_t> d_err;
 
     // prefilter products

@@ -58,9 +58,24 @@ ReadsView lcty_reads::view() const {
     v.pair_meta = d_pair_meta.p;
     v.status = d_status.p; v.weight = d_weight.p; v.unmapped_prob = d_unmapped.p; v.uniq_kmers = d_uniq.p;
     v.matrix = d_matrix.p;
-    v.pa = d_pa.p; v.pa_cap = d_pa.n; v.pa_count = d_pa_count.p; v.pa_off = d_pa_off.p; v.pa_cnt = d_pa_cnt.p;
+    v.pa = d_pa.p; v.pa_cap = d_pa.n; v.pa_count = d_pa_count.p; v.pa_off = d_pa_off.p; v.pa_cnt = d_pa_cnt.p; v.pa_idx = d_pa_idx.p;
     v.err_flag = d_err.p;
     return v;
+}
+
+void lcty_reads::ensure_good_index() {
+    if (good_valid) return;
+    if (n_pairs >= 0xFFFFFFFFull) lcty::fail(LCTY_ERR_UNSUPPORTED, "more than 2^32 read pairs in one batch");
+    std::vector<uint8_t> status(n_pairs);
+    d_status.download(status.data(), n_pairs, ctx->stream);
+    LCTY_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> good;
+    for (uint64_t r = 0; r < n_pairs; r++) if (status[r] == LCTY_READ_GOOD) good.push_back(static_cast<uint32_t>(r));
+    d_good_ix.alloc(std::max<size_t>(good.size(), 1));
+    d_good_ix.upload(good.data(), good.size(), ctx->stream);
+    LCTY_HIP(hipStreamSynchronize(ctx->stream));
+    n_good_cached = good.size();
+    good_valid = true;
 }
 
 void lcty_reads::check_device_error() {
@@ -111,6 +126,7 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
         R->d_pa_count.alloc(1);
         R->d_pa_off.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_pa_cnt.alloc(std::max<uint64_t>(cap_pairs, 1));
+        R->d_pa_idx.alloc(std::max<uint64_t>(cap_pairs * A, 1));
         R->d_err.alloc(1);
         R->d_err.zero(ctx->stream);
         R->d_pa_count.zero(ctx->stream);
@@ -188,6 +204,7 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         R->max_recs_per_pair = max_recs;
         R->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
         R->scored = false;
+        R->good_valid = false;
     });
 }
 
@@ -210,6 +227,7 @@ int32_t lcty_score_reads(lcty_reads* reads) {
         reads->ctx->activate();
         if (reads->n_pairs) launch_score_reads(reads);
         reads->scored = true;
+        reads->good_valid = false;
     });
 }
 

@@ -740,6 +740,7 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
                     const uint32_t my_off = run + wave_excl_scan_u32(cnt, lane, &tot);
                     run += tot;
                     PairAlnDev* out = R.pa + pa_base + my_off;
+                    if (c < A) R.pa_idx[p * A + c] = my_off | (cnt << 24);      // direct (pair, contig) -> entries index
                     if (room && cnt && !general) {
                         const uint32_t hw = head32[c];
                         const Fast3 f = fast_candidates(ins, rec, hw & 0xFFFFu, hw >> 16, bl0, bl1, unm_ins_penalty, paired);

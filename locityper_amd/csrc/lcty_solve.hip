@@ -1,0 +1,736 @@
+// lcty_solve.hip — the solver stages of `locityper genotype` on gfx950.
+//
+// One 256-thread workgroup per (genotype, attempt) chain:
+//   K12  apply_tweak (src/model/assgn.rs:127-151): window distributions of the genotype in LDS
+//        (generate_windows, windows.rs:478-486; neighb_info 439-445; DistrCache::get_distribution 83-92)
+//   K11  GenotypeAlignments::new (assgn.rs:41-84) is NOT materialised: the possible locations of a read on the
+//        genotype (extend_read_gt_alns, windows.rs:762-797) are re-derived on demand from the per-(pair, contig)
+//        index the scoring kernel leaves behind — a merge of <= ploidy sorted runs plus "both unmapped".
+//   K13  ReadAssignment::try_new + recalc_likelihood (assgn.rs:199-226, 346-354): all 256 threads stream the
+//        reads once: initial location, depth histogram (LDS atomics), alignment likelihood, ordered list of
+//        non-trivial reads.
+//   K14  Greedy / SimAnneal (src/solvers/stoch.rs:81-120, 195-245) on wave 0: the chain itself is serial; the
+//        `sample_size` candidate reads of a greedy step are evaluated by different lanes.
+//
+// Randomness is the injected per-chain seed described in oracle/lcty_oracle.h (the reference's rand adaptors
+// are not in its tree): counter-based draws for tweaks / random starts, xoshiro256++ for the solver loop.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <numeric>
+
+#include "lcty_objects.hpp"
+
+namespace lcty {
+
+constexpr uint32_t MAXP = 4;                  // ploidy handled by the device solver
+constexpr uint32_t NONE32S = 0xFFFFFFFFu;
+constexpr uint64_t WINDOW_KEY_XOR = 0xD1B54A32D192ED03ull;
+constexpr uint64_t INIT_KEY_XOR = 0x8CB92BA72F3D8DD7ull;
+
+struct SolveView {
+    // locus
+    uint32_t A, window, left_padding, tweak;
+    double min_weight, prob_diff, depth_contrib, aln_contrib;
+    const uint32_t* n_windows;
+    const uint32_t* reg_start;
+    const uint32_t* allele_len;
+    const uint32_t* ci_off;
+    const uint8_t* gc;
+    const double* win_weight;
+    const double* depth_lut;
+    const DepthNB* depth_nb;
+    uint32_t n_alt;
+    // reads
+    const uint32_t* good_ix;
+    uint32_t n_good;
+    const double* unmapped;
+    const PairAlnDev* pa;
+    const uint64_t* pa_off;
+    const uint32_t* pa_idx;
+    // chains
+    const uint16_t* genotypes;      // [n_gt][ploidy]
+    uint32_t ploidy, attempts;
+    const uint64_t* seeds;          // [n_chains]
+    const double* priors;           // [n_gt] or null
+    lcty_solver solver;
+    uint16_t* state;                // [n_chains][n_good]  (number of locations << 8) | current location
+    uint32_t* non_trivial;          // [n_chains][n_good]
+    double* liks;                   // [n_chains] prior + likelihood
+    double* parts;                  // [n_chains][2] aln_lik, depth_lik (diagnostics)
+    uint32_t max_windows;           // LDS sizing: 2 + ploidy * max n_windows
+};
+
+// ---- randomness (definitions shared with oracle/lcty_oracle_solve.c) ----
+__device__ __forceinline__ uint64_t counter_u64(uint64_t key, uint64_t i) {
+    uint64_t z = key + (i + 1) * 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+struct Xoshiro {
+    uint64_t s0, s1, s2, s3;
+    __device__ __forceinline__ void seed(uint64_t x) {         // seed_from_u64: SplitMix64 fill (ext/rand.rs:3-22)
+        s0 = counter_u64(x, 0); s1 = counter_u64(x, 1); s2 = counter_u64(x, 2); s3 = counter_u64(x, 3);
+    }
+    __device__ __forceinline__ uint64_t next() {               // xoshiro256++
+        const uint64_t sum = s0 + s3;
+        const uint64_t result = ((sum << 23) | (sum >> 41)) + s0;
+        const uint64_t t = s1 << 17;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = (s3 << 45) | (s3 >> 19);
+        return result;
+    }
+    __device__ __forceinline__ uint64_t below(uint64_t n) { return __umul64hi(next(), n); }
+    __device__ __forceinline__ double f64() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+// ---- possible locations of one read on the genotype (extend_read_gt_alns, windows.rs:762-797) ----
+struct Locs {
+    const PairAlnDev* e[MAXP];
+    uint32_t n[MAXP];
+    double unm, thresh;
+    bool has_unm;
+    uint32_t nw;
+};
+
+__device__ __forceinline__ void locs_init(Locs& L, const SolveView& V, uint32_t r, const uint32_t ids[MAXP]) {
+    const uint64_t off = V.pa_off[r];
+    L.unm = V.unmapped[r];
+    double top = L.unm;
+#pragma unroll
+    for (uint32_t p = 0; p < MAXP; p++) {
+        L.n[p] = 0; L.e[p] = nullptr;
+        if (p < V.ploidy) {
+            const uint32_t idx = V.pa_idx[static_cast<uint64_t>(r) * V.A + ids[p]];
+            L.n[p] = idx >> 24;
+            L.e[p] = V.pa + off + (idx & 0xFFFFFFu);
+            if (L.n[p]) top = fmax(top, L.e[p][0].ln_prob);
+        }
+    }
+    L.thresh = top - V.prob_diff;          // max(unm - d, best_i - d, ...) == max(...) - d
+    L.nw = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < MAXP; p++) {
+        uint32_t k = 0;
+        while (k < L.n[p] && L.e[p][k].ln_prob >= L.thresh) k++;
+        L.n[p] = k;
+        L.nw += k;
+    }
+    L.has_unm = L.unm >= L.thresh;
+    L.nw += L.has_unm;
+}
+
+struct LocOut {
+    double lp;
+    uint32_t mid1, mid2, cix;              // cix 0xFF: both mates unmapped
+};
+
+// locations in decreasing ln_prob, ties in push order (contig_ix ascending, then "unmapped") — windows.rs:793
+struct LocIter {
+    uint32_t cur[MAXP];
+    bool unm_left;
+    __device__ __forceinline__ void start(const Locs& L) {
+#pragma unroll
+        for (uint32_t p = 0; p < MAXP; p++) cur[p] = 0;
+        unm_left = L.has_unm;
+    }
+    __device__ __forceinline__ bool next(const Locs& L, LocOut& o) {
+        double best = -INFINITY;
+        uint32_t bp = NONE32S;
+#pragma unroll
+        for (uint32_t p = 0; p < MAXP; p++) {
+            if (cur[p] < L.n[p]) {
+                const double lp = L.e[p][cur[p]].ln_prob;
+                if (bp == NONE32S || lp > best) { best = lp; bp = p; }
+            }
+        }
+        if (unm_left && (bp == NONE32S || L.unm > best)) {
+            unm_left = false;
+            o.lp = L.unm; o.mid1 = o.mid2 = NONE32S; o.cix = 0xFFu;
+            return true;
+        }
+        if (bp == NONE32S) return false;
+        PairAlnDev a;
+#pragma unroll
+        for (uint32_t p = 0; p < MAXP; p++)
+            if (p == bp) { a = L.e[p][cur[p]]; cur[p]++; }
+        o.lp = a.ln_prob; o.mid1 = a.mid1; o.mid2 = a.mid2; o.cix = bp;
+        return true;
+    }
+};
+
+struct GtWin {                             // GenotypeWindows (windows.rs:709-739) of this chain
+    uint32_t shift[MAXP], reg_start[MAXP], reg_end[MAXP];
+};
+
+// get_shifted_window_ix + middle_window (windows.rs:62-68, 465-470) with define_windows_random (123-136)
+__device__ __forceinline__ void loc_windows(const SolveView& V, const GtWin& G, const LocOut& o, uint64_t seed, uint32_t rp,
+                                            uint32_t t, uint32_t* w1, uint32_t* w2) {
+    if (o.cix == 0xFFu) { *w1 = 0; *w2 = 0; return; }
+    uint32_t t1 = 0, t2 = 0;
+    if (V.tweak) {
+        const uint64_t r = counter_u64(seed, (static_cast<uint64_t>(rp) << 16) | t);
+        t1 = static_cast<uint32_t>(r >> 32) % (2 * V.tweak + 1);
+        t2 = static_cast<uint32_t>(r) % (2 * V.tweak + 1);
+    }
+    uint32_t sh = 0, rs = 0, re = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < MAXP; p++) if (p == o.cix) { sh = G.shift[p]; rs = G.reg_start[p]; re = G.reg_end[p]; }
+    auto ix = [&](uint32_t mid, uint32_t tw) -> uint32_t {
+        if (mid == NONE32S) return 0u;                                       // UNMAPPED_WINDOW
+        const uint32_t m = mid + tw;
+        return (rs <= m && m < re) ? (m - rs) / V.window + sh : 1u;          // BOUNDARY_WINDOW
+    };
+    *w1 = ix(o.mid1, t1);
+    *w2 = ix(o.mid2, t2);
+}
+
+// BayesCalc::ln_pmf evaluated directly (depth >= 256): bayes.rs:27-35 with Ln::map_sum_init (math/mod.rs:80-94)
+__device__ __noinline__ double bayes_ln_pmf_direct(const DepthNB* nb, uint32_t n_alt, uint32_t depth) {
+    const double x = static_cast<double>(depth);
+    const double lg1 = lgamma(x + 1.0);
+    const double null_prob = nb->lnpmf_const[0] + lgamma(nb->n[0] + x) - lg1 + x * nb->lnq;
+    if (n_alt == 0) return null_prob - null_prob;
+    double v[LCTY_MAX_ALT_CN];
+    double m = null_prob;
+    for (uint32_t i = 0; i < n_alt; i++) {
+        v[i] = nb->lnpmf_const[i + 1] + lgamma(nb->n[i + 1] + x) - lg1 + x * nb->lnq;
+        m = fmax(m, v[i]);
+    }
+    double sum_prob;
+    if (n_alt == 1) {                                                       // Ln::add (math/mod.rs:29-35)
+        const double a = null_prob, b = v[0];
+        if (a >= b) sum_prob = b == -INFINITY ? a : b + log1p(exp(a - b));
+        else sum_prob = a == -INFINITY ? b : a + log1p(exp(b - a));
+    } else if (isinf(m)) {
+        sum_prob = m;
+    } else {
+        double s = exp(null_prob - m);
+        for (uint32_t i = 0; i < n_alt; i++) s += exp(v[i] - m);
+        sum_prob = m + log(s);
+    }
+    return null_prob - sum_prob;
+}
+
+struct Chain {
+    const SolveView* V;
+    const uint32_t* depth;      // LDS
+    const uint8_t* wgc;         // LDS
+    const double* ww;           // LDS
+    // WindowDistr::ln_prob (distr_cache.rs:34-39) through LinearCache (lincache.rs:41-48)
+    __device__ __forceinline__ double wlp(uint32_t w, uint32_t d) const {
+        const double weight = ww[w];
+        if (weight == 0.0) return 0.0;                                      // WindowDistr::TRIVIAL
+        const uint32_t g = wgc[w];
+        const double v = d < LCTY_DEPTH_CACHE ? V->depth_lut[g * LCTY_DEPTH_CACHE + d]
+                                              : bayes_ln_pmf_direct(V->depth_nb + g, V->n_alt, d);
+        return weight * v;
+    }
+    __device__ __forceinline__ double atomic_diff(uint32_t w, int32_t c) const {     // assgn.rs:244-254
+        if (c == 0) return 0.0;
+        const uint32_t old_depth = depth[w];
+        return wlp(w, static_cast<uint32_t>(static_cast<int32_t>(old_depth) + c)) - wlp(w, old_depth);
+    }
+    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {   // assgn.rs:259-284
+        int32_t c1 = -1, c2, c3, c4;
+        if (w2 == w1) { c1 -= 1; c2 = 0; } else c2 = -1;
+        if (w3 == w1) { c1 += 1; c3 = 0; } else if (w3 == w2) { c2 += 1; c3 = 0; } else c3 = 1;
+        if (w4 == w1) { c1 += 1; c4 = 0; } else if (w4 == w2) { c2 += 1; c4 = 0; } else if (w4 == w3) { c3 += 1; c4 = 0; } else c4 = 1;
+        return atomic_diff(w1, c1) + atomic_diff(w2, c2) + atomic_diff(w3, c3) + atomic_diff(w4, c4);
+    }
+};
+
+struct Move {                  // ReassignmentTarget + what reassign() needs
+    uint32_t rp, new_assgn;
+    uint32_t w1, w2, w3, w4;
+    double lp_old, lp_new;
+};
+
+// location `t` (and optionally `t2`) of read rp: ln_prob + tweaked windows
+__device__ __forceinline__ void fetch_two(const SolveView& V, const GtWin& G, const Locs& L, uint64_t seed, uint32_t rp, uint32_t ta,
+                                          uint32_t tb, Move& m) {
+    LocIter it; it.start(L);
+    LocOut o;
+    for (uint32_t t = 0; t < L.nw && it.next(L, o); t++) {
+        if (t == ta) { m.lp_old = o.lp; loc_windows(V, G, o, seed, rp, t, &m.w1, &m.w2); }
+        if (t == tb) { m.lp_new = o.lp; loc_windows(V, G, o, seed, rp, t, &m.w3, &m.w4); }
+        if (t >= ta && t >= tb) break;
+    }
+}
+
+__global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t W = V.max_windows;
+    double* ww = reinterpret_cast<double*>(smem);                       // [W]
+    uint32_t* depth = reinterpret_cast<uint32_t*>(ww + W);              // [W]
+    uint8_t* wgc = reinterpret_cast<uint8_t*>(depth + W);               // [W]
+    double* red = reinterpret_cast<double*>(smem + ((W * 13 + 15) & ~15u));   // [256] reduction scratch
+    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(red + 256);        // [8]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t chain = blockIdx.x;
+    const uint32_t gi = chain / V.attempts;
+    const uint64_t seed = V.seeds[chain];
+    uint32_t ids[MAXP];
+    GtWin G;
+    uint32_t total_w = 2;                                               // REG_WINDOW_SHIFT
+#pragma unroll
+    for (uint32_t p = 0; p < MAXP; p++) {
+        ids[p] = 0; G.shift[p] = G.reg_start[p] = G.reg_end[p] = 0;
+        if (p < V.ploidy) {
+            ids[p] = V.genotypes[static_cast<uint64_t>(gi) * V.ploidy + p];
+            G.shift[p] = total_w;
+            G.reg_start[p] = V.reg_start[ids[p]];
+            const uint32_t nw = V.n_windows[ids[p]];
+            G.reg_end[p] = G.reg_start[p] + nw * V.window;
+            total_w += nw;
+        }
+    }
+    uint16_t* state = V.state + static_cast<uint64_t>(chain) * V.n_good;
+    uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.n_good;
+
+    // ---------------- K12: window distributions (apply_tweak, assgn.rs:140-150) ----------------
+    for (uint32_t w = tid; w < total_w; w += 256) {
+        depth[w] = 0;
+        double weight = 0.0; uint32_t g = 0;
+        if (w >= 2) {
+            uint32_t p = 0;
+#pragma unroll
+            for (uint32_t q = 1; q < MAXP; q++) if (q < V.ploidy && w >= G.shift[q]) p = q;
+            uint32_t allele = 0, sh = 0, rs = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < MAXP; q++) if (q == p) { allele = ids[q]; sh = G.shift[q]; rs = G.reg_start[q]; }
+            const uint32_t start = rs + (w - sh) * V.window, end = start + V.window;
+            const uint32_t left = min(V.tweak, start), right = min(V.tweak, V.allele_len[allele] - end);
+            const uint64_t r = counter_u64(seed ^ WINDOW_KEY_XOR, w);                 // rng.random_range(-left..=right)
+            const int64_t off = -static_cast<int64_t>(left) + static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(left + right + 1)));
+            const uint32_t wstart = static_cast<uint32_t>(static_cast<int64_t>(start) + off);
+            const uint32_t i = V.ci_off[allele] + (wstart > V.left_padding ? wstart - V.left_padding : 0u);
+            weight = V.win_weight[i];
+            g = V.gc[i];
+            if (weight < V.min_weight || weight < 1e-7) { weight = 0.0; g = 0; }      // assgn.rs:144-148, distr_cache.rs:84
+        }
+        ww[w] = weight; wgc[w] = static_cast<uint8_t>(g);
+    }
+    __syncthreads();
+
+    // ---------------- K13: initial assignment, depth histogram, non-trivial reads ----------------
+    const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
+    double aln_part = 0.0;
+    uint32_t nt_total = 0;
+    for (uint32_t base = 0; base < V.n_good; base += 256) {
+        const uint32_t rp = base + tid;
+        bool nontrivial = false;
+        if (rp < V.n_good) {
+            const uint32_t r = V.good_ix[rp];
+            Locs L; locs_init(L, V, r, ids);
+            uint32_t a0 = 0;
+            if (L.nw > 1 && random_start)
+                a0 = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
+            Move m; m.w1 = m.w2 = 0; m.lp_old = 0.0;
+            fetch_two(V, G, L, seed, rp, a0, a0, m);
+            atomicAdd(&depth[m.w1], 1u);
+            atomicAdd(&depth[m.w2], 1u);
+            aln_part += m.lp_old;
+            state[rp] = static_cast<uint16_t>((min(L.nw, 255u) << 8) | a0);
+            nontrivial = L.nw > 1;
+        }
+        // ordered compaction of the non-trivial reads (assgn.rs:61-63)
+        const unsigned long long bal = __ballot(nontrivial);
+        if (lane == 0) wave_cnt[wave] = static_cast<uint32_t>(__popcll(bal));
+        __syncthreads();
+        uint32_t before = nt_total;
+        for (uint32_t q = 0; q < wave; q++) before += wave_cnt[q];
+        if (nontrivial) nontriv[before + static_cast<uint32_t>(__popcll(bal & ((1ull << lane) - 1ull)))] = rp;
+        nt_total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    red[tid] = aln_part;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    double aln_lik = red[0];
+    __syncthreads();
+    Chain C{&V, depth, wgc, ww};
+    // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
+    double dl = 0.0;
+    for (uint32_t w = tid; w < total_w; w += 256) dl += C.wlp(w, depth[w]);
+    red[tid] = dl;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    double depth_lik = red[0];
+    __threadfence_block();
+    __syncthreads();
+    if (wave != 0) return;
+
+    // ---------------- K14: the solver chain on wave 0 ----------------
+    const uint32_t nnt = nt_total;
+    uint32_t* depth_rw = depth;
+    Xoshiro rng; rng.seed(seed);
+    const double rel_contrib = V.depth_contrib / V.aln_contrib;
+
+    auto load_state = [&](uint32_t rp) -> uint32_t {
+        return __hip_atomic_load(&state[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // ReassignmentTarget::random (assgn.rs:451-471); wave-uniform
+    auto random_move = [&](Move& m) {
+        const uint32_t rp = nontriv[rng.below(nnt)];
+        const uint32_t st = load_state(rp);
+        const uint32_t total = st >> 8, old_assgn = st & 0xFFu;
+        uint32_t new_assgn;
+        if (total == 2) new_assgn = 1 - old_assgn;
+        else {
+            const uint32_t i = 1 + static_cast<uint32_t>(rng.below(total - 1));
+            new_assgn = i <= old_assgn ? i - 1 : i;
+        }
+        m.rp = rp; m.new_assgn = new_assgn;
+        Locs L; locs_init(L, V, V.good_ix[rp], ids);
+        fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
+    };
+    auto improvement = [&](const Move& m) -> double {                         // calculate_improvement (assgn.rs:321-328)
+        return V.depth_contrib * C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4) + V.aln_contrib * (m.lp_new - m.lp_old);
+    };
+    auto reassign = [&](const Move& m) {                                      // assgn.rs:331-343 (wave-uniform move)
+        depth_lik += C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+        aln_lik += m.lp_new - m.lp_old;
+        if (lane == 0) {
+            depth_rw[m.w3] += 1; depth_rw[m.w4] += 1;
+            depth_rw[m.w1] -= 1; depth_rw[m.w2] -= 1;
+            const uint32_t st = load_state(m.rp);
+            __hip_atomic_store(&state[m.rp], static_cast<uint16_t>((st & 0xFF00u) | m.new_assgn), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    if (nnt > 0) {
+        // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
+        double max_abs = 0.0;
+        for (uint32_t i = 0; i < 100; i++) {
+            Move m; random_move(m);
+            max_abs = fmax(max_abs, fabs(improvement(m)));
+        }
+        const double min_diff = fmax(1e-10 * max_abs, 1e-14);                 // minimum_allowed_diff (stoch.rs:27-29)
+        const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
+        if (V.solver.kind == LCTY_SOLVER_GREEDY) {
+            const uint32_t sample_size = min(V.solver.sample_size, nnt);
+            uint32_t curr_plato = 0;
+            for (uint64_t iter = 0; iter < max_iter; iter++) {
+                // non_trivial_reads.sample(rng, sample_size): distinct indices, repeats rejected (our adaptor);
+                // lane j keeps the j-th pick
+                uint32_t my_pick = NONE32S;
+                for (uint32_t j = 0; j < sample_size; j++) {
+                    uint32_t idx;
+                    bool dup;
+                    do {
+                        idx = static_cast<uint32_t>(rng.below(nnt));
+                        dup = __ballot(lane < j && my_pick == idx) != 0ull;
+                    } while (dup);
+                    if (lane == j) my_pick = idx;
+                }
+                // best_read_improvement (assgn.rs:287-317), one candidate read per lane
+                double my_improv = -INFINITY;
+                Move mm; mm.rp = 0; mm.new_assgn = 0; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
+                if (lane < sample_size) {
+                    const uint32_t rp = nontriv[my_pick];
+                    const uint32_t st = load_state(rp);
+                    const uint32_t old_assgn = st & 0xFFu;
+                    Locs L; locs_init(L, V, V.good_ix[rp], ids);
+                    Move cur; cur.w1 = cur.w2 = 0; cur.lp_old = 0.0;
+                    fetch_two(V, G, L, seed, rp, old_assgn, old_assgn, cur);
+                    double best_improv = -INFINITY;
+                    LocIter it; it.start(L);
+                    LocOut o;
+                    for (uint32_t t = 0; t < L.nw && it.next(L, o); t++) {
+                        if (t == old_assgn) continue;
+                        uint32_t w3, w4;
+                        loc_windows(V, G, o, seed, rp, t, &w3, &w4);
+                        const double improv = o.lp + rel_contrib * C.depth_lik_diff(cur.w1, cur.w2, w3, w4);
+                        if (improv > best_improv) {
+                            best_improv = improv;
+                            mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = o.lp;
+                        }
+                    }
+                    mm.rp = rp; mm.w1 = cur.w1; mm.w2 = cur.w2; mm.lp_old = cur.lp_old;
+                    my_improv = V.aln_contrib * (best_improv - cur.lp_old);
+                }
+                // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
+                double best = my_improv;
+                for (int o2 = 32; o2 > 0; o2 >>= 1) best = fmax(best, __shfl_xor(best, o2));
+                const unsigned long long who = __ballot(lane < sample_size && my_improv == best);
+                if (best > min_diff && who) {
+                    const int src = __ffsll(static_cast<long long>(who)) - 1;
+                    Move m;
+                    m.rp = __shfl(mm.rp, src); m.new_assgn = __shfl(mm.new_assgn, src);
+                    m.w1 = __shfl(mm.w1, src); m.w2 = __shfl(mm.w2, src); m.w3 = __shfl(mm.w3, src); m.w4 = __shfl(mm.w4, src);
+                    m.lp_old = __shfl(mm.lp_old, src); m.lp_new = __shfl(mm.lp_new, src);
+                    curr_plato = 0;
+                    reassign(m);
+                } else {
+                    curr_plato++;
+                    if (curr_plato > V.solver.plato_size) break;
+                }
+            }
+        } else {
+            // SimAnneal::solve_nontrivial (stoch.rs:195-245)
+            const double start_temp = fmax(-max_abs / log(V.solver.init_prob), 1e-5);
+            const double temp_step = start_temp / static_cast<double>(V.solver.anneal_steps);
+            uint32_t curr_plato = 0;
+            for (uint32_t i = V.solver.anneal_steps; i >= 1; i--) {
+                Move m; random_move(m);
+                const double diff = improvement(m) - min_diff;
+                bool accept = diff >= 0.0;
+                if (!accept) accept = rng.f64() <= exp(diff / (temp_step * static_cast<double>(i)));
+                if (accept) { reassign(m); curr_plato = 0; }
+                else { curr_plato++; if (curr_plato >= V.solver.plato_size) break; }
+            }
+            for (uint64_t iter = 0; iter < max_iter; iter++) {
+                if (curr_plato >= V.solver.plato_size) break;
+                Move m; random_move(m);
+                const double diff = improvement(m);
+                if (diff > min_diff) { reassign(m); curr_plato = 0; } else curr_plato++;
+            }
+        }
+    }
+    if (lane == 0) {
+        const double lik = V.depth_contrib * depth_lik + V.aln_contrib * aln_lik;       // assgn.rs:235-237
+        V.liks[chain] = (V.priors ? V.priors[gi] : 0.0) + lik;                          // solve.rs:827
+        V.parts[2 * chain] = aln_lik; V.parts[2 * chain + 1] = depth_lik;
+    }
+}
+
+}  // namespace lcty
+
+using namespace lcty;
+
+// ---------------------------------------------------------------- host: K15 and the stage driver
+namespace {
+
+double students_t_cdf(double freedom, double x) {         // statrs StudentsT::cdf (location 0, scale 1)
+    if (std::isinf(freedom)) return 0.5 * std::erfc(-x / std::sqrt(2.0));
+    const double h = freedom / (freedom + x * x);
+    const double ib = 0.5 * math::beta_reg(freedom / 2.0, 0.5, h);
+    return x <= 0.0 ? ib : 1.0 - ib;
+}
+
+// compare_two_likelihoods (src/solvers/solve.rs:319-336) with the Welch tests of src/math/mod.rs:180-220
+double compare_two(double mean1, double var1, uint32_t att1, double mean2, double var2, uint32_t att2) {
+    const double simple_norm = mean1 - math::ln_add(mean1, mean2);
+    if (std::isnormal(var1) && std::isnormal(var2)) {
+        double t_pval;
+        if (att1 == att2) {
+            const double n = att1, var_sum = var1 + var2;
+            const double t_stat = (mean1 - mean2) * std::sqrt(n / var_sum);
+            const double freedom = (n - 1.0) * var_sum * var_sum / (var1 * var1 + var2 * var2);
+            t_pval = students_t_cdf(freedom, t_stat);
+        } else {
+            const double n1 = att1, n2 = att2, nv1 = var1 / n1, nv2 = var2 / n2, sum = nv1 + nv2;
+            const double t_stat = (mean1 - mean2) / std::sqrt(sum);
+            const double freedom = sum * sum / (nv1 * nv1 / (n1 - 1.0) + nv2 * nv2 / (n2 - 1.0));
+            t_pval = students_t_cdf(freedom, t_stat);
+        }
+        return std::fmax(simple_norm, std::log(t_pval));
+    }
+    return simple_norm;
+}
+
+void sort_by_mean(const double* lik_mean, uint64_t* ixs, uint64_t n) {      // sort_indices (solve.rs:418-423)
+    std::sort(ixs, ixs + n, [&](uint64_t a, uint64_t b) {
+        if (lik_mean[a] != lik_mean[b]) return lik_mean[a] > lik_mean[b];
+        return a < b;
+    });
+}
+
+double ln_sum(const double* v, size_t n) {                // Ln::map_sum (math/mod.rs:62-76)
+    if (n == 0) return -std::numeric_limits<double>::infinity();
+    if (n == 1) return v[0];
+    double m = -std::numeric_limits<double>::infinity();
+    for (size_t i = 0; i < n; i++) m = std::fmax(m, v[i]);
+    if (std::isinf(m)) return m;
+    double s = 0.0;
+    for (size_t i = 0; i < n; i++) s += std::exp(v[i] - m);
+    return m + std::log(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Greedy::default / SimAnneal::default (src/solvers/stoch.rs:45-52, 161-168)
+int32_t lcty_solver_default(lcty_solver* s, int32_t kind) {
+    return guarded([&] {
+        if (!s || (kind != LCTY_SOLVER_GREEDY && kind != LCTY_SOLVER_ANNEAL)) fail(LCTY_ERR_INVALID_INPUT, "unknown solver kind");
+        memset(s, 0, sizeof(*s));
+        s->kind = kind; s->best_start = 1; s->sample_size = 10;
+        s->plato_size = kind == LCTY_SOLVER_GREEDY ? 100 : 10000;
+        s->anneal_steps = 20000; s->init_prob = 0.5;
+    });
+}
+
+// one chain seed per (genotype, attempt): consecutive next_u64() of Xoshiro256PlusPlus::seed_from_u64(master_seed)
+int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out) {
+    return guarded([&] {
+        if (!out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        uint64_t x = master_seed, s[4];
+        for (int i = 0; i < 4; i++) {
+            uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            s[i] = z ^ (z >> 31);
+        }
+        auto rotl = [](uint64_t v, int k) { return (v << k) | (v >> (64 - k)); };
+        for (uint64_t i = 0; i < n; i++) {
+            out[i] = rotl(s[0] + s[3], 23) + s[0];
+            const uint64_t t = s[1] << 17;
+            s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        }
+    });
+}
+
+int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
+                         const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                         double* lik_mean, double* lik_var, double* liks_out) {
+    return guarded([&] {
+        if (!reads || !genotypes || !solver || !chain_seeds || !lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
+        if (ploidy == 0 || ploidy > MAXP) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles ploidy 1..%u", MAXP);
+        if (attempts == 0) fail(LCTY_ERR_INVALID_INPUT, "At least one attempt is required for each stage");
+        if (solver->kind == LCTY_SOLVER_ANNEAL && !(solver->init_prob > 0.0 && solver->init_prob <= 1.0))
+            fail(LCTY_ERR_INVALID_INPUT, "Initial probability (%g) must be within (0, 1]", solver->init_prob);
+        if (solver->kind == LCTY_SOLVER_ANNEAL && solver->anneal_steps == 0) fail(LCTY_ERR_INVALID_INPUT, "Number of annealing steps must be positive");
+        if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size == 0) fail(LCTY_ERR_INVALID_INPUT, "Sample size must be positive");
+        if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size > 64) fail(LCTY_ERR_UNSUPPORTED, "greedy sample size above 64");
+        lcty_ctx* ctx = reads->ctx;
+        lcty_locus* loc = reads->locus;
+        ctx->activate();
+        reads->check_device_error();
+        reads->ensure_good_index();
+        const uint32_t A = loc->n_alleles;
+        for (uint64_t i = 0; i < n_gt * ploidy; i++)
+            if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
+        const uint64_t n_good = reads->n_good_cached;
+        hipStream_t s = ctx->stream;
+
+        SolveView V{};
+        V.A = A; V.window = loc->bg.window; V.left_padding = loc->left_padding; V.tweak = static_cast<uint32_t>(loc->prm.tweak);
+        V.min_weight = loc->prm.min_weight; V.prob_diff = loc->prm.prob_diff;
+        V.depth_contrib = 1.0 + loc->prm.lik_skew; V.aln_contrib = 1.0 - loc->prm.lik_skew;      // assgn.rs:80-81
+        V.n_windows = loc->d_n_windows.p; V.reg_start = loc->d_reg_start.p; V.allele_len = loc->d_allele_len.p;
+        V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
+        V.depth_lut = loc->d_depth_lut.p; V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
+        V.good_ix = reads->d_good_ix.p; V.n_good = static_cast<uint32_t>(n_good);
+        V.unmapped = reads->d_unmapped.p; V.pa = reads->d_pa.p; V.pa_off = reads->d_pa_off.p; V.pa_idx = reads->d_pa_idx.p;
+        V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
+        V.max_windows = 2 + ploidy * loc->max_n_windows;
+        const size_t lds = ((static_cast<size_t>(V.max_windows) * 13 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
+        if (lds > 160 * 1024) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype do not fit in LDS", V.max_windows);
+        if (lds > 48 * 1024)
+            LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_chain_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+
+        // chains are processed in batches so that the per-chain state (6 B per good read) stays bounded
+        const uint64_t per_chain = std::max<uint64_t>(n_good, 1) * 6;
+        const uint64_t budget = 24ull << 30;
+        const uint64_t gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
+        DevBuf<uint16_t> d_gt, d_state; DevBuf<uint32_t> d_nt; DevBuf<uint64_t> d_seeds; DevBuf<double> d_pri, d_liks, d_parts;
+        const uint64_t max_chains = gt_per_batch * attempts;
+        d_state.alloc(max_chains * std::max<uint64_t>(n_good, 1));
+        d_nt.alloc(max_chains * std::max<uint64_t>(n_good, 1));
+        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(2 * max_chains);
+        if (priors) d_pri.alloc(gt_per_batch);
+        std::vector<double> liks(max_chains);
+        for (uint64_t g0 = 0; g0 < n_gt; g0 += gt_per_batch) {
+            const uint64_t ng = std::min(gt_per_batch, n_gt - g0), nch = ng * attempts;
+            d_gt.upload(genotypes + g0 * ploidy, ng * ploidy, s);
+            d_seeds.upload(chain_seeds + g0 * attempts, nch, s);
+            if (priors) d_pri.upload(priors + g0, ng, s);
+            V.genotypes = d_gt.p; V.seeds = d_seeds.p; V.priors = priors ? d_pri.p : nullptr;
+            V.state = d_state.p; V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
+            ctx->timed(LCTY_K_SOLVE, [&] {
+                hipLaunchKernelGGL(solve_chain_kernel, dim3(static_cast<uint32_t>(nch)), dim3(256), lds, s, V);
+            });
+            LCTY_HIP(hipGetLastError());
+            d_liks.download(liks.data(), nch, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            for (uint64_t g = 0; g < ng; g++) {
+                // mean_variance_or_nan (src/ext/vec.rs:74-116)
+                const double* l = liks.data() + g * attempts;
+                double sum = -0.0;
+                for (uint32_t a = 0; a < attempts; a++) sum += l[a];
+                const double mean = sum / static_cast<double>(attempts);
+                double var = std::numeric_limits<double>::quiet_NaN();
+                if (attempts > 1) {
+                    double acc = 0.0;
+                    for (uint32_t a = 0; a < attempts; a++) { const double d = l[a] - mean; acc += d * d; }
+                    var = acc / static_cast<double>(attempts - 1);
+                }
+                lik_mean[g0 + g] = mean; lik_var[g0 + g] = var;
+                if (liks_out) memcpy(liks_out + (g0 + g) * attempts, l, sizeof(double) * attempts);
+            }
+        }
+    });
+}
+
+// discard_improbable_genotypes (src/solvers/solve.rs:425-480): ixs in/out, *n_keep = new count
+int32_t lcty_discard_improbable(const double* lik_mean, const double* lik_var, const uint32_t* attempts, uint64_t* ixs, uint64_t n,
+                                double prob_thresh, uint64_t out_size, uint64_t threads, uint64_t* n_keep) {
+    return guarded([&] {
+        if (!lik_mean || !lik_var || !attempts || !ixs || !n_keep) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        out_size = std::max(out_size, threads);
+        if (prob_thresh == -std::numeric_limits<double>::infinity() || out_size >= n) { *n_keep = n; return; }
+        sort_by_mean(lik_mean, ixs, n);
+        const uint64_t best = ixs[0];
+        uint64_t m = out_size;
+        if (out_size <= 500) {                          // SOPHISTICATED_COUNT
+            uint32_t dropped = 0;
+            for (uint64_t t = out_size; t < n; t++) {
+                const uint64_t ix = ixs[t];
+                const double ln_pval = compare_two(lik_mean[ix], lik_var[ix], attempts[ix], lik_mean[best], lik_var[best], attempts[best]);
+                if (ln_pval >= prob_thresh) ixs[m++] = ix;
+                else if (++dropped >= 5) break;         // STOP_COUNT
+            }
+        }
+        *n_keep = m;
+    });
+}
+
+// produce_result (src/solvers/solve.rs:482-535): out arrays sized >= min(n, 50)
+int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const uint32_t* attempts, const uint64_t* ixs_in, uint64_t n_in,
+                            double prob_thresh, uint64_t out_bams, uint64_t* out_ixs, double* out_ln_probs, uint64_t* n_out,
+                            double* quality) {
+    return guarded([&] {
+        if (!lik_mean || !lik_var || !attempts || !ixs_in || !out_ixs || !out_ln_probs || !n_out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (n_in == 0) fail(LCTY_ERR_INVALID_INPUT, "no genotypes");
+        const double THRESH = -11.512925464970229;
+        const uint64_t min_output = std::max<uint64_t>(4, out_bams);
+        const double thresh_prob = std::fmin(THRESH, prob_thresh);
+        std::vector<uint64_t> ixs(ixs_in, ixs_in + n_in);
+        sort_by_mean(lik_mean, ixs.data(), n_in);
+        uint64_t n = std::min<uint64_t>(n_in, 50);      // MAX_GENOTYPES
+        std::vector<double> ln_probs(n, 0.0);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t u = ixs[i];
+            for (uint64_t j = i + 1; j < n; j++) {
+                const uint64_t v = ixs[j];
+                const double prob_j = compare_two(lik_mean[v], lik_var[v], attempts[v], lik_mean[u], lik_var[u], attempts[u]);
+                if (i == 0 && j >= min_output && prob_j < thresh_prob) { n = j; break; }
+                ln_probs[i] += std::log1p(-std::exp(prob_j));
+                ln_probs[j] += prob_j;
+            }
+        }
+        const double norm = ln_sum(ln_probs.data(), n);
+        for (uint64_t t = 0; t < n; t++) { out_ixs[t] = ixs[t]; out_ln_probs[t] = ln_probs[t] - norm; }
+        *n_out = n;
+        if (quality) {
+            std::vector<double> rest(out_ln_probs + (n ? 1 : 0), out_ln_probs + n);
+            *quality = std::fmin(-10.0 * (ln_sum(rest.data(), rest.size()) * 0.4342944819032518277), 1e9);   // Phred::from_ln_prob
+        }
+    });
+}
+
+}  // extern "C"
