@@ -296,3 +296,50 @@ def truncate_ixs(scores, ixs, filt_diff, min_size, threads):
     keep = U64()
     check(lib().lcty_truncate(scores.ctypes.data, ixs.ctypes.data, len(ixs), filt_diff, min_size, threads, C.byref(keep)))
     return ixs[:int(keep.value)]
+
+
+# ---------------------------------------------------------------- solve::solve (src/solvers/solve.rs:926-981)
+DEFAULT_SCHEME = (("greedy", 5000, 1), ("anneal", 20, 20))      # "-S greedy:i=5k,a=1 -S anneal:i=20,a=20" (solve.rs:211-230)
+
+
+def solve(aa, params, scheme=DEFAULT_SCHEME, master_seed=1, priors=None, ploidy=2, genotypes=None, solvers=None):
+    """The genotyping of one locus after AllAlignments::load, following solve::solve + solve_single_thread:
+    run_filter/truncate_ixs when there are more genotypes than the first stage takes, then every stage
+    (skipped when the survivors already fit the next stage's input, solve.rs:805-809) with
+    discard_improbable_genotypes in between, and produce_result at the end.
+
+    Returns dict(genotypes, ln_probs, quality, lik_mean, lik_var, attempts, kept_per_stage)."""
+    A = aa.locus.n_alleles
+    gts = generate_genotypes(A, ploidy) if genotypes is None else np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n = len(gts)
+    pri = np.zeros(n) if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    ixs = np.arange(n, dtype=np.uint64)
+    threads = 1           # chains are independent on the GPU: the reference's `threads` floor on kept genotypes is 1
+    kept = []
+    if params.dont_skip or scheme[0][1] < n:
+        if genotypes is None:
+            scores = aa.run_filter(ploidy=ploidy)
+            scores = scores + pri
+        else:
+            scores = aa.run_filter(gts, pri)
+        ixs = truncate_ixs(scores, ixs, params.filt_diff, scheme[0][1], threads)
+        kept.append(len(ixs))
+    lik_mean = np.full(n, np.nan)
+    lik_var = np.full(n, np.nan)
+    att = np.zeros(n, dtype=np.uint32)
+    seed_base = 0
+    all_seeds = None
+    for si, (name, in_size, attempts) in enumerate(scheme):
+        out_size = scheme[si + 1][1] if si + 1 < len(scheme) else None
+        if not (params.dont_skip or out_size is None or out_size < len(ixs)):
+            continue                                               # "Skipping stage, not enough genotypes"
+        solver = solvers[si] if solvers else default_solver(cdefs.SOLVER_GREEDY if name == "greedy" else cdefs.SOLVER_ANNEAL)
+        seeds = chain_seeds(master_seed + 0x9E3779B97F4A7C15 * (si + 1) & 0xFFFFFFFFFFFFFFFF, len(ixs) * attempts)
+        m, v, _ = solve_stage(aa, gts[ixs], solver, attempts, seeds, priors=pri[ixs])
+        lik_mean[ixs], lik_var[ixs], att[ixs] = m, v, attempts
+        if out_size is not None:
+            ixs = discard_improbable(lik_mean, lik_var, att, ixs, params.prob_thresh, out_size, threads)
+        kept.append(len(ixs))
+    out_ixs, ln_probs, quality = produce_result(lik_mean, lik_var, att, ixs, params.prob_thresh)
+    return dict(genotypes=gts[out_ixs], ixs=out_ixs, ln_probs=ln_probs, quality=quality, lik_mean=lik_mean, lik_var=lik_var,
+                attempts=att, kept_per_stage=kept)

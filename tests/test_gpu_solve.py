@@ -1,0 +1,153 @@
+"""GPU solver stages (through the C ABI) against the oracle. The oracle is fed the GPU's own tables and
+AllAlignments products (test hooks), so every chain sees bit-identical inputs and must follow the same
+trajectory; likelihoods then differ only by the order of two big sums."""
+import numpy as np
+import pytest
+
+from locityper_amd import _lib, api, cdefs, synth
+from tests import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(ctx, n_alleles, n_pairs, base_len, seed=31, tech=cdefs.TECH_ILLUMINA, read_len=150, **prm):
+    L = synth.SynthLocus(n_alleles, n_pairs, seed=seed, base_len=base_len, technology=tech, read_len=read_len)
+    p = api.default_params()
+    for k, v in prm.items():
+        setattr(p, k, v)
+    api.resolve_params(p, L.bg)
+    loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    aa = api.AllAlignments.load(loc, L.reads(0, n_pairs))
+    st, w, unm, uk = aa.status()
+    off, pa = aa.pair_alns()
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ol.inject_tables(loc.depth_lut(), loc.window_weights())
+    oa = O.alns_from_arrays(n_alleles, st, w, unm, off, pa)
+    return L, p, loc, aa, ol, oa
+
+
+def compare_stage(aa, ol, oa, gts, solver, attempts, seeds, priors=None):
+    gm, gv, gl = api.solve_stage(aa, gts, solver, attempts, seeds, priors)
+    om, ov, olk = O.solve_stage(ol, oa, gts, solver, attempts, seeds, priors)
+    assert np.abs(gl - olk).max() <= 1e-9 * np.abs(olk).max()            # same trajectories, f64 sums in another order
+    assert np.allclose(gm, om, rtol=1e-9) and np.allclose(gv, ov, rtol=1e-6, atol=1e-9, equal_nan=True)
+    return gm, gv, gl
+
+
+def test_window_weight_table(gpu_ctx):
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 6, 500, 8000)
+    ol2 = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)       # without injection
+    ww = loc.window_weights()
+    import ctypes as C
+    pos = 0
+    for a in range(6):
+        npos = int(L.seq_off[a + 1] - L.seq_off[a]) - L.bg.neighb + 1
+        left = (L.bg.neighb - L.bg.window) // 2
+        for i in (0, 7, npos // 2, npos - 1):
+            want = O.lib().orc_window_weight(ol2._h, a, i + left, None)
+            assert abs(ww[pos + i] - want) <= 1e-12 * max(1.0, want)
+        pos += npos
+    assert 0.0 <= ww.min() and ww.max() <= 1.0
+
+
+@pytest.mark.parametrize("n_alleles,n_pairs,base_len,n_gt,attempts", [(8, 3000, 20000, 16, 2), (16, 12000, 30000, 30, 3)])
+def test_greedy_and_anneal_chains_match_oracle(gpu_ctx, n_alleles, n_pairs, base_len, n_gt, attempts):
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, n_alleles, n_pairs, base_len)
+    gts = api.generate_genotypes(n_alleles, 2)
+    order = np.argsort(-aa.run_filter())[:n_gt]
+    sub = gts[order]
+    seeds = api.chain_seeds(2024, len(sub) * attempts)
+    for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+        solver = api.default_solver(kind)
+        gm, gv, gl = compare_stage(aa, ol, oa, sub, solver, attempts, seeds)
+        assert tuple(sub[int(np.argmax(gm))]) == L.true_genotype
+    # priors shift the likelihood of every attempt (solve.rs:827)
+    pri = -np.arange(len(sub), dtype=np.float64)
+    g0 = api.default_solver(cdefs.SOLVER_GREEDY)
+    m0, _, _ = api.solve_stage(aa, sub, g0, attempts, seeds)
+    m1, _, _ = api.solve_stage(aa, sub, g0, attempts, seeds, pri)
+    assert np.allclose(m1, m0 + pri, rtol=1e-12)
+    # non-default solver parameters: random start, other sample / plateau sizes, short annealing
+    g1 = api.default_solver(cdefs.SOLVER_GREEDY)
+    g1.best_start, g1.sample_size, g1.plato_size = 0, 3, 30
+    compare_stage(aa, ol, oa, sub[:6], g1, attempts, seeds[:6 * attempts])
+    a1 = api.default_solver(cdefs.SOLVER_ANNEAL)
+    a1.anneal_steps, a1.plato_size, a1.init_prob = 500, 200, 0.3
+    compare_stage(aa, ol, oa, sub[:6], a1, attempts, seeds[:6 * attempts])
+
+
+def test_chain_seeds_are_the_xoshiro_stream(gpu_ctx):
+    import ctypes as C
+    r = O.rng_from_seed(77)
+    want = [O.lib().orc_rng_next(C.byref(r)) for _ in range(5)]
+    assert api.chain_seeds(77, 5).tolist() == want
+
+
+def test_homozygous_single_end_and_deep_coverage(gpu_ctx):
+    # homozygous genotypes list the allele twice (duplicate locations, different window shifts)
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 6, 2500, 12000)
+    homo = np.array([[a, a] for a in range(6)], dtype=np.uint16)
+    seeds = api.chain_seeds(5, 12)
+    compare_stage(aa, ol, oa, homo, api.default_solver(cdefs.SOLVER_GREEDY), 2, seeds)
+    compare_stage(aa, ol, oa, homo[:3], api.default_solver(cdefs.SOLVER_ANNEAL), 2, seeds[:6])
+    # ploidy 1 and 3
+    for ploidy in (1, 3):
+        g = api.generate_genotypes(6, ploidy)[:5]
+        compare_stage(aa, ol, oa, g, api.default_solver(cdefs.SOLVER_GREEDY), 1, api.chain_seeds(9, 5))
+    # single-end long reads
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 6, 300, 40000, tech=cdefs.TECH_NANOPORE, read_len=4000)
+    g = api.generate_genotypes(6, 2)[:8]
+    compare_stage(aa, ol, oa, g, api.default_solver(cdefs.SOLVER_GREEDY), 2, api.chain_seeds(3, 16))
+    # depths beyond the 256-entry LinearCache: BayesCalc evaluated directly with the device lgamma
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 4, 20000, 4000)
+    g = api.generate_genotypes(4, 2)
+    seeds = api.chain_seeds(8, len(g))
+    gm, gv, gl = api.solve_stage(aa, g, api.default_solver(cdefs.SOLVER_GREEDY), 1, seeds)
+    om, ov, olk = O.solve_stage(ol, oa, g, api.default_solver(cdefs.SOLVER_GREEDY), 1, seeds)
+    # lgamma implementations differ by ~1e-13, a near-tie may flip: compare statistically, not per chain
+    assert np.abs(gm - om).max() <= 1e-3 * np.abs(om).max()
+    assert int(np.argmax(gm)) == int(np.argmax(om))
+
+
+def test_tweak_zero_and_min_weight(gpu_ctx):
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 6, 2000, 12000, tweak=0)
+    g = api.generate_genotypes(6, 2)[:10]
+    compare_stage(aa, ol, oa, g, api.default_solver(cdefs.SOLVER_GREEDY), 2, api.chain_seeds(4, 20))
+
+
+def test_final_comparison_and_full_scheme(gpu_ctx):
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 12, 6000, 20000)
+    gts = api.generate_genotypes(12, 2)
+    greedy = api.default_solver(cdefs.SOLVER_GREEDY)
+    attempts = 3
+    seeds = api.chain_seeds(11, len(gts) * attempts)
+    gm, gv, gl = api.solve_stage(aa, gts, greedy, attempts, seeds)
+    att = np.full(len(gts), attempts, dtype=np.uint32)
+    ix = np.arange(len(gts))
+    for out_size in (4, 20, 600):
+        k1 = api.discard_improbable(gm, gv, att, ix, p.prob_thresh, out_size, 1)
+        k2 = O.discard_improbable(gm, gv, att, ix, p.prob_thresh, out_size, 1)
+        assert np.array_equal(k1, k2)
+    k = api.discard_improbable(gm, gv, att, ix, p.prob_thresh, 20, 1)
+    i1, lp1, q1 = api.produce_result(gm, gv, att, k, p.prob_thresh)
+    i2, lp2, q2 = O.produce_result(gm, gv, att, k, p.prob_thresh)
+    assert np.array_equal(i1, i2) and np.allclose(lp1, lp2, rtol=1e-9, atol=1e-9) and abs(q1 - q2) <= 1e-6 * max(1.0, abs(q2))
+    # whole scheme (prefilter -> greedy -> anneal -> result) calls the true genotype
+    res = api.solve(aa, p, scheme=(("greedy", 40, 1), ("anneal", 6, 4)), master_seed=3)
+    assert tuple(res["genotypes"][0]) == L.true_genotype
+    assert abs(np.logaddexp.reduce(res["ln_probs"])) < 1e-9 and res["quality"] >= 0.0
+    assert res["kept_per_stage"][0] >= 40
+
+
+def test_solver_misuse_fails_loudly(gpu_ctx):
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 4, 300, 6000)
+    g = api.generate_genotypes(4, 2)
+    with pytest.raises(_lib.LocityperError):
+        api.solve_stage(aa, np.array([[0, 9]], dtype=np.uint16), api.default_solver(0), 1, api.chain_seeds(1, 1))
+    with pytest.raises(_lib.LocityperError) as e:
+        api.solve_stage(aa, api.generate_genotypes(4, 5)[:2], api.default_solver(0), 1, api.chain_seeds(1, 2))
+    assert e.value.code == cdefs.ERR_UNSUPPORTED
+    bad = api.default_solver(1)
+    bad.init_prob = 0.0
+    with pytest.raises(_lib.LocityperError):
+        api.solve_stage(aa, g[:1], bad, 1, api.chain_seeds(1, 1))

@@ -76,9 +76,35 @@ def test_compute_entry_points_fail_loudly_without_gpu():
 
 
 def test_product_package_never_imports_the_oracle():
+    """No file of the product includes, imports, links or loads anything under oracle/ (comments may cite it)."""
     pkg = os.path.join(ROOT, "locityper_amd")
+    bad = re.compile(r"(^\s*#\s*include[^\n]*oracle)|(^\s*(from|import)\s+[^\n]*oracle)|(CDLL[^\n]*oracle)|(dlopen[^\n]*oracle)|"
+                     r"(liblcty_oracle)|(\borc_[a-z_]+\s*\()", re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".c")):
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".c")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "oracle_ffi" not in txt and "lcty_oracle" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)
+                assert not bad.search(txt), os.path.join(dirpath, f)
+
+
+def test_final_comparison_host_entry_points_match_oracle():
+    # lcty_chain_seeds, lcty_solver_default, lcty_discard_improbable, lcty_produce_result are host-only
+    r = O.rng_from_seed(123)
+    assert api.chain_seeds(123, 7).tolist() == [O.lib().orc_rng_next(C.byref(r)) for _ in range(7)]
+    g, a = api.default_solver(cdefs.SOLVER_GREEDY), api.default_solver(cdefs.SOLVER_ANNEAL)
+    assert (g.best_start, g.sample_size, g.plato_size) == (1, 10, 100)             # stoch.rs:45-53
+    assert (a.anneal_steps, a.plato_size) == (20000, 10000) and a.init_prob == 0.5   # stoch.rs:161-169
+    rng = np.random.default_rng(5)
+    for n, spread in ((3, 1.0), (40, 30.0), (500, 400.0)):
+        mean = -1e5 - spread * rng.random(n) ** 2 * 10
+        att = rng.integers(1, 6, n).astype(np.uint32)
+        var = np.where(att > 1, rng.random(n) * 4.0, np.nan)
+        ixs = rng.permutation(n)[: max(2, n - n // 5)]
+        for out_size in (1, 5, n):
+            k1 = api.discard_improbable(mean, var, att, ixs, -4.0 * np.log(10), out_size, 2)
+            k2 = O.discard_improbable(mean, var, att, ixs, -4.0 * np.log(10), out_size, 2)
+            assert np.array_equal(k1, k2)
+        i1, lp1, q1 = api.produce_result(mean, var, att, ixs, -4.0 * np.log(10))
+        i2, lp2, q2 = O.produce_result(mean, var, att, ixs, -4.0 * np.log(10))
+        assert np.array_equal(i1, i2) and np.allclose(lp1, lp2, rtol=1e-10, atol=1e-10)
+        assert abs(q1 - q2) <= 1e-7 * max(1.0, abs(q2))
