@@ -6,6 +6,8 @@ A step = one pass of the hot path over one locus' batch, inputs resident in HBM:
     lcty_score_reads   (K2+K4+K5+K7+K8: AllAlignments::load -> likelihood matrix + pair alignments)
     lcty_prefilter     (K9: run_filter over all C(A+1,2) genotypes) + scores D2H
     lcty_truncate      (K10: truncate_ixs on the host)
+    lcty_solve_stage   (K11-K14: greedy on the survivors, 1 attempt; annealing on the best 20, 20 attempts)
+    lcty_discard_improbable / lcty_produce_result (K15: final genotype comparison)
 N > 1: one process per GPU, one independent locus per rank (loci are independent in the reference,
 command/genotype.rs:1331-1351) -> weak scaling, no data-path collective; torch.distributed (gloo)
 only carries the barrier and the max-over-ranks of the timed region.
@@ -46,6 +48,7 @@ def parse_args():
     ap.add_argument("--alleles", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
+    ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
     return ap.parse_args()
 
 
@@ -103,12 +106,36 @@ def main():
     G = api.count_genotypes(A, 2)
     all_ixs = np.arange(G, dtype=np.uint64)
 
-    def step():
+    gts = api.generate_genotypes(A, 2)
+    greedy, anneal = api.default_solver(cdefs.SOLVER_GREEDY), api.default_solver(cdefs.SOLVER_ANNEAL)
+    stage_s = {"greedy": 0.0, "anneal": 0.0}
+    solved = {"greedy_chains": 0, "anneal_chains": 0}
+
+    def step(it=0):
         aa.score()
         aa.prefilter_async()
         scores = aa.prefilter_scores()
-        keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, params.threads)   # in_size of stage 1 (solve.rs:216-221)
-        return scores, keep
+        keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, 1)   # in_size of stage 1 (solve.rs:216-221)
+        if args.no_solve:
+            return scores, keep, None
+        # default scheme "-S greedy:i=5k,a=1 -S anneal:i=20,a=20" (solve.rs:211-230), then the final comparison
+        n = len(gts)
+        mean, var, att = np.full(n, np.nan), np.full(n, np.nan), np.zeros(n, dtype=np.uint32)
+        ixs = keep
+        ts = time.perf_counter()
+        if 20 < len(ixs):
+            m, v, _ = api.solve_stage(aa, gts[ixs], greedy, 1, api.chain_seeds(1000 + it, len(ixs)))
+            mean[ixs], var[ixs], att[ixs] = m, v, 1
+            solved["greedy_chains"] += len(ixs)
+            ixs = api.discard_improbable(mean, var, att, ixs, params.prob_thresh, 20, 1)
+        tm = time.perf_counter()
+        m, v, _ = api.solve_stage(aa, gts[ixs], anneal, 20, api.chain_seeds(2000 + it, 20 * len(ixs)))
+        mean[ixs], var[ixs], att[ixs] = m, v, 20
+        solved["anneal_chains"] += 20 * len(ixs)
+        res = api.produce_result(mean, var, att, ixs, params.prob_thresh)
+        te = time.perf_counter()
+        stage_s["greedy"] += tm - ts; stage_s["anneal"] += te - tm
+        return scores, keep, res
 
     def barrier():
         ctx.synchronize()
@@ -119,9 +146,10 @@ def main():
         step()
     barrier()
     ctx.timing_reset()
+    stage_s.update(greedy=0.0, anneal=0.0); solved.update(greedy_chains=0, anneal_chains=0)
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        scores, keep = step()
+    for it in range(args.steps):
+        scores, keep, res = step(it)
     ctx.synchronize()
     elapsed = time.perf_counter() - t_start
     barrier()
@@ -133,8 +161,8 @@ def main():
     n_score, ms_score = ctx.timing(api.K_SCORE)
     n_pref, ms_pref = ctx.timing(api.K_PREFILTER)
 
-    top = int(keep[0])
-    gts = api.generate_genotypes(A, 2)
+    n_solve, ms_solve = ctx.timing(api.K_SOLVE)
+    top = int(keep[0]) if res is None else int(res[0][0])
     called = tuple(int(x) for x in gts[top])
 
     if rank != 0:
@@ -167,7 +195,13 @@ def main():
                    "records": tot_recs, "cigar_words": tot_cigar, "parallelism": f"loci x{world}"},
         "genotypes_per_s": world * G * args.steps / elapsed,
         "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3),
-        "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms},
+        "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms, "solve_chain_per_step": ms_solve / args.steps},
+        "solver": None if args.no_solve else {
+            "scheme": "greedy:i=5k,a=1 -> anneal:i=20,a=20 -> final comparison",
+            "genotypes_solved_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"] / 20.0) / elapsed,
+            "chains_per_step": {k: v / args.steps for k, v in solved.items()},
+            "stage_ms_per_step": {k: 1e3 * v / args.steps for k, v in stage_s.items()},
+            "quality": None if res is None else float(res[2])},
         "roofline": {"bound": "hbm", "kernel": "score_reads_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "layout_bytes_per_launch": layout_bytes,

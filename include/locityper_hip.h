@@ -301,8 +301,10 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
  * stream; kernel ids LCTY_K_*.                                                 */
 #define LCTY_K_SCORE     0
 #define LCTY_K_PREFILTER 1
-#define LCTY_K_SOLVE     2
-#define LCTY_K_COUNT     3
+#define LCTY_K_SOLVE     2   /* solve_loop_kernel: the Greedy / SimAnneal chains */
+#define LCTY_K_SOLVE_INIT  3 /* solve_init_kernel: apply_tweak + ReadAssignment::try_new of every chain */
+#define LCTY_K_SOLVE_TABLE 4 /* build_loc_table_kernel: allele-major location table of a scored batch */
+#define LCTY_K_COUNT     5
 int32_t lcty_timing_reset(lcty_ctx* ctx);
 int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms);
 

@@ -58,7 +58,7 @@ class Context:
             pass
 
 
-K_SCORE, K_PREFILTER, K_SOLVE = 0, 1, 2
+K_SCORE, K_PREFILTER, K_SOLVE, K_SOLVE_INIT, K_SOLVE_TABLE = 0, 1, 2, 3, 4
 
 
 class Locus:

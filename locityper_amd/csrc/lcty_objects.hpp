@@ -48,6 +48,8 @@ struct lcty_locus {
     lcty::DevBuf<lcty::DepthNB> d_depth_nb;  // [101]
     lcty::DevBuf<uint32_t> d_n_windows, d_reg_start;   // [A]
     lcty::DevBuf<double> d_win_weight;       // per position: ContigInfo::neighb_info weight (windows.rs:439-445)
+    lcty::DevBuf<double> d_lut_ext;          // [101][lut_ext_depth] depth table of the solver stages (lcty_solve.hip)
+    uint32_t lut_ext_depth = 0;
     uint32_t max_n_windows = 0;
 
     lcty::LocusView view() const;
@@ -88,6 +90,12 @@ struct lcty_reads {
     uint64_t n_good_cached = 0;
     bool good_valid = false;
     void ensure_good_index();
+    // allele-major location table of the solver stages (lcty_solve.hip), rows of ngp entries
+    lcty::DevBuf<double> d_t_lp, d_unm_g;
+    lcty::DevBuf<uint2> d_t_mid;
+    lcty::DevBuf<uint32_t> d_t_ext;
+    uint64_t ngp = 0;
+    bool loc_table_valid = false;
     lcty::DevBuf<uint32_t> d_err;
 
     // prefilter products

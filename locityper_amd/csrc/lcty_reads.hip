@@ -204,7 +204,7 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         R->max_recs_per_pair = max_recs;
         R->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
         R->scored = false;
-        R->good_valid = false;
+        R->good_valid = false; R->loc_table_valid = false;
     });
 }
 
@@ -227,7 +227,7 @@ int32_t lcty_score_reads(lcty_reads* reads) {
         reads->ctx->activate();
         if (reads->n_pairs) launch_score_reads(reads);
         reads->scored = true;
-        reads->good_valid = false;
+        reads->good_valid = false; reads->loc_table_valid = false;
     });
 }
 

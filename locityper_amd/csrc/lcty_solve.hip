@@ -1,16 +1,29 @@
 // lcty_solve.hip — the solver stages of `locityper genotype` on gfx950.
 //
-// One 256-thread workgroup per (genotype, attempt) chain:
-//   K12  apply_tweak (src/model/assgn.rs:127-151): window distributions of the genotype in LDS
-//        (generate_windows, windows.rs:478-486; neighb_info 439-445; DistrCache::get_distribution 83-92)
-//   K11  GenotypeAlignments::new (assgn.rs:41-84) is NOT materialised: the possible locations of a read on the
-//        genotype (extend_read_gt_alns, windows.rs:762-797) are re-derived on demand from the per-(pair, contig)
-//        index the scoring kernel leaves behind — a merge of <= ploidy sorted runs plus "both unmapped".
-//   K13  ReadAssignment::try_new + recalc_likelihood (assgn.rs:199-226, 346-354): all 256 threads stream the
-//        reads once: initial location, depth histogram (LDS atomics), alignment likelihood, ordered list of
-//        non-trivial reads.
-//   K14  Greedy / SimAnneal (src/solvers/stoch.rs:81-120, 195-245) on wave 0: the chain itself is serial; the
-//        `sample_size` candidate reads of a greedy step are evaluated by different lanes.
+// Data the stages work on (built once per scored batch, all in HBM):
+//   location table  T[contig][good read]  — allele-major transposition of the (pair, contig) index the scoring
+//        kernel leaves behind: ln-probability and the two alignment middles of the best pair-alignment on that
+//        contig, the number of pair-alignments there, and where the others sit in the pair-alignment arena.
+//        A chain of genotype (a, b, ..) streams rows a, b, .. with coalesced loads; a single move needs one
+//        16-byte gather per contig.
+//   depth table     lut[GC bin][depth]    — DistrCache (src/model/distr_cache.rs:61-92) extended past the
+//        256 entries of the reference's LinearCache (src/math/distr/lincache.rs:41-48) with the same
+//        BayesCalc::ln_pmf (bayes.rs:27-35) evaluated on the device, so that one deep window costs one
+//        L2 gather instead of (2 + n_alt) lgamma calls.
+//
+// Kernels:
+//   build_loc_table_kernel   K11 input: GenotypeAlignments::new (assgn.rs:41-84) is NOT materialised; the possible
+//        locations of a read on a genotype (extend_read_gt_alns, windows.rs:762-797) are re-derived on demand as a
+//        merge of <= ploidy sorted runs plus "both mates unmapped".
+//   solve_init_kernel<P>     one 256-thread workgroup per (genotype, attempt) chain:
+//        K12 apply_tweak (assgn.rs:127-151): window distributions (generate_windows, windows.rs:478-486;
+//            neighb_info 439-445; get_distribution distr_cache.rs:83-92)
+//        K13 ReadAssignment::try_new (assgn.rs:199-226): initial location of every read, depth histogram
+//            (LDS atomics), alignment likelihood, ordered list of non-trivial reads
+//   solve_loop_kernel<P>     one wavefront per chain, window state in LDS:
+//        K14 Greedy / SimAnneal (src/solvers/stoch.rs:81-120, 195-245). The chain is serial by definition; the
+//            `sample_size` candidate reads of a greedy step are evaluated by different lanes, and many chains
+//            share a CU to hide the gather latency of each other.
 //
 // Randomness is the injected per-chain seed described in oracle/lcty_oracle.h (the reference's rand adaptors
 // are not in its tree): counter-based draws for tweaks / random starts, xoshiro256++ for the solver loop.
@@ -25,6 +38,7 @@ namespace lcty {
 
 constexpr uint32_t MAXP = 4;                  // ploidy handled by the device solver
 constexpr uint32_t NONE32S = 0xFFFFFFFFu;
+constexpr uint32_t MID_NONE24 = 0xFFFFFFu;    // "mate unmapped" inside the location table
 constexpr uint64_t WINDOW_KEY_XOR = 0xD1B54A32D192ED03ull;
 constexpr uint64_t INIT_KEY_XOR = 0x8CB92BA72F3D8DD7ull;
 
@@ -38,27 +52,35 @@ struct SolveView {
     const uint32_t* ci_off;
     const uint8_t* gc;
     const double* win_weight;
-    const double* depth_lut;
+    const double* lut;              // [LCTY_GC_BINS][lut_depth]
+    uint32_t lut_depth;
     const DepthNB* depth_nb;
     uint32_t n_alt;
     // reads
-    const uint32_t* good_ix;
     uint32_t n_good;
-    const double* unmapped;
+    uint64_t ngp;                   // row stride of the location table (n_good rounded up to 64)
+    const double* unm_g;            // [n_good] "both mates unmapped" probability
+    const double* t_lp;             // [A][ngp]
+    const uint2* t_mid;             // [A][ngp]  x = mid1 (24 bit) | count << 24, y = mid2
+    const uint32_t* t_ext;          // [A][ngp]  arena index of the second pair-alignment on the contig
     const PairAlnDev* pa;
-    const uint64_t* pa_off;
-    const uint32_t* pa_idx;
     // chains
     const uint16_t* genotypes;      // [n_gt][ploidy]
     uint32_t ploidy, attempts;
     const uint64_t* seeds;          // [n_chains]
     const double* priors;           // [n_gt] or null
     lcty_solver solver;
-    uint16_t* state;                // [n_chains][n_good]  (number of locations << 8) | current location
-    uint32_t* non_trivial;          // [n_chains][n_good]
+    uint8_t* state;                 // [n_chains][ngp] current location of every read
+    uint32_t* non_trivial;          // [n_chains][ngp]
+    uint32_t wstride;               // per-chain stride of the window arrays (>= 2 + ploidy * max n_windows)
+    double* c_ww;                   // [n_chains][wstride] window weights (0 = trivial distribution)
+    uint8_t* c_gc;                  // [n_chains][wstride]
+    uint32_t* c_depth;              // [n_chains][wstride]
+    uint32_t* c_nnt;                // [n_chains]
+    double* c_aln;                  // [n_chains] alignment likelihood after K13
     double* liks;                   // [n_chains] prior + likelihood
     double* parts;                  // [n_chains][2] aln_lik, depth_lik (diagnostics)
-    uint32_t max_windows;           // LDS sizing: 2 + ploidy * max n_windows
+    uint32_t* overflow;             // set when a window got deeper than the depth table (the host widens it and repeats)
 };
 
 // ---- randomness (definitions shared with oracle/lcty_oracle_solve.c) ----
@@ -84,108 +106,56 @@ struct Xoshiro {
     __device__ __forceinline__ double f64() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
 };
 
-// ---- possible locations of one read on the genotype (extend_read_gt_alns, windows.rs:762-797) ----
-struct Locs {
-    const PairAlnDev* e[MAXP];
-    uint32_t n[MAXP];
-    double unm, thresh;
-    bool has_unm;
-    uint32_t nw;
-};
-
-__device__ __forceinline__ void locs_init(Locs& L, const SolveView& V, uint32_t r, const uint32_t ids[MAXP]) {
-    const uint64_t off = V.pa_off[r];
-    L.unm = V.unmapped[r];
-    double top = L.unm;
-#pragma unroll
-    for (uint32_t p = 0; p < MAXP; p++) {
-        L.n[p] = 0; L.e[p] = nullptr;
-        if (p < V.ploidy) {
-            const uint32_t idx = V.pa_idx[static_cast<uint64_t>(r) * V.A + ids[p]];
-            L.n[p] = idx >> 24;
-            L.e[p] = V.pa + off + (idx & 0xFFFFFFu);
-            if (L.n[p]) top = fmax(top, L.e[p][0].ln_prob);
+// ---- K11 input: allele-major location table ----
+__global__ __launch_bounds__(256) void build_loc_table_kernel(const uint32_t* __restrict__ good_ix, uint32_t n_good, uint64_t ngp,
+                                                              uint32_t A, const uint32_t* __restrict__ pa_idx,
+                                                              const uint64_t* __restrict__ pa_off, const PairAlnDev* __restrict__ pa,
+                                                              const double* __restrict__ unmapped, double* __restrict__ t_lp,
+                                                              uint2* __restrict__ t_mid, uint32_t* __restrict__ t_ext,
+                                                              double* __restrict__ unm_g, uint32_t* __restrict__ err) {
+    // 64 reads x 32 contigs per workgroup: the (pair, contig) index is read along contigs, the table written along reads
+    __shared__ double s_lp[64][33];
+    __shared__ uint2 s_mid[64][33];
+    __shared__ uint32_t s_ext[64][33];
+    const uint32_t g0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
+    {
+        const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
+        for (uint32_t i = ty; i < 64; i += 8) {
+            const uint32_t g = g0 + i, c = c0 + tx;
+            double lp = -INFINITY; uint2 mid = make_uint2(MID_NONE24, NONE32S); uint32_t ext = 0;
+            if (g < n_good && c < A) {
+                const uint32_t r = good_ix[g];
+                const uint32_t idx = pa_idx[static_cast<uint64_t>(r) * A + c];
+                const uint32_t cnt = idx >> 24;
+                if (cnt) {
+                    const uint64_t at = pa_off[r] + (idx & 0xFFFFFFu);
+                    const PairAlnDev e = pa[at];
+                    if ((e.mid1 != NONE32S && e.mid1 >= MID_NONE24) || at + cnt > 0xFFFFFFFFull)
+                        atomicMax(err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED));
+                    lp = e.ln_prob;
+                    mid.x = (e.mid1 == NONE32S ? MID_NONE24 : e.mid1) | (cnt << 24);
+                    mid.y = e.mid2;
+                    ext = static_cast<uint32_t>(at + 1);
+                }
+                if (c == 0) unm_g[g] = unmapped[r];
+            }
+            s_lp[i][tx] = lp; s_mid[i][tx] = mid; s_ext[i][tx] = ext;
         }
     }
-    L.thresh = top - V.prob_diff;          // max(unm - d, best_i - d, ...) == max(...) - d
-    L.nw = 0;
-#pragma unroll
-    for (uint32_t p = 0; p < MAXP; p++) {
-        uint32_t k = 0;
-        while (k < L.n[p] && L.e[p][k].ln_prob >= L.thresh) k++;
-        L.n[p] = k;
-        L.nw += k;
-    }
-    L.has_unm = L.unm >= L.thresh;
-    L.nw += L.has_unm;
-}
-
-struct LocOut {
-    double lp;
-    uint32_t mid1, mid2, cix;              // cix 0xFF: both mates unmapped
-};
-
-// locations in decreasing ln_prob, ties in push order (contig_ix ascending, then "unmapped") — windows.rs:793
-struct LocIter {
-    uint32_t cur[MAXP];
-    bool unm_left;
-    __device__ __forceinline__ void start(const Locs& L) {
-#pragma unroll
-        for (uint32_t p = 0; p < MAXP; p++) cur[p] = 0;
-        unm_left = L.has_unm;
-    }
-    __device__ __forceinline__ bool next(const Locs& L, LocOut& o) {
-        double best = -INFINITY;
-        uint32_t bp = NONE32S;
-#pragma unroll
-        for (uint32_t p = 0; p < MAXP; p++) {
-            if (cur[p] < L.n[p]) {
-                const double lp = L.e[p][cur[p]].ln_prob;
-                if (bp == NONE32S || lp > best) { best = lp; bp = p; }
+    __syncthreads();
+    {
+        const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+        for (uint32_t j = ty; j < 32; j += 4) {
+            const uint32_t c = c0 + j, g = g0 + tx;
+            if (c < A && g < ngp) {
+                const uint64_t o = static_cast<uint64_t>(c) * ngp + g;
+                t_lp[o] = s_lp[tx][j]; t_mid[o] = s_mid[tx][j]; t_ext[o] = s_ext[tx][j];
             }
         }
-        if (unm_left && (bp == NONE32S || L.unm > best)) {
-            unm_left = false;
-            o.lp = L.unm; o.mid1 = o.mid2 = NONE32S; o.cix = 0xFFu;
-            return true;
-        }
-        if (bp == NONE32S) return false;
-        PairAlnDev a;
-#pragma unroll
-        for (uint32_t p = 0; p < MAXP; p++)
-            if (p == bp) { a = L.e[p][cur[p]]; cur[p]++; }
-        o.lp = a.ln_prob; o.mid1 = a.mid1; o.mid2 = a.mid2; o.cix = bp;
-        return true;
     }
-};
-
-struct GtWin {                             // GenotypeWindows (windows.rs:709-739) of this chain
-    uint32_t shift[MAXP], reg_start[MAXP], reg_end[MAXP];
-};
-
-// get_shifted_window_ix + middle_window (windows.rs:62-68, 465-470) with define_windows_random (123-136)
-__device__ __forceinline__ void loc_windows(const SolveView& V, const GtWin& G, const LocOut& o, uint64_t seed, uint32_t rp,
-                                            uint32_t t, uint32_t* w1, uint32_t* w2) {
-    if (o.cix == 0xFFu) { *w1 = 0; *w2 = 0; return; }
-    uint32_t t1 = 0, t2 = 0;
-    if (V.tweak) {
-        const uint64_t r = counter_u64(seed, (static_cast<uint64_t>(rp) << 16) | t);
-        t1 = static_cast<uint32_t>(r >> 32) % (2 * V.tweak + 1);
-        t2 = static_cast<uint32_t>(r) % (2 * V.tweak + 1);
-    }
-    uint32_t sh = 0, rs = 0, re = 0;
-#pragma unroll
-    for (uint32_t p = 0; p < MAXP; p++) if (p == o.cix) { sh = G.shift[p]; rs = G.reg_start[p]; re = G.reg_end[p]; }
-    auto ix = [&](uint32_t mid, uint32_t tw) -> uint32_t {
-        if (mid == NONE32S) return 0u;                                       // UNMAPPED_WINDOW
-        const uint32_t m = mid + tw;
-        return (rs <= m && m < re) ? (m - rs) / V.window + sh : 1u;          // BOUNDARY_WINDOW
-    };
-    *w1 = ix(o.mid1, t1);
-    *w2 = ix(o.mid2, t2);
 }
 
-// BayesCalc::ln_pmf evaluated directly (depth >= 256): bayes.rs:27-35 with Ln::map_sum_init (math/mod.rs:80-94)
+// BayesCalc::ln_pmf evaluated directly: bayes.rs:27-35 with Ln::map_sum_init (math/mod.rs:80-94)
 __device__ __noinline__ double bayes_ln_pmf_direct(const DepthNB* nb, uint32_t n_alt, uint32_t depth) {
     const double x = static_cast<double>(depth);
     const double lg1 = lgamma(x + 1.0);
@@ -212,33 +182,145 @@ __device__ __noinline__ double bayes_ln_pmf_direct(const DepthNB* nb, uint32_t n
     return null_prob - sum_prob;
 }
 
-struct Chain {
-    const SolveView* V;
-    const uint32_t* depth;      // LDS
-    const uint8_t* wgc;         // LDS
-    const double* ww;           // LDS
-    // WindowDistr::ln_prob (distr_cache.rs:34-39) through LinearCache (lincache.rs:41-48)
-    __device__ __forceinline__ double wlp(uint32_t w, uint32_t d) const {
-        const double weight = ww[w];
-        if (weight == 0.0) return 0.0;                                      // WindowDistr::TRIVIAL
-        const uint32_t g = wgc[w];
-        const double v = d < LCTY_DEPTH_CACHE ? V->depth_lut[g * LCTY_DEPTH_CACHE + d]
-                                              : bayes_ln_pmf_direct(V->depth_nb + g, V->n_alt, d);
-        return weight * v;
-    }
-    __device__ __forceinline__ double atomic_diff(uint32_t w, int32_t c) const {     // assgn.rs:244-254
-        if (c == 0) return 0.0;
-        const uint32_t old_depth = depth[w];
-        return wlp(w, static_cast<uint32_t>(static_cast<int32_t>(old_depth) + c)) - wlp(w, old_depth);
-    }
-    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {   // assgn.rs:259-284
-        int32_t c1 = -1, c2, c3, c4;
-        if (w2 == w1) { c1 -= 1; c2 = 0; } else c2 = -1;
-        if (w3 == w1) { c1 += 1; c3 = 0; } else if (w3 == w2) { c2 += 1; c3 = 0; } else c3 = 1;
-        if (w4 == w1) { c1 += 1; c4 = 0; } else if (w4 == w2) { c2 += 1; c4 = 0; } else if (w4 == w3) { c3 += 1; c4 = 0; } else c4 = 1;
-        return atomic_diff(w1, c1) + atomic_diff(w2, c2) + atomic_diff(w3, c3) + atomic_diff(w4, c4);
+// depth table: the first LCTY_DEPTH_CACHE columns are the locus' LinearCache, the others the same formula on the device
+__global__ __launch_bounds__(256) void build_depth_table_kernel(const double* __restrict__ cache, const DepthNB* __restrict__ nb,
+                                                                uint32_t n_alt, uint32_t lut_depth, double* __restrict__ lut) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= LCTY_GC_BINS * lut_depth) return;
+    const uint32_t g = i / lut_depth, d = i % lut_depth;
+    lut[i] = d < LCTY_DEPTH_CACHE ? cache[g * LCTY_DEPTH_CACHE + d] : bayes_ln_pmf_direct(nb + g, n_alt, d);
+}
+
+// ---- the genotype of a chain: GenotypeWindows (windows.rs:709-739) ----
+template <uint32_t P>
+struct Geno {
+    uint32_t id[P], shift[P], reg_start[P], reg_end[P];
+    uint32_t total_w;
+    __device__ __forceinline__ void init(const SolveView& V, uint32_t gi) {
+        total_w = 2;                                                        // REG_WINDOW_SHIFT
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) {
+            id[p] = V.genotypes[static_cast<uint64_t>(gi) * P + p];
+            shift[p] = total_w;
+            reg_start[p] = V.reg_start[id[p]];
+            const uint32_t nw = V.n_windows[id[p]];
+            reg_end[p] = reg_start[p] + nw * V.window;
+            total_w += nw;
+        }
     }
 };
+
+// ---- possible locations of one read on the genotype (extend_read_gt_alns, windows.rs:762-797) ----
+template <uint32_t P>
+struct Locs {
+    double lp[P];                  // best pair-alignment on contig p
+    uint32_t m1[P], m2[P];
+    uint32_t ext[P];               // arena index of the next one
+    uint32_t n[P];                 // pair-alignments on contig p that pass the threshold
+    double unm;
+    bool has_unm;
+    uint32_t nw;
+};
+
+template <uint32_t P>
+__device__ __forceinline__ void locs_init(Locs<P>& L, const SolveView& V, uint32_t g, const Geno<P>& G) {
+    L.unm = V.unm_g[g];
+    double top = L.unm;
+    uint32_t raw[P];
+#pragma unroll
+    for (uint32_t p = 0; p < P; p++) {
+        const uint64_t o = static_cast<uint64_t>(G.id[p]) * V.ngp + g;
+        L.lp[p] = V.t_lp[o];
+        const uint2 mid = V.t_mid[o];
+        raw[p] = mid.x >> 24;
+        L.m1[p] = (mid.x & MID_NONE24) == MID_NONE24 ? NONE32S : (mid.x & MID_NONE24);
+        L.m2[p] = mid.y;
+        L.ext[p] = 0;
+        top = fmax(top, L.lp[p]);                                           // -inf where the contig has nothing
+    }
+    const double thresh = top - V.prob_diff;                                // max(unm - d, best_i - d, ...) == max(...) - d
+    L.nw = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < P; p++) {
+        uint32_t k = (raw[p] && L.lp[p] >= thresh) ? 1u : 0u;
+        if (k && raw[p] > 1) {
+            L.ext[p] = V.t_ext[static_cast<uint64_t>(G.id[p]) * V.ngp + g];
+            while (k < raw[p] && V.pa[L.ext[p] + k - 1].ln_prob >= thresh) k++;
+        }
+        L.n[p] = k;
+        L.nw += k;
+    }
+    L.has_unm = L.unm >= thresh;
+    L.nw += L.has_unm;
+}
+
+struct LocOut {
+    double lp;
+    uint32_t mid1, mid2, cix;              // cix 0xFF: both mates unmapped
+};
+
+// locations in decreasing ln_prob, ties in push order (contig_ix ascending, then "unmapped") — windows.rs:793
+template <uint32_t P>
+struct LocIter {
+    double lp[P];
+    uint32_t m1[P], m2[P], cur[P];
+    bool unm_left;
+    __device__ __forceinline__ void start(const Locs<P>& L) {
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) { cur[p] = 0; lp[p] = L.lp[p]; m1[p] = L.m1[p]; m2[p] = L.m2[p]; }
+        unm_left = L.has_unm;
+    }
+    __device__ __forceinline__ bool next(const Locs<P>& L, const SolveView& V, LocOut& o) {
+        double best = -INFINITY;
+        uint32_t bp = NONE32S;
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) {
+            if (cur[p] < L.n[p] && (bp == NONE32S || lp[p] > best)) { best = lp[p]; bp = p; }
+        }
+        if (unm_left && (bp == NONE32S || L.unm > best)) {
+            unm_left = false;
+            o.lp = L.unm; o.mid1 = o.mid2 = NONE32S; o.cix = 0xFFu;
+            return true;
+        }
+        if (bp == NONE32S) return false;
+        o.cix = bp;
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) {
+            if (p == bp) {
+                o.lp = lp[p]; o.mid1 = m1[p]; o.mid2 = m2[p];
+                cur[p]++;
+                if (cur[p] < L.n[p]) {
+                    const PairAlnDev e = V.pa[L.ext[p] + cur[p] - 1];
+                    lp[p] = e.ln_prob; m1[p] = e.mid1; m2[p] = e.mid2;
+                }
+            }
+        }
+        return true;
+    }
+};
+
+// get_shifted_window_ix + middle_window (windows.rs:62-68, 465-470) with define_windows_random (123-136)
+template <uint32_t P>
+__device__ __forceinline__ void loc_windows(const SolveView& V, const Geno<P>& G, const LocOut& o, uint64_t seed, uint32_t rp,
+                                            uint32_t t, uint32_t* w1, uint32_t* w2) {
+    if (o.cix == 0xFFu) { *w1 = 0; *w2 = 0; return; }
+    uint32_t t1 = 0, t2 = 0;
+    if (V.tweak) {
+        const uint64_t r = counter_u64(seed, (static_cast<uint64_t>(rp) << 16) | t);
+        t1 = static_cast<uint32_t>(r >> 32) % (2 * V.tweak + 1);
+        t2 = static_cast<uint32_t>(r) % (2 * V.tweak + 1);
+    }
+    uint32_t sh = 0, rs = 0, re = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < P; p++) if (p == o.cix) { sh = G.shift[p]; rs = G.reg_start[p]; re = G.reg_end[p]; }
+    auto ix = [&](uint32_t mid, uint32_t tw) -> uint32_t {
+        if (mid == NONE32S) return 0u;                                       // UNMAPPED_WINDOW
+        const uint32_t m = mid + tw;
+        return (rs <= m && m < re) ? (m - rs) / V.window + sh : 1u;          // BOUNDARY_WINDOW
+    };
+    *w1 = ix(o.mid1, t1);
+    *w2 = ix(o.mid2, t2);
+}
 
 struct Move {                  // ReassignmentTarget + what reassign() needs
     uint32_t rp, new_assgn;
@@ -246,59 +328,44 @@ struct Move {                  // ReassignmentTarget + what reassign() needs
     double lp_old, lp_new;
 };
 
-// location `t` (and optionally `t2`) of read rp: ln_prob + tweaked windows
-__device__ __forceinline__ void fetch_two(const SolveView& V, const GtWin& G, const Locs& L, uint64_t seed, uint32_t rp, uint32_t ta,
+// location `ta` (and `tb`) of read rp: ln_prob + tweaked windows
+template <uint32_t P>
+__device__ __forceinline__ void fetch_two(const SolveView& V, const Geno<P>& G, const Locs<P>& L, uint64_t seed, uint32_t rp, uint32_t ta,
                                           uint32_t tb, Move& m) {
-    LocIter it; it.start(L);
+    LocIter<P> it; it.start(L);
     LocOut o;
-    for (uint32_t t = 0; t < L.nw && it.next(L, o); t++) {
+    for (uint32_t t = 0; t < L.nw && it.next(L, V, o); t++) {
         if (t == ta) { m.lp_old = o.lp; loc_windows(V, G, o, seed, rp, t, &m.w1, &m.w2); }
         if (t == tb) { m.lp_new = o.lp; loc_windows(V, G, o, seed, rp, t, &m.w3, &m.w4); }
         if (t >= ta && t >= tb) break;
     }
 }
 
-__global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
+// ---------------- K12 + K13: one 256-thread workgroup per chain ----------------
+template <uint32_t P>
+__global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t W = V.max_windows;
-    double* ww = reinterpret_cast<double*>(smem);                       // [W]
-    uint32_t* depth = reinterpret_cast<uint32_t*>(ww + W);              // [W]
-    uint8_t* wgc = reinterpret_cast<uint8_t*>(depth + W);               // [W]
-    double* red = reinterpret_cast<double*>(smem + ((W * 13 + 15) & ~15u));   // [256] reduction scratch
-    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(red + 256);        // [8]
+    uint32_t* depth = reinterpret_cast<uint32_t*>(smem);                          // [wstride]
+    double* red = reinterpret_cast<double*>(smem + ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)));   // [256]
+    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(red + 256);                  // [4]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = V.seeds[chain];
-    uint32_t ids[MAXP];
-    GtWin G;
-    uint32_t total_w = 2;                                               // REG_WINDOW_SHIFT
-#pragma unroll
-    for (uint32_t p = 0; p < MAXP; p++) {
-        ids[p] = 0; G.shift[p] = G.reg_start[p] = G.reg_end[p] = 0;
-        if (p < V.ploidy) {
-            ids[p] = V.genotypes[static_cast<uint64_t>(gi) * V.ploidy + p];
-            G.shift[p] = total_w;
-            G.reg_start[p] = V.reg_start[ids[p]];
-            const uint32_t nw = V.n_windows[ids[p]];
-            G.reg_end[p] = G.reg_start[p] + nw * V.window;
-            total_w += nw;
-        }
-    }
-    uint16_t* state = V.state + static_cast<uint64_t>(chain) * V.n_good;
-    uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.n_good;
+    Geno<P> G; G.init(V, gi);
+    uint8_t* state = V.state + static_cast<uint64_t>(chain) * V.ngp;
+    uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
+    double* ww = V.c_ww + static_cast<uint64_t>(chain) * V.wstride;
+    uint8_t* wgc = V.c_gc + static_cast<uint64_t>(chain) * V.wstride;
 
-    // ---------------- K12: window distributions (apply_tweak, assgn.rs:140-150) ----------------
-    for (uint32_t w = tid; w < total_w; w += 256) {
+    // K12: window distributions (apply_tweak, assgn.rs:140-150)
+    for (uint32_t w = tid; w < G.total_w; w += 256) {
         depth[w] = 0;
         double weight = 0.0; uint32_t g = 0;
         if (w >= 2) {
-            uint32_t p = 0;
+            uint32_t allele = G.id[0], sh = G.shift[0], rs = G.reg_start[0];
 #pragma unroll
-            for (uint32_t q = 1; q < MAXP; q++) if (q < V.ploidy && w >= G.shift[q]) p = q;
-            uint32_t allele = 0, sh = 0, rs = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < MAXP; q++) if (q == p) { allele = ids[q]; sh = G.shift[q]; rs = G.reg_start[q]; }
+            for (uint32_t q = 1; q < P; q++) if (w >= G.shift[q]) { allele = G.id[q]; sh = G.shift[q]; rs = G.reg_start[q]; }
             const uint32_t start = rs + (w - sh) * V.window, end = start + V.window;
             const uint32_t left = min(V.tweak, start), right = min(V.tweak, V.allele_len[allele] - end);
             const uint64_t r = counter_u64(seed ^ WINDOW_KEY_XOR, w);                 // rng.random_range(-left..=right)
@@ -313,7 +380,7 @@ __global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
     }
     __syncthreads();
 
-    // ---------------- K13: initial assignment, depth histogram, non-trivial reads ----------------
+    // K13: initial assignment, depth histogram, non-trivial reads
     const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
     double aln_part = 0.0;
     uint32_t nt_total = 0;
@@ -321,8 +388,7 @@ __global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
         const uint32_t rp = base + tid;
         bool nontrivial = false;
         if (rp < V.n_good) {
-            const uint32_t r = V.good_ix[rp];
-            Locs L; locs_init(L, V, r, ids);
+            Locs<P> L; locs_init(L, V, rp, G);
             uint32_t a0 = 0;
             if (L.nw > 1 && random_start)
                 a0 = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
@@ -331,7 +397,7 @@ __global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
             atomicAdd(&depth[m.w1], 1u);
             atomicAdd(&depth[m.w2], 1u);
             aln_part += m.lp_old;
-            state[rp] = static_cast<uint16_t>((min(L.nw, 255u) << 8) | a0);
+            state[rp] = static_cast<uint8_t>(a0);
             nontrivial = L.nw > 1;
         }
         // ordered compaction of the non-trivial reads (assgn.rs:61-63)
@@ -350,37 +416,80 @@ __global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
-    double aln_lik = red[0];
+    uint32_t* gdepth = V.c_depth + static_cast<uint64_t>(chain) * V.wstride;
+    for (uint32_t w = tid; w < G.total_w; w += 256) gdepth[w] = depth[w];
+    if (tid == 0) { V.c_aln[chain] = red[0]; V.c_nnt[chain] = nt_total; }
+}
+
+// window state of one chain in LDS
+struct Chain {
+    const SolveView* V;
+    uint32_t* depth;            // LDS
+    const uint8_t* wgc;         // LDS
+    const double* ww;           // LDS
+    // WindowDistr::ln_prob (distr_cache.rs:34-39) through the depth table
+    __device__ __forceinline__ double wlp(uint32_t w, uint32_t d) const {
+        const double weight = ww[w];
+        if (weight == 0.0) return 0.0;                                      // WindowDistr::TRIVIAL
+        const uint32_t g = wgc[w];
+        if (d >= V->lut_depth) { *V->overflow = 1u; return 0.0; }           // every chain of the batch is repeated
+        return weight * V->lut[g * V->lut_depth + d];
+    }
+    __device__ __forceinline__ double atomic_diff(uint32_t w, int32_t c) const {     // assgn.rs:244-254
+        if (c == 0) return 0.0;
+        const uint32_t old_depth = depth[w];
+        return wlp(w, static_cast<uint32_t>(static_cast<int32_t>(old_depth) + c)) - wlp(w, old_depth);
+    }
+    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {   // assgn.rs:259-284
+        int32_t c1 = -1, c2, c3, c4;
+        if (w2 == w1) { c1 -= 1; c2 = 0; } else c2 = -1;
+        if (w3 == w1) { c1 += 1; c3 = 0; } else if (w3 == w2) { c2 += 1; c3 = 0; } else c3 = 1;
+        if (w4 == w1) { c1 += 1; c4 = 0; } else if (w4 == w2) { c2 += 1; c4 = 0; } else if (w4 == w3) { c3 += 1; c4 = 0; } else c4 = 1;
+        return atomic_diff(w1, c1) + atomic_diff(w2, c2) + atomic_diff(w3, c3) + atomic_diff(w4, c4);
+    }
+};
+
+// ---------------- K14: one wavefront per chain ----------------
+template <uint32_t P>
+__global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t W = V.wstride;
+    double* ww = reinterpret_cast<double*>(smem);                       // [W]
+    uint32_t* depth = reinterpret_cast<uint32_t*>(ww + W);              // [W]
+    uint8_t* wgc = reinterpret_cast<uint8_t*>(depth + W);               // [W]
+    const uint32_t lane = threadIdx.x;
+    const uint32_t chain = blockIdx.x;
+    const uint32_t gi = chain / V.attempts;
+    const uint64_t seed = V.seeds[chain];
+    Geno<P> G; G.init(V, gi);
+    uint8_t* state = V.state + static_cast<uint64_t>(chain) * V.ngp;
+    const uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
+    {
+        const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
+        const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
+        const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
+        for (uint32_t w = lane; w < G.total_w; w += 64) { ww[w] = gww[w]; wgc[w] = ggc[w]; depth[w] = gd[w]; }
+    }
     __syncthreads();
     Chain C{&V, depth, wgc, ww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
-    double dl = 0.0;
-    for (uint32_t w = tid; w < total_w; w += 256) dl += C.wlp(w, depth[w]);
-    red[tid] = dl;
-    __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    double depth_lik = red[0];
-    __threadfence_block();
-    __syncthreads();
-    if (wave != 0) return;
-
-    // ---------------- K14: the solver chain on wave 0 ----------------
-    const uint32_t nnt = nt_total;
-    uint32_t* depth_rw = depth;
+    double depth_lik = 0.0;
+    for (uint32_t w = lane; w < G.total_w; w += 64) depth_lik += C.wlp(w, depth[w]);
+    for (int o2 = 32; o2 > 0; o2 >>= 1) depth_lik += __shfl_xor(depth_lik, o2);
+    double aln_lik = V.c_aln[chain];
+    const uint32_t nnt = V.c_nnt[chain];
     Xoshiro rng; rng.seed(seed);
     const double rel_contrib = V.depth_contrib / V.aln_contrib;
 
     auto load_state = [&](uint32_t rp) -> uint32_t {
-        return __hip_atomic_load(&state[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(&state[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // ReassignmentTarget::random (assgn.rs:451-471); wave-uniform
     auto random_move = [&](Move& m) {
         const uint32_t rp = nontriv[rng.below(nnt)];
-        const uint32_t st = load_state(rp);
-        const uint32_t total = st >> 8, old_assgn = st & 0xFFu;
+        const uint32_t old_assgn = load_state(rp);
+        Locs<P> L; locs_init(L, V, rp, G);
+        const uint32_t total = L.nw;
         uint32_t new_assgn;
         if (total == 2) new_assgn = 1 - old_assgn;
         else {
@@ -388,7 +497,6 @@ __global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
             new_assgn = i <= old_assgn ? i - 1 : i;
         }
         m.rp = rp; m.new_assgn = new_assgn;
-        Locs L; locs_init(L, V, V.good_ix[rp], ids);
         fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
     };
     auto improvement = [&](const Move& m) -> double {                         // calculate_improvement (assgn.rs:321-328)
@@ -398,11 +506,9 @@ __global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
         depth_lik += C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
         aln_lik += m.lp_new - m.lp_old;
         if (lane == 0) {
-            depth_rw[m.w3] += 1; depth_rw[m.w4] += 1;
-            depth_rw[m.w1] -= 1; depth_rw[m.w2] -= 1;
-            const uint32_t st = load_state(m.rp);
-            __hip_atomic_store(&state[m.rp], static_cast<uint16_t>((st & 0xFF00u) | m.new_assgn), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            depth[m.w3] += 1; depth[m.w4] += 1;
+            depth[m.w1] -= 1; depth[m.w2] -= 1;
+            __hip_atomic_store(&state[m.rp], static_cast<uint8_t>(m.new_assgn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -438,15 +544,15 @@ __global__ __launch_bounds__(256) void solve_chain_kernel(const SolveView V) {
                 Move mm; mm.rp = 0; mm.new_assgn = 0; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
                 if (lane < sample_size) {
                     const uint32_t rp = nontriv[my_pick];
-                    const uint32_t st = load_state(rp);
-                    const uint32_t old_assgn = st & 0xFFu;
-                    Locs L; locs_init(L, V, V.good_ix[rp], ids);
+                    const uint32_t old_assgn = load_state(rp);
+                    Locs<P> L; locs_init(L, V, rp, G);
+                    double best_improv = -INFINITY;
+                    // pass 1: the current location; pass 2: every other one (same merge, at most a handful of steps)
                     Move cur; cur.w1 = cur.w2 = 0; cur.lp_old = 0.0;
                     fetch_two(V, G, L, seed, rp, old_assgn, old_assgn, cur);
-                    double best_improv = -INFINITY;
-                    LocIter it; it.start(L);
+                    LocIter<P> it; it.start(L);
                     LocOut o;
-                    for (uint32_t t = 0; t < L.nw && it.next(L, o); t++) {
+                    for (uint32_t t = 0; t < L.nw && it.next(L, V, o); t++) {
                         if (t == old_assgn) continue;
                         uint32_t w3, w4;
                         loc_windows(V, G, o, seed, rp, t, &w3, &w4);
@@ -559,7 +665,73 @@ double ln_sum(const double* v, size_t n) {                // Ln::map_sum (math/m
 
 }  // namespace
 
+namespace {
+
+// location table + compact "unmapped" column of a scored batch (rebuilt after every lcty_score_reads)
+void ensure_solver_tables(lcty_reads* reads) {
+    reads->ensure_good_index();
+    if (reads->loc_table_valid) return;
+    lcty_ctx* ctx = reads->ctx;
+    lcty_locus* loc = reads->locus;
+    const uint64_t n_good = reads->n_good_cached, A = loc->n_alleles;
+    const uint64_t ngp = std::max<uint64_t>(64, (n_good + 63) / 64 * 64);
+    const size_t need = static_cast<size_t>(A) * ngp;
+    if (reads->d_t_lp.n < need) { reads->d_t_lp.alloc(need); reads->d_t_mid.alloc(need); reads->d_t_ext.alloc(need); }
+    if (reads->d_unm_g.n < ngp) reads->d_unm_g.alloc(ngp);
+    reads->ngp = ngp;
+    if (n_good) {
+        const dim3 grid(static_cast<uint32_t>(ngp / 64), static_cast<uint32_t>((A + 31) / 32));
+        ctx->timed(LCTY_K_SOLVE_TABLE, [&] {
+            hipLaunchKernelGGL(build_loc_table_kernel, grid, dim3(256), 0, ctx->stream, reads->d_good_ix.p, static_cast<uint32_t>(n_good), ngp,
+                               static_cast<uint32_t>(A), reads->d_pa_idx.p, reads->d_pa_off.p, reads->d_pa.p, reads->d_unmapped.p,
+                               reads->d_t_lp.p, reads->d_t_mid.p, reads->d_t_ext.p, reads->d_unm_g.p, reads->d_err.p);
+        });
+        LCTY_HIP(hipGetLastError());
+        uint32_t flag = 0;
+        reads->d_err.download(&flag, 1, ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        if (flag == LCTY_ERR_UNSUPPORTED) {
+            uint32_t zero = 0;
+            reads->d_err.upload(&zero, 1, ctx->stream);
+            fail(LCTY_ERR_UNSUPPORTED, "the device solver handles alleles below 16 Mb and pair-alignment arenas below 2^32 entries");
+        }
+    }
+    reads->loc_table_valid = true;
+}
+
+// depth table of the locus, wide enough for `n_good` reads piling up on the shortest contig
+void ensure_depth_table(lcty_locus* loc, uint64_t want) {
+    uint32_t depth = LCTY_DEPTH_CACHE;
+    while (depth < want) depth *= 2;
+    if (loc->lut_ext_depth >= depth) return;
+    lcty_ctx* ctx = loc->ctx;
+    loc->d_lut_ext.alloc(static_cast<size_t>(LCTY_GC_BINS) * depth);
+    const uint32_t n = LCTY_GC_BINS * depth;
+    hipLaunchKernelGGL(build_depth_table_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, loc->d_depth_lut.p, loc->d_depth_nb.p,
+                       static_cast<uint32_t>(loc->prm.n_alt_cn), depth, loc->d_lut_ext.p);
+    LCTY_HIP(hipGetLastError());
+    loc->lut_ext_depth = depth;
+}
+
+template <uint32_t P>
+void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, size_t lds_loop) {
+    hipStream_t s = ctx->stream;
+    if (lds_init > 48 * 1024)
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds_init)));
+    if (lds_loop > 48 * 1024)
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_loop_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds_loop)));
+    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); });
+    LCTY_HIP(hipGetLastError());
+    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(solve_loop_kernel<P>, dim3(nch), dim3(64), lds_loop, s, V); });
+    LCTY_HIP(hipGetLastError());
+}
+
+}  // namespace
+
 extern "C" {
+
 
 // Greedy::default / SimAnneal::default (src/solvers/stoch.rs:45-52, 161-168)
 int32_t lcty_solver_default(lcty_solver* s, int32_t kind) {
@@ -592,6 +764,8 @@ int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out) {
     });
 }
 
+
+
 int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
                          const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out) {
@@ -609,11 +783,18 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
         lcty_locus* loc = reads->locus;
         ctx->activate();
         reads->check_device_error();
-        reads->ensure_good_index();
         const uint32_t A = loc->n_alleles;
         for (uint64_t i = 0; i < n_gt * ploidy; i++)
             if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
-        const uint64_t n_good = reads->n_good_cached;
+        if (n_gt * attempts >= 0x7FFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many chains in one stage");
+        ensure_solver_tables(reads);
+        const uint64_t n_good = reads->n_good_cached, ngp = reads->ngp;
+        // depth table: wide enough for twice the mean depth of "every read on the shortest contig" (two mates per pair);
+        // a chain that still runs past it raises `overflow` and the batch is repeated with a wider table
+        uint32_t min_w = 0xFFFFFFFFu;
+        for (uint32_t a = 0; a < A; a++) min_w = std::min(min_w, std::max(loc->n_windows[a], 1u));
+        const uint64_t depth_cap = 2 * n_good + 2;                       // no window can be deeper
+        ensure_depth_table(loc, std::min<uint64_t>(4 * n_good / min_w + 64, depth_cap));
         hipStream_t s = ctx->stream;
 
         SolveView V{};
@@ -622,25 +803,27 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
         V.depth_contrib = 1.0 + loc->prm.lik_skew; V.aln_contrib = 1.0 - loc->prm.lik_skew;      // assgn.rs:80-81
         V.n_windows = loc->d_n_windows.p; V.reg_start = loc->d_reg_start.p; V.allele_len = loc->d_allele_len.p;
         V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
-        V.depth_lut = loc->d_depth_lut.p; V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
-        V.good_ix = reads->d_good_ix.p; V.n_good = static_cast<uint32_t>(n_good);
-        V.unmapped = reads->d_unmapped.p; V.pa = reads->d_pa.p; V.pa_off = reads->d_pa_off.p; V.pa_idx = reads->d_pa_idx.p;
+        V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
+        V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
+        V.unm_g = reads->d_unm_g.p; V.t_lp = reads->d_t_lp.p; V.t_mid = reads->d_t_mid.p; V.t_ext = reads->d_t_ext.p; V.pa = reads->d_pa.p;
         V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
-        V.max_windows = 2 + ploidy * loc->max_n_windows;
-        const size_t lds = ((static_cast<size_t>(V.max_windows) * 13 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
-        if (lds > 160 * 1024) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype do not fit in LDS", V.max_windows);
-        if (lds > 48 * 1024)
-            LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_chain_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
+        const size_t lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
+        const size_t lds_loop = static_cast<size_t>(V.wstride) * 13 + 16;
+        if (lds_loop > 160 * 1024) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype do not fit in LDS", V.wstride);
 
-        // chains are processed in batches so that the per-chain state (6 B per good read) stays bounded
-        const uint64_t per_chain = std::max<uint64_t>(n_good, 1) * 6;
-        const uint64_t budget = 24ull << 30;
+        // chains are processed in batches so that the per-chain state (5 B per good read) stays bounded
+        const uint64_t per_chain = ngp * 5 + static_cast<uint64_t>(V.wstride) * 13;
+        const uint64_t budget = 64ull << 30;
         const uint64_t gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
-        DevBuf<uint16_t> d_gt, d_state; DevBuf<uint32_t> d_nt; DevBuf<uint64_t> d_seeds; DevBuf<double> d_pri, d_liks, d_parts;
         const uint64_t max_chains = gt_per_batch * attempts;
-        d_state.alloc(max_chains * std::max<uint64_t>(n_good, 1));
-        d_nt.alloc(max_chains * std::max<uint64_t>(n_good, 1));
+        DevBuf<uint16_t> d_gt; DevBuf<uint8_t> d_state, d_cgc; DevBuf<uint32_t> d_nt, d_cdepth, d_cnnt; DevBuf<uint64_t> d_seeds;
+        DevBuf<double> d_pri, d_liks, d_parts, d_cww, d_caln;
+        DevBuf<uint32_t> d_ovf; d_ovf.alloc(1); d_ovf.zero(s);
+        d_state.alloc(max_chains * ngp);
+        d_nt.alloc(max_chains * ngp);
+        d_cww.alloc(max_chains * V.wstride); d_cgc.alloc(max_chains * V.wstride); d_cdepth.alloc(max_chains * V.wstride);
+        d_cnnt.alloc(max_chains); d_caln.alloc(max_chains);
         d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(2 * max_chains);
         if (priors) d_pri.alloc(gt_per_batch);
         std::vector<double> liks(max_chains);
@@ -651,12 +834,25 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
             if (priors) d_pri.upload(priors + g0, ng, s);
             V.genotypes = d_gt.p; V.seeds = d_seeds.p; V.priors = priors ? d_pri.p : nullptr;
             V.state = d_state.p; V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
-            ctx->timed(LCTY_K_SOLVE, [&] {
-                hipLaunchKernelGGL(solve_chain_kernel, dim3(static_cast<uint32_t>(nch)), dim3(256), lds, s, V);
-            });
-            LCTY_HIP(hipGetLastError());
-            d_liks.download(liks.data(), nch, s);
-            LCTY_HIP(hipStreamSynchronize(s));
+            V.c_ww = d_cww.p; V.c_gc = d_cgc.p; V.c_depth = d_cdepth.p; V.c_nnt = d_cnnt.p; V.c_aln = d_caln.p;
+            V.overflow = d_ovf.p;
+            for (;;) {
+                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth;
+                switch (ploidy) {
+                    case 1: launch_chains<1>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                    case 2: launch_chains<2>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                    case 3: launch_chains<3>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                    default: launch_chains<4>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                }
+                uint32_t ovf = 0;
+                d_ovf.download(&ovf, 1, s);
+                d_liks.download(liks.data(), nch, s);
+                LCTY_HIP(hipStreamSynchronize(s));
+                if (!ovf) break;
+                if (loc->lut_ext_depth >= depth_cap) fail(LCTY_ERR_RUNTIME, "window depth beyond 2 * reads + 2");
+                d_ovf.zero(s);
+                ensure_depth_table(loc, std::min<uint64_t>(4ull * loc->lut_ext_depth, depth_cap));
+            }
             for (uint64_t g = 0; g < ng; g++) {
                 // mean_variance_or_nan (src/ext/vec.rs:74-116)
                 const double* l = liks.data() + g * attempts;

@@ -1,0 +1,37 @@
+"""Developer measurement: solver-stage kernel time vs read count / chain count (config-2 shaped locus)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from locityper_amd import api, synth, cdefs
+
+def main():
+    A = int(sys.argv[1]); pairs = int(sys.argv[2]); chains = [int(x) for x in sys.argv[3].split(",")]
+    kinds = sys.argv[4] if len(sys.argv) > 4 else "ga"
+    L = synth.SynthLocus(A, pairs, seed=synth.SEED)
+    p = api.resolve_params(api.default_params(), L.bg)
+    ctx = api.Context(0)
+    loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    aa = None
+    chunk = 32768
+    for lo in range(0, pairs, chunk):
+        ch = L.reads(lo, min(chunk, pairs - lo))
+        if aa is None:
+            f = 1.05 * pairs / ch.n_pairs
+            aa = api.AllAlignments(loc, pairs, (int(ch.n_bases * f) + 2048) // 32 * 32, int(len(ch.recs) * f) + 4096, int(len(ch.cigar) * f) + 65536)
+        aa.append(ch)
+    aa.score()
+    sc = aa.run_filter()
+    gts = api.generate_genotypes(A, 2)
+    order = np.argsort(-sc, kind="stable")
+    print(f"A={A} pairs={pairs} n_good={aa.n_good()} max n_windows={max(loc.contig_info(a)[3] for a in range(min(A,4)))}", flush=True)
+    for kind, name in ((cdefs.SOLVER_GREEDY, "g"), (cdefs.SOLVER_ANNEAL, "a")):
+        if name not in kinds: continue
+        for n in chains:
+            sub = gts[order[:n]]
+            ctx.timing_reset()
+            t = time.time()
+            m, v, l = api.solve_stage(aa, sub, api.default_solver(kind), 1, api.chain_seeds(7, n))
+            dt = time.time() - t
+            print(f"  kind={name} chains={n}: wall {dt:.3f} s kernel {ctx.timing(api.K_SOLVE)[1]:.1f} ms best={sub[int(np.argmax(m))]} true={L.true_genotype}", flush=True)
+
+main()
