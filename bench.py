@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — reads/s scored + genotypes/s prefiltered on the BASELINE.json config
+"""bench.py — reads/s scored + genotypes/s solved on the BASELINE.json config
 ("1M synthetic 150 bp PE reads, 1 locus, 256 alleles, k=25" = configs[1]).
 
 A step = one pass of the hot path over one locus' batch, inputs resident in HBM:
@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per locus (BASELINE: 1M)")
     ap.add_argument("--alleles", type=int, default=256)
@@ -108,14 +108,16 @@ def main():
 
     gts = api.generate_genotypes(A, 2)
     greedy, anneal = api.default_solver(cdefs.SOLVER_GREEDY), api.default_solver(cdefs.SOLVER_ANNEAL)
-    stage_s = {"greedy": 0.0, "anneal": 0.0}
+    stage_s = {"score_prefilter": 0.0, "greedy": 0.0, "anneal": 0.0}
     solved = {"greedy_chains": 0, "anneal_chains": 0}
 
     def step(it=0):
+        t0s = time.perf_counter()
         aa.score()
         aa.prefilter_async()
         scores = aa.prefilter_scores()
         keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, 1)   # in_size of stage 1 (solve.rs:216-221)
+        stage_s["score_prefilter"] += time.perf_counter() - t0s
         if args.no_solve:
             return scores, keep, None
         # default scheme "-S greedy:i=5k,a=1 -S anneal:i=20,a=20" (solve.rs:211-230), then the final comparison
@@ -146,7 +148,7 @@ def main():
         step()
     barrier()
     ctx.timing_reset()
-    stage_s.update(greedy=0.0, anneal=0.0); solved.update(greedy_chains=0, anneal_chains=0)
+    stage_s.update(score_prefilter=0.0, greedy=0.0, anneal=0.0); solved.update(greedy_chains=0, anneal_chains=0)
     t_start = time.perf_counter()
     for it in range(args.steps):
         scores, keep, res = step(it)
@@ -162,6 +164,8 @@ def main():
     n_pref, ms_pref = ctx.timing(api.K_PREFILTER)
 
     n_solve, ms_solve = ctx.timing(api.K_SOLVE)
+    n_init, ms_init = ctx.timing(api.K_SOLVE_INIT)
+    n_tab, ms_tab = ctx.timing(api.K_SOLVE_TABLE)
     top = int(keep[0]) if res is None else int(res[0][0])
     called = tuple(int(x) for x in gts[top])
 
@@ -177,7 +181,8 @@ def main():
                     + 8 * 4 * args.pairs)      # what the kernel's inputs/outputs occupy, excl. pair-alignment arena
     achieved = alg_bytes / (score_ms * 1e-3) / 1e9
     out = {
-        "metric": "reads/s scored (read pairs -> likelihood-matrix row + all genotypes prefiltered)",
+        "metric": "reads/s through the whole genotyping path (scored + prefiltered + default solver scheme); "
+                  "reads_scored_per_s and genotypes_solved_per_s give the two halves",
         "value": reads_per_s,
         "unit": "read pairs/s",
         "n_gpus": world,
@@ -193,12 +198,16 @@ def main():
                                "(BASELINE.json configs[1])",
                    "read_pairs": args.pairs, "alleles": A, "genotypes": G, "k": 25,
                    "records": tot_recs, "cigar_words": tot_cigar, "parallelism": f"loci x{world}"},
-        "genotypes_per_s": world * G * args.steps / elapsed,
+        "reads_scored_per_s": world * args.pairs * args.steps / max(stage_s["score_prefilter"], 1e-9),
+        "genotypes_prefiltered_per_s": world * G * args.steps / max(stage_s["score_prefilter"], 1e-9),
         "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3),
-        "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms, "solve_chain_per_step": ms_solve / args.steps},
+        "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms, "solve_loop_per_step": ms_solve / args.steps,
+                      "solve_init_per_step": ms_init / args.steps, "solve_table_per_step": ms_tab / args.steps},
         "solver": None if args.no_solve else {
             "scheme": "greedy:i=5k,a=1 -> anneal:i=20,a=20 -> final comparison",
-            "genotypes_solved_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"] / 20.0) / elapsed,
+            "genotypes_solved_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"] / 20.0)
+                                      / max(stage_s["greedy"] + stage_s["anneal"], 1e-9),
+            "chains_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"]) / max(stage_s["greedy"] + stage_s["anneal"], 1e-9),
             "chains_per_step": {k: v / args.steps for k, v in solved.items()},
             "stage_ms_per_step": {k: 1e3 * v / args.steps for k, v in stage_s.items()},
             "quality": None if res is None else float(res[2])},
@@ -227,11 +236,25 @@ def main():
         t_load = time.perf_counter() - tc
         tc = time.perf_counter()
         so = O.run_filter(Mo, gts)
-        O.truncate(so, all_ixs, params.filt_diff, 5000, params.threads)
+        keep_o = O.truncate(so, all_ixs, params.filt_diff, 5000, 1)
         t_filter = time.perf_counter() - tc
-        out["cpu_baseline"] = {"value": ns / (t_load + t_filter), "unit": "read pairs/s", "cores": 1, "kind": "port",
-                               "sample": f"first {ns} read pairs of the same workload x {A} alleles, all {G} genotypes "
-                                         f"(load {t_load:.2f} s + run_filter {t_filter:.2f} s)",
+        t_solve_cpu, cpu_chains = 0.0, 0
+        if not args.no_solve:
+            # the same scheme, bounded: greedy on the best 64 of the kept genotypes, annealing on the best 2 with 4 attempts
+            tc = time.perf_counter()
+            sub = np.asarray(keep_o[:64], dtype=np.int64)
+            m, v, _ = O.solve_stage(ol, oa, gts[sub], greedy, 1, api.chain_seeds(1000, len(sub)))
+            best2 = sub[np.argsort(-m, kind="stable")[:2]]
+            O.solve_stage(ol, oa, gts[best2], anneal, 4, api.chain_seeds(2000, 8))
+            t_solve_cpu = time.perf_counter() - tc
+            cpu_chains = len(sub) + 8
+        out["cpu_baseline"] = {"value": ns / (t_load + t_filter + t_solve_cpu), "unit": "read pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"first {ns} read pairs of the same workload x {A} alleles, all {G} genotypes prefiltered "
+                                         f"(load {t_load:.2f} s + run_filter {t_filter:.2f} s)"
+                                         + (f", solver scheme bounded to greedy on 64 genotypes + annealing 2 x 4 attempts "
+                                            f"({cpu_chains} chains, {t_solve_cpu:.2f} s)" if cpu_chains else ""),
+                               "reads_scored_per_s": ns / (t_load + t_filter),
+                               "chains_per_s": (cpu_chains / t_solve_cpu) if cpu_chains else None,
                                "cpu_count": os.cpu_count()}
     print(json.dumps(out))
 

@@ -91,9 +91,7 @@ struct lcty_reads {
     bool good_valid = false;
     void ensure_good_index();
     // allele-major location table of the solver stages (lcty_solve.hip), rows of ngp entries
-    lcty::DevBuf<double> d_t_lp, d_unm_g;
-    lcty::DevBuf<uint2> d_t_mid;
-    lcty::DevBuf<uint32_t> d_t_ext;
+    lcty::DevBuf<uint8_t> d_loc_table;       // [A][ngp] 32-byte LocEntry cells
     uint64_t ngp = 0;
     bool loc_table_valid = false;
     lcty::DevBuf<uint32_t> d_err;

@@ -42,6 +42,17 @@ constexpr uint32_t MID_NONE24 = 0xFFFFFFu;    // "mate unmapped" inside the loca
 constexpr uint64_t WINDOW_KEY_XOR = 0xD1B54A32D192ED03ull;
 constexpr uint64_t INIT_KEY_XOR = 0x8CB92BA72F3D8DD7ull;
 
+// one (contig, good read) cell of the location table: everything a move needs from this contig in one 32-byte gather
+struct __attribute__((aligned(32))) LocEntry {
+    double lp;                      // best pair-alignment of the read pair on the contig, -inf = none
+    uint32_t m1n;                   // its first middle (24 bit, MID_NONE24 = unmapped mate) | number of pair-alignments << 24
+    uint32_t m2;                    // its second middle
+    double unm;                     // "both mates unmapped" probability of the read pair (same in every row)
+    uint32_t ext;                   // arena index of the second pair-alignment on this contig
+    uint32_t _pad;
+};
+static_assert(sizeof(LocEntry) == 32, "LocEntry layout");
+
 struct SolveView {
     // locus
     uint32_t A, window, left_padding, tweak;
@@ -59,10 +70,7 @@ struct SolveView {
     // reads
     uint32_t n_good;
     uint64_t ngp;                   // row stride of the location table (n_good rounded up to 64)
-    const double* unm_g;            // [n_good] "both mates unmapped" probability
-    const double* t_lp;             // [A][ngp]
-    const uint2* t_mid;             // [A][ngp]  x = mid1 (24 bit) | count << 24, y = mid2
-    const uint32_t* t_ext;          // [A][ngp]  arena index of the second pair-alignment on the contig
+    const LocEntry* table;          // [A][ngp]
     const PairAlnDev* pa;
     // chains
     const uint16_t* genotypes;      // [n_gt][ploidy]
@@ -70,8 +78,7 @@ struct SolveView {
     const uint64_t* seeds;          // [n_chains]
     const double* priors;           // [n_gt] or null
     lcty_solver solver;
-    uint8_t* state;                 // [n_chains][ngp] current location of every read
-    uint32_t* non_trivial;          // [n_chains][ngp]
+    uint32_t* non_trivial;          // [n_chains][ngp] read (24 bit) | current location << 24; trivial reads never move
     uint32_t wstride;               // per-chain stride of the window arrays (>= 2 + ploidy * max n_windows)
     double* c_ww;                   // [n_chains][wstride] window weights (0 = trivial distribution)
     uint8_t* c_gc;                  // [n_chains][wstride]
@@ -79,7 +86,7 @@ struct SolveView {
     uint32_t* c_nnt;                // [n_chains]
     double* c_aln;                  // [n_chains] alignment likelihood after K13
     double* liks;                   // [n_chains] prior + likelihood
-    double* parts;                  // [n_chains][2] aln_lik, depth_lik (diagnostics)
+    double* parts;                  // [n_chains][3] aln_lik, depth_lik, solver iterations (diagnostics)
     uint32_t* overflow;             // set when a window got deeper than the depth table (the host widens it and repeats)
 };
 
@@ -110,48 +117,37 @@ struct Xoshiro {
 __global__ __launch_bounds__(256) void build_loc_table_kernel(const uint32_t* __restrict__ good_ix, uint32_t n_good, uint64_t ngp,
                                                               uint32_t A, const uint32_t* __restrict__ pa_idx,
                                                               const uint64_t* __restrict__ pa_off, const PairAlnDev* __restrict__ pa,
-                                                              const double* __restrict__ unmapped, double* __restrict__ t_lp,
-                                                              uint2* __restrict__ t_mid, uint32_t* __restrict__ t_ext,
-                                                              double* __restrict__ unm_g, uint32_t* __restrict__ err) {
-    // 64 reads x 32 contigs per workgroup: the (pair, contig) index is read along contigs, the table written along reads
-    __shared__ double s_lp[64][33];
-    __shared__ uint2 s_mid[64][33];
-    __shared__ uint32_t s_ext[64][33];
-    const uint32_t g0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
-    {
-        const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
-        for (uint32_t i = ty; i < 64; i += 8) {
-            const uint32_t g = g0 + i, c = c0 + tx;
-            double lp = -INFINITY; uint2 mid = make_uint2(MID_NONE24, NONE32S); uint32_t ext = 0;
-            if (g < n_good && c < A) {
-                const uint32_t r = good_ix[g];
-                const uint32_t idx = pa_idx[static_cast<uint64_t>(r) * A + c];
-                const uint32_t cnt = idx >> 24;
-                if (cnt) {
-                    const uint64_t at = pa_off[r] + (idx & 0xFFFFFFu);
-                    const PairAlnDev e = pa[at];
-                    if ((e.mid1 != NONE32S && e.mid1 >= MID_NONE24) || at + cnt > 0xFFFFFFFFull)
-                        atomicMax(err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED));
-                    lp = e.ln_prob;
-                    mid.x = (e.mid1 == NONE32S ? MID_NONE24 : e.mid1) | (cnt << 24);
-                    mid.y = e.mid2;
-                    ext = static_cast<uint32_t>(at + 1);
-                }
-                if (c == 0) unm_g[g] = unmapped[r];
+                                                              const double* __restrict__ unmapped, LocEntry* __restrict__ table,
+                                                              uint32_t* __restrict__ err) {
+    // 32 reads x 32 contigs per workgroup: the (pair, contig) index is read along contigs, the table written along reads
+    __shared__ LocEntry tile[32][33];
+    const uint32_t g0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
+    for (uint32_t i = ty; i < 32; i += 8) {
+        const uint32_t g = g0 + i, c = c0 + tx;
+        LocEntry e{-INFINITY, MID_NONE24, NONE32S, 0.0, 0u, 0u};
+        if (g < n_good && c < A) {
+            const uint32_t r = good_ix[g];
+            const uint32_t idx = pa_idx[static_cast<uint64_t>(r) * A + c];
+            const uint32_t cnt = idx >> 24;
+            e.unm = unmapped[r];
+            if (cnt) {
+                const uint64_t at = pa_off[r] + (idx & 0xFFFFFFu);
+                const PairAlnDev p = pa[at];
+                if ((p.mid1 != NONE32S && p.mid1 >= MID_NONE24) || at + cnt > 0xFFFFFFFFull)
+                    atomicMax(err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED));
+                e.lp = p.ln_prob;
+                e.m1n = (p.mid1 == NONE32S ? MID_NONE24 : p.mid1) | (cnt << 24);
+                e.m2 = p.mid2;
+                e.ext = static_cast<uint32_t>(at + 1);
             }
-            s_lp[i][tx] = lp; s_mid[i][tx] = mid; s_ext[i][tx] = ext;
         }
+        tile[i][tx] = e;
     }
     __syncthreads();
-    {
-        const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
-        for (uint32_t j = ty; j < 32; j += 4) {
-            const uint32_t c = c0 + j, g = g0 + tx;
-            if (c < A && g < ngp) {
-                const uint64_t o = static_cast<uint64_t>(c) * ngp + g;
-                t_lp[o] = s_lp[tx][j]; t_mid[o] = s_mid[tx][j]; t_ext[o] = s_ext[tx][j];
-            }
-        }
+    for (uint32_t j = ty; j < 32; j += 8) {
+        const uint32_t c = c0 + j, g = g0 + tx;
+        if (c < A && g < ngp) table[static_cast<uint64_t>(c) * ngp + g] = tile[tx][j];
     }
 }
 
@@ -224,29 +220,27 @@ struct Locs {
 
 template <uint32_t P>
 __device__ __forceinline__ void locs_init(Locs<P>& L, const SolveView& V, uint32_t g, const Geno<P>& G) {
-    L.unm = V.unm_g[g];
-    double top = L.unm;
     uint32_t raw[P];
+    double top = -INFINITY;
 #pragma unroll
     for (uint32_t p = 0; p < P; p++) {
-        const uint64_t o = static_cast<uint64_t>(G.id[p]) * V.ngp + g;
-        L.lp[p] = V.t_lp[o];
-        const uint2 mid = V.t_mid[o];
-        raw[p] = mid.x >> 24;
-        L.m1[p] = (mid.x & MID_NONE24) == MID_NONE24 ? NONE32S : (mid.x & MID_NONE24);
-        L.m2[p] = mid.y;
-        L.ext[p] = 0;
-        top = fmax(top, L.lp[p]);                                           // -inf where the contig has nothing
+        const LocEntry e = V.table[static_cast<uint64_t>(G.id[p]) * V.ngp + g];
+        L.lp[p] = e.lp;
+        raw[p] = e.m1n >> 24;
+        L.m1[p] = (e.m1n & MID_NONE24) == MID_NONE24 ? NONE32S : (e.m1n & MID_NONE24);
+        L.m2[p] = e.m2;
+        L.ext[p] = e.ext;
+        L.unm = e.unm;
+        top = fmax(top, e.lp);                                              // -inf where the contig has nothing
     }
+    top = fmax(top, L.unm);
     const double thresh = top - V.prob_diff;                                // max(unm - d, best_i - d, ...) == max(...) - d
     L.nw = 0;
 #pragma unroll
     for (uint32_t p = 0; p < P; p++) {
         uint32_t k = (raw[p] && L.lp[p] >= thresh) ? 1u : 0u;
-        if (k && raw[p] > 1) {
-            L.ext[p] = V.t_ext[static_cast<uint64_t>(G.id[p]) * V.ngp + g];
+        if (k && raw[p] > 1)
             while (k < raw[p] && V.pa[L.ext[p] + k - 1].ln_prob >= thresh) k++;
-        }
         L.n[p] = k;
         L.nw += k;
     }
@@ -323,7 +317,7 @@ __device__ __forceinline__ void loc_windows(const SolveView& V, const Geno<P>& G
 }
 
 struct Move {                  // ReassignmentTarget + what reassign() needs
-    uint32_t rp, new_assgn;
+    uint32_t rp, new_assgn, slot;
     uint32_t w1, w2, w3, w4;
     double lp_old, lp_new;
 };
@@ -353,7 +347,6 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = V.seeds[chain];
     Geno<P> G; G.init(V, gi);
-    uint8_t* state = V.state + static_cast<uint64_t>(chain) * V.ngp;
     uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
     double* ww = V.c_ww + static_cast<uint64_t>(chain) * V.wstride;
     uint8_t* wgc = V.c_gc + static_cast<uint64_t>(chain) * V.wstride;
@@ -387,9 +380,10 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     for (uint32_t base = 0; base < V.n_good; base += 256) {
         const uint32_t rp = base + tid;
         bool nontrivial = false;
+        uint32_t a0 = 0;
         if (rp < V.n_good) {
             Locs<P> L; locs_init(L, V, rp, G);
-            uint32_t a0 = 0;
+            if (L.nw > 255) atomicMax(V.overflow, 2u);                           // the list keeps the location in 8 bits
             if (L.nw > 1 && random_start)
                 a0 = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
             Move m; m.w1 = m.w2 = 0; m.lp_old = 0.0;
@@ -397,7 +391,6 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
             atomicAdd(&depth[m.w1], 1u);
             atomicAdd(&depth[m.w2], 1u);
             aln_part += m.lp_old;
-            state[rp] = static_cast<uint8_t>(a0);
             nontrivial = L.nw > 1;
         }
         // ordered compaction of the non-trivial reads (assgn.rs:61-63)
@@ -406,7 +399,7 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
         __syncthreads();
         uint32_t before = nt_total;
         for (uint32_t q = 0; q < wave; q++) before += wave_cnt[q];
-        if (nontrivial) nontriv[before + static_cast<uint32_t>(__popcll(bal & ((1ull << lane) - 1ull)))] = rp;
+        if (nontrivial) nontriv[before + static_cast<uint32_t>(__popcll(bal & ((1ull << lane) - 1ull)))] = rp | (a0 << 24);
         nt_total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
@@ -421,24 +414,24 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     if (tid == 0) { V.c_aln[chain] = red[0]; V.c_nnt[chain] = nt_total; }
 }
 
-// window state of one chain in LDS
+// window state of one chain: depth (25 bit) | GC bin << 25 in LDS, weights in the chain's row of c_ww (L2)
+constexpr uint32_t DEPTH_MASK = 0x1FFFFFFu;
 struct Chain {
     const SolveView* V;
-    uint32_t* depth;            // LDS
-    const uint8_t* wgc;         // LDS
-    const double* ww;           // LDS
+    uint32_t* wd;               // LDS
+    const double* ww;           // global
     // WindowDistr::ln_prob (distr_cache.rs:34-39) through the depth table
-    __device__ __forceinline__ double wlp(uint32_t w, uint32_t d) const {
+    __device__ __forceinline__ double wlp(uint32_t w, uint32_t g, uint32_t d) const {
         const double weight = ww[w];
         if (weight == 0.0) return 0.0;                                      // WindowDistr::TRIVIAL
-        const uint32_t g = wgc[w];
-        if (d >= V->lut_depth) { *V->overflow = 1u; return 0.0; }           // every chain of the batch is repeated
+        if (d >= V->lut_depth) { atomicMax(V->overflow, 1u); return 0.0; }  // every chain of the batch is repeated
         return weight * V->lut[g * V->lut_depth + d];
     }
     __device__ __forceinline__ double atomic_diff(uint32_t w, int32_t c) const {     // assgn.rs:244-254
         if (c == 0) return 0.0;
-        const uint32_t old_depth = depth[w];
-        return wlp(w, static_cast<uint32_t>(static_cast<int32_t>(old_depth) + c)) - wlp(w, old_depth);
+        const uint32_t word = wd[w];
+        const uint32_t old_depth = word & DEPTH_MASK, g = word >> 25;
+        return wlp(w, g, static_cast<uint32_t>(static_cast<int32_t>(old_depth) + c)) - wlp(w, g, old_depth);
     }
     __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {   // assgn.rs:259-284
         int32_t c1 = -1, c2, c3, c4;
@@ -451,43 +444,41 @@ struct Chain {
 
 // ---------------- K14: one wavefront per chain ----------------
 template <uint32_t P>
-__global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
+__global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t W = V.wstride;
-    double* ww = reinterpret_cast<double*>(smem);                       // [W]
-    uint32_t* depth = reinterpret_cast<uint32_t*>(ww + W);              // [W]
-    uint8_t* wgc = reinterpret_cast<uint8_t*>(depth + W);               // [W]
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem);                   // [W] depth | GC bin << 25
     const uint32_t lane = threadIdx.x;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = V.seeds[chain];
     Geno<P> G; G.init(V, gi);
-    uint8_t* state = V.state + static_cast<uint64_t>(chain) * V.ngp;
-    const uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
+    uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
+    const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
     {
-        const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
         const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
         const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
-        for (uint32_t w = lane; w < G.total_w; w += 64) { ww[w] = gww[w]; wgc[w] = ggc[w]; depth[w] = gd[w]; }
+        for (uint32_t w = lane; w < G.total_w; w += 64) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
     }
     __syncthreads();
-    Chain C{&V, depth, wgc, ww};
+    Chain C{&V, wd, gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
-    for (uint32_t w = lane; w < G.total_w; w += 64) depth_lik += C.wlp(w, depth[w]);
+    for (uint32_t w = lane; w < G.total_w; w += 64) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
     for (int o2 = 32; o2 > 0; o2 >>= 1) depth_lik += __shfl_xor(depth_lik, o2);
     double aln_lik = V.c_aln[chain];
     const uint32_t nnt = V.c_nnt[chain];
     Xoshiro rng; rng.seed(seed);
     const double rel_contrib = V.depth_contrib / V.aln_contrib;
 
-    auto load_state = [&](uint32_t rp) -> uint32_t {
-        return __hip_atomic_load(&state[rp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    auto load_slot = [&](uint32_t slot) -> uint32_t {
+        return __hip_atomic_load(&nontriv[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // ReassignmentTarget::random (assgn.rs:451-471); wave-uniform
     auto random_move = [&](Move& m) {
-        const uint32_t rp = nontriv[rng.below(nnt)];
-        const uint32_t old_assgn = load_state(rp);
+        m.slot = static_cast<uint32_t>(rng.below(nnt));
+        const uint32_t packed = load_slot(m.slot);
+        const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
         Locs<P> L; locs_init(L, V, rp, G);
         const uint32_t total = L.nw;
         uint32_t new_assgn;
@@ -506,14 +497,15 @@ __global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
         depth_lik += C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
         aln_lik += m.lp_new - m.lp_old;
         if (lane == 0) {
-            depth[m.w3] += 1; depth[m.w4] += 1;
-            depth[m.w1] -= 1; depth[m.w2] -= 1;
-            __hip_atomic_store(&state[m.rp], static_cast<uint8_t>(m.new_assgn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            wd[m.w3] += 1; wd[m.w4] += 1;                                     // the depth field never borrows from the GC bits
+            wd[m.w1] -= 1; wd[m.w2] -= 1;
+            __hip_atomic_store(&nontriv[m.slot], m.rp | (m.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
 
+    uint64_t n_iter = 0;
     if (nnt > 0) {
         // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
         double max_abs = 0.0;
@@ -527,6 +519,7 @@ __global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
             const uint32_t sample_size = min(V.solver.sample_size, nnt);
             uint32_t curr_plato = 0;
             for (uint64_t iter = 0; iter < max_iter; iter++) {
+                n_iter++;
                 // non_trivial_reads.sample(rng, sample_size): distinct indices, repeats rejected (our adaptor);
                 // lane j keeps the j-th pick
                 uint32_t my_pick = NONE32S;
@@ -541,10 +534,10 @@ __global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
                 }
                 // best_read_improvement (assgn.rs:287-317), one candidate read per lane
                 double my_improv = -INFINITY;
-                Move mm; mm.rp = 0; mm.new_assgn = 0; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
+                Move mm; mm.rp = 0; mm.new_assgn = 0; mm.slot = my_pick; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
                 if (lane < sample_size) {
-                    const uint32_t rp = nontriv[my_pick];
-                    const uint32_t old_assgn = load_state(rp);
+                    const uint32_t packed = load_slot(my_pick);
+                    const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
                     Locs<P> L; locs_init(L, V, rp, G);
                     double best_improv = -INFINITY;
                     // pass 1: the current location; pass 2: every other one (same merge, at most a handful of steps)
@@ -572,7 +565,7 @@ __global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
                 if (best > min_diff && who) {
                     const int src = __ffsll(static_cast<long long>(who)) - 1;
                     Move m;
-                    m.rp = __shfl(mm.rp, src); m.new_assgn = __shfl(mm.new_assgn, src);
+                    m.rp = __shfl(mm.rp, src); m.new_assgn = __shfl(mm.new_assgn, src); m.slot = __shfl(mm.slot, src);
                     m.w1 = __shfl(mm.w1, src); m.w2 = __shfl(mm.w2, src); m.w3 = __shfl(mm.w3, src); m.w4 = __shfl(mm.w4, src);
                     m.lp_old = __shfl(mm.lp_old, src); m.lp_new = __shfl(mm.lp_new, src);
                     curr_plato = 0;
@@ -588,6 +581,7 @@ __global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
             const double temp_step = start_temp / static_cast<double>(V.solver.anneal_steps);
             uint32_t curr_plato = 0;
             for (uint32_t i = V.solver.anneal_steps; i >= 1; i--) {
+                n_iter++;
                 Move m; random_move(m);
                 const double diff = improvement(m) - min_diff;
                 bool accept = diff >= 0.0;
@@ -597,6 +591,7 @@ __global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
             }
             for (uint64_t iter = 0; iter < max_iter; iter++) {
                 if (curr_plato >= V.solver.plato_size) break;
+                n_iter++;
                 Move m; random_move(m);
                 const double diff = improvement(m);
                 if (diff > min_diff) { reassign(m); curr_plato = 0; } else curr_plato++;
@@ -606,7 +601,7 @@ __global__ __launch_bounds__(64) void solve_loop_kernel(const SolveView V) {
     if (lane == 0) {
         const double lik = V.depth_contrib * depth_lik + V.aln_contrib * aln_lik;       // assgn.rs:235-237
         V.liks[chain] = (V.priors ? V.priors[gi] : 0.0) + lik;                          // solve.rs:827
-        V.parts[2 * chain] = aln_lik; V.parts[2 * chain + 1] = depth_lik;
+        V.parts[3 * chain] = aln_lik; V.parts[3 * chain + 1] = depth_lik; V.parts[3 * chain + 2] = static_cast<double>(n_iter);
     }
 }
 
@@ -676,15 +671,15 @@ void ensure_solver_tables(lcty_reads* reads) {
     const uint64_t n_good = reads->n_good_cached, A = loc->n_alleles;
     const uint64_t ngp = std::max<uint64_t>(64, (n_good + 63) / 64 * 64);
     const size_t need = static_cast<size_t>(A) * ngp;
-    if (reads->d_t_lp.n < need) { reads->d_t_lp.alloc(need); reads->d_t_mid.alloc(need); reads->d_t_ext.alloc(need); }
-    if (reads->d_unm_g.n < ngp) reads->d_unm_g.alloc(ngp);
+    if (n_good >= (1ull << 24)) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles up to 2^24 good read pairs per locus");
+    if (reads->d_loc_table.n < need * sizeof(LocEntry)) reads->d_loc_table.alloc(need * sizeof(LocEntry));
     reads->ngp = ngp;
     if (n_good) {
-        const dim3 grid(static_cast<uint32_t>(ngp / 64), static_cast<uint32_t>((A + 31) / 32));
+        const dim3 grid(static_cast<uint32_t>(ngp / 32), static_cast<uint32_t>((A + 31) / 32));
         ctx->timed(LCTY_K_SOLVE_TABLE, [&] {
             hipLaunchKernelGGL(build_loc_table_kernel, grid, dim3(256), 0, ctx->stream, reads->d_good_ix.p, static_cast<uint32_t>(n_good), ngp,
                                static_cast<uint32_t>(A), reads->d_pa_idx.p, reads->d_pa_off.p, reads->d_pa.p, reads->d_unmapped.p,
-                               reads->d_t_lp.p, reads->d_t_mid.p, reads->d_t_ext.p, reads->d_unm_g.p, reads->d_err.p);
+                               reinterpret_cast<LocEntry*>(reads->d_loc_table.p), reads->d_err.p);
         });
         LCTY_HIP(hipGetLastError());
         uint32_t flag = 0;
@@ -805,26 +800,25 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
         V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
         V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
-        V.unm_g = reads->d_unm_g.p; V.t_lp = reads->d_t_lp.p; V.t_mid = reads->d_t_mid.p; V.t_ext = reads->d_t_ext.p; V.pa = reads->d_pa.p;
+        V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p;
         V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
         V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
         const size_t lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
-        const size_t lds_loop = static_cast<size_t>(V.wstride) * 13 + 16;
+        const size_t lds_loop = static_cast<size_t>(V.wstride) * 4 + 16;
         if (lds_loop > 160 * 1024) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype do not fit in LDS", V.wstride);
 
-        // chains are processed in batches so that the per-chain state (5 B per good read) stays bounded
-        const uint64_t per_chain = ngp * 5 + static_cast<uint64_t>(V.wstride) * 13;
+        // chains are processed in batches so that the per-chain state (4 B per good read) stays bounded
+        const uint64_t per_chain = ngp * 4 + static_cast<uint64_t>(V.wstride) * 13;
         const uint64_t budget = 64ull << 30;
         const uint64_t gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
         const uint64_t max_chains = gt_per_batch * attempts;
-        DevBuf<uint16_t> d_gt; DevBuf<uint8_t> d_state, d_cgc; DevBuf<uint32_t> d_nt, d_cdepth, d_cnnt; DevBuf<uint64_t> d_seeds;
+        DevBuf<uint16_t> d_gt; DevBuf<uint8_t> d_cgc; DevBuf<uint32_t> d_nt, d_cdepth, d_cnnt; DevBuf<uint64_t> d_seeds;
         DevBuf<double> d_pri, d_liks, d_parts, d_cww, d_caln;
         DevBuf<uint32_t> d_ovf; d_ovf.alloc(1); d_ovf.zero(s);
-        d_state.alloc(max_chains * ngp);
         d_nt.alloc(max_chains * ngp);
         d_cww.alloc(max_chains * V.wstride); d_cgc.alloc(max_chains * V.wstride); d_cdepth.alloc(max_chains * V.wstride);
         d_cnnt.alloc(max_chains); d_caln.alloc(max_chains);
-        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(2 * max_chains);
+        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(3 * max_chains);
         if (priors) d_pri.alloc(gt_per_batch);
         std::vector<double> liks(max_chains);
         for (uint64_t g0 = 0; g0 < n_gt; g0 += gt_per_batch) {
@@ -833,7 +827,7 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
             d_seeds.upload(chain_seeds + g0 * attempts, nch, s);
             if (priors) d_pri.upload(priors + g0, ng, s);
             V.genotypes = d_gt.p; V.seeds = d_seeds.p; V.priors = priors ? d_pri.p : nullptr;
-            V.state = d_state.p; V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
+            V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
             V.c_ww = d_cww.p; V.c_gc = d_cgc.p; V.c_depth = d_cdepth.p; V.c_nnt = d_cnnt.p; V.c_aln = d_caln.p;
             V.overflow = d_ovf.p;
             for (;;) {
@@ -848,7 +842,17 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                 d_ovf.download(&ovf, 1, s);
                 d_liks.download(liks.data(), nch, s);
                 LCTY_HIP(hipStreamSynchronize(s));
+                if (!ovf && getenv("LCTY_SOLVE_STATS")) {
+                    std::vector<double> parts(3 * nch);
+                    d_parts.download(parts.data(), 3 * nch, s);
+                    LCTY_HIP(hipStreamSynchronize(s));
+                    double sum = 0, mx = 0, mn = 1e300;
+                    for (uint64_t c = 0; c < nch; c++) { const double it = parts[3 * c + 2]; sum += it; mx = std::max(mx, it); mn = std::min(mn, it); }
+                    fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f lut_depth=%u\n",
+                            static_cast<unsigned long long>(nch), sum / nch, mn, mx, loc->lut_ext_depth);
+                }
                 if (!ovf) break;
+                if (ovf == 2) fail(LCTY_ERR_UNSUPPORTED, "a read pair with more than 255 possible locations on one genotype");
                 if (loc->lut_ext_depth >= depth_cap) fail(LCTY_ERR_RUNTIME, "window depth beyond 2 * reads + 2");
                 d_ovf.zero(s);
                 ensure_depth_table(loc, std::min<uint64_t>(4ull * loc->lut_ext_depth, depth_cap));
