@@ -42,6 +42,24 @@ constexpr uint32_t MID_NONE24 = 0xFFFFFFu;    // "mate unmapped" inside the loca
 constexpr uint64_t WINDOW_KEY_XOR = 0xD1B54A32D192ED03ull;
 constexpr uint64_t INIT_KEY_XOR = 0x8CB92BA72F3D8DD7ull;
 
+// exact n / d and n % d for every 32-bit n by multiplication (Granlund & Montgomery); d is a locus constant
+struct FastDiv {
+    uint32_t d, m, s1, s2;
+    __host__ static FastDiv make(uint32_t d) {
+        FastDiv f{d, 0, 0, 0};
+        uint32_t l = 0;
+        while ((1ull << l) < d) l++;
+        f.m = static_cast<uint32_t>(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+        f.s1 = l < 1 ? l : 1; f.s2 = l > 0 ? l - 1 : 0;
+        return f;
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+    __device__ __forceinline__ uint32_t mod(uint32_t n) const { return n - div(n) * d; }
+};
+
 // one (contig, good read) cell of the location table: everything a move needs from this contig in one 32-byte gather
 struct __attribute__((aligned(32))) LocEntry {
     double lp;                      // best pair-alignment of the read pair on the contig, -inf = none
@@ -56,6 +74,7 @@ static_assert(sizeof(LocEntry) == 32, "LocEntry layout");
 struct SolveView {
     // locus
     uint32_t A, window, left_padding, tweak;
+    FastDiv by_window, by_tweak;    // window; 2 * tweak + 1
     double min_weight, prob_diff, depth_contrib, aln_contrib;
     const uint32_t* n_windows;
     const uint32_t* reg_start;
@@ -301,8 +320,8 @@ __device__ __forceinline__ void loc_windows(const SolveView& V, const Geno<P>& G
     uint32_t t1 = 0, t2 = 0;
     if (V.tweak) {
         const uint64_t r = counter_u64(seed, (static_cast<uint64_t>(rp) << 16) | t);
-        t1 = static_cast<uint32_t>(r >> 32) % (2 * V.tweak + 1);
-        t2 = static_cast<uint32_t>(r) % (2 * V.tweak + 1);
+        t1 = V.by_tweak.mod(static_cast<uint32_t>(r >> 32));
+        t2 = V.by_tweak.mod(static_cast<uint32_t>(r));
     }
     uint32_t sh = 0, rs = 0, re = 0;
 #pragma unroll
@@ -310,7 +329,7 @@ __device__ __forceinline__ void loc_windows(const SolveView& V, const Geno<P>& G
     auto ix = [&](uint32_t mid, uint32_t tw) -> uint32_t {
         if (mid == NONE32S) return 0u;                                       // UNMAPPED_WINDOW
         const uint32_t m = mid + tw;
-        return (rs <= m && m < re) ? (m - rs) / V.window + sh : 1u;          // BOUNDARY_WINDOW
+        return (rs <= m && m < re) ? V.by_window.div(m - rs) + sh : 1u;      // BOUNDARY_WINDOW
     };
     *w1 = ix(o.mid1, t1);
     *w2 = ix(o.mid2, t2);
@@ -320,6 +339,7 @@ struct Move {                  // ReassignmentTarget + what reassign() needs
     uint32_t rp, new_assgn, slot;
     uint32_t w1, w2, w3, w4;
     double lp_old, lp_new;
+    double ddiff;              // depth_lik_diff(w1, w2, w3, w4) at the time the move was evaluated
 };
 
 // location `ta` (and `tb`) of read rp: ln_prob + tweaked windows
@@ -427,18 +447,40 @@ struct Chain {
         if (d >= V->lut_depth) { atomicMax(V->overflow, 1u); return 0.0; }  // every chain of the batch is repeated
         return weight * V->lut[g * V->lut_depth + d];
     }
-    __device__ __forceinline__ double atomic_diff(uint32_t w, int32_t c) const {     // assgn.rs:244-254
-        if (c == 0) return 0.0;
-        const uint32_t word = wd[w];
-        const uint32_t old_depth = word & DEPTH_MASK, g = word >> 25;
-        return wlp(w, g, static_cast<uint32_t>(static_cast<int32_t>(old_depth) + c)) - wlp(w, g, old_depth);
-    }
-    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {   // assgn.rs:259-284
-        int32_t c1 = -1, c2, c3, c4;
-        if (w2 == w1) { c1 -= 1; c2 = 0; } else c2 = -1;
-        if (w3 == w1) { c1 += 1; c3 = 0; } else if (w3 == w2) { c2 += 1; c3 = 0; } else c3 = 1;
-        if (w4 == w1) { c1 += 1; c4 = 0; } else if (w4 == w2) { c2 += 1; c4 = 0; } else if (w4 == w3) { c3 += 1; c4 = 0; } else c4 = 1;
-        return atomic_diff(w1, c1) + atomic_diff(w2, c2) + atomic_diff(w3, c3) + atomic_diff(w4, c4);
+    // depth_lik_diff (assgn.rs:259-284) = sum of atomic_depth_lik_diff (244-254) over the four windows. All operands
+    // are fetched before any of them is used: one LDS round trip, then twelve independent L2 gathers.
+    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {
+        int32_t c[4];
+        c[0] = -1;
+        if (w2 == w1) { c[0] -= 1; c[1] = 0; } else c[1] = -1;
+        if (w3 == w1) { c[0] += 1; c[2] = 0; } else if (w3 == w2) { c[1] += 1; c[2] = 0; } else c[2] = 1;
+        if (w4 == w1) { c[0] += 1; c[3] = 0; } else if (w4 == w2) { c[1] += 1; c[3] = 0; } else if (w4 == w3) { c[2] += 1; c[3] = 0; } else c[3] = 1;
+        const uint32_t w[4] = {w1, w2, w3, w4};
+        uint32_t word[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) word[i] = wd[w[i]];
+        double weight[4], vnew[4], vold[4];
+        uint32_t deepest[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t d_old = word[i] & DEPTH_MASK, row = (word[i] >> 25) * V->lut_depth;
+            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + c[i]);
+            deepest[i] = max(d_new, d_old);
+            weight[i] = ww[w[i]];
+            vnew[i] = V->lut[row + min(d_new, V->lut_depth - 1)];
+            vold[i] = V->lut[row + min(d_old, V->lut_depth - 1)];
+        }
+        double sum = 0.0;
+        bool over = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool live = c[i] != 0 && weight[i] != 0.0;                 // c == 0: no change; weight 0: WindowDistr::TRIVIAL
+            over |= live && deepest[i] >= V->lut_depth;
+            const double term = live ? weight[i] * vnew[i] - weight[i] * vold[i] : 0.0;
+            sum = i == 0 ? term : sum + term;
+        }
+        if (over) atomicMax(V->overflow, 1u);                               // every chain of the batch is repeated
+        return sum;
     }
 };
 
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
     // ReassignmentTarget::random (assgn.rs:451-471); wave-uniform
     auto random_move = [&](Move& m) {
         m.slot = static_cast<uint32_t>(rng.below(nnt));
-        const uint32_t packed = load_slot(m.slot);
+        const uint32_t packed = __builtin_amdgcn_readfirstlane(load_slot(m.slot));      // the move is wave-uniform
         const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
         Locs<P> L; locs_init(L, V, rp, G);
         const uint32_t total = L.nw;
@@ -489,12 +531,13 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
         }
         m.rp = rp; m.new_assgn = new_assgn;
         fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
+        m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
     };
     auto improvement = [&](const Move& m) -> double {                         // calculate_improvement (assgn.rs:321-328)
-        return V.depth_contrib * C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4) + V.aln_contrib * (m.lp_new - m.lp_old);
+        return V.depth_contrib * m.ddiff + V.aln_contrib * (m.lp_new - m.lp_old);
     };
     auto reassign = [&](const Move& m) {                                      // assgn.rs:331-343 (wave-uniform move)
-        depth_lik += C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+        depth_lik += m.ddiff;                                                 // nothing moved since it was evaluated
         aln_lik += m.lp_new - m.lp_old;
         if (lane == 0) {
             wd[m.w3] += 1; wd[m.w4] += 1;                                     // the depth field never borrows from the GC bits
@@ -535,6 +578,7 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
                 // best_read_improvement (assgn.rs:287-317), one candidate read per lane
                 double my_improv = -INFINITY;
                 Move mm; mm.rp = 0; mm.new_assgn = 0; mm.slot = my_pick; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
+                mm.ddiff = 0.0;
                 if (lane < sample_size) {
                     const uint32_t packed = load_slot(my_pick);
                     const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
@@ -549,10 +593,11 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
                         if (t == old_assgn) continue;
                         uint32_t w3, w4;
                         loc_windows(V, G, o, seed, rp, t, &w3, &w4);
-                        const double improv = o.lp + rel_contrib * C.depth_lik_diff(cur.w1, cur.w2, w3, w4);
+                        const double dd = C.depth_lik_diff(cur.w1, cur.w2, w3, w4);
+                        const double improv = o.lp + rel_contrib * dd;
                         if (improv > best_improv) {
                             best_improv = improv;
-                            mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = o.lp;
+                            mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = o.lp; mm.ddiff = dd;
                         }
                     }
                     mm.rp = rp; mm.w1 = cur.w1; mm.w2 = cur.w2; mm.lp_old = cur.lp_old;
@@ -567,7 +612,7 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
                     Move m;
                     m.rp = __shfl(mm.rp, src); m.new_assgn = __shfl(mm.new_assgn, src); m.slot = __shfl(mm.slot, src);
                     m.w1 = __shfl(mm.w1, src); m.w2 = __shfl(mm.w2, src); m.w3 = __shfl(mm.w3, src); m.w4 = __shfl(mm.w4, src);
-                    m.lp_old = __shfl(mm.lp_old, src); m.lp_new = __shfl(mm.lp_new, src);
+                    m.lp_old = __shfl(mm.lp_old, src); m.lp_new = __shfl(mm.lp_new, src); m.ddiff = __shfl(mm.ddiff, src);
                     curr_plato = 0;
                     reassign(m);
                 } else {
@@ -793,6 +838,7 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
         hipStream_t s = ctx->stream;
 
         SolveView V{};
+        V.by_window = FastDiv::make(loc->bg.window); V.by_tweak = FastDiv::make(2 * static_cast<uint32_t>(loc->prm.tweak) + 1);
         V.A = A; V.window = loc->bg.window; V.left_padding = loc->left_padding; V.tweak = static_cast<uint32_t>(loc->prm.tweak);
         V.min_weight = loc->prm.min_weight; V.prob_diff = loc->prm.prob_diff;
         V.depth_contrib = 1.0 + loc->prm.lik_skew; V.aln_contrib = 1.0 - loc->prm.lik_skew;      // assgn.rs:80-81
