@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--alleles", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
+                    help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
     return ap.parse_args()
 
@@ -221,6 +223,16 @@ def main():
         "called_genotype": called, "true_genotype": L.true_genotype, "kept_after_prefilter": int(len(keep)),
         "setup_s": {"generate_and_upload": gen_s, "locus_create": locus_setup_s},
     }
+
+    # HBM traffic of the scoring kernel from the committed PMC passes (counters cannot be read from inside this process)
+    try:
+        tr = json.load(open(args.traffic))
+        if tr.get("read_pairs") == args.pairs and tr.get("alleles") == A:
+            k = tr["kernels"]["lcty::score_reads_kernel"]
+            out["roofline"]["traffic"] = k["hbm_bytes"]
+            out["roofline"]["traffic_source"] = os.path.relpath(args.traffic, ROOT) + " (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE)"
+    except (OSError, KeyError, ValueError):
+        pass
 
     if first is not None:
         # ---- CPU baseline: the oracle (C restatement of the reference algorithms, single thread:

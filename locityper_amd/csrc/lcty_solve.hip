@@ -105,7 +105,7 @@ struct SolveView {
     uint32_t* c_nnt;                // [n_chains]
     double* c_aln;                  // [n_chains] alignment likelihood after K13
     double* liks;                   // [n_chains] prior + likelihood
-    double* parts;                  // [n_chains][3] aln_lik, depth_lik, solver iterations (diagnostics)
+    double* parts;                  // [n_chains][4] aln_lik, depth_lik, solver iterations, accepted moves (diagnostics)
     uint32_t* overflow;             // set when a window got deeper than the depth table (the host widens it and repeats)
 };
 
@@ -486,7 +486,7 @@ struct Chain {
 
 // ---------------- K14: one wavefront per chain ----------------
 template <uint32_t P>
-__global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
+__global__ __launch_bounds__(64, 4) void solve_loop_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t W = V.wstride;
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem);                   // [W] depth | GC bin << 25
@@ -511,6 +511,7 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
     double aln_lik = V.c_aln[chain];
     const uint32_t nnt = V.c_nnt[chain];
     Xoshiro rng; rng.seed(seed);
+    uint64_t n_iter = 0, n_acc = 0;
     const double rel_contrib = V.depth_contrib / V.aln_contrib;
 
     auto load_slot = [&](uint32_t slot) -> uint32_t {
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
         return V.depth_contrib * m.ddiff + V.aln_contrib * (m.lp_new - m.lp_old);
     };
     auto reassign = [&](const Move& m) {                                      // assgn.rs:331-343 (wave-uniform move)
+        n_acc++;
         depth_lik += m.ddiff;                                                 // nothing moved since it was evaluated
         aln_lik += m.lp_new - m.lp_old;
         if (lane == 0) {
@@ -548,7 +550,6 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
         __builtin_amdgcn_wave_barrier();
     };
 
-    uint64_t n_iter = 0;
     if (nnt > 0) {
         // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
         double max_abs = 0.0;
@@ -634,19 +635,80 @@ __global__ __launch_bounds__(64, 5) void solve_loop_kernel(const SolveView V) {
                 if (accept) { reassign(m); curr_plato = 0; }
                 else { curr_plato++; if (curr_plato >= V.solver.plato_size) break; }
             }
-            for (uint64_t iter = 0; iter < max_iter; iter++) {
-                if (curr_plato >= V.solver.plato_size) break;
-                n_iter++;
-                Move m; random_move(m);
-                const double diff = improvement(m);
-                if (diff > min_diff) { reassign(m); curr_plato = 0; } else curr_plato++;
+            // Second loop of stoch.rs:228-241: a move changes the state only when it is accepted, so the moves that
+            // follow a rejection see the same state. Lane q evaluates the move that starts at draw q of the random
+            // stream (a move takes one draw, two when the read has more than two locations); the lanes that lie on
+            // the true chain of moves are then walked in order up to the first accepted one, which is applied, and
+            // the stream continues right behind it. Same moves, same order, same result as the serial loop.
+            unsigned long long draw = 0, d64 = 0;                              // draws q (lane q) and 64 of the window
+            for (uint32_t j = 0; j <= 64; j++) {
+                const unsigned long long v = rng.next();
+                if (j == 64) d64 = v; else if (lane == j) draw = v;
+            }
+            uint64_t iter = 0;
+            uint32_t width = 16;                                               // lanes that speculate: about twice the recent run length
+            while (iter < max_iter && curr_plato < V.solver.plato_size) {
+                const unsigned long long up = __shfl_down(draw, 1);
+                const unsigned long long draw_next = lane == 63 ? d64 : up;
+                Move m;
+                m.slot = 0; m.rp = 0; m.new_assgn = 0; m.ddiff = 0.0;
+                m.w1 = m.w2 = m.w3 = m.w4 = 0; m.lp_old = m.lp_new = 0.0;
+                bool accepted = false, wide = false;
+                if (lane < width) {
+                    m.slot = static_cast<uint32_t>(__umul64hi(draw, static_cast<uint64_t>(nnt)));
+                    const uint32_t packed = load_slot(m.slot);
+                    const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
+                    Locs<P> L; locs_init(L, V, rp, G);
+                    uint32_t new_assgn;
+                    if (L.nw == 2) new_assgn = 1 - old_assgn;
+                    else {
+                        const uint32_t i = 1 + static_cast<uint32_t>(__umul64hi(draw_next, static_cast<uint64_t>(L.nw - 1)));
+                        new_assgn = i <= old_assgn ? i - 1 : i;
+                    }
+                    m.rp = rp; m.new_assgn = new_assgn;
+                    fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
+                    m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+                    accepted = improvement(m) > min_diff;
+                    wide = L.nw > 2;
+                }
+                const unsigned long long acc = __ballot(accepted);
+                const unsigned long long two = __ballot(wide);
+                uint32_t q = 0, walked = 0;
+                int hit = -1;
+                while (q < width) {
+                    if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
+                    iter++; n_iter++; walked++;
+                    const uint32_t cons = 1 + static_cast<uint32_t>((two >> q) & 1ull);
+                    if ((acc >> q) & 1ull) { hit = static_cast<int>(q); q += cons; break; }
+                    curr_plato++;
+                    q += cons;
+                }
+                if (hit >= 0) {
+                    Move a;
+                    a.rp = __shfl(m.rp, hit); a.new_assgn = __shfl(m.new_assgn, hit); a.slot = __shfl(m.slot, hit);
+                    a.w1 = __shfl(m.w1, hit); a.w2 = __shfl(m.w2, hit); a.w3 = __shfl(m.w3, hit); a.w4 = __shfl(m.w4, hit);
+                    a.lp_old = __shfl(m.lp_old, hit); a.lp_new = __shfl(m.lp_new, hit); a.ddiff = __shfl(m.ddiff, hit);
+                    reassign(a);
+                    curr_plato = 0;
+                }
+                width = min(64u, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
+                // the stream moves on by q draws (1..65): shift the window and refill its tail
+                unsigned long long nd = __shfl(draw, static_cast<int>((lane + q) & 63u));
+                if (lane + q == 64) nd = d64;
+                for (uint32_t j = 0; j < q; j++) {
+                    const unsigned long long v = rng.next();
+                    const uint32_t idx = 65 - q + j;
+                    if (idx == 64) d64 = v; else if (lane == idx) nd = v;
+                }
+                draw = nd;
             }
         }
     }
     if (lane == 0) {
         const double lik = V.depth_contrib * depth_lik + V.aln_contrib * aln_lik;       // assgn.rs:235-237
         V.liks[chain] = (V.priors ? V.priors[gi] : 0.0) + lik;                          // solve.rs:827
-        V.parts[3 * chain] = aln_lik; V.parts[3 * chain + 1] = depth_lik; V.parts[3 * chain + 2] = static_cast<double>(n_iter);
+        V.parts[4 * chain] = aln_lik; V.parts[4 * chain + 1] = depth_lik; V.parts[4 * chain + 2] = static_cast<double>(n_iter);
+        V.parts[4 * chain + 3] = static_cast<double>(n_acc);
     }
 }
 
@@ -864,7 +926,7 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
         d_nt.alloc(max_chains * ngp);
         d_cww.alloc(max_chains * V.wstride); d_cgc.alloc(max_chains * V.wstride); d_cdepth.alloc(max_chains * V.wstride);
         d_cnnt.alloc(max_chains); d_caln.alloc(max_chains);
-        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(3 * max_chains);
+        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(4 * max_chains);
         if (priors) d_pri.alloc(gt_per_batch);
         std::vector<double> liks(max_chains);
         for (uint64_t g0 = 0; g0 < n_gt; g0 += gt_per_batch) {
@@ -889,13 +951,16 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                 d_liks.download(liks.data(), nch, s);
                 LCTY_HIP(hipStreamSynchronize(s));
                 if (!ovf && getenv("LCTY_SOLVE_STATS")) {
-                    std::vector<double> parts(3 * nch);
-                    d_parts.download(parts.data(), 3 * nch, s);
+                    std::vector<double> parts(4 * nch);
+                    d_parts.download(parts.data(), 4 * nch, s);
                     LCTY_HIP(hipStreamSynchronize(s));
-                    double sum = 0, mx = 0, mn = 1e300;
-                    for (uint64_t c = 0; c < nch; c++) { const double it = parts[3 * c + 2]; sum += it; mx = std::max(mx, it); mn = std::min(mn, it); }
-                    fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f lut_depth=%u\n",
-                            static_cast<unsigned long long>(nch), sum / nch, mn, mx, loc->lut_ext_depth);
+                    double sum = 0, mx = 0, mn = 1e300, acc = 0;
+                    for (uint64_t c = 0; c < nch; c++) {
+                        const double it = parts[4 * c + 2];
+                        sum += it; mx = std::max(mx, it); mn = std::min(mn, it); acc += parts[4 * c + 3];
+                    }
+                    fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f accepted mean=%.0f lut_depth=%u\n",
+                            static_cast<unsigned long long>(nch), sum / nch, mn, mx, acc / nch, loc->lut_ext_depth);
                 }
                 if (!ovf) break;
                 if (ovf == 2) fail(LCTY_ERR_UNSUPPORTED, "a read pair with more than 255 possible locations on one genotype");

@@ -1,0 +1,47 @@
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, MI355X_MICROARCH.md §rocprofv3 PMC slots) into
+profiles/<tag>_pmc_traffic.json: HBM bytes per launch of every lcty kernel.
+
+  FETCH_SIZE, WRITE_SIZE are kilobytes (rocprofv3 -L). gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE tallies
+  128-byte read requests at 64 bytes, i.e. reports half of a wide streaming read -> doubled here ("fetch_bytes_corrected");
+  WRITE_SIZE is exact. Narrow gathers are uncalibrated, so both the raw and the corrected figure are kept.
+
+usage: python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [workload note]
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    tot = collections.defaultdict(float)
+    launches = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        tot[name] += float(r["Counter_Value"])
+        launches[name].add(r["Dispatch_Id"])
+    return {k: (tot[k], len(launches[k])) for k in tot}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "unit": "bytes per launch", "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("lcty::"):
+            continue
+        f, nf = fetch.get(k, (0.0, 0))
+        w, nw = write.get(k, (0.0, 0))
+        fb = 1024.0 * f / max(nf, 1)
+        wb = 1024.0 * w / max(nw, 1)
+        out["kernels"][k] = {"launches": max(nf, nw), "fetch_bytes_raw": fb, "fetch_bytes_corrected": 2.0 * fb, "write_bytes": wb,
+                             "hbm_bytes": 2.0 * fb + wb}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print(f"{k:45s} x{v['launches']:<3d} fetch {v['fetch_bytes_corrected'] / 1e9:9.3f} GB (raw {v['fetch_bytes_raw'] / 1e9:8.3f})  "
+              f"write {v['write_bytes'] / 1e9:8.3f} GB")
+
+
+main()
