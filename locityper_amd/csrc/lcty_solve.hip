@@ -485,8 +485,8 @@ struct Chain {
 };
 
 // ---------------- K14: one wavefront per chain ----------------
-template <uint32_t P>
-__global__ __launch_bounds__(64, 4) void solve_loop_kernel(const SolveView V) {
+template <uint32_t P, int KIND>
+__global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_loop_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t W = V.wstride;
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem);                   // [W] depth | GC bin << 25
@@ -559,66 +559,121 @@ __global__ __launch_bounds__(64, 4) void solve_loop_kernel(const SolveView V) {
         }
         const double min_diff = fmax(1e-10 * max_abs, 1e-14);                 // minimum_allowed_diff (stoch.rs:27-29)
         const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
-        if (V.solver.kind == LCTY_SOLVER_GREEDY) {
-            const uint32_t sample_size = min(V.solver.sample_size, nnt);
+        if (KIND == LCTY_SOLVER_GREEDY) {
+            // Greedy::solve_nontrivial (stoch.rs:81-120). The random stream of the greedy loop does not depend on what
+            // the moves do, so the reads of the next few iterations are known in advance: `NB` consecutive iterations
+            // are prepared together, one candidate read per lane (slot, locations, tweaked windows: the part that does
+            // not depend on the window depths), and then scored and applied one iteration after the other.
+            const uint32_t S = min(V.solver.sample_size, nnt);
+            const uint32_t NB = max(1u, min(6u, 64u / S));
+            const uint32_t grp = lane / S, jj = lane - grp * S;
             uint32_t curr_plato = 0;
-            for (uint64_t iter = 0; iter < max_iter; iter++) {
-                n_iter++;
-                // non_trivial_reads.sample(rng, sample_size): distinct indices, repeats rejected (our adaptor);
-                // lane j keeps the j-th pick
+            uint64_t iter = 0;
+            bool done = false;
+            while (!done && iter < max_iter) {
+                const uint32_t nb = static_cast<uint32_t>(min(static_cast<uint64_t>(NB), max_iter - iter));
+                // non_trivial_reads.sample(rng, S) of each iteration: distinct indices, repeats rejected (our adaptor);
+                // lane b * S + j keeps the j-th pick of iteration b
                 uint32_t my_pick = NONE32S;
-                for (uint32_t j = 0; j < sample_size; j++) {
-                    uint32_t idx;
-                    bool dup;
-                    do {
-                        idx = static_cast<uint32_t>(rng.below(nnt));
-                        dup = __ballot(lane < j && my_pick == idx) != 0ull;
-                    } while (dup);
-                    if (lane == j) my_pick = idx;
+                for (uint32_t b = 0; b < nb; b++) {
+                    for (uint32_t j = 0; j < S; j++) {
+                        uint32_t idx;
+                        bool dup;
+                        do {
+                            idx = static_cast<uint32_t>(rng.below(nnt));
+                            dup = __ballot(grp == b && jj < j && my_pick == idx) != 0ull;
+                        } while (dup);
+                        if (grp == b && jj == j) my_pick = idx;
+                    }
                 }
-                // best_read_improvement (assgn.rs:287-317), one candidate read per lane
-                double my_improv = -INFINITY;
-                Move mm; mm.rp = 0; mm.new_assgn = 0; mm.slot = my_pick; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
-                mm.ddiff = 0.0;
-                if (lane < sample_size) {
+                // preparation: everything about the candidate read that the moves of this batch cannot change
+                uint32_t rp = 0, cur_assgn = 0, nloc = 0;
+                double lps[4];
+                uint32_t wins[4];                                              // w1 | w2 << 16
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) { lps[t] = 0.0; wins[t] = 0; }
+                if (grp < nb) {
                     const uint32_t packed = load_slot(my_pick);
-                    const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
+                    rp = packed & 0xFFFFFFu; cur_assgn = packed >> 24;
                     Locs<P> L; locs_init(L, V, rp, G);
-                    double best_improv = -INFINITY;
-                    // pass 1: the current location; pass 2: every other one (same merge, at most a handful of steps)
-                    Move cur; cur.w1 = cur.w2 = 0; cur.lp_old = 0.0;
-                    fetch_two(V, G, L, seed, rp, old_assgn, old_assgn, cur);
+                    nloc = L.nw;
                     LocIter<P> it; it.start(L);
                     LocOut o;
-                    for (uint32_t t = 0; t < L.nw && it.next(L, V, o); t++) {
-                        if (t == old_assgn) continue;
-                        uint32_t w3, w4;
-                        loc_windows(V, G, o, seed, rp, t, &w3, &w4);
-                        const double dd = C.depth_lik_diff(cur.w1, cur.w2, w3, w4);
-                        const double improv = o.lp + rel_contrib * dd;
-                        if (improv > best_improv) {
-                            best_improv = improv;
-                            mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = o.lp; mm.ddiff = dd;
+#pragma unroll
+                    for (uint32_t t = 0; t < 4; t++) {
+                        if (t < nloc && it.next(L, V, o)) {
+                            uint32_t wa, wb;
+                            loc_windows(V, G, o, seed, rp, t, &wa, &wb);
+                            lps[t] = o.lp; wins[t] = wa | (wb << 16);
                         }
                     }
-                    mm.rp = rp; mm.w1 = cur.w1; mm.w2 = cur.w2; mm.lp_old = cur.lp_old;
-                    my_improv = V.aln_contrib * (best_improv - cur.lp_old);
                 }
-                // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
-                double best = my_improv;
-                for (int o2 = 32; o2 > 0; o2 >>= 1) best = fmax(best, __shfl_xor(best, o2));
-                const unsigned long long who = __ballot(lane < sample_size && my_improv == best);
-                if (best > min_diff && who) {
-                    const int src = __ffsll(static_cast<long long>(who)) - 1;
-                    Move m;
-                    m.rp = __shfl(mm.rp, src); m.new_assgn = __shfl(mm.new_assgn, src); m.slot = __shfl(mm.slot, src);
-                    m.w1 = __shfl(mm.w1, src); m.w2 = __shfl(mm.w2, src); m.w3 = __shfl(mm.w3, src); m.w4 = __shfl(mm.w4, src);
-                    m.lp_old = __shfl(mm.lp_old, src); m.lp_new = __shfl(mm.lp_new, src); m.ddiff = __shfl(mm.ddiff, src);
-                    curr_plato = 0;
-                    reassign(m);
-                } else {
-                    curr_plato++;
-                    if (curr_plato > V.solver.plato_size) break;
+                for (uint32_t b = 0; b < nb; b++) {
+                    n_iter++; iter++;
+                    // best_read_improvement (assgn.rs:287-317), one candidate read per lane
+                    double my_improv = -INFINITY;
+                    Move mm; mm.rp = rp; mm.new_assgn = 0; mm.slot = my_pick; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
+                    mm.ddiff = 0.0;
+                    if (grp == b) {
+                        double best_improv = -INFINITY;
+                        if (nloc <= 4) {
+                            double cur_lp = lps[0]; uint32_t cur_w = wins[0];
+#pragma unroll
+                            for (uint32_t t = 1; t < 4; t++) if (t == cur_assgn) { cur_lp = lps[t]; cur_w = wins[t]; }
+                            mm.w1 = cur_w & 0xFFFFu; mm.w2 = cur_w >> 16; mm.lp_old = cur_lp;
+#pragma unroll 1
+                            for (uint32_t t = 0; t < nloc; t++) {
+                                if (t == cur_assgn) continue;
+                                double lp_t = lps[0]; uint32_t win_t = wins[0];
+#pragma unroll
+                                for (uint32_t u = 1; u < 4; u++) if (u == t) { lp_t = lps[u]; win_t = wins[u]; }
+                                const uint32_t w3 = win_t & 0xFFFFu, w4 = win_t >> 16;
+                                const double dd = C.depth_lik_diff(mm.w1, mm.w2, w3, w4);
+                                const double improv = lp_t + rel_contrib * dd;
+                                if (improv > best_improv) {
+                                    best_improv = improv;
+                                    mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = lp_t; mm.ddiff = dd;
+                                }
+                            }
+                        } else {
+                            // more locations than the prepared four: walk the merge again
+                            Locs<P> L; locs_init(L, V, rp, G);
+                            Move cur; cur.w1 = cur.w2 = 0; cur.lp_old = 0.0;
+                            fetch_two(V, G, L, seed, rp, cur_assgn, cur_assgn, cur);
+                            LocIter<P> it; it.start(L);
+                            LocOut o;
+                            for (uint32_t t = 0; t < L.nw && it.next(L, V, o); t++) {
+                                if (t == cur_assgn) continue;
+                                uint32_t w3, w4;
+                                loc_windows(V, G, o, seed, rp, t, &w3, &w4);
+                                const double dd = C.depth_lik_diff(cur.w1, cur.w2, w3, w4);
+                                const double improv = o.lp + rel_contrib * dd;
+                                if (improv > best_improv) {
+                                    best_improv = improv;
+                                    mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = o.lp; mm.ddiff = dd;
+                                }
+                            }
+                            mm.w1 = cur.w1; mm.w2 = cur.w2; mm.lp_old = cur.lp_old;
+                        }
+                        my_improv = V.aln_contrib * (best_improv - mm.lp_old);
+                    }
+                    // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
+                    double best = my_improv;
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) best = fmax(best, __shfl_xor(best, o2));
+                    const unsigned long long who = __ballot(grp == b && my_improv == best);
+                    if (best > min_diff && who) {
+                        const int src = __ffsll(static_cast<long long>(who)) - 1;
+                        Move m;
+                        m.rp = __shfl(mm.rp, src); m.new_assgn = __shfl(mm.new_assgn, src); m.slot = __shfl(mm.slot, src);
+                        m.w1 = __shfl(mm.w1, src); m.w2 = __shfl(mm.w2, src); m.w3 = __shfl(mm.w3, src); m.w4 = __shfl(mm.w4, src);
+                        m.lp_old = __shfl(mm.lp_old, src); m.lp_new = __shfl(mm.lp_new, src); m.ddiff = __shfl(mm.ddiff, src);
+                        curr_plato = 0;
+                        reassign(m);
+                        if (my_pick == m.slot) cur_assgn = m.new_assgn;       // the same read may come up again in this batch
+                    } else {
+                        curr_plato++;
+                        if (curr_plato > V.solver.plato_size) { done = true; break; }
+                    }
                 }
             }
         } else {
@@ -821,12 +876,13 @@ void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_i
     if (lds_init > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_init)));
+    auto loop_kernel = V.solver.kind == LCTY_SOLVER_GREEDY ? solve_loop_kernel<P, LCTY_SOLVER_GREEDY> : solve_loop_kernel<P, LCTY_SOLVER_ANNEAL>;
     if (lds_loop > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_loop_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_loop)));
     ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); });
     LCTY_HIP(hipGetLastError());
-    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(solve_loop_kernel<P>, dim3(nch), dim3(64), lds_loop, s, V); });
+    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(loop_kernel, dim3(nch), dim3(64), lds_loop, s, V); });
     LCTY_HIP(hipGetLastError());
 }
 
