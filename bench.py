@@ -111,7 +111,7 @@ def main():
     gts = api.generate_genotypes(A, 2)
     greedy, anneal = api.default_solver(cdefs.SOLVER_GREEDY), api.default_solver(cdefs.SOLVER_ANNEAL)
     stage_s = {"score_prefilter": 0.0, "greedy": 0.0, "anneal": 0.0}
-    solved = {"greedy_chains": 0, "anneal_chains": 0}
+    solved = {"greedy_chains": 0, "anneal_chains": 0, "greedy_iterations": 0, "anneal_moves": 0}
 
     def step(it=0):
         t0s = time.perf_counter()
@@ -131,11 +131,13 @@ def main():
             m, v, _ = api.solve_stage(aa, gts[ixs], greedy, 1, api.chain_seeds(1000 + it, len(ixs)))
             mean[ixs], var[ixs], att[ixs] = m, v, 1
             solved["greedy_chains"] += len(ixs)
+            solved["greedy_iterations"] += api.solve_stats(aa)[1]
             ixs = api.discard_improbable(mean, var, att, ixs, params.prob_thresh, 20, 1)
         tm = time.perf_counter()
         m, v, _ = api.solve_stage(aa, gts[ixs], anneal, 20, api.chain_seeds(2000 + it, 20 * len(ixs)))
         mean[ixs], var[ixs], att[ixs] = m, v, 20
         solved["anneal_chains"] += 20 * len(ixs)
+        solved["anneal_moves"] += api.solve_stats(aa)[1]
         res = api.produce_result(mean, var, att, ixs, params.prob_thresh)
         te = time.perf_counter()
         stage_s["greedy"] += tm - ts; stage_s["anneal"] += te - tm
@@ -150,7 +152,7 @@ def main():
         step()
     barrier()
     ctx.timing_reset()
-    stage_s.update(score_prefilter=0.0, greedy=0.0, anneal=0.0); solved.update(greedy_chains=0, anneal_chains=0)
+    stage_s.update(score_prefilter=0.0, greedy=0.0, anneal=0.0); solved.update(greedy_chains=0, anneal_chains=0, greedy_iterations=0, anneal_moves=0)
     t_start = time.perf_counter()
     for it in range(args.steps):
         scores, keep, res = step(it)
@@ -210,13 +212,21 @@ def main():
             "genotypes_solved_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"] / 20.0)
                                       / max(stage_s["greedy"] + stage_s["anneal"], 1e-9),
             "chains_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"]) / max(stage_s["greedy"] + stage_s["anneal"], 1e-9),
-            "chains_per_step": {k: v / args.steps for k, v in solved.items()},
+            "per_step": {k: v / args.steps for k, v in solved.items()},
             "stage_ms_per_step": {k: 1e3 * v / args.steps for k, v in stage_s.items()},
             "quality": None if res is None else float(res[2])},
         "roofline": {"bound": "hbm", "kernel": "score_reads_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "layout_bytes_per_launch": layout_bytes,
                      "achieved_layout_GBs": layout_bytes / (score_ms * 1e-3) / 1e9},
+        "roofline_solver": None if args.no_solve else {
+            "bound": "hbm", "kernel": "solve_loop_kernel (greedy + annealing launches)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # per evaluated candidate read: 4 B list slot + one 32 B location cell per contig of the genotype; the
+            # depth table and window weights are cache resident by design
+            "algorithmic_bytes_per_step": (4 + 32 * 2) * (10 * solved["greedy_iterations"] + solved["anneal_moves"]) / args.steps,
+            "achieved": (4 + 32 * 2) * (10 * solved["greedy_iterations"] + solved["anneal_moves"]) / max(ms_solve, 1e-9) / 1e6,
+            "frac": (4 + 32 * 2) * (10 * solved["greedy_iterations"] + solved["anneal_moves"]) / max(ms_solve, 1e-9) / 1e6 / HBM_PEAK_GBS,
+            "note": "serial chains: bound by dependent gathers, not by bandwidth"},
         "roofline_prefilter": {"bound": "valu_f64", "achieved": 2.0 * G * args.pairs / (pref_ms * 1e-3) / 1e12,
                                "peak": 39.3, "unit": "Tmaxadd/s",
                                "frac": 2.0 * G * args.pairs / (pref_ms * 1e-3) / 1e12 / 39.3},

@@ -279,7 +279,7 @@ int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* 
 /* ---- solver stages (src/solvers/solve.rs:789-850, src/solvers/stoch.rs, src/model/assgn.rs) ----------------
  * The reference drives these stages from one Xoshiro256++ through rand ^0.10 adaptors that are not in its tree and
  * whose results already depend on --threads (solve.rs:1017, 1051). Here every (genotype, attempt) chain gets its
- * own 64-bit seed (lcty_chain_seeds draws them from seed_from_u64(master)); DESIGN.md §7 lists the adaptors. */
+ * own 64-bit seed (lcty_chain_seeds draws them from seed_from_u64(master)); DESIGN.md §2 lists the adaptors. */
 int32_t lcty_solver_default(lcty_solver* out, int32_t kind);                 /* Greedy::default / SimAnneal::default */
 int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out);
 /* One stage over genotypes[n_gt][ploidy] (the body of the stage loop, solve.rs:816-843): per genotype `attempts` x
@@ -288,6 +288,9 @@ int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out);
 int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
                          const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out);
+/* Diagnostics of the last lcty_solve_stage on this batch: chains run, solver iterations (greedy iterations /
+ * annealing moves) and accepted moves summed over the chains (stoch.rs has no counterpart; used by bench.py). */
+int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted);
 /* Predictions::discard_improbable_genotypes (solve.rs:425-480): ixs in/out */
 int32_t lcty_discard_improbable(const double* lik_mean, const double* lik_var, const uint32_t* attempts, uint64_t* ixs, uint64_t n,
                                 double prob_thresh, uint64_t out_size, uint64_t threads, uint64_t* n_keep);

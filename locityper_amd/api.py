@@ -255,6 +255,13 @@ def solve_stage(aa, genotypes, solver, attempts, seeds, priors=None):
     return mean, var, liks
 
 
+def solve_stats(aa):
+    """(chains, iterations, accepted moves) of the last solve_stage on this batch."""
+    c, i, a = U64(), U64(), U64()
+    check(lib().lcty_solve_stats(aa._h, C.byref(c), C.byref(i), C.byref(a)))
+    return int(c.value), int(i.value), int(a.value)
+
+
 def discard_improbable(lik_mean, lik_var, attempts, ixs, prob_thresh, out_size, threads):
     lik_mean = np.ascontiguousarray(lik_mean, dtype=np.float64)
     lik_var = np.ascontiguousarray(lik_var, dtype=np.float64)

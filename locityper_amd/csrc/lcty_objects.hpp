@@ -94,6 +94,7 @@ struct lcty_reads {
     lcty::DevBuf<uint8_t> d_loc_table;       // [A][ngp] 32-byte LocEntry cells
     uint64_t ngp = 0;
     bool loc_table_valid = false;
+    uint64_t stat_chains = 0, stat_iterations = 0, stat_accepted = 0;   // last lcty_solve_stage
     lcty::DevBuf<uint32_t> d_err;
 
     // prefilter products

@@ -946,6 +946,7 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
             if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
         if (n_gt * attempts >= 0x7FFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many chains in one stage");
         ensure_solver_tables(reads);
+        reads->stat_chains = reads->stat_iterations = reads->stat_accepted = 0;
         const uint64_t n_good = reads->n_good_cached, ngp = reads->ngp;
         // depth table: wide enough for twice the mean depth of "every read on the shortest contig" (two mates per pair);
         // a chain that still runs past it raises `overflow` and the batch is repeated with a wider table
@@ -1006,7 +1007,7 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                 d_ovf.download(&ovf, 1, s);
                 d_liks.download(liks.data(), nch, s);
                 LCTY_HIP(hipStreamSynchronize(s));
-                if (!ovf && getenv("LCTY_SOLVE_STATS")) {
+                if (!ovf) {
                     std::vector<double> parts(4 * nch);
                     d_parts.download(parts.data(), 4 * nch, s);
                     LCTY_HIP(hipStreamSynchronize(s));
@@ -1015,7 +1016,9 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                         const double it = parts[4 * c + 2];
                         sum += it; mx = std::max(mx, it); mn = std::min(mn, it); acc += parts[4 * c + 3];
                     }
-                    fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f accepted mean=%.0f lut_depth=%u\n",
+                    reads->stat_chains += nch; reads->stat_iterations += static_cast<uint64_t>(sum);
+                    reads->stat_accepted += static_cast<uint64_t>(acc);
+                    if (getenv("LCTY_SOLVE_STATS")) fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f accepted mean=%.0f lut_depth=%u\n",
                             static_cast<unsigned long long>(nch), sum / nch, mn, mx, acc / nch, loc->lut_ext_depth);
                 }
                 if (!ovf) break;
@@ -1040,6 +1043,15 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                 if (liks_out) memcpy(liks_out + (g0 + g) * attempts, l, sizeof(double) * attempts);
             }
         }
+    });
+}
+
+int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted) {
+    return guarded([&] {
+        if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (chains) *chains = reads->stat_chains;
+        if (iterations) *iterations = reads->stat_iterations;
+        if (accepted) *accepted = reads->stat_accepted;
     });
 }
 
