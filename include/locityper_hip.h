@@ -288,6 +288,15 @@ int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out);
 int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
                          const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out);
+/* Per-read assignment counts of ONE genotype over `attempts` chains — the "per-read posteriors" behind the output BAMs
+ * (GenotypeAlignments::create_counts + ReadAssignment::update_counts, assgn.rs:94-96, 374-378; solve.rs:821-836;
+ * model/bam.rs divides by `attempts`). read_off[n_good + 1]: first count of every good read pair, its possible
+ * locations on the genotype in extend_read_gt_alns order (windows.rs:762-797); counts[read_off[n_good]] (u16 as in the
+ * reference). counts == NULL: only read_off / *n_counts are produced. The chains are the ones lcty_solve_stage runs
+ * for the same genotype, solver and seeds. */
+int32_t lcty_assignment_counts(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, const lcty_solver* solver,
+                               uint32_t attempts, const uint64_t* chain_seeds, uint64_t* read_off, uint16_t* counts, uint64_t cap,
+                               uint64_t* n_counts);
 /* Diagnostics of the last lcty_solve_stage on this batch: chains run, solver iterations (greedy iterations /
  * annealing moves) and accepted moves summed over the chains (stoch.rs has no counterpart; used by bench.py). */
 int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted);

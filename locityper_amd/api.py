@@ -255,6 +255,21 @@ def solve_stage(aa, genotypes, solver, attempts, seeds, priors=None):
     return mean, var, liks
 
 
+def assignment_counts(aa, genotype, solver, attempts, seeds):
+    """Per-read assignment counts of one genotype (update_counts, assgn.rs:374-378): (read_off[n_good+1], counts u16)."""
+    genotype = np.ascontiguousarray(genotype, dtype=np.uint16).reshape(-1)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    assert len(seeds) == attempts
+    n_good = aa.n_good()
+    off = np.zeros(n_good + 1, dtype=np.uint64)
+    n = U64()
+    args = (aa._h, genotype.ctypes.data, len(genotype), C.byref(solver), attempts, seeds.ctypes.data, off.ctypes.data)
+    check(lib().lcty_assignment_counts(*args, None, 0, C.byref(n)))
+    counts = np.zeros(int(n.value), dtype=np.uint16)
+    check(lib().lcty_assignment_counts(*args, counts.ctypes.data, len(counts), C.byref(n)))
+    return off, counts
+
+
 def solve_stats(aa):
     """(chains, iterations, accepted moves) of the last solve_stage on this batch."""
     c, i, a = U64(), U64(), U64()

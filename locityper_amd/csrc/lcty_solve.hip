@@ -767,6 +767,32 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
     }
 }
 
+// ---- per-read outputs (GenotypeAlignments::create_counts / ReadAssignment::update_counts, assgn.rs:94-96, 374-378) ----
+// number of possible locations of every good read pair on the genotype of chain 0 (read_ixs, assgn.rs:52-60)
+template <uint32_t P>
+__global__ __launch_bounds__(256) void read_nw_kernel(const SolveView V, uint32_t* __restrict__ nw) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= V.n_good) return;
+    Geno<P> G; G.init(V, 0);
+    Locs<P> L; locs_init(L, V, g, G);
+    nw[g] = L.nw;
+}
+
+// counts[read_off[read] + location] += 1 for every attempt. The chains of one genotype share the list of non-trivial
+// reads (same reads, same order), only the location byte differs; a read with one location is always at location 0.
+__global__ __launch_bounds__(256) void assignment_counts_kernel(const SolveView V, const uint32_t* __restrict__ nw,
+                                                                const uint64_t* __restrict__ read_off, uint16_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < V.n_good && nw[i] == 1) counts[read_off[i]] = static_cast<uint16_t>(V.attempts);
+    if (i < V.c_nnt[0]) {
+        const uint32_t rp = V.non_trivial[i] & 0xFFFFFFu;
+        for (uint32_t a = 0; a < V.attempts; a++) {
+            const uint32_t loc = V.non_trivial[static_cast<uint64_t>(a) * V.ngp + i] >> 24;
+            counts[read_off[rp] + loc] += 1;
+        }
+    }
+}
+
 }  // namespace lcty
 
 using namespace lcty;
@@ -886,6 +912,130 @@ void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_i
     LCTY_HIP(hipGetLastError());
 }
 
+
+// One stage = every (genotype, attempt) chain, in batches that fit the state budget. `after_batch(g0, ng, liks)` runs
+// while the batch's device state (lists of non-trivial reads, window arrays) is still alive.
+struct StageRunner {
+    lcty_reads* reads; lcty_ctx* ctx; lcty_locus* loc;
+    SolveView V{};
+    uint64_t n_gt; uint32_t ploidy, attempts;
+    size_t lds_init = 0, lds_loop = 0;
+    uint64_t gt_per_batch = 1, depth_cap = 2;
+    DevBuf<uint16_t> d_gt; DevBuf<uint8_t> d_cgc; DevBuf<uint32_t> d_nt, d_cdepth, d_cnnt, d_ovf; DevBuf<uint64_t> d_seeds;
+    DevBuf<double> d_pri, d_liks, d_parts, d_cww, d_caln;
+
+    StageRunner(lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver, uint32_t attempts_,
+                const uint64_t* chain_seeds) : reads(r), n_gt(n_gt_), ploidy(ploidy_), attempts(attempts_) {
+        if (!reads || !genotypes || !solver || !chain_seeds) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
+        if (ploidy == 0 || ploidy > MAXP) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles ploidy 1..%u", MAXP);
+        if (attempts == 0) fail(LCTY_ERR_INVALID_INPUT, "At least one attempt is required for each stage");
+        if (solver->kind != LCTY_SOLVER_GREEDY && solver->kind != LCTY_SOLVER_ANNEAL) fail(LCTY_ERR_INVALID_INPUT, "unknown solver kind");
+        if (solver->kind == LCTY_SOLVER_ANNEAL && !(solver->init_prob > 0.0 && solver->init_prob <= 1.0))
+            fail(LCTY_ERR_INVALID_INPUT, "Initial probability (%g) must be within (0, 1]", solver->init_prob);
+        if (solver->kind == LCTY_SOLVER_ANNEAL && solver->anneal_steps == 0) fail(LCTY_ERR_INVALID_INPUT, "Number of annealing steps must be positive");
+        if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size == 0) fail(LCTY_ERR_INVALID_INPUT, "Sample size must be positive");
+        if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size > 64) fail(LCTY_ERR_UNSUPPORTED, "greedy sample size above 64");
+        ctx = reads->ctx; loc = reads->locus;
+        ctx->activate();
+        reads->check_device_error();
+        const uint32_t A = loc->n_alleles;
+        for (uint64_t i = 0; i < n_gt * ploidy; i++)
+            if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
+        if (n_gt * attempts >= 0x7FFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many chains in one stage");
+        ensure_solver_tables(reads);
+        reads->stat_chains = reads->stat_iterations = reads->stat_accepted = 0;
+        const uint64_t n_good = reads->n_good_cached, ngp = reads->ngp;
+        // depth table: wide enough for twice the mean depth of "every read on the shortest contig" (two mates per pair);
+        // a chain that still runs past it raises `overflow` and the batch is repeated with a wider table
+        uint32_t min_w = 0xFFFFFFFFu;
+        for (uint32_t a = 0; a < A; a++) min_w = std::min(min_w, std::max(loc->n_windows[a], 1u));
+        depth_cap = 2 * n_good + 2;                                      // no window can be deeper
+        ensure_depth_table(loc, std::min<uint64_t>(4 * n_good / min_w + 64, depth_cap));
+        hipStream_t s = ctx->stream;
+
+        V.by_window = FastDiv::make(loc->bg.window); V.by_tweak = FastDiv::make(2 * static_cast<uint32_t>(loc->prm.tweak) + 1);
+        V.A = A; V.window = loc->bg.window; V.left_padding = loc->left_padding; V.tweak = static_cast<uint32_t>(loc->prm.tweak);
+        V.min_weight = loc->prm.min_weight; V.prob_diff = loc->prm.prob_diff;
+        V.depth_contrib = 1.0 + loc->prm.lik_skew; V.aln_contrib = 1.0 - loc->prm.lik_skew;      // assgn.rs:80-81
+        V.n_windows = loc->d_n_windows.p; V.reg_start = loc->d_reg_start.p; V.allele_len = loc->d_allele_len.p;
+        V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
+        V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
+        V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
+        V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p;
+        V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
+        V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
+        lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
+        lds_loop = static_cast<size_t>(V.wstride) * 4 + 16;
+        if (lds_loop > 160 * 1024 || V.wstride > 65535) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype: too many for the device solver", V.wstride);
+
+        // chains are processed in batches so that the per-chain state (4 B per good read) stays bounded
+        const uint64_t per_chain = ngp * 4 + static_cast<uint64_t>(V.wstride) * 13;
+        const uint64_t budget = 64ull << 30;
+        gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
+        const uint64_t max_chains = gt_per_batch * attempts;
+        d_ovf.alloc(1); d_ovf.zero(s);
+        d_nt.alloc(max_chains * ngp);
+        d_cww.alloc(max_chains * V.wstride); d_cgc.alloc(max_chains * V.wstride); d_cdepth.alloc(max_chains * V.wstride);
+        d_cnnt.alloc(max_chains); d_caln.alloc(max_chains);
+        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(4 * max_chains);
+        d_pri.alloc(gt_per_batch);
+        V.genotypes = d_gt.p; V.seeds = d_seeds.p; V.priors = nullptr;
+        V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
+        V.c_ww = d_cww.p; V.c_gc = d_cgc.p; V.c_depth = d_cdepth.p; V.c_nnt = d_cnnt.p; V.c_aln = d_caln.p;
+        V.overflow = d_ovf.p;
+    }
+
+    void upload_genotypes(const uint16_t* genotypes, uint64_t ng) { d_gt.upload(genotypes, ng * ploidy, ctx->stream); }
+
+    template <typename F>
+    void run(const uint16_t* genotypes, const double* priors, const uint64_t* chain_seeds, F&& after_batch) {
+        hipStream_t s = ctx->stream;
+        std::vector<double> liks(gt_per_batch * attempts);
+        for (uint64_t g0 = 0; g0 < n_gt; g0 += gt_per_batch) {
+            const uint64_t ng = std::min(gt_per_batch, n_gt - g0), nch = ng * attempts;
+            upload_genotypes(genotypes + g0 * ploidy, ng);
+            d_seeds.upload(chain_seeds + g0 * attempts, nch, s);
+            if (priors) d_pri.upload(priors + g0, ng, s);
+            V.priors = priors ? d_pri.p : nullptr;
+            for (;;) {
+                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth;
+                switch (ploidy) {
+                    case 1: launch_chains<1>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                    case 2: launch_chains<2>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                    case 3: launch_chains<3>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                    default: launch_chains<4>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
+                }
+                uint32_t ovf = 0;
+                d_ovf.download(&ovf, 1, s);
+                d_liks.download(liks.data(), nch, s);
+                LCTY_HIP(hipStreamSynchronize(s));
+                if (!ovf) {
+                    std::vector<double> parts(4 * nch);
+                    d_parts.download(parts.data(), 4 * nch, s);
+                    LCTY_HIP(hipStreamSynchronize(s));
+                    double sum = 0, mx = 0, mn = 1e300, acc = 0;
+                    for (uint64_t c = 0; c < nch; c++) {
+                        const double it = parts[4 * c + 2];
+                        sum += it; mx = std::max(mx, it); mn = std::min(mn, it); acc += parts[4 * c + 3];
+                    }
+                    reads->stat_chains += nch; reads->stat_iterations += static_cast<uint64_t>(sum);
+                    reads->stat_accepted += static_cast<uint64_t>(acc);
+                    if (getenv("LCTY_SOLVE_STATS"))
+                        fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f accepted mean=%.0f lut_depth=%u\n",
+                                static_cast<unsigned long long>(nch), sum / nch, mn, mx, acc / nch, loc->lut_ext_depth);
+                    break;
+                }
+                if (ovf == 2) fail(LCTY_ERR_UNSUPPORTED, "a read pair with more than 255 possible locations on one genotype");
+                if (loc->lut_ext_depth >= depth_cap) fail(LCTY_ERR_RUNTIME, "window depth beyond 2 * reads + 2");
+                d_ovf.zero(s);
+                ensure_depth_table(loc, std::min<uint64_t>(4ull * loc->lut_ext_depth, depth_cap));
+            }
+            after_batch(g0, ng, liks.data());
+        }
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -928,108 +1078,12 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                          const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out) {
     return guarded([&] {
-        if (!reads || !genotypes || !solver || !chain_seeds || !lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
-        if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
-        if (ploidy == 0 || ploidy > MAXP) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles ploidy 1..%u", MAXP);
-        if (attempts == 0) fail(LCTY_ERR_INVALID_INPUT, "At least one attempt is required for each stage");
-        if (solver->kind == LCTY_SOLVER_ANNEAL && !(solver->init_prob > 0.0 && solver->init_prob <= 1.0))
-            fail(LCTY_ERR_INVALID_INPUT, "Initial probability (%g) must be within (0, 1]", solver->init_prob);
-        if (solver->kind == LCTY_SOLVER_ANNEAL && solver->anneal_steps == 0) fail(LCTY_ERR_INVALID_INPUT, "Number of annealing steps must be positive");
-        if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size == 0) fail(LCTY_ERR_INVALID_INPUT, "Sample size must be positive");
-        if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size > 64) fail(LCTY_ERR_UNSUPPORTED, "greedy sample size above 64");
-        lcty_ctx* ctx = reads->ctx;
-        lcty_locus* loc = reads->locus;
-        ctx->activate();
-        reads->check_device_error();
-        const uint32_t A = loc->n_alleles;
-        for (uint64_t i = 0; i < n_gt * ploidy; i++)
-            if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
-        if (n_gt * attempts >= 0x7FFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many chains in one stage");
-        ensure_solver_tables(reads);
-        reads->stat_chains = reads->stat_iterations = reads->stat_accepted = 0;
-        const uint64_t n_good = reads->n_good_cached, ngp = reads->ngp;
-        // depth table: wide enough for twice the mean depth of "every read on the shortest contig" (two mates per pair);
-        // a chain that still runs past it raises `overflow` and the batch is repeated with a wider table
-        uint32_t min_w = 0xFFFFFFFFu;
-        for (uint32_t a = 0; a < A; a++) min_w = std::min(min_w, std::max(loc->n_windows[a], 1u));
-        const uint64_t depth_cap = 2 * n_good + 2;                       // no window can be deeper
-        ensure_depth_table(loc, std::min<uint64_t>(4 * n_good / min_w + 64, depth_cap));
-        hipStream_t s = ctx->stream;
-
-        SolveView V{};
-        V.by_window = FastDiv::make(loc->bg.window); V.by_tweak = FastDiv::make(2 * static_cast<uint32_t>(loc->prm.tweak) + 1);
-        V.A = A; V.window = loc->bg.window; V.left_padding = loc->left_padding; V.tweak = static_cast<uint32_t>(loc->prm.tweak);
-        V.min_weight = loc->prm.min_weight; V.prob_diff = loc->prm.prob_diff;
-        V.depth_contrib = 1.0 + loc->prm.lik_skew; V.aln_contrib = 1.0 - loc->prm.lik_skew;      // assgn.rs:80-81
-        V.n_windows = loc->d_n_windows.p; V.reg_start = loc->d_reg_start.p; V.allele_len = loc->d_allele_len.p;
-        V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
-        V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
-        V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
-        V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p;
-        V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
-        V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
-        const size_t lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
-        const size_t lds_loop = static_cast<size_t>(V.wstride) * 4 + 16;
-        if (lds_loop > 160 * 1024) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype do not fit in LDS", V.wstride);
-
-        // chains are processed in batches so that the per-chain state (4 B per good read) stays bounded
-        const uint64_t per_chain = ngp * 4 + static_cast<uint64_t>(V.wstride) * 13;
-        const uint64_t budget = 64ull << 30;
-        const uint64_t gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
-        const uint64_t max_chains = gt_per_batch * attempts;
-        DevBuf<uint16_t> d_gt; DevBuf<uint8_t> d_cgc; DevBuf<uint32_t> d_nt, d_cdepth, d_cnnt; DevBuf<uint64_t> d_seeds;
-        DevBuf<double> d_pri, d_liks, d_parts, d_cww, d_caln;
-        DevBuf<uint32_t> d_ovf; d_ovf.alloc(1); d_ovf.zero(s);
-        d_nt.alloc(max_chains * ngp);
-        d_cww.alloc(max_chains * V.wstride); d_cgc.alloc(max_chains * V.wstride); d_cdepth.alloc(max_chains * V.wstride);
-        d_cnnt.alloc(max_chains); d_caln.alloc(max_chains);
-        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(4 * max_chains);
-        if (priors) d_pri.alloc(gt_per_batch);
-        std::vector<double> liks(max_chains);
-        for (uint64_t g0 = 0; g0 < n_gt; g0 += gt_per_batch) {
-            const uint64_t ng = std::min(gt_per_batch, n_gt - g0), nch = ng * attempts;
-            d_gt.upload(genotypes + g0 * ploidy, ng * ploidy, s);
-            d_seeds.upload(chain_seeds + g0 * attempts, nch, s);
-            if (priors) d_pri.upload(priors + g0, ng, s);
-            V.genotypes = d_gt.p; V.seeds = d_seeds.p; V.priors = priors ? d_pri.p : nullptr;
-            V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
-            V.c_ww = d_cww.p; V.c_gc = d_cgc.p; V.c_depth = d_cdepth.p; V.c_nnt = d_cnnt.p; V.c_aln = d_caln.p;
-            V.overflow = d_ovf.p;
-            for (;;) {
-                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth;
-                switch (ploidy) {
-                    case 1: launch_chains<1>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                    case 2: launch_chains<2>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                    case 3: launch_chains<3>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                    default: launch_chains<4>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                }
-                uint32_t ovf = 0;
-                d_ovf.download(&ovf, 1, s);
-                d_liks.download(liks.data(), nch, s);
-                LCTY_HIP(hipStreamSynchronize(s));
-                if (!ovf) {
-                    std::vector<double> parts(4 * nch);
-                    d_parts.download(parts.data(), 4 * nch, s);
-                    LCTY_HIP(hipStreamSynchronize(s));
-                    double sum = 0, mx = 0, mn = 1e300, acc = 0;
-                    for (uint64_t c = 0; c < nch; c++) {
-                        const double it = parts[4 * c + 2];
-                        sum += it; mx = std::max(mx, it); mn = std::min(mn, it); acc += parts[4 * c + 3];
-                    }
-                    reads->stat_chains += nch; reads->stat_iterations += static_cast<uint64_t>(sum);
-                    reads->stat_accepted += static_cast<uint64_t>(acc);
-                    if (getenv("LCTY_SOLVE_STATS")) fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f accepted mean=%.0f lut_depth=%u\n",
-                            static_cast<unsigned long long>(nch), sum / nch, mn, mx, acc / nch, loc->lut_ext_depth);
-                }
-                if (!ovf) break;
-                if (ovf == 2) fail(LCTY_ERR_UNSUPPORTED, "a read pair with more than 255 possible locations on one genotype");
-                if (loc->lut_ext_depth >= depth_cap) fail(LCTY_ERR_RUNTIME, "window depth beyond 2 * reads + 2");
-                d_ovf.zero(s);
-                ensure_depth_table(loc, std::min<uint64_t>(4ull * loc->lut_ext_depth, depth_cap));
-            }
+        if (!lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        StageRunner R(reads, genotypes, n_gt, ploidy, solver, attempts, chain_seeds);
+        R.run(genotypes, priors, chain_seeds, [&](uint64_t g0, uint64_t ng, const double* liks) {
             for (uint64_t g = 0; g < ng; g++) {
                 // mean_variance_or_nan (src/ext/vec.rs:74-116)
-                const double* l = liks.data() + g * attempts;
+                const double* l = liks + g * attempts;
                 double sum = -0.0;
                 for (uint32_t a = 0; a < attempts; a++) sum += l[a];
                 const double mean = sum / static_cast<double>(attempts);
@@ -1042,7 +1096,54 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                 lik_mean[g0 + g] = mean; lik_var[g0 + g] = var;
                 if (liks_out) memcpy(liks_out + (g0 + g) * attempts, l, sizeof(double) * attempts);
             }
+        });
+    });
+}
+
+int32_t lcty_assignment_counts(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, const lcty_solver* solver,
+                               uint32_t attempts, const uint64_t* chain_seeds, uint64_t* read_off, uint16_t* counts, uint64_t cap,
+                               uint64_t* n_counts) {
+    return guarded([&] {
+        if (!read_off || !n_counts) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (attempts > 65535) fail(LCTY_ERR_UNSUPPORTED, "assignment counts are 16-bit (as in the reference, assgn.rs:94-96)");
+        StageRunner R(reads, genotype, 1, ploidy, solver, attempts, chain_seeds);
+        lcty_ctx* ctx = reads->ctx;
+        hipStream_t s = ctx->stream;
+        const uint64_t n_good = reads->n_good_cached;
+        // GenotypeAlignments::read_ixs (assgn.rs:52-60): prefix sums of the number of locations of every read pair
+        DevBuf<uint32_t> d_nw; d_nw.alloc(std::max<uint64_t>(n_good, 1));
+        R.upload_genotypes(genotype, 1);
+        if (n_good) {
+            const uint32_t blocks = static_cast<uint32_t>((n_good + 255) / 256);
+            switch (ploidy) {
+                case 1: hipLaunchKernelGGL(read_nw_kernel<1>, dim3(blocks), dim3(256), 0, s, R.V, d_nw.p); break;
+                case 2: hipLaunchKernelGGL(read_nw_kernel<2>, dim3(blocks), dim3(256), 0, s, R.V, d_nw.p); break;
+                case 3: hipLaunchKernelGGL(read_nw_kernel<3>, dim3(blocks), dim3(256), 0, s, R.V, d_nw.p); break;
+                default: hipLaunchKernelGGL(read_nw_kernel<4>, dim3(blocks), dim3(256), 0, s, R.V, d_nw.p); break;
+            }
+            LCTY_HIP(hipGetLastError());
         }
+        std::vector<uint32_t> nw(n_good);
+        d_nw.download(nw.data(), n_good, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        read_off[0] = 0;
+        for (uint64_t g = 0; g < n_good; g++) read_off[g + 1] = read_off[g] + nw[g];
+        *n_counts = read_off[n_good];
+        if (!counts) return;
+        if (cap < *n_counts) fail(LCTY_ERR_INVALID_INPUT, "counts buffer too small (%llu < %llu)", static_cast<unsigned long long>(cap),
+                                  static_cast<unsigned long long>(*n_counts));
+        DevBuf<uint64_t> d_off; d_off.alloc(n_good + 1); d_off.upload(read_off, n_good + 1, s);
+        DevBuf<uint16_t> d_counts; d_counts.alloc(std::max<uint64_t>(*n_counts, 1)); d_counts.zero(s);
+        R.run(genotype, nullptr, chain_seeds, [&](uint64_t, uint64_t, const double*) {
+            // ReadAssignment::update_counts (assgn.rs:374-378) of every attempt, while the chains' lists are still on the device
+            if (!n_good) return;
+            const uint32_t blocks = static_cast<uint32_t>((n_good + 255) / 256);
+            hipLaunchKernelGGL(assignment_counts_kernel, dim3(blocks), dim3(256), 0, s, R.V, d_nw.p, d_off.p, d_counts.p);
+            LCTY_HIP(hipGetLastError());
+            LCTY_HIP(hipStreamSynchronize(s));
+        });
+        d_counts.download(counts, *n_counts, s);
+        LCTY_HIP(hipStreamSynchronize(s));
     });
 }
 

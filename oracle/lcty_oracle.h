@@ -172,6 +172,10 @@ void     orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* 
                          const double* priors, const lcty_solver* s, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out);
 
+/* per-read assignment counts of one genotype over its attempts (assgn.rs:94-96, 374-378; solve.rs:821-836) */
+uint64_t orc_assignment_counts(const orc_locus* l, const orc_alns* a, const uint16_t* ids, uint32_t ploidy, const lcty_solver* s,
+                               uint32_t attempts, const uint64_t* chain_seeds, uint64_t* read_ixs_out, uint16_t* counts_out);
+
 /* compare_two_likelihoods (solve.rs:319-336) */
 double   orc_compare_two_likelihoods(double mean1, double var1, uint32_t att1, double mean2, double var2, uint32_t att2);
 /* discard_improbable_genotypes (solve.rs:425-480): ixs in/out, returns the new count */

@@ -530,6 +530,28 @@ void orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* geno
     free(liks);
 }
 
+/* GenotypeAlignments::create_counts + ReadAssignment::update_counts over the attempts of one genotype —
+ * assgn.rs:94-96, 374-378 as driven by solve.rs:821-836. read_ixs_out[n_reads + 1], counts_out[n_alns] (or NULL to
+ * size them). Returns n_alns. */
+uint64_t orc_assignment_counts(const orc_locus* l, const orc_alns* a, const uint16_t* ids, uint32_t ploidy, const lcty_solver* s,
+                               uint32_t attempts, const uint64_t* chain_seeds, uint64_t* read_ixs_out, uint16_t* counts_out) {
+    orc_gt_alns* g = orc_gt_alns_new(l, a, ids, ploidy);
+    const uint64_t n_alns = g->n_alns;
+    if (read_ixs_out) for (uint64_t r = 0; r <= g->n_reads; r++) read_ixs_out[r] = g->read_ixs[r];
+    if (counts_out) {
+        memset(counts_out, 0, sizeof(uint16_t) * n_alns);
+        uint16_t* assgn = (uint16_t*)malloc(sizeof(uint16_t) * (g->n_reads ? g->n_reads : 1));
+        for (uint32_t at = 0; at < attempts; at++) {
+            orc_gt_alns_apply_tweak(g, chain_seeds[at]);
+            orc_solve(g, s, chain_seeds[at], assgn, NULL);
+            for (uint64_t r = 0; r < g->n_reads; r++) counts_out[g->read_ixs[r] + assgn[r]] += 1;
+        }
+        free(assgn);
+    }
+    orc_gt_alns_free(g);
+    return n_alns;
+}
+
 /* ---------------------------------------------------------------- K15: comparing genotypes */
 /* compare_two_likelihoods — solve.rs:319-336 (DIFF_VAR = false selects the Welch branch: the const generic is
  * named EQ_VAR in math/mod.rs:180 and receives `false`) */

@@ -106,6 +106,7 @@ def lib():
     sig("orc_locus_inject_tables", None, VP, VP, VP)
     sig("orc_assignment_likelihood", D, VP, VP, VP)
     sig("orc_solve_stage", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP)
+    sig("orc_assignment_counts", U64, VP, VP, VP, U32, C.POINTER(Solver), U32, VP, VP, VP)
     sig("orc_compare_two_likelihoods", D, D, D, U32, D, D, U32)
     sig("orc_discard_improbable", U64, VP, VP, VP, VP, U64, D, U64, U64)
     sig("orc_produce_result", U64, VP, VP, VP, VP, U64, D, U64, VP, VP, C.POINTER(D))
@@ -352,6 +353,18 @@ def solve_stage(locus, alns, genotypes, solver, attempts, chain_seeds, priors=No
     lib().orc_solve_stage(locus._h, alns._h, genotypes.ctypes.data, n, ploidy, None if pri is None else pri.ctypes.data,
                           C.byref(solver), attempts, seeds.ctypes.data, mean.ctypes.data, var.ctypes.data, liks.ctypes.data)
     return mean, var, liks
+
+
+def assignment_counts(locus, alns, genotype, solver, attempts, chain_seeds):
+    genotype = np.ascontiguousarray(genotype, dtype=np.uint16).reshape(-1)
+    seeds = np.ascontiguousarray(chain_seeds, dtype=np.uint64)
+    assert len(seeds) == attempts
+    off = np.zeros(alns.n_good + 1, dtype=np.uint64)
+    args = (locus._h, alns._h, genotype.ctypes.data, len(genotype), C.byref(solver), attempts, seeds.ctypes.data)
+    n = lib().orc_assignment_counts(*args, off.ctypes.data, None)
+    counts = np.zeros(int(n), dtype=np.uint16)
+    lib().orc_assignment_counts(*args, off.ctypes.data, counts.ctypes.data)
+    return off, counts
 
 
 def discard_improbable(lik_mean, lik_var, attempts, ixs, prob_thresh, out_size, threads):

@@ -151,3 +151,31 @@ def test_solver_misuse_fails_loudly(gpu_ctx):
     bad.init_prob = 0.0
     with pytest.raises(_lib.LocityperError):
         api.solve_stage(aa, g[:1], bad, 1, api.chain_seeds(1, 1))
+
+
+def test_per_read_assignment_counts_match_oracle(gpu_ctx):
+    # the "per-read posteriors" of the output BAMs: counts / attempts (assgn.rs:374-378, model/bam.rs)
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 8, 3000, 20000)
+    for gt, kind, attempts in (((L.true_genotype), cdefs.SOLVER_ANNEAL, 6), ((0, 0), cdefs.SOLVER_GREEDY, 3),
+                               ((1, 5), cdefs.SOLVER_GREEDY, 4)):
+        gt = np.array(gt, dtype=np.uint16)
+        solver = api.default_solver(kind)
+        seeds = api.chain_seeds(99, attempts)
+        off, counts = api.assignment_counts(aa, gt, solver, attempts, seeds)
+        ooff, ocounts = O.assignment_counts(ol, oa, gt, solver, attempts, seeds)
+        assert np.array_equal(off, ooff)
+        assert np.array_equal(counts, ocounts)
+        assert np.all(np.add.reduceat(counts.astype(np.int64), off[:-1].astype(np.int64)) == attempts)
+    # ploidy 3 and a too-small buffer
+    gt3 = np.array([0, 2, 2], dtype=np.uint16)
+    off, counts = api.assignment_counts(aa, gt3, api.default_solver(cdefs.SOLVER_GREEDY), 2, api.chain_seeds(5, 2))
+    ooff, ocounts = O.assignment_counts(ol, oa, gt3, api.default_solver(cdefs.SOLVER_GREEDY), 2, api.chain_seeds(5, 2))
+    assert np.array_equal(off, ooff) and np.array_equal(counts, ocounts)
+    import ctypes as C
+    n = C.c_uint64()
+    small = np.zeros(4, dtype=np.uint16)
+    sv = api.default_solver(cdefs.SOLVER_GREEDY)
+    seeds = api.chain_seeds(5, 2)
+    rc = _lib.lib().lcty_assignment_counts(aa._h, gt3.ctypes.data, 3, C.byref(sv), 2, seeds.ctypes.data, off.ctypes.data,
+                                           small.ctypes.data, 4, C.byref(n))
+    assert rc == cdefs.ERR_INVALID_INPUT

@@ -206,3 +206,25 @@ def test_stage_and_final_comparison():
     # unexplained reads
     n_un = O.lib().orc_count_unexplained(oa._h, np.array(L.true_genotype, dtype=np.uint16).ctypes.data, 2)
     assert 0 <= n_un < oa.n_good // 10
+
+
+def test_assignment_counts_bookkeeping():
+    # update_counts (assgn.rs:374-378): every attempt adds exactly one count per read pair, at its final location
+    L, p, ol, oa = small_case(n_pairs=400)
+    gt = np.array(L.true_genotype, dtype=np.uint16)
+    greedy = O.default_solver(cdefs.SOLVER_GREEDY)
+    attempts = 5
+    seeds = np.arange(attempts, dtype=np.uint64) * 104729 + 3
+    off, counts = O.assignment_counts(ol, oa, gt, greedy, attempts, seeds)
+    assert len(off) == oa.n_good + 1 and off[0] == 0 and off[-1] == len(counts)
+    per_read = np.add.reduceat(counts.astype(np.int64), off[:-1].astype(np.int64))
+    assert np.all(per_read == attempts)
+    nw = np.diff(off.astype(np.int64))
+    assert nw.min() >= 1 and np.all(counts[off[:-1][nw == 1].astype(np.int64)] == attempts)      # trivial reads never move
+    # the same list of locations as the Python transliteration of extend_read_gt_alns
+    g = O.GtAlns(ol, oa, gt) if hasattr(O, "GtAlns") else None
+    if g is not None:
+        assert g.n_alns == len(counts)
+    # one attempt == the assignment orc_solve reports
+    off1, c1 = O.assignment_counts(ol, oa, gt, greedy, 1, seeds[:1])
+    assert np.array_equal(off1, off) and set(np.unique(c1)) <= {0, 1}
