@@ -297,6 +297,9 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
 int32_t lcty_assignment_counts(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, const lcty_solver* solver,
                                uint32_t attempts, const uint64_t* chain_seeds, uint64_t* read_off, uint16_t* counts, uint64_t cap,
                                uint64_t* n_counts);
+/* Genotyping::count_unexplained_reads (solve.rs:718-729): good read pairs whose best alignment on the alleles of the
+ * called genotype is no better than "both mates unmapped" (+1e-8). */
+int32_t lcty_count_unexplained(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, uint32_t* out);
 /* Diagnostics of the last lcty_solve_stage on this batch: chains run, solver iterations (greedy iterations /
  * annealing moves) and accepted moves summed over the chains (stoch.rs has no counterpart; used by bench.py). */
 int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted);

@@ -270,6 +270,14 @@ def assignment_counts(aa, genotype, solver, attempts, seeds):
     return off, counts
 
 
+def count_unexplained(aa, genotype):
+    """Genotyping::count_unexplained_reads (solve.rs:718-729)."""
+    genotype = np.ascontiguousarray(genotype, dtype=np.uint16).reshape(-1)
+    out = U32()
+    check(lib().lcty_count_unexplained(aa._h, genotype.ctypes.data, len(genotype), C.byref(out)))
+    return int(out.value)
+
+
 def solve_stats(aa):
     """(chains, iterations, accepted moves) of the last solve_stage on this batch."""
     c, i, a = U64(), U64(), U64()
@@ -363,5 +371,6 @@ def solve(aa, params, scheme=DEFAULT_SCHEME, master_seed=1, priors=None, ploidy=
             ixs = discard_improbable(lik_mean, lik_var, att, ixs, params.prob_thresh, out_size, threads)
         kept.append(len(ixs))
     out_ixs, ln_probs, quality = produce_result(lik_mean, lik_var, att, ixs, params.prob_thresh)
-    return dict(genotypes=gts[out_ixs], ixs=out_ixs, ln_probs=ln_probs, quality=quality, lik_mean=lik_mean, lik_var=lik_var,
+    unexpl = count_unexplained(aa, gts[out_ixs[0]])
+    return dict(unexpl_reads=unexpl, genotypes=gts[out_ixs], ixs=out_ixs, ln_probs=ln_probs, quality=quality, lik_mean=lik_mean, lik_var=lik_var,
                 attempts=att, kept_per_stage=kept)

@@ -767,6 +767,25 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
     }
 }
 
+// count_unexplained_reads (solve.rs:718-729): best_at_contig (locs.rs:605-611) is the likelihood-matrix entry
+__global__ __launch_bounds__(256) void count_unexplained_kernel(const uint8_t* __restrict__ status, const double* __restrict__ unmapped,
+                                                                const double* __restrict__ matrix, uint64_t n_pairs, uint32_t A,
+                                                                const uint16_t* __restrict__ ids, uint32_t ploidy,
+                                                                unsigned long long* __restrict__ out) {
+    uint32_t mine = 0;
+    for (uint64_t r = blockIdx.x * 256ull + threadIdx.x; r < n_pairs; r += static_cast<uint64_t>(gridDim.x) * 256ull) {
+        if (status[r] != LCTY_READ_GOOD) continue;
+        double best = -INFINITY;
+        for (uint32_t i = 0; i < ploidy; i++) best = fmax(best, matrix[r * A + ids[i]]);
+        mine += best < unmapped[r] + 1e-8;
+    }
+    const unsigned long long bal = __ballot(mine != 0);
+    if (bal) {
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(static_cast<int>(mine), o);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(out, static_cast<unsigned long long>(mine));
+    }
+}
+
 // ---- per-read outputs (GenotypeAlignments::create_counts / ReadAssignment::update_counts, assgn.rs:94-96, 374-378) ----
 // number of possible locations of every good read pair on the genotype of chain 0 (read_ixs, assgn.rs:52-60)
 template <uint32_t P>
@@ -1144,6 +1163,30 @@ int32_t lcty_assignment_counts(lcty_reads* reads, const uint16_t* genotype, uint
         });
         d_counts.download(counts, *n_counts, s);
         LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int32_t lcty_count_unexplained(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, uint32_t* out) {
+    return guarded([&] {
+        if (!reads || !genotype || !out || ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
+        lcty_ctx* ctx = reads->ctx;
+        ctx->activate();
+        reads->check_device_error();
+        const uint32_t A = reads->locus->n_alleles;
+        for (uint32_t i = 0; i < ploidy; i++)
+            if (genotype[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotype[i], A);
+        DevBuf<uint16_t> d_ids; d_ids.alloc(ploidy); d_ids.upload(genotype, ploidy, ctx->stream);
+        DevBuf<unsigned long long> d_out; d_out.alloc(1); d_out.zero(ctx->stream);
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((reads->n_pairs + 255) / 256, 4096));
+        if (reads->n_pairs)
+            hipLaunchKernelGGL(count_unexplained_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_status.p, reads->d_unmapped.p,
+                               reads->d_matrix.p, reads->n_pairs, A, d_ids.p, ploidy, d_out.p);
+        LCTY_HIP(hipGetLastError());
+        unsigned long long v = 0;
+        d_out.download(&v, 1, ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        *out = static_cast<uint32_t>(v);
     });
 }
 

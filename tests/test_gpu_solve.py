@@ -137,6 +137,12 @@ def test_final_comparison_and_full_scheme(gpu_ctx):
     assert tuple(res["genotypes"][0]) == L.true_genotype
     assert abs(np.logaddexp.reduce(res["ln_probs"])) < 1e-9 and res["quality"] >= 0.0
     assert res["kept_per_stage"][0] >= 40
+    # output assembly (a34): unexplained reads of the call and of a wrong genotype
+    import ctypes as C
+    for gt in (res["genotypes"][0], np.array([0, 1], dtype=np.uint16), np.array([3, 3], dtype=np.uint16)):
+        g16 = np.ascontiguousarray(gt, dtype=np.uint16)
+        assert api.count_unexplained(aa, g16) == O.lib().orc_count_unexplained(oa._h, g16.ctypes.data, 2)
+    assert res["unexpl_reads"] == api.count_unexplained(aa, res["genotypes"][0])
 
 
 def test_solver_misuse_fails_loudly(gpu_ctx):
