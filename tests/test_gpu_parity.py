@@ -96,6 +96,51 @@ def test_config1_full(gpu_ctx):
     assert aa.n_good() == oa.n_good > 8000
 
 
+def test_config1_whole_path_against_the_oracle_pipeline(gpu_ctx):
+    """configs[0] end to end, each side on its OWN tables (the oracle's lgamma is statrs' Lanczos, the product's is
+    libm / ocml: 1e-13 apart): prefilter -> greedy -> annealing -> final comparison. A stochastic local search is
+    chaotic in its inputs: a 1e-13 difference in a depth table entry can flip one near-tie and send a chain to another
+    local optimum a few log-units away (the exact, move-for-move comparison on injected tables is
+    tests/test_gpu_solve.py). What must agree here: the prefilter and its kept set, every chain that did not hit such a
+    tie (most), all stage means within the spread between attempts, the best genotype of every stage, and the call."""
+    cfg = synth.CONFIGS[1]
+    L = synth.SynthLocus(cfg["n_alleles"], cfg["n_pairs"])
+    loc, ol, p = both_loci(gpu_ctx, L)
+    ch = L.reads(0, cfg["n_pairs"])
+    aa = api.AllAlignments.load(loc, ch)
+    oa = ol.load(ch)
+    gts = api.generate_genotypes(8, 2)
+    sc = aa.run_filter()
+    so = O.run_filter(oa.best_aln_matrix(), gts)
+    ix = np.arange(len(gts))
+    keep_g = api.truncate_ixs(sc, ix, p.filt_diff, 12, 1)
+    keep_o = O.truncate(so, ix, p.filt_diff, 12, 1)
+    assert np.array_equal(keep_g, keep_o)
+    att = np.zeros(len(gts), dtype=np.uint32)
+    mg, vg = np.full(len(gts), np.nan), np.full(len(gts), np.nan)
+    mo, vo = mg.copy(), vg.copy()
+    stages = ((api.default_solver(cdefs.SOLVER_GREEDY), 2, 4), (api.default_solver(cdefs.SOLVER_ANNEAL), 4, None))
+    kg, ko = keep_g, keep_o
+    for si, (solver, attempts, out_size) in enumerate(stages):
+        seeds = api.chain_seeds(100 + si, len(kg) * attempts)
+        m, v, _ = api.solve_stage(aa, gts[kg], solver, attempts, seeds)
+        m2, v2, _ = O.solve_stage(ol, oa, gts[ko], solver, attempts, seeds)
+        assert np.allclose(m, m2, rtol=1e-3, atol=0) and np.mean(np.abs(m - m2) <= 1e-9 * np.abs(m2)) >= 0.25
+        assert kg[int(np.argmax(m))] == ko[int(np.argmax(m2))]
+        mg[kg], vg[kg], mo[ko], vo[ko], att[kg] = m, v, m2, v2, attempts
+        if out_size:
+            kg = api.discard_improbable(mg, vg, att, kg, p.prob_thresh, out_size, 1)
+            ko = O.discard_improbable(mo, vo, att, ko, p.prob_thresh, out_size, 1)
+            assert kg[0] == ko[0] and len(set(kg[:out_size]) & set(ko[:out_size])) >= out_size - 1
+            ko = kg.copy()                                       # continue from the same survivors on both sides
+    rg = api.produce_result(mg, vg, att, kg, p.prob_thresh)
+    ro = O.produce_result(mo, vo, att, ko, p.prob_thresh)
+    assert rg[0][0] == ro[0][0] and tuple(gts[int(rg[0][0])]) == L.true_genotype
+    assert abs(rg[1][0] - ro[1][0]) < 1e-3                       # ln-probability of the call
+    g0 = np.ascontiguousarray(gts[int(rg[0][0])], dtype=np.uint16)
+    assert api.count_unexplained(aa, g0) == O.lib().orc_count_unexplained(oa._h, g0.ctypes.data, 2)
+
+
 @pytest.mark.parametrize("n_alleles,n_pairs", [(256, 2048), (20, 700), (130, 300), (300, 200)])
 def test_config2_shape_sample(gpu_ctx, n_alleles, n_pairs):
     """configs[1] shape (256 alleles, k=25, 150 bp PE) on a sample the oracle finishes in seconds,
@@ -320,3 +365,23 @@ def test_full_size_properties(gpu_ctx):
     keep = api.truncate_ixs(sc_full, np.arange(len(sc_full)), p.filt_diff, 5000, p.threads)
     assert len(keep) >= 5000 and np.all(np.diff(sc_full[keep]) <= 0)
     assert 0.85 * n < (st == cdefs.READ_GOOD).sum() <= n
+    # solver stages at full size: chains are deterministic given their seeds, priors shift the likelihood, a chain does
+    # not depend on the batch it runs in, every attempt leaves one count per read pair, and the scheme calls the truth
+    sub = gts[keep[:48]]
+    seeds = api.chain_seeds(17, 96)
+    greedy = api.default_solver(cdefs.SOLVER_GREEDY)
+    m1, v1, l1 = api.solve_stage(full, sub, greedy, 2, seeds)
+    m2, v2, l2 = api.solve_stage(full, sub, greedy, 2, seeds)
+    assert np.array_equal(l1, l2)
+    pri = -np.arange(48, dtype=np.float64)
+    m3, _, l3 = api.solve_stage(full, sub[:8], greedy, 2, seeds[:16], priors=pri[:8])
+    assert np.allclose(l3, l1[:8] + pri[:8, None], rtol=1e-13, atol=0)
+    assert tuple(sub[int(np.argmax(m1))]) == L.true_genotype
+    anneal = api.default_solver(cdefs.SOLVER_ANNEAL)
+    ma, va, la = api.solve_stage(full, sub[:4], anneal, 3, seeds[:12])
+    assert np.all(np.isfinite(la)) and np.all(va >= 0)
+    assert int(np.argmax(ma)) == 0 or tuple(sub[int(np.argmax(ma))]) == L.true_genotype
+    off, counts = api.assignment_counts(full, sub[0], anneal, 3, seeds[:3])
+    assert off[-1] == len(counts) and np.all(np.add.reduceat(counts.astype(np.int64), off[:-1].astype(np.int64)) == 3)
+    chains, iters, acc = api.solve_stats(full)
+    assert chains == 3 and 0 < acc <= iters
