@@ -1,11 +1,11 @@
 // lcty_locus.hip — per-locus preprocessing.
 //   K1  UniqueKmers::new (src/model/locs.rs:930-963): device hash set of locus-unique canonical k-mers
 //   K3  ContigInfo::new  (src/model/windows.rs:362-424): GC / unique-k-mer / complexity moving windows
-//       (host threads in this round; one-off O(A*L) per locus, not on the per-read path)
+//       (contig_info_kernel: thread per neighbourhood position, seen ck-mers as an LDS bit set)
 //   LUTs: InsertDistr (bg/insertsz.rs:195-208), DistrCache (model/distr_cache.rs:61-75),
 //         EditDistCache (bg/err_prof.rs:415-448)
 #include <algorithm>
-#include <thread>
+#include <memory>
 
 #include "lcty_objects.hpp"
 
@@ -111,58 +111,54 @@ static uint64_t next_pow2(uint64_t x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 on host threads: ContigInfo::new (windows.rs:386-407) + linguistic_complexity (compl.rs:115-140)
+// K3: ContigInfo::new (windows.rs:386-407) + linguistic_complexity (compl.rs:115-140), one thread per
+// neighbourhood position. Everything is an integer numerator; the f64 values of the reference are count * mult.
+//   gc        rounded percentage of C/G among the `neighb` bases (windows.rs:387-391)
+//   uniq      k-mers with off-target count 0 among the neighb + 1 - k k-mers of the window (395-403)
+//   compl     distinct (non-canonical) ck-mers among the neighb + 1 - ck of the window; every ck-mer that contains
+//             a non-ACGT base is the single value UNDEF. Seen ck-mers are bits of a per-thread set in LDS
+//             (word w of thread t at [w * 64 + t]).
 // ---------------------------------------------------------------------------------------------
-static void contig_info_host(const uint8_t* seq, uint32_t len, const uint16_t* cnt, uint32_t k, uint32_t neighb,
-                             uint32_t ck, uint8_t* gc, uint32_t* uniq, uint16_t* compl_cnt) {
+__global__ __launch_bounds__(64) void contig_info_kernel(const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ seq_off,
+                                                         const uint16_t* __restrict__ counts, const uint64_t* __restrict__ cnt_off,
+                                                         const uint32_t* __restrict__ ci_off, uint32_t k, uint32_t neighb, uint32_t ck,
+                                                         uint32_t words, uint8_t* __restrict__ gc, uint32_t* __restrict__ uniq,
+                                                         uint16_t* __restrict__ compl_cnt) {
+    extern __shared__ uint32_t seen[];                       // [words][64]
+    const uint32_t a = blockIdx.y, tid = threadIdx.x;
+    const uint8_t* seq = seqs + seq_off[a];
+    const uint16_t* cnt = counts + cnt_off[a];
+    const uint32_t len = static_cast<uint32_t>(seq_off[a + 1] - seq_off[a]);
     const uint32_t n_pos = len - neighb + 1;
-    // GC content: rolling count over `neighb` bases, rounded percentage (windows.rs:387-391)
-    {
-        uint32_t c = 0;
-        for (uint32_t i = 0; i < neighb; i++) c += (seq[i] == 'C' || seq[i] == 'G');
-        const double mult = 100.0 / static_cast<double>(neighb);
-        for (uint32_t i = 0;; i++) {
-            gc[i] = static_cast<uint8_t>(std::round(mult * static_cast<double>(c)));
-            if (i + 1 == n_pos) break;
-            c += (seq[i + neighb] == 'C' || seq[i + neighb] == 'G');
-            c -= (seq[i] == 'C' || seq[i] == 'G');
+    const uint32_t p = blockIdx.x * 64 + tid;
+    if (blockIdx.x * 64 >= n_pos) return;
+    const bool valid = p < n_pos;
+    const uint32_t q = valid ? p : 0;                        // idle lanes shadow position 0
+    for (uint32_t w = 0; w < words; w++) seen[w * 64 + tid] = 0;
+    const uint32_t mask = ck >= 16 ? 0xFFFFFFFFu : ((1u << (2 * ck)) - 1u);
+    uint32_t c_gc = 0, v = 0, bad = 0, undef_seen = 0;
+    for (uint32_t i = 0; i < neighb; i++) {
+        const uint8_t b = seq[q + i];
+        c_gc += (b == 'C' || b == 'G');
+        uint32_t enc;
+        switch (b) { case 'A': enc = 0; break; case 'C': enc = 1; break; case 'G': enc = 2; break; case 'T': enc = 3; break;
+                     default: enc = 4; }
+        if (enc == 4) { bad = ck; v = (v << 2) & mask; } else { v = ((v << 2) | enc) & mask; if (bad) bad--; }
+        if (i + 1 >= ck) {
+            if (bad) undef_seen = 1;
+            else seen[(v >> 5) * 64 + tid] |= 1u << (v & 31u);
         }
     }
-    // number of off-target-count == 0 k-mers among the neighb+1-k k-mers of the window (windows.rs:395-403)
-    {
-        const uint32_t span = neighb + 1 - k;
-        uint32_t c = 0;
-        for (uint32_t i = 0; i < span; i++) c += cnt[i] == 0;
-        for (uint32_t i = 0;; i++) {
-            uniq[i] = c;
-            if (i + 1 == n_pos) break;
-            c += cnt[i + span] == 0;
-            c -= cnt[i] == 0;
-        }
-    }
-    // distinct ck-mers (non-canonical; a window with a non-ACGT base is the single value UNDEF) per window
-    {
-        const uint32_t nk = len + 1 - ck, span = neighb + 1 - ck;
-        const uint32_t undef = 1u << (2 * ck);
-        std::vector<uint32_t> code(nk);
-        uint32_t v = 0, bad = 0;     // bad = number of remaining positions poisoned by a non-ACGT base
-        const uint32_t mask = undef - 1;
-        for (uint32_t i = 0; i < len; i++) {
-            uint32_t enc;
-            switch (seq[i]) { case 'A': enc = 0; break; case 'C': enc = 1; break; case 'G': enc = 2; break;
-                              case 'T': enc = 3; break; default: enc = 4; }
-            if (enc == 4) { bad = ck; v = (v << 2) & mask; } else { v = ((v << 2) | enc) & mask; if (bad) bad--; }
-            if (i + 1 >= ck) code[i + 1 - ck] = bad ? undef : v;
-        }
-        std::vector<uint16_t> table(undef + 1, 0);
-        uint32_t distinct = 0;
-        for (uint32_t i = 0; i < span; i++) distinct += table[code[i]]++ == 0;
-        for (uint32_t i = 0;; i++) {
-            compl_cnt[i] = static_cast<uint16_t>(distinct);
-            if (i + 1 == n_pos) break;
-            distinct += table[code[i + span]]++ == 0;
-            distinct -= --table[code[i]] == 0;
-        }
+    uint32_t distinct = undef_seen;
+    for (uint32_t w = 0; w < words; w++) distinct += __popc(seen[w * 64 + tid]);
+    uint32_t c_u = 0;
+    const uint32_t span = neighb + 1 - k;
+    for (uint32_t i = 0; i < span; i++) c_u += cnt[q + i] == 0;
+    if (valid) {
+        const uint64_t o = static_cast<uint64_t>(ci_off[a]) + p;
+        gc[o] = static_cast<uint8_t>(round(100.0 / static_cast<double>(neighb) * static_cast<double>(c_gc)));
+        uniq[o] = c_u;
+        compl_cnt[o] = static_cast<uint16_t>(distinct);
     }
 }
 
@@ -252,7 +248,7 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
         L->ci_off.resize(n_alleles + 1);
         L->n_windows.resize(n_alleles);
         L->reg_start.resize(n_alleles);
-        uint64_t total_pos = 0, zero_positions = 0;
+        uint64_t total_pos = 0;
         for (uint32_t a = 0; a < n_alleles; a++) {
             const uint64_t len64 = seq_off[a + 1] - seq_off[a];
             if (len64 >= (1ull << 32)) fail(LCTY_ERR_INVALID_DATA, "allele %u is too long", a);
@@ -276,29 +272,31 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
         L->uniq_mult = 1.0 / static_cast<double>(neighb + 1 - k);
         L->compl_mult = 1.0 / static_cast<double>(std::min<uint64_t>(neighb + 1 - ck, 1ull << (2 * ck)));
 
-        // ---- K3 (host threads) ----
-        L->gc.resize(total_pos); L->uniq_cnt.resize(total_pos); L->compl_cnt.resize(total_pos);
-        {
-            unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
-            nt = std::min<unsigned>(nt, n_alleles);
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++)
-                th.emplace_back([&, t] {
-                    for (uint32_t a = t; a < n_alleles; a += nt)
-                        contig_info_host(seqs + seq_off[a], L->allele_len[a], offtarget + cnt_off[a], k, neighb, ck,
-                                         L->gc.data() + L->ci_off[a], L->uniq_cnt.data() + L->ci_off[a],
-                                         L->compl_cnt.data() + L->ci_off[a]);
-                });
-            for (auto& t : th) t.join();
-        }
-        for (uint64_t i = 0, n = cnt_off[n_alleles]; i < n; i++) zero_positions += offtarget[i] == 0;
-
         hipStream_t s = ctx->stream;
+        DevBuf<uint8_t> d_seqs; DevBuf<uint64_t> d_seq_off, d_cnt_off; DevBuf<uint16_t> d_counts;
+        const uint64_t total_seq = seq_off[n_alleles], total_cnt = cnt_off[n_alleles];
+        d_seqs.alloc(total_seq); d_seqs.upload(seqs, total_seq, s);
+        d_seq_off.alloc(n_alleles + 1); d_seq_off.upload(seq_off, n_alleles + 1, s);
+        d_cnt_off.alloc(n_alleles + 1); d_cnt_off.upload(cnt_off, n_alleles + 1, s);
+        d_counts.alloc(total_cnt); d_counts.upload(offtarget, total_cnt, s);
         L->d_allele_len.alloc(n_alleles); L->d_allele_len.upload(L->allele_len.data(), n_alleles, s);
         L->d_ci_off.alloc(n_alleles + 1); L->d_ci_off.upload(L->ci_off.data(), n_alleles + 1, s);
-        L->d_compl_cnt.alloc(total_pos); L->d_compl_cnt.upload(L->compl_cnt.data(), total_pos, s);
-        L->d_gc.alloc(total_pos); L->d_gc.upload(L->gc.data(), total_pos, s);
-        L->d_uniq_cnt.alloc(total_pos); L->d_uniq_cnt.upload(L->uniq_cnt.data(), total_pos, s);
+
+        // ---- K3 (device) ----
+        L->d_compl_cnt.alloc(total_pos); L->d_gc.alloc(total_pos); L->d_uniq_cnt.alloc(total_pos);
+        {
+            if (ck > 7) fail(LCTY_ERR_UNSUPPORTED, "complexity k-mer size %u: the device handles up to 7", ck);
+            const uint32_t words = std::max(1u, (1u << (2 * ck)) / 32u);
+            const size_t lds = static_cast<size_t>(words) * 64 * sizeof(uint32_t);
+            if (lds > 48 * 1024)
+                LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contig_info_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds)));
+            const uint32_t max_len0 = *std::max_element(L->allele_len.begin(), L->allele_len.end());
+            const dim3 grid((max_len0 - neighb + 1 + 63) / 64, n_alleles);
+            hipLaunchKernelGGL(contig_info_kernel, grid, dim3(64), lds, s, d_seqs.p, d_seq_off.p, d_counts.p, d_cnt_off.p, L->d_ci_off.p,
+                               k, neighb, ck, words, L->d_gc.p, L->d_uniq_cnt.p, L->d_compl_cnt.p);
+            LCTY_HIP(hipGetLastError());
+        }
         L->d_n_windows.alloc(n_alleles); L->d_n_windows.upload(L->n_windows.data(), n_alleles, s);
         L->d_reg_start.alloc(n_alleles); L->d_reg_start.upload(L->reg_start.data(), n_alleles, s);
         L->max_n_windows = *std::max_element(L->n_windows.begin(), L->n_windows.end());
@@ -311,14 +309,8 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
 
         // ---- K1 (device) ----
         {
-            DevBuf<uint8_t> d_seqs; DevBuf<uint64_t> d_seq_off, d_cnt_off; DevBuf<uint16_t> d_counts;
             DevBuf<uint64_t> d_big; DevBuf<uint32_t> d_flag; DevBuf<unsigned long long> d_n;
-            const uint64_t total_seq = seq_off[n_alleles], total_cnt = cnt_off[n_alleles];
-            d_seqs.alloc(total_seq); d_seqs.upload(seqs, total_seq, s);
-            d_seq_off.alloc(n_alleles + 1); d_seq_off.upload(seq_off, n_alleles + 1, s);
-            d_cnt_off.alloc(n_alleles + 1); d_cnt_off.upload(cnt_off, n_alleles + 1, s);
-            d_counts.alloc(total_cnt); d_counts.upload(offtarget, total_cnt, s);
-            const uint64_t big_cap = next_pow2(std::max<uint64_t>(2 * zero_positions, 1024));
+            const uint64_t big_cap = next_pow2(std::max<uint64_t>(2 * total_cnt, 1024));      // at most one key per k-mer position
             d_big.alloc(big_cap);
             LCTY_HIP(hipMemsetAsync(d_big.p, 0xFF, big_cap * sizeof(uint64_t), s));
             d_flag.alloc(1); d_flag.zero(s);
@@ -403,9 +395,12 @@ int32_t lcty_locus_contig_info(const lcty_locus* locus, uint32_t allele, uint8_t
         if (!locus) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         if (allele >= locus->n_alleles) fail(LCTY_ERR_INVALID_INPUT, "allele index out of range");
         const size_t o = locus->ci_off[allele], n = locus->ci_off[allele + 1] - o;
-        if (gc) memcpy(gc, locus->gc.data() + o, n);
-        if (uniq_cnt) memcpy(uniq_cnt, locus->uniq_cnt.data() + o, n * sizeof(uint32_t));
-        if (compl_cnt) memcpy(compl_cnt, locus->compl_cnt.data() + o, n * sizeof(uint16_t));
+        hipStream_t s = locus->ctx->stream;
+        locus->ctx->activate();
+        if (gc) locus->d_gc.download(gc, n, s, o);
+        if (uniq_cnt) locus->d_uniq_cnt.download(uniq_cnt, n, s, o);
+        if (compl_cnt) locus->d_compl_cnt.download(compl_cnt, n, s, o);
+        LCTY_HIP(hipStreamSynchronize(s));
         if (n_windows) *n_windows = locus->n_windows[allele];
         if (reg_start) *reg_start = locus->reg_start[allele];
     });

@@ -18,9 +18,6 @@ struct lcty_locus {
     // host copies
     std::vector<uint32_t> allele_len;
     std::vector<uint32_t> ci_off;            // [A+1]
-    std::vector<uint8_t> gc;                 // NeighbInfo::gc_content
-    std::vector<uint32_t> uniq_cnt;          // numerator of uniq_kmer_frac
-    std::vector<uint16_t> compl_cnt;         // numerator of complexity
     std::vector<uint32_t> n_windows, reg_start;
     double uniq_mult = 0, compl_mult = 0;
     uint32_t left_padding = 0, half_neighb = 0;
