@@ -185,3 +185,47 @@ def test_per_read_assignment_counts_match_oracle(gpu_ctx):
     rc = _lib.lib().lcty_assignment_counts(aa._h, gt3.ctypes.data, 3, C.byref(sv), 2, seeds.ctypes.data, off.ctypes.data,
                                            small.ctypes.data, 4, C.byref(n))
     assert rc == cdefs.ERR_INVALID_INPUT
+
+
+def test_solver_edge_cases(gpu_ctx):
+    """Degenerate inputs the reference handles implicitly: no good reads, one read, every read trivial (Solver::solve
+    returns the only assignment, solvers/mod.rs:57-66), fewer non-trivial reads than the greedy sample."""
+    from tests.helpers import make_bg, random_alleles, locus_arrays
+    from tests.test_gpu_parity import edge_pairs
+    from locityper_amd.cdefs import ReadsChunk
+    alleles = random_alleles(3, 2600, seed=11)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol.inject_tables(loc.depth_lut(), loc.window_weights())
+    pairs = edge_pairs(alleles)
+    gts = api.generate_genotypes(3, 2)
+    for sub in (pairs, pairs[:1], pairs[:0]):
+        ch = ReadsChunk.from_pairs(sub) if sub else None
+        if ch is None:
+            aa = api.AllAlignments(loc, 1, 64, 1, 1)
+            aa.score()
+        else:
+            aa = api.AllAlignments.load(loc, ch)
+        st, w, unm, uk = aa.status()
+        off, pa = aa.pair_alns()
+        oa = O.alns_from_arrays(3, st, w, unm, off, pa)
+        for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+            solver = api.default_solver(kind)
+            seeds = api.chain_seeds(1, len(gts) * 2)
+            gm, gv, gl = api.solve_stage(aa, gts, solver, 2, seeds)
+            om, ov, olk = O.solve_stage(ol, oa, gts, solver, 2, seeds)
+            assert np.allclose(gl, olk, rtol=1e-9, atol=1e-9), (len(sub), kind)
+        for gt in gts[:3]:
+            o1, c1 = api.assignment_counts(aa, gt, api.default_solver(cdefs.SOLVER_GREEDY), 2, api.chain_seeds(1, 2))
+            o2, c2 = O.assignment_counts(ol, oa, gt, api.default_solver(cdefs.SOLVER_GREEDY), 2, api.chain_seeds(1, 2))
+            assert np.array_equal(o1, o2) and np.array_equal(c1, c2)
+    # a greedy sample larger than the list of non-trivial reads, and the largest supported one
+    L, p2, loc2, aa2, ol2, oa2 = setup(gpu_ctx, 4, 60, 5000)
+    g = api.generate_genotypes(4, 2)
+    big = api.default_solver(cdefs.SOLVER_GREEDY)
+    for ss in (64, 33, 1):
+        big.sample_size = ss
+        compare_stage(aa2, ol2, oa2, g, big, 2, api.chain_seeds(2, 2 * len(g)))
