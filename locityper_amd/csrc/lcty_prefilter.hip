@@ -20,6 +20,14 @@ constexpr uint32_t DIAG_BLOCKS = 136;   // 8x8 blocks (bi <= bj) of a diagonal t
 
 __device__ inline uint32_t swz(uint32_t col) { return col + ((col >> 5) << 1); }
 
+// max of two f64 as the single instruction it is: clang's fmax() quiets its operands first (one more v_max_f64 per
+// loaded value under IEEE mode), which v_max_f64 already does by itself
+__device__ __forceinline__ double vmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // genotype index of the multiset {i <= j} among all C(A+1, 2) (lexicographic; ext/vec.rs:298-339)
 __host__ __device__ inline uint64_t gt_index(uint64_t i, uint64_t j, uint64_t A) { return i * A - i * (i - 1) / 2 + (j - i); }
 
@@ -57,18 +65,27 @@ __global__ __launch_bounds__(256) void prefilter_tile_kernel(const double* __res
     if (diag) lds_b = lds_a;
 
     for (uint64_t r0 = r_begin; r0 < r_end; r0 += RC) {
-        // stage RC rows x 128 columns of both tiles (zero fill outside the matrix: max(0,0)+acc == acc)
-#pragma unroll 4
-        for (uint32_t t = 0; t < RC * PT / 256; t++) {
-            const uint32_t e = tid + 256u * t;
-            const uint32_t rr = e / PT, col = e % PT;
-            const uint64_t r = r0 + rr;
-            const bool rin = r < r_end;
-            const double va = (rin && colI + col < A) ? M[r * A + colI + col] : 0.0;
-            lds_a[rr * ROWD + swz(col)] = va;
-            if (!diag) {
-                const double vb = (rin && colJ + col < A) ? M[r * A + colJ + col] : 0.0;
-                lds_b[rr * ROWD + swz(col)] = vb;
+        // stage RC rows x 128 columns of both tiles (zero fill outside the matrix: max(0,0)+acc == acc); every load of
+        // the stage is issued before the first LDS write
+        constexpr uint32_t NT = RC * PT / 256, HALF = NT / 2;
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            double va[HALF], vb[HALF];
+#pragma unroll
+            for (uint32_t t = 0; t < HALF; t++) {
+                const uint32_t e = tid + 256u * (h * HALF + t);
+                const uint32_t rr = e / PT, col = e % PT;
+                const uint64_t r = r0 + rr;
+                const bool rin = r < r_end;
+                va[t] = (rin && colI + col < A) ? M[r * A + colI + col] : 0.0;
+                vb[t] = (!diag && rin && colJ + col < A) ? M[r * A + colJ + col] : 0.0;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < HALF; t++) {
+                const uint32_t e = tid + 256u * (h * HALF + t);
+                const uint32_t rr = e / PT, col = e % PT;
+                lds_a[rr * ROWD + swz(col)] = va[t];
+                if (!diag) lds_b[rr * ROWD + swz(col)] = vb[t];
             }
         }
         __syncthreads();
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(256) void prefilter_tile_kernel(const double* __res
 #pragma unroll
                 for (int x = 0; x < 8; x++)
 #pragma unroll
-                    for (int y = 0; y < 8; y++) acc[x][y] += fmax(a[x], b[y]);
+                    for (int y = 0; y < 8; y++) acc[x][y] += vmax(a[x], b[y]);
             }
         }
         __syncthreads();
