@@ -489,7 +489,11 @@ template <uint32_t P, int KIND>
 __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_loop_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t W = V.wstride;
-    uint32_t* wd = reinterpret_cast<uint32_t*>(smem);                   // [W] depth | GC bin << 25
+    // [W] window weights first (greedy only: its 3 waves/SIMD leave room for them; the 400-odd annealing chains read
+    // theirs through L2), then [W] depth | GC bin << 25
+    constexpr bool WW_LDS = KIND == LCTY_SOLVER_GREEDY;
+    double* lww = reinterpret_cast<double*>(smem);
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + (WW_LDS ? static_cast<size_t>(W) * 8 : 0));
     const uint32_t lane = threadIdx.x;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
@@ -500,10 +504,13 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
     {
         const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
         const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
-        for (uint32_t w = lane; w < G.total_w; w += 64) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
+        for (uint32_t w = lane; w < G.total_w; w += 64) {
+            wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
+            if (WW_LDS) lww[w] = gww[w];
+        }
     }
     __syncthreads();
-    Chain C{&V, wd, gww};
+    Chain C{&V, wd, WW_LDS ? lww : gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
     for (uint32_t w = lane; w < G.total_w; w += 64) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
@@ -916,7 +923,8 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
 }
 
 template <uint32_t P>
-void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, size_t lds_loop) {
+void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, size_t lds_loop_base) {
+    const size_t lds_loop = lds_loop_base + (V.solver.kind == LCTY_SOLVER_GREEDY ? static_cast<size_t>(V.wstride) * 8 : 0);
     hipStream_t s = ctx->stream;
     if (lds_init > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -986,7 +994,7 @@ struct StageRunner {
         V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
         lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
         lds_loop = static_cast<size_t>(V.wstride) * 4 + 16;
-        if (lds_loop > 160 * 1024 || V.wstride > 65535) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype: too many for the device solver", V.wstride);
+        if (lds_loop + static_cast<size_t>(V.wstride) * 8 > 160 * 1024 || V.wstride > 65535) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype: too many for the device solver", V.wstride);
 
         // chains are processed in batches so that the per-chain state (4 B per good read) stays bounded
         const uint64_t per_chain = ngp * 4 + static_cast<uint64_t>(V.wstride) * 13;
