@@ -522,7 +522,8 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
     const double rel_contrib = V.depth_contrib / V.aln_contrib;
 
     auto load_slot = [&](uint32_t slot) -> uint32_t {
-        return __hip_atomic_load(&nontriv[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // agent scope = served by L2, where this wavefront's own stores to the list arrive in program order
+        return __hip_atomic_load(&nontriv[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // ReassignmentTarget::random (assgn.rs:451-471); wave-uniform
     auto random_move = [&](Move& m) {
@@ -551,9 +552,11 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
         if (lane == 0) {
             wd[m.w3] += 1; wd[m.w4] += 1;                                     // the depth field never borrows from the GC bits
             wd[m.w1] -= 1; wd[m.w2] -= 1;
-            __hip_atomic_store(&nontriv[m.slot], m.rp | (m.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&nontriv[m.slot], m.rp | (m.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // one wavefront owns the chain: LDS and vector-memory operations of a wavefront execute in program order, so the
+        // following reads see these updates without waiting for the store to complete (no s_waitcnt vmcnt(0) here)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
