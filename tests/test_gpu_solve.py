@@ -229,3 +229,24 @@ def test_solver_edge_cases(gpu_ctx):
     for ss in (64, 33, 1):
         big.sample_size = ss
         compare_stage(aa2, ol2, oa2, g, big, 2, api.chain_seeds(2, 2 * len(g)))
+
+
+@pytest.mark.parametrize("prm", [
+    dict(lik_skew=0.0), dict(lik_skew=0.5, tweak=10), dict(prob_diff=3.0), dict(prob_diff=60.0, tweak=100),
+    dict(min_weight=0.5), dict(n_alt_cn=0), dict(n_alt_cn=1), dict(n_alt_cn=2, lik_skew=-0.3),
+])
+def test_solver_parameter_sweep(gpu_ctx, prm):
+    """model::Params that steer the solver stages (model/mod.rs:64-135): likelihood skew, location threshold,
+    tweak size, minimal window weight, alternative copy-number hypotheses of the depth distribution."""
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 8, 2500, 15000, seed=5, **prm)
+    gts = api.generate_genotypes(8, 2)
+    sub = gts[np.argsort(-aa.run_filter(), kind="stable")[:10]]
+    seeds = api.chain_seeds(77, 20)
+    for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+        solver = api.default_solver(kind)
+        if kind == cdefs.SOLVER_ANNEAL:
+            solver.anneal_steps, solver.plato_size = 3000, 2000
+        compare_stage(aa, ol, oa, sub, solver, 2, seeds)
+    off, counts = api.assignment_counts(aa, sub[0], api.default_solver(cdefs.SOLVER_GREEDY), 2, seeds[:2])
+    ooff, ocounts = O.assignment_counts(ol, oa, sub[0], api.default_solver(cdefs.SOLVER_GREEDY), 2, seeds[:2])
+    assert np.array_equal(off, ooff) and np.array_equal(counts, ocounts)
