@@ -241,6 +241,10 @@ def main():
             k = tr["kernels"]["lcty::score_reads_kernel"]
             out["roofline"]["traffic"] = k["hbm_bytes"]
             out["roofline"]["traffic_source"] = os.path.relpath(args.traffic, ROOT) + " (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE)"
+            if out.get("roofline_solver"):
+                ks = [v for name, v in tr["kernels"].items() if name.startswith("lcty::solve_loop_kernel")]
+                out["roofline_solver"]["traffic"] = sum(v["hbm_bytes"] for v in ks)
+                out["roofline_solver"]["traffic_fetch_raw"] = sum(v["fetch_bytes_raw"] for v in ks)
     except (OSError, KeyError, ValueError):
         pass
 
