@@ -109,6 +109,12 @@ struct SolveView {
     uint32_t* overflow;             // set when a window got deeper than the depth table (the host widens it and repeats)
 };
 
+// a wave-uniform 64-bit value, told to the compiler as such (it then lives in scalar registers)
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x >> 32));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
 // ---- randomness (definitions shared with oracle/lcty_oracle_solve.c) ----
 __device__ __forceinline__ uint64_t counter_u64(uint64_t key, uint64_t i) {
     uint64_t z = key + (i + 1) * 0x9e3779b97f4a7c15ull;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
     const uint32_t lane = threadIdx.x;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
-    const uint64_t seed = V.seeds[chain];
+    const uint64_t seed = uniform64(V.seeds[chain]);
     Geno<P> G; G.init(V, gi);
     uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
     const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
@@ -585,15 +591,37 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
                 // non_trivial_reads.sample(rng, S) of each iteration: distinct indices, repeats rejected (our adaptor);
                 // lane b * S + j keeps the j-th pick of iteration b
                 uint32_t my_pick = NONE32S;
-                for (uint32_t b = 0; b < nb; b++) {
-                    for (uint32_t j = 0; j < S; j++) {
-                        uint32_t idx;
-                        bool dup;
-                        do {
-                            idx = static_cast<uint32_t>(rng.below(nnt));
-                            dup = __ballot(grp == b && jj < j && my_pick == idx) != 0ull;
-                        } while (dup);
-                        if (grp == b && jj == j) my_pick = idx;
+                {
+                    // fast path: the nb * S draws of the batch go to their lanes as they are; the sample of an iteration
+                    // almost never repeats an index (S^2 / 2 nnt), and when one does the batch is redone by the book
+                    const Xoshiro saved = rng;
+                    uint64_t mine = 0;
+                    const uint32_t n_draws = nb * S;
+                    for (uint32_t kk = 0; kk < n_draws; kk++) {
+                        const uint64_t v = rng.next();                         // scalar unit; lane kk keeps it
+                        if (lane == kk) mine = v;
+                    }
+                    const uint32_t idx = static_cast<uint32_t>(__umul64hi(mine, static_cast<uint64_t>(nnt)));
+                    bool dup = false;
+                    for (uint32_t d = 1; d < S; d++) {
+                        const uint32_t other = static_cast<uint32_t>(__shfl_up(static_cast<int>(idx), d));
+                        dup |= jj >= d && other == idx;
+                    }
+                    if (__ballot(dup && lane < n_draws) == 0ull) {
+                        if (lane < n_draws) my_pick = idx;
+                    } else {
+                        rng = saved;
+                        for (uint32_t b = 0; b < nb; b++) {
+                            for (uint32_t j = 0; j < S; j++) {
+                                uint32_t pick;
+                                bool again;
+                                do {
+                                    pick = static_cast<uint32_t>(rng.below(nnt));
+                                    again = __ballot(grp == b && jj < j && my_pick == pick) != 0ull;
+                                } while (again);
+                                if (grp == b && jj == j) my_pick = pick;
+                            }
+                        }
                     }
                 }
                 // preparation: everything about the candidate read that the moves of this batch cannot change
