@@ -182,12 +182,9 @@ void launch_prefilter_diploid(lcty_reads* reads) {
     if (reads->d_partials.n < splits * G) reads->d_partials.alloc(splits * G);
     reads->n_scores = G;
     const size_t lds = 2 * RC * ROWD * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_tile_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        attr_set = true;
-    }
+    // per device and cheap: no process-wide "already done" flag (contexts on several GPUs, several host threads)
+    LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_tile_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     ctx->timed(LCTY_K_PREFILTER, [&] {
         hipLaunchKernelGGL(prefilter_tile_kernel, dim3(n_tp, static_cast<uint32_t>(splits)), dim3(256), lds, ctx->stream,
                            reads->d_matrix.p, R, A, n_tiles, per, reads->d_partials.p, G);

@@ -244,12 +244,24 @@ struct Locs {
 };
 
 template <uint32_t P>
+__device__ __forceinline__ void locs_from_cells(Locs<P>& L, const SolveView& V, const LocEntry* cells);
+
+template <uint32_t P>
 __device__ __forceinline__ void locs_init(Locs<P>& L, const SolveView& V, uint32_t g, const Geno<P>& G) {
+    LocEntry cells[P];
+#pragma unroll
+    for (uint32_t p = 0; p < P; p++) cells[p] = V.table[static_cast<uint64_t>(G.id[p]) * V.ngp + g];
+    locs_from_cells<P>(L, V, cells);
+}
+
+// the same from cells that are already at hand (registers or LDS)
+template <uint32_t P>
+__device__ __forceinline__ void locs_from_cells(Locs<P>& L, const SolveView& V, const LocEntry* cells) {
     uint32_t raw[P];
     double top = -INFINITY;
 #pragma unroll
     for (uint32_t p = 0; p < P; p++) {
-        const LocEntry e = V.table[static_cast<uint64_t>(G.id[p]) * V.ngp + g];
+        const LocEntry e = cells[p];
         L.lp[p] = e.lp;
         raw[p] = e.m1n >> 24;
         L.m1[p] = (e.m1n & MID_NONE24) == MID_NONE24 ? NONE32S : (e.m1n & MID_NONE24);
@@ -490,17 +502,30 @@ struct Chain {
     }
 };
 
-// ---------------- K14: one wavefront per chain ----------------
+// ---------------- K14: one wavefront per chain (+ a staging wavefront for annealing) ----------------
+constexpr uint32_t RING = 64;                  // staged positions of the random stream (power of two)
+constexpr uint32_t SPIN_LIMIT = 200u * 1000u * 1000u;    // bounded waits: a lost hand-shake becomes an error, not a hang
+template <uint32_t P>
+struct AnnealRing {
+    uint64_t draw[RING];
+    LocEntry cell[RING][P];
+    uint64_t rng[4];
+    uint32_t produced, consumed, stop, go;
+};
+
 template <uint32_t P, int KIND>
-__global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_loop_kernel(const SolveView V) {
-    extern __shared__ __align__(16) uint8_t smem[];
+__global__ __launch_bounds__(KIND == LCTY_SOLVER_GREEDY ? 64 : 128, KIND == LCTY_SOLVER_GREEDY ? 3 : 4)
+void solve_loop_kernel(const SolveView V) {
+    extern __shared__ __align__(32) uint8_t smem[];
     const uint32_t W = V.wstride;
     // [W] window weights first (greedy only: its 3 waves/SIMD leave room for them; the 400-odd annealing chains read
     // theirs through L2), then [W] depth | GC bin << 25
     constexpr bool WW_LDS = KIND == LCTY_SOLVER_GREEDY;
     double* lww = reinterpret_cast<double*>(smem);
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem + (WW_LDS ? static_cast<size_t>(W) * 8 : 0));
-    const uint32_t lane = threadIdx.x;
+    // annealing only: a second wavefront stages the reads of the coming moves in an LDS ring (see the second loop)
+    AnnealRing<P>* ring = reinterpret_cast<AnnealRing<P>*>(smem + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = uniform64(V.seeds[chain]);
@@ -510,21 +535,61 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
     {
         const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
         const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
-        for (uint32_t w = lane; w < G.total_w; w += 64) {
+        for (uint32_t w = lane; wave == 0 && w < G.total_w; w += 64) {
             wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
             if (WW_LDS) lww[w] = gww[w];
         }
     }
+    const uint32_t nnt = V.c_nnt[chain];
+    if (KIND == LCTY_SOLVER_ANNEAL && wave == 0 && lane == 0) { ring->produced = 0; ring->consumed = 0; ring->stop = 0; ring->go = 0; }
     __syncthreads();
+    if (KIND == LCTY_SOLVER_ANNEAL && wave == 1) {
+        // ---- producer: runs the random stream ahead of the chain and stages, for every draw taken as "the read of a
+        // move", the read index and its location cells (two dependent HBM gathers the chain then does not wait for)
+        __syncthreads();                                                     // hand-over of the stream (below)
+        if (__hip_atomic_load(&ring->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            Xoshiro prng;
+            prng.s0 = uniform64(ring->rng[0]); prng.s1 = uniform64(ring->rng[1]);
+            prng.s2 = uniform64(ring->rng[2]); prng.s3 = uniform64(ring->rng[3]);
+            uint32_t produced = 0, idle = 0;
+            for (;;) {
+                if (__hip_atomic_load(&ring->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                const uint32_t c = __hip_atomic_load(&ring->consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t n = RING - (produced - c);
+                if (n == 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++idle > SPIN_LIMIT) { atomicMax(V.overflow, 3u); break; }
+                    continue;
+                }
+                idle = 0;
+                uint64_t mine = 0;
+                for (uint32_t kk = 0; kk < n; kk++) {
+                    const uint64_t v = prng.next();
+                    if (lane == kk) mine = v;
+                }
+                if (lane < n) {
+                    const uint32_t slot = static_cast<uint32_t>(__umul64hi(mine, static_cast<uint64_t>(nnt)));
+                    const uint32_t rp = V.non_trivial[static_cast<uint64_t>(chain) * V.ngp + slot] & 0xFFFFFFu;
+                    const uint32_t pos = (produced + lane) & (RING - 1);
+                    ring->draw[pos] = mine;
+#pragma unroll
+                    for (uint32_t p = 0; p < P; p++) ring->cell[pos][p] = V.table[static_cast<uint64_t>(G.id[p]) * V.ngp + rp];
+                }
+                produced += n;
+                __hip_atomic_store(&ring->produced, produced, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
     Chain C{&V, wd, WW_LDS ? lww : gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
     for (uint32_t w = lane; w < G.total_w; w += 64) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
     for (int o2 = 32; o2 > 0; o2 >>= 1) depth_lik += __shfl_xor(depth_lik, o2);
     double aln_lik = V.c_aln[chain];
-    const uint32_t nnt = V.c_nnt[chain];
     Xoshiro rng; rng.seed(seed);
     uint64_t n_iter = 0, n_acc = 0;
+    bool handed_over = false;
     const double rel_contrib = V.depth_contrib / V.aln_contrib;
 
     auto load_slot = [&](uint32_t slot) -> uint32_t {
@@ -733,25 +798,40 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
             // stream (a move takes one draw, two when the read has more than two locations); the lanes that lie on
             // the true chain of moves are then walked in order up to the first accepted one, which is applied, and
             // the stream continues right behind it. Same moves, same order, same result as the serial loop.
-            unsigned long long draw = 0, d64 = 0;                              // draws q (lane q) and 64 of the window
-            for (uint32_t j = 0; j <= 64; j++) {
-                const unsigned long long v = rng.next();
-                if (j == 64) d64 = v; else if (lane == j) draw = v;
-            }
+            //
+            // The reads of the coming moves (list slot -> read -> location cells: two dependent HBM gathers) are staged by
+            // the second wavefront of the workgroup, which runs the same random stream ahead and treats every draw as if
+            // it started a move; this wavefront only re-reads the list slot (for the current location, L2-warm) and
+            // finds the cells in LDS.
+            if (lane == 0) { ring->rng[0] = rng.s0; ring->rng[1] = rng.s1; ring->rng[2] = rng.s2; ring->rng[3] = rng.s3; }
+            __hip_atomic_store(&ring->go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            handed_over = true;
+            __syncthreads();
             uint64_t iter = 0;
-            uint32_t width = 16;                                               // lanes that speculate: about twice the recent run length
+            uint32_t consumed = 0, width = 16;                                 // lanes that speculate: about twice the recent run length
+            bool lost = false;
             while (iter < max_iter && curr_plato < V.solver.plato_size) {
-                const unsigned long long up = __shfl_down(draw, 1);
-                const unsigned long long draw_next = lane == 63 ? d64 : up;
+                // a move may take the draw after its own: two staged positions at least
+                uint32_t avail = 0, idle = 0;
+                for (;;) {
+                    avail = __hip_atomic_load(&ring->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - consumed;
+                    if (avail >= 2) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++idle > SPIN_LIMIT) { lost = true; break; }
+                }
+                if (lost) { atomicMax(V.overflow, 3u); break; }
+                const uint32_t w = min(width, avail - 1);
                 Move m;
                 m.slot = 0; m.rp = 0; m.new_assgn = 0; m.ddiff = 0.0;
                 m.w1 = m.w2 = m.w3 = m.w4 = 0; m.lp_old = m.lp_new = 0.0;
                 bool accepted = false, wide = false;
-                if (lane < width) {
+                if (lane < w) {
+                    const uint32_t pos = (consumed + lane) & (RING - 1);
+                    const uint64_t draw = ring->draw[pos], draw_next = ring->draw[(pos + 1) & (RING - 1)];
                     m.slot = static_cast<uint32_t>(__umul64hi(draw, static_cast<uint64_t>(nnt)));
                     const uint32_t packed = load_slot(m.slot);
                     const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
-                    Locs<P> L; locs_init(L, V, rp, G);
+                    Locs<P> L; locs_from_cells<P>(L, V, ring->cell[pos]);
                     uint32_t new_assgn;
                     if (L.nw == 2) new_assgn = 1 - old_assgn;
                     else {
@@ -768,7 +848,7 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
                 const unsigned long long two = __ballot(wide);
                 uint32_t q = 0, walked = 0;
                 int hit = -1;
-                while (q < width) {
+                while (q < w) {
                     if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
                     iter++; n_iter++; walked++;
                     const uint32_t cons = 1 + static_cast<uint32_t>((two >> q) & 1ull);
@@ -784,18 +864,16 @@ __global__ __launch_bounds__(64, KIND == LCTY_SOLVER_GREEDY ? 3 : 4) void solve_
                     reassign(a);
                     curr_plato = 0;
                 }
-                width = min(64u, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
-                // the stream moves on by q draws (1..65): shift the window and refill its tail
-                unsigned long long nd = __shfl(draw, static_cast<int>((lane + q) & 63u));
-                if (lane + q == 64) nd = d64;
-                for (uint32_t j = 0; j < q; j++) {
-                    const unsigned long long v = rng.next();
-                    const uint32_t idx = 65 - q + j;
-                    if (idx == 64) d64 = v; else if (lane == idx) nd = v;
-                }
-                draw = nd;
+                width = min(RING - 1, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
+                // the stream moves on by q draws: the producer may reuse their ring entries
+                consumed += q;
+                __hip_atomic_store(&ring->consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+    }
+    if (KIND == LCTY_SOLVER_ANNEAL) {
+        if (!handed_over) __syncthreads();                                   // the producer waits for exactly one hand-over
+        __hip_atomic_store(&ring->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (lane == 0) {
         const double lik = V.depth_contrib * depth_lik + V.aln_contrib * aln_lik;       // assgn.rs:235-237
@@ -955,7 +1033,10 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
 
 template <uint32_t P>
 void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, size_t lds_loop_base) {
-    const size_t lds_loop = lds_loop_base + (V.solver.kind == LCTY_SOLVER_GREEDY ? static_cast<size_t>(V.wstride) * 8 : 0);
+    const size_t lds_loop = V.solver.kind == LCTY_SOLVER_GREEDY
+        ? lds_loop_base + static_cast<size_t>(V.wstride) * 8
+        : ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing<P>) + 64;
+    const uint32_t loop_threads = V.solver.kind == LCTY_SOLVER_GREEDY ? 64 : 128;
     hipStream_t s = ctx->stream;
     if (lds_init > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -966,7 +1047,7 @@ void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_i
                                      static_cast<int>(lds_loop)));
     ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); });
     LCTY_HIP(hipGetLastError());
-    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(loop_kernel, dim3(nch), dim3(64), lds_loop, s, V); });
+    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(loop_kernel, dim3(nch), dim3(loop_threads), lds_loop, s, V); });
     LCTY_HIP(hipGetLastError());
 }
 
@@ -1085,6 +1166,7 @@ struct StageRunner {
                     break;
                 }
                 if (ovf == 2) fail(LCTY_ERR_UNSUPPORTED, "a read pair with more than 255 possible locations on one genotype");
+                if (ovf == 3) fail(LCTY_ERR_RUNTIME, "annealing kernel: the staging wavefront and the chain lost each other");
                 if (loc->lut_ext_depth >= depth_cap) fail(LCTY_ERR_RUNTIME, "window depth beyond 2 * reads + 2");
                 d_ovf.zero(s);
                 ensure_depth_table(loc, std::min<uint64_t>(4ull * loc->lut_ext_depth, depth_cap));
