@@ -505,10 +505,16 @@ struct Chain {
 // ---------------- K14: one wavefront per chain (+ a staging wavefront for annealing) ----------------
 constexpr uint32_t RING = 64;                  // staged positions of the random stream (power of two)
 constexpr uint32_t SPIN_LIMIT = 200u * 1000u * 1000u;    // bounded waits: a lost hand-shake becomes an error, not a hang
-template <uint32_t P>
+// one staged draw: the read it would pick and everything about that read that no move can change — its possible
+// locations on the genotype in order (ln-probability, tweaked windows w1 | w2 << 16); nloc > 4: not staged, walk the merge
+struct __attribute__((aligned(16))) StagedRead {
+    uint64_t draw;
+    uint32_t rp, nloc;
+    double lp[4];
+    uint32_t win[4];
+};
 struct AnnealRing {
-    uint64_t draw[RING];
-    LocEntry cell[RING][P];
+    StagedRead pos[RING];
     uint64_t rng[4];
     uint32_t produced, consumed, stop, go;
 };
@@ -524,7 +530,7 @@ void solve_loop_kernel(const SolveView V) {
     double* lww = reinterpret_cast<double*>(smem);
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem + (WW_LDS ? static_cast<size_t>(W) * 8 : 0));
     // annealing only: a second wavefront stages the reads of the coming moves in an LDS ring (see the second loop)
-    AnnealRing<P>* ring = reinterpret_cast<AnnealRing<P>*>(smem + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
+    AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
@@ -545,7 +551,8 @@ void solve_loop_kernel(const SolveView V) {
     __syncthreads();
     if (KIND == LCTY_SOLVER_ANNEAL && wave == 1) {
         // ---- producer: runs the random stream ahead of the chain and stages, for every draw taken as "the read of a
-        // move", the read index and its location cells (two dependent HBM gathers the chain then does not wait for)
+        // move", the read and its possible locations (two dependent HBM gathers, the merge of the contigs' runs and the
+        // tweaked windows: nothing of it depends on the state of the chain)
         __syncthreads();                                                     // hand-over of the stream (below)
         if (__hip_atomic_load(&ring->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             Xoshiro prng;
@@ -570,10 +577,21 @@ void solve_loop_kernel(const SolveView V) {
                 if (lane < n) {
                     const uint32_t slot = static_cast<uint32_t>(__umul64hi(mine, static_cast<uint64_t>(nnt)));
                     const uint32_t rp = V.non_trivial[static_cast<uint64_t>(chain) * V.ngp + slot] & 0xFFFFFFu;
-                    const uint32_t pos = (produced + lane) & (RING - 1);
-                    ring->draw[pos] = mine;
+                    StagedRead* e = &ring->pos[(produced + lane) & (RING - 1)];
+                    Locs<P> L; locs_init(L, V, rp, G);
+                    e->draw = mine; e->rp = rp; e->nloc = L.nw;
+                    if (L.nw <= 4) {
+                        LocIter<P> it; it.start(L);
+                        LocOut o;
 #pragma unroll
-                    for (uint32_t p = 0; p < P; p++) ring->cell[pos][p] = V.table[static_cast<uint64_t>(G.id[p]) * V.ngp + rp];
+                        for (uint32_t t = 0; t < 4; t++) {
+                            if (t < L.nw && it.next(L, V, o)) {
+                                uint32_t wa, wb;
+                                loc_windows(V, G, o, seed, rp, t, &wa, &wb);
+                                e->lp[t] = o.lp; e->win[t] = wa | (wb << 16);
+                            }
+                        }
+                    }
                 }
                 produced += n;
                 __hip_atomic_store(&ring->produced, produced, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -632,15 +650,15 @@ void solve_loop_kernel(const SolveView V) {
     };
 
     if (nnt > 0) {
-        // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
-        double max_abs = 0.0;
-        for (uint32_t i = 0; i < 100; i++) {
-            Move m; random_move(m);
-            max_abs = fmax(max_abs, fabs(improvement(m)));
-        }
-        const double min_diff = fmax(1e-10 * max_abs, 1e-14);                 // minimum_allowed_diff (stoch.rs:27-29)
         const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
         if (KIND == LCTY_SOLVER_GREEDY) {
+            // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
+            double max_abs = 0.0;
+            for (uint32_t i = 0; i < 100; i++) {
+                Move m; random_move(m);
+                max_abs = fmax(max_abs, fabs(improvement(m)));
+            }
+            const double min_diff = fmax(1e-10 * max_abs, 1e-14);             // minimum_allowed_diff (stoch.rs:27-29)
             // Greedy::solve_nontrivial (stoch.rs:81-120). The random stream of the greedy loop does not depend on what
             // the moves do, so the reads of the next few iterations are known in advance: `NB` consecutive iterations
             // are prepared together, one candidate read per lane (slot, locations, tweaked windows: the part that does
@@ -780,69 +798,113 @@ void solve_loop_kernel(const SolveView V) {
                 }
             }
         } else {
-            // SimAnneal::solve_nontrivial (stoch.rs:195-245)
+            // SimAnneal::solve_nontrivial (stoch.rs:195-245).
+            // Every draw of the chain's random stream comes out of an LDS ring that the second wavefront of the workgroup
+            // fills ahead of time: it runs the same stream, treats every draw as if it picked the read of a move, and
+            // stages that read's possible locations (list slot -> read -> location cells: two dependent HBM gathers, the
+            // merge and the tweaked windows). What is left here per move: the list slot again (for the current location,
+            // L2-warm), two of the staged locations, depth_lik_diff.
+            if (lane == 0) { ring->rng[0] = rng.s0; ring->rng[1] = rng.s1; ring->rng[2] = rng.s2; ring->rng[3] = rng.s3; }
+            __hip_atomic_store(&ring->go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            handed_over = true;
+            __syncthreads();
+            uint32_t consumed = 0;
+            bool lost = false;
+            auto ring_wait = [&](uint32_t need) -> uint32_t {                  // staged positions (>= need), 0 = hand-shake lost
+                uint32_t idle = 0;
+                for (;;) {
+                    const uint32_t avail = __hip_atomic_load(&ring->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - consumed;
+                    if (avail >= need) return avail;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++idle > SPIN_LIMIT) { lost = true; atomicMax(V.overflow, 3u); return 0; }
+                }
+            };
+            auto ring_f64 = [&](uint32_t off) -> double {                      // rng.random::<f64>() at stream position consumed + off
+                return static_cast<double>(ring->pos[(consumed + off) & (RING - 1)].draw >> 11) * (1.0 / 9007199254740992.0);
+            };
+            // ReassignmentTarget::random (assgn.rs:451-471) at stream position consumed + off; returns the draws it takes
+            auto ring_move = [&](uint32_t off, Move& m) -> uint32_t {
+                const StagedRead* e = &ring->pos[(consumed + off) & (RING - 1)];
+                const uint64_t draw = e->draw, draw_next = ring->pos[(consumed + off + 1) & (RING - 1)].draw;
+                const uint32_t nloc = e->nloc;
+                m.slot = static_cast<uint32_t>(__umul64hi(draw, static_cast<uint64_t>(nnt)));
+                const uint32_t packed = load_slot(m.slot);                     // only the current location is news
+                const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
+                uint32_t new_assgn;
+                if (nloc == 2) new_assgn = 1 - old_assgn;
+                else {
+                    const uint32_t i = 1 + static_cast<uint32_t>(__umul64hi(draw_next, static_cast<uint64_t>(nloc - 1)));
+                    new_assgn = i <= old_assgn ? i - 1 : i;
+                }
+                m.rp = rp; m.new_assgn = new_assgn;
+                if (nloc <= 4) {
+                    double lp_o = e->lp[0], lp_n = lp_o; uint32_t w_o = e->win[0], w_n = w_o;
+#pragma unroll
+                    for (uint32_t t = 1; t < 4; t++) {
+                        const double lp_t = e->lp[t]; const uint32_t w_t = e->win[t];
+                        if (t == old_assgn) { lp_o = lp_t; w_o = w_t; }
+                        if (t == new_assgn) { lp_n = lp_t; w_n = w_t; }
+                    }
+                    m.lp_old = lp_o; m.lp_new = lp_n;
+                    m.w1 = w_o & 0xFFFFu; m.w2 = w_o >> 16; m.w3 = w_n & 0xFFFFu; m.w4 = w_n >> 16;
+                } else {
+                    Locs<P> L; locs_init(L, V, rp, G);
+                    fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
+                }
+                m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+                return nloc > 2 ? 2u : 1u;
+            };
+            auto retire = [&](uint32_t q) {                                    // the producer may reuse the ring entries of q draws
+                consumed += q;
+                __hip_atomic_store(&ring->consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            auto blank = [](Move& m) {
+                m.slot = 0; m.rp = 0; m.new_assgn = 0; m.ddiff = 0.0;
+                m.w1 = m.w2 = m.w3 = m.w4 = 0; m.lp_old = m.lp_new = 0.0;
+            };
+
+            // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
+            double max_abs = 0.0;
+            for (uint32_t i = 0; i < 100 && !lost; i++) {
+                if (!ring_wait(2)) break;
+                Move m; blank(m);
+                const uint32_t c = ring_move(0, m);
+                max_abs = fmax(max_abs, fabs(improvement(m)));
+                retire(c);
+            }
+            const double min_diff = fmax(1e-10 * max_abs, 1e-14);             // minimum_allowed_diff (stoch.rs:27-29)
             const double start_temp = fmax(-max_abs / log(V.solver.init_prob), 1e-5);
             const double temp_step = start_temp / static_cast<double>(V.solver.anneal_steps);
             uint32_t curr_plato = 0;
-            for (uint32_t i = V.solver.anneal_steps; i >= 1; i--) {
+            for (uint32_t i = V.solver.anneal_steps; i >= 1 && !lost; i--) {
+                if (!ring_wait(3)) break;
                 n_iter++;
-                Move m; random_move(m);
+                Move m; blank(m);
+                uint32_t c = ring_move(0, m);
                 const double diff = improvement(m) - min_diff;
                 bool accept = diff >= 0.0;
-                if (!accept) accept = rng.f64() <= exp(diff / (temp_step * static_cast<double>(i)));
+                if (!accept) { accept = ring_f64(c) <= exp(diff / (temp_step * static_cast<double>(i))); c++; }
                 if (accept) { reassign(m); curr_plato = 0; }
-                else { curr_plato++; if (curr_plato >= V.solver.plato_size) break; }
+                else { curr_plato++; }
+                retire(c);
+                if (!accept && curr_plato >= V.solver.plato_size) break;
             }
             // Second loop of stoch.rs:228-241: a move changes the state only when it is accepted, so the moves that
             // follow a rejection see the same state. Lane q evaluates the move that starts at draw q of the random
             // stream (a move takes one draw, two when the read has more than two locations); the lanes that lie on
             // the true chain of moves are then walked in order up to the first accepted one, which is applied, and
             // the stream continues right behind it. Same moves, same order, same result as the serial loop.
-            //
-            // The reads of the coming moves (list slot -> read -> location cells: two dependent HBM gathers) are staged by
-            // the second wavefront of the workgroup, which runs the same random stream ahead and treats every draw as if
-            // it started a move; this wavefront only re-reads the list slot (for the current location, L2-warm) and
-            // finds the cells in LDS.
-            if (lane == 0) { ring->rng[0] = rng.s0; ring->rng[1] = rng.s1; ring->rng[2] = rng.s2; ring->rng[3] = rng.s3; }
-            __hip_atomic_store(&ring->go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            handed_over = true;
-            __syncthreads();
             uint64_t iter = 0;
-            uint32_t consumed = 0, width = 16;                                 // lanes that speculate: about twice the recent run length
-            bool lost = false;
-            while (iter < max_iter && curr_plato < V.solver.plato_size) {
-                // a move may take the draw after its own: two staged positions at least
-                uint32_t avail = 0, idle = 0;
-                for (;;) {
-                    avail = __hip_atomic_load(&ring->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - consumed;
-                    if (avail >= 2) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++idle > SPIN_LIMIT) { lost = true; break; }
-                }
-                if (lost) { atomicMax(V.overflow, 3u); break; }
+            uint32_t width = 16;                                               // lanes that speculate: about twice the recent run length
+            while (!lost && iter < max_iter && curr_plato < V.solver.plato_size) {
+                const uint32_t avail = ring_wait(2);                           // a move may take the draw after its own
+                if (!avail) break;
                 const uint32_t w = min(width, avail - 1);
-                Move m;
-                m.slot = 0; m.rp = 0; m.new_assgn = 0; m.ddiff = 0.0;
-                m.w1 = m.w2 = m.w3 = m.w4 = 0; m.lp_old = m.lp_new = 0.0;
+                Move m; blank(m);
                 bool accepted = false, wide = false;
                 if (lane < w) {
-                    const uint32_t pos = (consumed + lane) & (RING - 1);
-                    const uint64_t draw = ring->draw[pos], draw_next = ring->draw[(pos + 1) & (RING - 1)];
-                    m.slot = static_cast<uint32_t>(__umul64hi(draw, static_cast<uint64_t>(nnt)));
-                    const uint32_t packed = load_slot(m.slot);
-                    const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
-                    Locs<P> L; locs_from_cells<P>(L, V, ring->cell[pos]);
-                    uint32_t new_assgn;
-                    if (L.nw == 2) new_assgn = 1 - old_assgn;
-                    else {
-                        const uint32_t i = 1 + static_cast<uint32_t>(__umul64hi(draw_next, static_cast<uint64_t>(L.nw - 1)));
-                        new_assgn = i <= old_assgn ? i - 1 : i;
-                    }
-                    m.rp = rp; m.new_assgn = new_assgn;
-                    fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
-                    m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+                    wide = ring_move(lane, m) == 2;
                     accepted = improvement(m) > min_diff;
-                    wide = L.nw > 2;
                 }
                 const unsigned long long acc = __ballot(accepted);
                 const unsigned long long two = __ballot(wide);
@@ -865,9 +927,7 @@ void solve_loop_kernel(const SolveView V) {
                     curr_plato = 0;
                 }
                 width = min(RING - 1, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
-                // the stream moves on by q draws: the producer may reuse their ring entries
-                consumed += q;
-                __hip_atomic_store(&ring->consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                retire(q);
             }
         }
     }
@@ -1035,7 +1095,7 @@ template <uint32_t P>
 void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, size_t lds_loop_base) {
     const size_t lds_loop = V.solver.kind == LCTY_SOLVER_GREEDY
         ? lds_loop_base + static_cast<size_t>(V.wstride) * 8
-        : ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing<P>) + 64;
+        : ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
     const uint32_t loop_threads = V.solver.kind == LCTY_SOLVER_GREEDY ? 64 : 128;
     hipStream_t s = ctx->stream;
     if (lds_init > 48 * 1024)
