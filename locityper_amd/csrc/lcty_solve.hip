@@ -669,6 +669,7 @@ void solve_loop_kernel(const SolveView V) {
             uint32_t curr_plato = 0;
             uint64_t iter = 0;
             bool done = false;
+            double depth_mine = 0.0, aln_mine = 0.0;                           // likelihood changes of the moves this lane applied
             while (!done && iter < max_iter) {
                 const uint32_t nb = static_cast<uint32_t>(min(static_cast<uint64_t>(NB), max_iter - iter));
                 // non_trivial_reads.sample(rng, S) of each iteration: distinct indices, repeats rejected (our adaptor);
@@ -783,20 +784,31 @@ void solve_loop_kernel(const SolveView V) {
                     for (int o2 = 32; o2 > 0; o2 >>= 1) best = fmax(best, __shfl_xor(best, o2));
                     const unsigned long long who = __ballot(grp == b && my_improv == best);
                     if (best > min_diff && who) {
-                        const int src = __ffsll(static_cast<long long>(who)) - 1;
-                        Move m;
-                        m.rp = __shfl(mm.rp, src); m.new_assgn = __shfl(mm.new_assgn, src); m.slot = __shfl(mm.slot, src);
-                        m.w1 = __shfl(mm.w1, src); m.w2 = __shfl(mm.w2, src); m.w3 = __shfl(mm.w3, src); m.w4 = __shfl(mm.w4, src);
-                        m.lp_old = __shfl(mm.lp_old, src); m.lp_new = __shfl(mm.lp_new, src); m.ddiff = __shfl(mm.ddiff, src);
+                        // reassign (assgn.rs:331-343) by the lane that holds the move; the others only learn which list
+                        // slot changed. The lane's share of the likelihood is added up at the end.
+                        const uint32_t src = static_cast<uint32_t>(__ffsll(static_cast<long long>(who))) - 1u;
+                        if (lane == src) {
+                            wd[mm.w3] += 1; wd[mm.w4] += 1;                   // the depth field never borrows from the GC bits
+                            wd[mm.w1] -= 1; wd[mm.w2] -= 1;
+                            __hip_atomic_store(&nontriv[mm.slot], mm.rp | (mm.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            depth_mine += mm.ddiff;
+                            aln_mine += mm.lp_new - mm.lp_old;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t moved_slot = __builtin_amdgcn_readlane(mm.slot, src);
+                        const uint32_t moved_to = __builtin_amdgcn_readlane(mm.new_assgn, src);
+                        n_acc++;
                         curr_plato = 0;
-                        reassign(m);
-                        if (my_pick == m.slot) cur_assgn = m.new_assgn;       // the same read may come up again in this batch
+                        if (my_pick == moved_slot) cur_assgn = moved_to;      // the same read may come up again in this batch
                     } else {
                         curr_plato++;
                         if (curr_plato > V.solver.plato_size) { done = true; break; }
                     }
                 }
             }
+            for (int o2 = 32; o2 > 0; o2 >>= 1) { depth_mine += __shfl_xor(depth_mine, o2); aln_mine += __shfl_xor(aln_mine, o2); }
+            depth_lik += depth_mine; aln_lik += aln_mine;
         } else {
             // SimAnneal::solve_nontrivial (stoch.rs:195-245).
             // Every draw of the chain's random stream comes out of an LDS ring that the second wavefront of the workgroup
