@@ -42,6 +42,7 @@ struct __attribute__((aligned(16))) Rec16 {
 static_assert(sizeof(Rec16) == 16, "Rec16 layout");
 
 struct __attribute__((packed, aligned(4))) W8 { uint32_t w[8]; };
+struct __attribute__((packed, aligned(4))) W4 { uint32_t w[4]; };
 
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
     for (int o = WAVE / 2; o > 0; o >>= 1) v = min(v, static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), o)));
@@ -112,7 +113,21 @@ __device__ __forceinline__ OpCounts count_ops(const W8& first, const uint32_t* c
 #pragma unroll
     for (uint32_t i = 0; i < 8; i++)
         if (i < nc) { count_op(c, first.w[i], i == 0 || i + 1 == nc); wl = first.w[i]; }
-    for (uint32_t i = 8; i < nc; i++) { wl = cig[i]; count_op(c, wl, i + 1 == nc); }
+    // long CIGARs (ONT / HiFi): eight, then four words per step from unaligned 16-byte loads
+    uint32_t i = 8;
+    for (; i + 8 <= nc; i += 8) {
+        const W8 q = *reinterpret_cast<const W8*>(cig + i);
+#pragma unroll
+        for (uint32_t t = 0; t < 8; t++) count_op(c, q.w[t], i + t + 1 == nc);
+        wl = q.w[7];
+    }
+    for (; i + 4 <= nc; i += 4) {
+        const W4 q = *reinterpret_cast<const W4*>(cig + i);
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) count_op(c, q.w[t], i + t + 1 == nc);
+        wl = q.w[3];
+    }
+    for (; i < nc; i++) { wl = cig[i]; count_op(c, wl, i + 1 == nc); }
     // soft_clipping (cigar.rs:519-527) after hard_to_soft (309-320)
     const uint32_t w0 = first.w[0];
     const uint32_t op0 = w0 & 15u, opl = wl & 15u;
