@@ -300,6 +300,14 @@ int32_t lcty_assignment_counts(lcty_reads* reads, const uint16_t* genotype, uint
 /* Genotyping::count_unexplained_reads (solve.rs:718-729): good read pairs whose best alignment on the alleles of the
  * called genotype is no better than "both mates unmapped" (+1e-8). */
 int32_t lcty_count_unexplained(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, uint32_t* out);
+/* Genotyping::{find_weighted_dist, check_first_prob, check_num_of_reads} (solve.rs:621-675). genotypes[n][ploidy] and
+ * ln_probs[n] as produced by lcty_produce_result (best first); dist: optional n_alleles x n_alleles matrix of contig distances
+ * (symmetric, LCTY_NONE_U32 = unknown; `contig_distances`, solve.rs:974-976). distances_out[n] (LCTY_NONE_U32 = None),
+ * *weighted_dist (NaN = None), *warnings = LCTY_WARN_* bits. Host only. */
+#define LCTY_WARN_NO_PROBABLE_GENOTYPE 1u
+#define LCTY_WARN_FEW_READS            2u
+int32_t lcty_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy, const double* ln_probs, uint32_t n_reads,
+                         const uint32_t* dist, uint32_t n_alleles, uint32_t* distances_out, double* weighted_dist, uint32_t* warnings);
 /* Diagnostics of the last lcty_solve_stage on this batch: chains run, solver iterations (greedy iterations /
  * annealing moves) and accepted moves summed over the chains (stoch.rs has no counterpart; used by bench.py). */
 int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
     "lcty_assignment_counts": (I32, [VP, VP, U32, P(Solver), U32, VP, VP, VP, U64, P(U64)]),
     "lcty_count_unexplained": (I32, [VP, VP, U32, P(U32)]),
+    "lcty_call_checks": (I32, [VP, U64, U32, VP, U32, VP, U32, VP, P(D), P(U32)]),
     "lcty_solve_stats": (I32, [VP, P(U64), P(U64), P(U64)]),
     "lcty_discard_improbable": (I32, [VP, VP, VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),

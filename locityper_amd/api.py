@@ -278,6 +278,19 @@ def count_unexplained(aa, genotype):
     return int(out.value)
 
 
+def call_checks(genotypes, ln_probs, n_reads, dist=None, n_alleles=0):
+    """find_weighted_dist / check_first_prob / check_num_of_reads (solve.rs:621-675): (distances, weighted_dist, warnings)."""
+    genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n, ploidy = genotypes.shape
+    lp = np.ascontiguousarray(ln_probs, dtype=np.float64)
+    dm = None if dist is None else np.ascontiguousarray(dist, dtype=np.uint32)
+    out = np.zeros(n, dtype=np.uint32)
+    wd, warn = D(), U32()
+    check(lib().lcty_call_checks(genotypes.ctypes.data, n, ploidy, lp.ctypes.data, n_reads, None if dm is None else dm.ctypes.data,
+                                 n_alleles if dm is None else dm.shape[0], out.ctypes.data, C.byref(wd), C.byref(warn)))
+    return out, float(wd.value), int(warn.value)
+
+
 def solve_stats(aa):
     """(chains, iterations, accepted moves) of the last solve_stage on this batch."""
     c, i, a = U64(), U64(), U64()

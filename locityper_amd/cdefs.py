@@ -240,3 +240,5 @@ class ReadsChunk:
             self.nmask[int(mo[0]) // 32:max(int(mo[-1]) // 32, int(mo[0]) // 32 + 1)],
             ao - ao[0], self.recs[int(ao[0]):int(ao[-1])], co - co[0],
             self.cigar[int(co[0]):int(co[-1])])
+
+WARN_NO_PROBABLE_GENOTYPE, WARN_FEW_READS = 1, 2      # lcty_call_checks

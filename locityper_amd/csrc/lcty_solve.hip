@@ -1383,6 +1383,72 @@ int32_t lcty_count_unexplained(lcty_reads* reads, const uint16_t* genotype, uint
     });
 }
 
+// Genotyping::{find_weighted_dist, check_first_prob, check_num_of_reads} (solve.rs:621-675) with genotype_distance
+// (339-357) over gen_permutations (ext/vec.rs:342-372: for three or more elements Heap's algorithm as written there never
+// hands the unpermuted order to the callback, so it is not among the candidates — kept as is)
+int32_t lcty_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy, const double* ln_probs, uint32_t n_reads,
+                         const uint32_t* dist, uint32_t n_alleles, uint32_t* distances_out, double* weighted_dist, uint32_t* warnings) {
+    return guarded([&] {
+        if (!genotypes || !ln_probs || n == 0 || ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (ploidy > 8) fail(LCTY_ERR_UNSUPPORTED, "ploidy above 8");
+        uint32_t w = 0;
+        const double lp0 = ln_probs[0];
+        if (std::isnan(lp0) || lp0 < -2.0 * 2.302585092994045684) w |= LCTY_WARN_NO_PROBABLE_GENOTYPE;     // < 0.01
+        if (n_reads < ploidy) w |= LCTY_WARN_FEW_READS;
+        else if (ploidy > 1 && n_reads < ploidy * 10) {
+            const double k = ploidy, nr = n_reads;
+            if (std::exp(std::log(k - 1.0) * nr - std::log(k) * (nr - 1.0)) > 0.1) w |= LCTY_WARN_FEW_READS;
+        }
+        if (warnings) *warnings = w;
+        if (!dist) { if (weighted_dist) *weighted_dist = std::numeric_limits<double>::quiet_NaN(); return; }
+        for (uint64_t i = 0; i < n * ploidy; i++)
+            if (genotypes[i] >= n_alleles) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], n_alleles);
+        auto pair_dist = [&](const uint16_t* a, const uint16_t* b) -> uint32_t {        // one permutation of gt1 against gt2
+            uint32_t d = 0;
+            for (uint32_t t = 0; t < ploidy; t++) {
+                if (a[t] == b[t]) continue;
+                const uint32_t v = dist[static_cast<size_t>(a[t]) * n_alleles + b[t]];
+                if (v == LCTY_NONE_U32) return LCTY_NONE_U32;
+                d += v;
+            }
+            return d;
+        };
+        const uint16_t* g0 = genotypes;
+        double sum_prob = 0.0, sum_dist = 0.0;
+        bool all_known = true;
+        for (uint64_t i = 0; i < n; i++) {
+            const double prob = std::exp(ln_probs[i]);
+            sum_prob += prob;
+            uint32_t best = 0;
+            if (i > 0) {
+                const uint16_t* g = genotypes + i * ploidy;
+                best = LCTY_NONE_U32;
+                uint16_t buf[8];
+                for (uint32_t t = 0; t < ploidy; t++) buf[t] = g0[t];
+                if (ploidy == 1) best = pair_dist(buf, g);
+                else if (ploidy == 2) {
+                    best = pair_dist(buf, g);
+                    std::swap(buf[0], buf[1]);
+                    best = std::min(best, pair_dist(buf, g));
+                } else {
+                    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (uint32_t k = 1; k < ploidy;) {
+                        if (c[k] < k) {
+                            std::swap(buf[k], buf[(k & 1u) ? c[k] : 0u]);
+                            best = std::min(best, pair_dist(buf, g));
+                            c[k]++; k = 1;
+                        } else { c[k] = 0; k++; }
+                    }
+                }
+            }
+            if (distances_out) distances_out[i] = best;
+            if (best == LCTY_NONE_U32) all_known = false;
+            else sum_dist += prob * static_cast<double>(best);
+        }
+        if (weighted_dist) *weighted_dist = all_known ? sum_dist / sum_prob : std::numeric_limits<double>::quiet_NaN();
+    });
+}
+
 int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted) {
     return guarded([&] {
         if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");

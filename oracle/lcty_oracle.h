@@ -185,6 +185,9 @@ uint64_t orc_discard_improbable(const double* lik_mean, const double* lik_var, c
 uint64_t orc_produce_result(const double* lik_mean, const double* lik_var, const uint32_t* attempts, const uint64_t* ixs,
                             uint64_t n, double prob_thresh, uint64_t out_bams, uint64_t* out_ixs, double* out_ln_probs,
                             double* quality);
+/* find_weighted_dist / check_first_prob / check_num_of_reads (solve.rs:621-675) */
+void orc_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy, const double* ln_probs, uint32_t n_reads,
+                     const uint32_t* dist, uint32_t n_alleles, uint32_t* distances_out, double* weighted_dist, uint32_t* warnings);
 /* count_unexplained_reads (solve.rs:718-729) */
 uint32_t orc_count_unexplained(const orc_alns* a, const uint16_t* ids, uint32_t ploidy);
 

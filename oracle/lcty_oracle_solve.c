@@ -652,6 +652,70 @@ uint32_t orc_count_unexplained(const orc_alns* a, const uint16_t* ids, uint32_t 
     return unexplained;
 }
 
+/* genotype_distance — solve.rs:339-357; gen_permutations — ext/vec.rs:342-372 (n >= 3: the loop only calls `action` after a
+ * swap, so the initial order is never visited) */
+static uint32_t perm_dist(const uint16_t* a, const uint16_t* b, uint32_t ploidy, const uint32_t* dist, uint32_t n_alleles) {
+    uint32_t d = 0;
+    for (uint32_t i = 0; i < ploidy; i++) {
+        if (a[i] != b[i]) {
+            const uint32_t v = dist[(size_t)a[i] * n_alleles + b[i]];
+            if (v == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+            d += v;
+        }
+    }
+    return d;
+}
+static uint32_t orc_genotype_distance(const uint16_t* gt1, const uint16_t* gt2, uint32_t n, const uint32_t* dist, uint32_t n_alleles) {
+    uint32_t min_dist = 0xFFFFFFFFu, d;
+    uint16_t buffer[16];
+    memcpy(buffer, gt1, sizeof(uint16_t) * n);
+    if (n == 1) {
+        d = perm_dist(buffer, gt2, n, dist, n_alleles); if (d < min_dist) min_dist = d;
+    } else if (n == 2) {
+        d = perm_dist(buffer, gt2, n, dist, n_alleles); if (d < min_dist) min_dist = d;
+        const uint16_t sw[2] = {gt1[1], gt1[0]};
+        d = perm_dist(sw, gt2, n, dist, n_alleles); if (d < min_dist) min_dist = d;
+    } else {
+        uint32_t c[16] = {0};
+        uint32_t i = 1;
+        while (i < n) {
+            if (c[i] < i) {
+                const uint32_t j = c[i] * (i % 2);                       /* 0 if i is even, c[i] if i is odd */
+                const uint16_t t = buffer[i]; buffer[i] = buffer[j]; buffer[j] = t;
+                d = perm_dist(buffer, gt2, n, dist, n_alleles); if (d < min_dist) min_dist = d;
+                c[i] += 1; i = 1;
+            } else { c[i] = 0; i += 1; }
+        }
+    }
+    return min_dist;
+}
+
+/* Genotyping::find_weighted_dist (solve.rs:621-636), check_first_prob (638-646), check_num_of_reads (650-675):
+ * warnings bit 0 = NoProbableGenotype, bit 1 = FewReads; weighted_dist NaN = None */
+void orc_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy, const double* ln_probs, uint32_t n_reads,
+                     const uint32_t* dist, uint32_t n_alleles, uint32_t* distances_out, double* weighted_dist, uint32_t* warnings) {
+    uint32_t w = 0;
+    if (isnan(ln_probs[0]) || ln_probs[0] < -2.0 * log(10.0)) w |= 1u;
+    if (n_reads < ploidy) w |= 2u;
+    else if (ploidy > 1 && n_reads < ploidy * 10) {
+        const double k = (double)ploidy, nr = (double)n_reads;
+        const double exp_zeros = exp(log(k - 1.0) * nr - log(k) * (nr - 1.0));
+        if (exp_zeros > 0.1) w |= 2u;
+    }
+    *warnings = w;
+    if (!dist) { *weighted_dist = NAN; return; }
+    double sum_prob = 0.0, sum_dist = 0.0;
+    int have = 1;
+    for (uint64_t i = 0; i < n; i++) {
+        const double prob = exp(ln_probs[i]);
+        sum_prob += prob;
+        const uint32_t d = i > 0 ? orc_genotype_distance(genotypes, genotypes + i * ploidy, ploidy, dist, n_alleles) : 0u;
+        if (d == 0xFFFFFFFFu) have = 0; else if (have) sum_dist += prob * (double)d;
+        if (distances_out) distances_out[i] = d;
+    }
+    *weighted_dist = have ? sum_dist / sum_prob : NAN;
+}
+
 /* Test hook: make the solver consume externally supplied tables (the ones the GPU built), so that oracle and GPU
  * chains see bit-identical inputs and their trajectories can be compared exactly. */
 void orc_locus_inject_tables(orc_locus* l, const double* depth_lut, const double* win_weight) {

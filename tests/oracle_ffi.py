@@ -106,6 +106,7 @@ def lib():
     sig("orc_locus_inject_tables", None, VP, VP, VP)
     sig("orc_assignment_likelihood", D, VP, VP, VP)
     sig("orc_solve_stage", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP)
+    sig("orc_call_checks", None, VP, U64, U32, VP, U32, VP, U32, VP, C.POINTER(D), C.POINTER(U32))
     sig("orc_assignment_counts", U64, VP, VP, VP, U32, C.POINTER(Solver), U32, VP, VP, VP)
     sig("orc_compare_two_likelihoods", D, D, D, U32, D, D, U32)
     sig("orc_discard_improbable", U64, VP, VP, VP, VP, U64, D, U64, U64)
@@ -365,6 +366,18 @@ def assignment_counts(locus, alns, genotype, solver, attempts, chain_seeds):
     counts = np.zeros(int(n), dtype=np.uint16)
     lib().orc_assignment_counts(*args, off.ctypes.data, counts.ctypes.data)
     return off, counts
+
+
+def call_checks(genotypes, ln_probs, n_reads, dist=None):
+    genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n, ploidy = genotypes.shape
+    lp = np.ascontiguousarray(ln_probs, dtype=np.float64)
+    dm = None if dist is None else np.ascontiguousarray(dist, dtype=np.uint32)
+    out = np.zeros(n, dtype=np.uint32)
+    wd, warn = D(), U32()
+    lib().orc_call_checks(genotypes.ctypes.data, n, ploidy, lp.ctypes.data, n_reads, None if dm is None else dm.ctypes.data,
+                          0 if dm is None else dm.shape[0], out.ctypes.data, C.byref(wd), C.byref(warn))
+    return out, float(wd.value), int(warn.value)
 
 
 def discard_improbable(lik_mean, lik_var, attempts, ixs, prob_thresh, out_size, threads):

@@ -108,3 +108,35 @@ def test_final_comparison_host_entry_points_match_oracle():
         i2, lp2, q2 = O.produce_result(mean, var, att, ixs, -4.0 * np.log(10))
         assert np.array_equal(i1, i2) and np.allclose(lp1, lp2, rtol=1e-10, atol=1e-10)
         assert abs(q1 - q2) <= 1e-7 * max(1.0, abs(q2))
+
+
+def test_call_checks_match_oracle_and_hand_values():
+    # find_weighted_dist / check_first_prob / check_num_of_reads (solve.rs:621-675)
+    rng = np.random.default_rng(9)
+    A = 7
+    dm = rng.integers(1, 500, (A, A)).astype(np.uint32)
+    dm = np.minimum(dm, dm.T); np.fill_diagonal(dm, 0)
+    for ploidy in (1, 2, 3, 4):
+        gts = api.generate_genotypes(A, ploidy)
+        pick = gts[rng.permutation(len(gts))[:12]]
+        lp = np.sort(rng.random(12) * -8.0)[::-1].copy()
+        lp -= np.logaddexp.reduce(lp)
+        for d in (dm, None):
+            g = api.call_checks(pick, lp, 1000, d)
+            o = O.call_checks(pick, lp, 1000, d)
+            assert np.array_equal(g[0], o[0]) and g[2] == o[2] == 0
+            assert (np.isnan(g[1]) and np.isnan(o[1])) or abs(g[1] - o[1]) <= 1e-12 * max(1.0, abs(o[1]))
+    # diploid by hand: min over the two pairings, identical alleles cost nothing
+    g2 = np.array([[0, 1], [1, 0], [0, 2], [3, 4]], dtype=np.uint16)
+    d, wdist, warn = api.call_checks(g2, np.log([0.7, 0.1, 0.1, 0.1]), 500, dm)
+    assert d.tolist() == [0, 0, int(dm[1, 2]), int(min(dm[0, 3] + dm[1, 4], dm[1, 3] + dm[0, 4]))]
+    assert abs(wdist - (0.1 * d[2] + 0.1 * d[3])) < 1e-9
+    # an unknown distance poisons the weighted distance, not the other entries
+    dm2 = dm.copy(); dm2[0, 3] = dm2[3, 0] = dm2[1, 3] = dm2[3, 1] = 0xFFFFFFFF
+    d2, w2, _ = api.call_checks(g2, np.log([0.7, 0.1, 0.1, 0.1]), 500, dm2)
+    o2 = O.call_checks(g2, np.log([0.7, 0.1, 0.1, 0.1]), 500, dm2)
+    assert d2[3] == 0xFFFFFFFF and np.isnan(w2) and np.array_equal(d2, o2[0]) and np.isnan(o2[1])
+    # warnings: improbable call; too few reads (ploidy 2: 1 read, 5 reads -> (1/2)^4 = 0.0625 <= 0.1 is fine, 3 reads -> 0.25)
+    assert api.call_checks(g2[:1], [np.log(0.005)], 500)[2] == cdefs.WARN_NO_PROBABLE_GENOTYPE == O.call_checks(g2[:1], [np.log(0.005)], 500)[2]
+    for n_reads, want in ((1, 2), (3, 2), (5, 0), (19, 0), (20, 0)):
+        assert api.call_checks(g2[:1], [0.0], n_reads)[2] == want == O.call_checks(g2[:1], [0.0], n_reads)[2]
