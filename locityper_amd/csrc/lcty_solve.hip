@@ -1162,7 +1162,10 @@ struct StageRunner {
         uint32_t min_w = 0xFFFFFFFFu;
         for (uint32_t a = 0; a < A; a++) min_w = std::min(min_w, std::max(loc->n_windows[a], 1u));
         depth_cap = 2 * n_good + 2;                                      // no window can be deeper
-        ensure_depth_table(loc, std::min<uint64_t>(4 * n_good / min_w + 64, depth_cap));
+        uint64_t first_width = std::min<uint64_t>(4 * n_good / min_w + 64, depth_cap);
+        if (const char* e = getenv("LCTY_DEPTH_TABLE_START"))              // developer / test switch: start narrow, exercise the widening
+            first_width = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        ensure_depth_table(loc, first_width);
         hipStream_t s = ctx->stream;
 
         V.by_window = FastDiv::make(loc->bg.window); V.by_tweak = FastDiv::make(2 * static_cast<uint32_t>(loc->prm.tweak) + 1);

@@ -250,3 +250,20 @@ def test_solver_parameter_sweep(gpu_ctx, prm):
     off, counts = api.assignment_counts(aa, sub[0], api.default_solver(cdefs.SOLVER_GREEDY), 2, seeds[:2])
     ooff, ocounts = O.assignment_counts(ol, oa, sub[0], api.default_solver(cdefs.SOLVER_GREEDY), 2, seeds[:2])
     assert np.array_equal(off, ooff) and np.array_equal(counts, ocounts)
+
+
+def test_depth_table_widening_gives_the_same_chains(gpu_ctx, monkeypatch):
+    """A chain that runs past the depth table raises a flag and the batch is repeated with a wider table: the result
+    must not depend on where the table started."""
+    gts = api.generate_genotypes(4, 2)
+    seeds = api.chain_seeds(8, 2 * len(gts))
+    out = []
+    for start in (None, "256"):
+        if start is None:
+            monkeypatch.delenv("LCTY_DEPTH_TABLE_START", raising=False)
+        else:
+            monkeypatch.setenv("LCTY_DEPTH_TABLE_START", start)
+        L, p, loc, aa, ol, oa = setup(gpu_ctx, 4, 20000, 4000)          # ~600 mates per window: far beyond 256
+        res = [api.solve_stage(aa, gts, api.default_solver(k), 2, seeds)[2] for k in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL)]
+        out.append(res)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
