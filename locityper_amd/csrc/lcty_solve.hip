@@ -1185,7 +1185,9 @@ struct StageRunner {
 
         // chains are processed in batches so that the per-chain state (4 B per good read) stays bounded
         const uint64_t per_chain = ngp * 4 + static_cast<uint64_t>(V.wstride) * 13;
-        const uint64_t budget = 64ull << 30;
+        uint64_t budget = 64ull << 30;
+        if (const char* e = getenv("LCTY_SOLVE_BUDGET_MB"))                   // developer / test switch: force several batches
+            budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
         gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
         const uint64_t max_chains = gt_per_batch * attempts;
         d_ovf.alloc(1); d_ovf.zero(s);

@@ -91,7 +91,7 @@ def test_homozygous_single_end_and_deep_coverage(gpu_ctx):
     compare_stage(aa, ol, oa, homo, api.default_solver(cdefs.SOLVER_GREEDY), 2, seeds)
     compare_stage(aa, ol, oa, homo[:3], api.default_solver(cdefs.SOLVER_ANNEAL), 2, seeds[:6])
     # ploidy 1 and 3
-    for ploidy in (1, 3):
+    for ploidy in (1, 3, 4):
         g = api.generate_genotypes(6, ploidy)[:5]
         compare_stage(aa, ol, oa, g, api.default_solver(cdefs.SOLVER_GREEDY), 1, api.chain_seeds(9, 5))
     # single-end long reads
@@ -267,3 +267,17 @@ def test_depth_table_widening_gives_the_same_chains(gpu_ctx, monkeypatch):
         res = [api.solve_stage(aa, gts, api.default_solver(k), 2, seeds)[2] for k in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL)]
         out.append(res)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_chain_batches_do_not_change_results(gpu_ctx, monkeypatch):
+    """Stages whose per-chain state exceeds the memory budget run in several batches of genotypes."""
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 8, 3000, 20000)
+    gts = api.generate_genotypes(8, 2)
+    seeds = api.chain_seeds(21, 3 * len(gts))
+    pri = -0.5 * np.arange(len(gts), dtype=np.float64)
+    monkeypatch.delenv("LCTY_SOLVE_BUDGET_MB", raising=False)
+    one = api.solve_stage(aa, gts, api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds, pri)
+    monkeypatch.setenv("LCTY_SOLVE_BUDGET_MB", "1")                      # a few genotypes per batch
+    many = api.solve_stage(aa, gts, api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds, pri)
+    assert np.array_equal(one[2], many[2]) and np.array_equal(one[0], many[0])
+    assert api.solve_stats(aa)[0] == 3 * len(gts)
