@@ -308,6 +308,34 @@ int32_t lcty_count_unexplained(lcty_reads* reads, const uint16_t* genotype, uint
 #define LCTY_WARN_FEW_READS            2u
 int32_t lcty_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy, const double* ln_probs, uint32_t n_reads,
                          const uint32_t* dist, uint32_t n_alleles, uint32_t* distances_out, double* weighted_dist, uint32_t* warnings);
+/* ---- the whole genotyping of one locus: solve::solve (src/solvers/solve.rs:926-981) ---------------------------------
+ * Scheme = list of stages (Stage, solve.rs:138-171; default "-S greedy:i=5k,a=1 -S anneal:i=20,a=20", 211-230). The call:
+ * all genotypes of `ploidy` (generate_genotypes) with optional priors -> run_filter + truncate_ixs when the first stage
+ * takes fewer genotypes than there are (or dont_skip) -> every stage (skipped when the survivors already fit the next
+ * stage, 805-809) + discard_improbable_genotypes -> produce_result -> count_unexplained_reads / check_first_prob /
+ * check_num_of_reads. Chain seeds of stage s: lcty_chain_seeds(master_seed + (s + 1) * 0x9e3779b97f4a7c15, n * attempts).
+ * lik_mean / lik_var / attempts_out (optional, [G]): NaN / 0 for genotypes that were never solved. */
+typedef struct lcty_stage {
+    lcty_solver solver;
+    uint64_t in_size;       /* genotypes this stage takes (Stage::in_size) */
+    uint32_t attempts;      /* chains per genotype */
+    uint32_t _pad0;
+} lcty_stage;
+#define LCTY_MAX_RESULT 50  /* MAX_GENOTYPES of produce_result (solve.rs:485) */
+typedef struct lcty_call {
+    uint64_t n_out;                       /* genotypes reported, best first */
+    uint64_t ixs[LCTY_MAX_RESULT];        /* indices into generate_genotypes order */
+    double   ln_probs[LCTY_MAX_RESULT];
+    double   quality;                     /* Phred of "the call is wrong", capped at 1e9 */
+    uint32_t unexpl_reads;                /* count_unexplained_reads of the call */
+    uint32_t warnings;                    /* LCTY_WARN_* */
+    uint64_t n_good;                      /* read pairs used */
+    uint64_t kept_after_filter;           /* genotypes after run_filter (= all when it was skipped) */
+} lcty_call;
+int32_t lcty_stages_default(lcty_stage* stages /* [2] */, uint32_t* n_stages);
+int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages, uint64_t master_seed,
+                   const double* priors, lcty_call* out, double* lik_mean, double* lik_var, uint32_t* attempts_out);
+
 /* Diagnostics of the last lcty_solve_stage on this batch: chains run, solver iterations (greedy iterations /
  * annealing moves) and accepted moves summed over the chains (stoch.rs has no counterpart; used by bench.py). */
 int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted);

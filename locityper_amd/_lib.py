@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 
-from .cdefs import Bg, Params, ReadsHost, PairAln, Solver
+from .cdefs import Bg, Params, ReadsHost, PairAln, Solver, Stage, Call
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocityper_hip.so")
@@ -50,6 +50,8 @@ SIGNATURES = {
     "lcty_assignment_counts": (I32, [VP, VP, U32, P(Solver), U32, VP, VP, VP, U64, P(U64)]),
     "lcty_count_unexplained": (I32, [VP, VP, U32, P(U32)]),
     "lcty_call_checks": (I32, [VP, U64, U32, VP, U32, VP, U32, VP, P(D), P(U32)]),
+    "lcty_stages_default": (I32, [P(Stage), P(U32)]),
+    "lcty_solve": (I32, [VP, U32, P(Stage), U32, U64, VP, P(Call), VP, VP, VP]),
     "lcty_solve_stats": (I32, [VP, P(U64), P(U64), P(U64)]),
     "lcty_discard_improbable": (I32, [VP, VP, VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),

@@ -387,3 +387,23 @@ def solve(aa, params, scheme=DEFAULT_SCHEME, master_seed=1, priors=None, ploidy=
     unexpl = count_unexplained(aa, gts[out_ixs[0]])
     return dict(unexpl_reads=unexpl, genotypes=gts[out_ixs], ixs=out_ixs, ln_probs=ln_probs, quality=quality, lik_mean=lik_mean, lik_var=lik_var,
                 attempts=att, kept_per_stage=kept)
+
+
+def default_stages():
+    """Scheme::default (solve.rs:211-230) as an array of lcty_stage."""
+    st = (cdefs.Stage * 2)()
+    n = U32()
+    check(lib().lcty_stages_default(st, C.byref(n)))
+    return st
+
+
+def solve_locus(aa, stages=None, master_seed=1, priors=None, ploidy=2):
+    """lcty_solve: the library's own solve::solve (scheme loop in C++). Returns (Call, lik_mean, lik_var, attempts)."""
+    stages = default_stages() if stages is None else stages
+    G = count_genotypes(aa.locus.n_alleles, ploidy)
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    mean, var, att = np.zeros(G), np.zeros(G), np.zeros(G, dtype=np.uint32)
+    call = cdefs.Call()
+    check(lib().lcty_solve(aa._h, ploidy, stages, len(stages), master_seed, None if pri is None else pri.ctypes.data, C.byref(call),
+                           mean.ctypes.data, var.ctypes.data, att.ctypes.data))
+    return call, mean, var, att

@@ -242,3 +242,16 @@ class ReadsChunk:
             self.cigar[int(co[0]):int(co[-1])])
 
 WARN_NO_PROBABLE_GENOTYPE, WARN_FEW_READS = 1, 2      # lcty_call_checks
+
+
+class Stage(C.Structure):                # lcty_stage
+    _fields_ = [("solver", Solver), ("in_size", C.c_uint64), ("attempts", C.c_uint32), ("_pad0", C.c_uint32)]
+
+
+MAX_RESULT = 50
+
+
+class Call(C.Structure):                 # lcty_call
+    _fields_ = [("n_out", C.c_uint64), ("ixs", C.c_uint64 * MAX_RESULT), ("ln_probs", C.c_double * MAX_RESULT),
+                ("quality", C.c_double), ("unexpl_reads", C.c_uint32), ("warnings", C.c_uint32), ("n_good", C.c_uint64),
+                ("kept_after_filter", C.c_uint64)]

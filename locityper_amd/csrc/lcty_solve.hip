@@ -1454,6 +1454,76 @@ int32_t lcty_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy,
     });
 }
 
+// Scheme::default (solve.rs:211-230)
+int32_t lcty_stages_default(lcty_stage* stages, uint32_t* n_stages) {
+    return guarded([&] {
+        if (!stages || !n_stages) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        memset(stages, 0, 2 * sizeof(lcty_stage));
+        lcty_solver_default(&stages[0].solver, LCTY_SOLVER_GREEDY); stages[0].in_size = 5000; stages[0].attempts = 1;
+        lcty_solver_default(&stages[1].solver, LCTY_SOLVER_ANNEAL); stages[1].in_size = 20; stages[1].attempts = 20;
+        *n_stages = 2;
+    });
+}
+
+// solve::solve (solve.rs:926-981) with solve_single_thread (789-857) as the stage loop
+int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages, uint64_t master_seed,
+                   const double* priors, lcty_call* out, double* lik_mean_out, double* lik_var_out, uint32_t* attempts_out) {
+    return guarded([&] {
+        if (!reads || !stages || !out || n_stages == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
+        for (uint32_t s = 0; s < n_stages; s++)
+            if (stages[s].attempts == 0 || stages[s].in_size == 0) fail(LCTY_ERR_INVALID_INPUT, "stage %u: attempts and in_size must be positive", s);
+        const lcty_locus* loc = reads->locus;
+        const lcty_params& prm = loc->prm;
+        const uint32_t A = loc->n_alleles;
+        const uint64_t G = count_genotypes(A, ploidy);
+        auto ok = [](int32_t rc) { if (rc != LCTY_OK) throw Error(rc, std::string(lcty_last_error())); };
+        std::vector<uint16_t> gts(G * ploidy);
+        ok(lcty_generate_genotypes(A, ploidy, gts.data(), G));
+        std::vector<uint64_t> ixs(G);
+        std::iota(ixs.begin(), ixs.end(), 0ull);
+        uint64_t n = G;
+        memset(out, 0, sizeof(*out));
+        // filter (solve.rs:940-945); the reference's floor of `threads` kept genotypes is 1 here: chains do not share a thread pool
+        if (prm.dont_skip || stages[0].in_size < G) {
+            std::vector<double> scores(G);
+            ok(lcty_prefilter(reads, nullptr, G, ploidy, priors, scores.data()));
+            ok(lcty_truncate(scores.data(), ixs.data(), G, prm.filt_diff, stages[0].in_size, 1, &n));
+        }
+        out->kept_after_filter = n;
+        std::vector<double> mean(G, std::numeric_limits<double>::quiet_NaN()), var(G, std::numeric_limits<double>::quiet_NaN());
+        std::vector<uint32_t> att(G, 0);
+        std::vector<uint16_t> sub; std::vector<double> pri, m, v; std::vector<uint64_t> seeds;
+        for (uint32_t si = 0; si < n_stages; si++) {
+            const bool last = si + 1 == n_stages;
+            const uint64_t out_size = last ? 0 : stages[si + 1].in_size;
+            if (!(prm.dont_skip || last || out_size < n)) continue;                  // "Skipping stage, not enough genotypes"
+            const uint32_t attempts = stages[si].attempts;
+            sub.resize(n * ploidy); pri.resize(n); m.resize(n); v.resize(n); seeds.resize(n * attempts);
+            for (uint64_t t = 0; t < n; t++) {
+                memcpy(sub.data() + t * ploidy, gts.data() + ixs[t] * ploidy, ploidy * sizeof(uint16_t));
+                pri[t] = priors ? priors[ixs[t]] : 0.0;
+            }
+            ok(lcty_chain_seeds(master_seed + static_cast<uint64_t>(si + 1) * 0x9e3779b97f4a7c15ull, n * attempts, seeds.data()));
+            ok(lcty_solve_stage(reads, sub.data(), n, ploidy, pri.data(), &stages[si].solver, attempts, seeds.data(), m.data(), v.data(), nullptr));
+            for (uint64_t t = 0; t < n; t++) { mean[ixs[t]] = m[t]; var[ixs[t]] = v[t]; att[ixs[t]] = attempts; }
+            if (!last) ok(lcty_discard_improbable(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, out_size, 1, &n));
+        }
+        ok(lcty_produce_result(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, 0, out->ixs, out->ln_probs, &out->n_out,
+                               &out->quality));
+        ok(lcty_count_unexplained(reads, gts.data() + out->ixs[0] * ploidy, ploidy, &out->unexpl_reads));
+        reads->ensure_good_index();
+        out->n_good = reads->n_good_cached;
+        std::vector<uint16_t> res(out->n_out * ploidy);
+        for (uint64_t t = 0; t < out->n_out; t++) memcpy(res.data() + t * ploidy, gts.data() + out->ixs[t] * ploidy, ploidy * sizeof(uint16_t));
+        ok(lcty_call_checks(res.data(), out->n_out, ploidy, out->ln_probs, static_cast<uint32_t>(std::min<uint64_t>(out->n_good, 0xFFFFFFFFull)),
+                            nullptr, A, nullptr, nullptr, &out->warnings));
+        if (lik_mean_out) memcpy(lik_mean_out, mean.data(), G * sizeof(double));
+        if (lik_var_out) memcpy(lik_var_out, var.data(), G * sizeof(double));
+        if (attempts_out) memcpy(attempts_out, att.data(), G * sizeof(uint32_t));
+    });
+}
+
 int32_t lcty_solve_stats(const lcty_reads* reads, uint64_t* chains, uint64_t* iterations, uint64_t* accepted) {
     return guarded([&] {
         if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");

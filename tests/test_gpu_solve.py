@@ -281,3 +281,25 @@ def test_chain_batches_do_not_change_results(gpu_ctx, monkeypatch):
     many = api.solve_stage(aa, gts, api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds, pri)
     assert np.array_equal(one[2], many[2]) and np.array_equal(one[0], many[0])
     assert api.solve_stats(aa)[0] == 3 * len(gts)
+
+
+def test_library_scheme_driver_equals_the_composed_calls(gpu_ctx):
+    """lcty_solve (solve::solve in C++ inside the library) against the same sequence of C-ABI calls made from Python."""
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 12, 6000, 20000)
+    stages = (cdefs.Stage * 2)()
+    stages[0].solver = api.default_solver(cdefs.SOLVER_GREEDY); stages[0].in_size = 40; stages[0].attempts = 1
+    stages[1].solver = api.default_solver(cdefs.SOLVER_ANNEAL); stages[1].in_size = 6; stages[1].attempts = 4
+    pri = -0.01 * np.arange(api.count_genotypes(12, 2), dtype=np.float64)
+    call, mean, var, att = api.solve_locus(aa, stages, master_seed=3, priors=pri)
+    ref = api.solve(aa, p, scheme=(("greedy", 40, 1), ("anneal", 6, 4)), master_seed=3, priors=pri)
+    n = int(call.n_out)
+    assert n == len(ref["ixs"]) and list(call.ixs[:n]) == ref["ixs"].tolist()
+    assert np.array_equal(np.array(call.ln_probs[:n]), ref["ln_probs"]) and call.quality == ref["quality"]
+    assert np.array_equal(mean, ref["lik_mean"], equal_nan=True) and np.array_equal(att, ref["attempts"])
+    assert call.unexpl_reads == ref["unexpl_reads"] and call.n_good == aa.n_good() and call.warnings == 0
+    assert call.kept_after_filter == ref["kept_per_stage"][0]
+    gts = api.generate_genotypes(12, 2)
+    assert tuple(gts[int(call.ixs[0])]) == L.true_genotype
+    # the default scheme runs too (fewer genotypes than the first stage takes: no filter, greedy stage on all 78)
+    call2, _, _, att2 = api.solve_locus(aa)
+    assert call2.kept_after_filter == 78 and tuple(gts[int(call2.ixs[0])]) == L.true_genotype and att2.max() == 20
