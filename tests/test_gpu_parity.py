@@ -385,3 +385,87 @@ def test_full_size_properties(gpu_ctx):
     assert off[-1] == len(counts) and np.all(np.add.reduceat(counts.astype(np.int64), off[:-1].astype(np.int64)) == 3)
     chains, iters, acc = api.solve_stats(full)
     assert chains == 3 and 0 < acc <= iters
+
+
+# ------------------------------------------------------------------ randomised adversarial pairs
+def random_cigar(rng, read_len):
+    """A valid CIGAR that consumes exactly read_len query bases: optional clips, =/X/I/D runs."""
+    left = int(rng.integers(0, 12)) if rng.random() < 0.25 else 0
+    right = int(rng.integers(0, 12)) if rng.random() < 0.25 else 0
+    body = read_len - left - right
+    ops, used = [], 0
+    while used < body:
+        r = rng.random()
+        n = int(min(body - used, rng.integers(1, 70)))
+        if r < 0.70: ops.append((n, "="))
+        elif r < 0.85: n = min(n, 4); ops.append((n, "X"))
+        elif r < 0.93: n = min(n, 5); ops.append((n, "I"))
+        else:
+            ops.append((int(rng.integers(1, 6)), "D")); n = 0
+        used += n
+    if ops and ops[-1][1] == "D": ops[-1] = (1, "=") if used < body else ops[-1]
+    if ops and ops[-1][1] == "D": ops.pop()
+    merged = []
+    for n, o in ops:                       # adjacent equal operations would be merged by any real aligner
+        if merged and merged[-1][1] == o: merged[-1] = (merged[-1][0] + n, o)
+        else: merged.append((n, o))
+    total_q = sum(n for n, o in merged if o in "=XI")
+    if total_q < body: merged.append((body - total_q, "="))
+    clipl = "S" if rng.random() < 0.7 else "H"
+    clipr = "S" if rng.random() < 0.7 else "H"
+    s = (f"{left}{clipl}" if left else "") + "".join(f"{n}{o}" for n, o in merged) + (f"{right}{clipr}" if right else "")
+    return s
+
+
+def random_pairs(rng, alleles, n_pairs, paired=True):
+    A, L = len(alleles), len(alleles[0])
+    pairs = []
+    for _ in range(n_pairs):
+        src = int(rng.integers(0, A))
+        p1 = int(rng.integers(0, L - 700))
+        p2 = p1 + int(rng.integers(150, 520))
+        s1 = alleles[src][p1:p1 + 150].decode()
+        s2 = alleles[src][p2:p2 + 150].decode()
+        if rng.random() < 0.1:
+            i = int(rng.integers(0, 150)); s1 = s1[:i] + "N" + s1[i + 1:]
+        recs = []
+        for end, (seq, pos) in enumerate(((s1, p1), (s2, p2)) if paired else ((s1, p1),)):
+            mate = M2 if end else 0
+            strand = REV if end else 0
+            unmapped_primary = rng.random() < 0.04
+            n_sec = int(rng.integers(0, 14)) if rng.random() < 0.5 else int(rng.integers(0, 3))
+            for j in range(1 + n_sec):
+                if j == 0 and unmapped_primary:
+                    recs.append((0, 0, mate | cdefs.FLAG_UNMAPPED, ""))
+                    continue
+                contig = src if j == 0 else int(rng.integers(0, A))
+                jitter = int(rng.integers(-3, 4)) if rng.random() < 0.5 else int(rng.integers(-400, 400))
+                q = max(0, min(L - 200, pos + (0 if j == 0 else jitter)))
+                cig = "150=" if (j == 0 and rng.random() < 0.6) else random_cigar(rng, len(seq))
+                if j and "H" not in cig and rng.random() < 0.03: cig = ""          # empty CIGAR: skipped with a warning
+                if j == 0: cig = cig.replace("H", "S")                              # primaries are never hard-clipped
+                fl = mate | (SEC if j else 0) | (strand if rng.random() < 0.9 else (REV - strand if strand else REV))
+                recs.append((contig, q, fl, cig))
+        pairs.append({"seq1": s1, "seq2": s2 if paired else None, "recs": recs})
+    return pairs
+
+
+@pytest.mark.parametrize("seed,n_alleles,paired", [(1, 3, True), (2, 5, True), (3, 9, True), (4, 4, False), (5, 70, True)])
+def test_random_adversarial_pairs(gpu_ctx, seed, n_alleles, paired):
+    """Randomised read pairs with everything the hand-written cases have, in random combination: clips (S and H), indels,
+    many secondaries on the same and on other contigs, near-duplicate positions (128-bp bins), wrong strands, unmapped
+    primaries, empty CIGARs, N bases. Status, k-mer counts, pair alignments and matrix must match the oracle exactly /
+    to 1e-9."""
+    rng = np.random.default_rng(1000 + seed)
+    alleles = random_alleles(n_alleles, 2600, seed=seed, snp_rate=0.02)
+    bg = make_bg(paired=paired)
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ch = ReadsChunk.from_pairs(random_pairs(rng, alleles, 400, paired))
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    assert len(set(oa.status.tolist())) >= 2
+    if paired:
+        check_prefilter(aa, Mo, n_alleles, p)
