@@ -469,3 +469,20 @@ def test_random_adversarial_pairs(gpu_ctx, seed, n_alleles, paired):
     assert len(set(oa.status.tolist())) >= 2
     if paired:
         check_prefilter(aa, Mo, n_alleles, p)
+    if n_alleles <= 9:
+        # the solver stages on the same reads: several pair-alignments per contig, reads with up to a dozen locations
+        st, w, unm, uk = aa.status()
+        off, pa = aa.pair_alns()
+        ol.inject_tables(loc.depth_lut(), loc.window_weights())
+        oa2 = O.alns_from_arrays(n_alleles, st, w, unm, off, pa)
+        gts = api.generate_genotypes(n_alleles, 2)[:12]
+        seeds = api.chain_seeds(seed, 2 * len(gts))
+        for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+            sv = api.default_solver(kind)
+            sv.anneal_steps, sv.plato_size = (2000, 1500) if kind == cdefs.SOLVER_ANNEAL else (sv.anneal_steps, sv.plato_size)
+            gl = api.solve_stage(aa, gts, sv, 2, seeds)[2]
+            olk = O.solve_stage(ol, oa2, gts, sv, 2, seeds)[2]
+            assert np.abs(gl - olk).max() <= 1e-9 * np.abs(olk).max()
+        o1, c1 = api.assignment_counts(aa, gts[1], api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds[:3])
+        o2, c2 = O.assignment_counts(ol, oa2, gts[1], api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds[:3])
+        assert np.array_equal(o1, o2) and np.array_equal(c1, c2) and np.diff(o1.astype(np.int64)).max() >= 4
