@@ -531,6 +531,14 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
         }
         for (uint32_t i = lane; i < A; i += WAVE) head32[i] = 0xFFFFFFFFu;
         if (lane == 0) *scratch_cursor = 0;
+        // the records of the first group of pass 1 are requested now, so that they arrive while lanes 0 / 1 work out the
+        // thresholds (two more dependent loads each)
+        uint4 raw_first[GR];
+#pragma unroll
+        for (int g = 0; g < GR; g++) {
+            const uint32_t idx = g * WAVE + lane;
+            raw_first[g] = idx < n_eff ? reinterpret_cast<const uint4*>(recs)[idx] : make_uint4(0, 0, 0, 0);
+        }
 
         // ---------------- thresholds (lanes 0 / 1 score the primaries) ----------------
         // state: 1 examined-ok, 2 primary saved, 4 error
@@ -592,7 +600,8 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
 #pragma unroll
             for (int g = 0; g < GR; g++) {
                 const uint32_t idx = base + g * WAVE + lane;
-                raw[g] = idx < n_eff ? reinterpret_cast<const uint4*>(recs)[idx] : make_uint4(0, 0, 0, 0);
+                if (base == 0) raw[g] = raw_first[g];
+                else raw[g] = idx < n_eff ? reinterpret_cast<const uint4*>(recs)[idx] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < GR; g++) {
