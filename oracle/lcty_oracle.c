@@ -574,6 +574,8 @@ typedef struct {
     uint8_t reverse;
     uint32_t edit, read_len; /* EditDist */
     double ln_prob;
+    uint32_t* own_cigar;     /* raw CIGAR words of a transferred alignment (NULL: the input record rec_ix) */
+    uint32_t own_n;
 } o_aln;
 
 typedef struct { uint64_t key; uint32_t index, pos; } pos_entry;   /* PosCollection, locs.rs:186-217 */
@@ -585,11 +587,14 @@ typedef struct {
     uint32_t* hslot; uint32_t* hgen; size_t hcap; uint32_t gen;
     uint32_t good_dist[2], passable_dist[2], best_edit[2];
     double best_lik[2];
+    uint32_t** owned; size_t n_owned, cap_owned;       /* CIGARs of transferred alignments, freed with the read */
 } prelim;
 
 #define NOT_SAVED 0xFFFFFFFFu
 
 static void prelim_reset(prelim* p, size_t n_records) {
+    for (size_t i = 0; i < p->n_owned; i++) free(p->owned[i]);
+    p->n_owned = 0;
     p->n_alns = 0; p->n_pos = 0;
     size_t need = 16;
     while (need < 2 * n_records + 2) need <<= 1;
@@ -664,6 +669,7 @@ static int score_record(load_ctx* c, const lcty_aln_rec* rec, const uint32_t* ci
     out->ln_prob = lp[0] * (double)matches + lp[1] * (double)mism + lp[2] * (double)ins
                    + lp[3] * (double)del + lp[4] * (double)clip;
     out->start = start; out->end = end;
+    out->own_cigar = NULL; out->own_n = 0;
     out->contig = rec->contig;
     out->read_end = read_end;
     out->reverse = (rec->flags & LCTY_FLAG_REVERSE) != 0;
@@ -969,7 +975,96 @@ static void identify_single_end(const orc_locus* l, prelim* p, size_t max_alns, 
     *unmapped_out = weight * l->prm.unmapped_penalty;
 }
 
-orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) {
+/* PosCollection::get — locs.rs:245-262 (the neighbour test as written: a hit when the stored start is 64 or more away) */
+static int pos_get(const prelim* p, int read_end, uint32_t contig, uint32_t pos, uint32_t* index) {
+    const uint64_t key = ((uint64_t)(read_end + 1) << 48) | ((uint64_t)contig << 32) | (uint64_t)(pos >> 7);
+    for (int pass = 0; pass < 2; pass++) {
+        const uint64_t kk = pass == 0 ? key : (uint64_t)((int64_t)key + ((pos & 64u) == 0 ? -1 : 1));
+        size_t h = (size_t)mix64(kk) & (p->hcap - 1);
+        while (p->hgen[h] == p->gen) {
+            const pos_entry* e = &p->pos[p->hslot[h]];
+            if (e->key == kk) {
+                if (pass == 0) { *index = e->index; return 1; }
+                const uint32_t d = e->pos > pos ? e->pos - pos : pos - e->pos;
+                if ((d >> 6) != 0) { *index = e->index; return 1; }
+                return 0;
+            }
+            h = (h + 1) & (p->hcap - 1);
+        }
+    }
+    return 0;
+}
+
+static void revcomp(const uint8_t* in, uint32_t n, uint8_t* out) {
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t c = in[n - 1 - i];
+        out[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+    }
+}
+
+/* HapAlns::transfer_alignments — seq/transfer.rs:70-140. Returns the number of new alignments. */
+static size_t transfer_alignments(load_ctx* c, const orc_hap_alns* hap, prelim* p, uint64_t pair, const uint8_t* const mate_seq[2],
+                                  const uint8_t* const mate_rc[2], const int mate_rev[2]) {
+    const orc_locus* l = c->l;
+    const lcty_reads_host* in = c->in;
+    const size_t n = p->n_alns;
+    uint8_t* seen = (uint8_t*)calloc(n ? n : 1, 1);
+    orc_cigar src, out; orc_cigar_init(&src); orc_cigar_init(&out);
+    const uint32_t* cig_base = in->cigar + in->cigar_off[pair];
+    const lcty_aln_rec* recs = in->recs + in->aln_off[pair];
+    for (size_t i = 0; i < n; i++) {
+        if (seen[i]) continue;
+        seen[i] = 1;
+        const o_aln sa = p->alns[i];                                     /* copied before the vector may change */
+        if (sa.own_cigar) orc_cigar_from_raw(&src, sa.own_cigar, sa.own_n, 0);
+        else orc_cigar_from_raw(&src, cig_base + recs[sa.rec_ix].cigar_rel, recs[sa.rec_ix].n_cigar, 1);
+        const int e = sa.read_end;
+        const uint32_t read_len = in->mate_len[2 * pair + e];
+        const uint8_t* read_seq = (sa.reverse != 0) == (mate_rev[e] != 0) ? mate_seq[e] : mate_rc[e];     /* MateData::get_seq */
+        const uint32_t passable = p->passable_dist[e];
+        uint32_t fails_left = orc_hap_alns_transfer_fails(hap);
+        const uint32_t nb = orc_hap_alns_n_best(hap, sa.contig);
+        for (uint32_t t = 0; t < nb; t++) {
+            const uint32_t target = orc_hap_alns_best(hap, sa.contig, t);
+            const uint32_t approx = orc_hap_alns_approx_pos(hap, sa.contig, target, sa.start);
+            uint32_t ix;
+            if (pos_get(p, e, target, approx, &ix)) {                     /* a similar position is already there */
+                if (ix < n) seen[ix] = 1;
+                continue;
+            }
+            const uint32_t tlen = l->infos[target].len;
+            const uint32_t new_start = orc_hap_alns_transfer(hap, sa.contig, target, sa.start, &src, read_seq, read_len, l->seqs[target], tlen, &out);
+            const uint32_t ref_len = out.rlen, qlen = out.qlen;
+            const uint32_t diff = ref_len > qlen ? ref_len - qlen : qlen - ref_len;
+            if (diff > passable || ref_len < 50) {                        /* MIN_ALN_SIZE */
+                if (fails_left == 0) break;
+                fails_left--;
+                continue;
+            }
+            /* Alignment::new + PrelimAlignments::push */
+            uint32_t* raw = (uint32_t*)malloc(sizeof(uint32_t) * (out.n ? out.n : 1));
+            orc_cigar_to_raw(&out, raw);
+            if (p->n_owned == p->cap_owned) { p->cap_owned = p->cap_owned ? 2 * p->cap_owned : 16; p->owned = (uint32_t**)realloc(p->owned, sizeof(uint32_t*) * p->cap_owned); }
+            p->owned[p->n_owned++] = raw;
+            lcty_aln_rec fake; memset(&fake, 0, sizeof(fake));
+            fake.pos = new_start; fake.contig = (uint16_t)target; fake.flags = (uint16_t)(LCTY_FLAG_SECONDARY | (sa.reverse ? LCTY_FLAG_REVERSE : 0));
+            fake.n_cigar = out.n;
+            o_aln na; int empty;
+            if (!score_record(c, &fake, raw, 0, (uint8_t)e, &na, &empty) || empty) continue;
+            na.rec_ix = 0xFFFFFFFFu; na.own_cigar = raw; na.own_n = out.n;
+            prelim_push(p, &na);
+        }
+    }
+    orc_cigar_free(&src); orc_cigar_free(&out);
+    free(seen);
+    return p->n_alns - n;
+}
+
+static orc_alns* load_impl(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, int* err);
+orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) { return load_impl(l, in, NULL, err); }
+orc_alns* orc_load_recover(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, int* err) { return load_impl(l, in, hap, err); }
+
+static orc_alns* load_impl(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, int* err) {
     orc_alns* A = (orc_alns*)calloc(1, sizeof(orc_alns));
     uint64_t R = in->n_pairs;
     A->n_pairs = R; A->n_alleles = l->n_alleles;
@@ -990,13 +1085,15 @@ orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) {
     uint32_t max_len = 1;
     for (uint64_t m = 0; m < 2 * R; m++) max_len = MAX(max_len, in->mate_len[m]);
     uint8_t* seqbuf = (uint8_t*)malloc(max_len);
+    uint8_t* mate_buf[4];
+    for (int t = 0; t < 4; t++) mate_buf[t] = (uint8_t*)malloc(max_len);
     orc_u128* kbuf = (orc_u128*)malloc(sizeof(orc_u128) * ((size_t)max_len + 1));
 
     for (uint64_t r = 0; r < R && !c.err; r++) {
         A->pa_off[r] = pv.n;
         uint64_t ri = in->aln_off[r], r_end = in->aln_off[r + 1];
         double weight = 1.0;
-        prelim_reset(&p, (size_t)(r_end - ri));
+        prelim_reset(&p, (size_t)(r_end - ri) + (hap ? (size_t)(r_end - ri) * l->n_alleles + l->n_alleles : 0));
         int well_mapped = read_next_alns(&c, r, &ri, r_end, 0, &weight, &p);    /* locs.rs:1119 */
         if (c.err) break;
         if (is_paired && well_mapped)
@@ -1025,7 +1122,26 @@ orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) {
         double w = l->weight_interc + (double)paired_count * l->weight_mult;
         w = w < 0.0 ? 0.0 : (w > 1.0 ? 1.0 : w);
         weight *= w;
-        /* recover_and_group_alignments — locs.rs:1255-1286 (no hap_alns) */
+        /* recover_and_group_alignments — locs.rs:1255-1286 */
+        if (hap && weight >= l->prm.min_weight) {                        /* locs.rs:1257-1260 */
+            const uint8_t* ms[2] = {NULL, NULL}; const uint8_t* mr[2] = {NULL, NULL};
+            int mrev[2] = {0, 0};
+            for (int e = 0; e < (is_paired ? 2 : 1); e++) {
+                const uint32_t len = in->mate_len[2 * r + e];
+                unpack_mate(in, 2 * r + e, mate_buf[e]);
+                revcomp(mate_buf[e], len, mate_buf[2 + e]);
+                ms[e] = mate_buf[e]; mr[e] = mate_buf[2 + e];
+            }
+            /* strand of the mate's primary record (MateData::new) */
+            {
+                uint64_t q = in->aln_off[r];
+                mrev[0] = (in->recs[q].flags & LCTY_FLAG_REVERSE) != 0;
+                for (q = q + 1; q < in->aln_off[r + 1]; q++)
+                    if (!(in->recs[q].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL))) { mrev[1] = (in->recs[q].flags & LCTY_FLAG_REVERSE) != 0; break; }
+            }
+            transfer_alignments(&c, hap, &p, r, ms, mr, mrev);
+            if (c.err) break;
+        }
         if (!(p.best_edit[0] <= p.good_dist[0] && p.best_edit[1] <= p.good_dist[1])) {
             /* the read is dropped entirely; its MateData is unobservable -> reported as 0 */
             A->uniq_kmers[2 * r] = A->uniq_kmers[2 * r + 1] = 0;
@@ -1040,6 +1156,9 @@ orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) {
         if (gw >= l->prm.min_weight) { A->status[r] = LCTY_READ_GOOD; A->n_good++; }
         else A->status[r] = LCTY_READ_FEW_KMERS;
     }
+    for (size_t i = 0; i < p.n_owned; i++) free(p.owned[i]);
+    free(p.owned);
+    for (int t = 0; t < 4; t++) free(mate_buf[t]);
     free(seqbuf); free(kbuf); free(p.alns); free(p.pos); free(p.hslot); free(p.hgen); free(pv.tmp); free(pv.buffer); free(kv.kept);
     if (c.err) {
         if (err) *err = c.err;
@@ -1050,6 +1169,19 @@ orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) {
     A->pa = pv.v; A->n_pa = pv.n;
     if (err) *err = 0;
     return A;
+}
+
+/* test hook: one Cigar::transfer_read_alignment behind HapAlns */
+uint32_t orc_transfer_one(const orc_hap_alns* h, uint32_t source, uint32_t target, uint32_t source_start, const uint32_t* read_cigar,
+                          uint32_t n_read_cigar, const uint8_t* read_seq, uint32_t read_len, const uint8_t* target_seq,
+                          uint32_t target_len, uint32_t* out_cigar, uint32_t out_cap, uint32_t* n_out) {
+    orc_cigar src, out; orc_cigar_init(&src); orc_cigar_init(&out);
+    orc_cigar_from_raw(&src, read_cigar, n_read_cigar, 1);
+    const uint32_t st = orc_hap_alns_transfer(h, source, target, source_start, &src, read_seq, read_len, target_seq, target_len, &out);
+    *n_out = out.n;
+    if (out.n <= out_cap) orc_cigar_to_raw(&out, out_cigar);
+    orc_cigar_free(&src); orc_cigar_free(&out);
+    return st;
 }
 
 /* Test hook: an orc_alns assembled from arrays (e.g. the products of the GPU scoring kernel), so that the solver

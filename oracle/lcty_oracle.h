@@ -176,6 +176,26 @@ void     orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* 
 uint64_t orc_assignment_counts(const orc_locus* l, const orc_alns* a, const uint16_t* ids, uint32_t ploidy, const lcty_solver* s,
                                uint32_t attempts, const uint64_t* chain_seeds, uint64_t* read_ixs_out, uint16_t* counts_out);
 
+/* ---- alignment recovery (lcty_oracle_transfer.c). Haplotype-to-haplotype alignments as HapAlns::add
+ * takes them (transfer.rs:41-62): id1 = query contig, id2 = target contig, a full forward alignment as raw BAM CIGAR words
+ * (=, X, I, D), its number of matches and its length (paf.rs:191-208). transfer_fails / max_div: genotype.rs defaults. */
+typedef struct orc_hap_alns orc_hap_alns;
+orc_hap_alns* orc_hap_alns_new(uint32_t n_contigs, uint32_t transfer_fails, double max_div);
+void orc_hap_alns_free(orc_hap_alns* h);
+void orc_hap_alns_add(orc_hap_alns* h, uint32_t id1, uint32_t id2, const uint32_t* cigar, uint32_t n_cigar, uint32_t n_matches,
+                      uint32_t aln_len);
+void orc_hap_alns_sort(orc_hap_alns* h);
+/* AllAlignments::load with alignment recovery (locs.rs:1237-1288 with opt_hap_alns = Some) */
+orc_alns* orc_load_recover(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, int* err);
+/* test hook: one transfer (Cigar::transfer_read_alignment behind HapAlns): returns the new start, writes raw CIGAR words */
+uint32_t orc_transfer_one(const orc_hap_alns* h, uint32_t source, uint32_t target, uint32_t source_start, const uint32_t* read_cigar,
+                          uint32_t n_read_cigar, const uint8_t* read_seq, uint32_t read_len, const uint8_t* target_seq,
+                          uint32_t target_len, uint32_t* out_cigar, uint32_t out_cap, uint32_t* n_out);
+
+void orc_transfer_set_optimize(int on);     /* test switch, see lcty_oracle_transfer.c */
+int orc_dp_align(const uint8_t* s1, uint32_t n, const uint8_t* s2, uint32_t m, int match_bonus, int mode, uint32_t* out_cigar, uint32_t out_cap,
+                 uint32_t* n_out);
+
 /* compare_two_likelihoods (solve.rs:319-336) */
 double   orc_compare_two_likelihoods(double mean1, double var1, uint32_t att1, double mean2, double var2, uint32_t att2);
 /* discard_improbable_genotypes (solve.rs:425-480): ixs in/out, returns the new count */

@@ -38,6 +38,27 @@ struct orc_locus {
     double* win_weight_inj; uint64_t* ci_off_inj;   /* test hook: injected per-position window weights */
 };
 
+/* ---- alignment recovery (lcty_oracle_transfer.c) ---- */
+typedef struct { uint32_t op, len; } orc_citem;                    /* CigarItem, BAM operation codes */
+typedef struct { orc_citem* t; uint32_t n, cap, rlen, qlen; } orc_cigar;   /* Cigar — cigar.rs:203-208 */
+void orc_cigar_init(orc_cigar* c);
+void orc_cigar_free(orc_cigar* c);
+void orc_cigar_clear(orc_cigar* c);
+void orc_cigar_push_unchecked(orc_cigar* c, uint32_t op, uint32_t len);
+void orc_cigar_push_checked(orc_cigar* c, uint32_t op, uint32_t len);
+void orc_cigar_copy(orc_cigar* dst, const orc_cigar* src);
+void orc_cigar_from_raw(orc_cigar* c, const uint32_t* raw, uint32_t n, int hard_to_soft);
+uint32_t orc_cigar_to_raw(const orc_cigar* c, uint32_t* out);
+uint32_t orc_transfer_read_alignment(const orc_cigar* cigar_jk, int dir_jk, uint32_t start_j, uint32_t off_cigar_ix, uint32_t off_qpos,
+                                     uint32_t off_rpos, const orc_cigar* cigar_ij, const uint8_t* seq_i, uint32_t len_i,
+                                     const uint8_t* seq_k, uint32_t len_k, orc_cigar* out);
+uint32_t orc_hap_alns_n_best(const orc_hap_alns* h, uint32_t contig);
+uint32_t orc_hap_alns_best(const orc_hap_alns* h, uint32_t contig, uint32_t i);
+uint32_t orc_hap_alns_transfer_fails(const orc_hap_alns* h);
+uint32_t orc_hap_alns_approx_pos(const orc_hap_alns* h, uint32_t source, uint32_t target, uint32_t source_start);
+uint32_t orc_hap_alns_transfer(const orc_hap_alns* h, uint32_t source, uint32_t target, uint32_t source_start, const orc_cigar* source_cigar,
+                               const uint8_t* read_seq, uint32_t read_len, const uint8_t* target_seq, uint32_t target_len, orc_cigar* out);
+
 struct orc_alns {
     uint64_t n_pairs, n_good;
     uint32_t n_alleles;

@@ -107,6 +107,14 @@ def lib():
     sig("orc_assignment_likelihood", D, VP, VP, VP)
     sig("orc_solve_stage", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP)
     sig("orc_call_checks", None, VP, U64, U32, VP, U32, VP, U32, VP, C.POINTER(D), C.POINTER(U32))
+    sig("orc_hap_alns_new", VP, U32, U32, D)
+    sig("orc_hap_alns_free", None, VP)
+    sig("orc_hap_alns_add", None, VP, U32, U32, VP, U32, U32, U32)
+    sig("orc_hap_alns_sort", None, VP)
+    sig("orc_load_recover", VP, VP, C.POINTER(ReadsHost), VP, C.POINTER(C.c_int))
+    sig("orc_transfer_one", U32, VP, U32, U32, U32, VP, U32, VP, U32, VP, U32, VP, U32, C.POINTER(U32))
+    sig("orc_transfer_set_optimize", None, C.c_int)
+    sig("orc_dp_align", C.c_int, VP, U32, VP, U32, C.c_int, C.c_int, VP, U32, C.POINTER(U32))
     sig("orc_assignment_counts", U64, VP, VP, VP, U32, C.POINTER(Solver), U32, VP, VP, VP)
     sig("orc_compare_two_likelihoods", D, D, D, U32, D, D, U32)
     sig("orc_discard_improbable", U64, VP, VP, VP, VP, U64, D, U64, U64)
@@ -201,6 +209,74 @@ class OracleLocus:
         if not h:
             raise ValueError(f"orc_load failed: {err.value}")
         return OracleAlns(h, self.n_alleles)
+
+    def load_recover(self, chunk, hap):
+        """AllAlignments::load with alignment recovery (opt_hap_alns = Some)."""
+        err = C.c_int(0)
+        hs = chunk.host_struct()
+        h = lib().orc_load_recover(self._h, C.byref(hs), hap._h, C.byref(err))
+        if not h:
+            raise ValueError(f"orc_load_recover failed: {err.value}")
+        return OracleAlns(h, self.n_alleles)
+
+
+OPC = {"M": 0, "I": 1, "D": 2, "S": 4, "H": 5, "=": 7, "X": 8}
+OPS = {v: k for k, v in OPC.items()}
+
+
+def cigar_words(s):
+    """'10=1X3I' -> raw BAM words"""
+    out, num = [], ""
+    for ch in s:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((int(num) << 4) | OPC[ch]); num = ""
+    return np.array(out, dtype=np.uint32)
+
+
+def cigar_str(words):
+    return "".join(f"{int(w) >> 4}{OPS[int(w) & 15]}" for w in words)
+
+
+def dp_align(s1, s2, match_bonus=0, mode=0):
+    """The oracle's aligner on its own (reference s1, query s2): (penalty, cigar string)."""
+    a = np.frombuffer(s1, dtype=np.uint8); b = np.frombuffer(s2, dtype=np.uint8)
+    out = np.zeros(len(a) + len(b) + 2, dtype=np.uint32)
+    n = U32()
+    pen = lib().orc_dp_align(a.ctypes.data, len(a), b.ctypes.data, len(b), match_bonus, mode, out.ctypes.data, len(out), C.byref(n))
+    return pen, cigar_str(out[:n.value])
+
+
+class HapAlns:
+    """HapAlns (seq/transfer.rs:21-67) from pairwise alignments of the alleles."""
+
+    def __init__(self, n_contigs, transfer_fails=3, max_div=0.05):
+        self._h = lib().orc_hap_alns_new(n_contigs, transfer_fails, max_div)
+        self.entries = []
+
+    def add(self, id1, id2, cigar):
+        w = cigar_words(cigar) if isinstance(cigar, str) else np.ascontiguousarray(cigar, dtype=np.uint32)
+        nm = int(sum(int(x) >> 4 for x in w if int(x) & 15 == 7))
+        ln = int(sum(int(x) >> 4 for x in w))
+        lib().orc_hap_alns_add(self._h, id1, id2, w.ctypes.data, len(w), nm, ln)
+        self.entries.append((id1, id2, w, nm, ln))
+
+    def sort(self):
+        lib().orc_hap_alns_sort(self._h)
+
+    def transfer_one(self, source, target, start, read_cigar, read_seq, target_seq):
+        rc = cigar_words(read_cigar)
+        rs = np.frombuffer(read_seq, dtype=np.uint8); ts = np.frombuffer(target_seq, dtype=np.uint8)
+        out = np.zeros(2 * len(rs) + 16, dtype=np.uint32)
+        n = U32()
+        st = lib().orc_transfer_one(self._h, source, target, start, rc.ctypes.data, len(rc), rs.ctypes.data, len(rs), ts.ctypes.data, len(ts),
+                                    out.ctypes.data, len(out), C.byref(n))
+        return int(st), cigar_str(out[:n.value])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_hap_alns_free(self._h); self._h = None
 
 
 class OracleAlns:
