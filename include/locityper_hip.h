@@ -276,6 +276,24 @@ int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double fi
 uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy);
 int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* out, uint64_t cap);
 
+/* ---- alignment recovery (AllAlignments::load with opt_hap_alns = Some; src/seq/transfer.rs, src/seq/cigar.rs:1085-1384,
+ * src/seq/wfa.rs) ------------------------------------------------------------------------------------------------------
+ * lcty_locus_set_hap_alns: the pairwise haplotype alignments of `haplotypes.paf` as HapAlns::add takes them (transfer.rs:41-62):
+ * entry t aligns contig id1[t] (query) to contig id2[t] (target) over their full lengths on the forward strand
+ * (PafEntry::full_positive_alignment), CIGAR = raw BAM words cigar[cigar_off[t] .. cigar_off[t+1]) with =, X, I, D;
+ * n_matches / aln_len as in the PAF columns (divergence filter: (aln_len - n_matches) / aln_len <= max_div, paf.rs:201-208).
+ * The first entry of a pair of contigs wins; targets of a contig are tried in order of decreasing n_matches.
+ * lcty_recover_alignments: transfer_alignments (transfer.rs:70-140) for every read pair of the batch that reaches
+ * recover_and_group_alignments with weight >= min_weight (locs.rs:1255-1260). Call order:
+ *     lcty_score_reads -> lcty_recover_alignments -> lcty_score_reads.
+ * Transferred alignments become records of the batch (after the original records of their read end); nothing can be appended
+ * to the batch afterwards. The aligner is an exact gap-affine dynamic programme (WFA2-lib computes the same optimum); the
+ * device handles stretches between anchors of up to 255 bases, i.e. short reads, and fails with LCTY_ERR_UNSUPPORTED beyond. */
+int32_t lcty_locus_set_hap_alns(lcty_locus* locus, uint32_t n_entries, const uint32_t* id1, const uint32_t* id2, const uint64_t* cigar_off,
+                                const uint32_t* cigar, const uint32_t* n_matches, const uint32_t* aln_len, uint32_t transfer_fails,
+                                double max_div);
+int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered);
+
 /* ---- solver stages (src/solvers/solve.rs:789-850, src/solvers/stoch.rs, src/model/assgn.rs) ----------------
  * The reference drives these stages from one Xoshiro256++ through rand ^0.10 adaptors that are not in its tree and
  * whose results already depend on --threads (solve.rs:1017, 1051). Here every (genotype, attempt) chain gets its
@@ -355,7 +373,8 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
 #define LCTY_K_SOLVE     2   /* solve_loop_kernel: the Greedy / SimAnneal chains */
 #define LCTY_K_SOLVE_INIT  3 /* solve_init_kernel: apply_tweak + ReadAssignment::try_new of every chain */
 #define LCTY_K_SOLVE_TABLE 4 /* build_loc_table_kernel: allele-major location table of a scored batch */
-#define LCTY_K_COUNT     5
+#define LCTY_K_TRANSFER  5   /* transfer_kernel: alignment recovery */
+#define LCTY_K_COUNT     6
 int32_t lcty_timing_reset(lcty_ctx* ctx);
 int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms);
 

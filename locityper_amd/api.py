@@ -86,6 +86,19 @@ class Locus:
         except Exception:
             pass
 
+    def set_hap_alns(self, entries, transfer_fails=3, max_div=0.05):
+        """HapAlns (seq/transfer.rs:21-67): entries = [(id1 query, id2 target, raw CIGAR words, n_matches, aln_len)]."""
+        n = len(entries)
+        id1 = np.array([e[0] for e in entries], dtype=np.uint32)
+        id2 = np.array([e[1] for e in entries], dtype=np.uint32)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(e[2]) for e in entries], out=off[1:])
+        words = np.concatenate([np.asarray(e[2], dtype=np.uint32) for e in entries]) if n else np.zeros(1, dtype=np.uint32)
+        nm = np.array([e[3] for e in entries], dtype=np.uint32)
+        ln = np.array([e[4] for e in entries], dtype=np.uint32)
+        check(lib().lcty_locus_set_hap_alns(self._h, n, id1.ctypes.data, id2.ctypes.data, off.ctypes.data, words.ctypes.data, nm.ctypes.data,
+                                            ln.ctypes.data, transfer_fails, max_div))
+
     def n_unique_kmers(self):
         n = U64()
         check(lib().lcty_locus_n_unique_kmers(self._h, C.byref(n)))
@@ -156,6 +169,13 @@ class AllAlignments:
     def score(self):
         check(lib().lcty_score_reads(self._h))
         self._scored = True
+
+    def recover(self):
+        """Alignment recovery (transfer.rs:70-140) between two scoring passes; returns the number of transferred alignments."""
+        n = U64()
+        check(lib().lcty_recover_alignments(self._h, C.byref(n)))
+        self.score()
+        return int(n.value)
 
     def close(self):
         if self._h:

@@ -273,7 +273,9 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
         L->compl_mult = 1.0 / static_cast<double>(std::min<uint64_t>(neighb + 1 - ck, 1ull << (2 * ck)));
 
         hipStream_t s = ctx->stream;
-        DevBuf<uint8_t> d_seqs; DevBuf<uint64_t> d_seq_off, d_cnt_off; DevBuf<uint16_t> d_counts;
+        DevBuf<uint8_t>& d_seqs = L->d_seqs;                              // stay resident: alignment recovery reads them
+        DevBuf<uint64_t>& d_seq_off = L->d_seq_off;
+        DevBuf<uint64_t> d_cnt_off; DevBuf<uint16_t> d_counts;
         const uint64_t total_seq = seq_off[n_alleles], total_cnt = cnt_off[n_alleles];
         d_seqs.alloc(total_seq); d_seqs.upload(seqs, total_seq, s);
         d_seq_off.alloc(n_alleles + 1); d_seq_off.upload(seq_off, n_alleles + 1, s);

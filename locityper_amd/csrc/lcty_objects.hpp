@@ -45,6 +45,13 @@ struct lcty_locus {
     lcty::DevBuf<lcty::DepthNB> d_depth_nb;  // [101]
     lcty::DevBuf<uint32_t> d_n_windows, d_reg_start;   // [A]
     lcty::DevBuf<double> d_win_weight;       // per position: ContigInfo::neighb_info weight (windows.rs:439-445)
+    // alignment recovery (lcty_transfer.hip): allele sequences stay resident, haplotype-to-haplotype alignments + indices
+    lcty::DevBuf<uint8_t> d_seqs;
+    lcty::DevBuf<uint64_t> d_seq_off;
+    lcty::DevBuf<uint32_t> d_hap_cell_of, d_hap_item_off, d_hap_sparse_off, d_hap_best_off, d_hap_best_ids, d_hap_len;
+    lcty::DevBuf<uint2> d_hap_items, d_hap_positions, d_hap_sparse;
+    uint32_t hap_transfer_fails = 0, hap_cells = 0;
+    bool has_hap_alns = false;
     lcty::DevBuf<double> d_lut_ext;          // [101][lut_ext_depth] depth table of the solver stages (lcty_solve.hip)
     uint32_t lut_ext_depth = 0;
     uint32_t max_n_windows = 0;
@@ -93,6 +100,7 @@ struct lcty_reads {
     bool loc_table_valid = false;
     uint64_t stat_chains = 0, stat_iterations = 0, stat_accepted = 0;   // last lcty_solve_stage
     lcty::DevBuf<uint32_t> d_err;
+    lcty::DevBuf<double> d_recover_w;        // per pair: read weight when the pair reaches recover_and_group_alignments, else -1
 
     // prefilter products
     lcty::DevBuf<double> d_scores;           // [G]

@@ -60,6 +60,7 @@ ReadsView lcty_reads::view() const {
     v.matrix = d_matrix.p;
     v.pa = d_pa.p; v.pa_cap = d_pa.n; v.pa_count = d_pa_count.p; v.pa_off = d_pa_off.p; v.pa_cnt = d_pa_cnt.p; v.pa_idx = d_pa_idx.p;
     v.err_flag = d_err.p;
+    v.recover_w = d_recover_w.p;
     return v;
 }
 
@@ -129,6 +130,7 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
         R->d_pa_idx.alloc(std::max<uint64_t>(cap_pairs * A, 1));
         R->d_err.alloc(1);
         R->d_err.zero(ctx->stream);
+        R->d_recover_w.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_pa_count.zero(ctx->stream);
         const uint64_t zero = 0;
         R->d_mate_off.upload(&zero, 1, ctx->stream);

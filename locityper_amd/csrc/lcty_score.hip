@@ -673,6 +673,7 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
         double unmapped_prob = 0.0;
         uint64_t pa_base = 0;
 
+        if (!accepted && lane == 0) R.recover_w[p] = -1.0;
         if (accepted) {
             // ---------------- K2: unique k-mers -> read weight (locs.rs:968-1002) ----------------
             // (evaluated after the in-bounds test in the reference; no side effects, order irrelevant)
@@ -740,6 +741,7 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
             }
             const bool any_inb = __ballot(inb) != 0ull;
             total_cnt = wave_sum_u32(total_cnt);
+            if (lane == 0) R.recover_w[p] = any_inb ? weight : -1.0;                         // alignment recovery looks at these pairs
             const bool edit_good = be0 <= thr0 && (!paired || be1 <= thr1);                   // best_edit_is_good, locs.rs:293-295
             if (!any_inb) { status = LCTY_READ_OUT_OF_BOUNDS; accepted = false; }
             else if (!edit_good) { status = LCTY_READ_POORLY_MAPPED; accepted = false; }

@@ -1,0 +1,621 @@
+// lcty_transfer.hip — alignment recovery of AllAlignments::load (K6):
+//   HapAlns::{add, sort_best_ixs, transfer_alignments}   src/seq/transfer.rs:21-140
+//   CigarIndex                                            src/seq/cigar.rs:1085-1162
+//   Cigar::transfer_read_alignment + the aligner           lcty_transfer_device.hpp
+//
+// Recovery runs between two scoring passes. The first pass tells which read pairs reach recover_and_group_alignments
+// (locs.rs:1255-1260: well mapped, in bounds, weight >= min_weight). For those, `transfer_kernel` (one wavefront per read
+// pair) rebuilds the PrelimAlignments of the pair (push order, 128-bp position set, thresholds: locs.rs:298-344, 502-567),
+// walks its alignments in order as the reference does, and gives every (alignment, target haplotype) transfer of a source
+// to its own lane. Transferred alignments are appended to the batch's record table — after the original records of their
+// read end, which is the order PrelimAlignments::push sees them in within an end — and the second scoring pass treats them
+// like any other record.
+#include <algorithm>
+#include <memory>
+#include <numeric>
+
+#include "lcty_objects.hpp"
+#include "lcty_transfer_device.hpp"
+
+namespace lcty {
+
+using namespace xfer;
+
+constexpr uint32_t NONE32T = 0xFFFFFFFFu;
+
+struct HapView {
+    uint32_t A, transfer_fails;
+    const uint32_t* cell_of;       // [A * A] at (min, max): cell index or NONE
+    const uint32_t* item_off;      // [cells + 1]
+    const uint2* items;            // {op, len}, query = lower contig id
+    const uint2* positions;        // {qpos, rpos} at the start of every item
+    const uint32_t* sparse_off;    // [2 * cells + 1]: direction 0 (query -> ref) then 1 of every cell
+    const uint2* sparse;           // {cigar_ix, pos}
+    const uint32_t* best_off;      // [A + 1]
+    const uint32_t* best_ids;
+    const uint8_t* seqs; const uint64_t* seq_off;
+};
+
+// one scored alignment of the pair (Alignment + what push needs)
+struct PAln {
+    double ln_prob;
+    uint32_t start, contig_end;    // contig | read end << 16 | reverse << 17
+    uint32_t edit, src;            // src: record index, or 0x80000000 | index of a transferred alignment
+};
+struct NewAln {                    // a transferred alignment, in push order
+    double ln_prob;
+    uint32_t start, contig_end, edit, n_cigar, cigar_at;     // cigar_at: word offset in the pair's new-CIGAR block
+    uint32_t pushed;
+};
+
+struct PairScratch {
+    PAln* alns; uint32_t cap_alns;
+    uint64_t* hkey; uint2* hval; uint32_t hcap;         // position set: key -> {index, pos}; key 0 = free (real keys have bits 48+ set)
+    uint8_t* seen;
+    NewAln* news; uint32_t cap_new;
+    uint32_t* words; uint32_t cap_words;
+    uint8_t* lanes;                                      // 64 x SCRATCH_BYTES
+};
+
+__host__ __device__ inline size_t pair_scratch_bytes(uint32_t cap_alns, uint32_t hcap, uint32_t cap_new, uint32_t cap_words) {
+    size_t b = 0;
+    b += sizeof(PAln) * cap_alns; b = (b + 15) & ~size_t(15);
+    b += 8 * hcap + 8 * hcap;
+    b += (cap_alns + 15) & ~15u;
+    b += sizeof(NewAln) * cap_new; b = (b + 15) & ~size_t(15);
+    b += 4 * static_cast<size_t>(cap_words); b = (b + 15) & ~size_t(15);
+    b += 64 * ((SCRATCH_BYTES + 15) & ~size_t(15));
+    return (b + 255) & ~size_t(255);
+}
+
+__device__ inline PairScratch carve(uint8_t* base, uint32_t cap_alns, uint32_t hcap, uint32_t cap_new, uint32_t cap_words) {
+    PairScratch s;
+    size_t b = 0;
+    s.alns = reinterpret_cast<PAln*>(base); s.cap_alns = cap_alns; b += sizeof(PAln) * cap_alns; b = (b + 15) & ~size_t(15);
+    s.hkey = reinterpret_cast<uint64_t*>(base + b); b += 8 * hcap;
+    s.hval = reinterpret_cast<uint2*>(base + b); b += 8 * hcap; s.hcap = hcap;
+    s.seen = base + b; b += (cap_alns + 15) & ~15u;
+    s.news = reinterpret_cast<NewAln*>(base + b); s.cap_new = cap_new; b += sizeof(NewAln) * cap_new; b = (b + 15) & ~size_t(15);
+    s.words = reinterpret_cast<uint32_t*>(base + b); s.cap_words = cap_words; b += 4 * static_cast<size_t>(cap_words); b = (b + 15) & ~size_t(15);
+    s.lanes = base + b;
+    return s;
+}
+
+// count_region_operations_fast (aln.rs:288-317) + ErrorProfile::ln_prob (err_prof.rs:212-221) of raw CIGAR words
+struct Scored { double ln_prob; uint32_t start, end, edit; bool bad; };
+__device__ inline Scored score_words(const LocusView& L, const uint32_t* raw, uint32_t n, uint32_t pos, uint32_t contig_len, bool primary) {
+    uint32_t matches = 0, mism = 0, ins = 0, del = 0, left = 0, right = 0;
+    bool bad = false;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t op = raw[i] & 15u;
+        const uint32_t len = raw[i] >> 4;
+        const bool edge = i == 0 || i + 1 == n;
+        if (op == OP_H) { if (edge && !primary) op = OP_S; else bad = true; }
+        if (op == OP_EQ) matches += len; else if (op == OP_X) mism += len; else if (op == OP_I) ins += len; else if (op == OP_D) del += len;
+        else if (op == OP_S) { if (i == 0) left = len; if (i + 1 == n) right = len; }
+        else bad = true;
+    }
+    Scored s;
+    const uint32_t ref_len = matches + mism + del;
+    s.start = pos; s.end = pos + ref_len;
+    const uint32_t clip = min(left, pos) + min(right, contig_len > s.end ? contig_len - s.end : 0u);
+    const uint32_t common = mism + ins + clip;
+    s.edit = common + del;
+    s.ln_prob = L.lp[0] * static_cast<double>(matches) + L.lp[1] * static_cast<double>(mism) + L.lp[2] * static_cast<double>(ins)
+              + L.lp[3] * static_cast<double>(del) + L.lp[4] * static_cast<double>(clip);
+    s.bad = bad;
+    return s;
+}
+
+__device__ __forceinline__ uint64_t pos_key(uint32_t read_end, uint32_t contig, uint32_t pos) {       // encode, locs.rs:181-184
+    return (static_cast<uint64_t>(read_end + 1) << 48) | (static_cast<uint64_t>(contig) << 32) | static_cast<uint64_t>(pos >> 7);
+}
+__device__ inline uint32_t hfind(const PairScratch& P, uint64_t key, bool* found) {
+    uint32_t h = static_cast<uint32_t>(mix64(key)) & (P.hcap - 1);
+    while (P.hkey[h] != 0) {
+        if (P.hkey[h] == key) { *found = true; return h; }
+        h = (h + 1) & (P.hcap - 1);
+    }
+    *found = false;
+    return h;
+}
+
+// PrelimAlignments state of the pair (single lane)
+struct Prelim {
+    uint32_t n_alns, passable[2], best_edit[2];
+    double best_lik[2];
+};
+constexpr uint32_t NOT_SAVED = 0xFFFFFFFFu;
+
+// PrelimAlignments::push (locs.rs:298-344)
+__device__ inline bool prelim_push(const PairScratch& P, Prelim& S, const PAln& a, uint32_t* err) {
+    const uint32_t e = (a.contig_end >> 16) & 1u, contig = a.contig_end & 0xFFFFu;
+    S.best_edit[e] = min(S.best_edit[e], a.edit);
+    S.best_lik[e] = fmax(S.best_lik[e], a.ln_prob);
+    const uint32_t new_ix = S.n_alns;
+    const bool save = a.edit <= S.passable[e];
+    if (new_ix == 0 && !save) return false;
+    bool found;
+    const uint32_t h = hfind(P, pos_key(e, contig, a.start), &found);
+    auto append = [&]() {
+        if (S.n_alns < P.cap_alns) P.alns[S.n_alns++] = a; else atomicMax(err, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
+    };
+    if (found) {
+        if (save) {
+            if (P.hval[h].x == NOT_SAVED) { P.hval[h] = make_uint2(new_ix, a.start); append(); }
+            else if (a.ln_prob > P.alns[P.hval[h].x].ln_prob) { P.alns[P.hval[h].x] = a; P.hval[h].y = a.start; }
+        }
+    } else {
+        P.hkey[h] = pos_key(e, contig, a.start);
+        if (save) { P.hval[h] = make_uint2(new_ix, a.start); append(); }
+        else P.hval[h] = make_uint2(NOT_SAVED, a.start);
+    }
+    return save;
+}
+
+// PosCollection::get (locs.rs:245-262), the neighbour test as written there
+__device__ inline bool pos_get(const PairScratch& P, uint32_t read_end, uint32_t contig, uint32_t pos, uint32_t* index) {
+    const uint64_t key = pos_key(read_end, contig, pos);
+    bool found;
+    uint32_t h = hfind(P, key, &found);
+    if (found) { *index = P.hval[h].x; return true; }
+    const uint64_t key2 = (pos & 64u) == 0 ? key - 1 : key + 1;
+    h = hfind(P, key2, &found);
+    if (found) {
+        const uint32_t sp = P.hval[h].y;
+        const uint32_t d = sp > pos ? sp - pos : pos - sp;
+        if ((d >> 6) != 0) { *index = P.hval[h].x; return true; }
+    }
+    return false;
+}
+
+struct TransferArgs {
+    uint32_t cap_alns, hcap, cap_new, cap_words;
+    uint8_t* scratch; size_t scratch_stride;
+    // outputs
+    uint32_t* new_cnt;             // [R][2] transferred alignments per read end
+    uint32_t* new_words;           // [R] CIGAR words of the pair's transferred alignments
+    unsigned long long* rec_cursor; unsigned long long* word_cursor;
+    lcty_aln_rec* out_recs; uint64_t out_recs_cap;      // arena: per pair contiguous, end 0 then end 1, push order inside
+    uint32_t* out_words; uint64_t out_words_cap;
+    uint64_t* out_rec_at; uint64_t* out_word_at;        // [R]
+    uint32_t* flag;                // 1 = arena overflow (retry larger), LCTY_ERR_* >= 2 otherwise
+    double min_weight;
+};
+
+__global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
+    const uint32_t lane = threadIdx.x;
+    uint8_t* base = T.scratch + static_cast<size_t>(blockIdx.x) * T.scratch_stride;
+    const PairScratch P = carve(base, T.cap_alns, T.hcap, T.cap_new, T.cap_words);
+    const Scratch LS = scratch_at(P.lanes + static_cast<size_t>(lane) * ((SCRATCH_BYTES + 15) & ~size_t(15)), T.flag);
+    const bool paired = L.is_paired != 0;
+    __shared__ Prelim S;
+    __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop;
+
+    for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
+        if (lane == 0) { T.new_cnt[2 * p] = T.new_cnt[2 * p + 1] = 0; T.new_words[p] = 0; }
+        if (!(R.recover_w[p] >= T.min_weight)) continue;                    // locs.rs:1257 (and not a candidate at all: -1)
+        const uint64_t a0 = R.aln_off[p];
+        const uint32_t* cig = R.cigar + R.cigar_off[p];
+        const uint2 meta = R.pair_meta[p];
+        const uint32_t j2 = meta.x, n_eff = meta.y, split = min(j2, n_eff);
+        const lcty_aln_rec* recs = R.recs + a0;
+        const uint32_t len0 = R.mate_len[2 * p], len1 = paired ? R.mate_len[2 * p + 1] : 0u;
+        for (uint32_t i = lane; i < P.hcap; i += 64) P.hkey[i] = 0;
+        for (uint32_t i = lane; i < P.cap_alns; i += 64) P.seen[i] = 0;
+        __syncthreads();
+
+        // ---- PrelimAlignments of the pair, as read_next_alns builds them (locs.rs:502-567), one lane: the order matters ----
+        if (lane == 0) {
+            S.n_alns = 0;
+            for (int e = 0; e < 2; e++) { S.passable[e] = NONE32T; S.best_edit[e] = NONE32T; S.best_lik[e] = -INFINITY; }
+            sh_n_new = 0; sh_words = 0;
+            for (uint32_t e = 0; e < (paired ? 2u : 1u); e++) {
+                const uint32_t first = e ? j2 : 0u, last = e ? n_eff : split;
+                const uint32_t read_len = e ? len1 : len0;
+                for (uint32_t idx = first; idx < last; idx++) {
+                    const lcty_aln_rec rc = recs[idx];
+                    const bool primary = idx == first;
+                    if (rc.n_cigar == 0) continue;                           // skipped with a warning, locs.rs:550-554
+                    const Scored sc = score_words(L, cig + rc.cigar_rel, rc.n_cigar, rc.pos, L.allele_len[rc.contig], primary);
+                    if (primary) {                                           // thresholds, locs.rs:529-537
+                        const uint2 gp = L.edit_lut[min(read_len, L.edit_lut_size - 1)];
+                        uint32_t good = gp.x, passable = gp.y, thr = good;
+                        double compl_v = 1.0;
+                        if (L.short_reads) {
+                            const uint32_t mid = (sc.start + sc.end) / 2;
+                            const uint32_t o = L.ci_off[rc.contig], npos = L.ci_off[rc.contig + 1] - o;
+                            const uint32_t i = min(mid > L.half_neighb ? mid - L.half_neighb : 0u, npos - 1);
+                            compl_v = static_cast<double>(L.compl_cnt[o + i]) * L.compl_mult;
+                        }
+                        if (compl_v <= L.poor_compl) {
+                            thr = max(good, static_cast<uint32_t>(L.poor_compl_edit * static_cast<double>(read_len)));
+                            passable += thr - good;
+                        }
+                        S.passable[e] = passable;
+                    }
+                    PAln a;
+                    a.ln_prob = sc.ln_prob; a.start = sc.start; a.edit = sc.edit; a.src = idx;
+                    a.contig_end = rc.contig | (e << 16) | ((rc.flags & LCTY_FLAG_REVERSE) ? (1u << 17) : 0u);
+                    prelim_push(P, S, a, T.flag);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n0 = S.n_alns;
+
+        // ---- HapAlns::transfer_alignments (transfer.rs:70-140): sources in order, targets of a source across lanes ----
+        for (uint32_t i = 0; i < n0; i++) {
+            if (P.seen[i]) continue;                                         // uniform: written before the barrier below
+            __syncthreads();
+            if (lane == 0) { P.seen[i] = 1; sh_fails = 0; sh_stop = 0; }
+            __syncthreads();
+            const PAln sa = P.alns[i];
+            const uint32_t s_contig = sa.contig_end & 0xFFFFu, e = (sa.contig_end >> 16) & 1u;
+            const bool s_rev = (sa.contig_end >> 17) & 1u;
+            SrcCigar src;
+            if (sa.src & 0x80000000u) { const NewAln na = P.news[sa.src & 0x7FFFFFFFu]; src.raw = P.words + na.cigar_at; src.n = na.n_cigar; src.hard_to_soft = false; }
+            else { src.raw = cig + recs[sa.src].cigar_rel; src.n = recs[sa.src].n_cigar; src.hard_to_soft = true; }
+            // the read in the orientation of the source alignment: the stored bases are the primary record's (MateData::new)
+            const uint32_t prim = e ? j2 : 0u;
+            const bool prim_rev = (recs[prim].flags & LCTY_FLAG_REVERSE) != 0;
+            const uint64_t moff = R.mate_off[2 * p + e];
+            Seqs Q;
+            Q.w64 = reinterpret_cast<const uint64_t*>(R.bases2) + (moff >> 5); Q.nm = R.nmask + (moff >> 5);
+            Q.read_len = e ? len1 : len0; Q.flip = s_rev != prim_rev;
+            const uint32_t passable = S.passable[e];
+            const uint32_t nb = H.best_off[s_contig + 1] - H.best_off[s_contig];
+            for (uint32_t t0 = 0; t0 < nb && !sh_stop; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                // 0 nothing, 1 similar position exists (index in `hit`), 2 failed transfer, 3 new alignment
+                uint32_t kind = 0, hit = NONE32T, target = 0;
+                PAln na; na.ln_prob = 0.0; na.start = 0; na.contig_end = 0; na.edit = 0; na.src = 0;
+                DCigar out; out.init(LS.cig_a);
+                if (t < nb) {
+                    target = H.best_ids[H.best_off[s_contig] + t];
+                    const uint32_t lo = min(s_contig, target), hi = max(s_contig, target);
+                    const uint32_t cell = H.cell_of[lo * H.A + hi];
+                    const int dir = s_contig < target ? 0 : 1;
+                    const uint2* sp = H.sparse + H.sparse_off[2 * cell + dir];
+                    // find_approx_position (cigar.rs:1128-1140)
+                    const uint32_t si = sa.start >> 8;
+                    const uint2 s1 = sp[si], s2 = sp[si + 1];
+                    const uint32_t approx = s1.y + (((sa.start & 255u) * (s2.y - s1.y)) >> 8);
+                    if (pos_get(P, e, target, approx, &hit)) kind = 1;
+                    else {
+                        // find_cigar_offset (cigar.rs:1143-1162)
+                        const uint2* pos = H.positions + H.item_off[cell];
+                        uint32_t ci;
+                        if (s1.x == s2.x) ci = s1.x;
+                        else {
+                            uint32_t l = s1.x, h = s2.x + 1;
+                            while (l < h) {
+                                const uint32_t mid = l + (h - l) / 2;
+                                const uint32_t qp = dir ? pos[mid].y : pos[mid].x;
+                                if (qp <= sa.start) l = mid + 1; else h = mid;
+                            }
+                            ci = l - 1;
+                        }
+                        const uint32_t qpos_at = dir ? pos[ci].y : pos[ci].x, rpos_at = dir ? pos[ci].x : pos[ci].y;
+                        Q.target = H.seqs + H.seq_off[target];
+                        Q.target_len = static_cast<uint32_t>(H.seq_off[target + 1] - H.seq_off[target]);
+                        const uint32_t new_start = transfer_read(H.items + H.item_off[cell], H.item_off[cell + 1] - H.item_off[cell], dir, sa.start, ci,
+                                                                 qpos_at, rpos_at, src, Q, out, LS);
+                        if (out.overflow) atomicMax(T.flag, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED));
+                        const uint32_t diff = out.rlen > out.qlen ? out.rlen - out.qlen : out.qlen - out.rlen;
+                        if (diff > passable || out.rlen < 50) kind = 2;    // MIN_ALN_SIZE
+                        else {
+                            kind = 3;
+                            // Alignment::new + the scoring of push(): the CIGAR goes through the same counting as a record's
+                            uint32_t* w = reinterpret_cast<uint32_t*>(LS.cig_b);
+                            for (uint32_t k = 0; k < out.n; k++) w[k] = (out.t[k].y << 4) | out.t[k].x;
+                            const Scored sc = score_words(L, w, out.n, new_start, Q.target_len, false);
+                            na.ln_prob = sc.ln_prob; na.start = new_start; na.edit = sc.edit;
+                            na.contig_end = target | (e << 16) | (s_rev ? (1u << 17) : 0u);
+                        }
+                    }
+                }
+                // the loop of transfer.rs:90-136 stops at the (transfer_fails + 1)-th failure: everything behind it did not happen
+                const unsigned long long fail_mask = __ballot(kind == 2);
+                const uint32_t fails_before = sh_fails + static_cast<uint32_t>(__popcll(fail_mask & ((1ull << lane) - 1ull)));
+                const bool alive = t < nb && fails_before <= H.transfer_fails;
+                if (alive && kind == 1 && hit < n0) P.seen[hit] = 1;
+                const bool fresh = alive && kind == 3;
+                const unsigned long long fresh_mask = __ballot(fresh);
+                // slots and CIGAR space in lane order
+                uint32_t my_words = fresh ? out.n : 0u, word_at = my_words;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(word_at, o); if (lane >= static_cast<uint32_t>(o)) word_at += v; }
+                const uint32_t words_total = __shfl(word_at, 63);
+                word_at = sh_words + word_at - my_words;
+                const uint32_t slot = sh_n_new + static_cast<uint32_t>(__popcll(fresh_mask & ((1ull << lane) - 1ull)));
+                const uint32_t n_fresh = static_cast<uint32_t>(__popcll(fresh_mask));
+                const bool room = sh_n_new + n_fresh <= P.cap_new && sh_words + words_total <= P.cap_words;
+                if (!room) atomicMax(T.flag, 1u);
+                if (fresh && room) {
+                    NewAln nn;
+                    nn.ln_prob = na.ln_prob; nn.start = na.start; nn.contig_end = na.contig_end; nn.edit = na.edit;
+                    nn.n_cigar = out.n; nn.cigar_at = word_at; nn.pushed = 0;
+                    P.news[slot] = nn;
+                    for (uint32_t k = 0; k < out.n; k++) P.words[word_at + k] = (out.t[k].y << 4) | out.t[k].x;
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    if (room) {
+                        for (uint32_t k = 0; k < n_fresh; k++) {              // push in target order
+                            const NewAln nn = P.news[sh_n_new + k];
+                            PAln a;
+                            a.ln_prob = nn.ln_prob; a.start = nn.start; a.contig_end = nn.contig_end; a.edit = nn.edit;
+                            a.src = 0x80000000u | (sh_n_new + k);
+                            prelim_push(P, S, a, T.flag);
+                            P.news[sh_n_new + k].pushed = 1;
+                        }
+                        sh_n_new += n_fresh; sh_words += words_total;
+                    }
+                    sh_fails += static_cast<uint32_t>(__popcll(fail_mask));
+                    if (sh_fails > H.transfer_fails || !room) sh_stop = 1;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+
+        // ---- hand the transferred alignments over: per pair a contiguous run, read end 0 first, push order inside an end ----
+        const uint32_t n_new = sh_n_new, n_words = sh_words;
+        if (n_new) {
+            __shared__ unsigned long long rec_at, word_at0;
+            if (lane == 0) {
+                rec_at = atomicAdd(T.rec_cursor, static_cast<unsigned long long>(n_new));
+                word_at0 = atomicAdd(T.word_cursor, static_cast<unsigned long long>(n_words));
+            }
+            __syncthreads();
+            const bool room = rec_at + n_new <= T.out_recs_cap && word_at0 + n_words <= T.out_words_cap;
+            if (!room) { if (lane == 0) atomicMax(T.flag, 1u); }
+            else {
+                uint32_t c0 = 0;
+                for (uint32_t k = 0; k < n_new; k++) c0 += ((P.news[k].contig_end >> 16) & 1u) == 0;       // uniform count
+                if (lane == 0) {
+                    uint32_t at[2] = {0, c0};
+                    for (uint32_t k = 0; k < n_new; k++) {
+                        const NewAln nn = P.news[k];
+                        const uint32_t e = (nn.contig_end >> 16) & 1u;
+                        lcty_aln_rec r;
+                        r.pos = nn.start; r.contig = static_cast<uint16_t>(nn.contig_end & 0xFFFFu);
+                        r.flags = static_cast<uint16_t>(LCTY_FLAG_SECONDARY | (((nn.contig_end >> 17) & 1u) ? LCTY_FLAG_REVERSE : 0) | (e ? LCTY_FLAG_MATE2 : 0));
+                        r.n_cigar = nn.n_cigar; r.cigar_rel = nn.cigar_at;     // relative to the pair's block of new words
+                        T.out_recs[rec_at + at[e]++] = r;
+                    }
+                    T.new_cnt[2 * p] = c0; T.new_cnt[2 * p + 1] = n_new - c0; T.new_words[p] = n_words;
+                    T.out_rec_at[p] = rec_at; T.out_word_at[p] = word_at0;
+                }
+                for (uint32_t k = lane; k < n_words; k += 64) T.out_words[word_at0 + k] = P.words[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// merged record table: per pair [end-0 originals][end-0 transferred][end-1 originals][end-1 transferred][anything behind n_eff]
+__global__ __launch_bounds__(64) void merge_kernel(const ReadsView R, const uint32_t* __restrict__ new_cnt, const uint32_t* __restrict__ new_words,
+                                                   const uint64_t* __restrict__ rec_at, const uint64_t* __restrict__ word_at,
+                                                   const lcty_aln_rec* __restrict__ xrecs, const uint32_t* __restrict__ xwords,
+                                                   const uint64_t* __restrict__ m_aln_off, const uint64_t* __restrict__ m_cigar_off,
+                                                   lcty_aln_rec* __restrict__ m_recs, uint32_t* __restrict__ m_cigar, uint2* __restrict__ m_meta) {
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
+        const uint64_t a0 = R.aln_off[p], c0 = R.cigar_off[p];
+        const uint32_t n_old = static_cast<uint32_t>(R.aln_off[p + 1] - a0), w_old = static_cast<uint32_t>(R.cigar_off[p + 1] - c0);
+        const uint2 meta = R.pair_meta[p];
+        const uint32_t j2 = meta.x, n_eff = meta.y, split = min(j2, n_eff);
+        const uint32_t n0 = new_cnt[2 * p], n1 = new_cnt[2 * p + 1];
+        lcty_aln_rec* out = m_recs + m_aln_off[p];
+        uint32_t* cw = m_cigar + m_cigar_off[p];
+        for (uint32_t k = lane; k < w_old; k += 64) cw[k] = R.cigar[c0 + k];
+        for (uint32_t k = lane; k < new_words[p]; k += 64) cw[w_old + k] = xwords[word_at[p] + k];
+        for (uint32_t k = lane; k < n_old + n0 + n1; k += 64) {
+            lcty_aln_rec r;
+            if (k < split) r = R.recs[a0 + k];
+            else if (k < split + n0) { r = xrecs[rec_at[p] + (k - split)]; r.cigar_rel += w_old; }
+            else if (k < n_eff + n0) r = R.recs[a0 + (k - n0)];
+            else if (k < n_eff + n0 + n1) { r = xrecs[rec_at[p] + n0 + (k - n_eff - n0)]; r.cigar_rel += w_old; }
+            else r = R.recs[a0 + (k - n0 - n1)];
+            out[k] = r;
+        }
+        if (lane == 0) m_meta[p] = make_uint2(j2 + n0, n_eff + n0 + n1);
+    }
+}
+
+}  // namespace lcty
+
+using namespace lcty;
+
+extern "C" {
+
+// HapAlns::new / add / sort_best_ixs (transfer.rs:33-67) + CigarIndex::new (cigar.rs:1099-1126) on the host
+int32_t lcty_locus_set_hap_alns(lcty_locus* loc, uint32_t n_entries, const uint32_t* id1, const uint32_t* id2, const uint64_t* cigar_off,
+                                const uint32_t* cigar, const uint32_t* n_matches, const uint32_t* aln_len, uint32_t transfer_fails,
+                                double max_div) {
+    return guarded([&] {
+        if (!loc || (n_entries && (!id1 || !id2 || !cigar_off || !cigar || !n_matches || !aln_len))) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        const uint32_t A = loc->n_alleles;
+        struct Cell { std::vector<uint2> items, positions; std::vector<uint2> sparse[2]; uint32_t rlen = 0, qlen = 0; };
+        std::vector<uint32_t> cell_of(static_cast<size_t>(A) * A, NONE32T);
+        std::vector<Cell> cells;
+        struct Best { uint32_t id, n_matches, order; };
+        std::vector<std::vector<Best>> best(A);
+        auto cq = [](uint32_t op) { return op == 0 || op == 7 || op == 8 || op == 1 || op == 4; };
+        auto cr = [](uint32_t op) { return op == 0 || op == 7 || op == 8 || op == 2; };
+        for (uint32_t t = 0; t < n_entries; t++) {
+            const uint32_t q = id1[t], r = id2[t];
+            if (q >= A || r >= A) fail(LCTY_ERR_INVALID_INPUT, "haplotype alignment %u refers to a contig out of range", t);
+            if (q == r) continue;
+            const uint32_t lo = std::min(q, r), hi = std::max(q, r);
+            if (cell_of[static_cast<size_t>(lo) * A + hi] != NONE32T) continue;                  // first alignment of a pair wins
+            const double div = aln_len[t] == 0 ? std::numeric_limits<double>::infinity()
+                                               : static_cast<double>(aln_len[t] - n_matches[t]) / static_cast<double>(aln_len[t]);     // paf.rs:201-208
+            if (div > max_div) continue;
+            Cell c;
+            for (uint64_t k = cigar_off[t]; k < cigar_off[t + 1]; k++) {
+                uint32_t op = cigar[k] & 15u;
+                const uint32_t len = cigar[k] >> 4;
+                if (!(op == 7 || op == 8 || op == 1 || op == 2 || op == 0)) fail(LCTY_ERR_INVALID_DATA, "haplotype alignment %u: unsupported CIGAR operation", t);
+                if (q > r) op = op == 1 ? 2u : (op == 2 ? 1u : op);                             // Cigar::invert: query = lower id
+                c.items.push_back(make_uint2(op, len));
+            }
+            if (c.items.empty()) continue;
+            // the alignment has to cover both haplotypes (full_positive_alignment, paf.rs:211-216)
+            uint32_t qpos = 0, rpos = 0;
+            for (size_t k = 0; k < c.items.size(); k++) {
+                const uint32_t op = c.items[k].x, len = c.items[k].y;
+                c.positions.push_back(make_uint2(qpos, rpos));
+                const uint32_t old_q = qpos;
+                auto upd = [&](std::vector<uint2>& v, uint32_t pos1, uint32_t pos2, bool other) {   // update_sparse_index, cigar.rs:972-986
+                    const uint32_t last = (pos1 + len - 1) >> 8;
+                    for (uint32_t i = static_cast<uint32_t>(v.size()); i <= last; i++)
+                        v.push_back(make_uint2(static_cast<uint32_t>(k), pos2 + (other ? (i << 8) - pos1 : 0u)));
+                };
+                if (cq(op)) { upd(c.sparse[0], qpos, rpos, cr(op)); qpos += len; }
+                if (cr(op)) { upd(c.sparse[1], rpos, old_q, cq(op)); rpos += len; }
+            }
+            c.qlen = qpos; c.rlen = rpos;
+            if (qpos != loc->allele_len[lo] || rpos != loc->allele_len[hi])
+                fail(LCTY_ERR_INVALID_DATA, "haplotype alignment %u does not cover both sequences (%u/%u vs %u/%u)", t, qpos, rpos, loc->allele_len[lo],
+                     loc->allele_len[hi]);
+            c.sparse[0].push_back(make_uint2(static_cast<uint32_t>(c.items.size() - 1), c.rlen));
+            c.sparse[1].push_back(make_uint2(static_cast<uint32_t>(c.items.size() - 1), c.qlen));
+            cell_of[static_cast<size_t>(lo) * A + hi] = static_cast<uint32_t>(cells.size());
+            cells.push_back(std::move(c));
+            best[q].push_back(Best{r, n_matches[t], static_cast<uint32_t>(best[q].size())});
+            best[r].push_back(Best{q, n_matches[t], static_cast<uint32_t>(best[r].size())});
+        }
+        for (auto& v : best) std::stable_sort(v.begin(), v.end(), [](const Best& a, const Best& b) { return a.n_matches > b.n_matches; });
+        // flatten
+        std::vector<uint32_t> item_off(cells.size() + 1, 0), sparse_off(2 * cells.size() + 1, 0), best_off(A + 1, 0), best_ids;
+        std::vector<uint2> items, positions, sparse;
+        for (size_t c = 0; c < cells.size(); c++) {
+            items.insert(items.end(), cells[c].items.begin(), cells[c].items.end());
+            positions.insert(positions.end(), cells[c].positions.begin(), cells[c].positions.end());
+            item_off[c + 1] = static_cast<uint32_t>(items.size());
+            for (int d = 0; d < 2; d++) {
+                sparse.insert(sparse.end(), cells[c].sparse[d].begin(), cells[c].sparse[d].end());
+                sparse_off[2 * c + d + 1] = static_cast<uint32_t>(sparse.size());
+            }
+        }
+        for (uint32_t a = 0; a < A; a++) { for (const Best& b : best[a]) best_ids.push_back(b.id); best_off[a + 1] = static_cast<uint32_t>(best_ids.size()); }
+        lcty_ctx* ctx = loc->ctx;
+        ctx->activate();
+        hipStream_t s = ctx->stream;
+        auto up32 = [&](DevBuf<uint32_t>& d, const std::vector<uint32_t>& v) { d.alloc(std::max<size_t>(v.size(), 1)); d.upload(v.data(), v.size(), s); };
+        auto up2 = [&](DevBuf<uint2>& d, const std::vector<uint2>& v) { d.alloc(std::max<size_t>(v.size(), 1)); d.upload(v.data(), v.size(), s); };
+        up32(loc->d_hap_cell_of, cell_of); up32(loc->d_hap_item_off, item_off); up32(loc->d_hap_sparse_off, sparse_off);
+        up32(loc->d_hap_best_off, best_off); up32(loc->d_hap_best_ids, best_ids);
+        up2(loc->d_hap_items, items); up2(loc->d_hap_positions, positions); up2(loc->d_hap_sparse, sparse);
+        LCTY_HIP(hipStreamSynchronize(s));
+        loc->hap_transfer_fails = transfer_fails; loc->hap_cells = static_cast<uint32_t>(cells.size());
+        loc->has_hap_alns = true;
+    });
+}
+
+// recover_and_group_alignments' transfer step (locs.rs:1255-1260) for the whole batch; lcty_score_reads before and after
+int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
+    return guarded([&] {
+        if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        lcty_locus* loc = reads->locus;
+        lcty_ctx* ctx = reads->ctx;
+        if (!loc->has_hap_alns) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_set_hap_alns has not been called");
+        if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads first: recovery looks at the read pairs the first pass lets through");
+        ctx->activate();
+        reads->check_device_error();
+        hipStream_t s = ctx->stream;
+        const uint64_t R = reads->n_pairs;
+        if (n_recovered) *n_recovered = 0;
+        if (R == 0) return;
+        const uint32_t A = loc->n_alleles;
+        HapView H{};
+        H.A = A; H.transfer_fails = loc->hap_transfer_fails;
+        H.cell_of = loc->d_hap_cell_of.p; H.item_off = loc->d_hap_item_off.p; H.items = loc->d_hap_items.p; H.positions = loc->d_hap_positions.p;
+        H.sparse_off = loc->d_hap_sparse_off.p; H.sparse = loc->d_hap_sparse.p; H.best_off = loc->d_hap_best_off.p; H.best_ids = loc->d_hap_best_ids.p;
+        H.seqs = loc->d_seqs.p; H.seq_off = loc->d_seq_off.p;
+
+        DevBuf<uint32_t> d_new_cnt, d_new_words, d_flag;
+        DevBuf<uint64_t> d_rec_at, d_word_at;
+        DevBuf<unsigned long long> d_cursors;
+        d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(2);
+        uint32_t cap_new = std::min<uint32_t>(std::max<uint32_t>(4 * A, 64), 1u << 15);
+        uint64_t arena_recs = std::max<uint64_t>(1024, 2 * R), arena_words = 16 * arena_recs;
+        DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords; DevBuf<uint8_t> d_scratch;
+        unsigned long long cursors[2] = {0, 0};
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(R, 1024));
+        for (int attempt = 0;; attempt++) {
+            if (attempt > 12) fail(LCTY_ERR_RUNTIME, "alignment recovery: arenas keep overflowing");
+            const uint32_t cap_alns = reads->max_recs_per_pair + cap_new;
+            uint32_t hcap = 64;
+            while (hcap < 2 * cap_alns + 2) hcap <<= 1;
+            const uint32_t cap_words = cap_new * 24;
+            const size_t stride = pair_scratch_bytes(cap_alns, hcap, cap_new, cap_words);
+            d_scratch.alloc(stride * blocks);
+            d_xrecs.alloc(arena_recs); d_xwords.alloc(arena_words);
+            d_flag.zero(s); d_cursors.zero(s);
+            TransferArgs T{};
+            T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
+            T.scratch = d_scratch.p; T.scratch_stride = stride;
+            T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
+            T.out_recs = d_xrecs.p; T.out_recs_cap = arena_recs; T.out_words = d_xwords.p; T.out_words_cap = arena_words;
+            T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.min_weight = loc->prm.min_weight;
+            ctx->timed(LCTY_K_TRANSFER, [&] {
+                hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
+            });
+            LCTY_HIP(hipGetLastError());
+            uint32_t flag = 0;
+            d_flag.download(&flag, 1, s);
+            d_cursors.download(cursors, 2, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            if (flag == 0) break;
+            if (flag == LCTY_ERR_UNSUPPORTED)
+                fail(LCTY_ERR_UNSUPPORTED, "alignment recovery: a stretch between anchors is longer than %u bases (or a transferred CIGAR has more than %u "
+                     "operations): the device aligner handles short reads", DP_MAX_DIM, CIGAR_CAP);
+            if (flag != 1) fail(static_cast<int32_t>(flag), "alignment recovery failed on the device");
+            cap_new = std::min<uint32_t>(cap_new * 4, 1u << 20);                 // some arena was too small: larger, again
+            arena_recs = std::max<uint64_t>(arena_recs * 2, cursors[0] + 1024); arena_words = std::max<uint64_t>(arena_words * 2, cursors[1] + 1024);
+        }
+        const uint64_t total_new = cursors[0], total_words = cursors[1];
+        if (n_recovered) *n_recovered = total_new;
+        if (total_new == 0) return;
+
+        // merged tables
+        std::vector<uint32_t> new_cnt(2 * R), new_words(R);
+        std::vector<uint64_t> aln_off(R + 1), cigar_off(R + 1);
+        d_new_cnt.download(new_cnt.data(), 2 * R, s); d_new_words.download(new_words.data(), R, s);
+        reads->d_aln_off.download(aln_off.data(), R + 1, s); reads->d_cigar_off.download(cigar_off.data(), R + 1, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        std::vector<uint64_t> m_aln(R + 1, 0), m_cig(R + 1, 0);
+        uint64_t max_recs = 0, max_cig = 0;
+        for (uint64_t p = 0; p < R; p++) {
+            const uint64_t nr = aln_off[p + 1] - aln_off[p] + new_cnt[2 * p] + new_cnt[2 * p + 1];
+            const uint64_t nw = cigar_off[p + 1] - cigar_off[p] + new_words[p];
+            m_aln[p + 1] = m_aln[p] + nr; m_cig[p + 1] = m_cig[p] + nw;
+            max_recs = std::max(max_recs, nr); max_cig = std::max(max_cig, nw);
+        }
+        if (max_recs > 65535) fail(LCTY_ERR_UNSUPPORTED, "more than 65535 alignments of one read pair after recovery");
+        DevBuf<uint64_t> d_m_aln, d_m_cig; DevBuf<lcty_aln_rec> d_m_recs; DevBuf<uint32_t> d_m_cigar; DevBuf<uint2> d_m_meta;
+        d_m_aln.alloc(std::max<uint64_t>(reads->cap_pairs, R) + 1); d_m_cig.alloc(std::max<uint64_t>(reads->cap_pairs, R) + 1);
+        d_m_aln.upload(m_aln.data(), R + 1, s); d_m_cig.upload(m_cig.data(), R + 1, s);
+        d_m_recs.alloc(m_aln[R] + 1); d_m_cigar.alloc(m_cig[R] + 8); d_m_meta.alloc(std::max<uint64_t>(reads->cap_pairs, R));
+        hipLaunchKernelGGL(merge_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(R, 65535))), dim3(64), 0, s, reads->view(), d_new_cnt.p, d_new_words.p,
+                           d_rec_at.p, d_word_at.p, d_xrecs.p, d_xwords.p, d_m_aln.p, d_m_cig.p, d_m_recs.p, d_m_cigar.p, d_m_meta.p);
+        LCTY_HIP(hipGetLastError());
+        LCTY_HIP(hipStreamSynchronize(s));
+        reads->d_aln_off = std::move(d_m_aln); reads->d_cigar_off = std::move(d_m_cig);
+        reads->d_recs = std::move(d_m_recs); reads->d_cigar = std::move(d_m_cigar); reads->d_pair_meta = std::move(d_m_meta);
+        reads->n_recs = m_aln[R]; reads->n_cigar = m_cig[R];
+        reads->cap_recs = reads->n_recs; reads->cap_cigar = reads->n_cigar;           // the merged tables are exactly full
+        // the pair-alignment arena was sized for the records of lcty_reads_create (same bound as there)
+        const uint64_t pa_cap = std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * reads->cap_pairs * A, 2 * reads->n_recs + reads->cap_pairs) + 64;
+        if (reads->d_pa.n < pa_cap) reads->d_pa.alloc(pa_cap);
+        reads->max_recs_per_pair = static_cast<uint32_t>(max_recs);
+        reads->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
+        reads->scored = false; reads->good_valid = false; reads->loc_table_valid = false;
+        (void)total_words;
+    });
+}
+
+}  // extern "C"

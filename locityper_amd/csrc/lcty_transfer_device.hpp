@@ -1,0 +1,395 @@
+// lcty_transfer_device.hpp — device side of alignment recovery (K6): one lane carries one transfer of a read alignment
+// from the haplotype it was found on to another haplotype, through the alignment of the two haplotypes
+// (Cigar::transfer_read_alignment, src/seq/cigar.rs:1248-1384) with the aligner calls of src/seq/wfa.rs restated as an
+// exact gap-affine dynamic programme (WFA2-lib computes the same optimum; its tie-breaks are not pinned anywhere, ours
+// are: walking back from the end, diagonal before deletion before insertion, a gap is extended before it is opened).
+// Scalar code per lane with private scratch in global memory: this is control-heavy work, the parallelism is across the
+// (alignment, target haplotype) pairs of a read.
+#pragma once
+
+#include "lcty_device.hpp"
+
+namespace lcty {
+namespace xfer {
+
+constexpr uint32_t OP_I = 1, OP_D = 2, OP_S = 4, OP_H = 5, OP_EQ = 7, OP_X = 8;
+constexpr int PEN_X = 4, PEN_O = 6, PEN_E = 1;             // Penalties::default (wfa.rs:30-38)
+constexpr int MAX_STEPS = 10000;                            // alignment_steps(6), wfa.rs:103-117
+constexpr int INF32 = 1 << 28;
+constexpr int DP_DROPPED = -(1 << 30);
+constexpr uint32_t DP_MAX_DIM = 255, DP_MAX_CELLS = 32768;  // per-lane scratch; larger stretches raise LCTY_ERR_UNSUPPORTED
+constexpr uint32_t CIGAR_CAP = 192;                         // items of a transferred CIGAR
+
+__device__ __forceinline__ bool cons_q(uint32_t op) { return op == 0 || op == OP_EQ || op == OP_X || op == OP_I || op == OP_S; }
+__device__ __forceinline__ bool cons_r(uint32_t op) { return op == 0 || op == OP_EQ || op == OP_X || op == OP_D; }
+__device__ __forceinline__ uint32_t op_invert(uint32_t op) {                  // Operation::invert, cigar.rs:147-159
+    return (op == OP_I || op == OP_S) ? OP_D : (op == OP_D ? OP_I : op);
+}
+
+// Cigar under construction (cigar.rs:203-208): items {op, len} in the lane's scratch
+struct DCigar {
+    uint2* t;
+    uint32_t n, rlen, qlen;
+    bool overflow;
+    __device__ void init(uint2* buf) { t = buf; n = 0; rlen = qlen = 0; overflow = false; }
+    __device__ void clear() { n = 0; rlen = qlen = 0; }
+    __device__ void push_unchecked(uint32_t op, uint32_t len) {              // cigar.rs:343-352
+        if (cons_q(op)) qlen += len;
+        if (cons_r(op)) rlen += len;
+        if (n < CIGAR_CAP) t[n++] = make_uint2(op, len); else overflow = true;
+    }
+    __device__ void push_checked(uint32_t op, uint32_t len) {                // cigar.rs:355-363
+        if (cons_q(op)) qlen += len;
+        if (cons_r(op)) rlen += len;
+        if (n && t[n - 1].x == op) t[n - 1].y += len;
+        else if (n < CIGAR_CAP) t[n++] = make_uint2(op, len);
+        else overflow = true;
+    }
+    __device__ void append_items(const uint2* it, uint32_t k) {              // tuples.extend_from_slice: lengths untouched
+        for (uint32_t i = 0; i < k; i++) { if (n < CIGAR_CAP) t[n++] = it[i]; else overflow = true; }
+    }
+};
+
+// the read in the orientation of the alignment (MateData::get_seq, locs.rs:87-93) and the target haplotype, as ASCII
+struct Seqs {
+    const uint64_t* w64; const uint32_t* nm; uint32_t read_len; bool flip;   // packed mate, N mask; flip = reverse complement
+    const uint8_t* target; uint32_t target_len;
+    __device__ __forceinline__ uint8_t q(uint32_t i) const {
+        const uint32_t j = flip ? read_len - 1 - i : i;
+        if ((nm[j >> 5] >> (j & 31u)) & 1u) return 'N';
+        uint32_t c = static_cast<uint32_t>(w64[j >> 5] >> ((j & 31u) * 2u)) & 3u;
+        if (flip) c = 3u - c;
+        return static_cast<uint8_t>("ACGT"[c]);
+    }
+    __device__ __forceinline__ uint8_t r(uint32_t i) const { return target[i]; }
+};
+
+// per-lane scratch
+struct Scratch {
+    uint2* cig_a;          // [CIGAR_CAP]
+    uint2* cig_b;          // [CIGAR_CAP] (optimize)
+    uint8_t* ops;          // [2 * DP_MAX_DIM + 4] aligner output, reversed
+    uint8_t* dirs;         // [DP_MAX_CELLS]
+    int32_t* rows;         // [2][DP_MAX_DIM + 1][3]
+    int32_t* lastcol;      // [DP_MAX_DIM + 1][3]
+    uint32_t* err;         // kernel-wide error flag
+};
+constexpr size_t SCRATCH_BYTES = CIGAR_CAP * 8 * 2 + 1024 + DP_MAX_CELLS + 2 * (DP_MAX_DIM + 1) * 12 + (DP_MAX_DIM + 1) * 12;
+
+__device__ inline Scratch scratch_at(uint8_t* base, uint32_t* err) {
+    Scratch s;
+    s.cig_a = reinterpret_cast<uint2*>(base); base += CIGAR_CAP * 8;
+    s.cig_b = reinterpret_cast<uint2*>(base); base += CIGAR_CAP * 8;
+    s.rows = reinterpret_cast<int32_t*>(base); base += 2 * (DP_MAX_DIM + 1) * 12;
+    s.lastcol = reinterpret_cast<int32_t*>(base); base += (DP_MAX_DIM + 1) * 12;
+    s.ops = base; base += 1024;
+    s.dirs = base;
+    s.err = err;
+    return s;
+}
+
+// Penalties::align_simple (wfa.rs:49-84): reference [i1, i1+n) against query [j1, j1+m)
+__device__ inline int align_simple(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, DCigar& cg) {
+    const int diff = static_cast<int>(n) - static_cast<int>(m);
+    int score;
+    uint32_t i = 0, j = 0;
+    if (diff < 0) { cg.push_unchecked(OP_I, static_cast<uint32_t>(-diff)); score = -PEN_O + diff * PEN_E; j = static_cast<uint32_t>(-diff); }
+    else if (diff > 0) { cg.push_unchecked(OP_D, static_cast<uint32_t>(diff)); score = -PEN_O - diff * PEN_E; i = static_cast<uint32_t>(diff); }
+    else score = 0;
+    bool curr_match = S.r(i1 + i) == S.q(j1 + j);
+    uint32_t curr_len = 1;
+    for (uint32_t t = 1; i + t < n && j + t < m; t++) {
+        const bool eq = S.r(i1 + i + t) == S.q(j1 + j + t);
+        if (eq != curr_match) {
+            cg.push_unchecked(curr_match ? OP_EQ : OP_X, curr_len);
+            score -= curr_match ? 0 : PEN_X * static_cast<int>(curr_len);
+            curr_match = !curr_match; curr_len = 1;
+        } else curr_len++;
+    }
+    cg.push_unchecked(curr_match ? OP_EQ : OP_X, curr_len);
+    score -= curr_match ? 0 : PEN_X * static_cast<int>(curr_len);
+    return score;
+}
+
+// Gap-affine alignment of reference [i1, i1+n) and query [j1, j1+m); mb = match bonus (0 global aligner, 2 semi-global one,
+// wfa.rs:194-197); mode 0 end to end, 1 free begin of both (LEFT), 2 free end of both (RIGHT). Writes the operations in
+// REVERSE order into sc.ops and returns the penalty, or DP_DROPPED (wfa.rs:262-266: status != 0).
+__device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, int mb, int mode, const Scratch& sc, uint32_t* n_ops) {
+    if (n > DP_MAX_DIM || m > DP_MAX_DIM || (n + 1) * (m + 1) > DP_MAX_CELLS) { atomicMax(sc.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); return DP_DROPPED; }
+    const uint32_t W = m + 1;
+    int32_t* prev = sc.rows;
+    int32_t* cur = sc.rows + (DP_MAX_DIM + 1) * 3;
+    for (uint32_t a = 0; a <= n; a++) {
+        for (uint32_t b = 0; b <= m; b++) {
+            int32_t cm = INF32, cd = INF32, ci = INF32;
+            uint32_t dm = 3, dd = 0, di = 0;
+            if (a == 0 && b == 0) cm = 0;
+            else if (mode == 1 && (a == 0 || b == 0)) cm = 0;                 // a prefix of one sequence is skipped for free
+            if (a > 0 && b > 0) {
+                const int32_t pm = prev[(b - 1) * 3], pd = prev[(b - 1) * 3 + 1], pi = prev[(b - 1) * 3 + 2];
+                const int32_t best = min(pm, min(pd, pi));
+                if (best < INF32) {
+                    const int32_t v = best + (S.r(i1 + a - 1) == S.q(j1 + b - 1) ? -mb : PEN_X);
+                    if (v < cm) { cm = v; dm = pm == best ? 0u : (pd == best ? 1u : 2u); }
+                }
+            }
+            if (a > 0) {
+                const int32_t pm = prev[b * 3], pd = prev[b * 3 + 1], pi = prev[b * 3 + 2];
+                int32_t v = min(pm, pi) + PEN_O + PEN_E;
+                if (pd + PEN_E < v) v = pd + PEN_E;
+                if (v < INF32) { cd = v; dd = (pd + PEN_E == v) ? 1u : (pm <= pi ? 0u : 2u); }
+            }
+            if (b > 0) {
+                const int32_t pm = cur[(b - 1) * 3], pd = cur[(b - 1) * 3 + 1], pi = cur[(b - 1) * 3 + 2];
+                int32_t v = min(pm, pd) + PEN_O + PEN_E;
+                if (pi + PEN_E < v) v = pi + PEN_E;
+                if (v < INF32) { ci = v; di = (pi + PEN_E == v) ? 2u : (pm <= pd ? 0u : 1u); }
+            }
+            cur[b * 3] = cm; cur[b * 3 + 1] = cd; cur[b * 3 + 2] = ci;
+            sc.dirs[a * W + b] = static_cast<uint8_t>(dm | (dd << 2) | (di << 4));
+        }
+        sc.lastcol[a * 3] = cur[m * 3]; sc.lastcol[a * 3 + 1] = cur[m * 3 + 1]; sc.lastcol[a * 3 + 2] = cur[m * 3 + 2];
+        int32_t* t = prev; prev = cur; cur = t;
+    }
+    const int32_t* lastrow = prev;                                           // row n
+    uint32_t ea = n, eb = m;
+    int32_t best = INF32, em = INF32, ed = INF32, ei = INF32;
+    if (mode == 2) {                                                         // the alignment may stop on the last row or column
+        for (uint32_t b = 0; b <= m; b++) {
+            const int32_t v = min(lastrow[b * 3], min(lastrow[b * 3 + 1], lastrow[b * 3 + 2]));
+            if (v < best) { best = v; ea = n; eb = b; em = lastrow[b * 3]; ed = lastrow[b * 3 + 1]; ei = lastrow[b * 3 + 2]; }
+        }
+        for (uint32_t a = 0; a <= n; a++) {
+            const int32_t v = min(sc.lastcol[a * 3], min(sc.lastcol[a * 3 + 1], sc.lastcol[a * 3 + 2]));
+            if (v < best) { best = v; ea = a; eb = m; em = sc.lastcol[a * 3]; ed = sc.lastcol[a * 3 + 1]; ei = sc.lastcol[a * 3 + 2]; }
+        }
+    } else {
+        em = lastrow[m * 3]; ed = lastrow[m * 3 + 1]; ei = lastrow[m * 3 + 2];
+        best = min(em, min(ed, ei));
+    }
+    if (best >= INF32 || best > MAX_STEPS) return DP_DROPPED;
+    uint32_t k = 0;
+    if (mode == 2) {                                                         // the skipped suffix, as the aligner reports it
+        for (uint32_t b = m; b > eb; b--) sc.ops[k++] = 'I';
+        for (uint32_t a = n; a > ea; a--) sc.ops[k++] = 'D';
+    }
+    uint32_t a = ea, b = eb;
+    uint32_t st = (em <= ed && em <= ei) ? 0u : (ed <= ei ? 1u : 2u);
+    while (a > 0 || b > 0) {
+        if (mode == 1 && (a == 0 || b == 0) && st == 0) break;               // reached the free border
+        const uint32_t d = sc.dirs[a * W + b];
+        if (st == 0) {
+            sc.ops[k++] = S.r(i1 + a - 1) == S.q(j1 + b - 1) ? '=' : 'X';
+            st = d & 3u; a--; b--;
+        } else if (st == 1) {
+            sc.ops[k++] = 'D';
+            const uint32_t dd = (d >> 2) & 3u;
+            st = dd == 1 ? 1u : (dd == 0 ? 0u : 2u);
+            a--;
+        } else {
+            sc.ops[k++] = 'I';
+            const uint32_t di = (d >> 4) & 3u;
+            st = di == 2 ? 2u : (di == 0 ? 0u : 1u);
+            b--;
+        }
+    }
+    if (mode == 1) {                                                         // the skipped prefix
+        for (; b > 0; b--) sc.ops[k++] = 'I';
+        for (; a > 0; a--) sc.ops[k++] = 'D';
+    }
+    *n_ops = k;
+    return best;
+}
+
+__device__ __forceinline__ uint32_t op_from_char(uint8_t ch) { return ch == '=' ? OP_EQ : ch == 'X' ? OP_X : ch == 'I' ? OP_I : OP_D; }
+
+// Aligner::align::<LEFT_CLIPPING> (wfa.rs:254-299). semiglobal: 0 global aligner, 1 LEFT, 2 RIGHT free ends
+__device__ inline int aligner_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, int semiglobal, bool left_clipping, DCigar& cg,
+                                    const Scratch& sc) {
+    uint32_t n_ops = 0;
+    const int pen = dp_align(S, i1, n, j1, m, semiglobal ? max(1, PEN_X / 2) : 0, semiglobal, sc, &n_ops);
+    if (pen == DP_DROPPED) return align_simple(S, i1, n, j1, m, cg);
+    bool no_matches_yet = true;
+    for (uint32_t t = n_ops; t-- > 0;) {                                     // sc.ops is reversed
+        const uint32_t op = op_from_char(sc.ops[t]);
+        if (left_clipping && no_matches_yet && op == OP_EQ) {
+            no_matches_yet = false;
+            const uint32_t soft = cg.qlen;
+            cg.clear();
+            if (soft > 0) cg.push_unchecked(OP_I, soft);
+        }
+        cg.push_checked(op, 1);
+    }
+    if (left_clipping && no_matches_yet) {
+        const uint32_t soft = cg.qlen;
+        cg.clear();
+        if (soft > 0) cg.push_unchecked(OP_I, soft);
+    }
+    return -pen;
+}
+
+// smart_align (wfa.rs:301-347); max_gap 0xFFFFFFFF = the `()` threshold
+__device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, uint32_t max_gap, DCigar& cg, const Scratch& sc) {
+    const uint32_t jump1 = i2 - i1, jump2 = j2 - j1;
+    if (jump1 > 0 && jump2 > 0) {
+        const uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;      // wfa.rs:212
+        if (max_gap < jump1 || max_gap < jump2) return align_simple(S, i1, jump1, j1, jump2, cg);
+        if (jump1 == jump2 && jump1 <= safe_mismatch) {
+            int ndiff = 0;
+            for (uint32_t t = 0; t < jump1; t++) {
+                const bool eq = S.r(i1 + t) == S.q(j1 + t);
+                cg.push_checked(eq ? OP_EQ : OP_X, 1);
+                ndiff -= !eq;
+            }
+            return ndiff * PEN_X;
+        }
+        return aligner_align(S, i1, jump1, j1, jump2, 0, false, cg, sc);
+    }
+    if (jump1 > 0) { cg.push_unchecked(OP_D, jump1); return -PEN_O - static_cast<int>(jump1) * PEN_E; }
+    if (jump2 > 0) { cg.push_unchecked(OP_I, jump2); return -PEN_O - static_cast<int>(jump2) * PEN_E; }
+    return 0;
+}
+
+// align_ends::<LEFT> (wfa.rs:349-365)
+__device__ inline void align_ends(bool left, const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, DCigar& cg, const Scratch& sc) {
+    if (i1 == i2) { cg.push_unchecked(OP_I, j2 - j1); return; }
+    aligner_align(S, i1, i2 - i1, j1, j2 - j1, left ? 1 : 2, left, cg, sc);
+    if (!left) {
+        uint32_t soft = 0;
+        while (cg.n && cg.t[cg.n - 1].x != OP_EQ) {                          // pop_if(op != Equal)
+            const uint2 it = cg.t[--cg.n];
+            if (cons_q(it.x)) { cg.qlen -= it.y; soft += it.y; }
+            if (cons_r(it.x)) cg.rlen -= it.y;
+        }
+        if (soft > 0) cg.push_unchecked(OP_I, soft);
+    }
+}
+
+// Cigar::optimize (cigar.rs:1167-1237). As upstream, the reference positions are counted from the start of the CIGAR while the
+// sequence handed in is the whole target haplotype (cigar.rs:1362-1364): kept as written.
+__device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_gap, uint32_t anchor_size, const Scratch& sc) {
+    uint32_t i = 0, qpos1 = 0, rpos1 = 0, qpos2 = 0, rpos2 = 0;
+    uint32_t flag = 0;
+    DCigar nc; nc.init(sc.cig_b);
+    bool have = false;
+    for (uint32_t j = 0; j < self.n; j++) {
+        const uint32_t op = self.t[j].x, len = self.t[j].y;
+        const bool cq = cons_q(op), cr = cons_r(op);
+        if (cq && cr && len >= anchor_size) {
+            const uint32_t qshift = qpos2 - qpos1, rshift = rpos2 - rpos1;
+            if (flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
+                if (!have) { have = true; nc.append_items(self.t, i); nc.qlen = qpos1; nc.rlen = rpos1; }
+                smart_align(S, rpos1, rpos2, qpos1, qpos2, 0xFFFFFFFFu, nc, sc);
+                i = j;
+            }
+            qpos2 += len; rpos2 += len; qpos1 = qpos2; rpos1 = rpos2; flag = 0;
+            if (have) {
+                nc.append_items(self.t + i, j - i);
+                nc.push_checked(op, len);
+                nc.qlen = qpos2; nc.rlen = rpos2;
+            }
+            i = j + 1;
+        } else {
+            qpos2 += cq ? len : 0; rpos2 += cr ? len : 0;
+            flag |= (cq ? 0u : 1u) | ((cr ? 0u : 1u) << 1);
+        }
+    }
+    const uint32_t qshift = qpos2 - qpos1, rshift = rpos2 - rpos1;
+    if (flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
+        if (!have) { have = true; nc.append_items(self.t, i); nc.qlen = qpos1; nc.rlen = rpos1; }
+        smart_align(S, rpos1, rpos2, qpos1, qpos2, 0xFFFFFFFFu, nc, sc);
+        i = self.n;
+    }
+    if (have) {
+        nc.append_items(self.t + i, self.n - i);
+        for (uint32_t t = 0; t < nc.n; t++) self.t[t] = nc.t[t];             // self.tuples = new_cigar.tuples (lengths stay)
+        self.n = nc.n;
+        self.overflow |= nc.overflow;
+    }
+}
+
+// double_cigar_move_and_shift (cigar.rs:1422-1466)
+__device__ __forceinline__ uint32_t cons_class(uint32_t op) { return cons_q(op) && cons_r(op) ? 0u : (cons_q(op) ? 1u : 2u); }
+__device__ inline uint32_t double_move(uint32_t op1, uint32_t op2, uint32_t& pos1, uint32_t& rem1, uint32_t& pos2, uint32_t& rem2) {
+    // bit 0 read moves, 1 read CIGAR shifts, 2 haplotype moves, 3 haplotype CIGAR shifts; index = class(op1) * 3 + class(op2)
+    const uint32_t table[9] = {0xF, 0xB, 0xC, 0x3, 0x3, 0xF, 0xE, 0xA, 0xC};
+    const uint32_t f = table[cons_class(op1) * 3 + cons_class(op2)];
+    const bool rs = f & 2u, hs = f & 8u;
+    const uint32_t shift = (rs && (!hs || rem1 <= rem2)) ? rem1 : rem2;
+    pos1 += (f & 1u) ? shift : 0; rem1 -= rs ? shift : 0;
+    pos2 += (f & 4u) ? shift : 0; rem2 -= hs ? shift : 0;
+    return shift;
+}
+
+// the read's own CIGAR as it is stored: raw BAM words, hard clips at the ends count as soft ones (cigar.rs:309-320)
+struct SrcCigar {
+    const uint32_t* raw; uint32_t n; bool hard_to_soft;
+    __device__ __forceinline__ uint2 item(uint32_t i) const {
+        uint32_t op = raw[i] & 15u;
+        if (hard_to_soft && op == OP_H && (i == 0 || i + 1 == n)) op = OP_S;
+        return make_uint2(op, raw[i] >> 4);
+    }
+    __device__ uint32_t ref_len() const {
+        uint32_t r = 0;
+        for (uint32_t i = 0; i < n; i++) { const uint2 it = item(i); if (cons_r(it.x)) r += it.y; }
+        return r;
+    }
+};
+
+// Cigar::transfer_alignment::<false> as called by transfer_read_alignment (cigar.rs:1248-1384): anchor size 5, no maximum gap.
+// jk: items of the haplotype-to-haplotype CIGAR (query = lower contig id), dir_jk 0 = QueryToRef, 1 = RefToQuery.
+__device__ inline uint32_t transfer_read(const uint2* jk_items, uint32_t jk_n, int dir_jk, uint32_t start_j, uint32_t off_ix, uint32_t off_qpos,
+                                         uint32_t off_rpos, const SrcCigar& ij, const Seqs& S, DCigar& out, const Scratch& sc) {
+    const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3, FULL_MATCH_PADDING = 3;
+    out.clear();
+    uint32_t jk = off_ix;
+    uint32_t op2 = dir_jk ? op_invert(jk_items[jk].x) : jk_items[jk].x;
+    const uint32_t init_shift = start_j - off_qpos;
+    uint32_t len2 = jk_items[jk].y, rem2 = len2 - init_shift;
+    jk++;
+    uint32_t start_k = off_rpos + (cons_r(op2) ? init_shift : 0);
+    if (op2 == OP_EQ && init_shift >= FULL_MATCH_PADDING && rem2 >= ij.ref_len() + FULL_MATCH_PADDING) {
+        for (uint32_t i = 0; i < ij.n; i++) { const uint2 it = ij.item(i); out.push_unchecked(it.x, it.y); }
+        return start_k;
+    }
+    uint32_t ijx = 0;
+    uint2 it1 = ij.item(0);
+    uint32_t len1 = it1.y, rem1 = len1, op1 = it1.x;
+    ijx++;
+    uint32_t last1 = 0, pos1 = 0, last2 = start_k, pos2 = start_k;
+    const uint32_t len_i = S.read_len, len_k = S.target_len;
+    for (;;) {
+        int add = -1;
+        const bool e1 = op1 == OP_EQ, e2 = op2 == OP_EQ;
+        if (e1 && e2) { if (min(rem1, rem2) >= anchor_size) add = OP_EQ; }
+        else if (e1 && !e2) { if (rem1 >= anchor_size && len1 - rem1 >= ANCHOR_MARGIN) add = static_cast<int>(op2); }
+        else if (!e1 && e2) { if (rem2 >= anchor_size && len2 - rem2 >= ANCHOR_MARGIN) add = static_cast<int>(op1); }
+        if (add >= 0) {
+            if (last1 == 0 && pos1 > 0) {
+                const uint32_t from = last2 > pos1 + CLIP_PADDING ? last2 - (pos1 + CLIP_PADDING) : 0;     // saturating_sub
+                align_ends(true, S, from, pos2, last1, pos1, out, sc);
+                start_k = start_k + pos2 - last2 - out.rlen;
+            } else smart_align(S, last2, pos2, last1, pos1, 0xFFFFFFFFu, out, sc);
+        }
+        const uint32_t shift = double_move(op1, op2, pos1, rem1, pos2, rem2);
+        if (add >= 0) { out.push_checked(static_cast<uint32_t>(add), shift); last1 = pos1; last2 = pos2; }
+        if (rem1 == 0) {
+            if (ijx == ij.n) break;
+            it1 = ij.item(ijx); len1 = it1.y; rem1 = len1; op1 = it1.x; ijx++;
+        }
+        if (rem2 == 0) {
+            if (jk == jk_n) break;
+            len2 = jk_items[jk].y; rem2 = len2; op2 = dir_jk ? op_invert(jk_items[jk].x) : jk_items[jk].x; jk++;
+        }
+    }
+    if (last1 != len_i) align_ends(false, S, last2, min(len_k, last2 + len_i - last1 + CLIP_PADDING), last1, len_i, out, sc);
+    cigar_optimize(out, S, 20, 5, sc);                                        // MAX_OPTIMIZATION_GAP, OPTIMIZATION_ANCHOR
+    if (out.n) {                                                              // boundary_ins_to_soft, cigar.rs:554-561
+        if (out.t[0].x == OP_I) out.t[0].x = OP_S;
+        if (out.t[out.n - 1].x == OP_I) out.t[out.n - 1].x = OP_S;
+    }
+    return start_k;
+}
+
+}  // namespace xfer
+}  // namespace lcty

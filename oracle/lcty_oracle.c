@@ -568,7 +568,7 @@ static double neighb_complexity(const orc_locus* l, uint32_t contig, uint32_t mi
 
 typedef struct {
     uint32_t start, end;     /* Interval */
-    uint32_t rec_ix;         /* index of the record inside the pair (input order) */
+    uint32_t rec_ix;         /* index of the record inside the pair (input order); 0x80000000 | k for the k-th transferred alignment */
     uint16_t contig;
     uint8_t read_end;        /* 0 / 1 */
     uint8_t reverse;
@@ -1051,7 +1051,9 @@ static size_t transfer_alignments(load_ctx* c, const orc_hap_alns* hap, prelim* 
             fake.n_cigar = out.n;
             o_aln na; int empty;
             if (!score_record(c, &fake, raw, 0, (uint8_t)e, &na, &empty) || empty) continue;
-            na.rec_ix = 0xFFFFFFFFu; na.own_cigar = raw; na.own_n = out.n;
+            /* ties between equally likely alignments keep the order of the merged table the product builds: the input records of
+             * a read end first, then its transferred alignments in push order (the reference's sort_unstable leaves ties open) */
+            na.rec_ix = 0x80000000u | (uint32_t)(p->n_owned - 1); na.own_cigar = raw; na.own_n = out.n;
             prelim_push(p, &na);
         }
     }

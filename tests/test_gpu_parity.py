@@ -486,3 +486,169 @@ def test_random_adversarial_pairs(gpu_ctx, seed, n_alleles, paired):
         o1, c1 = api.assignment_counts(aa, gts[1], api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds[:3])
         o2, c2 = O.assignment_counts(ol, oa2, gts[1], api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds[:3])
         assert np.array_equal(o1, o2) and np.array_equal(c1, c2) and np.diff(o1.astype(np.int64)).max() >= 4
+
+
+# ------------------------------------------------------------------ alignment recovery (K6)
+def test_alignment_recovery_matches_oracle(gpu_ctx):
+    """AllAlignments::load with haplotype-to-haplotype alignments: the mapper reports only the primary alignments, the
+    others are transferred (transfer.rs:70-140). Status, pair alignments and the matrix must equal the oracle's."""
+    from tests.test_oracle_transfer import make_haps, hap_alns_for
+    rng = np.random.default_rng(5)
+    haps = make_haps(rng, 6, 2600)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays([bytearray(h) for h in haps], 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    for tf in (3, 0):
+        H = hap_alns_for(haps, transfer_fails=tf)
+        loc.set_hap_alns(H.entries, transfer_fails=tf, max_div=0.2)
+        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        pairs = []
+        for i in range(150):
+            src = int(rng.integers(0, 6))
+            p1 = int(rng.integers(320, len(haps[src]) - 800)); p2 = p1 + int(rng.integers(200, 420))
+            r1, r2 = bytearray(haps[src][p1:p1 + 150]), bytearray(haps[src][p2:p2 + 150])
+            c1 = c2 = "150="
+            if i % 3 == 0:                                                # a sequencing error in mate 1
+                q = int(rng.integers(5, 145)); r1[q] = ord("A") if r1[q] != ord("A") else ord("C"); c1 = f"{q}=1X{149 - q}="
+            recs = [(src, p1, 0, c1)]
+            if i % 5 == 0:                                                # a second reported alignment of mate 1 on another allele
+                oth = (src + 1) % 6
+                recs.append((oth, max(0, p1 - 2), SEC, "150="))
+            recs.append((src, p2, M2 | REV, c2))
+            pairs.append({"seq1": bytes(r1).decode(), "seq2": bytes(r2).decode(), "recs": recs})
+        ch = ReadsChunk.from_pairs(pairs)
+        aa = api.AllAlignments.load(loc, ch)
+        n_rec = aa.recover()
+        oa = ol.load_recover(ch, H)
+        assert n_rec > 300
+        compare_gpu_to_oracle(aa, oa, index_fields=())
+        plain = ol.load(ch)
+        assert oa.pa_off[-1] > 2 * plain.pa_off[-1]
+
+
+def _recovery_case(gpu_ctx, haps, pairs, bg, tf=3):
+    from tests.test_oracle_transfer import hap_alns_for
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays([bytearray(h) for h in haps], 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    H = hap_alns_for(haps, transfer_fails=tf)
+    loc.set_hap_alns(H.entries, transfer_fails=tf, max_div=0.2)
+    ch = ReadsChunk.from_pairs(pairs)
+    aa = api.AllAlignments.load(loc, ch)
+    n_rec = aa.recover()
+    oa = ol.load_recover(ch, H)
+    compare_gpu_to_oracle(aa, oa, index_fields=())
+    return n_rec, aa, oa
+
+
+@pytest.mark.gpu
+def test_alignment_recovery_edge_cases(gpu_ctx):
+    """Sources on either strand, soft / hard clips, indels, N bases, reads at the ends of the alleles (transfers that fail the
+    MIN_ALN_SIZE / passable-distance checks and use up transfer_fails)."""
+    from tests.test_oracle_transfer import make_haps
+    rng = np.random.default_rng(23)
+    haps = make_haps(rng, 7, 2400)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    acgt = list(b"ACGT")
+    pairs = []
+    for i in range(260):
+        src = int(rng.integers(0, 7)); L = len(haps[src])
+        if i % 7 == 0: p1 = int(rng.integers(0, 40))                           # hanging over the left end of other alleles
+        elif i % 7 == 1: p1 = L - 150 - int(rng.integers(300, 340))
+        else: p1 = int(rng.integers(200, L - 900))
+        p2 = min(L - 150, p1 + int(rng.integers(180, 460)))
+        r1, r2 = bytearray(haps[src][p1:p1 + 150]), bytearray(haps[src][p2:p2 + 150])
+        kind = i % 6
+        c1 = "150="
+        if kind == 1:                                                         # soft clip: the first bases are adapter
+            k = int(rng.integers(3, 30)); r1[:k] = bytes(rng.choice(acgt, k).tolist()); c1 = f"{k}S{150 - k}="
+        elif kind == 2:                                                       # an insertion in the read
+            q = int(rng.integers(20, 120)); k = int(rng.integers(1, 6))
+            r1 = r1[:q] + bytearray(rng.choice(acgt, k).tolist()) + r1[q:150 - k]; c1 = f"{q}={k}I{150 - q - k}="
+        elif kind == 3:                                                       # a deletion in the read
+            q = int(rng.integers(20, 120)); k = int(rng.integers(1, 6))
+            r1 = bytearray(haps[src][p1:p1 + q] + haps[src][p1 + q + k:p1 + 150 + k]); c1 = f"{q}={k}D{150 - q}="
+        elif kind == 4:                                                       # unknown bases
+            for q in rng.integers(0, 150, 3): r1[int(q)] = ord("N")
+        assert len(r1) == 150
+        c2 = "150="
+        if i % 4 == 0:
+            k = int(rng.integers(2, 20)); r2[150 - k:] = bytes(rng.choice(acgt, k).tolist()); c2 = f"{150 - k}={k}S"
+        # orientation: FR with mate 1 forward, or mate 1 reverse (the stored bases are those of the record, i.e. allele-forward)
+        f1, f2 = (0, REV) if i % 2 == 0 else (REV, 0)
+        recs = [(src, p1, f1, c1)]
+        if i % 5 == 0:                                                        # a hard-clipped supplementary-like record on another allele
+            oth = (src + 2) % 7
+            recs.append((oth, min(p1, len(haps[oth]) - 150), SEC | f1, "6H144=" if kind in (0, 4) else "150="))
+        if i % 11 == 3:                                                       # a secondary on the opposite strand of the primary
+            oth = (src + 3) % 7
+            recs.append((oth, min(p1 + 5, len(haps[oth]) - 150), SEC | (f1 ^ REV), "150="))
+        recs.append((src, p2, M2 | f2, c2))
+        if i % 9 == 0: recs.append(((src + 1) % 7, min(p2, len(haps[(src + 1) % 7]) - 150), M2 | SEC | f2, "150="))
+        pairs.append({"seq1": bytes(r1).decode(), "seq2": bytes(r2).decode(), "recs": recs})
+    bg = make_bg()
+    for tf in (0, 2):
+        n_rec, aa, oa = _recovery_case(gpu_ctx, haps, pairs, bg, tf)
+        assert n_rec > 400
+
+
+@pytest.mark.gpu
+def test_alignment_recovery_single_end_and_empty(gpu_ctx):
+    from tests.test_oracle_transfer import make_haps
+    rng = np.random.default_rng(29)
+    haps = make_haps(rng, 5, 2200)
+    pairs = []
+    for i in range(120):
+        src = int(rng.integers(0, 5))
+        p1 = int(rng.integers(100, len(haps[src]) - 400))
+        n = int(rng.integers(100, 251))
+        recs = [(src, p1, REV if i % 3 == 0 else 0, f"{n}=")]
+        if i % 10 == 0: recs = [(0, 0, cdefs.FLAG_UNMAPPED, "")]              # an unmapped read
+        pairs.append({"seq1": haps[src][p1:p1 + n].decode(), "seq2": None, "recs": recs})
+    n_rec, aa, oa = _recovery_case(gpu_ctx, haps, pairs, make_bg(paired=False))
+    assert n_rec > 200
+    # nothing to recover: a chunk of unmapped pairs
+    ch = ReadsChunk.from_pairs([{"seq1": "ACGT" * 30, "seq2": "ACGT" * 30,
+                                 "recs": [(0, 0, cdefs.FLAG_UNMAPPED, ""), (0, 0, cdefs.FLAG_UNMAPPED | M2, "")]}] * 3)
+    p = api.resolve_params(api.default_params(), make_bg())
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays([bytearray(h) for h in haps], 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, make_bg(), p)
+    from tests.test_oracle_transfer import hap_alns_for
+    loc.set_hap_alns(hap_alns_for(haps).entries, transfer_fails=3, max_div=0.2)
+    aa = api.AllAlignments.load(loc, ch)
+    assert aa.recover() == 0
+
+
+@pytest.mark.gpu
+def test_alignment_recovery_refuses_what_it_cannot_hold(gpu_ctx):
+    """A stretch between anchors longer than the per-lane aligner holds is an error, never a silently different
+    alignment; recover() without haplotype alignments is an error too."""
+    from tests.test_oracle_transfer import make_haps, hap_alns_for
+    rng = np.random.default_rng(31)
+    base = make_haps(rng, 1, 2400)[0]
+    ins = bytes(rng.choice(list(b"ACGT"), 400).tolist())
+    haps = [base, base[:1000] + ins + base[1000:], base[:700] + base[705:]]
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays([bytearray(h) for h in haps], 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    # a read spanning the insertion point of allele 0 -> on allele 1 its two halves are 400 bases apart
+    pairs = [{"seq1": base[930:1080].decode(), "seq2": base[1300:1450].decode(),
+              "recs": [(0, 930, 0, "150="), (0, 1300, M2 | REV, "150=")]}]
+    ch = ReadsChunk.from_pairs(pairs)
+    aa = api.AllAlignments.load(loc, ch)
+    with pytest.raises(_lib.LocityperError):
+        aa.recover()                                                          # no haplotype alignments yet
+    loc.set_hap_alns(hap_alns_for(haps).entries, transfer_fails=3, max_div=0.5)
+    aa = api.AllAlignments.load(loc, ch)
+    try:
+        aa.recover()
+    except _lib.LocityperError as e:
+        assert e.code == cdefs.ERR_UNSUPPORTED
+    else:
+        # the oracle has no such limit: if the kernel went through, it must agree
+        ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+        compare_gpu_to_oracle(aa, ol.load_recover(ch, hap_alns_for(haps)), index_fields=())
