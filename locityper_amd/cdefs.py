@@ -241,6 +241,28 @@ class ReadsChunk:
             ao - ao[0], self.recs[int(ao[0]):int(ao[-1])], co - co[0],
             self.cigar[int(co[0]):int(co[-1])])
 
+    def primaries(self):
+        """The same pairs with only the primary record of each read end (no secondary / supplementary records)."""
+        n = len(self.aln_off) - 1
+        keep = (self.recs["flags"] & (FLAG_SECONDARY | FLAG_SUPPL)) == 0
+        pair_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(self.aln_off.astype(np.int64)))
+        recs = self.recs[keep].copy()
+        pair_k = pair_of[keep]
+        aln_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.bincount(pair_k, minlength=n), out=aln_off[1:], dtype=np.uint64)
+        nc = recs["n_cigar"].astype(np.int64)
+        src = self.cigar_off.astype(np.int64)[pair_k] + recs["cigar_rel"].astype(np.int64)
+        ends = np.cumsum(nc)
+        starts = ends - nc
+        cigar_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.bincount(pair_k, weights=nc, minlength=n).astype(np.uint64), out=cigar_off[1:], dtype=np.uint64)
+        recs["cigar_rel"] = (starts - cigar_off.astype(np.int64)[pair_k]).astype(np.uint32)
+        total = int(ends[-1]) if len(ends) else 0
+        gather = np.repeat(src - starts, nc) + np.arange(total, dtype=np.int64)
+        cigar = self.cigar[gather] if total else np.zeros(0, dtype=np.uint32)
+        return ReadsChunk(self.mate_len, self.mate_off, self.bases2, self.nmask, aln_off, recs, cigar_off, cigar)
+
+
 WARN_NO_PROBABLE_GENOTYPE, WARN_FEW_READS = 1, 2      # lcty_call_checks
 
 

@@ -541,10 +541,15 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         DevBuf<unsigned long long> d_cursors;
         d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(2);
         uint32_t cap_new = std::min<uint32_t>(std::max<uint32_t>(4 * A, 64), 1u << 15);
-        uint64_t arena_recs = std::max<uint64_t>(1024, 2 * R), arena_words = 16 * arena_recs;
+        // every record can reach every other contig once; beyond 1.5 G records (24 GB) the first launch only counts and the second one fits
+        uint64_t arena_recs = std::min<uint64_t>(reads->n_recs * static_cast<uint64_t>(A > 1 ? A - 1 : 1) + 1024, 1500ull << 20);
+        uint64_t arena_words = 4 * arena_recs;
         DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords; DevBuf<uint8_t> d_scratch;
         unsigned long long cursors[2] = {0, 0};
-        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(R, 1024));
+        // one wavefront per workgroup, 141 VGPRs: three wavefronts per SIMD
+        uint32_t waves = 12;
+        if (const char* e = std::getenv("LCTY_TRANSFER_WAVES")) waves = std::max(1, std::atoi(e));
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(R, static_cast<uint64_t>(ctx->props.multiProcessorCount) * waves));
         for (int attempt = 0;; attempt++) {
             if (attempt > 12) fail(LCTY_ERR_RUNTIME, "alignment recovery: arenas keep overflowing");
             const uint32_t cap_alns = reads->max_recs_per_pair + cap_new;

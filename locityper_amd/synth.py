@@ -35,6 +35,8 @@ def lib():
         L.synth_locus_true_genotype.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.synth_reads_sizes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.synth_reads_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 7
+        L.synth_hap_cigar.restype = C.c_uint32
+        L.synth_hap_cigar.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -67,8 +69,29 @@ class SynthLocus:
     def allele(self, a):
         return bytes(self.seqs[int(self.seq_off[a]):int(self.seq_off[a + 1])])
 
-    def reads(self, first, n):
-        """Read pairs [first, first+n) with all their candidate alignments."""
+    def hap_alns(self):
+        """Pairwise allele alignments (the content of `haplotypes.paf`): [(query, target, CIGAR words, n_matches, aln_len)]
+        for every query < target, as Locus.set_hap_alns takes them."""
+        L = lib()
+        buf = np.zeros(4 * (int(self.seq_off[-1]) // self.n_alleles // 50 + 64), dtype=np.uint32)
+        nm, ln = C.c_uint32(), C.c_uint32()
+        out = []
+        for q in range(self.n_alleles):
+            for r in range(q + 1, self.n_alleles):
+                n = L.synth_hap_cigar(self._h, q, r, buf.ctypes.data, len(buf), C.byref(nm), C.byref(ln))
+                if n > len(buf):
+                    buf = np.zeros(2 * n, dtype=np.uint32)
+                    n = L.synth_hap_cigar(self._h, q, r, buf.ctypes.data, len(buf), C.byref(nm), C.byref(ln))
+                out.append((q, r, buf[:n].copy(), int(nm.value), int(ln.value)))
+        return out
+
+    def reads(self, first, n, primaries_only=False):
+        """Read pairs [first, first+n) with all their candidate alignments (primaries_only: what the mapper reports when
+        the other alleles are left to alignment recovery — the first record of each read end)."""
+        ch = self._reads(first, n)
+        return ch.primaries() if primaries_only else ch
+
+    def _reads(self, first, n):
         L = lib()
         mate_len = np.zeros(2 * n, dtype=np.uint32)
         rec_cnt = np.zeros(n, dtype=np.uint32)

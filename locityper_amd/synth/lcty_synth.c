@@ -617,3 +617,47 @@ void synth_reads_fill(const synth_locus* L, uint64_t first, uint64_t n, const ui
         scratch_free(S);
     }
 }
+
+/* ---- haplotype-to-haplotype alignments ---------------------------------------------------------------------------
+ * The alignment of allele q (query) to allele r (reference) implied by the variants both were built from, as raw BAM
+ * CIGAR words with =, X, I, D (what `haplotypes.paf` holds for a real database). Returns the number of words; words
+ * beyond `cap` are counted but not written. n_matches / aln_len as in the PAF columns. */
+typedef struct { uint32_t* w; uint32_t n, cap; uint32_t last_op, last_len; uint32_t n_matches, aln_len; } hapcig;
+static void hc_flush(hapcig* h) {
+    if (!h->last_len) return;
+    if (h->n < h->cap) h->w[h->n] = (h->last_len << 4) | h->last_op;
+    h->n++; h->last_len = 0;
+}
+static void hc_push(hapcig* h, uint32_t op, uint32_t len) {
+    if (!len) return;
+    if (op == 7) h->n_matches += len;
+    h->aln_len += len;
+    if (h->last_len && h->last_op == op) { h->last_len += len; return; }
+    hc_flush(h);
+    h->last_op = op; h->last_len = len;
+}
+uint32_t synth_hap_cigar(const synth_locus* L, uint32_t q, uint32_t r, uint32_t* words, uint32_t cap, uint32_t* n_matches, uint32_t* aln_len) {
+    hapcig h; memset(&h, 0, sizeof(h)); h.w = words; h.cap = cap;
+    uint32_t p = 0;
+    for (uint32_t i = 0; i < L->n_vars; i++) {
+        const variant* v = &L->vars[i];
+        const int cq = carries(L, q, v), cr = carries(L, r, v);
+        if (!cq && !cr) continue;
+        if (v->pos < p) continue;
+        hc_push(&h, 7, v->pos - p); p = v->pos;
+        if (v->type == 0) { hc_push(&h, cq == cr ? 7 : 8, 1); p++; }
+        else if (v->type == 1) {
+            hc_push(&h, 7, 1); p++;
+            hc_push(&h, cq && cr ? 7 : (cq ? 1 : 2), v->len);
+        } else {
+            if (cq && !cr) hc_push(&h, 2, v->len);          /* the query lacks the stretch */
+            else if (cr && !cq) hc_push(&h, 1, v->len);
+            p += v->len;
+        }
+    }
+    hc_push(&h, 7, L->base_len - p);
+    hc_flush(&h);
+    if (n_matches) *n_matches = h.n_matches;
+    if (aln_len) *aln_len = h.aln_len;
+    return h.n;
+}
