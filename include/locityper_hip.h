@@ -287,12 +287,15 @@ int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* 
  * recover_and_group_alignments with weight >= min_weight (locs.rs:1255-1260). Call order:
  *     lcty_score_reads -> lcty_recover_alignments -> lcty_score_reads.
  * Transferred alignments become records of the batch (after the original records of their read end); nothing can be appended
- * to the batch afterwards. The aligner is an exact gap-affine dynamic programme (WFA2-lib computes the same optimum); the
- * device handles stretches between anchors of up to 255 bases, i.e. short reads, and fails with LCTY_ERR_UNSUPPORTED beyond. */
+ * to the batch afterwards. The aligner is an exact gap-affine dynamic programme (WFA2-lib computes the same optimum). Lanes
+ * hold stretches between anchors of up to 255 bases; a read pair with a transfer that needs more is repeated with larger lane
+ * scratch (2 047, then 16 383 bases; transferred CIGARs of up to 16 x the level-0 capacity) and LCTY_ERR_UNSUPPORTED beyond.
+ * lcty_recover_stats: level_pairs[3] = read pairs the last lcty_recover_alignments took at each of the three levels. */
 int32_t lcty_locus_set_hap_alns(lcty_locus* locus, uint32_t n_entries, const uint32_t* id1, const uint32_t* id2, const uint64_t* cigar_off,
                                 const uint32_t* cigar, const uint32_t* n_matches, const uint32_t* aln_len, uint32_t transfer_fails,
                                 double max_div);
 int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered);
+int32_t lcty_recover_stats(lcty_reads* reads, uint64_t* level_pairs);
 
 /* ---- solver stages (src/solvers/solve.rs:789-850, src/solvers/stoch.rs, src/model/assgn.rs) ----------------
  * The reference drives these stages from one Xoshiro256++ through rand ^0.10 adaptors that are not in its tree and

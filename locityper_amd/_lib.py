@@ -46,6 +46,7 @@ SIGNATURES = {
     "lcty_locus_window_weights": (I32, [VP, VP]),
     "lcty_locus_set_hap_alns": (I32, [VP, U32, VP, VP, VP, VP, VP, VP, U32, D]),
     "lcty_recover_alignments": (I32, [VP, P(U64)]),
+    "lcty_recover_stats": (I32, [VP, P(U64)]),
     "lcty_solver_default": (I32, [P(Solver), I32]),
     "lcty_chain_seeds": (I32, [U64, U64, VP]),
     "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),

@@ -177,6 +177,12 @@ class AllAlignments:
         self.score()
         return int(n.value)
 
+    def recover_stats(self):
+        """Read pairs the last recover() took at each of the three lane-scratch levels."""
+        out = (C.c_uint64 * 3)()
+        check(lib().lcty_recover_stats(self._h, out))
+        return [int(x) for x in out]
+
     def close(self):
         if self._h:
             lib().lcty_reads_destroy(self._h)

@@ -69,6 +69,8 @@ struct lcty_reads {
     uint64_t n_pairs = 0, n_bases = 0, n_recs = 0, n_cigar = 0;
     uint32_t max_recs_per_pair = 0;
     uint32_t max_cigar_per_pair = 0;
+    uint32_t max_cigar_per_rec = 0;
+    uint64_t recover_level_pairs[3] = {0, 0, 0};   // pairs the transfer kernel took at each scratch level (lcty_recover_stats)
     bool scored = false;
 
     lcty::DevBuf<uint32_t> d_mate_len;

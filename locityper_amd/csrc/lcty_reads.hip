@@ -158,6 +158,7 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         // host-side validation of the CSR structure (cheap, O(pairs + records))
         uint32_t max_recs = R->max_recs_per_pair;
         uint64_t max_cig = R->max_cigar_per_pair;
+        uint32_t max_rec_cig = R->max_cigar_per_rec;
         for (uint64_t m = 0; m < 2 * n; m++) {
             if (h->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
             if (h->mate_off[m + 1] < h->mate_off[m] + h->mate_len[m]) fail(LCTY_ERR_INVALID_INPUT, "mate offsets overlap");
@@ -178,6 +179,7 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
             for (uint64_t i = h->aln_off[r]; i < h->aln_off[r + 1]; i++) {
                 if (static_cast<uint64_t>(h->recs[i].cigar_rel) + h->recs[i].n_cigar > cw)
                     fail(LCTY_ERR_INVALID_INPUT, "CIGAR of record %llu leaves its pair's CIGAR range", (unsigned long long)i);
+                max_rec_cig = std::max(max_rec_cig, h->recs[i].n_cigar);
                 const uint32_t idx = static_cast<uint32_t>(i - h->aln_off[r]);
                 if (idx > 0 && (h->recs[i].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0) {
                     if (j2 == cnt) j2 = idx; else if (j3 == cnt) j3 = idx;
@@ -205,6 +207,7 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         R->n_pairs += n; R->n_bases += nb; R->n_recs += nr; R->n_cigar += nc;
         R->max_recs_per_pair = max_recs;
         R->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
+        R->max_cigar_per_rec = max_rec_cig;
         R->scored = false;
         R->good_valid = false; R->loc_table_valid = false;
     });

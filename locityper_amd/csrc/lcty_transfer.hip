@@ -54,17 +54,17 @@ struct PairScratch {
     uint8_t* seen;
     NewAln* news; uint32_t cap_new;
     uint32_t* words; uint32_t cap_words;
-    uint8_t* lanes;                                      // 64 x SCRATCH_BYTES
+    uint8_t* lanes;                                      // 64 x lane_scratch_bytes
 };
 
-__host__ __device__ inline size_t pair_scratch_bytes(uint32_t cap_alns, uint32_t hcap, uint32_t cap_new, uint32_t cap_words) {
+__host__ __device__ inline size_t pair_scratch_bytes(uint32_t cap_alns, uint32_t hcap, uint32_t cap_new, uint32_t cap_words, const Limits& lim) {
     size_t b = 0;
     b += sizeof(PAln) * cap_alns; b = (b + 15) & ~size_t(15);
     b += 8 * hcap + 8 * hcap;
     b += (cap_alns + 15) & ~15u;
     b += sizeof(NewAln) * cap_new; b = (b + 15) & ~size_t(15);
     b += 4 * static_cast<size_t>(cap_words); b = (b + 15) & ~size_t(15);
-    b += 64 * ((SCRATCH_BYTES + 15) & ~size_t(15));
+    b += 64 * lane_scratch_bytes(lim);
     return (b + 255) & ~size_t(255);
 }
 
@@ -171,6 +171,9 @@ __device__ inline bool pos_get(const PairScratch& P, uint32_t read_end, uint32_t
 
 struct TransferArgs {
     uint32_t cap_alns, hcap, cap_new, cap_words;
+    Limits lim; uint32_t last_level;                    // what a lane can hold at this level; 1: nothing behind it
+    const uint64_t* pair_list; uint64_t n_list;         // the pairs of this launch (NULL: all of the batch)
+    uint64_t* redo_list; unsigned long long* redo_n;    // pairs handed to the next level
     uint8_t* scratch; size_t scratch_stride;
     // outputs
     uint32_t* new_cnt;             // [R][2] transferred alignments per read end
@@ -187,12 +190,13 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
     const uint32_t lane = threadIdx.x;
     uint8_t* base = T.scratch + static_cast<size_t>(blockIdx.x) * T.scratch_stride;
     const PairScratch P = carve(base, T.cap_alns, T.hcap, T.cap_new, T.cap_words);
-    const Scratch LS = scratch_at(P.lanes + static_cast<size_t>(lane) * ((SCRATCH_BYTES + 15) & ~size_t(15)), T.flag);
+    Scratch LS = scratch_at(P.lanes + static_cast<size_t>(lane) * lane_scratch_bytes(T.lim), T.lim);
     const bool paired = L.is_paired != 0;
     __shared__ Prelim S;
-    __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop;
+    __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop, sh_redo;
 
-    for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
+    for (uint64_t ii = blockIdx.x; ii < T.n_list; ii += gridDim.x) {
+        const uint64_t p = T.pair_list ? T.pair_list[ii] : ii;
         if (lane == 0) { T.new_cnt[2 * p] = T.new_cnt[2 * p + 1] = 0; T.new_words[p] = 0; }
         if (!(R.recover_w[p] >= T.min_weight)) continue;                    // locs.rs:1257 (and not a candidate at all: -1)
         const uint64_t a0 = R.aln_off[p];
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
         if (lane == 0) {
             S.n_alns = 0;
             for (int e = 0; e < 2; e++) { S.passable[e] = NONE32T; S.best_edit[e] = NONE32T; S.best_lik[e] = -INFINITY; }
-            sh_n_new = 0; sh_words = 0;
+            sh_n_new = 0; sh_words = 0; sh_redo = 0;
             for (uint32_t e = 0; e < (paired ? 2u : 1u); e++) {
                 const uint32_t first = e ? j2 : 0u, last = e ? n_eff : split;
                 const uint32_t read_len = e ? len1 : len0;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
         const uint32_t n0 = S.n_alns;
 
         // ---- HapAlns::transfer_alignments (transfer.rs:70-140): sources in order, targets of a source across lanes ----
-        for (uint32_t i = 0; i < n0; i++) {
+        for (uint32_t i = 0; i < n0 && !sh_redo; i++) {
             if (P.seen[i]) continue;                                         // uniform: written before the barrier below
             __syncthreads();
             if (lane == 0) { P.seen[i] = 1; sh_fails = 0; sh_stop = 0; }
@@ -270,7 +274,8 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                 // 0 nothing, 1 similar position exists (index in `hit`), 2 failed transfer, 3 new alignment
                 uint32_t kind = 0, hit = NONE32T, target = 0;
                 PAln na; na.ln_prob = 0.0; na.start = 0; na.contig_end = 0; na.edit = 0; na.src = 0;
-                DCigar out; out.init(LS.cig_a);
+                DCigar out; out.init(LS.cig_a, T.lim.cigar_cap);
+                bool beyond = false;                                         // this transfer needs a lane with more scratch
                 if (t < nb) {
                     target = H.best_ids[H.best_off[s_contig] + t];
                     const uint32_t lo = min(s_contig, target), hi = max(s_contig, target);
@@ -299,11 +304,14 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                         const uint32_t qpos_at = dir ? pos[ci].y : pos[ci].x, rpos_at = dir ? pos[ci].x : pos[ci].y;
                         Q.target = H.seqs + H.seq_off[target];
                         Q.target_len = static_cast<uint32_t>(H.seq_off[target + 1] - H.seq_off[target]);
+                        LS.big = 0;
                         const uint32_t new_start = transfer_read(H.items + H.item_off[cell], H.item_off[cell + 1] - H.item_off[cell], dir, sa.start, ci,
                                                                  qpos_at, rpos_at, src, Q, out, LS);
-                        if (out.overflow) atomicMax(T.flag, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED));
                         const uint32_t diff = out.rlen > out.qlen ? out.rlen - out.qlen : out.qlen - out.rlen;
-                        if (diff > passable || out.rlen < 50) kind = 2;    // MIN_ALN_SIZE
+                        // the lengths of an end-to-end stretch do not depend on how it is aligned: a stand-in decides the length test
+                        if (out.overflow || (LS.big & 2u)) beyond = true;
+                        else if (diff > passable || out.rlen < 50) kind = 2;    // MIN_ALN_SIZE
+                        else if (LS.big & 1u) beyond = true;
                         else {
                             kind = 3;
                             // Alignment::new + the scoring of push(): the CIGAR goes through the same counting as a record's
@@ -319,6 +327,21 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                 const unsigned long long fail_mask = __ballot(kind == 2);
                 const uint32_t fails_before = sh_fails + static_cast<uint32_t>(__popcll(fail_mask & ((1ull << lane) - 1ull)));
                 const bool alive = t < nb && fails_before <= H.transfer_fails;
+                // the first transfer that is beyond this level decides (what is behind it may depend on its outcome): if the loop gets
+                // that far, the whole pair goes to the next level
+                const unsigned long long beyond_mask = __ballot(beyond);
+                if (beyond_mask) {
+                    const int first = __ffsll(static_cast<long long>(beyond_mask)) - 1;
+                    if (__shfl(alive ? 1 : 0, first)) {
+                        if (lane == 0) {
+                            sh_redo = 1; sh_stop = 1;
+                            if (T.last_level) atomicMax(T.flag, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED));
+                            else T.redo_list[atomicAdd(T.redo_n, 1ull)] = p;
+                        }
+                        __syncthreads();
+                        break;
+                    }
+                }
                 if (alive && kind == 1 && hit < n0) P.seen[hit] = 1;
                 const bool fresh = alive && kind == 3;
                 const unsigned long long fresh_mask = __ballot(fresh);
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
         __syncthreads();
 
         // ---- hand the transferred alignments over: per pair a contiguous run, read end 0 first, push order inside an end ----
-        const uint32_t n_new = sh_n_new, n_words = sh_words;
+        const uint32_t n_new = sh_redo ? 0u : sh_n_new, n_words = sh_words;
         if (n_new) {
             __shared__ unsigned long long rec_at, word_at0;
             if (lane == 0) {
@@ -537,47 +560,80 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         H.seqs = loc->d_seqs.p; H.seq_off = loc->d_seq_off.p;
 
         DevBuf<uint32_t> d_new_cnt, d_new_words, d_flag;
-        DevBuf<uint64_t> d_rec_at, d_word_at;
-        DevBuf<unsigned long long> d_cursors;
-        d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(2);
-        uint32_t cap_new = std::min<uint32_t>(std::max<uint32_t>(4 * A, 64), 1u << 15);
-        // every record can reach every other contig once; beyond 1.5 G records (24 GB) the first launch only counts and the second one fits
-        uint64_t arena_recs = std::min<uint64_t>(reads->n_recs * static_cast<uint64_t>(A > 1 ? A - 1 : 1) + 1024, 1500ull << 20);
-        uint64_t arena_words = 4 * arena_recs;
-        DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords; DevBuf<uint8_t> d_scratch;
-        unsigned long long cursors[2] = {0, 0};
+        DevBuf<uint64_t> d_rec_at, d_word_at, d_list_a, d_list_b;
+        DevBuf<unsigned long long> d_cursors;                                      // records, words, pairs for the next level
+        d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(3);
+        d_list_a.alloc(R); d_list_b.alloc(R);
+        // Levels of lane scratch. Level 0 is sized for the reads of the batch (short reads: transferred CIGARs of <= 192 items,
+        // stretches between anchors of <= 255 bases) and takes every pair at full occupancy; a pair with a transfer that needs more
+        // is repeated at the next level, which has fewer lanes in flight.
+        const uint32_t rec_cigar = std::max<uint32_t>(reads->max_cigar_per_rec, 1);
+        std::vector<Limits> levels;
+        {
+            Limits l0; l0.cigar_cap = std::max<uint32_t>(192, 2 * rec_cigar + 128); l0.dp_dim = 255; l0.dp_cells = 32768;
+            Limits l1; l1.cigar_cap = std::max<uint32_t>(2048, 4 * l0.cigar_cap); l1.dp_dim = 2047; l1.dp_cells = 1u << 20;
+            Limits l2; l2.cigar_cap = 4 * l1.cigar_cap; l2.dp_dim = 16383; l2.dp_cells = 1u << 26;
+            levels = {l0, l1, l2};
+            if (const char* e = std::getenv("LCTY_TRANSFER_LEVELS")) levels.resize(std::min<size_t>(levels.size(), std::max(1, std::atoi(e))));
+        }
+        uint64_t scratch_budget = 24ull << 30;
+        if (const char* e = std::getenv("LCTY_TRANSFER_SCRATCH_MB")) scratch_budget = std::max<uint64_t>(64, std::strtoull(e, nullptr, 10)) << 20;
         // one wavefront per workgroup, 141 VGPRs: three wavefronts per SIMD
         uint32_t waves = 12;
         if (const char* e = std::getenv("LCTY_TRANSFER_WAVES")) waves = std::max(1, std::atoi(e));
-        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>(R, static_cast<uint64_t>(ctx->props.multiProcessorCount) * waves));
+        const uint32_t max_blocks = static_cast<uint32_t>(ctx->props.multiProcessorCount) * waves;
+
+        uint32_t cap_new = std::min<uint32_t>(std::max<uint32_t>(4 * A, 64), 1u << 15);
+        const uint32_t words_per_new = std::max<uint32_t>(24, std::min<uint32_t>(levels[0].cigar_cap, rec_cigar + 32));
+        // every record can reach every other contig once; beyond 1.5 G records (24 GB) the first launch only counts and the second one fits
+        uint64_t arena_recs = std::min<uint64_t>(reads->n_recs * static_cast<uint64_t>(A > 1 ? A - 1 : 1) + 1024, 1500ull << 20);
+        uint64_t arena_words = std::min<uint64_t>(arena_recs * std::max<uint32_t>(4, rec_cigar + 8), 6ull << 30);
+        DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords; DevBuf<uint8_t> d_scratch;
+        unsigned long long cursors[3] = {0, 0, 0};
         for (int attempt = 0;; attempt++) {
             if (attempt > 12) fail(LCTY_ERR_RUNTIME, "alignment recovery: arenas keep overflowing");
             const uint32_t cap_alns = reads->max_recs_per_pair + cap_new;
             uint32_t hcap = 64;
             while (hcap < 2 * cap_alns + 2) hcap <<= 1;
-            const uint32_t cap_words = cap_new * 24;
-            const size_t stride = pair_scratch_bytes(cap_alns, hcap, cap_new, cap_words);
-            d_scratch.alloc(stride * blocks);
+            const uint64_t cap_words64 = static_cast<uint64_t>(cap_new) * words_per_new;
+            const uint32_t cap_words = static_cast<uint32_t>(std::min<uint64_t>(cap_words64, 1u << 30));
             d_xrecs.alloc(arena_recs); d_xwords.alloc(arena_words);
             d_flag.zero(s); d_cursors.zero(s);
-            TransferArgs T{};
-            T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
-            T.scratch = d_scratch.p; T.scratch_stride = stride;
-            T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
-            T.out_recs = d_xrecs.p; T.out_recs_cap = arena_recs; T.out_words = d_xwords.p; T.out_words_cap = arena_words;
-            T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.min_weight = loc->prm.min_weight;
-            ctx->timed(LCTY_K_TRANSFER, [&] {
-                hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
-            });
-            LCTY_HIP(hipGetLastError());
             uint32_t flag = 0;
-            d_flag.download(&flag, 1, s);
-            d_cursors.download(cursors, 2, s);
-            LCTY_HIP(hipStreamSynchronize(s));
+            reads->recover_level_pairs[0] = reads->recover_level_pairs[1] = reads->recover_level_pairs[2] = 0;
+            const uint64_t* list = nullptr;
+            uint64_t n_list = R;
+            for (size_t lv = 0; lv < levels.size() && n_list; lv++) {
+                const Limits lim = levels[lv];
+                const size_t stride = pair_scratch_bytes(cap_alns, hcap, cap_new, cap_words, lim);
+                const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>({n_list, max_blocks, scratch_budget / stride})));
+                if (d_scratch.n < stride * blocks) d_scratch.alloc(stride * blocks);
+                TransferArgs T{};
+                T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
+                T.lim = lim; T.last_level = lv + 1 == levels.size();
+                T.pair_list = list; T.n_list = n_list;
+                uint64_t* next = (lv % 2 == 0) ? d_list_a.p : d_list_b.p;
+                T.redo_list = next; T.redo_n = d_cursors.p + 2;
+                T.scratch = d_scratch.p; T.scratch_stride = stride;
+                T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
+                T.out_recs = d_xrecs.p; T.out_recs_cap = arena_recs; T.out_words = d_xwords.p; T.out_words_cap = arena_words;
+                T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.min_weight = loc->prm.min_weight;
+                LCTY_HIP(hipMemsetAsync(d_cursors.p + 2, 0, sizeof(unsigned long long), s));
+                ctx->timed(LCTY_K_TRANSFER, [&] {
+                    hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
+                });
+                LCTY_HIP(hipGetLastError());
+                d_flag.download(&flag, 1, s);
+                d_cursors.download(cursors, 3, s);
+                LCTY_HIP(hipStreamSynchronize(s));
+                if (flag != 0) break;
+                list = next; n_list = cursors[2];
+                reads->recover_level_pairs[std::min<size_t>(lv, 2)] = T.n_list;
+            }
             if (flag == 0) break;
             if (flag == LCTY_ERR_UNSUPPORTED)
-                fail(LCTY_ERR_UNSUPPORTED, "alignment recovery: a stretch between anchors is longer than %u bases (or a transferred CIGAR has more than %u "
-                     "operations): the device aligner handles short reads", DP_MAX_DIM, CIGAR_CAP);
+                fail(LCTY_ERR_UNSUPPORTED, "alignment recovery: a stretch between anchors beyond %u bases / %u cells, or a transferred CIGAR of more than %u "
+                     "operations", levels.back().dp_dim, levels.back().dp_cells, levels.back().cigar_cap);
             if (flag != 1) fail(static_cast<int32_t>(flag), "alignment recovery failed on the device");
             cap_new = std::min<uint32_t>(cap_new * 4, 1u << 20);                 // some arena was too small: larger, again
             arena_recs = std::max<uint64_t>(arena_recs * 2, cursors[0] + 1024); arena_words = std::max<uint64_t>(arena_words * 2, cursors[1] + 1024);
@@ -620,6 +676,13 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         reads->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
         reads->scored = false; reads->good_valid = false; reads->loc_table_valid = false;
         (void)total_words;
+    });
+}
+
+int32_t lcty_recover_stats(lcty_reads* reads, uint64_t* level_pairs) {
+    return guarded([&] {
+        if (!reads || !level_pairs) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        for (int i = 0; i < 3; i++) level_pairs[i] = reads->recover_level_pairs[i];
     });
 }
 

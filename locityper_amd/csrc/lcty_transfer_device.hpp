@@ -17,8 +17,22 @@ constexpr int PEN_X = 4, PEN_O = 6, PEN_E = 1;             // Penalties::default
 constexpr int MAX_STEPS = 10000;                            // alignment_steps(6), wfa.rs:103-117
 constexpr int INF32 = 1 << 28;
 constexpr int DP_DROPPED = -(1 << 30);
-constexpr uint32_t DP_MAX_DIM = 255, DP_MAX_CELLS = 32768;  // per-lane scratch; larger stretches raise LCTY_ERR_UNSUPPORTED
-constexpr uint32_t CIGAR_CAP = 192;                         // items of a transferred CIGAR
+constexpr int DP_TOO_BIG = DP_DROPPED + 1;                  // the stretch does not fit the lane's scratch at this level
+
+// What a lane's scratch holds. The transfer kernel runs in levels: a read pair whose transfers need more than the level
+// offers is handed to the next level (fewer lanes in flight, larger scratch); beyond the last level LCTY_ERR_UNSUPPORTED.
+struct Limits {
+    uint32_t cigar_cap;        // items of a transferred CIGAR
+    uint32_t dp_dim;           // longest side of a stretch the aligner takes
+    uint32_t dp_cells;         // (n + 1) * (m + 1) direction bytes
+};
+__host__ __device__ inline size_t lane_scratch_bytes(const Limits& m) {
+    size_t b = static_cast<size_t>(m.cigar_cap) * 8 * 2;                       // two CIGARs
+    b += 3 * (static_cast<size_t>(m.dp_dim) + 1) * 12;                         // two rolling rows + the last column
+    b += (2 * static_cast<size_t>(m.dp_dim) + 4 + 15) & ~size_t(15);           // operations of one alignment
+    b += m.dp_cells;
+    return (b + 15) & ~size_t(15);
+}
 
 __device__ __forceinline__ bool cons_q(uint32_t op) { return op == 0 || op == OP_EQ || op == OP_X || op == OP_I || op == OP_S; }
 __device__ __forceinline__ bool cons_r(uint32_t op) { return op == 0 || op == OP_EQ || op == OP_X || op == OP_D; }
@@ -29,24 +43,24 @@ __device__ __forceinline__ uint32_t op_invert(uint32_t op) {                  //
 // Cigar under construction (cigar.rs:203-208): items {op, len} in the lane's scratch
 struct DCigar {
     uint2* t;
-    uint32_t n, rlen, qlen;
-    bool overflow;
-    __device__ void init(uint2* buf) { t = buf; n = 0; rlen = qlen = 0; overflow = false; }
+    uint32_t n, rlen, qlen, cap;
+    bool overflow;                                                           // items were dropped: the lengths are still right
+    __device__ void init(uint2* buf, uint32_t capacity) { t = buf; cap = capacity; n = 0; rlen = qlen = 0; overflow = false; }
     __device__ void clear() { n = 0; rlen = qlen = 0; }
     __device__ void push_unchecked(uint32_t op, uint32_t len) {              // cigar.rs:343-352
         if (cons_q(op)) qlen += len;
         if (cons_r(op)) rlen += len;
-        if (n < CIGAR_CAP) t[n++] = make_uint2(op, len); else overflow = true;
+        if (n < cap) t[n++] = make_uint2(op, len); else overflow = true;
     }
     __device__ void push_checked(uint32_t op, uint32_t len) {                // cigar.rs:355-363
         if (cons_q(op)) qlen += len;
         if (cons_r(op)) rlen += len;
         if (n && t[n - 1].x == op) t[n - 1].y += len;
-        else if (n < CIGAR_CAP) t[n++] = make_uint2(op, len);
+        else if (n < cap) t[n++] = make_uint2(op, len);
         else overflow = true;
     }
     __device__ void append_items(const uint2* it, uint32_t k) {              // tuples.extend_from_slice: lengths untouched
-        for (uint32_t i = 0; i < k; i++) { if (n < CIGAR_CAP) t[n++] = it[i]; else overflow = true; }
+        for (uint32_t i = 0; i < k; i++) { if (n < cap) t[n++] = it[i]; else overflow = true; }
     }
 };
 
@@ -66,25 +80,25 @@ struct Seqs {
 
 // per-lane scratch
 struct Scratch {
-    uint2* cig_a;          // [CIGAR_CAP]
-    uint2* cig_b;          // [CIGAR_CAP] (optimize)
-    uint8_t* ops;          // [2 * DP_MAX_DIM + 4] aligner output, reversed
-    uint8_t* dirs;         // [DP_MAX_CELLS]
-    int32_t* rows;         // [2][DP_MAX_DIM + 1][3]
-    int32_t* lastcol;      // [DP_MAX_DIM + 1][3]
-    uint32_t* err;         // kernel-wide error flag
+    uint2* cig_a;          // [cigar_cap]
+    uint2* cig_b;          // [cigar_cap] (optimize)
+    uint8_t* ops;          // [2 * dp_dim + 4] aligner output, reversed
+    uint8_t* dirs;         // [dp_cells]
+    int32_t* rows;         // [2][dp_dim + 1][3]
+    int32_t* lastcol;      // [dp_dim + 1][3]
+    Limits lim;
+    uint32_t big;          // bit 0: an end-to-end stretch was too big (placeholder of the right lengths), bit 1: an ends-free one
 };
-constexpr size_t SCRATCH_BYTES = CIGAR_CAP * 8 * 2 + 1024 + DP_MAX_CELLS + 2 * (DP_MAX_DIM + 1) * 12 + (DP_MAX_DIM + 1) * 12;
 
-__device__ inline Scratch scratch_at(uint8_t* base, uint32_t* err) {
+__device__ inline Scratch scratch_at(uint8_t* base, const Limits& lim) {
     Scratch s;
-    s.cig_a = reinterpret_cast<uint2*>(base); base += CIGAR_CAP * 8;
-    s.cig_b = reinterpret_cast<uint2*>(base); base += CIGAR_CAP * 8;
-    s.rows = reinterpret_cast<int32_t*>(base); base += 2 * (DP_MAX_DIM + 1) * 12;
-    s.lastcol = reinterpret_cast<int32_t*>(base); base += (DP_MAX_DIM + 1) * 12;
-    s.ops = base; base += 1024;
+    s.cig_a = reinterpret_cast<uint2*>(base); base += static_cast<size_t>(lim.cigar_cap) * 8;
+    s.cig_b = reinterpret_cast<uint2*>(base); base += static_cast<size_t>(lim.cigar_cap) * 8;
+    s.rows = reinterpret_cast<int32_t*>(base); base += 2 * (static_cast<size_t>(lim.dp_dim) + 1) * 12;
+    s.lastcol = reinterpret_cast<int32_t*>(base); base += (static_cast<size_t>(lim.dp_dim) + 1) * 12;
+    s.ops = base; base += (2 * static_cast<size_t>(lim.dp_dim) + 4 + 15) & ~size_t(15);
     s.dirs = base;
-    s.err = err;
+    s.lim = lim; s.big = 0;
     return s;
 }
 
@@ -114,11 +128,16 @@ __device__ inline int align_simple(const Seqs& S, uint32_t i1, uint32_t n, uint3
 // Gap-affine alignment of reference [i1, i1+n) and query [j1, j1+m); mb = match bonus (0 global aligner, 2 semi-global one,
 // wfa.rs:194-197); mode 0 end to end, 1 free begin of both (LEFT), 2 free end of both (RIGHT). Writes the operations in
 // REVERSE order into sc.ops and returns the penalty, or DP_DROPPED (wfa.rs:262-266: status != 0).
-__device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, int mb, int mode, const Scratch& sc, uint32_t* n_ops) {
-    if (n > DP_MAX_DIM || m > DP_MAX_DIM || (n + 1) * (m + 1) > DP_MAX_CELLS) { atomicMax(sc.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); return DP_DROPPED; }
+__device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, int mb, int mode, Scratch& sc, uint32_t* n_ops) {
+    // end to end, every alignment pays for the difference of the lengths: beyond MAX_STEPS the aligner gives up whatever the bases are
+    if (mode == 0 && n != m && PEN_O + static_cast<int>(n > m ? n - m : m - n) * PEN_E > MAX_STEPS) return DP_DROPPED;
+    if (n > sc.lim.dp_dim || m > sc.lim.dp_dim || (static_cast<uint64_t>(n) + 1) * (m + 1) > sc.lim.dp_cells) {
+        sc.big |= mode == 0 ? 1u : 2u;
+        return DP_TOO_BIG;
+    }
     const uint32_t W = m + 1;
     int32_t* prev = sc.rows;
-    int32_t* cur = sc.rows + (DP_MAX_DIM + 1) * 3;
+    int32_t* cur = sc.rows + (sc.lim.dp_dim + 1) * 3;
     for (uint32_t a = 0; a <= n; a++) {
         for (uint32_t b = 0; b <= m; b++) {
             int32_t cm = INF32, cd = INF32, ci = INF32;
@@ -205,10 +224,11 @@ __device__ __forceinline__ uint32_t op_from_char(uint8_t ch) { return ch == '=' 
 
 // Aligner::align::<LEFT_CLIPPING> (wfa.rs:254-299). semiglobal: 0 global aligner, 1 LEFT, 2 RIGHT free ends
 __device__ inline int aligner_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, int semiglobal, bool left_clipping, DCigar& cg,
-                                    const Scratch& sc) {
+                                    Scratch& sc) {
     uint32_t n_ops = 0;
     const int pen = dp_align(S, i1, n, j1, m, semiglobal ? max(1, PEN_X / 2) : 0, semiglobal, sc, &n_ops);
-    if (pen == DP_DROPPED) return align_simple(S, i1, n, j1, m, cg);
+    // DP_TOO_BIG: a stand-in that consumes both stretches completely, as any end-to-end alignment does — the caller looks at sc.big
+    if (pen == DP_DROPPED || pen == DP_TOO_BIG) return align_simple(S, i1, n, j1, m, cg);
     bool no_matches_yet = true;
     for (uint32_t t = n_ops; t-- > 0;) {                                     // sc.ops is reversed
         const uint32_t op = op_from_char(sc.ops[t]);
@@ -229,7 +249,7 @@ __device__ inline int aligner_align(const Seqs& S, uint32_t i1, uint32_t n, uint
 }
 
 // smart_align (wfa.rs:301-347); max_gap 0xFFFFFFFF = the `()` threshold
-__device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, uint32_t max_gap, DCigar& cg, const Scratch& sc) {
+__device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, uint32_t max_gap, DCigar& cg, Scratch& sc) {
     const uint32_t jump1 = i2 - i1, jump2 = j2 - j1;
     if (jump1 > 0 && jump2 > 0) {
         const uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;      // wfa.rs:212
@@ -251,7 +271,7 @@ __device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint3
 }
 
 // align_ends::<LEFT> (wfa.rs:349-365)
-__device__ inline void align_ends(bool left, const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, DCigar& cg, const Scratch& sc) {
+__device__ inline void align_ends(bool left, const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, DCigar& cg, Scratch& sc) {
     if (i1 == i2) { cg.push_unchecked(OP_I, j2 - j1); return; }
     aligner_align(S, i1, i2 - i1, j1, j2 - j1, left ? 1 : 2, left, cg, sc);
     if (!left) {
@@ -267,10 +287,10 @@ __device__ inline void align_ends(bool left, const Seqs& S, uint32_t i1, uint32_
 
 // Cigar::optimize (cigar.rs:1167-1237). As upstream, the reference positions are counted from the start of the CIGAR while the
 // sequence handed in is the whole target haplotype (cigar.rs:1362-1364): kept as written.
-__device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_gap, uint32_t anchor_size, const Scratch& sc) {
+__device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_gap, uint32_t anchor_size, Scratch& sc) {
     uint32_t i = 0, qpos1 = 0, rpos1 = 0, qpos2 = 0, rpos2 = 0;
     uint32_t flag = 0;
-    DCigar nc; nc.init(sc.cig_b);
+    DCigar nc; nc.init(sc.cig_b, sc.lim.cigar_cap);
     bool have = false;
     for (uint32_t j = 0; j < self.n; j++) {
         const uint32_t op = self.t[j].x, len = self.t[j].y;
@@ -339,7 +359,7 @@ struct SrcCigar {
 // Cigar::transfer_alignment::<false> as called by transfer_read_alignment (cigar.rs:1248-1384): anchor size 5, no maximum gap.
 // jk: items of the haplotype-to-haplotype CIGAR (query = lower contig id), dir_jk 0 = QueryToRef, 1 = RefToQuery.
 __device__ inline uint32_t transfer_read(const uint2* jk_items, uint32_t jk_n, int dir_jk, uint32_t start_j, uint32_t off_ix, uint32_t off_qpos,
-                                         uint32_t off_rpos, const SrcCigar& ij, const Seqs& S, DCigar& out, const Scratch& sc) {
+                                         uint32_t off_rpos, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc) {
     const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3, FULL_MATCH_PADDING = 3;
     out.clear();
     uint32_t jk = off_ix;

@@ -622,33 +622,91 @@ def test_alignment_recovery_single_end_and_empty(gpu_ctx):
     assert aa.recover() == 0
 
 
+def _noisy_read(rng, hap, start, length, err=0.03):
+    """A read copied from hap[start:start+length] with substitutions / insertions / deletions and its true CIGAR."""
+    acgt = b"ACGT"
+    seq = bytearray(); ops = []
+    def push(op, n=1):
+        if ops and ops[-1][0] == op: ops[-1][1] += n
+        else: ops.append([op, n])
+    i = start
+    while i < start + length:
+        r = rng.random()
+        if r < err / 3:
+            seq.append(int(rng.choice([c for c in acgt if c != hap[i]]))); push("X"); i += 1
+        elif r < 2 * err / 3:
+            k = int(rng.integers(1, 4)); seq.extend(rng.choice(list(acgt), k).tolist()); push("I", k)
+        elif r < err and ops and ops[-1][0] == "=":
+            k = int(rng.integers(1, 4)); push("D", k); i += k
+        else:
+            seq.append(hap[i]); push("="); i += 1
+    while ops and ops[-1][0] in "DI":                                         # an alignment ends on an aligned base
+        op, n = ops.pop()
+        if op == "I": del seq[-n:]
+    return bytes(seq), "".join(f"{n}{op}" for op, n in ops)
+
+
 @pytest.mark.gpu
-def test_alignment_recovery_refuses_what_it_cannot_hold(gpu_ctx):
-    """A stretch between anchors longer than the per-lane aligner holds is an error, never a silently different
-    alignment; recover() without haplotype alignments is an error too."""
+def test_alignment_recovery_large_stretches_and_long_reads(gpu_ctx):
+    """Structural differences between the alleles (a 400-base insertion, a 700-base deletion) and long noisy reads: transfers
+    whose stretches between anchors do not fit the first level of lane scratch are repeated at the next one, with the same result
+    as the oracle (which has no limits)."""
+    import os
     from tests.test_oracle_transfer import make_haps, hap_alns_for
     rng = np.random.default_rng(31)
-    base = make_haps(rng, 1, 2400)[0]
+    base = make_haps(rng, 1, 3000)[0]
     ins = bytes(rng.choice(list(b"ACGT"), 400).tolist())
-    haps = [base, base[:1000] + ins + base[1000:], base[:700] + base[705:]]
+    haps = [base, base[:1000] + ins + base[1000:], base[:700] + base[705:], base[:1500] + base[2200:]]
+    pairs = []
+    for i in range(60):
+        src = i % 4
+        p1 = int(rng.integers(800, 1100)) if i % 2 == 0 else int(rng.integers(100, len(haps[src]) - 700))
+        p2 = p1 + int(rng.integers(200, 400))
+        pairs.append({"seq1": haps[src][p1:p1 + 150].decode(), "seq2": haps[src][p2:p2 + 150].decode(),
+                      "recs": [(src, p1, 0, "150="), (src, p2, M2 | REV, "150=")]})
+    n_rec, aa, oa = _recovery_case(gpu_ctx, haps, pairs, make_bg(), tf=3)
+    # the long stretches all end in alignments whose reference and read lengths differ too much: the length test needs no aligner
+    assert aa.recover_stats() == [len(pairs), 0, 0]
+
+    # long single-end reads with 3 % errors (CIGARs of hundreds of operations). Allele 3 carries a 320-base run of A where the
+    # others have no A at all: nothing in there can anchor, a read across it has a 320 x 320 stretch for the aligner -> second level
+    haps = make_haps(rng, 3, 6000)                                             # the oracle's aligner takes up to 64 M cells
+    haps = [h[:3900] + h[3900:4400].replace(b"A", b"C") + h[4400:] for h in haps]
+    haps.append(haps[0][:4000] + b"A" * 320 + haps[0][4320:])
+    reads = []
+    for i in range(40):
+        src = int(rng.integers(0, 4))
+        ln = int(rng.integers(1200, 3000))
+        p1 = int(rng.integers(50, len(haps[src]) - ln - 60)) if i % 4 else int(rng.integers(2800, 3900))
+        ln = min(ln, len(haps[src]) - p1 - 60)
+        seq, cg = _noisy_read(rng, haps[src], p1, ln)
+        reads.append({"seq1": seq.decode(), "seq2": None, "recs": [(src, p1, REV if i % 2 else 0, cg)]})
+    bg = make_bg(technology=cdefs.TECH_NANOPORE, paired=False, window=1000, neighb=1000)
+    bg.edit_alpha, bg.edit_beta = 6.0, 180.0                                   # error rate of the reads above
+    n_rec, aa, oa = _recovery_case(gpu_ctx, haps, reads, bg, tf=3)
+    st = aa.recover_stats()
+    assert n_rec >= 60 and oa.n_good >= 30 and st[0] == len(reads) and st[1] > 0 and st[2] == 0, (n_rec, st)
+    # one level only: the library refuses, it never answers differently
+    os.environ["LCTY_TRANSFER_LEVELS"] = "1"
+    try:
+        with pytest.raises(_lib.LocityperError) as ei:
+            _recovery_case(gpu_ctx, haps, reads, bg, tf=3)
+        assert ei.value.code == cdefs.ERR_UNSUPPORTED
+    finally:
+        del os.environ["LCTY_TRANSFER_LEVELS"]
+
+
+@pytest.mark.gpu
+def test_alignment_recovery_needs_haplotype_alignments(gpu_ctx):
+    from tests.test_oracle_transfer import make_haps
+    rng = np.random.default_rng(37)
+    haps = make_haps(rng, 3, 2400)
     bg = make_bg()
     p = api.resolve_params(api.default_params(), bg)
     seqs, seq_off, cflat, cnt_off, _ = locus_arrays([bytearray(h) for h in haps], 25)
     loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
-    # a read spanning the insertion point of allele 0 -> on allele 1 its two halves are 400 bases apart
-    pairs = [{"seq1": base[930:1080].decode(), "seq2": base[1300:1450].decode(),
-              "recs": [(0, 930, 0, "150="), (0, 1300, M2 | REV, "150=")]}]
-    ch = ReadsChunk.from_pairs(pairs)
+    ch = ReadsChunk.from_pairs([{"seq1": haps[0][930:1080].decode(), "seq2": haps[0][1300:1450].decode(),
+                                 "recs": [(0, 930, 0, "150="), (0, 1300, M2 | REV, "150=")]}])
     aa = api.AllAlignments.load(loc, ch)
     with pytest.raises(_lib.LocityperError):
-        aa.recover()                                                          # no haplotype alignments yet
-    loc.set_hap_alns(hap_alns_for(haps).entries, transfer_fails=3, max_div=0.5)
-    aa = api.AllAlignments.load(loc, ch)
-    try:
         aa.recover()
-    except _lib.LocityperError as e:
-        assert e.code == cdefs.ERR_UNSUPPORTED
-    else:
-        # the oracle has no such limit: if the kernel went through, it must agree
-        ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
-        compare_gpu_to_oracle(aa, ol.load_recover(ch, hap_alns_for(haps)), index_fields=())
