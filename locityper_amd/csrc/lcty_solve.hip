@@ -83,7 +83,7 @@ struct SolveView {
     const uint8_t* gc;
     const double* win_weight;
     const double* lut;              // [LCTY_GC_BINS][lut_depth]
-    uint32_t lut_depth;
+    uint32_t lut_depth, lut_shift;  // lut_depth = 1 << lut_shift
     const DepthNB* depth_nb;
     uint32_t n_alt;
     // reads
@@ -468,36 +468,40 @@ struct Chain {
     // depth_lik_diff (assgn.rs:259-284) = sum of atomic_depth_lik_diff (244-254) over the four windows. All operands
     // are fetched before any of them is used: one LDS round trip, then twelve independent L2 gathers.
     __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {
+        // the change of every window's depth, windows that coincide folded into the first of them (the if-chains of
+        // assgn.rs:259-284 written as sums of comparisons: no divergent paths)
+        const int32_t e21 = w2 == w1, e31 = w3 == w1, e41 = w4 == w1;
+        const int32_t e32 = w3 == w2, e42 = w4 == w2, e43 = w4 == w3;
         int32_t c[4];
-        c[0] = -1;
-        if (w2 == w1) { c[0] -= 1; c[1] = 0; } else c[1] = -1;
-        if (w3 == w1) { c[0] += 1; c[2] = 0; } else if (w3 == w2) { c[1] += 1; c[2] = 0; } else c[2] = 1;
-        if (w4 == w1) { c[0] += 1; c[3] = 0; } else if (w4 == w2) { c[1] += 1; c[3] = 0; } else if (w4 == w3) { c[2] += 1; c[3] = 0; } else c[3] = 1;
+        c[0] = -1 - e21 + e31 + e41;
+        c[1] = e21 ? 0 : -1 + e32 + e42;
+        c[2] = (e31 | e32) ? 0 : 1 + e43;
+        c[3] = (e41 | e42 | e43) ? 0 : 1;
         const uint32_t w[4] = {w1, w2, w3, w4};
         uint32_t word[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) word[i] = wd[w[i]];
         double weight[4], vnew[4], vold[4];
-        uint32_t deepest[4];
+        uint32_t deepest = 0;
+        const uint32_t last = V->lut_depth - 1;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t d_old = word[i] & DEPTH_MASK, row = (word[i] >> 25) * V->lut_depth;
+            const uint32_t d_old = word[i] & DEPTH_MASK, row = (word[i] >> 25) << V->lut_shift;
             const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + c[i]);
-            deepest[i] = max(d_new, d_old);
             weight[i] = ww[w[i]];
-            vnew[i] = V->lut[row + min(d_new, V->lut_depth - 1)];
-            vold[i] = V->lut[row + min(d_old, V->lut_depth - 1)];
+            vnew[i] = V->lut[row + min(d_new, last)];
+            vold[i] = V->lut[row + min(d_old, last)];
+            const bool live = c[i] != 0 && weight[i] != 0.0;                 // c == 0: no change; weight 0: WindowDistr::TRIVIAL
+            deepest = max(deepest, live ? max(d_new, d_old) : 0u);
         }
         double sum = 0.0;
-        bool over = false;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const bool live = c[i] != 0 && weight[i] != 0.0;                 // c == 0: no change; weight 0: WindowDistr::TRIVIAL
-            over |= live && deepest[i] >= V->lut_depth;
+            const bool live = c[i] != 0 && weight[i] != 0.0;
             const double term = live ? weight[i] * vnew[i] - weight[i] * vold[i] : 0.0;
             sum = i == 0 ? term : sum + term;
         }
-        if (over) atomicMax(V->overflow, 1u);                               // every chain of the batch is repeated
+        if (deepest > last) atomicMax(V->overflow, 1u);                     // every chain of the batch is repeated
         return sum;
     }
 };
@@ -676,36 +680,38 @@ void solve_loop_kernel(const SolveView V) {
                 // lane b * S + j keeps the j-th pick of iteration b
                 uint32_t my_pick = NONE32S;
                 {
-                    // fast path: the nb * S draws of the batch go to their lanes as they are; the sample of an iteration
-                    // almost never repeats an index (S^2 / 2 nnt), and when one does the batch is redone by the book
-                    const Xoshiro saved = rng;
-                    uint64_t mine = 0;
-                    const uint32_t n_draws = nb * S;
-                    for (uint32_t kk = 0; kk < n_draws; kk++) {
-                        const uint64_t v = rng.next();                         // scalar unit; lane kk keeps it
-                        if (lane == kk) mine = v;
+                    // one draw of the chain's generator per iteration (scalar unit); the S picks of an iteration are counter draws
+                    // under that key, one per lane. A sample almost never repeats an index (S^2 / 2 nnt); when one does, the
+                    // iteration's picks are redone in order, repeats skipped, as the rule says
+                    uint64_t key = 0;
+                    for (uint32_t b = 0; b < nb; b++) {
+                        const uint64_t v = rng.next();
+                        if (grp == b) key = v;
                     }
-                    const uint32_t idx = static_cast<uint32_t>(__umul64hi(mine, static_cast<uint64_t>(nnt)));
+                    const uint32_t idx = static_cast<uint32_t>(__umul64hi(counter_u64(key, jj), static_cast<uint64_t>(nnt)));
                     bool dup = false;
                     for (uint32_t d = 1; d < S; d++) {
                         const uint32_t other = static_cast<uint32_t>(__shfl_up(static_cast<int>(idx), d));
                         dup |= jj >= d && other == idx;
                     }
-                    if (__ballot(dup && lane < n_draws) == 0ull) {
-                        if (lane < n_draws) my_pick = idx;
-                    } else {
-                        rng = saved;
-                        for (uint32_t b = 0; b < nb; b++) {
-                            for (uint32_t j = 0; j < S; j++) {
-                                uint32_t pick;
-                                bool again;
-                                do {
-                                    pick = static_cast<uint32_t>(rng.below(nnt));
-                                    again = __ballot(grp == b && jj < j && my_pick == pick) != 0ull;
-                                } while (again);
-                                if (grp == b && jj == j) my_pick = pick;
-                            }
+                    if (grp < nb) my_pick = idx;
+                    unsigned long long dup_groups = __ballot(dup && grp < nb);
+                    while (dup_groups) {
+                        const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(dup_groups)) - 1) / S;   // S <= 64 / nb
+                        const uint64_t kb = uniform64(__shfl(key, b * S));
+                        uint64_t ctr = 0;
+                        for (uint32_t j = 0; j < S; j++) {
+                            uint32_t pick;
+                            bool again;
+                            do {
+                                pick = static_cast<uint32_t>(__umul64hi(counter_u64(kb, ctr++), static_cast<uint64_t>(nnt)));
+                                again = __ballot(grp == b && jj < j && my_pick == pick) != 0ull;
+                            } while (again);
+                            if (grp == b && jj == j) my_pick = pick;
                         }
+                        unsigned long long group_lanes = 0;
+                        for (uint32_t j = 0; j < S; j++) group_lanes |= 1ull << (b * S + j);
+                        dup_groups &= ~group_lanes;
                     }
                 }
                 // preparation: everything about the candidate read that the moves of this batch cannot change
@@ -744,8 +750,8 @@ void solve_loop_kernel(const SolveView V) {
                             for (uint32_t t = 1; t < 4; t++) if (t == cur_assgn) { cur_lp = lps[t]; cur_w = wins[t]; }
                             mm.w1 = cur_w & 0xFFFFu; mm.w2 = cur_w >> 16; mm.lp_old = cur_lp;
 #pragma unroll 1
-                            for (uint32_t t = 0; t < nloc; t++) {
-                                if (t == cur_assgn) continue;
+                            for (uint32_t u = 0; u + 1 < nloc; u++) {        // the other locations in order: no pass is spent on the current one
+                                const uint32_t t = u + (u >= cur_assgn ? 1u : 0u);
                                 double lp_t = lps[0]; uint32_t win_t = wins[0];
 #pragma unroll
                                 for (uint32_t u = 1; u < 4; u++) if (u == t) { lp_t = lps[u]; win_t = wins[u]; }
@@ -1174,7 +1180,7 @@ struct StageRunner {
         V.depth_contrib = 1.0 + loc->prm.lik_skew; V.aln_contrib = 1.0 - loc->prm.lik_skew;      // assgn.rs:80-81
         V.n_windows = loc->d_n_windows.p; V.reg_start = loc->d_reg_start.p; V.allele_len = loc->d_allele_len.p;
         V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
-        V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
+        V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
         V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p;
         V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
@@ -1215,7 +1221,7 @@ struct StageRunner {
             if (priors) d_pri.upload(priors + g0, ng, s);
             V.priors = priors ? d_pri.p : nullptr;
             for (;;) {
-                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth;
+                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth));
                 switch (ploidy) {
                     case 1: launch_chains<1>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
                     case 2: launch_chains<2>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;

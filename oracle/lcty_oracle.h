@@ -124,7 +124,9 @@ void     orc_rng_long_jump(orc_rng* r);
  * documented definitions, shared by oracle and GPU:
  *   below(n)  = high 64 bits of next_u64() * n          (stands in for random_range(0..n))
  *   f64()     = (next_u64() >> 11) * 2^-53              (random::<f64>())
- *   counter(key, i) = SplitMix64 finaliser of key + (i+1) * 0x9e3779b97f4a7c15  (order-free draws of apply_tweak) */
+ *   counter(key, i) = SplitMix64 finaliser of key + (i+1) * 0x9e3779b97f4a7c15  (order-free draws of apply_tweak)
+ *   sample(k of n)  = key = next_u64(); picks = high 64 bits of counter(key, 0), counter(key, 1), ... times n, repeats skipped
+ *                     (IndexedRandom::sample of the greedy loop: k distinct indices, one generator draw per iteration) */
 uint64_t orc_rng_below(orc_rng* r, uint64_t n);
 double   orc_rng_f64(orc_rng* r);
 uint64_t orc_counter_u64(uint64_t key, uint64_t i);

@@ -419,12 +419,16 @@ static void solve_greedy(rassgn* ra, const orc_gt_alns* g, const lcty_solver* s,
     for (uint64_t it = 0; it < max_iter; it++) {
         int have = 0; target best_t; memset(&best_t, 0, sizeof(best_t));
         double best_improv = min_diff;
-        /* non_trivial_reads.sample(rng, sample_size): distinct indices, rejection of repeats (our adaptor) */
+        /* non_trivial_reads.sample(rng, sample_size) (our adaptor): one draw of the chain's generator per iteration; the picks are
+         * counter draws under that key, taken in order, repeats skipped — distinct indices, and the picks of an iteration do not
+         * depend on each other (the GPU draws them on separate lanes) */
+        const uint64_t sample_key = orc_rng_next(rng);
+        uint64_t ctr = 0;
         for (uint64_t j = 0; j < sample_size; j++) {
             uint64_t idx;
             int dup;
             do {
-                idx = orc_rng_below(rng, nnt);
+                idx = (uint64_t)(((unsigned __int128)orc_counter_u64(sample_key, ctr++) * (unsigned __int128)nnt) >> 64);
                 dup = 0;
                 for (uint64_t q = 0; q < j; q++) dup |= picked[q] == idx;
             } while (dup);
