@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
+    ap.add_argument("--recovery-sample", type=int, default=262144,
+                    help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
 
 
@@ -247,6 +249,29 @@ def main():
                 out["roofline_solver"]["traffic_fetch_raw"] = sum(v["fetch_bytes_raw"] for v in ks)
     except (OSError, KeyError, ValueError):
         pass
+
+    if args.recovery_sample > 0 and world == 1:
+        # ---- alignment recovery (K6), not part of the step: the mapper reports only the primary alignment of each read end, the
+        # other alleles are reached through the haplotype-to-haplotype alignments (transfer.rs:70-140) ----
+        nrec = min(args.recovery_sample, args.pairs)
+        tr0 = time.perf_counter()
+        H = L.hap_alns()
+        loc.set_hap_alns(H, transfer_fails=100, max_div=0.1)                   # genotype.rs:149-150 defaults
+        t_set = time.perf_counter() - tr0
+        prim = [L.reads(lo, min(args.chunk, nrec - lo), primaries_only=True) for lo in range(0, nrec, args.chunk)]
+        ab = api.AllAlignments.load(loc, prim)
+        ctx.timing_reset()
+        tr0 = time.perf_counter()
+        n_new = ab.recover()
+        t_rec = time.perf_counter() - tr0
+        n_tr, ms_tr = ctx.timing(5)                                            # LCTY_K_TRANSFER
+        out["recovery"] = {"sample": f"first {nrec} read pairs, primary records only ({sum(len(c.recs) for c in prim)} records), "
+                                     f"{len(H)} haplotype alignments, transfer_fails 100",
+                           "alignments_transferred": int(n_new), "transfer_kernel_ms": ms_tr, "launches": int(n_tr),
+                           "transfers_per_s": n_new / (ms_tr * 1e-3) if ms_tr else None,
+                           "recover_and_rescore_s": t_rec, "set_hap_alns_s": t_set, "good_pairs_after": ab.n_good(),
+                           "level_pairs": ab.recover_stats()}
+        ab.close(); del prim
 
     if first is not None:
         # ---- CPU baseline: the oracle (C restatement of the reference algorithms, single thread:

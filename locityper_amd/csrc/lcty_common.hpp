@@ -82,6 +82,9 @@ struct DevBuf {
         n = count;
         if (count) LCTY_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
     }
+    void ensure(size_t count) {                      // grow-only: a workspace that survives the call
+        if (n < count) alloc(count);
+    }
     void upload(const T* host, size_t count, hipStream_t s, size_t dst_off = 0) {
         if (dst_off + count > n) fail(LCTY_ERR_RUNTIME, "device buffer overflow (%zu + %zu > %zu)", dst_off, count, n);
         if (count) LCTY_HIP(hipMemcpyAsync(p + dst_off, host, count * sizeof(T), hipMemcpyHostToDevice, s));

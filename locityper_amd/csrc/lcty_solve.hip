@@ -1138,11 +1138,20 @@ struct StageRunner {
     uint64_t n_gt; uint32_t ploidy, attempts;
     size_t lds_init = 0, lds_loop = 0;
     uint64_t gt_per_batch = 1, depth_cap = 2;
-    DevBuf<uint16_t> d_gt; DevBuf<uint8_t> d_cgc; DevBuf<uint32_t> d_nt, d_cdepth, d_cnnt, d_ovf; DevBuf<uint64_t> d_seeds;
-    DevBuf<double> d_pri, d_liks, d_parts, d_cww, d_caln;
+    // device state of the chains: the workspace of the batch (grow-only, lives as long as the reads)
+    DevBuf<uint16_t>& d_gt; DevBuf<uint8_t>& d_cgc; DevBuf<uint32_t>& d_nt; DevBuf<uint32_t>& d_cdepth; DevBuf<uint32_t>& d_cnnt; DevBuf<uint32_t>& d_ovf;
+    DevBuf<uint64_t>& d_seeds; DevBuf<double>& d_pri; DevBuf<double>& d_liks; DevBuf<double>& d_parts; DevBuf<double>& d_cww; DevBuf<double>& d_caln;
 
     StageRunner(lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver, uint32_t attempts_,
-                const uint64_t* chain_seeds) : reads(r), n_gt(n_gt_), ploidy(ploidy_), attempts(attempts_) {
+                const uint64_t* chain_seeds)
+        : StageRunner(r ? r->solve_ws : null_workspace(), r, genotypes, n_gt_, ploidy_, solver, attempts_, chain_seeds) {}
+
+    static lcty_reads::SolveWorkspace& null_workspace() { static lcty_reads::SolveWorkspace w; return w; }   // never allocated: the null check comes first
+
+    StageRunner(lcty_reads::SolveWorkspace& ws, lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver,
+                uint32_t attempts_, const uint64_t* chain_seeds)
+        : reads(r), n_gt(n_gt_), ploidy(ploidy_), attempts(attempts_), d_gt(ws.gt), d_cgc(ws.cgc), d_nt(ws.nt), d_cdepth(ws.cdepth), d_cnnt(ws.cnnt),
+          d_ovf(ws.ovf), d_seeds(ws.seeds), d_pri(ws.pri), d_liks(ws.liks), d_parts(ws.parts), d_cww(ws.cww), d_caln(ws.caln) {
         if (!reads || !genotypes || !solver || !chain_seeds) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
         if (ploidy == 0 || ploidy > MAXP) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles ploidy 1..%u", MAXP);
@@ -1196,12 +1205,12 @@ struct StageRunner {
             budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
         gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
         const uint64_t max_chains = gt_per_batch * attempts;
-        d_ovf.alloc(1); d_ovf.zero(s);
-        d_nt.alloc(max_chains * ngp);
-        d_cww.alloc(max_chains * V.wstride); d_cgc.alloc(max_chains * V.wstride); d_cdepth.alloc(max_chains * V.wstride);
-        d_cnnt.alloc(max_chains); d_caln.alloc(max_chains);
-        d_gt.alloc(gt_per_batch * ploidy); d_seeds.alloc(max_chains); d_liks.alloc(max_chains); d_parts.alloc(4 * max_chains);
-        d_pri.alloc(gt_per_batch);
+        d_ovf.ensure(1); d_ovf.zero(s);
+        d_nt.ensure(max_chains * ngp);
+        d_cww.ensure(max_chains * V.wstride); d_cgc.ensure(max_chains * V.wstride); d_cdepth.ensure(max_chains * V.wstride);
+        d_cnnt.ensure(max_chains); d_caln.ensure(max_chains);
+        d_gt.ensure(gt_per_batch * ploidy); d_seeds.ensure(max_chains); d_liks.ensure(max_chains); d_parts.ensure(4 * max_chains);
+        d_pri.ensure(gt_per_batch);
         V.genotypes = d_gt.p; V.seeds = d_seeds.p; V.priors = nullptr;
         V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
         V.c_ww = d_cww.p; V.c_gc = d_cgc.p; V.c_depth = d_cdepth.p; V.c_nnt = d_cnnt.p; V.c_aln = d_caln.p;
