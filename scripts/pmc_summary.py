@@ -5,7 +5,7 @@ profiles/<tag>_pmc_traffic.json: HBM bytes per launch of every lcty kernel.
   128-byte read requests at 64 bytes, i.e. reports half of a wide streaming read -> doubled here ("fetch_bytes_corrected");
   WRITE_SIZE is exact. Narrow gathers are uncalibrated, so both the raw and the corrected figure are kept.
 
-usage: python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [workload note]
+usage: python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [workload note [read_pairs alleles]]
 """
 import collections
 import csv
@@ -29,6 +29,8 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "unit": "bytes per launch", "kernels": {}}
+    if len(sys.argv) > 6:
+        out["read_pairs"], out["alleles"] = int(sys.argv[5]), int(sys.argv[6])      # bench.py matches its workload against these
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("lcty::"):
             continue
