@@ -584,10 +584,12 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         const uint32_t max_blocks = static_cast<uint32_t>(ctx->props.multiProcessorCount) * waves;
 
         uint32_t cap_new = std::min<uint32_t>(std::max<uint32_t>(4 * A, 64), 1u << 15);
+        if (const char* e = std::getenv("LCTY_TRANSFER_CAP_NEW")) cap_new = std::max(1, std::atoi(e));    // developer / test switch: exercise the retries
         const uint32_t words_per_new = std::max<uint32_t>(24, std::min<uint32_t>(levels[0].cigar_cap, rec_cigar + 32));
         // every record can reach every other contig once; beyond 1.5 G records (24 GB) the first launch only counts and the second one fits
         uint64_t arena_recs = std::min<uint64_t>(reads->n_recs * static_cast<uint64_t>(A > 1 ? A - 1 : 1) + 1024, 1500ull << 20);
         uint64_t arena_words = std::min<uint64_t>(arena_recs * std::max<uint32_t>(4, rec_cigar + 8), 6ull << 30);
+        if (const char* e = std::getenv("LCTY_TRANSFER_ARENA")) { arena_recs = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)); arena_words = 2 * arena_recs; }
         DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords; DevBuf<uint8_t> d_scratch;
         unsigned long long cursors[3] = {0, 0, 0};
         for (int attempt = 0;; attempt++) {

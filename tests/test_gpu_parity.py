@@ -697,6 +697,25 @@ def test_alignment_recovery_large_stretches_and_long_reads(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_alignment_recovery_grows_its_arenas(gpu_ctx, monkeypatch):
+    """Output arenas and the per-pair blocks that start too small are enlarged and the launch repeated: same result."""
+    from tests.test_oracle_transfer import make_haps
+    rng = np.random.default_rng(41)
+    haps = make_haps(rng, 6, 2400)
+    pairs = []
+    for i in range(80):
+        src = int(rng.integers(0, 6))
+        p1 = int(rng.integers(200, len(haps[src]) - 800)); p2 = p1 + int(rng.integers(200, 420))
+        pairs.append({"seq1": haps[src][p1:p1 + 150].decode(), "seq2": haps[src][p2:p2 + 150].decode(),
+                      "recs": [(src, p1, 0, "150="), (src, p2, M2 | REV, "150=")]})
+    n_ref, _, _ = _recovery_case(gpu_ctx, haps, pairs, make_bg(), tf=3)
+    monkeypatch.setenv("LCTY_TRANSFER_CAP_NEW", "2")
+    monkeypatch.setenv("LCTY_TRANSFER_ARENA", "16")
+    n_small, _, _ = _recovery_case(gpu_ctx, haps, pairs, make_bg(), tf=3)
+    assert n_small == n_ref > 300
+
+
+@pytest.mark.gpu
 def test_alignment_recovery_needs_haplotype_alignments(gpu_ctx):
     from tests.test_oracle_transfer import make_haps
     rng = np.random.default_rng(37)
