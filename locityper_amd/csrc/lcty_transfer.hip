@@ -362,18 +362,50 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                     for (uint32_t k = 0; k < out.n; k++) P.words[word_at + k] = (out.t[k].y << 4) | out.t[k].x;
                 }
                 __syncthreads();
-                if (lane == 0) {
-                    if (room) {
-                        for (uint32_t k = 0; k < n_fresh; k++) {              // push in target order
-                            const NewAln nn = P.news[sh_n_new + k];
-                            PAln a;
-                            a.ln_prob = nn.ln_prob; a.start = nn.start; a.contig_end = nn.contig_end; a.edit = nn.edit;
-                            a.src = 0x80000000u | (sh_n_new + k);
-                            prelim_push(P, S, a, T.flag);
-                            P.news[sh_n_new + k].pushed = 1;
+                // PrelimAlignments::push of the chunk's new alignments (locs.rs:298-344), all lanes at once: the targets of one source are
+                // distinct contigs, so their position keys are distinct and every lane's table entry is its own; what the serial loop
+                // makes order-dependent is only the index an appended alignment gets, which is its rank among the appending lanes
+                if (room && n_fresh) {
+                    const uint32_t n_before = S.n_alns;                      // > 0: the pair has a saved primary (it would not be here otherwise)
+                    uint32_t be = fresh ? na.edit : NONE32T;
+                    double bl = fresh ? na.ln_prob : -INFINITY;
+                    for (int o = 32; o > 0; o >>= 1) { be = min(be, static_cast<uint32_t>(__shfl_xor(static_cast<int>(be), o))); bl = fmax(bl, __shfl_xor(bl, o)); }
+                    const bool save = fresh && na.edit <= S.passable[e];
+                    uint32_t h = 0, existing = NOT_SAVED;
+                    bool found = false;
+                    const uint64_t key = pos_key(e, target, na.start);
+                    if (fresh) {
+                        h = static_cast<uint32_t>(mix64(key)) & (P.hcap - 1);
+                        for (;;) {
+                            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&P.hkey[h]), 0ull, static_cast<unsigned long long>(key));
+                            if (old == 0ull) break;
+                            if (old == key) { found = true; existing = P.hval[h].x; break; }
+                            h = (h + 1) & (P.hcap - 1);
                         }
-                        sh_n_new += n_fresh; sh_words += words_total;
                     }
+                    const bool appends = save && (!found || existing == NOT_SAVED);
+                    const unsigned long long app_mask = __ballot(appends);
+                    const uint32_t new_ix = n_before + static_cast<uint32_t>(__popcll(app_mask & ((1ull << lane) - 1ull)));
+                    const uint32_t n_app = static_cast<uint32_t>(__popcll(app_mask));
+                    const bool fits = n_before + n_app <= P.cap_alns;
+                    if (!fits) atomicMax(T.flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
+                    if (fresh && fits) {
+                        PAln a;
+                        a.ln_prob = na.ln_prob; a.start = na.start; a.contig_end = na.contig_end; a.edit = na.edit;
+                        a.src = 0x80000000u | slot;
+                        if (appends) { P.hval[h] = make_uint2(new_ix, a.start); P.alns[new_ix] = a; }
+                        else if (save) { if (a.ln_prob > P.alns[existing].ln_prob) { P.alns[existing] = a; P.hval[h].y = a.start; } }
+                        else if (!found) P.hval[h] = make_uint2(NOT_SAVED, a.start);
+                        P.news[slot].pushed = 1;
+                    }
+                    if (lane == 0) {
+                        S.best_edit[e] = min(S.best_edit[e], be); S.best_lik[e] = fmax(S.best_lik[e], bl);
+                        if (fits) S.n_alns = n_before + n_app;
+                    }
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    if (room) { sh_n_new += n_fresh; sh_words += words_total; }
                     sh_fails += static_cast<uint32_t>(__popcll(fail_mask));
                     if (sh_fails > H.transfer_fails || !room) sh_stop = 1;
                 }
@@ -394,19 +426,20 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
             const bool room = rec_at + n_new <= T.out_recs_cap && word_at0 + n_words <= T.out_words_cap;
             if (!room) { if (lane == 0) atomicMax(T.flag, 1u); }
             else {
+                // sources are taken in push order, read end 0 before read end 1, so the transferred alignments already lie end 0 first
                 uint32_t c0 = 0;
-                for (uint32_t k = 0; k < n_new; k++) c0 += ((P.news[k].contig_end >> 16) & 1u) == 0;       // uniform count
+                for (uint32_t k = lane; k < n_new; k += 64) {
+                    const NewAln nn = P.news[k];
+                    const uint32_t e2 = (nn.contig_end >> 16) & 1u;
+                    c0 += e2 == 0;
+                    lcty_aln_rec r;
+                    r.pos = nn.start; r.contig = static_cast<uint16_t>(nn.contig_end & 0xFFFFu);
+                    r.flags = static_cast<uint16_t>(LCTY_FLAG_SECONDARY | (((nn.contig_end >> 17) & 1u) ? LCTY_FLAG_REVERSE : 0) | (e2 ? LCTY_FLAG_MATE2 : 0));
+                    r.n_cigar = nn.n_cigar; r.cigar_rel = nn.cigar_at;         // relative to the pair's block of new words
+                    T.out_recs[rec_at + k] = r;
+                }
+                for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(static_cast<int>(c0), o);
                 if (lane == 0) {
-                    uint32_t at[2] = {0, c0};
-                    for (uint32_t k = 0; k < n_new; k++) {
-                        const NewAln nn = P.news[k];
-                        const uint32_t e = (nn.contig_end >> 16) & 1u;
-                        lcty_aln_rec r;
-                        r.pos = nn.start; r.contig = static_cast<uint16_t>(nn.contig_end & 0xFFFFu);
-                        r.flags = static_cast<uint16_t>(LCTY_FLAG_SECONDARY | (((nn.contig_end >> 17) & 1u) ? LCTY_FLAG_REVERSE : 0) | (e ? LCTY_FLAG_MATE2 : 0));
-                        r.n_cigar = nn.n_cigar; r.cigar_rel = nn.cigar_at;     // relative to the pair's block of new words
-                        T.out_recs[rec_at + at[e]++] = r;
-                    }
                     T.new_cnt[2 * p] = c0; T.new_cnt[2 * p + 1] = n_new - c0; T.new_words[p] = n_words;
                     T.out_rec_at[p] = rec_at; T.out_word_at[p] = word_at0;
                 }
