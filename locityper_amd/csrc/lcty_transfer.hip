@@ -81,14 +81,16 @@ __device__ inline PairScratch carve(uint8_t* base, uint32_t cap_alns, uint32_t h
     return s;
 }
 
-// count_region_operations_fast (aln.rs:288-317) + ErrorProfile::ln_prob (err_prof.rs:212-221) of raw CIGAR words
+// count_region_operations_fast (aln.rs:288-317) + ErrorProfile::ln_prob (err_prof.rs:212-221); word(i) = raw CIGAR word i
 struct Scored { double ln_prob; uint32_t start, end, edit; bool bad; };
-__device__ inline Scored score_words(const LocusView& L, const uint32_t* raw, uint32_t n, uint32_t pos, uint32_t contig_len, bool primary) {
+template <typename WordAt>
+__device__ inline Scored score_cigar(const LocusView& L, WordAt word, uint32_t n, uint32_t pos, uint32_t contig_len, bool primary) {
     uint32_t matches = 0, mism = 0, ins = 0, del = 0, left = 0, right = 0;
     bool bad = false;
     for (uint32_t i = 0; i < n; i++) {
-        uint32_t op = raw[i] & 15u;
-        const uint32_t len = raw[i] >> 4;
+        const uint32_t raw = word(i);
+        uint32_t op = raw & 15u;
+        const uint32_t len = raw >> 4;
         const bool edge = i == 0 || i + 1 == n;
         if (op == OP_H) { if (edge && !primary) op = OP_S; else bad = true; }
         if (op == OP_EQ) matches += len; else if (op == OP_X) mism += len; else if (op == OP_I) ins += len; else if (op == OP_D) del += len;
@@ -105,6 +107,9 @@ __device__ inline Scored score_words(const LocusView& L, const uint32_t* raw, ui
               + L.lp[3] * static_cast<double>(del) + L.lp[4] * static_cast<double>(clip);
     s.bad = bad;
     return s;
+}
+__device__ inline Scored score_words(const LocusView& L, const uint32_t* raw, uint32_t n, uint32_t pos, uint32_t contig_len, bool primary) {
+    return score_cigar(L, [raw](uint32_t i) { return raw[i]; }, n, pos, contig_len, primary);
 }
 
 __device__ __forceinline__ uint64_t pos_key(uint32_t read_end, uint32_t contig, uint32_t pos) {       // encode, locs.rs:181-184
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
     const bool paired = L.is_paired != 0;
     __shared__ Prelim S;
     __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop, sh_redo;
+    __shared__ uint2 lds_cigar[CIGAR_LDS_ITEMS * 64];              // the first items of every lane's CIGAR under construction
 
     for (uint64_t ii = blockIdx.x; ii < T.n_list; ii += gridDim.x) {
         const uint64_t p = T.pair_list ? T.pair_list[ii] : ii;
@@ -274,8 +280,10 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                 // 0 nothing, 1 similar position exists (index in `hit`), 2 failed transfer, 3 new alignment
                 uint32_t kind = 0, hit = NONE32T, target = 0;
                 PAln na; na.ln_prob = 0.0; na.start = 0; na.contig_end = 0; na.edit = 0; na.src = 0;
-                DCigar out; out.init(LS.cig_a, T.lim.cigar_cap);
+                DCigar out; out.init(LS.cig_a, T.lim.cigar_cap, lds_cigar + lane);
                 bool beyond = false;                                         // this transfer needs a lane with more scratch
+                bool transferring = false, walking = false;
+                Walk walk; walk.start_k = 0; walk.phase = PH_DONE;
                 if (t < nb) {
                     target = H.best_ids[H.best_off[s_contig] + t];
                     const uint32_t lo = min(s_contig, target), hi = max(s_contig, target);
@@ -305,22 +313,35 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                         Q.target = H.seqs + H.seq_off[target];
                         Q.target_len = static_cast<uint32_t>(H.seq_off[target + 1] - H.seq_off[target]);
                         LS.big = 0;
-                        const uint32_t new_start = transfer_read(H.items + H.item_off[cell], H.item_off[cell + 1] - H.item_off[cell], dir, sa.start, ci,
-                                                                 qpos_at, rpos_at, src, Q, out, LS);
-                        const uint32_t diff = out.rlen > out.qlen ? out.rlen - out.qlen : out.qlen - out.rlen;
-                        // the lengths of an end-to-end stretch do not depend on how it is aligned: a stand-in decides the length test
-                        if (out.overflow || (LS.big & 2u)) beyond = true;
-                        else if (diff > passable || out.rlen < 50) kind = 2;    // MIN_ALN_SIZE
-                        else if (LS.big & 1u) beyond = true;
-                        else {
-                            kind = 3;
-                            // Alignment::new + the scoring of push(): the CIGAR goes through the same counting as a record's
-                            uint32_t* w = reinterpret_cast<uint32_t*>(LS.cig_b);
-                            for (uint32_t k = 0; k < out.n; k++) w[k] = (out.t[k].y << 4) | out.t[k].x;
-                            const Scored sc = score_words(L, w, out.n, new_start, Q.target_len, false);
-                            na.ln_prob = sc.ln_prob; na.start = new_start; na.edit = sc.edit;
-                            na.contig_end = target | (e << 16) | (s_rev ? (1u << 17) : 0u);
-                        }
+                        transferring = true;
+                        walking = walk_init(walk, H.items + H.item_off[cell], H.item_off[cell + 1] - H.item_off[cell], dir, sa.start, ci, qpos_at, rpos_at,
+                                            src, out);
+                    }
+                }
+                // the walks of all lanes, resumed until none of them waits for the aligner any more: one converged call site
+                {
+                    Job job;
+                    bool need;
+                    do {
+                        need = walking && walk_step(walk, src, Q, out, LS, job);
+                        if (!need) walking = false;
+                        if (need) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);
+                    } while (__any(need));
+                }
+                if (transferring) {
+                    const uint32_t new_start = walk.start_k;
+                    const uint32_t diff = out.rlen > out.qlen ? out.rlen - out.qlen : out.qlen - out.rlen;
+                    // the lengths of an end-to-end stretch do not depend on how it is aligned: a stand-in decides the length test
+                    if (out.overflow || (LS.big & 2u)) beyond = true;
+                    else if (diff > passable || out.rlen < 50) kind = 2;    // MIN_ALN_SIZE
+                    else if (LS.big & 1u) beyond = true;
+                    else {
+                        kind = 3;
+                        // Alignment::new + the scoring of push(): the CIGAR goes through the same counting as a record's
+                        const Scored sc = score_cigar(L, [&out](uint32_t i) { const uint2 it = out.get(i); return (it.y << 4) | it.x; }, out.n, new_start,
+                                                      Q.target_len, false);
+                        na.ln_prob = sc.ln_prob; na.start = new_start; na.edit = sc.edit;
+                        na.contig_end = target | (e << 16) | (s_rev ? (1u << 17) : 0u);
                     }
                 }
                 // the loop of transfer.rs:90-136 stops at the (transfer_fails + 1)-th failure: everything behind it did not happen
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                     nn.ln_prob = na.ln_prob; nn.start = na.start; nn.contig_end = na.contig_end; nn.edit = na.edit;
                     nn.n_cigar = out.n; nn.cigar_at = word_at; nn.pushed = 0;
                     P.news[slot] = nn;
-                    for (uint32_t k = 0; k < out.n; k++) P.words[word_at + k] = (out.t[k].y << 4) | out.t[k].x;
+                    for (uint32_t k = 0; k < out.n; k++) { const uint2 it = out.get(k); P.words[word_at + k] = (it.y << 4) | it.x; }
                 }
                 __syncthreads();
                 // PrelimAlignments::push of the chunk's new alignments (locs.rs:298-344), all lanes at once: the targets of one source are

@@ -40,27 +40,36 @@ __device__ __forceinline__ uint32_t op_invert(uint32_t op) {                  //
     return (op == OP_I || op == OP_S) ? OP_D : (op == OP_D ? OP_I : op);
 }
 
-// Cigar under construction (cigar.rs:203-208): items {op, len} in the lane's scratch
+// Cigar under construction (cigar.rs:203-208): items {op, len}. The first `lds_n` items of a lane live in LDS (item i of lane l at
+// l_base[i * 64 + l]: conflict-free), the rest in the lane's global scratch — a transferred short-read CIGAR rarely has more, and
+// every push looks at the item before it
+constexpr uint32_t CIGAR_LDS_ITEMS = 12;
 struct DCigar {
-    uint2* t;
+    uint2* t;              // global part [cap]
+    uint2* l;              // LDS part, already offset by the lane (stride 64), or nullptr
+    uint32_t lds_n;
     uint32_t n, rlen, qlen, cap;
     bool overflow;                                                           // items were dropped: the lengths are still right
-    __device__ void init(uint2* buf, uint32_t capacity) { t = buf; cap = capacity; n = 0; rlen = qlen = 0; overflow = false; }
+    __device__ void init(uint2* buf, uint32_t capacity, uint2* lds = nullptr) {
+        t = buf; cap = capacity; l = lds; lds_n = lds ? CIGAR_LDS_ITEMS : 0u; n = 0; rlen = qlen = 0; overflow = false;
+    }
+    __device__ __forceinline__ uint2 get(uint32_t i) const { return i < lds_n ? l[i * 64] : t[i]; }
+    __device__ __forceinline__ void set(uint32_t i, uint2 v) { if (i < lds_n) l[i * 64] = v; else t[i] = v; }
     __device__ void clear() { n = 0; rlen = qlen = 0; }
+    __device__ void push_raw(uint2 it) { if (n < cap) set(n++, it); else overflow = true; }                 // lengths untouched
     __device__ void push_unchecked(uint32_t op, uint32_t len) {              // cigar.rs:343-352
         if (cons_q(op)) qlen += len;
         if (cons_r(op)) rlen += len;
-        if (n < cap) t[n++] = make_uint2(op, len); else overflow = true;
+        push_raw(make_uint2(op, len));
     }
     __device__ void push_checked(uint32_t op, uint32_t len) {                // cigar.rs:355-363
         if (cons_q(op)) qlen += len;
         if (cons_r(op)) rlen += len;
-        if (n && t[n - 1].x == op) t[n - 1].y += len;
-        else if (n < cap) t[n++] = make_uint2(op, len);
-        else overflow = true;
-    }
-    __device__ void append_items(const uint2* it, uint32_t k) {              // tuples.extend_from_slice: lengths untouched
-        for (uint32_t i = 0; i < k; i++) { if (n < cap) t[n++] = it[i]; else overflow = true; }
+        if (n) {
+            const uint2 last = get(n - 1);
+            if (last.x == op) { set(n - 1, make_uint2(op, last.y + len)); return; }
+        }
+        push_raw(make_uint2(op, len));
     }
 };
 
@@ -270,21 +279,6 @@ __device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint3
     return 0;
 }
 
-// align_ends::<LEFT> (wfa.rs:349-365)
-__device__ inline void align_ends(bool left, const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, DCigar& cg, Scratch& sc) {
-    if (i1 == i2) { cg.push_unchecked(OP_I, j2 - j1); return; }
-    aligner_align(S, i1, i2 - i1, j1, j2 - j1, left ? 1 : 2, left, cg, sc);
-    if (!left) {
-        uint32_t soft = 0;
-        while (cg.n && cg.t[cg.n - 1].x != OP_EQ) {                          // pop_if(op != Equal)
-            const uint2 it = cg.t[--cg.n];
-            if (cons_q(it.x)) { cg.qlen -= it.y; soft += it.y; }
-            if (cons_r(it.x)) cg.rlen -= it.y;
-        }
-        if (soft > 0) cg.push_unchecked(OP_I, soft);
-    }
-}
-
 // Cigar::optimize (cigar.rs:1167-1237). As upstream, the reference positions are counted from the start of the CIGAR while the
 // sequence handed in is the whole target haplotype (cigar.rs:1362-1364): kept as written.
 __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_gap, uint32_t anchor_size, Scratch& sc) {
@@ -293,18 +287,19 @@ __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_
     DCigar nc; nc.init(sc.cig_b, sc.lim.cigar_cap);
     bool have = false;
     for (uint32_t j = 0; j < self.n; j++) {
-        const uint32_t op = self.t[j].x, len = self.t[j].y;
+        const uint2 item_j = self.get(j);
+        const uint32_t op = item_j.x, len = item_j.y;
         const bool cq = cons_q(op), cr = cons_r(op);
         if (cq && cr && len >= anchor_size) {
             const uint32_t qshift = qpos2 - qpos1, rshift = rpos2 - rpos1;
             if (flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
-                if (!have) { have = true; nc.append_items(self.t, i); nc.qlen = qpos1; nc.rlen = rpos1; }
+                if (!have) { have = true; for (uint32_t k = 0; k < i; k++) nc.push_raw(self.get(k)); nc.qlen = qpos1; nc.rlen = rpos1; }
                 smart_align(S, rpos1, rpos2, qpos1, qpos2, 0xFFFFFFFFu, nc, sc);
                 i = j;
             }
             qpos2 += len; rpos2 += len; qpos1 = qpos2; rpos1 = rpos2; flag = 0;
             if (have) {
-                nc.append_items(self.t + i, j - i);
+                for (uint32_t k = i; k < j; k++) nc.push_raw(self.get(k));
                 nc.push_checked(op, len);
                 nc.qlen = qpos2; nc.rlen = rpos2;
             }
@@ -316,13 +311,13 @@ __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_
     }
     const uint32_t qshift = qpos2 - qpos1, rshift = rpos2 - rpos1;
     if (flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
-        if (!have) { have = true; nc.append_items(self.t, i); nc.qlen = qpos1; nc.rlen = rpos1; }
+        if (!have) { have = true; for (uint32_t k = 0; k < i; k++) nc.push_raw(self.get(k)); nc.qlen = qpos1; nc.rlen = rpos1; }
         smart_align(S, rpos1, rpos2, qpos1, qpos2, 0xFFFFFFFFu, nc, sc);
         i = self.n;
     }
     if (have) {
-        nc.append_items(self.t + i, self.n - i);
-        for (uint32_t t = 0; t < nc.n; t++) self.t[t] = nc.t[t];             // self.tuples = new_cigar.tuples (lengths stay)
+        for (uint32_t k = i; k < self.n; k++) nc.push_raw(self.get(k));
+        for (uint32_t t = 0; t < nc.n; t++) self.set(t, nc.get(t));           // self.tuples = new_cigar.tuples (lengths stay)
         self.n = nc.n;
         self.overflow |= nc.overflow;
     }
@@ -358,57 +353,124 @@ struct SrcCigar {
 
 // Cigar::transfer_alignment::<false> as called by transfer_read_alignment (cigar.rs:1248-1384): anchor size 5, no maximum gap.
 // jk: items of the haplotype-to-haplotype CIGAR (query = lower contig id), dir_jk 0 = QueryToRef, 1 = RefToQuery.
-__device__ inline uint32_t transfer_read(const uint2* jk_items, uint32_t jk_n, int dir_jk, uint32_t start_j, uint32_t off_ix, uint32_t off_qpos,
-                                         uint32_t off_rpos, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc) {
-    const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3, FULL_MATCH_PADDING = 3;
+//
+// The walk is written as a resumable state machine: the lanes of a wavefront carry different transfers and reach their aligner calls
+// at different points of their walks; if the dynamic programme were called from inside the walk, the wavefront would run it once
+// per distinct call point with one lane active. Instead a lane walks until it needs the aligner, hands the stretch out as a `Job`
+// and waits; the caller runs the aligner for all waiting lanes at one converged call site and resumes the walks.
+struct Job { uint32_t i1, n, j1, m; int semiglobal; bool left_clipping; };
+struct Walk {
+    const uint2* jk_items; uint32_t jk_n; int dir_jk;
+    uint32_t jk, op2, len2, rem2;
+    uint32_t ijx, op1, len1, rem1;
+    uint32_t last1, pos1, last2, pos2, start_k;
+    int add;
+    uint32_t phase;
+};
+enum : uint32_t { PH_TOP = 0, PH_POST_LEFT, PH_POST, PH_TAIL, PH_POST_RIGHT, PH_FINISH, PH_DONE };
+
+// returns false when the whole read alignment is a copy (the read lies inside one long match of the two haplotypes): `out` is final
+__device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, int dir_jk, uint32_t start_j, uint32_t off_ix, uint32_t off_qpos,
+                                 uint32_t off_rpos, const SrcCigar& ij, DCigar& out) {
+    const uint32_t FULL_MATCH_PADDING = 3;
     out.clear();
-    uint32_t jk = off_ix;
-    uint32_t op2 = dir_jk ? op_invert(jk_items[jk].x) : jk_items[jk].x;
+    w.jk_items = jk_items; w.jk_n = jk_n; w.dir_jk = dir_jk;
+    w.jk = off_ix;
+    w.op2 = dir_jk ? op_invert(jk_items[w.jk].x) : jk_items[w.jk].x;
     const uint32_t init_shift = start_j - off_qpos;
-    uint32_t len2 = jk_items[jk].y, rem2 = len2 - init_shift;
-    jk++;
-    uint32_t start_k = off_rpos + (cons_r(op2) ? init_shift : 0);
-    if (op2 == OP_EQ && init_shift >= FULL_MATCH_PADDING && rem2 >= ij.ref_len() + FULL_MATCH_PADDING) {
+    w.len2 = jk_items[w.jk].y; w.rem2 = w.len2 - init_shift;
+    w.jk++;
+    w.start_k = off_rpos + (cons_r(w.op2) ? init_shift : 0);
+    if (w.op2 == OP_EQ && init_shift >= FULL_MATCH_PADDING && w.rem2 >= ij.ref_len() + FULL_MATCH_PADDING) {
         for (uint32_t i = 0; i < ij.n; i++) { const uint2 it = ij.item(i); out.push_unchecked(it.x, it.y); }
-        return start_k;
+        w.phase = PH_DONE;
+        return false;
     }
-    uint32_t ijx = 0;
-    uint2 it1 = ij.item(0);
-    uint32_t len1 = it1.y, rem1 = len1, op1 = it1.x;
-    ijx++;
-    uint32_t last1 = 0, pos1 = 0, last2 = start_k, pos2 = start_k;
+    const uint2 it1 = ij.item(0);
+    w.len1 = it1.y; w.rem1 = w.len1; w.op1 = it1.x;
+    w.ijx = 1;
+    w.last1 = 0; w.pos1 = 0; w.last2 = w.start_k; w.pos2 = w.start_k;
+    w.add = -1;
+    w.phase = PH_TOP;
+    return true;
+}
+
+// walks on until the aligner is needed (returns true, `job` filled) or the transfer is complete (returns false)
+__device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc, Job& job) {
+    const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3;
     const uint32_t len_i = S.read_len, len_k = S.target_len;
     for (;;) {
-        int add = -1;
-        const bool e1 = op1 == OP_EQ, e2 = op2 == OP_EQ;
-        if (e1 && e2) { if (min(rem1, rem2) >= anchor_size) add = OP_EQ; }
-        else if (e1 && !e2) { if (rem1 >= anchor_size && len1 - rem1 >= ANCHOR_MARGIN) add = static_cast<int>(op2); }
-        else if (!e1 && e2) { if (rem2 >= anchor_size && len2 - rem2 >= ANCHOR_MARGIN) add = static_cast<int>(op1); }
-        if (add >= 0) {
-            if (last1 == 0 && pos1 > 0) {
-                const uint32_t from = last2 > pos1 + CLIP_PADDING ? last2 - (pos1 + CLIP_PADDING) : 0;     // saturating_sub
-                align_ends(true, S, from, pos2, last1, pos1, out, sc);
-                start_k = start_k + pos2 - last2 - out.rlen;
-            } else smart_align(S, last2, pos2, last1, pos1, 0xFFFFFFFFu, out, sc);
-        }
-        const uint32_t shift = double_move(op1, op2, pos1, rem1, pos2, rem2);
-        if (add >= 0) { out.push_checked(static_cast<uint32_t>(add), shift); last1 = pos1; last2 = pos2; }
-        if (rem1 == 0) {
-            if (ijx == ij.n) break;
-            it1 = ij.item(ijx); len1 = it1.y; rem1 = len1; op1 = it1.x; ijx++;
-        }
-        if (rem2 == 0) {
-            if (jk == jk_n) break;
-            len2 = jk_items[jk].y; rem2 = len2; op2 = dir_jk ? op_invert(jk_items[jk].x) : jk_items[jk].x; jk++;
-        }
+        if (w.phase == PH_TOP) {
+            int add = -1;
+            const bool e1 = w.op1 == OP_EQ, e2 = w.op2 == OP_EQ;
+            if (e1 && e2) { if (min(w.rem1, w.rem2) >= anchor_size) add = OP_EQ; }
+            else if (e1 && !e2) { if (w.rem1 >= anchor_size && w.len1 - w.rem1 >= ANCHOR_MARGIN) add = static_cast<int>(w.op2); }
+            else if (!e1 && e2) { if (w.rem2 >= anchor_size && w.len2 - w.rem2 >= ANCHOR_MARGIN) add = static_cast<int>(w.op1); }
+            w.add = add;
+            w.phase = PH_POST;
+            if (add >= 0) {
+                if (w.last1 == 0 && w.pos1 > 0) {
+                    // align_ends::<LEFT> (wfa.rs:349-365)
+                    const uint32_t from = w.last2 > w.pos1 + CLIP_PADDING ? w.last2 - (w.pos1 + CLIP_PADDING) : 0;     // saturating_sub
+                    w.phase = PH_POST_LEFT;
+                    if (from == w.pos2) out.push_unchecked(OP_I, w.pos1 - w.last1);
+                    else { job = Job{from, w.pos2 - from, w.last1, w.pos1 - w.last1, 1, true}; return true; }
+                } else {
+                    // smart_align (wfa.rs:301-347) without a maximum gap; only the dynamic programme is handed out
+                    const uint32_t jump1 = w.pos2 - w.last2, jump2 = w.pos1 - w.last1;
+                    if (jump1 > 0 && jump2 > 0) {
+                        const uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;      // wfa.rs:212
+                        if (jump1 == jump2 && jump1 <= safe_mismatch) {
+                            for (uint32_t t = 0; t < jump1; t++) out.push_checked(S.r(w.last2 + t) == S.q(w.last1 + t) ? OP_EQ : OP_X, 1);
+                        } else { job = Job{w.last2, jump1, w.last1, jump2, 0, false}; return true; }
+                    } else if (jump1 > 0) out.push_unchecked(OP_D, jump1);
+                    else if (jump2 > 0) out.push_unchecked(OP_I, jump2);
+                }
+            }
+        } else if (w.phase == PH_POST_LEFT) {
+            w.start_k = w.start_k + w.pos2 - w.last2 - out.rlen;
+            w.phase = PH_POST;
+        } else if (w.phase == PH_POST) {
+            const uint32_t shift = double_move(w.op1, w.op2, w.pos1, w.rem1, w.pos2, w.rem2);
+            if (w.add >= 0) { out.push_checked(static_cast<uint32_t>(w.add), shift); w.last1 = w.pos1; w.last2 = w.pos2; }
+            w.phase = PH_TOP;
+            if (w.rem1 == 0) {
+                if (w.ijx == ij.n) w.phase = PH_TAIL;
+                else { const uint2 it1 = ij.item(w.ijx); w.len1 = it1.y; w.rem1 = w.len1; w.op1 = it1.x; w.ijx++; }
+            }
+            if (w.phase == PH_TOP && w.rem2 == 0) {
+                if (w.jk == w.jk_n) w.phase = PH_TAIL;
+                else { w.len2 = w.jk_items[w.jk].y; w.rem2 = w.len2; w.op2 = w.dir_jk ? op_invert(w.jk_items[w.jk].x) : w.jk_items[w.jk].x; w.jk++; }
+            }
+        } else if (w.phase == PH_TAIL) {
+            w.phase = PH_FINISH;
+            if (w.last1 != len_i) {
+                // align_ends::<RIGHT>
+                const uint32_t i1 = w.last2, i2 = min(len_k, w.last2 + len_i - w.last1 + CLIP_PADDING);
+                if (i1 == i2) out.push_unchecked(OP_I, len_i - w.last1);
+                else { w.phase = PH_POST_RIGHT; job = Job{i1, i2 - i1, w.last1, len_i - w.last1, 2, false}; return true; }
+            }
+        } else if (w.phase == PH_POST_RIGHT) {
+            uint32_t soft = 0;
+            while (out.n && out.get(out.n - 1).x != OP_EQ) {                    // pop_if(op != Equal)
+                const uint2 it = out.get(--out.n);
+                if (cons_q(it.x)) { out.qlen -= it.y; soft += it.y; }
+                if (cons_r(it.x)) out.rlen -= it.y;
+            }
+            if (soft > 0) out.push_unchecked(OP_I, soft);
+            w.phase = PH_FINISH;
+        } else if (w.phase == PH_FINISH) {
+            cigar_optimize(out, S, 20, 5, sc);                                  // MAX_OPTIMIZATION_GAP, OPTIMIZATION_ANCHOR
+            if (out.n) {                                                        // boundary_ins_to_soft, cigar.rs:554-561
+                const uint2 first = out.get(0);
+                if (first.x == OP_I) out.set(0, make_uint2(OP_S, first.y));
+                const uint2 last = out.get(out.n - 1);
+                if (last.x == OP_I) out.set(out.n - 1, make_uint2(OP_S, last.y));
+            }
+            w.phase = PH_DONE;
+            return false;
+        } else return false;
     }
-    if (last1 != len_i) align_ends(false, S, last2, min(len_k, last2 + len_i - last1 + CLIP_PADDING), last1, len_i, out, sc);
-    cigar_optimize(out, S, 20, 5, sc);                                        // MAX_OPTIMIZATION_GAP, OPTIMIZATION_ANCHOR
-    if (out.n) {                                                              // boundary_ins_to_soft, cigar.rs:554-561
-        if (out.t[0].x == OP_I) out.t[0].x = OP_S;
-        if (out.t[out.n - 1].x == OP_I) out.t[out.n - 1].x = OP_S;
-    }
-    return start_k;
 }
 
 }  // namespace xfer

@@ -109,3 +109,28 @@ def compare_gpu_to_oracle(aa, oa, tol_lp=1e-9, index_fields=("ix1", "ix2")):
         assert np.abs(M - Mo).max() <= 1e-5       # north_star tolerance on log-likelihoods
         assert np.abs(M - Mo).max() <= tol_lp
     return M, Mo
+
+
+def noisy_read(rng, hap, start, length, err=0.03):
+    """A read copied from hap[start:start+length] with substitutions / insertions / deletions and its true CIGAR."""
+    acgt = b"ACGT"
+    seq = bytearray(); ops = []
+
+    def push(op, n=1):
+        if ops and ops[-1][0] == op: ops[-1][1] += n
+        else: ops.append([op, n])
+    i = start
+    while i < start + length:
+        r = rng.random()
+        if r < err / 3:
+            seq.append(int(rng.choice([c for c in acgt if c != hap[i]]))); push("X"); i += 1
+        elif r < 2 * err / 3 and ops:
+            k = int(rng.integers(1, 4)); seq.extend(rng.choice(list(acgt), k).tolist()); push("I", k)
+        elif r < err and ops and ops[-1][0] == "=":
+            k = int(rng.integers(1, 4)); push("D", k); i += k
+        else:
+            seq.append(hap[i]); push("="); i += 1
+    while ops and ops[-1][0] in "DI":                                         # an alignment ends on an aligned base
+        op, n = ops.pop()
+        if op == "I": del seq[-n:]
+    return bytes(seq), "".join(f"{n}{op}" for op, n in ops)

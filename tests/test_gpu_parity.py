@@ -7,7 +7,7 @@ import pytest
 from locityper_amd import _lib, api, cdefs, synth
 from locityper_amd.cdefs import ReadsChunk
 from tests import oracle_ffi as O
-from tests.helpers import make_bg, random_alleles, locus_arrays, compare_gpu_to_oracle
+from tests.helpers import make_bg, random_alleles, locus_arrays, compare_gpu_to_oracle, noisy_read
 
 pytestmark = pytest.mark.gpu
 
@@ -622,30 +622,6 @@ def test_alignment_recovery_single_end_and_empty(gpu_ctx):
     assert aa.recover() == 0
 
 
-def _noisy_read(rng, hap, start, length, err=0.03):
-    """A read copied from hap[start:start+length] with substitutions / insertions / deletions and its true CIGAR."""
-    acgt = b"ACGT"
-    seq = bytearray(); ops = []
-    def push(op, n=1):
-        if ops and ops[-1][0] == op: ops[-1][1] += n
-        else: ops.append([op, n])
-    i = start
-    while i < start + length:
-        r = rng.random()
-        if r < err / 3:
-            seq.append(int(rng.choice([c for c in acgt if c != hap[i]]))); push("X"); i += 1
-        elif r < 2 * err / 3:
-            k = int(rng.integers(1, 4)); seq.extend(rng.choice(list(acgt), k).tolist()); push("I", k)
-        elif r < err and ops and ops[-1][0] == "=":
-            k = int(rng.integers(1, 4)); push("D", k); i += k
-        else:
-            seq.append(hap[i]); push("="); i += 1
-    while ops and ops[-1][0] in "DI":                                         # an alignment ends on an aligned base
-        op, n = ops.pop()
-        if op == "I": del seq[-n:]
-    return bytes(seq), "".join(f"{n}{op}" for op, n in ops)
-
-
 @pytest.mark.gpu
 def test_alignment_recovery_large_stretches_and_long_reads(gpu_ctx):
     """Structural differences between the alleles (a 400-base insertion, a 700-base deletion) and long noisy reads: transfers
@@ -679,7 +655,7 @@ def test_alignment_recovery_large_stretches_and_long_reads(gpu_ctx):
         ln = int(rng.integers(1200, 3000))
         p1 = int(rng.integers(50, len(haps[src]) - ln - 60)) if i % 4 else int(rng.integers(2800, 3900))
         ln = min(ln, len(haps[src]) - p1 - 60)
-        seq, cg = _noisy_read(rng, haps[src], p1, ln)
+        seq, cg = noisy_read(rng, haps[src], p1, ln)
         reads.append({"seq1": seq.decode(), "seq2": None, "recs": [(src, p1, REV if i % 2 else 0, cg)]})
     bg = make_bg(technology=cdefs.TECH_NANOPORE, paired=False, window=1000, neighb=1000)
     bg.edit_alpha, bg.edit_beta = 6.0, 180.0                                   # error rate of the reads above

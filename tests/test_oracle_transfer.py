@@ -198,3 +198,38 @@ def test_load_with_recovery_against_full_alignment_lists():
     # deterministic
     rec2 = ol.load_recover(ch, H)
     assert np.array_equal(rec2.best_aln_matrix(), Mr)
+
+
+def test_transfer_matches_the_independent_transliteration():
+    """oracle/lcty_oracle_transfer.c against tests/pyref_transfer.py (written separately from the Rust): CigarIndex, the two-CIGAR
+    walk, anchors, clipped ends, optimize — new start and CIGAR must be identical, for reads with substitutions and indels, soft
+    clips, both directions of the haplotype alignment, reads at the ends of the alleles."""
+    from tests import pyref_transfer as PT
+    from tests.helpers import noisy_read
+    rng = np.random.default_rng(17)
+    haps = make_haps(rng, 4, 2000)
+    H = hap_alns_for(haps)
+    cigs, idxs = {}, {}
+    for q, r, w, nm, ln in H.entries:                                  # query = lower id
+        cigs[(q, r)] = PT.Cig.parse(O.cigar_str(w)); idxs[(q, r)] = PT.CigarIndex(cigs[(q, r)])
+    n_copy = n_walk = n_clipped = 0
+    for trial in range(400):
+        src, dst = rng.choice(4, 2, replace=False).tolist()
+        ln = int(rng.integers(60, 260))
+        kind = trial % 4
+        if kind == 3: start = int(rng.integers(0, 30)) if trial % 8 == 3 else len(haps[src]) - ln - int(rng.integers(0, 30))
+        else: start = int(rng.integers(30, len(haps[src]) - ln - 40))
+        read, cg = noisy_read(rng, haps[src], start, ln, err=0.0 if kind == 0 else 0.04)
+        if kind == 2:                                                      # adapter at one end: soft clip
+            k = int(rng.integers(3, 25))
+            first = PT.Cig.parse(cg).t[0]
+            if first[0] == "=" and first[1] > k + 5:
+                read = bytes(rng.choice(list(b"ACGT"), k).tolist()) + read[k:]
+                cg = f"{k}S{first[1] - k}=" + cg[len(str(first[1])) + 1:]
+                start += k
+        lo, hi = min(src, dst), max(src, dst)
+        got_start, got = H.transfer_one(src, dst, start, cg, read, haps[dst])
+        exp_start, exp = PT.transfer_read_alignment(cigs[(lo, hi)], idxs[(lo, hi)], src > dst, start, PT.Cig.parse(cg), read, haps[dst])
+        assert (got_start, got) == (exp_start, str(exp)), (trial, src, dst, start, cg)
+        n_copy += got == cg; n_walk += got != cg; n_clipped += "S" in got
+    assert n_copy > 20 and n_walk > 150 and n_clipped > 20, (n_copy, n_walk, n_clipped)
