@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="extra measurement outside the timed region: this many loci in flight on one GPU, each on its own context / "
+                         "stream (the annealing stage leaves most of the GPU idle); 0 or 1 = skip")
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
@@ -115,7 +118,7 @@ def main():
     stage_s = {"score_prefilter": 0.0, "greedy": 0.0, "anneal": 0.0}
     solved = {"greedy_chains": 0, "anneal_chains": 0, "greedy_iterations": 0, "anneal_moves": 0}
 
-    def step(it=0):
+    def step(it=0, aa=aa, stage_s=stage_s, solved=solved):
         t0s = time.perf_counter()
         aa.score()
         aa.prefilter_async()
@@ -249,6 +252,47 @@ def main():
                 out["roofline_solver"]["traffic_fetch_raw"] = sum(v["fetch_bytes_raw"] for v in ks)
     except (OSError, KeyError, ValueError):
         pass
+
+    if args.pipeline > 1 and world == 1 and not args.no_solve:
+        # ---- loci in flight: the same batch on further contexts (own stream each), one host thread per locus; a production run
+        # genotypes many loci, and the serial annealing chains of one leave the GPU to the scoring and greedy stages of the next ----
+        import threading
+        workers = [(ctx, aa)]
+        for w in range(1, args.pipeline):
+            cw = api.Context(local_rank % ndev)
+            lw = api.Locus(cw, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
+            aw = api.AllAlignments(lw, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096, int(dens_c * args.pairs * head) + 65536)
+            for ci in range(n_chunks):
+                lo = ci * args.chunk
+                aw.append(L.reads(lo, min(args.chunk, args.pairs - lo)))
+            workers.append((cw, aw))
+        scratch = [({"score_prefilter": 0.0, "greedy": 0.0, "anneal": 0.0},
+                    {"greedy_chains": 0, "anneal_chains": 0, "greedy_iterations": 0, "anneal_moves": 0}) for _ in workers]
+        for (cw, aw), (ss, so) in zip(workers[1:], scratch[1:]):
+            step(0, aw, ss, so)                                              # warm-up of the new batches (allocations)
+            cw.synchronize()
+        errs = []
+
+        def run(aw, ss, so):
+            try:
+                for it in range(args.steps):
+                    step(it, aw, ss, so)
+            except Exception as e:      # noqa: BLE001 - reported below
+                errs.append(e)
+        threads = [threading.Thread(target=run, args=(aw, ss, so)) for (cw, aw), (ss, so) in zip(workers, scratch)]
+        tp0 = time.perf_counter()
+        for t in threads: t.start()
+        for t in threads: t.join()
+        for cw, aw in workers: cw.synchronize()
+        tp = time.perf_counter() - tp0
+        if errs:
+            raise errs[0]
+        out["pipelined"] = {"loci_in_flight": len(workers), "steps_per_locus": args.steps, "elapsed_s": tp,
+                            "read_pairs_per_s": len(workers) * args.steps * args.pairs / tp,
+                            "ms_per_step": 1e3 * tp / (len(workers) * args.steps),
+                            "note": "not `value`: the same step on several contexts of one GPU at once"}
+        for cw, aw in workers[1:]:
+            aw.close()
 
     if args.recovery_sample > 0 and world == 1:
         # ---- alignment recovery (K6), not part of the step: the mapper reports only the primary alignment of each read end, the
