@@ -1218,7 +1218,7 @@ void orc_alns_status(const orc_alns* a, uint8_t* status, double* weight, double*
 }
 uint64_t orc_alns_pair_alns(const orc_alns* a, uint64_t* off, lcty_pair_aln* out, uint64_t cap) {
     if (off) memcpy(off, a->pa_off, sizeof(uint64_t) * (a->n_pairs + 1));
-    if (out) memcpy(out, a->pa, sizeof(lcty_pair_aln) * MIN((uint64_t)a->n_pa, cap));
+    if (out && a->n_pa && cap) memcpy(out, a->pa, sizeof(lcty_pair_aln) * MIN((uint64_t)a->n_pa, cap));
     return a->n_pa;
 }
 

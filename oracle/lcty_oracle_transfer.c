@@ -53,6 +53,7 @@ void orc_cigar_push_checked(orc_cigar* c, uint32_t op, uint32_t len) {
     else { cg_reserve(c, 1); c->t[c->n].op = op; c->t[c->n].len = len; c->n++; }
 }
 static void cg_append_items(orc_cigar* c, const orc_citem* it, uint32_t n) {      /* tuples.extend_from_slice: lengths untouched */
+    if (!n) return;
     cg_reserve(c, n);
     memcpy(c->t + c->n, it, sizeof(orc_citem) * n);
     c->n += n;
