@@ -49,6 +49,7 @@ struct lcty_locus {
     lcty::DevBuf<uint8_t> d_seqs;
     lcty::DevBuf<uint64_t> d_seq_off;
     lcty::DevBuf<uint32_t> d_hap_cell_of, d_hap_item_off, d_hap_sparse_off, d_hap_best_off, d_hap_best_ids, d_hap_len;
+    lcty::DevBuf<uint4> d_hap_best_meta;     // per (contig, target in best order): {target, first item, items, first sparse entry of the direction}
     lcty::DevBuf<uint2> d_hap_items, d_hap_positions, d_hap_sparse;
     uint32_t hap_transfer_fails = 0, hap_cells = 0;
     bool has_hap_alns = false;

@@ -33,6 +33,7 @@ struct HapView {
     const uint2* sparse;           // {cigar_ix, pos}
     const uint32_t* best_off;      // [A + 1]
     const uint32_t* best_ids;
+    const uint4* best_meta;        // [best entries] {target, first item of the pair's alignment, number of items, first sparse entry of the direction}
     const uint8_t* seqs; const uint64_t* seq_off;
 };
 
@@ -191,11 +192,11 @@ struct TransferArgs {
     double min_weight;
 };
 
-__global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
+__global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
     const uint32_t lane = threadIdx.x;
     uint8_t* base = T.scratch + static_cast<size_t>(blockIdx.x) * T.scratch_stride;
     const PairScratch P = carve(base, T.cap_alns, T.hcap, T.cap_new, T.cap_words);
-    Scratch LS = scratch_at(P.lanes + static_cast<size_t>(lane) * lane_scratch_bytes(T.lim), T.lim);
+    Scratch LS = scratch_at(P.lanes, lane, T.lim);
     const bool paired = L.is_paired != 0;
     __shared__ Prelim S;
     __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop, sh_redo;
@@ -285,11 +286,11 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                 bool transferring = false, walking = false;
                 Walk walk; walk.start_k = 0; walk.phase = PH_DONE;
                 if (t < nb) {
-                    target = H.best_ids[H.best_off[s_contig] + t];
-                    const uint32_t lo = min(s_contig, target), hi = max(s_contig, target);
-                    const uint32_t cell = H.cell_of[lo * H.A + hi];
+                    // one record per (source contig, target): what the walk needs of the pair's alignment, in the order the targets are tried
+                    const uint4 bm = H.best_meta[H.best_off[s_contig] + t];
+                    target = bm.x;
                     const int dir = s_contig < target ? 0 : 1;
-                    const uint2* sp = H.sparse + H.sparse_off[2 * cell + dir];
+                    const uint2* sp = H.sparse + bm.w;
                     // find_approx_position (cigar.rs:1128-1140)
                     const uint32_t si = sa.start >> 8;
                     const uint2 s1 = sp[si], s2 = sp[si + 1];
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                     if (pos_get(P, e, target, approx, &hit)) kind = 1;
                     else {
                         // find_cigar_offset (cigar.rs:1143-1162)
-                        const uint2* pos = H.positions + H.item_off[cell];
+                        const uint2* pos = H.positions + bm.y;
                         uint32_t ci;
                         if (s1.x == s2.x) ci = s1.x;
                         else {
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(64) void transfer_kernel(const LocusView L, const R
                         Q.target_len = static_cast<uint32_t>(H.seq_off[target + 1] - H.seq_off[target]);
                         LS.big = 0;
                         transferring = true;
-                        walking = walk_init(walk, H.items + H.item_off[cell], H.item_off[cell + 1] - H.item_off[cell], dir, sa.start, ci, qpos_at, rpos_at,
+                        walking = walk_init(walk, H.items + bm.y, bm.z, dir, sa.start, ci, qpos_at, rpos_at,
                                             src, out);
                     }
                 }
@@ -577,7 +578,15 @@ int32_t lcty_locus_set_hap_alns(lcty_locus* loc, uint32_t n_entries, const uint3
                 sparse_off[2 * c + d + 1] = static_cast<uint32_t>(sparse.size());
             }
         }
-        for (uint32_t a = 0; a < A; a++) { for (const Best& b : best[a]) best_ids.push_back(b.id); best_off[a + 1] = static_cast<uint32_t>(best_ids.size()); }
+        std::vector<uint4> best_meta;
+        for (uint32_t a = 0; a < A; a++) {
+            for (const Best& b : best[a]) {
+                best_ids.push_back(b.id);
+                const uint32_t lo = std::min(a, b.id), hi = std::max(a, b.id), cell = cell_of[static_cast<size_t>(lo) * A + hi];
+                best_meta.push_back(make_uint4(b.id, item_off[cell], item_off[cell + 1] - item_off[cell], sparse_off[2 * cell + (a < b.id ? 0 : 1)]));
+            }
+            best_off[a + 1] = static_cast<uint32_t>(best_ids.size());
+        }
         lcty_ctx* ctx = loc->ctx;
         ctx->activate();
         hipStream_t s = ctx->stream;
@@ -586,6 +595,7 @@ int32_t lcty_locus_set_hap_alns(lcty_locus* loc, uint32_t n_entries, const uint3
         up32(loc->d_hap_cell_of, cell_of); up32(loc->d_hap_item_off, item_off); up32(loc->d_hap_sparse_off, sparse_off);
         up32(loc->d_hap_best_off, best_off); up32(loc->d_hap_best_ids, best_ids);
         up2(loc->d_hap_items, items); up2(loc->d_hap_positions, positions); up2(loc->d_hap_sparse, sparse);
+        loc->d_hap_best_meta.alloc(std::max<size_t>(best_meta.size(), 1)); loc->d_hap_best_meta.upload(best_meta.data(), best_meta.size(), s);
         LCTY_HIP(hipStreamSynchronize(s));
         loc->hap_transfer_fails = transfer_fails; loc->hap_cells = static_cast<uint32_t>(cells.size());
         loc->has_hap_alns = true;
@@ -610,7 +620,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         HapView H{};
         H.A = A; H.transfer_fails = loc->hap_transfer_fails;
         H.cell_of = loc->d_hap_cell_of.p; H.item_off = loc->d_hap_item_off.p; H.items = loc->d_hap_items.p; H.positions = loc->d_hap_positions.p;
-        H.sparse_off = loc->d_hap_sparse_off.p; H.sparse = loc->d_hap_sparse.p; H.best_off = loc->d_hap_best_off.p; H.best_ids = loc->d_hap_best_ids.p;
+        H.sparse_off = loc->d_hap_sparse_off.p; H.sparse = loc->d_hap_sparse.p; H.best_off = loc->d_hap_best_off.p; H.best_ids = loc->d_hap_best_ids.p; H.best_meta = loc->d_hap_best_meta.p;
         H.seqs = loc->d_seqs.p; H.seq_off = loc->d_seq_off.p;
 
         DevBuf<uint32_t> d_new_cnt, d_new_words, d_flag;
@@ -632,8 +642,8 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         }
         uint64_t scratch_budget = 24ull << 30;
         if (const char* e = std::getenv("LCTY_TRANSFER_SCRATCH_MB")) scratch_budget = std::max<uint64_t>(64, std::strtoull(e, nullptr, 10)) << 20;
-        // one wavefront per workgroup, 141 VGPRs: three wavefronts per SIMD
-        uint32_t waves = 12;
+        // one wavefront per workgroup, 128 VGPRs (launch bounds; a few spills are cheaper than the fourth wavefront per SIMD is worth)
+        uint32_t waves = 16;
         if (const char* e = std::getenv("LCTY_TRANSFER_WAVES")) waves = std::max(1, std::atoi(e));
         const uint32_t max_blocks = static_cast<uint32_t>(ctx->props.multiProcessorCount) * waves;
 

@@ -87,26 +87,32 @@ struct Seqs {
     __device__ __forceinline__ uint8_t r(uint32_t i) const { return target[i]; }
 };
 
-// per-lane scratch
+// per-lane scratch. The aligner's arrays are interleaved across the 64 lanes of the wavefront (element i of lane l at
+// base[i * 64 + l]): the lanes of a wavefront align similar stretches in lockstep — the targets of one source alignment — and
+// then touch the same element index at the same time, i.e. one contiguous line instead of 64 scattered ones
+constexpr uint32_t LANE_STRIDE = 64;                                  // lane stride of the interleaved arrays
 struct Scratch {
-    uint2* cig_a;          // [cigar_cap]
-    uint2* cig_b;          // [cigar_cap] (optimize)
-    uint8_t* ops;          // [2 * dp_dim + 4] aligner output, reversed
-    uint8_t* dirs;         // [dp_cells]
-    int32_t* rows;         // [2][dp_dim + 1][3]
-    int32_t* lastcol;      // [dp_dim + 1][3]
+    uint2* cig_a;          // [cigar_cap]                      (contiguous per lane)
+    uint2* cig_b;          // [cigar_cap] (optimize)           (contiguous per lane)
+    uint8_t* ops;          // [2 * dp_dim + 4] x LANE_STRIDE            aligner output, reversed
+    uint8_t* dirs;         // [dp_cells] x LANE_STRIDE
+    int32_t* rows;         // [2][dp_dim + 1][3] x LANE_STRIDE
+    int32_t* lastcol;      // [dp_dim + 1][3] x LANE_STRIDE
     Limits lim;
     uint32_t big;          // bit 0: an end-to-end stretch was too big (placeholder of the right lengths), bit 1: an ends-free one
 };
 
-__device__ inline Scratch scratch_at(uint8_t* base, const Limits& lim) {
+// `base`: the wavefront's block of 64 * lane_scratch_bytes(lim) bytes
+__device__ inline Scratch scratch_at(uint8_t* base, uint32_t lane, const Limits& lim) {
     Scratch s;
-    s.cig_a = reinterpret_cast<uint2*>(base); base += static_cast<size_t>(lim.cigar_cap) * 8;
-    s.cig_b = reinterpret_cast<uint2*>(base); base += static_cast<size_t>(lim.cigar_cap) * 8;
-    s.rows = reinterpret_cast<int32_t*>(base); base += 2 * (static_cast<size_t>(lim.dp_dim) + 1) * 12;
-    s.lastcol = reinterpret_cast<int32_t*>(base); base += (static_cast<size_t>(lim.dp_dim) + 1) * 12;
-    s.ops = base; base += (2 * static_cast<size_t>(lim.dp_dim) + 4 + 15) & ~size_t(15);
-    s.dirs = base;
+    const size_t cig = static_cast<size_t>(lim.cigar_cap) * 8, row = (static_cast<size_t>(lim.dp_dim) + 1) * 12;
+    const size_t nops = (2 * static_cast<size_t>(lim.dp_dim) + 4 + 15) & ~size_t(15);
+    s.cig_a = reinterpret_cast<uint2*>(base + lane * cig); base += 64 * cig;
+    s.cig_b = reinterpret_cast<uint2*>(base + lane * cig); base += 64 * cig;
+    s.rows = reinterpret_cast<int32_t*>(base) + lane; base += 64 * 2 * row;
+    s.lastcol = reinterpret_cast<int32_t*>(base) + lane; base += 64 * row;
+    s.ops = base + lane; base += 64 * nops;
+    s.dirs = base + lane;
     s.lim = lim; s.big = 0;
     return s;
 }
@@ -146,7 +152,7 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
     }
     const uint32_t W = m + 1;
     int32_t* prev = sc.rows;
-    int32_t* cur = sc.rows + (sc.lim.dp_dim + 1) * 3;
+    int32_t* cur = sc.rows + static_cast<size_t>(sc.lim.dp_dim + 1) * 3 * LANE_STRIDE;
     for (uint32_t a = 0; a <= n; a++) {
         for (uint32_t b = 0; b <= m; b++) {
             int32_t cm = INF32, cd = INF32, ci = INF32;
@@ -154,7 +160,7 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
             if (a == 0 && b == 0) cm = 0;
             else if (mode == 1 && (a == 0 || b == 0)) cm = 0;                 // a prefix of one sequence is skipped for free
             if (a > 0 && b > 0) {
-                const int32_t pm = prev[(b - 1) * 3], pd = prev[(b - 1) * 3 + 1], pi = prev[(b - 1) * 3 + 2];
+                const int32_t pm = prev[((b - 1) * 3) * LANE_STRIDE], pd = prev[((b - 1) * 3 + 1) * LANE_STRIDE], pi = prev[((b - 1) * 3 + 2) * LANE_STRIDE];
                 const int32_t best = min(pm, min(pd, pi));
                 if (best < INF32) {
                     const int32_t v = best + (S.r(i1 + a - 1) == S.q(j1 + b - 1) ? -mb : PEN_X);
@@ -162,21 +168,21 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
                 }
             }
             if (a > 0) {
-                const int32_t pm = prev[b * 3], pd = prev[b * 3 + 1], pi = prev[b * 3 + 2];
+                const int32_t pm = prev[(b * 3) * LANE_STRIDE], pd = prev[(b * 3 + 1) * LANE_STRIDE], pi = prev[(b * 3 + 2) * LANE_STRIDE];
                 int32_t v = min(pm, pi) + PEN_O + PEN_E;
                 if (pd + PEN_E < v) v = pd + PEN_E;
                 if (v < INF32) { cd = v; dd = (pd + PEN_E == v) ? 1u : (pm <= pi ? 0u : 2u); }
             }
             if (b > 0) {
-                const int32_t pm = cur[(b - 1) * 3], pd = cur[(b - 1) * 3 + 1], pi = cur[(b - 1) * 3 + 2];
+                const int32_t pm = cur[((b - 1) * 3) * LANE_STRIDE], pd = cur[((b - 1) * 3 + 1) * LANE_STRIDE], pi = cur[((b - 1) * 3 + 2) * LANE_STRIDE];
                 int32_t v = min(pm, pd) + PEN_O + PEN_E;
                 if (pi + PEN_E < v) v = pi + PEN_E;
                 if (v < INF32) { ci = v; di = (pi + PEN_E == v) ? 2u : (pm <= pd ? 0u : 1u); }
             }
-            cur[b * 3] = cm; cur[b * 3 + 1] = cd; cur[b * 3 + 2] = ci;
-            sc.dirs[a * W + b] = static_cast<uint8_t>(dm | (dd << 2) | (di << 4));
+            cur[(b * 3) * LANE_STRIDE] = cm; cur[(b * 3 + 1) * LANE_STRIDE] = cd; cur[(b * 3 + 2) * LANE_STRIDE] = ci;
+            sc.dirs[static_cast<size_t>(a * W + b) * LANE_STRIDE] = static_cast<uint8_t>(dm | (dd << 2) | (di << 4));
         }
-        sc.lastcol[a * 3] = cur[m * 3]; sc.lastcol[a * 3 + 1] = cur[m * 3 + 1]; sc.lastcol[a * 3 + 2] = cur[m * 3 + 2];
+        sc.lastcol[(a * 3) * LANE_STRIDE] = cur[(m * 3) * LANE_STRIDE]; sc.lastcol[(a * 3 + 1) * LANE_STRIDE] = cur[(m * 3 + 1) * LANE_STRIDE]; sc.lastcol[(a * 3 + 2) * LANE_STRIDE] = cur[(m * 3 + 2) * LANE_STRIDE];
         int32_t* t = prev; prev = cur; cur = t;
     }
     const int32_t* lastrow = prev;                                           // row n
@@ -184,46 +190,46 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
     int32_t best = INF32, em = INF32, ed = INF32, ei = INF32;
     if (mode == 2) {                                                         // the alignment may stop on the last row or column
         for (uint32_t b = 0; b <= m; b++) {
-            const int32_t v = min(lastrow[b * 3], min(lastrow[b * 3 + 1], lastrow[b * 3 + 2]));
-            if (v < best) { best = v; ea = n; eb = b; em = lastrow[b * 3]; ed = lastrow[b * 3 + 1]; ei = lastrow[b * 3 + 2]; }
+            const int32_t v = min(lastrow[(b * 3) * LANE_STRIDE], min(lastrow[(b * 3 + 1) * LANE_STRIDE], lastrow[(b * 3 + 2) * LANE_STRIDE]));
+            if (v < best) { best = v; ea = n; eb = b; em = lastrow[(b * 3) * LANE_STRIDE]; ed = lastrow[(b * 3 + 1) * LANE_STRIDE]; ei = lastrow[(b * 3 + 2) * LANE_STRIDE]; }
         }
         for (uint32_t a = 0; a <= n; a++) {
-            const int32_t v = min(sc.lastcol[a * 3], min(sc.lastcol[a * 3 + 1], sc.lastcol[a * 3 + 2]));
-            if (v < best) { best = v; ea = a; eb = m; em = sc.lastcol[a * 3]; ed = sc.lastcol[a * 3 + 1]; ei = sc.lastcol[a * 3 + 2]; }
+            const int32_t v = min(sc.lastcol[(a * 3) * LANE_STRIDE], min(sc.lastcol[(a * 3 + 1) * LANE_STRIDE], sc.lastcol[(a * 3 + 2) * LANE_STRIDE]));
+            if (v < best) { best = v; ea = a; eb = m; em = sc.lastcol[(a * 3) * LANE_STRIDE]; ed = sc.lastcol[(a * 3 + 1) * LANE_STRIDE]; ei = sc.lastcol[(a * 3 + 2) * LANE_STRIDE]; }
         }
     } else {
-        em = lastrow[m * 3]; ed = lastrow[m * 3 + 1]; ei = lastrow[m * 3 + 2];
+        em = lastrow[(m * 3) * LANE_STRIDE]; ed = lastrow[(m * 3 + 1) * LANE_STRIDE]; ei = lastrow[(m * 3 + 2) * LANE_STRIDE];
         best = min(em, min(ed, ei));
     }
     if (best >= INF32 || best > MAX_STEPS) return DP_DROPPED;
     uint32_t k = 0;
     if (mode == 2) {                                                         // the skipped suffix, as the aligner reports it
-        for (uint32_t b = m; b > eb; b--) sc.ops[k++] = 'I';
-        for (uint32_t a = n; a > ea; a--) sc.ops[k++] = 'D';
+        for (uint32_t b = m; b > eb; b--) sc.ops[static_cast<size_t>(k++) * LANE_STRIDE] = 'I';
+        for (uint32_t a = n; a > ea; a--) sc.ops[static_cast<size_t>(k++) * LANE_STRIDE] = 'D';
     }
     uint32_t a = ea, b = eb;
     uint32_t st = (em <= ed && em <= ei) ? 0u : (ed <= ei ? 1u : 2u);
     while (a > 0 || b > 0) {
         if (mode == 1 && (a == 0 || b == 0) && st == 0) break;               // reached the free border
-        const uint32_t d = sc.dirs[a * W + b];
+        const uint32_t d = sc.dirs[static_cast<size_t>(a * W + b) * LANE_STRIDE];
         if (st == 0) {
-            sc.ops[k++] = S.r(i1 + a - 1) == S.q(j1 + b - 1) ? '=' : 'X';
+            sc.ops[static_cast<size_t>(k++) * LANE_STRIDE] = S.r(i1 + a - 1) == S.q(j1 + b - 1) ? '=' : 'X';
             st = d & 3u; a--; b--;
         } else if (st == 1) {
-            sc.ops[k++] = 'D';
+            sc.ops[static_cast<size_t>(k++) * LANE_STRIDE] = 'D';
             const uint32_t dd = (d >> 2) & 3u;
             st = dd == 1 ? 1u : (dd == 0 ? 0u : 2u);
             a--;
         } else {
-            sc.ops[k++] = 'I';
+            sc.ops[static_cast<size_t>(k++) * LANE_STRIDE] = 'I';
             const uint32_t di = (d >> 4) & 3u;
             st = di == 2 ? 2u : (di == 0 ? 0u : 1u);
             b--;
         }
     }
     if (mode == 1) {                                                         // the skipped prefix
-        for (; b > 0; b--) sc.ops[k++] = 'I';
-        for (; a > 0; a--) sc.ops[k++] = 'D';
+        for (; b > 0; b--) sc.ops[static_cast<size_t>(k++) * LANE_STRIDE] = 'I';
+        for (; a > 0; a--) sc.ops[static_cast<size_t>(k++) * LANE_STRIDE] = 'D';
     }
     *n_ops = k;
     return best;
@@ -240,7 +246,7 @@ __device__ inline int aligner_align(const Seqs& S, uint32_t i1, uint32_t n, uint
     if (pen == DP_DROPPED || pen == DP_TOO_BIG) return align_simple(S, i1, n, j1, m, cg);
     bool no_matches_yet = true;
     for (uint32_t t = n_ops; t-- > 0;) {                                     // sc.ops is reversed
-        const uint32_t op = op_from_char(sc.ops[t]);
+        const uint32_t op = op_from_char(sc.ops[static_cast<size_t>(t) * LANE_STRIDE]);
         if (left_clipping && no_matches_yet && op == OP_EQ) {
             no_matches_yet = false;
             const uint32_t soft = cg.qlen;
