@@ -213,6 +213,24 @@ void orc_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy, con
 /* count_unexplained_reads (solve.rs:718-729) */
 uint32_t orc_count_unexplained(const orc_alns* a, const uint16_t* ids, uint32_t ploidy);
 
+
+/* ---- minimizer read recruitment (src/seq/recruit.rs, src/seq/kmers.rs:71-340, src/math/frac.rs) — lcty_oracle_recruit.c ---- */
+uint64_t orc_fast_hash64(uint64_t x);                                                        /* kmers.rs:93-103 */
+size_t   orc_canon_minimizers(const uint8_t* seq, size_t n, uint32_t k, uint32_t w, uint32_t* pos_out, uint64_t* hash_out,
+                              uint8_t* fw_out, size_t cap);                                  /* kmers.rs:265-340 */
+void     orc_fraction_approximate_u16(double x, uint16_t* num, uint16_t* den);               /* frac.rs:50-76 */
+typedef struct orc_targets orc_targets;
+orc_targets* orc_targets_new(uint8_t k, uint8_t w, double match_frac, uint32_t match_length, uint16_t thresh_kmer_count);   /* Params::new */
+void     orc_targets_free(orc_targets* t);
+void     orc_targets_params(const orc_targets* t, uint16_t* mf_num, uint16_t* mf_den, uint32_t* stretch_minims, uint32_t* stretch_score);
+uint32_t orc_targets_add_locus(orc_targets* t, uint32_t n_alleles, const uint8_t* seqs, const uint64_t* seq_off, const uint16_t* counts,
+                               const uint64_t* cnt_off, uint32_t base_k);                    /* TargetBuilder::add */
+void     orc_targets_finalize(orc_targets* t);
+size_t   orc_targets_n_entries(const orc_targets* t);
+void     orc_targets_entry(const orc_targets* t, size_t i, uint64_t* minim, uint32_t* locus, uint8_t* direction, uint8_t* rare);
+/* recruit_read_pair (seq2 != NULL) / recruit_short_read / recruit_long_read: loci in increasing order */
+size_t   orc_recruit(const orc_targets* t, const uint8_t* seq1, size_t n1, const uint8_t* seq2, size_t n2, uint32_t* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

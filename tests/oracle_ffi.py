@@ -120,6 +120,17 @@ def lib():
     sig("orc_discard_improbable", U64, VP, VP, VP, VP, U64, D, U64, U64)
     sig("orc_produce_result", U64, VP, VP, VP, VP, U64, D, U64, VP, VP, C.POINTER(D))
     sig("orc_count_unexplained", U32, VP, VP, U32)
+    sig("orc_fast_hash64", U64, U64)
+    sig("orc_canon_minimizers", C.c_size_t, VP, C.c_size_t, U32, U32, VP, VP, VP, C.c_size_t)
+    sig("orc_fraction_approximate_u16", None, D, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16))
+    sig("orc_targets_new", VP, C.c_uint8, C.c_uint8, D, U32, C.c_uint16)
+    sig("orc_targets_free", None, VP)
+    sig("orc_targets_params", None, VP, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(U32), C.POINTER(U32))
+    sig("orc_targets_add_locus", U32, VP, U32, VP, VP, VP, VP, U32)
+    sig("orc_targets_finalize", None, VP)
+    sig("orc_targets_n_entries", C.c_size_t, VP)
+    sig("orc_targets_entry", None, VP, C.c_size_t, C.POINTER(U64), C.POINTER(U32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8))
+    sig("orc_recruit", C.c_size_t, VP, VP, C.c_size_t, VP, C.c_size_t, VP, C.c_size_t)
     _lib = L
     return L
 
@@ -477,3 +488,60 @@ def produce_result(lik_mean, lik_var, attempts, ixs, prob_thresh, out_bams=0):
     n = lib().orc_produce_result(lik_mean.ctypes.data, lik_var.ctypes.data, attempts.ctypes.data, ixs.ctypes.data, len(ixs),
                                  prob_thresh, out_bams, out_ixs.ctypes.data, out_lp.ctypes.data, C.byref(q))
     return out_ixs[:int(n)], out_lp[:int(n)], q.value
+
+
+def canon_minimizers(seq, k, w):
+    """[(pos, hash, forward)] of kmers.rs:265-331."""
+    a = np.frombuffer(bytes(seq), dtype=np.uint8)
+    cap = len(a) + 1
+    pos = np.zeros(cap, dtype=np.uint32); hs = np.zeros(cap, dtype=np.uint64); fw = np.zeros(cap, dtype=np.uint8)
+    n = lib().orc_canon_minimizers(a.ctypes.data, len(a), k, w, pos.ctypes.data, hs.ctypes.data, fw.ctypes.data, cap)
+    return [(int(pos[i]), int(hs[i]), bool(fw[i])) for i in range(n)]
+
+
+def fraction_approximate_u16(x):
+    a, b = C.c_uint16(), C.c_uint16()
+    lib().orc_fraction_approximate_u16(x, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class OracleTargets:
+    """recruit::Targets (TargetBuilder + Params) of the oracle."""
+
+    def __init__(self, k=15, w=10, match_frac=0.5, match_length=2000, thresh_kmer_count=50):
+        self._h = lib().orc_targets_new(k, w, match_frac, match_length, thresh_kmer_count)
+        self.n_loci = 0
+
+    def params(self):
+        a, b, c, d = C.c_uint16(), C.c_uint16(), U32(), U32()
+        lib().orc_targets_params(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return (a.value, b.value), c.value, d.value
+
+    def add_locus(self, seqs, seq_off, counts, cnt_off, base_k):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8); seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint16); cnt_off = np.ascontiguousarray(cnt_off, dtype=np.uint64)
+        self.n_loci += 1
+        return lib().orc_targets_add_locus(self._h, len(seq_off) - 1, seqs.ctypes.data, seq_off.ctypes.data, counts.ctypes.data, cnt_off.ctypes.data, base_k)
+
+    def finalize(self):
+        lib().orc_targets_finalize(self._h)
+
+    def entries(self):
+        out = []
+        m, l, d, r = U64(), U32(), C.c_uint8(), C.c_uint8()
+        for i in range(lib().orc_targets_n_entries(self._h)):
+            lib().orc_targets_entry(self._h, i, C.byref(m), C.byref(l), C.byref(d), C.byref(r))
+            out.append((m.value, l.value, d.value, bool(r.value)))
+        return out
+
+    def recruit(self, seq1, seq2=None):
+        a = np.frombuffer(bytes(seq1), dtype=np.uint8)
+        b = np.frombuffer(bytes(seq2), dtype=np.uint8) if seq2 is not None else None
+        out = np.zeros(max(self.n_loci, 1), dtype=np.uint32)
+        n = lib().orc_recruit(self._h, a.ctypes.data, len(a), b.ctypes.data if b is not None else None, len(b) if b is not None else 0,
+                              out.ctypes.data, len(out))
+        return [int(x) for x in out[:n]]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_targets_free(self._h); self._h = None
