@@ -297,6 +297,33 @@ int32_t lcty_locus_set_hap_alns(lcty_locus* locus, uint32_t n_entries, const uin
 int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered);
 int32_t lcty_recover_stats(lcty_reads* reads, uint64_t* level_pairs);
 
+/* ---- minimizer read recruitment: the step of `locityper genotype` immediately before the path (SURVEY.md §8f rank 1;
+ * src/seq/recruit.rs, src/seq/kmers.rs:71-340, src/math/frac.rs) ----------------------------------------------------------------
+ * lcty_recruit_params_default: DEFAULT_MINIM_KW = (15, 10), match length 2000, k-mer threshold 50 (genotype.rs:136-139) and
+ *   Technology::default_match_frac (bg/mod.rs:245-252).
+ * lcty_targets_create / _add_locus / _finalize: recruit::Params::new (recruit.rs:65-105), TargetBuilder::add (688-738: canonical
+ *   minimizers of every allele, rare = off-target count of the k-mer around the minimizer < thresh_kmer_count) and ::finalize.
+ *   counts / cnt_off / base_k as in lcty_locus_create. Loci are numbered in the order they are added.
+ * lcty_recruit: Targets::recruit_read_pair (883-929) for every pair of the chunk when `paired`, otherwise recruit_short_read
+ *   (848-879) on mate 1 (reads of more than 500 bases go through recruit_long_read upstream: LCTY_ERR_UNSUPPORTED here, and so is
+ *   a read that matches minimizers of more than 8 loci). Only the sequence fields of the chunk are read. Output: out_cnt[i] loci of
+ *   pair i in out_loci[i * max_out ...], increasing (the reference writes the read to the files of exactly these loci). */
+typedef struct lcty_recruit_params {
+    double   match_frac;
+    uint32_t match_length;
+    uint16_t thresh_kmer_count;
+    uint8_t  minimizer_k, minimizer_w;
+} lcty_recruit_params;
+typedef struct lcty_targets lcty_targets;
+int32_t lcty_recruit_params_default(lcty_recruit_params* p, int32_t technology, int32_t is_paired);
+int32_t lcty_targets_create(lcty_ctx* ctx, const lcty_recruit_params* params, lcty_targets** out);
+void    lcty_targets_destroy(lcty_targets* targets);
+int32_t lcty_targets_add_locus(lcty_targets* targets, uint32_t n_alleles, const uint8_t* seqs, const uint64_t* seq_off,
+                               const uint16_t* counts, const uint64_t* cnt_off, uint32_t base_k, uint32_t* locus_ix);
+int32_t lcty_targets_finalize(lcty_targets* targets, uint64_t* n_minimizers);
+int32_t lcty_recruit(lcty_targets* targets, const lcty_reads_host* chunk, int32_t paired, uint32_t max_out, uint32_t* out_cnt,
+                     uint32_t* out_loci);
+
 /* ---- solver stages (src/solvers/solve.rs:789-850, src/solvers/stoch.rs, src/model/assgn.rs) ----------------
  * The reference drives these stages from one Xoshiro256++ through rand ^0.10 adaptors that are not in its tree and
  * whose results already depend on --threads (solve.rs:1017, 1051). Here every (genotype, attempt) chain gets its
@@ -377,7 +404,8 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
 #define LCTY_K_SOLVE_INIT  3 /* solve_init_kernel: apply_tweak + ReadAssignment::try_new of every chain */
 #define LCTY_K_SOLVE_TABLE 4 /* build_loc_table_kernel: allele-major location table of a scored batch */
 #define LCTY_K_TRANSFER  5   /* transfer_kernel: alignment recovery */
-#define LCTY_K_COUNT     6
+#define LCTY_K_RECRUIT   6   /* recruit_kernel: minimizer read recruitment */
+#define LCTY_K_COUNT     7
 int32_t lcty_timing_reset(lcty_ctx* ctx);
 int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms);
 

@@ -47,6 +47,12 @@ SIGNATURES = {
     "lcty_locus_set_hap_alns": (I32, [VP, U32, VP, VP, VP, VP, VP, VP, U32, D]),
     "lcty_recover_alignments": (I32, [VP, P(U64)]),
     "lcty_recover_stats": (I32, [VP, P(U64)]),
+    "lcty_recruit_params_default": (I32, [VP, I32, I32]),
+    "lcty_targets_create": (I32, [VP, VP, P(VP)]),
+    "lcty_targets_destroy": (None, [VP]),
+    "lcty_targets_add_locus": (I32, [VP, U32, VP, VP, VP, VP, U32, P(U32)]),
+    "lcty_targets_finalize": (I32, [VP, P(U64)]),
+    "lcty_recruit": (I32, [VP, VP, I32, U32, VP, VP]),
     "lcty_solver_default": (I32, [P(Solver), I32]),
     "lcty_chain_seeds": (I32, [U64, U64, VP]),
     "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),

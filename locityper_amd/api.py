@@ -433,3 +433,58 @@ def solve_locus(aa, stages=None, master_seed=1, priors=None, ploidy=2):
     check(lib().lcty_solve(aa._h, ploidy, stages, len(stages), master_seed, None if pri is None else pri.ctypes.data, C.byref(call),
                            mean.ctypes.data, var.ctypes.data, att.ctypes.data))
     return call, mean, var, att
+
+
+K_RECRUIT = 6
+
+
+def recruit_params(technology=cdefs.TECH_ILLUMINA, paired=True, **over):
+    """recruit::Params defaults (DEFAULT_MINIM_KW, match length 2000, k-mer threshold 50, Technology::default_match_frac)."""
+    p = cdefs.RecruitParams()
+    check(lib().lcty_recruit_params_default(C.byref(p), technology, int(paired)))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Targets:
+    """recruit::Targets (TargetBuilder::add per locus, then finalize) and Targets::recruit_* on the device."""
+
+    def __init__(self, ctx, params):
+        self.ctx = ctx
+        self._h = VP()
+        check(lib().lcty_targets_create(ctx._h, C.byref(params), C.byref(self._h)))
+        self.n_loci = 0
+
+    def add_locus(self, seqs, seq_off, counts, cnt_off, base_k):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8); seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint16); cnt_off = np.ascontiguousarray(cnt_off, dtype=np.uint64)
+        ix = U32()
+        check(lib().lcty_targets_add_locus(self._h, len(seq_off) - 1, seqs.ctypes.data, seq_off.ctypes.data, counts.ctypes.data,
+                                           cnt_off.ctypes.data, base_k, C.byref(ix)))
+        self.n_loci += 1
+        return int(ix.value)
+
+    def finalize(self):
+        n = U64()
+        check(lib().lcty_targets_finalize(self._h, C.byref(n)))
+        return int(n.value)
+
+    def recruit(self, chunk, paired=True, max_out=8):
+        """Loci of every read pair (single read) of the chunk: list of sorted lists."""
+        hs = chunk.host_struct()
+        n = chunk.n_pairs
+        cnt = np.zeros(max(n, 1), dtype=np.uint32); loci = np.zeros(max(n, 1) * max_out, dtype=np.uint32)
+        check(lib().lcty_recruit(self._h, C.byref(hs), int(paired), max_out, cnt.ctypes.data, loci.ctypes.data))
+        return cnt[:n], loci.reshape(-1, max_out)[:n]
+
+    def close(self):
+        if self._h:
+            lib().lcty_targets_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

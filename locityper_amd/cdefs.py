@@ -263,6 +263,11 @@ class ReadsChunk:
         return ReadsChunk(self.mate_len, self.mate_off, self.bases2, self.nmask, aln_off, recs, cigar_off, cigar)
 
 
+class RecruitParams(C.Structure):      # lcty_recruit_params
+    _fields_ = [("match_frac", C.c_double), ("match_length", C.c_uint32), ("thresh_kmer_count", C.c_uint16),
+                ("minimizer_k", C.c_uint8), ("minimizer_w", C.c_uint8)]
+
+
 WARN_NO_PROBABLE_GENOTYPE, WARN_FEW_READS = 1, 2      # lcty_call_checks
 
 

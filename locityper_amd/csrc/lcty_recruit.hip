@@ -1,0 +1,389 @@
+// lcty_recruit.hip — minimizer read recruitment: which loci does a read (pair) belong to?
+//   src/seq/recruit.rs (Params 43-105, MatchCount 236-367, TargetBuilder 663-756, Targets::recruit_* 848-996),
+//   src/seq/kmers.rs:93-103 (fasthash mix), 243-331 (canonical minimizers), src/math/frac.rs:50-93.
+//
+// Targets are built on the host once (minimizers of the alleles, one entry per (minimizer, locus): direction bits, "rare");
+// the device holds an open-addressing table minimizer -> run of entries. recruit_kernel: one lane per read pair. A lane walks
+// its two mates base by base (rolling forward / reverse k-mer, hash, ring of the last w hashes in LDS, window minimum with the
+// rescan rule of the reference), probes the table at every minimizer and counts matches per locus in registers (up to 8 loci per
+// read pair, linear search), then applies the fraction tests. Integer arithmetic throughout: results are those of the reference.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+#include <unordered_map>
+
+#include "lcty_objects.hpp"
+
+namespace lcty {
+
+constexpr uint64_t UNDEF64 = ~0ull;
+constexpr uint32_t MAX_LOCI_PER_READ = 8;
+constexpr uint32_t READ_LENGTH_THRESH = 500;       // recruit.rs:35
+
+__host__ __device__ inline uint64_t fast_hash64(uint64_t x) {      // kmers.rs:93-103
+    x = ~x;
+    x ^= x >> 23;
+    x *= 0x2127599bf4325c37ull;
+    x ^= x >> 47;
+    return x;
+}
+
+struct TableSlot { uint64_t key; uint32_t start, count; };      // key UNDEF64 = free (UNDEF is never a minimizer, kmers.rs:27-30)
+// entry: locus | direction << 24 (bit 0 backward, bit 1 forward) | rare << 26
+
+struct RecruitView {
+    const TableSlot* table; uint64_t table_mask;
+    const uint32_t* entries;
+    uint32_t k, w, ring;                 // ring: power of two >= w
+    uint32_t mf_num, mf_den;             // match_frac_short
+    // reads
+    uint64_t n_pairs;
+    const uint32_t* mate_len; const uint64_t* mate_off; const uint32_t* bases2; const uint32_t* nmask;
+    int paired;
+    uint32_t max_out;
+    uint32_t* out_cnt; uint32_t* out_loci;
+    uint32_t* err;
+};
+
+// per-lane match counts of up to MAX_LOCI_PER_READ loci; counts packed 4 x u16: [common-bw, common-fw, rare-bw, rare-fw] (recruit.rs:236-240)
+struct Matches {
+    uint32_t locus[MAX_LOCI_PER_READ];
+    uint64_t first[MAX_LOCI_PER_READ], second[MAX_LOCI_PER_READ];
+    uint32_t n;
+};
+
+// minimizers::<u64, _, CANONICAL> (kmers.rs:265-331) of one mate; calls on_minimizer(hash, forward) for every minimizer; returns their number
+template <typename F>
+__device__ inline uint32_t walk_minimizers(const RecruitView& V, const uint64_t* w64, const uint32_t* nm, uint32_t len, uint64_t* ring, F&& on_minimizer) {
+    const uint32_t k = V.k, w = V.w, k_1 = k - 1, w_1 = w - 1, rmask = V.ring - 1;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const uint32_t rv_shift = 2 * k - 2;
+    uint64_t fw_kmer = 0, rv_kmer = 0, fwd_bits = ~0ull;              // forward flag of ring slot j at bit j
+    for (uint32_t j = 0; j < V.ring; j++) ring[j * 64] = UNDEF64;
+    int64_t last_pos = -1;
+    uint32_t best_pos = 0;
+    uint64_t best_hash = UNDEF64;
+    uint32_t first_kmer = k_1, first_window = k_1 + w_1, total = 0;
+    uint64_t word = 0; uint32_t nword = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        if ((i & 31u) == 0) { word = w64[i >> 5]; nword = nm[i >> 5]; }
+        const uint64_t enc = (word >> ((i & 31u) * 2u)) & 3ull;
+        const bool isn = (nword >> (i & 31u)) & 1u;
+        uint64_t fw_enc = enc, rv_enc = 3ull - enc;
+        if (isn) { first_kmer = i + k; fw_enc = 0; rv_enc = 0; }
+        fw_kmer = ((fw_kmer << 2) | fw_enc) & mask;
+        rv_kmer = (rv_kmer >> 2) | (rv_enc << rv_shift);
+        const bool fwd = !(rv_kmer < fw_kmer);
+        const uint64_t kmer = fwd ? fw_kmer : rv_kmer;
+        const uint64_t h = i < first_kmer ? UNDEF64 : fast_hash64(kmer);
+        ring[(i & rmask) * 64] = h;
+        fwd_bits = (fwd_bits & ~(1ull << (i & rmask))) | (static_cast<uint64_t>(fwd) << (i & rmask));
+        if (h < best_hash) { best_hash = h; best_pos = i; }
+        if (i < first_window) continue;
+        const uint32_t start = i - w_1;
+        if (best_pos < start) {
+            best_pos = start; best_hash = ring[(start & rmask) * 64];           // find_min (kmers.rs:243-258): leftmost minimum
+            for (uint32_t j = start + 1; j <= i; j++) { const uint64_t v = ring[(j & rmask) * 64]; if (v < best_hash) { best_pos = j; best_hash = v; } }
+            if (best_hash == UNDEF64) { first_window = first_window + w_1; continue; }
+        }
+        if (static_cast<int64_t>(best_pos) > last_pos) {
+            last_pos = best_pos;
+            total++;
+            on_minimizer(best_hash, ((fwd_bits >> (best_pos & rmask)) & 1ull) != 0);
+        }
+    }
+    return total;
+}
+
+__device__ __forceinline__ uint32_t c16(uint64_t packed, uint32_t i) { return static_cast<uint32_t>(packed >> (16 * i)) & 0xFFFFu; }
+// (Wr + c) / (W(n - c) + c) with W = 3 (recruit.rs:282-325), all in u16 as upstream
+__device__ __forceinline__ uint32_t fw_num(uint64_t a) { return (3u * c16(a, 3) + c16(a, 1)) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t bw_num(uint64_t a) { return (3u * c16(a, 2) + c16(a, 0)) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t fw_den(uint64_t a, uint32_t total) { return (3u * (total - c16(a, 1)) + c16(a, 1)) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t bw_den(uint64_t a, uint32_t total) { return (3u * (total - c16(a, 0)) + c16(a, 0)) & 0xFFFFu; }
+__device__ __forceinline__ bool has_rare(uint64_t a) { return (a >> 32) != 0; }
+
+__global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint64_t* ring = reinterpret_cast<uint64_t*>(smem) + threadIdx.x;           // slot j of this lane at ring[j * 64]
+    const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
+    if (p >= V.n_pairs) return;
+    const uint32_t len1 = V.mate_len[2 * p], len2 = V.paired ? V.mate_len[2 * p + 1] : 0u;
+    V.out_cnt[p] = 0;
+    if (!V.paired && len1 > READ_LENGTH_THRESH) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); return; }
+    Matches M; M.n = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) { M.locus[j] = 0xFFFFFFFFu; M.first[j] = 0; M.second[j] = 0; }
+    bool overflow = false;
+    auto probe = [&](uint64_t minim, bool forward, bool second) {
+        uint64_t slot = mix64(minim) & V.table_mask;
+        TableSlot ts = V.table[slot];
+        while (ts.key != UNDEF64 && ts.key != minim) { slot = (slot + 1) & V.table_mask; ts = V.table[slot]; }
+        if (ts.key != minim) return;
+        for (uint32_t q = 0; q < ts.count; q++) {
+            const uint32_t e = V.entries[ts.start + q];
+            const uint32_t locus = e & 0xFFFFFFu, direction = (e >> 24) & 3u, rare = (e >> 26) & 1u;
+            // BaseMatchCount::inc (recruit.rs:250-256)
+            const uint64_t inc = (static_cast<uint64_t>((direction & (1u + !forward)) != 0) << (32 * rare))
+                               | (static_cast<uint64_t>((direction & (1u + forward)) != 0) << (32 * rare + 16));
+            bool found = false;
+#pragma unroll
+            for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++)
+                if (M.locus[j] == locus) { found = true; if (second) M.second[j] += inc; else M.first[j] += inc; }
+            if (!found && !second) {                                             // get_or_insert; the second mate never inserts (912-915)
+                if (M.n == MAX_LOCI_PER_READ) overflow = true;
+                else {
+#pragma unroll
+                    for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) if (j == M.n) { M.locus[j] = locus; M.first[j] = inc; }
+                    M.n++;
+                }
+            }
+        }
+    };
+    const uint64_t off1 = V.mate_off[2 * p];
+    const uint32_t total1 = walk_minimizers(V, reinterpret_cast<const uint64_t*>(V.bases2) + (off1 >> 5), V.nmask + (off1 >> 5), len1, ring,
+                                            [&](uint64_t h, bool fw) { probe(h, fw, false); });
+    uint32_t total2 = 0;
+    if (V.paired && M.n) {
+        const uint64_t off2 = V.mate_off[2 * p + 1];
+        total2 = walk_minimizers(V, reinterpret_cast<const uint64_t*>(V.bases2) + (off2 >> 5), V.nmask + (off2 >> 5), len2, ring,
+                                 [&](uint64_t h, bool fw) { probe(h, fw, true); });
+    }
+    if (overflow) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); return; }
+    uint32_t n_out = 0;
+    uint32_t* out = V.out_loci + p * V.max_out;
+#pragma unroll
+    for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) {
+        if (j >= M.n) continue;
+        const uint64_t a = M.first[j], b = M.second[j];
+        bool take = false;
+        if (V.paired) {
+            if (has_rare(a) || has_rare(b)) {                                    // recruit_read_pair (919-927), better_pair_fraction (351-367)
+                uint32_t n1, d1, n2, d2;
+                if (((fw_num(a) + bw_num(b)) & 0xFFFFu) >= ((bw_num(a) + fw_num(b)) & 0xFFFFu)) { n1 = fw_num(a); d1 = fw_den(a, total1); n2 = bw_num(b); d2 = bw_den(b, total2); }
+                else { n1 = bw_num(a); d1 = bw_den(a, total1); n2 = fw_num(b); d2 = fw_den(b, total2); }
+                take = n1 * V.mf_den >= V.mf_num * d1 && n2 * V.mf_den >= V.mf_num * d2;      // Fraction<u16>::partial_cmp (frac.rs:87-93)
+            }
+        } else if (has_rare(a)) {                                                // recruit_short_read (871-877), better_fraction (340-348)
+            uint32_t n1, d1;
+            if (fw_num(a) >= bw_num(a)) { n1 = fw_num(a); d1 = fw_den(a, total1); } else { n1 = bw_num(a); d1 = bw_den(a, total1); }
+            take = n1 * V.mf_den >= V.mf_num * d1;
+        }
+        if (take) { if (n_out < V.max_out) out[n_out] = M.locus[j]; n_out++; }
+    }
+    if (n_out > V.max_out) atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_INVALID_INPUT));
+    V.out_cnt[p] = n_out;
+}
+
+}  // namespace lcty
+
+using namespace lcty;
+
+struct lcty_targets {
+    lcty_ctx* ctx = nullptr;
+    lcty_recruit_params prm{};
+    uint16_t mf_num = 0, mf_den = 1;
+    uint32_t n_loci = 0;
+    bool finalized = false;
+    struct Entry { uint32_t locus; uint8_t direction, rare; };
+    std::unordered_map<uint64_t, std::vector<Entry>> minim_to_loci;
+    DevBuf<TableSlot> d_table; DevBuf<uint32_t> d_entries, d_err;
+    uint64_t table_mask = 0;
+};
+
+namespace {
+
+// minimizers::<u64, _, CANONICAL> on the host (ASCII input), with positions: TargetBuilder::add needs them
+void host_minimizers(const uint8_t* seq, size_t n, uint32_t k, uint32_t w, std::vector<uint32_t>& pos, std::vector<uint64_t>& hs, std::vector<uint8_t>& fwv) {
+    pos.clear(); hs.clear(); fwv.clear();
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const uint32_t rv_shift = 2 * k - 2, k_1 = k - 1, w_1 = w - 1;
+    uint64_t fw_kmer = 0, rv_kmer = 0, hashes[64]; uint8_t forward[64];
+    for (int i = 0; i < 64; i++) { hashes[i] = UNDEF64; forward[i] = 1; }
+    int64_t last_pos = -1; uint32_t best_pos = 0; uint64_t best_hash = UNDEF64;
+    uint32_t first_kmer = k_1, first_window = k_1 + w_1;
+    for (size_t ii = 0; ii < n; ii++) {
+        const uint32_t i = static_cast<uint32_t>(ii);
+        uint64_t fe = 0, re = 0;
+        switch (seq[ii]) {
+            case 'A': fe = 0; re = 3; break;
+            case 'C': fe = 1; re = 2; break;
+            case 'G': fe = 2; re = 1; break;
+            case 'T': fe = 3; re = 0; break;
+            default: first_kmer = i + k;
+        }
+        fw_kmer = ((fw_kmer << 2) | fe) & mask;
+        rv_kmer = (rv_kmer >> 2) | (re << rv_shift);
+        const bool fwd = !(rv_kmer < fw_kmer);
+        const uint64_t h = i < first_kmer ? UNDEF64 : fast_hash64(fwd ? fw_kmer : rv_kmer);
+        hashes[i & 63] = h; forward[i & 63] = fwd;
+        if (h < best_hash) { best_hash = h; best_pos = i; }
+        if (i < first_window) continue;
+        const uint32_t start = i - w_1;
+        if (best_pos < start) {
+            best_pos = start; best_hash = hashes[start & 63];
+            for (uint32_t j = start + 1; j <= i; j++) if (hashes[j & 63] < best_hash) { best_pos = j; best_hash = hashes[j & 63]; }
+            if (best_hash == UNDEF64) { first_window = first_window + w_1; continue; }
+        }
+        if (static_cast<int64_t>(best_pos) > last_pos) {
+            last_pos = best_pos;
+            pos.push_back(best_pos - k_1); hs.push_back(best_hash); fwv.push_back(forward[best_pos & 63]);
+        }
+    }
+}
+
+// Fraction::<u16>::approximate (frac.rs:50-76)
+void approximate_u16(double x, uint16_t* num, uint16_t* den) {
+    uint64_t a2 = 1, a1 = static_cast<uint64_t>(std::floor(x)), b2 = 0, b1 = 1;
+    double xk = x;
+    for (int it = 0; it < 20; it++) {
+        const double numer = xk - std::floor(xk);
+        if (numer <= 2.220446049250313e-16) break;
+        xk = 1.0 / numer;
+        const double fl = std::floor(xk);
+        if (!(fl >= 0.0 && fl <= 65535.0)) break;
+        const uint64_t f = static_cast<uint64_t>(fl);
+        if (f * a1 > 65535 || f * a1 + a2 > 65535 || f * b1 > 65535 || f * b1 + b2 > 65535) break;
+        const uint64_t a0 = f * a1 + a2, b0 = f * b1 + b2;
+        a2 = a1; a1 = a0; b2 = b1; b1 = b0;
+        if (std::fabs(static_cast<double>(a1) / static_cast<double>(b1) - x) <= 2.220446049250313e-16) break;
+    }
+    *num = static_cast<uint16_t>(a1); *den = static_cast<uint16_t>(b1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t lcty_recruit_params_default(lcty_recruit_params* p, int32_t technology, int32_t is_paired) {
+    return guarded([&] {
+        if (!p) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (technology != LCTY_TECH_ILLUMINA && is_paired) fail(LCTY_ERR_INVALID_INPUT, "Paired-end long reads are not supported");   // bg/mod.rs:250
+        memset(p, 0, sizeof(*p));
+        p->minimizer_k = 15; p->minimizer_w = 10;                               // recruit::DEFAULT_MINIM_KW
+        p->match_length = 2000; p->thresh_kmer_count = 50;                      // recruit.rs:31, genotype.rs:139
+        p->match_frac = technology == LCTY_TECH_ILLUMINA ? (is_paired ? 0.5 : 0.7) : 0.5;    // bg/mod.rs:245-252
+    });
+}
+
+int32_t lcty_targets_create(lcty_ctx* ctx, const lcty_recruit_params* prm, lcty_targets** out) {
+    return guarded([&] {
+        if (!ctx || !prm || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        // Params::new (recruit.rs:65-105)
+        if (!(prm->minimizer_k > 0 && prm->minimizer_k <= 31)) fail(LCTY_ERR_INVALID_INPUT, "Minimizer kmer-size must be within [1, 31]");
+        if (!(prm->minimizer_w > 1 && prm->minimizer_w <= 64)) fail(LCTY_ERR_INVALID_INPUT, "Minimizer window-size must be within [2, 64]");
+        if (prm->minimizer_w == 64) fail(LCTY_ERR_UNSUPPORTED, "minimizer window of 64 k-mers");       // kmers.rs:268 asserts w < 64 as well
+        if (!(prm->match_frac >= 0.25 && prm->match_frac <= 1.0)) fail(LCTY_ERR_INVALID_INPUT, "Minimizer match fraction (%g) must be in [0.25000, 1]", prm->match_frac);
+        if (!(prm->match_length >= 200 && prm->match_length <= 100000)) fail(LCTY_ERR_INVALID_INPUT, "Matching stretch length (%u) should be between 200 and 100,000", prm->match_length);
+        if (prm->thresh_kmer_count == 0) fail(LCTY_ERR_INVALID_INPUT, "k-mer threshold must be positive");
+        auto t = std::make_unique<lcty_targets>();
+        t->ctx = ctx; t->prm = *prm;
+        approximate_u16(prm->match_frac, &t->mf_num, &t->mf_den);
+        *out = t.release();
+    });
+}
+
+void lcty_targets_destroy(lcty_targets* t) { delete t; }
+
+int32_t lcty_targets_add_locus(lcty_targets* t, uint32_t n_alleles, const uint8_t* seqs, const uint64_t* seq_off, const uint16_t* counts,
+                               const uint64_t* cnt_off, uint32_t base_k, uint32_t* locus_ix) {
+    return guarded([&] {
+        if (!t || !seqs || !seq_off || !counts || !cnt_off) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (t->finalized) fail(LCTY_ERR_INVALID_INPUT, "targets are finalized");
+        if (t->n_loci >= (1u << 24) - 1) fail(LCTY_ERR_UNSUPPORTED, "too many loci");
+        const uint32_t locus = t->n_loci, mk = t->prm.minimizer_k;
+        const size_t shift = mk <= base_k ? (base_k - mk) / 2 : mk - base_k;
+        std::vector<uint32_t> pos; std::vector<uint64_t> hs; std::vector<uint8_t> fw;
+        for (uint32_t a = 0; a < n_alleles; a++) {
+            const size_t len = seq_off[a + 1] - seq_off[a], n_counts = cnt_off[a + 1] - cnt_off[a];
+            if ((len + 1 > base_k ? len + 1 - base_k : 0) != n_counts) fail(LCTY_ERR_INVALID_DATA, "Sequence and k-mer lengths do not match");   // recruit.rs:703
+            const uint16_t* cnt = counts + cnt_off[a];
+            host_minimizers(seqs + seq_off[a], len, mk, t->prm.minimizer_w, pos, hs, fw);
+            for (size_t i = 0; i < hs.size(); i++) {
+                const size_t p = pos[i];
+                bool rare;
+                if (mk <= base_k) rare = cnt[std::min<size_t>(p > shift ? p - shift : 0, n_counts - 1)] < t->prm.thresh_kmer_count;
+                else rare = cnt[p] < t->prm.thresh_kmer_count && cnt[p + shift] < t->prm.thresh_kmer_count;
+                auto& v = t->minim_to_loci[hs[i]];
+                if (!v.empty() && v.back().locus == locus) { v.back().direction |= static_cast<uint8_t>(1 + fw[i]); v.back().rare &= static_cast<uint8_t>(rare); }
+                else v.push_back(lcty_targets::Entry{locus, static_cast<uint8_t>(1 + fw[i]), static_cast<uint8_t>(rare)});
+            }
+        }
+        t->n_loci++;
+        if (locus_ix) *locus_ix = locus;
+    });
+}
+
+int32_t lcty_targets_finalize(lcty_targets* t, uint64_t* n_minimizers) {
+    return guarded([&] {
+        if (!t) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (t->minim_to_loci.empty()) fail(LCTY_ERR_RUNTIME, "No minimizers for recruitment");       // recruit.rs:748
+        uint64_t cap = 64;
+        while (cap < 2 * t->minim_to_loci.size() + 2) cap <<= 1;
+        std::vector<TableSlot> table(cap, TableSlot{UNDEF64, 0, 0});
+        std::vector<uint32_t> entries;
+        for (const auto& kv : t->minim_to_loci) {
+            uint64_t slot = mix64(kv.first) & (cap - 1);
+            while (table[slot].key != UNDEF64) slot = (slot + 1) & (cap - 1);
+            table[slot] = TableSlot{kv.first, static_cast<uint32_t>(entries.size()), static_cast<uint32_t>(kv.second.size())};
+            for (const auto& e : kv.second) entries.push_back(e.locus | (static_cast<uint32_t>(e.direction) << 24) | (static_cast<uint32_t>(e.rare) << 26));
+        }
+        lcty_ctx* ctx = t->ctx;
+        ctx->activate();
+        hipStream_t s = ctx->stream;
+        t->d_table.alloc(cap); t->d_table.upload(table.data(), cap, s);
+        t->d_entries.alloc(std::max<size_t>(entries.size(), 1)); t->d_entries.upload(entries.data(), entries.size(), s);
+        t->d_err.alloc(1);
+        LCTY_HIP(hipStreamSynchronize(s));
+        t->table_mask = cap - 1;
+        t->finalized = true;
+        if (n_minimizers) *n_minimizers = t->minim_to_loci.size();
+    });
+}
+
+int32_t lcty_recruit(lcty_targets* t, const lcty_reads_host* h, int32_t paired, uint32_t max_out, uint32_t* out_cnt, uint32_t* out_loci) {
+    return guarded([&] {
+        if (!t || !h || !out_cnt || !out_loci || max_out == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (!t->finalized) fail(LCTY_ERR_INVALID_INPUT, "lcty_targets_finalize has not been called");
+        const uint64_t n = h->n_pairs;
+        if (n == 0) return;
+        if (!h->mate_len || !h->mate_off || !h->bases2 || !h->nmask) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        lcty_ctx* ctx = t->ctx;
+        ctx->activate();
+        hipStream_t s = ctx->stream;
+        const uint64_t nb = h->mate_off[2 * n];
+        for (uint64_t m = 0; m < 2 * n; m++) {
+            if (h->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
+            if (h->mate_off[m + 1] < h->mate_off[m] + h->mate_len[m]) fail(LCTY_ERR_INVALID_INPUT, "mate offsets overlap");
+        }
+        DevBuf<uint32_t> d_len, d_bases, d_nm, d_cnt, d_loci; DevBuf<uint64_t> d_off;
+        d_len.alloc(2 * n); d_off.alloc(2 * n + 1); d_bases.alloc(std::max<uint64_t>(nb / 16, 2)); d_nm.alloc(std::max<uint64_t>(nb / 32, 1));
+        d_cnt.alloc(n); d_loci.alloc(n * max_out);
+        d_len.upload(h->mate_len, 2 * n, s); d_off.upload(h->mate_off, 2 * n + 1, s);
+        d_bases.upload(h->bases2, nb / 16, s); d_nm.upload(h->nmask, nb / 32, s);
+        t->d_err.zero(s);
+        RecruitView V{};
+        V.table = t->d_table.p; V.table_mask = t->table_mask; V.entries = t->d_entries.p;
+        V.k = t->prm.minimizer_k; V.w = t->prm.minimizer_w;
+        V.ring = 2; while (V.ring < V.w) V.ring <<= 1;
+        V.mf_num = t->mf_num; V.mf_den = t->mf_den;
+        V.n_pairs = n; V.mate_len = d_len.p; V.mate_off = d_off.p; V.bases2 = d_bases.p; V.nmask = d_nm.p;
+        V.paired = paired != 0; V.max_out = max_out; V.out_cnt = d_cnt.p; V.out_loci = d_loci.p; V.err = t->d_err.p;
+        const size_t lds = static_cast<size_t>(V.ring) * 64 * 8;
+        ctx->timed(LCTY_K_RECRUIT, [&] {
+            hipLaunchKernelGGL(recruit_kernel, dim3(static_cast<uint32_t>((n + 63) / 64)), dim3(64), lds, s, V);
+        });
+        LCTY_HIP(hipGetLastError());
+        uint32_t err = 0;
+        t->d_err.download(&err, 1, s);
+        d_cnt.download(out_cnt, n, s); d_loci.download(out_loci, n * max_out, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        if (err == LCTY_ERR_UNSUPPORTED) fail(LCTY_ERR_UNSUPPORTED, "recruitment: a single read of more than %u bases (long-read recruitment is not on the device yet) or a read matching minimizers of more than %u loci", READ_LENGTH_THRESH, MAX_LOCI_PER_READ);
+        if (err == LCTY_ERR_INVALID_INPUT) fail(LCTY_ERR_INVALID_INPUT, "recruitment: max_out is smaller than the number of loci of a read");
+        if (err) fail(static_cast<int32_t>(err), "recruitment failed on the device");
+        for (uint64_t i = 0; i < n; i++) std::sort(out_loci + i * max_out, out_loci + i * max_out + out_cnt[i]);
+    });
+}
+
+}  // extern "C"

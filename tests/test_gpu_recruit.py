@@ -1,0 +1,102 @@
+"""Minimizer read recruitment on the device against the oracle, through the C ABI: bit-exact (sets of loci)."""
+import numpy as np
+import pytest
+
+from locityper_amd import _lib, api, cdefs
+from locityper_amd.cdefs import ReadsChunk
+from tests import oracle_ffi as O
+from tests.helpers import noisy_read
+from tests.test_oracle_recruit import _loci, revcomp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx():
+    return api.Context(0)
+
+
+def _both(ctx, loci, base_k=25, **over):
+    prm = api.recruit_params(**over)
+    gt = api.Targets(ctx, prm)
+    ot = O.OracleTargets(prm.minimizer_k, prm.minimizer_w, prm.match_frac, prm.match_length, prm.thresh_kmer_count)
+    rng = np.random.default_rng(9)
+    for alleles in loci:
+        counts = [np.where(rng.random(len(a) - base_k + 1) < 0.1, 80, 0).astype(np.uint16) for a in alleles]
+        seqs = np.frombuffer(b"".join(alleles), dtype=np.uint8)
+        seq_off = np.cumsum([0] + [len(a) for a in alleles]).astype(np.uint64)
+        cnt_off = np.cumsum([0] + [len(c) for c in counts]).astype(np.uint64)
+        gt.add_locus(seqs, seq_off, np.concatenate(counts), cnt_off, base_k)
+        ot.add_locus(seqs, seq_off, np.concatenate(counts), cnt_off, base_k)
+    n = gt.finalize(); ot.finalize()
+    assert n == len({e[0] for e in ot.entries()})
+    return gt, ot
+
+
+def _reads(rng, loci, n, lens=(150, 150)):
+    pairs = []
+    for i in range(n):
+        li = int(rng.integers(0, len(loci))); al = loci[li][int(rng.integers(0, len(loci[li])))]
+        kind = i % 7
+        l1 = int(rng.integers(lens[0], lens[1] + 1)); l2 = int(rng.integers(lens[0], lens[1] + 1))
+        if kind == 6:
+            r1 = bytes(rng.choice(list(b"ACGT"), l1).tolist()); r2 = bytes(rng.choice(list(b"ACGT"), l2).tolist())
+        else:
+            p = int(rng.integers(0, len(al) - 800))
+            r1, _ = noisy_read(rng, al, p, l1, err=0.02 * (kind % 3)); r2, _ = noisy_read(rng, al, p + 300, l2, err=0.02 * (kind % 3))
+            r2 = revcomp(r2)
+            if kind == 4: r1 = r1[:30] + b"NN" + r1[32:]
+            if kind == 5: r2 = r2[:10] + b"N" * 60 + r2[70:]
+            if i % 2: r1, r2 = revcomp(r1), revcomp(r2)
+        pairs.append({"seq1": r1.decode(), "seq2": r2.decode(), "recs": []})
+    return pairs
+
+
+@pytest.mark.parametrize("over", [dict(), dict(minimizer_k=27, minimizer_w=5, match_frac=0.7), dict(minimizer_k=11, minimizer_w=20, match_frac=0.3),
+                                  dict(minimizer_k=31, minimizer_w=31, match_frac=0.5), dict(thresh_kmer_count=200)])
+def test_read_pairs_and_single_reads_match_oracle(gpu_ctx, over):
+    rng = np.random.default_rng(5)
+    loci = _loci(rng, n_loci=4)
+    gt, ot = _both(gpu_ctx, loci, **over)
+    pairs = _reads(rng, loci, 700, lens=(60, 250))
+    ch = ReadsChunk.from_pairs(pairs)
+    cnt, out = gt.recruit(ch, paired=True)
+    n_rec = n_multi = 0
+    for i, pr in enumerate(pairs):
+        exp = ot.recruit(pr["seq1"].encode(), pr["seq2"].encode())
+        assert list(out[i, :cnt[i]]) == exp, (i, over)
+        n_rec += bool(exp); n_multi += len(exp) > 1
+    assert n_rec > 100 and n_multi > 5
+    cnt, out = gt.recruit(ch, paired=False)
+    for i, pr in enumerate(pairs):
+        assert list(out[i, :cnt[i]]) == ot.recruit(pr["seq1"].encode()), (i, over)
+
+
+def test_edges_and_misuse(gpu_ctx):
+    rng = np.random.default_rng(7)
+    loci = _loci(rng, n_loci=3)
+    gt, ot = _both(gpu_ctx, loci)
+    al = loci[0][0]
+    # reads shorter than k + w - 1, empty mates, all-N reads, a read pair whose second mate is foreign
+    pairs = [{"seq1": al[100:110].decode(), "seq2": al[400:420].decode(), "recs": []},
+             {"seq1": "N" * 150, "seq2": al[400:550].decode(), "recs": []},
+             {"seq1": al[100:250].decode(), "seq2": "ACGT" * 40, "recs": []},
+             {"seq1": al[100:250].decode(), "seq2": revcomp(al[400:550]).decode(), "recs": []},
+             {"seq1": al[100:124].decode(), "seq2": al[400:424].decode(), "recs": []}]
+    ch = ReadsChunk.from_pairs(pairs)
+    cnt, out = gt.recruit(ch, paired=True)
+    for i, pr in enumerate(pairs):
+        assert list(out[i, :cnt[i]]) == ot.recruit(pr["seq1"].encode(), pr["seq2"].encode()), i
+    assert list(cnt) == [0, 0, 0, 1, 0] or cnt[3] == 1
+    # a long single read is refused (recruit_long_read is not on the device), never answered differently
+    long_ch = ReadsChunk.from_pairs([{"seq1": al[:900].decode(), "seq2": None, "recs": []}])
+    with pytest.raises(_lib.LocityperError) as ei:
+        gt.recruit(long_ch, paired=False)
+    assert ei.value.code == cdefs.ERR_UNSUPPORTED
+    with pytest.raises(_lib.LocityperError):
+        api.Targets(gpu_ctx, api.recruit_params(match_frac=0.1))
+    with pytest.raises(_lib.LocityperError):
+        api.Targets(gpu_ctx, api.recruit_params(minimizer_k=32))
+    empty = api.Targets(gpu_ctx, api.recruit_params())
+    with pytest.raises(_lib.LocityperError):
+        empty.finalize()                                                      # "No minimizers for recruitment"
