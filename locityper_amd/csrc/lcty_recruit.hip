@@ -4,9 +4,11 @@
 //
 // Targets are built on the host once (minimizers of the alleles, one entry per (minimizer, locus): direction bits, "rare");
 // the device holds an open-addressing table minimizer -> run of entries. recruit_kernel: one lane per read pair. A lane walks
-// its two mates base by base (rolling forward / reverse k-mer, hash, ring of the last w hashes in LDS, window minimum with the
-// rescan rule of the reference), probes the table at every minimizer and counts matches per locus in registers (up to 8 loci per
-// read pair, linear search), then applies the fraction tests. Integer arithmetic throughout: results are those of the reference.
+// a mate base by base (rolling forward / reverse k-mer, hash, ring of the last w hashes in LDS, window minimum with the rescan
+// rule of the reference) and only WRITES its minimizers down (wavefront scratch, interleaved across the lanes); then all lanes
+// probe the table with their j-th minimizer together — the lanes find their minimizers at different bases, and a probe inside
+// the walk would run the table look-up (a dependent global load) once per base with one lane active. Matches are counted per
+// locus in registers (up to 8 loci per read pair, linear search); then the fraction tests. Integer arithmetic throughout.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -43,6 +45,7 @@ struct RecruitView {
     int paired;
     uint32_t max_out;
     uint32_t* out_cnt; uint32_t* out_loci;
+    uint64_t* scratch; uint32_t scratch_cap;      // per workgroup [scratch_cap][64] minimizers of the mate being walked
     uint32_t* err;
 };
 
@@ -53,7 +56,10 @@ struct Matches {
     uint32_t n;
 };
 
-// minimizers::<u64, _, CANONICAL> (kmers.rs:265-331) of one mate; calls on_minimizer(hash, forward) for every minimizer; returns their number
+// minimizers::<u64, _, CANONICAL> (kmers.rs:265-331) of one mate, as written there (ring of hashes, best position, rescan when the
+// best leaves the window, the first_kmer / first_window bookkeeping around bases that are not ACGT); calls
+// on_minimizer(hash, forward) for every minimizer; returns their number. The lanes of a wavefront rescan at different bases, so
+// this form runs its rescan loop at almost every base: it is kept for the mates that contain such bases (and as the definition).
 template <typename F>
 __device__ inline uint32_t walk_minimizers(const RecruitView& V, const uint64_t* w64, const uint32_t* nm, uint32_t len, uint64_t* ring, F&& on_minimizer) {
     const uint32_t k = V.k, w = V.w, k_1 = k - 1, w_1 = w - 1, rmask = V.ring - 1;
@@ -96,6 +102,67 @@ __device__ inline uint32_t walk_minimizers(const RecruitView& V, const uint64_t*
     return total;
 }
 
+// The same minimizers for a mate made of A, C, G, T only, without data-dependent branches: with every hash defined, the best
+// position of the reference is simply the leftmost minimum of the last w k-mers, and a minimizer is reported whenever that
+// position moves. Sliding minimum by blocks of w k-mers (van Herk / Gil-Werman): leftmost prefix minimum of the running block in
+// registers, leftmost suffix minima of the block before it in LDS, written once per block by a backward pass — the same work
+// at the same k-mer for all lanes. Returns false (nothing reported) if a hash happens to be UNDEF: the caller takes the form above.
+template <typename F>
+__device__ inline bool walk_minimizers_acgt(const RecruitView& V, const uint64_t* w64, uint32_t len, uint64_t* ring, uint64_t* suf_h, uint32_t* suf_p,
+                                            uint32_t* total_out, F&& on_minimizer) {
+    const uint32_t k = V.k, w = V.w, k_1 = k - 1, w_1 = w - 1, rmask = V.ring - 1;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const uint32_t rv_shift = 2 * k - 2;
+    uint64_t fw_kmer = 0, rv_kmer = 0, fwd_bits = 0;                  // forward flag of k-mer t at bit t & 63 (only the last w matter, w < 64)
+    uint64_t pre_h = UNDEF64; uint32_t pre_p = 0;                     // leftmost minimum of the running block
+    uint32_t in_block = 0;                                            // k-mers of the running block so far
+    int64_t last_pos = -1;
+    uint32_t total = 0;
+    bool undef_seen = false;
+    uint64_t word = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        if ((i & 31u) == 0) word = w64[i >> 5];
+        const uint64_t enc = (word >> ((i & 31u) * 2u)) & 3ull;
+        fw_kmer = ((fw_kmer << 2) | enc) & mask;
+        rv_kmer = (rv_kmer >> 2) | ((3ull - enc) << rv_shift);
+        if (i < k_1) continue;
+        const uint32_t t = i - k_1;                                   // index of the k-mer that ends here
+        const bool fwd = !(rv_kmer < fw_kmer);
+        const uint64_t h = fast_hash64(fwd ? fw_kmer : rv_kmer);
+        undef_seen |= h == UNDEF64;
+        ring[(t & rmask) * 64] = h;
+        fwd_bits = (fwd_bits & ~(1ull << (t & 63u))) | (static_cast<uint64_t>(fwd) << (t & 63u));
+        if (in_block == 0 || h < pre_h) { pre_h = h; pre_p = t; }
+        in_block++;
+        if (t >= w_1) {
+            // window [t - w_1, t]: its part in the block before (suffix minimum from t - w_1 on) and the running block
+            uint64_t best_h = pre_h; uint32_t best_p = pre_p;
+            if (in_block < w) {
+                const uint32_t sidx = ((t - w_1) & rmask) * 64;
+                const uint64_t sh = suf_h[sidx];
+                if (sh <= pre_h) { best_h = sh; best_p = suf_p[sidx]; }
+            }
+            if (static_cast<int64_t>(best_p) > last_pos) {
+                last_pos = best_p;
+                on_minimizer(best_h, ((fwd_bits >> (best_p & 63u)) & 1ull) != 0);
+                total++;
+            }
+        }
+        if (in_block == w) {                                          // block complete: its leftmost suffix minima, back to front
+            uint64_t sh = UNDEF64; uint32_t sp = 0;
+            for (uint32_t q = 0; q < w; q++) {
+                const uint32_t j = t - q;
+                const uint64_t v = ring[(j & rmask) * 64];
+                if (q == 0 || v <= sh) { sh = v; sp = j; }
+                suf_h[(j & rmask) * 64] = sh; suf_p[(j & rmask) * 64] = sp;
+            }
+            in_block = 0;
+        }
+    }
+    *total_out = total;
+    return !undef_seen;
+}
+
 __device__ __forceinline__ uint32_t c16(uint64_t packed, uint32_t i) { return static_cast<uint32_t>(packed >> (16 * i)) & 0xFFFFu; }
 // (Wr + c) / (W(n - c) + c) with W = 3 (recruit.rs:282-325), all in u16 as upstream
 __device__ __forceinline__ uint32_t fw_num(uint64_t a) { return (3u * c16(a, 3) + c16(a, 1)) & 0xFFFFu; }
@@ -106,74 +173,115 @@ __device__ __forceinline__ bool has_rare(uint64_t a) { return (a >> 32) != 0; }
 
 __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
     extern __shared__ __align__(16) uint8_t smem[];
-    uint64_t* ring = reinterpret_cast<uint64_t*>(smem) + threadIdx.x;           // slot j of this lane at ring[j * 64]
-    const uint64_t p = static_cast<uint64_t>(blockIdx.x) * 64 + threadIdx.x;
-    if (p >= V.n_pairs) return;
-    const uint32_t len1 = V.mate_len[2 * p], len2 = V.paired ? V.mate_len[2 * p + 1] : 0u;
-    V.out_cnt[p] = 0;
-    if (!V.paired && len1 > READ_LENGTH_THRESH) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); return; }
-    Matches M; M.n = 0;
+    const uint32_t lane = threadIdx.x;
+    uint64_t* ring = reinterpret_cast<uint64_t*>(smem) + lane;                  // slot j of this lane at ring[j * 64]
+    uint64_t* suf_h = ring + static_cast<size_t>(V.ring) * 64;                  // suffix minima of the block before the running one
+    uint32_t* suf_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(smem) + static_cast<size_t>(V.ring) * 128) + lane;
+    uint64_t* buf = V.scratch + static_cast<size_t>(blockIdx.x) * V.scratch_cap * 64 + lane;     // minimizer j of this lane at buf[j * 64]
+    for (uint64_t p0 = static_cast<uint64_t>(blockIdx.x) * 64; p0 < V.n_pairs; p0 += static_cast<uint64_t>(gridDim.x) * 64) {
+        const uint64_t p = p0 + lane;
+        const bool valid = p < V.n_pairs;
+        const uint32_t len1 = valid ? V.mate_len[2 * p] : 0u, len2 = (valid && V.paired) ? V.mate_len[2 * p + 1] : 0u;
+        bool bad = false;
+        if (valid && !V.paired && len1 > READ_LENGTH_THRESH) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); bad = true; }
+        Matches M; M.n = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) { M.locus[j] = 0xFFFFFFFFu; M.first[j] = 0; M.second[j] = 0; }
-    bool overflow = false;
-    auto probe = [&](uint64_t minim, bool forward, bool second) {
-        uint64_t slot = mix64(minim) & V.table_mask;
-        TableSlot ts = V.table[slot];
-        while (ts.key != UNDEF64 && ts.key != minim) { slot = (slot + 1) & V.table_mask; ts = V.table[slot]; }
-        if (ts.key != minim) return;
-        for (uint32_t q = 0; q < ts.count; q++) {
-            const uint32_t e = V.entries[ts.start + q];
-            const uint32_t locus = e & 0xFFFFFFu, direction = (e >> 24) & 3u, rare = (e >> 26) & 1u;
-            // BaseMatchCount::inc (recruit.rs:250-256)
-            const uint64_t inc = (static_cast<uint64_t>((direction & (1u + !forward)) != 0) << (32 * rare))
-                               | (static_cast<uint64_t>((direction & (1u + forward)) != 0) << (32 * rare + 16));
-            bool found = false;
+        for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) { M.locus[j] = 0xFFFFFFFFu; M.first[j] = 0; M.second[j] = 0; }
+        bool overflow = false;
+        auto probe = [&](uint64_t minim, bool forward, bool second) {
+            uint64_t slot = mix64(minim) & V.table_mask;
+            TableSlot ts = V.table[slot];
+            while (ts.key != UNDEF64 && ts.key != minim) { slot = (slot + 1) & V.table_mask; ts = V.table[slot]; }
+            if (ts.key != minim) return;
+            for (uint32_t q = 0; q < ts.count; q++) {
+                const uint32_t e = V.entries[ts.start + q];
+                const uint32_t locus = e & 0xFFFFFFu, direction = (e >> 24) & 3u, rare = (e >> 26) & 1u;
+                // BaseMatchCount::inc (recruit.rs:250-256)
+                const uint64_t inc = (static_cast<uint64_t>((direction & (1u + !forward)) != 0) << (32 * rare))
+                                   | (static_cast<uint64_t>((direction & (1u + forward)) != 0) << (32 * rare + 16));
+                bool found = false;
 #pragma unroll
-            for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++)
-                if (M.locus[j] == locus) { found = true; if (second) M.second[j] += inc; else M.first[j] += inc; }
-            if (!found && !second) {                                             // get_or_insert; the second mate never inserts (912-915)
-                if (M.n == MAX_LOCI_PER_READ) overflow = true;
-                else {
+                for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++)
+                    if (M.locus[j] == locus) { found = true; if (second) M.second[j] += inc; else M.first[j] += inc; }
+                if (!found && !second) {                                         // get_or_insert; the second mate never inserts (912-915)
+                    if (M.n == MAX_LOCI_PER_READ) overflow = true;
+                    else {
 #pragma unroll
-                    for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) if (j == M.n) { M.locus[j] = locus; M.first[j] = inc; }
-                    M.n++;
+                        for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) if (j == M.n) { M.locus[j] = locus; M.first[j] = inc; }
+                        M.n++;
+                    }
+                }
+            }
+        };
+        uint32_t totals[2] = {0, 0};
+        for (uint32_t mate = 0; mate < (V.paired ? 2u : 1u); mate++) {
+            const uint32_t len = mate ? len2 : len1;
+            // the second mate is only looked at when the first one matched something (recruit.rs:899)
+            const bool walk = valid && !bad && (mate == 0 || M.n > 0);
+            uint32_t total = 0;
+            uint64_t fwd_of[4] = {0, 0, 0, 0};                                   // direction of minimizer j at bit j
+            if (walk) {
+                const uint64_t off = V.mate_off[2 * p + mate];
+                const uint64_t* w64 = reinterpret_cast<const uint64_t*>(V.bases2) + (off >> 5);
+                const uint32_t* nm = V.nmask + (off >> 5);
+                uint32_t any_n = 0;
+                for (uint32_t q = 0; q * 32 < len; q++) any_n |= nm[q] & (len - q * 32 >= 32 ? 0xFFFFFFFFu : ((1u << (len - q * 32)) - 1u));
+                auto keep = [&](uint64_t h, bool fw) {
+                    if (total < V.scratch_cap) buf[static_cast<size_t>(total) * 64] = h;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) if ((total >> 6) == q) fwd_of[q] |= static_cast<uint64_t>(fw) << (total & 63u);
+                    total++;
+                };
+                bool done = false;
+                if (any_n == 0) {
+                    uint32_t n_fast = 0;
+                    done = walk_minimizers_acgt(V, w64, len, ring, suf_h, suf_p, &n_fast, keep);
+                    if (!done) { total = 0; fwd_of[0] = fwd_of[1] = fwd_of[2] = fwd_of[3] = 0; }
+                }
+                if (!done) {
+                    const uint32_t n_ref = walk_minimizers(V, w64, nm, len, ring, keep);
+                    (void)n_ref;
+                }
+            }
+            totals[mate] = total;
+            uint32_t most = total;
+            for (int o = 32; o > 0; o >>= 1) most = max(most, static_cast<uint32_t>(__shfl_xor(static_cast<int>(most), o)));
+            for (uint32_t j = 0; j < most; j++) {
+                if (j < total) {
+                    uint64_t bits = fwd_of[0];
+#pragma unroll
+                    for (uint32_t q = 1; q < 4; q++) if ((j >> 6) == q) bits = fwd_of[q];
+                    probe(buf[static_cast<size_t>(j) * 64], ((bits >> (j & 63u)) & 1ull) != 0, mate != 0);
                 }
             }
         }
-    };
-    const uint64_t off1 = V.mate_off[2 * p];
-    const uint32_t total1 = walk_minimizers(V, reinterpret_cast<const uint64_t*>(V.bases2) + (off1 >> 5), V.nmask + (off1 >> 5), len1, ring,
-                                            [&](uint64_t h, bool fw) { probe(h, fw, false); });
-    uint32_t total2 = 0;
-    if (V.paired && M.n) {
-        const uint64_t off2 = V.mate_off[2 * p + 1];
-        total2 = walk_minimizers(V, reinterpret_cast<const uint64_t*>(V.bases2) + (off2 >> 5), V.nmask + (off2 >> 5), len2, ring,
-                                 [&](uint64_t h, bool fw) { probe(h, fw, true); });
-    }
-    if (overflow) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); return; }
-    uint32_t n_out = 0;
-    uint32_t* out = V.out_loci + p * V.max_out;
+        if (!valid || bad) continue;
+        if (overflow) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); V.out_cnt[p] = 0; continue; }
+        const uint32_t total1 = totals[0], total2 = totals[1];
+        uint32_t n_out = 0;
+        uint32_t* out = V.out_loci + p * V.max_out;
 #pragma unroll
-    for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) {
-        if (j >= M.n) continue;
-        const uint64_t a = M.first[j], b = M.second[j];
-        bool take = false;
-        if (V.paired) {
-            if (has_rare(a) || has_rare(b)) {                                    // recruit_read_pair (919-927), better_pair_fraction (351-367)
-                uint32_t n1, d1, n2, d2;
-                if (((fw_num(a) + bw_num(b)) & 0xFFFFu) >= ((bw_num(a) + fw_num(b)) & 0xFFFFu)) { n1 = fw_num(a); d1 = fw_den(a, total1); n2 = bw_num(b); d2 = bw_den(b, total2); }
-                else { n1 = bw_num(a); d1 = bw_den(a, total1); n2 = fw_num(b); d2 = fw_den(b, total2); }
-                take = n1 * V.mf_den >= V.mf_num * d1 && n2 * V.mf_den >= V.mf_num * d2;      // Fraction<u16>::partial_cmp (frac.rs:87-93)
+        for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) {
+            if (j >= M.n) continue;
+            const uint64_t a = M.first[j], b = M.second[j];
+            bool take = false;
+            if (V.paired) {
+                if (has_rare(a) || has_rare(b)) {                                // recruit_read_pair (919-927), better_pair_fraction (351-367)
+                    uint32_t n1, d1, n2, d2;
+                    if (((fw_num(a) + bw_num(b)) & 0xFFFFu) >= ((bw_num(a) + fw_num(b)) & 0xFFFFu)) { n1 = fw_num(a); d1 = fw_den(a, total1); n2 = bw_num(b); d2 = bw_den(b, total2); }
+                    else { n1 = bw_num(a); d1 = bw_den(a, total1); n2 = fw_num(b); d2 = fw_den(b, total2); }
+                    take = n1 * V.mf_den >= V.mf_num * d1 && n2 * V.mf_den >= V.mf_num * d2;      // Fraction<u16>::partial_cmp (frac.rs:87-93)
+                }
+            } else if (has_rare(a)) {                                            // recruit_short_read (871-877), better_fraction (340-348)
+                uint32_t n1, d1;
+                if (fw_num(a) >= bw_num(a)) { n1 = fw_num(a); d1 = fw_den(a, total1); } else { n1 = bw_num(a); d1 = bw_den(a, total1); }
+                take = n1 * V.mf_den >= V.mf_num * d1;
             }
-        } else if (has_rare(a)) {                                                // recruit_short_read (871-877), better_fraction (340-348)
-            uint32_t n1, d1;
-            if (fw_num(a) >= bw_num(a)) { n1 = fw_num(a); d1 = fw_den(a, total1); } else { n1 = bw_num(a); d1 = bw_den(a, total1); }
-            take = n1 * V.mf_den >= V.mf_num * d1;
+            if (take) { if (n_out < V.max_out) out[n_out] = M.locus[j]; n_out++; }
         }
-        if (take) { if (n_out < V.max_out) out[n_out] = M.locus[j]; n_out++; }
+        if (n_out > V.max_out) atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_INVALID_INPUT));
+        V.out_cnt[p] = min(n_out, V.max_out);
     }
-    if (n_out > V.max_out) atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_INVALID_INPUT));
-    V.out_cnt[p] = n_out;
 }
 
 }  // namespace lcty
@@ -370,9 +478,17 @@ int32_t lcty_recruit(lcty_targets* t, const lcty_reads_host* h, int32_t paired, 
         V.mf_num = t->mf_num; V.mf_den = t->mf_den;
         V.n_pairs = n; V.mate_len = d_len.p; V.mate_off = d_off.p; V.bases2 = d_bases.p; V.nmask = d_nm.p;
         V.paired = paired != 0; V.max_out = max_out; V.out_cnt = d_cnt.p; V.out_loci = d_loci.p; V.err = t->d_err.p;
-        const size_t lds = static_cast<size_t>(V.ring) * 64 * 8;
+        const size_t lds = static_cast<size_t>(V.ring) * 64 * (8 + 8 + 4);
+        uint32_t max_len = 1;
+        for (uint64_t m = 0; m < 2 * n; m++) max_len = std::max(max_len, h->mate_len[m]);
+        if (max_len > 256) fail(LCTY_ERR_UNSUPPORTED, "recruitment: a mate of %u bases (the device kernel takes reads of up to 256 bases)", max_len);
+        V.scratch_cap = max_len;                                                 // a mate has fewer minimizers than bases
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 63) / 64, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 12));
+        DevBuf<uint64_t> d_scratch;
+        d_scratch.alloc(static_cast<size_t>(blocks) * V.scratch_cap * 64);
+        V.scratch = d_scratch.p;
         ctx->timed(LCTY_K_RECRUIT, [&] {
-            hipLaunchKernelGGL(recruit_kernel, dim3(static_cast<uint32_t>((n + 63) / 64)), dim3(64), lds, s, V);
+            hipLaunchKernelGGL(recruit_kernel, dim3(blocks), dim3(64), lds, s, V);
         });
         LCTY_HIP(hipGetLastError());
         uint32_t err = 0;
