@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="extra measurement outside the timed region: this many loci in flight on one GPU, each on its own context / "
                          "stream (the annealing stage leaves most of the GPU idle); 0 or 1 = skip")
+    ap.add_argument("--recruit-sample", type=int, default=8_000_000,
+                    help="read pairs of the extra recruitment measurement (the step before the path, SURVEY 8f rank 1; 0 = skip)")
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
@@ -293,6 +295,32 @@ def main():
                             "note": "not `value`: the same step on several contexts of one GPU at once"}
         for cw, aw in workers[1:]:
             aw.close()
+
+    if args.recruit_sample > 0 and world == 1:
+        # ---- minimizer read recruitment (Targets::recruit_read_pair, seq/recruit.rs:883-929), the step before the path: random
+        # 150 + 150-base pairs (whole-genome input is almost entirely foreign to a locus) against this locus' alleles ----
+        nrq = args.recruit_sample
+        rprm = api.recruit_params()
+        tq0 = time.perf_counter()
+        T = api.Targets(ctx, rprm)
+        T.add_locus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k)
+        n_minim = T.finalize()
+        t_targets = time.perf_counter() - tq0
+        rngq = np.random.default_rng(11)
+        words = rngq.integers(0, 1 << 32, size=nrq * 20, dtype=np.uint64).astype(np.uint32)
+        from locityper_amd.cdefs import ReadsChunk, ALN_REC_DTYPE
+        rq = ReadsChunk(np.full(2 * nrq, 150, dtype=np.uint32), np.arange(2 * nrq + 1, dtype=np.uint64) * 160, words,
+                        np.zeros(nrq * 10, dtype=np.uint32), np.zeros(nrq + 1, dtype=np.uint64), np.zeros(0, dtype=ALN_REC_DTYPE),
+                        np.zeros(nrq + 1, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+        ctx.timing_reset()
+        tq0 = time.perf_counter()
+        cntq, _ = T.recruit(rq, paired=True)
+        t_call = time.perf_counter() - tq0
+        _, ms_q = ctx.timing(api.K_RECRUIT)
+        out["recruitment"] = {"sample": f"{nrq} random 150 + 150-base read pairs against the {A} alleles of the locus ({n_minim} minimizers)",
+                              "kernel_ms": ms_q, "read_pairs_per_s_kernel": nrq / (ms_q * 1e-3) if ms_q else None,
+                              "read_pairs_per_s_call": nrq / t_call, "targets_build_s": t_targets, "recruited": int(np.count_nonzero(cntq))}
+        T.close(); del rq, words
 
     if args.recovery_sample > 0 and world == 1:
         # ---- alignment recovery (K6), not part of the step: the mapper reports only the primary alignment of each read end, the
