@@ -305,8 +305,9 @@ int32_t lcty_recover_stats(lcty_reads* reads, uint64_t* level_pairs);
  *   minimizers of every allele, rare = off-target count of the k-mer around the minimizer < thresh_kmer_count) and ::finalize.
  *   counts / cnt_off / base_k as in lcty_locus_create. Loci are numbered in the order they are added.
  * lcty_recruit: Targets::recruit_read_pair (883-929) for every pair of the chunk when `paired`, otherwise recruit_short_read
- *   (848-879) on mate 1. The device kernel takes mates of up to 256 bases (upstream: short reads up to 500, recruit_long_read
- *   beyond) and up to 8 loci per read; anything else is LCTY_ERR_UNSUPPORTED, never a different answer. Only the sequence fields of the chunk are read. Output: out_cnt[i] loci of
+ *   (848-879) for single reads of up to 500 bases and recruit_long_read (938-996) beyond, as upstream dispatches (589-595).
+ *   Mates of a pair: up to 256 bases; loci per read: up to 8 (16 for single reads beyond 256 bases); anything else is
+ *   LCTY_ERR_UNSUPPORTED, never a different answer. Only the sequence fields of the chunk are read. Output: out_cnt[i] loci of
  *   pair i in out_loci[i * max_out ...], increasing (the reference writes the read to the files of exactly these loci). */
 typedef struct lcty_recruit_params {
     double   match_frac;

@@ -46,6 +46,10 @@ struct RecruitView {
     uint32_t max_out;
     uint32_t* out_cnt; uint32_t* out_loci;
     uint64_t* scratch; uint32_t scratch_cap;      // per workgroup [scratch_cap][64] minimizers of the mate being walked
+    // single reads of more than 256 bases: one wavefront per read
+    const uint32_t* long_list; uint32_t n_long; uint32_t long_cap;      // reads of the list; minimizers a read can have
+    uint64_t* long_h; uint8_t* long_f;             // per workgroup 2 x [long_cap]: minimizers in read order (second half: staging)
+    double match_frac; uint32_t stretch_minims, stretch_score;
     uint32_t* err;
 };
 
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
         const bool valid = p < V.n_pairs;
         const uint32_t len1 = valid ? V.mate_len[2 * p] : 0u, len2 = (valid && V.paired) ? V.mate_len[2 * p + 1] : 0u;
         bool bad = false;
-        if (valid && !V.paired && len1 > READ_LENGTH_THRESH) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); bad = true; }
+        if (valid && !V.paired && len1 > 256u) bad = true;                           // taken by recruit_single_kernel, one wavefront per read
         Matches M; M.n = 0;
 #pragma unroll
         for (uint32_t j = 0; j < MAX_LOCI_PER_READ; j++) { M.locus[j] = 0xFFFFFFFFu; M.first[j] = 0; M.second[j] = 0; }
@@ -281,6 +285,214 @@ __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
         }
         if (n_out > V.max_out) atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_INVALID_INPUT));
         V.out_cnt[p] = min(n_out, V.max_out);
+    }
+}
+
+// ---- single reads beyond the lane kernel's reach (recruit_short_read up to 500 bases, recruit_long_read beyond): one wavefront
+// per read. The windows of the read are dealt to the lanes in 64 contiguous runs; a lane walks its run (plus the w k-mers before
+// it, for the window that precedes its first one) with the block-wise sliding minimum and keeps the minimizers of its windows;
+// the runs are then packed into one list in read order. Counting goes over the list 64 entries at a time into an LDS table of
+// loci; has_matching_stretch — a running sum clamped at zero — is evaluated per lane as a function of the sum it starts with
+// (s -> max(a, s + b), closed under composition) and the 64 pieces are chained.
+constexpr uint32_t LONG_LOCI = 16;
+struct LongTable { uint32_t locus[LONG_LOCI]; uint32_t cnt[LONG_LOCI][4]; uint32_t n; uint32_t total; uint32_t lane_cnt[64]; };
+
+template <typename F>
+__device__ inline void walk_run_acgt(const RecruitView& V, const uint64_t* w64, uint32_t t_own0, uint32_t t_own1, uint64_t* ring, uint64_t* suf_h,
+                                     uint32_t* suf_p, bool* undef_seen, F&& on_minimizer) {
+    // windows ending at k-mers [t_own0, t_own1) are this lane's; the window before the first one only fixes the last reported position
+    const uint32_t k = V.k, w = V.w, k_1 = k - 1, w_1 = w - 1, rmask = V.ring - 1;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const uint32_t rv_shift = 2 * k - 2;
+    const uint32_t ts = t_own0 >= w_1 + 1 ? t_own0 - 1 - w_1 : 0u;            // first k-mer needed
+    uint64_t fw_kmer = 0, rv_kmer = 0, fwd_bits = 0;
+    uint64_t pre_h = UNDEF64; uint32_t pre_p = 0, in_block = 0;
+    int64_t last_pos = -1;
+    uint64_t word = w64[ts >> 5];
+    for (uint32_t i = ts; i < t_own1 + k_1; i++) {
+        if ((i & 31u) == 0) word = w64[i >> 5];
+        const uint64_t enc = (word >> ((i & 31u) * 2u)) & 3ull;
+        fw_kmer = ((fw_kmer << 2) | enc) & mask;
+        rv_kmer = (rv_kmer >> 2) | ((3ull - enc) << rv_shift);
+        if (i < ts + k_1) continue;
+        const uint32_t t = i - k_1;
+        const bool fwd = !(rv_kmer < fw_kmer);
+        const uint64_t h = fast_hash64(fwd ? fw_kmer : rv_kmer);
+        *undef_seen |= h == UNDEF64;
+        ring[(t & rmask) * 64] = h;
+        fwd_bits = (fwd_bits & ~(1ull << (t & 63u))) | (static_cast<uint64_t>(fwd) << (t & 63u));
+        if (in_block == 0 || h < pre_h) { pre_h = h; pre_p = t; }
+        in_block++;
+        if (t - ts >= w_1) {
+            uint64_t best_h = pre_h; uint32_t best_p = pre_p;
+            if (in_block < w) {
+                const uint32_t sidx = ((t - w_1) & rmask) * 64;
+                const uint64_t sh = suf_h[sidx];
+                if (sh <= pre_h) { best_h = sh; best_p = suf_p[sidx]; }
+            }
+            if (static_cast<int64_t>(best_p) > last_pos) {
+                last_pos = best_p;
+                if (t >= t_own0) on_minimizer(best_h, ((fwd_bits >> (best_p & 63u)) & 1ull) != 0);
+            }
+        }
+        if (in_block == w) {
+            uint64_t sh = UNDEF64; uint32_t sp = 0;
+            for (uint32_t q = 0; q < w; q++) {
+                const uint32_t j = t - q;
+                const uint64_t v = ring[(j & rmask) * 64];
+                if (q == 0 || v <= sh) { sh = v; sp = j; }
+                suf_h[(j & rmask) * 64] = sh; suf_p[(j & rmask) * 64] = sp;
+            }
+            in_block = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void recruit_single_kernel(const RecruitView V) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ LongTable T;
+    const uint32_t lane = threadIdx.x;
+    uint64_t* ring = reinterpret_cast<uint64_t*>(smem) + lane;
+    uint64_t* suf_h = ring + static_cast<size_t>(V.ring) * 64;
+    uint32_t* suf_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(smem) + static_cast<size_t>(V.ring) * 128) + lane;
+    uint64_t* list_h = V.long_h + static_cast<size_t>(blockIdx.x) * 2 * V.long_cap;
+    uint8_t* list_f = V.long_f + static_cast<size_t>(blockIdx.x) * 2 * V.long_cap;
+    uint64_t* stage_h = list_h + V.long_cap; uint8_t* stage_f = list_f + V.long_cap;
+    const uint32_t k = V.k, w_1 = V.w - 1;
+    for (uint32_t r = blockIdx.x; r < V.n_long; r += gridDim.x) {
+        const uint64_t p = V.long_list[r];
+        const uint32_t len = V.mate_len[2 * p];
+        const uint64_t off = V.mate_off[2 * p];
+        const uint64_t* w64 = reinterpret_cast<const uint64_t*>(V.bases2) + (off >> 5);
+        const uint32_t* nm = V.nmask + (off >> 5);
+        // ---- the read's minimizers, in order ----
+        uint32_t any_n = 0;
+        for (uint32_t q = lane; q * 32 < len; q += 64) any_n |= nm[q] & (len - q * 32 >= 32 ? 0xFFFFFFFFu : ((1u << (len - q * 32)) - 1u));
+        bool slow = __ballot(any_n != 0) != 0ull;
+        uint32_t total = 0;
+        const uint32_t n_kmers = len >= k ? len - k + 1 : 0u;
+        if (!slow) {
+            const uint32_t n_win = n_kmers > w_1 ? n_kmers - w_1 : 0u;
+            const uint32_t per = (n_win + 63) / 64;
+            const uint32_t t0 = w_1 + min(lane * per, n_win), t1 = w_1 + min((lane + 1) * per, n_win);
+            uint32_t mine = 0;
+            bool undef_seen = false;
+            if (t1 > t0)
+                walk_run_acgt(V, w64, t0, t1, ring, suf_h, suf_p, &undef_seen, [&](uint64_t h, bool fw) {
+                    stage_h[lane * per + mine] = h; stage_f[lane * per + mine] = fw; mine++;
+                });
+            if (__ballot(undef_seen) != 0ull) slow = true;                       // a hash equal to UNDEF: by the book
+            else {
+                if (lane == 0) T.n = 0;
+                T.lane_cnt[lane] = mine;
+                __syncthreads();
+                uint32_t before = 0;
+                for (uint32_t q = 0; q < lane; q++) before += T.lane_cnt[q];
+                for (uint32_t j = 0; j < mine; j++) { list_h[before + j] = stage_h[lane * per + j]; list_f[before + j] = stage_f[lane * per + j]; }
+                total = before + mine;
+                total = __shfl(static_cast<int>(total), 63);
+            }
+        }
+        if (slow) {
+            if (lane == 0) {
+                uint32_t n = 0;
+                walk_minimizers(V, w64, nm, len, ring, [&](uint64_t h, bool fw) { list_h[n] = h; list_f[n] = fw; n++; });
+                T.total = n;
+            }
+            __syncthreads();
+            total = T.total;
+        }
+        // ---- matches per locus (BaseMatchCount<u32>, recruit.rs:236-262) ----
+        if (lane < LONG_LOCI) { T.locus[lane] = 0xFFFFFFFFu; T.cnt[lane][0] = T.cnt[lane][1] = T.cnt[lane][2] = T.cnt[lane][3] = 0; }
+        __syncthreads();
+        __threadfence_block();
+        bool overflow = false;
+        for (uint32_t j = lane; j < total; j += 64) {
+            const uint64_t minim = list_h[j];
+            const bool forward = list_f[j] != 0;
+            uint64_t slot = mix64(minim) & V.table_mask;
+            TableSlot ts = V.table[slot];
+            while (ts.key != UNDEF64 && ts.key != minim) { slot = (slot + 1) & V.table_mask; ts = V.table[slot]; }
+            if (ts.key != minim) continue;
+            for (uint32_t q = 0; q < ts.count; q++) {
+                const uint32_t e = V.entries[ts.start + q];
+                const uint32_t locus = e & 0xFFFFFFu, direction = (e >> 24) & 3u, rare = (e >> 26) & 1u;
+                uint32_t at = LONG_LOCI;
+                for (uint32_t u = 0; u < LONG_LOCI; u++) {
+                    const uint32_t old = atomicCAS(&T.locus[u], 0xFFFFFFFFu, locus);
+                    if (old == 0xFFFFFFFFu || old == locus) { at = u; break; }
+                }
+                if (at == LONG_LOCI) { overflow = true; continue; }
+                atomicAdd(&T.cnt[at][rare * 2], static_cast<uint32_t>((direction & (1u + !forward)) != 0));
+                atomicAdd(&T.cnt[at][rare * 2 + 1], static_cast<uint32_t>((direction & (1u + forward)) != 0));
+            }
+        }
+        __syncthreads();
+        if (__ballot(overflow) != 0ull) { if (lane == 0) { atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_UNSUPPORTED)); V.out_cnt[p] = 0; } continue; }
+        // ---- decisions ----
+        uint32_t n_out = 0;
+        for (uint32_t u = 0; u < LONG_LOCI; u++) {
+            const uint32_t locus = T.locus[u];
+            if (locus == 0xFFFFFFFFu) break;
+            const uint32_t c0 = T.cnt[u][0], c1 = T.cnt[u][1], c2 = T.cnt[u][2], c3 = T.cnt[u][3];      // common-bw, common-fw, rare-bw, rare-fw
+            bool take = false;
+            if (len <= READ_LENGTH_THRESH) {                                     // recruit_short_read (871-877) in u16 arithmetic
+                if (c2 || c3) {
+                    const uint32_t fn = (3u * c3 + c1) & 0xFFFFu, bn = (3u * c2 + c0) & 0xFFFFu;
+                    uint32_t n1, d1;
+                    if (fn >= bn) { n1 = fn; d1 = (3u * (total - c1) + c1) & 0xFFFFu; } else { n1 = bn; d1 = (3u * (total - c0) + c0) & 0xFFFFu; }
+                    take = n1 * V.mf_den >= V.mf_num * d1;
+                }
+            } else {                                                             // recruit_long_read (985-994)
+                uint32_t num, den;
+                if (c3 >= c2) { num = c3; den = total - c1; } else { num = c2; den = total - c0; }                 // rare_fraction (271-279)
+                const uint32_t thr = max(1u, static_cast<uint32_t>(ceil(static_cast<double>(min(V.stretch_minims, den)) * V.match_frac)));
+                take = num >= thr;
+                if (take && den >= V.stretch_minims) {
+                    // has_matching_stretch (938-961): s_fw / s_bw as functions of the sum the lane's piece starts with
+                    const int64_t NEG = -(1ll << 40);
+                    int64_t A[2] = {NEG, NEG}, B[2] = {0, 0}, Am[2] = {NEG, NEG}, Bm[2] = {NEG, NEG};
+                    const uint32_t per = (total + 63) / 64;
+                    for (uint32_t j = lane * per; j < min(total, (lane + 1) * per); j++) {
+                        const uint64_t minim = list_h[j];
+                        const bool forward = list_f[j] != 0;
+                        int64_t add[2] = {0, 0};
+                        uint64_t slot = mix64(minim) & V.table_mask;
+                        TableSlot ts = V.table[slot];
+                        while (ts.key != UNDEF64 && ts.key != minim) { slot = (slot + 1) & V.table_mask; ts = V.table[slot]; }
+                        if (ts.key == minim)
+                            for (uint32_t q = 0; q < ts.count; q++) {
+                                const uint32_t e = V.entries[ts.start + q];
+                                if ((e & 0xFFFFFFu) != locus) continue;
+                                const uint32_t direction = (e >> 24) & 3u, x = 1u + ((e >> 26) & 1u) * 3u;           // SUBSUM_PENALTY + rare * SUBSUM_BONUS
+                                add[0] = (direction & (1u + forward)) ? x : 0;
+                                add[1] = (direction & (1u + !forward)) ? x : 0;
+                            }
+                        for (int d = 0; d < 2; d++) {                              // s = max(0, s + add - 1)
+                            A[d] = max(static_cast<int64_t>(0), A[d] + add[d] - 1); B[d] += add[d] - 1;
+                            Am[d] = max(Am[d], A[d]); Bm[d] = max(Bm[d], B[d]);
+                        }
+                    }
+                    int64_t s[2] = {0, 0};
+                    bool hit = false;
+                    for (int l = 0; l < 64; l++) {
+                        for (int d = 0; d < 2; d++) {
+                            const int64_t a = __shfl(static_cast<long long>(A[d]), l), b = __shfl(static_cast<long long>(B[d]), l);
+                            const int64_t am = __shfl(static_cast<long long>(Am[d]), l), bm = __shfl(static_cast<long long>(Bm[d]), l);
+                            hit |= max(am, s[d] + bm) >= static_cast<int64_t>(V.stretch_score);
+                            s[d] = max(a, s[d] + b);
+                        }
+                    }
+                    take = hit;
+                }
+            }
+            if (take) { if (lane == 0 && n_out < V.max_out) V.out_loci[p * V.max_out + n_out] = locus; n_out++; }
+        }
+        if (lane == 0) {
+            if (n_out > V.max_out) atomicMax(V.err, static_cast<uint32_t>(LCTY_ERR_INVALID_INPUT));
+            V.out_cnt[p] = min(n_out, V.max_out);
+        }
+        __syncthreads();
     }
 }
 
@@ -479,23 +691,44 @@ int32_t lcty_recruit(lcty_targets* t, const lcty_reads_host* h, int32_t paired, 
         V.n_pairs = n; V.mate_len = d_len.p; V.mate_off = d_off.p; V.bases2 = d_bases.p; V.nmask = d_nm.p;
         V.paired = paired != 0; V.max_out = max_out; V.out_cnt = d_cnt.p; V.out_loci = d_loci.p; V.err = t->d_err.p;
         const size_t lds = static_cast<size_t>(V.ring) * 64 * (8 + 8 + 4);
-        uint32_t max_len = 1;
-        for (uint64_t m = 0; m < 2 * n; m++) max_len = std::max(max_len, h->mate_len[m]);
-        if (max_len > 256) fail(LCTY_ERR_UNSUPPORTED, "recruitment: a mate of %u bases (the device kernel takes reads of up to 256 bases)", max_len);
+        // single reads of more than 256 bases go to the wavefront-per-read kernel (short-read rule up to 500 bases, long-read rule beyond)
+        uint32_t max_len = 1, max_long = 0;
+        std::vector<uint32_t> long_list;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint32_t l1 = h->mate_len[2 * i], l2 = paired ? h->mate_len[2 * i + 1] : 0u;
+            if (!paired && l1 > 256) { long_list.push_back(static_cast<uint32_t>(i)); max_long = std::max(max_long, l1); }
+            else max_len = std::max(max_len, std::max(l1, l2));
+        }
+        if (max_len > 256) fail(LCTY_ERR_UNSUPPORTED, "recruitment: a mate of %u bases in a read pair (the device kernel takes mates of up to 256 bases)", max_len);
+        if (n > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "recruitment: more than 2^32 reads in one call");
         V.scratch_cap = max_len;                                                 // a mate has fewer minimizers than bases
         const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 63) / 64, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 12));
-        DevBuf<uint64_t> d_scratch;
+        DevBuf<uint64_t> d_scratch, d_long_h; DevBuf<uint8_t> d_long_f; DevBuf<uint32_t> d_long_list;
         d_scratch.alloc(static_cast<size_t>(blocks) * V.scratch_cap * 64);
         V.scratch = d_scratch.p;
+        V.match_frac = t->prm.match_frac;
+        // Params::new (recruit.rs:92-98)
+        V.stretch_minims = (2 * t->prm.match_length + (static_cast<uint32_t>(t->prm.minimizer_w) + 1) - 1) / (static_cast<uint32_t>(t->prm.minimizer_w) + 1);
+        V.stretch_score = static_cast<uint32_t>(std::ceil(std::max(static_cast<double>(V.stretch_minims) * (4.0 * t->prm.match_frac - 1.0), 3.0)));
         ctx->timed(LCTY_K_RECRUIT, [&] {
             hipLaunchKernelGGL(recruit_kernel, dim3(blocks), dim3(64), lds, s, V);
         });
+        if (!long_list.empty()) {
+            V.n_long = static_cast<uint32_t>(long_list.size()); V.long_cap = max_long + 64;
+            const uint32_t lblocks = static_cast<uint32_t>(std::min<uint64_t>(long_list.size(), static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8));
+            d_long_list.alloc(long_list.size()); d_long_list.upload(long_list.data(), long_list.size(), s);
+            d_long_h.alloc(static_cast<size_t>(lblocks) * 2 * V.long_cap); d_long_f.alloc(static_cast<size_t>(lblocks) * 2 * V.long_cap);
+            V.long_list = d_long_list.p; V.long_h = d_long_h.p; V.long_f = d_long_f.p;
+            ctx->timed(LCTY_K_RECRUIT, [&] {
+                hipLaunchKernelGGL(recruit_single_kernel, dim3(lblocks), dim3(64), lds, s, V);
+            });
+        }
         LCTY_HIP(hipGetLastError());
         uint32_t err = 0;
         t->d_err.download(&err, 1, s);
         d_cnt.download(out_cnt, n, s); d_loci.download(out_loci, n * max_out, s);
         LCTY_HIP(hipStreamSynchronize(s));
-        if (err == LCTY_ERR_UNSUPPORTED) fail(LCTY_ERR_UNSUPPORTED, "recruitment: a single read of more than %u bases (long-read recruitment is not on the device yet) or a read matching minimizers of more than %u loci", READ_LENGTH_THRESH, MAX_LOCI_PER_READ);
+        if (err == LCTY_ERR_UNSUPPORTED) fail(LCTY_ERR_UNSUPPORTED, "recruitment: a read matching minimizers of more than %u loci (%u for single reads beyond 256 bases)", MAX_LOCI_PER_READ, LONG_LOCI);
         if (err == LCTY_ERR_INVALID_INPUT) fail(LCTY_ERR_INVALID_INPUT, "recruitment: max_out is smaller than the number of loci of a read");
         if (err) fail(static_cast<int32_t>(err), "recruitment failed on the device");
         for (uint64_t i = 0; i < n; i++) std::sort(out_loci + i * max_out, out_loci + i * max_out + out_cnt[i]);

@@ -88,10 +88,10 @@ def test_edges_and_misuse(gpu_ctx):
     for i, pr in enumerate(pairs):
         assert list(out[i, :cnt[i]]) == ot.recruit(pr["seq1"].encode(), pr["seq2"].encode()), i
     assert list(cnt) == [0, 0, 0, 1, 0] or cnt[3] == 1
-    # a long single read is refused (recruit_long_read is not on the device), never answered differently
-    long_ch = ReadsChunk.from_pairs([{"seq1": al[:900].decode(), "seq2": None, "recs": []}])
+    # mates of a pair beyond 256 bases are refused, never answered differently
+    long_pair = ReadsChunk.from_pairs([{"seq1": al[:300].decode(), "seq2": al[400:700].decode(), "recs": []}])
     with pytest.raises(_lib.LocityperError) as ei:
-        gt.recruit(long_ch, paired=False)
+        gt.recruit(long_pair, paired=True)
     assert ei.value.code == cdefs.ERR_UNSUPPORTED
     with pytest.raises(_lib.LocityperError):
         api.Targets(gpu_ctx, api.recruit_params(match_frac=0.1))
@@ -100,3 +100,33 @@ def test_edges_and_misuse(gpu_ctx):
     empty = api.Targets(gpu_ctx, api.recruit_params())
     with pytest.raises(_lib.LocityperError):
         empty.finalize()                                                      # "No minimizers for recruitment"
+
+
+@pytest.mark.parametrize("over", [dict(technology=cdefs.TECH_NANOPORE, paired=False), dict(technology=cdefs.TECH_NANOPORE, paired=False, minimizer_k=19, minimizer_w=24, match_length=800),
+                                  dict(technology=cdefs.TECH_ILLUMINA, paired=False)])
+def test_single_reads_of_every_length_match_oracle(gpu_ctx, over):
+    """recruit_short_read up to 500 bases, recruit_long_read (rare fraction, threshold, has_matching_stretch) beyond — one wavefront per read
+    above 256 bases; reads with other bases than ACGT take the reference's procedure as written."""
+    rng = np.random.default_rng(13)
+    loci = _loci(rng, n_loci=3, length=9000)
+    gt, ot = _both(gpu_ctx, loci, **over)
+    reads = []
+    for i in range(260):
+        li = int(rng.integers(0, 3)); al = loci[li][int(rng.integers(0, 3))]
+        kind = i % 8
+        ln = int(rng.integers(100, 700)) if kind < 3 else int(rng.integers(700, 7000))
+        p = int(rng.integers(0, len(al) - ln))
+        r, _ = noisy_read(rng, al, p, ln, err=0.03 * (i % 4))
+        if kind == 5: r = bytes(rng.choice(list(b"ACGT"), 2500).tolist()) + r[:900]          # mostly foreign: the stretch decides
+        if kind == 6: r = r[:len(r) // 2] + b"N" * 3 + r[len(r) // 2 + 3:]
+        if kind == 7: r = bytes(rng.choice(list(b"ACGT"), len(r)).tolist())
+        if i % 2: r = revcomp(r)
+        reads.append({"seq1": r.decode(), "seq2": None, "recs": []})
+    ch = ReadsChunk.from_pairs(reads)
+    cnt, out = gt.recruit(ch, paired=False, max_out=4)
+    n_rec = n_long_rec = 0
+    for i, rd in enumerate(reads):
+        exp = ot.recruit(rd["seq1"].encode())
+        assert list(out[i, :cnt[i]]) == exp, (i, len(rd["seq1"]), over)
+        n_rec += bool(exp); n_long_rec += bool(exp) and len(rd["seq1"]) > 500
+    assert n_rec > 60 and n_long_rec > 30, (n_rec, n_long_rec)
