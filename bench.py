@@ -51,6 +51,10 @@ def parse_args():
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
+    ap.add_argument("--shard-reads", action="store_true",
+                    help="one locus over all ranks: every rank scores and prefilters a contiguous shard of the read pairs, the run_filter "
+                         "scores are SUM-all-reduced on the devices (RCCL), truncate_ixs runs everywhere; implies --no-solve (the chains "
+                         "need every read) and strong scaling. Not the default: the driver's runs are one locus per rank")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="extra measurement outside the timed region: this many loci in flight on one GPU, each on its own context / "
                          "stream (the annealing stage leaves most of the GPU idle); 0 or 1 = skip")
@@ -79,9 +83,28 @@ def main():
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
     ctx = api.Context(local_rank % ndev)
 
+    comm = None
+    first_pair = 0
+    total_pairs = args.pairs
+    if args.shard_reads:
+        os.environ.pop("NCCL_DEBUG", None)         # RCCL logs to stdout, which carries the one JSON line
+        os.environ["NCCL_DEBUG_FILE"] = os.devnull
+        args.no_solve = True
+        args.pipeline = args.recovery_sample = args.recruit_sample = 0
+        uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
+        if dist is not None:
+            import torch
+            t_uid = torch.tensor(list(uid), dtype=torch.uint8)
+            dist.broadcast(t_uid, src=0)
+            uid = bytes(t_uid.tolist())
+        comm = api.Comm(ctx, world, rank, uid)
+        per = (args.pairs + world - 1) // world
+        first_pair = min(rank * per, args.pairs)
+        args.pairs = min(first_pair + per, total_pairs) - first_pair          # this rank's shard
+
     # ---- synthetic locus + reads (seed + locus index) -> HBM ----
     t0 = time.time()
-    L = synth.SynthLocus(args.alleles, args.pairs, seed=synth.SEED + rank)
+    L = synth.SynthLocus(args.alleles, total_pairs, seed=synth.SEED + (0 if args.shard_reads else rank))
     params = api.resolve_params(api.default_params(), L.bg)
     t1 = time.time()
     loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
@@ -93,7 +116,7 @@ def main():
     # first pass over chunks only to size the device batch would double the generation time; instead
     # generate chunk by chunk, keep totals, and allocate from the first chunk's density with head-room.
     n_chunks = (args.pairs + args.chunk - 1) // args.chunk
-    c0 = L.reads(0, min(args.chunk, args.pairs))
+    c0 = L.reads(first_pair, min(args.chunk, args.pairs))
     dens_b = c0.n_bases / c0.n_pairs
     dens_r = len(c0.recs) / c0.n_pairs
     dens_c = len(c0.cigar) / c0.n_pairs
@@ -106,7 +129,7 @@ def main():
     first = c0 if (rank == 0 and world == 1 and args.cpu_sample > 0) else None
     for ci in range(1, n_chunks):
         lo = ci * args.chunk
-        ch = L.reads(lo, min(args.chunk, args.pairs - lo))
+        ch = L.reads(first_pair + lo, min(args.chunk, args.pairs - lo))
         aa.append(ch)
         tot_recs += len(ch.recs); tot_cigar += len(ch.cigar); tot_bases += ch.n_bases
         del ch
@@ -120,10 +143,14 @@ def main():
     stage_s = {"score_prefilter": 0.0, "greedy": 0.0, "anneal": 0.0}
     solved = {"greedy_chains": 0, "anneal_chains": 0, "greedy_iterations": 0, "anneal_moves": 0}
 
+    aa_main = aa
+
     def step(it=0, aa=aa, stage_s=stage_s, solved=solved):
         t0s = time.perf_counter()
         aa.score()
         aa.prefilter_async()
+        if comm is not None and aa is aa_main:
+            comm.prefilter_allreduce(aa)                                      # read shards -> scores of the whole batch on every rank
         scores = aa.prefilter_scores()
         keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, 1)   # in_size of stage 1 (solve.rs:216-221)
         stage_s["score_prefilter"] += time.perf_counter() - t0s
@@ -184,7 +211,7 @@ def main():
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
-    reads_per_s = world * args.pairs * args.steps / elapsed
+    reads_per_s = (total_pairs if args.shard_reads else world * args.pairs) * args.steps / elapsed
     score_ms = ms_score / max(n_score, 1)
     pref_ms = ms_pref / max(n_pref, 1)
     alg_bytes = survey_bytes_per_pair(A) * args.pairs
@@ -201,15 +228,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.shard_reads else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.pairs} synthetic 150 bp PE read pairs x {A} alleles, 1 locus per GPU, k=25 "
                                "(BASELINE.json configs[1])",
                    "read_pairs": args.pairs, "alleles": A, "genotypes": G, "k": 25,
-                   "records": tot_recs, "cigar_words": tot_cigar, "parallelism": f"loci x{world}"},
-        "reads_scored_per_s": world * args.pairs * args.steps / max(stage_s["score_prefilter"], 1e-9),
+                   "records": tot_recs, "cigar_words": tot_cigar, "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"loci x{world}")},
+        "reads_scored_per_s": (total_pairs if args.shard_reads else world * args.pairs) * args.steps / max(stage_s["score_prefilter"], 1e-9),
         "genotypes_prefiltered_per_s": world * G * args.steps / max(stage_s["score_prefilter"], 1e-9),
         "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3),
         "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms, "solve_loop_per_step": ms_solve / args.steps,

@@ -276,6 +276,19 @@ int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double fi
 uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy);
 int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* out, uint64_t cap);
 
+/* ---- one locus over several GPUs: the exchange step -----------------------------------------------------------
+ * run_filter's score of a genotype is a sum over reads (solve.rs:105-119): with the reads of a locus sharded over ranks (one process
+ * per GPU), every rank runs lcty_score_reads + lcty_prefilter_async on its shard and lcty_prefilter_allreduce sums the G-long f64
+ * vectors in place on the devices (RCCL all-reduce over xGMI); lcty_prefilter_scores then returns the scores of the whole batch on
+ * every rank and truncate_ixs proceeds identically everywhere. Priors are added afterwards (they are not per-read).
+ * lcty_comm_unique_id: ncclGetUniqueId on rank 0; the launcher hands the 128 bytes to the other ranks. n_ranks == 1 is allowed. */
+#define LCTY_COMM_ID_BYTES 128
+typedef struct lcty_comm lcty_comm;
+int32_t lcty_comm_unique_id(uint8_t* id);
+int32_t lcty_comm_create(lcty_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* id, lcty_comm** out);
+void    lcty_comm_destroy(lcty_comm* comm);
+int32_t lcty_prefilter_allreduce(lcty_reads* reads, lcty_comm* comm);
+
 /* ---- alignment recovery (AllAlignments::load with opt_hap_alns = Some; src/seq/transfer.rs, src/seq/cigar.rs:1085-1384,
  * src/seq/wfa.rs) ------------------------------------------------------------------------------------------------------
  * lcty_locus_set_hap_alns: the pairwise haplotype alignments of `haplotypes.paf` as HapAlns::add takes them (transfer.rs:41-62):

@@ -47,6 +47,10 @@ SIGNATURES = {
     "lcty_locus_set_hap_alns": (I32, [VP, U32, VP, VP, VP, VP, VP, VP, U32, D]),
     "lcty_recover_alignments": (I32, [VP, P(U64)]),
     "lcty_recover_stats": (I32, [VP, P(U64)]),
+    "lcty_comm_unique_id": (I32, [VP]),
+    "lcty_comm_create": (I32, [VP, I32, I32, VP, P(VP)]),
+    "lcty_comm_destroy": (None, [VP]),
+    "lcty_prefilter_allreduce": (I32, [VP, VP]),
     "lcty_recruit_params_default": (I32, [VP, I32, I32]),
     "lcty_targets_create": (I32, [VP, VP, P(VP)]),
     "lcty_targets_destroy": (None, [VP]),

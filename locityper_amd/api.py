@@ -488,3 +488,39 @@ class Targets:
             self.close()
         except Exception:
             pass
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId (rank 0); hand the bytes to the other ranks (locityper_amd.dist.make_comm does that over torch.distributed)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().lcty_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of one process per GPU (lcty_comm): the SUM all-reduce of read-sharded run_filter scores."""
+
+    def __init__(self, ctx, n_ranks, rank, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.ctx = ctx
+        self._h = VP()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().lcty_comm_create(ctx._h, n_ranks, rank, buf, C.byref(self._h)))
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def prefilter_allreduce(self, aa):
+        check(lib().lcty_prefilter_allreduce(aa._h, self._h))
+
+    def close(self):
+        if self._h:
+            lib().lcty_comm_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -3,7 +3,8 @@
 The path shards at two levels:
   * loci are independent (command/genotype.rs:1331-1351): round-robin over ranks, no collective;
   * inside one locus reads contribute additively to run_filter scores (solvers/solve.rs:105-119):
-    read shards -> one SUM all-reduce of the G-long f64 score vector.
+    read shards -> one SUM all-reduce of the G-long f64 score vector — on the devices through RCCL (make_comm +
+    Comm.prefilter_allreduce, the library's lcty_prefilter_allreduce), or of host arrays through the process group.
 torch.distributed is plumbing only (rendezvous, barrier, small host-staged reductions); it is
 imported lazily and only when WORLD_SIZE > 1, after liblocityper_hip.so has been loaded.
 """
@@ -73,6 +74,19 @@ def allreduce_sum_f64(arr):
     t = torch.from_numpy(arr.copy())
     _pg.all_reduce(t, op=_pg.ReduceOp.SUM)
     return t.numpy()
+
+
+def make_comm(ctx):
+    """RCCL communicator over all ranks (one process per GPU): rank 0 draws the id, the process group (gloo) carries it."""
+    from . import api
+    rank, _, world = env()
+    uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
+    if _pg is not None:
+        import torch
+        t = torch.tensor(list(uid), dtype=torch.uint8)
+        _pg.broadcast(t, src=0)
+        uid = bytes(t.tolist())
+    return api.Comm(ctx, world, rank, uid)
 
 
 def gather_objects(obj):

@@ -705,3 +705,30 @@ def test_alignment_recovery_needs_haplotype_alignments(gpu_ctx):
     aa = api.AllAlignments.load(loc, ch)
     with pytest.raises(_lib.LocityperError):
         aa.recover()
+
+
+@pytest.mark.gpu
+def test_read_sharded_prefilter_allreduce(gpu_ctx):
+    """The exchange step of a locus sharded over GPUs: shards prefiltered separately and summed give the scores of the whole
+    batch; the device all-reduce (RCCL) runs here with one rank — the library call, the communicator and the in-place reduction are the
+    ones N ranks use."""
+    L = synth.SynthLocus(16, 6000, seed=77, base_len=20000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ch = L.reads(0, 6000)
+    whole = api.AllAlignments.load(loc, ch)
+    whole.prefilter_async()
+    full = whole.prefilter_scores()
+    parts = []
+    for lo, hi in ((0, 2500), (2500, 6000)):
+        aa = api.AllAlignments.load(loc, ch.slice(lo, hi))
+        aa.prefilter_async()
+        parts.append(aa.prefilter_scores())
+    assert np.allclose(parts[0] + parts[1], full, rtol=1e-12, atol=1e-9) and int(np.argmax(parts[0] + parts[1])) == int(np.argmax(full))
+    comm = api.Comm(gpu_ctx, 1, 0, api.comm_unique_id())
+    comm.prefilter_allreduce(whole)
+    assert np.array_equal(whole.prefilter_scores(), full)
+    other = api.Context(0)
+    with pytest.raises(_lib.LocityperError):
+        api.Comm(other, 1, 0, api.comm_unique_id()).prefilter_allreduce(whole)      # communicator of another context
+    comm.close()
