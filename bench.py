@@ -406,6 +406,20 @@ def main():
                                "reads_scored_per_s": ns / (t_load + t_filter),
                                "chains_per_s": (cpu_chains / t_solve_cpu) if cpu_chains else None,
                                "cpu_count": os.cpu_count()}
+        if out.get("recruitment") and args.recruit_sample > 0:
+            # recruitment on the same core: the oracle's recruit_read_pair on a bounded sample of random pairs
+            ot = O.OracleTargets(rprm.minimizer_k, rprm.minimizer_w, rprm.match_frac, rprm.match_length, rprm.thresh_kmer_count)
+            ot.add_locus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k)
+            ot.finalize()
+            nsq = 20000
+            acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+            rq_words = np.random.default_rng(11).integers(0, 1 << 32, size=nsq * 20, dtype=np.uint64).astype(np.uint32).reshape(nsq, 2, 10)
+            codes = ((rq_words[..., None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(nsq, 2, 160)[:, :, :150]
+            sq = acgt[codes]
+            tc = time.perf_counter()
+            for i in range(nsq):
+                ot.recruit(sq[i, 0].tobytes(), sq[i, 1].tobytes())
+            out["cpu_baseline"]["recruitment_read_pairs_per_s"] = nsq / (time.perf_counter() - tc)
     print(json.dumps(out))
 
 

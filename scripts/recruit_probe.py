@@ -1,6 +1,6 @@
 """Developer probe for minimizer read recruitment: whole-genome-like input, most read pairs foreign.
     python scripts/recruit_probe.py [n_pairs] [n_loci] [fraction_from_loci]
-Prints one JSON line: read pairs/s of recruit_kernel (inputs resident), of the whole call, and of the oracle on a sample."""
+Prints one JSON line: read pairs/s of recruit_kernel (inputs resident) and of the whole call (the oracle's rate is in bench.py's cpu_baseline)."""
 import json
 import os
 import sys
@@ -74,19 +74,4 @@ n_launch, ms = ctx.timing(api.K_RECRUIT)
 res.update({"kernel_ms": round(ms, 3), "launches": n_launch, "pairs_per_s_kernel": round(N / (ms * 1e-3)),
             "packed_input_GBs": round(N * 80 / (ms * 1e-3) / 1e9, 1), "pairs_per_s_call_random_part": round(n_rand / t_rand),
             "foreign_pairs_recruited": int(np.count_nonzero(cnt_r)), "locus_pairs": n_loc, "locus_pairs_recruited_to_their_locus": rec_loc})
-# the oracle (single thread) on a sample of the random pairs
-from tests import oracle_ffi as O
-ot = O.OracleTargets(prm.minimizer_k, prm.minimizer_w, prm.match_frac, prm.match_length, prm.thresh_kmer_count)
-for L in loci:
-    ot.add_locus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k)
-ot.finalize()
-ns = 20000
-acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-w = rand.bases2[:ns * 20].reshape(ns, 2, 10)
-codes = ((w[..., None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(ns, 2, 160)[:, :, :150]
-seqs = acgt[codes]
-t0 = time.time()
-n_o = sum(bool(ot.recruit(seqs[i, 0].tobytes(), seqs[i, 1].tobytes())) for i in range(ns))
-res["oracle_pairs_per_s_1_thread"] = round(ns / (time.time() - t0))
-res["oracle_sample_recruited"] = n_o
 print(json.dumps(res))
