@@ -276,6 +276,11 @@ int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double fi
 uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy);
 int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* out, uint64_t cap);
 
+/* Per-read posteriors: assignment counts of a genotype's attempts (lcty_assignment_counts) -> probability and mapping quality of
+ * every (read, location), as the output BAMs carry them in the `pr` tag / MAPQ — count_to_prob (src/model/bam.rs:56-67):
+ * 0 -> (0, 0); all attempts -> (1, 60); otherwise count / attempts in f32 and min(60, round(-10 log10(1 - p))). */
+int32_t lcty_counts_to_posteriors(const uint16_t* counts, uint64_t n, uint16_t attempts, float* prob, uint8_t* mapq);
+
 /* ---- one locus over several GPUs: the exchange step -----------------------------------------------------------
  * run_filter's score of a genotype is a sum over reads (solve.rs:105-119): with the reads of a locus sharded over ranks (one process
  * per GPU), every rank runs lcty_score_reads + lcty_prefilter_async on its shard and lcty_prefilter_allreduce sums the G-long f64

@@ -524,3 +524,11 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def counts_to_posteriors(counts, attempts):
+    """count_to_prob (model/bam.rs:56-67) for every entry of an assignment-count array: (probability f32, MAPQ u8)."""
+    counts = np.ascontiguousarray(counts, dtype=np.uint16)
+    prob = np.zeros(len(counts), dtype=np.float32); mapq = np.zeros(len(counts), dtype=np.uint8)
+    check(lib().lcty_counts_to_posteriors(counts.ctypes.data, len(counts), attempts, prob.ctypes.data, mapq.ctypes.data))
+    return prob, mapq

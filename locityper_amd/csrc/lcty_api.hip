@@ -259,4 +259,22 @@ int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, doubl
     });
 }
 
+// count_to_prob (src/model/bam.rs:56-67)
+int32_t lcty_counts_to_posteriors(const uint16_t* counts, uint64_t n, uint16_t attempts, float* prob, uint8_t* mapq) {
+    return guarded([&] {
+        if ((n && !counts) || !prob || !mapq) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        for (uint64_t i = 0; i < n; i++) {
+            const uint16_t c = counts[i];
+            if (c == 0) { prob[i] = 0.0f; mapq[i] = 0; }
+            else if (c == attempts) { prob[i] = 1.0f; mapq[i] = 60; }
+            else {
+                if (c > attempts) fail(LCTY_ERR_INVALID_INPUT, "count %u of %u attempts", c, attempts);       // assert!(count < attempts)
+                const float p = static_cast<float>(c) / static_cast<float>(attempts);
+                prob[i] = p;
+                mapq[i] = static_cast<uint8_t>(std::fmin(std::round(-10.0f * std::log10(1.0f - p)), 60.0f));
+            }
+        }
+    });
+}
+
 }  // extern "C"

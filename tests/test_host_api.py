@@ -140,3 +140,17 @@ def test_call_checks_match_oracle_and_hand_values():
     assert api.call_checks(g2[:1], [np.log(0.005)], 500)[2] == cdefs.WARN_NO_PROBABLE_GENOTYPE == O.call_checks(g2[:1], [np.log(0.005)], 500)[2]
     for n_reads, want in ((1, 2), (3, 2), (5, 0), (19, 0), (20, 0)):
         assert api.call_checks(g2[:1], [0.0], n_reads)[2] == want == O.call_checks(g2[:1], [0.0], n_reads)[2]
+
+
+def test_counts_to_posteriors():
+    """count_to_prob (model/bam.rs:56-67): the per-read posteriors the output BAMs carry (probability, MAPQ)."""
+    import math
+    prob, mapq = api.counts_to_posteriors([0, 20, 19, 10, 1, 2], 20)
+    assert list(mapq) == [0, 60, 13, 3, 0, 0] and prob[0] == 0.0 and prob[1] == 1.0
+    for c, p, q in zip([19, 10, 1, 2], prob[2:], mapq[2:]):
+        pf = np.float32(c) / np.float32(20)
+        assert p == pf and q == min(60, int(round(-10.0 * math.log10(1.0 - float(pf)))))
+    prob, mapq = api.counts_to_posteriors([999], 1000)
+    assert mapq[0] == 30
+    with pytest.raises(_lib.LocityperError):
+        api.counts_to_posteriors([21], 20)
