@@ -1,6 +1,6 @@
 """Developer probe for alignment recovery (K6): the mapper reports only the primary alignment of each read end, the alignments
 to the other alleles are transferred through the haplotype-to-haplotype alignments (transfer.rs:70-140).
-    python scripts/recovery_probe.py [n_pairs] [n_alleles] [transfer_fails]
+    python scripts/recovery_probe.py [n_pairs] [n_alleles] [transfer_fails] [ont]
 Prints one JSON line: transfers/s of the transfer kernel, the second scoring pass, agreement with the all-alignments load."""
 import json
 import os
@@ -18,7 +18,8 @@ TF = int(sys.argv[3]) if len(sys.argv) > 3 else 100      # the reference's defau
 
 ctx = api.Context(0)
 t0 = time.time()
-L = synth.SynthLocus(A, R)
+ONT = len(sys.argv) > 4 and sys.argv[4] == "ont"          # single-end long reads (10 kb, CIGARs of hundreds of operations)
+L = synth.SynthLocus(A, R, technology=cdefs.TECH_NANOPORE, read_len=10_000) if ONT else synth.SynthLocus(A, R)
 p = api.resolve_params(api.default_params(), L.bg)
 loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
 H = L.hap_alns()
