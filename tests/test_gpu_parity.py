@@ -153,6 +153,17 @@ def test_config2_shape_sample(gpu_ctx, n_alleles, n_pairs):
     check_prefilter(aa, Mo, n_alleles, p)
 
 
+def test_config5_shape_many_alleles(gpu_ctx):
+    """configs[4] shape in small: 1 000 alleles (an allele count beyond one 128 x 128 prefilter tile row and beyond 512, with 500 500
+    genotypes), 2 000 records per read pair; scoring, matrix and the prefilter scores of every genotype against the oracle."""
+    L = synth.SynthLocus(1000, 1_000_000, base_len=12_000)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    ch = L.reads(1000, 260)
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    check_prefilter(aa, Mo, 1000, p)
+
+
 def test_config3_ont_single_end(gpu_ctx):
     """configs[2] shape: single-end long reads (p-value edit thresholds, window 5000-like, SE grouping)."""
     L = synth.SynthLocus(16, 3000, technology=cdefs.TECH_NANOPORE, read_len=10_000, base_len=60_000)
