@@ -53,7 +53,8 @@ def _reads(rng, loci, n, lens=(150, 150)):
 
 
 @pytest.mark.parametrize("over", [dict(), dict(minimizer_k=27, minimizer_w=5, match_frac=0.7), dict(minimizer_k=11, minimizer_w=20, match_frac=0.3),
-                                  dict(minimizer_k=31, minimizer_w=31, match_frac=0.5), dict(thresh_kmer_count=200)])
+                                  dict(minimizer_k=31, minimizer_w=31, match_frac=0.5), dict(thresh_kmer_count=200),
+                                  dict(minimizer_k=9, minimizer_w=45, match_frac=0.4), dict(minimizer_k=20, minimizer_w=2, match_frac=0.6)])
 def test_read_pairs_and_single_reads_match_oracle(gpu_ctx, over):
     rng = np.random.default_rng(5)
     loci = _loci(rng, n_loci=4)
