@@ -67,6 +67,11 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # stdout carries exactly one JSON line: whatever the libraries underneath print there (gloo announces its connections, RCCL its
+    # version) goes to stderr, the line itself to the real stdout at the very end
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     _lib.lib()      # load the HIP library before anything else can bring another HIP runtime into scope
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -420,7 +425,8 @@ def main():
             for i in range(nsq):
                 ot.recruit(sq[i, 0].tobytes(), sq[i, 1].tobytes())
             out["cpu_baseline"]["recruitment_read_pairs_per_s"] = nsq / (time.perf_counter() - tc)
-    print(json.dumps(out))
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
 
 
 if __name__ == "__main__":
