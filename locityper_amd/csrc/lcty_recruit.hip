@@ -45,7 +45,7 @@ struct RecruitView {
     int paired;
     uint32_t max_out;
     uint32_t* out_cnt; uint32_t* out_loci;
-    uint64_t* scratch; uint32_t scratch_cap;      // per workgroup [scratch_cap][64] minimizers of the mate being walked
+    uint64_t* scratch; uint8_t* scratch_f; uint32_t scratch_cap;      // per workgroup [scratch_cap][64] minimizers of the mate being walked (hash, direction)
     // single reads of more than 256 bases: one wavefront per read
     const uint32_t* long_list; uint32_t n_long; uint32_t long_cap;      // reads of the list; minimizers a read can have
     uint64_t* long_h; uint8_t* long_f;             // per workgroup 2 x [long_cap]: minimizers in read order (second half: staging)
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
     uint64_t* suf_h = ring + static_cast<size_t>(V.ring) * 64;                  // suffix minima of the block before the running one
     uint32_t* suf_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(smem) + static_cast<size_t>(V.ring) * 128) + lane;
     uint64_t* buf = V.scratch + static_cast<size_t>(blockIdx.x) * V.scratch_cap * 64 + lane;     // minimizer j of this lane at buf[j * 64]
+    uint8_t* buf_f = V.scratch_f + static_cast<size_t>(blockIdx.x) * V.scratch_cap * 64 + lane;  // its direction
     for (uint64_t p0 = static_cast<uint64_t>(blockIdx.x) * 64; p0 < V.n_pairs; p0 += static_cast<uint64_t>(gridDim.x) * 64) {
         const uint64_t p = p0 + lane;
         const bool valid = p < V.n_pairs;
@@ -223,7 +224,6 @@ __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
             // the second mate is only looked at when the first one matched something (recruit.rs:899)
             const bool walk = valid && !bad && (mate == 0 || M.n > 0);
             uint32_t total = 0;
-            uint64_t fwd_of[4] = {0, 0, 0, 0};                                   // direction of minimizer j at bit j
             if (walk) {
                 const uint64_t off = V.mate_off[2 * p + mate];
                 const uint64_t* w64 = reinterpret_cast<const uint64_t*>(V.bases2) + (off >> 5);
@@ -231,16 +231,14 @@ __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
                 uint32_t any_n = 0;
                 for (uint32_t q = 0; q * 32 < len; q++) any_n |= nm[q] & (len - q * 32 >= 32 ? 0xFFFFFFFFu : ((1u << (len - q * 32)) - 1u));
                 auto keep = [&](uint64_t h, bool fw) {
-                    if (total < V.scratch_cap) buf[static_cast<size_t>(total) * 64] = h;
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; q++) if ((total >> 6) == q) fwd_of[q] |= static_cast<uint64_t>(fw) << (total & 63u);
+                    if (total < V.scratch_cap) { buf[static_cast<size_t>(total) * 64] = h; buf_f[static_cast<size_t>(total) * 64] = fw; }
                     total++;
                 };
                 bool done = false;
                 if (any_n == 0) {
                     uint32_t n_fast = 0;
                     done = walk_minimizers_acgt(V, w64, len, ring, suf_h, suf_p, &n_fast, keep);
-                    if (!done) { total = 0; fwd_of[0] = fwd_of[1] = fwd_of[2] = fwd_of[3] = 0; }
+                    if (!done) total = 0;
                 }
                 if (!done) {
                     const uint32_t n_ref = walk_minimizers(V, w64, nm, len, ring, keep);
@@ -251,12 +249,7 @@ __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
             uint32_t most = total;
             for (int o = 32; o > 0; o >>= 1) most = max(most, static_cast<uint32_t>(__shfl_xor(static_cast<int>(most), o)));
             for (uint32_t j = 0; j < most; j++) {
-                if (j < total) {
-                    uint64_t bits = fwd_of[0];
-#pragma unroll
-                    for (uint32_t q = 1; q < 4; q++) if ((j >> 6) == q) bits = fwd_of[q];
-                    probe(buf[static_cast<size_t>(j) * 64], ((bits >> (j & 63u)) & 1ull) != 0, mate != 0);
-                }
+                if (j < total) probe(buf[static_cast<size_t>(j) * 64], buf_f[static_cast<size_t>(j) * 64] != 0, mate != 0);
             }
         }
         if (!valid || bad) continue;
@@ -703,9 +696,9 @@ int32_t lcty_recruit(lcty_targets* t, const lcty_reads_host* h, int32_t paired, 
         if (n > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "recruitment: more than 2^32 reads in one call");
         V.scratch_cap = max_len;                                                 // a mate has fewer minimizers than bases
         const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 63) / 64, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 12));
-        DevBuf<uint64_t> d_scratch, d_long_h; DevBuf<uint8_t> d_long_f; DevBuf<uint32_t> d_long_list;
-        d_scratch.alloc(static_cast<size_t>(blocks) * V.scratch_cap * 64);
-        V.scratch = d_scratch.p;
+        DevBuf<uint64_t> d_scratch, d_long_h; DevBuf<uint8_t> d_long_f, d_scratch_f; DevBuf<uint32_t> d_long_list;
+        d_scratch.alloc(static_cast<size_t>(blocks) * V.scratch_cap * 64); d_scratch_f.alloc(static_cast<size_t>(blocks) * V.scratch_cap * 64);
+        V.scratch = d_scratch.p; V.scratch_f = d_scratch_f.p;
         V.match_frac = t->prm.match_frac;
         // Params::new (recruit.rs:92-98)
         V.stretch_minims = (2 * t->prm.match_length + (static_cast<uint32_t>(t->prm.minimizer_w) + 1) - 1) / (static_cast<uint32_t>(t->prm.minimizer_w) + 1);
