@@ -114,12 +114,13 @@ __device__ inline uint32_t walk_minimizers(const RecruitView& V, const uint64_t*
 template <typename F>
 __device__ inline bool walk_minimizers_acgt(const RecruitView& V, const uint64_t* w64, uint32_t len, uint64_t* ring, uint64_t* suf_h, uint32_t* suf_p,
                                             uint32_t* total_out, F&& on_minimizer) {
-    const uint32_t k = V.k, w = V.w, k_1 = k - 1, w_1 = w - 1, rmask = V.ring - 1;
+    // ring / suf_h / suf_p: w slots each (not a power of two: the slot index is a counter that wraps), slot s of this lane at [s * 64]
+    const uint32_t k = V.k, w = V.w, k_1 = k - 1, w_1 = w - 1;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const uint32_t rv_shift = 2 * k - 2;
     uint64_t fw_kmer = 0, rv_kmer = 0, fwd_bits = 0;                  // forward flag of k-mer t at bit t & 63 (only the last w matter, w < 64)
     uint64_t pre_h = UNDEF64; uint32_t pre_p = 0;                     // leftmost minimum of the running block
-    uint32_t in_block = 0;                                            // k-mers of the running block so far
+    uint32_t in_block = 0;                                            // k-mers of the running block so far = slot of the next k-mer
     int64_t last_pos = -1;
     uint32_t total = 0;
     bool undef_seen = false;
@@ -130,19 +131,20 @@ __device__ inline bool walk_minimizers_acgt(const RecruitView& V, const uint64_t
         fw_kmer = ((fw_kmer << 2) | enc) & mask;
         rv_kmer = (rv_kmer >> 2) | ((3ull - enc) << rv_shift);
         if (i < k_1) continue;
-        const uint32_t t = i - k_1;                                   // index of the k-mer that ends here
+        const uint32_t t = i - k_1;                                   // index of the k-mer that ends here; its slot is in_block (blocks start at slot 0)
         const bool fwd = !(rv_kmer < fw_kmer);
         const uint64_t h = fast_hash64(fwd ? fw_kmer : rv_kmer);
         undef_seen |= h == UNDEF64;
-        ring[(t & rmask) * 64] = h;
+        const uint32_t slot = in_block;
+        ring[slot * 64] = h;
         fwd_bits = (fwd_bits & ~(1ull << (t & 63u))) | (static_cast<uint64_t>(fwd) << (t & 63u));
         if (in_block == 0 || h < pre_h) { pre_h = h; pre_p = t; }
         in_block++;
         if (t >= w_1) {
-            // window [t - w_1, t]: its part in the block before (suffix minimum from t - w_1 on) and the running block
+            // window [t - w_1, t]: its part in the block before (suffix minimum from t - w_1 on: slot + 1 of that block) and the running block
             uint64_t best_h = pre_h; uint32_t best_p = pre_p;
             if (in_block < w) {
-                const uint32_t sidx = ((t - w_1) & rmask) * 64;
+                const uint32_t sidx = (slot + 1) * 64;
                 const uint64_t sh = suf_h[sidx];
                 if (sh <= pre_h) { best_h = sh; best_p = suf_p[sidx]; }
             }
@@ -155,10 +157,10 @@ __device__ inline bool walk_minimizers_acgt(const RecruitView& V, const uint64_t
         if (in_block == w) {                                          // block complete: its leftmost suffix minima, back to front
             uint64_t sh = UNDEF64; uint32_t sp = 0;
             for (uint32_t q = 0; q < w; q++) {
-                const uint32_t j = t - q;
-                const uint64_t v = ring[(j & rmask) * 64];
-                if (q == 0 || v <= sh) { sh = v; sp = j; }
-                suf_h[(j & rmask) * 64] = sh; suf_p[(j & rmask) * 64] = sp;
+                const uint32_t s = w_1 - q;                               // slot of k-mer t - q
+                const uint64_t v = ring[s * 64];
+                if (q == 0 || v <= sh) { sh = v; sp = t - q; }
+                suf_h[s * 64] = sh; suf_p[s * 64] = sp;
             }
             in_block = 0;
         }
@@ -179,8 +181,9 @@ __global__ __launch_bounds__(64) void recruit_kernel(const RecruitView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t lane = threadIdx.x;
     uint64_t* ring = reinterpret_cast<uint64_t*>(smem) + lane;                  // slot j of this lane at ring[j * 64]
-    uint64_t* suf_h = ring + static_cast<size_t>(V.ring) * 64;                  // suffix minima of the block before the running one
-    uint32_t* suf_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(smem) + static_cast<size_t>(V.ring) * 128) + lane;
+    // the block-wise walk uses w slots of each of its three arrays; the walk as written uses V.ring slots of `ring` (same lane column)
+    uint64_t* suf_h = ring + static_cast<size_t>(V.w) * 64;                     // suffix minima of the block before the running one
+    uint32_t* suf_p = reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(smem) + static_cast<size_t>(V.w) * 128) + lane;
     uint64_t* buf = V.scratch + static_cast<size_t>(blockIdx.x) * V.scratch_cap * 64 + lane;     // minimizer j of this lane at buf[j * 64]
     uint8_t* buf_f = V.scratch_f + static_cast<size_t>(blockIdx.x) * V.scratch_cap * 64 + lane;  // its direction
     for (uint64_t p0 = static_cast<uint64_t>(blockIdx.x) * 64; p0 < V.n_pairs; p0 += static_cast<uint64_t>(gridDim.x) * 64) {
@@ -683,7 +686,8 @@ int32_t lcty_recruit(lcty_targets* t, const lcty_reads_host* h, int32_t paired, 
         V.mf_num = t->mf_num; V.mf_den = t->mf_den;
         V.n_pairs = n; V.mate_len = d_len.p; V.mate_off = d_off.p; V.bases2 = d_bases.p; V.nmask = d_nm.p;
         V.paired = paired != 0; V.max_out = max_out; V.out_cnt = d_cnt.p; V.out_loci = d_loci.p; V.err = t->d_err.p;
-        const size_t lds = static_cast<size_t>(V.ring) * 64 * (8 + 8 + 4);
+        const size_t lds_single = static_cast<size_t>(V.ring) * 64 * (8 + 8 + 4);
+        const size_t lds = std::max<size_t>(static_cast<size_t>(V.ring) * 8, static_cast<size_t>(V.w) * (8 + 8 + 4)) * 64;   // pair kernel: w slots per array
         // single reads of more than 256 bases go to the wavefront-per-read kernel (short-read rule up to 500 bases, long-read rule beyond)
         uint32_t max_len = 1, max_long = 0;
         std::vector<uint32_t> long_list;
@@ -695,7 +699,7 @@ int32_t lcty_recruit(lcty_targets* t, const lcty_reads_host* h, int32_t paired, 
         if (max_len > 256) fail(LCTY_ERR_UNSUPPORTED, "recruitment: a mate of %u bases in a read pair (the device kernel takes mates of up to 256 bases)", max_len);
         if (n > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "recruitment: more than 2^32 reads in one call");
         V.scratch_cap = max_len;                                                 // a mate has fewer minimizers than bases
-        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 63) / 64, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 12));
+        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n + 63) / 64, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16));
         DevBuf<uint64_t> d_scratch, d_long_h; DevBuf<uint8_t> d_long_f, d_scratch_f; DevBuf<uint32_t> d_long_list;
         d_scratch.alloc(static_cast<size_t>(blocks) * V.scratch_cap * 64); d_scratch_f.alloc(static_cast<size_t>(blocks) * V.scratch_cap * 64);
         V.scratch = d_scratch.p; V.scratch_f = d_scratch_f.p;
@@ -713,7 +717,7 @@ int32_t lcty_recruit(lcty_targets* t, const lcty_reads_host* h, int32_t paired, 
             d_long_h.alloc(static_cast<size_t>(lblocks) * 2 * V.long_cap); d_long_f.alloc(static_cast<size_t>(lblocks) * 2 * V.long_cap);
             V.long_list = d_long_list.p; V.long_h = d_long_h.p; V.long_f = d_long_f.p;
             ctx->timed(LCTY_K_RECRUIT, [&] {
-                hipLaunchKernelGGL(recruit_single_kernel, dim3(lblocks), dim3(64), lds, s, V);
+                hipLaunchKernelGGL(recruit_single_kernel, dim3(lblocks), dim3(64), lds_single, s, V);
             });
         }
         LCTY_HIP(hipGetLastError());
