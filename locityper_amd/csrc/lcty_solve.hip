@@ -928,13 +928,35 @@ void solve_loop_kernel(const SolveView V) {
                 const unsigned long long two = __ballot(wide);
                 uint32_t q = 0, walked = 0;
                 int hit = -1;
-                while (q < w) {
-                    if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
-                    iter++; n_iter++; walked++;
-                    const uint32_t cons = 1 + static_cast<uint32_t>((two >> q) & 1ull);
-                    if ((acc >> q) & 1ull) { hit = static_cast<int>(q); q += cons; break; }
-                    curr_plato++;
-                    q += cons;
+                // Which lanes lie on the true chain of moves: position 0 does; position p > 0 does unless p - 1 does and its move takes two
+                // draws. Behind the nearest position r < p whose move takes one draw (or the start) the chain alternates, so p is on it
+                // iff p - (r + 1) is even: one count-leading-zeros per lane instead of a serial walk over the draws.
+                const unsigned long long below = lane ? ((1ull << lane) - 1ull) : 0ull;
+                const unsigned long long ones = ~two & below;
+                const uint32_t after = ones ? 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(ones))) : 0u;      // r + 1
+                const unsigned long long chain_mask = __ballot(lane < w && ((lane - after) & 1u) == 0u);
+                const unsigned long long hits = acc & chain_mask;
+                const uint32_t stop = hits ? static_cast<uint32_t>(__ffsll(static_cast<long long>(hits))) - 1u : w;   // first accepted move on the chain
+                const uint32_t moves = static_cast<uint32_t>(__popcll(chain_mask & (stop >= 63u ? ~0ull : ((2ull << stop) - 1ull))));   // evaluated in order, the hit included
+                const uint32_t rejected = moves - (hits ? 1u : 0u);
+                if (iter + moves <= max_iter && curr_plato + rejected < V.solver.plato_size) {
+                    // neither cap is reached inside this step: the serial loop would have gone exactly this far
+                    iter += moves; n_iter += moves; walked = moves; curr_plato += rejected;
+                    if (hits) { hit = static_cast<int>(stop); q = stop + 1u + static_cast<uint32_t>((two >> stop) & 1ull); }
+                    else {
+                        // everything evaluated was rejected: the draws used are those of the chain's moves among the first w positions
+                        const uint32_t last = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(chain_mask)));
+                        q = last + 1u + static_cast<uint32_t>((two >> last) & 1ull);
+                    }
+                } else {
+                    while (q < w) {                                               // the last steps of a chain: one move at a time
+                        if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
+                        iter++; n_iter++; walked++;
+                        const uint32_t cons = 1 + static_cast<uint32_t>((two >> q) & 1ull);
+                        if ((acc >> q) & 1ull) { hit = static_cast<int>(q); q += cons; break; }
+                        curr_plato++;
+                        q += cons;
+                    }
                 }
                 if (hit >= 0) {
                     Move a;
