@@ -643,8 +643,9 @@ void solve_loop_kernel(const SolveView V) {
         depth_lik += m.ddiff;                                                 // nothing moved since it was evaluated
         aln_lik += m.lp_new - m.lp_old;
         if (lane == 0) {
-            wd[m.w3] += 1; wd[m.w4] += 1;                                     // the depth field never borrows from the GC bits
-            wd[m.w1] -= 1; wd[m.w2] -= 1;
+            // LDS atomics (no return value): four operations in program order without a read-modify-write round trip each
+            atomicAdd(&wd[m.w3], 1u); atomicAdd(&wd[m.w4], 1u);                // the depth field never borrows from the GC bits
+            atomicSub(&wd[m.w1], 1u); atomicSub(&wd[m.w2], 1u);
             __hip_atomic_store(&nontriv[m.slot], m.rp | (m.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // one wavefront owns the chain: LDS and vector-memory operations of a wavefront execute in program order, so the
@@ -794,8 +795,8 @@ void solve_loop_kernel(const SolveView V) {
                         // slot changed. The lane's share of the likelihood is added up at the end.
                         const uint32_t src = static_cast<uint32_t>(__ffsll(static_cast<long long>(who))) - 1u;
                         if (lane == src) {
-                            wd[mm.w3] += 1; wd[mm.w4] += 1;                   // the depth field never borrows from the GC bits
-                            wd[mm.w1] -= 1; wd[mm.w2] -= 1;
+                            atomicAdd(&wd[mm.w3], 1u); atomicAdd(&wd[mm.w4], 1u);   // the depth field never borrows from the GC bits
+                            atomicSub(&wd[mm.w1], 1u); atomicSub(&wd[mm.w2], 1u);
                             __hip_atomic_store(&nontriv[mm.slot], mm.rp | (mm.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             depth_mine += mm.ddiff;
                             aln_mine += mm.lp_new - mm.lp_old;
