@@ -528,13 +528,12 @@ __global__ __launch_bounds__(KIND == LCTY_SOLVER_GREEDY ? 64 : 128, KIND == LCTY
 void solve_loop_kernel(const SolveView V) {
     extern __shared__ __align__(32) uint8_t smem[];
     const uint32_t W = V.wstride;
-    // [W] window weights first (greedy only: its 3 waves/SIMD leave room for them; the 400-odd annealing chains read
-    // theirs through L2), then [W] depth | GC bin << 25
-    constexpr bool WW_LDS = KIND == LCTY_SOLVER_GREEDY;
+    // [W] window weights first, then [W] depth | GC bin << 25
+    constexpr bool WW_LDS = true;
     double* lww = reinterpret_cast<double*>(smem);
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem + (WW_LDS ? static_cast<size_t>(W) * 8 : 0));
     // annealing only: a second wavefront stages the reads of the coming moves in an LDS ring (see the second loop)
-    AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
+    AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + static_cast<size_t>(W) * 8 + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
@@ -1136,7 +1135,7 @@ template <uint32_t P>
 void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, size_t lds_loop_base) {
     const size_t lds_loop = V.solver.kind == LCTY_SOLVER_GREEDY
         ? lds_loop_base + static_cast<size_t>(V.wstride) * 8
-        : ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
+        : static_cast<size_t>(V.wstride) * 8 + ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
     const uint32_t loop_threads = V.solver.kind == LCTY_SOLVER_GREEDY ? 64 : 128;
     hipStream_t s = ctx->stream;
     if (lds_init > 48 * 1024)
