@@ -422,7 +422,71 @@ static void set_insert(u128set* s, orc_u128 k) {
 
 const lcty_params* orc_locus_params(const orc_locus* l) { return &l->prm; }
 
-/* ContigInfo::new — src/model/windows.rs:362-424 (no explicit weights) */
+/* ExplicitWeights — model/windows.rs:196-250. SCALE = 2^32; the running sums are integers, so sums over ranges are exact. */
+#define EW_SCALE 4294967296.0
+double orc_explicit_average(const orc_locus* l, uint32_t allele, uint32_t i, uint32_t j) {     /* windows.rs:236-238 */
+    const uint64_t* cum = l->ew_cum[allele];
+    return (double)((cum[j] - cum[i]) / (uint64_t)(j - i)) / EW_SCALE;
+}
+/* ContigInfo::read_end_weight — windows.rs:493-503: the largest of the values at the middle of the read end and half a window
+ * to either side (weights.len() counts the entry finish() appends) */
+double orc_read_end_weight(const orc_locus* l, uint32_t allele, uint32_t middle) {
+    if (middle == LCTY_NONE_U32) return 0.0;
+    const double* val = l->ew_val[allele];
+    const uint32_t n = l->infos[allele].len + 1;
+    const uint32_t u = l->bg.window / 2;
+    const uint32_t lo = middle > u ? middle - u : 0;                       /* saturating_sub */
+    const uint32_t hi = middle + u < n - 1 ? middle + u : n - 1;
+    return fmax(fmax(val[middle], val[lo]), val[hi]);
+}
+
+static void free_explicit(orc_locus* l) {
+    if (l->ew_val) for (uint32_t a = 0; a < l->n_alleles; a++) free(l->ew_val[a]);
+    if (l->ew_cum) for (uint32_t a = 0; a < l->n_alleles; a++) free(l->ew_cum[a]);
+    free(l->ew_val); free(l->ew_cum);
+    l->ew_val = NULL; l->ew_cum = NULL; l->has_explicit = 0;
+}
+
+/* load_explicit_weights — windows.rs:257-317 (lines already split into fields) */
+int orc_locus_set_explicit_weights(orc_locus* l, uint32_t n, const uint32_t* allele, const uint32_t* start, const uint32_t* end,
+                                   const double* value) {
+    const uint32_t A = l->n_alleles;
+    free_explicit(l);
+    l->ew_val = (double**)calloc(A, sizeof(double*));
+    l->ew_cum = (uint64_t**)calloc(A, sizeof(uint64_t*));
+    uint32_t* filled = (uint32_t*)calloc(A, sizeof(uint32_t));
+    uint64_t* sum = (uint64_t*)calloc(A, sizeof(uint64_t));
+    int err = 0;
+    for (uint32_t a = 0; a < A; a++) {
+        l->ew_val[a] = (double*)malloc(sizeof(double) * ((size_t)l->infos[a].len + 1));
+        l->ew_cum[a] = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)l->infos[a].len + 1));
+    }
+    for (uint32_t t = 0; t < n && !err; t++) {
+        const uint32_t a = allele[t];
+        if (a >= A) continue;                                                /* unknown contig: line ignored (269-272) */
+        if (start[t] >= end[t] || end[t] > l->infos[a].len) { err = 2; break; }   /* InvalidInput, interv.rs:112-116 (an empty interval: Interval::new asserts) */
+        if (!(value[t] >= 0.0 && value[t] <= 1.0)) { err = 1; break; }       /* 285-288 */
+        if (filled[a] != start[t]) { err = 1; break; }                       /* "not fully covered", 291-295 */
+        const uint64_t inc = (uint64_t)(value[t] * EW_SCALE);                /* extend_by, 212-218 */
+        for (uint32_t i = start[t]; i < end[t]; i++) {
+            l->ew_val[a][i] = value[t];
+            l->ew_cum[a][i] = sum[a];
+            sum[a] += inc;
+        }
+        filled[a] = end[t];
+    }
+    for (uint32_t a = 0; a < A && !err; a++) {
+        if (filled[a] == 0 || filled[a] != l->infos[a].len) { err = 1; break; }   /* missing / different length, 305-313 */
+        l->ew_val[a][filled[a]] = l->ew_val[a][filled[a] - 1];              /* finish(), 221-224 */
+        l->ew_cum[a][filled[a]] = sum[a];
+    }
+    free(filled); free(sum);
+    if (err) { free_explicit(l); return err == 2 ? LCTY_ERR_INVALID_INPUT : LCTY_ERR_INVALID_DATA; }
+    l->has_explicit = 1;
+    return LCTY_OK;
+}
+
+/* ContigInfo::new — src/model/windows.rs:362-424 (explicit weights: orc_locus_set_explicit_weights) */
 static int contig_info_new(orc_locus* l, uint32_t a, const uint16_t* counts, size_t n_counts) {
     orc_contig_info* ci = &l->infos[a];
     const uint8_t* seq = l->seqs[a];
@@ -525,6 +589,7 @@ void orc_locus_free(orc_locus* l) {
     if (l->infos) for (uint32_t a = 0; a < l->n_alleles; a++) {
         free(l->infos[a].gc); free(l->infos[a].uniq_cnt); free(l->infos[a].compl_cnt);
     }
+    free_explicit(l);
     free(l->depth_lut); free(l->win_weight_inj); free(l->ci_off_inj); free(l->infos); free(l->seqs); free(l->seq_store); free(l->seq_off); free(l->ins_lut);
     set_free(&l->unique);
     free(l);
@@ -912,6 +977,19 @@ typedef struct {
     o_aln* kept; size_t cap;
 } kept_vec;
 
+/* ContigInfos::explicit_read_weight — model/windows.rs:683-693: the mean over the pair alignments of the larger of the two
+ * read-end weights; 1.0 without explicit weights */
+static double explicit_read_weight(const orc_locus* l, const lcty_pair_aln* pairs, size_t n) {
+    if (!l->has_explicit) return 1.0;
+    double s = 0.0;
+    for (size_t t = 0; t < n; t++) {
+        const double w1 = orc_read_end_weight(l, pairs[t].contig, pairs[t].mid1);
+        const double w2 = orc_read_end_weight(l, pairs[t].contig, pairs[t].mid2);
+        s += fmax(w1, w2);
+    }
+    return s / (double)n;
+}
+
 /* identify_paired_end_alignments — src/model/locs.rs:805-868 */
 static void identify_paired_end(const orc_locus* l, prelim* p, size_t max_alns, double read_weight,
                                 pair_vec* out, kept_vec* kv, double* weight_out, double* unmapped_out) {
@@ -940,7 +1018,7 @@ static void identify_paired_end(const orc_locus* l, prelim* p, size_t max_alns, 
     }
     if (i < k)
         identify_contig_pair_alns(l, alignments, i, MIN(j, k), k, out, max_alns, unm_ins_penalty, l->prm.prob_diff);
-    double weight = read_weight * 1.0;      /* explicit_read_weight == 1.0 without explicit weights, windows.rs:683-686 */
+    double weight = read_weight * explicit_read_weight(l, out->v + start_pairs, out->n - start_pairs);   /* locs.rs:860 */
     for (size_t t = start_pairs; t < out->n; t++) out->v[t].ln_prob *= weight;
     *weight_out = weight;
     *unmapped_out = weight * (2.0 * l->prm.unmapped_penalty + insert_penalty);
@@ -969,7 +1047,7 @@ static void identify_single_end(const orc_locus* l, prelim* p, size_t max_alns, 
             curr_saved++;
         }
     }
-    double weight = read_weight * 1.0;
+    double weight = read_weight * explicit_read_weight(l, out->v + start_pairs, out->n - start_pairs);   /* locs.rs:903 */
     for (size_t t = start_pairs; t < out->n; t++) out->v[t].ln_prob *= weight;
     *weight_out = weight;
     *unmapped_out = weight * l->prm.unmapped_penalty;

@@ -161,6 +161,13 @@ void     orc_solver_default(lcty_solver* s, int32_t kind);
 /* Solver::solve (solvers/mod.rs:57-72) -> ReadAssignment::likelihood() (assgn.rs:235-237);
  * assgn_out[n_reads] = chosen location per read; lik_parts = {aln_lik, depth_lik} */
 double   orc_solve(const orc_gt_alns* g, const lcty_solver* s, uint64_t seed, uint16_t* assgn_out, double* lik_parts);
+/* load_explicit_weights (model/windows.rs:257-317) without the text parsing: the lines of the BED file in file order as
+ * (allele, start, end, value); an allele index >= n_alleles is an unknown contig (line skipped, 269-272). Errors as upstream
+ * (value outside [0, 1]; an allele not covered from its start, missing, or of different length: ParsingError ->
+ * LCTY_ERR_INVALID_DATA; an interval beyond the end of its allele: LCTY_ERR_INVALID_INPUT, interv.rs:112-116).
+ * From then on window weights carry the window's average (409-413, 443) and read pairs their explicit_read_weight (683-693). */
+int      orc_locus_set_explicit_weights(orc_locus* l, uint32_t n, const uint32_t* allele, const uint32_t* start, const uint32_t* end,
+                                        const double* value);
 /* test hook: depth_lut[101*256] and/or win_weight (per position, alleles concatenated) replace the oracle's own tables */
 void     orc_locus_inject_tables(orc_locus* l, const double* depth_lut, const double* win_weight);
 /* likelihood of an explicit assignment (recalc_likelihood, assgn.rs:346-354) */

@@ -36,7 +36,13 @@ struct orc_locus {
     double uniq_mult, compl_mult;
     double* depth_lut;      /* [101][256] LinearCache<BayesCalc> values (distr_cache.rs:61-75) */
     double* win_weight_inj; uint64_t* ci_off_inj;   /* test hook: injected per-position window weights */
+    /* ExplicitWeights per allele (model/windows.rs:196-250): len + 1 entries (value, running fixed-point sum) after finish() */
+    int has_explicit;
+    double** ew_val; uint64_t** ew_cum;
 };
+/* ExplicitWeights::{at,average} and ContigInfo::read_end_weight (windows.rs:226-238, 493-503) */
+double orc_explicit_average(const orc_locus* l, uint32_t allele, uint32_t i, uint32_t j);
+double orc_read_end_weight(const orc_locus* l, uint32_t allele, uint32_t middle /* LCTY_NONE_U32 = None */);
 
 /* ---- alignment recovery (lcty_oracle_transfer.c) ---- */
 typedef struct { uint32_t op, len; } orc_citem;                    /* CigarItem, BAM operation codes */

@@ -76,7 +76,7 @@ double orc_weight_calc(double breakpoint, double power, double x) {
     return 1.0 / (1.0 + const_fct * pow((1.0 - x) / x, power));
 }
 
-/* ContigInfo::neighb_info — windows.rs:439-445 (explicit weight == 1) */
+/* ContigInfo::neighb_info — windows.rs:439-445 */
 double orc_window_weight(const orc_locus* l, uint32_t allele, uint32_t wstart, uint32_t* gc) {
     const orc_contig_info* ci = &l->infos[allele];
     const uint32_t i = wstart > l->left_padding ? wstart - l->left_padding : 0;
@@ -87,7 +87,9 @@ double orc_window_weight(const orc_locus* l, uint32_t allele, uint32_t wstart, u
     double w = 1.0;
     if (l->prm.kmers_weight_bp > 0.0) w = orc_weight_calc(l->prm.kmers_weight_bp, l->prm.kmers_weight_pow, uniq_frac);
     if (l->prm.compl_weight_bp > 0.0) w = w * orc_weight_calc(l->prm.compl_weight_bp, l->prm.compl_weight_pow, complexity);
-    return w * 1.0;
+    /* info.explicit_weight: 1.0 (windows.rs:336) or the average over the window itself (409-413) */
+    const double ew = l->has_explicit ? orc_explicit_average(l, allele, i + l->left_padding, i + l->left_padding + l->bg.window) : 1.0;
+    return w * ew;
 }
 
 /* WindowDistr::ln_prob — distr_cache.rs:34-39 with LinearCache (lincache.rs:41-48) */

@@ -90,6 +90,7 @@ def lib():
     sig("orc_counter_u64", U64, U64, U64)
     sig("orc_weight_calc", D, D, D, D)
     sig("orc_window_weight", D, VP, U32, U32, C.POINTER(U32))
+    sig("orc_locus_set_explicit_weights", C.c_int, VP, U32, VP, VP, VP, VP)
     sig("orc_depth_ln_prob", D, VP, U32, D, U32)
     sig("orc_gt_alns_new", VP, VP, VP, VP, U32)
     sig("orc_gt_alns_free", None, VP)
@@ -187,6 +188,13 @@ class OracleLocus:
 
     def n_unique_kmers(self):
         return int(lib().orc_locus_n_unique_kmers(self._h))
+
+    def set_explicit_weights(self, allele, start, end, value):
+        """load_explicit_weights (windows.rs:257-317) on parsed lines; returns the status code"""
+        al = np.ascontiguousarray(allele, dtype=np.uint32); st = np.ascontiguousarray(start, dtype=np.uint32)
+        en = np.ascontiguousarray(end, dtype=np.uint32); va = np.ascontiguousarray(value, dtype=np.float64)
+        return int(lib().orc_locus_set_explicit_weights(self._h, len(al), al.ctypes.data, st.ctypes.data, en.ctypes.data,
+                                                        va.ctypes.data))
 
     def contig_info(self, a):
         ln = int(self.seq_off[a + 1] - self.seq_off[a])

@@ -65,8 +65,58 @@ def complexity_counts(seq: bytes, k: int, w: int):
     return res
 
 
+class ParsingError(Exception):
+    pass
+
+
+class PyExplicitWeights:
+    """ExplicitWeights of one haplotype (model/windows.rs:196-250): (value, running sum in units of 2^-32) per base pair."""
+    SCALE = float(1 << 32)
+
+    def __init__(self):
+        self.weights = []
+        self.sum = 0
+
+    def extend_by(self, n, val):                        # 212-218
+        i = int(val * self.SCALE)
+        for _ in range(n):
+            self.weights.append((val, self.sum))
+            self.sum += i
+
+    def finish(self):                                   # 221-224
+        self.weights.append((self.weights[-1][0], self.sum))
+
+    def at(self, i):
+        return self.weights[i][0]
+
+    def average(self, i, j):                            # 236-238: integer division, then to f64
+        return float((self.weights[j][1] - self.weights[i][1]) // (j - i)) / self.SCALE
+
+
+def load_explicit_weights(lines, lengths):
+    """load_explicit_weights (windows.rs:257-317) on lines already split: (contig index or None if unknown, start, end, value)."""
+    ws = [PyExplicitWeights() for _ in lengths]
+    for contig, start, end, val in lines:
+        if contig is None or contig >= len(lengths):
+            continue                                    # unknown contig: ignored
+        if end > lengths[contig] or start >= end:
+            raise ValueError("interval out of range")   # InvalidInput (interv.rs:112-116)
+        if val < 0.0 or val > 1.0:
+            raise ParsingError("value must be in [0, 1]")
+        if len(ws[contig].weights) != start:
+            raise ParsingError("not fully covered")
+        ws[contig].extend_by(end - start, val)
+    for w, n in zip(ws, lengths):
+        if not w.weights:
+            raise ParsingError("haplotype missing")
+        if len(w.weights) != n:
+            raise ParsingError("not fully covered/has different length")
+        w.finish()
+    return ws
+
+
 class PyLocus:
-    """ContigSet + ContigInfos + UniqueKmers with the scalars of the path (no explicit weights)."""
+    """ContigSet + ContigInfos + UniqueKmers with the scalars of the path."""
 
     def __init__(self, alleles, counts, k, bg, params, insert_lnprob, insert_penalty, edit_thresholds):
         self.alleles = alleles                  # list[bytes]
@@ -94,6 +144,32 @@ class PyLocus:
         c = self.compl[contig]
         i = min(max(middle - self.half_neighb, 0), len(c) - 1)
         return c[i] * self.compl_mult
+
+    explicit = None                                     # list[PyExplicitWeights] once --reg-weights are given
+
+    def set_explicit_weights(self, lines):
+        self.explicit = load_explicit_weights(lines, [len(a) for a in self.alleles])
+
+    def window_explicit_weight(self, contig, i):        # windows.rs:409-413: mov_info[i].explicit_weight
+        if self.explicit is None:
+            return 1.0
+        start = i + (self.bg.neighb - self.bg.window) // 2
+        return self.explicit[contig].average(start, start + self.bg.window)
+
+    def read_end_weight(self, contig, middle):          # windows.rs:493-503
+        if middle is None or middle == cdefs.NONE_U32:
+            return 0.0
+        w = self.explicit[contig]
+        n, u = len(w.weights), self.bg.window // 2
+        return max(w.at(middle), w.at(max(middle - u, 0)), w.at(min(middle + u, n - 1)))
+
+    def explicit_read_weight(self, pairs):              # windows.rs:683-693; pairs: [ln_prob, contig, ix1, mid1, ix2, mid2]
+        if self.explicit is None:
+            return 1.0
+        s = 0.0
+        for pa in pairs:
+            s += max(self.read_end_weight(pa[1], pa[3]), self.read_end_weight(pa[1], pa[5]))
+        return s / len(pairs)
 
 
 def _decode_chunk(chunk):
@@ -350,6 +426,7 @@ def load(L, chunk):
             k = len(kept)
             if i < k:
                 pairs += _contig_pairs(L, kept, i, k if j is None else min(j, k), k, max_alns, unm_ins)
+            weight = weight * L.explicit_read_weight(pairs)            # locs.rs:860
             unm = weight * (2.0 * L.prm.unmapped_penalty + pen)
         else:
             tmp = sorted(prelim.alns, key=lambda a: (a["contig"], -a["ln_prob"], a["rec_ix"]))
@@ -361,6 +438,7 @@ def load(L, chunk):
                     pairs.append([a["ln_prob"], a["contig"], a["rec_ix"], (a["start"] + a["end"]) // 2,
                                   cdefs.NONE_U32, cdefs.NONE_U32])
                     saved += 1
+            weight = weight * L.explicit_read_weight(pairs)            # locs.rs:903
             unm = weight * L.prm.unmapped_penalty
         for pa in pairs:
             pa[0] = pa[0] * weight
