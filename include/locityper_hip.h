@@ -227,6 +227,20 @@ int32_t lcty_locus_depth_lut(const lcty_locus* locus, double* out /* [101*256] *
  * (sum over alleles of len - neighb + 1 values) */
 int32_t lcty_locus_window_weights(const lcty_locus* locus, double* out);
 
+/* Explicit region weights (`locityper genotype --reg-weights`): replaces load_explicit_weights (src/model/windows.rs:257-317)
+ * minus the text parsing — the lines of the BED file in file order as (allele index, start, end, value); an index >= n_alleles
+ * stands for a contig name the locus does not have (the line is skipped, 269-272). Errors as upstream: value outside [0, 1],
+ * an allele not covered from its first base on without gaps, missing, or covered to a different length -> LCTY_ERR_INVALID_DATA
+ * (Error::ParsingError); an interval beyond the end of its allele -> LCTY_ERR_INVALID_INPUT (seq/interv.rs:112-116).
+ * Effects, both on the device: every window weight gets the window's average as its last factor (ExplicitWeights::average,
+ * 236-238; ContigInfo::new 409-413; neighb_info 441-443), and lcty_score_reads multiplies a read pair's weight by
+ * ContigInfos::explicit_read_weight over its PairAlignments (683-693, read_end_weight 493-503; locs.rs:860, 903).
+ * A NaN value is rejected as out of range (upstream's `val < 0.0 || val > 1.0` lets it through and every weight turns NaN).
+ * Call it after lcty_locus_create and before the reads of the locus are scored; a second call replaces the first.
+ * (ContigInfos::weighted_aln_prob / average_read_weight, windows.rs:506-643, have no caller upstream and are not built.) */
+int32_t lcty_locus_set_explicit_weights(lcty_locus* locus, uint32_t n_lines, const uint32_t* allele, const uint32_t* start,
+                                        const uint32_t* end, const double* value);
+
 /* ---- reads: device-resident batch -----------------------------------------
  * Capacity is fixed at creation so a batch larger than host memory can be
  * appended chunk by chunk (each append is one set of H2D copies).             */

@@ -127,6 +127,14 @@ class Locus:
         check(lib().lcty_locus_insert_lnprob(self._h, len(sizes), sizes.ctypes.data, out.ctypes.data, C.byref(pen)))
         return out, pen.value
 
+    def set_explicit_weights(self, allele, start, end, value):
+        """Explicit region weights (--reg-weights; load_explicit_weights, windows.rs:257-317) as parsed BED lines in file order."""
+        al = np.ascontiguousarray(allele, dtype=np.uint32); st = np.ascontiguousarray(start, dtype=np.uint32)
+        en = np.ascontiguousarray(end, dtype=np.uint32); va = np.ascontiguousarray(value, dtype=np.float64)
+        if not (len(al) == len(st) == len(en) == len(va)):
+            raise ValueError("explicit weights: columns of different lengths")
+        check(lib().lcty_locus_set_explicit_weights(self._h, len(al), al.ctypes.data, st.ctypes.data, en.ctypes.data, va.ctypes.data))
+
     def window_weights(self):
         """ContigInfo::neighb_info weights of every moving-window position (alleles concatenated)."""
         n = sum(int(self.seq_off[a + 1] - self.seq_off[a]) - self.bg.neighb + 1 for a in range(self.n_alleles))

@@ -55,6 +55,10 @@ struct LocusView {
     double unmapped_penalty, prob_diff, min_weight, poor_compl, poor_compl_edit;
     uint32_t boundary;              // boundary_size - tweak (locs.rs:1099)
     uint32_t is_paired, short_reads, strict_subset;
+    // ExplicitWeights (src/model/windows.rs:196-250), null without --reg-weights: len + 1 values per allele
+    const double* ew_val;
+    const uint64_t* ew_off;         // [A+1]
+    uint32_t half_window;           // window_size / 2 (windows.rs:499)
 };
 
 struct ReadsView {

@@ -101,7 +101,23 @@ __global__ void window_weight_kernel(const uint32_t* __restrict__ uniq_cnt, cons
     double w = 1.0;
     if (kmers_bp > 0.0) w = weight_calc(kmers_bp, kmers_pow, static_cast<double>(uniq_cnt[i]) * uniq_mult);
     if (compl_bp > 0.0) w = w * weight_calc(compl_bp, compl_pow, static_cast<double>(compl_cnt[i]) * compl_mult);
-    out[i] = w * 1.0;      // explicit weight == 1 (no --weights file)
+    out[i] = w * 1.0;      // explicit weight == 1 (no --reg-weights file); explicit_window_kernel otherwise
+}
+
+// NeighbInfo::explicit_weight of every moving-window position (windows.rs:409-413): the average of the window's own bases,
+// taken from the running fixed-point sums as ExplicitWeights::average does (236-238: the INTEGER sum is divided by the
+// number of bases, then scaled by 2^-32) and multiplied into the window weight as its last factor (441-443).
+__global__ void explicit_window_kernel(const uint64_t* __restrict__ cum, const uint64_t* __restrict__ ew_off,
+                                       const uint32_t* __restrict__ ci_off, uint32_t left_padding, uint32_t window,
+                                       double* __restrict__ win_weight) {
+    const uint32_t a = blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t o = ci_off[a], n = ci_off[a + 1] - o;
+    if (i >= n) return;
+    const uint64_t* c = cum + ew_off[a];
+    const uint32_t start = i + left_padding;
+    const double avg = static_cast<double>((c[start + window] - c[start]) / static_cast<uint64_t>(window)) / 4294967296.0;
+    win_weight[o + i] = win_weight[o + i] * avg;
 }
 
 static uint64_t next_pow2(uint64_t x) {
@@ -183,6 +199,7 @@ LocusView lcty_locus::view() const {
     v.boundary = prm.boundary_size - static_cast<uint32_t>(prm.tweak);
     v.is_paired = bg.is_paired != 0; v.short_reads = bg.technology == LCTY_TECH_ILLUMINA;
     v.strict_subset = prm.strict_subset;
+    v.ew_val = has_explicit ? d_ew_val.p : nullptr; v.ew_off = d_ew_off.p; v.half_window = bg.window / 2;
     return v;
 }
 
@@ -422,6 +439,65 @@ int32_t lcty_locus_insert_lnprob(const lcty_locus* locus, uint32_t n, const uint
         for (uint32_t i = 0; i < n; i++)
             out[i] = sizes[i] < locus->ins_lut.size() ? locus->ins_lut[sizes[i]] : locus->ins.ln_pmf(sizes[i]);
         if (insert_penalty) *insert_penalty = locus->insert_penalty;
+    });
+}
+
+int32_t lcty_locus_set_explicit_weights(lcty_locus* locus, uint32_t n_lines, const uint32_t* allele, const uint32_t* start,
+                                        const uint32_t* end, const double* value) {
+    return guarded([&] {
+        if (!locus || (n_lines && (!allele || !start || !end || !value))) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        lcty_locus* L = locus;
+        const uint32_t A = L->n_alleles;
+        // load_explicit_weights (windows.rs:257-317) on parsed lines: per allele len + 1 (value, running sum) entries
+        std::vector<uint64_t> off(A + 1, 0);
+        for (uint32_t a = 0; a < A; a++) off[a + 1] = off[a] + L->allele_len[a] + 1;
+        std::vector<double> val(off[A]);
+        std::vector<uint64_t> cum(off[A]);
+        std::vector<uint32_t> filled(A, 0);
+        std::vector<uint64_t> sum(A, 0);
+        for (uint32_t t = 0; t < n_lines; t++) {
+            const uint32_t a = allele[t];
+            if (a >= A) continue;                                             // unknown contig: the line is skipped (269-272)
+            if (start[t] >= end[t] || end[t] > L->allele_len[a])
+                fail(LCTY_ERR_INVALID_INPUT, "explicit weights, line %u: interval %u-%u out of range on allele %u (length %u)",
+                     t, start[t], end[t], a, L->allele_len[a]);              // interv.rs:112-116
+            if (!(value[t] >= 0.0 && value[t] <= 1.0))
+                fail(LCTY_ERR_INVALID_DATA, "Failed to parse explicit weights (line %u): value must be in [0, 1]", t);
+            if (filled[a] != start[t])
+                fail(LCTY_ERR_INVALID_DATA, "Failed to parse explicit weights: haplotype %u not fully covered", a);
+            const uint64_t inc = static_cast<uint64_t>(value[t] * 4294967296.0);                      // extend_by, 212-218
+            double* v = val.data() + off[a];
+            uint64_t* c = cum.data() + off[a];
+            for (uint32_t i = start[t]; i < end[t]; i++) { v[i] = value[t]; c[i] = sum[a]; sum[a] += inc; }
+            filled[a] = end[t];
+        }
+        for (uint32_t a = 0; a < A; a++) {
+            if (filled[a] == 0) fail(LCTY_ERR_INVALID_DATA, "Failed to parse explicit weights: haplotype %u missing", a);
+            if (filled[a] != L->allele_len[a])
+                fail(LCTY_ERR_INVALID_DATA, "Failed to parse explicit weights: haplotype %u not fully covered/has different length", a);
+            val[off[a] + filled[a]] = val[off[a] + filled[a] - 1];                                    // finish(), 221-224
+            cum[off[a] + filled[a]] = sum[a];
+        }
+        L->ctx->activate();
+        hipStream_t s = L->ctx->stream;
+        LCTY_HIP(hipStreamSynchronize(s));                  // a kernel still reading the old tables
+        DevBuf<uint64_t> d_cum;
+        d_cum.alloc(off[A]); d_cum.upload(cum.data(), off[A], s);
+        L->d_ew_val.alloc(off[A]); L->d_ew_val.upload(val.data(), off[A], s);
+        L->d_ew_off.alloc(A + 1); L->d_ew_off.upload(off.data(), A + 1, s);
+        // window weights from scratch (a second call replaces the first), then the window averages as the last factor
+        const uint64_t total_pos = L->ci_off[A];
+        hipLaunchKernelGGL(window_weight_kernel, dim3(static_cast<uint32_t>((total_pos + 255) / 256)), dim3(256), 0, s,
+                           L->d_uniq_cnt.p, L->d_compl_cnt.p, total_pos, L->uniq_mult, L->compl_mult,
+                           L->prm.kmers_weight_bp, L->prm.kmers_weight_pow, L->prm.compl_weight_bp, L->prm.compl_weight_pow,
+                           L->d_win_weight.p);
+        uint32_t max_pos = 0;
+        for (uint32_t a = 0; a < A; a++) max_pos = std::max(max_pos, L->ci_off[a + 1] - L->ci_off[a]);
+        hipLaunchKernelGGL(explicit_window_kernel, dim3((max_pos + 255) / 256, A), dim3(256), 0, s, d_cum.p, L->d_ew_off.p,
+                           L->d_ci_off.p, L->left_padding, L->bg.window, L->d_win_weight.p);
+        LCTY_HIP(hipGetLastError());
+        LCTY_HIP(hipStreamSynchronize(s));                  // host vectors and d_cum go out of scope
+        L->has_explicit = true;
     });
 }
 

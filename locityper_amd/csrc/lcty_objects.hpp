@@ -45,6 +45,10 @@ struct lcty_locus {
     lcty::DevBuf<lcty::DepthNB> d_depth_nb;  // [101]
     lcty::DevBuf<uint32_t> d_n_windows, d_reg_start;   // [A]
     lcty::DevBuf<double> d_win_weight;       // per position: ContigInfo::neighb_info weight (windows.rs:439-445)
+    // ExplicitWeights (windows.rs:196-250) once lcty_locus_set_explicit_weights was called: len + 1 values per allele
+    lcty::DevBuf<double> d_ew_val;
+    lcty::DevBuf<uint64_t> d_ew_off;         // [A+1]
+    bool has_explicit = false;
     // alignment recovery (lcty_transfer.hip): allele sequences stay resident, haplotype-to-haplotype alignments + indices
     lcty::DevBuf<uint8_t> d_seqs;
     lcty::DevBuf<uint64_t> d_seq_off;

@@ -56,6 +56,10 @@ __device__ inline uint32_t wave_sum_u32(uint32_t v) {
     for (int o = WAVE / 2; o > 0; o >>= 1) v += static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), o));
     return v;
 }
+__device__ inline double wave_sum_f64(double v) {
+    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 // exclusive prefix sum across the wave; *total = wave sum
 __device__ inline uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t* total) {
     uint32_t x = v;
@@ -483,8 +487,21 @@ __device__ __forceinline__ void fast_emit(const Fast3& f, uint32_t cnt, double w
     }
 }
 
-__global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
-                                                              const uint32_t dbg) {
+// ContigInfo::read_end_weight (windows.rs:493-503): the largest explicit weight among the middle of the read end and half a
+// window to either side; ExplicitWeights holds len + 1 values per allele (finish(), 221-224). None -> 0.0.
+__device__ __forceinline__ double read_end_weight(const LocusView& L, uint32_t contig, uint32_t clen, uint32_t middle) {
+    if (middle == NONE32) return 0.0;
+    const double* val = L.ew_val + L.ew_off[contig];
+    const uint32_t u = L.half_window;
+    const uint32_t lo = middle > u ? middle - u : 0u;
+    const uint32_t hi = min(middle + u, clen);                  // n - 1 with n = len + 1
+    return fmax(fmax(val[middle], val[lo]), val[hi]);
+}
+
+// EW = explicit region weights are set (lcty_locus_set_explicit_weights): the pair's weight is multiplied by
+// ContigInfos::explicit_read_weight over its PairAlignments (windows.rs:683-693; locs.rs:860, 903) before it scales them.
+template <bool EW>
+__device__ __forceinline__ void score_reads_body(const LocusView& L, const ReadsView& R, const uint32_t max_recs, const uint32_t dbg) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t A = L.n_alleles;
     const uint32_t mr2 = (max_recs + 1) & ~1u;
@@ -735,7 +752,8 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
                     }
                 }
                 if (c < A) {
-                    mrow[c] = res.cnt ? res.best * weight : unmapped_prob;   // locs.rs:861-863, 621-629
+                    // locs.rs:861-863, 621-629 (EW: the weight is not final yet; scaled below, by the lane that wrote it)
+                    mrow[c] = res.cnt ? (EW ? res.best : res.best * weight) : unmapped_prob;
                     total_cnt += res.cnt;
                 }
             }
@@ -745,7 +763,7 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
             const bool edit_good = be0 <= thr0 && (!paired || be1 <= thr1);                   // best_edit_is_good, locs.rs:293-295
             if (!any_inb) { status = LCTY_READ_OUT_OF_BOUNDS; accepted = false; }
             else if (!edit_good) { status = LCTY_READ_POORLY_MAPPED; accepted = false; }
-            else status = weight >= L.min_weight ? LCTY_READ_GOOD : LCTY_READ_FEW_KMERS;     // locs.rs:1277-1285
+            else status = weight >= L.min_weight ? LCTY_READ_GOOD : LCTY_READ_FEW_KMERS;     // locs.rs:1277-1285 (EW: again below)
             __syncthreads();
 
             if (accepted) {
@@ -756,6 +774,8 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
                 pa_base = __shfl(pa_base, 0);
                 const bool room = pa_base + total_cnt <= R.pa_cap && dbg != 4;
                 // ---------------- pass 3b: emit PairAlignments, contig-ascending ----------------
+                const double emit_weight = EW ? 1.0 : weight;
+                double ew_sum = 0.0;
                 uint32_t run = 0;
                 for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
                     const uint32_t c = c0 + lane;
@@ -770,14 +790,39 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
                     if (room && cnt && !general) {
                         const uint32_t hw = head32[c];
                         const Fast3 f = fast_candidates(ins, rec, hw & 0xFFFFu, hw >> 16, bl0, bl1, unm_ins_penalty, paired);
-                        fast_emit(f, cnt, weight, c, out);
+                        fast_emit(f, cnt, emit_weight, c, out);
                     }
                     if (__ballot(room && general && cnt)) {
                         if (room && general && cnt) {
                             const uint32_t hw = head32[c];
                             const PairCtx pc{ins, rec, order + (hw >> 16), order + (hw & 0xFFFFu), kk1[c], kk2[c], bl0, bl1,
                                              unm_ins_penalty, paired};
-                            general_emit(pc, cnt, weight, c, out);
+                            general_emit(pc, cnt, emit_weight, c, out);
+                        }
+                    }
+                    if constexpr (EW) {
+                        // every lane reads back the entries it has just written itself (same thread: program order)
+                        if (room && cnt) {
+                            const uint32_t clen = alen[c];
+                            for (uint32_t e = 0; e < cnt; e++)
+                                ew_sum += fmax(read_end_weight(L, c, clen, out[e].mid1), read_end_weight(L, c, clen, out[e].mid2));
+                        }
+                    }
+                }
+                if constexpr (EW) {
+                    // explicit_read_weight = mean over all PairAlignments of the pair (windows.rs:688-692); the sum is taken
+                    // per lane and then across the wave (a different order of additions than upstream's serial loop)
+                    ew_sum = wave_sum_f64(ew_sum);
+                    weight = weight * (ew_sum / static_cast<double>(total_cnt));                       // locs.rs:860, 903
+                    unmapped_prob = paired ? weight * (2.0 * L.unmapped_penalty + L.insert_penalty) : weight * L.unmapped_penalty;
+                    status = weight >= L.min_weight ? LCTY_READ_GOOD : LCTY_READ_FEW_KMERS;           // GrouppedAlignments::weight()
+                    for (uint32_t c = lane; c < A; c += WAVE) {
+                        const uint32_t ix = R.pa_idx[p * A + c];
+                        const uint32_t cnt = ix >> 24;
+                        mrow[c] = cnt ? mrow[c] * weight : unmapped_prob;
+                        if (room) {
+                            PairAlnDev* out = R.pa + pa_base + (ix & 0xFFFFFFu);
+                            for (uint32_t e = 0; e < cnt; e++) out[e].ln_prob = out[e].ln_prob * weight;
                         }
                     }
                 }
@@ -800,6 +845,16 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L,
     }
 }
 
+__global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
+                                                              const uint32_t dbg) {
+    score_reads_body<false>(L, R, max_recs, dbg);
+}
+// the same with explicit region weights (--reg-weights)
+__global__ __launch_bounds__(WAVE, 3) void score_reads_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
+                                                                       const uint32_t dbg) {
+    score_reads_body<true>(L, R, max_recs, dbg);
+}
+
 static size_t score_lds_bytes(uint32_t max_recs, uint32_t A) {
     const size_t mr2 = (max_recs + 1) & ~1u;
     size_t b = static_cast<size_t>(max_recs) * sizeof(Rec16) + static_cast<size_t>(A) * 8 + 4;   // rec + head + alen + cursor
@@ -819,8 +874,10 @@ void launch_score_reads(lcty_reads* reads) {
         fail(LCTY_ERR_UNSUPPORTED,
              "a read pair with %u records on %u alleles needs %zu B of LDS (> %zu): not supported by this build",
              max_recs, L.n_alleles, lds, lds_max);
+    const bool explicit_weights = L.ew_val != nullptr;
+    auto kernel = explicit_weights ? score_reads_explicit_kernel : score_reads_kernel;
     if (lds > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_reads_kernel),
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
     const uint32_t per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(12, lds_max / lds)));
@@ -829,7 +886,7 @@ void launch_score_reads(lcty_reads* reads) {
     const uint32_t dbg = dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u;
     reads->d_pa_count.zero(ctx->stream);
     ctx->timed(LCTY_K_SCORE, [&] {
-        hipLaunchKernelGGL(score_reads_kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs, dbg);
+        hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs, dbg);
     });
     LCTY_HIP(hipGetLastError());
 }
