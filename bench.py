@@ -55,6 +55,10 @@ def parse_args():
                     help="one locus over all ranks: every rank scores and prefilters a contiguous shard of the read pairs, the run_filter "
                          "scores are SUM-all-reduced on the devices (RCCL), truncate_ixs runs everywhere; implies --no-solve (the chains "
                          "need every read) and strong scaling. Not the default: the driver's runs are one locus per rank")
+    ap.add_argument("--shard-chains", action="store_true",
+                    help="one locus over all ranks, whole path: every rank scores and prefilters all reads of the locus (replicated), the "
+                         "(genotype, attempt) chains of both solver stages are dealt to the ranks and their likelihoods all-gathered on the "
+                         "devices (RCCL; lcty_solve_stage_sharded, SURVEY 8e level 3); strong scaling. Not the default either")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="extra measurement outside the timed region: this many loci in flight on one GPU, each on its own context / "
                          "stream (the annealing stage leaves most of the GPU idle); 0 or 1 = skip")
@@ -91,10 +95,11 @@ def main():
     comm = None
     first_pair = 0
     total_pairs = args.pairs
-    if args.shard_reads:
+    one_locus = args.shard_reads or args.shard_chains
+    if one_locus:
         os.environ.pop("NCCL_DEBUG", None)         # RCCL logs to stdout, which carries the one JSON line
         os.environ["NCCL_DEBUG_FILE"] = os.devnull
-        args.no_solve = True
+        args.no_solve = args.shard_reads
         args.pipeline = args.recovery_sample = args.recruit_sample = 0
         uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
         if dist is not None:
@@ -103,13 +108,14 @@ def main():
             dist.broadcast(t_uid, src=0)
             uid = bytes(t_uid.tolist())
         comm = api.Comm(ctx, world, rank, uid)
+    if args.shard_reads:
         per = (args.pairs + world - 1) // world
         first_pair = min(rank * per, args.pairs)
         args.pairs = min(first_pair + per, total_pairs) - first_pair          # this rank's shard
 
     # ---- synthetic locus + reads (seed + locus index) -> HBM ----
     t0 = time.time()
-    L = synth.SynthLocus(args.alleles, total_pairs, seed=synth.SEED + (0 if args.shard_reads else rank))
+    L = synth.SynthLocus(args.alleles, total_pairs, seed=synth.SEED + (0 if one_locus else rank))
     params = api.resolve_params(api.default_params(), L.bg)
     t1 = time.time()
     loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
@@ -154,7 +160,7 @@ def main():
         t0s = time.perf_counter()
         aa.score()
         aa.prefilter_async()
-        if comm is not None and aa is aa_main:
+        if args.shard_reads and aa is aa_main:
             comm.prefilter_allreduce(aa)                                      # read shards -> scores of the whole batch on every rank
         scores = aa.prefilter_scores()
         keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, 1)   # in_size of stage 1 (solve.rs:216-221)
@@ -165,15 +171,17 @@ def main():
         n = len(gts)
         mean, var, att = np.full(n, np.nan), np.full(n, np.nan), np.zeros(n, dtype=np.uint32)
         ixs = keep
+        # --shard-chains: the same call on every rank, the chains dealt to the ranks inside the library
+        run_stage = comm.solve_stage if (args.shard_chains and aa is aa_main) else api.solve_stage
         ts = time.perf_counter()
         if 20 < len(ixs):
-            m, v, _ = api.solve_stage(aa, gts[ixs], greedy, 1, api.chain_seeds(1000 + it, len(ixs)))
+            m, v, _ = run_stage(aa, gts[ixs], greedy, 1, api.chain_seeds(1000 + it, len(ixs)))
             mean[ixs], var[ixs], att[ixs] = m, v, 1
             solved["greedy_chains"] += len(ixs)
             solved["greedy_iterations"] += api.solve_stats(aa)[1]
             ixs = api.discard_improbable(mean, var, att, ixs, params.prob_thresh, 20, 1)
         tm = time.perf_counter()
-        m, v, _ = api.solve_stage(aa, gts[ixs], anneal, 20, api.chain_seeds(2000 + it, 20 * len(ixs)))
+        m, v, _ = run_stage(aa, gts[ixs], anneal, 20, api.chain_seeds(2000 + it, 20 * len(ixs)))
         mean[ixs], var[ixs], att[ixs] = m, v, 20
         solved["anneal_chains"] += 20 * len(ixs)
         solved["anneal_moves"] += api.solve_stats(aa)[1]
@@ -216,7 +224,7 @@ def main():
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
-    reads_per_s = (total_pairs if args.shard_reads else world * args.pairs) * args.steps / elapsed
+    reads_per_s = (total_pairs if one_locus else world * args.pairs) * args.steps / elapsed
     score_ms = ms_score / max(n_score, 1)
     pref_ms = ms_pref / max(n_pref, 1)
     alg_bytes = survey_bytes_per_pair(A) * args.pairs
@@ -233,15 +241,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if args.shard_reads else "weak",
+        "scaling": "strong" if one_locus else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.pairs} synthetic 150 bp PE read pairs x {A} alleles, 1 locus per GPU, k=25 "
                                "(BASELINE.json configs[1])",
                    "read_pairs": args.pairs, "alleles": A, "genotypes": G, "k": 25,
-                   "records": tot_recs, "cigar_words": tot_cigar, "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"loci x{world}")},
-        "reads_scored_per_s": (total_pairs if args.shard_reads else world * args.pairs) * args.steps / max(stage_s["score_prefilter"], 1e-9),
+                   "records": tot_recs, "cigar_words": tot_cigar, "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
+        "reads_scored_per_s": (total_pairs if args.shard_reads else args.pairs if args.shard_chains else world * args.pairs) * args.steps / max(stage_s["score_prefilter"], 1e-9),
         "genotypes_prefiltered_per_s": world * G * args.steps / max(stage_s["score_prefilter"], 1e-9),
         "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3),
         "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms, "solve_loop_per_step": ms_solve / args.steps,

@@ -307,6 +307,14 @@ int32_t lcty_comm_unique_id(uint8_t* id);
 int32_t lcty_comm_create(lcty_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* id, lcty_comm** out);
 void    lcty_comm_destroy(lcty_comm* comm);
 int32_t lcty_prefilter_allreduce(lcty_reads* reads, lcty_comm* comm);
+/* One solver stage with its (genotype, attempt) chains dealt to the ranks of `comm` (SURVEY.md 8e level 3; the reference deals
+ * the genotypes of a stage to its worker threads, solve.rs:1052-1062): every rank passes the SAME arguments and holds the same
+ * scored reads; rank r runs the r-th contiguous block of the genotype list, the per-chain likelihoods are all-gathered on the
+ * devices (RCCL) and every rank returns mean / variance / likelihoods of ALL n_gt genotypes — bit for bit what lcty_solve_stage
+ * returns on one GPU, for any number of ranks. */
+int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                                 const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                                 double* lik_mean, double* lik_var, double* liks_out /* [n_gt][attempts] or NULL */);
 
 /* ---- alignment recovery (AllAlignments::load with opt_hap_alns = Some; src/seq/transfer.rs, src/seq/cigar.rs:1085-1384,
  * src/seq/wfa.rs) ------------------------------------------------------------------------------------------------------

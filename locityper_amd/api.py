@@ -522,6 +522,20 @@ class Comm:
     def prefilter_allreduce(self, aa):
         check(lib().lcty_prefilter_allreduce(aa._h, self._h))
 
+    def solve_stage(self, aa, genotypes, solver, attempts, seeds, priors=None):
+        """solve_stage with the chains dealt to the ranks (lcty_solve_stage_sharded): same arguments on every rank, the results
+        of all genotypes on every rank."""
+        genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+        n, ploidy = genotypes.shape
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert len(seeds) == n * attempts
+        mean, var, liks = np.zeros(n), np.zeros(n), np.zeros((n, attempts))
+        pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+        check(lib().lcty_solve_stage_sharded(aa._h, self._h, genotypes.ctypes.data, n, ploidy, None if pri is None else pri.ctypes.data,
+                                             C.byref(solver), attempts, seeds.ctypes.data, mean.ctypes.data, var.ctypes.data,
+                                             liks.ctypes.data))
+        return mean, var, liks
+
     def close(self):
         if self._h:
             lib().lcty_comm_destroy(self._h)

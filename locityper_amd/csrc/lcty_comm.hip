@@ -1,10 +1,13 @@
-// lcty_comm.hip — the one exchange step of the path when a locus' reads are sharded over GPUs (SURVEY.md §8e level 2):
+// lcty_comm.hip — the exchange steps of the path over several GPUs. Level 2, the one exchange step of the path when a locus' reads are sharded over GPUs (SURVEY.md §8e level 2):
 // run_filter's score of a genotype is a sum over reads (src/solvers/solve.rs:105-119), so every rank prefilters its shard and the
 // G-long f64 score vectors are SUM-all-reduced — RCCL over xGMI, on the device buffers, from C++. One process per GPU; the host
 // launcher (torch.distributed / MPI / anything) only has to hand rank 0's 128-byte id to the other ranks.
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <limits>
 #include <memory>
+#include <vector>
 
 #include "lcty_objects.hpp"
 
@@ -66,6 +69,47 @@ int32_t lcty_prefilter_allreduce(lcty_reads* reads, lcty_comm* comm) {
         // in place, on the stream the prefilter kernels ran on: ordered behind them without a host synchronisation
         LCTY_NCCL(ncclAllReduce(reads->d_scores.p, reads->d_scores.p, reads->n_scores, ncclDouble, ncclSum, comm->comm, s));
         LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// SURVEY.md §8e level 3: the (genotype, attempt) chains of a stage are independent units — the reference deals the genotypes of a
+// stage to its worker threads (solve.rs:1052-1062); here a contiguous block of the stage's genotype list goes to every rank, each
+// rank runs its block on its own GPU (the scored reads are replicated), and the per-chain likelihoods are all-gathered on the
+// devices (RCCL over xGMI); mean and variance are then taken by every rank from the same numbers with the same code, so the
+// result does not depend on the number of ranks and equals lcty_solve_stage bit for bit (a chain's random stream is its seed).
+int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                                 const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                                 double* lik_mean, double* lik_var, double* liks_out) {
+    return guarded([&] {
+        if (!reads || !comm || !genotypes || !solver || !chain_seeds || !lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (reads->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
+        if (attempts == 0 || ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "attempts and ploidy must be positive");
+        const uint64_t n_ranks = static_cast<uint64_t>(comm->n_ranks), rank = static_cast<uint64_t>(comm->rank);
+        const uint64_t per = (n_gt + n_ranks - 1) / n_ranks;                 // block partition of the stage's genotype list
+        const uint64_t lo = std::min(rank * per, n_gt), hi = std::min(lo + per, n_gt);
+        std::vector<double> local(std::max<uint64_t>(per * attempts, 1), std::numeric_limits<double>::quiet_NaN());
+        if (hi > lo) {
+            std::vector<double> m(hi - lo), v(hi - lo);
+            const int32_t rc = lcty_solve_stage(reads, genotypes + lo * ploidy, hi - lo, ploidy, priors ? priors + lo : nullptr, solver,
+                                                attempts, chain_seeds + lo * attempts, m.data(), v.data(), local.data());
+            if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
+        }
+        reads->ctx->activate();
+        hipStream_t s = reads->ctx->stream;
+        DevBuf<double> d_send, d_recv;
+        d_send.alloc(std::max<uint64_t>(per * attempts, 1));
+        d_recv.alloc(std::max<uint64_t>(per * attempts, 1) * n_ranks);
+        d_send.upload(local.data(), per * attempts, s);
+        if (per) LCTY_NCCL(ncclAllGather(d_send.p, d_recv.p, per * attempts, ncclDouble, comm->comm, s));
+        std::vector<double> all(std::max<uint64_t>(per * attempts, 1) * n_ranks);
+        d_recv.download(all.data(), per * attempts * n_ranks, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        // rank r's block starts at r * per in the gathered array and at genotype r * per in the list: the same index
+        for (uint64_t g = 0; g < n_gt; g++) {
+            const double* l = all.data() + g * attempts;
+            math::mean_variance_or_nan(l, attempts, &lik_mean[g], &lik_var[g]);
+            if (liks_out) memcpy(liks_out + g * attempts, l, sizeof(double) * attempts);
+        }
     });
 }
 

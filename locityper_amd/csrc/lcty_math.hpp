@@ -161,5 +161,19 @@ struct DepthDistr {
     }
 };
 
+// F64Ext::mean_variance_or_nan (src/ext/vec.rs:74-116): iter().sum() / n, variance over n - 1 (NaN for one value)
+inline void mean_variance_or_nan(const double* l, uint32_t n, double* mean_out, double* var_out) {
+    double sum = -0.0;
+    for (uint32_t a = 0; a < n; a++) sum += l[a];
+    const double mean = sum / static_cast<double>(n);
+    double var = std::numeric_limits<double>::quiet_NaN();
+    if (n > 1) {
+        double acc = 0.0;
+        for (uint32_t a = 0; a < n; a++) { const double d = l[a] - mean; acc += d * d; }
+        var = acc / static_cast<double>(n - 1);
+    }
+    *mean_out = mean; *var_out = var;
+}
+
 }  // namespace math
 }  // namespace lcty

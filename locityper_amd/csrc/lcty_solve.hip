@@ -1336,18 +1336,8 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
         StageRunner R(reads, genotypes, n_gt, ploidy, solver, attempts, chain_seeds);
         R.run(genotypes, priors, chain_seeds, [&](uint64_t g0, uint64_t ng, const double* liks) {
             for (uint64_t g = 0; g < ng; g++) {
-                // mean_variance_or_nan (src/ext/vec.rs:74-116)
                 const double* l = liks + g * attempts;
-                double sum = -0.0;
-                for (uint32_t a = 0; a < attempts; a++) sum += l[a];
-                const double mean = sum / static_cast<double>(attempts);
-                double var = std::numeric_limits<double>::quiet_NaN();
-                if (attempts > 1) {
-                    double acc = 0.0;
-                    for (uint32_t a = 0; a < attempts; a++) { const double d = l[a] - mean; acc += d * d; }
-                    var = acc / static_cast<double>(attempts - 1);
-                }
-                lik_mean[g0 + g] = mean; lik_var[g0 + g] = var;
+                math::mean_variance_or_nan(l, attempts, &lik_mean[g0 + g], &lik_var[g0 + g]);
                 if (liks_out) memcpy(liks_out + (g0 + g) * attempts, l, sizeof(double) * attempts);
             }
         });

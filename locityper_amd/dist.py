@@ -1,10 +1,13 @@
 """Multi-GPU plumbing: one process per GPU (torch.distributed launcher / env contract).
 
-The path shards at two levels:
+The path shards at three levels:
   * loci are independent (command/genotype.rs:1331-1351): round-robin over ranks, no collective;
   * inside one locus reads contribute additively to run_filter scores (solvers/solve.rs:105-119):
     read shards -> one SUM all-reduce of the G-long f64 score vector — on the devices through RCCL (make_comm +
     Comm.prefilter_allreduce, the library's lcty_prefilter_allreduce), or of host arrays through the process group.
+  * the (genotype, attempt) chains of a solver stage are independent (solvers/solve.rs:1052-1062 deals them to threads):
+    contiguous blocks of the stage's genotype list per rank, all-gather of the per-chain likelihoods — on the devices
+    through the library's lcty_solve_stage_sharded (Comm.solve_stage), or of host arrays through the process group.
 torch.distributed is plumbing only (rendezvous, barrier, small host-staged reductions); it is
 imported lazily and only when WORLD_SIZE > 1, after liblocityper_hip.so has been loaded.
 """
@@ -74,6 +77,29 @@ def allreduce_sum_f64(arr):
     t = torch.from_numpy(arr.copy())
     _pg.all_reduce(t, op=_pg.ReduceOp.SUM)
     return t.numpy()
+
+
+def chain_block(n_genotypes, rank, world):
+    """Block [lo, hi) of a stage's genotype list that rank `rank` solves, and the block size every rank pads to
+    (the partition lcty_solve_stage_sharded uses)."""
+    per = (n_genotypes + world - 1) // world
+    lo = min(rank * per, n_genotypes)
+    return lo, min(lo + per, n_genotypes), per
+
+
+def allgather_chain_liks(local, n_genotypes, attempts):
+    """All-gather of the per-chain likelihoods of every rank's block -> [n_genotypes][attempts] on every rank."""
+    rank, _, world = env()
+    lo, hi, per = chain_block(n_genotypes, rank, world)
+    buf = np.full((per, attempts), np.nan)
+    buf[:hi - lo] = np.asarray(local, dtype=np.float64).reshape(hi - lo, attempts)
+    if _pg is None:
+        return buf[:n_genotypes]
+    import torch
+    mine = torch.from_numpy(buf)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    _pg.all_gather(parts, mine)
+    return torch.cat(parts).numpy()[:n_genotypes]
 
 
 def make_comm(ctx):

@@ -29,8 +29,20 @@ lo, hi = dist.read_shard(200, rank, world)
 part = O.run_filter(ol.load(ch.slice(lo, hi)).best_aln_matrix(), gts)
 tot = dist.allreduce_sum_f64(part)
 full = O.run_filter(ol.load(ch).best_aln_matrix(), gts)
+# level 3: the chains of a stage dealt to the ranks in contiguous genotype blocks, likelihoods all-gathered
+oa = ol.load(ch)
+sv = O.default_solver(1)
+sv.anneal_steps, sv.plato_size = 300, 200
+gsub = gts[:7]                                           # 7 genotypes over 2 ranks: blocks of 4 and 3
+seeds = np.arange(3 * len(gsub), dtype=np.uint64) * 7919 + 11
+clo, chi, per = dist.chain_block(len(gsub), rank, world)
+local = O.solve_stage(ol, oa, gsub[clo:chi], sv, 3, seeds[3 * clo:3 * chi])[2]
+liks = dist.allgather_chain_liks(local, len(gsub), 3)
+whole = O.solve_stage(ol, oa, gsub, sv, 3, seeds)
 dist.barrier()
-res = dist.gather_objects({"rank": rank, "loci": loci, "shard": [lo, hi]})
+res = dist.gather_objects({"rank": rank, "loci": loci, "shard": [lo, hi], "block": [clo, chi, per],
+                            "chains_equal": bool(np.array_equal(liks, whole[2])),
+                            "mean_equal": bool(np.array_equal(liks.mean(axis=1), whole[2].mean(axis=1)))})
 if rank == 0:
     print(json.dumps({"t": t, "res": res, "maxrel": float(np.abs(tot - full).max() / np.abs(full).max()),
                       "argmax": [int(np.argmax(tot)), int(np.argmax(full))]}))
@@ -60,3 +72,6 @@ def test_two_rank_gloo(tmp_path):
     assert sorted(out["res"][0]["loci"] + out["res"][1]["loci"]) == [0, 1, 2, 3, 4]
     assert out["res"][0]["shard"] == [0, 100] and out["res"][1]["shard"] == [100, 200]
     assert out["maxrel"] < 1e-13 and out["argmax"][0] == out["argmax"][1]
+    # chains of a stage in blocks of ceil(7 / 2): the gathered likelihoods are the single-process ones, bit for bit
+    assert out["res"][0]["block"] == [0, 4, 4] and out["res"][1]["block"] == [4, 7, 4]
+    assert all(r["chains_equal"] and r["mean_equal"] for r in out["res"])

@@ -743,3 +743,37 @@ def test_read_sharded_prefilter_allreduce(gpu_ctx):
     with pytest.raises(_lib.LocityperError):
         api.Comm(other, 1, 0, api.comm_unique_id()).prefilter_allreduce(whole)      # communicator of another context
     comm.close()
+
+
+@pytest.mark.gpu
+def test_chain_sharded_stage(gpu_ctx):
+    """SURVEY 8e level 3: the chains of a stage dealt to the ranks in contiguous blocks of the genotype list, likelihoods all-gathered
+    on the devices. With the one GPU of this box: the library call with a communicator of one rank returns what lcty_solve_stage
+    returns, bit for bit; and the blocks two ranks would solve, run one after the other and laid side by side as the all-gather
+    lays them, are the single-call likelihoods (a chain depends on nothing but its seed)."""
+    from locityper_amd import dist
+    L = synth.SynthLocus(12, 3000, seed=31, base_len=12000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    aa = api.AllAlignments.load(loc, L.reads(0, 3000))
+    gts = api.generate_genotypes(12, 2)[:23]
+    pri = -np.arange(len(gts), dtype=np.float64)
+    comm = api.Comm(gpu_ctx, 1, 0, api.comm_unique_id())
+    for kind, attempts in ((cdefs.SOLVER_GREEDY, 1), (cdefs.SOLVER_ANNEAL, 3)):
+        sv = api.default_solver(kind)
+        if kind == cdefs.SOLVER_ANNEAL:
+            sv.anneal_steps, sv.plato_size = 1500, 1000
+        seeds = api.chain_seeds(9, attempts * len(gts))
+        m1, v1, l1 = api.solve_stage(aa, gts, sv, attempts, seeds, priors=pri)
+        m2, v2, l2 = comm.solve_stage(aa, gts, sv, attempts, seeds, priors=pri)
+        assert np.array_equal(m1, m2) and np.array_equal(v1, v2, equal_nan=True) and np.array_equal(l1, l2)
+        for world in (2, 3, 8, 32):                     # 32 ranks > 23 genotypes: the last ranks have empty blocks
+            gathered = np.full((0, attempts), 0.0)
+            for r in range(world):
+                lo, hi, per = dist.chain_block(len(gts), r, world)
+                block = np.full((per, attempts), np.nan)
+                if hi > lo:
+                    block[:hi - lo] = api.solve_stage(aa, gts[lo:hi], sv, attempts, seeds[attempts * lo:attempts * hi], priors=pri[lo:hi])[2]
+                gathered = np.concatenate([gathered, block])
+            assert np.array_equal(gathered[:len(gts)], l1)
+    comm.close()
