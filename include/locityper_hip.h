@@ -246,6 +246,15 @@ int32_t lcty_locus_set_explicit_weights(lcty_locus* locus, uint32_t n_lines, con
  * appended chunk by chunk (each append is one set of H2D copies).             */
 int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_bases,
                           uint64_t cap_recs, uint64_t cap_cigar, lcty_reads** out);
+/* A batch larger than HBM (1 M ONT reads x 256 alleles carry 600 GB of CIGAR words): the records, CIGAR words and bases of ONE
+ * chunk are on the device at a time, the products of every scored chunk stay (status, weights, k-mer counts, matrix rows,
+ * PairAlignments: about 9 KB per read at 256 alleles). Use:  create_streaming; { lcty_reads_append (one or more chunks that fit
+ * the chunk capacities); lcty_score_reads } ...; then prefilter / solver stages / read-backs as for any batch — they see all
+ * pairs appended so far, in order, and the results are those of one resident batch (AllAlignments::load is a loop over reads,
+ * locs.rs:1119-1185). An append after a score drops the records of the scored chunk. cap_pair_alns = room for that many
+ * PairAlignments in total (0: three per (pair, allele)); overflow fails loudly. lcty_recover_alignments: LCTY_ERR_UNSUPPORTED. */
+int32_t lcty_reads_create_streaming(lcty_locus* locus, uint64_t cap_pairs, uint64_t chunk_pairs, uint64_t chunk_bases,
+                                    uint64_t chunk_recs, uint64_t chunk_cigar, uint64_t cap_pair_alns, lcty_reads** out);
 int32_t lcty_reads_append(lcty_reads* reads, const lcty_reads_host* chunk);
 void    lcty_reads_destroy(lcty_reads* reads);
 int32_t lcty_reads_n_pairs(const lcty_reads* reads, uint64_t* out);

@@ -151,11 +151,29 @@ class Locus:
 class AllAlignments:
     """Device-resident batch of read pairs and the products of AllAlignments::load."""
 
-    def __init__(self, locus, cap_pairs, cap_bases, cap_recs, cap_cigar):
+    def __init__(self, locus, cap_pairs, cap_bases, cap_recs, cap_cigar, streaming_chunk_pairs=None, cap_pair_alns=0):
+        """streaming_chunk_pairs: a streaming batch (lcty_reads_create_streaming) — cap_bases / cap_recs / cap_cigar are then the
+        capacities of ONE chunk, cap_pairs that of the whole batch; append + score chunk after chunk."""
         self.locus = locus
         self._h = VP()
-        check(lib().lcty_reads_create(locus._h, cap_pairs, cap_bases, cap_recs, cap_cigar, C.byref(self._h)))
+        if streaming_chunk_pairs is None:
+            check(lib().lcty_reads_create(locus._h, cap_pairs, cap_bases, cap_recs, cap_cigar, C.byref(self._h)))
+        else:
+            check(lib().lcty_reads_create_streaming(locus._h, cap_pairs, streaming_chunk_pairs, cap_bases, cap_recs, cap_cigar,
+                                                    cap_pair_alns, C.byref(self._h)))
         self._scored = False
+
+    @classmethod
+    def load_streaming(cls, locus, chunks, cap_pair_alns=0):
+        """AllAlignments::load of a batch whose records do not have to fit the device together: one chunk resident at a time."""
+        chunks = list(chunks)
+        self = cls(locus, sum(c.n_pairs for c in chunks), (max(c.n_bases for c in chunks) + 31) // 32 * 32,
+                   max(len(c.recs) for c in chunks), max(len(c.cigar) for c in chunks),
+                   streaming_chunk_pairs=max(c.n_pairs for c in chunks), cap_pair_alns=cap_pair_alns)
+        for c in chunks:
+            self.append(c)
+            self.score()
+        return self
 
     @classmethod
     def load(cls, locus, chunks):

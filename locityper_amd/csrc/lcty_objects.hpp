@@ -77,6 +77,12 @@ struct lcty_reads {
     uint32_t max_cigar_per_rec = 0;
     uint64_t recover_level_pairs[3] = {0, 0, 0};   // pairs the transfer kernel took at each scratch level (lcty_recover_stats)
     bool scored = false;
+    // streaming batch (lcty_reads_create_streaming): the record / CIGAR / base buffers hold one chunk at a time, the products
+    // of every scored chunk stay. Pairs before raw_first have been scored and their raw data dropped; the per-pair raw arrays
+    // (mate_len, mate_off, aln_off, cigar_off, pair_meta) are indexed relative to raw_first. raw_first == 0 otherwise.
+    bool streaming = false;
+    uint64_t raw_first = 0, cap_raw_pairs = 0;
+    unsigned long long pa_at_raw_first = 0;   // arena cursor when the current chunk started (a chunk can be scored again)
 
     lcty::DevBuf<uint32_t> d_mate_len;
     lcty::DevBuf<uint64_t> d_mate_off;

@@ -50,17 +50,21 @@ void compact_matrix(lcty_reads* reads, double* d_out, uint64_t n_good) {
 
 }  // namespace lcty
 
+// The pairs whose records are on the device: all of them, or the current chunk of a streaming batch — then the per-pair
+// products are addressed from raw_first on, the arena and its cursor are the batch's (pa_off stays absolute).
 ReadsView lcty_reads::view() const {
     ReadsView v{};
-    v.n_pairs = n_pairs;
+    const uint64_t f = raw_first, A = locus->n_alleles;
+    v.n_pairs = n_pairs - f;
     v.mate_len = d_mate_len.p; v.mate_off = d_mate_off.p; v.bases2 = d_bases2.p; v.nmask = d_nmask.p;
     v.aln_off = d_aln_off.p; v.recs = d_recs.p; v.cigar_off = d_cigar_off.p; v.cigar = d_cigar.p;
     v.pair_meta = d_pair_meta.p;
-    v.status = d_status.p; v.weight = d_weight.p; v.unmapped_prob = d_unmapped.p; v.uniq_kmers = d_uniq.p;
-    v.matrix = d_matrix.p;
-    v.pa = d_pa.p; v.pa_cap = d_pa.n; v.pa_count = d_pa_count.p; v.pa_off = d_pa_off.p; v.pa_cnt = d_pa_cnt.p; v.pa_idx = d_pa_idx.p;
+    v.status = d_status.p + f; v.weight = d_weight.p + f; v.unmapped_prob = d_unmapped.p + f; v.uniq_kmers = d_uniq.p + 2 * f;
+    v.matrix = d_matrix.p + f * A;
+    v.pa = d_pa.p; v.pa_cap = d_pa.n; v.pa_count = d_pa_count.p; v.pa_off = d_pa_off.p + f; v.pa_cnt = d_pa_cnt.p + f;
+    v.pa_idx = d_pa_idx.p + f * A;
     v.err_flag = d_err.p;
-    v.recover_w = d_recover_w.p;
+    v.recover_w = d_recover_w.p + f;
     return v;
 }
 
@@ -92,8 +96,9 @@ void lcty_reads::check_device_error() {
 
 extern "C" {
 
-int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_bases, uint64_t cap_recs,
-                          uint64_t cap_cigar, lcty_reads** out) {
+// cap_pairs: pairs of the whole batch (products); raw_pairs / cap_bases / cap_recs / cap_cigar: what is resident at a time
+static int32_t create_reads(lcty_locus* locus, uint64_t cap_pairs, uint64_t raw_pairs, uint64_t cap_bases, uint64_t cap_recs,
+                            uint64_t cap_cigar, uint64_t cap_pair_alns, bool streaming, lcty_reads** out) {
     return guarded([&] {
         if (!locus || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         if (cap_bases % 32) fail(LCTY_ERR_INVALID_INPUT, "cap_bases must be a multiple of 32");
@@ -102,16 +107,17 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
         auto R = std::unique_ptr<lcty_reads>(new lcty_reads());
         R->locus = locus; R->ctx = ctx;
         R->cap_pairs = cap_pairs; R->cap_bases = cap_bases; R->cap_recs = cap_recs; R->cap_cigar = cap_cigar;
+        R->streaming = streaming; R->cap_raw_pairs = raw_pairs;
         const uint32_t A = locus->n_alleles;
-        R->d_mate_len.alloc(2 * cap_pairs);
-        R->d_mate_off.alloc(2 * cap_pairs + 1);
+        R->d_mate_len.alloc(2 * raw_pairs);
+        R->d_mate_off.alloc(2 * raw_pairs + 1);
         R->d_bases2.alloc(cap_bases / 16 + 4);      // +4 words: the k-mer window loader may touch one 64-bit word past a mate
         R->d_nmask.alloc(cap_bases / 32 + 2);
-        R->d_aln_off.alloc(cap_pairs + 1);
+        R->d_aln_off.alloc(raw_pairs + 1);
         R->d_recs.alloc(std::max<uint64_t>(cap_recs, 1));
-        R->d_cigar_off.alloc(cap_pairs + 1);
+        R->d_cigar_off.alloc(raw_pairs + 1);
         R->d_cigar.alloc(cap_cigar + 16);            // +16: the CIGAR loader reads 8 words per record unconditionally
-        R->d_pair_meta.alloc(std::max<uint64_t>(cap_pairs, 1));
+        R->d_pair_meta.alloc(std::max<uint64_t>(raw_pairs, 1));
         R->d_status.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_weight.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_unmapped.alloc(std::max<uint64_t>(cap_pairs, 1));
@@ -121,8 +127,11 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
         // list is capped at MAX_USED_ALNS per (pair, contig with records) — bound by 10 per record is loose,
         // the tight bound is min(10 * contigs_with_records, pairs + alones) <= 2 * recs per typical data.
         // We allocate 10 per (pair, allele) capped by 2 * records + pairs and report overflow loudly.
-        const uint64_t pa_cap = std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * cap_pairs * A,
-                                                   2 * cap_recs + cap_pairs) + 64;
+        // A streaming batch does not know the records of the chunks to come: the caller says how many PairAlignments to
+        // make room for, by default three per (pair, allele) (one per contig is the rule, 24 B each).
+        const uint64_t pa_cap = streaming
+            ? (cap_pair_alns ? cap_pair_alns : std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS), 3) * cap_pairs * A) + 64
+            : std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * cap_pairs * A, 2 * cap_recs + cap_pairs) + 64;
         R->d_pa.alloc(pa_cap);
         R->d_pa_count.alloc(1);
         R->d_pa_off.alloc(std::max<uint64_t>(cap_pairs, 1));
@@ -143,6 +152,17 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
     });
 }
 
+int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_bases, uint64_t cap_recs,
+                          uint64_t cap_cigar, lcty_reads** out) {
+    return create_reads(locus, cap_pairs, cap_pairs, cap_bases, cap_recs, cap_cigar, 0, false, out);
+}
+
+int32_t lcty_reads_create_streaming(lcty_locus* locus, uint64_t cap_pairs, uint64_t chunk_pairs, uint64_t chunk_bases,
+                                    uint64_t chunk_recs, uint64_t chunk_cigar, uint64_t cap_pair_alns, lcty_reads** out) {
+    if (chunk_pairs == 0 || chunk_pairs > cap_pairs) chunk_pairs = cap_pairs;
+    return create_reads(locus, cap_pairs, chunk_pairs, chunk_bases, chunk_recs, chunk_cigar, cap_pair_alns, true, out);
+}
+
 int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
     return guarded([&] {
         if (!R || !h) fail(LCTY_ERR_INVALID_INPUT, "null argument");
@@ -152,9 +172,18 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         if (n == 0) return;
         const uint64_t nb = h->mate_off[2 * n], nr = h->aln_off[n], nc = h->cigar_off[n];
         if (h->mate_off[0] || h->aln_off[0] || h->cigar_off[0]) fail(LCTY_ERR_INVALID_INPUT, "chunk offsets must start at 0");
-        if (R->n_pairs + n > R->cap_pairs || R->n_bases + nb > R->cap_bases || R->n_recs + nr > R->cap_recs ||
-            R->n_cigar + nc > R->cap_cigar)
-            fail(LCTY_ERR_INVALID_INPUT, "chunk exceeds the capacity given to lcty_reads_create");
+        if (R->streaming && R->scored && R->n_pairs > R->raw_first) {
+            // the chunk on the device has been scored: its products stay, its records make room for the next one
+            R->check_device_error();
+            LCTY_HIP(hipMemcpyAsync(&R->pa_at_raw_first, R->d_pa_count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            LCTY_HIP(hipStreamSynchronize(ctx->stream));
+            R->raw_first = R->n_pairs;
+            R->n_bases = R->n_recs = R->n_cigar = 0;
+        }
+        const uint64_t raw_pairs = R->n_pairs - R->raw_first;       // pairs whose records are on the device
+        if (R->n_pairs + n > R->cap_pairs || raw_pairs + n > R->cap_raw_pairs || R->n_bases + nb > R->cap_bases ||
+            R->n_recs + nr > R->cap_recs || R->n_cigar + nc > R->cap_cigar)
+            fail(LCTY_ERR_INVALID_INPUT, "chunk exceeds the capacity given to lcty_reads_create%s", R->streaming ? "_streaming" : "");
         // host-side validation of the CSR structure (cheap, O(pairs + records))
         uint32_t max_recs = R->max_recs_per_pair;
         uint64_t max_cig = R->max_cigar_per_pair;
@@ -190,7 +219,7 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         R->locus->ensure_edit_thresholds(h->mate_len, 2 * n);
 
         hipStream_t s = ctx->stream;
-        R->d_mate_len.upload(h->mate_len, 2 * n, s, 2 * R->n_pairs);
+        R->d_mate_len.upload(h->mate_len, 2 * n, s, 2 * raw_pairs);
         R->d_bases2.upload(h->bases2, nb / 16, s, R->n_bases / 16);
         R->d_nmask.upload(h->nmask, nb / 32, s, R->n_bases / 32);
         R->d_recs.upload(h->recs, nr, s, R->n_recs);
@@ -199,10 +228,10 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         std::vector<uint64_t> mo(2 * n), ao(n), co(n);
         for (uint64_t m = 0; m < 2 * n; m++) mo[m] = h->mate_off[m + 1] + R->n_bases;
         for (uint64_t r = 0; r < n; r++) { ao[r] = h->aln_off[r + 1] + R->n_recs; co[r] = h->cigar_off[r + 1] + R->n_cigar; }
-        R->d_mate_off.upload(mo.data(), 2 * n, s, 2 * R->n_pairs + 1);
-        R->d_aln_off.upload(ao.data(), n, s, R->n_pairs + 1);
-        R->d_cigar_off.upload(co.data(), n, s, R->n_pairs + 1);
-        R->d_pair_meta.upload(meta.data(), n, s, R->n_pairs);
+        R->d_mate_off.upload(mo.data(), 2 * n, s, 2 * raw_pairs + 1);
+        R->d_aln_off.upload(ao.data(), n, s, raw_pairs + 1);
+        R->d_cigar_off.upload(co.data(), n, s, raw_pairs + 1);
+        R->d_pair_meta.upload(meta.data(), n, s, raw_pairs);
         LCTY_HIP(hipStreamSynchronize(s));
         R->n_pairs += n; R->n_bases += nb; R->n_recs += nr; R->n_cigar += nc;
         R->max_recs_per_pair = max_recs;
@@ -230,7 +259,7 @@ int32_t lcty_score_reads(lcty_reads* reads) {
     return guarded([&] {
         if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         reads->ctx->activate();
-        if (reads->n_pairs) launch_score_reads(reads);
+        if (reads->n_pairs > reads->raw_first) launch_score_reads(reads);      // streaming: the chunk on the device
         reads->scored = true;
         reads->good_valid = false; reads->loc_table_valid = false;
     });

@@ -881,10 +881,12 @@ void launch_score_reads(lcty_reads* reads) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
     const uint32_t per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(12, lds_max / lds)));
-    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(reads->n_pairs, static_cast<uint64_t>(cus) * per_cu));
+    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(R.n_pairs, static_cast<uint64_t>(cus) * per_cu));
     const char* dbg_env = getenv("LCTY_DBG");      // developer ablation switch; 0 / unset = the real kernel
     const uint32_t dbg = dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u;
-    reads->d_pa_count.zero(ctx->stream);
+    // the arena cursor goes back to where the pairs on the device start (0 unless a streaming batch has dropped chunks)
+    if (reads->raw_first == 0) reads->d_pa_count.zero(ctx->stream);
+    else reads->d_pa_count.upload(&reads->pa_at_raw_first, 1, ctx->stream);
     ctx->timed(LCTY_K_SCORE, [&] {
         hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs, dbg);
     });

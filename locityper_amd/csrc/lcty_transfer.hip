@@ -610,6 +610,8 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         lcty_ctx* ctx = reads->ctx;
         if (!loc->has_hap_alns) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_set_hap_alns has not been called");
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads first: recovery looks at the read pairs the first pass lets through");
+        if (reads->streaming)
+            fail(LCTY_ERR_UNSUPPORTED, "alignment recovery needs the records of the whole batch on the device: not available for a streaming batch");
         ctx->activate();
         reads->check_device_error();
         hipStream_t s = ctx->stream;
