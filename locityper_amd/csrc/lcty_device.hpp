@@ -86,6 +86,8 @@ struct ReadsView {
     uint32_t* pa_idx;               // [R][A]: offset of the contig's entries inside the pair's arena segment | count << 24
     uint32_t* err_flag;             // first LCTY_ERR_* raised by a kernel
     double* recover_w;              // per pair: read weight if it reaches recover_and_group_alignments (locs.rs:1255), else -1
+    uint8_t* park;                  // scoring kernel, large pairs: per-workgroup scratch of saved alignments (else null)
+    uint64_t park_stride;
 };
 
 __host__ __device__ inline uint64_t mix64(uint64_t x) {

@@ -92,6 +92,7 @@ struct lcty_reads {
     lcty::DevBuf<uint64_t> d_cigar_off;
     lcty::DevBuf<uint32_t> d_cigar;
     lcty::DevBuf<uint2> d_pair_meta;
+    lcty::DevBuf<uint8_t> d_park;            // scoring kernel, pairs whose saved alignments do not fit the LDS (lcty_score.hip)
 
     lcty::DevBuf<uint8_t> d_status;
     lcty::DevBuf<double> d_weight, d_unmapped;

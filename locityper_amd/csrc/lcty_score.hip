@@ -498,21 +498,33 @@ __device__ __forceinline__ double read_end_weight(const LocusView& L, uint32_t c
     return fmax(fmax(val[middle], val[lo]), val[hi]);
 }
 
+// barrier between the passes over a pair; parked alignments in global memory (BIG) are made visible to the other lanes first
+template <bool BIG>
+__device__ __forceinline__ void pair_barrier() {
+    if constexpr (BIG) __threadfence_block();
+    __syncthreads();
+}
+
 // EW = explicit region weights are set (lcty_locus_set_explicit_weights): the pair's weight is multiplied by
 // ContigInfos::explicit_read_weight over its PairAlignments (windows.rs:683-693; locs.rs:860, 903) before it scales them.
-template <bool EW>
+// BIG = the saved alignments of a pair (16 B each + two 16-bit links) do not fit the LDS next to the per-allele tables (4 096
+// alleles with an alignment per read end on each: 209 KB): they are parked in a scratch of the workgroup in global memory
+// (L2-resident: written and read back by the same CU within microseconds); the per-allele tables stay in LDS.
+template <bool EW, bool BIG>
 __device__ __forceinline__ void score_reads_body(const LocusView& L, const ReadsView& R, const uint32_t max_recs, const uint32_t dbg) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t A = L.n_alleles;
     const uint32_t mr2 = (max_recs + 1) & ~1u;
-    // region sizes must match score_lds_bytes()
-    Rec16* rec = reinterpret_cast<Rec16*>(smem);                              // [max_recs] saved alignments, by record index
-    uint32_t* head32 = reinterpret_cast<uint32_t*>(rec + max_recs);           // [A] {head(end 0) | head(end 1) << 16}
+    // region sizes must match score_lds_bytes() / score_park_bytes()
+    uint8_t* const park_base = BIG ? R.park + static_cast<uint64_t>(blockIdx.x) * R.park_stride : smem;
+    Rec16* rec = reinterpret_cast<Rec16*>(park_base);                         // [max_recs] saved alignments, by record index
+    uint16_t* nxt = reinterpret_cast<uint16_t*>(rec + max_recs);              // [max_recs] chain links
+    uint16_t* order = nxt + mr2;                                              // [max_recs] scratch of the general path
+    uint8_t* const tables = BIG ? smem : reinterpret_cast<uint8_t*>(order + mr2);
+    uint32_t* head32 = reinterpret_cast<uint32_t*>(tables);                   // [A] {head(end 0) | head(end 1) << 16}
     uint32_t* alen = head32 + A;                                              // [A] allele lengths (filled once per workgroup)
     uint32_t* scratch_cursor = alen + A;                                      // [1]
-    uint16_t* nxt = reinterpret_cast<uint16_t*>(scratch_cursor + 1);          // [max_recs] chain links
-    uint16_t* order = nxt + mr2;                                              // [max_recs] scratch of the general path
-    uint8_t* kk1 = reinterpret_cast<uint8_t*>(order + mr2);                   // [A] general path: kept first-end alns (<= 10)
+    uint8_t* kk1 = reinterpret_cast<uint8_t*>(scratch_cursor + 1);            // [A] general path: kept first-end alns (<= 10)
     uint8_t* kk2 = kk1 + A;                                                   // [A]
     uint8_t* cnt8 = kk2 + A;                                                  // [A] emitted PairAlignments (<= 10); bit 7 = general path
     const int lane = threadIdx.x;
@@ -603,7 +615,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
         }
         const uint32_t good0 = __shfl(my_good, 0), thr0 = __shfl(my_thr, 0), pass0 = __shfl(my_pass, 0), st0 = __shfl(my_state, 0);
         const uint32_t good1 = __shfl(my_good, 1), thr1 = __shfl(my_thr, 1), pass1 = __shfl(my_pass, 1), st1 = __shfl(my_state, 1);
-        __syncthreads();      // head table initialised
+        pair_barrier<BIG>();      // head table initialised
 
         // ---------------- pass 1: records -> (best edit, best ln-prob), saved ones -> LDS chains ----------------
         uint32_t be0 = NONE32, be1 = NONE32, bad0 = 0, bad1 = 0;
@@ -669,7 +681,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
         be0 = wave_min_u32(be0); be1 = wave_min_u32(be1);
         bl0 = wave_max_f64(bl0); bl1 = wave_max_f64(bl1);
         bad0 = wave_sum_u32(bad0); bad1 = wave_sum_u32(bad1);
-        __syncthreads();
+        pair_barrier<BIG>();
         if (dbg == 1) { if (lane == 0) R.status[p] = static_cast<uint8_t>(be0 + be1); continue; }   // ablation (LCTY_DBG)
 
         // end 1 is only looked at when end 0 is well mapped (locs.rs:1125-1132); its secondaries only when its
@@ -764,7 +776,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
             if (!any_inb) { status = LCTY_READ_OUT_OF_BOUNDS; accepted = false; }
             else if (!edit_good) { status = LCTY_READ_POORLY_MAPPED; accepted = false; }
             else status = weight >= L.min_weight ? LCTY_READ_GOOD : LCTY_READ_FEW_KMERS;     // locs.rs:1277-1285 (EW: again below)
-            __syncthreads();
+            pair_barrier<BIG>();
 
             if (accepted) {
                 if (lane == 0) {
@@ -841,18 +853,27 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
             R.uniq_kmers[2 * p] = accepted ? static_cast<uint16_t>(uk0) : 0;
             R.uniq_kmers[2 * p + 1] = accepted ? static_cast<uint16_t>(uk1) : 0;
         }
-        __syncthreads();
+        pair_barrier<BIG>();
     }
 }
 
 __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
                                                               const uint32_t dbg) {
-    score_reads_body<false>(L, R, max_recs, dbg);
+    score_reads_body<false, false>(L, R, max_recs, dbg);
 }
 // the same with explicit region weights (--reg-weights)
 __global__ __launch_bounds__(WAVE, 3) void score_reads_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
                                                                        const uint32_t dbg) {
-    score_reads_body<true>(L, R, max_recs, dbg);
+    score_reads_body<true, false>(L, R, max_recs, dbg);
+}
+// the same two for read pairs whose saved alignments do not fit the LDS (thousands of alleles): parked in global memory
+__global__ __launch_bounds__(WAVE, 3) void score_reads_big_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
+                                                                  const uint32_t dbg) {
+    score_reads_body<false, true>(L, R, max_recs, dbg);
+}
+__global__ __launch_bounds__(WAVE, 3) void score_reads_big_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
+                                                                           const uint32_t dbg) {
+    score_reads_body<true, true>(L, R, max_recs, dbg);
 }
 
 static size_t score_lds_bytes(uint32_t max_recs, uint32_t A) {
@@ -862,26 +883,46 @@ static size_t score_lds_bytes(uint32_t max_recs, uint32_t A) {
     return (b + 15) & ~static_cast<size_t>(15);
 }
 
+// BIG variant: the parked alignments (global scratch per workgroup) and the per-allele tables (LDS)
+static size_t score_park_bytes(uint32_t max_recs) {
+    const size_t mr2 = (max_recs + 1) & ~1u;
+    return (static_cast<size_t>(max_recs) * sizeof(Rec16) + 2 * mr2 * sizeof(uint16_t) + 255) & ~static_cast<size_t>(255);
+}
+static size_t score_table_bytes(uint32_t A) {
+    return (static_cast<size_t>(A) * 8 + 4 + static_cast<size_t>(3) * A + 15) & ~static_cast<size_t>(15);
+}
+
 void launch_score_reads(lcty_reads* reads) {
     lcty_ctx* ctx = reads->ctx;
     const LocusView L = reads->locus->view();
-    const ReadsView R = reads->view();
+    ReadsView R = reads->view();
     const uint32_t max_recs = std::max<uint32_t>(reads->max_recs_per_pair, 1);
-    const size_t lds = score_lds_bytes(max_recs, L.n_alleles);
+    size_t lds = score_lds_bytes(max_recs, L.n_alleles);
     const size_t lds_max = 160 * 1024;
     if (max_recs >= 65535) fail(LCTY_ERR_UNSUPPORTED, "more than 65534 records in one read pair");
-    if (lds > lds_max)
-        fail(LCTY_ERR_UNSUPPORTED,
-             "a read pair with %u records on %u alleles needs %zu B of LDS (> %zu): not supported by this build",
-             max_recs, L.n_alleles, lds, lds_max);
+    // the saved alignments of a pair live in LDS when they fit; beyond that (thousands of alleles, an alignment on each) in a
+    // per-workgroup scratch in global memory, only the per-allele tables in LDS
+    const bool big = lds > lds_max;
+    if (big) {
+        lds = score_table_bytes(L.n_alleles);
+        if (lds > lds_max)
+            fail(LCTY_ERR_UNSUPPORTED, "%u alleles need %zu B of LDS for the per-allele tables (> %zu): not supported by this build",
+                 L.n_alleles, lds, lds_max);
+    }
     const bool explicit_weights = L.ew_val != nullptr;
-    auto kernel = explicit_weights ? score_reads_explicit_kernel : score_reads_kernel;
+    auto kernel = big ? (explicit_weights ? score_reads_big_explicit_kernel : score_reads_big_kernel)
+                      : (explicit_weights ? score_reads_explicit_kernel : score_reads_kernel);
     if (lds > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
     const uint32_t per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(12, lds_max / lds)));
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(R.n_pairs, static_cast<uint64_t>(cus) * per_cu));
+    if (big) {
+        const size_t stride = score_park_bytes(max_recs);
+        reads->d_park.ensure(stride * grid);
+        R.park = reads->d_park.p; R.park_stride = stride;
+    }
     const char* dbg_env = getenv("LCTY_DBG");      // developer ablation switch; 0 / unset = the real kernel
     const uint32_t dbg = dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u;
     // the arena cursor goes back to where the pairs on the device start (0 unless a streaming batch has dropped chunks)

@@ -777,3 +777,63 @@ def test_chain_sharded_stage(gpu_ctx):
                 gathered = np.concatenate([gathered, block])
             assert np.array_equal(gathered[:len(gts)], l1)
     comm.close()
+
+
+@pytest.mark.gpu
+def test_config5_allele_count_pairs_beyond_the_lds(gpu_ctx):
+    """configs[4] has 4 096 alleles and the mapper is asked for min(25 000, 4 x alleles) locations per read end
+    (genotype.rs:971): a pair with an alignment per end on every allele has 8 192+ records, more than the LDS holds next to the
+    per-allele tables. The kernel then parks the saved alignments in a per-workgroup scratch in global memory; results must
+    not depend on where they are parked."""
+    A = 4200
+    L = synth.SynthLocus(A, 48, seed=61, base_len=3000)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    ch = L.reads(0, 48)
+    assert np.diff(ch.aln_off.astype(np.int64)).max() >= 2 * A - 2
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    assert aa.n_good() > 30
+    sc = aa.run_filter()                                         # all 8 822 100 genotypes
+    gts = O.generate_genotypes(A, 2)
+    so = O.run_filter(Mo, gts)
+    assert np.abs(sc - so).max() <= 1e-9 * max(np.abs(so).max(), 1.0)
+    assert so[int(np.argmax(sc))] >= so.max() - 1e-9 * abs(so.max())        # 48 pairs leave many genotypes tied
+    # the same read pairs with explicit region weights (the fourth instantiation of the kernel)
+    from tests.test_oracle_explicit import bed_lines, columns
+    n = [int(L.seq_off[a + 1] - L.seq_off[a]) for a in range(A)]
+    cols = columns(bed_lines(n, np.random.default_rng(8), piece=(100, 1500)))
+    loc.set_explicit_weights(*cols)
+    assert ol.set_explicit_weights(*cols) == 0
+    compare_gpu_to_oracle(api.AllAlignments.load(loc, ch), ol.load(ch))
+
+
+@pytest.mark.gpu
+def test_many_secondaries_per_pair_beyond_the_lds(gpu_ctx):
+    """Few alleles, thousands of secondary alignments per read pair (general path of the grouping: several alignments per
+    contig and end): 9 000 records of a pair need 180 KB of LDS -> parked in global memory."""
+    rng = np.random.default_rng(77)
+    alleles = random_alleles(12, 30_000, seed=3, snp_rate=0.01)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    pairs = []
+    for _ in range(6):
+        a0 = int(rng.integers(0, 12)); pos = int(rng.integers(1000, 20_000))
+        s1 = alleles[a0][pos:pos + 150].decode(); s2 = alleles[a0][pos + 300:pos + 450].decode()
+        recs = [(a0, pos, 0, "150=")]
+        for _ in range(4600):                                   # secondaries of end 1 all over the locus, some of them good
+            c = int(rng.integers(0, 12)); q = int(rng.integers(0, 29_000))
+            nx = int(rng.integers(0, 6))
+            recs.append((c, q, SEC | (REV if rng.random() < 0.3 else 0), f"{150 - nx}={nx}X" if nx else "150="))
+        recs.append((a0, pos + 300, M2 | REV, "150="))
+        for _ in range(4400):
+            c = int(rng.integers(0, 12)); q = int(rng.integers(0, 29_000))
+            nx = int(rng.integers(0, 6))
+            recs.append((c, q, SEC | M2 | (REV if rng.random() < 0.7 else 0), f"{nx}X{150 - nx}=" if nx else "150="))
+        pairs.append({"seq1": s1, "seq2": s2, "recs": recs})
+    ch = ReadsChunk.from_pairs(pairs)
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    compare_gpu_to_oracle(aa, oa)
+    assert np.diff(oa.pa_off.astype(np.int64)).max() >= 40
