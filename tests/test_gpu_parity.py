@@ -837,3 +837,19 @@ def test_many_secondaries_per_pair_beyond_the_lds(gpu_ctx):
     aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
     compare_gpu_to_oracle(aa, oa)
     assert np.diff(oa.pa_off.astype(np.int64)).max() >= 40
+
+
+@pytest.mark.gpu
+def test_alignment_recovery_neighbour_bin_quirk(gpu_ctx):
+    """SURVEY App. C quirk 2 on the device (the scenario of tests/test_quirks.py): PosCollection::get calls a stored start in the
+    neighbouring 128-bp bin "similar" when it is 64 bases or more away, not when it is closer."""
+    rng = np.random.default_rng(4)
+    hap = bytes(rng.choice(list(b"ACGT"), 2600).astype(np.uint8))
+    r1, r2 = hap[1030:1180].decode(), hap[1400:1550].decode()
+    got = {}
+    for q in (1000, 900):
+        recs = [(0, 1030, 0, "150="), (1, q, SEC, "150="), (0, 1400, M2 | REV, "150="), (1, 1400, M2 | REV | SEC, "150=")]
+        n_rec, aa, oa = _recovery_case(gpu_ctx, [hap, hap], [{"seq1": r1, "seq2": r2, "recs": recs}], make_bg())
+        off, pa = aa.pair_alns()
+        got[q] = {int(x["mid1"]) for x in pa if int(x["contig"]) == 1 and int(x["mid1"]) != cdefs.NONE_U32}
+    assert (1030 + 1180) // 2 in got[1000] and (1030 + 1180) // 2 not in got[900]
