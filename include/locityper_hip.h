@@ -208,6 +208,14 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles,
                           const uint16_t* offtarget, const uint64_t* cnt_off, uint32_t k,
                           const lcty_bg* bg, const lcty_params* params, lcty_locus** out);
 void    lcty_locus_destroy(lcty_locus* locus);
+/* KmerCounts::load (src/seq/counts.rs:127-150) on the decompressed bytes of `kmers.bin.br` / `.lz4` (command/paths.rs:4-5): parses
+ * the FIRST block, which holds the off-target counts (command/add.rs:647-650; contigs.rs:301-303), into the arrays
+ * lcty_locus_create takes. Values are clamped to min(65535, 2^(8 * counter bytes) - 1). Two calls: with cnt_off = counts = NULL it
+ * only reports k, the number of contigs and (in *consumed) the bytes of the block; the total number of values is then
+ * cnt_off[n_contigs] of the second call, for which cap_counts may be the remaining length of the buffer (a value takes at least
+ * one byte). Truncated data / overlong varints / a counter length > 8: LCTY_ERR_INVALID_DATA. Host code. */
+int32_t lcty_kmer_counts_parse(const uint8_t* buf, uint64_t len, uint32_t* k, uint32_t* n_contigs, uint64_t* cnt_off /* [n_contigs+1] */,
+                               uint64_t cap_contigs, uint16_t* counts, uint64_t cap_counts, uint64_t* consumed);
 /* number of locus-unique canonical k-mers (the count logged at locs.rs:953) */
 int32_t lcty_locus_n_unique_kmers(const lcty_locus* locus, uint64_t* out);
 /* ContigInfo::new products per allele (windows.rs:386-407): position count = len-neighb+1.

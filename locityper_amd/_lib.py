@@ -45,6 +45,7 @@ SIGNATURES = {
     "lcty_count_genotypes": (U64, [U32, U32]),
     "lcty_generate_genotypes": (I32, [U32, U32, VP, U64]),
     "lcty_locus_window_weights": (I32, [VP, VP]),
+    "lcty_kmer_counts_parse": (I32, [VP, U64, P(U32), P(U32), VP, U64, VP, U64, P(U64)]),
     "lcty_locus_set_explicit_weights": (I32, [VP, U32, VP, VP, VP, VP]),
     "lcty_locus_set_hap_alns": (I32, [VP, U32, VP, VP, VP, VP, VP, VP, U32, D]),
     "lcty_recover_alignments": (I32, [VP, P(U64)]),

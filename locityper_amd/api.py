@@ -384,6 +384,19 @@ def generate_genotypes(n_alleles, ploidy):
     return out
 
 
+def parse_kmer_counts(data):
+    """KmerCounts::load (counts.rs:127-150) of the decompressed `kmers.bin`: (k, cnt_off[n_contigs+1], counts u16, bytes consumed)
+    of the first block (the off-target counts)."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    k, n, used = U32(), U32(), U64()
+    check(lib().lcty_kmer_counts_parse(buf.ctypes.data, len(buf), C.byref(k), C.byref(n), None, 0, None, 0, C.byref(used)))
+    off = np.zeros(n.value + 1, dtype=np.uint64)
+    counts = np.zeros(max(int(used.value), 1), dtype=np.uint16)
+    check(lib().lcty_kmer_counts_parse(buf.ctypes.data, len(buf), C.byref(k), C.byref(n), off.ctypes.data, n.value, counts.ctypes.data,
+                                       len(counts), C.byref(used)))
+    return int(k.value), off, counts[:int(off[-1])], int(used.value)
+
+
 def truncate_ixs(scores, ixs, filt_diff, min_size, threads):
     """truncate_ixs (solve.rs:52-84): returns the kept indices sorted by (score desc, index asc)."""
     scores = np.ascontiguousarray(scores, dtype=np.float64)

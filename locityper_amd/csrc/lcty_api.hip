@@ -206,6 +206,56 @@ int32_t lcty_prefilter(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_
     });
 }
 
+// KmerCounts::load — src/seq/counts.rs:127-150: the first KmerCounts block of `kmers.bin` (after the caller has taken the
+// brotli / lz4 layer off, ext/sys.rs:41-76): u8 k, u8 counter bytes, varint n_contigs, then per contig varint n_kmers and n_kmers
+// varints, clamped to min(u16::MAX, 2^(8 bytes) - 1). The varints are those of the `varint-rs` crate (^2.2, not in the tree):
+// little-endian groups of 7 bits, the high bit of a byte says another one follows. The first block holds the off-target
+// counts (command/add.rs:647-650) — the ones lcty_locus_create takes; the second block (all counts) is left unread, as upstream.
+int32_t lcty_kmer_counts_parse(const uint8_t* buf, uint64_t len, uint32_t* k_out, uint32_t* n_contigs_out, uint64_t* cnt_off,
+                               uint64_t cap_contigs, uint16_t* counts, uint64_t cap_counts, uint64_t* consumed) {
+    return guarded([&] {
+        if (!buf || !k_out || !n_contigs_out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        uint64_t at = 0;
+        auto byte = [&]() -> uint8_t {
+            if (at >= len) fail(LCTY_ERR_INVALID_DATA, "k-mer counts: unexpected end of data at byte %llu", static_cast<unsigned long long>(at));
+            return buf[at++];
+        };
+        auto varint = [&](uint32_t max_bytes) -> uint64_t {
+            uint64_t v = 0;
+            for (uint32_t i = 0; i < max_bytes; i++) {
+                const uint8_t b = byte();
+                v |= static_cast<uint64_t>(b & 0x7Fu) << (7 * i);
+                if (!(b & 0x80u)) return v;
+            }
+            fail(LCTY_ERR_INVALID_DATA, "k-mer counts: a varint of more than %u bytes at byte %llu", max_bytes, static_cast<unsigned long long>(at));
+            return 0;
+        };
+        const uint32_t k = byte();
+        const uint32_t byte_len = byte();
+        if (byte_len > 8) fail(LCTY_ERR_INVALID_DATA, "k-mer counts: counter length of %u bytes", byte_len);            // assert!, counts.rs:133
+        const uint64_t max_value = std::min<uint64_t>(0xFFFFu, byte_len == 8 ? ~0ull : (1ull << (byte_len * 8)) - 1);
+        const uint64_t n_contigs = varint(5);
+        *k_out = k; *n_contigs_out = static_cast<uint32_t>(n_contigs);
+        const bool store = cnt_off && counts;
+        if (store && cap_contigs < n_contigs) fail(LCTY_ERR_INVALID_INPUT, "k-mer counts: room for %llu contigs, the file has %llu",
+                                                   static_cast<unsigned long long>(cap_contigs), static_cast<unsigned long long>(n_contigs));
+        uint64_t total = 0;
+        if (cnt_off && cap_contigs >= n_contigs) cnt_off[0] = 0;
+        for (uint64_t c = 0; c < n_contigs; c++) {
+            const uint64_t n_kmers = varint(5);
+            if (store && total + n_kmers > cap_counts) fail(LCTY_ERR_INVALID_INPUT, "k-mer counts: room for %llu values is not enough",
+                                                            static_cast<unsigned long long>(cap_counts));
+            for (uint64_t i = 0; i < n_kmers; i++) {
+                const uint64_t v = varint(10);
+                if (store) counts[total + i] = static_cast<uint16_t>(std::min(v, max_value));
+            }
+            total += n_kmers;
+            if (cnt_off && cap_contigs >= n_contigs) cnt_off[c + 1] = total;
+        }
+        if (consumed) *consumed = at;
+    });
+}
+
 // truncate_ixs — src/solvers/solve.rs:52-84; ties ordered by index ascending
 int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double filt_diff, uint64_t min_size,
                       uint64_t threads, uint64_t* n_keep) {

@@ -154,3 +154,51 @@ def test_counts_to_posteriors():
     assert mapq[0] == 30
     with pytest.raises(_lib.LocityperError):
         api.counts_to_posteriors([21], 20)
+
+
+# ---------------------------------------------------------------- KmerCounts::load (seq/counts.rs:108-150)
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _save_kmer_counts(k, counter_bytes, contigs):
+    """KmerCounts::save (counts.rs:108-124): u8 k, u8 counter bytes, u32 varint contigs, per contig u32 varint + u64 varints."""
+    out = bytearray([k, counter_bytes]) + _varint(len(contigs))
+    for c in contigs:
+        out += _varint(len(c))
+        for v in c:
+            out += _varint(int(v))
+    return bytes(out)
+
+
+def test_kmer_counts_parse_known_answers_and_errors():
+    from locityper_amd import api, _lib
+    assert _varint(0) == b"\x00" and _varint(127) == b"\x7f" and _varint(128) == b"\x80\x01" and _varint(300) == b"\xac\x02"
+    rng = np.random.default_rng(3)
+    off_target = [rng.choice([0, 0, 0, 1, 5, 127, 128, 200, 16383, 16384, 65535, 70000, 2 ** 40], n) for n in (976, 0, 1, 3000)]
+    regular = [np.ones(len(c), dtype=np.int64) for c in off_target]
+    blob = _save_kmer_counts(25, 2, off_target) + _save_kmer_counts(25, 2, regular)      # add.rs:647-650: two blocks, the first is read
+    k, off, counts, used = api.parse_kmer_counts(blob)
+    assert k == 25 and used == len(_save_kmer_counts(25, 2, off_target))
+    assert off.tolist() == [0, 976, 976, 977, 3977]
+    want = np.concatenate([np.minimum(c, 65535) for c in off_target]).astype(np.uint16)                # clamped to KmerCount::MAX
+    assert np.array_equal(counts, want)
+    k2, off2, counts2, used2 = api.parse_kmer_counts(blob[used:])                                      # the second block parses too
+    assert used2 == len(blob) - used and np.all(counts2 == 1) and off2.tolist() == off.tolist()
+    # one counter byte: max_value = 255 (counts.rs:134)
+    k3, off3, c3, _ = api.parse_kmer_counts(_save_kmer_counts(31, 1, [[0, 254, 255, 256, 65535]]))
+    assert k3 == 31 and c3.tolist() == [0, 254, 255, 255, 255]
+    # eight counter bytes: u64::MAX, i.e. the u16 clamp alone
+    assert api.parse_kmer_counts(_save_kmer_counts(15, 8, [[1, 2 ** 63]]))[2].tolist() == [1, 65535]
+    assert api.parse_kmer_counts(_save_kmer_counts(15, 2, []))[1].tolist() == [0]                        # no contigs
+    for bad in (blob[:used - 1], blob[:1], b"", _save_kmer_counts(25, 9, [[1]]), bytes([25, 2]) + b"\xff" * 6,
+                bytes([25, 2, 1, 1]) + b"\x80" * 10 + b"\x01"):
+        with pytest.raises((_lib.LocityperError, ValueError)) as e:
+            api.parse_kmer_counts(bad)
+        assert not isinstance(e.value, _lib.LocityperError) or e.value.code in (cdefs.ERR_INVALID_DATA, cdefs.ERR_INVALID_INPUT)
