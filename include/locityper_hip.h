@@ -260,7 +260,8 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
  * the chunk capacities); lcty_score_reads } ...; then prefilter / solver stages / read-backs as for any batch — they see all
  * pairs appended so far, in order, and the results are those of one resident batch (AllAlignments::load is a loop over reads,
  * locs.rs:1119-1185). An append after a score drops the records of the scored chunk. cap_pair_alns = room for that many
- * PairAlignments in total (0: three per (pair, allele)); overflow fails loudly. lcty_recover_alignments: LCTY_ERR_UNSUPPORTED. */
+ * PairAlignments in total (0: three per (pair, allele)); overflow fails loudly. With alignment recovery the loop body is
+ * { append; lcty_score_reads; lcty_recover_alignments; lcty_score_reads }: recovery works on the chunk whose records are resident. */
 int32_t lcty_reads_create_streaming(lcty_locus* locus, uint64_t cap_pairs, uint64_t chunk_pairs, uint64_t chunk_bases,
                                     uint64_t chunk_recs, uint64_t chunk_cigar, uint64_t cap_pair_alns, lcty_reads** out);
 int32_t lcty_reads_append(lcty_reads* reads, const lcty_reads_host* chunk);

@@ -82,6 +82,7 @@ struct lcty_reads {
     // (mate_len, mate_off, aln_off, cigar_off, pair_meta) are indexed relative to raw_first. raw_first == 0 otherwise.
     bool streaming = false;
     uint64_t raw_first = 0, cap_raw_pairs = 0;
+    uint64_t chunk_cap_recs = 0, chunk_cap_cigar = 0;   // record / CIGAR capacity of a chunk as given at creation (recovery replaces the tables)
     unsigned long long pa_at_raw_first = 0;   // arena cursor when the current chunk started (a chunk can be scored again)
 
     lcty::DevBuf<uint32_t> d_mate_len;

@@ -108,6 +108,7 @@ static int32_t create_reads(lcty_locus* locus, uint64_t cap_pairs, uint64_t raw_
         R->locus = locus; R->ctx = ctx;
         R->cap_pairs = cap_pairs; R->cap_bases = cap_bases; R->cap_recs = cap_recs; R->cap_cigar = cap_cigar;
         R->streaming = streaming; R->cap_raw_pairs = raw_pairs;
+        R->chunk_cap_recs = cap_recs; R->chunk_cap_cigar = cap_cigar;
         const uint32_t A = locus->n_alleles;
         R->d_mate_len.alloc(2 * raw_pairs);
         R->d_mate_off.alloc(2 * raw_pairs + 1);
@@ -179,6 +180,10 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
             LCTY_HIP(hipStreamSynchronize(ctx->stream));
             R->raw_first = R->n_pairs;
             R->n_bases = R->n_recs = R->n_cigar = 0;
+            // alignment recovery leaves record / CIGAR tables that are exactly as large as the merged chunk was
+            if (R->d_recs.n < std::max<uint64_t>(R->chunk_cap_recs, 1)) R->d_recs.alloc(std::max<uint64_t>(R->chunk_cap_recs, 1));
+            if (R->d_cigar.n < R->chunk_cap_cigar + 16) R->d_cigar.alloc(R->chunk_cap_cigar + 16);
+            R->cap_recs = std::max<uint64_t>(R->chunk_cap_recs, R->d_recs.n); R->cap_cigar = R->d_cigar.n - 16;
         }
         const uint64_t raw_pairs = R->n_pairs - R->raw_first;       // pairs whose records are on the device
         if (R->n_pairs + n > R->cap_pairs || raw_pairs + n > R->cap_raw_pairs || R->n_bases + nb > R->cap_bases ||

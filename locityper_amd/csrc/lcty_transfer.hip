@@ -610,12 +610,12 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         lcty_ctx* ctx = reads->ctx;
         if (!loc->has_hap_alns) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_set_hap_alns has not been called");
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads first: recovery looks at the read pairs the first pass lets through");
-        if (reads->streaming)
-            fail(LCTY_ERR_UNSUPPORTED, "alignment recovery needs the records of the whole batch on the device: not available for a streaming batch");
         ctx->activate();
         reads->check_device_error();
         hipStream_t s = ctx->stream;
-        const uint64_t R = reads->n_pairs;
+        // the pairs whose records are on the device: the whole batch, or the current chunk of a streaming batch (reads->view()
+        // addresses them from 0; recovery then sits between the two scoring passes of every chunk)
+        const uint64_t R = reads->n_pairs - reads->raw_first;
         if (n_recovered) *n_recovered = 0;
         if (R == 0) return;
         const uint32_t A = loc->n_alleles;
@@ -726,9 +726,10 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         }
         if (max_recs > 65535) fail(LCTY_ERR_UNSUPPORTED, "more than 65535 alignments of one read pair after recovery");
         DevBuf<uint64_t> d_m_aln, d_m_cig; DevBuf<lcty_aln_rec> d_m_recs; DevBuf<uint32_t> d_m_cigar; DevBuf<uint2> d_m_meta;
-        d_m_aln.alloc(std::max<uint64_t>(reads->cap_pairs, R) + 1); d_m_cig.alloc(std::max<uint64_t>(reads->cap_pairs, R) + 1);
+        const uint64_t raw_pairs_cap = std::max<uint64_t>(reads->streaming ? reads->cap_raw_pairs : reads->cap_pairs, R);
+        d_m_aln.alloc(raw_pairs_cap + 1); d_m_cig.alloc(raw_pairs_cap + 1);
         d_m_aln.upload(m_aln.data(), R + 1, s); d_m_cig.upload(m_cig.data(), R + 1, s);
-        d_m_recs.alloc(m_aln[R] + 1); d_m_cigar.alloc(m_cig[R] + 8); d_m_meta.alloc(std::max<uint64_t>(reads->cap_pairs, R));
+        d_m_recs.alloc(m_aln[R] + 1); d_m_cigar.alloc(m_cig[R] + 8); d_m_meta.alloc(raw_pairs_cap);
         hipLaunchKernelGGL(merge_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(R, 65535))), dim3(64), 0, s, reads->view(), d_new_cnt.p, d_new_words.p,
                            d_rec_at.p, d_word_at.p, d_xrecs.p, d_xwords.p, d_m_aln.p, d_m_cig.p, d_m_recs.p, d_m_cigar.p, d_m_meta.p);
         LCTY_HIP(hipGetLastError());
@@ -739,9 +740,11 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         reads->cap_recs = reads->n_recs; reads->cap_cigar = reads->n_cigar;           // the merged tables are exactly full
         // the pair-alignment arena was sized for the records of lcty_reads_create (same bound as there)
         const uint64_t pa_cap = std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * reads->cap_pairs * A, 2 * reads->n_recs + reads->cap_pairs) + 64;
-        if (reads->d_pa.n < pa_cap) reads->d_pa.alloc(pa_cap);
-        reads->max_recs_per_pair = static_cast<uint32_t>(max_recs);
-        reads->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
+        // (a streaming batch keeps the arena it was created with: the PairAlignments of the chunks before this one live in it)
+        if (!reads->streaming && reads->d_pa.n < pa_cap) reads->d_pa.alloc(pa_cap);
+        reads->max_recs_per_pair = std::max<uint32_t>(reads->streaming ? reads->max_recs_per_pair : 0u, static_cast<uint32_t>(max_recs));
+        reads->max_cigar_per_pair = std::max<uint32_t>(reads->streaming ? reads->max_cigar_per_pair : 0u,
+                                                       static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull)));
         reads->scored = false; reads->good_valid = false; reads->loc_table_valid = false;
         (void)total_words;
     });

@@ -103,3 +103,43 @@ def test_streaming_long_reads_beyond_one_chunk_of_memory(gpu_ctx):
     gts = api.generate_genotypes(A, 2)
     sc = O.run_filter(M, gts)
     assert tuple(gts[int(np.argmax(sc))]) == L.true_genotype
+
+
+def test_streaming_with_alignment_recovery_per_chunk(gpu_ctx):
+    """Alignment recovery on a streaming batch sits between the two scoring passes of every chunk (it needs the records of the
+    pairs it looks at, nothing of other pairs): products equal those of the resident batch recovered in one go."""
+    from tests.test_oracle_transfer import make_haps, hap_alns_for
+    from tests.helpers import make_bg, locus_arrays
+    from locityper_amd.cdefs import ReadsChunk
+    rng = np.random.default_rng(15)
+    haps = make_haps(rng, 5, 2600)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays([bytearray(h) for h in haps], 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    H = hap_alns_for(haps, transfer_fails=3)
+    loc.set_hap_alns(H.entries, transfer_fails=3, max_div=0.2)
+    M2, REV = cdefs.FLAG_MATE2, cdefs.FLAG_REVERSE
+    pairs = []
+    for _ in range(300):
+        src = int(rng.integers(0, 5))
+        p1 = int(rng.integers(320, len(haps[src]) - 800)); p2 = p1 + int(rng.integers(200, 420))
+        pairs.append({"seq1": haps[src][p1:p1 + 150].decode(), "seq2": haps[src][p2:p2 + 150].decode(),
+                      "recs": [(src, p1, 0, "150="), (src, p2, M2 | REV, "150=")]})
+    resident = api.AllAlignments.load(loc, ReadsChunk.from_pairs(pairs))
+    n_all = resident.recover()
+    assert n_all > 1500
+    chunks = [ReadsChunk.from_pairs(pairs[a:b]) for a, b in ((0, 120), (120, 121), (121, 300))]
+    cap = lambda f: int(1.1 * max(f(c) for c in chunks)) + 64
+    s = api.AllAlignments(loc, 300, (cap(lambda c: c.n_bases) + 31) // 32 * 32, cap(lambda c: len(c.recs)), cap(lambda c: len(c.cigar)),
+                          streaming_chunk_pairs=179, cap_pair_alns=300 * 5 * 10)
+    n_stream = 0
+    for c in chunks:
+        s.append(c); s.score()
+        n_stream += s.recover()                                  # transfers + the second scoring pass of the chunk
+    assert n_stream == n_all
+    same_products(s, resident)
+    assert np.array_equal(s.run_filter(), resident.run_filter())
+    # against the oracle's load with recovery
+    ol = O.OracleLocus(seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    compare_gpu_to_oracle(s, ol.load_recover(ReadsChunk.from_pairs(pairs), H), index_fields=())
