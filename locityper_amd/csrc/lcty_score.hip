@@ -520,17 +520,20 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
     Rec16* rec = reinterpret_cast<Rec16*>(park_base);                         // [max_recs] saved alignments, by record index
     uint16_t* nxt = reinterpret_cast<uint16_t*>(rec + max_recs);              // [max_recs] chain links
     uint16_t* order = nxt + mr2;                                              // [max_recs] scratch of the general path
+    // LDS form: [rec | nxt | order | head32 | alen | cursor | kk1 kk2 cnt8]; BIG: LDS holds head32 + cursor only (4 B per allele, so
+    // that ten workgroups fit a CU at 4 096 alleles), the lane-private per-allele bytes go to the park, allele lengths come from L2
     uint8_t* const tables = BIG ? smem : reinterpret_cast<uint8_t*>(order + mr2);
     uint32_t* head32 = reinterpret_cast<uint32_t*>(tables);                   // [A] {head(end 0) | head(end 1) << 16}
-    uint32_t* alen = head32 + A;                                              // [A] allele lengths (filled once per workgroup)
-    uint32_t* scratch_cursor = alen + A;                                      // [1]
-    uint8_t* kk1 = reinterpret_cast<uint8_t*>(scratch_cursor + 1);            // [A] general path: kept first-end alns (<= 10)
+    uint32_t* alen_lds = head32 + A;                                          // [A] allele lengths (filled once per workgroup; not BIG)
+    uint32_t* scratch_cursor = BIG ? head32 + A : alen_lds + A;               // [1]
+    uint8_t* kk1 = BIG ? reinterpret_cast<uint8_t*>(order + mr2) : reinterpret_cast<uint8_t*>(scratch_cursor + 1);   // [A] general path: kept first-end alns (<= 10)
     uint8_t* kk2 = kk1 + A;                                                   // [A]
     uint8_t* cnt8 = kk2 + A;                                                  // [A] emitted PairAlignments (<= 10); bit 7 = general path
+    const uint32_t* alen = BIG ? L.allele_len : alen_lds;
     const int lane = threadIdx.x;
     const bool paired = L.is_paired != 0;
     const InsLut ins{L.ins_lut, L.ins_lut_size, L.ins_n, L.ins_lnq, L.ins_lnpmf_const};
-    for (uint32_t i = lane; i < A; i += WAVE) alen[i] = L.allele_len[i];
+    if constexpr (!BIG) for (uint32_t i = lane; i < A; i += WAVE) alen_lds[i] = L.allele_len[i];
     __syncthreads();
 
     for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
@@ -884,12 +887,12 @@ static size_t score_lds_bytes(uint32_t max_recs, uint32_t A) {
 }
 
 // BIG variant: the parked alignments (global scratch per workgroup) and the per-allele tables (LDS)
-static size_t score_park_bytes(uint32_t max_recs) {
+static size_t score_park_bytes(uint32_t max_recs, uint32_t A) {
     const size_t mr2 = (max_recs + 1) & ~1u;
-    return (static_cast<size_t>(max_recs) * sizeof(Rec16) + 2 * mr2 * sizeof(uint16_t) + 255) & ~static_cast<size_t>(255);
+    return (static_cast<size_t>(max_recs) * sizeof(Rec16) + 2 * mr2 * sizeof(uint16_t) + static_cast<size_t>(3) * A + 255) & ~static_cast<size_t>(255);
 }
 static size_t score_table_bytes(uint32_t A) {
-    return (static_cast<size_t>(A) * 8 + 4 + static_cast<size_t>(3) * A + 15) & ~static_cast<size_t>(15);
+    return (static_cast<size_t>(A) * 4 + 4 + 15) & ~static_cast<size_t>(15);
 }
 
 void launch_score_reads(lcty_reads* reads) {
@@ -919,7 +922,7 @@ void launch_score_reads(lcty_reads* reads) {
     const uint32_t per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(12, lds_max / lds)));
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(R.n_pairs, static_cast<uint64_t>(cus) * per_cu));
     if (big) {
-        const size_t stride = score_park_bytes(max_recs);
+        const size_t stride = score_park_bytes(max_recs, L.n_alleles);
         reads->d_park.ensure(stride * grid);
         R.park = reads->d_park.p; R.park_stride = stride;
     }
