@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--alleles", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of every CPU-baseline figure (the median is reported)")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
@@ -67,6 +68,138 @@ def parse_args():
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
+
+
+def physical_cores():
+    """Physical cores of the host (unique (physical id, core id) pairs of /proc/cpuinfo); falls back to os.cpu_count()."""
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        n = len(cores) or os.cpu_count()
+    except OSError:
+        n = os.cpu_count()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(1, int(n))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G):
+    """The reference's CPU path beside the GPU number: the oracle — a C restatement of the reference algorithms —
+    with the reference's own thread structure, at threads = 8 (the reference default, genotype.rs:127) and at all physical cores:
+      load     AllAlignments::load: single-threaded BAM loop + recover_and_group_alignments on `threads` workers, reads dealt
+               round-robin (locs.rs:1116-1174) -> orc_load_mt on the first --cpu-sample read pairs of the same workload;
+      filter   run_filter, single-threaded as solve.rs:87-122, on the sample's matrix, all G genotypes;
+      solver   the stages of MainWorker::run (solve.rs:1047-1062: genotypes in contiguous runs over the workers) -> orc_solve_stage_mt
+               on ALL read pairs of the workload (the oracle gets the batch the GPU scored: bit-identical inputs by the parity tests),
+               one genotype per worker and stage: `threads` greedy chains, then `threads` annealing chains.
+    Every stage is linear in the number of read pairs (and the solver stages in the number of chains), so the whole path on the
+    workload — load + run_filter + 5 000 greedy chains + 20 x 20 annealing chains, the default scheme — is composed from the measured
+    rates; median of --cpu-reps runs per figure."""
+    from tests import oracle_ffi as O
+    A = args.alleles
+    ns = min(args.cpu_sample, first.n_pairs)
+    sample = first.slice(0, ns)
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
+    reps = max(1, args.cpu_reps)
+    med = lambda xs: float(np.median(xs))
+    n_phys = physical_cores()
+    thread_sets = [8] if n_phys == 8 else [8, n_phys]
+    # ---- run_filter: single thread whatever `threads` is ----
+    oa = ol.load(sample)
+    Mo = oa.best_aln_matrix()
+    tf = []
+    for _ in range(reps):
+        tc = time.perf_counter()
+        so = O.run_filter(Mo, gts)
+        O.truncate(so, all_ixs, params.filt_diff, 5000, 8)
+        tf.append(time.perf_counter() - tc)
+    t_filter = med(tf)
+    n_good_sample = oa.n_good
+    # ---- solver inputs at full size: the scored batch of the GPU ----
+    solver_pairs, oa_full = 0, None
+    if not args.no_solve:
+        try:
+            avail_kb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
+        except (OSError, StopIteration):
+            avail_kb = 0
+        status, weight, unm, _ = aa.status()
+        off, pa = aa.pair_alns()
+        need_kb = 3 * pa.nbytes // 1024
+        if avail_kb and avail_kb < need_kb:
+            raise RuntimeError(f"cpu_baseline: {need_kb >> 20} GB of host memory needed for the solver sample, {avail_kb >> 20} GB available "
+                               "(use --cpu-sample 0 to skip)")
+        oa_full = O.alns_from_arrays(A, status, weight, unm, off, pa)
+        solver_pairs = aa.n_pairs
+        del pa, off
+    by = {}
+    for T in thread_sets:
+        tl, ts_, tg_ = [], [], []
+        for _ in range(reps):
+            tc = time.perf_counter()
+            ob, secs = ol.load_mt(sample, T)
+            ob.best_aln_matrix()
+            tl.append(time.perf_counter() - tc); ts_.append(secs[0]); tg_.append(secs[1])
+            del ob
+        t_load = med(tl)
+        entry = {"threads": T, "load_s": t_load, "load_serial_s": med(ts_), "load_group_s": med(tg_),
+                 "run_filter_s": t_filter, "reads_scored_per_s": ns / (t_load + t_filter)}
+        # whole path on the workload, composed from rates that are linear in the number of read pairs
+        scale = args.pairs / ns
+        total = (t_load + t_filter) * scale
+        if oa_full is not None:
+            # the best genotypes of the sample's prefilter: what the stages would work on
+            order = np.argsort(-so, kind="stable")
+            ng = min(max(T, 8), len(order))
+            sub_g = gts[order[:ng]]
+            na = min(max(T, 4), len(order))
+            sub_a = gts[order[:na]]
+            tgreedy, tanneal = [], []
+            for rep in range(reps):
+                tc = time.perf_counter()
+                O.solve_stage(ol, oa_full, sub_g, greedy, 1, api.chain_seeds(1000 + rep, ng), threads=T)
+                tgreedy.append(time.perf_counter() - tc)
+                tc = time.perf_counter()
+                O.solve_stage(ol, oa_full, sub_a, anneal, 1, api.chain_seeds(2000 + rep, na), threads=T)
+                tanneal.append(time.perf_counter() - tc)
+            g_cps, a_cps = ng / med(tgreedy), na / med(tanneal)
+            entry.update({"greedy_chains_per_s@R": g_cps, "anneal_chains_per_s@R": a_cps, "solver_read_pairs": solver_pairs,
+                          "greedy_chains_timed": ng, "anneal_chains_timed": na,
+                          "chains_per_s": 5400.0 / (5000.0 / g_cps + 400.0 / a_cps)})
+            total += (5000.0 / g_cps + 400.0 / a_cps) * (args.pairs / solver_pairs)
+        entry["seconds_per_locus"] = total
+        entry["value"] = args.pairs / total
+        by["threads_8" if T == 8 else "all_cores"] = entry
+    if "all_cores" not in by:
+        by["all_cores"] = dict(by["threads_8"])          # an 8-core host: the two coincide
+    best = by["all_cores"]
+    return {"value": best["value"], "unit": "read pairs/s", "cores": best["threads"], "kind": "port",
+            "sample": f"load + run_filter on the first {ns} read pairs x {A} alleles (all {G} genotypes; {n_good_sample} good pairs); "
+                      + (f"solver chains on all {solver_pairs} read pairs (inputs = the batch the GPU scored); " if oa_full is not None else "")
+                      + f"whole path composed for {args.pairs} read pairs and the default scheme; median of {reps}",
+            "cpu_model": cpu_model(), "physical_cores": n_phys, "cpu_count": os.cpu_count(),
+            "by_threads": by,
+            "reads_scored_per_s": best["reads_scored_per_s"], "chains_per_s": best.get("chains_per_s"),
+            "note": "reference-algorithm CPU restatement (oracle/), never 'locityper': the Rust reference cannot be built here"}
 
 
 def main():
@@ -246,7 +379,9 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.pairs} synthetic 150 bp PE read pairs x {A} alleles, 1 locus per GPU, k=25 "
-                               "(BASELINE.json configs[1])",
+                               + ("(BASELINE.json configs[1])" if (total_pairs, A) == (1_000_000, 256) and not one_locus
+                                  else "(one GPU's share of BASELINE.json configs[4])" if A == 4096
+                                  else "(not a BASELINE.json configuration)"),
                    "read_pairs": args.pairs, "alleles": A, "genotypes": G, "k": 25,
                    "records": tot_recs, "cigar_words": tot_cigar, "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
         "reads_scored_per_s": (total_pairs if args.shard_reads else args.pairs if args.shard_chains else world * args.pairs) * args.steps / max(stage_s["score_prefilter"], 1e-9),
@@ -386,39 +521,9 @@ def main():
         ab.close(); del prim
 
     if first is not None:
-        # ---- CPU baseline: the oracle (C restatement of the reference algorithms, single thread:
-        # AllAlignments::load is a single-threaded BAM loop and run_filter is single-threaded in the
-        # reference) on a bounded sample of the same workload ----
+        out["cpu_baseline"] = cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G)
+        out["vs_cpu_baseline"] = {k: reads_per_s / v["value"] for k, v in out["cpu_baseline"]["by_threads"].items()}
         from tests import oracle_ffi as O
-        ns = min(args.cpu_sample, first.n_pairs)
-        sample = first.slice(0, ns)
-        ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
-        tc = time.perf_counter()
-        oa = ol.load(sample)
-        Mo = oa.best_aln_matrix()
-        t_load = time.perf_counter() - tc
-        tc = time.perf_counter()
-        so = O.run_filter(Mo, gts)
-        keep_o = O.truncate(so, all_ixs, params.filt_diff, 5000, 1)
-        t_filter = time.perf_counter() - tc
-        t_solve_cpu, cpu_chains = 0.0, 0
-        if not args.no_solve:
-            # the same scheme, bounded: greedy on the best 64 of the kept genotypes, annealing on the best 2 with 4 attempts
-            tc = time.perf_counter()
-            sub = np.asarray(keep_o[:64], dtype=np.int64)
-            m, v, _ = O.solve_stage(ol, oa, gts[sub], greedy, 1, api.chain_seeds(1000, len(sub)))
-            best2 = sub[np.argsort(-m, kind="stable")[:2]]
-            O.solve_stage(ol, oa, gts[best2], anneal, 4, api.chain_seeds(2000, 8))
-            t_solve_cpu = time.perf_counter() - tc
-            cpu_chains = len(sub) + 8
-        out["cpu_baseline"] = {"value": ns / (t_load + t_filter + t_solve_cpu), "unit": "read pairs/s", "cores": 1, "kind": "port",
-                               "sample": f"first {ns} read pairs of the same workload x {A} alleles, all {G} genotypes prefiltered "
-                                         f"(load {t_load:.2f} s + run_filter {t_filter:.2f} s)"
-                                         + (f", solver scheme bounded to greedy on 64 genotypes + annealing 2 x 4 attempts "
-                                            f"({cpu_chains} chains, {t_solve_cpu:.2f} s)" if cpu_chains else ""),
-                               "reads_scored_per_s": ns / (t_load + t_filter),
-                               "chains_per_s": (cpu_chains / t_solve_cpu) if cpu_chains else None,
-                               "cpu_count": os.cpu_count()}
         if out.get("recruitment") and args.recruit_sample > 0:
             # recruitment on the same core: the oracle's recruit_read_pair on a bounded sample of random pairs
             ot = O.OracleTargets(rprm.minimizer_k, rprm.minimizer_w, rprm.match_frac, rprm.match_length, rprm.thresh_kmer_count)

@@ -187,6 +187,13 @@ int32_t lcty_device_count(void);
 int32_t lcty_ctx_create(int32_t device_id, lcty_ctx** out);
 void    lcty_ctx_destroy(lcty_ctx* ctx);
 int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
+/* Limits of the retry / batching machinery of this context, for tests that must reach those paths with small inputs (no
+ * environment variable changes what the library computes): "transfer_levels", "transfer_scratch_mb", "transfer_waves",
+ * "transfer_cap_new", "transfer_arena" (lcty_recover_alignments: scratch levels, arenas), "depth_table_start" (first width of the
+ * extended depth table), "solve_budget_mb" (device memory for the per-chain state of a solver stage), "solve_chains_per_wave",
+ * "solve_stats" (1: per-stage iteration counts on stderr). value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT.
+ * None of them changes a result. */
+int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value);
 
 /* defaults of model::Params::default (model/mod.rs:108-135) */
 void    lcty_params_default(lcty_params* out);
@@ -202,7 +209,9 @@ int32_t lcty_params_resolve(lcty_params* params, const lcty_bg* bg);
  * (src/model/distr_cache.rs:61-75).
  *   seqs       ASCII allele sequences, concatenated; seq_off[n_alleles+1]
  *   offtarget  off-target k-mer counts (first KmerCounts block), cnt_off[n_alleles+1],
- *              cnt_off[a+1]-cnt_off[a] == len(a)+1-k                                  */
+ *              cnt_off[a+1]-cnt_off[a] == len(a)+1-k
+ *   k          the reference stores k-mers as u128, k <= 63 (src/seq/kmers.rs:8, 43); the device k-mer set uses 64-bit keys
+ *              for k <= 31 and 128-bit keys for 32 <= k <= 63 (two-word slots, the same probing)                          */
 int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles,
                           const uint8_t* seqs, const uint64_t* seq_off,
                           const uint16_t* offtarget, const uint64_t* cnt_off, uint32_t k,
@@ -465,6 +474,8 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
 #define LCTY_K_TRANSFER  5   /* transfer_kernel: alignment recovery */
 #define LCTY_K_RECRUIT   6   /* recruit_kernel: minimizer read recruitment */
 #define LCTY_K_COUNT     7
+/* Timing is opt-in: nothing is recorded before the first lcty_timing_reset on a context (a production run that never reads
+ * timings creates no events); afterwards every launch is bracketed by two events, at most 256 pairs per kernel id kept. */
 int32_t lcty_timing_reset(lcty_ctx* ctx);
 int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms);
 

@@ -38,7 +38,12 @@ class Context:
     def synchronize(self):
         check(lib().lcty_ctx_synchronize(self._h))
 
+    def set_knob(self, name, value):
+        """lcty_ctx_set_knob: a limit of the retry / batching machinery (tests lower them); value < 0 = default."""
+        check(lib().lcty_ctx_set_knob(self._h, name.encode(), int(value)))
+
     def timing_reset(self):
+        """Switches the HIP-event timing of this context on (it is off until the first call) and zeroes the totals."""
         check(lib().lcty_timing_reset(self._h))
 
     def timing(self, kernel):
@@ -422,7 +427,7 @@ def solve(aa, params, scheme=DEFAULT_SCHEME, master_seed=1, priors=None, ploidy=
     n = len(gts)
     pri = np.zeros(n) if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
     ixs = np.arange(n, dtype=np.uint64)
-    threads = 1           # chains are independent on the GPU: the reference's `threads` floor on kept genotypes is 1
+    threads = max(1, int(params.threads))     # run_filter gets data.threads (solve.rs:945); discard gets it too unless it is 1 (797, 1087)
     kept = []
     if params.dont_skip or scheme[0][1] < n:
         if genotypes is None:

@@ -20,7 +20,34 @@ hipEvent_t lcty_ctx::get_event() {
     return e;
 }
 
+// the oldest `count` event pairs of a timer are waited for and added up (bounds what a long timed run keeps alive)
+void lcty_ctx::fold_oldest(lcty::KernelTimer& t, size_t count) {
+    count = std::min(count, t.pending.size());
+    for (size_t i = 0; i < count; i++) {
+        float ms = 0.f;
+        LCTY_HIP(hipEventSynchronize(t.pending[i].second));
+        LCTY_HIP(hipEventElapsedTime(&ms, t.pending[i].first, t.pending[i].second));
+        t.total_ms += ms; t.launches++;
+        event_pool.push_back(t.pending[i].first); event_pool.push_back(t.pending[i].second);
+    }
+    t.pending.erase(t.pending.begin(), t.pending.begin() + static_cast<std::ptrdiff_t>(count));
+}
+
 extern "C" {
+
+// Limits of the retry / batching machinery, settable per context so that tests can reach those paths with small inputs
+// (a value < 0 restores the default). Nothing here changes a result; an unknown name is an error.
+int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value) {
+    return guarded([&] {
+        if (!ctx || !name) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        static const char* const known[] = {"transfer_levels", "transfer_scratch_mb", "transfer_waves", "transfer_cap_new", "transfer_arena",
+                                            "depth_table_start", "solve_budget_mb", "solve_stats", "solve_chains_per_wave", nullptr};
+        bool ok = false;
+        for (const char* const* k = known; *k; k++) ok |= strcmp(*k, name) == 0;
+        if (!ok) fail(LCTY_ERR_INVALID_INPUT, "unknown knob '%s'", name);
+        if (value < 0) ctx->knobs.erase(name); else ctx->knobs[name] = value;
+    });
+}
 
 const char* lcty_last_error(void) { return g_last_error.c_str(); }
 const char* lcty_version(void) { return "locityper_hip 0.1.0 (gfx950)"; }
@@ -262,6 +289,11 @@ int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double fi
     return guarded([&] {
         if (!scores || !ixs || !n_keep) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         if (n == 0) fail(LCTY_ERR_INVALID_INPUT, "no genotypes to filter");
+        // The reference orders with f64::total_cmp (solve.rs:60) and can never see a NaN here: matrix entries are finite or -inf and
+        // priors are checked to be finite when they are read (genotype.rs:1113-1117). `>` is a strict weak order on everything but
+        // NaN, so a NaN (a caller's own priors) is refused instead of handed to std::sort / nth_element.
+        for (uint64_t t = 0; t < n; t++)
+            if (std::isnan(scores[ixs[t]])) fail(LCTY_ERR_INVALID_INPUT, "score of genotype %llu is NaN", static_cast<unsigned long long>(ixs[t]));
         // truncate_ixs (solve.rs:52-84) sorts all indices and keeps a prefix; only the prefix is returned here in sorted order
         // (score descending, ties by index), found by selection: O(n + kept log kept) instead of a sort of 8.4 M indices at
         // 4 096 alleles. What follows the kept prefix in `ixs` is unspecified.
@@ -298,6 +330,7 @@ int32_t lcty_timing_reset(lcty_ctx* ctx) {
         if (!ctx) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         ctx->activate();
         LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->timing_on = true;                          // timing is opt-in: launches before the first reset are not timed
         for (auto& t : ctx->timers) {
             for (auto& pr : t.pending) { ctx->event_pool.push_back(pr.first); ctx->event_pool.push_back(pr.second); }
             t.pending.clear(); t.launches = 0; t.total_ms = 0.0;

@@ -25,7 +25,34 @@ struct lcty_comm {
     lcty_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     int32_t n_ranks = 0, rank = 0;
+    DevBuf<int32_t> d_status;          // one word: the status every rank agrees on before a data collective
 };
+
+namespace {
+
+// A rank whose local part failed (a bad read shard, an arena overflow, a chain that lost its hand-shake ...) must not leave the
+// others inside the data collective for ever: every rank joins this one-word MAX all-reduce unconditionally, with its own status,
+// and all of them raise when any of them failed. `local` runs the rank's part and may throw.
+template <typename F>
+void agree_then(lcty_comm* comm, F&& local) {
+    int32_t rc = LCTY_OK;
+    std::string msg;
+    try { local(); }
+    catch (const Error& e) { rc = e.code; msg = e.what(); }
+    catch (const std::exception& e) { rc = LCTY_ERR_RUNTIME; msg = e.what(); }
+    comm->ctx->activate();
+    hipStream_t s = comm->ctx->stream;
+    comm->d_status.ensure(1);
+    int32_t agreed = rc;
+    comm->d_status.upload(&rc, 1, s);
+    LCTY_NCCL(ncclAllReduce(comm->d_status.p, comm->d_status.p, 1, ncclInt32, ncclMax, comm->comm, s));
+    comm->d_status.download(&agreed, 1, s);
+    LCTY_HIP(hipStreamSynchronize(s));
+    if (rc != LCTY_OK) fail(rc, "%s", msg.c_str());
+    if (agreed != LCTY_OK) fail(agreed, "rank %d: another rank of the communicator failed with status %d before the exchange", comm->rank, agreed);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -64,7 +91,7 @@ int32_t lcty_prefilter_allreduce(lcty_reads* reads, lcty_comm* comm) {
         if (reads->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
         if (reads->n_scores == 0) fail(LCTY_ERR_INVALID_INPUT, "lcty_prefilter_async has not been called on this batch");
         reads->ctx->activate();
-        reads->check_device_error();
+        agree_then(comm, [&] { reads->check_device_error(); });
         hipStream_t s = reads->ctx->stream;
         // in place, on the stream the prefilter kernels ran on: ordered behind them without a host synchronisation
         LCTY_NCCL(ncclAllReduce(reads->d_scores.p, reads->d_scores.p, reads->n_scores, ncclDouble, ncclSum, comm->comm, s));
@@ -88,12 +115,13 @@ int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint1
         const uint64_t per = (n_gt + n_ranks - 1) / n_ranks;                 // block partition of the stage's genotype list
         const uint64_t lo = std::min(rank * per, n_gt), hi = std::min(lo + per, n_gt);
         std::vector<double> local(std::max<uint64_t>(per * attempts, 1), std::numeric_limits<double>::quiet_NaN());
-        if (hi > lo) {
+        agree_then(comm, [&] {
+            if (hi <= lo) return;
             std::vector<double> m(hi - lo), v(hi - lo);
             const int32_t rc = lcty_solve_stage(reads, genotypes + lo * ploidy, hi - lo, ploidy, priors ? priors + lo : nullptr, solver,
                                                 attempts, chain_seeds + lo * attempts, m.data(), v.data(), local.data());
             if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
-        }
+        });
         reads->ctx->activate();
         hipStream_t s = reads->ctx->stream;
         DevBuf<double> d_send, d_recv;

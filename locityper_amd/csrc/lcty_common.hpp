@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -113,16 +114,26 @@ struct lcty_ctx {
     hipDeviceProp_t props{};
     lcty::KernelTimer timers[LCTY_K_COUNT];
     std::vector<hipEvent_t> event_pool;
+    bool timing_on = false;                           // lcty_timing_reset switches the event timing on; a run that never asks pays nothing
+    std::map<std::string, int64_t> knobs;             // lcty_ctx_set_knob: limits that tests lower to exercise retry / batching paths
 
     hipEvent_t get_event();
-    // records start/stop events around fn() on the stream; resolved lazily in lcty_timing_get
+    void fold_oldest(lcty::KernelTimer& t, size_t count);
+    // records start/stop events around fn() on the stream; resolved lazily in lcty_timing_get (or here once 256 pairs wait)
     template <typename F>
     void timed(int kernel, F&& fn) {
+        if (!timing_on) { fn(); return; }
+        lcty::KernelTimer& t = timers[kernel];
+        if (t.pending.size() >= 256) fold_oldest(t, 128);
         hipEvent_t a = get_event(), b = get_event();
         LCTY_HIP(hipEventRecord(a, stream));
         fn();
         LCTY_HIP(hipEventRecord(b, stream));
-        timers[kernel].pending.emplace_back(a, b);
+        t.pending.emplace_back(a, b);
+    }
+    int64_t knob(const char* name, int64_t dflt) const {
+        auto it = knobs.find(name);
+        return it == knobs.end() ? dflt : it->second;
     }
     void activate() const { LCTY_HIP(hipSetDevice(device)); }
 };

@@ -511,7 +511,7 @@ __device__ __forceinline__ void pair_barrier() {
 // alleles with an alignment per read end on each: 209 KB): they are parked in a scratch of the workgroup in global memory
 // (L2-resident: written and read back by the same CU within microseconds); the per-allele tables stay in LDS.
 template <bool EW, bool BIG>
-__device__ __forceinline__ void score_reads_body(const LocusView& L, const ReadsView& R, const uint32_t max_recs, const uint32_t dbg) {
+__device__ __forceinline__ void score_reads_body(const LocusView& L, const ReadsView& R, const uint32_t max_recs) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t A = L.n_alleles;
     const uint32_t mr2 = (max_recs + 1) & ~1u;
@@ -685,7 +685,6 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
         bl0 = wave_max_f64(bl0); bl1 = wave_max_f64(bl1);
         bad0 = wave_sum_u32(bad0); bad1 = wave_sum_u32(bad1);
         pair_barrier<BIG>();
-        if (dbg == 1) { if (lane == 0) R.status[p] = static_cast<uint8_t>(be0 + be1); continue; }   // ablation (LCTY_DBG)
 
         // end 1 is only looked at when end 0 is well mapped (locs.rs:1125-1132); its secondaries only when its
         // primary was pushed
@@ -709,8 +708,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
         if (accepted) {
             // ---------------- K2: unique k-mers -> read weight (locs.rs:968-1002) ----------------
             // (evaluated after the in-bounds test in the reference; no side effects, order irrelevant)
-            if (dbg == 3) { uk0 = uk1 = 5; }
-            else if (regs_ok) pair_unique_kmers_regs(L.kset, L.kset_mask, L.undef_in_set, L.k, len0, len1, bw0, bw1, nm0, nm1, lane, &uk0, &uk1);
+            if (regs_ok) pair_unique_kmers_regs(L.kset, L.kset_mask, L.undef_in_set, L.k, len0, len1, bw0, bw1, nm0, nm1, lane, &uk0, &uk1);
             else {
                 const uint64_t off0 = R.mate_off[2 * p], off1 = R.mate_off[2 * p + 1];
                 uk0 = mate_unique_kmers_global(L.kset, L.kset_mask, L.undef_in_set, L.k,
@@ -787,7 +785,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                     if (pa_base + total_cnt > R.pa_cap) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
                 }
                 pa_base = __shfl(pa_base, 0);
-                const bool room = pa_base + total_cnt <= R.pa_cap && dbg != 4;
+                const bool room = pa_base + total_cnt <= R.pa_cap;
                 // ---------------- pass 3b: emit PairAlignments, contig-ascending ----------------
                 const double emit_weight = EW ? 1.0 : weight;
                 double ew_sum = 0.0;
@@ -860,23 +858,19 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
     }
 }
 
-__global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
-                                                              const uint32_t dbg) {
-    score_reads_body<false, false>(L, R, max_recs, dbg);
+__global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<false, false>(L, R, max_recs);
 }
 // the same with explicit region weights (--reg-weights)
-__global__ __launch_bounds__(WAVE, 3) void score_reads_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
-                                                                       const uint32_t dbg) {
-    score_reads_body<true, false>(L, R, max_recs, dbg);
+__global__ __launch_bounds__(WAVE, 3) void score_reads_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<true, false>(L, R, max_recs);
 }
 // the same two for read pairs whose saved alignments do not fit the LDS (thousands of alleles): parked in global memory
-__global__ __launch_bounds__(WAVE, 3) void score_reads_big_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
-                                                                  const uint32_t dbg) {
-    score_reads_body<false, true>(L, R, max_recs, dbg);
+__global__ __launch_bounds__(WAVE, 3) void score_reads_big_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<false, true>(L, R, max_recs);
 }
-__global__ __launch_bounds__(WAVE, 3) void score_reads_big_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs,
-                                                                           const uint32_t dbg) {
-    score_reads_body<true, true>(L, R, max_recs, dbg);
+__global__ __launch_bounds__(WAVE, 3) void score_reads_big_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<true, true>(L, R, max_recs);
 }
 
 static size_t score_lds_bytes(uint32_t max_recs, uint32_t A) {
@@ -926,13 +920,11 @@ void launch_score_reads(lcty_reads* reads) {
         reads->d_park.ensure(stride * grid);
         R.park = reads->d_park.p; R.park_stride = stride;
     }
-    const char* dbg_env = getenv("LCTY_DBG");      // developer ablation switch; 0 / unset = the real kernel
-    const uint32_t dbg = dbg_env ? static_cast<uint32_t>(atoi(dbg_env)) : 0u;
     // the arena cursor goes back to where the pairs on the device start (0 unless a streaming batch has dropped chunks)
     if (reads->raw_first == 0) reads->d_pa_count.zero(ctx->stream);
     else reads->d_pa_count.upload(&reads->pa_at_raw_first, 1, ctx->stream);
     ctx->timed(LCTY_K_SCORE, [&] {
-        hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs, dbg);
+        hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs);
     });
     LCTY_HIP(hipGetLastError());
 }

@@ -1200,8 +1200,8 @@ struct StageRunner {
         for (uint32_t a = 0; a < A; a++) min_w = std::min(min_w, std::max(loc->n_windows[a], 1u));
         depth_cap = 2 * n_good + 2;                                      // no window can be deeper
         uint64_t first_width = std::min<uint64_t>(4 * n_good / min_w + 64, depth_cap);
-        if (const char* e = getenv("LCTY_DEPTH_TABLE_START"))              // developer / test switch: start narrow, exercise the widening
-            first_width = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        if (ctx->knob("depth_table_start", 0) > 0)                          // lcty_ctx_set_knob: start narrow, exercise the widening
+            first_width = static_cast<uint64_t>(ctx->knob("depth_table_start", 0));
         ensure_depth_table(loc, first_width);
         hipStream_t s = ctx->stream;
 
@@ -1223,8 +1223,8 @@ struct StageRunner {
         // chains are processed in batches so that the per-chain state (4 B per good read) stays bounded
         const uint64_t per_chain = ngp * 4 + static_cast<uint64_t>(V.wstride) * 13;
         uint64_t budget = 64ull << 30;
-        if (const char* e = getenv("LCTY_SOLVE_BUDGET_MB"))                   // developer / test switch: force several batches
-            budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
+        if (ctx->knob("solve_budget_mb", 0) > 0)                              // lcty_ctx_set_knob: force several batches
+            budget = static_cast<uint64_t>(ctx->knob("solve_budget_mb", 0)) << 20;
         gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
         const uint64_t max_chains = gt_per_batch * attempts;
         d_ovf.ensure(1); d_ovf.zero(s);
@@ -1274,7 +1274,7 @@ struct StageRunner {
                     }
                     reads->stat_chains += nch; reads->stat_iterations += static_cast<uint64_t>(sum);
                     reads->stat_accepted += static_cast<uint64_t>(acc);
-                    if (getenv("LCTY_SOLVE_STATS"))
+                    if (ctx->knob("solve_stats", 0))
                         fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f accepted mean=%.0f lut_depth=%u\n",
                                 static_cast<unsigned long long>(nch), sum / nch, mn, mx, acc / nch, loc->lut_ext_depth);
                     break;
@@ -1511,11 +1511,13 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
         std::iota(ixs.begin(), ixs.end(), 0ull);
         uint64_t n = G;
         memset(out, 0, sizeof(*out));
-        // filter (solve.rs:940-945); the reference's floor of `threads` kept genotypes is 1 here: chains do not share a thread pool
+        // filter (solve.rs:940-945): run_filter gets data.threads as the floor of kept genotypes; the stage loop passes ONE_THREAD
+        // to discard_improbable_genotypes when threads == 1 (solve.rs:797, 853) and data.threads otherwise (1087-1089)
+        const uint64_t threads = std::max<uint64_t>(1, prm.threads);
         if (prm.dont_skip || stages[0].in_size < G) {
             std::vector<double> scores(G);
             ok(lcty_prefilter(reads, nullptr, G, ploidy, priors, scores.data()));
-            ok(lcty_truncate(scores.data(), ixs.data(), G, prm.filt_diff, stages[0].in_size, 1, &n));
+            ok(lcty_truncate(scores.data(), ixs.data(), G, prm.filt_diff, stages[0].in_size, threads, &n));
         }
         out->kept_after_filter = n;
         std::vector<double> mean(G, std::numeric_limits<double>::quiet_NaN()), var(G, std::numeric_limits<double>::quiet_NaN());
@@ -1534,7 +1536,7 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
             ok(lcty_chain_seeds(master_seed + static_cast<uint64_t>(si + 1) * 0x9e3779b97f4a7c15ull, n * attempts, seeds.data()));
             ok(lcty_solve_stage(reads, sub.data(), n, ploidy, pri.data(), &stages[si].solver, attempts, seeds.data(), m.data(), v.data(), nullptr));
             for (uint64_t t = 0; t < n; t++) { mean[ixs[t]] = m[t]; var[ixs[t]] = v[t]; att[ixs[t]] = attempts; }
-            if (!last) ok(lcty_discard_improbable(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, out_size, 1, &n));
+            if (!last) ok(lcty_discard_improbable(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, out_size, threads, &n));
         }
         ok(lcty_produce_result(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, 0, out->ixs, out->ln_probs, &out->n_out,
                                &out->quality));

@@ -640,22 +640,22 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             Limits l1; l1.cigar_cap = std::max<uint32_t>(2048, 4 * l0.cigar_cap); l1.dp_dim = 2047; l1.dp_cells = 1u << 20;
             Limits l2; l2.cigar_cap = 4 * l1.cigar_cap; l2.dp_dim = 16383; l2.dp_cells = 1u << 26;
             levels = {l0, l1, l2};
-            if (const char* e = std::getenv("LCTY_TRANSFER_LEVELS")) levels.resize(std::min<size_t>(levels.size(), std::max(1, std::atoi(e))));
+            levels.resize(std::min<size_t>(levels.size(), static_cast<size_t>(std::max<int64_t>(1, ctx->knob("transfer_levels", 3)))));
         }
         uint64_t scratch_budget = 24ull << 30;
-        if (const char* e = std::getenv("LCTY_TRANSFER_SCRATCH_MB")) scratch_budget = std::max<uint64_t>(64, std::strtoull(e, nullptr, 10)) << 20;
+        if (ctx->knob("transfer_scratch_mb", 0) > 0) scratch_budget = std::max<uint64_t>(64, static_cast<uint64_t>(ctx->knob("transfer_scratch_mb", 0))) << 20;
         // one wavefront per workgroup, 128 VGPRs (launch bounds; a few spills are cheaper than the fourth wavefront per SIMD is worth)
         uint32_t waves = 16;
-        if (const char* e = std::getenv("LCTY_TRANSFER_WAVES")) waves = std::max(1, std::atoi(e));
+        waves = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_waves", waves)));
         const uint32_t max_blocks = static_cast<uint32_t>(ctx->props.multiProcessorCount) * waves;
 
         uint32_t cap_new = std::min<uint32_t>(std::max<uint32_t>(4 * A, 64), 1u << 15);
-        if (const char* e = std::getenv("LCTY_TRANSFER_CAP_NEW")) cap_new = std::max(1, std::atoi(e));    // developer / test switch: exercise the retries
+        cap_new = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_cap_new", cap_new)));    // lcty_ctx_set_knob: tests exercise the retries
         const uint32_t words_per_new = std::max<uint32_t>(24, std::min<uint32_t>(levels[0].cigar_cap, rec_cigar + 32));
         // every record can reach every other contig once; beyond 1.5 G records (24 GB) the first launch only counts and the second one fits
         uint64_t arena_recs = std::min<uint64_t>(reads->n_recs * static_cast<uint64_t>(A > 1 ? A - 1 : 1) + 1024, 1500ull << 20);
         uint64_t arena_words = std::min<uint64_t>(arena_recs * std::max<uint32_t>(4, rec_cigar + 8), 6ull << 30);
-        if (const char* e = std::getenv("LCTY_TRANSFER_ARENA")) { arena_recs = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)); arena_words = 2 * arena_recs; }
+        if (ctx->knob("transfer_arena", 0) > 0) { arena_recs = static_cast<uint64_t>(ctx->knob("transfer_arena", 0)); arena_words = 2 * arena_recs; }
         DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords; DevBuf<uint8_t> d_scratch;
         unsigned long long cursors[3] = {0, 0, 0};
         for (int attempt = 0;; attempt++) {

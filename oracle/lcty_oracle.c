@@ -1144,102 +1144,141 @@ static orc_alns* load_impl(const orc_locus* l, const lcty_reads_host* in, const 
 orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err) { return load_impl(l, in, NULL, err); }
 orc_alns* orc_load_recover(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, int* err) { return load_impl(l, in, hap, err); }
 
-static orc_alns* load_impl(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, int* err) {
+/* Scratch of one thread of the load: sequence buffers, the output vector of its PairAlignments. */
+typedef struct {
+    uint8_t* seqbuf; uint8_t* mate_buf[4]; orc_u128* kbuf;
+    pair_vec pv; kept_vec kv;
+} load_scratch;
+
+static void scratch_init(load_scratch* s, uint32_t max_len) {
+    memset(s, 0, sizeof(*s));
+    s->seqbuf = (uint8_t*)malloc(max_len);
+    for (int t = 0; t < 4; t++) s->mate_buf[t] = (uint8_t*)malloc(max_len);
+    s->kbuf = (orc_u128*)malloc(sizeof(orc_u128) * ((size_t)max_len + 1));
+}
+static void scratch_free(load_scratch* s) {
+    for (int t = 0; t < 4; t++) free(s->mate_buf[t]);
+    free(s->seqbuf); free(s->kbuf); free(s->pv.tmp); free(s->pv.buffer); free(s->kv.kept);
+}
+static void prelim_free(prelim* p) {
+    for (size_t i = 0; i < p->n_owned; i++) free(p->owned[i]);
+    free(p->owned); free(p->alns); free(p->pos); free(p->hslot); free(p->hgen);
+}
+
+/* The part of AllAlignments::load that runs inside the single-threaded BAM loop (locs.rs:1116-1150): read_next_alns for both
+ * ends, in_bounds, calculate_read_weight. Returns 1 when the read goes on to recover_and_group_alignments with *weight. */
+static int load_serial_part(load_ctx* c, orc_alns* A, uint64_t r, prelim* p, load_scratch* sc, int with_hap, double* weight_out) {
+    const orc_locus* l = c->l; const lcty_reads_host* in = c->in;
+    const int is_paired = l->bg.is_paired;
+    const uint32_t boundary = l->prm.boundary_size - (uint32_t)l->prm.tweak;     /* locs.rs:1099 */
+    uint64_t ri = in->aln_off[r], r_end = in->aln_off[r + 1];
+    double weight = 1.0;
+    prelim_reset(p, (size_t)(r_end - ri) + (with_hap ? (size_t)(r_end - ri) * l->n_alleles + l->n_alleles : 0));
+    int well_mapped = read_next_alns(c, r, &ri, r_end, 0, &weight, p);    /* locs.rs:1119 */
+    if (c->err) return 0;
+    if (is_paired && well_mapped)
+        well_mapped = read_next_alns(c, r, &ri, r_end, 1, &weight, p);    /* locs.rs:1125-1132 */
+    if (c->err) return 0;
+    if (!well_mapped) { A->status[r] = LCTY_READ_POORLY_MAPPED; return 0; }
+    /* in_bounds — locs.rs:1008-1014 */
+    int inb = 0;
+    for (size_t t = 0; t < p->n_alns; t++) {
+        uint32_t clen = l->infos[p->alns[t].contig].len;
+        uint32_t mid = (p->alns[t].start + p->alns[t].end) / 2;
+        if (boundary <= mid && mid < clen - boundary) { inb = 1; break; }
+    }
+    if (!inb) { A->status[r] = LCTY_READ_OUT_OF_BOUNDS; return 0; }
+    /* calculate_read_weight — locs.rs:968-1002 */
+    uint16_t paired_count = 0;
+    for (int e = 0; e < 2; e++) {
+        uint32_t len = in->mate_len[2 * r + e];
+        if (len == 0) continue;
+        if (e == 1 && !is_paired) continue;     /* mates[1] is None for single-end input */
+        unpack_mate(in, 2 * r + e, sc->seqbuf);
+        uint16_t cnt = count_unique_kmers(l, sc->seqbuf, len, sc->kbuf);
+        A->uniq_kmers[2 * r + e] = cnt;
+        paired_count = (uint16_t)(paired_count + cnt);
+    }
+    double w = l->weight_interc + (double)paired_count * l->weight_mult;
+    w = w < 0.0 ? 0.0 : (w > 1.0 ? 1.0 : w);
+    *weight_out = weight * w;
+    return 1;
+}
+
+/* recover_and_group_alignments for one read (locs.rs:1255-1286): the part the reference runs on `threads` threads.
+ * The read's PairAlignments are appended to sc->pv. */
+static void load_group_part(load_ctx* c, orc_alns* A, uint64_t r, prelim* p, load_scratch* sc, const orc_hap_alns* hap, double weight,
+                            uint64_t* n_good) {
+    const orc_locus* l = c->l; const lcty_reads_host* in = c->in;
+    const int is_paired = l->bg.is_paired;
+    if (hap && weight >= l->prm.min_weight) {                        /* locs.rs:1257-1260 */
+        const uint8_t* ms[2] = {NULL, NULL}; const uint8_t* mr[2] = {NULL, NULL};
+        int mrev[2] = {0, 0};
+        for (int e = 0; e < (is_paired ? 2 : 1); e++) {
+            const uint32_t len = in->mate_len[2 * r + e];
+            unpack_mate(in, 2 * r + e, sc->mate_buf[e]);
+            revcomp(sc->mate_buf[e], len, sc->mate_buf[2 + e]);
+            ms[e] = sc->mate_buf[e]; mr[e] = sc->mate_buf[2 + e];
+        }
+        /* strand of the mate's primary record (MateData::new) */
+        {
+            uint64_t q = in->aln_off[r];
+            mrev[0] = (in->recs[q].flags & LCTY_FLAG_REVERSE) != 0;
+            for (q = q + 1; q < in->aln_off[r + 1]; q++)
+                if (!(in->recs[q].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL))) { mrev[1] = (in->recs[q].flags & LCTY_FLAG_REVERSE) != 0; break; }
+        }
+        transfer_alignments(c, hap, p, r, ms, mr, mrev);
+        if (c->err) return;
+    }
+    if (!(p->best_edit[0] <= p->good_dist[0] && p->best_edit[1] <= p->good_dist[1])) {
+        /* the read is dropped entirely; its MateData is unobservable -> reported as 0 */
+        A->uniq_kmers[2 * r] = A->uniq_kmers[2 * r + 1] = 0;
+        A->status[r] = LCTY_READ_POORLY_MAPPED; return;
+    }
+    for (size_t t = 0; t < p->n_alns; t++) p->alns[t].ln_prob -= p->best_lik[p->alns[t].read_end];   /* normalize_probs */
+    size_t max_alns = weight >= l->prm.min_weight ? LCTY_MAX_USED_ALNS : LCTY_MAX_UNUSED_ALNS;
+    double gw, unm;
+    if (is_paired) identify_paired_end(l, p, max_alns, weight, &sc->pv, &sc->kv, &gw, &unm);
+    else identify_single_end(l, p, max_alns, weight, &sc->pv, &gw, &unm);
+    A->weight[r] = gw; A->unmapped_prob[r] = unm;
+    if (gw >= l->prm.min_weight) { A->status[r] = LCTY_READ_GOOD; (*n_good)++; }
+    else A->status[r] = LCTY_READ_FEW_KMERS;
+}
+
+static orc_alns* alns_alloc(const orc_locus* l, uint64_t R) {
     orc_alns* A = (orc_alns*)calloc(1, sizeof(orc_alns));
-    uint64_t R = in->n_pairs;
     A->n_pairs = R; A->n_alleles = l->n_alleles;
     A->status = (uint8_t*)calloc(R ? R : 1, 1);
     A->weight = (double*)calloc(R ? R : 1, sizeof(double));
     A->unmapped_prob = (double*)calloc(R ? R : 1, sizeof(double));
     A->uniq_kmers = (uint16_t*)calloc(R ? 2 * R : 1, sizeof(uint16_t));
     A->pa_off = (uint64_t*)calloc(R + 1, sizeof(uint64_t));
+    return A;
+}
+
+static orc_alns* load_impl(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, int* err) {
+    uint64_t R = in->n_pairs;
+    orc_alns* A = alns_alloc(l, R);
     load_ctx c; c.l = l; c.in = in; c.err = 0;
-    int is_paired = l->bg.is_paired;
     uint32_t boundary = l->prm.boundary_size - (uint32_t)l->prm.tweak;     /* locs.rs:1099 */
     for (uint32_t a = 0; a < l->n_alleles; a++)
         if (!(l->infos[a].len > 2 * boundary)) { c.err = LCTY_ERR_RUNTIME; }   /* assert! locs.rs:1100 */
 
     prelim p; memset(&p, 0, sizeof(p));
-    pair_vec pv; memset(&pv, 0, sizeof(pv));
-    kept_vec kv; memset(&kv, 0, sizeof(kv));
     uint32_t max_len = 1;
     for (uint64_t m = 0; m < 2 * R; m++) max_len = MAX(max_len, in->mate_len[m]);
-    uint8_t* seqbuf = (uint8_t*)malloc(max_len);
-    uint8_t* mate_buf[4];
-    for (int t = 0; t < 4; t++) mate_buf[t] = (uint8_t*)malloc(max_len);
-    orc_u128* kbuf = (orc_u128*)malloc(sizeof(orc_u128) * ((size_t)max_len + 1));
-
+    load_scratch sc; scratch_init(&sc, max_len);
+    uint64_t n_good = 0;
     for (uint64_t r = 0; r < R && !c.err; r++) {
-        A->pa_off[r] = pv.n;
-        uint64_t ri = in->aln_off[r], r_end = in->aln_off[r + 1];
-        double weight = 1.0;
-        prelim_reset(&p, (size_t)(r_end - ri) + (hap ? (size_t)(r_end - ri) * l->n_alleles + l->n_alleles : 0));
-        int well_mapped = read_next_alns(&c, r, &ri, r_end, 0, &weight, &p);    /* locs.rs:1119 */
-        if (c.err) break;
-        if (is_paired && well_mapped)
-            well_mapped = read_next_alns(&c, r, &ri, r_end, 1, &weight, &p);    /* locs.rs:1125-1132 */
-        if (c.err) break;
-        if (!well_mapped) { A->status[r] = LCTY_READ_POORLY_MAPPED; continue; }
-        /* in_bounds — locs.rs:1008-1014 */
-        int inb = 0;
-        for (size_t t = 0; t < p.n_alns; t++) {
-            uint32_t clen = l->infos[p.alns[t].contig].len;
-            uint32_t mid = (p.alns[t].start + p.alns[t].end) / 2;
-            if (boundary <= mid && mid < clen - boundary) { inb = 1; break; }
-        }
-        if (!inb) { A->status[r] = LCTY_READ_OUT_OF_BOUNDS; continue; }
-        /* calculate_read_weight — locs.rs:968-1002 */
-        uint16_t paired_count = 0;
-        for (int e = 0; e < 2; e++) {
-            uint32_t len = in->mate_len[2 * r + e];
-            if (len == 0) continue;
-            if (e == 1 && !is_paired) continue;     /* mates[1] is None for single-end input */
-            unpack_mate(in, 2 * r + e, seqbuf);
-            uint16_t cnt = count_unique_kmers(l, seqbuf, len, kbuf);
-            A->uniq_kmers[2 * r + e] = cnt;
-            paired_count = (uint16_t)(paired_count + cnt);
-        }
-        double w = l->weight_interc + (double)paired_count * l->weight_mult;
-        w = w < 0.0 ? 0.0 : (w > 1.0 ? 1.0 : w);
-        weight *= w;
-        /* recover_and_group_alignments — locs.rs:1255-1286 */
-        if (hap && weight >= l->prm.min_weight) {                        /* locs.rs:1257-1260 */
-            const uint8_t* ms[2] = {NULL, NULL}; const uint8_t* mr[2] = {NULL, NULL};
-            int mrev[2] = {0, 0};
-            for (int e = 0; e < (is_paired ? 2 : 1); e++) {
-                const uint32_t len = in->mate_len[2 * r + e];
-                unpack_mate(in, 2 * r + e, mate_buf[e]);
-                revcomp(mate_buf[e], len, mate_buf[2 + e]);
-                ms[e] = mate_buf[e]; mr[e] = mate_buf[2 + e];
-            }
-            /* strand of the mate's primary record (MateData::new) */
-            {
-                uint64_t q = in->aln_off[r];
-                mrev[0] = (in->recs[q].flags & LCTY_FLAG_REVERSE) != 0;
-                for (q = q + 1; q < in->aln_off[r + 1]; q++)
-                    if (!(in->recs[q].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL))) { mrev[1] = (in->recs[q].flags & LCTY_FLAG_REVERSE) != 0; break; }
-            }
-            transfer_alignments(&c, hap, &p, r, ms, mr, mrev);
-            if (c.err) break;
-        }
-        if (!(p.best_edit[0] <= p.good_dist[0] && p.best_edit[1] <= p.good_dist[1])) {
-            /* the read is dropped entirely; its MateData is unobservable -> reported as 0 */
-            A->uniq_kmers[2 * r] = A->uniq_kmers[2 * r + 1] = 0;
-            A->status[r] = LCTY_READ_POORLY_MAPPED; continue;
-        }
-        for (size_t t = 0; t < p.n_alns; t++) p.alns[t].ln_prob -= p.best_lik[p.alns[t].read_end];   /* normalize_probs */
-        size_t max_alns = weight >= l->prm.min_weight ? LCTY_MAX_USED_ALNS : LCTY_MAX_UNUSED_ALNS;
-        double gw, unm;
-        if (is_paired) identify_paired_end(l, &p, max_alns, weight, &pv, &kv, &gw, &unm);
-        else identify_single_end(l, &p, max_alns, weight, &pv, &gw, &unm);
-        A->weight[r] = gw; A->unmapped_prob[r] = unm;
-        if (gw >= l->prm.min_weight) { A->status[r] = LCTY_READ_GOOD; A->n_good++; }
-        else A->status[r] = LCTY_READ_FEW_KMERS;
+        A->pa_off[r] = sc.pv.n;
+        double weight;
+        if (!load_serial_part(&c, A, r, &p, &sc, hap != NULL, &weight)) continue;
+        load_group_part(&c, A, r, &p, &sc, hap, weight, &n_good);
     }
-    for (size_t i = 0; i < p.n_owned; i++) free(p.owned[i]);
-    free(p.owned);
-    for (int t = 0; t < 4; t++) free(mate_buf[t]);
-    free(seqbuf); free(kbuf); free(p.alns); free(p.pos); free(p.hslot); free(p.hgen); free(pv.tmp); free(pv.buffer); free(kv.kept);
+    A->n_good = n_good;
+    prelim_free(&p);
+    pair_vec pv = sc.pv; sc.pv.v = NULL;
+    scratch_free(&sc);
     if (c.err) {
         if (err) *err = c.err;
         free(pv.v); orc_alns_free(A);
@@ -1247,6 +1286,128 @@ static orc_alns* load_impl(const orc_locus* l, const lcty_reads_host* in, const 
     }
     A->pa_off[R] = pv.n;
     A->pa = pv.v; A->n_pa = pv.n;
+    if (err) *err = 0;
+    return A;
+}
+
+/* ---- the same load with the reference's thread structure (the CPU baseline of bench.py) --------------------------------------
+ * AllAlignments::load reads the BAM on one thread (locs.rs:1116-1150: read_next_alns, in_bounds, calculate_read_weight), deals the
+ * reads that pass round-robin to `threads` vectors (1149) and runs recover_and_group_alignments on one thread per vector
+ * (1157-1174). Here the input is processed in blocks of reads so that the PrelimAlignments of a block, not of the whole input,
+ * are alive at a time: serial part of the block on the calling thread, then the block's reads grouped by the workers, the
+ * k-th passing read on worker k % threads. The sum of the serial and of the parallel time is what the reference's two phases
+ * take; results are identical to orc_load (per-read outputs do not depend on which thread produced them).
+ * seconds[0] / seconds[1] (optional) receive the wall time of the serial / the grouping phases. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct mt_shared mt_shared;
+typedef struct {
+    mt_shared* sh; uint32_t tid;
+    load_scratch sc; load_ctx c;
+    uint64_t n_good;
+} mt_worker;
+struct mt_shared {
+    const orc_locus* l; const lcty_reads_host* in; const orc_hap_alns* hap; orc_alns* A;
+    uint32_t threads, block;
+    prelim* prelims;             /* [block] */
+    uint64_t* read_of;           /* [block] read index of the k-th passing read of the block */
+    double* weight_of;           /* [block] */
+    uint32_t n_pass; uint64_t first_k;   /* passing reads in this block; number of passing reads before it */
+    uint32_t* pa_thread; uint64_t* pa_start; uint32_t* pa_count;   /* [R] where a read's PairAlignments are */
+    pthread_barrier_t go, done;
+    int stop;
+};
+
+static void* mt_worker_main(void* arg) {
+    mt_worker* w = (mt_worker*)arg; mt_shared* sh = w->sh;
+    for (;;) {
+        pthread_barrier_wait(&sh->go);
+        if (sh->stop) break;
+        for (uint32_t k = 0; k < sh->n_pass; k++) {
+            if ((sh->first_k + k) % sh->threads != w->tid) continue;         /* locs.rs:1149 */
+            const uint64_t r = sh->read_of[k];
+            const size_t before = w->sc.pv.n;
+            if (!w->c.err) load_group_part(&w->c, sh->A, r, &sh->prelims[k], &w->sc, sh->hap, sh->weight_of[k], &w->n_good);
+            sh->pa_thread[r] = w->tid; sh->pa_start[r] = before; sh->pa_count[r] = (uint32_t)(w->sc.pv.n - before);
+        }
+        pthread_barrier_wait(&sh->done);
+    }
+    return NULL;
+}
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+orc_alns* orc_load_mt(const orc_locus* l, const lcty_reads_host* in, const orc_hap_alns* hap, uint32_t threads, double* seconds, int* err) {
+    if (threads < 1) threads = 1;
+    const uint64_t R = in->n_pairs;
+    orc_alns* A = alns_alloc(l, R);
+    load_ctx c; c.l = l; c.in = in; c.err = 0;
+    uint32_t boundary = l->prm.boundary_size - (uint32_t)l->prm.tweak;
+    for (uint32_t a = 0; a < l->n_alleles; a++)
+        if (!(l->infos[a].len > 2 * boundary)) { c.err = LCTY_ERR_RUNTIME; }
+    uint32_t max_len = 1;
+    for (uint64_t m = 0; m < 2 * R; m++) max_len = MAX(max_len, in->mate_len[m]);
+    mt_shared sh; memset(&sh, 0, sizeof(sh));
+    sh.l = l; sh.in = in; sh.hap = hap; sh.A = A; sh.threads = threads;
+    sh.block = MAX(64u, 32u * threads);
+    sh.prelims = (prelim*)calloc(sh.block, sizeof(prelim));
+    sh.read_of = (uint64_t*)malloc(sizeof(uint64_t) * sh.block);
+    sh.weight_of = (double*)malloc(sizeof(double) * sh.block);
+    sh.pa_thread = (uint32_t*)calloc(R ? R : 1, sizeof(uint32_t));
+    sh.pa_start = (uint64_t*)calloc(R ? R : 1, sizeof(uint64_t));
+    sh.pa_count = (uint32_t*)calloc(R ? R : 1, sizeof(uint32_t));
+    pthread_barrier_init(&sh.go, NULL, threads + 1);
+    pthread_barrier_init(&sh.done, NULL, threads + 1);
+    mt_worker* ws = (mt_worker*)calloc(threads, sizeof(mt_worker));
+    pthread_t* tids = (pthread_t*)calloc(threads, sizeof(pthread_t));
+    for (uint32_t t = 0; t < threads; t++) {
+        ws[t].sh = &sh; ws[t].tid = t; ws[t].c = c; scratch_init(&ws[t].sc, max_len);
+        pthread_create(&tids[t], NULL, mt_worker_main, &ws[t]);
+    }
+    load_scratch sc; scratch_init(&sc, max_len);
+    double t_serial = 0.0, t_group = 0.0;
+    uint64_t r = 0;
+    while (r < R && !c.err) {
+        double t0 = now_s();
+        sh.n_pass = 0;
+        while (r < R && sh.n_pass < sh.block && !c.err) {
+            double weight;
+            if (load_serial_part(&c, A, r, &sh.prelims[sh.n_pass], &sc, hap != NULL, &weight)) {
+                sh.read_of[sh.n_pass] = r; sh.weight_of[sh.n_pass] = weight; sh.n_pass++;
+            }
+            r++;
+        }
+        double t1 = now_s();
+        pthread_barrier_wait(&sh.go);
+        pthread_barrier_wait(&sh.done);
+        sh.first_k += sh.n_pass;
+        t_serial += t1 - t0; t_group += now_s() - t1;
+    }
+    sh.stop = 1;
+    pthread_barrier_wait(&sh.go);
+    for (uint32_t t = 0; t < threads; t++) { pthread_join(tids[t], NULL); if (ws[t].c.err && !c.err) c.err = ws[t].c.err; }
+    /* AllAlignments::extend (locs.rs:1168-1172, 1187-1190): the threads' results are concatenated; here in input order */
+    double t2 = now_s();
+    uint64_t total = 0;
+    for (uint64_t q = 0; q < R; q++) total += sh.pa_count[q];
+    A->pa = (lcty_pair_aln*)malloc(sizeof(lcty_pair_aln) * (total ? total : 1));
+    uint64_t at = 0;
+    for (uint64_t q = 0; q < R; q++) {
+        A->pa_off[q] = at;
+        if (sh.pa_count[q]) memcpy(A->pa + at, ws[sh.pa_thread[q]].sc.pv.v + sh.pa_start[q], sizeof(lcty_pair_aln) * sh.pa_count[q]);
+        at += sh.pa_count[q];
+    }
+    A->pa_off[R] = at; A->n_pa = at;
+    t_group += now_s() - t2;
+    for (uint32_t t = 0; t < threads; t++) { A->n_good += ws[t].n_good; free(ws[t].sc.pv.v); scratch_free(&ws[t].sc); }
+    for (uint32_t k = 0; k < sh.block; k++) prelim_free(&sh.prelims[k]);
+    scratch_free(&sc); free(sc.pv.v);
+    free(sh.prelims); free(sh.read_of); free(sh.weight_of); free(sh.pa_thread); free(sh.pa_start); free(sh.pa_count);
+    pthread_barrier_destroy(&sh.go); pthread_barrier_destroy(&sh.done);
+    free(ws); free(tids);
+    if (seconds) { seconds[0] = t_serial; seconds[1] = t_group; }
+    if (c.err) { if (err) *err = c.err; orc_alns_free(A); return NULL; }
     if (err) *err = 0;
     return A;
 }

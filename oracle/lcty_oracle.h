@@ -85,6 +85,12 @@ typedef struct orc_alns orc_alns;
 /* returns NULL and sets *err (LCTY_ERR_*) on invalid data (the reference panics / errors) */
 orc_alns* orc_load(const orc_locus* l, const lcty_reads_host* in, int* err);
 void      orc_alns_free(orc_alns* a);
+/* orc_load / orc_load_recover (hap != NULL) with the reference's thread structure: the BAM loop (read_next_alns, in_bounds,
+ * calculate_read_weight, locs.rs:1116-1150) on the calling thread, recover_and_group_alignments on `threads` workers, the k-th
+ * read that passes the loop on worker k % threads (1149, 1157-1174). Same results as orc_load. seconds[2] (optional): wall time
+ * of the serial and of the grouping phase. The CPU baseline of bench.py. */
+struct orc_hap_alns;
+orc_alns* orc_load_mt(const orc_locus* l, const lcty_reads_host* in, const struct orc_hap_alns* hap, uint32_t threads, double* seconds, int* err);
 /* test hook: orc_alns from arrays (status, weight, unmapped_prob [n_pairs], pa_off [n_pairs+1], pa) */
 orc_alns* orc_alns_from_arrays(uint64_t n_pairs, uint32_t n_alleles, const uint8_t* status, const double* weight,
                                const double* unmapped_prob, const uint64_t* pa_off, const lcty_pair_aln* pa);
@@ -180,6 +186,12 @@ double   orc_assignment_likelihood(const orc_gt_alns* g, const uint16_t* assgn, 
 void     orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
                          const double* priors, const lcty_solver* s, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out);
+
+/* orc_solve_stage on `threads` worker threads, the stage's genotypes dealt in contiguous runs as MainWorker::run does
+ * (solve.rs:1047-1062); same results for any number of threads. The CPU baseline of bench.py. */
+void     orc_solve_stage_mt(const orc_locus* l, const orc_alns* a, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                            const double* priors, const lcty_solver* s, uint32_t attempts, const uint64_t* chain_seeds,
+                            double* lik_mean, double* lik_var, double* liks_out, uint32_t threads);
 
 /* per-read assignment counts of one genotype over its attempts (assgn.rs:94-96, 374-378; solve.rs:821-836) */
 uint64_t orc_assignment_counts(const orc_locus* l, const orc_alns* a, const uint16_t* ids, uint32_t ploidy, const lcty_solver* s,

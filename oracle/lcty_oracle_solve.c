@@ -536,6 +536,42 @@ void orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* geno
     free(liks);
 }
 
+/* The same stage with the reference's worker threads (MainWorker::run, solve.rs:1047-1062): the stage's genotype list is cut into
+ * `threads` contiguous runs (ceil-div of what is left over the workers that are left), one run per worker; a worker handles its
+ * genotypes one after the other (Worker::run, 1108-1146). The reference shuffles the list first (1051) only to balance the runs;
+ * chains here are driven by their own seeds, so the result equals orc_solve_stage for any number of threads. */
+#include <pthread.h>
+typedef struct {
+    const orc_locus* l; const orc_alns* a; const uint16_t* genotypes; uint64_t n_gt; uint32_t ploidy; const double* priors;
+    const lcty_solver* s; uint32_t attempts; const uint64_t* chain_seeds; double* lik_mean; double* lik_var; double* liks_out;
+} stage_task;
+static void* stage_worker(void* arg) {
+    stage_task* t = (stage_task*)arg;
+    orc_solve_stage(t->l, t->a, t->genotypes, t->n_gt, t->ploidy, t->priors, t->s, t->attempts, t->chain_seeds, t->lik_mean, t->lik_var,
+                    t->liks_out);
+    return NULL;
+}
+void orc_solve_stage_mt(const orc_locus* l, const orc_alns* a, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                        const double* priors, const lcty_solver* s, uint32_t attempts, const uint64_t* chain_seeds,
+                        double* lik_mean, double* lik_var, double* liks_out, uint32_t threads) {
+    if (threads < 1) threads = 1;
+    stage_task* tasks = (stage_task*)calloc(threads, sizeof(stage_task));
+    pthread_t* tids = (pthread_t*)calloc(threads, sizeof(pthread_t));
+    uint64_t start = 0; uint32_t used = 0;
+    for (uint32_t i = 0; i < threads && start < n_gt; i++) {
+        const uint64_t rem_workers = threads - i;
+        const uint64_t jobs = (n_gt - start + rem_workers - 1) / rem_workers;         /* fast_ceil_div, solve.rs:1057 */
+        stage_task* t = &tasks[used];
+        t->l = l; t->a = a; t->genotypes = genotypes + start * ploidy; t->n_gt = jobs; t->ploidy = ploidy;
+        t->priors = priors ? priors + start : NULL; t->s = s; t->attempts = attempts; t->chain_seeds = chain_seeds + start * attempts;
+        t->lik_mean = lik_mean + start; t->lik_var = lik_var + start; t->liks_out = liks_out ? liks_out + start * attempts : NULL;
+        pthread_create(&tids[used], NULL, stage_worker, t);
+        used++; start += jobs;
+    }
+    for (uint32_t i = 0; i < used; i++) pthread_join(tids[i], NULL);
+    free(tasks); free(tids);
+}
+
 /* GenotypeAlignments::create_counts + ReadAssignment::update_counts over the attempts of one genotype —
  * assgn.rs:94-96, 374-378 as driven by solve.rs:821-836. read_ixs_out[n_reads + 1], counts_out[n_alns] (or NULL to
  * size them). Returns n_alns. */

@@ -69,6 +69,7 @@ def lib():
     sig("orc_locus_insert_lnprob", D, VP, U32)
     sig("orc_locus_insert_penalty", D, VP)
     sig("orc_load", VP, VP, C.POINTER(ReadsHost), C.POINTER(C.c_int))
+    sig("orc_load_mt", VP, VP, C.POINTER(ReadsHost), VP, U32, VP, C.POINTER(C.c_int))
     sig("orc_alns_free", None, VP)
     sig("orc_alns_from_arrays", VP, U64, U32, VP, VP, VP, VP, VP)
     sig("orc_alns_n_pairs", U64, VP)
@@ -107,6 +108,7 @@ def lib():
     sig("orc_locus_inject_tables", None, VP, VP, VP)
     sig("orc_assignment_likelihood", D, VP, VP, VP)
     sig("orc_solve_stage", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP)
+    sig("orc_solve_stage_mt", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP, U32)
     sig("orc_call_checks", None, VP, U64, U32, VP, U32, VP, U32, VP, C.POINTER(D), C.POINTER(U32))
     sig("orc_hap_alns_new", VP, U32, U32, D)
     sig("orc_hap_alns_free", None, VP)
@@ -228,6 +230,17 @@ class OracleLocus:
         if not h:
             raise ValueError(f"orc_load failed: {err.value}")
         return OracleAlns(h, self.n_alleles)
+
+    def load_mt(self, chunk, threads, hap=None):
+        """The same load with the reference's thread structure (serial BAM loop + `threads` grouping workers).
+        Returns (OracleAlns, (serial seconds, grouping seconds))."""
+        err = C.c_int(0)
+        hs = chunk.host_struct()
+        secs = np.zeros(2)
+        h = lib().orc_load_mt(self._h, C.byref(hs), None if hap is None else hap._h, threads, secs.ctypes.data, C.byref(err))
+        if not h:
+            raise ValueError(f"orc_load_mt failed: {err.value}")
+        return OracleAlns(h, self.n_alleles), (float(secs[0]), float(secs[1]))
 
     def load_recover(self, chunk, hap):
         """AllAlignments::load with alignment recovery (opt_hap_alns = Some)."""
@@ -437,7 +450,8 @@ class OracleGtAlns:
         return lik, parts
 
 
-def solve_stage(locus, alns, genotypes, solver, attempts, chain_seeds, priors=None):
+def solve_stage(locus, alns, genotypes, solver, attempts, chain_seeds, priors=None, threads=None):
+    """threads = None: orc_solve_stage; a number: orc_solve_stage_mt (the reference's worker threads)."""
     genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
     n, ploidy = genotypes.shape
     seeds = np.ascontiguousarray(chain_seeds, dtype=np.uint64)
@@ -446,8 +460,12 @@ def solve_stage(locus, alns, genotypes, solver, attempts, chain_seeds, priors=No
     var = np.zeros(n)
     liks = np.zeros((n, attempts))
     pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
-    lib().orc_solve_stage(locus._h, alns._h, genotypes.ctypes.data, n, ploidy, None if pri is None else pri.ctypes.data,
-                          C.byref(solver), attempts, seeds.ctypes.data, mean.ctypes.data, var.ctypes.data, liks.ctypes.data)
+    args = (locus._h, alns._h, genotypes.ctypes.data, n, ploidy, None if pri is None else pri.ctypes.data,
+            C.byref(solver), attempts, seeds.ctypes.data, mean.ctypes.data, var.ctypes.data, liks.ctypes.data)
+    if threads is None:
+        lib().orc_solve_stage(*args)
+    else:
+        lib().orc_solve_stage_mt(*args, threads)
     return mean, var, liks
 
 

@@ -674,17 +674,17 @@ def test_alignment_recovery_large_stretches_and_long_reads(gpu_ctx):
     st = aa.recover_stats()
     assert n_rec >= 60 and oa.n_good >= 30 and st[0] == len(reads) and st[1] > 0 and st[2] == 0, (n_rec, st)
     # one level only: the library refuses, it never answers differently
-    os.environ["LCTY_TRANSFER_LEVELS"] = "1"
+    gpu_ctx.set_knob("transfer_levels", 1)
     try:
         with pytest.raises(_lib.LocityperError) as ei:
             _recovery_case(gpu_ctx, haps, reads, bg, tf=3)
         assert ei.value.code == cdefs.ERR_UNSUPPORTED
     finally:
-        del os.environ["LCTY_TRANSFER_LEVELS"]
+        gpu_ctx.set_knob("transfer_levels", -1)
 
 
 @pytest.mark.gpu
-def test_alignment_recovery_grows_its_arenas(gpu_ctx, monkeypatch):
+def test_alignment_recovery_grows_its_arenas(gpu_ctx):
     """Output arenas and the per-pair blocks that start too small are enlarged and the launch repeated: same result."""
     from tests.test_oracle_transfer import make_haps
     rng = np.random.default_rng(41)
@@ -696,9 +696,13 @@ def test_alignment_recovery_grows_its_arenas(gpu_ctx, monkeypatch):
         pairs.append({"seq1": haps[src][p1:p1 + 150].decode(), "seq2": haps[src][p2:p2 + 150].decode(),
                       "recs": [(src, p1, 0, "150="), (src, p2, M2 | REV, "150=")]})
     n_ref, _, _ = _recovery_case(gpu_ctx, haps, pairs, make_bg(), tf=3)
-    monkeypatch.setenv("LCTY_TRANSFER_CAP_NEW", "2")
-    monkeypatch.setenv("LCTY_TRANSFER_ARENA", "16")
-    n_small, _, _ = _recovery_case(gpu_ctx, haps, pairs, make_bg(), tf=3)
+    gpu_ctx.set_knob("transfer_cap_new", 2)
+    gpu_ctx.set_knob("transfer_arena", 16)
+    try:
+        n_small, _, _ = _recovery_case(gpu_ctx, haps, pairs, make_bg(), tf=3)
+    finally:
+        gpu_ctx.set_knob("transfer_cap_new", -1)
+        gpu_ctx.set_knob("transfer_arena", -1)
     assert n_small == n_ref > 300
 
 

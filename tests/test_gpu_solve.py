@@ -252,33 +252,35 @@ def test_solver_parameter_sweep(gpu_ctx, prm):
     assert np.array_equal(off, ooff) and np.array_equal(counts, ocounts)
 
 
-def test_depth_table_widening_gives_the_same_chains(gpu_ctx, monkeypatch):
+def test_depth_table_widening_gives_the_same_chains(gpu_ctx):
     """A chain that runs past the depth table raises a flag and the batch is repeated with a wider table: the result
     must not depend on where the table started."""
     gts = api.generate_genotypes(4, 2)
     seeds = api.chain_seeds(8, 2 * len(gts))
     out = []
-    for start in (None, "256"):
-        if start is None:
-            monkeypatch.delenv("LCTY_DEPTH_TABLE_START", raising=False)
-        else:
-            monkeypatch.setenv("LCTY_DEPTH_TABLE_START", start)
-        L, p, loc, aa, ol, oa = setup(gpu_ctx, 4, 20000, 4000)          # ~600 mates per window: far beyond 256
-        res = [api.solve_stage(aa, gts, api.default_solver(k), 2, seeds)[2] for k in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL)]
+    for start in (-1, 256):
+        gpu_ctx.set_knob("depth_table_start", start)
+        try:
+            L, p, loc, aa, ol, oa = setup(gpu_ctx, 4, 20000, 4000)          # ~600 mates per window: far beyond 256
+            res = [api.solve_stage(aa, gts, api.default_solver(k), 2, seeds)[2] for k in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL)]
+        finally:
+            gpu_ctx.set_knob("depth_table_start", -1)
         out.append(res)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-def test_chain_batches_do_not_change_results(gpu_ctx, monkeypatch):
+def test_chain_batches_do_not_change_results(gpu_ctx):
     """Stages whose per-chain state exceeds the memory budget run in several batches of genotypes."""
     L, p, loc, aa, ol, oa = setup(gpu_ctx, 8, 3000, 20000)
     gts = api.generate_genotypes(8, 2)
     seeds = api.chain_seeds(21, 3 * len(gts))
     pri = -0.5 * np.arange(len(gts), dtype=np.float64)
-    monkeypatch.delenv("LCTY_SOLVE_BUDGET_MB", raising=False)
     one = api.solve_stage(aa, gts, api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds, pri)
-    monkeypatch.setenv("LCTY_SOLVE_BUDGET_MB", "1")                      # a few genotypes per batch
-    many = api.solve_stage(aa, gts, api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds, pri)
+    gpu_ctx.set_knob("solve_budget_mb", 1)                               # a few genotypes per batch
+    try:
+        many = api.solve_stage(aa, gts, api.default_solver(cdefs.SOLVER_GREEDY), 3, seeds, pri)
+    finally:
+        gpu_ctx.set_knob("solve_budget_mb", -1)
     assert np.array_equal(one[2], many[2]) and np.array_equal(one[0], many[0])
     assert api.solve_stats(aa)[0] == 3 * len(gts)
 

@@ -202,3 +202,32 @@ def test_kmer_counts_parse_known_answers_and_errors():
         with pytest.raises((_lib.LocityperError, ValueError)) as e:
             api.parse_kmer_counts(bad)
         assert not isinstance(e.value, _lib.LocityperError) or e.value.code in (cdefs.ERR_INVALID_DATA, cdefs.ERR_INVALID_INPUT)
+
+
+def test_truncate_refuses_nan_and_orders_infinities():
+    """ADVICE r1: `>` is not a strict weak order with a NaN (undefined behaviour in std::sort / nth_element). The reference sorts with
+    f64::total_cmp (solve.rs:60) and never sees a NaN (priors are checked finite, genotype.rs:1116) -> refused up front; +-inf sort."""
+    ixs = np.arange(6, dtype=np.uint64)
+    s = np.array([0.0, -1.0, np.nan, -3.0, -2.0, -5.0])
+    with pytest.raises(_lib.LocityperError) as e:
+        api.truncate_ixs(s, ixs, 2.5, 2, 1)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
+    s = np.array([0.0, -np.inf, -1.0, np.inf, -np.inf, -2.0])
+    keep = api.truncate_ixs(s, ixs, 1.5, 2, 1)
+    assert keep.tolist() == O.truncate(s, ixs, 1.5, 2, 1).tolist() == [3, 0]
+    keep = api.truncate_ixs(s, ixs, 1.5, 5, 1)              # min_size reaches into the -inf tie: both stay (partition_point)
+    assert keep.tolist() == O.truncate(s, ixs, 1.5, 5, 1).tolist() == [3, 0, 2, 5, 1, 4]
+
+
+def test_truncate_keeps_at_least_threads_genotypes():
+    """run_filter passes data.threads to truncate_ixs (solve.rs:945, 80-81): with the default 8 threads at least 8 genotypes stay."""
+    s = -np.arange(20, dtype=np.float64) * 100.0
+    ixs = np.arange(20, dtype=np.uint64)
+    assert len(api.truncate_ixs(s, ixs, 150.0, 1, 1)) == 2
+    assert api.truncate_ixs(s, ixs, 150.0, 1, 8).tolist() == O.truncate(s, ixs, 150.0, 1, 8).tolist() == list(range(8))
+    assert api.default_params().threads == 8
+
+
+def test_knobs_are_named_and_checked():
+    L = _lib.lib()
+    assert L.lcty_ctx_set_knob(None, b"solve_budget_mb", 1) == cdefs.ERR_INVALID_INPUT

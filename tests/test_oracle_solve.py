@@ -228,3 +228,25 @@ def test_assignment_counts_bookkeeping():
     # one attempt == the assignment orc_solve reports
     off1, c1 = O.assignment_counts(ol, oa, gt, greedy, 1, seeds[:1])
     assert np.array_equal(off1, off) and set(np.unique(c1)) <= {0, 1}
+
+
+def test_threaded_oracle_equals_the_single_thread_one():
+    """The CPU baseline of bench.py runs the oracle with the reference's thread structure (locs.rs:1149-1174, solve.rs:1047-1062):
+    the same results for any number of threads, including more threads than reads / genotypes and ragged last blocks."""
+    L, p, ol, oa = small_case(n_pairs=700)
+    chunk = L.reads(0, 700)
+    s0 = oa.status
+    for threads in (1, 3, 8, 64):
+        ob, secs = ol.load_mt(chunk, threads)
+        assert ob.n_good == oa.n_good and secs[0] > 0 and secs[1] > 0
+        assert np.array_equal(ob.status, s0) and np.array_equal(ob.weight, oa.weight) and np.array_equal(ob.uniq_kmers, oa.uniq_kmers)
+        assert np.array_equal(ob.unmapped_prob, oa.unmapped_prob)
+        assert np.array_equal(oa.pa_off, ob.pa_off) and oa.pair_alns.tobytes() == ob.pair_alns.tobytes()
+    gts = O.generate_genotypes(6, 2)
+    seeds = np.arange(len(gts) * 2, dtype=np.uint64) * 104729 + 5
+    pri = -0.25 * np.arange(len(gts), dtype=np.float64)
+    for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+        ref = O.solve_stage(ol, oa, gts, O.default_solver(kind), 2, seeds, priors=pri)
+        for threads in (1, 4, 5, 40):
+            got = O.solve_stage(ol, oa, gts, O.default_solver(kind), 2, seeds, priors=pri, threads=threads)
+            assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
