@@ -194,6 +194,10 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  * "solve_stats" (1: per-stage iteration counts on stderr). value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT.
  * None of them changes a result. */
 int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value);
+/* The solver stages keep their per-chain device state (32 B per chain and good read pair: ~150 GB for the 5 000 greedy chains of
+ * the default scheme at 1 M read pairs; batches of chains when the device has less) with the context between stages and loci;
+ * this releases it (the next stage allocates again). */
+int32_t lcty_ctx_trim(lcty_ctx* ctx);
 
 /* defaults of model::Params::default (model/mod.rs:108-135) */
 void    lcty_params_default(lcty_params* out);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "lcty_discard_improbable": (I32, [VP, VP, VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),
     "lcty_ctx_set_knob": (I32, [VP, C.c_char_p, C.c_int64]),
+    "lcty_ctx_trim": (I32, [VP]),
     "lcty_timing_reset": (I32, [VP]),
     "lcty_timing_get": (I32, [VP, I32, P(U64), P(D)]),
 }

@@ -42,6 +42,10 @@ class Context:
         """lcty_ctx_set_knob: a limit of the retry / batching machinery (tests lower them); value < 0 = default."""
         check(lib().lcty_ctx_set_knob(self._h, name.encode(), int(value)))
 
+    def trim(self):
+        """lcty_ctx_trim: release the solver workspaces kept between stages."""
+        check(lib().lcty_ctx_trim(self._h))
+
     def timing_reset(self):
         """Switches the HIP-event timing of this context on (it is off until the first call) and zeroes the totals."""
         check(lib().lcty_timing_reset(self._h))

@@ -82,6 +82,7 @@ void lcty_ctx_destroy(lcty_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -91,6 +92,18 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx) {
         if (!ctx) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         ctx->activate();
         LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->side) LCTY_HIP(hipStreamSynchronize(ctx->side));
+    });
+}
+
+// releases the solver workspaces the context keeps between stages and loci (they are rebuilt by the next stage)
+int32_t lcty_ctx_trim(lcty_ctx* ctx) {
+    return guarded([&] {
+        if (!ctx) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        ctx->activate();
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->side) LCTY_HIP(hipStreamSynchronize(ctx->side));
+        for (auto& w : ctx->solve_ws) w.release_all();
     });
 }
 

@@ -99,6 +99,17 @@ struct DevBuf {
     }
 };
 
+// One non-trivial read of one solver chain / a location beyond its second (lcty_solve.hip)
+struct __attribute__((aligned(32))) ChainRec {
+    uint32_t rp_cur;                // good-read index (24 bit) | current location << 24 (the only field a move changes)
+    uint32_t meta;                  // number of locations (8 bit) | index of location 2 in the chain's ExtraLoc run << 8
+    double lp0, lp1;                // ln-probability of locations 0 and 1
+    uint32_t win0, win1;            // their windows: w1 | w2 << 16
+};
+static_assert(sizeof(ChainRec) == 32, "ChainRec layout");
+struct __attribute__((aligned(16))) ExtraLoc { double lp; uint32_t win; uint32_t _pad; };
+static_assert(sizeof(ExtraLoc) == 16, "ExtraLoc layout");
+
 struct KernelTimer {
     uint64_t launches = 0;
     double total_ms = 0.0;
@@ -121,16 +132,37 @@ struct lcty_ctx {
     void fold_oldest(lcty::KernelTimer& t, size_t count);
     // records start/stop events around fn() on the stream; resolved lazily in lcty_timing_get (or here once 256 pairs wait)
     template <typename F>
-    void timed(int kernel, F&& fn) {
+    void timed(int kernel, F&& fn, hipStream_t on = nullptr) {
         if (!timing_on) { fn(); return; }
+        if (!on) on = stream;
         lcty::KernelTimer& t = timers[kernel];
         if (t.pending.size() >= 256) fold_oldest(t, 128);
         hipEvent_t a = get_event(), b = get_event();
-        LCTY_HIP(hipEventRecord(a, stream));
+        LCTY_HIP(hipEventRecord(a, on));
         fn();
-        LCTY_HIP(hipEventRecord(b, stream));
+        LCTY_HIP(hipEventRecord(b, on));
         t.pending.emplace_back(a, b);
     }
+    // Second stream of the context: the last solver stage of a locus (a few long serial chains) runs here while the next
+    // locus of a queue is scored, prefiltered and greedily solved on `stream` (lcty_solve_queue).
+    hipStream_t side = nullptr;
+    hipStream_t side_stream() {
+        if (!side) LCTY_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        return side;
+    }
+    // Per-chain device state of the solver stages (lcty_solve.hip), one per stream of the context. Grow-only and kept between
+    // stages and loci: at 1 M read pairs the records of 5 000 chains are ~150 GB, and allocating / freeing that per stage costs
+    // more than the stage. lcty_ctx_trim releases it.
+    struct SolveWorkspace {
+        lcty::DevBuf<lcty::ChainRec> recs; lcty::DevBuf<lcty::ExtraLoc> extra;
+        uint32_t extra_cap = 0, extra_for_ploidy = 0; uint64_t extra_for_ngp = 0;
+        lcty::DevBuf<uint16_t> gt; lcty::DevBuf<uint8_t> cgc; lcty::DevBuf<uint32_t> cdepth, cnnt, ctotw, ovf; lcty::DevBuf<uint64_t> seeds;
+        lcty::DevBuf<double> pri, liks, parts, cww, caln;
+        void release_all() {
+            recs.release(); extra.release(); gt.release(); cgc.release(); cdepth.release(); cnnt.release(); ctotw.release(); ovf.release();
+            seeds.release(); pri.release(); liks.release(); parts.release(); cww.release(); caln.release(); extra_cap = 0;
+        }
+    } solve_ws[2];
     int64_t knob(const char* name, int64_t dflt) const {
         auto it = knobs.find(name);
         return it == knobs.end() ? dflt : it->second;

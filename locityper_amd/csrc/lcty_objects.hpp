@@ -111,11 +111,6 @@ struct lcty_reads {
     void ensure_good_index();
     // allele-major location table of the solver stages (lcty_solve.hip), rows of ngp entries
     lcty::DevBuf<uint8_t> d_loc_table;       // [A][ngp] 32-byte LocEntry cells
-    // per-chain state of the solver stages, kept between stages (allocating and freeing tens of GB per stage costs more than a stage)
-    struct SolveWorkspace {
-        lcty::DevBuf<uint16_t> gt; lcty::DevBuf<uint8_t> cgc; lcty::DevBuf<uint32_t> nt, cdepth, cnnt, ovf; lcty::DevBuf<uint64_t> seeds;
-        lcty::DevBuf<double> pri, liks, parts, cww, caln;
-    } solve_ws;
     uint64_t ngp = 0;
     bool loc_table_valid = false;
     uint64_t stat_chains = 0, stat_iterations = 0, stat_accepted = 0;   // last lcty_solve_stage

@@ -15,15 +15,20 @@
 //   build_loc_table_kernel   K11 input: GenotypeAlignments::new (assgn.rs:41-84) is NOT materialised; the possible
 //        locations of a read on a genotype (extend_read_gt_alns, windows.rs:762-797) are re-derived on demand as a
 //        merge of <= ploidy sorted runs plus "both mates unmapped".
-//   solve_init_kernel<P>     one 256-thread workgroup per (genotype, attempt) chain:
+//   solve_init_kernel<P>     one 256-thread workgroup per (genotype, attempt) chain, streaming the table rows of its alleles:
 //        K12 apply_tweak (assgn.rs:127-151): window distributions (generate_windows, windows.rs:478-486;
 //            neighb_info 439-445; get_distribution distr_cache.rs:83-92)
 //        K13 ReadAssignment::try_new (assgn.rs:199-226): initial location of every read, depth histogram
-//            (LDS atomics), alignment likelihood, ordered list of non-trivial reads
-//   solve_loop_kernel<P>     one wavefront per chain, window state in LDS:
-//        K14 Greedy / SimAnneal (src/solvers/stoch.rs:81-120, 195-245). The chain is serial by definition; the
-//            `sample_size` candidate reads of a greedy step are evaluated by different lanes, and many chains
-//            share a CU to hide the gather latency of each other.
+//            (LDS atomics), alignment likelihood, and the chain's ordered list of non-trivial reads as 32-byte
+//            RECORDS: everything a move of that read can need — its possible locations on the genotype in order
+//            (ln-probability, tweaked windows) and the current one. The state-independent half of every later move
+//            (two table gathers, the merge of the contigs' runs, the tweak draws) is done here once per (chain, read),
+//            coalesced, instead of once per candidate behind three dependent random gathers.
+//   greedy_loop_kernel<LPC>  K14 Greedy (stoch.rs:81-120): 64 / LPC chains per wavefront, a row of LPC lanes per chain,
+//            lane = candidate read of the iteration; one 32-byte record gather per candidate, issued two iterations
+//            ahead (the greedy random stream does not depend on the moves); window depths of the chain in LDS.
+//   anneal_loop_kernel       K14 SimAnneal (stoch.rs:195-245): a chain wavefront plus a staging wavefront that runs the
+//            random stream ahead and stages the records of the coming draws in an LDS ring.
 //
 // Randomness is the injected per-chain seed described in oracle/lcty_oracle.h (the reference's rand adaptors
 // are not in its tree): counter-based draws for tweaks / random starts, xoshiro256++ for the solver loop.
@@ -31,6 +36,7 @@
 #include <cmath>
 #include <memory>
 #include <numeric>
+#include <thread>
 
 #include "lcty_objects.hpp"
 
@@ -71,6 +77,9 @@ struct __attribute__((aligned(32))) LocEntry {
 };
 static_assert(sizeof(LocEntry) == 32, "LocEntry layout");
 
+// ChainRec (lcty_common.hpp): one non-trivial read of one chain, all a move can need in one 32-byte gather. Locations in the
+// order of extend_read_gt_alns (windows.rs:793: ln-probability descending, ties in push order); windows after apply_tweak.
+
 struct SolveView {
     // locus
     uint32_t A, window, left_padding, tweak;
@@ -97,7 +106,10 @@ struct SolveView {
     const uint64_t* seeds;          // [n_chains]
     const double* priors;           // [n_gt] or null
     lcty_solver solver;
-    uint32_t* non_trivial;          // [n_chains][ngp] read (24 bit) | current location << 24; trivial reads never move
+    ChainRec* recs;                 // [n_chains][ngp] the chain's non-trivial reads in read order; trivial reads never move
+    ExtraLoc* extra;                // [n_chains][extra_cap] locations 2.. of reads with more than two
+    uint32_t extra_cap;
+    uint32_t* c_totw;               // [n_chains] windows of the chain's genotype (2 + sum of n_windows)
     uint32_t wstride;               // per-chain stride of the window arrays (>= 2 + ploidy * max n_windows)
     double* c_ww;                   // [n_chains][wstride] window weights (0 = trivial distribution)
     uint8_t* c_gc;                  // [n_chains][wstride]
@@ -360,20 +372,24 @@ struct Move {                  // ReassignmentTarget + what reassign() needs
     double ddiff;              // depth_lik_diff(w1, w2, w3, w4) at the time the move was evaluated
 };
 
-// location `ta` (and `tb`) of read rp: ln_prob + tweaked windows
-template <uint32_t P>
-__device__ __forceinline__ void fetch_two(const SolveView& V, const Geno<P>& G, const Locs<P>& L, uint64_t seed, uint32_t rp, uint32_t ta,
-                                          uint32_t tb, Move& m) {
-    LocIter<P> it; it.start(L);
-    LocOut o;
-    for (uint32_t t = 0; t < L.nw && it.next(L, V, o); t++) {
-        if (t == ta) { m.lp_old = o.lp; loc_windows(V, G, o, seed, rp, t, &m.w1, &m.w2); }
-        if (t == tb) { m.lp_new = o.lp; loc_windows(V, G, o, seed, rp, t, &m.w3, &m.w4); }
-        if (t >= ta && t >= tb) break;
+// ---------------- K12 + K13: one 256-thread workgroup per chain ----------------
+// inclusive prefix sum over the 256 threads of the workgroup (wave shuffles + one LDS exchange); *total = sum of all
+__device__ __forceinline__ uint32_t block_prefix_excl(uint32_t v, uint32_t lane, uint32_t wave, uint32_t* wave_sums, uint32_t* total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), o));
+        if (lane >= static_cast<uint32_t>(o)) incl += up;
     }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t q = 0; q < wave; q++) before += wave_sums[q];
+    *total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    __syncthreads();
+    return before + incl - v;
 }
 
-// ---------------- K12 + K13: one 256-thread workgroup per chain ----------------
 template <uint32_t P>
 __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -385,7 +401,8 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = V.seeds[chain];
     Geno<P> G; G.init(V, gi);
-    uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
+    ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
+    ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
     double* ww = V.c_ww + static_cast<uint64_t>(chain) * V.wstride;
     uint8_t* wgc = V.c_gc + static_cast<uint64_t>(chain) * V.wstride;
 
@@ -411,36 +428,51 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     }
     __syncthreads();
 
-    // K13: initial assignment, depth histogram, non-trivial reads
+    // K13: initial assignment, depth histogram, the records of the non-trivial reads
     const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
     double aln_part = 0.0;
-    uint32_t nt_total = 0;
+    uint32_t nt_total = 0, ex_total = 0;
     for (uint32_t base = 0; base < V.n_good; base += 256) {
         const uint32_t rp = base + tid;
-        bool nontrivial = false;
+        Locs<P> L; L.nw = 0;
         uint32_t a0 = 0;
         if (rp < V.n_good) {
-            Locs<P> L; locs_init(L, V, rp, G);
-            if (L.nw > 255) atomicMax(V.overflow, 2u);                           // the list keeps the location in 8 bits
+            locs_init(L, V, rp, G);
+            if (L.nw > 255) atomicMax(V.overflow, 2u);                           // a record keeps the location in 8 bits
             if (L.nw > 1 && random_start)
                 a0 = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
-            Move m; m.w1 = m.w2 = 0; m.lp_old = 0.0;
-            fetch_two(V, G, L, seed, rp, a0, a0, m);
-            atomicAdd(&depth[m.w1], 1u);
-            atomicAdd(&depth[m.w2], 1u);
-            aln_part += m.lp_old;
-            nontrivial = L.nw > 1;
         }
-        // ordered compaction of the non-trivial reads (assgn.rs:61-63)
-        const unsigned long long bal = __ballot(nontrivial);
-        if (lane == 0) wave_cnt[wave] = static_cast<uint32_t>(__popcll(bal));
-        __syncthreads();
-        uint32_t before = nt_total;
-        for (uint32_t q = 0; q < wave; q++) before += wave_cnt[q];
-        if (nontrivial) nontriv[before + static_cast<uint32_t>(__popcll(bal & ((1ull << lane) - 1ull)))] = rp | (a0 << 24);
-        nt_total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+        const bool nontrivial = L.nw > 1;
+        const uint32_t n_extra = L.nw > 2 ? min(L.nw, 255u) - 2u : 0u;
+        // ordered compaction of the non-trivial reads (assgn.rs:61-63) and of their locations beyond the second
+        uint32_t chunk_nt, chunk_ex;
+        const uint32_t slot = nt_total + block_prefix_excl(nontrivial ? 1u : 0u, lane, wave, wave_cnt, &chunk_nt);
+        const uint32_t eix = ex_total + block_prefix_excl(n_extra, lane, wave, wave_cnt, &chunk_ex);
+        nt_total += chunk_nt; ex_total += chunk_ex;
+        if (L.nw > 0) {
+            ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = min(L.nw, 255u) | (eix << 8);
+            rec.lp0 = rec.lp1 = 0.0; rec.win0 = rec.win1 = 0;
+            const bool room = eix + n_extra <= V.extra_cap;
+            LocIter<P> it; it.start(L);
+            LocOut o;
+            for (uint32_t t = 0; t < min(L.nw, 255u) && it.next(L, V, o); t++) {
+                uint32_t wa, wb;
+                loc_windows(V, G, o, seed, rp, t, &wa, &wb);
+                const uint32_t win = wa | (wb << 16);
+                if (t == 0) { rec.lp0 = o.lp; rec.win0 = win; }
+                else if (t == 1) { rec.lp1 = o.lp; rec.win1 = win; }
+                else if (room) { ExtraLoc e; e.lp = o.lp; e.win = win; e._pad = 0; extra[eix + t - 2] = e; }
+                if (t == a0) {
+                    atomicAdd(&depth[wa], 1u);
+                    atomicAdd(&depth[wb], 1u);
+                    aln_part += o.lp;
+                }
+            }
+            if (nontrivial) recs[slot] = rec;
+        }
     }
+    if (ex_total > V.extra_cap) { atomicMax(V.overflow, 4u); atomicMax(V.overflow + 1, ex_total); }
+    if (ex_total >= (1u << 24)) atomicMax(V.overflow, 2u);
     red[tid] = aln_part;
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) {
@@ -449,15 +481,15 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     }
     uint32_t* gdepth = V.c_depth + static_cast<uint64_t>(chain) * V.wstride;
     for (uint32_t w = tid; w < G.total_w; w += 256) gdepth[w] = depth[w];
-    if (tid == 0) { V.c_aln[chain] = red[0]; V.c_nnt[chain] = nt_total; }
+    if (tid == 0) { V.c_aln[chain] = red[0]; V.c_nnt[chain] = nt_total; V.c_totw[chain] = G.total_w; }
 }
 
 // window state of one chain: depth (25 bit) | GC bin << 25 in LDS, weights in the chain's row of c_ww (L2)
 constexpr uint32_t DEPTH_MASK = 0x1FFFFFFu;
 struct Chain {
     const SolveView* V;
-    uint32_t* wd;               // LDS
-    const double* ww;           // global
+    uint32_t* wd;               // LDS: the chain's windows
+    const double* ww;           // window weights: LDS (annealing) or the chain's row of c_ww
     // WindowDistr::ln_prob (distr_cache.rs:34-39) through the depth table
     __device__ __forceinline__ double wlp(uint32_t w, uint32_t g, uint32_t d) const {
         const double weight = ww[w];
@@ -506,11 +538,273 @@ struct Chain {
     }
 };
 
-// ---------------- K14: one wavefront per chain (+ a staging wavefront for annealing) ----------------
+// the `cur` word of a record: served by L2 (agent scope), where a wavefront's own stores arrive in program order
+__device__ __forceinline__ uint32_t load_rp_cur(const ChainRec* r) {
+    return __hip_atomic_load(&r->rp_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_rp_cur(ChainRec* r, uint32_t v) {
+    __hip_atomic_store(&r->rp_cur, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the immutable part of a record: two 16-byte loads
+struct RecBody { uint32_t meta; double lp0, lp1; uint32_t win0, win1; };
+__device__ __forceinline__ RecBody load_body(const ChainRec* r) {
+    const uint4 a = *reinterpret_cast<const uint4*>(r);
+    const uint4 b = *(reinterpret_cast<const uint4*>(r) + 1);
+    RecBody o;
+    o.meta = a.y;
+    o.lp0 = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
+    o.lp1 = __hiloint2double(static_cast<int>(b.y), static_cast<int>(b.x));
+    o.win0 = b.z; o.win1 = b.w;
+    return o;
+}
+// location t of a record
+__device__ __forceinline__ void rec_loc(const RecBody& b, const ExtraLoc* extra, uint32_t t, double* lp, uint32_t* win) {
+    if (t == 0) { *lp = b.lp0; *win = b.win0; }
+    else if (t == 1) { *lp = b.lp1; *win = b.win1; }
+    else { const ExtraLoc e = extra[(b.meta >> 8) + t - 2]; *lp = e.lp; *win = e.win; }
+}
+
+// ReassignmentTarget::random (assgn.rs:451-471) from a generator; uniform over the lanes that share `rng`
+template <typename RNG>
+__device__ __forceinline__ void random_move(const Chain& C, ChainRec* recs, const ExtraLoc* extra, uint32_t nnt, RNG& rng, Move& m) {
+    m.slot = static_cast<uint32_t>(rng.below(nnt));
+    const uint32_t packed = load_rp_cur(&recs[m.slot]);
+    const RecBody b = load_body(&recs[m.slot]);
+    const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24, total = b.meta & 0xFFu;
+    uint32_t new_assgn;
+    if (total == 2) new_assgn = 1 - old_assgn;
+    else {
+        const uint32_t i = 1 + static_cast<uint32_t>(rng.below(total - 1));
+        new_assgn = i <= old_assgn ? i - 1 : i;
+    }
+    m.rp = rp; m.new_assgn = new_assgn;
+    uint32_t wo, wn;
+    rec_loc(b, extra, old_assgn, &m.lp_old, &wo);
+    rec_loc(b, extra, new_assgn, &m.lp_new, &wn);
+    m.w1 = wo & 0xFFFFu; m.w2 = wo >> 16; m.w3 = wn & 0xFFFFu; m.w4 = wn >> 16;
+    m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+}
+
+// ---- row operations: a row = the LPC lanes of one chain (LPC = 16: DPP inside a row of 16; wider: butterflies) ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <uint32_t LPC>
+__device__ __forceinline__ double row_max_f64(double x) {
+    if (LPC == 16) {
+        x = fmax(x, dpp_f64<0xB1>(x));            // quad_perm [1,0,3,2]
+        x = fmax(x, dpp_f64<0x4E>(x));            // quad_perm [2,3,0,1]
+        x = fmax(x, dpp_f64<0x141>(x));           // row_half_mirror
+        x = fmax(x, dpp_f64<0x140>(x));           // row_mirror
+        return x;
+    }
+    for (int o = static_cast<int>(LPC) / 2; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+    return x;
+}
+template <uint32_t LPC>
+__device__ __forceinline__ double row_sum_f64(double x) {
+    for (int o = static_cast<int>(LPC) / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+// ---------------- K14 Greedy: 64 / LPC chains per wavefront ----------------
+template <uint32_t LPC>
+__global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr uint32_t CPW = 64 / LPC;
+    const uint32_t W = V.wstride;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = lane / LPC, jj = lane % LPC, row_base = row * LPC;
+    const uint32_t chain_raw = blockIdx.x * CPW + row;
+    const bool live_row = chain_raw < n_chains;
+    const uint32_t chain = live_row ? chain_raw : n_chains - 1;                  // a spare row shadows the last chain, without effects
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(row) * W;
+    const uint32_t gi = chain / V.attempts;
+    ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
+    const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
+    const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
+    const uint32_t total_w = V.c_totw[chain];
+    {
+        const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
+        const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
+        for (uint32_t w = jj; w < total_w; w += LPC) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nnt = V.c_nnt[chain];
+    Chain C{&V, wd, gww};
+    // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
+    double depth_lik = 0.0;
+    for (uint32_t w = jj; w < total_w; w += LPC) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
+    depth_lik = row_sum_f64<LPC>(depth_lik);
+    double aln_lik = V.c_aln[chain];
+    Xoshiro rng; rng.seed(V.seeds[chain]);
+    uint64_t n_iter = 0, n_acc = 0;
+    const double rel_contrib = V.depth_contrib / V.aln_contrib;
+    double depth_mine = 0.0, aln_mine = 0.0;                                     // likelihood changes of the moves this lane applied
+
+    bool done = nnt == 0 || !live_row;
+    if (__any(!done)) {
+        const uint32_t nnt1 = max(nnt, 1u);
+        const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
+        // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets, the same in every lane of the row
+        double max_abs = 0.0;
+        for (uint32_t i = 0; i < 100; i++) {
+            Move m;
+            if (!done) {
+                random_move(C, recs, extra, nnt1, rng, m);
+                max_abs = fmax(max_abs, fabs(V.depth_contrib * m.ddiff + V.aln_contrib * (m.lp_new - m.lp_old)));
+            }
+        }
+        const double min_diff = fmax(1e-10 * max_abs, 1e-14);                 // minimum_allowed_diff (stoch.rs:27-29)
+        // Greedy::solve_nontrivial (stoch.rs:81-120). Lane jj of the row evaluates the jj-th read of the iteration's sample.
+        // The random stream does not depend on what the moves do, so the records of an iteration are requested two iterations
+        // ahead (stages A = this iteration, B, C); a move that changes the current location of a read that is already
+        // in flight patches it there.
+        const uint32_t S = min(V.solver.sample_size, nnt1);
+        const bool cand = jj < S;
+        struct Stage { uint32_t pick, rpc; RecBody b; };      // rpc: the record's rp_cur word, patched while in flight
+        auto sample = [&]() -> uint32_t {
+            // non_trivial_reads.sample(rng, S): one draw of the chain's generator as a key, the S picks as counter draws under it,
+            // repeats skipped (our adaptor, oracle/lcty_oracle.h). A sample almost never repeats an index (S^2 / 2 nnt)
+            const uint64_t key = rng.next();
+            uint32_t idx = cand ? static_cast<uint32_t>(__umul64hi(counter_u64(key, jj), static_cast<uint64_t>(nnt1))) : 0xFFFFFFFFu - jj;
+            bool dup = false;
+            if (LPC == 16) {
+                // every unordered pair of the row meets in one of eight rotations
+                const int v = static_cast<int>(idx);
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false) == v;
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false) == v;
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x123, 0xF, 0xF, false) == v;
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false) == v;
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x125, 0xF, 0xF, false) == v;
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x126, 0xF, 0xF, false) == v;
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x127, 0xF, 0xF, false) == v;
+                dup |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false) == v;
+            } else {
+                for (uint32_t d = 1; d < LPC; d++) {
+                    const uint32_t other = static_cast<uint32_t>(__shfl(static_cast<int>(idx), static_cast<int>(row_base + ((jj + d) % LPC))));
+                    dup |= other == idx;
+                }
+            }
+            unsigned long long dup_rows = __ballot(dup && cand);
+            while (dup_rows) {
+                // the picks of that row again, in order, repeats skipped, as the rule says
+                const uint32_t r = static_cast<uint32_t>(__ffsll(static_cast<long long>(dup_rows)) - 1) / LPC;
+                const uint64_t kb = uniform64(__shfl(key, static_cast<int>(r * LPC)));
+                const uint32_t nb = __builtin_amdgcn_readlane(nnt1, r * LPC);
+                const uint32_t Sb = min(V.solver.sample_size, nb);
+                uint64_t ctr = 0;
+                for (uint32_t j = 0; j < Sb; j++) {
+                    uint32_t pick;
+                    bool again;
+                    do {
+                        pick = static_cast<uint32_t>(__umul64hi(counter_u64(kb, ctr++), static_cast<uint64_t>(nb)));
+                        again = __ballot(row == r && jj < j && idx == pick) != 0ull;
+                    } while (again);
+                    if (row == r && jj == j) idx = pick;
+                }
+                const unsigned long long row_lanes = (LPC == 64 ? ~0ull : ((1ull << LPC) - 1ull)) << (r * LPC);
+                dup_rows &= ~row_lanes;
+            }
+            return idx;
+        };
+        auto request = [&](Stage& s) {
+            s.pick = sample();
+            const uint32_t slot = cand ? s.pick : 0u;
+            s.rpc = load_rp_cur(&recs[slot]);
+            s.b = load_body(&recs[slot]);
+        };
+        uint32_t curr_plato = 0;
+        uint64_t iter = 0;
+        Stage sA, sB, sC;
+        request(sA);
+        request(sB);
+        while (__any(!done)) {
+            // best_read_improvement (assgn.rs:287-317), one candidate read per lane
+            const uint32_t nloc = sA.b.meta & 0xFFu;
+            double cur_lp; uint32_t cur_w;
+            const uint32_t cur = sA.rpc >> 24;
+            if (cand) rec_loc(sA.b, extra, cur, &cur_lp, &cur_w); else { cur_lp = 0.0; cur_w = 0; }
+            const uint32_t w1 = cur_w & 0xFFFFu, w2 = cur_w >> 16;
+            double best_improv = -INFINITY, lp_new = 0.0, ddiff = 0.0;
+            uint32_t new_assgn = 0, w3 = 0, w4 = 0;
+            const uint32_t n_alt = (cand && !done) ? nloc - 1 : 0u;
+            // first alternative of every lane together; the record of iteration + 2 is requested behind its depth-table gathers
+            {
+                double lp_t = 0.0; uint32_t win_t = 0;
+                const uint32_t t = cur == 0 ? 1u : 0u;
+                if (n_alt) rec_loc(sA.b, extra, t, &lp_t, &win_t);
+                const uint32_t a3 = win_t & 0xFFFFu, a4 = win_t >> 16;
+                const double dd = C.depth_lik_diff(w1, w2, a3, a4);
+                request(sC);
+                const double improv = lp_t + rel_contrib * dd;
+                if (n_alt) { best_improv = improv; new_assgn = t; w3 = a3; w4 = a4; lp_new = lp_t; ddiff = dd; }
+            }
+            for (uint32_t u = 1; __any(u < n_alt); u++) {                       // reads with more than two locations
+                if (u < n_alt) {
+                    const uint32_t t = u + (u >= cur ? 1u : 0u);
+                    double lp_t; uint32_t win_t;
+                    rec_loc(sA.b, extra, t, &lp_t, &win_t);
+                    const uint32_t a3 = win_t & 0xFFFFu, a4 = win_t >> 16;
+                    const double dd = C.depth_lik_diff(w1, w2, a3, a4);
+                    const double improv = lp_t + rel_contrib * dd;
+                    if (improv > best_improv) { best_improv = improv; new_assgn = t; w3 = a3; w4 = a4; lp_new = lp_t; ddiff = dd; }
+                }
+            }
+            const double my_improv = n_alt ? V.aln_contrib * (best_improv - cur_lp) : -INFINITY;
+            // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
+            const double best = row_max_f64<LPC>(my_improv);
+            const unsigned long long who = __ballot(n_alt && my_improv == best);
+            const unsigned long long who_row = (who >> row_base) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63u)) - 1ull));
+            const uint32_t src = who_row ? static_cast<uint32_t>(__ffsll(static_cast<long long>(who_row))) - 1u : 0u;
+            const bool moved = !done && who_row != 0ull && best > min_diff;
+            // reassign (assgn.rs:331-343) by the lane that holds the move; the others only learn which list slot changed.
+            // The lane's share of the likelihood is added up at the end.
+            if (moved && jj == src) {
+                atomicAdd(&wd[w3], 1u); atomicAdd(&wd[w4], 1u);                   // the depth field never borrows from the GC bits
+                atomicSub(&wd[w1], 1u); atomicSub(&wd[w2], 1u);
+                store_rp_cur(&recs[sA.pick], (sA.rpc & 0xFFFFFFu) | (new_assgn << 24));
+                depth_mine += ddiff;
+                aln_mine += lp_new - cur_lp;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t moved_slot = static_cast<uint32_t>(__shfl(static_cast<int>(sA.pick), static_cast<int>(row_base + src)));
+            const uint32_t moved_to = static_cast<uint32_t>(__shfl(static_cast<int>(new_assgn), static_cast<int>(row_base + src)));
+            if (!done) {
+                n_iter++; iter++;
+                if (moved) {
+                    n_acc++; curr_plato = 0;
+                    if (sB.pick == moved_slot) sB.rpc = (sB.rpc & 0xFFFFFFu) | (moved_to << 24);   // the same read may come up again while it is in flight
+                    if (sC.pick == moved_slot) sC.rpc = (sC.rpc & 0xFFFFFFu) | (moved_to << 24);
+                } else {
+                    curr_plato++;
+                    if (curr_plato > V.solver.plato_size) done = true;
+                }
+                if (iter >= max_iter) done = true;
+            }
+            sA = sB; sB = sC;
+        }
+    }
+    depth_mine = row_sum_f64<LPC>(depth_mine); aln_mine = row_sum_f64<LPC>(aln_mine);
+    depth_lik += depth_mine; aln_lik += aln_mine;
+    if (jj == 0 && live_row) {
+        const double lik = V.depth_contrib * depth_lik + V.aln_contrib * aln_lik;       // assgn.rs:235-237
+        V.liks[chain] = (V.priors ? V.priors[gi] : 0.0) + lik;                          // solve.rs:827
+        V.parts[4 * chain] = aln_lik; V.parts[4 * chain + 1] = depth_lik; V.parts[4 * chain + 2] = static_cast<double>(n_iter);
+        V.parts[4 * chain + 3] = static_cast<double>(n_acc);
+    }
+}
+
+// ---------------- K14 SimAnneal: one chain wavefront + one staging wavefront ----------------
 constexpr uint32_t RING = 64;                  // staged positions of the random stream (power of two)
 constexpr uint32_t SPIN_LIMIT = 200u * 1000u * 1000u;    // bounded waits: a lost hand-shake becomes an error, not a hang
 // one staged draw: the read it would pick and everything about that read that no move can change — its possible
-// locations on the genotype in order (ln-probability, tweaked windows w1 | w2 << 16); nloc > 4: not staged, walk the merge
+// locations on the genotype in order (ln-probability, tweaked windows w1 | w2 << 16); nloc > 4: not staged, read from the record
 struct __attribute__((aligned(16))) StagedRead {
     uint64_t draw;
     uint32_t rp, nloc;
@@ -523,39 +817,35 @@ struct AnnealRing {
     uint32_t produced, consumed, stop, go;
 };
 
-template <uint32_t P, int KIND>
-__global__ __launch_bounds__(KIND == LCTY_SOLVER_GREEDY ? 64 : 128, KIND == LCTY_SOLVER_GREEDY ? 3 : 4)
-void solve_loop_kernel(const SolveView V) {
+__global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) {
     extern __shared__ __align__(32) uint8_t smem[];
     const uint32_t W = V.wstride;
-    // [W] window weights first, then [W] depth | GC bin << 25
-    constexpr bool WW_LDS = true;
+    // [W] window weights first, then [W] depth | GC bin << 25, then the ring the second wavefront fills
     double* lww = reinterpret_cast<double*>(smem);
-    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + (WW_LDS ? static_cast<size_t>(W) * 8 : 0));
-    // annealing only: a second wavefront stages the reads of the coming moves in an LDS ring (see the second loop)
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(W) * 8);
     AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + static_cast<size_t>(W) * 8 + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = uniform64(V.seeds[chain]);
-    Geno<P> G; G.init(V, gi);
-    uint32_t* nontriv = V.non_trivial + static_cast<uint64_t>(chain) * V.ngp;
-    const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
+    ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
+    const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
+    const uint32_t total_w = V.c_totw[chain];
     {
+        const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
         const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
         const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
-        for (uint32_t w = lane; wave == 0 && w < G.total_w; w += 64) {
+        for (uint32_t w = lane; wave == 0 && w < total_w; w += 64) {
             wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
-            if (WW_LDS) lww[w] = gww[w];
+            lww[w] = gww[w];
         }
     }
     const uint32_t nnt = V.c_nnt[chain];
-    if (KIND == LCTY_SOLVER_ANNEAL && wave == 0 && lane == 0) { ring->produced = 0; ring->consumed = 0; ring->stop = 0; ring->go = 0; }
+    if (wave == 0 && lane == 0) { ring->produced = 0; ring->consumed = 0; ring->stop = 0; ring->go = 0; }
     __syncthreads();
-    if (KIND == LCTY_SOLVER_ANNEAL && wave == 1) {
+    if (wave == 1) {
         // ---- producer: runs the random stream ahead of the chain and stages, for every draw taken as "the read of a
-        // move", the read and its possible locations (two dependent HBM gathers, the merge of the contigs' runs and the
-        // tweaked windows: nothing of it depends on the state of the chain)
+        // move", that read's record (one 32-byte gather; nothing of it but the current location depends on the chain's state)
         __syncthreads();                                                     // hand-over of the stream (below)
         if (__hip_atomic_load(&ring->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             Xoshiro prng;
@@ -579,21 +869,14 @@ void solve_loop_kernel(const SolveView V) {
                 }
                 if (lane < n) {
                     const uint32_t slot = static_cast<uint32_t>(__umul64hi(mine, static_cast<uint64_t>(nnt)));
-                    const uint32_t rp = V.non_trivial[static_cast<uint64_t>(chain) * V.ngp + slot] & 0xFFFFFFu;
+                    const uint32_t rp = recs[slot].rp_cur & 0xFFFFFFu;
+                    const RecBody b = load_body(&recs[slot]);
                     StagedRead* e = &ring->pos[(produced + lane) & (RING - 1)];
-                    Locs<P> L; locs_init(L, V, rp, G);
-                    e->draw = mine; e->rp = rp; e->nloc = L.nw;
-                    if (L.nw <= 4) {
-                        LocIter<P> it; it.start(L);
-                        LocOut o;
-#pragma unroll
-                        for (uint32_t t = 0; t < 4; t++) {
-                            if (t < L.nw && it.next(L, V, o)) {
-                                uint32_t wa, wb;
-                                loc_windows(V, G, o, seed, rp, t, &wa, &wb);
-                                e->lp[t] = o.lp; e->win[t] = wa | (wb << 16);
-                            }
-                        }
+                    const uint32_t nloc = b.meta & 0xFFu;
+                    e->draw = mine; e->rp = rp; e->nloc = nloc;
+                    e->lp[0] = b.lp0; e->lp[1] = b.lp1; e->win[0] = b.win0; e->win[1] = b.win1;
+                    if (nloc > 2 && nloc <= 4) {
+                        for (uint32_t t = 2; t < nloc; t++) { const ExtraLoc x = extra[(b.meta >> 8) + t - 2]; e->lp[t] = x.lp; e->win[t] = x.win; }
                     }
                 }
                 produced += n;
@@ -602,38 +885,16 @@ void solve_loop_kernel(const SolveView V) {
         }
         return;
     }
-    Chain C{&V, wd, WW_LDS ? lww : gww};
+    Chain C{&V, wd, lww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
-    for (uint32_t w = lane; w < G.total_w; w += 64) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
+    for (uint32_t w = lane; w < total_w; w += 64) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
     for (int o2 = 32; o2 > 0; o2 >>= 1) depth_lik += __shfl_xor(depth_lik, o2);
     double aln_lik = V.c_aln[chain];
     Xoshiro rng; rng.seed(seed);
     uint64_t n_iter = 0, n_acc = 0;
     bool handed_over = false;
-    const double rel_contrib = V.depth_contrib / V.aln_contrib;
 
-    auto load_slot = [&](uint32_t slot) -> uint32_t {
-        // agent scope = served by L2, where this wavefront's own stores to the list arrive in program order
-        return __hip_atomic_load(&nontriv[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    // ReassignmentTarget::random (assgn.rs:451-471); wave-uniform
-    auto random_move = [&](Move& m) {
-        m.slot = static_cast<uint32_t>(rng.below(nnt));
-        const uint32_t packed = __builtin_amdgcn_readfirstlane(load_slot(m.slot));      // the move is wave-uniform
-        const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
-        Locs<P> L; locs_init(L, V, rp, G);
-        const uint32_t total = L.nw;
-        uint32_t new_assgn;
-        if (total == 2) new_assgn = 1 - old_assgn;
-        else {
-            const uint32_t i = 1 + static_cast<uint32_t>(rng.below(total - 1));
-            new_assgn = i <= old_assgn ? i - 1 : i;
-        }
-        m.rp = rp; m.new_assgn = new_assgn;
-        fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
-        m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
-    };
     auto improvement = [&](const Move& m) -> double {                         // calculate_improvement (assgn.rs:321-328)
         return V.depth_contrib * m.ddiff + V.aln_contrib * (m.lp_new - m.lp_old);
     };
@@ -645,7 +906,7 @@ void solve_loop_kernel(const SolveView V) {
             // LDS atomics (no return value): four operations in program order without a read-modify-write round trip each
             atomicAdd(&wd[m.w3], 1u); atomicAdd(&wd[m.w4], 1u);                // the depth field never borrows from the GC bits
             atomicSub(&wd[m.w1], 1u); atomicSub(&wd[m.w2], 1u);
-            __hip_atomic_store(&nontriv[m.slot], m.rp | (m.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            store_rp_cur(&recs[m.slot], m.rp | (m.new_assgn << 24));
         }
         // one wavefront owns the chain: LDS and vector-memory operations of a wavefront execute in program order, so the
         // following reads see these updates without waiting for the store to complete (no s_waitcnt vmcnt(0) here)
@@ -655,326 +916,163 @@ void solve_loop_kernel(const SolveView V) {
 
     if (nnt > 0) {
         const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
-        if (KIND == LCTY_SOLVER_GREEDY) {
-            // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
-            double max_abs = 0.0;
-            for (uint32_t i = 0; i < 100; i++) {
-                Move m; random_move(m);
-                max_abs = fmax(max_abs, fabs(improvement(m)));
+        // SimAnneal::solve_nontrivial (stoch.rs:195-245).
+        // Every draw of the chain's random stream comes out of an LDS ring that the second wavefront of the workgroup
+        // fills ahead of time: it runs the same stream, treats every draw as if it picked the read of a move, and
+        // stages that read's record. What is left here per move: the record's current location (L2-warm), two of the
+        // staged locations, depth_lik_diff.
+        if (lane == 0) { ring->rng[0] = rng.s0; ring->rng[1] = rng.s1; ring->rng[2] = rng.s2; ring->rng[3] = rng.s3; }
+        __hip_atomic_store(&ring->go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        handed_over = true;
+        __syncthreads();
+        uint32_t consumed = 0;
+        bool lost = false;
+        auto ring_wait = [&](uint32_t need) -> uint32_t {                  // staged positions (>= need), 0 = hand-shake lost
+            uint32_t idle = 0;
+            for (;;) {
+                const uint32_t avail = __hip_atomic_load(&ring->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - consumed;
+                if (avail >= need) return avail;
+                __builtin_amdgcn_s_sleep(2);
+                if (++idle > SPIN_LIMIT) { lost = true; atomicMax(V.overflow, 3u); return 0; }
             }
-            const double min_diff = fmax(1e-10 * max_abs, 1e-14);             // minimum_allowed_diff (stoch.rs:27-29)
-            // Greedy::solve_nontrivial (stoch.rs:81-120). The random stream of the greedy loop does not depend on what
-            // the moves do, so the reads of the next few iterations are known in advance: `NB` consecutive iterations
-            // are prepared together, one candidate read per lane (slot, locations, tweaked windows: the part that does
-            // not depend on the window depths), and then scored and applied one iteration after the other.
-            const uint32_t S = min(V.solver.sample_size, nnt);
-            const uint32_t NB = max(1u, min(6u, 64u / S));
-            const uint32_t grp = lane / S, jj = lane - grp * S;
-            uint32_t curr_plato = 0;
-            uint64_t iter = 0;
-            bool done = false;
-            double depth_mine = 0.0, aln_mine = 0.0;                           // likelihood changes of the moves this lane applied
-            while (!done && iter < max_iter) {
-                const uint32_t nb = static_cast<uint32_t>(min(static_cast<uint64_t>(NB), max_iter - iter));
-                // non_trivial_reads.sample(rng, S) of each iteration: distinct indices, repeats rejected (our adaptor);
-                // lane b * S + j keeps the j-th pick of iteration b
-                uint32_t my_pick = NONE32S;
-                {
-                    // one draw of the chain's generator per iteration (scalar unit); the S picks of an iteration are counter draws
-                    // under that key, one per lane. A sample almost never repeats an index (S^2 / 2 nnt); when one does, the
-                    // iteration's picks are redone in order, repeats skipped, as the rule says
-                    uint64_t key = 0;
-                    for (uint32_t b = 0; b < nb; b++) {
-                        const uint64_t v = rng.next();
-                        if (grp == b) key = v;
-                    }
-                    const uint32_t idx = static_cast<uint32_t>(__umul64hi(counter_u64(key, jj), static_cast<uint64_t>(nnt)));
-                    bool dup = false;
-                    for (uint32_t d = 1; d < S; d++) {
-                        const uint32_t other = static_cast<uint32_t>(__shfl_up(static_cast<int>(idx), d));
-                        dup |= jj >= d && other == idx;
-                    }
-                    if (grp < nb) my_pick = idx;
-                    unsigned long long dup_groups = __ballot(dup && grp < nb);
-                    while (dup_groups) {
-                        const uint32_t b = static_cast<uint32_t>(__ffsll(static_cast<long long>(dup_groups)) - 1) / S;   // S <= 64 / nb
-                        const uint64_t kb = uniform64(__shfl(key, b * S));
-                        uint64_t ctr = 0;
-                        for (uint32_t j = 0; j < S; j++) {
-                            uint32_t pick;
-                            bool again;
-                            do {
-                                pick = static_cast<uint32_t>(__umul64hi(counter_u64(kb, ctr++), static_cast<uint64_t>(nnt)));
-                                again = __ballot(grp == b && jj < j && my_pick == pick) != 0ull;
-                            } while (again);
-                            if (grp == b && jj == j) my_pick = pick;
-                        }
-                        unsigned long long group_lanes = 0;
-                        for (uint32_t j = 0; j < S; j++) group_lanes |= 1ull << (b * S + j);
-                        dup_groups &= ~group_lanes;
-                    }
-                }
-                // preparation: everything about the candidate read that the moves of this batch cannot change
-                uint32_t rp = 0, cur_assgn = 0, nloc = 0;
-                double lps[4];
-                uint32_t wins[4];                                              // w1 | w2 << 16
-#pragma unroll
-                for (uint32_t t = 0; t < 4; t++) { lps[t] = 0.0; wins[t] = 0; }
-                if (grp < nb) {
-                    const uint32_t packed = load_slot(my_pick);
-                    rp = packed & 0xFFFFFFu; cur_assgn = packed >> 24;
-                    Locs<P> L; locs_init(L, V, rp, G);
-                    nloc = L.nw;
-                    LocIter<P> it; it.start(L);
-                    LocOut o;
-#pragma unroll
-                    for (uint32_t t = 0; t < 4; t++) {
-                        if (t < nloc && it.next(L, V, o)) {
-                            uint32_t wa, wb;
-                            loc_windows(V, G, o, seed, rp, t, &wa, &wb);
-                            lps[t] = o.lp; wins[t] = wa | (wb << 16);
-                        }
-                    }
-                }
-                for (uint32_t b = 0; b < nb; b++) {
-                    n_iter++; iter++;
-                    // best_read_improvement (assgn.rs:287-317), one candidate read per lane
-                    double my_improv = -INFINITY;
-                    Move mm; mm.rp = rp; mm.new_assgn = 0; mm.slot = my_pick; mm.w1 = mm.w2 = mm.w3 = mm.w4 = 0; mm.lp_old = mm.lp_new = 0.0;
-                    mm.ddiff = 0.0;
-                    if (grp == b) {
-                        double best_improv = -INFINITY;
-                        if (nloc <= 4) {
-                            double cur_lp = lps[0]; uint32_t cur_w = wins[0];
-#pragma unroll
-                            for (uint32_t t = 1; t < 4; t++) if (t == cur_assgn) { cur_lp = lps[t]; cur_w = wins[t]; }
-                            mm.w1 = cur_w & 0xFFFFu; mm.w2 = cur_w >> 16; mm.lp_old = cur_lp;
-#pragma unroll 1
-                            for (uint32_t u = 0; u + 1 < nloc; u++) {        // the other locations in order: no pass is spent on the current one
-                                const uint32_t t = u + (u >= cur_assgn ? 1u : 0u);
-                                double lp_t = lps[0]; uint32_t win_t = wins[0];
-#pragma unroll
-                                for (uint32_t u = 1; u < 4; u++) if (u == t) { lp_t = lps[u]; win_t = wins[u]; }
-                                const uint32_t w3 = win_t & 0xFFFFu, w4 = win_t >> 16;
-                                const double dd = C.depth_lik_diff(mm.w1, mm.w2, w3, w4);
-                                const double improv = lp_t + rel_contrib * dd;
-                                if (improv > best_improv) {
-                                    best_improv = improv;
-                                    mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = lp_t; mm.ddiff = dd;
-                                }
-                            }
-                        } else {
-                            // more locations than the prepared four: walk the merge again
-                            Locs<P> L; locs_init(L, V, rp, G);
-                            Move cur; cur.w1 = cur.w2 = 0; cur.lp_old = 0.0;
-                            fetch_two(V, G, L, seed, rp, cur_assgn, cur_assgn, cur);
-                            LocIter<P> it; it.start(L);
-                            LocOut o;
-                            for (uint32_t t = 0; t < L.nw && it.next(L, V, o); t++) {
-                                if (t == cur_assgn) continue;
-                                uint32_t w3, w4;
-                                loc_windows(V, G, o, seed, rp, t, &w3, &w4);
-                                const double dd = C.depth_lik_diff(cur.w1, cur.w2, w3, w4);
-                                const double improv = o.lp + rel_contrib * dd;
-                                if (improv > best_improv) {
-                                    best_improv = improv;
-                                    mm.new_assgn = t; mm.w3 = w3; mm.w4 = w4; mm.lp_new = o.lp; mm.ddiff = dd;
-                                }
-                            }
-                            mm.w1 = cur.w1; mm.w2 = cur.w2; mm.lp_old = cur.lp_old;
-                        }
-                        my_improv = V.aln_contrib * (best_improv - mm.lp_old);
-                    }
-                    // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
-                    double best = my_improv;
-                    for (int o2 = 32; o2 > 0; o2 >>= 1) best = fmax(best, __shfl_xor(best, o2));
-                    const unsigned long long who = __ballot(grp == b && my_improv == best);
-                    if (best > min_diff && who) {
-                        // reassign (assgn.rs:331-343) by the lane that holds the move; the others only learn which list
-                        // slot changed. The lane's share of the likelihood is added up at the end.
-                        const uint32_t src = static_cast<uint32_t>(__ffsll(static_cast<long long>(who))) - 1u;
-                        if (lane == src) {
-                            atomicAdd(&wd[mm.w3], 1u); atomicAdd(&wd[mm.w4], 1u);   // the depth field never borrows from the GC bits
-                            atomicSub(&wd[mm.w1], 1u); atomicSub(&wd[mm.w2], 1u);
-                            __hip_atomic_store(&nontriv[mm.slot], mm.rp | (mm.new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            depth_mine += mm.ddiff;
-                            aln_mine += mm.lp_new - mm.lp_old;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        const uint32_t moved_slot = __builtin_amdgcn_readlane(mm.slot, src);
-                        const uint32_t moved_to = __builtin_amdgcn_readlane(mm.new_assgn, src);
-                        n_acc++;
-                        curr_plato = 0;
-                        if (my_pick == moved_slot) cur_assgn = moved_to;      // the same read may come up again in this batch
-                    } else {
-                        curr_plato++;
-                        if (curr_plato > V.solver.plato_size) { done = true; break; }
-                    }
-                }
+        };
+        auto ring_f64 = [&](uint32_t off) -> double {                      // rng.random::<f64>() at stream position consumed + off
+            return static_cast<double>(ring->pos[(consumed + off) & (RING - 1)].draw >> 11) * (1.0 / 9007199254740992.0);
+        };
+        // ReassignmentTarget::random (assgn.rs:451-471) at stream position consumed + off; returns the draws it takes
+        auto ring_move = [&](uint32_t off, Move& m) -> uint32_t {
+            const StagedRead* e = &ring->pos[(consumed + off) & (RING - 1)];
+            const uint64_t draw = e->draw, draw_next = ring->pos[(consumed + off + 1) & (RING - 1)].draw;
+            const uint32_t nloc = e->nloc;
+            m.slot = static_cast<uint32_t>(__umul64hi(draw, static_cast<uint64_t>(nnt)));
+            const uint32_t packed = load_rp_cur(&recs[m.slot]);            // only the current location is news
+            const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
+            uint32_t new_assgn;
+            if (nloc == 2) new_assgn = 1 - old_assgn;
+            else {
+                const uint32_t i = 1 + static_cast<uint32_t>(__umul64hi(draw_next, static_cast<uint64_t>(nloc - 1)));
+                new_assgn = i <= old_assgn ? i - 1 : i;
             }
-            for (int o2 = 32; o2 > 0; o2 >>= 1) { depth_mine += __shfl_xor(depth_mine, o2); aln_mine += __shfl_xor(aln_mine, o2); }
-            depth_lik += depth_mine; aln_lik += aln_mine;
-        } else {
-            // SimAnneal::solve_nontrivial (stoch.rs:195-245).
-            // Every draw of the chain's random stream comes out of an LDS ring that the second wavefront of the workgroup
-            // fills ahead of time: it runs the same stream, treats every draw as if it picked the read of a move, and
-            // stages that read's possible locations (list slot -> read -> location cells: two dependent HBM gathers, the
-            // merge and the tweaked windows). What is left here per move: the list slot again (for the current location,
-            // L2-warm), two of the staged locations, depth_lik_diff.
-            if (lane == 0) { ring->rng[0] = rng.s0; ring->rng[1] = rng.s1; ring->rng[2] = rng.s2; ring->rng[3] = rng.s3; }
-            __hip_atomic_store(&ring->go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            handed_over = true;
-            __syncthreads();
-            uint32_t consumed = 0;
-            bool lost = false;
-            auto ring_wait = [&](uint32_t need) -> uint32_t {                  // staged positions (>= need), 0 = hand-shake lost
-                uint32_t idle = 0;
-                for (;;) {
-                    const uint32_t avail = __hip_atomic_load(&ring->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - consumed;
-                    if (avail >= need) return avail;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++idle > SPIN_LIMIT) { lost = true; atomicMax(V.overflow, 3u); return 0; }
-                }
-            };
-            auto ring_f64 = [&](uint32_t off) -> double {                      // rng.random::<f64>() at stream position consumed + off
-                return static_cast<double>(ring->pos[(consumed + off) & (RING - 1)].draw >> 11) * (1.0 / 9007199254740992.0);
-            };
-            // ReassignmentTarget::random (assgn.rs:451-471) at stream position consumed + off; returns the draws it takes
-            auto ring_move = [&](uint32_t off, Move& m) -> uint32_t {
-                const StagedRead* e = &ring->pos[(consumed + off) & (RING - 1)];
-                const uint64_t draw = e->draw, draw_next = ring->pos[(consumed + off + 1) & (RING - 1)].draw;
-                const uint32_t nloc = e->nloc;
-                m.slot = static_cast<uint32_t>(__umul64hi(draw, static_cast<uint64_t>(nnt)));
-                const uint32_t packed = load_slot(m.slot);                     // only the current location is news
-                const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
-                uint32_t new_assgn;
-                if (nloc == 2) new_assgn = 1 - old_assgn;
-                else {
-                    const uint32_t i = 1 + static_cast<uint32_t>(__umul64hi(draw_next, static_cast<uint64_t>(nloc - 1)));
-                    new_assgn = i <= old_assgn ? i - 1 : i;
-                }
-                m.rp = rp; m.new_assgn = new_assgn;
-                if (nloc <= 4) {
-                    double lp_o = e->lp[0], lp_n = lp_o; uint32_t w_o = e->win[0], w_n = w_o;
+            m.rp = rp; m.new_assgn = new_assgn;
+            uint32_t w_o, w_n;
+            if (nloc <= 4) {
+                double lp_o = e->lp[0], lp_n = lp_o; w_o = e->win[0]; w_n = w_o;
 #pragma unroll
-                    for (uint32_t t = 1; t < 4; t++) {
-                        const double lp_t = e->lp[t]; const uint32_t w_t = e->win[t];
-                        if (t == old_assgn) { lp_o = lp_t; w_o = w_t; }
-                        if (t == new_assgn) { lp_n = lp_t; w_n = w_t; }
-                    }
-                    m.lp_old = lp_o; m.lp_new = lp_n;
-                    m.w1 = w_o & 0xFFFFu; m.w2 = w_o >> 16; m.w3 = w_n & 0xFFFFu; m.w4 = w_n >> 16;
-                } else {
-                    Locs<P> L; locs_init(L, V, rp, G);
-                    fetch_two(V, G, L, seed, rp, old_assgn, new_assgn, m);
+                for (uint32_t t = 1; t < 4; t++) {
+                    const double lp_t = e->lp[t]; const uint32_t w_t = e->win[t];
+                    if (t == old_assgn) { lp_o = lp_t; w_o = w_t; }
+                    if (t == new_assgn) { lp_n = lp_t; w_n = w_t; }
                 }
-                m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
-                return nloc > 2 ? 2u : 1u;
-            };
-            auto retire = [&](uint32_t q) {                                    // the producer may reuse the ring entries of q draws
-                consumed += q;
-                __hip_atomic_store(&ring->consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-            auto blank = [](Move& m) {
-                m.slot = 0; m.rp = 0; m.new_assgn = 0; m.ddiff = 0.0;
-                m.w1 = m.w2 = m.w3 = m.w4 = 0; m.lp_old = m.lp_new = 0.0;
-            };
+                m.lp_old = lp_o; m.lp_new = lp_n;
+            } else {
+                const RecBody b = load_body(&recs[m.slot]);
+                rec_loc(b, extra, old_assgn, &m.lp_old, &w_o);
+                rec_loc(b, extra, new_assgn, &m.lp_new, &w_n);
+            }
+            m.w1 = w_o & 0xFFFFu; m.w2 = w_o >> 16; m.w3 = w_n & 0xFFFFu; m.w4 = w_n >> 16;
+            m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+            return nloc > 2 ? 2u : 1u;
+        };
+        auto retire = [&](uint32_t q) {                                    // the producer may reuse the ring entries of q draws
+            consumed += q;
+            __hip_atomic_store(&ring->consumed, consumed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto blank = [](Move& m) {
+            m.slot = 0; m.rp = 0; m.new_assgn = 0; m.ddiff = 0.0;
+            m.w1 = m.w2 = m.w3 = m.w4 = 0; m.lp_old = m.lp_new = 0.0;
+        };
 
-            // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
-            double max_abs = 0.0;
-            for (uint32_t i = 0; i < 100 && !lost; i++) {
-                if (!ring_wait(2)) break;
-                Move m; blank(m);
-                const uint32_t c = ring_move(0, m);
-                max_abs = fmax(max_abs, fabs(improvement(m)));
-                retire(c);
+        // max_abs_random (stoch.rs:19-22) over INIT_ITER = 100 random targets
+        double max_abs = 0.0;
+        for (uint32_t i = 0; i < 100 && !lost; i++) {
+            if (!ring_wait(2)) break;
+            Move m; blank(m);
+            const uint32_t c = ring_move(0, m);
+            max_abs = fmax(max_abs, fabs(improvement(m)));
+            retire(c);
+        }
+        const double min_diff = fmax(1e-10 * max_abs, 1e-14);             // minimum_allowed_diff (stoch.rs:27-29)
+        const double start_temp = fmax(-max_abs / log(V.solver.init_prob), 1e-5);
+        const double temp_step = start_temp / static_cast<double>(V.solver.anneal_steps);
+        uint32_t curr_plato = 0;
+        for (uint32_t i = V.solver.anneal_steps; i >= 1 && !lost; i--) {
+            if (!ring_wait(3)) break;
+            n_iter++;
+            Move m; blank(m);
+            uint32_t c = ring_move(0, m);
+            const double diff = improvement(m) - min_diff;
+            bool accept = diff >= 0.0;
+            if (!accept) { accept = ring_f64(c) <= exp(diff / (temp_step * static_cast<double>(i))); c++; }
+            if (accept) { reassign(m); curr_plato = 0; }
+            else { curr_plato++; }
+            retire(c);
+            if (!accept && curr_plato >= V.solver.plato_size) break;
+        }
+        // Second loop of stoch.rs:228-241: a move changes the state only when it is accepted, so the moves that
+        // follow a rejection see the same state. Lane q evaluates the move that starts at draw q of the random
+        // stream (a move takes one draw, two when the read has more than two locations); the lanes that lie on
+        // the true chain of moves are then walked in order up to the first accepted one, which is applied, and
+        // the stream continues right behind it. Same moves, same order, same result as the serial loop.
+        uint64_t iter = 0;
+        uint32_t width = 16;                                               // lanes that speculate: about twice the recent run length
+        while (!lost && iter < max_iter && curr_plato < V.solver.plato_size) {
+            const uint32_t avail = ring_wait(2);                           // a move may take the draw after its own
+            if (!avail) break;
+            const uint32_t w = min(width, avail - 1);
+            Move m; blank(m);
+            bool accepted = false, wide = false;
+            if (lane < w) {
+                wide = ring_move(lane, m) == 2;
+                accepted = improvement(m) > min_diff;
             }
-            const double min_diff = fmax(1e-10 * max_abs, 1e-14);             // minimum_allowed_diff (stoch.rs:27-29)
-            const double start_temp = fmax(-max_abs / log(V.solver.init_prob), 1e-5);
-            const double temp_step = start_temp / static_cast<double>(V.solver.anneal_steps);
-            uint32_t curr_plato = 0;
-            for (uint32_t i = V.solver.anneal_steps; i >= 1 && !lost; i--) {
-                if (!ring_wait(3)) break;
-                n_iter++;
-                Move m; blank(m);
-                uint32_t c = ring_move(0, m);
-                const double diff = improvement(m) - min_diff;
-                bool accept = diff >= 0.0;
-                if (!accept) { accept = ring_f64(c) <= exp(diff / (temp_step * static_cast<double>(i))); c++; }
-                if (accept) { reassign(m); curr_plato = 0; }
-                else { curr_plato++; }
-                retire(c);
-                if (!accept && curr_plato >= V.solver.plato_size) break;
+            const unsigned long long acc = __ballot(accepted);
+            const unsigned long long two = __ballot(wide);
+            uint32_t q = 0, walked = 0;
+            int hit = -1;
+            // Which lanes lie on the true chain of moves: position 0 does; position p > 0 does unless p - 1 does and its move takes two
+            // draws. Behind the nearest position r < p whose move takes one draw (or the start) the chain alternates, so p is on it
+            // iff p - (r + 1) is even: one count-leading-zeros per lane instead of a serial walk over the draws.
+            const unsigned long long below = lane ? ((1ull << lane) - 1ull) : 0ull;
+            const unsigned long long ones = ~two & below;
+            const uint32_t after = ones ? 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(ones))) : 0u;      // r + 1
+            const unsigned long long chain_mask = __ballot(lane < w && ((lane - after) & 1u) == 0u);
+            const unsigned long long hits = acc & chain_mask;
+            const uint32_t stop = hits ? static_cast<uint32_t>(__ffsll(static_cast<long long>(hits))) - 1u : w;   // first accepted move on the chain
+            const uint32_t moves = static_cast<uint32_t>(__popcll(chain_mask & (stop >= 63u ? ~0ull : ((2ull << stop) - 1ull))));   // evaluated in order, the hit included
+            const uint32_t rejected = moves - (hits ? 1u : 0u);
+            if (iter + moves <= max_iter && curr_plato + rejected < V.solver.plato_size) {
+                // neither cap is reached inside this step: the serial loop would have gone exactly this far
+                iter += moves; n_iter += moves; walked = moves; curr_plato += rejected;
+                if (hits) { hit = static_cast<int>(stop); q = stop + 1u + static_cast<uint32_t>((two >> stop) & 1ull); }
+                else {
+                    // everything evaluated was rejected: the draws used are those of the chain's moves among the first w positions
+                    const uint32_t last = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(chain_mask)));
+                    q = last + 1u + static_cast<uint32_t>((two >> last) & 1ull);
+                }
+            } else {
+                while (q < w) {                                               // the last steps of a chain: one move at a time
+                    if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
+                    iter++; n_iter++; walked++;
+                    const uint32_t cons = 1 + static_cast<uint32_t>((two >> q) & 1ull);
+                    if ((acc >> q) & 1ull) { hit = static_cast<int>(q); q += cons; break; }
+                    curr_plato++;
+                    q += cons;
+                }
             }
-            // Second loop of stoch.rs:228-241: a move changes the state only when it is accepted, so the moves that
-            // follow a rejection see the same state. Lane q evaluates the move that starts at draw q of the random
-            // stream (a move takes one draw, two when the read has more than two locations); the lanes that lie on
-            // the true chain of moves are then walked in order up to the first accepted one, which is applied, and
-            // the stream continues right behind it. Same moves, same order, same result as the serial loop.
-            uint64_t iter = 0;
-            uint32_t width = 16;                                               // lanes that speculate: about twice the recent run length
-            while (!lost && iter < max_iter && curr_plato < V.solver.plato_size) {
-                const uint32_t avail = ring_wait(2);                           // a move may take the draw after its own
-                if (!avail) break;
-                const uint32_t w = min(width, avail - 1);
-                Move m; blank(m);
-                bool accepted = false, wide = false;
-                if (lane < w) {
-                    wide = ring_move(lane, m) == 2;
-                    accepted = improvement(m) > min_diff;
-                }
-                const unsigned long long acc = __ballot(accepted);
-                const unsigned long long two = __ballot(wide);
-                uint32_t q = 0, walked = 0;
-                int hit = -1;
-                // Which lanes lie on the true chain of moves: position 0 does; position p > 0 does unless p - 1 does and its move takes two
-                // draws. Behind the nearest position r < p whose move takes one draw (or the start) the chain alternates, so p is on it
-                // iff p - (r + 1) is even: one count-leading-zeros per lane instead of a serial walk over the draws.
-                const unsigned long long below = lane ? ((1ull << lane) - 1ull) : 0ull;
-                const unsigned long long ones = ~two & below;
-                const uint32_t after = ones ? 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(ones))) : 0u;      // r + 1
-                const unsigned long long chain_mask = __ballot(lane < w && ((lane - after) & 1u) == 0u);
-                const unsigned long long hits = acc & chain_mask;
-                const uint32_t stop = hits ? static_cast<uint32_t>(__ffsll(static_cast<long long>(hits))) - 1u : w;   // first accepted move on the chain
-                const uint32_t moves = static_cast<uint32_t>(__popcll(chain_mask & (stop >= 63u ? ~0ull : ((2ull << stop) - 1ull))));   // evaluated in order, the hit included
-                const uint32_t rejected = moves - (hits ? 1u : 0u);
-                if (iter + moves <= max_iter && curr_plato + rejected < V.solver.plato_size) {
-                    // neither cap is reached inside this step: the serial loop would have gone exactly this far
-                    iter += moves; n_iter += moves; walked = moves; curr_plato += rejected;
-                    if (hits) { hit = static_cast<int>(stop); q = stop + 1u + static_cast<uint32_t>((two >> stop) & 1ull); }
-                    else {
-                        // everything evaluated was rejected: the draws used are those of the chain's moves among the first w positions
-                        const uint32_t last = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(chain_mask)));
-                        q = last + 1u + static_cast<uint32_t>((two >> last) & 1ull);
-                    }
-                } else {
-                    while (q < w) {                                               // the last steps of a chain: one move at a time
-                        if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
-                        iter++; n_iter++; walked++;
-                        const uint32_t cons = 1 + static_cast<uint32_t>((two >> q) & 1ull);
-                        if ((acc >> q) & 1ull) { hit = static_cast<int>(q); q += cons; break; }
-                        curr_plato++;
-                        q += cons;
-                    }
-                }
-                if (hit >= 0) {
-                    Move a;
-                    a.rp = __shfl(m.rp, hit); a.new_assgn = __shfl(m.new_assgn, hit); a.slot = __shfl(m.slot, hit);
-                    a.w1 = __shfl(m.w1, hit); a.w2 = __shfl(m.w2, hit); a.w3 = __shfl(m.w3, hit); a.w4 = __shfl(m.w4, hit);
-                    a.lp_old = __shfl(m.lp_old, hit); a.lp_new = __shfl(m.lp_new, hit); a.ddiff = __shfl(m.ddiff, hit);
-                    reassign(a);
-                    curr_plato = 0;
-                }
-                width = min(RING - 1, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
-                retire(q);
+            if (hit >= 0) {
+                Move a;
+                a.rp = __shfl(m.rp, hit); a.new_assgn = __shfl(m.new_assgn, hit); a.slot = __shfl(m.slot, hit);
+                a.w1 = __shfl(m.w1, hit); a.w2 = __shfl(m.w2, hit); a.w3 = __shfl(m.w3, hit); a.w4 = __shfl(m.w4, hit);
+                a.lp_old = __shfl(m.lp_old, hit); a.lp_new = __shfl(m.lp_new, hit); a.ddiff = __shfl(m.ddiff, hit);
+                reassign(a);
+                curr_plato = 0;
             }
+            width = min(RING - 1, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
+            retire(q);
         }
     }
-    if (KIND == LCTY_SOLVER_ANNEAL) {
-        if (!handed_over) __syncthreads();                                   // the producer waits for exactly one hand-over
-        __hip_atomic_store(&ring->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    if (!handed_over) __syncthreads();                                   // the producer waits for exactly one hand-over
+    __hip_atomic_store(&ring->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (lane == 0) {
         const double lik = V.depth_contrib * depth_lik + V.aln_contrib * aln_lik;       // assgn.rs:235-237
         V.liks[chain] = (V.priors ? V.priors[gi] : 0.0) + lik;                          // solve.rs:827
@@ -1020,9 +1118,9 @@ __global__ __launch_bounds__(256) void assignment_counts_kernel(const SolveView 
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < V.n_good && nw[i] == 1) counts[read_off[i]] = static_cast<uint16_t>(V.attempts);
     if (i < V.c_nnt[0]) {
-        const uint32_t rp = V.non_trivial[i] & 0xFFFFFFu;
+        const uint32_t rp = V.recs[i].rp_cur & 0xFFFFFFu;
         for (uint32_t a = 0; a < V.attempts; a++) {
-            const uint32_t loc = V.non_trivial[static_cast<uint64_t>(a) * V.ngp + i] >> 24;
+            const uint32_t loc = V.recs[static_cast<uint64_t>(a) * V.ngp + i].rp_cur >> 24;
             counts[read_off[rp] + loc] += 1;
         }
     }
@@ -1132,49 +1230,49 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
 }
 
 template <uint32_t P>
-void launch_chains(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, size_t lds_loop_base) {
-    const size_t lds_loop = V.solver.kind == LCTY_SOLVER_GREEDY
-        ? lds_loop_base + static_cast<size_t>(V.wstride) * 8
-        : static_cast<size_t>(V.wstride) * 8 + ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
-    const uint32_t loop_threads = V.solver.kind == LCTY_SOLVER_GREEDY ? 64 : 128;
-    hipStream_t s = ctx->stream;
+void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s) {
     if (lds_init > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_init)));
-    auto loop_kernel = V.solver.kind == LCTY_SOLVER_GREEDY ? solve_loop_kernel<P, LCTY_SOLVER_GREEDY> : solve_loop_kernel<P, LCTY_SOLVER_ANNEAL>;
-    if (lds_loop > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds_loop)));
-    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); });
-    LCTY_HIP(hipGetLastError());
-    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(loop_kernel, dim3(nch), dim3(loop_threads), lds_loop, s, V); });
+    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); }, s);
     LCTY_HIP(hipGetLastError());
 }
 
+template <uint32_t LPC>
+void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
+    constexpr uint32_t CPW = 64 / LPC;
+    const size_t lds = static_cast<size_t>(CPW) * V.wstride * 4;
+    if (lds > 48 * 1024)
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)));
+    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(greedy_loop_kernel<LPC>, dim3((nch + CPW - 1) / CPW), dim3(64), lds, s, V, nch); }, s);
+    LCTY_HIP(hipGetLastError());
+}
+
+void launch_anneal(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
+    const size_t lds = static_cast<size_t>(V.wstride) * 8 + ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
+    if (lds > 48 * 1024)
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(anneal_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)));
+    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(anneal_loop_kernel, dim3(nch), dim3(128), lds, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
+}
 
 // One stage = every (genotype, attempt) chain, in batches that fit the state budget. `after_batch(g0, ng, liks)` runs
-// while the batch's device state (lists of non-trivial reads, window arrays) is still alive.
+// while the batch's device state (records of the non-trivial reads, window arrays) is still alive.
 struct StageRunner {
     lcty_reads* reads; lcty_ctx* ctx; lcty_locus* loc;
     SolveView V{};
     uint64_t n_gt; uint32_t ploidy, attempts;
-    size_t lds_init = 0, lds_loop = 0;
+    size_t lds_init = 0;
     uint64_t gt_per_batch = 1, depth_cap = 2;
-    // device state of the chains: the workspace of the batch (grow-only, lives as long as the reads)
-    DevBuf<uint16_t>& d_gt; DevBuf<uint8_t>& d_cgc; DevBuf<uint32_t>& d_nt; DevBuf<uint32_t>& d_cdepth; DevBuf<uint32_t>& d_cnnt; DevBuf<uint32_t>& d_ovf;
-    DevBuf<uint64_t>& d_seeds; DevBuf<double>& d_pri; DevBuf<double>& d_liks; DevBuf<double>& d_parts; DevBuf<double>& d_cww; DevBuf<double>& d_caln;
+    uint32_t lane;                      // 0: the context's stream; 1: its side stream (the last stage of a locus while the next locus starts)
+    hipStream_t stream;
+    lcty_ctx::SolveWorkspace& ws;       // device state of the chains: grow-only, lives as long as the context
 
     StageRunner(lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver, uint32_t attempts_,
-                const uint64_t* chain_seeds)
-        : StageRunner(r ? r->solve_ws : null_workspace(), r, genotypes, n_gt_, ploidy_, solver, attempts_, chain_seeds) {}
-
-    static lcty_reads::SolveWorkspace& null_workspace() { static lcty_reads::SolveWorkspace w; return w; }   // never allocated: the null check comes first
-
-    StageRunner(lcty_reads::SolveWorkspace& ws, lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver,
-                uint32_t attempts_, const uint64_t* chain_seeds)
-        : reads(r), n_gt(n_gt_), ploidy(ploidy_), attempts(attempts_), d_gt(ws.gt), d_cgc(ws.cgc), d_nt(ws.nt), d_cdepth(ws.cdepth), d_cnnt(ws.cnnt),
-          d_ovf(ws.ovf), d_seeds(ws.seeds), d_pri(ws.pri), d_liks(ws.liks), d_parts(ws.parts), d_cww(ws.cww), d_caln(ws.caln) {
-        if (!reads || !genotypes || !solver || !chain_seeds) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+                const uint64_t* chain_seeds, uint32_t lane_ = 0)
+        : reads(r), n_gt(n_gt_), ploidy(ploidy_), attempts(attempts_), lane(lane_), ws(check_args(r, genotypes, solver, chain_seeds, lane_)) {
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
         if (ploidy == 0 || ploidy > MAXP) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles ploidy 1..%u", MAXP);
         if (attempts == 0) fail(LCTY_ERR_INVALID_INPUT, "At least one attempt is required for each stage");
@@ -1186,6 +1284,7 @@ struct StageRunner {
         if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size > 64) fail(LCTY_ERR_UNSUPPORTED, "greedy sample size above 64");
         ctx = reads->ctx; loc = reads->locus;
         ctx->activate();
+        stream = lane ? ctx->side_stream() : ctx->stream;
         reads->check_device_error();
         const uint32_t A = loc->n_alleles;
         for (uint64_t i = 0; i < n_gt * ploidy; i++)
@@ -1203,7 +1302,6 @@ struct StageRunner {
         if (ctx->knob("depth_table_start", 0) > 0)                          // lcty_ctx_set_knob: start narrow, exercise the widening
             first_width = static_cast<uint64_t>(ctx->knob("depth_table_start", 0));
         ensure_depth_table(loc, first_width);
-        hipStream_t s = ctx->stream;
 
         V.by_window = FastDiv::make(loc->bg.window); V.by_tweak = FastDiv::make(2 * static_cast<uint32_t>(loc->prm.tweak) + 1);
         V.A = A; V.window = loc->bg.window; V.left_padding = loc->left_padding; V.tweak = static_cast<uint32_t>(loc->prm.tweak);
@@ -1217,55 +1315,93 @@ struct StageRunner {
         V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
         V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
         lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
-        lds_loop = static_cast<size_t>(V.wstride) * 4 + 16;
-        if (lds_loop + static_cast<size_t>(V.wstride) * 8 > 160 * 1024 || V.wstride > 65535) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype: too many for the device solver", V.wstride);
+        if (static_cast<size_t>(V.wstride) * 12 + sizeof(AnnealRing) + 128 > 160 * 1024 || V.wstride > 65535)
+            fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype: too many for the device solver", V.wstride);
 
-        // chains are processed in batches so that the per-chain state (4 B per good read) stays bounded
-        const uint64_t per_chain = ngp * 4 + static_cast<uint64_t>(V.wstride) * 13;
-        uint64_t budget = 64ull << 30;
+        // Locations beyond the second of a read (ploidy > 2, several pair-alignments on a contig, "both unmapped" in reach): a run per
+        // chain; a chain that needs more raises a flag and the batch is repeated with the run it asked for
+        if (ws.extra_cap == 0 || ws.extra_for_ngp != ngp || ws.extra_for_ploidy != ploidy) {
+            ws.extra_cap = static_cast<uint32_t>(std::min<uint64_t>(ngp * (ploidy > 2 ? ploidy - 2 : 0) + std::max<uint64_t>(256, ngp / 64), (1u << 24) - 1));
+            ws.extra_for_ngp = ngp; ws.extra_for_ploidy = ploidy;
+        }
+        plan_batches();
+        V.overflow = ws.ovf.p;
+    }
+
+    static lcty_ctx::SolveWorkspace& check_args(lcty_reads* r, const uint16_t* genotypes, const lcty_solver* solver, const uint64_t* chain_seeds,
+                                                uint32_t lane) {
+        if (!r || !genotypes || !solver || !chain_seeds) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        return r->ctx->solve_ws[lane ? 1 : 0];
+    }
+
+    // chains are processed in batches so that the per-chain state (32 B per good read + the run of further locations) fits the device
+    void plan_batches() {
+        const uint64_t ngp = V.ngp;
+        const uint64_t per_chain = ngp * sizeof(ChainRec) + static_cast<uint64_t>(ws.extra_cap) * sizeof(ExtraLoc) + static_cast<uint64_t>(V.wstride) * 17 + 64;
+        size_t free_b = 0, total_b = 0;
+        LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t held = ws.recs.n * sizeof(ChainRec) + ws.extra.n * sizeof(ExtraLoc);      // what this workspace already owns counts as free
+        uint64_t budget = static_cast<uint64_t>(0.92 * static_cast<double>(free_b + held));
         if (ctx->knob("solve_budget_mb", 0) > 0)                              // lcty_ctx_set_knob: force several batches
             budget = static_cast<uint64_t>(ctx->knob("solve_budget_mb", 0)) << 20;
         gt_per_batch = std::max<uint64_t>(1, std::min<uint64_t>(n_gt, budget / (per_chain * attempts)));
         const uint64_t max_chains = gt_per_batch * attempts;
-        d_ovf.ensure(1); d_ovf.zero(s);
-        d_nt.ensure(max_chains * ngp);
-        d_cww.ensure(max_chains * V.wstride); d_cgc.ensure(max_chains * V.wstride); d_cdepth.ensure(max_chains * V.wstride);
-        d_cnnt.ensure(max_chains); d_caln.ensure(max_chains);
-        d_gt.ensure(gt_per_batch * ploidy); d_seeds.ensure(max_chains); d_liks.ensure(max_chains); d_parts.ensure(4 * max_chains);
-        d_pri.ensure(gt_per_batch);
-        V.genotypes = d_gt.p; V.seeds = d_seeds.p; V.priors = nullptr;
-        V.non_trivial = d_nt.p; V.liks = d_liks.p; V.parts = d_parts.p;
-        V.c_ww = d_cww.p; V.c_gc = d_cgc.p; V.c_depth = d_cdepth.p; V.c_nnt = d_cnnt.p; V.c_aln = d_caln.p;
-        V.overflow = d_ovf.p;
+        hipStream_t s = stream;
+        ws.ovf.ensure(2); ws.ovf.zero(s);
+        if (ws.recs.n < max_chains * ngp || ws.extra.n < max_chains * ws.extra_cap) {
+            // both at once, the old ones released first: the two together are most of the device
+            ws.recs.release(); ws.extra.release();
+            ws.recs.alloc(max_chains * ngp); ws.extra.alloc(std::max<uint64_t>(max_chains * ws.extra_cap, 1));
+        }
+        ws.cww.ensure(max_chains * V.wstride); ws.cgc.ensure(max_chains * V.wstride); ws.cdepth.ensure(max_chains * V.wstride);
+        ws.cnnt.ensure(max_chains); ws.ctotw.ensure(max_chains); ws.caln.ensure(max_chains);
+        ws.gt.ensure(gt_per_batch * ploidy); ws.seeds.ensure(max_chains); ws.liks.ensure(max_chains); ws.parts.ensure(4 * max_chains);
+        ws.pri.ensure(gt_per_batch);
+        V.genotypes = ws.gt.p; V.seeds = ws.seeds.p; V.priors = nullptr;
+        V.recs = ws.recs.p; V.extra = ws.extra.p; V.extra_cap = ws.extra_cap; V.liks = ws.liks.p; V.parts = ws.parts.p;
+        V.c_ww = ws.cww.p; V.c_gc = ws.cgc.p; V.c_depth = ws.cdepth.p; V.c_nnt = ws.cnnt.p; V.c_totw = ws.ctotw.p; V.c_aln = ws.caln.p;
     }
 
-    void upload_genotypes(const uint16_t* genotypes, uint64_t ng) { d_gt.upload(genotypes, ng * ploidy, ctx->stream); }
+    void upload_genotypes(const uint16_t* genotypes, uint64_t ng) { ws.gt.upload(genotypes, ng * ploidy, stream); }
+
+    void launch(uint32_t nch) {
+        switch (ploidy) {
+            case 1: launch_init<1>(ctx, V, nch, lds_init, stream); break;
+            case 2: launch_init<2>(ctx, V, nch, lds_init, stream); break;
+            case 3: launch_init<3>(ctx, V, nch, lds_init, stream); break;
+            default: launch_init<4>(ctx, V, nch, lds_init, stream); break;
+        }
+        if (V.solver.kind == LCTY_SOLVER_ANNEAL) { launch_anneal(ctx, V, nch, stream); return; }
+        // lanes per chain: a row of 16 holds the default sample of 10; 64 / LPC chains share a wavefront (and its LDS: 4 B per window and chain)
+        uint32_t lpc = V.solver.sample_size <= 16 ? 16 : V.solver.sample_size <= 32 ? 32 : 64;
+        const int64_t want = ctx->knob("solve_chains_per_wave", 0);
+        if (want > 0) lpc = std::max<uint32_t>(lpc, static_cast<uint32_t>(64 / std::min<int64_t>(want, 4)));
+        while (lpc < 64 && static_cast<size_t>(64 / lpc) * V.wstride * 4 > 64 * 1024) lpc *= 2;      // keep a few wavefronts per CU
+        if (lpc == 16) launch_greedy<16>(ctx, V, nch, stream);
+        else if (lpc == 32) launch_greedy<32>(ctx, V, nch, stream);
+        else launch_greedy<64>(ctx, V, nch, stream);
+    }
 
     template <typename F>
     void run(const uint16_t* genotypes, const double* priors, const uint64_t* chain_seeds, F&& after_batch) {
-        hipStream_t s = ctx->stream;
+        hipStream_t s = stream;
         std::vector<double> liks(gt_per_batch * attempts);
         for (uint64_t g0 = 0; g0 < n_gt; g0 += gt_per_batch) {
             const uint64_t ng = std::min(gt_per_batch, n_gt - g0), nch = ng * attempts;
             upload_genotypes(genotypes + g0 * ploidy, ng);
-            d_seeds.upload(chain_seeds + g0 * attempts, nch, s);
-            if (priors) d_pri.upload(priors + g0, ng, s);
-            V.priors = priors ? d_pri.p : nullptr;
+            ws.seeds.upload(chain_seeds + g0 * attempts, nch, s);
+            if (priors) ws.pri.upload(priors + g0, ng, s);
+            V.priors = priors ? ws.pri.p : nullptr;
             for (;;) {
                 V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth));
-                switch (ploidy) {
-                    case 1: launch_chains<1>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                    case 2: launch_chains<2>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                    case 3: launch_chains<3>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                    default: launch_chains<4>(ctx, V, static_cast<uint32_t>(nch), lds_init, lds_loop); break;
-                }
-                uint32_t ovf = 0;
-                d_ovf.download(&ovf, 1, s);
-                d_liks.download(liks.data(), nch, s);
+                launch(static_cast<uint32_t>(nch));
+                uint32_t ovf[2] = {0, 0};
+                ws.ovf.download(ovf, 2, s);
+                ws.liks.download(liks.data(), nch, s);
                 LCTY_HIP(hipStreamSynchronize(s));
-                if (!ovf) {
+                if (!ovf[0]) {
                     std::vector<double> parts(4 * nch);
-                    d_parts.download(parts.data(), 4 * nch, s);
+                    ws.parts.download(parts.data(), 4 * nch, s);
                     LCTY_HIP(hipStreamSynchronize(s));
                     double sum = 0, mx = 0, mn = 1e300, acc = 0;
                     for (uint64_t c = 0; c < nch; c++) {
@@ -1279,16 +1415,66 @@ struct StageRunner {
                                 static_cast<unsigned long long>(nch), sum / nch, mn, mx, acc / nch, loc->lut_ext_depth);
                     break;
                 }
-                if (ovf == 2) fail(LCTY_ERR_UNSUPPORTED, "a read pair with more than 255 possible locations on one genotype");
-                if (ovf == 3) fail(LCTY_ERR_RUNTIME, "annealing kernel: the staging wavefront and the chain lost each other");
+                if (ovf[0] == 2) fail(LCTY_ERR_UNSUPPORTED, "a read pair with more than 255 possible locations on one genotype (or 2^24 further locations in a chain)");
+                if (ovf[0] == 3) fail(LCTY_ERR_RUNTIME, "annealing kernel: the staging wavefront and the chain lost each other");
+                ws.ovf.zero(s);
+                if (ovf[0] == 4) {
+                    // a chain has more locations beyond the second than its run holds: the batch again with the run it asked for
+                    if (ovf[1] >= (1u << 24)) fail(LCTY_ERR_UNSUPPORTED, "2^24 or more further locations in one chain");
+                    ws.extra_cap = std::min<uint32_t>(std::max<uint32_t>(ovf[1] + ovf[1] / 8 + 64, 2 * ws.extra_cap), (1u << 24) - 1);
+                    const uint64_t before = gt_per_batch;
+                    plan_batches();
+                    V.overflow = ws.ovf.p;
+                    if (gt_per_batch < ng) fail(LCTY_ERR_RUNTIME, "device memory: %llu chains of this stage do not fit with %u further locations each (had %llu)",
+                                                static_cast<unsigned long long>(ng * attempts), ws.extra_cap, static_cast<unsigned long long>(before));
+                    continue;
+                }
                 if (loc->lut_ext_depth >= depth_cap) fail(LCTY_ERR_RUNTIME, "window depth beyond 2 * reads + 2");
-                d_ovf.zero(s);
                 ensure_depth_table(loc, std::min<uint64_t>(4ull * loc->lut_ext_depth, depth_cap));
             }
             after_batch(g0, ng, liks.data());
         }
     }
 };
+
+}  // namespace
+
+namespace {
+
+// one stage on the context's stream (lane 0) or on its side stream (lane 1)
+void solve_stage_on(uint32_t lane, lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
+                    const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds, double* lik_mean, double* lik_var,
+                    double* liks_out) {
+    if (!lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    StageRunner R(reads, genotypes, n_gt, ploidy, solver, attempts, chain_seeds, lane);
+    R.run(genotypes, priors, chain_seeds, [&](uint64_t g0, uint64_t ng, const double* liks) {
+        for (uint64_t g = 0; g < ng; g++) {
+            const double* l = liks + g * attempts;
+            math::mean_variance_or_nan(l, attempts, &lik_mean[g0 + g], &lik_var[g0 + g]);
+            if (liks_out) memcpy(liks_out + (g0 + g) * attempts, l, sizeof(double) * attempts);
+        }
+    });
+}
+
+uint32_t count_unexplained_on(hipStream_t s, lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy) {
+    lcty_ctx* ctx = reads->ctx;
+    ctx->activate();
+    reads->check_device_error();
+    const uint32_t A = reads->locus->n_alleles;
+    for (uint32_t i = 0; i < ploidy; i++)
+        if (genotype[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotype[i], A);
+    DevBuf<uint16_t> d_ids; d_ids.alloc(ploidy); d_ids.upload(genotype, ploidy, s);
+    DevBuf<unsigned long long> d_out; d_out.alloc(1); d_out.zero(s);
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((reads->n_pairs + 255) / 256, 4096));
+    if (reads->n_pairs)
+        hipLaunchKernelGGL(count_unexplained_kernel, dim3(blocks), dim3(256), 0, s, reads->d_status.p, reads->d_unmapped.p,
+                           reads->d_matrix.p, reads->n_pairs, A, d_ids.p, ploidy, d_out.p);
+    LCTY_HIP(hipGetLastError());
+    unsigned long long v = 0;
+    d_out.download(&v, 1, s);
+    LCTY_HIP(hipStreamSynchronize(s));
+    return static_cast<uint32_t>(v);
+}
 
 }  // namespace
 
@@ -1331,17 +1517,7 @@ int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out) {
 int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
                          const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out) {
-    return guarded([&] {
-        if (!lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
-        StageRunner R(reads, genotypes, n_gt, ploidy, solver, attempts, chain_seeds);
-        R.run(genotypes, priors, chain_seeds, [&](uint64_t g0, uint64_t ng, const double* liks) {
-            for (uint64_t g = 0; g < ng; g++) {
-                const double* l = liks + g * attempts;
-                math::mean_variance_or_nan(l, attempts, &lik_mean[g0 + g], &lik_var[g0 + g]);
-                if (liks_out) memcpy(liks_out + (g0 + g) * attempts, l, sizeof(double) * attempts);
-            }
-        });
-    });
+    return guarded([&] { solve_stage_on(0, reads, genotypes, n_gt, ploidy, priors, solver, attempts, chain_seeds, lik_mean, lik_var, liks_out); });
 }
 
 int32_t lcty_assignment_counts(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, const lcty_solver* solver,
@@ -1395,23 +1571,7 @@ int32_t lcty_count_unexplained(lcty_reads* reads, const uint16_t* genotype, uint
     return guarded([&] {
         if (!reads || !genotype || !out || ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
-        lcty_ctx* ctx = reads->ctx;
-        ctx->activate();
-        reads->check_device_error();
-        const uint32_t A = reads->locus->n_alleles;
-        for (uint32_t i = 0; i < ploidy; i++)
-            if (genotype[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotype[i], A);
-        DevBuf<uint16_t> d_ids; d_ids.alloc(ploidy); d_ids.upload(genotype, ploidy, ctx->stream);
-        DevBuf<unsigned long long> d_out; d_out.alloc(1); d_out.zero(ctx->stream);
-        const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((reads->n_pairs + 255) / 256, 4096));
-        if (reads->n_pairs)
-            hipLaunchKernelGGL(count_unexplained_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reads->d_status.p, reads->d_unmapped.p,
-                               reads->d_matrix.p, reads->n_pairs, A, d_ids.p, ploidy, d_out.p);
-        LCTY_HIP(hipGetLastError());
-        unsigned long long v = 0;
-        d_out.download(&v, 1, ctx->stream);
-        LCTY_HIP(hipStreamSynchronize(ctx->stream));
-        *out = static_cast<uint32_t>(v);
+        *out = count_unexplained_on(reads->ctx->stream, reads, genotype, ploidy);
     });
 }
 
@@ -1492,64 +1652,147 @@ int32_t lcty_stages_default(lcty_stage* stages, uint32_t* n_stages) {
     });
 }
 
-// solve::solve (solve.rs:926-981) with solve_single_thread (789-857) as the stage loop
-int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages, uint64_t master_seed,
-                   const double* priors, lcty_call* out, double* lik_mean_out, double* lik_var_out, uint32_t* attempts_out) {
-    return guarded([&] {
+}  // extern "C"
+
+namespace {
+
+// solve::solve (solve.rs:926-981) with solve_single_thread (789-857) as the stage loop, in two halves: `head` = run_filter and every
+// stage but the last, `tail` = the last stage (few genotypes, many attempts: long serial chains that leave most of the GPU idle),
+// the final comparison and the checks. lcty_solve runs them back to back; lcty_solve_queue runs the tail of a locus on the context's
+// side stream while the head of the next locus has the main one.
+struct LocusRun {
+    lcty_reads* reads = nullptr; uint32_t ploidy = 2; const lcty_stage* stages = nullptr; uint32_t n_stages = 0;
+    uint64_t master_seed = 0; const double* priors = nullptr; lcty_call* out = nullptr;
+    uint64_t G = 0, n = 0, threads = 1;
+    std::vector<uint16_t> gts; std::vector<uint64_t> ixs; std::vector<double> mean, var; std::vector<uint32_t> att;
+
+    static void ok(int32_t rc) { if (rc != LCTY_OK) throw Error(rc, std::string(lcty_last_error())); }
+
+    void stage(uint32_t si, uint32_t lane) {
+        const bool last = si + 1 == n_stages;
+        const lcty_params& prm = reads->locus->prm;
+        const uint64_t out_size = last ? 0 : stages[si + 1].in_size;
+        if (!(prm.dont_skip || last || out_size < n)) return;                    // "Skipping stage, not enough genotypes"
+        const uint32_t attempts = stages[si].attempts;
+        std::vector<uint16_t> sub(n * ploidy); std::vector<double> pri(n), m(n), v(n); std::vector<uint64_t> seeds(n * attempts);
+        for (uint64_t t = 0; t < n; t++) {
+            memcpy(sub.data() + t * ploidy, gts.data() + ixs[t] * ploidy, ploidy * sizeof(uint16_t));
+            pri[t] = priors ? priors[ixs[t]] : 0.0;
+        }
+        ok(lcty_chain_seeds(master_seed + static_cast<uint64_t>(si + 1) * 0x9e3779b97f4a7c15ull, n * attempts, seeds.data()));
+        solve_stage_on(lane, reads, sub.data(), n, ploidy, pri.data(), &stages[si].solver, attempts, seeds.data(), m.data(), v.data(), nullptr);
+        for (uint64_t t = 0; t < n; t++) { mean[ixs[t]] = m[t]; var[ixs[t]] = v[t]; att[ixs[t]] = attempts; }
+        if (!last) ok(lcty_discard_improbable(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, out_size, threads, &n));
+    }
+
+    void head(bool score) {
         if (!reads || !stages || !out || n_stages == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (score) ok(lcty_score_reads(reads));
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
         for (uint32_t s = 0; s < n_stages; s++)
             if (stages[s].attempts == 0 || stages[s].in_size == 0) fail(LCTY_ERR_INVALID_INPUT, "stage %u: attempts and in_size must be positive", s);
         const lcty_locus* loc = reads->locus;
         const lcty_params& prm = loc->prm;
         const uint32_t A = loc->n_alleles;
-        const uint64_t G = count_genotypes(A, ploidy);
-        auto ok = [](int32_t rc) { if (rc != LCTY_OK) throw Error(rc, std::string(lcty_last_error())); };
-        std::vector<uint16_t> gts(G * ploidy);
+        G = count_genotypes(A, ploidy);
+        gts.resize(G * ploidy);
         ok(lcty_generate_genotypes(A, ploidy, gts.data(), G));
-        std::vector<uint64_t> ixs(G);
+        ixs.resize(G);
         std::iota(ixs.begin(), ixs.end(), 0ull);
-        uint64_t n = G;
+        n = G;
         memset(out, 0, sizeof(*out));
         // filter (solve.rs:940-945): run_filter gets data.threads as the floor of kept genotypes; the stage loop passes ONE_THREAD
         // to discard_improbable_genotypes when threads == 1 (solve.rs:797, 853) and data.threads otherwise (1087-1089)
-        const uint64_t threads = std::max<uint64_t>(1, prm.threads);
+        threads = std::max<uint64_t>(1, prm.threads);
         if (prm.dont_skip || stages[0].in_size < G) {
             std::vector<double> scores(G);
             ok(lcty_prefilter(reads, nullptr, G, ploidy, priors, scores.data()));
             ok(lcty_truncate(scores.data(), ixs.data(), G, prm.filt_diff, stages[0].in_size, threads, &n));
         }
         out->kept_after_filter = n;
-        std::vector<double> mean(G, std::numeric_limits<double>::quiet_NaN()), var(G, std::numeric_limits<double>::quiet_NaN());
-        std::vector<uint32_t> att(G, 0);
-        std::vector<uint16_t> sub; std::vector<double> pri, m, v; std::vector<uint64_t> seeds;
-        for (uint32_t si = 0; si < n_stages; si++) {
-            const bool last = si + 1 == n_stages;
-            const uint64_t out_size = last ? 0 : stages[si + 1].in_size;
-            if (!(prm.dont_skip || last || out_size < n)) continue;                  // "Skipping stage, not enough genotypes"
-            const uint32_t attempts = stages[si].attempts;
-            sub.resize(n * ploidy); pri.resize(n); m.resize(n); v.resize(n); seeds.resize(n * attempts);
-            for (uint64_t t = 0; t < n; t++) {
-                memcpy(sub.data() + t * ploidy, gts.data() + ixs[t] * ploidy, ploidy * sizeof(uint16_t));
-                pri[t] = priors ? priors[ixs[t]] : 0.0;
-            }
-            ok(lcty_chain_seeds(master_seed + static_cast<uint64_t>(si + 1) * 0x9e3779b97f4a7c15ull, n * attempts, seeds.data()));
-            ok(lcty_solve_stage(reads, sub.data(), n, ploidy, pri.data(), &stages[si].solver, attempts, seeds.data(), m.data(), v.data(), nullptr));
-            for (uint64_t t = 0; t < n; t++) { mean[ixs[t]] = m[t]; var[ixs[t]] = v[t]; att[ixs[t]] = attempts; }
-            if (!last) ok(lcty_discard_improbable(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, out_size, threads, &n));
-        }
+        mean.assign(G, std::numeric_limits<double>::quiet_NaN()); var.assign(G, std::numeric_limits<double>::quiet_NaN());
+        att.assign(G, 0);
+        for (uint32_t si = 0; si + 1 < n_stages; si++) stage(si, 0);
+    }
+
+    void tail(uint32_t lane) {
+        lcty_ctx* ctx = reads->ctx;
+        ctx->activate();
+        const lcty_params& prm = reads->locus->prm;
+        stage(n_stages - 1, lane);
         ok(lcty_produce_result(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, 0, out->ixs, out->ln_probs, &out->n_out,
                                &out->quality));
-        ok(lcty_count_unexplained(reads, gts.data() + out->ixs[0] * ploidy, ploidy, &out->unexpl_reads));
-        reads->ensure_good_index();
+        out->unexpl_reads = count_unexplained_on(lane ? ctx->side_stream() : ctx->stream, reads, gts.data() + out->ixs[0] * ploidy, ploidy);
         out->n_good = reads->n_good_cached;
         std::vector<uint16_t> res(out->n_out * ploidy);
         for (uint64_t t = 0; t < out->n_out; t++) memcpy(res.data() + t * ploidy, gts.data() + out->ixs[t] * ploidy, ploidy * sizeof(uint16_t));
         ok(lcty_call_checks(res.data(), out->n_out, ploidy, out->ln_probs, static_cast<uint32_t>(std::min<uint64_t>(out->n_good, 0xFFFFFFFFull)),
-                            nullptr, A, nullptr, nullptr, &out->warnings));
-        if (lik_mean_out) memcpy(lik_mean_out, mean.data(), G * sizeof(double));
-        if (lik_var_out) memcpy(lik_var_out, var.data(), G * sizeof(double));
-        if (attempts_out) memcpy(attempts_out, att.data(), G * sizeof(uint32_t));
+                            nullptr, reads->locus->n_alleles, nullptr, nullptr, &out->warnings));
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages, uint64_t master_seed,
+                   const double* priors, lcty_call* out, double* lik_mean_out, double* lik_var_out, uint32_t* attempts_out) {
+    return guarded([&] {
+        LocusRun R;
+        R.reads = reads; R.ploidy = ploidy; R.stages = stages; R.n_stages = n_stages; R.master_seed = master_seed; R.priors = priors; R.out = out;
+        R.head(false);
+        R.tail(0);
+        if (lik_mean_out) memcpy(lik_mean_out, R.mean.data(), R.G * sizeof(double));
+        if (lik_var_out) memcpy(lik_var_out, R.var.data(), R.G * sizeof(double));
+        if (attempts_out) memcpy(attempts_out, R.att.data(), R.G * sizeof(uint32_t));
+    });
+}
+
+// The genotyping loop of `locityper genotype` over its loci (genotype.rs:1331-1351: analyze_locus one after the other) as a queue
+// on one GPU. Each entry is a batch of read pairs of its own locus, appended but not necessarily scored: for every entry
+// lcty_score_reads + lcty_solve. The loci are independent, so the last stage of locus i (the annealing attempts: a few hundred
+// serial chains that occupy a few per cent of the device) runs on the context's side stream from a second host thread while
+// locus i + 1 is scored, prefiltered and greedily solved on the main stream. Results are those of lcty_solve entry by entry
+// (a chain's random stream is its seed). An entry may appear again later in the queue, not next to itself; neighbours must
+// belong to different loci (lcty_locus objects): a stage may rebuild its locus' depth table.
+int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages,
+                         const uint64_t* master_seeds, const double* const* priors, lcty_call* out) {
+    return guarded([&] {
+        if (!batches || !stages || !master_seeds || !out || n_stages == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        for (uint32_t i = 0; i < n_batches; i++) {
+            if (!batches[i]) fail(LCTY_ERR_INVALID_INPUT, "null batch");
+            if (batches[i]->ctx != batches[0]->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batches of a queue share one context");
+            if (i && (batches[i] == batches[i - 1] || batches[i]->locus == batches[i - 1]->locus))
+                fail(LCTY_ERR_INVALID_INPUT, "neighbours in the queue must be different batches of different loci");
+        }
+        std::unique_ptr<LocusRun> prev;
+        std::thread tail_thread;
+        int32_t tail_rc = LCTY_OK; std::string tail_msg;
+        auto join_tail = [&] {
+            if (tail_thread.joinable()) tail_thread.join();
+            prev.reset();
+            if (tail_rc != LCTY_OK) { const int32_t rc = tail_rc; tail_rc = LCTY_OK; fail(rc, "%s", tail_msg.c_str()); }
+        };
+        try {
+            for (uint32_t i = 0; i < n_batches; i++) {
+                auto R = std::make_unique<LocusRun>();
+                R->reads = batches[i]; R->ploidy = ploidy; R->stages = stages; R->n_stages = n_stages; R->master_seed = master_seeds[i];
+                R->priors = priors ? priors[i] : nullptr; R->out = &out[i];
+                R->head(true);
+                join_tail();
+                prev = std::move(R);
+                LocusRun* run = prev.get();
+                tail_thread = std::thread([run, &tail_rc, &tail_msg] {
+                    try { run->tail(1); }
+                    catch (const Error& e) { tail_rc = e.code; tail_msg = e.what(); }
+                    catch (const std::exception& e) { tail_rc = LCTY_ERR_RUNTIME; tail_msg = e.what(); }
+                });
+            }
+            join_tail();
+        } catch (...) {
+            if (tail_thread.joinable()) tail_thread.join();
+            throw;
+        }
     });
 }
 
