@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of every CPU-baseline figure (the median is reported)")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
     ap.add_argument("--shard-reads", action="store_true",
@@ -60,9 +60,7 @@ def parse_args():
                     help="one locus over all ranks, whole path: every rank scores and prefilters all reads of the locus (replicated), the "
                          "(genotype, attempt) chains of both solver stages are dealt to the ranks and their likelihoods all-gathered on the "
                          "devices (RCCL; lcty_solve_stage_sharded, SURVEY 8e level 3); strong scaling. Not the default either")
-    ap.add_argument("--pipeline", type=int, default=2,
-                    help="extra measurement outside the timed region: this many loci in flight on one GPU, each on its own context / "
-                         "stream (the annealing stage leaves most of the GPU idle); 0 or 1 = skip")
+    ap.add_argument("--pipeline", type=int, default=0, help="ignored (round 1 option; the queue of loci is the default mode now)")
     ap.add_argument("--recruit-sample", type=int, default=8_000_000,
                     help="read pairs of the extra recruitment measurement (the step before the path, SURVEY 8f rank 1; 0 = skip)")
     ap.add_argument("--recovery-sample", type=int, default=262144,
@@ -233,7 +231,7 @@ def main():
         os.environ.pop("NCCL_DEBUG", None)         # RCCL logs to stdout, which carries the one JSON line
         os.environ["NCCL_DEBUG_FILE"] = os.devnull
         args.no_solve = args.shard_reads
-        args.pipeline = args.recovery_sample = args.recruit_sample = 0
+        args.recovery_sample = args.recruit_sample = 0
         uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
         if dist is not None:
             import torch
@@ -246,39 +244,46 @@ def main():
         first_pair = min(rank * per, args.pairs)
         args.pairs = min(first_pair + per, total_pairs) - first_pair          # this rank's shard
 
-    # ---- synthetic locus + reads (seed + locus index) -> HBM ----
+    # ---- synthetic loci + reads (seed + locus index) -> HBM ----
+    # The default mode runs a QUEUE of loci through lcty_solve_queue (the loop of `locityper genotype` over its loci): the library
+    # overlaps the last stage of a locus (annealing) with the scoring / prefilter / greedy stage of the next one, which needs two
+    # loci resident; a step = one locus through the whole path, K steps = a queue of K loci alternating between the two.
     t0 = time.time()
-    L = synth.SynthLocus(args.alleles, total_pairs, seed=synth.SEED + (0 if one_locus else rank))
-    params = api.resolve_params(api.default_params(), L.bg)
-    t1 = time.time()
-    loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
-    ctx.synchronize()
-    locus_setup_s = time.time() - t1
-    first = None
-    sizes = []
-    chunks = []
-    # first pass over chunks only to size the device batch would double the generation time; instead
-    # generate chunk by chunk, keep totals, and allocate from the first chunk's density with head-room.
-    n_chunks = (args.pairs + args.chunk - 1) // args.chunk
-    c0 = L.reads(first_pair, min(args.chunk, args.pairs))
-    dens_b = c0.n_bases / c0.n_pairs
-    dens_r = len(c0.recs) / c0.n_pairs
-    dens_c = len(c0.cigar) / c0.n_pairs
-    head = 1.03
-    cap_bases = (int(dens_b * args.pairs * head) + 1024) // 32 * 32 + 32
-    aa = api.AllAlignments(loc, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096,
-                           int(dens_c * args.pairs * head) + 65536)
-    aa.append(c0)
-    tot_recs, tot_cigar, tot_bases = len(c0.recs), len(c0.cigar), c0.n_bases
-    first = c0 if (rank == 0 and world == 1 and args.cpu_sample > 0) else None
-    for ci in range(1, n_chunks):
-        lo = ci * args.chunk
-        ch = L.reads(first_pair + lo, min(args.chunk, args.pairs - lo))
-        aa.append(ch)
-        tot_recs += len(ch.recs); tot_cigar += len(ch.cigar); tot_bases += ch.n_bases
-        del ch
-    gen_s = time.time() - t0
+    n_loci = 1 if (one_locus or args.no_solve) else 2
     A = args.alleles
+    loci, batches = [], []
+    locus_setup_s = 0.0
+    tot_recs = tot_cigar = tot_bases = 0
+    first = None
+    n_chunks = (args.pairs + args.chunk - 1) // args.chunk
+    for j in range(n_loci):
+        L = synth.SynthLocus(A, total_pairs, seed=synth.SEED + (0 if one_locus else n_loci * rank + j))
+        params = api.resolve_params(api.default_params(), L.bg)
+        t1 = time.time()
+        loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
+        ctx.synchronize()
+        locus_setup_s += time.time() - t1
+        # generate chunk by chunk, keep totals, and allocate from the first chunk's density with head-room
+        c0 = L.reads(first_pair, min(args.chunk, args.pairs))
+        dens_b, dens_r, dens_c = c0.n_bases / c0.n_pairs, len(c0.recs) / c0.n_pairs, len(c0.cigar) / c0.n_pairs
+        head = 1.03
+        cap_bases = (int(dens_b * args.pairs * head) + 1024) // 32 * 32 + 32
+        aa = api.AllAlignments(loc, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096, int(dens_c * args.pairs * head) + 65536)
+        aa.append(c0)
+        if j == 0:
+            tot_recs, tot_cigar, tot_bases = len(c0.recs), len(c0.cigar), c0.n_bases
+            first = c0 if (rank == 0 and world == 1 and args.cpu_sample > 0) else None
+        for ci in range(1, n_chunks):
+            lo = ci * args.chunk
+            ch = L.reads(first_pair + lo, min(args.chunk, args.pairs - lo))
+            aa.append(ch)
+            if j == 0:
+                tot_recs += len(ch.recs); tot_cigar += len(ch.cigar); tot_bases += ch.n_bases
+            del ch
+        loci.append((L, loc)); batches.append(aa)
+    L, loc = loci[0]
+    aa = batches[0]
+    gen_s = time.time() - t0
     G = api.count_genotypes(A, 2)
     all_ixs = np.arange(G, dtype=np.uint64)
 
@@ -286,17 +291,19 @@ def main():
     greedy, anneal = api.default_solver(cdefs.SOLVER_GREEDY), api.default_solver(cdefs.SOLVER_ANNEAL)
     stage_s = {"score_prefilter": 0.0, "greedy": 0.0, "anneal": 0.0}
     solved = {"greedy_chains": 0, "anneal_chains": 0, "greedy_iterations": 0, "anneal_moves": 0}
+    stages = api.default_stages()
 
     aa_main = aa
 
     def step(it=0, aa=aa, stage_s=stage_s, solved=solved):
+        """One locus through the path, call by call (per-stage wall times; the modes that shard one locus over the ranks)."""
         t0s = time.perf_counter()
         aa.score()
         aa.prefilter_async()
         if args.shard_reads and aa is aa_main:
             comm.prefilter_allreduce(aa)                                      # read shards -> scores of the whole batch on every rank
         scores = aa.prefilter_scores()
-        keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, 1)   # in_size of stage 1 (solve.rs:216-221)
+        keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, params.threads)   # in_size of stage 1 (solve.rs:216-221)
         stage_s["score_prefilter"] += time.perf_counter() - t0s
         if args.no_solve:
             return scores, keep, None
@@ -312,7 +319,7 @@ def main():
             mean[ixs], var[ixs], att[ixs] = m, v, 1
             solved["greedy_chains"] += len(ixs)
             solved["greedy_iterations"] += api.solve_stats(aa)[1]
-            ixs = api.discard_improbable(mean, var, att, ixs, params.prob_thresh, 20, 1)
+            ixs = api.discard_improbable(mean, var, att, ixs, params.prob_thresh, 20, params.threads)
         tm = time.perf_counter()
         m, v, _ = run_stage(aa, gts[ixs], anneal, 20, api.chain_seeds(2000 + it, 20 * len(ixs)))
         mean[ixs], var[ixs], att[ixs] = m, v, 20
@@ -323,19 +330,30 @@ def main():
         stage_s["greedy"] += tm - ts; stage_s["anneal"] += te - tm
         return scores, keep, res
 
+    queue_mode = n_loci == 2
+
+    def run_steps(k, first_it=0):
+        """k steps: a queue of k loci through lcty_solve_queue (default), or k passes call by call."""
+        if queue_mode:
+            order = [(first_it + i) % 2 for i in range(k)]
+            return api.solve_queue([batches[j] for j in order], stages, master_seeds=[1000 + first_it + i for i in range(k)]), order
+        out = None
+        for i in range(k):
+            out = step(first_it + i)
+        return out, None
+
     def barrier():
         ctx.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        run_steps(max(args.warmup, 2) if queue_mode else args.warmup)        # both loci once: allocations, the solver workspaces
     barrier()
     ctx.timing_reset()
     stage_s.update(score_prefilter=0.0, greedy=0.0, anneal=0.0); solved.update(greedy_chains=0, anneal_chains=0, greedy_iterations=0, anneal_moves=0)
     t_start = time.perf_counter()
-    for it in range(args.steps):
-        scores, keep, res = step(it)
+    result, order = run_steps(args.steps, 100)
     ctx.synchronize()
     elapsed = time.perf_counter() - t_start
     barrier()
@@ -346,24 +364,69 @@ def main():
         elapsed = float(t[0])
     n_score, ms_score = ctx.timing(api.K_SCORE)
     n_pref, ms_pref = ctx.timing(api.K_PREFILTER)
-
     n_solve, ms_solve = ctx.timing(api.K_SOLVE)
+    n_ann, ms_ann = ctx.timing(api.K_ANNEAL)
     n_init, ms_init = ctx.timing(api.K_SOLVE_INIT)
     n_tab, ms_tab = ctx.timing(api.K_SOLVE_TABLE)
-    top = int(keep[0]) if res is None else int(res[0][0])
-    called = tuple(int(x) for x in gts[top])
+    calls_ok = None
+    if queue_mode:
+        calls = result
+        called = tuple(int(x) for x in gts[int(calls[-1].ixs[0])])
+        truth = loci[order[-1]][0].true_genotype
+        calls_ok = all(tuple(int(x) for x in gts[int(c.ixs[0])]) == tuple(loci[j][0].true_genotype) for c, j in zip(calls, order))
+        kept = int(calls[-1].kept_after_filter)
+        quality = float(calls[-1].quality)
+        greedy_chains_per_step = float(np.mean([int(c.kept_after_filter) for c in calls]))
+        # per-stage wall times and iteration counts: one more locus call by call, outside the timed region
+        if rank == 0:
+            step(7)
+            ctx.synchronize()
+        res = None
+    else:
+        scores, keep, res = result
+        top = int(keep[0]) if res is None else int(res[0][0])
+        called = tuple(int(x) for x in gts[top]); truth = L.true_genotype
+        kept = int(len(keep)); quality = None if res is None else float(res[2])
+        greedy_chains_per_step = solved["greedy_chains"] / max(args.steps, 1)
 
     if rank != 0:
         return
 
+    n_break = 1 if queue_mode else args.steps                  # steps behind stage_s / solved
     ms_per_step = 1e3 * elapsed / args.steps
     reads_per_s = (total_pairs if one_locus else world * args.pairs) * args.steps / elapsed
     score_ms = ms_score / max(n_score, 1)
     pref_ms = ms_pref / max(n_pref, 1)
+    kern_steps = args.steps + (1 if queue_mode else 0)         # the timers also saw the call-by-call pass
     alg_bytes = survey_bytes_per_pair(A) * args.pairs
     layout_bytes = (tot_bases / 4 + tot_bases / 8 + 16 * tot_recs + 4 * tot_cigar + 8 * A * args.pairs
                     + 8 * 4 * args.pairs)      # what the kernel's inputs/outputs occupy, excl. pair-alignment arena
-    achieved = alg_bytes / (score_ms * 1e-3) / 1e9
+    n_good = aa.n_good()
+    # ---- rooflines of the kernels of a step; `roofline` is the one with the most kernel time (DESIGN.md section 4 for the bytes) ----
+    per_step = {k: v / max(n_break, 1) for k, v in solved.items()}
+    chains_step = per_step["greedy_chains"] + per_step["anneal_chains"]
+    roofs = {
+        "score_reads_kernel": {"ms_per_step": ms_score / kern_steps, "launch_ms": score_ms, "bound": "hbm",
+                               "bytes": alg_bytes, "what": "SURVEY 8(d): 75 + 2*A*16 + 2016 + A*8 B per read pair"},
+        "prefilter_tile_kernel": {"ms_per_step": ms_pref / kern_steps, "launch_ms": pref_ms, "bound": "valu_f64",
+                                  "ops": 2.0 * G * args.pairs, "what": "2 * G * R max-add"},
+        "solve_init_kernel": {"ms_per_step": ms_init / kern_steps, "launch_ms": ms_init / max(n_init, 1), "bound": "hbm",
+                              "bytes": (34.0 * n_good + 207e3) * chains_step / 2 if chains_step else 0.0,
+                              "what": "SURVEY 8(d): the reads CSR once per genotype x attempt, 34 B * R + 207 KB LUT, per launch (two launches per step)"},
+        "greedy_loop_kernel": {"ms_per_step": ms_solve / kern_steps, "launch_ms": ms_solve / max(n_solve, 1), "bound": "hbm",
+                               "bytes": 32.0 * 10 * per_step["greedy_iterations"],
+                               "what": "one 32 B record per candidate read, 10 candidates per iteration"},
+        "anneal_loop_kernel": {"ms_per_step": ms_ann / kern_steps, "launch_ms": ms_ann / max(n_ann, 1), "bound": "hbm",
+                               "bytes": 32.0 * per_step["anneal_moves"], "what": "one 32 B record per evaluated move (latency-bound serial chains)"},
+    }
+    for k, r in roofs.items():
+        if r["bound"] == "hbm":
+            r["achieved"] = r["bytes"] / max(r["launch_ms"], 1e-9) / 1e6; r["peak"] = HBM_PEAK_GBS; r["unit"] = "GB/s"
+        else:
+            r["achieved"] = r["ops"] / max(r["launch_ms"], 1e-9) / 1e9; r["peak"] = 39.3; r["unit"] = "Tmaxadd/s"
+        r["frac"] = r["achieved"] / r["peak"]
+    dominant = max((k for k in roofs if roofs[k]["bound"] == "hbm"), key=lambda k: roofs[k]["ms_per_step"])
+    achieved = roofs["score_reads_kernel"]["achieved"]
     out = {
         "metric": "reads/s through the whole genotyping path (scored + prefiltered + default solver scheme); "
                   "reads_scored_per_s and genotypes_solved_per_s give the two halves",
@@ -378,98 +441,49 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.pairs} synthetic 150 bp PE read pairs x {A} alleles, 1 locus per GPU, k=25 "
+        "config": {"workload": f"{args.pairs} synthetic 150 bp PE read pairs x {A} alleles, 1 locus per step, k=25 "
                                + ("(BASELINE.json configs[1])" if (total_pairs, A) == (1_000_000, 256) and not one_locus
                                   else "(one GPU's share of BASELINE.json configs[4])" if A == 4096
                                   else "(not a BASELINE.json configuration)"),
                    "read_pairs": args.pairs, "alleles": A, "genotypes": G, "k": 25,
-                   "records": tot_recs, "cigar_words": tot_cigar, "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
-        "reads_scored_per_s": (total_pairs if args.shard_reads else args.pairs if args.shard_chains else world * args.pairs) * args.steps / max(stage_s["score_prefilter"], 1e-9),
-        "genotypes_prefiltered_per_s": world * G * args.steps / max(stage_s["score_prefilter"], 1e-9),
+                   "records": tot_recs, "cigar_words": tot_cigar,
+                   "step": ("one locus through lcty_solve_queue (score + run_filter + default solver scheme + final comparison); the queue "
+                            "alternates between two resident loci and overlaps the annealing stage of a locus with the next locus"
+                            if queue_mode else "one locus, call by call"),
+                   "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
+        "reads_scored_per_s": (total_pairs if args.shard_reads else args.pairs if args.shard_chains else args.pairs) * n_break / max(stage_s["score_prefilter"], 1e-9),
+        "genotypes_prefiltered_per_s": G * n_break / max(stage_s["score_prefilter"], 1e-9),
         "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3),
-        "kernel_ms": {"score_reads": score_ms, "prefilter": pref_ms, "solve_loop_per_step": ms_solve / args.steps,
-                      "solve_init_per_step": ms_init / args.steps, "solve_table_per_step": ms_tab / args.steps},
+        "kernel_ms_per_step": {k: r["ms_per_step"] for k, r in roofs.items()} | {"build_loc_table_kernel": ms_tab / kern_steps},
         "solver": None if args.no_solve else {
             "scheme": "greedy:i=5k,a=1 -> anneal:i=20,a=20 -> final comparison",
-            "genotypes_solved_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"] / 20.0)
-                                      / max(stage_s["greedy"] + stage_s["anneal"], 1e-9),
-            "chains_per_s": world * (solved["greedy_chains"] + solved["anneal_chains"]) / max(stage_s["greedy"] + stage_s["anneal"], 1e-9),
-            "per_step": {k: v / args.steps for k, v in solved.items()},
-            "stage_ms_per_step": {k: 1e3 * v / args.steps for k, v in stage_s.items()},
-            "quality": None if res is None else float(res[2])},
-        "roofline": {"bound": "hbm", "kernel": "score_reads_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "layout_bytes_per_launch": layout_bytes,
-                     "achieved_layout_GBs": layout_bytes / (score_ms * 1e-3) / 1e9},
-        "roofline_solver": None if args.no_solve else {
-            "bound": "hbm", "kernel": "solve_loop_kernel (greedy + annealing launches)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            # per evaluated candidate read: 4 B list slot + one 32 B location cell per contig of the genotype; the
-            # depth table and window weights are cache resident by design
-            "algorithmic_bytes_per_step": (4 + 32 * 2) * (10 * solved["greedy_iterations"] + solved["anneal_moves"]) / args.steps,
-            "achieved": (4 + 32 * 2) * (10 * solved["greedy_iterations"] + solved["anneal_moves"]) / max(ms_solve, 1e-9) / 1e6,
-            "frac": (4 + 32 * 2) * (10 * solved["greedy_iterations"] + solved["anneal_moves"]) / max(ms_solve, 1e-9) / 1e6 / HBM_PEAK_GBS,
-            "note": "serial chains: bound by dependent gathers, not by bandwidth"},
-        "roofline_prefilter": {"bound": "valu_f64", "achieved": 2.0 * G * args.pairs / (pref_ms * 1e-3) / 1e12,
-                               "peak": 39.3, "unit": "Tmaxadd/s",
-                               "frac": 2.0 * G * args.pairs / (pref_ms * 1e-3) / 1e12 / 39.3},
-        "called_genotype": called, "true_genotype": L.true_genotype, "kept_after_prefilter": int(len(keep)),
+            "genotypes_solved_per_s": world * (greedy_chains_per_step + 20) * args.steps / elapsed,
+            "chains_per_s": world * (greedy_chains_per_step + 400) * args.steps / elapsed,
+            "per_step": per_step,
+            "call_by_call_stage_ms": {k: 1e3 * v / max(n_break, 1) for k, v in stage_s.items()},
+            "quality": quality, "all_calls_equal_truth": calls_ok},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roofs[dominant]["achieved"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": roofs[dominant]["frac"], "traffic": None,
+                     "algorithmic_bytes_per_launch": roofs[dominant]["bytes"], "launch_ms": roofs[dominant]["launch_ms"],
+                     "what": roofs[dominant]["what"]},
+        "roofline_all": roofs,
+        "roofline_score_layout": {"layout_bytes_per_launch": layout_bytes, "achieved_layout_GBs": layout_bytes / (score_ms * 1e-3) / 1e9},
+        "called_genotype": called, "true_genotype": truth, "kept_after_prefilter": kept,
         "setup_s": {"generate_and_upload": gen_s, "locus_create": locus_setup_s},
     }
 
-    # HBM traffic of the scoring kernel from the committed PMC passes (counters cannot be read from inside this process)
+    # HBM traffic from the committed PMC passes (counters cannot be read from inside this process)
     try:
         tr = json.load(open(args.traffic))
         if tr.get("read_pairs") == args.pairs and tr.get("alleles") == A:
-            k = tr["kernels"]["lcty::score_reads_kernel"]
-            out["roofline"]["traffic"] = k["hbm_bytes"]
+            for name, r in roofs.items():
+                k = tr["kernels"].get("lcty::" + name) or next((v for n, v in tr["kernels"].items() if n.startswith("lcty::" + name) or n.startswith("void lcty::" + name)), None)
+                if k:
+                    r["traffic"] = k["hbm_bytes"]; r["traffic_fetch_raw"] = k.get("fetch_bytes_raw")
+            out["roofline"]["traffic"] = roofs[dominant].get("traffic")
             out["roofline"]["traffic_source"] = os.path.relpath(args.traffic, ROOT) + " (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE)"
-            if out.get("roofline_solver"):
-                ks = [v for name, v in tr["kernels"].items() if name.startswith("lcty::solve_loop_kernel")]
-                out["roofline_solver"]["traffic"] = sum(v["hbm_bytes"] for v in ks)
-                out["roofline_solver"]["traffic_fetch_raw"] = sum(v["fetch_bytes_raw"] for v in ks)
     except (OSError, KeyError, ValueError):
         pass
-
-    if args.pipeline > 1 and world == 1 and not args.no_solve:
-        # ---- loci in flight: the same batch on further contexts (own stream each), one host thread per locus; a production run
-        # genotypes many loci, and the serial annealing chains of one leave the GPU to the scoring and greedy stages of the next ----
-        import threading
-        workers = [(ctx, aa)]
-        for w in range(1, args.pipeline):
-            cw = api.Context(local_rank % ndev)
-            lw = api.Locus(cw, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
-            aw = api.AllAlignments(lw, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096, int(dens_c * args.pairs * head) + 65536)
-            for ci in range(n_chunks):
-                lo = ci * args.chunk
-                aw.append(L.reads(lo, min(args.chunk, args.pairs - lo)))
-            workers.append((cw, aw))
-        scratch = [({"score_prefilter": 0.0, "greedy": 0.0, "anneal": 0.0},
-                    {"greedy_chains": 0, "anneal_chains": 0, "greedy_iterations": 0, "anneal_moves": 0}) for _ in workers]
-        for (cw, aw), (ss, so) in zip(workers[1:], scratch[1:]):
-            step(0, aw, ss, so)                                              # warm-up of the new batches (allocations)
-            cw.synchronize()
-        errs = []
-
-        def run(aw, ss, so):
-            try:
-                for it in range(args.steps):
-                    step(it, aw, ss, so)
-            except Exception as e:      # noqa: BLE001 - reported below
-                errs.append(e)
-        threads = [threading.Thread(target=run, args=(aw, ss, so)) for (cw, aw), (ss, so) in zip(workers, scratch)]
-        tp0 = time.perf_counter()
-        for t in threads: t.start()
-        for t in threads: t.join()
-        for cw, aw in workers: cw.synchronize()
-        tp = time.perf_counter() - tp0
-        if errs:
-            raise errs[0]
-        out["pipelined"] = {"loci_in_flight": len(workers), "steps_per_locus": args.steps, "elapsed_s": tp,
-                            "read_pairs_per_s": len(workers) * args.steps * args.pairs / tp,
-                            "ms_per_step": 1e3 * tp / (len(workers) * args.steps),
-                            "note": "not `value`: the same step on several contexts of one GPU at once"}
-        for cw, aw in workers[1:]:
-            aw.close()
 
     if args.recruit_sample > 0 and world == 1:
         # ---- minimizer read recruitment (Targets::recruit_read_pair, seq/recruit.rs:883-929), the step before the path: random

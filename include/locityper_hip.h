@@ -190,7 +190,7 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
 /* Limits of the retry / batching machinery of this context, for tests that must reach those paths with small inputs (no
  * environment variable changes what the library computes): "transfer_levels", "transfer_scratch_mb", "transfer_waves",
  * "transfer_cap_new", "transfer_arena" (lcty_recover_alignments: scratch levels, arenas), "depth_table_start" (first width of the
- * extended depth table), "solve_budget_mb" (device memory for the per-chain state of a solver stage), "solve_chains_per_wave",
+ * extended depth table), "solve_budget_mb" (device memory for the per-chain state of a solver stage), "solve_chains_per_wave", "solve_extra_start" (first size of a chain's run of locations beyond the second),
  * "solve_stats" (1: per-stage iteration counts on stderr). value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT.
  * None of them changes a result. */
 int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value);
@@ -455,6 +455,14 @@ typedef struct lcty_call {
 int32_t lcty_stages_default(lcty_stage* stages /* [2] */, uint32_t* n_stages);
 int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages, uint64_t master_seed,
                    const double* priors, lcty_call* out, double* lik_mean, double* lik_var, uint32_t* attempts_out);
+/* The loop of `locityper genotype` over its loci (analyze_locus one after the other, command/genotype.rs:1331-1351) as a queue on one
+ * GPU: for every entry lcty_score_reads + lcty_solve. Loci are independent, so the last stage of entry i (by default the annealing
+ * attempts: a few hundred long serial chains on a few per cent of the device) runs on a second stream of the context, from a second
+ * host thread, while entry i + 1 is scored, prefiltered and greedily solved. out[i] equals what lcty_solve gives for entry i alone.
+ * All batches share one context; neighbours in the queue are different batches of different lcty_locus objects (a batch may come
+ * again later in the queue: it is scored again). master_seeds[n_batches]; priors NULL or [n_batches] pointers (NULL = no priors). */
+int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages,
+                         const uint64_t* master_seeds, const double* const* priors, lcty_call* out);
 
 /* Diagnostics of the last lcty_solve_stage on this batch: chains run, solver iterations (greedy iterations /
  * annealing moves) and accepted moves summed over the chains (stoch.rs has no counterpart; used by bench.py). */
@@ -472,12 +480,13 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
  * stream; kernel ids LCTY_K_*.                                                 */
 #define LCTY_K_SCORE     0
 #define LCTY_K_PREFILTER 1
-#define LCTY_K_SOLVE     2   /* solve_loop_kernel: the Greedy / SimAnneal chains */
-#define LCTY_K_SOLVE_INIT  3 /* solve_init_kernel: apply_tweak + ReadAssignment::try_new of every chain */
+#define LCTY_K_SOLVE     2   /* greedy_loop_kernel: the Greedy chains */
+#define LCTY_K_SOLVE_INIT  3 /* solve_init_kernel: apply_tweak + ReadAssignment::try_new of every chain, its records */
 #define LCTY_K_SOLVE_TABLE 4 /* build_loc_table_kernel: allele-major location table of a scored batch */
 #define LCTY_K_TRANSFER  5   /* transfer_kernel: alignment recovery */
 #define LCTY_K_RECRUIT   6   /* recruit_kernel: minimizer read recruitment */
-#define LCTY_K_COUNT     7
+#define LCTY_K_ANNEAL    7   /* anneal_loop_kernel: the SimAnneal chains */
+#define LCTY_K_COUNT     8
 /* Timing is opt-in: nothing is recorded before the first lcty_timing_reset on a context (a production run that never reads
  * timings creates no events); afterwards every launch is bracketed by two events, at most 256 pairs per kernel id kept. */
 int32_t lcty_timing_reset(lcty_ctx* ctx);

@@ -68,6 +68,7 @@ class Context:
 
 
 K_SCORE, K_PREFILTER, K_SOLVE, K_SOLVE_INIT, K_SOLVE_TABLE = 0, 1, 2, 3, 4
+K_TRANSFER, K_ANNEAL = 5, 7
 
 
 class Locus:
@@ -481,6 +482,28 @@ def solve_locus(aa, stages=None, master_seed=1, priors=None, ploidy=2):
     check(lib().lcty_solve(aa._h, ploidy, stages, len(stages), master_seed, None if pri is None else pri.ctypes.data, C.byref(call),
                            mean.ctypes.data, var.ctypes.data, att.ctypes.data))
     return call, mean, var, att
+
+
+def solve_queue(batches, stages=None, master_seeds=None, priors=None, ploidy=2):
+    """lcty_solve_queue: score + solve every batch of the list (loci of one context), the last stage of each overlapped with the
+    next entry. Returns the list of Call structs, one per entry."""
+    stages = default_stages() if stages is None else stages
+    n = len(batches)
+    handles = (VP * n)(*[b._h for b in batches])
+    seeds = np.ascontiguousarray(np.arange(1, n + 1) if master_seeds is None else master_seeds, dtype=np.uint64)
+    assert len(seeds) == n
+    pri_ptr = None
+    keep = []
+    if priors is not None:
+        arr = (VP * n)()
+        for i, p in enumerate(priors):
+            if p is not None:
+                keep.append(np.ascontiguousarray(p, dtype=np.float64))
+                arr[i] = keep[-1].ctypes.data
+        pri_ptr = arr
+    calls = (cdefs.Call * n)()
+    check(lib().lcty_solve_queue(handles, n, ploidy, stages, len(stages), seeds.ctypes.data, pri_ptr, calls))
+    return list(calls)
 
 
 K_RECRUIT = 6

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -125,6 +126,7 @@ struct lcty_ctx {
     hipDeviceProp_t props{};
     lcty::KernelTimer timers[LCTY_K_COUNT];
     std::vector<hipEvent_t> event_pool;
+    std::mutex timing_mutex;
     bool timing_on = false;                           // lcty_timing_reset switches the event timing on; a run that never asks pays nothing
     std::map<std::string, int64_t> knobs;             // lcty_ctx_set_knob: limits that tests lower to exercise retry / batching paths
 
@@ -136,11 +138,16 @@ struct lcty_ctx {
         if (!timing_on) { fn(); return; }
         if (!on) on = stream;
         lcty::KernelTimer& t = timers[kernel];
-        if (t.pending.size() >= 256) fold_oldest(t, 128);
-        hipEvent_t a = get_event(), b = get_event();
+        hipEvent_t a, b;
+        {
+            std::lock_guard<std::mutex> g(timing_mutex);          // lcty_solve_queue times launches from two host threads
+            if (t.pending.size() >= 256) fold_oldest(t, 128);
+            a = get_event(); b = get_event();
+        }
         LCTY_HIP(hipEventRecord(a, on));
         fn();
         LCTY_HIP(hipEventRecord(b, on));
+        std::lock_guard<std::mutex> g(timing_mutex);
         t.pending.emplace_back(a, b);
     }
     // Second stream of the context: the last solver stage of a locus (a few long serial chains) runs here while the next

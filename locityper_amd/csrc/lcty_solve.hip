@@ -1254,7 +1254,7 @@ void launch_anneal(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t 
     if (lds > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(anneal_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
-    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(anneal_loop_kernel, dim3(nch), dim3(128), lds, s, V); }, s);
+    ctx->timed(LCTY_K_ANNEAL, [&] { hipLaunchKernelGGL(anneal_loop_kernel, dim3(nch), dim3(128), lds, s, V); }, s);
     LCTY_HIP(hipGetLastError());
 }
 
@@ -1323,6 +1323,7 @@ struct StageRunner {
         if (ws.extra_cap == 0 || ws.extra_for_ngp != ngp || ws.extra_for_ploidy != ploidy) {
             ws.extra_cap = static_cast<uint32_t>(std::min<uint64_t>(ngp * (ploidy > 2 ? ploidy - 2 : 0) + std::max<uint64_t>(256, ngp / 64), (1u << 24) - 1));
             ws.extra_for_ngp = ngp; ws.extra_for_ploidy = ploidy;
+            if (ctx->knob("solve_extra_start", 0) > 0) ws.extra_cap = static_cast<uint32_t>(ctx->knob("solve_extra_start", 0));   // tests: exercise the growth
         }
         plan_batches();
         V.overflow = ws.ovf.p;

@@ -305,3 +305,66 @@ def test_library_scheme_driver_equals_the_composed_calls(gpu_ctx):
     # the default scheme runs too (fewer genotypes than the first stage takes: no filter, greedy stage on all 78)
     call2, _, _, att2 = api.solve_locus(aa)
     assert call2.kept_after_filter == 78 and tuple(gts[int(call2.ixs[0])]) == L.true_genotype and att2.max() == 20
+
+
+def test_chains_per_wavefront_and_wide_samples_do_not_change_results(gpu_ctx):
+    """The greedy kernel puts 64 / LPC chains into a wavefront (LPC = 16 lanes per chain for samples of up to 16 reads, 32 and 64
+    beyond): every layout must give the chains of the oracle, including a last wavefront with spare rows."""
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 8, 4000, 20000)
+    gts = api.generate_genotypes(8, 2)[:13]                              # 13 chains x 2 attempts = 26: not a multiple of 4
+    seeds = api.chain_seeds(77, 26)
+    g = api.default_solver(cdefs.SOLVER_GREEDY)
+    ref = compare_stage(aa, ol, oa, gts, g, 2, seeds)
+    for cpw in (1, 2, 4):
+        gpu_ctx.set_knob("solve_chains_per_wave", cpw)
+        try:
+            got = api.solve_stage(aa, gts, g, 2, seeds)
+        finally:
+            gpu_ctx.set_knob("solve_chains_per_wave", -1)
+        assert np.array_equal(got[2], ref[2]), cpw
+    for sample in (1, 16, 17, 32, 40, 64):
+        g2 = api.default_solver(cdefs.SOLVER_GREEDY)
+        g2.sample_size = sample
+        compare_stage(aa, ol, oa, gts[:5], g2, 2, seeds[:10])
+
+
+def test_reads_with_many_locations_and_the_growth_of_their_runs(gpu_ctx):
+    """Locations beyond the second of a read (ploidy > 2; "both unmapped" within reach with a small unmapped penalty) live in a run per
+    chain that starts small and grows on demand: same chains as the oracle, whatever the first size."""
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 6, 2500, 12000)
+    g3 = api.generate_genotypes(6, 3)[:9]
+    seeds = api.chain_seeds(4, 18)
+    ref = [compare_stage(aa, ol, oa, g3, api.default_solver(k), 2, seeds)[2] for k in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL)]
+    gpu_ctx.set_knob("solve_extra_start", 7)
+    try:
+        gpu_ctx.trim()                                                   # forget the run size of the stage before
+        got = [api.solve_stage(aa, g3, api.default_solver(k), 2, seeds)[2] for k in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL)]
+    finally:
+        gpu_ctx.set_knob("solve_extra_start", -1)
+        gpu_ctx.trim()
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    g4 = api.generate_genotypes(6, 4)[:4]
+    compare_stage(aa, ol, oa, g4, api.default_solver(cdefs.SOLVER_ANNEAL), 2, api.chain_seeds(6, 8))
+
+
+def test_queue_of_loci_equals_one_locus_at_a_time(gpu_ctx):
+    """lcty_solve_queue overlaps the last stage of a locus (side stream, second host thread) with the head of the next one: every
+    entry must get exactly what lcty_solve gives it alone, also when a batch comes back later in the queue."""
+    stages = (cdefs.Stage * 2)()
+    stages[0].solver = api.default_solver(cdefs.SOLVER_GREEDY); stages[0].in_size = 30; stages[0].attempts = 1
+    stages[1].solver = api.default_solver(cdefs.SOLVER_ANNEAL); stages[1].in_size = 5; stages[1].attempts = 4
+    cases = [setup(gpu_ctx, 10, 3000 + 700 * i, 15000, seed=40 + i) for i in range(3)]
+    batches = [c[3] for c in cases]
+    alone = [api.solve_locus(b, stages, master_seed=11 + i)[0] for i, b in enumerate(batches)]
+    order = [0, 1, 2, 0, 1]
+    calls = api.solve_queue([batches[i] for i in order], stages, master_seeds=[11 + i for i in order])
+    for i, c in zip(order, calls):
+        a = alone[i]
+        n = int(a.n_out)
+        assert int(c.n_out) == n and list(c.ixs[:n]) == list(a.ixs[:n])
+        assert list(c.ln_probs[:n]) == list(a.ln_probs[:n]) and c.quality == a.quality
+        assert (c.unexpl_reads, c.n_good, c.warnings, c.kept_after_filter) == (a.unexpl_reads, a.n_good, a.warnings, a.kept_after_filter)
+        assert tuple(api.generate_genotypes(10, 2)[int(c.ixs[0])]) == cases[i][0].true_genotype
+    with pytest.raises(_lib.LocityperError) as e:                       # neighbours must be different loci
+        api.solve_queue([batches[0], batches[0]], stages)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
