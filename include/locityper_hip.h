@@ -247,6 +247,10 @@ int32_t lcty_locus_depth_lut(const lcty_locus* locus, double* out /* [101*256] *
 /* ContigInfo::neighb_info weight (windows.rs:439-445) of every moving-window position, alleles concatenated
  * (sum over alleles of len - neighb + 1 values) */
 int32_t lcty_locus_window_weights(const lcty_locus* locus, double* out);
+/* The depth table of the solver stages: DistrCache (src/model/distr_cache.rs:61-92) past the 256 entries of the reference's
+ * LinearCache, the same BayesCalc::ln_pmf (src/math/distr/bayes.rs:27-35) evaluated on the device. *width_io is rounded up to a
+ * power of two >= 256; out (may be NULL to ask for the width) receives [101][width]. */
+int32_t lcty_locus_depth_table(lcty_locus* locus, uint32_t* width_io, double* out);
 
 /* Explicit region weights (`locityper genotype --reg-weights`): replaces load_explicit_weights (src/model/windows.rs:257-317)
  * minus the text parsing — the lines of the BED file in file order as (allele index, start, end, value); an index >= n_alleles
@@ -491,6 +495,38 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
  * timings creates no events); afterwards every launch is bracketed by two events, at most 256 pairs per kernel id kept. */
 int32_t lcty_timing_reset(lcty_ctx* ctx);
 int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, double* total_ms);
+
+/* ---- file formats at the edges of the path (host code, no device) --------------------------------------------
+ * lcty_io_read_file: the whole file with its container removed, chosen by the extension as ext::sys::open does: .gz / .bgz / .bam
+ *   gzip members (zlib), .lz4 LZ4 frames, .br brotli streams one after the other (src/ext/sys/brotli.rs:18-86; needs the system's
+ *   libbrotlidec.so.1, LCTY_ERR_UNSUPPORTED without it), anything else as it is. *data is released with lcty_io_free.
+ *   `kmers.bin.br` / `.lz4` (command/paths.rs:4-5) -> lcty_io_read_file -> lcty_kmer_counts_parse.
+ * lcty_io_write_gz: ext::sys::create_gzip + write.
+ * lcty_bg_from_json: BgDistr::load (src/bg/mod.rs:159-177) on the text of PREPROC/distr.gz: seq_info (349-364), insert_distr
+ *   ({} = single-end, bg/insertsz.rs:195-208), error_profile (bg/err_prof.rs:321-329), bg_depth (bg/depth.rs:400-412; required, as
+ *   `locityper genotype` requires it); edit thresholds = EditThresh::default_for (err_prof.rs:394-399). Missing keys / wrong types
+ *   -> LCTY_ERR_INVALID_DATA (Error::JsonLoad).
+ * lcty_res_to_json: Genotyping::to_json (src/solvers/solve.rs:732-773) in the layout of write_pretty(.., 4) (genotype.rs:1256):
+ *   total_reads, quality, [dist_type, weight_dist], unexpl_reads, genotype, options[{genotype, lik_mean, lik_sd, prob, log10_prob,
+ *   [dist_to_primary]}], [warnings]; lik_sd is the log10-scaled VARIANCE, as upstream (solve.rs:755). genotypes[n_out][ploidy],
+ *   lik_mean / lik_var[n_out] in the order of call->ixs. Two calls: out = NULL sizes it (*needed includes the final 0). */
+int32_t lcty_io_read_file(const char* path, uint8_t** data, uint64_t* len);
+void    lcty_io_free(void* p);
+int32_t lcty_io_write_gz(const char* path, const uint8_t* data, uint64_t len);
+int32_t lcty_bg_from_json(const char* json, uint64_t len, lcty_bg* bg, double* read_len);
+int32_t lcty_res_to_json(const lcty_call* call, const uint16_t* genotypes, uint32_t ploidy, const char* const* names, uint32_t n_alleles,
+                         const double* lik_mean, const double* lik_var, const uint32_t* distances, int32_t true_edit_distances,
+                         double weighted_dist, char* out, uint64_t cap, uint64_t* needed);
+/* OUT/loci/<locus>/aln.bam -> the flat table of lcty_reads_append, grouped as AllAlignments::load walks the records
+ * (src/model/locs.rs:405-461, 502-567, 1116-1150): a group = a primary record + the non-primary records behind it; the first group
+ * of a read is its first end, with paired != 0 the next group (same name, else LCTY_ERR_INVALID_DATA as ReadData::set_name,
+ * 147-155) its second. Reference names map to allele indices through names[n_alleles] (construct_tid_to_contig_map, 388-401).
+ * lcty_bam_table_view: the table (valid while the handle lives), read names (name_off[n_pairs + 1] into name_blob) and the number
+ * of reference sequences of the header (fewer than alleles: set lcty_params.strict_subset, locs.rs:486). */
+typedef struct lcty_bam_table lcty_bam_table;
+int32_t lcty_bam_read(const char* path, const char* const* names, uint32_t n_alleles, int32_t paired, lcty_bam_table** out);
+int32_t lcty_bam_table_view(const lcty_bam_table* t, lcty_reads_host* view, const uint64_t** name_off, const char** name_blob, uint32_t* n_refs);
+void    lcty_bam_table_free(lcty_bam_table* t);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lcty_targets_add_locus": (I32, [VP, U32, VP, VP, VP, VP, U32, P(U32)]),
     "lcty_targets_finalize": (I32, [VP, P(U64)]),
     "lcty_recruit": (I32, [VP, VP, I32, U32, VP, VP]),
+    "lcty_locus_depth_table": (I32, [VP, P(U32), VP]),
     "lcty_solver_default": (I32, [P(Solver), I32]),
     "lcty_chain_seeds": (I32, [U64, U64, VP]),
     "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
@@ -76,6 +77,14 @@ SIGNATURES = {
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),
     "lcty_ctx_set_knob": (I32, [VP, C.c_char_p, C.c_int64]),
     "lcty_ctx_trim": (I32, [VP]),
+    "lcty_io_read_file": (I32, [C.c_char_p, P(VP), P(U64)]),
+    "lcty_io_free": (None, [VP]),
+    "lcty_io_write_gz": (I32, [C.c_char_p, VP, U64]),
+    "lcty_bg_from_json": (I32, [C.c_char_p, U64, VP, P(D)]),
+    "lcty_res_to_json": (I32, [VP, VP, U32, VP, U32, VP, VP, VP, I32, D, VP, U64, P(U64)]),
+    "lcty_bam_read": (I32, [C.c_char_p, VP, U32, I32, P(VP)]),
+    "lcty_bam_table_view": (I32, [VP, VP, P(VP), P(VP), P(U32)]),
+    "lcty_bam_table_free": (None, [VP]),
     "lcty_timing_reset": (I32, [VP]),
     "lcty_timing_get": (I32, [VP, I32, P(U64), P(D)]),
 }

@@ -152,6 +152,14 @@ class Locus:
         check(lib().lcty_locus_window_weights(self._h, out.ctypes.data))
         return out
 
+    def depth_table(self, width):
+        """lcty_locus_depth_table: the extended depth table of the solver stages, [101][width rounded up to a power of two]."""
+        w = U32(width)
+        check(lib().lcty_locus_depth_table(self._h, C.byref(w), None))
+        out = np.zeros((cdefs.GC_BINS, int(w.value)), dtype=np.float64)
+        check(lib().lcty_locus_depth_table(self._h, C.byref(w), out.ctypes.data))
+        return out
+
     def depth_lut(self):
         out = np.zeros((cdefs.GC_BINS, cdefs.DEPTH_CACHE), dtype=np.float64)
         check(lib().lcty_locus_depth_lut(self._h, out.ctypes.data))

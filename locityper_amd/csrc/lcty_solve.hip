@@ -1482,6 +1482,28 @@ uint32_t count_unexplained_on(hipStream_t s, lcty_reads* reads, const uint16_t* 
 extern "C" {
 
 
+// read-back of the extended depth table of the solver stages (DistrCache past the LinearCache, distr_cache.rs:61-92 with
+// bayes.rs:27-35 on the device): out[gc * width + depth], width = *width_io rounded up to a power of two >= 256
+int32_t lcty_locus_depth_table(lcty_locus* locus, uint32_t* width_io, double* out) {
+    return guarded([&] {
+        if (!locus || !width_io) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        uint32_t w = LCTY_DEPTH_CACHE;
+        while (w < *width_io) w *= 2;
+        if (w > (1u << 22)) fail(LCTY_ERR_INVALID_INPUT, "depth table width %u", *width_io);
+        *width_io = w;
+        if (!out) return;
+        lcty_ctx* ctx = locus->ctx;
+        ctx->activate();
+        ensure_depth_table(locus, w);
+        // the locus may hold a wider table already: rows are lut_ext_depth apart
+        std::vector<double> full(static_cast<size_t>(LCTY_GC_BINS) * locus->lut_ext_depth);
+        locus->d_lut_ext.download(full.data(), full.size(), ctx->stream);
+        LCTY_HIP(hipStreamSynchronize(ctx->stream));
+        for (uint32_t g = 0; g < LCTY_GC_BINS; g++)
+            memcpy(out + static_cast<size_t>(g) * w, full.data() + static_cast<size_t>(g) * locus->lut_ext_depth, sizeof(double) * w);
+    });
+}
+
 // Greedy::default / SimAnneal::default (src/solvers/stoch.rs:45-52, 161-168)
 int32_t lcty_solver_default(lcty_solver* s, int32_t kind) {
     return guarded([&] {

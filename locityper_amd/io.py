@@ -1,0 +1,85 @@
+"""ctypes wrappers of the file-format entry points of liblocityper_hip.so (lcty_io.hip): harness code for tests, bench and examples."""
+import ctypes as C
+
+import numpy as np
+
+from . import cdefs
+from ._lib import lib, check, VP, U32, U64, D
+
+
+def read_file(path):
+    """lcty_io_read_file: the bytes of a file with its .gz / .lz4 / .br container removed."""
+    data, n = VP(), U64()
+    check(lib().lcty_io_read_file(str(path).encode(), C.byref(data), C.byref(n)))
+    try:
+        return C.string_at(data, n.value)
+    finally:
+        lib().lcty_io_free(data)
+
+
+def write_gz(path, data):
+    buf = bytes(data)
+    check(lib().lcty_io_write_gz(str(path).encode(), buf, len(buf)))
+
+
+def bg_from_json(text):
+    """BgDistr::load -> (Bg, mean read length)."""
+    if isinstance(text, str):
+        text = text.encode()
+    bg, rl = cdefs.Bg(), D()
+    check(lib().lcty_bg_from_json(text, len(text), C.byref(bg), C.byref(rl)))
+    return bg, float(rl.value)
+
+
+def res_to_json(call, genotypes, names, lik_mean, lik_var, distances=None, true_edit=False, weighted_dist=float("nan")):
+    """Genotyping::to_json as text. genotypes[n_out][ploidy], lik_mean / lik_var[n_out] (natural log), in call.ixs order."""
+    gt = np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n_out, ploidy = gt.shape
+    assert n_out == int(call.n_out)
+    nm = (C.c_char_p * len(names))(*[s.encode() for s in names])
+    lm = np.ascontiguousarray(lik_mean, dtype=np.float64); lv = np.ascontiguousarray(lik_var, dtype=np.float64)
+    dist = None if distances is None else np.ascontiguousarray(distances, dtype=np.uint32)
+    need = U64()
+    args = (C.byref(call), gt.ctypes.data, ploidy, nm, len(names), lm.ctypes.data, lv.ctypes.data,
+            None if dist is None else dist.ctypes.data, int(true_edit), float(weighted_dist))
+    check(lib().lcty_res_to_json(*args, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(int(need.value))
+    check(lib().lcty_res_to_json(*args, buf, need.value, C.byref(need)))
+    return buf.value.decode()
+
+
+class BamTable:
+    """lcty_bam_read: aln.bam as a ReadsChunk (+ read names)."""
+
+    def __init__(self, path, names, paired=True):
+        self._h = VP()
+        nm = (C.c_char_p * len(names))(*[s.encode() for s in names])
+        check(lib().lcty_bam_read(str(path).encode(), nm, len(names), int(paired), C.byref(self._h)))
+        view = cdefs.ReadsHost()
+        noff, blob, nref = VP(), VP(), U32()
+        check(lib().lcty_bam_table_view(self._h, C.byref(view), C.byref(noff), C.byref(blob), C.byref(nref)))
+        self.view, self.n_refs = view, int(nref.value)
+        n = int(view.n_pairs)
+        self.n_pairs = n
+
+        def arr(p, count, dt):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(dt)), (count,)).copy() if count else np.zeros(0, dtype=dt)
+        mate_off = arr(view.mate_off, 2 * n + 1, C.c_uint64)
+        aln_off = arr(view.aln_off, n + 1, C.c_uint64)
+        cigar_off = arr(view.cigar_off, n + 1, C.c_uint64)
+        n_bases = int(mate_off[-1]) if n else 0
+        recs = np.frombuffer(C.string_at(view.recs, 16 * int(aln_off[-1])), dtype=cdefs.ALN_REC_DTYPE).copy() if n else np.zeros(0, dtype=cdefs.ALN_REC_DTYPE)
+        self.chunk = cdefs.ReadsChunk(arr(view.mate_len, 2 * n, C.c_uint32), mate_off, arr(view.bases2, max((n_bases + 15) // 16, 2), C.c_uint32),
+                                      arr(view.nmask, max((n_bases + 31) // 32, 1), C.c_uint32), aln_off, recs, cigar_off,
+                                      arr(view.cigar, int(cigar_off[-1]) if n else 0, C.c_uint32))
+        no = arr(noff, n + 1, C.c_uint64)
+        raw = C.string_at(blob, int(no[-1])) if n else b""
+        self.names = [raw[int(no[i]):int(no[i + 1])].decode() for i in range(n)]
+
+    def close(self):
+        if self._h:
+            lib().lcty_bam_table_free(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        self.close()

@@ -141,6 +141,10 @@ uint64_t orc_counter_u64(uint64_t key, uint64_t i);
 double   orc_weight_calc(double breakpoint, double power, double x);
 /* ContigInfo::neighb_info weight for a window starting at `wstart` (windows.rs:439-445); *gc = NeighbInfo::gc_content */
 double   orc_window_weight(const orc_locus* l, uint32_t allele, uint32_t wstart, uint32_t* gc);
+/* bulk forms for the pin tests: every per-position window weight (the oracle's own, not the injected ones); BayesCalc::ln_pmf
+ * for every GC bin and depth lo..hi-1 */
+void     orc_locus_window_weights(const orc_locus* l, double* out);
+void     orc_depth_table(const lcty_bg* bg, const lcty_params* prm, uint32_t lo, uint32_t hi, double* out);
 /* WindowDistr::ln_prob of the depth LUT / direct evaluation (distr_cache.rs:34-39, lincache.rs:41-48) */
 double   orc_depth_ln_prob(const orc_locus* l, uint32_t gc, double weight, uint32_t depth);
 

@@ -92,6 +92,23 @@ double orc_window_weight(const orc_locus* l, uint32_t allele, uint32_t wstart, u
     return w * ew;
 }
 
+/* every per-position window weight of the locus (alleles concatenated, len - neighb + 1 values each): the oracle's own values,
+ * whatever has been injected; and BayesCalc::ln_pmf for gc 0..100 x depth lo..hi-1 (out[gc * (hi - lo) + d - lo]) */
+void orc_locus_window_weights(const orc_locus* l, double* out) {
+    double* inj = l->win_weight_inj;
+    ((orc_locus*)l)->win_weight_inj = NULL;
+    size_t at = 0;
+    for (uint32_t a = 0; a < l->n_alleles; a++) {
+        const uint32_t npos = l->infos[a].len + 1 - l->bg.neighb;
+        for (uint32_t i = 0; i < npos; i++) out[at++] = orc_window_weight(l, a, i + l->left_padding, NULL);
+    }
+    ((orc_locus*)l)->win_weight_inj = inj;
+}
+void orc_depth_table(const lcty_bg* bg, const lcty_params* prm, uint32_t lo, uint32_t hi, double* out) {
+    for (uint32_t gc = 0; gc < LCTY_GC_BINS; gc++)
+        for (uint32_t d = lo; d < hi; d++) out[(size_t)gc * (hi - lo) + (d - lo)] = orc_depth_ln_pmf(bg, prm, gc, d);
+}
+
 /* WindowDistr::ln_prob — distr_cache.rs:34-39 with LinearCache (lincache.rs:41-48) */
 double orc_depth_ln_prob(const orc_locus* l, uint32_t gc, double weight, uint32_t depth) {
     if (weight == 0.0) return 0.0;                 /* WindowDistr::TRIVIAL */

@@ -68,6 +68,8 @@ def lib():
     sig("orc_locus_contig_info", C.c_int, VP, U32, VP, VP, VP, C.POINTER(U32), C.POINTER(U32))
     sig("orc_locus_insert_lnprob", D, VP, U32)
     sig("orc_locus_insert_penalty", D, VP)
+    sig("orc_locus_window_weights", None, VP, VP)
+    sig("orc_depth_table", None, VP, VP, U32, U32, VP)
     sig("orc_load", VP, VP, C.POINTER(ReadsHost), C.POINTER(C.c_int))
     sig("orc_load_mt", VP, VP, C.POINTER(ReadsHost), VP, U32, VP, C.POINTER(C.c_int))
     sig("orc_alns_free", None, VP)
