@@ -150,6 +150,21 @@ typedef struct lcty_reads_host {
     const uint32_t*     cigar;      /* raw BAM CIGAR words: len<<4 | op */
 } lcty_reads_host;
 
+/* One alignment with its operations already counted — the 16-byte alignment-table entry of SURVEY.md section 8(d). It holds what
+ * Alignment::count_region_operations_fast (src/seq/aln.rs:301-317) with limited_clipping (288-296) leaves of a record: the caller
+ * (who walks raw_cigar() anyway and knows the contig length) counts, the device computes edit_distance (bg/err_prof.rs:73-79),
+ * ErrorProfile::ln_prob (212-221) and everything behind. Counts are 16-bit: reads of up to 65 535 bases; longer reads, hard-clipped
+ * primaries and the other checks of the record path (seq/aln.rs:311, model/locs.rs:526) stay with the caller, as does alignment
+ * recovery (lcty_recover_alignments needs the CIGARs and refuses a counted batch). */
+#define LCTY_CF_REVERSE     (1u << 28)
+#define LCTY_CF_NOT_PRIMARY (1u << 29)   /* secondary or supplementary record */
+#define LCTY_CF_UNMAPPED    (1u << 30)
+typedef struct lcty_aln_counted {
+    uint32_t pos_flags;   /* 0-based leftmost position (28 bits) | LCTY_CF_* */
+    uint16_t contig;      /* ContigId of the allele */
+    uint16_t matches, mismatches, insertions, deletions, clipping;   /* OperCounts (bg/err_prof.rs:25-45), clipping already limited */
+} lcty_aln_counted;
+
 /* PairAlignment (src/model/locs.rs:668-676); LCTY_NONE_U32 encodes Option::None. */
 typedef struct lcty_pair_aln {
     double   ln_prob;    /* already multiplied by the read weight (locs.rs:861-863) */
@@ -282,6 +297,10 @@ int32_t lcty_reads_create(lcty_locus* locus, uint64_t cap_pairs, uint64_t cap_ba
 int32_t lcty_reads_create_streaming(lcty_locus* locus, uint64_t cap_pairs, uint64_t chunk_pairs, uint64_t chunk_bases,
                                     uint64_t chunk_recs, uint64_t chunk_cigar, uint64_t cap_pair_alns, lcty_reads** out);
 int32_t lcty_reads_append(lcty_reads* reads, const lcty_reads_host* chunk);
+/* The same chunk with its records counted by the caller: alns[aln_off[n_pairs]] in the record order of the chunk; chunk->recs,
+ * cigar_off and cigar are not read. A batch holds records or counted alignments, never both. lcty_score_reads, the prefilter and
+ * the solver stages see no difference; results equal the record path's bit for bit (tests/test_gpu_counted.py). */
+int32_t lcty_reads_append_counted(lcty_reads* reads, const lcty_reads_host* chunk, const lcty_aln_counted* alns);
 void    lcty_reads_destroy(lcty_reads* reads);
 int32_t lcty_reads_n_pairs(const lcty_reads* reads, uint64_t* out);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "lcty_locus_depth_lut": (I32, [VP, VP]),
     "lcty_reads_create": (I32, [VP, U64, U64, U64, U64, P(VP)]),
     "lcty_reads_create_streaming": (I32, [VP, U64, U64, U64, U64, U64, U64, P(VP)]),
+    "lcty_reads_append_counted": (I32, [VP, VP, VP]),
     "lcty_reads_append": (I32, [VP, P(ReadsHost)]),
     "lcty_reads_destroy": (None, [VP]),
     "lcty_reads_n_pairs": (I32, [VP, P(U64)]),

@@ -79,6 +79,7 @@ class Locus:
         self.counts = np.ascontiguousarray(counts, dtype=np.uint16)
         self.cnt_off = np.ascontiguousarray(cnt_off, dtype=np.uint64)
         self.n_alleles = len(self.seq_off) - 1
+        self.allele_len = np.diff(self.seq_off.astype(np.int64))
         self.k, self.bg, self.params = k, bg, params
         self._h = VP()
         check(lib().lcty_locus_create(ctx._h, self.n_alleles, self.seqs.ctypes.data, self.seq_off.ctypes.data,
@@ -194,20 +195,25 @@ class AllAlignments:
         return self
 
     @classmethod
-    def load(cls, locus, chunks):
-        """AllAlignments::load: upload `chunks` (ReadsChunk or list of them) and score them."""
+    def load(cls, locus, chunks, counted=False):
+        """AllAlignments::load: upload `chunks` (ReadsChunk or list of them) and score them. counted: hand the records over as
+        lcty_aln_counted entries (operations counted here, on the host, as the caller of lcty_reads_append_counted would)."""
         if not isinstance(chunks, (list, tuple)):
             chunks = [chunks]
         self = cls(locus, sum(c.n_pairs for c in chunks), sum(c.n_bases for c in chunks),
-                   sum(len(c.recs) for c in chunks), sum(len(c.cigar) for c in chunks))
+                   sum(len(c.recs) for c in chunks), 0 if counted else sum(len(c.cigar) for c in chunks))
         for c in chunks:
-            self.append(c)
+            self.append(c, counted=counted)
         self.score()
         return self
 
-    def append(self, chunk):
+    def append(self, chunk, counted=False):
         hs = chunk.host_struct()
-        check(lib().lcty_reads_append(self._h, C.byref(hs)))
+        if counted:
+            alns = np.ascontiguousarray(chunk.counted(self.locus.allele_len), dtype=np.uint32)
+            check(lib().lcty_reads_append_counted(self._h, C.byref(hs), alns.ctypes.data))
+        else:
+            check(lib().lcty_reads_append(self._h, C.byref(hs)))
         self._scored = False
 
     def score(self):

@@ -241,6 +241,44 @@ class ReadsChunk:
             ao - ao[0], self.recs[int(ao[0]):int(ao[-1])], co - co[0],
             self.cigar[int(co[0]):int(co[-1])])
 
+    def counted(self, allele_len):
+        """The chunk's records as lcty_aln_counted entries (uint32 x 4 per record): what count_region_operations_fast +
+        limited_clipping (aln.rs:288-317) leave of every record, computed here as the caller of lcty_reads_append_counted would.
+        Records with an empty CIGAR must not be in the chunk (the record path skips them; a counted batch has no way to say so)."""
+        n = len(self.recs)
+        pair_of = np.repeat(np.arange(self.n_pairs, dtype=np.int64), np.diff(self.aln_off.astype(np.int64)))
+        start = self.cigar_off[pair_of].astype(np.int64) + self.recs["cigar_rel"].astype(np.int64)
+        ncig = self.recs["n_cigar"].astype(np.int64)
+        unm = (self.recs["flags"].astype(np.int64) & FLAG_UNMAPPED) != 0
+        assert np.all((ncig > 0) | unm), "a mapped record with an empty CIGAR in a chunk that is to be counted"
+        rec_of = np.repeat(np.arange(n, dtype=np.int64), ncig)
+        first = np.cumsum(ncig) - ncig
+        word_ix = start[rec_of] + (np.arange(len(rec_of), dtype=np.int64) - first[rec_of])
+        w = self.cigar[word_ix].astype(np.int64)
+        op, ln = w & 15, w >> 4
+        is_first = (np.arange(len(rec_of)) - first[rec_of]) == 0
+        is_last = (np.arange(len(rec_of)) - first[rec_of]) == ncig[rec_of] - 1
+        op = np.where((op == CIGAR_H) & (is_first | is_last), CIGAR_S, op)                       # hard_to_soft (cigar.rs:309-320)
+        assert np.all(np.isin(op, (CIGAR_EQ, CIGAR_X, CIGAR_I, CIGAR_D, CIGAR_S))), "unsupported CIGAR operation"
+        def total(mask):
+            return np.bincount(rec_of[mask], weights=ln[mask], minlength=n).astype(np.int64)
+        matches, mism, ins, dele = total(op == CIGAR_EQ), total(op == CIGAR_X), total(op == CIGAR_I), total(op == CIGAR_D)
+        left = total((op == CIGAR_S) & is_first); right = total((op == CIGAR_S) & is_last & ~is_first)
+        pos = self.recs["pos"].astype(np.int64)
+        end = pos + matches + mism + dele
+        clen = np.asarray(allele_len, dtype=np.int64)[np.minimum(self.recs["contig"].astype(np.int64), len(allele_len) - 1)]
+        clip = np.minimum(left, pos) + np.minimum(right, np.maximum(clen - end, 0))               # limited_clipping (aln.rs:288-296)
+        assert max(matches.max(initial=0), mism.max(initial=0), ins.max(initial=0), dele.max(initial=0), clip.max(initial=0)) < 65536
+        fl = self.recs["flags"].astype(np.int64)
+        pos_flags = pos | np.where(fl & FLAG_REVERSE, 1 << 28, 0) | np.where(fl & (FLAG_SECONDARY | FLAG_SUPPL), 1 << 29, 0) \
+            | np.where(fl & FLAG_UNMAPPED, 1 << 30, 0)
+        out = np.zeros((n, 4), dtype=np.uint32)
+        out[:, 0] = pos_flags
+        out[:, 1] = self.recs["contig"].astype(np.int64) | (matches << 16)
+        out[:, 2] = mism | (ins << 16)
+        out[:, 3] = dele | (clip << 16)
+        return out
+
     def primaries(self):
         """The same pairs with only the primary record of each read end (no secondary / supplementary records)."""
         n = len(self.aln_off) - 1

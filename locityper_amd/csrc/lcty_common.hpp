@@ -162,7 +162,7 @@ struct lcty_ctx {
     // more than the stage. lcty_ctx_trim releases it.
     struct SolveWorkspace {
         lcty::DevBuf<lcty::ChainRec> recs; lcty::DevBuf<lcty::ExtraLoc> extra;
-        uint32_t extra_cap = 0, extra_for_ploidy = 0; uint64_t extra_for_ngp = 0;
+        uint32_t extra_cap = 0, extra_for_ploidy = 0;
         lcty::DevBuf<uint16_t> gt; lcty::DevBuf<uint8_t> cgc; lcty::DevBuf<uint32_t> cdepth, cnnt, ctotw, ovf; lcty::DevBuf<uint64_t> seeds;
         lcty::DevBuf<double> pri, liks, parts, cww, caln;
         void release_all() {

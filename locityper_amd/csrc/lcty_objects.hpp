@@ -77,6 +77,7 @@ struct lcty_reads {
     uint32_t max_cigar_per_rec = 0;
     uint64_t recover_level_pairs[3] = {0, 0, 0};   // pairs the transfer kernel took at each scratch level (lcty_recover_stats)
     bool scored = false;
+    bool counted = false;                    // the records are lcty_aln_counted entries (lcty_reads_append_counted): no CIGAR words
     // streaming batch (lcty_reads_create_streaming): the record / CIGAR / base buffers hold one chunk at a time, the products
     // of every scored chunk stay. Pairs before raw_first have been scored and their raw data dropped; the per-pair raw arrays
     // (mate_len, mate_off, aln_off, cigar_off, pair_meta) are indexed relative to raw_first. raw_first == 0 otherwise.
@@ -114,6 +115,7 @@ struct lcty_reads {
     uint64_t ngp = 0;
     bool loc_table_valid = false;
     uint64_t stat_chains = 0, stat_iterations = 0, stat_accepted = 0;   // last lcty_solve_stage
+    lcty::DevBuf<uint16_t> d_unexpl_ids; lcty::DevBuf<unsigned long long> d_unexpl_out;   // count_unexplained_reads scratch
     lcty::DevBuf<uint32_t> d_err;
     lcty::DevBuf<double> d_recover_w;        // per pair: read weight when the pair reaches recover_and_group_alignments, else -1
 

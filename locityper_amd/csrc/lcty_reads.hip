@@ -76,7 +76,7 @@ void lcty_reads::ensure_good_index() {
     LCTY_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<uint32_t> good;
     for (uint64_t r = 0; r < n_pairs; r++) if (status[r] == LCTY_READ_GOOD) good.push_back(static_cast<uint32_t>(r));
-    d_good_ix.alloc(std::max<size_t>(good.size(), 1));
+    d_good_ix.ensure(std::max<size_t>(good.size(), 1));       // grow-only: a hipFree waits for every stream of the device
     d_good_ix.upload(good.data(), good.size(), ctx->stream);
     LCTY_HIP(hipStreamSynchronize(ctx->stream));
     n_good_cached = good.size();
@@ -164,15 +164,19 @@ int32_t lcty_reads_create_streaming(lcty_locus* locus, uint64_t cap_pairs, uint6
     return create_reads(locus, cap_pairs, chunk_pairs, chunk_bases, chunk_recs, chunk_cigar, cap_pair_alns, true, out);
 }
 
-int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
+// lcty_reads_append and lcty_reads_append_counted: `h` carries the raw records, or — counted != NULL — everything but records and
+// CIGAR words, which `counted` (16-byte entries, one per record) replaces
+static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_aln_counted* counted) {
     return guarded([&] {
         if (!R || !h) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (R->n_pairs > 0 && R->counted != (counted != nullptr))
+            fail(LCTY_ERR_INVALID_INPUT, "a batch holds either BAM records or counted alignments, not both");
         lcty_ctx* ctx = R->ctx;
         ctx->activate();
         const uint64_t n = h->n_pairs;
         if (n == 0) return;
-        const uint64_t nb = h->mate_off[2 * n], nr = h->aln_off[n], nc = h->cigar_off[n];
-        if (h->mate_off[0] || h->aln_off[0] || h->cigar_off[0]) fail(LCTY_ERR_INVALID_INPUT, "chunk offsets must start at 0");
+        const uint64_t nb = h->mate_off[2 * n], nr = h->aln_off[n], nc = counted ? 0 : h->cigar_off[n];
+        if (h->mate_off[0] || h->aln_off[0] || (!counted && h->cigar_off[0])) fail(LCTY_ERR_INVALID_INPUT, "chunk offsets must start at 0");
         if (R->streaming && R->scored && R->n_pairs > R->raw_first) {
             // the chunk on the device has been scored: its products stay, its records make room for the next one
             R->check_device_error();
@@ -200,22 +204,29 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         std::vector<uint2> meta(n);
         const bool paired = R->locus->bg.is_paired != 0;
         for (uint64_t r = 0; r < n; r++) {
-            if (h->aln_off[r + 1] < h->aln_off[r] || h->cigar_off[r + 1] < h->cigar_off[r])
+            if (h->aln_off[r + 1] < h->aln_off[r] || (!counted && h->cigar_off[r + 1] < h->cigar_off[r]))
                 fail(LCTY_ERR_INVALID_INPUT, "record / CIGAR offsets must be non-decreasing");
             const uint64_t cnt = h->aln_off[r + 1] - h->aln_off[r];
             if (cnt > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many records in one read pair");
             max_recs = std::max<uint32_t>(max_recs, static_cast<uint32_t>(cnt));
-            const uint64_t cw = h->cigar_off[r + 1] - h->cigar_off[r];
+            const uint64_t cw = counted ? 0 : h->cigar_off[r + 1] - h->cigar_off[r];
             max_cig = std::max(max_cig, cw);
             // record groups (locs.rs:1119-1131): the second primary starts read end 2, a third one would start
             // the next read pair
             uint32_t j2 = static_cast<uint32_t>(cnt), j3 = static_cast<uint32_t>(cnt);
             for (uint64_t i = h->aln_off[r]; i < h->aln_off[r + 1]; i++) {
-                if (static_cast<uint64_t>(h->recs[i].cigar_rel) + h->recs[i].n_cigar > cw)
-                    fail(LCTY_ERR_INVALID_INPUT, "CIGAR of record %llu leaves its pair's CIGAR range", (unsigned long long)i);
-                max_rec_cig = std::max(max_rec_cig, h->recs[i].n_cigar);
+                bool is_primary;
+                if (counted) {
+                    if (counted[i].pos_flags >> 31) fail(LCTY_ERR_INVALID_INPUT, "counted alignment %llu: reserved flag bit set", (unsigned long long)i);
+                    is_primary = (counted[i].pos_flags & LCTY_CF_NOT_PRIMARY) == 0;
+                } else {
+                    if (static_cast<uint64_t>(h->recs[i].cigar_rel) + h->recs[i].n_cigar > cw)
+                        fail(LCTY_ERR_INVALID_INPUT, "CIGAR of record %llu leaves its pair's CIGAR range", (unsigned long long)i);
+                    max_rec_cig = std::max(max_rec_cig, h->recs[i].n_cigar);
+                    is_primary = (h->recs[i].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0;
+                }
                 const uint32_t idx = static_cast<uint32_t>(i - h->aln_off[r]);
-                if (idx > 0 && (h->recs[i].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0) {
+                if (idx > 0 && is_primary) {
                     if (j2 == cnt) j2 = idx; else if (j3 == cnt) j3 = idx;
                 }
             }
@@ -227,12 +238,13 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         R->d_mate_len.upload(h->mate_len, 2 * n, s, 2 * raw_pairs);
         R->d_bases2.upload(h->bases2, nb / 16, s, R->n_bases / 16);
         R->d_nmask.upload(h->nmask, nb / 32, s, R->n_bases / 32);
-        R->d_recs.upload(h->recs, nr, s, R->n_recs);
-        R->d_cigar.upload(h->cigar, nc, s, R->n_cigar);
+        static_assert(sizeof(lcty_aln_counted) == sizeof(lcty_aln_rec), "both record forms are 16 bytes");
+        R->d_recs.upload(counted ? reinterpret_cast<const lcty_aln_rec*>(counted) : h->recs, nr, s, R->n_recs);
+        if (!counted) R->d_cigar.upload(h->cigar, nc, s, R->n_cigar);
         // rebased offsets
         std::vector<uint64_t> mo(2 * n), ao(n), co(n);
         for (uint64_t m = 0; m < 2 * n; m++) mo[m] = h->mate_off[m + 1] + R->n_bases;
-        for (uint64_t r = 0; r < n; r++) { ao[r] = h->aln_off[r + 1] + R->n_recs; co[r] = h->cigar_off[r + 1] + R->n_cigar; }
+        for (uint64_t r = 0; r < n; r++) { ao[r] = h->aln_off[r + 1] + R->n_recs; co[r] = (counted ? 0 : h->cigar_off[r + 1]) + R->n_cigar; }
         R->d_mate_off.upload(mo.data(), 2 * n, s, 2 * raw_pairs + 1);
         R->d_aln_off.upload(ao.data(), n, s, raw_pairs + 1);
         R->d_cigar_off.upload(co.data(), n, s, raw_pairs + 1);
@@ -243,9 +255,20 @@ int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) {
         R->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
         R->max_cigar_per_rec = max_rec_cig;
         R->scored = false;
+        R->counted = counted != nullptr;
         R->good_valid = false; R->loc_table_valid = false;
     });
 }
+
+int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) { return append_impl(R, h, nullptr); }
+
+// the same chunk with its records already counted: h->recs / cigar_off / cigar are not read
+int32_t lcty_reads_append_counted(lcty_reads* R, const lcty_reads_host* h, const lcty_aln_counted* alns) {
+    if (!alns) return guarded([&] { fail(LCTY_ERR_INVALID_INPUT, "null argument"); });
+    return append_impl(R, h, alns);
+}
+
+
 
 void lcty_reads_destroy(lcty_reads* reads) {
     if (!reads) return;

@@ -147,6 +147,24 @@ struct Scored {
     bool bad;
 };
 
+// An alignment whose operations have been counted by the caller (lcty_aln_counted, 16 bytes): the OperCounts that
+// count_region_operations_fast + limited_clipping leave (aln.rs:288-317), so only edit_distance (err_prof.rs:73-79) and
+// ErrorProfile::ln_prob (212-221) remain. raw = {pos | flags << 28, contig | matches << 16, mismatches | insertions << 16,
+// deletions | clipping << 16}
+__device__ __forceinline__ Scored score_counted(const LocusView& L, const uint4 raw) {
+    const uint32_t matches = raw.y >> 16, mism = raw.z & 0xFFFFu, ins = raw.z >> 16, del = raw.w & 0xFFFFu, clip = raw.w >> 16;
+    Scored s;
+    s.start = raw.x & 0x0FFFFFFFu;
+    s.end = s.start + matches + mism + del;
+    const uint32_t common = mism + ins + clip;
+    s.edit = common + del;
+    s.ln_prob = L.lp[0] * static_cast<double>(matches) + L.lp[1] * static_cast<double>(mism)
+              + L.lp[2] * static_cast<double>(ins) + L.lp[3] * static_cast<double>(del)
+              + L.lp[4] * static_cast<double>(clip);
+    s.bad = false;
+    return s;
+}
+
 __device__ __forceinline__ Scored score_counts(const LocusView& L, const OpCounts& c, uint32_t pos, uint32_t contig_len) {
     Scored s;
     const uint32_t ref_len = c.matches + c.mism + c.del;
@@ -510,7 +528,8 @@ __device__ __forceinline__ void pair_barrier() {
 // BIG = the saved alignments of a pair (16 B each + two 16-bit links) do not fit the LDS next to the per-allele tables (4 096
 // alleles with an alignment per read end on each: 209 KB): they are parked in a scratch of the workgroup in global memory
 // (L2-resident: written and read back by the same CU within microseconds); the per-allele tables stay in LDS.
-template <bool EW, bool BIG>
+// CNT = the batch holds counted alignments (lcty_reads_append_counted) instead of BAM records with CIGAR words.
+template <bool EW, bool BIG, bool CNT = false>
 __device__ __forceinline__ void score_reads_body(const LocusView& L, const ReadsView& R, const uint32_t max_recs) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t A = L.n_alleles;
@@ -538,7 +557,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
 
     for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
         const uint64_t a0 = R.aln_off[p];
-        const uint32_t* cig = R.cigar + R.cigar_off[p];
+        const uint32_t* cig = CNT ? nullptr : R.cigar + R.cigar_off[p];
         const uint2 meta = R.pair_meta[p];                 // {index of the mate-2 primary (or n), records to look at}
         const uint32_t j2 = meta.x, n_eff = meta.y;
         const uint32_t split = min(j2, n_eff);
@@ -584,16 +603,24 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
             } else if (!exists) {
                 my_state = 4;                                   // expect("Cannot read any more records"), locs.rs:509
             } else {
+                const uint4 praw = reinterpret_cast<const uint4*>(recs)[pidx];
                 const lcty_aln_rec pr = recs[pidx];
                 const uint32_t read_len = e ? len1 : len0;
-                const bool is_primary = (pr.flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0;
+                const uint32_t pflags = CNT ? ((praw.x >> 28 & 1u) ? LCTY_FLAG_REVERSE : 0u) | ((praw.x >> 29 & 1u) ? LCTY_FLAG_SECONDARY : 0u)
+                                              | ((praw.x >> 30 & 1u) ? LCTY_FLAG_UNMAPPED : 0u) : pr.flags;
+                const uint32_t pcontig = CNT ? (praw.y & 0xFFFFu) : pr.contig;
+                const bool is_primary = (pflags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0;
                 if (read_len == 0 || !is_primary) my_state = 4;                 // locs.rs:511-517 / LaggedReader assert
-                else if (pr.flags & LCTY_FLAG_UNMAPPED) my_state = 0;           // locs.rs:520-523
-                else if (pr.n_cigar == 0 || pr.contig >= A) my_state = 4;
+                else if (pflags & LCTY_FLAG_UNMAPPED) my_state = 0;             // locs.rs:520-523
+                else if ((!CNT && pr.n_cigar == 0) || pcontig >= A) my_state = 4;
                 else {
-                    const W8 w8 = *reinterpret_cast<const W8*>(cig + pr.cigar_rel);
-                    const OpCounts oc = count_ops(w8, cig + pr.cigar_rel, pr.n_cigar, true);
-                    const Scored sc = score_counts(L, oc, pr.pos, L.allele_len[pr.contig]);
+                    Scored sc;
+                    if constexpr (CNT) sc = score_counted(L, praw);
+                    else {
+                        const W8 w8 = *reinterpret_cast<const W8*>(cig + pr.cigar_rel);
+                        const OpCounts oc = count_ops(w8, cig + pr.cigar_rel, pr.n_cigar, true);
+                        sc = score_counts(L, oc, pr.pos, L.allele_len[pr.contig]);
+                    }
                     if (sc.bad) my_state = 4;
                     else {
                         const uint2 gp = L.edit_lut[min(read_len, L.edit_lut_size - 1)];
@@ -601,8 +628,8 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                         double compl_v = 1.0;
                         if (L.short_reads) {                     // neighb_complexity, windows.rs:447-452, 696-698
                             const uint32_t mid = (sc.start + sc.end) / 2;
-                            const uint32_t o = L.ci_off[pr.contig];
-                            const uint32_t npos = L.ci_off[pr.contig + 1] - o;
+                            const uint32_t o = L.ci_off[pcontig];
+                            const uint32_t npos = L.ci_off[pcontig + 1] - o;
                             const uint32_t i = min(mid > L.half_neighb ? mid - L.half_neighb : 0u, npos - 1);
                             compl_v = static_cast<double>(L.compl_cnt[o + i]) * L.compl_mult;
                         }
@@ -635,28 +662,37 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                 if (base == 0) raw[g] = raw_first[g];
                 else raw[g] = idx < n_eff ? reinterpret_cast<const uint4*>(recs)[idx] : make_uint4(0, 0, 0, 0);
             }
+            if constexpr (!CNT) {
 #pragma unroll
-            for (int g = 0; g < GR; g++) {
-                if (raw[g].z) cw[g] = *reinterpret_cast<const W8*>(cig + raw[g].w);
-                else {
+                for (int g = 0; g < GR; g++) {
+                    if (raw[g].z) cw[g] = *reinterpret_cast<const W8*>(cig + raw[g].w);
+                    else {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) cw[g].w[i] = 0;
+                        for (int i = 0; i < 8; i++) cw[g].w[i] = 0;
+                    }
+                    const uint32_t contig = raw[g].y & 0xFFFFu;
+                    clen[g] = contig < A ? alen[contig] : 0u;
                 }
-                const uint32_t contig = raw[g].y & 0xFFFFu;
-                clen[g] = contig < A ? alen[contig] : 0u;
             }
 #pragma unroll
             for (int g = 0; g < GR; g++) {
                 const uint32_t idx = base + g * WAVE + lane;
-                const uint32_t nc = raw[g].z;
-                const uint32_t pos = raw[g].x, contig = raw[g].y & 0xFFFFu, bflags = raw[g].y >> 16;
+                const uint32_t nc = CNT ? (((raw[g].x >> 30) & 1u) ? 0u : 1u) : raw[g].z;      // counted: an unmapped record has no alignment (an empty CIGAR in the record form)
+                const uint32_t pos = CNT ? (raw[g].x & 0x0FFFFFFFu) : raw[g].x, contig = raw[g].y & 0xFFFFu;
+                const uint32_t bflags = CNT ? (((raw[g].x >> 28) & 1u) ? LCTY_FLAG_REVERSE : 0u) | (((raw[g].x >> 30) & 1u) ? LCTY_FLAG_UNMAPPED : 0u)
+                                            : raw[g].y >> 16;
                 const bool primary = idx == 0 || idx == j2;
                 // empty CIGAR: skipped with a warning (locs.rs:550-554); unmapped primaries end the pair above
                 if (idx < n_eff && nc != 0 && !(primary && (bflags & LCTY_FLAG_UNMAPPED))) {
                     const uint32_t e = idx >= split ? 1u : 0u;
                     const bool cbad = contig >= A;
-                    const OpCounts oc = count_ops(cw[g], cig + raw[g].w, nc, primary);
-                    const Scored sc = score_counts(L, oc, pos, clen[g]);
+                    Scored sc;
+                    if constexpr (CNT) sc = score_counted(L, raw[g]);
+                    else {
+                        const OpCounts oc = count_ops(cw[g], cig + raw[g].w, nc, primary);
+                        sc = score_counts(L, oc, pos, clen[g]);
+                    }
+                    (void)pos;
                     if (sc.bad || cbad) {
                         if (!primary) { if (e) bad1 = 1; else bad0 = 1; }   // primaries are judged by lanes 0/1 above
                     } else {
@@ -873,6 +909,20 @@ __global__ __launch_bounds__(WAVE, 3) void score_reads_big_explicit_kernel(const
     score_reads_body<true, true>(L, R, max_recs);
 }
 
+// the same four for batches of counted alignments (lcty_reads_append_counted): no CIGAR words to decode
+__global__ __launch_bounds__(WAVE, 3) void score_counted_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<false, false, true>(L, R, max_recs);
+}
+__global__ __launch_bounds__(WAVE, 3) void score_counted_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<true, false, true>(L, R, max_recs);
+}
+__global__ __launch_bounds__(WAVE, 3) void score_counted_big_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<false, true, true>(L, R, max_recs);
+}
+__global__ __launch_bounds__(WAVE, 3) void score_counted_big_explicit_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
+    score_reads_body<true, true, true>(L, R, max_recs);
+}
+
 static size_t score_lds_bytes(uint32_t max_recs, uint32_t A) {
     const size_t mr2 = (max_recs + 1) & ~1u;
     size_t b = static_cast<size_t>(max_recs) * sizeof(Rec16) + static_cast<size_t>(A) * 8 + 4;   // rec + head + alen + cursor
@@ -907,8 +957,11 @@ void launch_score_reads(lcty_reads* reads) {
                  L.n_alleles, lds, lds_max);
     }
     const bool explicit_weights = L.ew_val != nullptr;
-    auto kernel = big ? (explicit_weights ? score_reads_big_explicit_kernel : score_reads_big_kernel)
-                      : (explicit_weights ? score_reads_explicit_kernel : score_reads_kernel);
+    auto kernel = reads->counted
+        ? (big ? (explicit_weights ? score_counted_big_explicit_kernel : score_counted_big_kernel)
+               : (explicit_weights ? score_counted_explicit_kernel : score_counted_kernel))
+        : (big ? (explicit_weights ? score_reads_big_explicit_kernel : score_reads_big_kernel)
+               : (explicit_weights ? score_reads_explicit_kernel : score_reads_kernel));
     if (lds > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

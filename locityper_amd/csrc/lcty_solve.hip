@@ -611,12 +611,61 @@ __device__ __forceinline__ double row_sum_f64(double x) {
 }
 
 // ---------------- K14 Greedy: 64 / LPC chains per wavefront ----------------
+// hand-shake between the chain wavefront and the prefetch wavefront of a greedy workgroup
+struct GreedyShared {
+    uint64_t rng[4][4];             // the rows' generators when the main loop starts
+    uint32_t nnt[4], go, stop, iter, flagged;
+};
+constexpr uint32_t GREEDY_AHEAD = 4;        // iterations the prefetch wavefront runs ahead of the chains, in batches of four
+
 template <uint32_t LPC>
-__global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
+__global__ __launch_bounds__(128) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains, const uint32_t prefetch) {
     extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ GreedyShared sh;
     constexpr uint32_t CPW = 64 / LPC;
+    // a batch whose initialisation raised a flag (a chain's run of further locations was too short, ...) is repeated by the host:
+    // its records are incomplete and must not be followed
+    if (threadIdx.x == 0) {
+        sh.flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.go = 0; sh.stop = 0; sh.iter = 0;
+    }
+    __syncthreads();
+    if (sh.flagged != 0u) return;
     const uint32_t W = V.wstride;
     const uint32_t lane = threadIdx.x & 63u;
+    if ((threadIdx.x >> 6) == 1u) {
+        // ---- prefetch wavefront. The random stream of the greedy loop does not depend on the moves, so the records of the coming
+        // iterations are known: this wavefront draws the same picks a few iterations ahead and touches their records (one word
+        // each, thrown away), which brings their lines from HBM into the L2. The chain wavefront's own loads of those records
+        // then take an L2 round trip. Nothing else passes between the two: a missed or stale prefetch costs time, never a result.
+        __syncthreads();                                                     // hand-over of the generators (below)
+        if (prefetch && __hip_atomic_load(&sh.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            const uint32_t prow = lane / LPC, pjj = lane % LPC;
+            const uint32_t pchain = min(blockIdx.x * CPW + prow, n_chains - 1);
+            const ChainRec* precs = V.recs + static_cast<uint64_t>(pchain) * V.ngp;
+            Xoshiro prng;
+            prng.s0 = sh.rng[prow % 4][0]; prng.s1 = sh.rng[prow % 4][1]; prng.s2 = sh.rng[prow % 4][2]; prng.s3 = sh.rng[prow % 4][3];
+            const uint32_t pn = max(sh.nnt[prow % 4], 1u);
+            const bool pcand = pjj < min(V.solver.sample_size, pn);
+            uint32_t ahead = 0, sink = 0;
+            for (;;) {
+                if (__hip_atomic_load(&sh.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                const uint32_t at = __hip_atomic_load(&sh.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ahead >= at + GREEDY_AHEAD) { __builtin_amdgcn_s_sleep(8); continue; }
+                uint32_t v[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint64_t key = prng.next();
+                    const uint32_t idx = pcand ? static_cast<uint32_t>(__umul64hi(counter_u64(key, pjj), static_cast<uint64_t>(pn))) : 0u;
+                    v[b] = precs[idx].meta;
+                }
+                sink ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+                ahead += 4;
+            }
+            if (sink == 0x9E3779B9u && ahead == 0xFFFFFFFFu) V.parts[0] = 0.0;       // never true: keeps the loads
+        }
+        return;
+    }
     const uint32_t row = lane / LPC, jj = lane % LPC, row_base = row * LPC;
     const uint32_t chain_raw = blockIdx.x * CPW + row;
     const bool live_row = chain_raw < n_chains;
@@ -647,6 +696,8 @@ __global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, cons
     double depth_mine = 0.0, aln_mine = 0.0;                                     // likelihood changes of the moves this lane applied
 
     bool done = nnt == 0 || !live_row;
+    bool handed_over = false;
+    uint32_t wave_iter = 0;
     if (__any(!done)) {
         const uint32_t nnt1 = max(nnt, 1u);
         const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
@@ -667,6 +718,14 @@ __global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, cons
         const uint32_t S = min(V.solver.sample_size, nnt1);
         const bool cand = jj < S;
         struct Stage { uint32_t pick, rpc; RecBody b; };      // rpc: the record's rp_cur word, patched while in flight
+        // the prefetch wavefront takes the generators from here
+        if (jj == 0) {
+            sh.rng[row % 4][0] = rng.s0; sh.rng[row % 4][1] = rng.s1; sh.rng[row % 4][2] = rng.s2; sh.rng[row % 4][3] = rng.s3;
+            sh.nnt[row % 4] = nnt;
+        }
+        __hip_atomic_store(&sh.go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        handed_over = true;
+        __syncthreads();
         auto sample = [&]() -> uint32_t {
             // non_trivial_reads.sample(rng, S): one draw of the chain's generator as a key, the S picks as counter draws under it,
             // repeats skipped (our adaptor, oracle/lcty_oracle.h). A sample almost never repeats an index (S^2 / 2 nnt)
@@ -720,27 +779,29 @@ __global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, cons
         };
         uint32_t curr_plato = 0;
         uint64_t iter = 0;
-        Stage sA, sB, sC;
+        // one iteration of every row of the wavefront: the records of the next iteration are requested first (L2-warm thanks to the
+        // prefetch wavefront), then this iteration's candidates are scored while they arrive
+        Stage sA, sB;
         request(sA);
-        request(sB);
         while (__any(!done)) {
+            request(sB);                                                       // the next iteration's records: in flight while this one is scored
             // best_read_improvement (assgn.rs:287-317), one candidate read per lane
             const uint32_t nloc = sA.b.meta & 0xFFu;
             double cur_lp; uint32_t cur_w;
             const uint32_t cur = sA.rpc >> 24;
-            if (cand) rec_loc(sA.b, extra, cur, &cur_lp, &cur_w); else { cur_lp = 0.0; cur_w = 0; }
+            // lanes without a candidate (beyond the sample, rows that are done or spare) look at window 0 four times: no change, no effect
+            const uint32_t n_alt = (cand && !done) ? nloc - 1 : 0u;
+            if (n_alt) rec_loc(sA.b, extra, cur, &cur_lp, &cur_w); else { cur_lp = 0.0; cur_w = 0; }
             const uint32_t w1 = cur_w & 0xFFFFu, w2 = cur_w >> 16;
             double best_improv = -INFINITY, lp_new = 0.0, ddiff = 0.0;
             uint32_t new_assgn = 0, w3 = 0, w4 = 0;
-            const uint32_t n_alt = (cand && !done) ? nloc - 1 : 0u;
-            // first alternative of every lane together; the record of iteration + 2 is requested behind its depth-table gathers
+            // first alternative of every lane together
             {
                 double lp_t = 0.0; uint32_t win_t = 0;
                 const uint32_t t = cur == 0 ? 1u : 0u;
                 if (n_alt) rec_loc(sA.b, extra, t, &lp_t, &win_t);
                 const uint32_t a3 = win_t & 0xFFFFu, a4 = win_t >> 16;
                 const double dd = C.depth_lik_diff(w1, w2, a3, a4);
-                request(sC);
                 const double improv = lp_t + rel_contrib * dd;
                 if (n_alt) { best_improv = improv; new_assgn = t; w3 = a3; w4 = a4; lp_new = lp_t; ddiff = dd; }
             }
@@ -780,16 +841,19 @@ __global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, cons
                 if (moved) {
                     n_acc++; curr_plato = 0;
                     if (sB.pick == moved_slot) sB.rpc = (sB.rpc & 0xFFFFFFu) | (moved_to << 24);   // the same read may come up again while it is in flight
-                    if (sC.pick == moved_slot) sC.rpc = (sC.rpc & 0xFFFFFFu) | (moved_to << 24);
                 } else {
                     curr_plato++;
                     if (curr_plato > V.solver.plato_size) done = true;
                 }
                 if (iter >= max_iter) done = true;
             }
-            sA = sB; sB = sC;
+            // pace of the prefetch wavefront: the iterations the rows of this wavefront have been through
+            if (lane == 0) __hip_atomic_store(&sh.iter, static_cast<uint32_t>(++wave_iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sA = sB;
         }
     }
+    if (!handed_over) __syncthreads();                                   // the prefetch wavefront waits for exactly one hand-over
+    __hip_atomic_store(&sh.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     depth_mine = row_sum_f64<LPC>(depth_mine); aln_mine = row_sum_f64<LPC>(aln_mine);
     depth_lik += depth_mine; aln_lik += aln_mine;
     if (jj == 0 && live_row) {
@@ -819,6 +883,10 @@ struct AnnealRing {
 
 __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) {
     extern __shared__ __align__(32) uint8_t smem[];
+    __shared__ uint32_t flagged;
+    if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flagged != 0u) return;                     // the batch is repeated by the host (see greedy_loop_kernel)
     const uint32_t W = V.wstride;
     // [W] window weights first, then [W] depth | GC bin << 25, then the ring the second wavefront fills
     double* lww = reinterpret_cast<double*>(smem);
@@ -1245,7 +1313,7 @@ void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t 
     if (lds > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
-    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(greedy_loop_kernel<LPC>, dim3((nch + CPW - 1) / CPW), dim3(64), lds, s, V, nch); }, s);
+    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(greedy_loop_kernel<LPC>, dim3((nch + CPW - 1) / CPW), dim3(128), lds, s, V, nch, static_cast<uint32_t>(ctx->knob("solve_prefetch", nch < 2048 ? 1 : 0))); }, s);
     LCTY_HIP(hipGetLastError());
 }
 
@@ -1320,10 +1388,14 @@ struct StageRunner {
 
         // Locations beyond the second of a read (ploidy > 2, several pair-alignments on a contig, "both unmapped" in reach): a run per
         // chain; a chain that needs more raises a flag and the batch is repeated with the run it asked for
-        if (ws.extra_cap == 0 || ws.extra_for_ngp != ngp || ws.extra_for_ploidy != ploidy) {
-            ws.extra_cap = static_cast<uint32_t>(std::min<uint64_t>(ngp * (ploidy > 2 ? ploidy - 2 : 0) + std::max<uint64_t>(256, ngp / 64), (1u << 24) - 1));
-            ws.extra_for_ngp = ngp; ws.extra_for_ploidy = ploidy;
-            if (ctx->knob("solve_extra_start", 0) > 0) ws.extra_cap = static_cast<uint32_t>(ctx->knob("solve_extra_start", 0));   // tests: exercise the growth
+        // (the run size a stage asked for is kept for the next stages and loci of the context: loci of one data set look alike)
+        {
+            const uint32_t guess = static_cast<uint32_t>(std::min<uint64_t>(ngp * (ploidy > 2 ? ploidy - 2 : 0) + std::max<uint64_t>(256, ngp / 64), (1u << 24) - 1));
+            if (ws.extra_for_ploidy != ploidy) ws.extra_cap = 0;
+            ws.extra_for_ploidy = ploidy;
+            if (ctx->knob("solve_extra_start", 0) > 0) {                          // tests: exercise the growth
+                if (ws.extra_cap == 0) ws.extra_cap = static_cast<uint32_t>(ctx->knob("solve_extra_start", 0));
+            } else ws.extra_cap = std::max(ws.extra_cap, guess);
         }
         plan_batches();
         V.overflow = ws.ovf.p;
@@ -1464,8 +1536,10 @@ uint32_t count_unexplained_on(hipStream_t s, lcty_reads* reads, const uint16_t* 
     const uint32_t A = reads->locus->n_alleles;
     for (uint32_t i = 0; i < ploidy; i++)
         if (genotype[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotype[i], A);
-    DevBuf<uint16_t> d_ids; d_ids.alloc(ploidy); d_ids.upload(genotype, ploidy, s);
-    DevBuf<unsigned long long> d_out; d_out.alloc(1); d_out.zero(s);
+    // buffers of the batch, grow-only: allocating or freeing here would wait for every stream of the device (the next locus' kernels)
+    DevBuf<uint16_t>& d_ids = reads->d_unexpl_ids; DevBuf<unsigned long long>& d_out = reads->d_unexpl_out;
+    d_ids.ensure(ploidy); d_ids.upload(genotype, ploidy, s);
+    d_out.ensure(1); d_out.zero(s);
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((reads->n_pairs + 255) / 256, 4096));
     if (reads->n_pairs)
         hipLaunchKernelGGL(count_unexplained_kernel, dim3(blocks), dim3(256), 0, s, reads->d_status.p, reads->d_unmapped.p,

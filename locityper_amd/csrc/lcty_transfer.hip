@@ -609,6 +609,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         lcty_locus* loc = reads->locus;
         lcty_ctx* ctx = reads->ctx;
         if (!loc->has_hap_alns) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_set_hap_alns has not been called");
+        if (reads->counted) fail(LCTY_ERR_UNSUPPORTED, "alignment recovery walks the CIGARs of the records: not available for a batch of counted alignments");
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads first: recovery looks at the read pairs the first pass lets through");
         ctx->activate();
         reads->check_device_error();

@@ -53,8 +53,8 @@ def read_pairs_csv(status, unmapped_prob, pa_off, pair_alns, rec_pos, aln_off):
         base = int(aln_off[r])
         for t in range(int(pa_off[r]), int(pa_off[r + 1])):
             pa = pair_alns[t]
-            p1 = "*" if int(pa["ix1"]) == 0xFFFF else str(int(rec_pos[base + int(pa["ix1"])]) + 1)
-            p2 = "*" if int(pa["ix2"]) == 0xFFFF else str(int(rec_pos[base + int(pa["ix2"])]) + 1)
+            p1 = "*" if int(pa["ix1"]) == 0xFFFFFFFF else str(int(rec_pos[base + int(pa["ix1"])]) + 1)
+            p2 = "*" if int(pa["ix2"]) == 0xFFFFFFFF else str(int(rec_pos[base + int(pa["ix2"])]) + 1)
             out.append(f"{r}\ta{int(pa['contig'])}\t{p1}\t{p2}\t{float(pa['ln_prob']) * INV_LN10:.4f}")
         out.append(f"{r}\t*\t*\t*\t{float(unmapped_prob[r]) * INV_LN10:.4f}")
     return "\n".join(out) + "\n"

@@ -24,14 +24,21 @@ def main():
     gts = api.generate_genotypes(A, 2)
     order = np.argsort(-sc, kind="stable")
     print(f"A={A} pairs={pairs} n_good={aa.n_good()} max n_windows={max(loc.contig_info(a)[3] for a in range(min(A,4)))}", flush=True)
+    cpws = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
+    if len(sys.argv) > 6: ctx.set_knob("solve_prefetch", int(sys.argv[6]))
+    api.solve_stage(aa, gts[order[:max(chains)]], api.default_solver(cdefs.SOLVER_GREEDY), 1, api.chain_seeds(7, max(chains)))   # warm-up: tables, workspace
     for kind, name in ((cdefs.SOLVER_GREEDY, "g"), (cdefs.SOLVER_ANNEAL, "a")):
         if name not in kinds: continue
-        for n in chains:
-            sub = gts[order[:n]]
-            ctx.timing_reset()
-            t = time.time()
-            m, v, l = api.solve_stage(aa, sub, api.default_solver(kind), 1, api.chain_seeds(7, n))
-            dt = time.time() - t
-            print(f"  kind={name} chains={n}: wall {dt:.3f} s kernel {ctx.timing(api.K_SOLVE)[1]:.1f} ms best={sub[int(np.argmax(m))]} true={L.true_genotype}", flush=True)
+        for cpw in (cpws if name == "g" else [0]):
+            ctx.set_knob("solve_chains_per_wave", cpw if cpw else -1)
+            for n in chains:
+                sub = gts[order[:n]]
+                ctx.timing_reset()
+                t = time.time()
+                m, v, l = api.solve_stage(aa, sub, api.default_solver(kind), 1, api.chain_seeds(7, n))
+                dt = time.time() - t
+                ks = ctx.timing(api.K_SOLVE if name == "g" else api.K_ANNEAL)[1]
+                print(f"  kind={name} cpw={cpw} chains={n}: wall {dt:.3f} s loop kernel {ks:.1f} ms init {ctx.timing(api.K_SOLVE_INIT)[1]:.1f} ms "
+                      f"best={sub[int(np.argmax(m))]} true={L.true_genotype}", flush=True)
 
 main()

@@ -321,7 +321,8 @@ def test_chains_per_wavefront_and_wide_samples_do_not_change_results(gpu_ctx):
             got = api.solve_stage(aa, gts, g, 2, seeds)
         finally:
             gpu_ctx.set_knob("solve_chains_per_wave", -1)
-        assert np.array_equal(got[2], ref[2]), cpw
+        # the same moves; a chain's likelihood is summed over the lanes that applied them, in an order that depends on the layout
+        assert np.allclose(got[2], ref[2], rtol=1e-12, atol=0), cpw
     for sample in (1, 16, 17, 32, 40, 64):
         g2 = api.default_solver(cdefs.SOLVER_GREEDY)
         g2.sample_size = sample
