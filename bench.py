@@ -48,6 +48,12 @@ def parse_args():
     ap.add_argument("--alleles", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
+    ap.add_argument("--ont-sample", type=int, default=2048,
+                    help="reads of the extra long-read measurement (BASELINE.json configs[2] shape: 10 kb ONT reads x the locus' alleles, "
+                         "the mapper reports the primaries, the other alleles are reached by alignment recovery); 0 = skip")
+    ap.add_argument("--format", choices=("counted", "records"), default="counted",
+                    help="how the alignment table reaches the library: 16-byte counted alignments (lcty_reads_append_counted, SURVEY 8(d)'s "
+                         "alignment-table entry; the default) or BAM records with their CIGAR words (lcty_reads_append)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of every CPU-baseline figure (the median is reported)")
     ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
@@ -231,7 +237,7 @@ def main():
         os.environ.pop("NCCL_DEBUG", None)         # RCCL logs to stdout, which carries the one JSON line
         os.environ["NCCL_DEBUG_FILE"] = os.devnull
         args.no_solve = args.shard_reads
-        args.recovery_sample = args.recruit_sample = 0
+        args.recovery_sample = args.recruit_sample = args.ont_sample = 0
         uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
         if dist is not None:
             import torch
@@ -268,15 +274,17 @@ def main():
         dens_b, dens_r, dens_c = c0.n_bases / c0.n_pairs, len(c0.recs) / c0.n_pairs, len(c0.cigar) / c0.n_pairs
         head = 1.03
         cap_bases = (int(dens_b * args.pairs * head) + 1024) // 32 * 32 + 32
-        aa = api.AllAlignments(loc, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096, int(dens_c * args.pairs * head) + 65536)
-        aa.append(c0)
+        counted = args.format == "counted"
+        aa = api.AllAlignments(loc, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096,
+                               0 if counted else int(dens_c * args.pairs * head) + 65536)
+        aa.append(c0, counted=counted)
         if j == 0:
             tot_recs, tot_cigar, tot_bases = len(c0.recs), len(c0.cigar), c0.n_bases
             first = c0 if (rank == 0 and world == 1 and args.cpu_sample > 0) else None
         for ci in range(1, n_chunks):
             lo = ci * args.chunk
             ch = L.reads(first_pair + lo, min(args.chunk, args.pairs - lo))
-            aa.append(ch)
+            aa.append(ch, counted=counted)
             if j == 0:
                 tot_recs += len(ch.recs); tot_cigar += len(ch.cigar); tot_bases += ch.n_bases
             del ch
@@ -399,7 +407,7 @@ def main():
     pref_ms = ms_pref / max(n_pref, 1)
     kern_steps = args.steps + (1 if queue_mode else 0)         # the timers also saw the call-by-call pass
     alg_bytes = survey_bytes_per_pair(A) * args.pairs
-    layout_bytes = (tot_bases / 4 + tot_bases / 8 + 16 * tot_recs + 4 * tot_cigar + 8 * A * args.pairs
+    layout_bytes = (tot_bases / 4 + tot_bases / 8 + 16 * tot_recs + (0 if args.format == "counted" else 4 * tot_cigar) + 8 * A * args.pairs
                     + 8 * 4 * args.pairs)      # what the kernel's inputs/outputs occupy, excl. pair-alignment arena
     n_good = aa.n_good()
     # ---- rooflines of the kernels of a step; `roofline` is the one with the most kernel time (DESIGN.md section 4 for the bytes) ----
@@ -447,6 +455,8 @@ def main():
                                   else "(not a BASELINE.json configuration)"),
                    "read_pairs": args.pairs, "alleles": A, "genotypes": G, "k": 25,
                    "records": tot_recs, "cigar_words": tot_cigar,
+                   "alignment_table": ("16-byte counted alignments (lcty_reads_append_counted): the caller counts the CIGAR operations"
+                                       if args.format == "counted" else "16-byte BAM records + CIGAR words (lcty_reads_append)"),
                    "step": ("one locus through lcty_solve_queue (score + run_filter + default solver scheme + final comparison); the queue "
                             "alternates between two resident loci and overlaps the annealing stage of a locus with the next locus"
                             if queue_mode else "one locus, call by call"),
@@ -526,13 +536,45 @@ def main():
         n_new = ab.recover()
         t_rec = time.perf_counter() - tr0
         n_tr, ms_tr = ctx.timing(5)                                            # LCTY_K_TRANSFER
-        out["recovery"] = {"sample": f"first {nrec} read pairs, primary records only ({sum(len(c.recs) for c in prim)} records), "
+        cells_sr = ab.recover_dp_cells()
+        out["recovery"] = {"aligner_cells": int(cells_sr), "gcups": cells_sr / (ms_tr * 1e-3) / 1e9 if ms_tr else None,"sample": f"first {nrec} read pairs, primary records only ({sum(len(c.recs) for c in prim)} records), "
                                      f"{len(H)} haplotype alignments, transfer_fails 100",
                            "alignments_transferred": int(n_new), "transfer_kernel_ms": ms_tr, "launches": int(n_tr),
                            "transfers_per_s": n_new / (ms_tr * 1e-3) if ms_tr else None,
                            "recover_and_rescore_s": t_rec, "set_hap_alns_s": t_set, "good_pairs_after": ab.n_good(),
                            "level_pairs": ab.recover_stats()}
         ab.close(); del prim
+
+    if args.ont_sample > 0 and world == 1:
+        # ---- configs[2] shape, the long-read DP path: 10-kb single-end ONT reads, primaries only, every other allele reached by
+        # HapAlns::transfer_alignments (two-CIGAR walk + gap-affine aligner on the stretches between anchors) ----
+        nont = args.ont_sample
+        Lo = synth.SynthLocus(A, nont, seed=synth.SEED + 77, technology=cdefs.TECH_NANOPORE, read_len=10_000)
+        po = api.resolve_params(api.default_params(), Lo.bg)
+        loco = api.Locus(ctx, Lo.seqs, Lo.seq_off, Lo.counts, Lo.cnt_off, Lo.k, Lo.bg, po)
+        tr0 = time.perf_counter()
+        Ho = Lo.hap_alns()
+        loco.set_hap_alns(Ho, transfer_fails=100, max_div=0.1)
+        t_set = time.perf_counter() - tr0
+        chunk_o = 256
+        prim = [Lo.reads(lo, min(chunk_o, nont - lo), primaries_only=True) for lo in range(0, nont, chunk_o)]
+        ao = api.AllAlignments.load(loco, prim)
+        ctx.timing_reset()
+        tr0 = time.perf_counter()
+        n_new = ao.recover()
+        t_rec = time.perf_counter() - tr0
+        n_tr, ms_tr = ctx.timing(api.K_TRANSFER)
+        _, ms_sc = ctx.timing(api.K_SCORE)
+        cells = ao.recover_dp_cells()
+        out["long_reads"] = {"sample": f"{nont} synthetic 10-kb ONT reads x {A} alleles (BASELINE.json configs[2] shape), primary records only, "
+                                       f"{len(Ho)} haplotype alignments, transfer_fails 100",
+                             "alignments_transferred": int(n_new), "transfer_kernel_ms": ms_tr, "launches": int(n_tr),
+                             "transfers_per_s": n_new / (ms_tr * 1e-3) if ms_tr else None,
+                             "aligner_cells": int(cells), "gcups": cells / (ms_tr * 1e-3) / 1e9 if ms_tr else None,
+                             "bases_walked_per_s": n_new * 10_000 / (ms_tr * 1e-3) if ms_tr else None,
+                             "second_scoring_pass_ms": ms_sc, "recover_and_rescore_s": t_rec, "set_hap_alns_s": t_set,
+                             "good_reads_after": ao.n_good(), "level_pairs": ao.recover_stats()}
+        ao.close(); del prim
 
     if first is not None:
         out["cpu_baseline"] = cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G)

@@ -390,6 +390,9 @@ int32_t lcty_locus_set_hap_alns(lcty_locus* locus, uint32_t n_entries, const uin
                                 double max_div);
 int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered);
 int32_t lcty_recover_stats(lcty_reads* reads, uint64_t* level_pairs);
+/* cells of the gap-affine aligner's matrices (the stand-in for WFA2, src/seq/wfa.rs:162-365) filled by the last
+ * lcty_recover_alignments on this batch: cells / kernel time = the GCUPS figure of SURVEY.md section 8(d) */
+int32_t lcty_recover_dp_cells(lcty_reads* reads, uint64_t* cells);
 
 /* ---- minimizer read recruitment: the step of `locityper genotype` immediately before the path (SURVEY.md §8f rank 1;
  * src/seq/recruit.rs, src/seq/kmers.rs:71-340, src/math/frac.rs) ----------------------------------------------------------------

@@ -50,6 +50,7 @@ SIGNATURES = {
     "lcty_locus_set_explicit_weights": (I32, [VP, U32, VP, VP, VP, VP]),
     "lcty_locus_set_hap_alns": (I32, [VP, U32, VP, VP, VP, VP, VP, VP, U32, D]),
     "lcty_recover_alignments": (I32, [VP, P(U64)]),
+    "lcty_recover_dp_cells": (I32, [VP, P(U64)]),
     "lcty_recover_stats": (I32, [VP, P(U64)]),
     "lcty_counts_to_posteriors": (I32, [VP, U64, C.c_uint16, VP, VP]),
     "lcty_comm_unique_id": (I32, [VP]),

@@ -227,6 +227,12 @@ class AllAlignments:
         self.score()
         return int(n.value)
 
+    def recover_dp_cells(self):
+        """Cells of the aligner's matrices filled by the last recover()."""
+        n = U64()
+        check(lib().lcty_recover_dp_cells(self._h, C.byref(n)))
+        return int(n.value)
+
     def recover_stats(self):
         """Read pairs the last recover() took at each of the three lane-scratch levels."""
         out = (C.c_uint64 * 3)()

@@ -246,6 +246,19 @@ class ReadsChunk:
         limited_clipping (aln.rs:288-317) leave of every record, computed here as the caller of lcty_reads_append_counted would.
         Records with an empty CIGAR must not be in the chunk (the record path skips them; a counted batch has no way to say so)."""
         n = len(self.recs)
+        try:                                                     # the C helper of the synthetic-data library does the same loop
+            from . import synth
+            out = np.zeros((n, 4), dtype=np.uint32)
+            al = np.ascontiguousarray(allele_len, dtype=np.uint32)
+            f = synth.lib().synth_count_records
+            f.restype = C.c_uint64
+            f.argtypes = [C.c_uint64] + [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p]
+            bad = f(self.n_pairs, self.aln_off.ctypes.data, self.recs.ctypes.data, self.cigar_off.ctypes.data, self.cigar.ctypes.data,
+                    al.ctypes.data, len(al), out.ctypes.data)
+            assert bad == 0, f"record {bad - 1} cannot be counted (unsupported operation, empty CIGAR or a count above 65535)"
+            return out
+        except (ImportError, OSError, AttributeError):
+            pass
         pair_of = np.repeat(np.arange(self.n_pairs, dtype=np.int64), np.diff(self.aln_off.astype(np.int64)))
         start = self.cigar_off[pair_of].astype(np.int64) + self.recs["cigar_rel"].astype(np.int64)
         ncig = self.recs["n_cigar"].astype(np.int64)

@@ -75,6 +75,7 @@ struct lcty_reads {
     uint32_t max_recs_per_pair = 0;
     uint32_t max_cigar_per_pair = 0;
     uint32_t max_cigar_per_rec = 0;
+    uint64_t recover_dp_cells = 0;                 // aligner cells of the last recovery (lcty_recover_dp_cells)
     uint64_t recover_level_pairs[3] = {0, 0, 0};   // pairs the transfer kernel took at each scratch level (lcty_recover_stats)
     bool scored = false;
     bool counted = false;                    // the records are lcty_aln_counted entries (lcty_reads_append_counted): no CIGAR words

@@ -189,6 +189,7 @@ struct TransferArgs {
     uint32_t* out_words; uint64_t out_words_cap;
     uint64_t* out_rec_at; uint64_t* out_word_at;        // [R]
     uint32_t* flag;                // 1 = arena overflow (retry larger), LCTY_ERR_* >= 2 otherwise
+    unsigned long long* dp_cells;  // cells of the aligner's matrices, all lanes
     double min_weight;
 };
 
@@ -470,6 +471,10 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
         }
         __syncthreads();
     }
+    // aligner work of this wavefront (launches that are repeated with larger arenas count again: it is what the device did)
+    unsigned long long cells = LS.cells;
+    for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+    if (lane == 0 && cells) atomicAdd(T.dp_cells, cells);
 }
 
 // merged record table: per pair [end-0 originals][end-0 transferred][end-1 originals][end-1 transferred][anything behind n_eff]
@@ -628,8 +633,9 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
 
         DevBuf<uint32_t> d_new_cnt, d_new_words, d_flag;
         DevBuf<uint64_t> d_rec_at, d_word_at, d_list_a, d_list_b;
-        DevBuf<unsigned long long> d_cursors;                                      // records, words, pairs for the next level
-        d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(3);
+        DevBuf<unsigned long long> d_cursors;                                      // records, words, pairs for the next level, aligner cells
+        d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(4);
+        LCTY_HIP(hipMemsetAsync(d_cursors.p + 3, 0, sizeof(unsigned long long), s));
         d_list_a.alloc(R); d_list_b.alloc(R);
         // Levels of lane scratch. Level 0 is sized for the reads of the batch (short reads: transferred CIGARs of <= 192 items,
         // stretches between anchors of <= 255 bases) and takes every pair at full occupancy; a pair with a transfer that needs more
@@ -667,7 +673,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             const uint64_t cap_words64 = static_cast<uint64_t>(cap_new) * words_per_new;
             const uint32_t cap_words = static_cast<uint32_t>(std::min<uint64_t>(cap_words64, 1u << 30));
             d_xrecs.alloc(arena_recs); d_xwords.alloc(arena_words);
-            d_flag.zero(s); d_cursors.zero(s);
+            d_flag.zero(s); LCTY_HIP(hipMemsetAsync(d_cursors.p, 0, 3 * sizeof(unsigned long long), s));      // the aligner's cell count runs on
             uint32_t flag = 0;
             reads->recover_level_pairs[0] = reads->recover_level_pairs[1] = reads->recover_level_pairs[2] = 0;
             const uint64_t* list = nullptr;
@@ -686,7 +692,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 T.scratch = d_scratch.p; T.scratch_stride = stride;
                 T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
                 T.out_recs = d_xrecs.p; T.out_recs_cap = arena_recs; T.out_words = d_xwords.p; T.out_words_cap = arena_words;
-                T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.min_weight = loc->prm.min_weight;
+                T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.dp_cells = d_cursors.p + 3; T.min_weight = loc->prm.min_weight;
                 LCTY_HIP(hipMemsetAsync(d_cursors.p + 2, 0, sizeof(unsigned long long), s));
                 ctx->timed(LCTY_K_TRANSFER, [&] {
                     hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
@@ -708,6 +714,12 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             arena_recs = std::max<uint64_t>(arena_recs * 2, cursors[0] + 1024); arena_words = std::max<uint64_t>(arena_words * 2, cursors[1] + 1024);
         }
         const uint64_t total_new = cursors[0], total_words = cursors[1];
+        {
+            unsigned long long cells = 0;
+            d_cursors.download(&cells, 1, s, 3);
+            LCTY_HIP(hipStreamSynchronize(s));
+            reads->recover_dp_cells = cells;
+        }
         if (n_recovered) *n_recovered = total_new;
         if (total_new == 0) return;
 
@@ -755,6 +767,14 @@ int32_t lcty_recover_stats(lcty_reads* reads, uint64_t* level_pairs) {
     return guarded([&] {
         if (!reads || !level_pairs) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         for (int i = 0; i < 3; i++) level_pairs[i] = reads->recover_level_pairs[i];
+    });
+}
+
+// cells of the aligner's dynamic-programming matrices filled by the last lcty_recover_alignments on this batch (GCUPS = cells / time)
+int32_t lcty_recover_dp_cells(lcty_reads* reads, uint64_t* cells) {
+    return guarded([&] {
+        if (!reads || !cells) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        *cells = reads->recover_dp_cells;
     });
 }
 

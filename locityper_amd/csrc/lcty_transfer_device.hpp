@@ -100,6 +100,7 @@ struct Scratch {
     int32_t* lastcol;      // [dp_dim + 1][3] x LANE_STRIDE
     Limits lim;
     uint32_t big;          // bit 0: an end-to-end stretch was too big (placeholder of the right lengths), bit 1: an ends-free one
+    unsigned long long cells;   // cells of the aligner's matrices this lane has filled (GCUPS of lcty_recover_alignments)
 };
 
 // `base`: the wavefront's block of 64 * lane_scratch_bytes(lim) bytes
@@ -113,7 +114,7 @@ __device__ inline Scratch scratch_at(uint8_t* base, uint32_t lane, const Limits&
     s.lastcol = reinterpret_cast<int32_t*>(base) + lane; base += 64 * row;
     s.ops = base + lane; base += 64 * nops;
     s.dirs = base + lane;
-    s.lim = lim; s.big = 0;
+    s.lim = lim; s.big = 0; s.cells = 0;
     return s;
 }
 
@@ -151,6 +152,7 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
         return DP_TOO_BIG;
     }
     const uint32_t W = m + 1;
+    sc.cells += static_cast<unsigned long long>(n + 1) * W;
     int32_t* prev = sc.rows;
     int32_t* cur = sc.rows + static_cast<size_t>(sc.lim.dp_dim + 1) * 3 * LANE_STRIDE;
     for (uint32_t a = 0; a <= n; a++) {

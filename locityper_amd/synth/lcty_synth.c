@@ -661,3 +661,47 @@ uint32_t synth_hap_cigar(const synth_locus* L, uint32_t q, uint32_t r, uint32_t*
     if (aln_len) *aln_len = h.aln_len;
     return h.n;
 }
+
+/* The records of a chunk as lcty_aln_counted entries (harness side of lcty_reads_append_counted): what a caller does while it walks
+ * raw_cigar() — count_region_operations_fast + limited_clipping (seq/aln.rs:288-317), hard_to_soft (seq/cigar.rs:309-320).
+ * out[4 * n_recs] = {pos | flags << 28, contig | matches << 16, mismatches | insertions << 16, deletions | clipping << 16}.
+ * Returns 0, or 1 + the index of the first record that cannot be counted (unsupported operation, count above 65535). */
+uint64_t synth_count_records(uint64_t n_pairs, const uint64_t* aln_off, const lcty_aln_rec* recs, const uint64_t* cigar_off,
+                             const uint32_t* cigar, const uint32_t* allele_len, uint32_t n_alleles, uint32_t* out) {
+    uint64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(max : bad)
+    for (uint64_t r = 0; r < n_pairs; r++) {
+        for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; i++) {
+            const lcty_aln_rec* rc = &recs[i];
+            const uint32_t* cg = cigar + cigar_off[r] + rc->cigar_rel;
+            uint32_t n = rc->n_cigar, matches = 0, mism = 0, ins = 0, del = 0, left = 0, right = 0;
+            int ok = rc->contig < n_alleles || (rc->flags & LCTY_FLAG_UNMAPPED);
+            for (uint32_t t = 0; t < n; t++) {
+                uint32_t op = cg[t] & 15u, len = cg[t] >> 4;
+                if (op == LCTY_CIGAR_H && (t == 0 || t + 1 == n)) op = LCTY_CIGAR_S;
+                switch (op) {
+                    case LCTY_CIGAR_EQ: matches += len; break;
+                    case LCTY_CIGAR_X: mism += len; break;
+                    case LCTY_CIGAR_I: ins += len; break;
+                    case LCTY_CIGAR_D: del += len; break;
+                    case LCTY_CIGAR_S: if (t == 0) left = len; else if (t + 1 == n) right = len; break;
+                    default: ok = 0;
+                }
+            }
+            const uint32_t clen = rc->contig < n_alleles ? allele_len[rc->contig] : 0;
+            const uint32_t end = rc->pos + matches + mism + del;
+            const uint32_t lc = left < rc->pos ? left : rc->pos, room = clen > end ? clen - end : 0;
+            const uint32_t clip = lc + (right < room ? right : room);
+            if (matches > 65535 || mism > 65535 || ins > 65535 || del > 65535 || clip > 65535 || rc->pos >= (1u << 28)) ok = 0;
+            if (n == 0 && !(rc->flags & LCTY_FLAG_UNMAPPED)) ok = 0;
+            if (!ok && i + 1 > bad) bad = i + 1;
+            const uint32_t fl = ((rc->flags & LCTY_FLAG_REVERSE) ? 1u : 0u) | ((rc->flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) ? 2u : 0u)
+                              | ((rc->flags & LCTY_FLAG_UNMAPPED) ? 4u : 0u);
+            out[4 * i] = (rc->pos & 0x0FFFFFFFu) | (fl << 28);
+            out[4 * i + 1] = rc->contig | (matches << 16);
+            out[4 * i + 2] = mism | (ins << 16);
+            out[4 * i + 3] = del | (clip << 16);
+        }
+    }
+    return bad;
+}

@@ -857,3 +857,30 @@ def test_alignment_recovery_neighbour_bin_quirk(gpu_ctx):
         off, pa = aa.pair_alns()
         got[q] = {int(x["mid1"]) for x in pa if int(x["contig"]) == 1 and int(x["mid1"]) != cdefs.NONE_U32}
     assert (1030 + 1180) // 2 in got[1000] and (1030 + 1180) // 2 not in got[900]
+
+
+@pytest.mark.gpu
+def test_alignment_recovery_of_10kb_reads_against_the_oracle(gpu_ctx):
+    """BASELINE.json configs[2] in its stated form, at test size: 10-kb single-end ONT reads (3 % errors, CIGARs of ~670 operations),
+    the mapper reports the primary alignment only, every other allele is reached by HapAlns::transfer_alignments. Statuses, k-mer
+    counts, weights, the likelihood matrix and the pair alignments after recovery equal the oracle's."""
+    n_alleles, n_reads = 6, 48
+    L = synth.SynthLocus(n_alleles, n_reads, seed=synth.SEED + 5, technology=cdefs.TECH_NANOPORE, read_len=10_000, base_len=40_000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    H = O.HapAlns(n_alleles, transfer_fails=100, max_div=0.1)
+    for q, r, words, nm, ln in L.hap_alns():
+        H.add(q, r, words)
+    H.sort()
+    loc.set_hap_alns(H.entries, transfer_fails=100, max_div=0.1)
+    prim = L.reads(0, n_reads, primaries_only=True)
+    assert int(prim.mate_len.max()) > 7000 and len(prim.recs) <= 2 * n_reads
+    aa = api.AllAlignments.load(loc, prim)
+    n_rec = aa.recover()
+    oa = ol.load_recover(prim, H)
+    compare_gpu_to_oracle(aa, oa, index_fields=())
+    assert n_rec >= (n_alleles - 1) * oa.n_good * 0.8 and aa.recover_dp_cells() > 0
+    # and the recovered table carries the truth: the best genotype of the prefilter is the one the reads were drawn from
+    sc = aa.run_filter()
+    assert tuple(api.generate_genotypes(n_alleles, 2)[int(np.argmax(sc))]) == L.true_genotype
