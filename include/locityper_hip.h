@@ -539,6 +539,22 @@ int32_t lcty_bg_from_json(const char* json, uint64_t len, lcty_bg* bg, double* r
 int32_t lcty_res_to_json(const lcty_call* call, const uint16_t* genotypes, uint32_t ploidy, const char* const* names, uint32_t n_alleles,
                          const double* lik_mean, const double* lik_var, const uint32_t* distances, int32_t true_edit_distances,
                          double weighted_dist, char* out, uint64_t cap, uint64_t* needed);
+/* write_bam (src/model/bam.rs:356-413): the alignments of the batch's read pairs to the contigs of ONE genotype as a coordinate-sorted
+ * BAM file (path) and its BAI index (path + ".bai"). For every used read pair (status GOOD) the locations of the pair on the genotype
+ * (extend_read_gt_alns, model/windows.rs:762-797) are folded by (alignment of mate 1, alignment of mate 2) with their assignment counts
+ * (count_alignments, bam.rs:144-176) — read_off / counts exactly as lcty_assignment_counts returned them for THIS genotype and
+ * `attempts` —, one record (pair) per fold: MAPQ and pr from the counts (count_to_prob, 56-67), the fold with most counts primary,
+ * the others secondary; read pairs with few unique k-mers (status FEW_KMERS) follow with us:F (268-298, 328-353). Tags NM, il, al, uk,
+ * pr, us as bam.rs:123-141; flags, mate fields and insert sizes as connect_pair / calc_insert_size (69-86, 178-221).
+ *   table        the caller's copy of what was appended to the batch (records, CIGARs, packed sequences)
+ *   name_off     [n_pairs + 1] into names; qual_off [2 * n_pairs + 1] into quals (NULL: qualities 255), both as in the primary
+ *                record of each mate (lcty_bam_table_view hands them out for an aln.bam)
+ * Not after lcty_recover_alignments (the transferred alignments are not in the caller's table) and not for counted batches:
+ * LCTY_ERR_UNSUPPORTED. *n_records (may be NULL): records written. */
+int32_t lcty_write_bam(const char* path, lcty_reads* reads, const lcty_reads_host* table, const uint64_t* name_off, const char* names,
+                       const uint64_t* qual_off, const uint8_t* quals, const char* const* allele_names, const uint16_t* genotype,
+                       uint32_t ploidy, uint16_t attempts, const uint64_t* read_off, const uint16_t* counts, uint64_t* n_records);
+
 /* OUT/loci/<locus>/aln.bam -> the flat table of lcty_reads_append, grouped as AllAlignments::load walks the records
  * (src/model/locs.rs:405-461, 502-567, 1116-1150): a group = a primary record + the non-primary records behind it; the first group
  * of a read is its first end, with paired != 0 the next group (same name, else LCTY_ERR_INVALID_DATA as ReadData::set_name,

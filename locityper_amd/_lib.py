@@ -84,6 +84,7 @@ SIGNATURES = {
     "lcty_io_write_gz": (I32, [C.c_char_p, VP, U64]),
     "lcty_bg_from_json": (I32, [C.c_char_p, U64, VP, P(D)]),
     "lcty_res_to_json": (I32, [VP, VP, U32, VP, U32, VP, VP, VP, I32, D, VP, U64, P(U64)]),
+    "lcty_write_bam": (I32, [C.c_char_p, VP, VP, VP, VP, VP, VP, VP, VP, U32, C.c_uint16, VP, VP, P(U64)]),
     "lcty_bam_read": (I32, [C.c_char_p, VP, U32, I32, P(VP)]),
     "lcty_bam_table_view": (I32, [VP, VP, P(VP), P(VP), P(U32)]),
     "lcty_bam_table_free": (None, [VP]),

@@ -618,8 +618,9 @@ struct GreedyShared {
 };
 constexpr uint32_t GREEDY_AHEAD = 4;        // iterations the prefetch wavefront runs ahead of the chains, in batches of four
 
-template <uint32_t LPC>
-__global__ __launch_bounds__(128) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains, const uint32_t prefetch) {
+template <uint32_t LPC, bool HELPER>
+__global__ __launch_bounds__(HELPER ? 128 : 64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
+    constexpr uint32_t prefetch = HELPER ? 1u : 0u;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ GreedyShared sh;
     constexpr uint32_t CPW = 64 / LPC;
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(128) void greedy_loop_kernel(const SolveView V, con
     if (sh.flagged != 0u) return;
     const uint32_t W = V.wstride;
     const uint32_t lane = threadIdx.x & 63u;
-    if ((threadIdx.x >> 6) == 1u) {
+    if (HELPER && (threadIdx.x >> 6) == 1u) {
         // ---- prefetch wavefront. The random stream of the greedy loop does not depend on the moves, so the records of the coming
         // iterations are known: this wavefront draws the same picks a few iterations ahead and touches their records (one word
         // each, thrown away), which brings their lines from HBM into the L2. The chain wavefront's own loads of those records
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(128) void greedy_loop_kernel(const SolveView V, con
         }
         __hip_atomic_store(&sh.go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         handed_over = true;
-        __syncthreads();
+        if (HELPER) __syncthreads();
         auto sample = [&]() -> uint32_t {
             // non_trivial_reads.sample(rng, S): one draw of the chain's generator as a key, the S picks as counter draws under it,
             // repeats skipped (our adaptor, oracle/lcty_oracle.h). A sample almost never repeats an index (S^2 / 2 nnt)
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(128) void greedy_loop_kernel(const SolveView V, con
             sA = sB;
         }
     }
-    if (!handed_over) __syncthreads();                                   // the prefetch wavefront waits for exactly one hand-over
+    if (HELPER && !handed_over) __syncthreads();                         // the prefetch wavefront waits for exactly one hand-over
     __hip_atomic_store(&sh.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     depth_mine = row_sum_f64<LPC>(depth_mine); aln_mine = row_sum_f64<LPC>(aln_mine);
     depth_lik += depth_mine; aln_lik += aln_mine;
@@ -1306,14 +1307,16 @@ void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_ini
     LCTY_HIP(hipGetLastError());
 }
 
-template <uint32_t LPC>
+template <uint32_t LPC, bool HELPER>
 void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
     constexpr uint32_t CPW = 64 / LPC;
     const size_t lds = static_cast<size_t>(CPW) * V.wstride * 4;
     if (lds > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC, HELPER>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
-    ctx->timed(LCTY_K_SOLVE, [&] { hipLaunchKernelGGL(greedy_loop_kernel<LPC>, dim3((nch + CPW - 1) / CPW), dim3(128), lds, s, V, nch, static_cast<uint32_t>(ctx->knob("solve_prefetch", nch < 2048 ? 1 : 0))); }, s);
+    ctx->timed(LCTY_K_SOLVE, [&] {
+        hipLaunchKernelGGL((greedy_loop_kernel<LPC, HELPER>), dim3((nch + CPW - 1) / CPW), dim3(HELPER ? 128 : 64), lds, s, V, nch);
+    }, s);
     LCTY_HIP(hipGetLastError());
 }
 
@@ -1450,9 +1453,11 @@ struct StageRunner {
         const int64_t want = ctx->knob("solve_chains_per_wave", 0);
         if (want > 0) lpc = std::max<uint32_t>(lpc, static_cast<uint32_t>(64 / std::min<int64_t>(want, 4)));
         while (lpc < 64 && static_cast<size_t>(64 / lpc) * V.wstride * 4 > 64 * 1024) lpc *= 2;      // keep a few wavefronts per CU
-        if (lpc == 16) launch_greedy<16>(ctx, V, nch, stream);
-        else if (lpc == 32) launch_greedy<32>(ctx, V, nch, stream);
-        else launch_greedy<64>(ctx, V, nch, stream);
+        // the prefetch wavefront pays while the device has room (measured: +10 % at 256 chains, -3 % at 5 000)
+        const bool helper = ctx->knob("solve_prefetch", static_cast<uint64_t>(nch) * lpc / 64 < 1024 ? 1 : 0) != 0;
+        if (lpc == 16) { if (helper) launch_greedy<16, true>(ctx, V, nch, stream); else launch_greedy<16, false>(ctx, V, nch, stream); }
+        else if (lpc == 32) { if (helper) launch_greedy<32, true>(ctx, V, nch, stream); else launch_greedy<32, false>(ctx, V, nch, stream); }
+        else { if (helper) launch_greedy<64, true>(ctx, V, nch, stream); else launch_greedy<64, false>(ctx, V, nch, stream); }
     }
 
     template <typename F>

@@ -48,6 +48,28 @@ def res_to_json(call, genotypes, names, lik_mean, lik_var, distances=None, true_
     return buf.value.decode()
 
 
+def write_bam(path, aa, chunk, names, allele_names, genotype, attempts, read_off, counts, quals=None):
+    """lcty_write_bam: the alignments of the batch `aa` (scored from `chunk`) to one genotype, with the assignment counts of
+    api.assignment_counts for that genotype. names: one per read pair; quals: list of bytes per mate or None. Returns the records written."""
+    hs = chunk.host_struct()
+    blob = "".join(names).encode()
+    noff = np.zeros(len(names) + 1, dtype=np.uint64)
+    np.cumsum([len(n.encode()) for n in names], out=noff[1:])
+    qoff = qbuf = None
+    if quals is not None:
+        qoff = np.zeros(len(quals) + 1, dtype=np.uint64)
+        np.cumsum([len(q) for q in quals], out=qoff[1:])
+        qbuf = np.frombuffer(b"".join(quals), dtype=np.uint8).copy()
+    an = (C.c_char_p * len(allele_names))(*[s.encode() for s in allele_names])
+    gt = np.ascontiguousarray(genotype, dtype=np.uint16)
+    ro = np.ascontiguousarray(read_off, dtype=np.uint64); cn = np.ascontiguousarray(counts, dtype=np.uint16)
+    n = U64()
+    check(lib().lcty_write_bam(str(path).encode(), aa._h, C.byref(hs), noff.ctypes.data, blob, None if qoff is None else qoff.ctypes.data,
+                               None if qbuf is None else qbuf.ctypes.data, an, gt.ctypes.data, len(gt), attempts, ro.ctypes.data,
+                               cn.ctypes.data, C.byref(n)))
+    return int(n.value)
+
+
 class BamTable:
     """lcty_bam_read: aln.bam as a ReadsChunk (+ read names)."""
 
