@@ -229,8 +229,9 @@ int32_t lcty_params_resolve(lcty_params* params, const lcty_bg* bg);
  *   seqs       ASCII allele sequences, concatenated; seq_off[n_alleles+1]
  *   offtarget  off-target k-mer counts (first KmerCounts block), cnt_off[n_alleles+1],
  *              cnt_off[a+1]-cnt_off[a] == len(a)+1-k
- *   k          the reference stores k-mers as u128, k <= 63 (src/seq/kmers.rs:8, 43); the device k-mer set uses 64-bit keys
- *              for k <= 31 and 128-bit keys for 32 <= k <= 63 (two-word slots, the same probing)                          */
+ *   k          LIMIT: k <= 31. The reference stores k-mers as u128 and accepts k <= 63 (src/seq/kmers.rs:8, 43; locs.rs:919);
+ *              this build keeps them in 64 bits (the default k of `locityper add` is 25) and returns LCTY_ERR_UNSUPPORTED for
+ *              32 <= k <= 63, never a different count                                                                      */
 int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles,
                           const uint8_t* seqs, const uint64_t* seq_off,
                           const uint16_t* offtarget, const uint64_t* cnt_off, uint32_t k,
@@ -565,6 +566,9 @@ typedef struct lcty_bam_table lcty_bam_table;
 int32_t lcty_bam_read(const char* path, const char* const* names, uint32_t n_alleles, int32_t paired, lcty_bam_table** out);
 int32_t lcty_bam_table_view(const lcty_bam_table* t, lcty_reads_host* view, const uint64_t** name_off, const char** name_blob, uint32_t* n_refs);
 void    lcty_bam_table_free(lcty_bam_table* t);
+/* DB/loci/<locus>/haplotypes.fa[.gz] (ContigSet::load, src/seq/contigs.rs:295-306): names up to the first blank (0-separated in
+ * `names`), upper-cased sequences concatenated, seq_off[n_seqs + 1]. Called twice: with names = seqs = seq_off = NULL it returns the sizes. */
+int32_t lcty_fasta_read(const char* path, uint32_t* n_seqs, char* names, uint64_t* names_len, uint8_t* seqs, uint64_t* seqs_len, uint64_t* seq_off);
 
 #ifdef __cplusplus
 }

@@ -584,4 +584,42 @@ int32_t lcty_bam_table_view(const lcty_bam_table* t, lcty_reads_host* view, cons
 
 void lcty_bam_table_free(lcty_bam_table* t) { delete t; }
 
+// DB/loci/<locus>/haplotypes.fa.gz as ContigSet::load reads it (seq/contigs.rs:295-306 via fastx): names up to the first blank,
+// sequences upper-cased and concatenated. Two calls: names / seqs NULL sizes them (*n_seqs, *names_len incl. one 0 per name, *seqs_len).
+int32_t lcty_fasta_read(const char* path, uint32_t* n_seqs, char* names, uint64_t* names_len, uint8_t* seqs, uint64_t* seqs_len, uint64_t* seq_off) {
+    return guarded([&] {
+        if (!path || !n_seqs || !names_len || !seqs_len) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        std::vector<uint8_t> raw = slurp(path);
+        const std::string p(path);
+        const std::vector<uint8_t> text = (ends_with(p, ".gz") || ends_with(p, ".bgz")) ? inflate_gzip(raw, path) : raw;
+        std::string nm; std::vector<uint8_t> sq; std::vector<uint64_t> off{0};
+        uint32_t n = 0;
+        size_t i = 0;
+        while (i < text.size()) {
+            size_t e = i;
+            while (e < text.size() && text[e] != '\n') e++;
+            size_t le = e;
+            if (le > i && text[le - 1] == '\r') le--;
+            if (le > i && text[i] == '>') {
+                if (n) off.push_back(sq.size());
+                size_t q = i + 1;
+                while (q < le && text[q] != ' ' && text[q] != '\t') q++;
+                nm.append(reinterpret_cast<const char*>(&text[i + 1]), q - i - 1); nm.push_back(0);
+                n++;
+            } else if (le > i) {
+                if (!n) fail(LCTY_ERR_INVALID_DATA, "%s: sequence before the first FASTA header", path);
+                for (size_t q = i; q < le; q++) sq.push_back(static_cast<uint8_t>(toupper(text[q])));
+            }
+            i = e + 1;
+        }
+        if (n) off.push_back(sq.size());
+        if (names && *names_len >= nm.size()) memcpy(names, nm.data(), nm.size());
+        else if (names) fail(LCTY_ERR_INVALID_INPUT, "names buffer too small");
+        if (seqs && *seqs_len >= sq.size()) memcpy(seqs, sq.data(), sq.size());
+        else if (seqs) fail(LCTY_ERR_INVALID_INPUT, "sequence buffer too small");
+        if (seq_off) memcpy(seq_off, off.data(), sizeof(uint64_t) * off.size());
+        *n_seqs = n; *names_len = nm.size(); *seqs_len = sq.size();
+    });
+}
+
 }  // extern "C"
