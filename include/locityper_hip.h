@@ -370,6 +370,23 @@ int32_t lcty_prefilter_allreduce(lcty_reads* reads, lcty_comm* comm);
 int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
                                  const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                                  double* lik_mean, double* lik_var, double* liks_out /* [n_gt][attempts] or NULL */);
+/* One solver stage of a locus whose READS are sharded over the ranks (SURVEY.md 8e level 2 carried through the solver; BASELINE
+ * configs[4]): rank r scored the r-th contiguous block of the locus' read list into `shard`. GenotypeAlignments::new walks every
+ * read of the locus (assgn.rs:41-84), so the ranks exchange what a stage needs of it: the location-table rows of the alleles
+ * of the stage's genotypes — 32 B per (allele, good read pair) plus the runs of further pair-alignments — packed, all-gathered
+ * in chunks of rows (RCCL) and laid side by side in rank order. The chains are then dealt to the ranks as in
+ * lcty_solve_stage_sharded and their likelihoods all-gathered. Every rank passes the same stage arguments and gets the results of
+ * all n_gt genotypes — bit for bit what lcty_solve_stage returns on the unsharded batch. Device memory: alleles-of-the-stage x
+ * good read pairs of the locus x 32 B per rank (LCTY_ERR_RUNTIME when that does not fit).
+ * lcty_count_unexplained of a sharded locus: the sum of the ranks' counts. */
+int32_t lcty_solve_stage_read_sharded(lcty_reads* shard, lcty_comm* comm, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                                      const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                                      double* lik_mean, double* lik_var, double* liks_out /* [n_gt][attempts] or NULL */);
+/* The same with every shard on ONE device and no exchange: `shards` in read order, all of one locus and one context. The packing
+ * and the side-by-side layout are the code lcty_solve_stage_read_sharded runs between its collectives. Scratch lives on shards[0]. */
+int32_t lcty_solve_stage_from_shards(lcty_reads* const* shards, uint32_t n_shards, const uint16_t* genotypes, uint64_t n_gt,
+                                     uint32_t ploidy, const double* priors, const lcty_solver* solver, uint32_t attempts,
+                                     const uint64_t* chain_seeds, double* lik_mean, double* lik_var, double* liks_out);
 
 /* ---- alignment recovery (AllAlignments::load with opt_hap_alns = Some; src/seq/transfer.rs, src/seq/cigar.rs:1085-1384,
  * src/seq/wfa.rs) ------------------------------------------------------------------------------------------------------

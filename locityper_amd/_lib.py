@@ -68,6 +68,8 @@ SIGNATURES = {
     "lcty_chain_seeds": (I32, [U64, U64, VP]),
     "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
     "lcty_solve_stage_sharded": (I32, [VP, VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
+    "lcty_solve_stage_read_sharded": (I32, [VP, VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
+    "lcty_solve_stage_from_shards": (I32, [VP, U32, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
     "lcty_assignment_counts": (I32, [VP, VP, U32, P(Solver), U32, VP, VP, VP, U64, P(U64)]),
     "lcty_count_unexplained": (I32, [VP, VP, U32, P(U32)]),
     "lcty_call_checks": (I32, [VP, U64, U32, VP, U32, VP, U32, VP, P(D), P(U32)]),

@@ -337,6 +337,22 @@ def solve_stage(aa, genotypes, solver, attempts, seeds, priors=None):
     return mean, var, liks
 
 
+def solve_stage_from_shards(shards, genotypes, solver, attempts, seeds, priors=None):
+    """One solver stage over the reads of several batches of one locus on one device (lcty_solve_stage_from_shards): `shards` in
+    read order; equals solve_stage on the unsharded batch."""
+    genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+    n, ploidy = genotypes.shape
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    assert len(seeds) == n * attempts
+    mean, var, liks = np.zeros(n), np.zeros(n), np.zeros((n, attempts))
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    handles = (VP * len(shards))(*[s._h for s in shards])
+    check(lib().lcty_solve_stage_from_shards(handles, len(shards), genotypes.ctypes.data, n, ploidy,
+                                             None if pri is None else pri.ctypes.data, C.byref(solver), attempts, seeds.ctypes.data,
+                                             mean.ctypes.data, var.ctypes.data, liks.ctypes.data))
+    return mean, var, liks
+
+
 def assignment_counts(aa, genotype, solver, attempts, seeds):
     """Per-read assignment counts of one genotype (update_counts, assgn.rs:374-378): (read_off[n_good+1], counts u16)."""
     genotype = np.ascontiguousarray(genotype, dtype=np.uint16).reshape(-1)
@@ -617,6 +633,20 @@ class Comm:
         check(lib().lcty_solve_stage_sharded(aa._h, self._h, genotypes.ctypes.data, n, ploidy, None if pri is None else pri.ctypes.data,
                                              C.byref(solver), attempts, seeds.ctypes.data, mean.ctypes.data, var.ctypes.data,
                                              liks.ctypes.data))
+        return mean, var, liks
+
+    def solve_stage_read_sharded(self, shard, genotypes, solver, attempts, seeds, priors=None):
+        """One solver stage of a locus whose reads are sharded over the ranks (lcty_solve_stage_read_sharded): `shard` holds this
+        rank's block of the read list; same stage arguments on every rank, the results of all genotypes on every rank."""
+        genotypes = np.ascontiguousarray(genotypes, dtype=np.uint16)
+        n, ploidy = genotypes.shape
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert len(seeds) == n * attempts
+        mean, var, liks = np.zeros(n), np.zeros(n), np.zeros((n, attempts))
+        pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+        check(lib().lcty_solve_stage_read_sharded(shard._h, self._h, genotypes.ctypes.data, n, ploidy,
+                                                  None if pri is None else pri.ctypes.data, C.byref(solver), attempts,
+                                                  seeds.ctypes.data, mean.ctypes.data, var.ctypes.data, liks.ctypes.data))
         return mean, var, liks
 
     def close(self):

@@ -141,4 +141,70 @@ int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint1
     });
 }
 
+// SURVEY.md §8e level 2, the whole path: every rank scored ITS shard of the locus' reads (contiguous blocks of the read list, in
+// rank order). The prefilter's exchange is lcty_prefilter_allreduce; the solver stages need, for every allele of the stage's
+// genotypes, the possible locations of EVERY good read pair — GenotypeAlignments::new walks all reads of the locus
+// (assgn.rs:41-84). Exchange: the rows of those alleles of every rank's location table, packed (32-byte cells + the run of
+// further pair-alignments), all-gathered in chunks of rows over RCCL and laid side by side into one table per rank; then the
+// stage's chains are dealt to the ranks in contiguous blocks as in lcty_solve_stage_sharded and their likelihoods all-gathered.
+// The result equals lcty_solve_stage on the unsharded batch bit for bit (the table cells are the same numbers in the same order).
+int32_t lcty_solve_stage_read_sharded(lcty_reads* shard, lcty_comm* comm, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                                      const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                                      double* lik_mean, double* lik_var, double* liks_out) {
+    return guarded([&] {
+        if (!shard || !comm || !genotypes || !solver || !chain_seeds || !lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (shard->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
+        if (attempts == 0 || ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "attempts and ploidy must be positive");
+        const uint32_t n_ranks = static_cast<uint32_t>(comm->n_ranks), rank = static_cast<uint32_t>(comm->rank);
+        shard->ctx->activate();
+        hipStream_t s = shard->ctx->stream;
+        std::unique_ptr<RowGatherer> G;
+        uint64_t mine[2] = {0, 0};
+        agree_then(comm, [&] {
+            G = std::make_unique<RowGatherer>(shard, genotypes, n_gt, ploidy);
+            G->count(shard, rank, &mine[0], &mine[1]);
+        });
+        // sizes of every shard
+        DevBuf<uint64_t> d_mine, d_all;
+        d_mine.alloc(2); d_all.alloc(2ull * n_ranks);
+        d_mine.upload(mine, 2, s);
+        LCTY_NCCL(ncclAllGather(d_mine.p, d_all.p, 2, ncclUint64, comm->comm, s));
+        std::vector<uint64_t> all(2ull * n_ranks), goods(n_ranks), extras(n_ranks);
+        d_all.download(all.data(), all.size(), s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        for (uint32_t r = 0; r < n_ranks; r++) { goods[r] = all[2 * r]; extras[r] = all[2 * r + 1]; }
+        agree_then(comm, [&] { G->plan(goods.data(), extras.data(), n_ranks); });
+        for (uint32_t row0 = 0; row0 < G->n_rows; row0 += G->rows_per_chunk) {
+            G->pack_chunk(shard, rank, row0, G->send_cells(), shard->gather.send_pa.p);
+            LCTY_NCCL(ncclAllGather(G->send_cells(), G->recv_cells(0), G->chunk_cells() * 32, ncclUint8, comm->comm, s));
+            for (uint32_t r = 0; r < n_ranks; r++) G->place_chunk(G->recv_cells(r), r, row0);
+        }
+        LCTY_NCCL(ncclAllGather(shard->gather.send_pa.p, shard->gather.pa.p, G->ext_stride * sizeof(PairAlnDev), ncclUint8, comm->comm, s));
+        G->finish();
+
+        const uint64_t per = (n_gt + n_ranks - 1) / n_ranks;                 // block partition of the stage's genotype list
+        const uint64_t lo = std::min<uint64_t>(rank * per, n_gt), hi = std::min(lo + per, n_gt);
+        std::vector<double> local(std::max<uint64_t>(per * attempts, 1), std::numeric_limits<double>::quiet_NaN());
+        agree_then(comm, [&] {
+            if (hi <= lo) return;
+            std::vector<double> m(hi - lo), v(hi - lo);
+            solve_stage_gathered(shard, *G, genotypes + lo * ploidy, hi - lo, ploidy, priors ? priors + lo : nullptr, solver, attempts,
+                                 chain_seeds + lo * attempts, m.data(), v.data(), local.data());
+        });
+        DevBuf<double> d_send, d_recv;
+        d_send.alloc(std::max<uint64_t>(per * attempts, 1));
+        d_recv.alloc(std::max<uint64_t>(per * attempts, 1) * n_ranks);
+        d_send.upload(local.data(), per * attempts, s);
+        if (per) LCTY_NCCL(ncclAllGather(d_send.p, d_recv.p, per * attempts, ncclDouble, comm->comm, s));
+        std::vector<double> liks(std::max<uint64_t>(per * attempts, 1) * n_ranks);
+        d_recv.download(liks.data(), per * attempts * n_ranks, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        for (uint64_t g = 0; g < n_gt; g++) {
+            const double* l = liks.data() + g * attempts;
+            math::mean_variance_or_nan(l, attempts, &lik_mean[g], &lik_var[g]);
+            if (liks_out) memcpy(liks_out + g * attempts, l, sizeof(double) * attempts);
+        }
+    });
+}
+
 }  // extern "C"

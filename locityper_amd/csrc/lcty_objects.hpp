@@ -117,6 +117,14 @@ struct lcty_reads {
     bool loc_table_valid = false;
     uint64_t stat_chains = 0, stat_iterations = 0, stat_accepted = 0;   // last lcty_solve_stage
     lcty::DevBuf<uint16_t> d_unexpl_ids; lcty::DevBuf<unsigned long long> d_unexpl_out;   // count_unexplained_reads scratch
+    // the location-table rows of a stage's alleles over the reads of EVERY shard of the locus (lcty_solve_stage_read_sharded /
+    // lcty_solve_stage_from_shards): kept on the shard that asked, grow-only
+    struct RowGatherBufs {
+        lcty::DevBuf<uint8_t> table, send, recv;            // 32-byte cells: [rows][ngp]; one chunk of rows of this shard; of every shard
+        lcty::DevBuf<lcty::PairAlnDev> pa, send_pa;         // [shards][ext_stride]; this shard's run
+        lcty::DevBuf<uint16_t> alleles, row_of;
+        lcty::DevBuf<unsigned long long> counters;          // [shards] extras counted / handed out
+    } gather;
     lcty::DevBuf<uint32_t> d_err;
     lcty::DevBuf<double> d_recover_w;        // per pair: read weight when the pair reaches recover_and_group_alignments, else -1
 
@@ -136,4 +144,28 @@ void launch_prefilter_generic(lcty_reads* reads, const uint16_t* d_genotypes, ui
                               const double* d_priors, double* d_scores);
 void compact_matrix(lcty_reads* reads, double* d_out, uint64_t n_good);         // [A][n_good]
 uint64_t count_genotypes(uint32_t n_alleles, uint32_t ploidy);
+
+// The rows of a stage's alleles of the location tables of several batches (shards of one locus' reads, in read order), laid
+// side by side into one table the solver kernels run on (lcty_solve.hip). The caller moves the packed rows between devices
+// (lcty_comm.hip) or hands every shard over itself (lcty_solve_stage_from_shards).
+struct RowGatherer {
+    lcty_reads* owner; lcty_ctx* ctx; hipStream_t stream;
+    std::vector<uint16_t> alleles, row_of;                  // distinct alleles of the stage's genotypes; allele -> row (0xFFFF: none)
+    uint32_t n_rows = 0, n_shards = 0, rows_per_chunk = 0;
+    std::vector<uint64_t> goods, first;                     // good read pairs of every shard; where a shard's reads start
+    uint64_t stride = 0, ext_stride = 0, ngp = 0, n_good = 0;
+    RowGatherer(lcty_reads* owner, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy);
+    void count(lcty_reads* shard, uint32_t slot, uint64_t* n_good, uint64_t* n_extras);     // builds the shard's table first
+    void plan(const uint64_t* goods, const uint64_t* extras, uint32_t n_shards);
+    uint8_t* send_cells() const { return owner->gather.send.p; }
+    uint8_t* recv_cells(uint32_t shard) const { return owner->gather.recv.p + static_cast<size_t>(shard) * rows_per_chunk * stride * 32; }
+    size_t chunk_cells() const { return static_cast<size_t>(rows_per_chunk) * stride; }
+    PairAlnDev* run_of(uint32_t shard) const { return owner->gather.pa.p + static_cast<size_t>(shard) * ext_stride; }
+    void pack_chunk(lcty_reads* shard, uint32_t slot, uint32_t row0, uint8_t* cells, PairAlnDev* run);   // rows row0.. of one chunk
+    void place_chunk(const uint8_t* cells, uint32_t shard, uint32_t row0);
+    void finish();
+};
+void solve_stage_gathered(lcty_reads* owner, const RowGatherer& G, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                          const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                          double* lik_mean, double* lik_var, double* liks_out);
 }  // namespace lcty

@@ -98,7 +98,8 @@ struct SolveView {
     // reads
     uint32_t n_good;
     uint64_t ngp;                   // row stride of the location table (n_good rounded up to 64)
-    const LocEntry* table;          // [A][ngp]
+    const LocEntry* table;          // [A][ngp], or [rows][ngp] with row_of when only the rows of some alleles are held
+    const uint16_t* row_of;         // allele -> row of `table` (NULL: the allele itself)
     const PairAlnDev* pa;
     // chains
     const uint16_t* genotypes;      // [n_gt][ploidy]
@@ -188,6 +189,59 @@ __global__ __launch_bounds__(256) void build_loc_table_kernel(const uint32_t* __
     }
 }
 
+// ---- the location-table rows of some alleles over the reads of SEVERAL batches (shards of one locus' reads, SURVEY 8e level 2):
+// per shard the rows are packed — cells of the wanted alleles, the pair-alignments behind the first one of a cell compacted into
+// a run of the shard's own — and then laid side by side, shard after shard, into one table whose cells point into one array of
+// further pair-alignments. `ext` of a packed cell: index into the shard's run.
+__global__ __launch_bounds__(256) void pack_rows_count_kernel(const LocEntry* __restrict__ table, uint64_t ngp, uint32_t n_good,
+                                                              const uint16_t* __restrict__ alleles, uint32_t n_rows,
+                                                              unsigned long long* __restrict__ total) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    uint32_t mine = 0;
+    if (i < static_cast<uint64_t>(n_rows) * n_good) {
+        const uint32_t u = static_cast<uint32_t>(i / n_good), g = static_cast<uint32_t>(i % n_good);
+        const uint32_t cnt = table[static_cast<uint64_t>(alleles[u]) * ngp + g].m1n >> 24;
+        mine = cnt > 1 ? cnt - 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += static_cast<uint32_t>(__shfl_xor(static_cast<int>(mine), o));
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(total, static_cast<unsigned long long>(mine));
+}
+__global__ __launch_bounds__(256) void pack_rows_kernel(const LocEntry* __restrict__ table, uint64_t ngp, uint32_t n_good,
+                                                        const uint16_t* __restrict__ alleles, uint32_t n_rows, const PairAlnDev* __restrict__ pa,
+                                                        LocEntry* __restrict__ cells, uint64_t out_stride, PairAlnDev* __restrict__ extras,
+                                                        unsigned long long* __restrict__ cursor) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= static_cast<uint64_t>(n_rows) * out_stride) return;
+    const uint32_t u = static_cast<uint32_t>(i / out_stride), g = static_cast<uint32_t>(i % out_stride);
+    LocEntry e{-INFINITY, MID_NONE24, NONE32S, 0.0, 0u, 0u};
+    if (g < n_good) {
+        e = table[static_cast<uint64_t>(alleles[u]) * ngp + g];
+        const uint32_t cnt = e.m1n >> 24;
+        if (cnt > 1) {
+            const unsigned long long at = atomicAdd(cursor, static_cast<unsigned long long>(cnt - 1));
+            for (uint32_t k = 0; k + 1 < cnt; k++) extras[at + k] = pa[e.ext + k];
+            e.ext = static_cast<uint32_t>(at);
+        } else e.ext = 0;
+    }
+    cells[i] = e;
+}
+// one shard's packed rows into the gathered table: full[u][first + g] = cells[u][g], `ext` moved by where the shard's run starts
+__global__ __launch_bounds__(256) void place_rows_kernel(const LocEntry* __restrict__ cells, uint64_t in_stride, uint32_t n_good, uint32_t n_rows,
+                                                         uint32_t ext_base, LocEntry* __restrict__ full, uint64_t full_stride, uint64_t first) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= static_cast<uint64_t>(n_rows) * n_good) return;
+    const uint32_t u = static_cast<uint32_t>(i / n_good), g = static_cast<uint32_t>(i % n_good);
+    LocEntry e = cells[static_cast<uint64_t>(u) * in_stride + g];
+    if ((e.m1n >> 24) > 1) e.ext += ext_base;
+    full[static_cast<uint64_t>(u) * full_stride + first + g] = e;
+}
+__global__ __launch_bounds__(256) void pad_rows_kernel(LocEntry* __restrict__ full, uint64_t full_stride, uint64_t from, uint32_t n_rows) {
+    const uint64_t width = full_stride - from;
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= static_cast<uint64_t>(n_rows) * width) return;
+    full[(i / width) * full_stride + from + i % width] = LocEntry{-INFINITY, MID_NONE24, NONE32S, 0.0, 0u, 0u};
+}
+
 // BayesCalc::ln_pmf evaluated directly: bayes.rs:27-35 with Ln::map_sum_init (math/mod.rs:80-94)
 __device__ __noinline__ double bayes_ln_pmf_direct(const DepthNB* nb, uint32_t n_alt, uint32_t depth) {
     const double x = static_cast<double>(depth);
@@ -227,13 +281,14 @@ __global__ __launch_bounds__(256) void build_depth_table_kernel(const double* __
 // ---- the genotype of a chain: GenotypeWindows (windows.rs:709-739) ----
 template <uint32_t P>
 struct Geno {
-    uint32_t id[P], shift[P], reg_start[P], reg_end[P];
+    uint32_t id[P], row[P], shift[P], reg_start[P], reg_end[P];
     uint32_t total_w;
     __device__ __forceinline__ void init(const SolveView& V, uint32_t gi) {
         total_w = 2;                                                        // REG_WINDOW_SHIFT
 #pragma unroll
         for (uint32_t p = 0; p < P; p++) {
             id[p] = V.genotypes[static_cast<uint64_t>(gi) * P + p];
+            row[p] = V.row_of ? V.row_of[id[p]] : id[p];
             shift[p] = total_w;
             reg_start[p] = V.reg_start[id[p]];
             const uint32_t nw = V.n_windows[id[p]];
@@ -262,7 +317,7 @@ template <uint32_t P>
 __device__ __forceinline__ void locs_init(Locs<P>& L, const SolveView& V, uint32_t g, const Geno<P>& G) {
     LocEntry cells[P];
 #pragma unroll
-    for (uint32_t p = 0; p < P; p++) cells[p] = V.table[static_cast<uint64_t>(G.id[p]) * V.ngp + g];
+    for (uint32_t p = 0; p < P; p++) cells[p] = V.table[static_cast<uint64_t>(G.row[p]) * V.ngp + g];
     locs_from_cells<P>(L, V, cells);
 }
 
@@ -1342,7 +1397,7 @@ struct StageRunner {
     lcty_ctx::SolveWorkspace& ws;       // device state of the chains: grow-only, lives as long as the context
 
     StageRunner(lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver, uint32_t attempts_,
-                const uint64_t* chain_seeds, uint32_t lane_ = 0)
+                const uint64_t* chain_seeds, uint32_t lane_ = 0, const RowGatherer* gathered = nullptr)
         : reads(r), n_gt(n_gt_), ploidy(ploidy_), attempts(attempts_), lane(lane_), ws(check_args(r, genotypes, solver, chain_seeds, lane_)) {
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
         if (ploidy == 0 || ploidy > MAXP) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles ploidy 1..%u", MAXP);
@@ -1361,9 +1416,10 @@ struct StageRunner {
         for (uint64_t i = 0; i < n_gt * ploidy; i++)
             if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
         if (n_gt * attempts >= 0x7FFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many chains in one stage");
-        ensure_solver_tables(reads);
+        if (!gathered) ensure_solver_tables(reads);
         reads->stat_chains = reads->stat_iterations = reads->stat_accepted = 0;
-        const uint64_t n_good = reads->n_good_cached, ngp = reads->ngp;
+        // the batch's own table, or the rows of the stage's alleles over the reads of every shard of the locus
+        const uint64_t n_good = gathered ? gathered->n_good : reads->n_good_cached, ngp = gathered ? gathered->ngp : reads->ngp;
         // depth table: wide enough for twice the mean depth of "every read on the shortest contig" (two mates per pair);
         // a chain that still runs past it raises `overflow` and the batch is repeated with a wider table
         uint32_t min_w = 0xFFFFFFFFu;
@@ -1382,7 +1438,10 @@ struct StageRunner {
         V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
         V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
-        V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p;
+        V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p; V.row_of = nullptr;
+        if (gathered) {
+            V.table = reinterpret_cast<const LocEntry*>(reads->gather.table.p); V.pa = reads->gather.pa.p; V.row_of = reads->gather.row_of.p;
+        }
         V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
         V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
         lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
@@ -1503,6 +1562,7 @@ struct StageRunner {
                     const uint64_t before = gt_per_batch;
                     plan_batches();
                     V.overflow = ws.ovf.p;
+                    V.priors = priors ? ws.pri.p : nullptr;                    // plan_batches starts from "no priors"; this batch's are uploaded
                     if (gt_per_batch < ng) fail(LCTY_ERR_RUNTIME, "device memory: %llu chains of this stage do not fit with %u further locations each (had %llu)",
                                                 static_cast<unsigned long long>(ng * attempts), ws.extra_cap, static_cast<unsigned long long>(before));
                     continue;
@@ -1533,6 +1593,126 @@ void solve_stage_on(uint32_t lane, lcty_reads* reads, const uint16_t* genotypes,
         }
     });
 }
+
+}  // namespace
+
+// ---- RowGatherer (lcty_objects.hpp)
+RowGatherer::RowGatherer(lcty_reads* owner_, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy) : owner(owner_) {
+    if (!owner || !genotypes) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    ctx = owner->ctx; ctx->activate(); stream = ctx->stream;
+    const uint32_t A = owner->locus->n_alleles;
+    row_of.assign(A, 0xFFFF);
+    for (uint64_t i = 0; i < n_gt * ploidy; i++) {
+        if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
+        row_of[genotypes[i]] = 0;
+    }
+    for (uint32_t a = 0; a < A; a++)
+        if (row_of[a] == 0) { row_of[a] = static_cast<uint16_t>(alleles.size()); alleles.push_back(static_cast<uint16_t>(a)); }
+    n_rows = static_cast<uint32_t>(alleles.size());
+    if (n_rows == 0) fail(LCTY_ERR_INVALID_INPUT, "a stage without genotypes");
+    auto& B = owner->gather;
+    B.alleles.ensure(n_rows); B.alleles.upload(alleles.data(), n_rows, stream);
+    B.row_of.ensure(A); B.row_of.upload(row_of.data(), A, stream);
+}
+
+void RowGatherer::count(lcty_reads* shard, uint32_t slot, uint64_t* good_out, uint64_t* extras_out) {
+    if (!shard || shard->ctx != ctx || shard->locus != owner->locus) fail(LCTY_ERR_INVALID_INPUT, "the shards of a locus belong to one context and one locus");
+    if (!shard->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
+    shard->check_device_error();
+    ensure_solver_tables(shard);
+    auto& B = owner->gather;
+    if (B.counters.n < 2ull * (slot + 1)) {
+        // grow keeping what the earlier shards counted
+        std::vector<unsigned long long> old(B.counters.n, 0ull);
+        if (B.counters.n) { B.counters.download(old.data(), old.size(), stream); LCTY_HIP(hipStreamSynchronize(stream)); }
+        old.resize(2ull * std::max<uint32_t>(slot + 1, 8), 0ull);
+        B.counters.alloc(old.size()); B.counters.upload(old.data(), old.size(), stream);
+    }
+    unsigned long long zero[2] = {0, 0};
+    LCTY_HIP(hipMemcpyAsync(B.counters.p + 2 * slot, zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+    const uint64_t n = static_cast<uint64_t>(n_rows) * shard->n_good_cached;
+    if (n)
+        hipLaunchKernelGGL(pack_rows_count_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<const LocEntry*>(shard->d_loc_table.p), shard->ngp, static_cast<uint32_t>(shard->n_good_cached),
+                           B.alleles.p, n_rows, B.counters.p + 2 * slot);
+    LCTY_HIP(hipGetLastError());
+    unsigned long long v = 0;
+    LCTY_HIP(hipMemcpyAsync(&v, B.counters.p + 2 * slot, sizeof(v), hipMemcpyDeviceToHost, stream));
+    LCTY_HIP(hipStreamSynchronize(stream));
+    *good_out = shard->n_good_cached; *extras_out = v;
+}
+
+void RowGatherer::plan(const uint64_t* goods_, const uint64_t* extras, uint32_t n_shards_) {
+    n_shards = n_shards_;
+    goods.assign(goods_, goods_ + n_shards); first.assign(n_shards, 0);
+    n_good = 0; stride = 0; ext_stride = 0;
+    for (uint32_t r = 0; r < n_shards; r++) {
+        first[r] = n_good; n_good += goods[r];
+        stride = std::max(stride, goods[r]); ext_stride = std::max(ext_stride, extras[r]);
+    }
+    stride = std::max<uint64_t>(stride, 1); ext_stride = std::max<uint64_t>(ext_stride, 1);
+    if (n_good >= (1ull << 24)) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles up to 2^24 good read pairs per locus");
+    if (ext_stride * n_shards > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "2^32 or more further pair-alignments over the shards of a locus");
+    ngp = std::max<uint64_t>(64, (n_good + 63) / 64 * 64);
+    // rows travel in chunks so that the staging buffers stay small next to the table (lcty_ctx_set_knob "gather_chunk_mb")
+    const uint64_t chunk_bytes = static_cast<uint64_t>(ctx->knob("gather_chunk_mb", 256)) << 20;
+    rows_per_chunk = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(n_rows, chunk_bytes / (stride * n_shards * sizeof(LocEntry)))));
+    auto& B = owner->gather;
+    size_t free_b = 0, total_b = 0;
+    LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t need = static_cast<uint64_t>(n_rows) * ngp * sizeof(LocEntry);
+    if (B.table.n < need && need > free_b + B.table.n)
+        fail(LCTY_ERR_RUNTIME, "device memory: the rows of %u alleles over %llu good read pairs (%.1f GB) do not fit", n_rows,
+             static_cast<unsigned long long>(n_good), static_cast<double>(need) * 1e-9);
+    B.table.ensure(need);
+    B.send.ensure(chunk_cells() * sizeof(LocEntry)); B.recv.ensure(chunk_cells() * n_shards * sizeof(LocEntry));
+    B.pa.ensure(ext_stride * n_shards); B.send_pa.ensure(ext_stride);
+}
+
+void RowGatherer::pack_chunk(lcty_reads* shard, uint32_t slot, uint32_t row0, uint8_t* cells, PairAlnDev* run) {
+    const uint32_t nr = std::min(rows_per_chunk, n_rows - row0);
+    const uint64_t n = static_cast<uint64_t>(nr) * stride;
+    auto& B = owner->gather;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const LocEntry*>(shard->d_loc_table.p), shard->ngp, static_cast<uint32_t>(shard->n_good_cached),
+                       B.alleles.p + row0, nr, shard->d_pa.p, reinterpret_cast<LocEntry*>(cells), stride, run, B.counters.p + 2 * slot + 1);
+    LCTY_HIP(hipGetLastError());
+}
+
+void RowGatherer::place_chunk(const uint8_t* cells, uint32_t shard, uint32_t row0) {
+    const uint32_t nr = std::min(rows_per_chunk, n_rows - row0);
+    const uint64_t n = static_cast<uint64_t>(nr) * goods[shard];
+    if (!n) return;
+    hipLaunchKernelGGL(place_rows_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const LocEntry*>(cells), stride, static_cast<uint32_t>(goods[shard]), nr,
+                       static_cast<uint32_t>(shard * ext_stride), reinterpret_cast<LocEntry*>(owner->gather.table.p) + static_cast<size_t>(row0) * ngp,
+                       ngp, first[shard]);
+    LCTY_HIP(hipGetLastError());
+}
+
+void RowGatherer::finish() {
+    const uint64_t n = static_cast<uint64_t>(n_rows) * (ngp - n_good);
+    if (n)
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<LocEntry*>(owner->gather.table.p), ngp, n_good, n_rows);
+    LCTY_HIP(hipGetLastError());
+}
+
+void lcty::solve_stage_gathered(lcty_reads* owner, const RowGatherer& G, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                          const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                          double* lik_mean, double* lik_var, double* liks_out) {
+    if (!lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    StageRunner R(owner, genotypes, n_gt, ploidy, solver, attempts, chain_seeds, 0, &G);
+    R.run(genotypes, priors, chain_seeds, [&](uint64_t g0, uint64_t ng, const double* liks) {
+        for (uint64_t g = 0; g < ng; g++) {
+            const double* l = liks + g * attempts;
+            math::mean_variance_or_nan(l, attempts, &lik_mean[g0 + g], &lik_var[g0 + g]);
+            if (liks_out) memcpy(liks_out + (g0 + g) * attempts, l, sizeof(double) * attempts);
+        }
+    });
+}
+
+namespace {
 
 uint32_t count_unexplained_on(hipStream_t s, lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy) {
     lcty_ctx* ctx = reads->ctx;
@@ -1620,6 +1800,28 @@ int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t 
                          const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out) {
     return guarded([&] { solve_stage_on(0, reads, genotypes, n_gt, ploidy, priors, solver, attempts, chain_seeds, lik_mean, lik_var, liks_out); });
+}
+
+// One stage over the reads of several batches of one locus held by ONE device (shards in read order): the rows of the stage's
+// alleles are packed per shard and laid side by side exactly as lcty_solve_stage_read_sharded does between devices — the same
+// code with the exchange left out; equals lcty_solve_stage on the unsharded batch bit for bit.
+int32_t lcty_solve_stage_from_shards(lcty_reads* const* shards, uint32_t n_shards, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
+                                     const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
+                                     double* lik_mean, double* lik_var, double* liks_out) {
+    return guarded([&] {
+        if (!shards || n_shards == 0 || !shards[0]) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        RowGatherer G(shards[0], genotypes, n_gt, ploidy);
+        std::vector<uint64_t> goods(n_shards), extras(n_shards);
+        for (uint32_t r = 0; r < n_shards; r++) G.count(shards[r], r, &goods[r], &extras[r]);
+        G.plan(goods.data(), extras.data(), n_shards);
+        for (uint32_t row0 = 0; row0 < G.n_rows; row0 += G.rows_per_chunk)
+            for (uint32_t r = 0; r < n_shards; r++) {
+                G.pack_chunk(shards[r], r, row0, G.recv_cells(r), G.run_of(r));
+                G.place_chunk(G.recv_cells(r), r, row0);
+            }
+        G.finish();
+        solve_stage_gathered(shards[0], G, genotypes, n_gt, ploidy, priors, solver, attempts, chain_seeds, lik_mean, lik_var, liks_out);
+    });
 }
 
 int32_t lcty_assignment_counts(lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy, const lcty_solver* solver,

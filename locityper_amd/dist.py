@@ -8,6 +8,9 @@ The path shards at three levels:
   * the (genotype, attempt) chains of a solver stage are independent (solvers/solve.rs:1052-1062 deals them to threads):
     contiguous blocks of the stage's genotype list per rank, all-gather of the per-chain likelihoods — on the devices
     through the library's lcty_solve_stage_sharded (Comm.solve_stage), or of host arrays through the process group.
+  * a stage of a locus whose reads are sharded needs the possible locations of every read: the location-table rows of the stage's
+    alleles are all-gathered between the devices (Comm.solve_stage_read_sharded, lcty_solve_stage_read_sharded); the host-array
+    form of that exchange is allgather_read_shards.
 torch.distributed is plumbing only (rendezvous, barrier, small host-staged reductions); it is
 imported lazily and only when WORLD_SIZE > 1, after liblocityper_hip.so has been loaded.
 """
@@ -100,6 +103,24 @@ def allgather_chain_liks(local, n_genotypes, attempts):
     parts = [torch.empty_like(mine) for _ in range(world)]
     _pg.all_gather(parts, mine)
     return torch.cat(parts).numpy()[:n_genotypes]
+
+
+def allgather_read_shards(status, weight, unmapped_prob, pa_off, pair_alns):
+    """Host-array form of the read-sharded solver exchange (lcty_solve_stage_read_sharded carries the location-table rows of the
+    stage's alleles between the devices): every rank's per-pair AllAlignments products all-gathered and concatenated in rank
+    order, the pair-alignment offsets moved behind the earlier shards. Returns the arrays of the whole read list."""
+    mine = (np.asarray(status), np.asarray(weight), np.asarray(unmapped_prob), np.asarray(pa_off, dtype=np.uint64), np.asarray(pair_alns))
+    if _pg is None:
+        return mine
+    _, _, world = env()
+    parts = [None] * world
+    _pg.all_gather_object(parts, mine)
+    off, base = [np.zeros(1, dtype=np.uint64)], 0
+    for q in parts:
+        off.append(q[3][1:] + np.uint64(base))
+        base += int(q[3][-1])
+    return (np.concatenate([q[0] for q in parts]), np.concatenate([q[1] for q in parts]), np.concatenate([q[2] for q in parts]),
+            np.concatenate(off), np.concatenate([q[4] for q in parts]))
 
 
 def make_comm(ctx):

@@ -14,15 +14,22 @@ import sys
 
 
 def per_kernel(path, counter):
-    tot = collections.defaultdict(float)
-    launches = collections.defaultdict(set)
+    """(sum, launches) over the FULL-SIZE launches of every kernel: a dispatch counts when its grid is at least half the largest grid
+    the kernel was launched with (the solver also launches its kernels on single chains, which would drag a plain mean down)."""
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    grid = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        tot[name] += float(r["Counter_Value"])
-        launches[name].add(r["Dispatch_Id"])
-    return {k: (tot[k], len(launches[k])) for k in tot}
+        per[name][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        grid[name][r["Dispatch_Id"]] = float(r.get("Grid_Size") or 0)
+    out = {}
+    for k, d in per.items():
+        biggest = max(grid[k].values())
+        full = [i for i in d if grid[k][i] >= 0.5 * biggest]
+        out[k] = (sum(d[i] for i in full), len(full))
+    return out
 
 
 def main():

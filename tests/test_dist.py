@@ -39,8 +39,16 @@ clo, chi, per = dist.chain_block(len(gsub), rank, world)
 local = O.solve_stage(ol, oa, gsub[clo:chi], sv, 3, seeds[3 * clo:3 * chi])[2]
 liks = dist.allgather_chain_liks(local, len(gsub), 3)
 whole = O.solve_stage(ol, oa, gsub, sv, 3, seeds)
+# level 2 through the solver: every rank loaded only its shard of the reads; the per-pair products are all-gathered in rank order
+# (the host-array form of lcty_solve_stage_read_sharded's exchange), then the chains are dealt as above
+mine = ol.load(ch.slice(lo, hi))
+st, w, unm, off, pa = dist.allgather_read_shards(mine.status, mine.weight, mine.unmapped_prob, mine.pa_off, mine.pair_alns)
+joined = O.alns_from_arrays(6, st, w, unm, off, pa)
+local2 = O.solve_stage(ol, joined, gsub[clo:chi], sv, 3, seeds[3 * clo:3 * chi])[2]
+liks2 = dist.allgather_chain_liks(local2, len(gsub), 3)
 dist.barrier()
 res = dist.gather_objects({"rank": rank, "loci": loci, "shard": [lo, hi], "block": [clo, chi, per],
+                            "read_sharded_equal": bool(np.array_equal(liks2, whole[2])), "joined_pairs": int(len(st)),
                             "chains_equal": bool(np.array_equal(liks, whole[2])),
                             "mean_equal": bool(np.array_equal(liks.mean(axis=1), whole[2].mean(axis=1)))})
 if rank == 0:
@@ -75,3 +83,5 @@ def test_two_rank_gloo(tmp_path):
     # chains of a stage in blocks of ceil(7 / 2): the gathered likelihoods are the single-process ones, bit for bit
     assert out["res"][0]["block"] == [0, 4, 4] and out["res"][1]["block"] == [4, 7, 4]
     assert all(r["chains_equal"] and r["mean_equal"] for r in out["res"])
+    # reads sharded, per-pair products exchanged: the same chains again
+    assert all(r["read_sharded_equal"] and r["joined_pairs"] == 200 for r in out["res"])

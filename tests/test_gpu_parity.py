@@ -786,6 +786,56 @@ def test_chain_sharded_stage(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_read_sharded_stage(gpu_ctx):
+    """SURVEY 8e level 2 through the solver (BASELINE configs[4]): the reads of a locus in shards, the location-table rows of the stage's
+    alleles packed per shard and laid side by side. Every shard on this one GPU (lcty_solve_stage_from_shards) and one rank of RCCL
+    (lcty_solve_stage_read_sharded: the same packing with the all-gathers in between): both equal lcty_solve_stage on the unsharded
+    batch bit for bit — also with an empty shard, with the rows travelling in several chunks, and with ploidy 3."""
+    L = synth.SynthLocus(12, 3000, seed=31, base_len=12000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ch = L.reads(0, 3000)
+    whole = api.AllAlignments.load(loc, ch)
+    off, pa = whole.pair_alns()
+    assert sum(len(set(pa["contig"][off[i]:off[i + 1]].tolist())) < off[i + 1] - off[i] for i in range(3000)) > 100   # runs to carry
+    bounds = (0, 1100, 1100, 1733, 3000)
+    shards = [api.AllAlignments.load(loc, ch.slice(lo, hi)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    assert sum(s.n_good() for s in shards) == whole.n_good() and shards[1].n_good() == 0
+    all_gts = api.generate_genotypes(12, 2)
+    picks = all_gts[[3, 17, 18, 40, 41, 42, 77]]                         # 7 genotypes over a subset of the alleles
+    comm = api.Comm(gpu_ctx, 1, 0, api.comm_unique_id())
+    cases = [(picks, cdefs.SOLVER_GREEDY, 2), (picks, cdefs.SOLVER_ANNEAL, 2), (all_gts[:40], cdefs.SOLVER_GREEDY, 1),
+             (api.generate_genotypes(12, 3)[[0, 5, 100, 363]], cdefs.SOLVER_ANNEAL, 2)]
+    for chunk_mb in (-1, 1):
+        gpu_ctx.set_knob("gather_chunk_mb", chunk_mb)
+        for gts, kind, attempts in cases:
+            sv = api.default_solver(kind)
+            if kind == cdefs.SOLVER_ANNEAL:
+                sv.anneal_steps, sv.plato_size = 1500, 1000
+            seeds = api.chain_seeds(21, attempts * len(gts))
+            pri = -0.5 * np.arange(len(gts), dtype=np.float64)
+            m1, v1, l1 = api.solve_stage(whole, gts, sv, attempts, seeds, priors=pri)
+            m2, v2, l2 = api.solve_stage_from_shards(shards, gts, sv, attempts, seeds, priors=pri)
+            assert np.array_equal(l1, l2) and np.array_equal(m1, m2) and np.array_equal(v1, v2, equal_nan=True)
+            m3, v3, l3 = api.solve_stage_from_shards([whole], gts, sv, attempts, seeds, priors=pri)
+            assert np.array_equal(l1, l3)
+            m4, v4, l4 = comm.solve_stage_read_sharded(whole, gts, sv, attempts, seeds, priors=pri)
+            assert np.array_equal(l1, l4) and np.array_equal(m1, m4) and np.array_equal(v1, v4, equal_nan=True)
+    gpu_ctx.set_knob("gather_chunk_mb", -1)
+    # the unexplained reads of a sharded locus are the sum over the shards
+    gt = all_gts[17]
+    assert sum(api.count_unexplained(s, gt) for s in shards) == api.count_unexplained(whole, gt)
+    # shards of another locus are refused
+    L2 = synth.SynthLocus(12, 200, seed=32, base_len=12000)
+    loc2 = api.Locus(gpu_ctx, L2.seqs, L2.seq_off, L2.counts, L2.cnt_off, L2.k, L2.bg, p)
+    other = api.AllAlignments.load(loc2, L2.reads(0, 200))
+    with pytest.raises(_lib.LocityperError) as e:
+        api.solve_stage_from_shards([shards[0], other], picks, api.default_solver(cdefs.SOLVER_GREEDY), 1, api.chain_seeds(1, len(picks)))
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
+    comm.close()
+
+
+@pytest.mark.gpu
 def test_config5_allele_count_pairs_beyond_the_lds(gpu_ctx):
     """configs[4] has 4 096 alleles and the mapper is asked for min(25 000, 4 x alleles) locations per read end
     (genotype.rs:971): a pair with an alignment per end on every allele has 8 192+ records, more than the LDS holds next to the
