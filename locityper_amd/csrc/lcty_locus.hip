@@ -104,6 +104,14 @@ __global__ void window_weight_kernel(const uint32_t* __restrict__ uniq_cnt, cons
     out[i] = w * 1.0;      // explicit weight == 1 (no --reg-weights file); explicit_window_kernel otherwise
 }
 
+// one factor of the window weight as a table over the count it is a function of: out[i] = what window_weight_kernel computes for a
+// count of i (the same device code: the products of two entries are the kernel's weights bit for bit); out[n] = 0
+__global__ void weight_table_kernel(uint32_t n, double mult, double bp, double pw, bool with_zero_tail, double* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bp > 0.0 ? weight_calc(bp, pw, static_cast<double>(i) * mult) : 1.0;
+    else if (i == n && with_zero_tail) out[i] = 0.0;
+}
+
 // NeighbInfo::explicit_weight of every moving-window position (windows.rs:409-413): the average of the window's own bases,
 // taken from the running fixed-point sums as ExplicitWeights::average does (236-238: the INTEGER sum is divided by the
 // number of bases, then scaled by 2^-32) and multiplied into the window weight as its last factor (441-443).
@@ -325,6 +333,19 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
                            params->kmers_weight_bp, params->kmers_weight_pow, params->compl_weight_bp, params->compl_weight_pow,
                            L->d_win_weight.p);
         LCTY_HIP(hipGetLastError());
+        {
+            // counts run 0..neighb + 1 - k and 0..min(neighb + 1 - ck, 4^ck)
+            const uint64_t n_u = static_cast<uint64_t>(neighb) + 1 - k + 1, n_c = std::min<uint64_t>(neighb + 1 - ck, 1ull << (2 * ck)) + 1;
+            L->weight_tables_valid = n_u + 1 <= 512 && n_c <= 512;
+            if (L->weight_tables_valid) {
+                L->d_wk.alloc(n_u + 1); L->d_wc.alloc(n_c);
+                hipLaunchKernelGGL(weight_table_kernel, dim3(3), dim3(256), 0, s, static_cast<uint32_t>(n_u), L->uniq_mult,
+                                   params->kmers_weight_bp, params->kmers_weight_pow, true, L->d_wk.p);
+                hipLaunchKernelGGL(weight_table_kernel, dim3(3), dim3(256), 0, s, static_cast<uint32_t>(n_c), L->compl_mult,
+                                   params->compl_weight_bp, params->compl_weight_pow, false, L->d_wc.p);
+                LCTY_HIP(hipGetLastError());
+            }
+        }
 
         // ---- K1 (device) ----
         {

@@ -37,6 +37,10 @@ struct lcty_locus {
     lcty::DevBuf<uint16_t> d_compl_cnt;
     lcty::DevBuf<uint8_t> d_gc;
     lcty::DevBuf<uint32_t> d_uniq_cnt;
+    // the two factors of a window weight as tables over uniq_cnt / compl_cnt (+ a last wk entry of 0: "trivial"): the greedy
+    // loop keeps them in LDS. Valid when both counts fit nine bits.
+    lcty::DevBuf<double> d_wk, d_wc;
+    bool weight_tables_valid = false;
     lcty::DevBuf<uint64_t> d_kset;
     uint64_t kset_cap = 0;
     lcty::DevBuf<double> d_ins_lut;

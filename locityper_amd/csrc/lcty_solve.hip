@@ -37,6 +37,7 @@
 #include <memory>
 #include <numeric>
 #include <thread>
+#include <type_traits>
 
 #include "lcty_objects.hpp"
 
@@ -91,6 +92,11 @@ struct SolveView {
     const uint32_t* ci_off;
     const uint8_t* gc;
     const double* win_weight;
+    // the two factors of a window weight as tables over the counts they are functions of (locus without explicit weights):
+    // win_weight[i] == wk[uniq_cnt[i]] * wc[compl_cnt[i]] bit for bit; wk[n_wk - 1] = 0 stands for "trivial distribution"
+    const uint32_t* uniq_cnt; const uint16_t* compl_cnt;
+    const double* wk; const double* wc;
+    uint32_t n_wk, n_wc;            // 0: no tables (the greedy loop then gathers the weights)
     const double* lut;              // [LCTY_GC_BINS][lut_depth]
     uint32_t lut_depth, lut_shift;  // lut_depth = 1 << lut_shift
     const DepthNB* depth_nb;
@@ -113,6 +119,7 @@ struct SolveView {
     uint32_t* c_totw;               // [n_chains] windows of the chain's genotype (2 + sum of n_windows)
     uint32_t wstride;               // per-chain stride of the window arrays (>= 2 + ploidy * max n_windows)
     double* c_ww;                   // [n_chains][wstride] window weights (0 = trivial distribution)
+    uint32_t* c_uc;                 // [n_chains][wstride] index into wk | index into wc << 16 of the window (with the tables)
     uint8_t* c_gc;                  // [n_chains][wstride]
     uint32_t* c_depth;              // [n_chains][wstride]
     uint32_t* c_nnt;                // [n_chains]
@@ -460,11 +467,12 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
     double* ww = V.c_ww + static_cast<uint64_t>(chain) * V.wstride;
     uint8_t* wgc = V.c_gc + static_cast<uint64_t>(chain) * V.wstride;
+    uint32_t* wuc = V.n_wk ? V.c_uc + static_cast<uint64_t>(chain) * V.wstride : nullptr;
 
     // K12: window distributions (apply_tweak, assgn.rs:140-150)
     for (uint32_t w = tid; w < G.total_w; w += 256) {
         depth[w] = 0;
-        double weight = 0.0; uint32_t g = 0;
+        double weight = 0.0; uint32_t g = 0, uc = V.n_wk - 1;                      // windows 0 and 1 (unmapped / out of region): trivial
         if (w >= 2) {
             uint32_t allele = G.id[0], sh = G.shift[0], rs = G.reg_start[0];
 #pragma unroll
@@ -477,9 +485,11 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
             const uint32_t i = V.ci_off[allele] + (wstart > V.left_padding ? wstart - V.left_padding : 0u);
             weight = V.win_weight[i];
             g = V.gc[i];
-            if (weight < V.min_weight || weight < 1e-7) { weight = 0.0; g = 0; }      // assgn.rs:144-148, distr_cache.rs:84
+            if (wuc) uc = V.uniq_cnt[i] | (static_cast<uint32_t>(V.compl_cnt[i]) << 16);
+            if (weight < V.min_weight || weight < 1e-7) { weight = 0.0; g = 0; uc = V.n_wk - 1; }      // assgn.rs:144-148, distr_cache.rs:84
         }
         ww[w] = weight; wgc[w] = static_cast<uint8_t>(g);
+        if (wuc) wuc[w] = uc;
     }
     __syncthreads();
 
@@ -552,44 +562,115 @@ struct Chain {
         if (d >= V->lut_depth) { atomicMax(V->overflow, 1u); return 0.0; }  // every chain of the batch is repeated
         return weight * V->lut[g * V->lut_depth + d];
     }
-    // depth_lik_diff (assgn.rs:259-284) = sum of atomic_depth_lik_diff (244-254) over the four windows. All operands
-    // are fetched before any of them is used: one LDS round trip, then twelve independent L2 gathers.
-    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {
+    __device__ __forceinline__ double wlp_at(uint32_t w) const { return wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK); }
+    // depth_lik_diff (assgn.rs:259-284) = sum of atomic_depth_lik_diff (244-254) over the four windows, in two halves: `request`
+    // reads the windows' depths (LDS) and ISSUES the twelve gathers (table entry at the old and the new depth, window weight);
+    // `finish` uses them. Between the two a caller can issue further loads: the wait for these twelve then leaves those in flight.
+    struct DepthGather { int32_t c[4]; uint32_t dmax[4]; double weight[4], vnew[4], vold[4]; };
+    __device__ __forceinline__ void request(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, DepthGather& g) const {
         // the change of every window's depth, windows that coincide folded into the first of them (the if-chains of
         // assgn.rs:259-284 written as sums of comparisons: no divergent paths)
         const int32_t e21 = w2 == w1, e31 = w3 == w1, e41 = w4 == w1;
         const int32_t e32 = w3 == w2, e42 = w4 == w2, e43 = w4 == w3;
-        int32_t c[4];
-        c[0] = -1 - e21 + e31 + e41;
-        c[1] = e21 ? 0 : -1 + e32 + e42;
-        c[2] = (e31 | e32) ? 0 : 1 + e43;
-        c[3] = (e41 | e42 | e43) ? 0 : 1;
+        g.c[0] = -1 - e21 + e31 + e41;
+        g.c[1] = e21 ? 0 : -1 + e32 + e42;
+        g.c[2] = (e31 | e32) ? 0 : 1 + e43;
+        g.c[3] = (e41 | e42 | e43) ? 0 : 1;
         const uint32_t w[4] = {w1, w2, w3, w4};
         uint32_t word[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) word[i] = wd[w[i]];
-        double weight[4], vnew[4], vold[4];
-        uint32_t deepest = 0;
         const uint32_t last = V->lut_depth - 1;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t d_old = word[i] & DEPTH_MASK, row = (word[i] >> 25) << V->lut_shift;
-            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + c[i]);
-            weight[i] = ww[w[i]];
-            vnew[i] = V->lut[row + min(d_new, last)];
-            vold[i] = V->lut[row + min(d_old, last)];
-            const bool live = c[i] != 0 && weight[i] != 0.0;                 // c == 0: no change; weight 0: WindowDistr::TRIVIAL
-            deepest = max(deepest, live ? max(d_new, d_old) : 0u);
+            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
+            g.weight[i] = ww[w[i]];
+            g.vnew[i] = V->lut[row + min(d_new, last)];
+            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.dmax[i] = max(d_new, d_old);
         }
+    }
+    __device__ __forceinline__ double finish(const DepthGather& g) const {
+        uint32_t deepest = 0;
         double sum = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const bool live = c[i] != 0 && weight[i] != 0.0;
-            const double term = live ? weight[i] * vnew[i] - weight[i] * vold[i] : 0.0;
+            const bool live = g.c[i] != 0 && g.weight[i] != 0.0;             // c == 0: no change; weight 0: WindowDistr::TRIVIAL
+            deepest = max(deepest, live ? g.dmax[i] : 0u);
+            const double term = live ? g.weight[i] * g.vnew[i] - g.weight[i] * g.vold[i] : 0.0;
             sum = i == 0 ? term : sum + term;
         }
-        if (deepest > last) atomicMax(V->overflow, 1u);                     // every chain of the batch is repeated
+        if (deepest > V->lut_depth - 1) atomicMax(V->overflow, 1u);         // every chain of the batch is repeated
         return sum;
+    }
+    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {
+        DepthGather g;
+        request(w1, w2, w3, w4, g);
+        return finish(g);
+    }
+};
+
+// The same with the window weights in LDS (greedy loop, loci without explicit weights): a window is 6 bytes — depth (23 bit) |
+// index into wk << 23 in a word, GC bin | index into wc << 7 in a half-word — and its weight the product of two LDS table
+// entries, which is how window_weight_kernel made it. Every 8-byte weight gather moved a 128-byte line out of the L2;
+// at 5 000 chains those lines were a quarter of the loop's time.
+constexpr uint32_t LW_DEPTH_BITS = 23, LW_DEPTH_MASK = (1u << LW_DEPTH_BITS) - 1u;      // nine bits for a table index
+struct ChainLW {
+    const SolveView* V;
+    uint32_t* wd;               // LDS: depth | wk index << 23
+    const uint16_t* wh;         // LDS: GC bin | wc index << 7
+    const double* wk; const double* wc;     // LDS
+    using DepthGather = Chain::DepthGather;
+    __device__ __forceinline__ double weight_of(uint32_t word, uint32_t half) const { return wk[word >> LW_DEPTH_BITS] * wc[half >> 7]; }
+    __device__ __forceinline__ double wlp_at(uint32_t w) const {
+        const uint32_t word = wd[w], half = wh[w];
+        const double weight = weight_of(word, half);
+        const uint32_t d = word & LW_DEPTH_MASK;
+        if (weight == 0.0) return 0.0;
+        if (d >= V->lut_depth) { atomicMax(V->overflow, 1u); return 0.0; }
+        return weight * V->lut[(half & 0x7Fu) * V->lut_depth + d];
+    }
+    __device__ __forceinline__ void request(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, DepthGather& g) const {
+        const int32_t e21 = w2 == w1, e31 = w3 == w1, e41 = w4 == w1;
+        const int32_t e32 = w3 == w2, e42 = w4 == w2, e43 = w4 == w3;
+        g.c[0] = -1 - e21 + e31 + e41;
+        g.c[1] = e21 ? 0 : -1 + e32 + e42;
+        g.c[2] = (e31 | e32) ? 0 : 1 + e43;
+        g.c[3] = (e41 | e42 | e43) ? 0 : 1;
+        const uint32_t w[4] = {w1, w2, w3, w4};
+        uint32_t word[4], half[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { word[i] = wd[w[i]]; half[i] = wh[w[i]]; }
+        const uint32_t last = V->lut_depth - 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
+            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
+            g.vnew[i] = V->lut[row + min(d_new, last)];
+            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.dmax[i] = max(d_new, d_old);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) g.weight[i] = weight_of(word[i], half[i]);
+    }
+    __device__ __forceinline__ double finish(const DepthGather& g) const {
+        uint32_t deepest = 0;
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool live = g.c[i] != 0 && g.weight[i] != 0.0;
+            deepest = max(deepest, live ? g.dmax[i] : 0u);
+            const double term = live ? g.weight[i] * g.vnew[i] - g.weight[i] * g.vold[i] : 0.0;
+            sum = i == 0 ? term : sum + term;
+        }
+        if (deepest > V->lut_depth - 1) atomicMax(V->overflow, 1u);
+        return sum;
+    }
+    __device__ __forceinline__ double depth_lik_diff(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4) const {
+        DepthGather g;
+        request(w1, w2, w3, w4, g);
+        return finish(g);
     }
 };
 
@@ -620,8 +701,8 @@ __device__ __forceinline__ void rec_loc(const RecBody& b, const ExtraLoc* extra,
 }
 
 // ReassignmentTarget::random (assgn.rs:451-471) from a generator; uniform over the lanes that share `rng`
-template <typename RNG>
-__device__ __forceinline__ void random_move(const Chain& C, ChainRec* recs, const ExtraLoc* extra, uint32_t nnt, RNG& rng, Move& m) {
+template <typename CHAIN, typename RNG>
+__device__ __forceinline__ void random_move(const CHAIN& C, ChainRec* recs, const ExtraLoc* extra, uint32_t nnt, RNG& rng, Move& m) {
     m.slot = static_cast<uint32_t>(rng.below(nnt));
     const uint32_t packed = load_rp_cur(&recs[m.slot]);
     const RecBody b = load_body(&recs[m.slot]);
@@ -647,82 +728,60 @@ __device__ __forceinline__ double dpp_f64(double x) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// rows of 10 or 12 lanes (six / five chains per wavefront) do not line up with the hardware's rows of 16: their lanes talk
+// through the LDS crossbar, a ring inside the row (lane jj + s modulo LPC; spare lanes behind the last row only read)
 template <uint32_t LPC>
-__device__ __forceinline__ double row_max_f64(double x) {
-    if (LPC == 16) {
+__device__ __forceinline__ double row_max_f64(double x, uint32_t row_base, uint32_t jj) {
+    if constexpr (LPC == 16) {
         x = fmax(x, dpp_f64<0xB1>(x));            // quad_perm [1,0,3,2]
         x = fmax(x, dpp_f64<0x4E>(x));            // quad_perm [2,3,0,1]
         x = fmax(x, dpp_f64<0x141>(x));           // row_half_mirror
         x = fmax(x, dpp_f64<0x140>(x));           // row_mirror
         return x;
+    } else if constexpr ((LPC & (LPC - 1)) == 0) {
+        for (int o = static_cast<int>(LPC) / 2; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+        return x;
+    } else {
+        // after the shifts 1, 2, 4, 8 a lane has seen the 16 >= LPC lanes that follow it on the ring
+#pragma unroll
+        for (uint32_t sft = 1; sft < LPC; sft <<= 1) x = fmax(x, __shfl(x, static_cast<int>(row_base + (jj + sft) % LPC)));
+        return x;
     }
-    for (int o = static_cast<int>(LPC) / 2; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
-    return x;
 }
 template <uint32_t LPC>
-__device__ __forceinline__ double row_sum_f64(double x) {
-    for (int o = static_cast<int>(LPC) / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+__device__ __forceinline__ double row_sum_f64(double x, uint32_t row_base, uint32_t jj) {
+    if constexpr ((LPC & (LPC - 1)) == 0) {
+        for (int o = static_cast<int>(LPC) / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        return x;
+    } else {
+        double total = x;                              // outside the main loop: once per chain
+        for (uint32_t k = 1; k < LPC; k++) total += __shfl(x, static_cast<int>(row_base + (jj + k) % LPC));
+        return total;
+    }
 }
 
 // ---------------- K14 Greedy: 64 / LPC chains per wavefront ----------------
-// hand-shake between the chain wavefront and the prefetch wavefront of a greedy workgroup
-struct GreedyShared {
-    uint64_t rng[4][4];             // the rows' generators when the main loop starts
-    uint32_t nnt[4], go, stop, iter, flagged;
-};
-constexpr uint32_t GREEDY_AHEAD = 4;        // iterations the prefetch wavefront runs ahead of the chains, in batches of four
+// A candidate read of an iteration as its lane sees it: the record, and the first two of its locations beyond the second
+struct GreedyCand { uint32_t pick, rpc; RecBody b; };
+struct GreedyExt { double lp2, lp3; uint32_t win2, win3; };
+constexpr uint32_t GREEDY_INLINE_LOCS = 4;     // locations of a read the pipelined path holds in registers; reads with more take loads
+__device__ __forceinline__ void cand_loc(const RecBody& b, const GreedyExt& e, uint32_t t, double* lp, uint32_t* win) {
+    *lp = t == 0 ? b.lp0 : t == 1 ? b.lp1 : t == 2 ? e.lp2 : e.lp3;
+    *win = t == 0 ? b.win0 : t == 1 ? b.win1 : t == 2 ? e.win2 : e.win3;
+}
 
-template <uint32_t LPC, bool HELPER>
-__global__ __launch_bounds__(HELPER ? 128 : 64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
-    constexpr uint32_t prefetch = HELPER ? 1u : 0u;
+template <uint32_t LPC, bool LW>
+__global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ GreedyShared sh;
     constexpr uint32_t CPW = 64 / LPC;
+    using ChainT = typename std::conditional<LW, ChainLW, Chain>::type;
     // a batch whose initialisation raised a flag (a chain's run of further locations was too short, ...) is repeated by the host:
     // its records are incomplete and must not be followed
-    if (threadIdx.x == 0) {
-        sh.flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh.go = 0; sh.stop = 0; sh.iter = 0;
-    }
-    __syncthreads();
-    if (sh.flagged != 0u) return;
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
     const uint32_t W = V.wstride;
     const uint32_t lane = threadIdx.x & 63u;
-    if (HELPER && (threadIdx.x >> 6) == 1u) {
-        // ---- prefetch wavefront. The random stream of the greedy loop does not depend on the moves, so the records of the coming
-        // iterations are known: this wavefront draws the same picks a few iterations ahead and touches their records (one word
-        // each, thrown away), which brings their lines from HBM into the L2. The chain wavefront's own loads of those records
-        // then take an L2 round trip. Nothing else passes between the two: a missed or stale prefetch costs time, never a result.
-        __syncthreads();                                                     // hand-over of the generators (below)
-        if (prefetch && __hip_atomic_load(&sh.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-            const uint32_t prow = lane / LPC, pjj = lane % LPC;
-            const uint32_t pchain = min(blockIdx.x * CPW + prow, n_chains - 1);
-            const ChainRec* precs = V.recs + static_cast<uint64_t>(pchain) * V.ngp;
-            Xoshiro prng;
-            prng.s0 = sh.rng[prow % 4][0]; prng.s1 = sh.rng[prow % 4][1]; prng.s2 = sh.rng[prow % 4][2]; prng.s3 = sh.rng[prow % 4][3];
-            const uint32_t pn = max(sh.nnt[prow % 4], 1u);
-            const bool pcand = pjj < min(V.solver.sample_size, pn);
-            uint32_t ahead = 0, sink = 0;
-            for (;;) {
-                if (__hip_atomic_load(&sh.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                const uint32_t at = __hip_atomic_load(&sh.iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (ahead >= at + GREEDY_AHEAD) { __builtin_amdgcn_s_sleep(8); continue; }
-                uint32_t v[4];
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const uint64_t key = prng.next();
-                    const uint32_t idx = pcand ? static_cast<uint32_t>(__umul64hi(counter_u64(key, pjj), static_cast<uint64_t>(pn))) : 0u;
-                    v[b] = precs[idx].meta;
-                }
-                sink ^= v[0] ^ v[1] ^ v[2] ^ v[3];
-                ahead += 4;
-            }
-            if (sink == 0x9E3779B9u && ahead == 0xFFFFFFFFu) V.parts[0] = 0.0;       // never true: keeps the loads
-        }
-        return;
-    }
-    const uint32_t row = lane / LPC, jj = lane % LPC, row_base = row * LPC;
+    // lanes behind the last row (LPC 10, 12: lanes 60..63) ride along with it as lanes without a candidate
+    const uint32_t row = min(lane / LPC, CPW - 1), row_base = row * LPC, jj = lane - row_base;
     const uint32_t chain_raw = blockIdx.x * CPW + row;
     const bool live_row = chain_raw < n_chains;
     const uint32_t chain = live_row ? chain_raw : n_chains - 1;                  // a spare row shadows the last chain, without effects
@@ -730,21 +789,35 @@ __global__ __launch_bounds__(HELPER ? 128 : 64) void greedy_loop_kernel(const So
     const uint32_t gi = chain / V.attempts;
     ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
     const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
-    const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
     const uint32_t total_w = V.c_totw[chain];
-    {
-        const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
-        const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
-        for (uint32_t w = jj; w < total_w; w += LPC) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
+    const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
+    const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
+    ChainT C;
+    if constexpr (LW) {
+        // [CPW][W] words, [CPW][W] half-words, then the two weight tables (shared by the rows)
+        uint16_t* wh = reinterpret_cast<uint16_t*>(smem + static_cast<size_t>(CPW) * W * 4) + static_cast<size_t>(row) * W;
+        double* lwk = reinterpret_cast<double*>(smem + ((static_cast<size_t>(CPW) * W * 6 + 7) & ~static_cast<size_t>(7)));
+        double* lwc = lwk + V.n_wk;
+        const uint32_t* guc = V.c_uc + static_cast<uint64_t>(chain) * W;
+        for (uint32_t w = jj; w < total_w && jj < LPC; w += LPC) {
+            const uint32_t uc = guc[w];
+            wd[w] = gd[w] | ((uc & 0xFFFFu) << LW_DEPTH_BITS);
+            wh[w] = static_cast<uint16_t>(ggc[w] | ((uc >> 16) << 7));
+        }
+        for (uint32_t i = lane; i < V.n_wk; i += 64) lwk[i] = V.wk[i];
+        for (uint32_t i = lane; i < V.n_wc; i += 64) lwc[i] = V.wc[i];
+        C = ChainLW{&V, wd, wh, lwk, lwc};
+    } else {
+        for (uint32_t w = jj; w < total_w && jj < LPC; w += LPC) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
+        C = Chain{&V, wd, V.c_ww + static_cast<uint64_t>(chain) * W};
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t nnt = V.c_nnt[chain];
-    Chain C{&V, wd, gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
-    for (uint32_t w = jj; w < total_w; w += LPC) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
-    depth_lik = row_sum_f64<LPC>(depth_lik);
+    for (uint32_t w = jj; w < total_w && jj < LPC; w += LPC) depth_lik += C.wlp_at(w);
+    depth_lik = row_sum_f64<LPC>(depth_lik, row_base, jj);
     double aln_lik = V.c_aln[chain];
     Xoshiro rng; rng.seed(V.seeds[chain]);
     uint64_t n_iter = 0, n_acc = 0;
@@ -752,8 +825,6 @@ __global__ __launch_bounds__(HELPER ? 128 : 64) void greedy_loop_kernel(const So
     double depth_mine = 0.0, aln_mine = 0.0;                                     // likelihood changes of the moves this lane applied
 
     bool done = nnt == 0 || !live_row;
-    bool handed_over = false;
-    uint32_t wave_iter = 0;
     if (__any(!done)) {
         const uint32_t nnt1 = max(nnt, 1u);
         const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
@@ -768,27 +839,27 @@ __global__ __launch_bounds__(HELPER ? 128 : 64) void greedy_loop_kernel(const So
         }
         const double min_diff = fmax(1e-10 * max_abs, 1e-14);                 // minimum_allowed_diff (stoch.rs:27-29)
         // Greedy::solve_nontrivial (stoch.rs:81-120). Lane jj of the row evaluates the jj-th read of the iteration's sample.
-        // The random stream does not depend on what the moves do, so the records of an iteration are requested two iterations
-        // ahead (stages A = this iteration, B, C); a move that changes the current location of a read that is already
-        // in flight patches it there.
+        //
+        // The random stream does not depend on what the moves do, so the records an iteration will look at are known ahead: the
+        // loop is a software pipeline over three record slots. Iteration i, in program order:
+        //   1. its candidates are in registers (record of slot i, its further locations): depths from LDS, then ISSUE the
+        //      gathers of the table entries and window weights (twelve per alternative location);
+        //   2. ISSUE the further locations of iteration i + 1's candidates (their records arrived an iteration ago);
+        //   3. draw the sample of iteration i + 3 and ISSUE its record loads;
+        //   4. wait for the gathers of step 1 only — the vector-memory counter is in order, everything issued in 2 and 3 is
+        //      younger and stays in flight — score, pick the row's best, apply the move.
+        // A record therefore has three iterations to come from HBM, and an iteration waits for one L2 round trip.
+        // A move changes the current location of one read; the records of the next three iterations were requested before
+        // it: the last three moves are kept and applied to a record when it is used.
         const uint32_t S = min(V.solver.sample_size, nnt1);
         const bool cand = jj < S;
-        struct Stage { uint32_t pick, rpc; RecBody b; };      // rpc: the record's rp_cur word, patched while in flight
-        // the prefetch wavefront takes the generators from here
-        if (jj == 0) {
-            sh.rng[row % 4][0] = rng.s0; sh.rng[row % 4][1] = rng.s1; sh.rng[row % 4][2] = rng.s2; sh.rng[row % 4][3] = rng.s3;
-            sh.nnt[row % 4] = nnt;
-        }
-        __hip_atomic_store(&sh.go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        handed_over = true;
-        if (HELPER) __syncthreads();
         auto sample = [&]() -> uint32_t {
             // non_trivial_reads.sample(rng, S): one draw of the chain's generator as a key, the S picks as counter draws under it,
             // repeats skipped (our adaptor, oracle/lcty_oracle.h). A sample almost never repeats an index (S^2 / 2 nnt)
             const uint64_t key = rng.next();
             uint32_t idx = cand ? static_cast<uint32_t>(__umul64hi(counter_u64(key, jj), static_cast<uint64_t>(nnt1))) : 0xFFFFFFFFu - jj;
             bool dup = false;
-            if (LPC == 16) {
+            if constexpr (LPC == 16) {
                 // every unordered pair of the row meets in one of eight rotations
                 const int v = static_cast<int>(idx);
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false) == v;
@@ -827,54 +898,105 @@ __global__ __launch_bounds__(HELPER ? 128 : 64) void greedy_loop_kernel(const So
             }
             return idx;
         };
-        auto request = [&](Stage& s) {
-            s.pick = sample();
-            const uint32_t slot = cand ? s.pick : 0u;
-            s.rpc = load_rp_cur(&recs[slot]);
-            s.b = load_body(&recs[slot]);
+        // Loads that stay in flight across iterations are issued field by field (relaxed atomic loads: the compiler neither
+        // merges nor splits them). A merged 12- or 16-byte load comes back as a register tuple, and a tuple whose parts live
+        // on for different lengths gets copied apart by the register allocator right after the load — which waits for it.
+        auto field32 = [](const void* p, uint32_t byte_off) -> uint32_t {
+            return __hip_atomic_load(reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p) + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        };
+        auto field64 = [](const void* p, uint32_t byte_off) -> double {
+            return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+                reinterpret_cast<const unsigned long long*>(static_cast<const uint8_t*>(p) + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)));
+        };
+        auto request_record = [&](GreedyCand& c) {
+            c.pick = sample();
+            const ChainRec* r = &recs[cand ? c.pick : 0u];
+            c.rpc = load_rp_cur(r);
+            c.b.meta = field32(r, 4); c.b.lp0 = field64(r, 8); c.b.lp1 = field64(r, 16); c.b.win0 = field32(r, 24); c.b.win1 = field32(r, 28);
+        };
+        // the first two further locations of a record that has arrived (reads with two locations: the chain's first entry, unused)
+        auto request_ext = [&](const GreedyCand& c, GreedyExt& e) {
+            const uint32_t nloc = c.b.meta & 0xFFu;
+            const ExtraLoc* p = extra + (cand && nloc > 2 ? (c.b.meta >> 8) : 0u);   // the run has spare entries behind it
+            e.lp2 = field64(p, 0); e.win2 = field32(p, 8); e.lp3 = field64(p, 16); e.win3 = field32(p, 24);
         };
         uint32_t curr_plato = 0;
         uint64_t iter = 0;
-        // one iteration of every row of the wavefront: the records of the next iteration are requested first (L2-warm thanks to the
-        // prefetch wavefront), then this iteration's candidates are scored while they arrive
-        Stage sA, sB;
-        request(sA);
-        while (__any(!done)) {
-            request(sB);                                                       // the next iteration's records: in flight while this one is scored
-            // best_read_improvement (assgn.rs:287-317), one candidate read per lane
-            const uint32_t nloc = sA.b.meta & 0xFFu;
-            double cur_lp; uint32_t cur_w;
-            const uint32_t cur = sA.rpc >> 24;
+        // the last three moves of the row, newest first (slot 0xFFFFFFFF: none)
+        uint32_t h1s = 0xFFFFFFFFu, h1t = 0, h2s = 0xFFFFFFFFu, h2t = 0, h3s = 0xFFFFFFFFu, h3t = 0;
+
+        // one iteration: A = its candidates (arrived), EA their further locations (arrived); N = the candidates of the next
+        // iteration (arrived), EN receives their further locations; F = the slot the sample three iterations ahead goes to (= A's)
+        auto iteration = [&](GreedyCand& A, const GreedyExt& EA, const GreedyCand& N, GreedyExt& EN) {
+            const RecBody b = A.b;
+            const uint32_t pick = A.pick, rpc0 = A.rpc;
+            const uint32_t nloc = b.meta & 0xFFu;
+            uint32_t cur = rpc0 >> 24;
+            cur = pick == h3s ? h3t : cur; cur = pick == h2s ? h2t : cur; cur = pick == h1s ? h1t : cur;
             // lanes without a candidate (beyond the sample, rows that are done or spare) look at window 0 four times: no change, no effect
             const uint32_t n_alt = (cand && !done) ? nloc - 1 : 0u;
-            if (n_alt) rec_loc(sA.b, extra, cur, &cur_lp, &cur_w); else { cur_lp = 0.0; cur_w = 0; }
+            const bool deep = n_alt != 0 && nloc > GREEDY_INLINE_LOCS;           // some locations of this read are not in registers
+            double cur_lp = 0.0; uint32_t cur_w = 0;
+            if (n_alt) cand_loc(b, EA, min(cur, GREEDY_INLINE_LOCS - 1), &cur_lp, &cur_w);
+            if (__any(deep && cur >= GREEDY_INLINE_LOCS)) {                      // rare: the current location itself is beyond the fourth
+                if (deep && cur >= GREEDY_INLINE_LOCS) rec_loc(b, extra, cur, &cur_lp, &cur_w);
+                asm volatile("" : "+v"(cur_lp), "+v"(cur_w));                     // the wait for this load stays inside the rare branch
+            }
             const uint32_t w1 = cur_w & 0xFFFFu, w2 = cur_w >> 16;
+            // up to three alternatives per lane, all requested before any is used
+            constexpr uint32_t NA = GREEDY_INLINE_LOCS - 1;
+            double lp_t[NA]; uint32_t win_t[NA], t_of[NA];
+            typename ChainT::DepthGather g[NA];
+#pragma unroll
+            for (uint32_t u = 0; u < NA; u++) {
+                const bool has = u < n_alt && !(deep && u + (u >= cur ? 1u : 0u) >= GREEDY_INLINE_LOCS);
+                t_of[u] = u + (u >= cur ? 1u : 0u);
+                lp_t[u] = 0.0; win_t[u] = 0;
+                if (u == 0 || __any(has)) {
+                    if (has) cand_loc(b, EA, t_of[u], &lp_t[u], &win_t[u]);
+                    const bool on = has;
+                    C.request(on ? w1 : 0u, on ? w2 : 0u, on ? (win_t[u] & 0xFFFFu) : 0u, on ? (win_t[u] >> 16) : 0u, g[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            request_ext(N, EN);
+            __builtin_amdgcn_sched_barrier(0);
+            request_record(A);                                                  // A's registers have been read: the slot takes the sample of i + 3
+            __builtin_amdgcn_sched_barrier(0);
+            // best_read_improvement (assgn.rs:287-317): the alternatives in order, a later one only when strictly better
             double best_improv = -INFINITY, lp_new = 0.0, ddiff = 0.0;
             uint32_t new_assgn = 0, w3 = 0, w4 = 0;
-            // first alternative of every lane together
-            {
-                double lp_t = 0.0; uint32_t win_t = 0;
-                const uint32_t t = cur == 0 ? 1u : 0u;
-                if (n_alt) rec_loc(sA.b, extra, t, &lp_t, &win_t);
-                const uint32_t a3 = win_t & 0xFFFFu, a4 = win_t >> 16;
-                const double dd = C.depth_lik_diff(w1, w2, a3, a4);
-                const double improv = lp_t + rel_contrib * dd;
-                if (n_alt) { best_improv = improv; new_assgn = t; w3 = a3; w4 = a4; lp_new = lp_t; ddiff = dd; }
+#pragma unroll
+            for (uint32_t u = 0; u < NA; u++) {
+                const bool has = u < n_alt && !(deep && t_of[u] >= GREEDY_INLINE_LOCS);
+                if (u == 0 || __any(has)) {
+                    const double dd = C.finish(g[u]);
+                    const double improv = lp_t[u] + rel_contrib * dd;
+                    if (has && (u == 0 || improv > best_improv)) {
+                        best_improv = improv; new_assgn = t_of[u]; w3 = win_t[u] & 0xFFFFu; w4 = win_t[u] >> 16; lp_new = lp_t[u]; ddiff = dd;
+                    }
+                }
             }
-            for (uint32_t u = 1; __any(u < n_alt); u++) {                       // reads with more than two locations
-                if (u < n_alt) {
+            if (__any(deep)) {
+                // reads with more than four locations: the ones beyond the fourth from the chain's run, one at a time, in their place
+                // in the order (a read's alternatives are visited by ascending location; those in registers may come after these
+                // only when the current location is beyond the fourth — then none of the inline ones was skipped)
+                for (uint32_t u = 0; __any(deep && u < n_alt); u++) {
                     const uint32_t t = u + (u >= cur ? 1u : 0u);
-                    double lp_t; uint32_t win_t;
-                    rec_loc(sA.b, extra, t, &lp_t, &win_t);
-                    const uint32_t a3 = win_t & 0xFFFFu, a4 = win_t >> 16;
-                    const double dd = C.depth_lik_diff(w1, w2, a3, a4);
-                    const double improv = lp_t + rel_contrib * dd;
-                    if (improv > best_improv) { best_improv = improv; new_assgn = t; w3 = a3; w4 = a4; lp_new = lp_t; ddiff = dd; }
+                    if (deep && u < n_alt && (u >= NA || t >= GREEDY_INLINE_LOCS)) {
+                        double lp_u; uint32_t win_u;
+                        rec_loc(b, extra, t, &lp_u, &win_u);
+                        const uint32_t a3 = win_u & 0xFFFFu, a4 = win_u >> 16;
+                        const double dd = C.depth_lik_diff(w1, w2, a3, a4);
+                        const double improv = lp_u + rel_contrib * dd;
+                        // alternatives arrive in ascending u here as in the unrolled part: the inline ones have u < NA and t < 4
+                        if (improv > best_improv) { best_improv = improv; new_assgn = t; w3 = a3; w4 = a4; lp_new = lp_u; ddiff = dd; }
+                    }
                 }
             }
             const double my_improv = n_alt ? V.aln_contrib * (best_improv - cur_lp) : -INFINITY;
             // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
-            const double best = row_max_f64<LPC>(my_improv);
+            const double best = row_max_f64<LPC>(my_improv, row_base, jj);
             const unsigned long long who = __ballot(n_alt && my_improv == best);
             const unsigned long long who_row = (who >> row_base) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63u)) - 1ull));
             const uint32_t src = who_row ? static_cast<uint32_t>(__ffsll(static_cast<long long>(who_row))) - 1u : 0u;
@@ -884,33 +1006,39 @@ __global__ __launch_bounds__(HELPER ? 128 : 64) void greedy_loop_kernel(const So
             if (moved && jj == src) {
                 atomicAdd(&wd[w3], 1u); atomicAdd(&wd[w4], 1u);                   // the depth field never borrows from the GC bits
                 atomicSub(&wd[w1], 1u); atomicSub(&wd[w2], 1u);
-                store_rp_cur(&recs[sA.pick], (sA.rpc & 0xFFFFFFu) | (new_assgn << 24));
+                store_rp_cur(&recs[pick], (rpc0 & 0xFFFFFFu) | (new_assgn << 24));
                 depth_mine += ddiff;
                 aln_mine += lp_new - cur_lp;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t moved_slot = static_cast<uint32_t>(__shfl(static_cast<int>(sA.pick), static_cast<int>(row_base + src)));
+            const uint32_t moved_slot = static_cast<uint32_t>(__shfl(static_cast<int>(pick), static_cast<int>(row_base + src)));
             const uint32_t moved_to = static_cast<uint32_t>(__shfl(static_cast<int>(new_assgn), static_cast<int>(row_base + src)));
+            h3s = h2s; h3t = h2t; h2s = h1s; h2t = h1t;
+            h1s = moved ? moved_slot : 0xFFFFFFFFu; h1t = moved_to;
             if (!done) {
                 n_iter++; iter++;
-                if (moved) {
-                    n_acc++; curr_plato = 0;
-                    if (sB.pick == moved_slot) sB.rpc = (sB.rpc & 0xFFFFFFu) | (moved_to << 24);   // the same read may come up again while it is in flight
-                } else {
+                if (moved) { n_acc++; curr_plato = 0; }
+                else {
                     curr_plato++;
                     if (curr_plato > V.solver.plato_size) done = true;
                 }
                 if (iter >= max_iter) done = true;
             }
-            // pace of the prefetch wavefront: the iterations the rows of this wavefront have been through
-            if (lane == 0) __hip_atomic_store(&sh.iter, static_cast<uint32_t>(++wave_iter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            sA = sB;
+        };
+        GreedyCand R0, R1, R2;
+        GreedyExt E0, E1, E2;
+        request_record(R0); request_record(R1); request_record(R2);
+        request_ext(R0, E0);
+        while (__any(!done)) {
+            iteration(R0, E0, R1, E1);
+            if (!__any(!done)) break;
+            iteration(R1, E1, R2, E2);
+            if (!__any(!done)) break;
+            iteration(R2, E2, R0, E0);
         }
     }
-    if (HELPER && !handed_over) __syncthreads();                         // the prefetch wavefront waits for exactly one hand-over
-    __hip_atomic_store(&sh.stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    depth_mine = row_sum_f64<LPC>(depth_mine); aln_mine = row_sum_f64<LPC>(aln_mine);
+    depth_mine = row_sum_f64<LPC>(depth_mine, row_base, jj); aln_mine = row_sum_f64<LPC>(aln_mine, row_base, jj);
     depth_lik += depth_mine; aln_lik += aln_mine;
     if (jj == 0 && live_row) {
         const double lik = V.depth_contrib * depth_lik + V.aln_contrib * aln_lik;       // assgn.rs:235-237
@@ -1362,15 +1490,20 @@ void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_ini
     LCTY_HIP(hipGetLastError());
 }
 
-template <uint32_t LPC, bool HELPER>
+// LDS of a greedy workgroup: the rows' windows (4 bytes each; 6 with the weights in LDS, plus the two weight tables)
+inline size_t greedy_lds(uint32_t lpc, const SolveView& V, bool lw) {
+    const size_t rows = static_cast<size_t>(64 / lpc) * V.wstride;
+    return lw ? ((rows * 6 + 7) & ~static_cast<size_t>(7)) + static_cast<size_t>(V.n_wk + V.n_wc) * 8 : rows * 4;
+}
+template <uint32_t LPC, bool LW>
 void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
     constexpr uint32_t CPW = 64 / LPC;
-    const size_t lds = static_cast<size_t>(CPW) * V.wstride * 4;
+    const size_t lds = greedy_lds(LPC, V, LW);
     if (lds > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC, HELPER>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC, LW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
     ctx->timed(LCTY_K_SOLVE, [&] {
-        hipLaunchKernelGGL((greedy_loop_kernel<LPC, HELPER>), dim3((nch + CPW - 1) / CPW), dim3(HELPER ? 128 : 64), lds, s, V, nch);
+        hipLaunchKernelGGL((greedy_loop_kernel<LPC, LW>), dim3((nch + CPW - 1) / CPW), dim3(64), lds, s, V, nch);
     }, s);
     LCTY_HIP(hipGetLastError());
 }
@@ -1436,6 +1569,10 @@ struct StageRunner {
         V.depth_contrib = 1.0 + loc->prm.lik_skew; V.aln_contrib = 1.0 - loc->prm.lik_skew;      // assgn.rs:80-81
         V.n_windows = loc->d_n_windows.p; V.reg_start = loc->d_reg_start.p; V.allele_len = loc->d_allele_len.p;
         V.ci_off = loc->d_ci_off.p; V.gc = loc->d_gc.p; V.win_weight = loc->d_win_weight.p;
+        V.uniq_cnt = loc->d_uniq_cnt.p; V.compl_cnt = loc->d_compl_cnt.p;
+        const bool tables = loc->weight_tables_valid && !loc->has_explicit;
+        V.wk = tables ? loc->d_wk.p : nullptr; V.wc = tables ? loc->d_wc.p : nullptr;
+        V.n_wk = tables ? static_cast<uint32_t>(loc->d_wk.n) : 0u; V.n_wc = tables ? static_cast<uint32_t>(loc->d_wc.n) : 0u;
         V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
         V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p; V.row_of = nullptr;
@@ -1472,7 +1609,7 @@ struct StageRunner {
     // chains are processed in batches so that the per-chain state (32 B per good read + the run of further locations) fits the device
     void plan_batches() {
         const uint64_t ngp = V.ngp;
-        const uint64_t per_chain = ngp * sizeof(ChainRec) + static_cast<uint64_t>(ws.extra_cap) * sizeof(ExtraLoc) + static_cast<uint64_t>(V.wstride) * 17 + 64;
+        const uint64_t per_chain = ngp * sizeof(ChainRec) + static_cast<uint64_t>(ws.extra_cap) * sizeof(ExtraLoc) + static_cast<uint64_t>(V.wstride) * 21 + 64;
         size_t free_b = 0, total_b = 0;
         LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
         const uint64_t held = ws.recs.n * sizeof(ChainRec) + ws.extra.n * sizeof(ExtraLoc);      // what this workspace already owns counts as free
@@ -1483,18 +1620,19 @@ struct StageRunner {
         const uint64_t max_chains = gt_per_batch * attempts;
         hipStream_t s = stream;
         ws.ovf.ensure(2); ws.ovf.zero(s);
-        if (ws.recs.n < max_chains * ngp || ws.extra.n < max_chains * ws.extra_cap) {
+        if (ws.recs.n < max_chains * ngp || ws.extra.n < max_chains * ws.extra_cap + 2) {
             // both at once, the old ones released first: the two together are most of the device
             ws.recs.release(); ws.extra.release();
-            ws.recs.alloc(max_chains * ngp); ws.extra.alloc(std::max<uint64_t>(max_chains * ws.extra_cap, 1));
+            ws.recs.alloc(max_chains * ngp); ws.extra.alloc(max_chains * ws.extra_cap + 2);     // two spare entries: the greedy loop reads a pair per record
         }
         ws.cww.ensure(max_chains * V.wstride); ws.cgc.ensure(max_chains * V.wstride); ws.cdepth.ensure(max_chains * V.wstride);
+        ws.cuc.ensure(max_chains * V.wstride);
         ws.cnnt.ensure(max_chains); ws.ctotw.ensure(max_chains); ws.caln.ensure(max_chains);
         ws.gt.ensure(gt_per_batch * ploidy); ws.seeds.ensure(max_chains); ws.liks.ensure(max_chains); ws.parts.ensure(4 * max_chains);
         ws.pri.ensure(gt_per_batch);
         V.genotypes = ws.gt.p; V.seeds = ws.seeds.p; V.priors = nullptr;
         V.recs = ws.recs.p; V.extra = ws.extra.p; V.extra_cap = ws.extra_cap; V.liks = ws.liks.p; V.parts = ws.parts.p;
-        V.c_ww = ws.cww.p; V.c_gc = ws.cgc.p; V.c_depth = ws.cdepth.p; V.c_nnt = ws.cnnt.p; V.c_totw = ws.ctotw.p; V.c_aln = ws.caln.p;
+        V.c_ww = ws.cww.p; V.c_uc = ws.cuc.p; V.c_gc = ws.cgc.p; V.c_depth = ws.cdepth.p; V.c_nnt = ws.cnnt.p; V.c_totw = ws.ctotw.p; V.c_aln = ws.caln.p;
     }
 
     void upload_genotypes(const uint16_t* genotypes, uint64_t ng) { ws.gt.upload(genotypes, ng * ploidy, stream); }
@@ -1507,16 +1645,36 @@ struct StageRunner {
             default: launch_init<4>(ctx, V, nch, lds_init, stream); break;
         }
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) { launch_anneal(ctx, V, nch, stream); return; }
-        // lanes per chain: a row of 16 holds the default sample of 10; 64 / LPC chains share a wavefront (and its LDS: 4 B per window and chain)
-        uint32_t lpc = V.solver.sample_size <= 16 ? 16 : V.solver.sample_size <= 32 ? 32 : 64;
+        // Lanes per chain. The loop is bound by instruction issue — a wavefront-iteration costs the same whatever its number of busy
+        // lanes — and at its register count one wavefront fits a SIMD: the chains of a stage should make at most one wavefront per
+        // SIMD. A row of 16 lanes (the hardware's DPP rows: cheapest row operations) holds the default sample of 10 with four
+        // chains per wavefront; when that makes more wavefronts than SIMDs, rows of 12 or 10 lanes put five or six chains into one.
+        const uint32_t S = V.solver.sample_size;
+        const uint64_t simds = 4ull * static_cast<uint64_t>(ctx->props.multiProcessorCount);
+        uint32_t lpc = S <= 16 ? 16 : S <= 32 ? 32 : 64;
+        if (lpc == 16 && (nch + 3) / 4 > simds) {
+            if (S <= 12 && (nch + 4) / 5 <= simds) lpc = 12;
+            else if (S <= 10) lpc = 10;
+            else if (S <= 12) lpc = 12;
+        }
         const int64_t want = ctx->knob("solve_chains_per_wave", 0);
-        if (want > 0) lpc = std::max<uint32_t>(lpc, static_cast<uint32_t>(64 / std::min<int64_t>(want, 4)));
-        while (lpc < 64 && static_cast<size_t>(64 / lpc) * V.wstride * 4 > 64 * 1024) lpc *= 2;      // keep a few wavefronts per CU
-        // the prefetch wavefront pays while the device has room (measured: +10 % at 256 chains, -3 % at 5 000)
-        const bool helper = ctx->knob("solve_prefetch", static_cast<uint64_t>(nch) * lpc / 64 < 1024 ? 1 : 0) != 0;
-        if (lpc == 16) { if (helper) launch_greedy<16, true>(ctx, V, nch, stream); else launch_greedy<16, false>(ctx, V, nch, stream); }
-        else if (lpc == 32) { if (helper) launch_greedy<32, true>(ctx, V, nch, stream); else launch_greedy<32, false>(ctx, V, nch, stream); }
-        else { if (helper) launch_greedy<64, true>(ctx, V, nch, stream); else launch_greedy<64, false>(ctx, V, nch, stream); }
+        if (want > 0) {                                                        // lcty_ctx_set_knob: 1, 2, 4, 5, 6 chains per wavefront
+            const uint32_t forced = want >= 6 ? 10u : want == 5 ? 12u : static_cast<uint32_t>(64 / std::min<int64_t>(want, 4));
+            if (forced >= S) lpc = forced;
+        }
+        // window weights from LDS tables when the locus has them (no explicit weights, counts within the index bits) and the
+        // depths fit their field; lcty_ctx_set_knob "solve_lds_weights" 0 keeps the gathers
+        const bool lw = V.n_wk != 0 && 2 * static_cast<uint64_t>(V.n_good) + 2 <= LW_DEPTH_MASK && ctx->knob("solve_lds_weights", 1) != 0;
+        while (lpc < 64 && greedy_lds(lpc, V, lw) > 64 * 1024) lpc = lpc < 16 ? 16 : lpc * 2;      // the rows' windows share the LDS
+        auto go = [&](auto tag) {
+            constexpr uint32_t L = decltype(tag)::value;
+            if (lw) launch_greedy<L, true>(ctx, V, nch, stream); else launch_greedy<L, false>(ctx, V, nch, stream);
+        };
+        if (lpc == 10) go(std::integral_constant<uint32_t, 10>{});
+        else if (lpc == 12) go(std::integral_constant<uint32_t, 12>{});
+        else if (lpc == 16) go(std::integral_constant<uint32_t, 16>{});
+        else if (lpc == 32) go(std::integral_constant<uint32_t, 32>{});
+        else go(std::integral_constant<uint32_t, 64>{});
     }
 
     template <typename F>

@@ -1,10 +1,11 @@
 #!/bin/bash
-# what a random 32-byte gather costs: footprint x wavefronts x gathers in flight (scripts/probes/gather_probe.hip)
+# what a random 32-byte gather costs: footprint x wavefronts x gathers in flight (scripts/gather_probe.hip)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
 V=${1:-r2n}
-P=scripts/probes/gather_probe
+hipcc -O3 --offload-arch=gfx950 -o /tmp/gather_probe scripts/gather_probe.hip
+P=/tmp/gather_probe
 {
 for gb in 1 8 40 148; do
   timeout 120 $P $gb 64 40 1 20000

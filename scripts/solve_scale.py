@@ -2,7 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from locityper_amd import api, synth, cdefs
+from locityper_amd import api, synth, cdefs, _lib
+if os.environ.get("LCTY_EXPERIMENT_LIB"):              # developer experiments only (scripts/build_solve_experiments.sh)
+    _lib.LIB_PATH = os.environ["LCTY_EXPERIMENT_LIB"]
 
 def main():
     A = int(sys.argv[1]); pairs = int(sys.argv[2]); chains = [int(x) for x in sys.argv[3].split(",")]
@@ -25,7 +27,8 @@ def main():
     order = np.argsort(-sc, kind="stable")
     print(f"A={A} pairs={pairs} n_good={aa.n_good()} max n_windows={max(loc.contig_info(a)[3] for a in range(min(A,4)))}", flush=True)
     cpws = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
-    if len(sys.argv) > 6: ctx.set_knob("solve_prefetch", int(sys.argv[6]))
+    if len(sys.argv) > 6: ctx.set_knob("solve_lds_weights", int(sys.argv[6]))
+    ctx.set_knob("solve_stats", 1)
     api.solve_stage(aa, gts[order[:max(chains)]], api.default_solver(cdefs.SOLVER_GREEDY), 1, api.chain_seeds(7, max(chains)))   # warm-up: tables, workspace
     for kind, name in ((cdefs.SOLVER_GREEDY, "g"), (cdefs.SOLVER_ANNEAL, "a")):
         if name not in kinds: continue

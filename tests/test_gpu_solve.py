@@ -309,13 +309,14 @@ def test_library_scheme_driver_equals_the_composed_calls(gpu_ctx):
 
 def test_chains_per_wavefront_and_wide_samples_do_not_change_results(gpu_ctx):
     """The greedy kernel puts 64 / LPC chains into a wavefront (LPC = 16 lanes per chain for samples of up to 16 reads, 32 and 64
-    beyond): every layout must give the chains of the oracle, including a last wavefront with spare rows."""
+    beyond; rows of 12 or 10 lanes — five or six chains — when a stage has more chains than four per SIMD of the device): every
+    layout must give the chains of the oracle, including a last wavefront with spare rows and the spare lanes behind the last row."""
     L, p, loc, aa, ol, oa = setup(gpu_ctx, 8, 4000, 20000)
     gts = api.generate_genotypes(8, 2)[:13]                              # 13 chains x 2 attempts = 26: not a multiple of 4
     seeds = api.chain_seeds(77, 26)
     g = api.default_solver(cdefs.SOLVER_GREEDY)
     ref = compare_stage(aa, ol, oa, gts, g, 2, seeds)
-    for cpw in (1, 2, 4):
+    for cpw in (1, 2, 4, 5, 6):
         gpu_ctx.set_knob("solve_chains_per_wave", cpw)
         try:
             got = api.solve_stage(aa, gts, g, 2, seeds)
@@ -327,6 +328,22 @@ def test_chains_per_wavefront_and_wide_samples_do_not_change_results(gpu_ctx):
         g2 = api.default_solver(cdefs.SOLVER_GREEDY)
         g2.sample_size = sample
         compare_stage(aa, ol, oa, gts[:5], g2, 2, seeds[:10])
+    # window weights from the LDS tables (default) and gathered from the chains' rows: the same arithmetic, the same bits
+    gpu_ctx.set_knob("solve_lds_weights", 0)
+    try:
+        gathered = api.solve_stage(aa, gts, g, 2, seeds)
+    finally:
+        gpu_ctx.set_knob("solve_lds_weights", -1)
+    assert np.array_equal(gathered[2], api.solve_stage(aa, gts, g, 2, seeds)[2])
+    # rows of 12 and 10 lanes against the oracle directly, with samples that fill them and samples that do not
+    for cpw, sample in ((5, 12), (5, 7), (6, 10), (6, 3), (6, 12)):          # the last: a sample of 12 does not fit a row of 10 -> rows of 16
+        g3 = api.default_solver(cdefs.SOLVER_GREEDY)
+        g3.sample_size = sample
+        gpu_ctx.set_knob("solve_chains_per_wave", cpw)
+        try:
+            compare_stage(aa, ol, oa, gts, g3, 2, seeds)
+        finally:
+            gpu_ctx.set_knob("solve_chains_per_wave", -1)
 
 
 def test_reads_with_many_locations_and_the_growth_of_their_runs(gpu_ctx):
