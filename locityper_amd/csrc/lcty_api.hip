@@ -41,7 +41,7 @@ int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value) {
     return guarded([&] {
         if (!ctx || !name) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         static const char* const known[] = {"transfer_levels", "transfer_scratch_mb", "transfer_waves", "transfer_cap_new", "transfer_arena",
-                                            "depth_table_start", "solve_budget_mb", "solve_stats", "solve_chains_per_wave", "solve_extra_start", "solve_lds_weights", "gather_chunk_mb", nullptr};
+                                            "depth_table_start", "solve_budget_mb", "solve_stats", "solve_chains_per_wave", "solve_extra_start", "solve_lds_weights", "anneal_lds_weights", "gather_chunk_mb", nullptr};
         bool ok = false;
         for (const char* const* k = known; *k; k++) ok |= strcmp(*k, name) == 0;
         if (!ok) fail(LCTY_ERR_INVALID_INPUT, "unknown knob '%s'", name);
@@ -82,6 +82,7 @@ void lcty_ctx_destroy(lcty_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->gate.ev) (void)hipEventDestroy(ctx->gate.ev);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

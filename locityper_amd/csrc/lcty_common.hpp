@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -153,6 +154,16 @@ struct lcty_ctx {
     // Second stream of the context: the last solver stage of a locus (a few long serial chains) runs here while the next
     // locus of a queue is scored, prefiltered and greedily solved on `stream` (lcty_solve_queue).
     hipStream_t side = nullptr;
+    // Order of residence in a queue of loci (lcty_solve_queue): the annealing chains of locus i (side stream) are launched when the
+    // greedy chains of locus i + 1 are on the device — the greedy workgroups take the LDS and registers they need and the few
+    // annealing workgroups fill the gaps; the other way round the annealing wavefronts, one per SIMD, keep a second greedy
+    // wavefront from every SIMD they sit on and a part of the greedy stage waits for a second round.
+    struct LaunchGate {
+        std::mutex m; std::condition_variable cv;
+        uint64_t epoch = 0;             // greedy launches announced so far (or released by the queue)
+        uint64_t target = 0;            // what the running tail waits for (0: nothing)
+        hipEvent_t ev = nullptr;        // recorded on the main stream just before the greedy loop is launched
+    } gate;
     hipStream_t side_stream() {
         if (!side) LCTY_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
         return side;

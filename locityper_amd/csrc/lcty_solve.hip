@@ -770,22 +770,27 @@ __device__ __forceinline__ void cand_loc(const RecBody& b, const GreedyExt& e, u
     *win = t == 0 ? b.win0 : t == 1 ? b.win1 : t == 2 ? e.win2 : e.win3;
 }
 
+// With the weights in LDS a workgroup is two wavefronts that share the two tables (nothing else: after one barrier they run apart)
 template <uint32_t LPC, bool LW>
-__global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
+__global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
     extern __shared__ __align__(16) uint8_t smem[];
-    constexpr uint32_t CPW = 64 / LPC;
+    __shared__ uint32_t flagged;
+    constexpr uint32_t CPW = 64 / LPC, WAVES = LW ? 2u : 1u, ROWS = CPW * WAVES;
     using ChainT = typename std::conditional<LW, ChainLW, Chain>::type;
     // a batch whose initialisation raised a flag (a chain's run of further locations was too short, ...) is repeated by the host:
     // its records are incomplete and must not be followed
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
+    if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flagged != 0u) return;
     const uint32_t W = V.wstride;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // lanes behind the last row (LPC 10, 12: lanes 60..63) ride along with it as lanes without a candidate
     const uint32_t row = min(lane / LPC, CPW - 1), row_base = row * LPC, jj = lane - row_base;
-    const uint32_t chain_raw = blockIdx.x * CPW + row;
+    const uint32_t wg_row = wave * CPW + row;
+    const uint32_t chain_raw = blockIdx.x * ROWS + wg_row;
     const bool live_row = chain_raw < n_chains;
     const uint32_t chain = live_row ? chain_raw : n_chains - 1;                  // a spare row shadows the last chain, without effects
-    uint32_t* wd = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(row) * W;
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(wg_row) * W;
     const uint32_t gi = chain / V.attempts;
     ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
     const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
@@ -794,9 +799,9 @@ __global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, cons
     const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
     ChainT C;
     if constexpr (LW) {
-        // [CPW][W] words, [CPW][W] half-words, then the two weight tables (shared by the rows)
-        uint16_t* wh = reinterpret_cast<uint16_t*>(smem + static_cast<size_t>(CPW) * W * 4) + static_cast<size_t>(row) * W;
-        double* lwk = reinterpret_cast<double*>(smem + ((static_cast<size_t>(CPW) * W * 6 + 7) & ~static_cast<size_t>(7)));
+        // [ROWS][W] words, [ROWS][W] half-words, then the two weight tables
+        uint16_t* wh = reinterpret_cast<uint16_t*>(smem + static_cast<size_t>(ROWS) * W * 4) + static_cast<size_t>(wg_row) * W;
+        double* lwk = reinterpret_cast<double*>(smem + ((static_cast<size_t>(ROWS) * W * 6 + 7) & ~static_cast<size_t>(7)));
         double* lwc = lwk + V.n_wk;
         const uint32_t* guc = V.c_uc + static_cast<uint64_t>(chain) * W;
         for (uint32_t w = jj; w < total_w && jj < LPC; w += LPC) {
@@ -804,9 +809,10 @@ __global__ __launch_bounds__(64) void greedy_loop_kernel(const SolveView V, cons
             wd[w] = gd[w] | ((uc & 0xFFFFu) << LW_DEPTH_BITS);
             wh[w] = static_cast<uint16_t>(ggc[w] | ((uc >> 16) << 7));
         }
-        for (uint32_t i = lane; i < V.n_wk; i += 64) lwk[i] = V.wk[i];
-        for (uint32_t i = lane; i < V.n_wc; i += 64) lwc[i] = V.wc[i];
+        for (uint32_t i = threadIdx.x; i < V.n_wk; i += 64 * WAVES) lwk[i] = V.wk[i];
+        for (uint32_t i = threadIdx.x; i < V.n_wc; i += 64 * WAVES) lwc[i] = V.wc[i];
         C = ChainLW{&V, wd, wh, lwk, lwc};
+        __syncthreads();                                                         // the tables; from here on the wavefronts run apart
     } else {
         for (uint32_t w = jj; w < total_w && jj < LPC; w += LPC) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
         C = Chain{&V, wd, V.c_ww + static_cast<uint64_t>(chain) * W};
@@ -1065,6 +1071,9 @@ struct AnnealRing {
     uint32_t produced, consumed, stop, go;
 };
 
+// WWL: the window weights in LDS (8 bytes per window) or gathered from the chain's row in L2 — the same latency chain (they travel
+// with the table gathers), a third of the LDS: next to the greedy chains of the following locus the LDS of the device is what runs out
+template <bool WWL>
 __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) {
     extern __shared__ __align__(32) uint8_t smem[];
     __shared__ uint32_t flagged;
@@ -1072,10 +1081,11 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     __syncthreads();
     if (flagged != 0u) return;                     // the batch is repeated by the host (see greedy_loop_kernel)
     const uint32_t W = V.wstride;
-    // [W] window weights first, then [W] depth | GC bin << 25, then the ring the second wavefront fills
+    // [W] window weights first (WWL), then [W] depth | GC bin << 25, then the ring the second wavefront fills
+    const size_t ww_bytes = WWL ? static_cast<size_t>(W) * 8 : 0;
     double* lww = reinterpret_cast<double*>(smem);
-    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(W) * 8);
-    AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + static_cast<size_t>(W) * 8 + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + ww_bytes);
+    AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + ww_bytes + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
@@ -1083,13 +1093,13 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
     const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
     const uint32_t total_w = V.c_totw[chain];
+    const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
     {
-        const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
         const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
         const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
         for (uint32_t w = lane; wave == 0 && w < total_w; w += 64) {
             wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
-            lww[w] = gww[w];
+            if (WWL) lww[w] = gww[w];
         }
     }
     const uint32_t nnt = V.c_nnt[chain];
@@ -1137,7 +1147,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         }
         return;
     }
-    Chain C{&V, wd, lww};
+    Chain C{&V, wd, WWL ? lww : gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
     for (uint32_t w = lane; w < total_w; w += 64) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
@@ -1481,6 +1491,11 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
     loc->lut_ext_depth = depth;
 }
 
+// a few microseconds of nothing (one wavefront): lets the workgroups of a kernel launched just before on another stream get resident
+__global__ void pause_kernel(uint32_t rounds) {
+    for (uint32_t i = 0; i < rounds; i++) __builtin_amdgcn_s_sleep(127);
+}
+
 template <uint32_t P>
 void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s) {
     if (lds_init > 48 * 1024)
@@ -1492,29 +1507,34 @@ void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_ini
 
 // LDS of a greedy workgroup: the rows' windows (4 bytes each; 6 with the weights in LDS, plus the two weight tables)
 inline size_t greedy_lds(uint32_t lpc, const SolveView& V, bool lw) {
-    const size_t rows = static_cast<size_t>(64 / lpc) * V.wstride;
+    const size_t rows = static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * V.wstride;
     return lw ? ((rows * 6 + 7) & ~static_cast<size_t>(7)) + static_cast<size_t>(V.n_wk + V.n_wc) * 8 : rows * 4;
 }
 template <uint32_t LPC, bool LW>
 void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
-    constexpr uint32_t CPW = 64 / LPC;
+    constexpr uint32_t ROWS = (64 / LPC) * (LW ? 2 : 1);
     const size_t lds = greedy_lds(LPC, V, LW);
     if (lds > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC, LW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
     ctx->timed(LCTY_K_SOLVE, [&] {
-        hipLaunchKernelGGL((greedy_loop_kernel<LPC, LW>), dim3((nch + CPW - 1) / CPW), dim3(64), lds, s, V, nch);
+        hipLaunchKernelGGL((greedy_loop_kernel<LPC, LW>), dim3((nch + ROWS - 1) / ROWS), dim3(LW ? 128 : 64), lds, s, V, nch);
     }, s);
     LCTY_HIP(hipGetLastError());
 }
 
-void launch_anneal(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
-    const size_t lds = static_cast<size_t>(V.wstride) * 8 + ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
+template <bool WWL>
+void launch_anneal_as(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
+    const size_t lds = (WWL ? static_cast<size_t>(V.wstride) * 8 : 0) + ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
     if (lds > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(anneal_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(anneal_loop_kernel<WWL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
-    ctx->timed(LCTY_K_ANNEAL, [&] { hipLaunchKernelGGL(anneal_loop_kernel, dim3(nch), dim3(128), lds, s, V); }, s);
+    ctx->timed(LCTY_K_ANNEAL, [&] { hipLaunchKernelGGL(anneal_loop_kernel<WWL>, dim3(nch), dim3(128), lds, s, V); }, s);
     LCTY_HIP(hipGetLastError());
+}
+void launch_anneal(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
+    // lcty_ctx_set_knob "anneal_lds_weights": 1 keeps the chain's window weights in LDS (default: gathered, see the kernel)
+    if (ctx->knob("anneal_lds_weights", 0) != 0) launch_anneal_as<true>(ctx, V, nch, s); else launch_anneal_as<false>(ctx, V, nch, s);
 }
 
 // One stage = every (genotype, attempt) chain, in batches that fit the state budget. `after_batch(g0, ng, liks)` runs
@@ -1644,7 +1664,12 @@ struct StageRunner {
             case 3: launch_init<3>(ctx, V, nch, lds_init, stream); break;
             default: launch_init<4>(ctx, V, nch, lds_init, stream); break;
         }
-        if (V.solver.kind == LCTY_SOLVER_ANNEAL) { launch_anneal(ctx, V, nch, stream); return; }
+        if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
+            if (lane == 1) wait_for_greedy_of_next_locus();
+            launch_anneal(ctx, V, nch, stream);
+            return;
+        }
+        if (lane == 0) announce_greedy();
         // Lanes per chain. The loop is bound by instruction issue — a wavefront-iteration costs the same whatever its number of busy
         // lanes — and at its register count one wavefront fits a SIMD: the chains of a stage should make at most one wavefront per
         // SIMD. A row of 16 lanes (the hardware's DPP rows: cheapest row operations) holds the default sample of 10 with four
@@ -1665,7 +1690,7 @@ struct StageRunner {
         // window weights from LDS tables when the locus has them (no explicit weights, counts within the index bits) and the
         // depths fit their field; lcty_ctx_set_knob "solve_lds_weights" 0 keeps the gathers
         const bool lw = V.n_wk != 0 && 2 * static_cast<uint64_t>(V.n_good) + 2 <= LW_DEPTH_MASK && ctx->knob("solve_lds_weights", 1) != 0;
-        while (lpc < 64 && greedy_lds(lpc, V, lw) > 64 * 1024) lpc = lpc < 16 ? 16 : lpc * 2;      // the rows' windows share the LDS
+        while (lpc < 64 && greedy_lds(lpc, V, lw) > 80 * 1024) lpc = lpc < 16 ? 16 : lpc * 2;      // the rows' windows share the LDS
         auto go = [&](auto tag) {
             constexpr uint32_t L = decltype(tag)::value;
             if (lw) launch_greedy<L, true>(ctx, V, nch, stream); else launch_greedy<L, false>(ctx, V, nch, stream);
@@ -1675,6 +1700,29 @@ struct StageRunner {
         else if (lpc == 16) go(std::integral_constant<uint32_t, 16>{});
         else if (lpc == 32) go(std::integral_constant<uint32_t, 32>{});
         else go(std::integral_constant<uint32_t, 64>{});
+    }
+
+    // lcty_ctx::LaunchGate: the main stream's greedy loop of the next locus goes first, the side stream's annealing loop right behind
+    void announce_greedy() {
+        auto& g = ctx->gate;
+        if (!g.ev) LCTY_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+        {
+            std::lock_guard<std::mutex> lock(g.m);
+            LCTY_HIP(hipEventRecord(g.ev, stream));                              // behind the initialisation kernel: the greedy loop is next
+            g.epoch++;
+        }
+        g.cv.notify_all();
+    }
+    void wait_for_greedy_of_next_locus() {
+        auto& g = ctx->gate;
+        std::unique_lock<std::mutex> lock(g.m);
+        if (g.target == 0) return;
+        g.cv.wait(lock, [&] { return g.epoch >= g.target; });
+        if (g.ev) {
+            LCTY_HIP(hipStreamWaitEvent(stream, g.ev, 0));
+            hipLaunchKernelGGL(pause_kernel, dim3(1), dim3(64), 0, stream, 8u);
+        }
+        g.target = 0;
     }
 
     template <typename F>
@@ -2230,6 +2278,12 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
         std::unique_ptr<LocusRun> prev;
         std::thread tail_thread;
         int32_t tail_rc = LCTY_OK; std::string tail_msg;
+        lcty_ctx* ctx = n_batches ? batches[0]->ctx : nullptr;
+        auto release_gate = [&] {
+            if (!ctx) return;
+            { std::lock_guard<std::mutex> lock(ctx->gate.m); if (ctx->gate.target > ctx->gate.epoch) ctx->gate.epoch = ctx->gate.target; }
+            ctx->gate.cv.notify_all();
+        };
         auto join_tail = [&] {
             if (tail_thread.joinable()) tail_thread.join();
             prev.reset();
@@ -2240,10 +2294,17 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
                 auto R = std::make_unique<LocusRun>();
                 R->reads = batches[i]; R->ploidy = ploidy; R->stages = stages; R->n_stages = n_stages; R->master_seed = master_seeds[i];
                 R->priors = priors ? priors[i] : nullptr; R->out = &out[i];
-                R->head(true);
+                try { R->head(true); }
+                catch (...) { release_gate(); throw; }
+                release_gate();                                                  // a head that launched no greedy loop must not keep the tail waiting
                 join_tail();
                 prev = std::move(R);
                 LocusRun* run = prev.get();
+                {
+                    // the tail of this locus lets the greedy loop of the next locus go first (lcty_ctx::LaunchGate)
+                    std::lock_guard<std::mutex> lock(ctx->gate.m);
+                    ctx->gate.target = i + 1 < n_batches && n_stages > 1 && stages[0].solver.kind == LCTY_SOLVER_GREEDY ? ctx->gate.epoch + 1 : 0;
+                }
                 tail_thread = std::thread([run, &tail_rc, &tail_msg] {
                     try { run->tail(1); }
                     catch (const Error& e) { tail_rc = e.code; tail_msg = e.what(); }
@@ -2252,6 +2313,7 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
             }
             join_tail();
         } catch (...) {
+            release_gate();
             if (tail_thread.joinable()) tail_thread.join();
             throw;
         }
