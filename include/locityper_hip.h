@@ -206,13 +206,20 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  * environment variable changes what the library computes): "transfer_levels", "transfer_scratch_mb", "transfer_waves",
  * "transfer_cap_new", "transfer_arena" (lcty_recover_alignments: scratch levels, arenas), "depth_table_start" (first width of the
  * extended depth table), "solve_budget_mb" (device memory for the per-chain state of a solver stage), "solve_chains_per_wave", "solve_extra_start" (first size of a chain's run of locations beyond the second),
- * "solve_stats" (1: per-stage iteration counts on stderr). value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT.
- * None of them changes a result. */
+ * "solve_stats" (1: per-stage iteration counts on stderr), "solve_lds_weights" / "anneal_lds_weights" (0 / 1: where the solver loops
+ * keep the window weights), "gather_chunk_mb" (staging size of lcty_solve_stage_read_sharded). value < 0 restores the default; an
+ * unknown name is LCTY_ERR_INVALID_INPUT. None of them changes a result. */
 int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value);
 /* The solver stages keep their per-chain device state (32 B per chain and good read pair: ~150 GB for the 5 000 greedy chains of
  * the default scheme at 1 M read pairs; batches of chains when the device has less) with the context between stages and loci;
  * this releases it (the next stage allocates again). */
 int32_t lcty_ctx_trim(lcty_ctx* ctx);
+/* Page-locked host memory for the chunks handed to lcty_reads_append / lcty_reads_append_counted / lcty_recruit_*: the copies of
+ * a chunk that lies in such memory go over PCIe at link rate (a pageable chunk is staged through the driver's bounce buffers at
+ * about half of it). The reference reads its records into ordinary Vecs (locs.rs:1116-1150); a binding would fill these
+ * buffers instead. Release with lcty_host_free. */
+int32_t lcty_host_alloc(lcty_ctx* ctx, uint64_t bytes, void** out);
+void    lcty_host_free(void* p);
 
 /* defaults of model::Params::default (model/mod.rs:108-135) */
 void    lcty_params_default(lcty_params* out);

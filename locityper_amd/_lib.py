@@ -81,6 +81,8 @@ SIGNATURES = {
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),
     "lcty_ctx_set_knob": (I32, [VP, C.c_char_p, C.c_int64]),
     "lcty_ctx_trim": (I32, [VP]),
+    "lcty_host_alloc": (I32, [VP, U64, P(VP)]),
+    "lcty_host_free": (None, [VP]),
     "lcty_io_read_file": (I32, [C.c_char_p, P(VP), P(U64)]),
     "lcty_io_free": (None, [VP]),
     "lcty_io_write_gz": (I32, [C.c_char_p, VP, U64]),

@@ -30,6 +30,17 @@ def resolve_params(p, bg):
     return p
 
 
+class _PinnedBlock:
+    def __init__(self, addr):
+        self.addr = addr
+
+    def __del__(self):
+        try:
+            lib().lcty_host_free(self.addr)
+        except Exception:
+            pass
+
+
 class Context:
     def __init__(self, device=0):
         self._h = VP()
@@ -45,6 +56,25 @@ class Context:
     def trim(self):
         """lcty_ctx_trim: release the solver workspaces kept between stages."""
         check(lib().lcty_ctx_trim(self._h))
+
+    def pinned_like(self, arr):
+        """A copy of `arr` in page-locked host memory (lcty_host_alloc): chunks built from such arrays upload at PCIe link rate.
+        The memory is released when the returned array (and every view of it) is gone."""
+        arr = np.ascontiguousarray(arr)
+        p = VP()
+        check(lib().lcty_host_alloc(self._h, max(arr.nbytes, 1), C.byref(p)))
+        holder = _PinnedBlock(p.value)
+        buf = (C.c_uint8 * max(arr.nbytes, 1)).from_address(p.value)
+        out = np.frombuffer(buf, dtype=arr.dtype, count=arr.size).reshape(arr.shape)
+        out[...] = arr
+        buf._lcty_block = holder                  # the block lives as long as the buffer object the array is a view of
+        return out
+
+    def pinned_chunk(self, ch):
+        """A ReadsChunk whose arrays lie in page-locked memory."""
+        from .cdefs import ReadsChunk
+        return ReadsChunk(*(self.pinned_like(a) for a in (ch.mate_len, ch.mate_off, ch.bases2, ch.nmask, ch.aln_off, ch.recs,
+                                                          ch.cigar_off, ch.cigar)))
 
     def timing_reset(self):
         """Switches the HIP-event timing of this context on (it is off until the first call) and zeroes the totals."""

@@ -129,6 +129,14 @@ struct lcty_reads {
         lcty::DevBuf<uint16_t> alleles, row_of;
         lcty::DevBuf<unsigned long long> counters;          // [shards] extras counted / handed out
     } gather;
+    // run_filter as an integer Gram contraction on the matrix cores (lcty_gram.hip), grow-only
+    struct GramBufs {
+        lcty::DevBuf<uint32_t> bits, res_list;               // [A][columns / 32]; residual rows in order
+        lcty::DevBuf<double> delta, c_part, res_rows, res_scores;
+        lcty::DevBuf<uint8_t> dig, residual;                 // [planes][columns]; per row: left to the f64 kernel
+        lcty::DevBuf<unsigned long long> counters, S;        // [G] integer sums
+        lcty::DevBuf<int> f;
+    } gram;
     lcty::DevBuf<uint32_t> d_err;
     lcty::DevBuf<double> d_recover_w;        // per pair: read weight when the pair reaches recover_and_group_alignments, else -1
 
@@ -144,6 +152,8 @@ struct lcty_reads {
 namespace lcty {
 void launch_score_reads(lcty_reads* reads);
 void launch_prefilter_diploid(lcty_reads* reads);                               // all (i <= j) pairs
+bool launch_prefilter_gram(lcty_reads* reads);                                  // lcty_gram.hip: the same on the matrix cores, when it applies
+void launch_prefilter_tile(lcty_reads* reads, const double* M, uint64_t R, double* d_scores_out);
 void launch_prefilter_generic(lcty_reads* reads, const uint16_t* d_genotypes, uint64_t n_gt, uint32_t ploidy,
                               const double* d_priors, double* d_scores);
 void compact_matrix(lcty_reads* reads, double* d_out, uint64_t n_good);         // [A][n_good]

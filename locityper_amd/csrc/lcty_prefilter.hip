@@ -162,11 +162,11 @@ uint64_t count_genotypes(uint32_t n_alleles, uint32_t ploidy) {
     return acc;
 }
 
-void launch_prefilter_diploid(lcty_reads* reads) {
+// the f64 tile kernel over R rows of a read-major matrix (the batch's own, or the rows lcty_gram.hip leaves to it)
+void launch_prefilter_tile(lcty_reads* reads, const double* M, uint64_t R, double* d_scores_out) {
     lcty_ctx* ctx = reads->ctx;
     const uint32_t A = reads->locus->n_alleles;
     const uint64_t G = count_genotypes(A, 2);
-    const uint64_t R = reads->n_pairs;
     const uint32_t n_tiles = (A + PT - 1) / PT;
     const uint32_t n_tp = n_tiles * (n_tiles + 1) / 2;
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
@@ -178,21 +178,27 @@ void launch_prefilter_diploid(lcty_reads* reads) {
     per = (per + RC - 1) / RC * RC;
     if (per == 0) per = RC;
     splits = std::max<uint64_t>(1, (R + per - 1) / per);
-    if (reads->d_scores.n < G) reads->d_scores.alloc(G);
     if (reads->d_partials.n < splits * G) reads->d_partials.alloc(splits * G);
-    reads->n_scores = G;
     const size_t lds = 2 * RC * ROWD * sizeof(double);
     // per device and cheap: no process-wide "already done" flag (contexts on several GPUs, several host threads)
     LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_tile_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     ctx->timed(LCTY_K_PREFILTER, [&] {
         hipLaunchKernelGGL(prefilter_tile_kernel, dim3(n_tp, static_cast<uint32_t>(splits)), dim3(256), lds, ctx->stream,
-                           reads->d_matrix.p, R, A, n_tiles, per, reads->d_partials.p, G);
+                           M, R, A, n_tiles, per, reads->d_partials.p, G);
         hipLaunchKernelGGL(prefilter_reduce_kernel, dim3(static_cast<uint32_t>((G + 255) / 256)), dim3(256), 0, ctx->stream,
                            reads->d_partials.p, static_cast<uint32_t>(splits), G, static_cast<const double*>(nullptr),
-                           reads->d_scores.p);
+                           d_scores_out);
     });
     LCTY_HIP(hipGetLastError());
+}
+
+void launch_prefilter_diploid(lcty_reads* reads) {
+    if (launch_prefilter_gram(reads)) return;               // many alleles, few levels per row: the matrix cores (lcty_gram.hip)
+    const uint64_t G = count_genotypes(reads->locus->n_alleles, 2);
+    if (reads->d_scores.n < G) reads->d_scores.alloc(G);
+    reads->n_scores = G;
+    launch_prefilter_tile(reads, reads->d_matrix.p, reads->n_pairs, reads->d_scores.p);
 }
 
 void launch_prefilter_generic(lcty_reads* reads, const uint16_t* d_genotypes, uint64_t n_gt, uint32_t ploidy,

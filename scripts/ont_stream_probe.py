@@ -13,6 +13,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     A = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+    pinned = len(sys.argv) > 4 and sys.argv[4] == "pinned"            # chunks in page-locked memory (lcty_host_alloc)
     L = synth.SynthLocus(A, n, technology=cdefs.TECH_NANOPORE, read_len=10_000)
     p = api.resolve_params(api.default_params(), L.bg)
     ctx = api.Context(0)
@@ -27,6 +28,7 @@ def main():
     for lo in range(0, n, chunk):
         t0 = time.perf_counter()
         ch = c0 if lo == 0 else L.reads(lo, min(chunk, n - lo))
+        if pinned: ch = ctx.pinned_chunk(ch)
         t1 = time.perf_counter()
         aa.append(ch)
         t2 = time.perf_counter()
@@ -52,7 +54,7 @@ def main():
     mean[ixs], var[ixs], att[ixs] = m, v, 20
     res = api.produce_result(mean, var, att, ixs, p.prob_thresh)
     t_solve = time.perf_counter() - t0
-    out = {"workload": f"{n} single-end 10 kb ONT reads x {A} alleles, streaming batch with chunks of {chunk} reads",
+    out = {"workload": f"{n} single-end 10 kb ONT reads x {A} alleles, streaming batch with chunks of {chunk} reads", "host_memory": "page-locked" if pinned else "pageable",
            "records": recs, "cigar_words": words, "raw_GB": (16 * recs + 4 * words) / 1e9,
            "score_kernel_ms_total": ms, "reads_per_s_kernel": n / ms * 1e3, "records_cigar_GBs_kernel": (16 * recs + 4 * words) / ms / 1e6,
            "host_generation_s": t_gen, "upload_s": t_up, "score_s": t_score, "load_s_end_to_end": t_load,

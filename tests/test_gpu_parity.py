@@ -836,6 +836,47 @@ def test_read_sharded_stage(gpu_ctx):
 
 
 @pytest.mark.gpu
+def test_prefilter_on_the_matrix_cores(gpu_ctx):
+    """run_filter as an exact integer Gram contraction (lcty_gram.hip: level columns as bits, 35-bit fixed-point weights in five
+    digit planes, v_mfma_i32_32x32x32_i8) against the f64 tile kernel and against the oracle: 1e-9 relative as for the tile kernel,
+    the same best genotype and the same kept set; allele counts that do not fill the 32 / 128 tiles; rows left to the f64 kernel
+    when they have more levels than the contraction is told to take; too little room for the columns -> the tile kernel."""
+    for A, n, base_len in ((40, 3000, 9000), (131, 3000, 6000), (600, 2200, 4000)):
+        L = synth.SynthLocus(A, n, seed=90 + A, base_len=base_len)
+        loc, ol, p = both_loci(gpu_ctx, L)
+        ch = L.reads(0, n)
+        aa = api.AllAlignments.load(loc, ch)
+        gts = O.generate_genotypes(A, 2)
+        gpu_ctx.set_knob("prefilter_gram", 0)
+        tile = aa.run_filter()
+        try:
+            gpu_ctx.set_knob("prefilter_gram", 1)
+            gram = aa.run_filter()
+            again = aa.run_filter()
+            gpu_ctx.set_knob("prefilter_gram_levels", 3)                  # rows with a fourth level go through the f64 kernel
+            mixed = aa.run_filter()
+            gpu_ctx.set_knob("prefilter_gram_levels", -1)
+            gpu_ctx.set_knob("prefilter_gram_cols", 1)                    # one column per row is not enough room: falls back
+            fallback = aa.run_filter()
+        finally:
+            for k in ("prefilter_gram", "prefilter_gram_levels", "prefilter_gram_cols"):
+                gpu_ctx.set_knob(k, -1)
+        want = O.run_filter(aa.best_aln_matrix(), gts)
+        scale = np.abs(want).max()
+        assert np.abs(tile - want).max() <= 1e-9 * scale
+        assert np.abs(gram - want).max() <= 1e-9 * scale, (A, np.abs(gram - want).max() / scale)
+        assert np.abs(mixed - want).max() <= 1e-9 * scale, (A, np.abs(mixed - want).max() / scale)
+        assert np.array_equal(gram, again)                              # integer sums: reproducible whatever the column order
+        assert np.array_equal(fallback, tile)
+        assert int(np.argmax(gram)) == int(np.argmax(want)) and tuple(gts[int(np.argmax(gram))]) == L.true_genotype
+        keep_g = api.truncate_ixs(gram, np.arange(len(gram)), p.filt_diff, 500, 1)
+        keep_w = O.truncate(want, np.arange(len(want)), p.filt_diff, 500, 1)
+        assert set(keep_g.tolist()) == set(keep_w.tolist())
+        if A >= 512:                                                    # from 512 alleles on it is the default
+            assert np.array_equal(aa.run_filter(), gram)
+
+
+@pytest.mark.gpu
 def test_config5_allele_count_pairs_beyond_the_lds(gpu_ctx):
     """configs[4] has 4 096 alleles and the mapper is asked for min(25 000, 4 x alleles) locations per read end
     (genotype.rs:971): a pair with an alignment per end on every allele has 8 192+ records, more than the LDS holds next to the
