@@ -130,13 +130,18 @@ __global__ __launch_bounds__(256) void gram_levels_kernel(const double* __restri
     for (uint32_t a = tid; a < A; a += 256) {
         uint32_t word = 0, nb = 0;
         uint64_t w = w0;
-        for (uint32_t rr = 0; rr < GR_RB; rr++) {
-            const uint32_t n = ncol[rr];
-            if (n == 0) continue;
-            const double x = M[(r0 + rr) * A + a];
-            for (uint32_t k = 0; k < n; k++) {
-                word |= (x < lv[rr][k] ? 1u : 0u) << nb;
-                if (++nb == 32) { bits[static_cast<uint64_t>(a) * kw + w++] = word; word = 0; nb = 0; }
+        for (uint32_t r4 = 0; r4 < GR_RB; r4 += 4) {
+            // four rows' cells in flight (rows without columns — and rows behind the end of the matrix — are not read)
+            double x[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) x[q] = ncol[r4 + q] ? M[(r0 + r4 + q) * A + a] : 0.0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t rr = r4 + q, n = ncol[rr];
+                for (uint32_t k = 0; k < n; k++) {
+                    word |= (x[q] < lv[rr][k] ? 1u : 0u) << nb;
+                    if (++nb == 32) { bits[static_cast<uint64_t>(a) * kw + w++] = word; word = 0; nb = 0; }
+                }
             }
         }
         if (nb) bits[static_cast<uint64_t>(a) * kw + w] = word;

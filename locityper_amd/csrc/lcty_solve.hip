@@ -1080,6 +1080,9 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (flagged != 0u) return;                     // the batch is repeated by the host (see greedy_loop_kernel)
+    // These are few wavefronts with one dependent chain of instructions each; in a queue of loci they share their SIMDs with the
+    // greedy wavefronts of the next locus, which always have an instruction ready. The issue arbiter takes the higher priority first.
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t W = V.wstride;
     // [W] window weights first (WWL), then [W] depth | GC bin << 25, then the ring the second wavefront fills
     const size_t ww_bytes = WWL ? static_cast<size_t>(W) * 8 : 0;
