@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--pipeline", type=int, default=0, help="ignored (round 1 option; the queue of loci is the default mode now)")
     ap.add_argument("--recruit-sample", type=int, default=8_000_000,
                     help="read pairs of the extra recruitment measurement (the step before the path, SURVEY 8f rank 1; 0 = skip)")
+    ap.add_argument("--map-sample", type=int, default=32768, help="read pairs mapped onto 8 basis alleles by the candidate-generation slice (0 = skip)")
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
@@ -520,6 +521,31 @@ def main():
                               "kernel_ms": ms_q, "read_pairs_per_s_kernel": nrq / (ms_q * 1e-3) if ms_q else None,
                               "read_pairs_per_s_call": nrq / t_call, "targets_build_s": t_targets, "recruited": int(np.count_nonzero(cntq))}
         T.close(); del rq, words
+
+    if args.map_sample > 0 and world == 1:
+        # ---- candidate generation on the basis alleles (first slice; lcty_map.hip), the step the reference leaves to
+        # an external mapper: the first read pairs of the locus, their bases only, onto 8 basis alleles ----
+        nmp = min(args.map_sample, args.pairs)
+        src = L.reads(0, nmp)
+        from locityper_amd.cdefs import ReadsChunk, ALN_REC_DTYPE
+        zoff = np.zeros(nmp + 1, dtype=np.uint64)
+        bare = ReadsChunk(src.mate_len, src.mate_off, src.bases2, src.nmask, zoff, np.zeros(0, dtype=ALN_REC_DTYPE), zoff, np.zeros(0, dtype=np.uint32))
+        mp = api.map_params()
+        basis = list(range(0, A, max(1, A // 8)))[:8]
+        tm0 = time.perf_counter()
+        api.build_map_index(loc, basis, k=mp.k)
+        t_index = time.perf_counter() - tm0
+        api.map_reads(loc, bare, mp)                                              # warm-up
+        ctx.timing_reset()
+        tm0 = time.perf_counter()
+        mapped = api.map_reads(loc, bare, mp)
+        t_map = time.perf_counter() - tm0
+        _, ms_map = ctx.timing(api.K_MAP)
+        out["candidate_generation"] = {"sample": f"first {nmp} read pairs (bases only) onto {len(basis)} basis alleles, seeds of {mp.k} every {mp.stride} bases, extension without gaps",
+                                       "records": int(len(mapped.recs)), "kernel_ms_both_passes": ms_map,
+                                       "read_ends_per_s_kernel": 2 * nmp / (ms_map * 1e-3) if ms_map else None,
+                                       "read_ends_per_s_call": 2 * nmp / t_map, "index_build_s": t_index}
+        del src, bare, mapped
 
     if args.recovery_sample > 0 and world == 1:
         # ---- alignment recovery (K6), not part of the step: the mapper reports only the primary alignment of each read end, the

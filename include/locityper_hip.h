@@ -447,6 +447,32 @@ int32_t lcty_targets_finalize(lcty_targets* targets, uint64_t* n_minimizers);
 int32_t lcty_recruit(lcty_targets* targets, const lcty_reads_host* chunk, int32_t paired, uint32_t max_out, uint32_t* out_cnt,
                      uint32_t* out_loci);
 
+/* ---- candidate generation inside a locus (first slice) ----------------------------------------------------
+ * The reference runs an external mapper per locus — strobealign -k 15 -N/-M min(25000, 4 x alleles) -S 0.5 --eqx for short
+ * reads (src/command/genotype.rs:962-1005), piped through samtools view -e "[AS] >= 50 || flag & 2304 == 0" (1055-1094), on the
+ * basis haplotypes when --basis is given (1007-1052) — and reads the resulting aln.bam. No mapper source is in the reference
+ * tree; the algorithm of this slice is this build's own (locityper_amd/csrc/lcty_map.hip states it, tests/pyref_map.py restates
+ * it): k-mer seeds every `stride` bases -> votes for (basis allele, strand, diagonal) -> per (allele, strand) the diagonal with
+ * the most votes -> extension WITHOUT gaps (+match / -mismatch per base, end_bonus per read end reached; the best-scoring stretch,
+ * the rest soft-clipped) -> the best candidate of a read end is its primary record, the others with score >= min_score secondary
+ * records, a read end without candidates an unmapped record. Record order, flags, =/X/S CIGARs and SEQ orientation are those of
+ * the BAM the reference reads, so the result is a chunk for lcty_reads_append; the alleles outside the basis are reached with
+ * lcty_recover_alignments. Limits of the slice: read ends of up to 256 bases, up to 32 basis alleles, seed length 8..31, at most
+ * 64 seeds per read end and 1 024 votes (the first ones in seed order); gapped extension is not built.
+ * lcty_locus_build_map_index: the k-mers of the basis alleles (host hash table, once per locus).
+ * lcty_map_reads: only the sequence fields of `chunk` are read. aln_off / cigar_off [n_pairs + 1] are always written; with
+ *   recs == NULL the call only sizes. bases2_out / nmask_out: the chunk's bases in BAM orientation (same offsets). */
+typedef struct lcty_map_params {
+    uint32_t k, stride, min_votes;
+    uint32_t max_occ;            /* seeds with more places in the index do not vote; 0: four per basis allele */
+    int32_t  match, mismatch, end_bonus, min_score;
+} lcty_map_params;
+int32_t lcty_map_params_default(lcty_map_params* p);
+int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uint32_t n_basis, uint32_t k);
+int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_params* params, uint64_t* aln_off,
+                       lcty_aln_rec* recs, uint64_t cap_recs, uint64_t* cigar_off, uint32_t* cigar, uint64_t cap_cigar,
+                       uint32_t* bases2_out, uint32_t* nmask_out);
+
 /* ---- solver stages (src/solvers/solve.rs:789-850, src/solvers/stoch.rs, src/model/assgn.rs) ----------------
  * The reference drives these stages from one Xoshiro256++ through rand ^0.10 adaptors that are not in its tree and
  * whose results already depend on --threads (solve.rs:1017, 1051). Here every (genotype, attempt) chain gets its
@@ -537,7 +563,8 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
 #define LCTY_K_TRANSFER  5   /* transfer_kernel: alignment recovery */
 #define LCTY_K_RECRUIT   6   /* recruit_kernel: minimizer read recruitment */
 #define LCTY_K_ANNEAL    7   /* anneal_loop_kernel: the SimAnneal chains */
-#define LCTY_K_COUNT     8
+#define LCTY_K_MAP       8   /* map_kernel: candidate generation on the basis alleles */
+#define LCTY_K_COUNT     9
 /* Timing is opt-in: nothing is recorded before the first lcty_timing_reset on a context (a production run that never reads
  * timings creates no events); afterwards every launch is bracketed by two events, at most 256 pairs per kernel id kept. */
 int32_t lcty_timing_reset(lcty_ctx* ctx);

@@ -80,6 +80,9 @@ SIGNATURES = {
     "lcty_discard_improbable": (I32, [VP, VP, VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),
     "lcty_ctx_set_knob": (I32, [VP, C.c_char_p, C.c_int64]),
+    "lcty_map_params_default": (I32, [VP]),
+    "lcty_locus_build_map_index": (I32, [VP, VP, U32, U32]),
+    "lcty_map_reads": (I32, [VP, VP, VP, VP, VP, U64, VP, VP, U64, VP, VP]),
     "lcty_ctx_trim": (I32, [VP]),
     "lcty_host_alloc": (I32, [VP, U64, P(VP)]),
     "lcty_host_free": (None, [VP]),

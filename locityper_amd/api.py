@@ -573,6 +573,37 @@ def solve_queue(batches, stages=None, master_seeds=None, priors=None, ploidy=2):
 
 
 K_RECRUIT = 6
+K_MAP = 8
+
+
+def map_params(**over):
+    """lcty_map_params_default (seed length 15, a seed every 5 bases, scores 2 / 8 / end bonus 10, secondary records from score 50)."""
+    p = cdefs.MapParams()
+    check(lib().lcty_map_params_default(C.byref(p)))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def build_map_index(locus, basis, k=15):
+    """lcty_locus_build_map_index: the k-mers of the basis alleles of the locus."""
+    basis = np.ascontiguousarray(basis, dtype=np.uint16)
+    check(lib().lcty_locus_build_map_index(locus._h, basis.ctypes.data, len(basis), k))
+
+
+def map_reads(locus, chunk, params):
+    """lcty_map_reads: the read ends of `chunk` (its sequence fields) onto the basis alleles; returns a ReadsChunk with the found
+    records, =/X/S CIGARs and the bases in BAM orientation — ready for AllAlignments.append."""
+    h = chunk.host_struct()
+    n = chunk.n_pairs
+    aln_off = np.zeros(n + 1, dtype=np.uint64); cig_off = np.zeros(n + 1, dtype=np.uint64)
+    check(lib().lcty_map_reads(locus._h, C.byref(h), C.byref(params), aln_off.ctypes.data, None, 0, cig_off.ctypes.data, None, 0, None, None))
+    recs = np.zeros(int(aln_off[-1]), dtype=cdefs.ALN_REC_DTYPE)
+    cigar = np.zeros(max(int(cig_off[-1]), 1), dtype=np.uint32)
+    b2 = np.zeros_like(chunk.bases2); nm = np.zeros_like(chunk.nmask)
+    check(lib().lcty_map_reads(locus._h, C.byref(h), C.byref(params), aln_off.ctypes.data, recs.ctypes.data, len(recs), cig_off.ctypes.data,
+                               cigar.ctypes.data, len(cigar), b2.ctypes.data, nm.ctypes.data))
+    return cdefs.ReadsChunk(chunk.mate_len, chunk.mate_off, b2, nm, aln_off, recs, cig_off, cigar[:int(cig_off[-1])])
 
 
 def recruit_params(technology=cdefs.TECH_ILLUMINA, paired=True, **over):

@@ -1,0 +1,440 @@
+// lcty_map.hip — candidate generation inside a locus (first slice): where do the read ends of a chunk
+// align on the BASIS alleles of the locus? The reference leaves this to an external mapper (strobealign for short reads,
+// src/command/genotype.rs:962-1005; `| samtools view -e "[AS] >= 50 || flag & 2304 == 0"`, 1055-1094; mapping to the basis
+// haplotypes only with --basis, 1007-1052) and reads its `aln.bam`; the other alleles are then reached through the
+// haplotype-to-haplotype alignments (lcty_recover_alignments). No source of that mapper is in the reference tree: the
+// algorithm here is this build's own, stated below and restated in tests/pyref_map.py, against which the kernel is bit-exact.
+//
+//   index    every k-mer (k <= 31, canonical form) of every basis allele -> its (basis allele, position, "forward is canonical"),
+//            an open-addressing table of runs built on the host once per locus (basis sets are small: --basis).
+//   seeds    the k-mers of a read end at every `stride`-th position plus the last one; k-mers with a base that is not ACGT are skipped,
+//            and so are k-mers with more than max_occ places in the index (microsatellites; at most 64 places vote in any case).
+//   votes    every (seed, index entry) pair votes for (basis allele, strand, diagonal). An (allele, strand) whose best diagonal has
+//            >= half the votes of the read end's best one (strobealign -S 0.5) contributes its diagonals with >= min_votes votes and
+//            >= half the votes of its best as candidates (a read end in a tandem repeat has as many votes one period off), the
+//            first 64 in (allele, strand, diagonal) order.
+//   extend   without gaps along the diagonal: +match per equal base, -mismatch otherwise (bases that are not ACGT never match),
+//            `end_bonus` for each read end reached; the best-scoring stretch is the alignment, the rest is soft-clipped
+//            ; per (allele, strand) the candidate with the best score stays (ties: the smallest diagonal)
+//            (first slice: reads across an indel between alleles get the longer side and a clip; the gap-affine extension with the
+//            aligner of lcty_transfer_device.hpp is the next slice).
+//   records  the best candidate of a read end is its primary record, the others with a score >= min_score are secondary
+//            records (the samtools filter above); a read end without a candidate is an unmapped record. Record order, flags,
+//            =/X/S CIGARs and SEQ orientation (reverse-complemented when the primary is on the reverse strand) are those of
+//            the BAM the reference reads (model/locs.rs:1116-1150), so the chunk goes straight into lcty_reads_append.
+//
+// map_kernel<WRITE>: one wavefront per read end; lane = seed, then lane = hit (bitonic sort of <= 1 024 vote keys in LDS), then
+// lane = candidate (<= 64). Two passes (sizes, then records) with a host prefix sum in between.
+#include <algorithm>
+#include <unordered_map>
+
+#include "lcty_objects.hpp"
+
+namespace lcty {
+
+namespace {
+
+constexpr uint32_t MAP_MAX_LEN = 256;      // bases per read end
+constexpr uint32_t MAP_MAX_HITS = 1024;
+constexpr uint32_t MAP_MAX_BASIS = 32;
+constexpr uint32_t MAP_PER_SEED = 64;      // index entries a seed may vote with (the first ones: by allele, then position)
+
+struct MapSlot { uint64_t key; uint32_t start, count; };   // key ~0 = free
+constexpr uint64_t MAP_FREE = ~0ull;
+
+__host__ __device__ inline uint64_t map_hash(uint64_t x) {          // the mix of kmers.rs:93-103
+    x = ~x; x ^= x >> 23; x *= 0x2127599bf4325c37ull; x ^= x >> 47;
+    return x;
+}
+
+struct MapView {
+    const MapSlot* table; uint64_t mask;
+    const uint64_t* entries;               // basis index << 33 | position << 1 | forward-is-canonical
+    const uint16_t* basis;                 // basis index -> allele
+    uint32_t n_basis, k, stride, min_votes, max_occ;
+    int32_t match, mismatch, end_bonus, min_score;
+    const uint8_t* seqs; const uint64_t* seq_off; const uint32_t* allele_len;
+    // reads
+    uint64_t n_mates;
+    const uint32_t* mate_len; const uint64_t* mate_off; const uint32_t* bases2; const uint32_t* nmask;
+    int paired;
+    // pass 1
+    uint32_t* n_recs; uint32_t* n_cigar;
+    // pass 2
+    const uint64_t* rec_at; const uint64_t* cig_at;      // per read end: first record, first CIGAR word
+    const uint64_t* pair_cig;                            // per pair: first CIGAR word (records carry offsets relative to it)
+    lcty_aln_rec* recs; uint32_t* cigar;
+    uint32_t* out_bases2; uint32_t* out_nmask;
+};
+
+__device__ __forceinline__ uint32_t base_at(const uint32_t* b2, uint64_t off, uint32_t i) {
+    const uint64_t p = off + i;
+    return (b2[p >> 4] >> (2 * (p & 15u))) & 3u;
+}
+__device__ __forceinline__ bool n_at(const uint32_t* nm, uint64_t off, uint32_t i) {
+    const uint64_t p = off + i;
+    return (nm[p >> 5] >> (p & 31u)) & 1u;
+}
+__device__ __forceinline__ uint32_t enc_of(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void map_kernel(const MapView V) {
+    __shared__ uint64_t keys[MAP_MAX_HITS];
+    __shared__ unsigned long long best[2 * MAP_MAX_BASIS];
+    __shared__ uint64_t cand_key[64];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t m = blockIdx.x;
+    if (m >= V.n_mates) return;
+    const uint32_t L = V.mate_len[m];
+    if (L == 0) {                                                               // absent read end (single-end data)
+        if (!WRITE && lane == 0) { V.n_recs[m] = 0; V.n_cigar[m] = 0; }
+        return;
+    }
+    const uint64_t off = V.mate_off[m];
+    const uint32_t k = V.k;
+    // ---- seeds and votes
+    uint32_t n_hits = 0;
+    if (L >= k) {
+        const uint32_t span = L - k, n0 = span / V.stride + 1, n_seeds = n0 + (span % V.stride ? 1u : 0u);
+        uint32_t start = 0, count = 0, pr = 0;
+        bool read_fwd = false;
+        if (lane < n_seeds) {
+            pr = lane < n0 ? lane * V.stride : span;
+            uint64_t fw = 0, rv = 0;
+            bool bad = false;
+            for (uint32_t j = 0; j < k; j++) {
+                const uint32_t e = base_at(V.bases2, off, pr + j);
+                bad |= n_at(V.nmask, off, pr + j);
+                fw = (fw << 2) | e;
+                rv = (rv >> 2) | (static_cast<uint64_t>(3u - e) << (2 * k - 2));
+            }
+            if (!bad) {
+                read_fwd = fw <= rv;
+                const uint64_t canon = read_fwd ? fw : rv;
+                uint64_t h = map_hash(canon) & V.mask;
+                for (;;) {
+                    const MapSlot s = V.table[h];
+                    if (s.key == MAP_FREE) break;
+                    if (s.key == canon) { start = s.start; count = s.count > V.max_occ ? 0u : min(s.count, MAP_PER_SEED); break; }      // a repetitive k-mer says nothing about the place
+                    h = (h + 1) & V.mask;
+                }
+            }
+        }
+        // places of the lanes' votes in the list (seed order); what does not fit is dropped
+        uint32_t incl = count;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= static_cast<uint32_t>(o)) incl += up; }
+        const uint32_t at = incl - count;
+        n_hits = min(static_cast<uint32_t>(__shfl(incl, 63)), MAP_MAX_HITS);
+        for (uint32_t j = 0; j < count && at + j < MAP_MAX_HITS; j++) {
+            const uint64_t e = V.entries[start + j];
+            const uint32_t b = static_cast<uint32_t>(e >> 33), pa = static_cast<uint32_t>(e >> 1);
+            const bool allele_fwd = e & 1ull;
+            const uint32_t strand = read_fwd == allele_fwd ? 0u : 1u;
+            const int64_t diag = strand ? static_cast<int64_t>(pa) - static_cast<int64_t>(L - k - pr) : static_cast<int64_t>(pa) - static_cast<int64_t>(pr);
+            keys[at + j] = (static_cast<uint64_t>(b * 2 + strand) << 32) | static_cast<uint32_t>(diag + 0x80000000ll);
+        }
+    }
+    // ---- sort the votes (bitonic over the next power of two, padded with the largest key)
+    uint32_t n2 = 1;
+    while (n2 < n_hits) n2 <<= 1;
+    for (uint32_t i = n_hits + lane; i < n2; i += 64) keys[i] = ~0ull;
+    for (uint32_t i = lane; i < 2 * MAP_MAX_BASIS; i += 64) best[i] = 0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= n2; size <<= 1)
+        for (uint32_t strd = size >> 1; strd > 0; strd >>= 1) {
+            for (uint32_t i = lane; i < n2 / 2; i += 64) {
+                const uint32_t lo = 2 * i - (i & (strd - 1)), hi = lo + strd;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    // ---- per (allele, strand): the votes of its best diagonal
+    for (uint32_t i = lane; i < n_hits; i += 64) {
+        const uint64_t key = keys[i];
+        if (i > 0 && keys[i - 1] == key) continue;
+        uint32_t len = 1;
+        while (i + len < n_hits && keys[i + len] == key) len++;
+        atomicMax(&best[key >> 32], static_cast<unsigned long long>(len));
+    }
+    __syncthreads();
+    const uint32_t n_groups = 2 * V.n_basis;
+    uint32_t max_votes = lane < n_groups ? static_cast<uint32_t>(best[lane]) : 0u;
+    for (int o = 32; o > 0; o >>= 1) max_votes = max(max_votes, static_cast<uint32_t>(__shfl_xor(static_cast<int>(max_votes), o)));
+    // ---- candidates: the diagonals of an (allele, strand) with >= min_votes votes and >= half the votes of its best one (a read end
+    // in a tandem repeat has as many votes one period off: the extension decides), for the (allele, strand)s whose best diagonal has
+    // >= half the votes of the read end's best; in (allele, strand, diagonal) order, the first 64
+    uint32_t n_cand = 0;
+    for (uint32_t i0 = 0; i0 < n_hits && n_cand < 64; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool q = false;
+        if (i < n_hits) {
+            const uint64_t key = keys[i];
+            if (i == 0 || keys[i - 1] != key) {
+                uint32_t len = 1;
+                while (i + len < n_hits && keys[i + len] == key) len++;
+                const uint32_t gv = static_cast<uint32_t>(best[key >> 32]);
+                q = len >= V.min_votes && 2 * len >= gv && 2 * gv >= max_votes;
+            }
+        }
+        const unsigned long long qm = __ballot(q);
+        const uint32_t at = n_cand + static_cast<uint32_t>(__popcll(qm & ((1ull << lane) - 1ull)));
+        if (q && at < 64) cand_key[at] = keys[i];
+        n_cand = min(64u, n_cand + static_cast<uint32_t>(__popcll(qm)));
+    }
+    __syncthreads();
+    // ---- extension: lane = candidate
+    const bool cand = lane < n_cand;
+    const uint64_t ckey = cand ? cand_key[lane] : 0ull;
+    const uint32_t g = static_cast<uint32_t>(ckey >> 32);
+    const uint32_t strand = g & 1u, allele = cand ? V.basis[g >> 1] : 0u;
+    const int64_t diag = static_cast<int64_t>(static_cast<uint32_t>(ckey)) - 0x80000000ll;
+    const uint8_t* ref = V.seqs + V.seq_off[allele];
+    const int64_t alen = V.allele_len[allele];
+    // a position of the read end in alignment orientation: equal to the allele's base there?
+    auto equal_at = [&](uint32_t i) -> bool {
+        const uint32_t src = strand ? L - 1 - i : i;
+        if (n_at(V.nmask, off, src)) return false;
+        const uint32_t e = strand ? 3u - base_at(V.bases2, off, src) : base_at(V.bases2, off, src);
+        return enc_of(ref[diag + i]) == e;
+    };
+    // the best-scoring stretch [s, e) inside the part of the read end that lies on the allele
+    int32_t score = INT32_MIN; uint32_t s_best = 0, e_best = 0;
+    if (cand) {
+        const uint32_t i_lo = diag < 0 ? static_cast<uint32_t>(-diag) : 0u;
+        const uint32_t i_hi = static_cast<uint32_t>(max<int64_t>(0, min<int64_t>(L, alen - diag)));
+        int32_t run = 0; uint32_t run_s = 0; bool open = false;
+        for (uint32_t i = i_lo; i < i_hi; i++) {
+            const int32_t fresh = i == 0 ? V.end_bonus : 0;
+            if (!open || fresh > run) { run = fresh; run_s = i; open = true; }   // a stretch that starts here (an older start wins ties)
+            run += equal_at(i) ? V.match : -V.mismatch;
+            const int32_t total = run + (i + 1 == L ? V.end_bonus : 0);
+            if (total > score) { score = total; s_best = run_s; e_best = i + 1; }
+        }
+    }
+    // the best diagonal of every (allele, strand): highest score, the smallest diagonal (= first lane) on ties
+    for (uint32_t i = lane; i < 2 * MAP_MAX_BASIS; i += 64) best[i] = 0ull;
+    __syncthreads();
+    if (cand && score > INT32_MIN)
+        atomicMax(&best[g], (static_cast<unsigned long long>(static_cast<uint32_t>(score) ^ 0x80000000u) << 32) | (63u - lane));
+    __syncthreads();
+    const bool have = cand && score > INT32_MIN && static_cast<uint32_t>(best[g]) == 63u - lane;
+    // ---- the primary record: best score, the smallest (allele, strand) on ties (the lanes are in that order)
+    int32_t top = have ? score : INT32_MIN;
+    for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o));
+    const unsigned long long tops = __ballot(have && score == top);
+    const uint32_t lp = tops ? static_cast<uint32_t>(__ffsll(static_cast<long long>(tops))) - 1u : 0xFFFFFFFFu;
+    const bool keep = have && (lane == lp || score >= V.min_score);
+    // CIGAR words of a kept candidate: [S] runs of = / X [S]
+    uint32_t n_ops = 0;
+    if (keep) {
+        n_ops = (s_best > 0) + (e_best < L);
+        bool prev = false;
+        for (uint32_t i = s_best; i < e_best; i++) { const bool eq = equal_at(i); if (i == s_best || eq != prev) n_ops++; prev = eq; }
+    }
+    const unsigned long long kept = __ballot(keep);
+    const uint32_t n_kept = static_cast<uint32_t>(__popcll(kept));
+    uint32_t ops_incl = keep && lane != lp ? n_ops : 0u;                         // the others follow the primary in (allele, strand) order
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(ops_incl, o); if (lane >= static_cast<uint32_t>(o)) ops_incl += up; }
+    const uint32_t ops_primary = lp != 0xFFFFFFFFu ? static_cast<uint32_t>(__shfl(static_cast<int>(n_ops), static_cast<int>(lp))) : 0u;
+    const uint32_t ops_total = ops_primary + static_cast<uint32_t>(__shfl(static_cast<int>(ops_incl), 63));
+    if (!WRITE) {
+        if (lane == 0) { V.n_recs[m] = n_kept ? n_kept : 1u; V.n_cigar[m] = ops_total; }       // no candidate: one unmapped record
+        return;
+    }
+    const uint32_t mate2 = V.paired && (m & 1u) ? LCTY_FLAG_MATE2 : 0u;
+    const uint64_t rec0 = V.rec_at[m], cig0 = V.cig_at[m], rel0 = cig0 - V.pair_cig[m >> 1];
+    const bool primary_reverse = lp != 0xFFFFFFFFu && __shfl(static_cast<int>(strand), static_cast<int>(lp)) != 0;
+    if (n_kept == 0) {
+        if (lane == 0) V.recs[rec0] = lcty_aln_rec{0u, 0u, static_cast<uint16_t>(LCTY_FLAG_UNMAPPED | mate2), 0u, static_cast<uint32_t>(rel0)};
+    } else if (keep) {
+        const uint32_t rank = lane == lp ? 0u : 1u + static_cast<uint32_t>(__popcll(kept & ((1ull << lane) - 1ull) & ~(1ull << lp)));
+        const uint32_t cig_rel = lane == lp ? 0u : ops_primary + ops_incl - n_ops;
+        uint32_t* cg = V.cigar + cig0 + cig_rel;
+        uint32_t w = 0;
+        if (s_best > 0) cg[w++] = (s_best << 4) | 4u;                            // S
+        bool prev = false; uint32_t len = 0;
+        for (uint32_t i = s_best; i < e_best; i++) {
+            const bool eq = equal_at(i);
+            if (i > s_best && eq != prev) { cg[w++] = (len << 4) | (prev ? 7u : 8u); len = 0; }      // = / X
+            prev = eq; len++;
+        }
+        cg[w++] = (len << 4) | (prev ? 7u : 8u);
+        if (e_best < L) cg[w++] = ((L - e_best) << 4) | 4u;
+        const uint16_t flags = static_cast<uint16_t>((strand ? LCTY_FLAG_REVERSE : 0u) | (lane == lp ? 0u : LCTY_FLAG_SECONDARY) | mate2);
+        V.recs[rec0 + rank] = lcty_aln_rec{static_cast<uint32_t>(diag + s_best), static_cast<uint16_t>(allele), flags, n_ops,
+                                           static_cast<uint32_t>(rel0 + cig_rel)};
+    }
+    // SEQ as the BAM has it: reverse-complemented when the primary record is on the reverse strand. The read end owns whole
+    // 32-base words of the output (offsets are multiples of 32); lane = output word of 16 bases.
+    const uint32_t words = (L + 15) / 16;
+    for (uint32_t wi = lane; wi < words; wi += 64) {
+        uint32_t out = 0;
+        for (uint32_t j = 0; j < 16 && wi * 16 + j < L; j++) {
+            const uint32_t i = wi * 16 + j, src = primary_reverse ? L - 1 - i : i;
+            const uint32_t e = base_at(V.bases2, off, src);
+            out |= (primary_reverse ? 3u - e : e) << (2 * j);
+        }
+        V.out_bases2[(off >> 4) + wi] = out;
+    }
+    for (uint32_t wi = lane; wi < (L + 31) / 32; wi += 64) {
+        uint32_t out = 0;
+        for (uint32_t j = 0; j < 32 && wi * 32 + j < L; j++) {
+            const uint32_t i = wi * 32 + j, src = primary_reverse ? L - 1 - i : i;
+            out |= static_cast<uint32_t>(n_at(V.nmask, off, src)) << j;
+        }
+        V.out_nmask[(off >> 5) + wi] = out;
+    }
+}
+
+}  // namespace
+
+struct MapIndex {
+    DevBuf<MapSlot> table; DevBuf<uint64_t> entries; DevBuf<uint16_t> basis;
+    uint64_t mask = 0; uint32_t k = 0, n_basis = 0;
+};
+
+}  // namespace lcty
+
+using namespace lcty;
+
+extern "C" {
+
+int32_t lcty_map_params_default(lcty_map_params* p) {
+    return guarded([&] {
+        if (!p) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        memset(p, 0, sizeof(*p));
+        p->k = 15;                 // strobealign -k 15 in the reference's command line (genotype.rs:984)
+        p->stride = 5;
+        p->min_votes = 2;
+        p->max_occ = 0;            // 0: four times the number of basis alleles (strobealign -f / minimap2 -f: the most repetitive seeds are left out)
+        p->match = 2; p->mismatch = 8; p->end_bonus = 10;      // strobealign's scores
+        p->min_score = 50;         // samtools view -e "[AS] >= 50 || flag & 2304 == 0" (genotype.rs:1070)
+    });
+}
+
+int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uint32_t n_basis, uint32_t k) {
+    return guarded([&] {
+        if (!locus || !basis) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (n_basis == 0 || n_basis > MAP_MAX_BASIS) fail(LCTY_ERR_UNSUPPORTED, "1..%u basis alleles", MAP_MAX_BASIS);
+        if (k < 8 || k > 31) fail(LCTY_ERR_UNSUPPORTED, "seed length %u: 8..31", k);
+        lcty_ctx* ctx = locus->ctx;
+        ctx->activate();
+        hipStream_t s = ctx->stream;
+        for (uint32_t b = 0; b < n_basis; b++)
+            if (basis[b] >= locus->n_alleles) fail(LCTY_ERR_INVALID_INPUT, "basis allele %u >= %u", basis[b], locus->n_alleles);
+        std::vector<uint64_t> seq_off(locus->n_alleles + 1);
+        locus->d_seq_off.download(seq_off.data(), seq_off.size(), s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        std::unordered_map<uint64_t, std::vector<uint64_t>> runs;
+        std::vector<uint8_t> seq;
+        const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+        for (uint32_t b = 0; b < n_basis; b++) {
+            const uint64_t o = seq_off[basis[b]], len = seq_off[basis[b] + 1] - o;
+            seq.resize(len);
+            locus->d_seqs.download(seq.data(), len, s, o);
+            LCTY_HIP(hipStreamSynchronize(s));
+            uint64_t fw = 0, rv = 0, valid = 0;
+            for (uint64_t i = 0; i < len; i++) {
+                const uint8_t c = seq[i];
+                const uint32_t e = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+                if (e == 4) { valid = 0; fw = rv = 0; continue; }
+                fw = ((fw << 2) | e) & kmask;
+                rv = (rv >> 2) | (static_cast<uint64_t>(3u - e) << (2 * k - 2));
+                if (++valid >= k) {
+                    const bool fwd = fw <= rv;
+                    runs[fwd ? fw : rv].push_back((static_cast<uint64_t>(b) << 33) | ((i + 1 - k) << 1) | (fwd ? 1ull : 0ull));   // by allele, then position
+                }
+            }
+        }
+        uint64_t cap = 1024;
+        while (cap < 2 * runs.size()) cap <<= 1;
+        std::vector<MapSlot> table(cap, MapSlot{MAP_FREE, 0u, 0u});
+        std::vector<uint64_t> entries;
+        for (auto& kv : runs) {
+            uint64_t h = map_hash(kv.first) & (cap - 1);
+            while (table[h].key != MAP_FREE) h = (h + 1) & (cap - 1);
+            table[h] = MapSlot{kv.first, static_cast<uint32_t>(entries.size()), static_cast<uint32_t>(kv.second.size())};
+            entries.insert(entries.end(), kv.second.begin(), kv.second.end());
+        }
+        auto ix = std::make_shared<MapIndex>();
+        ix->table.alloc(cap); ix->table.upload(table.data(), cap, s);
+        ix->entries.alloc(std::max<size_t>(entries.size(), 1)); ix->entries.upload(entries.data(), entries.size(), s);
+        ix->basis.alloc(n_basis); ix->basis.upload(basis, n_basis, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        ix->mask = cap - 1; ix->k = k; ix->n_basis = n_basis;
+        locus->map_index = ix;
+    });
+}
+
+int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_params* params, uint64_t* aln_off, lcty_aln_rec* recs,
+                       uint64_t cap_recs, uint64_t* cigar_off, uint32_t* cigar, uint64_t cap_cigar, uint32_t* bases2_out, uint32_t* nmask_out) {
+    return guarded([&] {
+        if (!locus || !chunk || !params || !aln_off || !cigar_off) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        auto ix = std::static_pointer_cast<MapIndex>(locus->map_index);
+        if (!ix) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_build_map_index has not been called on this locus");
+        if (params->k != ix->k) fail(LCTY_ERR_INVALID_INPUT, "the index was built for k = %u", ix->k);
+        if (params->stride == 0 || params->match <= 0 || params->mismatch < 0 || params->end_bonus < 0) fail(LCTY_ERR_INVALID_INPUT, "mapper parameters");
+        lcty_ctx* ctx = locus->ctx;
+        ctx->activate();
+        hipStream_t s = ctx->stream;
+        const uint64_t n = chunk->n_pairs, n_mates = 2 * n;
+        aln_off[0] = 0; cigar_off[0] = 0;
+        if (n == 0) return;
+        const uint64_t nb = chunk->mate_off[n_mates];
+        for (uint64_t m = 0; m < n_mates; m++) {
+            if (chunk->mate_len[m] > MAP_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases (this one: %u)", MAP_MAX_LEN, chunk->mate_len[m]);
+            if (chunk->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
+            if (chunk->mate_len[m] && (chunk->mate_len[m] - params->k) / params->stride + 2 > 64 && chunk->mate_len[m] >= params->k)
+                fail(LCTY_ERR_UNSUPPORTED, "more than 64 seeds per read end: raise the stride");
+        }
+        DevBuf<uint32_t> d_len, d_b2, d_nm, d_nrec, d_ncig, d_ob2, d_onm;
+        DevBuf<uint64_t> d_off;
+        d_len.alloc(n_mates); d_len.upload(chunk->mate_len, n_mates, s);
+        d_off.alloc(n_mates + 1); d_off.upload(chunk->mate_off, n_mates + 1, s);
+        d_b2.alloc(std::max<uint64_t>(nb / 16, 1)); d_b2.upload(chunk->bases2, nb / 16, s);
+        d_nm.alloc(std::max<uint64_t>(nb / 32, 1)); d_nm.upload(chunk->nmask, nb / 32, s);
+        d_nrec.alloc(n_mates); d_ncig.alloc(n_mates);
+        MapView V{};
+        V.table = ix->table.p; V.mask = ix->mask; V.entries = ix->entries.p; V.basis = ix->basis.p; V.n_basis = ix->n_basis;
+        V.k = params->k; V.stride = params->stride; V.min_votes = std::max<uint32_t>(params->min_votes, 1);
+        V.max_occ = params->max_occ ? params->max_occ : 4 * ix->n_basis;
+        V.match = params->match; V.mismatch = params->mismatch; V.end_bonus = params->end_bonus; V.min_score = params->min_score;
+        V.seqs = locus->d_seqs.p; V.seq_off = locus->d_seq_off.p; V.allele_len = locus->d_allele_len.p;
+        V.n_mates = n_mates; V.mate_len = d_len.p; V.mate_off = d_off.p; V.bases2 = d_b2.p; V.nmask = d_nm.p;
+        V.paired = locus->bg.is_paired;
+        V.n_recs = d_nrec.p; V.n_cigar = d_ncig.p;
+        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<false>, dim3(static_cast<uint32_t>(n_mates)), dim3(64), 0, s, V); }, s);
+        LCTY_HIP(hipGetLastError());
+        std::vector<uint32_t> nrec(n_mates), ncig(n_mates);
+        d_nrec.download(nrec.data(), n_mates, s); d_ncig.download(ncig.data(), n_mates, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        std::vector<uint64_t> rec_at(n_mates), cig_at(n_mates), pair_cig(n);
+        uint64_t r = 0, c = 0;
+        for (uint64_t p = 0; p < n; p++) {
+            pair_cig[p] = c;
+            for (uint32_t e = 0; e < 2; e++) { rec_at[2 * p + e] = r; cig_at[2 * p + e] = c; r += nrec[2 * p + e]; c += ncig[2 * p + e]; }
+            aln_off[p + 1] = r; cigar_off[p + 1] = c;
+        }
+        if (!recs || !cigar || !bases2_out || !nmask_out) return;                // sizes only
+        if (r > cap_recs || c > cap_cigar) fail(LCTY_ERR_INVALID_INPUT, "room for %llu records and %llu CIGAR words is needed", (unsigned long long)r,
+                                                (unsigned long long)c);
+        DevBuf<uint64_t> d_rec_at, d_cig_at, d_pair_cig; DevBuf<lcty_aln_rec> d_recs; DevBuf<uint32_t> d_cigar;
+        d_rec_at.alloc(n_mates); d_rec_at.upload(rec_at.data(), n_mates, s);
+        d_cig_at.alloc(n_mates); d_cig_at.upload(cig_at.data(), n_mates, s);
+        d_pair_cig.alloc(n); d_pair_cig.upload(pair_cig.data(), n, s);
+        d_recs.alloc(std::max<uint64_t>(r, 1)); d_cigar.alloc(std::max<uint64_t>(c, 1));
+        d_ob2.alloc(std::max<uint64_t>(nb / 16, 1)); d_onm.alloc(std::max<uint64_t>(nb / 32, 1));
+        d_ob2.zero(s); d_onm.zero(s);
+        V.rec_at = d_rec_at.p; V.cig_at = d_cig_at.p; V.pair_cig = d_pair_cig.p; V.recs = d_recs.p; V.cigar = d_cigar.p;
+        V.out_bases2 = d_ob2.p; V.out_nmask = d_onm.p;
+        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<true>, dim3(static_cast<uint32_t>(n_mates)), dim3(64), 0, s, V); }, s);
+        LCTY_HIP(hipGetLastError());
+        d_recs.download(recs, r, s); d_cigar.download(cigar, c, s);
+        d_ob2.download(bases2_out, nb / 16, s); d_onm.download(nmask_out, nb / 32, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
+
+}  // extern "C"

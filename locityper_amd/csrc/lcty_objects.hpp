@@ -1,6 +1,7 @@
 // lcty_objects.hpp — the opaque handles behind include/locityper_hip.h.
 #pragma once
 
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -41,6 +42,7 @@ struct lcty_locus {
     // loop keeps them in LDS. Valid when both counts fit nine bits.
     lcty::DevBuf<double> d_wk, d_wc;
     bool weight_tables_valid = false;
+    std::shared_ptr<void> map_index;         // lcty_map.hip: k-mer index of the basis alleles (lcty_locus_build_map_index)
     lcty::DevBuf<uint64_t> d_kset;
     uint64_t kset_cap = 0;
     lcty::DevBuf<double> d_ins_lut;

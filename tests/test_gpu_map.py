@@ -1,0 +1,150 @@
+"""Candidate generation inside a locus (first slice; lcty_map.hip) against its Python restatement
+(tests/pyref_map.py), against the generator's truth, and through the rest of the path."""
+import numpy as np
+import pytest
+
+from locityper_amd import _lib, api, cdefs, synth
+from tests import pyref_map as R
+
+pytestmark = pytest.mark.gpu
+
+
+def fastq_orientation(ch):
+    """The generator's chunk holds SEQ as the BAM does (reverse-complemented for records on the reverse strand): back to the
+    orientation the sequencer gave, and without records."""
+    b2 = ch.bases2.copy(); nm = ch.nmask.copy()
+    for pair in range(ch.n_pairs):
+        j = int(ch.aln_off[pair])
+        first = {0: None, 1: None}
+        for i in range(int(ch.aln_off[pair]), int(ch.aln_off[pair + 1])):
+            fl = int(ch.recs["flags"][i])
+            e = 1 if fl & cdefs.FLAG_MATE2 else 0
+            if first[e] is None and not fl & (cdefs.FLAG_SECONDARY | cdefs.FLAG_SUPPL):
+                first[e] = fl
+        for e in (0, 1):
+            m = 2 * pair + e
+            ln, off = int(ch.mate_len[m]), int(ch.mate_off[m])
+            if ln == 0 or first[e] is None or not first[e] & cdefs.FLAG_REVERSE:
+                continue
+            bases = [(int(ch.bases2[(off + i) >> 4]) >> (2 * ((off + i) & 15))) & 3 for i in range(ln)]
+            isn = [(int(ch.nmask[(off + i) >> 5]) >> ((off + i) & 31)) & 1 for i in range(ln)]
+            for w in range((ln + 15) // 16):
+                b2[(off >> 4) + w] = 0
+            for w in range((ln + 31) // 32):
+                nm[(off >> 5) + w] = 0
+            for i in range(ln):
+                src = ln - 1 - i
+                b2[(off + i) >> 4] |= np.uint32((3 - bases[src]) << (2 * ((off + i) & 15)))
+                nm[(off + i) >> 5] |= np.uint32(isn[src] << ((off + i) & 31))
+    z = np.zeros(ch.n_pairs + 1, dtype=np.uint64)
+    return cdefs.ReadsChunk(ch.mate_len, ch.mate_off, b2, nm, z, np.zeros(0, dtype=cdefs.ALN_REC_DTYPE), z, np.zeros(0, dtype=np.uint32))
+
+
+def setup(gpu_ctx, n_alleles, n_pairs, base_len, seed):
+    L = synth.SynthLocus(n_alleles, n_pairs, seed=seed, base_len=base_len)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    return L, p, loc
+
+
+@pytest.mark.parametrize("basis,over", [([0, 1, 2, 3, 4, 5], {}), ([4, 1], {"stride": 11, "min_score": 120}), ([2], {"k": 11, "stride": 3, "min_votes": 3})])
+def test_mapper_equals_its_restatement(gpu_ctx, basis, over):
+    L, p, loc = setup(gpu_ctx, 6, 160, 5000, seed=3)
+    truth = L.reads(0, 160)
+    fq = fastq_orientation(truth)
+    mp = api.map_params(**over)
+    api.build_map_index(loc, basis, k=mp.k)
+    got = api.map_reads(loc, fq, mp)
+    aln_off, recs, cig_off, cigar, strands = R.map_chunk(fq, L.seqs, L.seq_off, basis, mp)
+    assert np.array_equal(got.aln_off, aln_off) and np.array_equal(got.cigar_off, cig_off)
+    assert np.array_equal(got.cigar, cigar)
+    want = np.array(recs, dtype=[("pos", "<u4"), ("contig", "<u2"), ("flags", "<u2"), ("n_cigar", "<u4"), ("cigar_rel", "<u4")])
+    for f in ("pos", "contig", "flags", "n_cigar", "cigar_rel"):
+        assert np.array_equal(got.recs[f], want[f]), f
+    # SEQ comes back in BAM orientation: reverse-complemented where the primary record is on the reverse strand
+    for m in range(2 * fq.n_pairs):
+        bases, isn = R.mate_bases(fq, m)
+        out, outn = R.mate_bases(got, m)
+        if strands[m]:
+            bases, isn = [3 - b for b in reversed(bases)], list(reversed(isn))
+        assert out == bases and outn == isn
+
+
+def test_mapper_finds_the_generators_alignments_and_the_path_calls_the_genotype(gpu_ctx):
+    """All alleles as the basis: every read end gets a record at the place the generator drew it from (same allele, same
+    position, same strand), and the mapped chunk through scoring + prefilter gives the true genotype — as the generator's own
+    chunk does."""
+    L, p, loc = setup(gpu_ctx, 6, 2500, 9000, seed=8)
+    truth = L.reads(0, 2500)
+    fq = fastq_orientation(truth)
+    mp = api.map_params()
+    api.build_map_index(loc, list(range(6)), k=mp.k)
+    got = api.map_reads(loc, fq, mp)
+    # back in BAM orientation: the read ends the generator aligned come back as the generator wrote them (a read end it left
+    # unmapped, or drew from elsewhere, has no orientation to agree on)
+    same = sum(R.mate_bases(got, m) == R.mate_bases(truth, m) for m in range(0, 2 * truth.n_pairs, 7))
+    assert same >= 0.93 * len(range(0, 2 * truth.n_pairs, 7)), same
+    hit = total = hit_exact = total_exact = 0
+    for pair in range(truth.n_pairs):
+        mine = {(int(r["contig"]), int(r["pos"]), int(r["flags"]) & (cdefs.FLAG_REVERSE | cdefs.FLAG_MATE2))
+                for r in got.recs[int(got.aln_off[pair]):int(got.aln_off[pair + 1])] if not int(r["flags"]) & cdefs.FLAG_UNMAPPED}
+        for r in truth.recs[int(truth.aln_off[pair]):int(truth.aln_off[pair + 1])]:
+            fl = int(r["flags"])
+            if fl & cdefs.FLAG_UNMAPPED or int(r["n_cigar"]) == 0:
+                continue
+            words = [int(w) for w in truth.cigar[int(truth.cigar_off[pair]) + int(r["cigar_rel"]):][:int(r["n_cigar"])]]
+            if any((w & 15) in (1, 2, 4) for w in words):
+                continue                                                         # clipped or gapped in the generator: not this slice
+            found = (int(r["contig"]), int(r["pos"]), fl & (cdefs.FLAG_REVERSE | cdefs.FLAG_MATE2)) in mine
+            total += 1; hit += found
+            if len(words) == 1:                                                  # the read end as it is on the allele
+                total_exact += 1; hit_exact += found
+    # exact placements are found — except for read ends that lie inside one of the generator's microsatellites (a tenth of a 9-kb
+    # synthetic locus): all their seeds are repetitive and do not vote, and they are exact at many shifts anyway; placements with
+    # mismatches lose seeds and, below half the votes of the read end's best candidate, are left out (as the reference's mapper
+    # does with -S 0.5): recovery brings those alleles back
+    assert total_exact > 3000 and hit_exact >= 0.85 * total_exact, (hit_exact, total_exact)
+    assert hit >= 0.75 * total, (hit, total)
+    aa = api.AllAlignments.load(loc, got)
+    ref = api.AllAlignments.load(loc, truth)
+    gts = api.generate_genotypes(6, 2)
+    assert tuple(gts[int(np.argmax(aa.run_filter()))]) == L.true_genotype == tuple(gts[int(np.argmax(ref.run_filter()))])
+
+
+def test_mapper_misuse_fails_loudly(gpu_ctx):
+    L, p, loc = setup(gpu_ctx, 4, 50, 4000, seed=5)
+    fq = fastq_orientation(L.reads(0, 50))
+    with pytest.raises(_lib.LocityperError):
+        api.map_reads(loc, fq, api.map_params())                            # no index yet
+    with pytest.raises(_lib.LocityperError):
+        api.build_map_index(loc, [9], k=15)                                 # not an allele of the locus
+    with pytest.raises(_lib.LocityperError):
+        api.build_map_index(loc, list(range(4)), k=40)
+    api.build_map_index(loc, [0, 1], k=15)
+    with pytest.raises(_lib.LocityperError):
+        api.map_reads(loc, fq, api.map_params(k=13))                        # the index was built for another k
+
+
+def test_basis_mapping_plus_alignment_recovery_carries_the_path(gpu_ctx):
+    """The reference's --basis flow without the external mapper: the read ends are mapped onto two basis alleles only, the other
+    four are reached through the haplotype-to-haplotype alignments (lcty_recover_alignments) — and the prefilter over the
+    recovered table finds the genotype the reads were drawn from, as it does with the generator's own records."""
+    from tests import oracle_ffi as O
+    L, p, loc = setup(gpu_ctx, 6, 2500, 9000, seed=8)
+    H = O.HapAlns(6, transfer_fails=100, max_div=0.1)
+    for q, r, words, nm, ln in L.hap_alns():
+        H.add(q, r, words)
+    H.sort()
+    loc.set_hap_alns(H.entries, transfer_fails=100, max_div=0.1)
+    fq = fastq_orientation(L.reads(0, 2500))
+    mp = api.map_params()
+    api.build_map_index(loc, [1, 4], k=mp.k)
+    mapped = api.map_reads(loc, fq, mp)
+    assert set(np.unique(mapped.recs["contig"][(mapped.recs["flags"] & cdefs.FLAG_UNMAPPED) == 0]).tolist()) == {1, 4}
+    aa = api.AllAlignments.load(loc, mapped)
+    before = int(aa.pair_alns()[0][-1])
+    n_rec = aa.recover()
+    after = int(aa.pair_alns()[0][-1])
+    assert n_rec > 4000 and after > 2 * before                                  # the other alleles came in
+    gts = api.generate_genotypes(6, 2)
+    assert tuple(gts[int(np.argmax(aa.run_filter()))]) == L.true_genotype
