@@ -21,7 +21,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         per[name][r["Dispatch_Id"]] += float(r["Counter_Value"])
         grid[name][r["Dispatch_Id"]] = float(r.get("Grid_Size") or 0)
     out = {}
