@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--ont-sample", type=int, default=2048,
                     help="reads of the extra long-read measurement (BASELINE.json configs[2] shape: 10 kb ONT reads x the locus' alleles, "
                          "the mapper reports the primaries, the other alleles are reached by alignment recovery); 0 = skip")
+    ap.add_argument("--many-alleles-sample", type=int, default=65536,
+                    help="read pairs of the extra measurement at 4 096 alleles (BASELINE.json configs[4], one GPU's shard): scoring and the "
+                         "prefilter as f64 tile kernel and as integer Gram contraction on the matrix cores; 0 = skip")
     ap.add_argument("--format", choices=("counted", "records"), default="counted",
                     help="how the alignment table reaches the library: 16-byte counted alignments (lcty_reads_append_counted, SURVEY 8(d)'s "
                          "alignment-table entry; the default) or BAM records with their CIGAR words (lcty_reads_append)")
@@ -570,6 +573,41 @@ def main():
                            "recover_and_rescore_s": t_rec, "set_hap_alns_s": t_set, "good_pairs_after": ab.n_good(),
                            "level_pairs": ab.recover_stats()}
         ab.close(); del prim
+
+    if args.many_alleles_sample > 0 and world == 1:
+        # ---- configs[4] shard shape: a locus of 4 096 alleles, the read pairs one of eight GPUs would hold. The prefilter is the
+        # dominant kernel there; from 512 alleles on it runs as an integer Gram contraction on the matrix cores (lcty_gram.hip) ----
+        nma, Ama = args.many_alleles_sample, 4096
+        ctx.trim()                                                                # the solver workspaces of the timed steps (160 GB) make room
+        Lm = synth.SynthLocus(Ama, nma, seed=synth.SEED + 5, base_len=3000)
+        pm = api.resolve_params(api.default_params(), Lm.bg)
+        locm = api.Locus(ctx, Lm.seqs, Lm.seq_off, Lm.counts, Lm.cnt_off, Lm.k, Lm.bg, pm)
+        am = None
+        for lo in range(0, nma, 4096):
+            chm = Lm.reads(lo, min(4096, nma - lo))
+            if am is None:
+                fm = 1.1 * nma / chm.n_pairs
+                am = api.AllAlignments(locm, nma, (int(chm.n_bases * fm) + 2048) // 32 * 32, int(len(chm.recs) * fm) + 4096, int(len(chm.cigar) * fm) + 65536)
+            am.append(chm)
+        ctx.timing_reset()
+        am.score(); ctx.synchronize()
+        _, ms_score_m = ctx.timing(api.K_SCORE)
+        leg = {"workload": f"{nma} read pairs x {Ama} alleles ({Ama * (Ama + 1) // 2} genotypes): the shard of one of eight GPUs of BASELINE configs[4]",
+               "score_reads_kernel_ms": ms_score_m}
+        scores_m = {}
+        for name, knob in (("f64_tile_kernel", 0), ("integer_gram_on_mfma", 1)):
+            ctx.set_knob("prefilter_gram", knob)
+            am.prefilter_async(); ctx.synchronize()
+            ctx.timing_reset()
+            am.prefilter_async(); ctx.synchronize()
+            leg[name + "_ms"] = ctx.timing(api.K_PREFILTER)[1]
+            scores_m[name] = am.prefilter_scores()
+        ctx.set_knob("prefilter_gram", -1)
+        leg["max_relative_difference"] = float(np.abs(scores_m["integer_gram_on_mfma"] - scores_m["f64_tile_kernel"]).max() / np.abs(scores_m["f64_tile_kernel"]).max())
+        best_m = api.generate_genotypes(Ama, 2)[int(np.argmax(scores_m["integer_gram_on_mfma"]))]
+        leg["best_genotype"] = [int(x) for x in best_m]; leg["true_genotype"] = list(Lm.true_genotype)
+        out["many_alleles"] = leg
+        am.close(); del scores_m
 
     if args.ont_sample > 0 and world == 1:
         # ---- configs[2] shape, the long-read DP path: 10-kb single-end ONT reads, primaries only, every other allele reached by

@@ -18,5 +18,5 @@ try:
     print({k:(round(v["launch_ms"],2), round(v["frac"],4)) for k,v in d["roofline_all"].items()}); print(d.get("vs_cpu_baseline"))
 except Exception as e: print("bench json:", e)
 PY
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${V} -o ${V} --output-format csv -- python3 bench.py --steps 4 --warmup 2 --recovery-sample 0 --recruit-sample 0 --ont-sample 0 --cpu-sample 0 --map-sample 0 > gpurun_out/${V}_prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${V} -o ${V} --output-format csv -- python3 bench.py --steps 4 --warmup 2 --recovery-sample 0 --recruit-sample 0 --ont-sample 0 --cpu-sample 0 --map-sample 0 --many-alleles-sample 0 > gpurun_out/${V}_prof_bench.log 2>&1
 head -8 gpurun_out/prof_${V}/*kernel_stats.csv 2>/dev/null | cut -c1-160

@@ -8,7 +8,7 @@ timeout 1200 python3 -m pytest tests/test_gpu_solve.py -m gpu -q -x -k "queue or
 grep -E "passed|failed|error" gpurun_out/${V}_pytest.log | tail -2; grep -E "^FAILED|^ERROR|^E  " gpurun_out/${V}_pytest.log | head -30
 
 cat gpurun_out/${V}_scale.log
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${V} -o ${V} --output-format csv -- python3 bench.py --steps 6 --warmup 2 --recovery-sample 0 --recruit-sample 0 --ont-sample 0 --cpu-sample 0 --map-sample 0 > gpurun_out/${V}_prof_bench.json 2> gpurun_out/${V}_prof_bench.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${V} -o ${V} --output-format csv -- python3 bench.py --steps 6 --warmup 2 --recovery-sample 0 --recruit-sample 0 --ont-sample 0 --cpu-sample 0 --map-sample 0 --many-alleles-sample 0 > gpurun_out/${V}_prof_bench.json 2> gpurun_out/${V}_prof_bench.err
 python3 - <<PY
 import json
 try:
