@@ -592,7 +592,7 @@ def main():
         ctx.timing_reset()
         am.score(); ctx.synchronize()
         _, ms_score_m = ctx.timing(api.K_SCORE)
-        leg = {"workload": f"{nma} read pairs x {Ama} alleles ({Ama * (Ama + 1) // 2} genotypes): the shard of one of eight GPUs of BASELINE configs[4]",
+        leg = {"workload": f"{nma} read pairs x {Ama} alleles ({Ama * (Ama + 1) // 2} genotypes): BASELINE configs[4] gives each of eight GPUs 625 000 read pairs of such a locus",
                "score_reads_kernel_ms": ms_score_m}
         scores_m = {}
         for name, knob in (("f64_tile_kernel", 0), ("integer_gram_on_mfma", 1)):
