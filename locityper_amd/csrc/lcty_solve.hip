@@ -1071,10 +1071,14 @@ struct AnnealRing {
     uint32_t produced, consumed, stop, go;
 };
 
-// WWL: the window weights in LDS (8 bytes per window) or gathered from the chain's row in L2 — the same latency chain (they travel
-// with the table gathers), a third of the LDS: next to the greedy chains of the following locus the LDS of the device is what runs out
-template <bool WWL>
+// Where the chain's window weights are (MODE): 0 gathered from its row in L2 with the table entries (the same latency chain, the
+// least LDS); 1 in LDS as they are (8 bytes per window); 2 as the greedy loop has them: the two table indices packed next to depth
+// and GC bin (6 bytes per window) and the two weight tables in LDS — no weight gathers and 15 KB per chain. Next to the greedy
+// chains of the following locus the LDS of the device is what runs out, and every gather shares the L2 -> L1 path with theirs.
+template <int MODE>
 __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) {
+    constexpr bool WWL = MODE == 1, LW = MODE == 2;
+    using ChainT = typename std::conditional<LW, ChainLW, Chain>::type;
     extern __shared__ __align__(32) uint8_t smem[];
     __shared__ uint32_t flagged;
     if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1084,11 +1088,14 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     // greedy wavefronts of the next locus, which always have an instruction ready. The issue arbiter takes the higher priority first.
     __builtin_amdgcn_s_setprio(3);
     const uint32_t W = V.wstride;
-    // [W] window weights first (WWL), then [W] depth | GC bin << 25, then the ring the second wavefront fills
-    const size_t ww_bytes = WWL ? static_cast<size_t>(W) * 8 : 0;
+    // [W] window weights first (MODE 1) or the two weight tables (MODE 2), then [W] depth words, [W] half-words (MODE 2), then the
+    // ring the second wavefront fills
+    const size_t head_bytes = WWL ? static_cast<size_t>(W) * 8 : LW ? static_cast<size_t>(V.n_wk + V.n_wc) * 8 : 0;
+    const size_t half_bytes = LW ? ((static_cast<size_t>(W) * 2 + 31) & ~static_cast<size_t>(31)) : 0;
     double* lww = reinterpret_cast<double*>(smem);
-    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + ww_bytes);
-    AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + ww_bytes + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
+    uint32_t* wd = reinterpret_cast<uint32_t*>(smem + head_bytes);
+    uint16_t* wh = reinterpret_cast<uint16_t*>(smem + head_bytes + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)));
+    AnnealRing* ring = reinterpret_cast<AnnealRing*>(smem + head_bytes + ((static_cast<size_t>(W) * 4 + 31) & ~static_cast<size_t>(31)) + half_bytes);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
@@ -1100,9 +1107,20 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     {
         const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
         const uint32_t* gd = V.c_depth + static_cast<uint64_t>(chain) * W;
-        for (uint32_t w = lane; wave == 0 && w < total_w; w += 64) {
-            wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
-            if (WWL) lww[w] = gww[w];
+        if constexpr (LW) {
+            const uint32_t* guc = V.c_uc + static_cast<uint64_t>(chain) * W;
+            for (uint32_t w = lane; wave == 0 && w < total_w; w += 64) {
+                const uint32_t uc = guc[w];
+                wd[w] = gd[w] | ((uc & 0xFFFFu) << LW_DEPTH_BITS);
+                wh[w] = static_cast<uint16_t>(ggc[w] | ((uc >> 16) << 7));
+            }
+            for (uint32_t i = threadIdx.x; i < V.n_wk; i += 128) lww[i] = V.wk[i];
+            for (uint32_t i = threadIdx.x; i < V.n_wc; i += 128) lww[V.n_wk + i] = V.wc[i];
+        } else {
+            for (uint32_t w = lane; wave == 0 && w < total_w; w += 64) {
+                wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
+                if (WWL) lww[w] = gww[w];
+            }
         }
     }
     const uint32_t nnt = V.c_nnt[chain];
@@ -1150,10 +1168,12 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         }
         return;
     }
-    Chain C{&V, wd, WWL ? lww : gww};
+    ChainT C;
+    if constexpr (LW) C = ChainLW{&V, wd, wh, lww, lww + V.n_wk};
+    else C = Chain{&V, wd, WWL ? lww : gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
-    for (uint32_t w = lane; w < total_w; w += 64) depth_lik += C.wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK);
+    for (uint32_t w = lane; w < total_w; w += 64) depth_lik += C.wlp_at(w);
     for (int o2 = 32; o2 > 0; o2 >>= 1) depth_lik += __shfl_xor(depth_lik, o2);
     double aln_lik = V.c_aln[chain];
     Xoshiro rng; rng.seed(seed);
@@ -1526,18 +1546,26 @@ void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t 
     LCTY_HIP(hipGetLastError());
 }
 
-template <bool WWL>
+template <int MODE>
 void launch_anneal_as(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
-    const size_t lds = (WWL ? static_cast<size_t>(V.wstride) * 8 : 0) + ((static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31)) + sizeof(AnnealRing) + 64;
+    const size_t words = (static_cast<size_t>(V.wstride) * 4 + 31) & ~static_cast<size_t>(31);
+    const size_t lds = (MODE == 1 ? static_cast<size_t>(V.wstride) * 8 : MODE == 2 ? static_cast<size_t>(V.n_wk + V.n_wc) * 8 + ((static_cast<size_t>(V.wstride) * 2 + 31) & ~static_cast<size_t>(31)) : 0) +
+                       words + sizeof(AnnealRing) + 64;
     if (lds > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(anneal_loop_kernel<WWL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(anneal_loop_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
-    ctx->timed(LCTY_K_ANNEAL, [&] { hipLaunchKernelGGL(anneal_loop_kernel<WWL>, dim3(nch), dim3(128), lds, s, V); }, s);
+    ctx->timed(LCTY_K_ANNEAL, [&] { hipLaunchKernelGGL(anneal_loop_kernel<MODE>, dim3(nch), dim3(128), lds, s, V); }, s);
     LCTY_HIP(hipGetLastError());
 }
 void launch_anneal(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
-    // lcty_ctx_set_knob "anneal_lds_weights": 1 keeps the chain's window weights in LDS (default: gathered, see the kernel)
-    if (ctx->knob("anneal_lds_weights", 0) != 0) launch_anneal_as<true>(ctx, V, nch, s); else launch_anneal_as<false>(ctx, V, nch, s);
+    // lcty_ctx_set_knob "anneal_lds_weights": 0 gathered, 1 in LDS as they are, 2 table indices + tables in LDS (the kernel's comment);
+    // default 2 where the locus has the tables and the depths fit their field, else 0
+    const bool tables = V.n_wk != 0 && 2 * static_cast<uint64_t>(V.n_good) + 2 <= LW_DEPTH_MASK;
+    int64_t mode = ctx->knob("anneal_lds_weights", tables ? 2 : 0);
+    if (mode == 2 && !tables) mode = 0;
+    if (mode == 2) launch_anneal_as<2>(ctx, V, nch, s);
+    else if (mode == 1) launch_anneal_as<1>(ctx, V, nch, s);
+    else launch_anneal_as<0>(ctx, V, nch, s);
 }
 
 // One stage = every (genotype, attempt) chain, in batches that fit the state budget. `after_batch(g0, ng, liks)` runs

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
 V=${1:-r2u}
-timeout 1200 python3 -m pytest tests/test_gpu_solve.py -m gpu -q -x -k "queue or scheme" > gpurun_out/${V}_pytest.log 2>&1
+timeout 1200 python3 -m pytest tests/test_gpu_solve.py -m gpu -q -x -k "queue or scheme or wavefront" > gpurun_out/${V}_pytest.log 2>&1
 grep -E "passed|failed|error" gpurun_out/${V}_pytest.log | tail -2; grep -E "^FAILED|^ERROR|^E  " gpurun_out/${V}_pytest.log | head -30
 
 cat gpurun_out/${V}_scale.log

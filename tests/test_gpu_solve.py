@@ -335,15 +335,16 @@ def test_chains_per_wavefront_and_wide_samples_do_not_change_results(gpu_ctx):
     finally:
         gpu_ctx.set_knob("solve_lds_weights", -1)
     assert np.array_equal(gathered[2], api.solve_stage(aa, gts, g, 2, seeds)[2])
-    # annealing with its window weights in LDS and gathered (the default): the same chains
+    # annealing with its window weights gathered, in LDS as they are, and as table indices + tables in LDS (the default): the same chains
     a = api.default_solver(cdefs.SOLVER_ANNEAL)
     a.anneal_steps, a.plato_size = 3000, 2000
     ref_a = compare_stage(aa, ol, oa, gts[:6], a, 2, seeds[:12])
-    gpu_ctx.set_knob("anneal_lds_weights", 1)
-    try:
-        assert np.array_equal(api.solve_stage(aa, gts[:6], a, 2, seeds[:12])[2], ref_a[2])
-    finally:
-        gpu_ctx.set_knob("anneal_lds_weights", -1)
+    for mode in (0, 1, 2):
+        gpu_ctx.set_knob("anneal_lds_weights", mode)
+        try:
+            assert np.array_equal(api.solve_stage(aa, gts[:6], a, 2, seeds[:12])[2], ref_a[2]), mode
+        finally:
+            gpu_ctx.set_knob("anneal_lds_weights", -1)
     # rows of 12 and 10 lanes against the oracle directly, with samples that fill them and samples that do not
     for cpw, sample in ((5, 12), (5, 7), (6, 10), (6, 3), (6, 12)):          # the last: a sample of 12 does not fit a row of 10 -> rows of 16
         g3 = api.default_solver(cdefs.SOLVER_GREEDY)
