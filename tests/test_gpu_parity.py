@@ -782,6 +782,17 @@ def test_chain_sharded_stage(gpu_ctx):
                     block[:hi - lo] = api.solve_stage(aa, gts[lo:hi], sv, attempts, seeds[attempts * lo:attempts * hi], priors=pri[lo:hi])[2]
                 gathered = np.concatenate([gathered, block])
             assert np.array_equal(gathered[:len(gts)], l1)
+    # a rank whose part fails reports its error through the one-word status exchange every rank joins before the data collective
+    # (agree_then, lcty_comm.hip) instead of leaving the others inside it; the communicator stays usable afterwards
+    bad = api.default_solver(cdefs.SOLVER_GREEDY)
+    bad.sample_size = 0
+    for call in (comm.solve_stage, comm.solve_stage_read_sharded):
+        with pytest.raises(_lib.LocityperError) as e:
+            call(aa, gts, bad, 1, api.chain_seeds(9, len(gts)))
+        assert e.value.code == cdefs.ERR_INVALID_INPUT
+    ok = api.default_solver(cdefs.SOLVER_GREEDY)
+    m_ok, _, _ = comm.solve_stage(aa, gts[:3], ok, 1, api.chain_seeds(9, 3))
+    assert np.array_equal(m_ok, api.solve_stage(aa, gts[:3], ok, 1, api.chain_seeds(9, 3))[0])
     comm.close()
 
 
