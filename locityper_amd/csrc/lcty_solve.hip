@@ -1224,13 +1224,13 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         auto ring_f64 = [&](uint32_t off) -> double {                      // rng.random::<f64>() at stream position consumed + off
             return static_cast<double>(ring->pos[(consumed + off) & (RING - 1)].draw >> 11) * (1.0 / 9007199254740992.0);
         };
-        // ReassignmentTarget::random (assgn.rs:451-471) at stream position consumed + off; returns the draws it takes
-        auto ring_move = [&](uint32_t off, Move& m) -> uint32_t {
+        // ReassignmentTarget::random (assgn.rs:451-471) at stream position consumed + off, given the `cur` word of its read's record;
+        // everything of the move but its depth term; returns the draws it takes
+        auto move_pre = [&](uint32_t off, uint32_t packed, Move& m) -> uint32_t {
             const StagedRead* e = &ring->pos[(consumed + off) & (RING - 1)];
             const uint64_t draw = e->draw, draw_next = ring->pos[(consumed + off + 1) & (RING - 1)].draw;
             const uint32_t nloc = e->nloc;
             m.slot = static_cast<uint32_t>(__umul64hi(draw, static_cast<uint64_t>(nnt)));
-            const uint32_t packed = load_rp_cur(&recs[m.slot]);            // only the current location is news
             const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24;
             uint32_t new_assgn;
             if (nloc == 2) new_assgn = 1 - old_assgn;
@@ -1253,10 +1253,41 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 const RecBody b = load_body(&recs[m.slot]);
                 rec_loc(b, extra, old_assgn, &m.lp_old, &w_o);
                 rec_loc(b, extra, new_assgn, &m.lp_new, &w_n);
+                asm volatile("" : "+v"(w_o), "+v"(w_n));                     // the wait for these loads stays in this rare branch
             }
             m.w1 = w_o & 0xFFFFu; m.w2 = w_o >> 16; m.w3 = w_n & 0xFFFFu; m.w4 = w_n >> 16;
-            m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
             return nloc > 2 ? 2u : 1u;
+        };
+        auto slot_at = [&](uint32_t off) -> uint32_t {
+            return static_cast<uint32_t>(__umul64hi(ring->pos[(consumed + off) & (RING - 1)].draw, static_cast<uint64_t>(nnt)));
+        };
+        auto ring_move = [&](uint32_t off, Move& m) -> uint32_t {          // with its own load of the `cur` word and its depth term at once
+            const uint32_t c = move_pre(off, load_rp_cur(&recs[slot_at(off)]), m);
+            m.ddiff = C.depth_lik_diff(m.w1, m.w2, m.w3, m.w4);
+            return c;
+        };
+        // The `cur` words of the staged positions ahead, one per lane, loaded ONE STEP AHEAD: the word of a read's record is the only
+        // thing of a move that comes from HBM at the time it is evaluated (the staging wavefront touched the record some tens of
+        // draws earlier; next to the greedy chains of the following locus the line has left the L2 by then), and it was a round
+        // trip of its own in front of the table gathers. pf of lane l is the word of position pf_base + l; the step that applied a
+        // move after the words were requested patches the one it changed (lm_*).
+        uint32_t pf = 0, pf_slot = 0xFFFFFFFFu, pf_base = 0, pf_n = 0, lm_slot = 0xFFFFFFFFu, lm_to = 0;
+        auto pf_issue = [&]() {                                               // one load per lane, no branch around it
+            const uint32_t avail = __hip_atomic_load(&ring->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - consumed;
+            pf_base = consumed; pf_n = min(avail, 64u);
+            pf_slot = lane < pf_n ? slot_at(lane) : 0u;
+            pf = load_rp_cur(&recs[pf_slot]);
+            lm_slot = 0xFFFFFFFFu;
+        };
+        auto pf_covered = [&]() -> uint32_t {                                 // positions from `consumed` on whose words are here
+            const uint32_t end = pf_base + pf_n;
+            return end - consumed <= 64u ? end - consumed : 0u;                // (unsigned: end < consumed wraps to a large number)
+        };
+        auto pf_take = [&](uint32_t off) -> uint32_t {                        // every lane calls it; valid for off < pf_covered()
+            const int src = static_cast<int>((consumed + off - pf_base) & 63u);
+            const uint32_t v = static_cast<uint32_t>(__shfl(static_cast<int>(pf), src));
+            const uint32_t vs = static_cast<uint32_t>(__shfl(static_cast<int>(pf_slot), src));
+            return vs == lm_slot ? (v & 0xFFFFFFu) | (lm_to << 24) : v;
         };
         auto retire = [&](uint32_t q) {                                    // the producer may reuse the ring entries of q draws
             consumed += q;
@@ -1284,11 +1315,18 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
             if (!ring_wait(3)) break;
             n_iter++;
             Move m; blank(m);
-            uint32_t c = ring_move(0, m);
+            if (pf_covered() < 1) pf_issue();                                  // the first step (or a ring that ran dry): wait for the words
+            uint32_t c = move_pre(0, pf_take(0), m);
+            {
+                typename ChainT::DepthGather g;
+                C.request(m.w1, m.w2, m.w3, m.w4, g);
+                pf_issue();                                                     // the words of the next step travel with this step's gathers
+                m.ddiff = C.finish(g);
+            }
             const double diff = improvement(m) - min_diff;
             bool accept = diff >= 0.0;
             if (!accept) { accept = ring_f64(c) <= exp(diff / (temp_step * static_cast<double>(i))); c++; }
-            if (accept) { reassign(m); curr_plato = 0; }
+            if (accept) { reassign(m); curr_plato = 0; lm_slot = m.slot; lm_to = m.new_assgn; }
             else { curr_plato++; }
             retire(c);
             if (!accept && curr_plato >= V.solver.plato_size) break;
@@ -1303,13 +1341,19 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         while (!lost && iter < max_iter && curr_plato < V.solver.plato_size) {
             const uint32_t avail = ring_wait(2);                           // a move may take the draw after its own
             if (!avail) break;
-            const uint32_t w = min(width, avail - 1);
+            if (pf_covered() < 2) pf_issue();
+            const uint32_t w = min(min(width, avail - 1), pf_covered());       // only positions whose `cur` words are here
             Move m; blank(m);
             bool accepted = false, wide = false;
-            if (lane < w) {
-                wide = ring_move(lane, m) == 2;
-                accepted = improvement(m) > min_diff;
+            const uint32_t packed = pf_take(lane);
+            if (lane < w) wide = move_pre(lane, packed, m) == 2;                // lanes beyond: windows 0, no effect
+            {
+                typename ChainT::DepthGather g;
+                C.request(m.w1, m.w2, m.w3, m.w4, g);
+                pf_issue();                                                     // the words of the next round travel with this round's gathers
+                m.ddiff = C.finish(g);
             }
+            accepted = lane < w && improvement(m) > min_diff;
             const unsigned long long acc = __ballot(accepted);
             const unsigned long long two = __ballot(wide);
             uint32_t q = 0, walked = 0;
@@ -1351,6 +1395,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 a.lp_old = __shfl(m.lp_old, hit); a.lp_new = __shfl(m.lp_new, hit); a.ddiff = __shfl(m.ddiff, hit);
                 reassign(a);
                 curr_plato = 0;
+                lm_slot = a.slot; lm_to = a.new_assgn;                          // the words requested above were read before this store
             }
             width = min(RING - 1, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
             retire(q);
