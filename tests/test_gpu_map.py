@@ -148,3 +148,61 @@ def test_basis_mapping_plus_alignment_recovery_carries_the_path(gpu_ctx):
     assert n_rec > 4000 and after > 2 * before                                  # the other alleles came in
     gts = api.generate_genotypes(6, 2)
     assert tuple(gts[int(np.argmax(aa.run_filter()))]) == L.true_genotype
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_mapper_on_random_inputs_equals_its_restatement(gpu_ctx, seed):
+    """Random alleles a few SNVs and an indel apart, read ends of 20..250 bases from either strand with errors, bases that are not
+    ACGT, read ends shorter than a seed, foreign read ends, single-end pairs; random parameters. Records, CIGAR words and SEQ
+    orientation must equal the restatement's."""
+    from tests.helpers import locus_arrays, make_bg
+    rng = np.random.default_rng(100 + seed)
+    base = rng.choice(list(b"ACGT"), size=2400).astype(np.uint8)
+    haps = []
+    for a in range(5):
+        h = base.copy()
+        for q in rng.integers(50, 2350, size=6):
+            h[q] = ord("ACGT"[(("ACGT".index(chr(h[q]))) + 1 + int(rng.integers(0, 3))) % 4])
+        h = h.tolist()
+        cut = int(rng.integers(300, 2000))
+        if a % 2:
+            del h[cut:cut + int(rng.integers(1, 9))]
+        else:
+            h[cut:cut] = rng.choice(list(b"ACGT"), size=int(rng.integers(1, 9))).tolist()
+        haps.append(bytearray(h))
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(haps, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def read_end():
+        kind = int(rng.integers(0, 10))
+        ln = int(rng.integers(20, 251)) if kind else int(rng.integers(1, 15))
+        if kind == 1:
+            s = bytes(rng.choice(list(b"ACGT"), size=ln).tolist())                       # foreign
+        else:
+            h = haps[int(rng.integers(0, 5))]
+            at = int(rng.integers(0, len(h) - ln))
+            s = bytearray(h[at:at + ln])
+            for _ in range(int(rng.integers(0, 4))):
+                q = int(rng.integers(0, ln)); s[q] = ord("ACGTN"[int(rng.integers(0, 5))])
+            s = bytes(s)
+        return (s.translate(comp)[::-1] if rng.integers(0, 2) else s).decode()
+    pairs = [{"seq1": read_end(), "seq2": read_end() if rng.integers(0, 6) else "", "recs": []} for _ in range(120)]
+    ch = cdefs.ReadsChunk.from_pairs(pairs)
+    basis = sorted(rng.choice(5, size=int(rng.integers(1, 6)), replace=False).tolist())
+    mp = api.map_params(k=int(rng.integers(9, 20)), stride=int(rng.integers(4, 9)), min_votes=int(rng.integers(1, 4)),
+                        min_score=int(rng.integers(0, 120)), max_occ=int(rng.integers(0, 3)) * 7)
+    api.build_map_index(loc, basis, k=mp.k)
+    got = api.map_reads(loc, ch, mp)
+    aln_off, recs, cig_off, cigar, strands = R.map_chunk(ch, seqs, seq_off, basis, mp)
+    assert np.array_equal(got.aln_off, aln_off) and np.array_equal(got.cigar_off, cig_off) and np.array_equal(got.cigar, cigar)
+    want = np.array(recs, dtype=[("pos", "<u4"), ("contig", "<u2"), ("flags", "<u2"), ("n_cigar", "<u4"), ("cigar_rel", "<u4")])
+    for f in ("pos", "contig", "flags", "n_cigar", "cigar_rel"):
+        assert np.array_equal(got.recs[f], want[f]), f
+    for m in range(2 * ch.n_pairs):
+        bases, isn = R.mate_bases(ch, m)
+        if strands[m]:
+            bases, isn = [3 - b for b in reversed(bases)], list(reversed(isn))
+        assert R.mate_bases(got, m) == (bases, isn)
