@@ -453,12 +453,13 @@ int32_t lcty_recruit(lcty_targets* targets, const lcty_reads_host* chunk, int32_
  * basis haplotypes when --basis is given (1007-1052) — and reads the resulting aln.bam. No mapper source is in the reference
  * tree; the algorithm of this slice is this build's own (locityper_amd/csrc/lcty_map.hip states it, tests/pyref_map.py restates
  * it): k-mer seeds every `stride` bases -> votes for (basis allele, strand, diagonal) -> per (allele, strand) the diagonal with
- * the most votes -> extension WITHOUT gaps (+match / -mismatch per base, end_bonus per read end reached; the best-scoring stretch,
- * the rest soft-clipped) -> the best candidate of a read end is its primary record, the others with score >= min_score secondary
+ * the most votes -> extension without gaps (+match / -mismatch per base, end_bonus per read end reached; the best-scoring stretch,
+ * the rest soft-clipped), and for a clipped candidate a gap-affine alignment in a band around its diagonal that replaces it when it
+ * scores higher -> the best candidate of a read end is its primary record, the others with score >= min_score secondary
  * records, a read end without candidates an unmapped record. Record order, flags, =/X/S CIGARs and SEQ orientation are those of
  * the BAM the reference reads, so the result is a chunk for lcty_reads_append; the alleles outside the basis are reached with
  * lcty_recover_alignments. Limits of the slice: read ends of up to 256 bases, up to 32 basis alleles, seed length 8..31, at most
- * 64 seeds per read end and 1 024 votes (the first ones in seed order); gapped extension is not built.
+ * 64 seeds per read end and 1 024 votes (the first ones in seed order).
  * lcty_locus_build_map_index: the k-mers of the basis alleles (host hash table, once per locus).
  * lcty_map_reads: only the sequence fields of `chunk` are read. aln_off / cigar_off [n_pairs + 1] are always written; with
  *   recs == NULL the call only sizes. bases2_out / nmask_out: the chunk's bases in BAM orientation (same offsets). */
@@ -466,6 +467,8 @@ typedef struct lcty_map_params {
     uint32_t k, stride, min_votes;
     uint32_t max_occ;            /* seeds with more places in the index do not vote; 0: four per basis allele */
     int32_t  match, mismatch, end_bonus, min_score;
+    uint32_t band;               /* diagonals on either side in the alignment with gaps of a clipped candidate (<= 16); 0: none */
+    int32_t  gap_open, gap_extend;   /* a gap of n bases costs gap_open + (n - 1) * gap_extend */
 } lcty_map_params;
 int32_t lcty_map_params_default(lcty_map_params* p);
 int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uint32_t n_basis, uint32_t k);

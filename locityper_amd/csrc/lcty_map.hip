@@ -15,9 +15,14 @@
 //            first 64 in (allele, strand, diagonal) order.
 //   extend   without gaps along the diagonal: +match per equal base, -mismatch otherwise (bases that are not ACGT never match),
 //            `end_bonus` for each read end reached; the best-scoring stretch is the alignment, the rest is soft-clipped
-//            ; per (allele, strand) the candidate with the best score stays (ties: the smallest diagonal)
-//            (first slice: reads across an indel between alleles get the longer side and a clip; the gap-affine extension with the
-//            aligner of lcty_transfer_device.hpp is the next slice).
+//            ; per (allele, strand) the candidate with the best score stays (ties: the smallest diagonal).
+//   gaps     a candidate that stayed and is clipped is aligned again WITH gaps: gap-affine (open + (n - 1) x extend for a gap of n) in
+//            a band of +-band diagonals around its own, starting and ending on an aligned base, soft clips and end bonuses as above
+//            (one lane = one candidate; M / deletion / insertion scores of the running row in LDS, one direction byte per cell
+//            in a scratch of the workgroup, traceback into = / X / I / D runs). It replaces the alignment without gaps when
+//            its score is higher. Order of preference on ties, fixed here and in the restatement: continue before starting
+//            afresh, M before deletion before insertion as predecessor, open before extend, the first best end cell by (read
+//            position, diagonal).
 //   records  the best candidate of a read end is its primary record, the others with a score >= min_score are secondary
 //            records (the samtools filter above); a read end without a candidate is an unmapped record. Record order, flags,
 //            =/X/S CIGARs and SEQ orientation (reverse-complemented when the primary is on the reverse strand) are those of
@@ -38,6 +43,11 @@ constexpr uint32_t MAP_MAX_LEN = 256;      // bases per read end
 constexpr uint32_t MAP_MAX_HITS = 1024;
 constexpr uint32_t MAP_MAX_BASIS = 32;
 constexpr uint32_t MAP_PER_SEED = 64;      // index entries a seed may vote with (the first ones: by allele, then position)
+constexpr uint32_t MAP_MAX_BAND = 16;      // diagonals on either side of a candidate's own in the alignment with gaps
+constexpr uint32_t MAP_BAND_W = 2 * MAP_MAX_BAND + 1;
+constexpr int32_t MAP_NEG = -(1 << 29);
+constexpr uint32_t MAP_OPS_CAP = MAP_MAX_LEN + 2 * MAP_MAX_BAND + 8;
+constexpr size_t MAP_LANE_SCRATCH = static_cast<size_t>(MAP_MAX_LEN) * MAP_BAND_W + MAP_OPS_CAP * 4;      // direction bytes + reversed CIGAR words
 
 struct MapSlot { uint64_t key; uint32_t start, count; };   // key ~0 = free
 constexpr uint64_t MAP_FREE = ~0ull;
@@ -51,8 +61,9 @@ struct MapView {
     const MapSlot* table; uint64_t mask;
     const uint64_t* entries;               // basis index << 33 | position << 1 | forward-is-canonical
     const uint16_t* basis;                 // basis index -> allele
-    uint32_t n_basis, k, stride, min_votes, max_occ;
-    int32_t match, mismatch, end_bonus, min_score;
+    uint32_t n_basis, k, stride, min_votes, max_occ, band;
+    int32_t match, mismatch, end_bonus, min_score, gap_open, gap_extend;
+    uint8_t* scratch;                      // [workgroups][64][MAP_LANE_SCRATCH]
     const uint8_t* seqs; const uint64_t* seq_off; const uint32_t* allele_len;
     // reads
     uint64_t n_mates;
@@ -78,13 +89,8 @@ __device__ __forceinline__ bool n_at(const uint32_t* nm, uint64_t off, uint32_t 
 __device__ __forceinline__ uint32_t enc_of(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
 
 template <bool WRITE>
-__global__ __launch_bounds__(64) void map_kernel(const MapView V) {
-    __shared__ uint64_t keys[MAP_MAX_HITS];
-    __shared__ unsigned long long best[2 * MAP_MAX_BASIS];
-    __shared__ uint64_t cand_key[64];
+__device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsigned long long* best, uint64_t* cand_key, int32_t* dp) {
     const uint32_t lane = threadIdx.x;
-    const uint64_t m = blockIdx.x;
-    if (m >= V.n_mates) return;
     const uint32_t L = V.mate_len[m];
     if (L == 0) {                                                               // absent read end (single-end data)
         if (!WRITE && lane == 0) { V.n_recs[m] = 0; V.n_cigar[m] = 0; }
@@ -220,6 +226,87 @@ __global__ __launch_bounds__(64) void map_kernel(const MapView V) {
         atomicMax(&best[g], (static_cast<unsigned long long>(static_cast<uint32_t>(score) ^ 0x80000000u) << 32) | (63u - lane));
     __syncthreads();
     const bool have = cand && score > INT32_MIN && static_cast<uint32_t>(best[g]) == 63u - lane;
+    // ---- a clipped candidate again, with gaps (the header comment states the recurrence and the tie rules)
+    bool gapped = false;
+    uint32_t g_ops = 0, g_lead = 0, g_trail = 0, g_pos = 0;
+    uint8_t* dirs = V.scratch + (static_cast<size_t>(blockIdx.x) * 64 + lane) * MAP_LANE_SCRATCH;
+    uint32_t* rops = reinterpret_cast<uint32_t*>(dirs + static_cast<size_t>(MAP_MAX_LEN) * MAP_BAND_W);      // CIGAR words, last first
+    auto equal_ref = [&](uint32_t i, int64_t refpos) -> bool {
+        const uint32_t src = strand ? L - 1 - i : i;
+        if (n_at(V.nmask, off, src)) return false;
+        const uint32_t e = strand ? 3u - base_at(V.bases2, off, src) : base_at(V.bases2, off, src);
+        return enc_of(ref[refpos]) == e;
+    };
+    const bool need = have && V.band > 0 && (s_best > 0 || e_best < L);
+    if (__any(need)) {
+        if (need) {
+            const int32_t B = static_cast<int32_t>(V.band), W = 2 * B + 1;
+            int32_t* M = dp + lane; int32_t* E = dp + MAP_BAND_W * 64 + lane; int32_t* F = dp + 2 * MAP_BAND_W * 64 + lane;      // [k * 64]
+            for (int32_t k = 0; k < W; k++) { M[k * 64] = MAP_NEG; E[k * 64] = MAP_NEG; F[k * 64] = MAP_NEG; }
+            int32_t best_total = INT32_MIN; uint32_t end_i = 0; int32_t end_k = 0;
+            for (uint32_t i = 0; i < L; i++) {
+                int32_t left_m = MAP_NEG, left_e = MAP_NEG;
+                const int32_t fresh = i == 0 ? V.end_bonus : 0;
+                for (int32_t k = 0; k < W; k++) {
+                    const int64_t refpos = diag + static_cast<int64_t>(i) + (k - B);
+                    const bool inref = refpos >= 0 && refpos < alen;
+                    const int32_t om = M[k * 64], oe = E[k * 64], of = F[k * 64];
+                    const int32_t rm = k + 1 < W ? M[(k + 1) * 64] : MAP_NEG, rf = k + 1 < W ? F[(k + 1) * 64] : MAP_NEG;
+                    int32_t prev = om; uint32_t code = 1;
+                    if (oe > prev) { prev = oe; code = 2; }
+                    if (of > prev) { prev = of; code = 3; }
+                    if (fresh > prev) { prev = fresh; code = 0; }
+                    int32_t nm = inref ? prev + (equal_ref(i, refpos) ? V.match : -V.mismatch) : MAP_NEG;
+                    const int32_t fo = rm - V.gap_open, fe = rf - V.gap_extend;
+                    int32_t nf = fe > fo ? fe : fo; const uint32_t fcode = fe > fo ? 1u : 0u;
+                    const int32_t eo = left_m - V.gap_open, ee = left_e - V.gap_extend;
+                    int32_t ne = ee > eo ? ee : eo; const uint32_t ecode = ee > eo ? 1u : 0u;
+                    if (!inref) ne = MAP_NEG;
+                    if (nm < MAP_NEG / 2) nm = MAP_NEG;
+                    if (nf < MAP_NEG / 2) nf = MAP_NEG;
+                    if (ne < MAP_NEG / 2) ne = MAP_NEG;
+                    dirs[static_cast<size_t>(i) * MAP_BAND_W + k] = static_cast<uint8_t>(code | (ecode << 2) | (fcode << 3));
+                    M[k * 64] = nm; E[k * 64] = ne; F[k * 64] = nf;
+                    left_m = nm; left_e = ne;
+                    if (nm > MAP_NEG) {
+                        const int32_t total = nm + (i + 1 == L ? V.end_bonus : 0);
+                        if (total > best_total) { best_total = total; end_i = i; end_k = k; }
+                    }
+                }
+            }
+            if (best_total > score) {
+                // traceback: CIGAR words last first
+                uint32_t i = end_i; int32_t k = end_k; uint32_t state = 0, n = 0, cur_op = 0xFFFFFFFFu, cur_len = 0;
+                auto emit = [&](uint32_t op) {
+                    if (op == cur_op) { cur_len++; return; }
+                    if (cur_len) rops[n++] = (cur_len << 4) | cur_op;
+                    cur_op = op; cur_len = 1;
+                };
+                for (;;) {
+                    const uint8_t d = dirs[static_cast<size_t>(i) * MAP_BAND_W + k];
+                    if (state == 0) {
+                        emit(equal_ref(i, diag + static_cast<int64_t>(i) + (k - B)) ? 7u : 8u);
+                        const uint32_t c = d & 3u;
+                        if (c == 0) break;
+                        state = c - 1;                                          // 1 -> M, 2 -> deletion, 3 -> insertion; all at (i - 1, k)
+                        i--;
+                    } else if (state == 1) {
+                        emit(2u);                                               // D
+                        state = (d >> 2) & 1u ? 1u : 0u;
+                        k--;
+                    } else {
+                        emit(1u);                                               // I
+                        state = (d >> 3) & 1u ? 2u : 0u;
+                        i--; k++;
+                    }
+                }
+                if (cur_len) rops[n++] = (cur_len << 4) | cur_op;
+                gapped = true; score = best_total;
+                g_lead = i; g_trail = L - 1 - end_i; g_ops = n + (g_lead > 0) + (g_trail > 0);
+                g_pos = static_cast<uint32_t>(diag + static_cast<int64_t>(i) + (k - B));
+            }
+        }
+    }
     // ---- the primary record: best score, the smallest (allele, strand) on ties (the lanes are in that order)
     int32_t top = have ? score : INT32_MIN;
     for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o));
@@ -228,7 +315,8 @@ __global__ __launch_bounds__(64) void map_kernel(const MapView V) {
     const bool keep = have && (lane == lp || score >= V.min_score);
     // CIGAR words of a kept candidate: [S] runs of = / X [S]
     uint32_t n_ops = 0;
-    if (keep) {
+    if (keep && gapped) n_ops = g_ops;
+    else if (keep) {
         n_ops = (s_best > 0) + (e_best < L);
         bool prev = false;
         for (uint32_t i = s_best; i < e_best; i++) { const bool eq = equal_at(i); if (i == s_best || eq != prev) n_ops++; prev = eq; }
@@ -253,17 +341,24 @@ __global__ __launch_bounds__(64) void map_kernel(const MapView V) {
         const uint32_t cig_rel = lane == lp ? 0u : ops_primary + ops_incl - n_ops;
         uint32_t* cg = V.cigar + cig0 + cig_rel;
         uint32_t w = 0;
-        if (s_best > 0) cg[w++] = (s_best << 4) | 4u;                            // S
-        bool prev = false; uint32_t len = 0;
-        for (uint32_t i = s_best; i < e_best; i++) {
-            const bool eq = equal_at(i);
-            if (i > s_best && eq != prev) { cg[w++] = (len << 4) | (prev ? 7u : 8u); len = 0; }      // = / X
-            prev = eq; len++;
+        if (gapped) {
+            if (g_lead > 0) cg[w++] = (g_lead << 4) | 4u;
+            const uint32_t inner = g_ops - (g_lead > 0) - (g_trail > 0);
+            for (uint32_t j = 0; j < inner; j++) cg[w++] = rops[inner - 1 - j];
+            if (g_trail > 0) cg[w++] = (g_trail << 4) | 4u;
+        } else {
+            if (s_best > 0) cg[w++] = (s_best << 4) | 4u;                        // S
+            bool prev = false; uint32_t len = 0;
+            for (uint32_t i = s_best; i < e_best; i++) {
+                const bool eq = equal_at(i);
+                if (i > s_best && eq != prev) { cg[w++] = (len << 4) | (prev ? 7u : 8u); len = 0; }      // = / X
+                prev = eq; len++;
+            }
+            cg[w++] = (len << 4) | (prev ? 7u : 8u);
+            if (e_best < L) cg[w++] = ((L - e_best) << 4) | 4u;
         }
-        cg[w++] = (len << 4) | (prev ? 7u : 8u);
-        if (e_best < L) cg[w++] = ((L - e_best) << 4) | 4u;
         const uint16_t flags = static_cast<uint16_t>((strand ? LCTY_FLAG_REVERSE : 0u) | (lane == lp ? 0u : LCTY_FLAG_SECONDARY) | mate2);
-        V.recs[rec0 + rank] = lcty_aln_rec{static_cast<uint32_t>(diag + s_best), static_cast<uint16_t>(allele), flags, n_ops,
+        V.recs[rec0 + rank] = lcty_aln_rec{gapped ? g_pos : static_cast<uint32_t>(diag + s_best), static_cast<uint16_t>(allele), flags, n_ops,
                                            static_cast<uint32_t>(rel0 + cig_rel)};
     }
     // SEQ as the BAM has it: reverse-complemented when the primary record is on the reverse strand. The read end owns whole
@@ -288,10 +383,23 @@ __global__ __launch_bounds__(64) void map_kernel(const MapView V) {
     }
 }
 
+// a fixed number of workgroups (their scratch is per workgroup) that take the read ends in turn
+template <bool WRITE>
+__global__ __launch_bounds__(64) void map_kernel(const MapView V) {
+    __shared__ uint64_t keys[MAP_MAX_HITS];
+    __shared__ unsigned long long best[2 * MAP_MAX_BASIS];
+    __shared__ uint64_t cand_key[64];
+    __shared__ int32_t dp[3 * MAP_BAND_W * 64];
+    for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) {
+        map_one<WRITE>(V, m, keys, best, cand_key, dp);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 struct MapIndex {
-    DevBuf<MapSlot> table; DevBuf<uint64_t> entries; DevBuf<uint16_t> basis;
+    DevBuf<MapSlot> table; DevBuf<uint64_t> entries; DevBuf<uint16_t> basis; DevBuf<uint8_t> scratch;
     uint64_t mask = 0; uint32_t k = 0, n_basis = 0;
 };
 
@@ -310,6 +418,7 @@ int32_t lcty_map_params_default(lcty_map_params* p) {
         p->min_votes = 2;
         p->max_occ = 0;            // 0: four times the number of basis alleles (strobealign -f / minimap2 -f: the most repetitive seeds are left out)
         p->match = 2; p->mismatch = 8; p->end_bonus = 10;      // strobealign's scores
+        p->band = 16; p->gap_open = 12; p->gap_extend = 1;     // a gap of n bases costs gap_open + (n - 1) * gap_extend; band 0: no alignment with gaps
         p->min_score = 50;         // samtools view -e "[AS] >= 50 || flag & 2304 == 0" (genotype.rs:1070)
     });
 }
@@ -375,7 +484,9 @@ int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lc
         auto ix = std::static_pointer_cast<MapIndex>(locus->map_index);
         if (!ix) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_build_map_index has not been called on this locus");
         if (params->k != ix->k) fail(LCTY_ERR_INVALID_INPUT, "the index was built for k = %u", ix->k);
-        if (params->stride == 0 || params->match <= 0 || params->mismatch < 0 || params->end_bonus < 0) fail(LCTY_ERR_INVALID_INPUT, "mapper parameters");
+        if (params->stride == 0 || params->match <= 0 || params->mismatch < 0 || params->end_bonus < 0 || params->gap_open < 0 || params->gap_extend < 0)
+            fail(LCTY_ERR_INVALID_INPUT, "mapper parameters");
+        if (params->band > MAP_MAX_BAND) fail(LCTY_ERR_UNSUPPORTED, "band of at most %u diagonals on either side", MAP_MAX_BAND);
         lcty_ctx* ctx = locus->ctx;
         ctx->activate();
         hipStream_t s = ctx->stream;
@@ -401,11 +512,15 @@ int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lc
         V.k = params->k; V.stride = params->stride; V.min_votes = std::max<uint32_t>(params->min_votes, 1);
         V.max_occ = params->max_occ ? params->max_occ : 4 * ix->n_basis;
         V.match = params->match; V.mismatch = params->mismatch; V.end_bonus = params->end_bonus; V.min_score = params->min_score;
+        V.band = params->band; V.gap_open = params->gap_open; V.gap_extend = params->gap_extend;
+        const uint32_t n_wg = static_cast<uint32_t>(std::min<uint64_t>(n_mates, 8ull * static_cast<uint64_t>(ctx->props.multiProcessorCount)));
+        ix->scratch.ensure(static_cast<size_t>(n_wg) * 64 * MAP_LANE_SCRATCH);
+        V.scratch = ix->scratch.p;
         V.seqs = locus->d_seqs.p; V.seq_off = locus->d_seq_off.p; V.allele_len = locus->d_allele_len.p;
         V.n_mates = n_mates; V.mate_len = d_len.p; V.mate_off = d_off.p; V.bases2 = d_b2.p; V.nmask = d_nm.p;
         V.paired = locus->bg.is_paired;
         V.n_recs = d_nrec.p; V.n_cigar = d_ncig.p;
-        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<false>, dim3(static_cast<uint32_t>(n_mates)), dim3(64), 0, s, V); }, s);
+        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<false>, dim3(n_wg), dim3(64), 0, s, V); }, s);
         LCTY_HIP(hipGetLastError());
         std::vector<uint32_t> nrec(n_mates), ncig(n_mates);
         d_nrec.download(nrec.data(), n_mates, s); d_ncig.download(ncig.data(), n_mates, s);
@@ -429,7 +544,7 @@ int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lc
         d_ob2.zero(s); d_onm.zero(s);
         V.rec_at = d_rec_at.p; V.cig_at = d_cig_at.p; V.pair_cig = d_pair_cig.p; V.recs = d_recs.p; V.cigar = d_cigar.p;
         V.out_bases2 = d_ob2.p; V.out_nmask = d_onm.p;
-        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<true>, dim3(static_cast<uint32_t>(n_mates)), dim3(64), 0, s, V); }, s);
+        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<true>, dim3(n_wg), dim3(64), 0, s, V); }, s);
         LCTY_HIP(hipGetLastError());
         d_recs.download(recs, r, s); d_cigar.download(cigar, c, s);
         d_ob2.download(bases2_out, nb / 16, s); d_onm.download(nmask_out, nb / 32, s);

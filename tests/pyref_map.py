@@ -37,6 +37,80 @@ def mate_bases(ch, m):
     return bases, isn
 
 
+NEG = -(1 << 29)
+
+
+def gapped(L, diag, ref, equal_ref, p):
+    """The clipped candidate again, with gaps: gap-affine in a band of +-p.band diagonals around `diag`, starting and ending on an
+    aligned base. -> (score, first read position, last read position, reference position of the first column, CIGAR words
+    without the soft clips) or None. equal_ref(i, refpos): base i of the read end (alignment orientation) equals ref[refpos]."""
+    B = p.band
+    W = 2 * B + 1
+    M, E, F = [NEG] * W, [NEG] * W, [NEG] * W
+    dirs = [[0] * W for _ in range(L)]
+    best_total, end_i, end_k = None, 0, 0
+    for i in range(L):
+        left_m = left_e = NEG
+        fresh = p.end_bonus if i == 0 else 0
+        for k in range(W):
+            refpos = diag + i + (k - B)
+            inref = 0 <= refpos < len(ref)
+            om, oe, of = M[k], E[k], F[k]
+            rm, rf = (M[k + 1], F[k + 1]) if k + 1 < W else (NEG, NEG)
+            prev, code = om, 1
+            if oe > prev:
+                prev, code = oe, 2
+            if of > prev:
+                prev, code = of, 3
+            if fresh > prev:
+                prev, code = fresh, 0
+            nm = prev + (p.match if equal_ref(i, refpos) else -p.mismatch) if inref else NEG
+            fo, fe = rm - p.gap_open, rf - p.gap_extend
+            nf, fcode = (fe, 1) if fe > fo else (fo, 0)
+            eo, ee = left_m - p.gap_open, left_e - p.gap_extend
+            ne, ecode = (ee, 1) if ee > eo else (eo, 0)
+            if not inref:
+                ne = NEG
+            nm = NEG if nm < NEG // 2 else nm
+            nf = NEG if nf < NEG // 2 else nf
+            ne = NEG if ne < NEG // 2 else ne
+            dirs[i][k] = code | (ecode << 2) | (fcode << 3)
+            M[k], E[k], F[k] = nm, ne, nf
+            left_m, left_e = nm, ne
+            if nm > NEG:
+                total = nm + (p.end_bonus if i + 1 == L else 0)
+                if best_total is None or total > best_total:
+                    best_total, end_i, end_k = total, i, k
+    if best_total is None:
+        return None
+    i, k, state, ops = end_i, end_k, 0, []                      # ops last first, as (op, length) runs
+    def emit(op):
+        if ops and ops[-1][0] == op:
+            ops[-1][1] += 1
+        else:
+            ops.append([op, 1])
+    while True:
+        d = dirs[i][k]
+        if state == 0:
+            emit(7 if equal_ref(i, diag + i + (k - B)) else 8)
+            c = d & 3
+            if c == 0:
+                break
+            state = c - 1
+            i -= 1
+        elif state == 1:
+            emit(2)
+            state = 1 if (d >> 2) & 1 else 0
+            k -= 1
+        else:
+            emit(1)
+            state = 2 if (d >> 3) & 1 else 0
+            i -= 1
+            k += 1
+    words = [(n << 4) | op for op, n in reversed(ops)]
+    return best_total, i, end_i, diag + i + (k - B), words
+
+
 def map_mate(bases, isn, index, seqs, seq_off, basis, p):
     """-> list of (allele, strand, pos, score, cigar words), primary first; [] = unmapped"""
     L, k = len(bases), p.k
@@ -112,8 +186,25 @@ def map_mate(bases, isn, index, seqs, seq_off, basis, p):
         cig.append((ln << 4) | (7 if prev else 8))
         if e_best < L:
             cig.append(((L - e_best) << 4) | 4)
-        per_group[g] = (g, allele, strand, diag + s_best, score, cig)
-    cands = [per_group[g] for g in sorted(per_group)]
+        per_group[g] = (g, allele, strand, diag + s_best, score, cig, diag, s_best, e_best)
+    cands = []
+    for g in sorted(per_group):
+        (_, allele, strand, pos, score, cig, diag, s_best, e_best) = per_group[g]
+        if getattr(p, "band", 0) > 0 and (s_best > 0 or e_best < L):
+            ref = bytes(seqs[int(seq_off[allele]):int(seq_off[allele + 1])])
+
+            def equal_ref(i, refpos, strand=strand, ref=ref):
+                src = L - 1 - i if strand else i
+                if isn[src]:
+                    return False
+                e = 3 - bases[src] if strand else bases[src]
+                return ENC.get(ref[refpos], 4) == e
+            got = gapped(L, diag, ref, equal_ref, p)
+            if got is not None and got[0] > score:
+                gscore, first, last, gpos, words = got
+                cig = ([(first << 4) | 4] if first > 0 else []) + words + ([((L - 1 - last) << 4) | 4] if last < L - 1 else [])
+                pos, score = gpos, gscore
+        cands.append((g, allele, strand, pos, score, cig))
     if not cands:
         return []
     top = max(c[4] for c in cands)

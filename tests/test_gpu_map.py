@@ -193,7 +193,8 @@ def test_mapper_on_random_inputs_equals_its_restatement(gpu_ctx, seed):
     ch = cdefs.ReadsChunk.from_pairs(pairs)
     basis = sorted(rng.choice(5, size=int(rng.integers(1, 6)), replace=False).tolist())
     mp = api.map_params(k=int(rng.integers(9, 20)), stride=int(rng.integers(4, 9)), min_votes=int(rng.integers(1, 4)),
-                        min_score=int(rng.integers(0, 120)), max_occ=int(rng.integers(0, 3)) * 7)
+                        min_score=int(rng.integers(0, 120)), max_occ=int(rng.integers(0, 3)) * 7, band=int(rng.choice([0, 3, 16])),
+                        gap_open=int(rng.integers(2, 14)), gap_extend=int(rng.integers(0, 3)))
     api.build_map_index(loc, basis, k=mp.k)
     got = api.map_reads(loc, ch, mp)
     aln_off, recs, cig_off, cigar, strands = R.map_chunk(ch, seqs, seq_off, basis, mp)
@@ -206,3 +207,32 @@ def test_mapper_on_random_inputs_equals_its_restatement(gpu_ctx, seed):
         if strands[m]:
             bases, isn = [3 - b for b in reversed(bases)], list(reversed(isn))
         assert R.mate_bases(got, m) == (bases, isn)
+
+
+def test_mapper_aligns_clipped_candidates_with_gaps(gpu_ctx):
+    """Read ends across a 4-base deletion / a 3-base insertion relative to the allele: end to end with one D / I run on the device
+    as in the restatement (tests/test_pyref_map.py derives these records by hand); without a band they stay clipped."""
+    from tests.helpers import locus_arrays, make_bg
+    rng = np.random.default_rng(21)
+    allele = bytes(rng.choice(list(b"ACGT"), size=2000).tolist())
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays([bytearray(allele)], 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    r_del = allele[500:580] + allele[584:654]
+    ins = b"TTG" if allele[1079:1082] != b"TTG" else b"CCA"
+    r_ins = allele[1000:1080] + ins + allele[1080:1147]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    ch = cdefs.ReadsChunk.from_pairs([{"seq1": r_del.decode(), "seq2": r_ins.translate(comp)[::-1].decode(), "recs": []}])
+    api.build_map_index(loc, [0], k=15)
+    for band in (16, 0):
+        mp = api.map_params(band=band)
+        got = api.map_reads(loc, ch, mp)
+        aln_off, recs, cig_off, cigar, strands = R.map_chunk(ch, seqs, seq_off, [0], mp)
+        assert np.array_equal(got.cigar, cigar) and [tuple(int(x) for x in r) for r in got.recs.tolist()] == [tuple(r) for r in recs]
+        ops = [[int(w) & 15 for w in got.cigar[int(r["cigar_rel"]):int(r["cigar_rel"]) + int(r["n_cigar"])]] for r in got.recs]
+        if band:
+            assert ops == [[7, 2, 7], [7, 1, 7]] and int(got.recs["flags"][1]) & cdefs.FLAG_REVERSE
+            assert [int(x) for x in got.recs["pos"]] == [500, 1000]
+        else:
+            assert all(4 in o and 1 not in o and 2 not in o for o in ops)

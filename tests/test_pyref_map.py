@@ -7,7 +7,7 @@ from tests import pyref_map as R
 
 
 class P:
-    k, stride, min_votes, max_occ, match, mismatch, end_bonus, min_score = 15, 5, 2, 0, 2, 8, 10, 50
+    k, stride, min_votes, max_occ, match, mismatch, end_bonus, min_score, band, gap_open, gap_extend = 15, 5, 2, 0, 2, 8, 10, 50, 16, 12, 1
 
 
 def test_known_placements():
@@ -53,3 +53,28 @@ def test_repetitive_seeds_do_not_vote():
     aln_off, recs, cig_off, cigar, strands = R.map_chunk(ch, seqs, seq_off, [0], P)
     assert recs[0][2] & R.FLAG_UNMAPPED
     assert recs[1][:3] == (330, 0, R.FLAG_MATE2) and int(cigar[recs[1][4]]) == (150 << 4) | 7
+
+
+def test_known_gapped_placements():
+    """A read end across a 4-base deletion and one with a 3-base insertion relative to the allele: without gaps they are clipped at
+    the indel, with gaps they are end to end (scores by hand: 2 per match, 12 + extend per further gap base, 10 per end reached)."""
+    rng = np.random.default_rng(21)
+    allele = bytes(rng.choice(list(b"ACGT"), size=2000).tolist())
+    seqs = np.frombuffer(allele, dtype=np.uint8)
+    seq_off = np.array([0, 2000], dtype=np.uint64)
+    r_del = allele[500:580] + allele[584:654]                                  # 150 bases, the allele has 4 more in the middle
+    ins = b"TTG" if allele[1079:1082] != b"TTG" else b"CCA"
+    r_ins = allele[1000:1080] + ins + allele[1080:1147]                        # 150 bases, 3 of them not on the allele
+    ch = ReadsChunk.from_pairs([{"seq1": r_del.decode(), "seq2": r_ins.decode(), "recs": []}])
+    aln_off, recs, cig_off, cigar, strands = R.map_chunk(ch, seqs, seq_off, [0], P)
+    op = lambda n, c: (n << 4) | "MIDNSHP=X".index(c)
+    w0 = [int(w) for w in cigar[recs[0][4]:recs[0][4] + recs[0][3]]]
+    w1 = [int(w) for w in cigar[recs[1][4]:recs[1][4] + recs[1][3]]]
+    assert recs[0][:2] == (500, 0) and recs[1][:2] == (1000, 0)
+    # the gap may sit anywhere inside a repeat of its flanks; its length and the totals are fixed
+    assert [w & 15 for w in w0] == [7, 2, 7] and (w0[1] >> 4) == 4 and (w0[0] >> 4) + (w0[2] >> 4) == 150
+    assert [w & 15 for w in w1] == [7, 1, 7] and (w1[1] >> 4) == 3 and (w1[0] >> 4) + (w1[2] >> 4) == 147
+    class NoGaps(P):
+        band = 0
+    _, recs0, _, cigar0, _ = R.map_chunk(ch, seqs, seq_off, [0], NoGaps)
+    assert [int(w) & 15 for w in cigar0[recs0[0][4]:recs0[0][4] + recs0[0][3]]] in ([7, 4], [4, 7])      # clipped at the indel
