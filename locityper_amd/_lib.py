@@ -83,6 +83,7 @@ SIGNATURES = {
     "lcty_map_params_default": (I32, [VP]),
     "lcty_locus_build_map_index": (I32, [VP, VP, U32, U32]),
     "lcty_map_reads": (I32, [VP, VP, VP, VP, VP, U64, VP, VP, U64, VP, VP]),
+    "lcty_reads_map_append": (I32, [VP, VP, VP]),
     "lcty_ctx_trim": (I32, [VP]),
     "lcty_host_alloc": (I32, [VP, U64, P(VP)]),
     "lcty_host_free": (None, [VP]),

@@ -591,6 +591,13 @@ def build_map_index(locus, basis, k=15):
     check(lib().lcty_locus_build_map_index(locus._h, basis.ctypes.data, len(basis), k))
 
 
+def map_append(aa, chunk, params):
+    """lcty_reads_map_append: the read ends of `chunk` mapped onto the basis alleles, the records straight into the batch `aa`."""
+    h = chunk.host_struct()
+    check(lib().lcty_reads_map_append(aa._h, C.byref(h), C.byref(params)))
+    aa._scored = False
+
+
 def map_reads(locus, chunk, params):
     """lcty_map_reads: the read ends of `chunk` (its sequence fields) onto the basis alleles; returns a ReadsChunk with the found
     records, =/X/S CIGARs and the bases in BAM orientation — ready for AllAlignments.append."""

@@ -477,78 +477,117 @@ int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uin
     });
 }
 
+namespace {
+
+// both passes of the kernel; the records stay on the device (out), the offsets come to the host
+struct MapRun {
+    DevBuf<uint32_t> d_len, d_b2, d_nm, d_nrec, d_ncig, d_ob2, d_onm, d_cigar;
+    DevBuf<uint64_t> d_off, d_rec_at, d_cig_at, d_pair_cig;
+    DevBuf<lcty_aln_rec> d_recs;
+    std::vector<uint32_t> nrec, ncig;
+    uint64_t n_recs = 0, n_cigar = 0;
+};
+
+void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_params* params, uint64_t* aln_off, uint64_t* cigar_off, bool sizes_only,
+             MapRun& X) {
+    if (!locus || !chunk || !params || !aln_off || !cigar_off) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    auto ix = std::static_pointer_cast<MapIndex>(locus->map_index);
+    if (!ix) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_build_map_index has not been called on this locus");
+    if (params->k != ix->k) fail(LCTY_ERR_INVALID_INPUT, "the index was built for k = %u", ix->k);
+    if (params->stride == 0 || params->match <= 0 || params->mismatch < 0 || params->end_bonus < 0 || params->gap_open < 0 || params->gap_extend < 0)
+        fail(LCTY_ERR_INVALID_INPUT, "mapper parameters");
+    if (params->band > MAP_MAX_BAND) fail(LCTY_ERR_UNSUPPORTED, "band of at most %u diagonals on either side", MAP_MAX_BAND);
+    lcty_ctx* ctx = locus->ctx;
+    ctx->activate();
+    hipStream_t s = ctx->stream;
+    const uint64_t n = chunk->n_pairs, n_mates = 2 * n;
+    aln_off[0] = 0; cigar_off[0] = 0;
+    if (n == 0) return;
+    const uint64_t nb = chunk->mate_off[n_mates];
+    for (uint64_t m = 0; m < n_mates; m++) {
+        if (chunk->mate_len[m] > MAP_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases (this one: %u)", MAP_MAX_LEN, chunk->mate_len[m]);
+        if (chunk->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
+        if (chunk->mate_len[m] >= params->k && (chunk->mate_len[m] - params->k) / params->stride + 2 > 64)
+            fail(LCTY_ERR_UNSUPPORTED, "more than 64 seeds per read end: raise the stride");
+    }
+    X.d_len.alloc(n_mates); X.d_len.upload(chunk->mate_len, n_mates, s);
+    X.d_off.alloc(n_mates + 1); X.d_off.upload(chunk->mate_off, n_mates + 1, s);
+    X.d_b2.alloc(std::max<uint64_t>(nb / 16, 1)); X.d_b2.upload(chunk->bases2, nb / 16, s);
+    X.d_nm.alloc(std::max<uint64_t>(nb / 32, 1)); X.d_nm.upload(chunk->nmask, nb / 32, s);
+    X.d_nrec.alloc(n_mates); X.d_ncig.alloc(n_mates);
+    MapView V{};
+    V.table = ix->table.p; V.mask = ix->mask; V.entries = ix->entries.p; V.basis = ix->basis.p; V.n_basis = ix->n_basis;
+    V.k = params->k; V.stride = params->stride; V.min_votes = std::max<uint32_t>(params->min_votes, 1);
+    V.max_occ = params->max_occ ? params->max_occ : 4 * ix->n_basis;
+    V.match = params->match; V.mismatch = params->mismatch; V.end_bonus = params->end_bonus; V.min_score = params->min_score;
+    V.band = params->band; V.gap_open = params->gap_open; V.gap_extend = params->gap_extend;
+    const uint32_t n_wg = static_cast<uint32_t>(std::min<uint64_t>(n_mates, 8ull * static_cast<uint64_t>(ctx->props.multiProcessorCount)));
+    ix->scratch.ensure(static_cast<size_t>(n_wg) * 64 * MAP_LANE_SCRATCH);
+    V.scratch = ix->scratch.p;
+    V.seqs = locus->d_seqs.p; V.seq_off = locus->d_seq_off.p; V.allele_len = locus->d_allele_len.p;
+    V.n_mates = n_mates; V.mate_len = X.d_len.p; V.mate_off = X.d_off.p; V.bases2 = X.d_b2.p; V.nmask = X.d_nm.p;
+    V.paired = locus->bg.is_paired;
+    V.n_recs = X.d_nrec.p; V.n_cigar = X.d_ncig.p;
+    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<false>, dim3(n_wg), dim3(64), 0, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
+    X.nrec.resize(n_mates); X.ncig.resize(n_mates);
+    X.d_nrec.download(X.nrec.data(), n_mates, s); X.d_ncig.download(X.ncig.data(), n_mates, s);
+    LCTY_HIP(hipStreamSynchronize(s));
+    std::vector<uint64_t> rec_at(n_mates), cig_at(n_mates), pair_cig(n);
+    uint64_t r = 0, c = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        pair_cig[p] = c;
+        for (uint32_t e = 0; e < 2; e++) { rec_at[2 * p + e] = r; cig_at[2 * p + e] = c; r += X.nrec[2 * p + e]; c += X.ncig[2 * p + e]; }
+        aln_off[p + 1] = r; cigar_off[p + 1] = c;
+    }
+    X.n_recs = r; X.n_cigar = c;
+    if (sizes_only) return;
+    X.d_rec_at.alloc(n_mates); X.d_rec_at.upload(rec_at.data(), n_mates, s);
+    X.d_cig_at.alloc(n_mates); X.d_cig_at.upload(cig_at.data(), n_mates, s);
+    X.d_pair_cig.alloc(n); X.d_pair_cig.upload(pair_cig.data(), n, s);
+    X.d_recs.alloc(std::max<uint64_t>(r, 1)); X.d_cigar.alloc(std::max<uint64_t>(c, 1));
+    X.d_ob2.alloc(std::max<uint64_t>(nb / 16, 1)); X.d_onm.alloc(std::max<uint64_t>(nb / 32, 1));
+    X.d_ob2.zero(s); X.d_onm.zero(s);
+    V.rec_at = X.d_rec_at.p; V.cig_at = X.d_cig_at.p; V.pair_cig = X.d_pair_cig.p; V.recs = X.d_recs.p; V.cigar = X.d_cigar.p;
+    V.out_bases2 = X.d_ob2.p; V.out_nmask = X.d_onm.p;
+    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<true>, dim3(n_wg), dim3(64), 0, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
+    LCTY_HIP(hipStreamSynchronize(s));                                          // rec_at & co. are host vectors of this frame
+}
+
+}  // namespace
+
 int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_params* params, uint64_t* aln_off, lcty_aln_rec* recs,
                        uint64_t cap_recs, uint64_t* cigar_off, uint32_t* cigar, uint64_t cap_cigar, uint32_t* bases2_out, uint32_t* nmask_out) {
     return guarded([&] {
-        if (!locus || !chunk || !params || !aln_off || !cigar_off) fail(LCTY_ERR_INVALID_INPUT, "null argument");
-        auto ix = std::static_pointer_cast<MapIndex>(locus->map_index);
-        if (!ix) fail(LCTY_ERR_INVALID_INPUT, "lcty_locus_build_map_index has not been called on this locus");
-        if (params->k != ix->k) fail(LCTY_ERR_INVALID_INPUT, "the index was built for k = %u", ix->k);
-        if (params->stride == 0 || params->match <= 0 || params->mismatch < 0 || params->end_bonus < 0 || params->gap_open < 0 || params->gap_extend < 0)
-            fail(LCTY_ERR_INVALID_INPUT, "mapper parameters");
-        if (params->band > MAP_MAX_BAND) fail(LCTY_ERR_UNSUPPORTED, "band of at most %u diagonals on either side", MAP_MAX_BAND);
-        lcty_ctx* ctx = locus->ctx;
-        ctx->activate();
-        hipStream_t s = ctx->stream;
-        const uint64_t n = chunk->n_pairs, n_mates = 2 * n;
-        aln_off[0] = 0; cigar_off[0] = 0;
+        MapRun X;
+        const bool sizes_only = !recs || !cigar || !bases2_out || !nmask_out;
+        run_map(locus, chunk, params, aln_off, cigar_off, sizes_only, X);
+        if (sizes_only || !chunk->n_pairs) return;
+        if (X.n_recs > cap_recs || X.n_cigar > cap_cigar)
+            fail(LCTY_ERR_INVALID_INPUT, "room for %llu records and %llu CIGAR words is needed", (unsigned long long)X.n_recs, (unsigned long long)X.n_cigar);
+        hipStream_t s = locus->ctx->stream;
+        const uint64_t nb = chunk->mate_off[2 * chunk->n_pairs];
+        X.d_recs.download(recs, X.n_recs, s); X.d_cigar.download(cigar, X.n_cigar, s);
+        X.d_ob2.download(bases2_out, nb / 16, s); X.d_onm.download(nmask_out, nb / 32, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// the same, with the records going straight into a batch of the locus: device to device, nothing but the offsets visits the host
+int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, const lcty_map_params* params) {
+    return guarded([&] {
+        if (!reads || !chunk || !params) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        const uint64_t n = chunk->n_pairs;
         if (n == 0) return;
-        const uint64_t nb = chunk->mate_off[n_mates];
-        for (uint64_t m = 0; m < n_mates; m++) {
-            if (chunk->mate_len[m] > MAP_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases (this one: %u)", MAP_MAX_LEN, chunk->mate_len[m]);
-            if (chunk->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
-            if (chunk->mate_len[m] && (chunk->mate_len[m] - params->k) / params->stride + 2 > 64 && chunk->mate_len[m] >= params->k)
-                fail(LCTY_ERR_UNSUPPORTED, "more than 64 seeds per read end: raise the stride");
-        }
-        DevBuf<uint32_t> d_len, d_b2, d_nm, d_nrec, d_ncig, d_ob2, d_onm;
-        DevBuf<uint64_t> d_off;
-        d_len.alloc(n_mates); d_len.upload(chunk->mate_len, n_mates, s);
-        d_off.alloc(n_mates + 1); d_off.upload(chunk->mate_off, n_mates + 1, s);
-        d_b2.alloc(std::max<uint64_t>(nb / 16, 1)); d_b2.upload(chunk->bases2, nb / 16, s);
-        d_nm.alloc(std::max<uint64_t>(nb / 32, 1)); d_nm.upload(chunk->nmask, nb / 32, s);
-        d_nrec.alloc(n_mates); d_ncig.alloc(n_mates);
-        MapView V{};
-        V.table = ix->table.p; V.mask = ix->mask; V.entries = ix->entries.p; V.basis = ix->basis.p; V.n_basis = ix->n_basis;
-        V.k = params->k; V.stride = params->stride; V.min_votes = std::max<uint32_t>(params->min_votes, 1);
-        V.max_occ = params->max_occ ? params->max_occ : 4 * ix->n_basis;
-        V.match = params->match; V.mismatch = params->mismatch; V.end_bonus = params->end_bonus; V.min_score = params->min_score;
-        V.band = params->band; V.gap_open = params->gap_open; V.gap_extend = params->gap_extend;
-        const uint32_t n_wg = static_cast<uint32_t>(std::min<uint64_t>(n_mates, 8ull * static_cast<uint64_t>(ctx->props.multiProcessorCount)));
-        ix->scratch.ensure(static_cast<size_t>(n_wg) * 64 * MAP_LANE_SCRATCH);
-        V.scratch = ix->scratch.p;
-        V.seqs = locus->d_seqs.p; V.seq_off = locus->d_seq_off.p; V.allele_len = locus->d_allele_len.p;
-        V.n_mates = n_mates; V.mate_len = d_len.p; V.mate_off = d_off.p; V.bases2 = d_b2.p; V.nmask = d_nm.p;
-        V.paired = locus->bg.is_paired;
-        V.n_recs = d_nrec.p; V.n_cigar = d_ncig.p;
-        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<false>, dim3(n_wg), dim3(64), 0, s, V); }, s);
-        LCTY_HIP(hipGetLastError());
-        std::vector<uint32_t> nrec(n_mates), ncig(n_mates);
-        d_nrec.download(nrec.data(), n_mates, s); d_ncig.download(ncig.data(), n_mates, s);
-        LCTY_HIP(hipStreamSynchronize(s));
-        std::vector<uint64_t> rec_at(n_mates), cig_at(n_mates), pair_cig(n);
-        uint64_t r = 0, c = 0;
-        for (uint64_t p = 0; p < n; p++) {
-            pair_cig[p] = c;
-            for (uint32_t e = 0; e < 2; e++) { rec_at[2 * p + e] = r; cig_at[2 * p + e] = c; r += nrec[2 * p + e]; c += ncig[2 * p + e]; }
-            aln_off[p + 1] = r; cigar_off[p + 1] = c;
-        }
-        if (!recs || !cigar || !bases2_out || !nmask_out) return;                // sizes only
-        if (r > cap_recs || c > cap_cigar) fail(LCTY_ERR_INVALID_INPUT, "room for %llu records and %llu CIGAR words is needed", (unsigned long long)r,
-                                                (unsigned long long)c);
-        DevBuf<uint64_t> d_rec_at, d_cig_at, d_pair_cig; DevBuf<lcty_aln_rec> d_recs; DevBuf<uint32_t> d_cigar;
-        d_rec_at.alloc(n_mates); d_rec_at.upload(rec_at.data(), n_mates, s);
-        d_cig_at.alloc(n_mates); d_cig_at.upload(cig_at.data(), n_mates, s);
-        d_pair_cig.alloc(n); d_pair_cig.upload(pair_cig.data(), n, s);
-        d_recs.alloc(std::max<uint64_t>(r, 1)); d_cigar.alloc(std::max<uint64_t>(c, 1));
-        d_ob2.alloc(std::max<uint64_t>(nb / 16, 1)); d_onm.alloc(std::max<uint64_t>(nb / 32, 1));
-        d_ob2.zero(s); d_onm.zero(s);
-        V.rec_at = d_rec_at.p; V.cig_at = d_cig_at.p; V.pair_cig = d_pair_cig.p; V.recs = d_recs.p; V.cigar = d_cigar.p;
-        V.out_bases2 = d_ob2.p; V.out_nmask = d_onm.p;
-        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<true>, dim3(n_wg), dim3(64), 0, s, V); }, s);
-        LCTY_HIP(hipGetLastError());
-        d_recs.download(recs, r, s); d_cigar.download(cigar, c, s);
-        d_ob2.download(bases2_out, nb / 16, s); d_onm.download(nmask_out, nb / 32, s);
-        LCTY_HIP(hipStreamSynchronize(s));
+        MapRun X;
+        std::vector<uint64_t> aln_off(n + 1), cigar_off(n + 1);
+        run_map(reads->locus, chunk, params, aln_off.data(), cigar_off.data(), false, X);
+        lcty_reads_host h = *chunk;
+        h.aln_off = aln_off.data(); h.cigar_off = cigar_off.data(); h.recs = nullptr; h.cigar = nullptr;
+        DeviceRecords dev{X.d_recs.p, X.d_cigar.p, X.d_ob2.p, X.d_onm.p, X.nrec.data(), MAP_OPS_CAP};
+        const int32_t rc = reads_append_device(reads, &h, &dev);
+        if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
     });
 }
 

@@ -160,6 +160,13 @@ void launch_prefilter_generic(lcty_reads* reads, const uint16_t* d_genotypes, ui
                               const double* d_priors, double* d_scores);
 void compact_matrix(lcty_reads* reads, double* d_out, uint64_t n_good);         // [A][n_good]
 uint64_t count_genotypes(uint32_t n_alleles, uint32_t ploidy);
+// a chunk whose records, CIGAR words and bases are on the device already (lcty_map.hip -> lcty_reads.hip)
+struct DeviceRecords {
+    const lcty_aln_rec* recs; const uint32_t* cigar; const uint32_t* bases2; const uint32_t* nmask;      // device
+    const uint32_t* n_recs_mate;                     // host, [2 * n_pairs]: records of every read end (its primary or unmapped record first)
+    uint32_t max_rec_cigar;
+};
+int32_t reads_append_device(lcty_reads* R, const lcty_reads_host* h, const DeviceRecords* dev);
 
 // The rows of a stage's alleles of the location tables of several batches (shards of one locus' reads, in read order), laid
 // side by side into one table the solver kernels run on (lcty_solve.hip). The caller moves the packed rows between devices

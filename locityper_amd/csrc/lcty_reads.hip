@@ -166,7 +166,9 @@ int32_t lcty_reads_create_streaming(lcty_locus* locus, uint64_t cap_pairs, uint6
 
 // lcty_reads_append and lcty_reads_append_counted: `h` carries the raw records, or — counted != NULL — everything but records and
 // CIGAR words, which `counted` (16-byte entries, one per record) replaces
-static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_aln_counted* counted) {
+// dev: the chunk's records, CIGAR words and (re-oriented) bases are on the device already (lcty_map.hip made them); h then gives the
+// sequence layout and the record / CIGAR offsets only
+static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_aln_counted* counted, const lcty::DeviceRecords* dev = nullptr) {
     return guarded([&] {
         if (!R || !h) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         if (R->n_pairs > 0 && R->counted != (counted != nullptr))
@@ -214,7 +216,12 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
             // record groups (locs.rs:1119-1131): the second primary starts read end 2, a third one would start
             // the next read pair
             uint32_t j2 = static_cast<uint32_t>(cnt), j3 = static_cast<uint32_t>(cnt);
-            for (uint64_t i = h->aln_off[r]; i < h->aln_off[r + 1]; i++) {
+            if (dev) {                                                        // one primary (or unmapped) record first for every read end that is there
+                if (dev->n_recs_mate[2 * r] + dev->n_recs_mate[2 * r + 1] != cnt) fail(LCTY_ERR_RUNTIME, "record counts of the read ends do not add up");
+                if (dev->n_recs_mate[2 * r + 1]) j2 = dev->n_recs_mate[2 * r];
+                max_rec_cig = std::max(max_rec_cig, dev->max_rec_cigar);
+            }
+            for (uint64_t i = h->aln_off[r]; !dev && i < h->aln_off[r + 1]; i++) {
                 bool is_primary;
                 if (counted) {
                     if (counted[i].pos_flags >> 31) fail(LCTY_ERR_INVALID_INPUT, "counted alignment %llu: reserved flag bit set", (unsigned long long)i);
@@ -236,11 +243,19 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
 
         hipStream_t s = ctx->stream;
         R->d_mate_len.upload(h->mate_len, 2 * n, s, 2 * raw_pairs);
-        R->d_bases2.upload(h->bases2, nb / 16, s, R->n_bases / 16);
-        R->d_nmask.upload(h->nmask, nb / 32, s, R->n_bases / 32);
         static_assert(sizeof(lcty_aln_counted) == sizeof(lcty_aln_rec), "both record forms are 16 bytes");
-        R->d_recs.upload(counted ? reinterpret_cast<const lcty_aln_rec*>(counted) : h->recs, nr, s, R->n_recs);
-        if (!counted) R->d_cigar.upload(h->cigar, nc, s, R->n_cigar);
+        if (dev) {
+            if (R->n_bases / 16 + nb / 16 > R->d_bases2.n || R->n_recs + nr > R->d_recs.n || R->n_cigar + nc > R->d_cigar.n) fail(LCTY_ERR_RUNTIME, "device buffer overflow");
+            LCTY_HIP(hipMemcpyAsync(R->d_bases2.p + R->n_bases / 16, dev->bases2, nb / 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            LCTY_HIP(hipMemcpyAsync(R->d_nmask.p + R->n_bases / 32, dev->nmask, nb / 32 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            if (nr) LCTY_HIP(hipMemcpyAsync(R->d_recs.p + R->n_recs, dev->recs, nr * sizeof(lcty_aln_rec), hipMemcpyDeviceToDevice, s));
+            if (nc) LCTY_HIP(hipMemcpyAsync(R->d_cigar.p + R->n_cigar, dev->cigar, nc * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        } else {
+            R->d_bases2.upload(h->bases2, nb / 16, s, R->n_bases / 16);
+            R->d_nmask.upload(h->nmask, nb / 32, s, R->n_bases / 32);
+            R->d_recs.upload(counted ? reinterpret_cast<const lcty_aln_rec*>(counted) : h->recs, nr, s, R->n_recs);
+            if (!counted) R->d_cigar.upload(h->cigar, nc, s, R->n_cigar);
+        }
         // rebased offsets
         std::vector<uint64_t> mo(2 * n), ao(n), co(n);
         for (uint64_t m = 0; m < 2 * n; m++) mo[m] = h->mate_off[m + 1] + R->n_bases;
@@ -261,6 +276,12 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
 }
 
 int32_t lcty_reads_append(lcty_reads* R, const lcty_reads_host* h) { return append_impl(R, h, nullptr); }
+
+extern "C++" {
+namespace lcty {
+int32_t reads_append_device(lcty_reads* R, const lcty_reads_host* h, const DeviceRecords* dev) { return append_impl(R, h, nullptr, dev); }
+}
+}
 
 // the same chunk with its records already counted: h->recs / cigar_off / cigar are not read
 int32_t lcty_reads_append_counted(lcty_reads* R, const lcty_reads_host* h, const lcty_aln_counted* alns) {

@@ -236,3 +236,28 @@ def test_mapper_aligns_clipped_candidates_with_gaps(gpu_ctx):
             assert [int(x) for x in got.recs["pos"]] == [500, 1000]
         else:
             assert all(4 in o and 1 not in o and 2 not in o for o in ops)
+
+
+def test_mapped_records_straight_into_the_batch(gpu_ctx):
+    """lcty_reads_map_append (records, CIGAR words and bases copied device to device) leaves the batch as lcty_reads_append of the
+    mapped chunk does: the same status, pair alignments and matrix after scoring; chunk after chunk."""
+    L, p, loc = setup(gpu_ctx, 6, 1200, 9000, seed=9)
+    fq = fastq_orientation(L.reads(0, 1200))
+    mp = api.map_params()
+    api.build_map_index(loc, [0, 2, 5], k=mp.k)
+    halves = [fq.slice(0, 500), fq.slice(500, 1200)]
+    mapped = [api.map_reads(loc, h, mp) for h in halves]
+    via_host = api.AllAlignments.load(loc, mapped)
+    direct = api.AllAlignments(loc, 1200, sum(h.n_bases for h in halves), sum(len(m.recs) for m in mapped), sum(len(m.cigar) for m in mapped))
+    for h in halves:
+        api.map_append(direct, h, mp)
+    direct.score()
+    assert direct.n_good() == via_host.n_good() > 800
+    for x, y in zip(direct.status(), via_host.status()):
+        assert np.array_equal(x, y)
+    o1, p1 = direct.pair_alns(); o2, p2 = via_host.pair_alns()
+    assert np.array_equal(o1, o2) and np.array_equal(p1, p2)
+    assert np.array_equal(direct.best_aln_matrix(), via_host.best_aln_matrix())
+    tiny = api.AllAlignments(loc, 1200, fq.n_bases, 10, 10)                  # no room for the records: refused, nothing written
+    with pytest.raises(_lib.LocityperError):
+        api.map_append(tiny, fq, mp)
