@@ -202,13 +202,22 @@ int32_t lcty_device_count(void);
 int32_t lcty_ctx_create(int32_t device_id, lcty_ctx** out);
 void    lcty_ctx_destroy(lcty_ctx* ctx);
 int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
-/* Limits of the retry / batching machinery of this context, for tests that must reach those paths with small inputs (no
- * environment variable changes what the library computes): "transfer_levels", "transfer_scratch_mb", "transfer_waves",
- * "transfer_cap_new", "transfer_arena" (lcty_recover_alignments: scratch levels, arenas), "depth_table_start" (first width of the
- * extended depth table), "solve_budget_mb" (device memory for the per-chain state of a solver stage), "solve_chains_per_wave", "solve_extra_start" (first size of a chain's run of locations beyond the second),
- * "solve_stats" (1: per-stage iteration counts on stderr), "solve_lds_weights" / "anneal_lds_weights" (0 / 1: where the solver loops
- * keep the window weights), "gather_chunk_mb" (staging size of lcty_solve_stage_read_sharded). value < 0 restores the default; an
- * unknown name is LCTY_ERR_INVALID_INPUT. None of them changes a result. */
+/* Limits of the retry / batching machinery of this context and choices between equivalent kernel forms, for tests that must reach
+ * those paths with small inputs (no environment variable changes what the library computes):
+ *   "transfer_levels", "transfer_scratch_mb", "transfer_waves", "transfer_cap_new", "transfer_arena"   lcty_recover_alignments: scratch
+ *       levels, arenas;
+ *   "depth_table_start"   first width of the extended depth table;   "solve_budget_mb"   device memory for the per-chain state of a
+ *       solver stage;   "solve_extra_start"   first size of a chain's run of locations beyond the second;
+ *   "solve_chains_per_wave"   1, 2, 4, 5, 6 chains of the greedy loop per wavefront;   "solve_lds_weights"   0: the greedy loop gathers
+ *       the window weights, 1 (default where the locus has the weight tables): table indices + tables in LDS;
+ *   "anneal_lds_weights"   0 gathered, 1 in LDS as they are, 2 (default where possible) table indices + tables in LDS;
+ *   "solve_stats"   1: per-stage iteration counts on stderr;   "gather_chunk_mb"   staging size of lcty_solve_stage_read_sharded;
+ *   "prefilter_gram"   0: always the f64 tile kernel, 1: the integer Gram contraction on the matrix cores whenever it applies
+ *       (default: from 512 alleles on);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the
+ *       f64 kernel takes the batch);   "prefilter_gram_levels"   levels of a row the contraction takes (<= 16; rows with more go
+ *       through the f64 kernel).
+ * value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT. None of them changes a result beyond the last bits of
+ * an f64 sum (the order in which a chain's likelihood or a genotype's score is added up). */
 int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value);
 /* The solver stages keep their per-chain device state (32 B per chain and good read pair: ~150 GB for the 5 000 greedy chains of
  * the default scheme at 1 M read pairs; batches of chains when the device has less) with the context between stages and loci;
