@@ -499,6 +499,9 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    if world == 1:
+        ctx.trim()          # the solver workspaces of the timed steps (160 GB) make room for the extra measurements below
+
     if args.recruit_sample > 0 and world == 1:
         # ---- minimizer read recruitment (Targets::recruit_read_pair, seq/recruit.rs:883-929), the step before the path: random
         # 150 + 150-base pairs (whole-genome input is almost entirely foreign to a locus) against this locus' alleles ----
@@ -544,7 +547,7 @@ def main():
         mapped = api.map_reads(loc, bare, mp)
         t_map = time.perf_counter() - tm0
         _, ms_map = ctx.timing(api.K_MAP)
-        out["candidate_generation"] = {"sample": f"first {nmp} read pairs (bases only) onto {len(basis)} basis alleles, seeds of {mp.k} every {mp.stride} bases, extension without gaps",
+        out["candidate_generation"] = {"sample": f"first {nmp} read pairs (bases only) onto {len(basis)} basis alleles, seeds of {mp.k} every {mp.stride} bases, ungapped extension then a band alignment with gaps for clipped candidates",
                                        "records": int(len(mapped.recs)), "kernel_ms_both_passes": ms_map,
                                        "read_ends_per_s_kernel": 2 * nmp / (ms_map * 1e-3) if ms_map else None,
                                        "read_ends_per_s_call": 2 * nmp / t_map, "index_build_s": t_index}
@@ -578,7 +581,6 @@ def main():
         # ---- configs[4] shard shape: a locus of 4 096 alleles, the read pairs one of eight GPUs would hold. The prefilter is the
         # dominant kernel there; from 512 alleles on it runs as an integer Gram contraction on the matrix cores (lcty_gram.hip) ----
         nma, Ama = args.many_alleles_sample, 4096
-        ctx.trim()                                                                # the solver workspaces of the timed steps (160 GB) make room
         Lm = synth.SynthLocus(Ama, nma, seed=synth.SEED + 5, base_len=3000)
         pm = api.resolve_params(api.default_params(), Lm.bg)
         locm = api.Locus(ctx, Lm.seqs, Lm.seq_off, Lm.counts, Lm.cnt_off, Lm.k, Lm.bg, pm)

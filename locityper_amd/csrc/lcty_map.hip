@@ -18,8 +18,8 @@
 //            ; per (allele, strand) the candidate with the best score stays (ties: the smallest diagonal).
 //   gaps     a candidate that stayed and is clipped is aligned again WITH gaps: gap-affine (open + (n - 1) x extend for a gap of n) in
 //            a band of +-band diagonals around its own, starting and ending on an aligned base, soft clips and end bonuses as above
-//            (one lane = one candidate; M / deletion / insertion scores of the running row in LDS, one direction byte per cell
-//            in a scratch of the workgroup, traceback into = / X / I / D runs). It replaces the alignment without gaps when
+//            (one lane = one candidate; M / deletion / insertion scores of the running row in registers, the bases under the band in LDS,
+//            one direction nibble per cell in a scratch of the workgroup, traceback into = / X / I / D runs). It replaces the alignment without gaps when
 //            its score is higher. Order of preference on ties, fixed here and in the restatement: continue before starting
 //            afresh, M before deletion before insertion as predecessor, open before extend, the first best end cell by (read
 //            position, diagonal).
@@ -47,7 +47,9 @@ constexpr uint32_t MAP_MAX_BAND = 16;      // diagonals on either side of a cand
 constexpr uint32_t MAP_BAND_W = 2 * MAP_MAX_BAND + 1;
 constexpr int32_t MAP_NEG = -(1 << 29);
 constexpr uint32_t MAP_OPS_CAP = MAP_MAX_LEN + 2 * MAP_MAX_BAND + 8;
-constexpr size_t MAP_LANE_SCRATCH = static_cast<size_t>(MAP_MAX_LEN) * MAP_BAND_W + MAP_OPS_CAP * 4;      // direction bytes + reversed CIGAR words
+constexpr uint32_t MAP_DIR_WORDS = (MAP_BAND_W + 7) / 8;                 // direction nibbles of a row, eight per word
+constexpr size_t MAP_LANE_SCRATCH = static_cast<size_t>(MAP_MAX_LEN) * MAP_DIR_WORDS * 4 + MAP_OPS_CAP * 4;      // direction nibbles + reversed CIGAR words
+constexpr uint32_t MAP_REFW = MAP_MAX_LEN + 2 * MAP_MAX_BAND;             // bases of the allele a band alignment can touch
 
 struct MapSlot { uint64_t key; uint32_t start, count; };   // key ~0 = free
 constexpr uint64_t MAP_FREE = ~0ull;
@@ -89,7 +91,8 @@ __device__ __forceinline__ bool n_at(const uint32_t* nm, uint64_t off, uint32_t 
 __device__ __forceinline__ uint32_t enc_of(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
 
 template <bool WRITE>
-__device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsigned long long* best, uint64_t* cand_key, int32_t* dp) {
+__device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsigned long long* best, uint64_t* cand_key, uint8_t* rb,
+                        uint8_t* refw_all) {
     const uint32_t lane = threadIdx.x;
     const uint32_t L = V.mate_len[m];
     if (L == 0) {                                                               // absent read end (single-end data)
@@ -229,48 +232,69 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
     // ---- a clipped candidate again, with gaps (the header comment states the recurrence and the tie rules)
     bool gapped = false;
     uint32_t g_ops = 0, g_lead = 0, g_trail = 0, g_pos = 0;
-    uint8_t* dirs = V.scratch + (static_cast<size_t>(blockIdx.x) * 64 + lane) * MAP_LANE_SCRATCH;
-    uint32_t* rops = reinterpret_cast<uint32_t*>(dirs + static_cast<size_t>(MAP_MAX_LEN) * MAP_BAND_W);      // CIGAR words, last first
-    auto equal_ref = [&](uint32_t i, int64_t refpos) -> bool {
-        const uint32_t src = strand ? L - 1 - i : i;
-        if (n_at(V.nmask, off, src)) return false;
-        const uint32_t e = strand ? 3u - base_at(V.bases2, off, src) : base_at(V.bases2, off, src);
-        return enc_of(ref[refpos]) == e;
-    };
+    uint32_t* dirs = reinterpret_cast<uint32_t*>(V.scratch + (static_cast<size_t>(blockIdx.x) * 64 + lane) * MAP_LANE_SCRATCH);
+    uint32_t* rops = dirs + static_cast<size_t>(MAP_MAX_LEN) * MAP_DIR_WORDS;        // CIGAR words, last first
     const bool need = have && V.band > 0 && (s_best > 0 || e_best < L);
     if (__any(need)) {
+        // the inner loop touches LDS only: the read end's bases once per read end, the allele's bases under the band once per candidate
+        for (uint32_t i = lane; i < L; i += 64) rb[i] = n_at(V.nmask, off, i) ? 4u : static_cast<uint8_t>(base_at(V.bases2, off, i));
+        __syncthreads();
+        const int32_t B = static_cast<int32_t>(V.band), W = 2 * B + 1;
+        uint8_t* refw = refw_all + lane * MAP_REFW;                             // refw[j] = allele base at diag - B + j, 5 outside the allele
         if (need) {
-            const int32_t B = static_cast<int32_t>(V.band), W = 2 * B + 1;
-            int32_t* M = dp + lane; int32_t* E = dp + MAP_BAND_W * 64 + lane; int32_t* F = dp + 2 * MAP_BAND_W * 64 + lane;      // [k * 64]
-            for (int32_t k = 0; k < W; k++) { M[k * 64] = MAP_NEG; E[k * 64] = MAP_NEG; F[k * 64] = MAP_NEG; }
+            const uint32_t span = L + 2 * static_cast<uint32_t>(B);
+            for (uint32_t j = 0; j < span; j++) {
+                const int64_t rp = diag - B + static_cast<int64_t>(j);
+                refw[j] = rp >= 0 && rp < alen ? static_cast<uint8_t>(enc_of(ref[rp])) : 5u;
+            }
+        }
+        // base i of the read end in alignment orientation against refw[j]
+        auto equal_w = [&](uint32_t i, uint32_t j) -> bool {
+            const uint32_t r = rb[strand ? L - 1 - i : i];
+            return r < 4u && refw[j] == (strand ? 3u - r : r);
+        };
+        if (need) {
+            // the running row of M / deletion / insertion scores in registers: the loop over the band is unrolled to its full width
+            // (a narrower band leaves the outer diagonals at "no alignment")
+            int32_t M[MAP_BAND_W], E[MAP_BAND_W], F[MAP_BAND_W];
+#pragma unroll
+            for (uint32_t k = 0; k < MAP_BAND_W; k++) { M[k] = MAP_NEG; E[k] = MAP_NEG; F[k] = MAP_NEG; }
             int32_t best_total = INT32_MIN; uint32_t end_i = 0; int32_t end_k = 0;
             for (uint32_t i = 0; i < L; i++) {
                 int32_t left_m = MAP_NEG, left_e = MAP_NEG;
                 const int32_t fresh = i == 0 ? V.end_bonus : 0;
-                for (int32_t k = 0; k < W; k++) {
-                    const int64_t refpos = diag + static_cast<int64_t>(i) + (k - B);
-                    const bool inref = refpos >= 0 && refpos < alen;
-                    const int32_t om = M[k * 64], oe = E[k * 64], of = F[k * 64];
-                    const int32_t rm = k + 1 < W ? M[(k + 1) * 64] : MAP_NEG, rf = k + 1 < W ? F[(k + 1) * 64] : MAP_NEG;
-                    int32_t prev = om; uint32_t code = 1;
-                    if (oe > prev) { prev = oe; code = 2; }
-                    if (of > prev) { prev = of; code = 3; }
-                    if (fresh > prev) { prev = fresh; code = 0; }
-                    int32_t nm = inref ? prev + (equal_ref(i, refpos) ? V.match : -V.mismatch) : MAP_NEG;
-                    const int32_t fo = rm - V.gap_open, fe = rf - V.gap_extend;
-                    int32_t nf = fe > fo ? fe : fo; const uint32_t fcode = fe > fo ? 1u : 0u;
-                    const int32_t eo = left_m - V.gap_open, ee = left_e - V.gap_extend;
-                    int32_t ne = ee > eo ? ee : eo; const uint32_t ecode = ee > eo ? 1u : 0u;
-                    if (!inref) ne = MAP_NEG;
-                    if (nm < MAP_NEG / 2) nm = MAP_NEG;
-                    if (nf < MAP_NEG / 2) nf = MAP_NEG;
-                    if (ne < MAP_NEG / 2) ne = MAP_NEG;
-                    dirs[static_cast<size_t>(i) * MAP_BAND_W + k] = static_cast<uint8_t>(code | (ecode << 2) | (fcode << 3));
-                    M[k * 64] = nm; E[k * 64] = ne; F[k * 64] = nf;
-                    left_m = nm; left_e = ne;
-                    if (nm > MAP_NEG) {
-                        const int32_t total = nm + (i + 1 == L ? V.end_bonus : 0);
-                        if (total > best_total) { best_total = total; end_i = i; end_k = k; }
+                const uint32_t r = rb[strand ? L - 1 - i : i];
+                const uint32_t want = r < 4u ? (strand ? 3u - r : r) : 6u;     // the allele base that equals this read base (6: none does)
+                uint32_t packed = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < MAP_BAND_W; k++) {
+                    if (static_cast<int32_t>(k) < W) {
+                        const uint32_t rbase = refw[i + k];                     // the allele position diag + i + (k - B) is entry i + k of the window
+                        const bool inref = rbase != 5u;
+                        const int32_t om = M[k], oe = E[k], of = F[k];
+                        const int32_t rm = k + 1 < MAP_BAND_W && static_cast<int32_t>(k) + 1 < W ? M[k + 1 < MAP_BAND_W ? k + 1 : k] : MAP_NEG;
+                        const int32_t rf = k + 1 < MAP_BAND_W && static_cast<int32_t>(k) + 1 < W ? F[k + 1 < MAP_BAND_W ? k + 1 : k] : MAP_NEG;
+                        int32_t prev = om; uint32_t code = 1;
+                        if (oe > prev) { prev = oe; code = 2; }
+                        if (of > prev) { prev = of; code = 3; }
+                        if (fresh > prev) { prev = fresh; code = 0; }
+                        int32_t nm = inref ? prev + (rbase == want ? V.match : -V.mismatch) : MAP_NEG;
+                        const int32_t fo = rm - V.gap_open, fe = rf - V.gap_extend;
+                        int32_t nf = fe > fo ? fe : fo; const uint32_t fcode = fe > fo ? 1u : 0u;
+                        const int32_t eo = left_m - V.gap_open, ee = left_e - V.gap_extend;
+                        int32_t ne = ee > eo ? ee : eo; const uint32_t ecode = ee > eo ? 1u : 0u;
+                        if (!inref) ne = MAP_NEG;
+                        if (nm < MAP_NEG / 2) nm = MAP_NEG;
+                        if (nf < MAP_NEG / 2) nf = MAP_NEG;
+                        if (ne < MAP_NEG / 2) ne = MAP_NEG;
+                        packed |= (code | (ecode << 2) | (fcode << 3)) << (4 * (k & 7));
+                        if ((k & 7) == 7 || static_cast<int32_t>(k) + 1 == W) { dirs[static_cast<size_t>(i) * MAP_DIR_WORDS + (k >> 3)] = packed; packed = 0; }
+                        M[k] = nm; E[k] = ne; F[k] = nf;
+                        left_m = nm; left_e = ne;
+                        if (nm > MAP_NEG) {
+                            const int32_t total = nm + (i + 1 == L ? V.end_bonus : 0);
+                            if (total > best_total) { best_total = total; end_i = i; end_k = static_cast<int32_t>(k); }
+                        }
                     }
                 }
             }
@@ -283,9 +307,9 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
                     cur_op = op; cur_len = 1;
                 };
                 for (;;) {
-                    const uint8_t d = dirs[static_cast<size_t>(i) * MAP_BAND_W + k];
+                    const uint32_t d = (dirs[static_cast<size_t>(i) * MAP_DIR_WORDS + (k >> 3)] >> (4 * (k & 7))) & 15u;
                     if (state == 0) {
-                        emit(equal_ref(i, diag + static_cast<int64_t>(i) + (k - B)) ? 7u : 8u);
+                        emit(equal_w(i, i + static_cast<uint32_t>(k)) ? 7u : 8u);
                         const uint32_t c = d & 3u;
                         if (c == 0) break;
                         state = c - 1;                                          // 1 -> M, 2 -> deletion, 3 -> insertion; all at (i - 1, k)
@@ -306,6 +330,7 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
                 g_pos = static_cast<uint32_t>(diag + static_cast<int64_t>(i) + (k - B));
             }
         }
+        __syncthreads();
     }
     // ---- the primary record: best score, the smallest (allele, strand) on ties (the lanes are in that order)
     int32_t top = have ? score : INT32_MIN;
@@ -389,9 +414,10 @@ __global__ __launch_bounds__(64) void map_kernel(const MapView V) {
     __shared__ uint64_t keys[MAP_MAX_HITS];
     __shared__ unsigned long long best[2 * MAP_MAX_BASIS];
     __shared__ uint64_t cand_key[64];
-    __shared__ int32_t dp[3 * MAP_BAND_W * 64];
+    __shared__ uint8_t rb[MAP_MAX_LEN];                      // the read end's bases (0..3, 4 = not ACGT) as sequenced
+    __shared__ uint8_t refw_all[64 * MAP_REFW];              // per lane: the allele's bases under its band (4 = not ACGT or outside)
     for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) {
-        map_one<WRITE>(V, m, keys, best, cand_key, dp);
+        map_one<WRITE>(V, m, keys, best, cand_key, rb, refw_all);
         __syncthreads();
     }
 }
