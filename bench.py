@@ -548,7 +548,7 @@ def main():
         t_map = time.perf_counter() - tm0
         _, ms_map = ctx.timing(api.K_MAP)
         out["candidate_generation"] = {"sample": f"first {nmp} read pairs (bases only) onto {len(basis)} basis alleles, seeds of {mp.k} every {mp.stride} bases, ungapped extension then a band alignment with gaps for clipped candidates",
-                                       "records": int(len(mapped.recs)), "kernel_ms_both_passes": ms_map,
+                                       "records": int(len(mapped.recs)), "kernel_ms": ms_map,
                                        "read_ends_per_s_kernel": 2 * nmp / (ms_map * 1e-3) if ms_map else None,
                                        "read_ends_per_s_call": 2 * nmp / t_map, "index_build_s": t_index}
         del src, bare, mapped

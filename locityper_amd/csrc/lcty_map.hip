@@ -18,8 +18,9 @@
 //            ; per (allele, strand) the candidate with the best score stays (ties: the smallest diagonal).
 //   gaps     a candidate that stayed and is clipped is aligned again WITH gaps: gap-affine (open + (n - 1) x extend for a gap of n) in
 //            a band of +-band diagonals around its own, starting and ending on an aligned base, soft clips and end bonuses as above
-//            (one lane = one candidate; M / deletion / insertion scores of the running row in registers, the bases under the band in LDS,
-//            one direction nibble per cell in a scratch of the workgroup, traceback into = / X / I / D runs). It replaces the alignment without gaps when
+//            (one lane = one candidate, the lanes of a wavefront taking candidates of any read ends from a list; M / deletion /
+//            insertion scores of the running row in registers, the bases under the band in LDS, one direction nibble per cell in a
+//            scratch of the workgroup, traceback into = / X / I / D runs). It replaces the alignment without gaps when
 //            its score is higher. Order of preference on ties, fixed here and in the restatement: continue before starting
 //            afresh, M before deletion before insertion as predecessor, open before extend, the first best end cell by (read
 //            position, diagonal).
@@ -28,8 +29,10 @@
 //            =/X/S CIGARs and SEQ orientation (reverse-complemented when the primary is on the reverse strand) are those of
 //            the BAM the reference reads (model/locs.rs:1116-1150), so the chunk goes straight into lcty_reads_append.
 //
-// map_kernel<WRITE>: one wavefront per read end; lane = seed, then lane = hit (bitonic sort of <= 1 024 vote keys in LDS), then
-// lane = candidate (<= 64). Two passes (sizes, then records) with a host prefix sum in between.
+// Three kernels: map_seed_kernel (one wavefront per read end; lane = seed, then lane = hit: bitonic sort of <= 1 024 vote keys in
+// LDS, then lane = candidate, <= 64) leaves the candidates that stayed and lists the clipped ones; map_gap_kernel aligns the
+// listed ones with gaps, one per lane; map_emit_kernel<WRITE> (one wavefront per read end, lane = candidate) runs twice: sizes,
+// then records, with a host prefix sum in between.
 #include <algorithm>
 #include <unordered_map>
 
@@ -46,9 +49,7 @@ constexpr uint32_t MAP_PER_SEED = 64;      // index entries a seed may vote with
 constexpr uint32_t MAP_MAX_BAND = 16;      // diagonals on either side of a candidate's own in the alignment with gaps
 constexpr uint32_t MAP_BAND_W = 2 * MAP_MAX_BAND + 1;
 constexpr int32_t MAP_NEG = -(1 << 29);
-constexpr uint32_t MAP_OPS_CAP = MAP_MAX_LEN + 2 * MAP_MAX_BAND + 8;
 constexpr uint32_t MAP_DIR_WORDS = (MAP_BAND_W + 7) / 8;                 // direction nibbles of a row, eight per word
-constexpr size_t MAP_LANE_SCRATCH = static_cast<size_t>(MAP_MAX_LEN) * MAP_DIR_WORDS * 4 + MAP_OPS_CAP * 4;      // direction nibbles + reversed CIGAR words
 constexpr uint32_t MAP_REFW = MAP_MAX_LEN + 2 * MAP_MAX_BAND;             // bases of the allele a band alignment can touch
 
 struct MapSlot { uint64_t key; uint32_t start, count; };   // key ~0 = free
@@ -59,13 +60,27 @@ __host__ __device__ inline uint64_t map_hash(uint64_t x) {          // the mix o
     return x;
 }
 
+// a candidate between the kernels
+struct MapCand {
+    uint32_t diag;                         // + 2^31
+    int32_t score; uint16_t s, e;          // without gaps: score, aligned stretch [s, e) of the read end
+    uint16_t g, state;                     // basis index * 2 + strand; 0: as extended without gaps, 1: listed for kernel 2, 2: aligned with gaps (below)
+    int32_t g_score; uint32_t g_pos; uint16_t g_lead, g_trail; uint32_t ops_at; uint16_t g_inner, pad;
+};
+
 struct MapView {
     const MapSlot* table; uint64_t mask;
     const uint64_t* entries;               // basis index << 33 | position << 1 | forward-is-canonical
     const uint16_t* basis;                 // basis index -> allele
     uint32_t n_basis, k, stride, min_votes, max_occ, band;
     int32_t match, mismatch, end_bonus, min_score, gap_open, gap_extend;
-    uint8_t* scratch;                      // [workgroups][64][MAP_LANE_SCRATCH]
+    // between the kernels
+    MapCand* cands; uint32_t slots;        // [read end][slots]: the candidates that stayed, in (allele, strand) order
+    uint32_t* n_have;                      // per read end
+    uint32_t* work; uint32_t n_work;       // slots of the candidates to be aligned with gaps
+    uint32_t* counters;                    // [0] entries of `work`, [1] CIGAR words asked for in `ops`
+    uint32_t* ops; uint32_t ops_cap;       // CIGAR words of the alignments with gaps (without the soft clips)
+    uint32_t* scratch; uint32_t max_len;   // direction nibbles: [workgroup of kernel 2][max_len * MAP_DIR_WORDS][64]
     const uint8_t* seqs; const uint64_t* seq_off; const uint32_t* allele_len;
     // reads
     uint64_t n_mates;
@@ -90,13 +105,12 @@ __device__ __forceinline__ bool n_at(const uint32_t* nm, uint64_t off, uint32_t 
 }
 __device__ __forceinline__ uint32_t enc_of(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
 
-template <bool WRITE>
-__device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsigned long long* best, uint64_t* cand_key, uint8_t* rb,
-                        uint8_t* refw_all) {
+// ---- kernel 1: seeds -> votes -> candidates -> extension without gaps; the candidates that stay, in (allele, strand) order
+__device__ void map_seed_one(const MapView& V, const uint64_t m, uint64_t* keys, unsigned long long* best, uint64_t* cand_key) {
     const uint32_t lane = threadIdx.x;
     const uint32_t L = V.mate_len[m];
     if (L == 0) {                                                               // absent read end (single-end data)
-        if (!WRITE && lane == 0) { V.n_recs[m] = 0; V.n_cigar[m] = 0; }
+        if (lane == 0) V.n_have[m] = 0;
         return;
     }
     const uint64_t off = V.mate_off[m];
@@ -201,13 +215,6 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
     const int64_t diag = static_cast<int64_t>(static_cast<uint32_t>(ckey)) - 0x80000000ll;
     const uint8_t* ref = V.seqs + V.seq_off[allele];
     const int64_t alen = V.allele_len[allele];
-    // a position of the read end in alignment orientation: equal to the allele's base there?
-    auto equal_at = [&](uint32_t i) -> bool {
-        const uint32_t src = strand ? L - 1 - i : i;
-        if (n_at(V.nmask, off, src)) return false;
-        const uint32_t e = strand ? 3u - base_at(V.bases2, off, src) : base_at(V.bases2, off, src);
-        return enc_of(ref[diag + i]) == e;
-    };
     // the best-scoring stretch [s, e) inside the part of the read end that lies on the allele
     int32_t score = INT32_MIN; uint32_t s_best = 0, e_best = 0;
     if (cand) {
@@ -217,7 +224,9 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
         for (uint32_t i = i_lo; i < i_hi; i++) {
             const int32_t fresh = i == 0 ? V.end_bonus : 0;
             if (!open || fresh > run) { run = fresh; run_s = i; open = true; }   // a stretch that starts here (an older start wins ties)
-            run += equal_at(i) ? V.match : -V.mismatch;
+            const uint32_t src = strand ? L - 1 - i : i;
+            const uint32_t e = strand ? 3u - base_at(V.bases2, off, src) : base_at(V.bases2, off, src);
+            run += !n_at(V.nmask, off, src) && enc_of(ref[diag + i]) == e ? V.match : -V.mismatch;
             const int32_t total = run + (i + 1 == L ? V.end_bonus : 0);
             if (total > score) { score = total; s_best = run_s; e_best = i + 1; }
         }
@@ -229,118 +238,185 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
         atomicMax(&best[g], (static_cast<unsigned long long>(static_cast<uint32_t>(score) ^ 0x80000000u) << 32) | (63u - lane));
     __syncthreads();
     const bool have = cand && score > INT32_MIN && static_cast<uint32_t>(best[g]) == 63u - lane;
-    // ---- a clipped candidate again, with gaps (the header comment states the recurrence and the tie rules)
-    bool gapped = false;
-    uint32_t g_ops = 0, g_lead = 0, g_trail = 0, g_pos = 0;
-    uint32_t* dirs = reinterpret_cast<uint32_t*>(V.scratch + (static_cast<size_t>(blockIdx.x) * 64 + lane) * MAP_LANE_SCRATCH);
-    uint32_t* rops = dirs + static_cast<size_t>(MAP_MAX_LEN) * MAP_DIR_WORDS;        // CIGAR words, last first
+    // a clipped candidate that stayed goes to the list of kernel 2
     const bool need = have && V.band > 0 && (s_best > 0 || e_best < L);
-    if (__any(need)) {
-        // the inner loop touches LDS only: the read end's bases once per read end, the allele's bases under the band once per candidate
-        for (uint32_t i = lane; i < L; i += 64) rb[i] = n_at(V.nmask, off, i) ? 4u : static_cast<uint8_t>(base_at(V.bases2, off, i));
-        __syncthreads();
-        const int32_t B = static_cast<int32_t>(V.band), W = 2 * B + 1;
-        uint8_t* refw = refw_all + lane * MAP_REFW;                             // refw[j] = allele base at diag - B + j, 5 outside the allele
-        if (need) {
-            const uint32_t span = L + 2 * static_cast<uint32_t>(B);
-            for (uint32_t j = 0; j < span; j++) {
-                const int64_t rp = diag - B + static_cast<int64_t>(j);
-                refw[j] = rp >= 0 && rp < alen ? static_cast<uint8_t>(enc_of(ref[rp])) : 5u;
-            }
-        }
-        // base i of the read end in alignment orientation against refw[j]
-        auto equal_w = [&](uint32_t i, uint32_t j) -> bool {
-            const uint32_t r = rb[strand ? L - 1 - i : i];
-            return r < 4u && refw[j] == (strand ? 3u - r : r);
-        };
-        if (need) {
-            // the running row of M / deletion / insertion scores in registers: the loop over the band is unrolled to its full width
-            // (a narrower band leaves the outer diagonals at "no alignment")
-            int32_t M[MAP_BAND_W], E[MAP_BAND_W], F[MAP_BAND_W];
-#pragma unroll
-            for (uint32_t k = 0; k < MAP_BAND_W; k++) { M[k] = MAP_NEG; E[k] = MAP_NEG; F[k] = MAP_NEG; }
-            int32_t best_total = INT32_MIN; uint32_t end_i = 0; int32_t end_k = 0;
-            for (uint32_t i = 0; i < L; i++) {
-                int32_t left_m = MAP_NEG, left_e = MAP_NEG;
-                const int32_t fresh = i == 0 ? V.end_bonus : 0;
-                const uint32_t r = rb[strand ? L - 1 - i : i];
-                const uint32_t want = r < 4u ? (strand ? 3u - r : r) : 6u;     // the allele base that equals this read base (6: none does)
-                uint32_t packed = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < MAP_BAND_W; k++) {
-                    if (static_cast<int32_t>(k) < W) {
-                        const uint32_t rbase = refw[i + k];                     // the allele position diag + i + (k - B) is entry i + k of the window
-                        const bool inref = rbase != 5u;
-                        const int32_t om = M[k], oe = E[k], of = F[k];
-                        const int32_t rm = k + 1 < MAP_BAND_W && static_cast<int32_t>(k) + 1 < W ? M[k + 1 < MAP_BAND_W ? k + 1 : k] : MAP_NEG;
-                        const int32_t rf = k + 1 < MAP_BAND_W && static_cast<int32_t>(k) + 1 < W ? F[k + 1 < MAP_BAND_W ? k + 1 : k] : MAP_NEG;
-                        int32_t prev = om; uint32_t code = 1;
-                        if (oe > prev) { prev = oe; code = 2; }
-                        if (of > prev) { prev = of; code = 3; }
-                        if (fresh > prev) { prev = fresh; code = 0; }
-                        int32_t nm = inref ? prev + (rbase == want ? V.match : -V.mismatch) : MAP_NEG;
-                        const int32_t fo = rm - V.gap_open, fe = rf - V.gap_extend;
-                        int32_t nf = fe > fo ? fe : fo; const uint32_t fcode = fe > fo ? 1u : 0u;
-                        const int32_t eo = left_m - V.gap_open, ee = left_e - V.gap_extend;
-                        int32_t ne = ee > eo ? ee : eo; const uint32_t ecode = ee > eo ? 1u : 0u;
-                        if (!inref) ne = MAP_NEG;
-                        if (nm < MAP_NEG / 2) nm = MAP_NEG;
-                        if (nf < MAP_NEG / 2) nf = MAP_NEG;
-                        if (ne < MAP_NEG / 2) ne = MAP_NEG;
-                        packed |= (code | (ecode << 2) | (fcode << 3)) << (4 * (k & 7));
-                        if ((k & 7) == 7 || static_cast<int32_t>(k) + 1 == W) { dirs[static_cast<size_t>(i) * MAP_DIR_WORDS + (k >> 3)] = packed; packed = 0; }
-                        M[k] = nm; E[k] = ne; F[k] = nf;
-                        left_m = nm; left_e = ne;
-                        if (nm > MAP_NEG) {
-                            const int32_t total = nm + (i + 1 == L ? V.end_bonus : 0);
-                            if (total > best_total) { best_total = total; end_i = i; end_k = static_cast<int32_t>(k); }
-                        }
-                    }
-                }
-            }
-            if (best_total > score) {
-                // traceback: CIGAR words last first
-                uint32_t i = end_i; int32_t k = end_k; uint32_t state = 0, n = 0, cur_op = 0xFFFFFFFFu, cur_len = 0;
-                auto emit = [&](uint32_t op) {
-                    if (op == cur_op) { cur_len++; return; }
-                    if (cur_len) rops[n++] = (cur_len << 4) | cur_op;
-                    cur_op = op; cur_len = 1;
-                };
-                for (;;) {
-                    const uint32_t d = (dirs[static_cast<size_t>(i) * MAP_DIR_WORDS + (k >> 3)] >> (4 * (k & 7))) & 15u;
-                    if (state == 0) {
-                        emit(equal_w(i, i + static_cast<uint32_t>(k)) ? 7u : 8u);
-                        const uint32_t c = d & 3u;
-                        if (c == 0) break;
-                        state = c - 1;                                          // 1 -> M, 2 -> deletion, 3 -> insertion; all at (i - 1, k)
-                        i--;
-                    } else if (state == 1) {
-                        emit(2u);                                               // D
-                        state = (d >> 2) & 1u ? 1u : 0u;
-                        k--;
-                    } else {
-                        emit(1u);                                               // I
-                        state = (d >> 3) & 1u ? 2u : 0u;
-                        i--; k++;
-                    }
-                }
-                if (cur_len) rops[n++] = (cur_len << 4) | cur_op;
-                gapped = true; score = best_total;
-                g_lead = i; g_trail = L - 1 - end_i; g_ops = n + (g_lead > 0) + (g_trail > 0);
-                g_pos = static_cast<uint32_t>(diag + static_cast<int64_t>(i) + (k - B));
-            }
-        }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long hm = __ballot(have), wm = __ballot(need);
+    const uint32_t slot = static_cast<uint32_t>(m) * V.slots + static_cast<uint32_t>(__popcll(hm & below));
+    if (have) {
+        MapCand c{};
+        c.diag = static_cast<uint32_t>(ckey); c.score = score; c.s = static_cast<uint16_t>(s_best); c.e = static_cast<uint16_t>(e_best);
+        c.g = static_cast<uint16_t>(g); c.state = need ? 1u : 0u;
+        V.cands[slot] = c;
+    }
+    if (lane == 0) V.n_have[m] = static_cast<uint32_t>(__popcll(hm));
+    if (wm) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&V.counters[0], static_cast<uint32_t>(__popcll(wm)));
+        base = static_cast<uint32_t>(__shfl(static_cast<int>(base), 0));
+        if (need) V.work[base + static_cast<uint32_t>(__popcll(wm & below))] = slot;
+    }
+}
+
+__global__ __launch_bounds__(64) void map_seed_kernel(const MapView V) {
+    __shared__ uint64_t keys[MAP_MAX_HITS];
+    __shared__ unsigned long long best[2 * MAP_MAX_BASIS];
+    __shared__ uint64_t cand_key[64];
+    for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) {
+        map_seed_one(V, m, keys, best, cand_key);
         __syncthreads();
     }
+}
+
+// ---- kernel 2: the clipped candidates again, with gaps (the header comment states the recurrence and the tie rules). One lane = one
+// candidate of the list, whichever read end it belongs to: every lane of a wavefront runs a band alignment of its own.
+__global__ __launch_bounds__(64) void map_gap_kernel(const MapView V) {
+    __shared__ uint8_t wantw[MAP_MAX_LEN * 64];         // [i][lane]: the allele base that equals base i of the read end in alignment orientation (6: none does)
+    __shared__ uint8_t refw[MAP_REFW * 64];             // [j][lane]: the allele base at diag - band + j (4: not ACGT, 5: outside the allele)
+    const uint32_t lane = threadIdx.x;
+    uint32_t* dirs = V.scratch + static_cast<size_t>(blockIdx.x) * V.max_len * MAP_DIR_WORDS * 64 + lane;      // [(i * MAP_DIR_WORDS + word) * 64]
+    const int32_t B = static_cast<int32_t>(V.band), W = 2 * B + 1;
+    for (uint32_t w0 = blockIdx.x * 64u; w0 < V.n_work; w0 += gridDim.x * 64u) {
+        if (w0 + lane >= V.n_work) continue;            // the columns of LDS are the lanes' own: no barrier below
+        const uint32_t slot = V.work[w0 + lane];
+        MapCand c = V.cands[slot];
+        const uint64_t m = slot / V.slots;
+        const uint32_t L = V.mate_len[m];
+        const uint64_t off = V.mate_off[m];
+        const uint32_t strand = c.g & 1u, allele = V.basis[c.g >> 1];
+        const int64_t diag = static_cast<int64_t>(c.diag) - 0x80000000ll;
+        const uint8_t* ref = V.seqs + V.seq_off[allele];
+        const int64_t alen = V.allele_len[allele];
+        for (uint32_t i = 0; i < L; i++) {
+            const uint32_t src = strand ? L - 1 - i : i;
+            const uint32_t r = base_at(V.bases2, off, src);
+            wantw[i * 64 + lane] = n_at(V.nmask, off, src) ? 6u : static_cast<uint8_t>(strand ? 3u - r : r);
+        }
+        const uint32_t span = L + 2 * static_cast<uint32_t>(B);
+        for (uint32_t j = 0; j < span; j++) {
+            const int64_t rp = diag - B + static_cast<int64_t>(j);
+            refw[j * 64 + lane] = rp >= 0 && rp < alen ? static_cast<uint8_t>(enc_of(ref[rp])) : 5u;
+        }
+        // the running row of M / deletion / insertion scores in registers: the loop over the band is unrolled to its full width
+        // (a narrower band leaves the outer diagonals at "no alignment")
+        int32_t M[MAP_BAND_W], E[MAP_BAND_W], F[MAP_BAND_W];
+#pragma unroll
+        for (uint32_t k = 0; k < MAP_BAND_W; k++) { M[k] = MAP_NEG; E[k] = MAP_NEG; F[k] = MAP_NEG; }
+        int32_t best_total = INT32_MIN; uint32_t end_i = 0; int32_t end_k = 0;
+        for (uint32_t i = 0; i < L; i++) {
+            int32_t left_m = MAP_NEG, left_e = MAP_NEG;
+            const int32_t fresh = i == 0 ? V.end_bonus : 0;
+            const uint32_t want = wantw[i * 64 + lane];
+            uint32_t packed = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < MAP_BAND_W; k++) {
+                if (static_cast<int32_t>(k) < W) {
+                    const uint32_t rbase = refw[(i + k) * 64 + lane];        // the allele position diag + i + (k - B) is entry i + k of the window
+                    const bool inref = rbase != 5u;
+                    const int32_t om = M[k], oe = E[k], of = F[k];
+                    const int32_t rm = k + 1 < MAP_BAND_W && static_cast<int32_t>(k) + 1 < W ? M[k + 1 < MAP_BAND_W ? k + 1 : k] : MAP_NEG;
+                    const int32_t rf = k + 1 < MAP_BAND_W && static_cast<int32_t>(k) + 1 < W ? F[k + 1 < MAP_BAND_W ? k + 1 : k] : MAP_NEG;
+                    int32_t prev = om; uint32_t code = 1;
+                    if (oe > prev) { prev = oe; code = 2; }
+                    if (of > prev) { prev = of; code = 3; }
+                    if (fresh > prev) { prev = fresh; code = 0; }
+                    int32_t nm = inref ? prev + (rbase == want ? V.match : -V.mismatch) : MAP_NEG;
+                    const int32_t fo = rm - V.gap_open, fe = rf - V.gap_extend;
+                    int32_t nf = fe > fo ? fe : fo; const uint32_t fcode = fe > fo ? 1u : 0u;
+                    const int32_t eo = left_m - V.gap_open, ee = left_e - V.gap_extend;
+                    int32_t ne = ee > eo ? ee : eo; const uint32_t ecode = ee > eo ? 1u : 0u;
+                    if (!inref) ne = MAP_NEG;
+                    if (nm < MAP_NEG / 2) nm = MAP_NEG;
+                    if (nf < MAP_NEG / 2) nf = MAP_NEG;
+                    if (ne < MAP_NEG / 2) ne = MAP_NEG;
+                    packed |= (code | (ecode << 2) | (fcode << 3)) << (4 * (k & 7));
+                    if ((k & 7) == 7 || static_cast<int32_t>(k) + 1 == W) { dirs[static_cast<size_t>(i * MAP_DIR_WORDS + (k >> 3)) * 64] = packed; packed = 0; }
+                    M[k] = nm; E[k] = ne; F[k] = nf;
+                    left_m = nm; left_e = ne;
+                    if (nm > MAP_NEG) {
+                        const int32_t total = nm + (i + 1 == L ? V.end_bonus : 0);
+                        if (total > best_total) { best_total = total; end_i = i; end_k = static_cast<int32_t>(k); }
+                    }
+                }
+            }
+        }
+        if (best_total <= c.score) continue;
+        // traceback, twice: the number of CIGAR words, then the words (met last first) into their place of the list
+        uint32_t n_words = 0, at = 0, lead = 0; int32_t k_first = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            uint32_t i = end_i; int32_t k = end_k; uint32_t state = 0, n = 0, cur_op = 0xFFFFFFFFu, cur_len = 0;
+            auto emit = [&](uint32_t op) {
+                if (op == cur_op) { cur_len++; return; }
+                if (cur_len) { if (pass) V.ops[at + n_words - 1 - n] = (cur_len << 4) | cur_op; n++; }
+                cur_op = op; cur_len = 1;
+            };
+            for (;;) {
+                const uint32_t d = (dirs[static_cast<size_t>(i * MAP_DIR_WORDS + (static_cast<uint32_t>(k) >> 3)) * 64] >> (4 * (k & 7))) & 15u;
+                if (state == 0) {
+                    emit(refw[(i + static_cast<uint32_t>(k)) * 64 + lane] == wantw[i * 64 + lane] ? 7u : 8u);
+                    const uint32_t cc = d & 3u;
+                    if (cc == 0) break;
+                    state = cc - 1;                                             // 1 -> M, 2 -> deletion, 3 -> insertion; all at (i - 1, k)
+                    i--;
+                } else if (state == 1) {
+                    emit(2u);                                                   // D
+                    state = (d >> 2) & 1u ? 1u : 0u;
+                    k--;
+                } else {
+                    emit(1u);                                                   // I
+                    state = (d >> 3) & 1u ? 2u : 0u;
+                    i--; k++;
+                }
+            }
+            if (cur_len) { if (pass) V.ops[at + n_words - 1 - n] = (cur_len << 4) | cur_op; n++; }
+            if (!pass) {
+                n_words = n; lead = i; k_first = k;
+                at = atomicAdd(&V.counters[1], n_words);
+                if (at + n_words > V.ops_cap || at + n_words < at) break;      // the host repeats the kernel with room for counters[1] words
+            } else {
+                c.state = 2; c.g_score = best_total; c.g_pos = static_cast<uint32_t>(diag + static_cast<int64_t>(lead) + (k_first - B));
+                c.g_lead = static_cast<uint16_t>(lead); c.g_trail = static_cast<uint16_t>(L - 1 - end_i); c.g_inner = static_cast<uint16_t>(n_words); c.ops_at = at;
+                V.cands[slot] = c;
+            }
+        }
+    }
+}
+
+// ---- kernel 3: the records of a read end from its candidates; sizes (WRITE = false), then the records themselves
+template <bool WRITE>
+__device__ void map_emit_one(const MapView& V, const uint64_t m) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t L = V.mate_len[m];
+    if (L == 0) {
+        if (!WRITE && lane == 0) { V.n_recs[m] = 0; V.n_cigar[m] = 0; }
+        return;
+    }
+    const uint64_t off = V.mate_off[m];
+    const bool have = lane < V.n_have[m];
+    MapCand c{};
+    if (have) c = V.cands[static_cast<uint32_t>(m) * V.slots + lane];
+    const bool gapped = have && c.state == 2;
+    const int32_t score = gapped ? c.g_score : c.score;
+    const uint32_t strand = c.g & 1u, allele = have ? V.basis[c.g >> 1] : 0u;
+    const int64_t diag = static_cast<int64_t>(c.diag) - 0x80000000ll;
+    const uint8_t* ref = V.seqs + V.seq_off[allele];
+    const uint32_t s_best = c.s, e_best = c.e;
+    // a position of the read end in alignment orientation: equal to the allele's base there?
+    auto equal_at = [&](uint32_t i) -> bool {
+        const uint32_t src = strand ? L - 1 - i : i;
+        if (n_at(V.nmask, off, src)) return false;
+        const uint32_t e = strand ? 3u - base_at(V.bases2, off, src) : base_at(V.bases2, off, src);
+        return enc_of(ref[diag + i]) == e;
+    };
     // ---- the primary record: best score, the smallest (allele, strand) on ties (the lanes are in that order)
     int32_t top = have ? score : INT32_MIN;
     for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o));
     const unsigned long long tops = __ballot(have && score == top);
     const uint32_t lp = tops ? static_cast<uint32_t>(__ffsll(static_cast<long long>(tops))) - 1u : 0xFFFFFFFFu;
     const bool keep = have && (lane == lp || score >= V.min_score);
-    // CIGAR words of a kept candidate: [S] runs of = / X [S]
+    // CIGAR words of a kept candidate: [S] runs of = / X [S], or what kernel 2 left
     uint32_t n_ops = 0;
-    if (keep && gapped) n_ops = g_ops;
+    if (keep && gapped) n_ops = c.g_inner + (c.g_lead > 0) + (c.g_trail > 0);
     else if (keep) {
         n_ops = (s_best > 0) + (e_best < L);
         bool prev = false;
@@ -354,6 +430,9 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
     const uint32_t ops_total = ops_primary + static_cast<uint32_t>(__shfl(static_cast<int>(ops_incl), 63));
     if (!WRITE) {
         if (lane == 0) { V.n_recs[m] = n_kept ? n_kept : 1u; V.n_cigar[m] = ops_total; }       // no candidate: one unmapped record
+        uint32_t widest = n_ops;
+        for (int o = 32; o > 0; o >>= 1) widest = max(widest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(widest), o)));
+        if (lane == 0 && widest > V.counters[2]) atomicMax(&V.counters[2], widest);
         return;
     }
     const uint32_t mate2 = V.paired && (m & 1u) ? LCTY_FLAG_MATE2 : 0u;
@@ -367,10 +446,9 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
         uint32_t* cg = V.cigar + cig0 + cig_rel;
         uint32_t w = 0;
         if (gapped) {
-            if (g_lead > 0) cg[w++] = (g_lead << 4) | 4u;
-            const uint32_t inner = g_ops - (g_lead > 0) - (g_trail > 0);
-            for (uint32_t j = 0; j < inner; j++) cg[w++] = rops[inner - 1 - j];
-            if (g_trail > 0) cg[w++] = (g_trail << 4) | 4u;
+            if (c.g_lead > 0) cg[w++] = (static_cast<uint32_t>(c.g_lead) << 4) | 4u;
+            for (uint32_t j = 0; j < c.g_inner; j++) cg[w++] = V.ops[c.ops_at + j];
+            if (c.g_trail > 0) cg[w++] = (static_cast<uint32_t>(c.g_trail) << 4) | 4u;
         } else {
             if (s_best > 0) cg[w++] = (s_best << 4) | 4u;                        // S
             bool prev = false; uint32_t len = 0;
@@ -383,7 +461,7 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
             if (e_best < L) cg[w++] = ((L - e_best) << 4) | 4u;
         }
         const uint16_t flags = static_cast<uint16_t>((strand ? LCTY_FLAG_REVERSE : 0u) | (lane == lp ? 0u : LCTY_FLAG_SECONDARY) | mate2);
-        V.recs[rec0 + rank] = lcty_aln_rec{gapped ? g_pos : static_cast<uint32_t>(diag + s_best), static_cast<uint16_t>(allele), flags, n_ops,
+        V.recs[rec0 + rank] = lcty_aln_rec{gapped ? c.g_pos : static_cast<uint32_t>(diag + s_best), static_cast<uint16_t>(allele), flags, n_ops,
                                            static_cast<uint32_t>(rel0 + cig_rel)};
     }
     // SEQ as the BAM has it: reverse-complemented when the primary record is on the reverse strand. The read end owns whole
@@ -408,24 +486,15 @@ __device__ void map_one(const MapView& V, const uint64_t m, uint64_t* keys, unsi
     }
 }
 
-// a fixed number of workgroups (their scratch is per workgroup) that take the read ends in turn
 template <bool WRITE>
-__global__ __launch_bounds__(64) void map_kernel(const MapView V) {
-    __shared__ uint64_t keys[MAP_MAX_HITS];
-    __shared__ unsigned long long best[2 * MAP_MAX_BASIS];
-    __shared__ uint64_t cand_key[64];
-    __shared__ uint8_t rb[MAP_MAX_LEN];                      // the read end's bases (0..3, 4 = not ACGT) as sequenced
-    __shared__ uint8_t refw_all[64 * MAP_REFW];              // per lane: the allele's bases under its band (4 = not ACGT or outside)
-    for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) {
-        map_one<WRITE>(V, m, keys, best, cand_key, rb, refw_all);
-        __syncthreads();
-    }
+__global__ __launch_bounds__(64) void map_emit_kernel(const MapView V) {
+    for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) map_emit_one<WRITE>(V, m);
 }
 
 }  // namespace
 
 struct MapIndex {
-    DevBuf<MapSlot> table; DevBuf<uint64_t> entries; DevBuf<uint16_t> basis; DevBuf<uint8_t> scratch;
+    DevBuf<MapSlot> table; DevBuf<uint64_t> entries; DevBuf<uint16_t> basis; DevBuf<uint32_t> scratch;
     uint64_t mask = 0; uint32_t k = 0, n_basis = 0;
 };
 
@@ -507,7 +576,9 @@ namespace {
 
 // both passes of the kernel; the records stay on the device (out), the offsets come to the host
 struct MapRun {
-    DevBuf<uint32_t> d_len, d_b2, d_nm, d_nrec, d_ncig, d_ob2, d_onm, d_cigar;
+    DevBuf<uint32_t> d_len, d_b2, d_nm, d_nrec, d_ncig, d_ob2, d_onm, d_cigar, d_nhave, d_work, d_counters, d_ops;
+    DevBuf<MapCand> d_cands;
+    uint32_t max_rec_cigar = 0;
     DevBuf<uint64_t> d_off, d_rec_at, d_cig_at, d_pair_cig;
     DevBuf<lcty_aln_rec> d_recs;
     std::vector<uint32_t> nrec, ncig;
@@ -530,7 +601,9 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
     aln_off[0] = 0; cigar_off[0] = 0;
     if (n == 0) return;
     const uint64_t nb = chunk->mate_off[n_mates];
+    uint32_t max_len = 1;
     for (uint64_t m = 0; m < n_mates; m++) {
+        max_len = std::max(max_len, chunk->mate_len[m]);
         if (chunk->mate_len[m] > MAP_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases (this one: %u)", MAP_MAX_LEN, chunk->mate_len[m]);
         if (chunk->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
         if (chunk->mate_len[m] >= params->k && (chunk->mate_len[m] - params->k) / params->stride + 2 > 64)
@@ -547,18 +620,53 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
     V.max_occ = params->max_occ ? params->max_occ : 4 * ix->n_basis;
     V.match = params->match; V.mismatch = params->mismatch; V.end_bonus = params->end_bonus; V.min_score = params->min_score;
     V.band = params->band; V.gap_open = params->gap_open; V.gap_extend = params->gap_extend;
-    const uint32_t n_wg = static_cast<uint32_t>(std::min<uint64_t>(n_mates, 8ull * static_cast<uint64_t>(ctx->props.multiProcessorCount)));
-    ix->scratch.ensure(static_cast<size_t>(n_wg) * 64 * MAP_LANE_SCRATCH);
-    V.scratch = ix->scratch.p;
+    const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
+    const uint32_t n_wg = static_cast<uint32_t>(std::min<uint64_t>(n_mates, 16ull * cus));
     V.seqs = locus->d_seqs.p; V.seq_off = locus->d_seq_off.p; V.allele_len = locus->d_allele_len.p;
     V.n_mates = n_mates; V.mate_len = X.d_len.p; V.mate_off = X.d_off.p; V.bases2 = X.d_b2.p; V.nmask = X.d_nm.p;
     V.paired = locus->bg.is_paired;
     V.n_recs = X.d_nrec.p; V.n_cigar = X.d_ncig.p;
-    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<false>, dim3(n_wg), dim3(64), 0, s, V); }, s);
+    // kernel 1: the candidates that stay, and the list of those to be aligned with gaps
+    V.slots = std::min<uint32_t>(64, 2 * ix->n_basis);
+    if (n_mates * V.slots > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "chunks of up to %llu read pairs with this basis", (unsigned long long)(0xFFFFFFFFull / V.slots / 2));
+    X.d_cands.alloc(n_mates * V.slots); X.d_nhave.alloc(n_mates); X.d_work.alloc(n_mates * V.slots);
+    X.d_counters.alloc(4); X.d_counters.zero(s);
+    V.cands = X.d_cands.p; V.n_have = X.d_nhave.p; V.work = X.d_work.p; V.counters = X.d_counters.p;
+    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_seed_kernel, dim3(n_wg), dim3(64), 0, s, V); }, s);
     LCTY_HIP(hipGetLastError());
+    uint32_t counters[4] = {0, 0, 0, 0};
+    X.d_counters.download(counters, 4, s);
+    LCTY_HIP(hipStreamSynchronize(s));
+    // kernel 2: the band alignments, repeated with more room if their CIGAR words did not fit
+    V.n_work = counters[0];
+    if (V.n_work) {
+        const uint32_t n_wg2 = static_cast<uint32_t>(std::min<uint64_t>((V.n_work + 63) / 64, 4ull * cus));
+        V.max_len = max_len;
+        ix->scratch.ensure(static_cast<size_t>(n_wg2) * max_len * MAP_DIR_WORDS * 64);
+        V.scratch = ix->scratch.p;
+        uint64_t cap = 6ull * V.n_work + 1024;
+        for (;;) {
+            if (cap > 0xFFFFFFF0ull) fail(LCTY_ERR_UNSUPPORTED, "CIGAR words of the alignments with gaps: map the chunk in parts");
+            X.d_ops.alloc(cap);
+            V.ops = X.d_ops.p; V.ops_cap = static_cast<uint32_t>(cap);
+            ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_gap_kernel, dim3(n_wg2), dim3(64), 0, s, V); }, s);
+            LCTY_HIP(hipGetLastError());
+            X.d_counters.download(counters, 4, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            if (counters[1] <= cap) break;
+            cap = static_cast<uint64_t>(counters[1]) + 1024;
+            const uint32_t zero = 0;
+            X.d_counters.upload(&zero, 1, s, 1);
+        }
+    }
+    // kernel 3, sizes
+    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_emit_kernel<false>, dim3(n_wg), dim3(64), 0, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
+    X.d_counters.download(counters, 4, s);
     X.nrec.resize(n_mates); X.ncig.resize(n_mates);
     X.d_nrec.download(X.nrec.data(), n_mates, s); X.d_ncig.download(X.ncig.data(), n_mates, s);
     LCTY_HIP(hipStreamSynchronize(s));
+    X.max_rec_cigar = counters[2];
     std::vector<uint64_t> rec_at(n_mates), cig_at(n_mates), pair_cig(n);
     uint64_t r = 0, c = 0;
     for (uint64_t p = 0; p < n; p++) {
@@ -576,7 +684,7 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
     X.d_ob2.zero(s); X.d_onm.zero(s);
     V.rec_at = X.d_rec_at.p; V.cig_at = X.d_cig_at.p; V.pair_cig = X.d_pair_cig.p; V.recs = X.d_recs.p; V.cigar = X.d_cigar.p;
     V.out_bases2 = X.d_ob2.p; V.out_nmask = X.d_onm.p;
-    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_kernel<true>, dim3(n_wg), dim3(64), 0, s, V); }, s);
+    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_emit_kernel<true>, dim3(n_wg), dim3(64), 0, s, V); }, s);
     LCTY_HIP(hipGetLastError());
     LCTY_HIP(hipStreamSynchronize(s));                                          // rec_at & co. are host vectors of this frame
 }
@@ -611,7 +719,7 @@ int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, c
         run_map(reads->locus, chunk, params, aln_off.data(), cigar_off.data(), false, X);
         lcty_reads_host h = *chunk;
         h.aln_off = aln_off.data(); h.cigar_off = cigar_off.data(); h.recs = nullptr; h.cigar = nullptr;
-        DeviceRecords dev{X.d_recs.p, X.d_cigar.p, X.d_ob2.p, X.d_onm.p, X.nrec.data(), MAP_OPS_CAP};
+        DeviceRecords dev{X.d_recs.p, X.d_cigar.p, X.d_ob2.p, X.d_onm.p, X.nrec.data(), X.max_rec_cigar};
         const int32_t rc = reads_append_device(reads, &h, &dev);
         if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
     });
