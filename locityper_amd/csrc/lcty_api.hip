@@ -118,6 +118,7 @@ int32_t lcty_ctx_trim(lcty_ctx* ctx) {
         LCTY_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->side) LCTY_HIP(hipStreamSynchronize(ctx->side));
         for (auto& w : ctx->solve_ws) w.release_all();
+        ctx->release_transfer_scratch();
     });
 }
 

@@ -181,6 +181,15 @@ struct lcty_ctx {
             seeds.release(); pri.release(); liks.release(); parts.release(); cww.release(); caln.release(); extra_cap = 0;
         }
     } solve_ws[2];
+    // Lane scratch of alignment recovery (lcty_transfer.hip): tens of GB for long reads, kept between the chunks of a streaming batch
+    // (allocating it costs more than the kernel). The solver stages take it back before they size their own workspace; lcty_ctx_trim
+    // releases it.
+    lcty::DevBuf<uint8_t> transfer_scratch;
+    std::mutex scratch_mutex;
+    void release_transfer_scratch() {
+        std::lock_guard<std::mutex> g(scratch_mutex);
+        if (transfer_scratch.n) transfer_scratch.release();
+    }
     int64_t knob(const char* name, int64_t dflt) const {
         auto it = knobs.find(name);
         return it == knobs.end() ? dflt : it->second;

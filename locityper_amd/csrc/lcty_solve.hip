@@ -1707,6 +1707,7 @@ struct StageRunner {
         const uint64_t ngp = V.ngp;
         const uint64_t per_chain = ngp * sizeof(ChainRec) + static_cast<uint64_t>(ws.extra_cap) * sizeof(ExtraLoc) + static_cast<uint64_t>(V.wstride) * 21 + 64;
         size_t free_b = 0, total_b = 0;
+        ctx->release_transfer_scratch();
         LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
         const uint64_t held = ws.recs.n * sizeof(ChainRec) + ws.extra.n * sizeof(ExtraLoc);      // what this workspace already owns counts as free
         uint64_t budget = static_cast<uint64_t>(0.92 * static_cast<double>(free_b + held));

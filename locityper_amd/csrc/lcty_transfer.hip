@@ -649,7 +649,14 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             levels = {l0, l1, l2};
             levels.resize(std::min<size_t>(levels.size(), static_cast<size_t>(std::max<int64_t>(1, ctx->knob("transfer_levels", 3)))));
         }
+        // long reads need tens of MB per wavefront (two CIGARs per lane, the words of every transferred alignment of the read): the more
+        // wavefronts fit, the better their gathers overlap — up to half of what is free on the device, at least 24 GB
         uint64_t scratch_budget = 24ull << 30;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                scratch_budget = std::max<uint64_t>(scratch_budget, std::min<uint64_t>((free_b + ctx->transfer_scratch.n) / 2, 128ull << 30));      // what the context already holds counts as free
+        }
         if (ctx->knob("transfer_scratch_mb", 0) > 0) scratch_budget = std::max<uint64_t>(64, static_cast<uint64_t>(ctx->knob("transfer_scratch_mb", 0))) << 20;
         // one wavefront per workgroup, 128 VGPRs (launch bounds; a few spills are cheaper than the fourth wavefront per SIMD is worth)
         uint32_t waves = 16;
@@ -663,7 +670,9 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         uint64_t arena_recs = std::min<uint64_t>(reads->n_recs * static_cast<uint64_t>(A > 1 ? A - 1 : 1) + 1024, 1500ull << 20);
         uint64_t arena_words = std::min<uint64_t>(arena_recs * std::max<uint32_t>(4, rec_cigar + 8), 6ull << 30);
         if (ctx->knob("transfer_arena", 0) > 0) { arena_recs = static_cast<uint64_t>(ctx->knob("transfer_arena", 0)); arena_words = 2 * arena_recs; }
-        DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords; DevBuf<uint8_t> d_scratch;
+        DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords;
+        std::lock_guard<std::mutex> scratch_guard(ctx->scratch_mutex);
+        DevBuf<uint8_t>& d_scratch = ctx->transfer_scratch;
         unsigned long long cursors[3] = {0, 0, 0};
         for (int attempt = 0;; attempt++) {
             if (attempt > 12) fail(LCTY_ERR_RUNTIME, "alignment recovery: arenas keep overflowing");
