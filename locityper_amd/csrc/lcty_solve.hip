@@ -435,21 +435,27 @@ struct Move {                  // ReassignmentTarget + what reassign() needs
 };
 
 // ---------------- K12 + K13: one 256-thread workgroup per chain ----------------
-// inclusive prefix sum over the 256 threads of the workgroup (wave shuffles + one LDS exchange); *total = sum of all
-__device__ __forceinline__ uint32_t block_prefix_excl(uint32_t v, uint32_t lane, uint32_t wave, uint32_t* wave_sums, uint32_t* total) {
-    uint32_t incl = v;
+// a barrier that orders LDS traffic only: __syncthreads() also waits for every global load of the wavefront (one counter for loads and
+// stores on this architecture), which would end the prefetch below at the first barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// inclusive prefix sums of two values over the 256 threads of the workgroup (wave shuffles + one LDS exchange); *total = sum of all
+__device__ __forceinline__ void block_prefix_excl2(uint32_t va, uint32_t vb, uint32_t lane, uint32_t wave, uint2* wave_sums, uint32_t* ea, uint32_t* eb,
+                                                   uint32_t* total_a, uint32_t* total_b) {
+    uint32_t ia = va, ib = vb;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), o));
-        if (lane >= static_cast<uint32_t>(o)) incl += up;
+        const uint32_t ua = static_cast<uint32_t>(__shfl_up(static_cast<int>(ia), o)), ub = static_cast<uint32_t>(__shfl_up(static_cast<int>(ib), o));
+        if (lane >= static_cast<uint32_t>(o)) { ia += ua; ib += ub; }
     }
-    if (lane == 63) wave_sums[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t q = 0; q < wave; q++) before += wave_sums[q];
-    *total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
-    __syncthreads();
-    return before + incl - v;
+    if (lane == 63) wave_sums[wave] = make_uint2(ia, ib);
+    lds_barrier();
+    uint32_t ba = 0, bb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) { const uint2 w = wave_sums[q]; if (q < wave) { ba += w.x; bb += w.y; } ta += w.x; tb += w.y; }
+    *total_a = ta; *total_b = tb;
+    lds_barrier();
+    *ea = ba + ia - va; *eb = bb + ib - vb;
 }
 
 template <uint32_t P>
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* depth = reinterpret_cast<uint32_t*>(smem);                          // [wstride]
     double* red = reinterpret_cast<double*>(smem + ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)));   // [256]
-    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(red + 256);                  // [4]
+    uint2* wave_cnt = reinterpret_cast<uint2*>(red + 256);                        // [4]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
@@ -497,12 +503,25 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
     double aln_part = 0.0;
     uint32_t nt_total = 0, ex_total = 0;
+    // the table cells of the next 256 reads are requested before this block's are used (the barriers below do not wait for them)
+    LocEntry nxt[P];
+    if (tid < V.n_good) {
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) nxt[p] = V.table[static_cast<uint64_t>(G.row[p]) * V.ngp + tid];
+    }
     for (uint32_t base = 0; base < V.n_good; base += 256) {
         const uint32_t rp = base + tid;
         Locs<P> L; L.nw = 0;
         uint32_t a0 = 0;
+        LocEntry cur[P];
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) cur[p] = nxt[p];
+        if (rp + 256 < V.n_good) {
+#pragma unroll
+            for (uint32_t p = 0; p < P; p++) nxt[p] = V.table[static_cast<uint64_t>(G.row[p]) * V.ngp + rp + 256];
+        }
         if (rp < V.n_good) {
-            locs_init(L, V, rp, G);
+            locs_from_cells<P>(L, V, cur);
             if (L.nw > 255) atomicMax(V.overflow, 2u);                           // a record keeps the location in 8 bits
             if (L.nw > 1 && random_start)
                 a0 = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
@@ -510,9 +529,9 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
         const bool nontrivial = L.nw > 1;
         const uint32_t n_extra = L.nw > 2 ? min(L.nw, 255u) - 2u : 0u;
         // ordered compaction of the non-trivial reads (assgn.rs:61-63) and of their locations beyond the second
-        uint32_t chunk_nt, chunk_ex;
-        const uint32_t slot = nt_total + block_prefix_excl(nontrivial ? 1u : 0u, lane, wave, wave_cnt, &chunk_nt);
-        const uint32_t eix = ex_total + block_prefix_excl(n_extra, lane, wave, wave_cnt, &chunk_ex);
+        uint32_t chunk_nt, chunk_ex, slot, eix;
+        block_prefix_excl2(nontrivial ? 1u : 0u, n_extra, lane, wave, wave_cnt, &slot, &eix, &chunk_nt, &chunk_ex);
+        slot += nt_total; eix += ex_total;
         nt_total += chunk_nt; ex_total += chunk_ex;
         if (L.nw > 0) {
             ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = min(L.nw, 255u) | (eix << 8);
