@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per locus (BASELINE: 1M)")
     ap.add_argument("--alleles", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
+    ap.add_argument("--knob", action="append", default=[], help="developer experiments: name=value for lcty_ctx_set_knob (repeatable)")
     ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
     ap.add_argument("--ont-sample", type=int, default=6144,
                     help="reads of the extra long-read measurement (BASELINE.json configs[2] shape: 10 kb ONT reads x the locus' alleles, "
@@ -232,6 +233,9 @@ def main():
     if ndev < 1:
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
     ctx = api.Context(local_rank % ndev)
+    for kv in args.knob:
+        name, _, val = kv.partition("=")
+        ctx.set_knob(name, int(val))
 
     comm = None
     first_pair = 0

@@ -245,9 +245,9 @@ int32_t lcty_params_resolve(lcty_params* params, const lcty_bg* bg);
  *   seqs       ASCII allele sequences, concatenated; seq_off[n_alleles+1]
  *   offtarget  off-target k-mer counts (first KmerCounts block), cnt_off[n_alleles+1],
  *              cnt_off[a+1]-cnt_off[a] == len(a)+1-k
- *   k          LIMIT: k <= 31. The reference stores k-mers as u128 and accepts k <= 63 (src/seq/kmers.rs:8, 43; locs.rs:919);
- *              this build keeps them in 64 bits (the default k of `locityper add` is 25) and returns LCTY_ERR_UNSUPPORTED for
- *              32 <= k <= 63, never a different count                                                                      */
+ *   k          2 <= k <= 63 as in the reference (u128 k-mers, src/seq/kmers.rs:8-26; locs.rs:919). k <= 31 (the default of
+ *              `locityper add` is 25): 64-bit keys, the set built on the device, the reads' k-mers taken from registers;
+ *              32 <= k <= 63: 128-bit keys in a table of {lo, hi} pairs built on the host, the reads' k-mers from memory          */
 int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles,
                           const uint8_t* seqs, const uint64_t* seq_off,
                           const uint16_t* offtarget, const uint64_t* cnt_off, uint32_t k,

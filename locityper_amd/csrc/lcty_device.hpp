@@ -122,6 +122,47 @@ __device__ inline bool window_has_n(const uint32_t* nm, uint32_t q, uint32_t k) 
     return (bits & ((1u << k) - 1u)) != 0u;
 }
 
+// ---- k-mers of 32..63 bases (the reference keeps every k-mer of UniqueKmers in a u128, locs.rs:919-963): 128-bit keys as {lo, hi}
+// pairs, the set an open-addressing table of pairs built on the host (lcty_locus_create), free = {~0, ~0} ----
+struct Kmer128 { uint64_t lo, hi; };
+__host__ __device__ inline uint64_t kmer128_hash(uint64_t lo, uint64_t hi) { return mix64(lo ^ mix64(hi ^ 0x9E3779B97F4A7C15ull)); }
+__device__ __forceinline__ uint64_t pair_reverse64(uint64_t x) {
+    const uint64_t y = __brevll(x);
+    return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+}
+// canonical k-mer of the window at base q, 32 <= k <= 63 (the 64-bit form above, on two words)
+__device__ inline Kmer128 canonical_kmer_2bit128(const uint64_t* w64, uint32_t q, uint32_t k) {
+    const uint32_t word = q >> 5, sh = (q & 31u) * 2u, last = (q + k - 1) >> 5;
+    const uint64_t a = w64[word], b = last > word ? w64[word + 1] : 0ull, c = last > word + 1 ? w64[word + 2] : 0ull;
+    uint64_t xlo = a, xhi = b;
+    if (sh) { xlo = (a >> sh) | (b << (64u - sh)); xhi = (b >> sh) | (c << (64u - sh)); }
+    const uint32_t hb = 2u * k - 64u;                                    // bits of the k-mer in the high word: 0..62
+    const uint64_t hmask = (1ull << hb) - 1ull;
+    xhi &= hmask;
+    const uint64_t rlo = ~xlo, rhi = (~xhi) & hmask;                      // the reverse complement's value
+    const uint64_t ylo = pair_reverse64(xhi), yhi = pair_reverse64(xlo); // the digits of x in reverse order, at the top of 128 bits
+    const uint32_t s = 128u - 2u * k;                                     // 2..64
+    const uint64_t flo = s == 64u ? yhi : (ylo >> s) | (yhi << (64u - s)), fhi = s == 64u ? 0ull : yhi >> s;
+    const bool rv_less = rhi < fhi || (rhi == fhi && rlo < flo);
+    return rv_less ? Kmer128{rlo, rhi} : Kmer128{flo, fhi};
+}
+// any "not ACGT" base inside [q, q+k), k <= 63
+__device__ inline bool window_has_n_wide(const uint32_t* nm, uint32_t q, uint32_t k) {
+    const uint32_t w = q >> 5, s = q & 31u, last = (q + k - 1) >> 5;
+    uint64_t bits = (static_cast<uint64_t>(nm[w]) | (last > w ? static_cast<uint64_t>(nm[w + 1]) << 32 : 0ull)) >> s;
+    if (last > w + 1) bits |= static_cast<uint64_t>(nm[w + 2]) << (64u - s);       // s > 0 here: three words only with an offset
+    return (bits & ((1ull << k) - 1ull)) != 0ull;
+}
+__device__ inline bool kset128_contains(const uint64_t* kset, uint64_t mask, Kmer128 key) {
+    uint64_t slot = kmer128_hash(key.lo, key.hi) & mask;
+    while (true) {
+        const uint64_t lo = kset[2 * slot], hi = kset[2 * slot + 1];
+        if (lo == key.lo && hi == key.hi) return true;
+        if (lo == KSET_EMPTY && hi == KSET_EMPTY) return false;
+        slot = (slot + 1) & mask;
+    }
+}
+
 __device__ inline bool kset_contains(const uint64_t* kset, uint64_t mask, uint64_t key) {
     uint64_t slot = mix64(key) & mask;
     while (true) {

@@ -250,7 +250,7 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
         if (n_alleles == 0 || n_alleles > 65535)
             fail(LCTY_ERR_INVALID_INPUT, "number of alleles (%u) must be in 1..65535 (seq/contigs.rs:96-98)", n_alleles);
         if (k < 2) fail(LCTY_ERR_INVALID_INPUT, "k-mer size (%u) must be over 1 (locs.rs:937)", k);
-        if (k > 31) fail(LCTY_ERR_UNSUPPORTED, "k = %u: this build stores k-mers in 64 bits (k <= 31)", k);
+        if (k > 63) fail(LCTY_ERR_INVALID_INPUT, "k-mer size (%u) must be at most 63 (kmers.rs:24-26: u128 k-mers)", k);
         if (params->tweak < 0 || std::isnan(params->prob_diff) || std::isnan(params->unmapped_penalty))
             fail(LCTY_ERR_INVALID_INPUT, "params have unresolved auto fields: call lcty_params_resolve first");
         if (static_cast<uint32_t>(params->tweak) >= params->boundary_size)
@@ -347,6 +347,52 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
             }
         }
 
+        // ---- K1: k-mers of 32..63 bases on the host (128-bit keys; the walk of kset_build_kernel) ----
+        if (k > 31) {
+            typedef unsigned __int128 u128;
+            const u128 kmask = (static_cast<u128>(1) << (2 * k)) - 1;
+            const uint32_t rv_shift = 2 * k - 2;
+            std::vector<u128> keys;
+            bool undef = false;
+            for (uint32_t a = 0; a < n_alleles; a++) {
+                const uint8_t* seq = seqs + seq_off[a];
+                const uint64_t len = seq_off[a + 1] - seq_off[a];
+                const uint16_t* cnt = offtarget + cnt_off[a];
+                if (len < k) continue;
+                u128 fw = 0, rv = 0;
+                uint64_t reset = k - 1;
+                for (uint64_t i = 0; i < len; i++) {
+                    const uint8_t ch = seq[i];
+                    const uint32_t enc = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+                    if (enc == 4) {
+                        reset = i + k;
+                        if (i + 1 >= k && cnt[i + 1 - k] == 0) undef = true;         // UNDEF enters the set (kmers.rs:184-190)
+                        continue;
+                    }
+                    fw = ((fw << 2) | enc) & kmask;
+                    rv = (rv >> 2) | (static_cast<u128>(3 - enc) << rv_shift);
+                    if (i + 1 >= k) {
+                        const uint64_t pos = i + 1 - k;
+                        if (cnt[pos] != 0) continue;
+                        if (i >= reset) keys.push_back(rv < fw ? rv : fw); else undef = true;
+                    }
+                }
+            }
+            std::sort(keys.begin(), keys.end());
+            keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+            L->undef_in_set = undef ? 1u : 0u;
+            L->n_unique = keys.size() + (undef ? 1 : 0);
+            L->kset_cap = next_pow2(std::max<uint64_t>(4 * keys.size(), 1024));
+            std::vector<uint64_t> table(2 * L->kset_cap, KSET_EMPTY);
+            for (const u128 key : keys) {
+                const uint64_t lo = static_cast<uint64_t>(key), hi = static_cast<uint64_t>(key >> 64);
+                uint64_t slot = kmer128_hash(lo, hi) & (L->kset_cap - 1);
+                while (table[2 * slot] != KSET_EMPTY || table[2 * slot + 1] != KSET_EMPTY) slot = (slot + 1) & (L->kset_cap - 1);
+                table[2 * slot] = lo; table[2 * slot + 1] = hi;
+            }
+            L->d_kset.alloc(table.size()); L->d_kset.upload(table.data(), table.size(), s);
+            LCTY_HIP(hipStreamSynchronize(s));
+        } else
         // ---- K1 (device) ----
         {
             DevBuf<uint64_t> d_big; DevBuf<uint32_t> d_flag; DevBuf<unsigned long long> d_n;

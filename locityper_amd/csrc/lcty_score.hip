@@ -211,7 +211,10 @@ __device__ __noinline__ uint32_t mate_unique_kmers_global(const uint64_t* kset, 
         const uint32_t q = base + lane;
         bool hit = false;
         if (q < nk) {
-            if (window_has_n(nm, q, k)) hit = undef_in_set != 0;         // UNDEF k-mer (kmers.rs:184-190)
+            if (k > 31) {                                                // 128-bit k-mers: a table of {lo, hi} pairs
+                if (window_has_n_wide(nm, q, k)) hit = undef_in_set != 0;
+                else hit = kset128_contains(kset, kset_mask, canonical_kmer_2bit128(w64, q, k));
+            } else if (window_has_n(nm, q, k)) hit = undef_in_set != 0;  // UNDEF k-mer (kmers.rs:184-190)
             else hit = kset_contains(kset, kset_mask, canonical_kmer_2bit(w64, q, k));
         }
         walk.feed(__ballot(hit), base, k);
@@ -566,7 +569,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
         const lcty_aln_rec* recs = R.recs + a0;
 
         // ---------------- prologue: prefetch read bases (consumed by K2) ----------------
-        const bool regs_ok = len0 <= 2016 && len1 <= 2016;
+        const bool regs_ok = len0 <= 2016 && len1 <= 2016 && L.k <= 31;      // k-mers of 32..63 bases take the general path
         uint64_t bw0 = 0, bw1 = 0;
         uint32_t nm0 = 0, nm1 = 0;
         if (regs_ok) {

@@ -81,6 +81,34 @@ def test_undef_kmer_quirk(gpu_ctx):
     assert oa.uniq_kmers[0] == 6        # the N windows are "hits"
 
 
+@pytest.mark.parametrize("k", [32, 41, 63])
+def test_kmers_beyond_31_bases(gpu_ctx, k):
+    """k-mers of 32..63 bases (u128 in the reference: kmers.rs:8-26, locs.rs:919-963): the unique set, the per-mate counts of
+    unique non-overlapping k-mers (bit-exact) and everything downstream of the read weight; an N inside an allele window
+    with count 0 still puts UNDEF into the set."""
+    L = synth.SynthLocus(6, 3000, seed=41, base_len=6000, k=k)
+    loc, ol, p = both_loci(gpu_ctx, L)
+    assert loc.n_unique_kmers() == ol.n_unique_kmers() > 1000
+    ch = L.reads(0, 3000)
+    aa, oa = api.AllAlignments.load(loc, ch), ol.load(ch)
+    M, Mo = compare_gpu_to_oracle(aa, oa)
+    assert len(set(oa.uniq_kmers.tolist())) >= 3 and oa.n_good > 1000
+    check_prefilter(aa, Mo, 6, p)
+    alleles = random_alleles(2, 1500, seed=9)
+    alleles[1] = alleles[1][:700] + b"N" + alleles[1][701:]
+    bg = make_bg()
+    p2 = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(alleles, k)
+    loc2 = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, k, bg, p2)
+    ol2 = O.OracleLocus(seqs, seq_off, cflat, cnt_off, k, bg, p2)
+    assert loc2.n_unique_kmers() == ol2.n_unique_kmers()
+    s1 = alleles[0][300:450].decode()
+    s1n = s1[:60] + "N" + s1[61:]
+    s2 = alleles[0][620:770].decode()
+    ch2 = ReadsChunk.from_pairs([{"seq1": s1n, "seq2": s2, "recs": [(0, 300, 0, "150="), (0, 620, M2 | REV, "150=")]}])
+    compare_gpu_to_oracle(api.AllAlignments.load(loc2, ch2), ol2.load(ch2))
+
+
 # ------------------------------------------------------------------ scoring + prefilter on the synthetic configs
 def test_config1_full(gpu_ctx):
     """BASELINE configs[0]: 10k PE pairs x 8 alleles (the reference's own CPU-runnable case), complete."""
@@ -320,8 +348,11 @@ def test_invalid_inputs_fail_loudly(gpu_ctx):
     with pytest.raises(_lib.LocityperError):
         aa.status()                                   # not scored yet
     with pytest.raises(_lib.LocityperError) as e:
-        api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 40, bg, p)      # k > 31: loud UNSUPPORTED, counts mismatch first
-    assert e.value.code in (cdefs.ERR_UNSUPPORTED, cdefs.ERR_INVALID_DATA)
+        api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 64, bg, p)      # k > 63: beyond u128 k-mers (kmers.rs:24-26)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
+    with pytest.raises(_lib.LocityperError) as e:
+        api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 40, bg, p)      # counts made for another k (locs.rs:944)
+    assert e.value.code == cdefs.ERR_INVALID_DATA
 
 
 def test_empty_batch(gpu_ctx):
