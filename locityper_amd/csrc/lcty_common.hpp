@@ -185,10 +185,13 @@ struct lcty_ctx {
     // (allocating it costs more than the kernel). The solver stages take it back before they size their own workspace; lcty_ctx_trim
     // releases it.
     lcty::DevBuf<uint8_t> transfer_scratch;
+    lcty::DevBuf<uint8_t> transfer_recs; lcty::DevBuf<uint32_t> transfer_words;      // arenas of the transferred alignments (records as bytes: lcty_aln_rec is declared later)
     std::mutex scratch_mutex;
     void release_transfer_scratch() {
         std::lock_guard<std::mutex> g(scratch_mutex);
         if (transfer_scratch.n) transfer_scratch.release();
+        if (transfer_recs.n) transfer_recs.release();
+        if (transfer_words.n) transfer_words.release();
     }
     int64_t knob(const char* name, int64_t dflt) const {
         auto it = knobs.find(name);

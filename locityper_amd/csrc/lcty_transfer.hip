@@ -670,9 +670,10 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         uint64_t arena_recs = std::min<uint64_t>(reads->n_recs * static_cast<uint64_t>(A > 1 ? A - 1 : 1) + 1024, 1500ull << 20);
         uint64_t arena_words = std::min<uint64_t>(arena_recs * std::max<uint32_t>(4, rec_cigar + 8), 6ull << 30);
         if (ctx->knob("transfer_arena", 0) > 0) { arena_recs = static_cast<uint64_t>(ctx->knob("transfer_arena", 0)); arena_words = 2 * arena_recs; }
-        DevBuf<lcty_aln_rec> d_xrecs; DevBuf<uint32_t> d_xwords;
         std::lock_guard<std::mutex> scratch_guard(ctx->scratch_mutex);
         DevBuf<uint8_t>& d_scratch = ctx->transfer_scratch;
+        DevBuf<uint8_t>& d_xrecs_bytes = ctx->transfer_recs; DevBuf<uint32_t>& d_xwords = ctx->transfer_words;     // kept between calls, as the scratch
+        lcty_aln_rec* xrecs = nullptr;
         unsigned long long cursors[3] = {0, 0, 0};
         for (int attempt = 0;; attempt++) {
             if (attempt > 12) fail(LCTY_ERR_RUNTIME, "alignment recovery: arenas keep overflowing");
@@ -681,7 +682,8 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             while (hcap < 2 * cap_alns + 2) hcap <<= 1;
             const uint64_t cap_words64 = static_cast<uint64_t>(cap_new) * words_per_new;
             const uint32_t cap_words = static_cast<uint32_t>(std::min<uint64_t>(cap_words64, 1u << 30));
-            d_xrecs.alloc(arena_recs); d_xwords.alloc(arena_words);
+            d_xrecs_bytes.ensure(arena_recs * sizeof(lcty_aln_rec)); d_xwords.ensure(arena_words);
+            xrecs = reinterpret_cast<lcty_aln_rec*>(d_xrecs_bytes.p);
             d_flag.zero(s); LCTY_HIP(hipMemsetAsync(d_cursors.p, 0, 3 * sizeof(unsigned long long), s));      // the aligner's cell count runs on
             uint32_t flag = 0;
             reads->recover_level_pairs[0] = reads->recover_level_pairs[1] = reads->recover_level_pairs[2] = 0;
@@ -700,7 +702,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 T.redo_list = next; T.redo_n = d_cursors.p + 2;
                 T.scratch = d_scratch.p; T.scratch_stride = stride;
                 T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
-                T.out_recs = d_xrecs.p; T.out_recs_cap = arena_recs; T.out_words = d_xwords.p; T.out_words_cap = arena_words;
+                T.out_recs = xrecs; T.out_recs_cap = arena_recs; T.out_words = d_xwords.p; T.out_words_cap = arena_words;
                 T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.dp_cells = d_cursors.p + 3; T.min_weight = loc->prm.min_weight;
                 LCTY_HIP(hipMemsetAsync(d_cursors.p + 2, 0, sizeof(unsigned long long), s));
                 ctx->timed(LCTY_K_TRANSFER, [&] {
@@ -753,7 +755,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         d_m_aln.upload(m_aln.data(), R + 1, s); d_m_cig.upload(m_cig.data(), R + 1, s);
         d_m_recs.alloc(m_aln[R] + 1); d_m_cigar.alloc(m_cig[R] + 8); d_m_meta.alloc(raw_pairs_cap);
         hipLaunchKernelGGL(merge_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(R, 65535))), dim3(64), 0, s, reads->view(), d_new_cnt.p, d_new_words.p,
-                           d_rec_at.p, d_word_at.p, d_xrecs.p, d_xwords.p, d_m_aln.p, d_m_cig.p, d_m_recs.p, d_m_cigar.p, d_m_meta.p);
+                           d_rec_at.p, d_word_at.p, xrecs, d_xwords.p, d_m_aln.p, d_m_cig.p, d_m_recs.p, d_m_cigar.p, d_m_meta.p);
         LCTY_HIP(hipGetLastError());
         LCTY_HIP(hipStreamSynchronize(s));
         reads->d_aln_off = std::move(d_m_aln); reads->d_cigar_off = std::move(d_m_cig);
