@@ -635,6 +635,14 @@ void    lcty_bam_table_free(lcty_bam_table* t);
 /* DB/loci/<locus>/haplotypes.fa[.gz] (ContigSet::load, src/seq/contigs.rs:295-306): names up to the first blank (0-separated in
  * `names`), upper-cased sequences concatenated, seq_off[n_seqs + 1]. Called twice: with names = seqs = seq_off = NULL it returns the sizes. */
 int32_t lcty_fasta_read(const char* path, uint32_t* n_seqs, char* names, uint64_t* names_len, uint8_t* seqs, uint64_t* seqs_len, uint64_t* seq_off);
+/* DB/loci/<locus>/haplotypes.paf[.gz|.br|.lz4] as process_paf reads it (src/command/genotype.rs:1131-1160; PafFile::next and
+ * PafEntry::parse, src/seq/paf.rs:31-56, 103-144): the entries lcty_locus_set_hap_alns takes, in file order. names[n_alleles]: the
+ * contig names of the locus (their order gives the ids). Left out, as there: empty and '#' lines, lines naming a contig the locus
+ * does not have, self-alignments, entries without a cg:Z: tag, entries that do not cover both sequences on the forward strand
+ * (HapAlns::add, src/seq/transfer.rs:48-52). Malformed lines are errors, as there. Called twice: id1 = NULL sizes it
+ * (*n_entries, *n_cigar); with buffers, *n_entries / *n_cigar carry their capacities in. cigar_off[n_entries + 1]. */
+int32_t lcty_paf_read(const char* path, const char* const* names, uint32_t n_alleles, uint64_t* n_entries, uint32_t* id1, uint32_t* id2,
+                      uint32_t* n_matches, uint32_t* aln_len, uint64_t* cigar_off, uint32_t* cigar, uint64_t* n_cigar);
 
 #ifdef __cplusplus
 }

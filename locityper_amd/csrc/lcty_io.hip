@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "lcty_common.hpp"
@@ -619,6 +620,101 @@ int32_t lcty_fasta_read(const char* path, uint32_t* n_seqs, char* names, uint64_
         else if (seqs) fail(LCTY_ERR_INVALID_INPUT, "sequence buffer too small");
         if (seq_off) memcpy(seq_off, off.data(), sizeof(uint64_t) * off.size());
         *n_seqs = n; *names_len = nm.size(); *seqs_len = sq.size();
+    });
+}
+
+// DB/loci/<locus>/haplotypes.paf[.gz|.br|.lz4] as process_paf reads it (command/genotype.rs:1131-1160; PafFile::next, seq/paf.rs:31-56;
+// PafEntry::parse, 103-144): the entries lcty_locus_set_hap_alns takes. Left out, as there: empty lines and lines that start with '#',
+// lines that name a contig the locus does not have, self-alignments, entries without a cg:Z: tag, and entries that do not cover both
+// sequences on the forward strand (HapAlns::add drops those without remembering the pair, transfer.rs:48-52). Fewer than 12 columns,
+// a number that does not parse, a strand other than + / - or a CIGAR operation outside MIDSH=X: an error, as there.
+// Two calls: id1 = NULL sizes it (*n_entries, *n_cigar); with buffers, *n_entries / *n_cigar hold their capacities on entry.
+int32_t lcty_paf_read(const char* path, const char* const* names, uint32_t n_alleles, uint64_t* n_entries, uint32_t* id1, uint32_t* id2,
+                      uint32_t* n_matches, uint32_t* aln_len, uint64_t* cigar_off, uint32_t* cigar, uint64_t* n_cigar) {
+    return guarded([&] {
+        if (!path || !names || !n_entries || !n_cigar) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        const bool fill = id1 != nullptr;
+        if (fill && (!id2 || !n_matches || !aln_len || !cigar_off || !cigar)) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        std::vector<uint8_t> raw = slurp(path);
+        const std::string p(path);
+        const std::vector<uint8_t> text = (ends_with(p, ".gz") || ends_with(p, ".bgz")) ? inflate_gzip(raw, path)
+                                          : ends_with(p, ".lz4") ? decode_lz4(raw, path) : ends_with(p, ".br") ? decode_brotli(raw, path) : raw;
+        std::unordered_map<std::string, uint32_t> ids;
+        for (uint32_t a = 0; a < n_alleles; a++) {
+            if (!names[a]) fail(LCTY_ERR_INVALID_INPUT, "null contig name");
+            ids.emplace(names[a], a);
+        }
+        const uint64_t cap_e = fill ? *n_entries : 0, cap_c = fill ? *n_cigar : 0;
+        uint64_t ne = 0, nc = 0;
+        std::vector<uint32_t> words;
+        size_t i = 0;
+        while (i < text.size()) {
+            size_t e = i;
+            while (e < text.size() && text[e] != '\n') e++;
+            size_t le = e;
+            if (le > i && text[le - 1] == '\r') le--;
+            const size_t line0 = i;
+            i = e + 1;
+            if (le == line0 || text[line0] == '#') continue;
+            std::vector<std::pair<size_t, size_t>> col;                       // [begin, end)
+            for (size_t q = line0, b = line0;; q++) {
+                if (q == le || text[q] == '\t') { col.emplace_back(b, q); b = q + 1; if (q == le) break; }
+            }
+            auto str = [&](size_t c) { return std::string(reinterpret_cast<const char*>(&text[col[c].first]), col[c].second - col[c].first); };
+            if (col.size() < 12) fail(LCTY_ERR_INVALID_INPUT, "%s: PAF line (%s) has too few columns", path, str(0).c_str());
+            const auto q_it = ids.find(str(0));
+            if (q_it == ids.end()) continue;
+            const auto t_it = ids.find(str(5));
+            if (t_it == ids.end()) continue;
+            auto num = [&](size_t c) -> uint32_t {                              // str::parse::<u32>: digits only (a leading '+' is accepted there too)
+                const std::string v = str(c);
+                size_t k = (!v.empty() && v[0] == '+') ? 1 : 0;
+                if (k == v.size()) fail(LCTY_ERR_INVALID_DATA, "%s: could not parse PAF line of %s", path, str(0).c_str());
+                uint64_t x = 0;
+                for (; k < v.size(); k++) {
+                    if (v[k] < '0' || v[k] > '9') fail(LCTY_ERR_INVALID_DATA, "%s: could not parse PAF line of %s", path, str(0).c_str());
+                    x = x * 10 + static_cast<uint64_t>(v[k] - '0');
+                    if (x > 0xFFFFFFFFull) fail(LCTY_ERR_INVALID_DATA, "%s: could not parse PAF line of %s", path, str(0).c_str());
+                }
+                return static_cast<uint32_t>(x);
+            };
+            const uint32_t qlen = num(1), qs = num(2), qe = num(3);
+            const std::string strand = str(4);
+            if (strand != "+" && strand != "-") fail(LCTY_ERR_INVALID_DATA, "%s: strand '%s'", path, strand.c_str());
+            const uint32_t tlen = num(6), ts = num(7), te = num(8), nm = num(9), al = num(10);
+            bool have_cigar = false;
+            words.clear();
+            for (size_t c = 12; c < col.size(); c++) {
+                if (col[c].second - col[c].first < 5 || memcmp(&text[col[c].first], "cg:Z:", 5) != 0) continue;
+                have_cigar = true;
+                words.clear();                                                    // a later tag replaces an earlier one
+                uint32_t len = 0;
+                for (size_t k = col[c].first + 5; k < col[c].second; k++) {
+                    const char ch = static_cast<char>(text[k]);
+                    if (ch >= '0' && ch <= '9') { len = 10 * len + static_cast<uint32_t>(ch - '0'); continue; }
+                    uint32_t op;
+                    switch (ch) {
+                        case 'M': op = 0; break; case 'I': op = 1; break; case 'D': op = 2; break; case 'S': op = 4; break;
+                        case 'H': op = 5; break; case '=': op = 7; break; case 'X': op = 8; break;
+                        case 'N': case 'P': fail(LCTY_ERR_RUNTIME, "CIGAR operations N and P are not supported");
+                        default: fail(LCTY_ERR_INVALID_DATA, "Unexpected CIGAR operation %c", ch);
+                    }
+                    words.push_back((len << 4) | op);
+                    len = 0;
+                }
+            }
+            if (q_it->second == t_it->second || !have_cigar) continue;
+            if (strand != "+" || qs != 0 || qe != qlen || ts != 0 || te != tlen) continue;      // full_positive_alignment, paf.rs:211-215
+            if (fill) {
+                if (ne >= cap_e || nc + words.size() > cap_c) fail(LCTY_ERR_INVALID_INPUT, "PAF buffers too small");
+                id1[ne] = q_it->second; id2[ne] = t_it->second; n_matches[ne] = nm; aln_len[ne] = al;
+                cigar_off[ne] = nc;
+                memcpy(cigar + nc, words.data(), words.size() * sizeof(uint32_t));
+            }
+            ne++; nc += words.size();
+        }
+        if (fill) cigar_off[ne] = nc;
+        *n_entries = ne; *n_cigar = nc;
     });
 }
 

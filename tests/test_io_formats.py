@@ -290,3 +290,58 @@ def test_bam_reader_reproduces_the_flat_table(tmp_path):
         with pytest.raises(_lib.LocityperError) as e:
             lio.BamTable(p, names_bad, paired=paired)
         assert e.value.code == cdefs.ERR_INVALID_DATA
+
+
+def test_paf_reader_keeps_what_process_paf_keeps(tmp_path):
+    """haplotypes.paf as command/genotype.rs:1131-1160 + seq/paf.rs read it: which lines become entries (hand-derived), the raw CIGAR
+    words, the containers, the errors; a PAF written from the synthetic haplotype alignments comes back as they were."""
+    names = ["h1", "h2", "h3"]
+    lines = [
+        "# a comment",
+        "",
+        "h1\t100\t0\t100\t+\th2\t102\t0\t102\t95\t104\t60\tNM:i:9\tcg:Z:50=1X20=2D29=",            # kept
+        "h1\t100\t0\t100\t+\thX\t102\t0\t102\t95\t104\t60\tcg:Z:100=",                              # unknown target
+        "hY\tnot-a-number\t0\t100\t+\th2\t102\t0\t102\t95\t104\t60\tcg:Z:100=",                     # unknown query: skipped before its numbers are read
+        "h2\t102\t0\t102\t+\th2\t102\t0\t102\t102\t102\t60\tcg:Z:102=",                             # self-alignment
+        "h1\t100\t0\t100\t+\th3\t90\t0\t90\t90\t100\t60\ttp:A:P",                                    # no CIGAR tag
+        "h1\t100\t5\t100\t+\th3\t90\t0\t90\t90\t95\t60\tcg:Z:90=5I",                                 # does not start at 0
+        "h1\t100\t0\t100\t-\th3\t90\t0\t90\t90\t100\t60\tcg:Z:90=10I",                               # reverse strand
+        "h3\t90\t0\t90\t+\th1\t100\t0\t100\t88\t101\t60\tcg:Z:40=1X49=10D\r",                       # kept (query id > target id; CR LF)
+        "h2\t102\t0\t102\t+\th3\t90\t0\t90\t0\t0\t60\tcg:Z:90M12I",                                  # kept: M passes the reader (aln_len 0: the divergence filter is lcty_locus_set_hap_alns')
+    ]
+    text = ("\n".join(lines) + "\n").encode()
+    want = [(0, 1, [(50, 7), (1, 8), (20, 7), (2, 2), (29, 7)], 95, 104),
+            (2, 0, [(40, 7), (1, 8), (49, 7), (10, 2)], 88, 101),
+            (1, 2, [(90, 0), (12, 1)], 0, 0)]
+    import gzip as _gz
+    for fname, blob in (("haplotypes.paf", text), ("haplotypes.paf.gz", _gz.compress(text))):
+        p = tmp_path / fname
+        p.write_bytes(blob)
+        got = lio.paf_read(p, names)
+        assert [(a, b, [(int(w) >> 4, int(w) & 15) for w in ws], nm, al) for a, b, ws, nm, al in got] == want
+    for bad, code in (("h1\t100\t0\t100\t+\th2\t102\t0\t102\t95", cdefs.ERR_INVALID_INPUT),                              # too few columns
+                      ("h1\t100\t0\tx\t+\th2\t102\t0\t102\t95\t104\t60\tcg:Z:100=", cdefs.ERR_INVALID_DATA),          # a number that does not parse
+                      ("h1\t100\t0\t100\t*\th2\t102\t0\t102\t95\t104\t60\tcg:Z:100=", cdefs.ERR_INVALID_DATA),       # strand
+                      ("h1\t100\t0\t100\t+\th2\t102\t0\t102\t95\t104\t60\tcg:Z:50=3N50=", cdefs.ERR_RUNTIME),        # N is refused by name
+                      ("h1\t100\t0\t100\t+\th2\t102\t0\t102\t95\t104\t60\tcg:Z:50=3Q50=", cdefs.ERR_INVALID_DATA)):
+        p = tmp_path / "bad.paf"
+        p.write_text(bad + "\n")
+        with pytest.raises(_lib.LocityperError) as e:
+            lio.paf_read(p, names)
+        assert e.value.code == code, bad
+    # the synthetic locus: its haplotype alignments written as a PAF and read back
+    from locityper_amd import synth
+    L = synth.SynthLocus(5, 10, seed=3, base_len=3000)
+    ents = L.hap_alns()
+    hn = [f"hap{i}" for i in range(5)]
+    lens = np.diff(L.seq_off).astype(int)
+    out = []
+    for a, b, ws, nm, al in ents:
+        cg = "".join(f"{int(w) >> 4}{'MIDNSHP=X'[int(w) & 15]}" for w in ws)
+        out.append(f"{hn[a]}\t{lens[a]}\t0\t{lens[a]}\t+\t{hn[b]}\t{lens[b]}\t0\t{lens[b]}\t{nm}\t{al}\t60\tcg:Z:{cg}")
+    p = tmp_path / "synth.paf.gz"
+    p.write_bytes(_gz.compress(("\n".join(out) + "\n").encode()))
+    back = lio.paf_read(p, hn)
+    assert len(back) == len(ents) > 0
+    for (a, b, ws, nm, al), (a2, b2, ws2, nm2, al2) in zip(ents, back):
+        assert (a, b, nm, al) == (a2, b2, nm2, al2) and np.array_equal(np.asarray(ws, dtype=np.uint32), ws2)
