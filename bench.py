@@ -4,8 +4,8 @@
 
 A step = one pass of the hot path over one locus' batch, inputs resident in HBM:
     lcty_score_reads   (K2+K4+K5+K7+K8: AllAlignments::load -> likelihood matrix + pair alignments)
-    lcty_prefilter     (K9: run_filter over all C(A+1,2) genotypes) + scores D2H
-    lcty_truncate      (K10: truncate_ixs on the host)
+    lcty_prefilter_async (K9: run_filter over all C(A+1,2) genotypes), scores stay in HBM
+    lcty_prefilter_truncate (K10: truncate_ixs as a device sort + prefix; the kept indices D2H)
     lcty_solve_stage   (K11-K14: greedy on the survivors, 1 attempt; annealing on the best 20, 20 attempts)
     lcty_discard_improbable / lcty_produce_result (K15: final genotype comparison)
 N > 1: one process per GPU, one independent locus per rank (loci are independent in the reference,
@@ -318,8 +318,8 @@ def main():
         aa.prefilter_async()
         if args.shard_reads and aa is aa_main:
             comm.prefilter_allreduce(aa)                                      # read shards -> scores of the whole batch on every rank
-        scores = aa.prefilter_scores()
-        keep = api.truncate_ixs(scores, all_ixs, params.filt_diff, 5000, params.threads)   # in_size of stage 1 (solve.rs:216-221)
+        scores = None                                                         # they stay on the device: only the kept indices come back
+        keep = aa.prefilter_truncate(params.filt_diff, 5000, params.threads)  # truncate_ixs, in_size of stage 1 (solve.rs:216-221)
         stage_s["score_prefilter"] += time.perf_counter() - t0s
         if args.no_solve:
             return scores, keep, None

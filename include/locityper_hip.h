@@ -357,6 +357,12 @@ int32_t lcty_prefilter_scores(lcty_reads* reads, double* scores, uint64_t n);
 int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double filt_diff,
                       uint64_t min_size, uint64_t threads, uint64_t* n_keep);
 
+/* The same on the scores the last prefilter call left on the device (lcty_prefilter_async / lcty_prefilter /
+ * lcty_prefilter_allreduce), all genotypes as candidates: a stable device radix sort of (score descending, index ascending) and the
+ * prefix truncate_ixs keeps; only the kept indices come to the host (at 4 096 alleles the scores are 67 MB). ixs = NULL: *n_keep only. */
+int32_t lcty_prefilter_truncate(lcty_reads* reads, double filt_diff, uint64_t min_size, uint64_t threads, uint64_t* ixs, uint64_t cap,
+                                uint64_t* n_keep);
+
 /* generate_genotypes without priors (src/command/genotype.rs:1120-1126) */
 uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy);
 int32_t  lcty_generate_genotypes(uint32_t n_alleles, uint32_t ploidy, uint16_t* out, uint64_t cap);

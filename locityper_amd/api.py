@@ -340,6 +340,14 @@ class AllAlignments:
         check(lib().lcty_prefilter_scores(self._h, scores.ctypes.data, n))
         return scores
 
+    def prefilter_truncate(self, filt_diff, min_size, threads):
+        """lcty_prefilter_truncate: truncate_ixs on the scores the last prefilter call left on the device; the kept genotype indices
+        sorted by (score desc, index asc)."""
+        keep = U64()
+        ixs = np.empty(count_genotypes(self.locus.n_alleles, 2), dtype=np.uint64)      # room for all of them: one call, one sort
+        check(lib().lcty_prefilter_truncate(self._h, filt_diff, min_size, threads, ixs.ctypes.data, len(ixs), C.byref(keep)))
+        return ixs[:int(keep.value)].copy()
+
 
 def default_solver(kind):
     s = Solver()

@@ -144,6 +144,9 @@ struct lcty_reads {
 
     // prefilter products
     lcty::DevBuf<double> d_scores;           // [G]
+    // lcty_prefilter_truncate's sort buffers: grow-only on the batch (an allocation or a release in the head of a queued locus would
+    // wait for the annealing chains of the locus before it)
+    struct SelectBufs { lcty::DevBuf<uint64_t> k_in, k_out, v_in, v_out; lcty::DevBuf<uint8_t> tmp; lcty::DevBuf<unsigned long long> out; } select;
     lcty::DevBuf<double> d_partials;         // [splits][G]
     uint64_t n_scores = 0;
 

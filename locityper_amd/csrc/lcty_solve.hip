@@ -2311,9 +2311,15 @@ struct LocusRun {
         // to discard_improbable_genotypes when threads == 1 (solve.rs:797, 853) and data.threads otherwise (1087-1089)
         threads = std::max<uint64_t>(1, prm.threads);
         if (prm.dont_skip || stages[0].in_size < G) {
-            std::vector<double> scores(G);
-            ok(lcty_prefilter(reads, nullptr, G, ploidy, priors, scores.data()));
-            ok(lcty_truncate(scores.data(), ixs.data(), G, prm.filt_diff, stages[0].in_size, threads, &n));
+            if (!priors && ploidy == 2) {
+                // the scores stay on the device: sorted and cut there, only the kept indices come back (lcty_select.hip)
+                ok(lcty_prefilter_async(reads, 2));
+                ok(lcty_prefilter_truncate(reads, prm.filt_diff, stages[0].in_size, threads, ixs.data(), G, &n));
+            } else {
+                std::vector<double> scores(G);
+                ok(lcty_prefilter(reads, nullptr, G, ploidy, priors, scores.data()));
+                ok(lcty_truncate(scores.data(), ixs.data(), G, prm.filt_diff, stages[0].in_size, threads, &n));
+            }
         }
         out->kept_after_filter = n;
         mean.assign(G, std::numeric_limits<double>::quiet_NaN()); var.assign(G, std::numeric_limits<double>::quiet_NaN());

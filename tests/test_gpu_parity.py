@@ -34,6 +34,10 @@ def check_prefilter(aa, Mo, n_alleles, p):
         k1 = api.truncate_ixs(sc, np.arange(len(sc)), p.filt_diff, min_size, p.threads)
         k2 = O.truncate(so, np.arange(len(so)), p.filt_diff, min_size, p.threads)
         assert set(k1.tolist()) == set(k2.tolist())
+        k3 = aa.prefilter_truncate(p.filt_diff, min_size, p.threads)        # the same on the device's scores: same set, same order
+        assert np.array_equal(k3, k1)
+    for fd, ms, th in ((0.0, 1, 1), (1.0, 3, 8), (1e300, 7, 1), (5.0, len(sc) + 5, 2), (0.5, 2, len(sc) + 9)):
+        assert np.array_equal(aa.prefilter_truncate(fd, ms, th), api.truncate_ixs(sc, np.arange(len(sc)), fd, ms, th)), (fd, ms, th)
     return sc, so, gts
 
 
