@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=16, help="loci of the timed queue (its last locus finishes alone: 0.33 s of drain shared by all)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per locus (BASELINE: 1M)")
     ap.add_argument("--alleles", type=int, default=256)

@@ -33,6 +33,7 @@
 // Randomness is the injected per-chain seed described in oracle/lcty_oracle.h (the reference's rand adaptors
 // are not in its tree): counter-based draws for tweaks / random starts, xoshiro256++ for the solver loop.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <memory>
 #include <numeric>
@@ -1763,9 +1764,13 @@ struct StageRunner {
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
             if (lane == 1) wait_for_greedy_of_next_locus();
             launch_anneal(ctx, V, nch, stream);
+            if (ctx->knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p annealing launched (lane %u)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), static_cast<const void*>(reads), lane);
             return;
         }
         if (lane == 0) announce_greedy();
+        if (ctx->knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p greedy about to launch (lane %u)\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), static_cast<const void*>(reads), lane);
         // Lanes per chain. The loop is bound by instruction issue — a wavefront-iteration costs the same whatever its number of busy
         // lanes — and at its register count one wavefront fits a SIMD: the chains of a stage should make at most one wavefront per
         // SIMD. A row of 16 lanes (the hardware's DPP rows: cheapest row operations) holds the default sample of 10 with four
@@ -2273,6 +2278,12 @@ struct LocusRun {
     std::vector<uint16_t> gts; std::vector<uint64_t> ixs; std::vector<double> mean, var; std::vector<uint32_t> att;
 
     static void ok(int32_t rc) { if (rc != LCTY_OK) throw Error(rc, std::string(lcty_last_error())); }
+    // lcty_ctx_set_knob "queue_trace" 1: wall-clock marks of the phases of a locus on stderr (where does a step of the queue go?)
+    void mark(const char* what) const {
+        if (!reads || reads->ctx->knob("queue_trace", 0) == 0) return;
+        const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "[lcty queue] %.3f ms batch %p %s\n", t, static_cast<const void*>(reads), what);
+    }
 
     void stage(uint32_t si, uint32_t lane) {
         const bool last = si + 1 == n_stages;
@@ -2286,14 +2297,19 @@ struct LocusRun {
             pri[t] = priors ? priors[ixs[t]] : 0.0;
         }
         ok(lcty_chain_seeds(master_seed + static_cast<uint64_t>(si + 1) * 0x9e3779b97f4a7c15ull, n * attempts, seeds.data()));
+        mark(lane ? "tail stage: inputs ready" : "head stage: inputs ready");
         solve_stage_on(lane, reads, sub.data(), n, ploidy, pri.data(), &stages[si].solver, attempts, seeds.data(), m.data(), v.data(), nullptr);
+        mark(lane ? "tail stage: chains done" : "head stage: chains done");
         for (uint64_t t = 0; t < n; t++) { mean[ixs[t]] = m[t]; var[ixs[t]] = v[t]; att[ixs[t]] = attempts; }
         if (!last) ok(lcty_discard_improbable(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, out_size, threads, &n));
+        mark(lane ? "tail stage: discarded" : "head stage: discarded");
     }
 
     void head(bool score) {
         if (!reads || !stages || !out || n_stages == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        mark("head: start");
         if (score) ok(lcty_score_reads(reads));
+        mark("head: scoring launched");
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
         for (uint32_t s = 0; s < n_stages; s++)
             if (stages[s].attempts == 0 || stages[s].in_size == 0) fail(LCTY_ERR_INVALID_INPUT, "stage %u: attempts and in_size must be positive", s);
@@ -2322,6 +2338,7 @@ struct LocusRun {
             }
         }
         out->kept_after_filter = n;
+        mark("head: prefiltered and truncated");
         mean.assign(G, std::numeric_limits<double>::quiet_NaN()); var.assign(G, std::numeric_limits<double>::quiet_NaN());
         att.assign(G, 0);
         for (uint32_t si = 0; si + 1 < n_stages; si++) stage(si, 0);
@@ -2331,6 +2348,7 @@ struct LocusRun {
         lcty_ctx* ctx = reads->ctx;
         ctx->activate();
         const lcty_params& prm = reads->locus->prm;
+        mark("tail: start");
         stage(n_stages - 1, lane);
         ok(lcty_produce_result(mean.data(), var.data(), att.data(), ixs.data(), n, prm.prob_thresh, 0, out->ixs, out->ln_probs, &out->n_out,
                                &out->quality));
