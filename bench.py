@@ -112,6 +112,14 @@ def cpu_model():
     return "unknown"
 
 
+_T_START = time.time()
+
+
+def progress(what):
+    """where the wall time of a run goes (stderr; the JSON line is the only thing on stdout)"""
+    print(f"[bench {time.time() - _T_START:7.1f} s] {what}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G):
     """The reference's CPU path beside the GPU number: the oracle — a C restatement of the reference algorithms —
     with the reference's own thread structure, at threads = 8 (the reference default, genotype.rs:127) and at all physical cores:
@@ -183,7 +191,8 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G):
             na = min(max(T, 4), len(order))
             sub_a = gts[order[:na]]
             tgreedy, tanneal = [], []
-            for rep in range(reps):
+            # at all cores one worker per core runs a full-size chain (4 s each, twice): once is 1.5 min of the run, so no repeats there
+            for rep in range(reps if T == 8 else 1):
                 tc = time.perf_counter()
                 O.solve_stage(ol, oa_full, sub_g, greedy, 1, api.chain_seeds(1000 + rep, ng), threads=T)
                 tgreedy.append(time.perf_counter() - tc)
@@ -204,7 +213,7 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G):
     return {"value": best["value"], "unit": "read pairs/s", "cores": best["threads"], "kind": "port",
             "sample": f"load + run_filter on the first {ns} read pairs x {A} alleles (all {G} genotypes; {n_good_sample} good pairs); "
                       + (f"solver chains on all {solver_pairs} read pairs (inputs = the batch the GPU scored); " if oa_full is not None else "")
-                      + f"whole path composed for {args.pairs} read pairs and the default scheme; median of {reps}",
+                      + f"whole path composed for {args.pairs} read pairs and the default scheme; median of {reps} (solver chains at all cores: one run)",
             "cpu_model": cpu_model(), "physical_cores": n_phys, "cpu_count": os.cpu_count(),
             "by_threads": by,
             "reads_scored_per_s": best["reads_scored_per_s"], "chains_per_s": best.get("chains_per_s"),
@@ -262,6 +271,7 @@ def main():
     # The default mode runs a QUEUE of loci through lcty_solve_queue (the loop of `locityper genotype` over its loci): the library
     # overlaps the last stage of a locus (annealing) with the scoring / prefilter / greedy stage of the next one, which needs two
     # loci resident; a step = one locus through the whole path, K steps = a queue of K loci alternating between the two.
+    progress("generating the loci and their read pairs")
     t0 = time.time()
     n_loci = 1 if (one_locus or args.no_solve) else 2
     A = args.alleles
@@ -504,9 +514,11 @@ def main():
         pass
 
     if world == 1:
+        progress("timed region done")
         ctx.trim()          # the solver workspaces of the timed steps (160 GB) make room for the extra measurements below
 
     if args.recruit_sample > 0 and world == 1:
+        progress("recruitment leg")
         # ---- minimizer read recruitment (Targets::recruit_read_pair, seq/recruit.rs:883-929), the step before the path: random
         # 150 + 150-base pairs (whole-genome input is almost entirely foreign to a locus) against this locus' alleles ----
         nrq = args.recruit_sample
@@ -533,6 +545,7 @@ def main():
         T.close(); del rq, words
 
     if args.map_sample > 0 and world == 1:
+        progress("candidate-generation leg")
         # ---- candidate generation on the basis alleles (first slice; lcty_map.hip), the step the reference leaves to
         # an external mapper: the first read pairs of the locus, their bases only, onto 8 basis alleles ----
         nmp = min(args.map_sample, args.pairs)
@@ -563,6 +576,7 @@ def main():
         del src, bare, mapped
 
     if args.recovery_sample > 0 and world == 1:
+        progress("alignment-recovery leg")
         # ---- alignment recovery (K6), not part of the step: the mapper reports only the primary alignment of each read end, the
         # other alleles are reached through the haplotype-to-haplotype alignments (transfer.rs:70-140) ----
         nrec = min(args.recovery_sample, args.pairs)
@@ -587,6 +601,7 @@ def main():
         ab.close(); del prim
 
     if args.many_alleles_sample > 0 and world == 1:
+        progress("many-alleles leg")
         # ---- configs[4] shard shape: a locus of 4 096 alleles, the read pairs one of eight GPUs would hold. The prefilter is the
         # dominant kernel there; from 512 alleles on it runs as an integer Gram contraction on the matrix cores (lcty_gram.hip) ----
         nma, Ama = args.many_alleles_sample, 4096
@@ -621,6 +636,7 @@ def main():
         am.close(); del scores_m
 
     if args.ont_sample > 0 and world == 1:
+        progress("long-read leg")
         # ---- configs[2] shape, the long-read DP path: 10-kb single-end ONT reads, primaries only, every other allele reached by
         # HapAlns::transfer_alignments (two-CIGAR walk + gap-affine aligner on the stretches between anchors) ----
         nont = args.ont_sample
@@ -657,6 +673,7 @@ def main():
         ao.close(); del prim
 
     if first is not None:
+        progress("CPU baseline")
         out["cpu_baseline"] = cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G)
         out["vs_cpu_baseline"] = {k: reads_per_s / v["value"] for k, v in out["cpu_baseline"]["by_threads"].items()}
         from tests import oracle_ffi as O
