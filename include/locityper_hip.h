@@ -222,7 +222,9 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
 int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value);
 /* The solver stages keep their per-chain device state (32 B per chain and good read pair: ~150 GB for the 5 000 greedy chains of
  * the default scheme at 1 M read pairs; batches of chains when the device has less) with the context between stages and loci;
- * this releases it (the next stage allocates again). */
+ * this releases it (the next stage allocates again). So does alignment recovery with its lane scratch and the arenas of the
+ * transferred alignments (up to half of what is free on the device when lcty_recover_alignments first runs; long reads need tens of MB
+ * per wavefront): kept between calls, handed back when a solver stage sizes its workspace, and by this call. */
 int32_t lcty_ctx_trim(lcty_ctx* ctx);
 /* Page-locked host memory for the chunks handed to lcty_reads_append / lcty_reads_append_counted / lcty_recruit_*: the copies of
  * a chunk that lies in such memory go over PCIe at link rate (a pageable chunk is staged through the driver's bounce buffers at
