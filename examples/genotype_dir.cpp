@@ -4,6 +4,8 @@
 //   <root>/DB/loci/<locus>/kmers.bin.lz4 | .br   off-target k-mer counts          (lcty_io_read_file + lcty_kmer_counts_parse)
 //   <root>/PREPROC/distr.gz                      background distributions         (lcty_io_read_file + lcty_bg_from_json)
 //   <root>/OUT/loci/<locus>/aln.bam              the mapper's output              (lcty_bam_read)
+//   <root>/DB/loci/<locus>/haplotypes.paf[.gz]   optional: pairwise haplotype alignments (lcty_paf_read + lcty_locus_set_hap_alns +
+//                                                lcty_recover_alignments: the mapper saw the basis haplotypes only)
 //        -> lcty_locus_create, lcty_reads_create / append, lcty_score_reads, lcty_solve (default scheme)
 //   <root>/OUT/loci/<locus>/res.json.gz          the genotype call                (lcty_res_to_json + lcty_io_write_gz)
 //   <root>/OUT/loci/<locus>/alns/00.bam (+ .bai) read placements on the call      (lcty_assignment_counts + lcty_write_bam)
@@ -80,6 +82,25 @@ int main(int argc, char** argv) {
     ok(lcty_reads_append(reads, &table), "append");
     ok(lcty_score_reads(reads), "AllAlignments::load");
 
+    // haplotypes.paf[.gz]: the mapper saw the basis haplotypes only; the alignments reach the other alleles through the pairwise
+    // haplotype alignments (process_paf + HapAlns::transfer_alignments, genotype.rs:1131-1160, 149-150: --transfer 0.1 100)
+    uint64_t n_recovered = 0;
+    bool recovered = false;
+    for (const char* paf_name : {"/haplotypes.paf.gz", "/haplotypes.paf"}) {
+        const std::string paf = db + paf_name;
+        if (FILE* f = std::fopen(paf.c_str(), "rb")) std::fclose(f); else continue;
+        uint64_t n_ent = 0, n_words = 0;
+        ok(lcty_paf_read(paf.c_str(), names.data(), A, &n_ent, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &n_words), "haplotypes.paf (size)");
+        std::vector<uint32_t> id1(n_ent + 1), id2(n_ent + 1), nm(n_ent + 1), al(n_ent + 1), words(n_words + 1);
+        std::vector<uint64_t> woff(n_ent + 1);
+        ok(lcty_paf_read(paf.c_str(), names.data(), A, &n_ent, id1.data(), id2.data(), nm.data(), al.data(), woff.data(), words.data(), &n_words), "haplotypes.paf");
+        ok(lcty_locus_set_hap_alns(loc, static_cast<uint32_t>(n_ent), id1.data(), id2.data(), woff.data(), words.data(), nm.data(), al.data(), 100, 0.1), "HapAlns");
+        ok(lcty_recover_alignments(reads, &n_recovered), "transfer_alignments");
+        ok(lcty_score_reads(reads), "AllAlignments::load after recovery");
+        recovered = true;
+        break;
+    }
+
     // solve::solve with the default scheme
     lcty_stage stages[2]; uint32_t n_stages = 0;
     ok(lcty_stages_default(stages, &n_stages), "Scheme::default");
@@ -113,11 +134,14 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> cnts(n_cnt ? n_cnt : 1);
     ok(lcty_assignment_counts(reads, best, 2, &stages[n_stages - 1].solver, attempts, seeds.data(), read_off.data(), cnts.data(), n_cnt, &n_cnt), "counts");
     uint64_t n_rec = 0;
+    // (the placements' BAM needs the records of every alignment on the host: not after alignment recovery, whose records live on the device)
+    if (!recovered)
     ok(lcty_write_bam((outd + "/alns/00.bam").c_str(), reads, &table, name_off, read_names, nullptr, nullptr, names.data(), best, 2,
                       static_cast<uint16_t>(attempts), read_off.data(), cnts.data(), &n_rec), "write_bam");
 
-    std::printf("genotype %s,%s quality %.1f reads %llu unexplained %u warnings %u bam_records %llu\n", names[best[0]], names[best[1]],
-                call.quality, static_cast<unsigned long long>(call.n_good), call.unexpl_reads, call.warnings, static_cast<unsigned long long>(n_rec));
+    std::printf("genotype %s,%s quality %.1f reads %llu unexplained %u warnings %u bam_records %llu recovered %llu\n", names[best[0]], names[best[1]],
+                call.quality, static_cast<unsigned long long>(call.n_good), call.unexpl_reads, call.warnings, static_cast<unsigned long long>(n_rec),
+                static_cast<unsigned long long>(n_recovered));
     lcty_reads_destroy(reads); lcty_bam_table_free(bam); lcty_locus_destroy(loc); lcty_ctx_destroy(ctx);
     return 0;
 }

@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--alleles", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=10_000)
     ap.add_argument("--base-len", type=int, default=50_000)
+    ap.add_argument("--paf", action="store_true", help="the layout of a run on basis haplotypes: aln.bam holds the primary alignments only and "
+                    "DB/loci/<locus>/haplotypes.paf.gz the pairwise haplotype alignments that carry them to the other alleles")
     a = ap.parse_args()
     L = synth.SynthLocus(a.alleles, a.pairs, base_len=a.base_len)
     db, outd = os.path.join(a.root, "DB", "loci", a.locus), os.path.join(a.root, "OUT", "loci", a.locus)
@@ -128,7 +130,12 @@ def main():
              "bg_depth": {"ploidy": 2, "window": bg.window, "neighb": bg.neighb, "n": list(bg.depth_n), "p": list(bg.depth_p)}}
     with gzip.open(os.path.join(a.root, "PREPROC", "distr.gz"), "wt") as f:
         json.dump(distr, f, indent=4)
-    ch = L.reads(0, a.pairs)
+    ch = L.reads(0, a.pairs, primaries_only=a.paf)
+    if a.paf:
+        with gzip.open(os.path.join(db, "haplotypes.paf.gz"), "wt") as f:
+            for q, t, words, nm, al in L.hap_alns():
+                cg = "".join(f"{int(w) >> 4}{'MIDNSHP=X'[int(w) & 15]}" for w in words)
+                f.write(f"{names[q]}\t{lens[q]}\t0\t{lens[q]}\t+\t{names[t]}\t{lens[t]}\t0\t{lens[t]}\t{nm}\t{al}\t60\ttp:A:P\tcg:Z:{cg}\n")
     open(os.path.join(outd, "aln.bam"), "wb").write(bgzf(bam_bytes(list(zip(names, lens)), ch)))
     json.dump({"genotype": [names[g] for g in L.true_genotype], "pairs": a.pairs}, open(os.path.join(a.root, "truth.json"), "w"))
     print(f"wrote {a.root}: {a.alleles} alleles, {a.pairs} read pairs, truth {L.true_genotype}")

@@ -56,3 +56,27 @@ def test_example_from_a_locityper_directory(tmp_path):
     raw = gzip.open(bam, "rb").read()
     assert raw[:4] == b"BAM\x01" and os.path.getsize(bam + ".bai") > 32
     assert r.stdout.startswith("genotype " + res["genotype"])
+
+
+@pytest.mark.gpu
+def test_example_from_a_directory_of_a_basis_run(tmp_path):
+    """The same with the layout of a run on basis haplotypes: aln.bam holds the primary alignments only, haplotypes.paf.gz the pairwise
+    haplotype alignments (lcty_paf_read -> lcty_locus_set_hap_alns -> lcty_recover_alignments); the call must be the genotype the
+    reads were drawn from."""
+    import gzip
+    import json
+    import sys
+    root = str(tmp_path / "lcty")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_locityper_dir.py"), root, "--alleles", "6", "--pairs", "5000",
+                        "--base-len", "20000", "--paf"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.getsize(os.path.join(root, "DB", "loci", "L1", "haplotypes.paf.gz")) > 100
+    exe = str(tmp_path / "genotype_dir")
+    build_example(exe, "genotype_dir.cpp")
+    r = subprocess.run([exe, root, "L1", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    truth = json.load(open(os.path.join(root, "truth.json")))
+    res = json.load(gzip.open(os.path.join(root, "OUT", "loci", "L1", "res.json.gz"), "rt"))
+    assert res["genotype"] == ",".join(truth["genotype"]) and res["quality"] > 20
+    recovered = int(r.stdout.strip().split(" recovered ")[1])
+    assert recovered > 4 * 5000                                           # every read pair reaches the other five alleles
