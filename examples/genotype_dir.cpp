@@ -134,8 +134,15 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> cnts(n_cnt ? n_cnt : 1);
     ok(lcty_assignment_counts(reads, best, 2, &stages[n_stages - 1].solver, attempts, seeds.data(), read_off.data(), cnts.data(), n_cnt, &n_cnt), "counts");
     uint64_t n_rec = 0;
-    // (the placements' BAM needs the records of every alignment on the host: not after alignment recovery, whose records live on the device)
-    if (!recovered)
+    // after alignment recovery the batch's record table (the mapper's records + the transferred alignments) comes back from the device
+    std::vector<uint64_t> m_aln_off, m_cig_off; std::vector<lcty_aln_rec> m_recs; std::vector<uint32_t> m_cigar;
+    if (recovered) {
+        m_aln_off.resize(R + 1); m_cig_off.resize(R + 1);
+        ok(lcty_reads_get_records(reads, m_aln_off.data(), nullptr, 0, m_cig_off.data(), nullptr, 0), "records (size)");
+        m_recs.resize(m_aln_off[R] + 1); m_cigar.resize(m_cig_off[R] + 1);
+        ok(lcty_reads_get_records(reads, m_aln_off.data(), m_recs.data(), m_recs.size(), m_cig_off.data(), m_cigar.data(), m_cigar.size()), "records");
+        table.aln_off = m_aln_off.data(); table.recs = m_recs.data(); table.cigar_off = m_cig_off.data(); table.cigar = m_cigar.data();
+    }
     ok(lcty_write_bam((outd + "/alns/00.bam").c_str(), reads, &table, name_off, read_names, nullptr, nullptr, names.data(), best, 2,
                       static_cast<uint16_t>(attempts), read_off.data(), cnts.data(), &n_rec), "write_bam");
 

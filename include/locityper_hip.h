@@ -344,6 +344,12 @@ int32_t lcty_best_aln_matrix(lcty_reads* reads, double* out);
  * pairs: off[n_pairs+1]; entries contig-ascending, ln_prob-descending inside a contig
  * (locs.rs:819-851). Call with out == NULL to obtain only the offsets / total. */
 int32_t lcty_reads_get_pair_alns(lcty_reads* reads, uint64_t* off, lcty_pair_aln* out, uint64_t cap);
+/* The record table as the batch holds it now: after lcty_recover_alignments the caller's records with the transferred alignments
+ * behind the original records of their read end (secondary records, CIGAR offsets relative to the pair's block as everywhere) — the
+ * `table` lcty_write_bam needs then. aln_off / cigar_off [n_pairs + 1]; recs = cigar = NULL: the sizes only (aln_off[n_pairs],
+ * cigar_off[n_pairs]). Not for counted or streaming batches. */
+int32_t lcty_reads_get_records(lcty_reads* reads, uint64_t* aln_off, lcty_aln_rec* recs, uint64_t cap_recs, uint64_t* cigar_off, uint32_t* cigar,
+                               uint64_t cap_cigar);
 
 /* run_filter (src/solvers/solve.rs:87-122): scores[g] = prior[g] + sum_r max_{a in g} M[a][r].
  * genotypes == NULL: all multisets of size `ploidy` in the order of

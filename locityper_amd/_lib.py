@@ -39,6 +39,7 @@ SIGNATURES = {
     "lcty_reads_n_good": (I32, [VP, P(U64)]),
     "lcty_best_aln_matrix": (I32, [VP, VP]),
     "lcty_reads_get_pair_alns": (I32, [VP, VP, VP, U64]),
+    "lcty_reads_get_records": (I32, [VP, VP, VP, U64, VP, VP, U64]),
     "lcty_prefilter": (I32, [VP, VP, U64, U32, VP, VP]),
     "lcty_prefilter_async": (I32, [VP, U32]),
     "lcty_prefilter_scores": (I32, [VP, VP, U64]),

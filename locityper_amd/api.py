@@ -331,6 +331,16 @@ class AllAlignments:
         check(lib().lcty_prefilter(self._h, gptr, n, ploidy, None if pr is None else pr.ctypes.data, scores.ctypes.data))
         return scores
 
+    def records(self):
+        """lcty_reads_get_records: (aln_off, recs, cigar_off, cigar) as the batch holds them now (after recover(): with the transferred
+        alignments)."""
+        n = self.n_pairs
+        aln_off = np.zeros(n + 1, dtype=np.uint64); cig_off = np.zeros(n + 1, dtype=np.uint64)
+        check(lib().lcty_reads_get_records(self._h, aln_off.ctypes.data, None, 0, cig_off.ctypes.data, None, 0))
+        recs = np.zeros(max(int(aln_off[-1]), 1), dtype=cdefs.ALN_REC_DTYPE); cigar = np.zeros(max(int(cig_off[-1]), 1), dtype=np.uint32)
+        check(lib().lcty_reads_get_records(self._h, aln_off.ctypes.data, recs.ctypes.data, len(recs), cig_off.ctypes.data, cigar.ctypes.data, len(cigar)))
+        return aln_off, recs[:int(aln_off[-1])], cig_off, cigar[:int(cig_off[-1])]
+
     def prefilter_async(self, ploidy=2):
         check(lib().lcty_prefilter_async(self._h, ploidy))
 

@@ -368,6 +368,30 @@ int32_t lcty_best_aln_matrix(lcty_reads* reads, double* out) {
     });
 }
 
+// the record table as the batch holds it now — after lcty_recover_alignments the caller's records with the transferred alignments
+// behind the records of their read end (what lcty_write_bam needs as its `table`)
+int32_t lcty_reads_get_records(lcty_reads* reads, uint64_t* aln_off, lcty_aln_rec* recs, uint64_t cap_recs, uint64_t* cigar_off, uint32_t* cigar,
+                               uint64_t cap_cigar) {
+    return guarded([&] {
+        if (!reads || !aln_off || !cigar_off) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (reads->counted) fail(LCTY_ERR_UNSUPPORTED, "a batch of counted alignments has no records");
+        if (reads->streaming) fail(LCTY_ERR_UNSUPPORTED, "a streaming batch keeps the records of its current chunk only");
+        reads->ctx->activate();
+        hipStream_t s = reads->ctx->stream;
+        const uint64_t n = reads->n_pairs;
+        reads->d_aln_off.download(aln_off, n + 1, s);
+        reads->d_cigar_off.download(cigar_off, n + 1, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        if (!recs && !cigar) return;                                        // sizing call: aln_off[n], cigar_off[n]
+        if (!recs || !cigar) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (cap_recs < aln_off[n] || cap_cigar < cigar_off[n])
+            fail(LCTY_ERR_INVALID_INPUT, "room for %llu records and %llu CIGAR words is needed", (unsigned long long)aln_off[n], (unsigned long long)cigar_off[n]);
+        reads->d_recs.download(recs, aln_off[n], s);
+        reads->d_cigar.download(cigar, cigar_off[n], s);
+        LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
+
 int32_t lcty_reads_get_pair_alns(lcty_reads* reads, uint64_t* off, lcty_pair_aln* out, uint64_t cap) {
     return guarded([&] {
         require_scored(reads);

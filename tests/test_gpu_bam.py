@@ -144,6 +144,55 @@ def test_bam_of_one_genotype(gpu_ctx, tmp_path, paired):
             lio.write_bam(tmp_path / "x.bam", aa, ch, names, allele_names, gt, 1, ro2, c2)
 
 
+def test_bam_after_alignment_recovery(gpu_ctx, tmp_path):
+    """The mapper reported the primaries only; the other alleles came in through alignment recovery. The batch's record table comes
+    back from the device (lcty_reads_get_records) and lcty_write_bam places the reads on the call with it: the transferred alignments
+    are records like any other."""
+    n_alleles, n_pairs, attempts = 6, 1200, 6
+    L = synth.SynthLocus(n_alleles, n_pairs, base_len=12_000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    loc.set_hap_alns(L.hap_alns(), transfer_fails=100, max_div=0.1)
+    ch = L.reads(0, n_pairs, primaries_only=True)
+    aa = api.AllAlignments.load(loc, ch)
+    n_new = aa.recover()
+    aa.score()
+    assert n_new > 3 * n_pairs
+    aln_off, recs, cig_off, cigar = aa.records()
+    assert len(recs) == len(ch.recs) + n_new and np.all(np.diff(aln_off.astype(np.int64)) >= np.diff(ch.aln_off.astype(np.int64)))
+    merged = cdefs.ReadsChunk(ch.mate_len, ch.mate_off, ch.bases2, ch.nmask, aln_off, recs, cig_off, cigar)
+    gt = np.array(L.true_genotype, dtype=np.uint16)
+    read_off, counts = api.assignment_counts(aa, gt, api.default_solver(cdefs.SOLVER_ANNEAL), attempts, api.chain_seeds(9, attempts))
+    names = [f"read{r}" for r in range(n_pairs)]
+    allele_names = [f"hap{a}" for a in range(n_alleles)]
+    path = tmp_path / "00.bam"
+    with pytest.raises(_lib.LocityperError):
+        lio.write_bam(path, aa, ch, names, allele_names, gt, attempts, read_off, counts)      # the mapper's table no longer matches
+    n_written = lio.write_bam(path, aa, merged, names, allele_names, gt, attempts, read_off, counts)
+    text, refs, bam = parse_bam(path)
+    assert n_written == len(bam) and len(refs) == len(set(L.true_genotype))
+    status = aa.status()[0]
+    good = np.flatnonzero(status == cdefs.READ_GOOD)
+    by_read = {}
+    for r in bam:
+        by_read.setdefault(int(r["name"][4:]), []).append(r)
+    assert set(good.tolist()) <= set(by_read) and len(good) > n_pairs // 2
+    on_other = 0
+    for gi, r in enumerate(good[:300]):
+        rr = by_read[int(r)]
+        first = [x for x in rr if x["flag"] & 0x40]
+        assert abs(sum(x["tags"]["pr"] for x in first) - 1.0) < 1e-6
+        for x in rr:
+            if x["flag"] & 0x4: continue
+            ops = [(w & 15, w >> 4) for w in x["cigar"]]
+            assert len(x["seq"]) == sum(n for o, n in ops if o in (7, 8, 1, 4)) == int(ch.mate_len[2 * r + (1 if x["flag"] & 0x80 else 0)])
+            assert 0 <= x["pos"] and x["pos"] + sum(n for o, n in ops if o in (7, 8, 2)) <= refs[x["tid"]][1]
+            # a placement on an allele the mapper had no record on can only be a transferred alignment
+            src = int(ch.recs[int(ch.aln_off[r])]["contig"])
+            on_other += allele_names[src] != refs[x["tid"]][0]
+    assert on_other > 50
+
+
 def _reg2bin(beg, end):
     end -= 1
     if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)

@@ -80,3 +80,7 @@ def test_example_from_a_directory_of_a_basis_run(tmp_path):
     assert res["genotype"] == ",".join(truth["genotype"]) and res["quality"] > 20
     recovered = int(r.stdout.strip().split(" recovered ")[1])
     assert recovered > 4 * 5000                                           # every read pair reaches the other five alleles
+    bam = os.path.join(root, "OUT", "loci", "L1", "alns", "00.bam")      # the placements on the call, transferred alignments included
+    raw = gzip.open(bam, "rb").read()
+    assert raw[:4] == b"BAM\x01" and os.path.getsize(bam + ".bai") > 32
+    assert int(r.stdout.split(" bam_records ")[1].split()[0]) >= 2 * 4000
