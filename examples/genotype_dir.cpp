@@ -86,19 +86,35 @@ int main(int argc, char** argv) {
     // haplotype alignments (process_paf + HapAlns::transfer_alignments, genotype.rs:1131-1160, 149-150: --transfer 0.1 100)
     uint64_t n_recovered = 0;
     bool recovered = false;
+    std::vector<uint32_t> dist;                                  // contig_distances: from the PAF ("edit") or distances.bin ("minim-div")
+    bool edit_distances = false;
     for (const char* paf_name : {"/haplotypes.paf.gz", "/haplotypes.paf"}) {
         const std::string paf = db + paf_name;
         if (FILE* f = std::fopen(paf.c_str(), "rb")) std::fclose(f); else continue;
         uint64_t n_ent = 0, n_words = 0;
-        ok(lcty_paf_read(paf.c_str(), names.data(), A, &n_ent, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &n_words), "haplotypes.paf (size)");
+        ok(lcty_paf_read(paf.c_str(), names.data(), A, &n_ent, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &n_words, nullptr), "haplotypes.paf (size)");
         std::vector<uint32_t> id1(n_ent + 1), id2(n_ent + 1), nm(n_ent + 1), al(n_ent + 1), words(n_words + 1);
         std::vector<uint64_t> woff(n_ent + 1);
-        ok(lcty_paf_read(paf.c_str(), names.data(), A, &n_ent, id1.data(), id2.data(), nm.data(), al.data(), woff.data(), words.data(), &n_words), "haplotypes.paf");
+        dist.assign(static_cast<size_t>(A) * A, 0u);
+        edit_distances = true;
+        ok(lcty_paf_read(paf.c_str(), names.data(), A, &n_ent, id1.data(), id2.data(), nm.data(), al.data(), woff.data(), words.data(), &n_words, dist.data()), "haplotypes.paf");
         ok(lcty_locus_set_hap_alns(loc, static_cast<uint32_t>(n_ent), id1.data(), id2.data(), woff.data(), words.data(), nm.data(), al.data(), 100, 0.1), "HapAlns");
         ok(lcty_recover_alignments(reads, &n_recovered), "transfer_alignments");
         ok(lcty_score_reads(reads), "AllAlignments::load after recovery");
         recovered = true;
         break;
+    }
+
+    if (dist.empty()) {                                          // genotype.rs:1229-1237
+        const std::string dfile = db + "/distances.bin";
+        if (FILE* f = std::fopen(dfile.c_str(), "rb")) {
+            std::fclose(f);
+            uint8_t* dbuf = nullptr; uint64_t dlen = 0;
+            ok(lcty_io_read_file(dfile.c_str(), &dbuf, &dlen), "distances.bin");
+            dist.assign(static_cast<size_t>(A) * A, 0u);
+            ok(lcty_distances_parse(dbuf, dlen, A, nullptr, nullptr, dist.data()), "load_divergences");
+            lcty_io_free(dbuf);
+        }
     }
 
     // solve::solve with the default scheme
@@ -117,10 +133,16 @@ int main(int argc, char** argv) {
         out_gts[2 * t] = gts[2 * call.ixs[t]]; out_gts[2 * t + 1] = gts[2 * call.ixs[t] + 1];
         om[t] = mean[call.ixs[t]]; ov[t] = var[call.ixs[t]];
     }
+    // dist_to_primary / weight_dist (find_weighted_dist, solve.rs:621-645) when the contig distances are known
+    std::vector<uint32_t> gdist(call.n_out + 1);
+    double wdist = NAN; uint32_t warn2 = 0;
+    if (!dist.empty())
+        ok(lcty_call_checks(out_gts.data(), call.n_out, 2, call.ln_probs, static_cast<uint32_t>(call.n_good), dist.data(), A, gdist.data(), &wdist, &warn2), "find_weighted_dist");
+    const uint32_t* gd = dist.empty() ? nullptr : gdist.data();
     uint64_t need = 0;
-    ok(lcty_res_to_json(&call, out_gts.data(), 2, names.data(), A, om.data(), ov.data(), nullptr, 0, NAN, nullptr, 0, &need), "to_json (size)");
+    ok(lcty_res_to_json(&call, out_gts.data(), 2, names.data(), A, om.data(), ov.data(), gd, edit_distances, wdist, nullptr, 0, &need), "to_json (size)");
     std::vector<char> json(need);
-    ok(lcty_res_to_json(&call, out_gts.data(), 2, names.data(), A, om.data(), ov.data(), nullptr, 0, NAN, json.data(), need, &need), "to_json");
+    ok(lcty_res_to_json(&call, out_gts.data(), 2, names.data(), A, om.data(), ov.data(), gd, edit_distances, wdist, json.data(), need, &need), "to_json");
     ok(lcty_io_write_gz((outd + "/res.json.gz").c_str(), reinterpret_cast<const uint8_t*>(json.data()), need - 1), "res.json.gz");
 
     // read placements on the call: the per-read posteriors of the last stage's solver, as `--out-bams 1` (solve.rs:960-973)

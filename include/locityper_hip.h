@@ -657,7 +657,14 @@ int32_t lcty_fasta_read(const char* path, uint32_t* n_seqs, char* names, uint64_
  * (HapAlns::add, src/seq/transfer.rs:48-52). Malformed lines are errors, as there. Called twice: id1 = NULL sizes it
  * (*n_entries, *n_cigar); with buffers, *n_entries / *n_cigar carry their capacities in. cigar_off[n_entries + 1]. */
 int32_t lcty_paf_read(const char* path, const char* const* names, uint32_t n_alleles, uint64_t* n_entries, uint32_t* id1, uint32_t* id2,
-                      uint32_t* n_matches, uint32_t* aln_len, uint64_t* cigar_off, uint32_t* cigar, uint64_t* n_cigar);
+                      uint32_t* n_matches, uint32_t* aln_len, uint64_t* cigar_off, uint32_t* cigar, uint64_t* n_cigar,
+                      uint32_t* dist /* NULL or [n_alleles x n_alleles]: contig_distances (genotype.rs:1139-1150), the edit distance
+                                        aln_len - n_matches of every entry with a CIGAR between two different contigs of the locus,
+                                        symmetric, LCTY_NONE_U32 where the file has none: the `dist` of lcty_call_checks, "edit" */);
+/* DB/loci/<locus>/distances.bin (load_divergences_and_convert, src/seq/minim_div.rs:126-149; read when there is no PAF,
+ * genotype.rs:1229-1237): u8 k, u8 w, varint n (= n_alleles or LCTY_ERR_INVALID_DATA), then the non-shared minimizers of the pairs
+ * i < j row by row. dist[n_alleles x n_alleles]: symmetric, LCTY_NONE_U32 on the diagonal: the `dist` of lcty_call_checks, "minim-div". */
+int32_t lcty_distances_parse(const uint8_t* buf, uint64_t len, uint32_t n_alleles, uint32_t* k, uint32_t* w, uint32_t* dist);
 
 #ifdef __cplusplus
 }

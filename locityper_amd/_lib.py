@@ -99,7 +99,8 @@ SIGNATURES = {
     "lcty_bam_table_view": (I32, [VP, VP, P(VP), P(VP), P(U32)]),
     "lcty_bam_table_free": (None, [VP]),
     "lcty_fasta_read": (I32, [C.c_char_p, P(U32), VP, P(U64), VP, P(U64), VP]),
-    "lcty_paf_read": (I32, [C.c_char_p, P(C.c_char_p), U32, P(U64), VP, VP, VP, VP, VP, VP, P(U64)]),
+    "lcty_paf_read": (I32, [C.c_char_p, P(C.c_char_p), U32, P(U64), VP, VP, VP, VP, VP, VP, P(U64), VP]),
+    "lcty_distances_parse": (I32, [VP, U64, U32, P(U32), P(U32), VP]),
     "lcty_timing_reset": (I32, [VP]),
     "lcty_timing_get": (I32, [VP, I32, P(U64), P(D)]),
 }

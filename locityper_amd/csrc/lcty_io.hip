@@ -630,7 +630,7 @@ int32_t lcty_fasta_read(const char* path, uint32_t* n_seqs, char* names, uint64_
 // a number that does not parse, a strand other than + / - or a CIGAR operation outside MIDSH=X: an error, as there.
 // Two calls: id1 = NULL sizes it (*n_entries, *n_cigar); with buffers, *n_entries / *n_cigar hold their capacities on entry.
 int32_t lcty_paf_read(const char* path, const char* const* names, uint32_t n_alleles, uint64_t* n_entries, uint32_t* id1, uint32_t* id2,
-                      uint32_t* n_matches, uint32_t* aln_len, uint64_t* cigar_off, uint32_t* cigar, uint64_t* n_cigar) {
+                      uint32_t* n_matches, uint32_t* aln_len, uint64_t* cigar_off, uint32_t* cigar, uint64_t* n_cigar, uint32_t* dist) {
     return guarded([&] {
         if (!path || !names || !n_entries || !n_cigar) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         const bool fill = id1 != nullptr;
@@ -644,6 +644,7 @@ int32_t lcty_paf_read(const char* path, const char* const* names, uint32_t n_all
             if (!names[a]) fail(LCTY_ERR_INVALID_INPUT, "null contig name");
             ids.emplace(names[a], a);
         }
+        if (dist) std::fill(dist, dist + static_cast<size_t>(n_alleles) * n_alleles, LCTY_NONE_U32);
         const uint64_t cap_e = fill ? *n_entries : 0, cap_c = fill ? *n_cigar : 0;
         uint64_t ne = 0, nc = 0;
         std::vector<uint32_t> words;
@@ -704,6 +705,12 @@ int32_t lcty_paf_read(const char* path, const char* const* names, uint32_t n_all
                 }
             }
             if (q_it->second == t_it->second || !have_cigar) continue;
+            // contig_distances (genotype.rs:1148-1150): the edit distance of every such entry, whatever it covers; a later line replaces
+            if (dist && al != 0) {
+                const uint32_t d = al - nm;
+                dist[static_cast<size_t>(q_it->second) * n_alleles + t_it->second] = d;
+                dist[static_cast<size_t>(t_it->second) * n_alleles + q_it->second] = d;
+            }
             if (strand != "+" || qs != 0 || qe != qlen || ts != 0 || te != tlen) continue;      // full_positive_alignment, paf.rs:211-215
             if (fill) {
                 if (ne >= cap_e || nc + words.size() > cap_c) fail(LCTY_ERR_INVALID_INPUT, "PAF buffers too small");
@@ -715,6 +722,42 @@ int32_t lcty_paf_read(const char* path, const char* const* names, uint32_t n_all
         }
         if (fill) cigar_off[ne] = nc;
         *n_entries = ne; *n_cigar = nc;
+    });
+}
+
+// DB/loci/<locus>/distances.bin (write_divergences / load_divergences_and_convert, src/seq/minim_div.rs:112-149; not compressed):
+// u8 k, u8 w, varint n, then the n (n - 1) / 2 numbers of non-shared minimizers of the pairs (i, j), i < j, row by row
+// (TriangleMatrix::indices, src/ext/trimat.rs:15-17) as varints. dist[n_alleles x n_alleles]: symmetric, the diagonal LCTY_NONE_U32.
+int32_t lcty_distances_parse(const uint8_t* buf, uint64_t len, uint32_t n_alleles, uint32_t* k, uint32_t* w, uint32_t* dist) {
+    return guarded([&] {
+        if (!buf || !dist) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        uint64_t at = 0;
+        auto byte = [&]() -> uint8_t {
+            if (at >= len) fail(LCTY_ERR_INVALID_DATA, "distances: unexpected end of data at byte %llu", static_cast<unsigned long long>(at));
+            return buf[at++];
+        };
+        auto varint = [&]() -> uint32_t {
+            uint64_t v = 0;
+            for (uint32_t i = 0; i < 5; i++) {
+                const uint8_t b = byte();
+                v |= static_cast<uint64_t>(b & 0x7Fu) << (7 * i);
+                if (!(b & 0x80u)) return static_cast<uint32_t>(v);
+            }
+            fail(LCTY_ERR_INVALID_DATA, "distances: a varint of more than 5 bytes at byte %llu", static_cast<unsigned long long>(at));
+            return 0;
+        };
+        const uint32_t kk = byte(), ww = byte();
+        if (k) *k = kk;
+        if (w) *w = ww;
+        const uint32_t n = varint();
+        if (n != n_alleles)
+            fail(LCTY_ERR_INVALID_DATA, "Cannot read distances: invalid number of haplotypes (expected %u, found %u)", n_alleles, n);
+        std::fill(dist, dist + static_cast<size_t>(n) * n, LCTY_NONE_U32);
+        for (uint32_t i = 0; i + 1 < n; i++)
+            for (uint32_t j = i + 1; j < n; j++) {
+                const uint32_t d = varint();
+                dist[static_cast<size_t>(i) * n + j] = d; dist[static_cast<size_t>(j) * n + i] = d;
+            }
     });
 }
 

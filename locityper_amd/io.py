@@ -22,19 +22,30 @@ def write_gz(path, data):
     check(lib().lcty_io_write_gz(str(path).encode(), buf, len(buf)))
 
 
-def paf_read(path, names):
+def distances_parse(data, n_alleles):
+    """lcty_distances_parse: distances.bin -> (k, w, symmetric u32 matrix, NONE_U32 on the diagonal)."""
+    buf = bytes(data)
+    k, w = U32(), U32()
+    dist = np.zeros((n_alleles, n_alleles), dtype=np.uint32)
+    check(lib().lcty_distances_parse(buf, len(buf), n_alleles, C.byref(k), C.byref(w), dist.ctypes.data))
+    return int(k.value), int(w.value), dist
+
+
+def paf_read(path, names, with_distances=False):
     """lcty_paf_read: haplotypes.paf[.gz|.br|.lz4] -> [(id1 query, id2 target, raw CIGAR words, n_matches, aln_len)] in file order,
     the list Locus.set_hap_alns takes. names: the contig names of the locus in id order."""
     arr = (C.c_char_p * len(names))(*[n.encode() if isinstance(n, str) else bytes(n) for n in names])
     ne, nc = U64(0), U64(0)
-    check(lib().lcty_paf_read(str(path).encode(), arr, len(names), C.byref(ne), None, None, None, None, None, None, C.byref(nc)))
+    check(lib().lcty_paf_read(str(path).encode(), arr, len(names), C.byref(ne), None, None, None, None, None, None, C.byref(nc), None))
     n, w = int(ne.value), int(nc.value)
     id1 = np.zeros(max(n, 1), dtype=np.uint32); id2 = np.zeros(max(n, 1), dtype=np.uint32)
     nm = np.zeros(max(n, 1), dtype=np.uint32); al = np.zeros(max(n, 1), dtype=np.uint32)
     off = np.zeros(n + 1, dtype=np.uint64); words = np.zeros(max(w, 1), dtype=np.uint32)
+    dist = np.zeros((len(names), len(names)), dtype=np.uint32)
     check(lib().lcty_paf_read(str(path).encode(), arr, len(names), C.byref(ne), id1.ctypes.data, id2.ctypes.data, nm.ctypes.data, al.ctypes.data,
-                              off.ctypes.data, words.ctypes.data, C.byref(nc)))
-    return [(int(id1[t]), int(id2[t]), words[int(off[t]):int(off[t + 1])].copy(), int(nm[t]), int(al[t])) for t in range(n)]
+                              off.ctypes.data, words.ctypes.data, C.byref(nc), dist.ctypes.data if with_distances else None))
+    ents = [(int(id1[t]), int(id2[t]), words[int(off[t]):int(off[t + 1])].copy(), int(nm[t]), int(al[t])) for t in range(n)]
+    return (ents, dist) if with_distances else ents
 
 
 def bg_from_json(text):

@@ -78,6 +78,8 @@ def test_example_from_a_directory_of_a_basis_run(tmp_path):
     truth = json.load(open(os.path.join(root, "truth.json")))
     res = json.load(gzip.open(os.path.join(root, "OUT", "loci", "L1", "res.json.gz"), "rt"))
     assert res["genotype"] == ",".join(truth["genotype"]) and res["quality"] > 20
+    assert res["dist_type"] == "edit" and res["options"][0]["dist_to_primary"] == 0 and res["weight_dist"] >= 0.0
+    assert all(isinstance(o["dist_to_primary"], int) for o in res["options"])
     recovered = int(r.stdout.strip().split(" recovered ")[1])
     assert recovered > 4 * 5000                                           # every read pair reaches the other five alleles
     bam = os.path.join(root, "OUT", "loci", "L1", "alns", "00.bam")      # the placements on the call, transferred alignments included

@@ -319,6 +319,12 @@ def test_paf_reader_keeps_what_process_paf_keeps(tmp_path):
         p.write_bytes(blob)
         got = lio.paf_read(p, names)
         assert [(a, b, [(int(w) >> 4, int(w) & 15) for w in ws], nm, al) for a, b, ws, nm, al in got] == want
+    # contig_distances (genotype.rs:1139-1150): aln_len - n_matches of every entry with a CIGAR between two contigs of the locus,
+    # whatever it covers, a later line replacing an earlier one: h1-h2 104 - 95; h1-h3 95 - 90, then 100 - 90, then (h3-h1) 101 - 88;
+    # h2-h3 has aln_len 0: no distance
+    _, dist = lio.paf_read(p, names, with_distances=True)
+    NONE = 0xFFFFFFFF
+    assert dist.tolist() == [[NONE, 9, 13], [9, NONE, NONE], [13, NONE, NONE]]
     for bad, code in (("h1\t100\t0\t100\t+\th2\t102\t0\t102\t95", cdefs.ERR_INVALID_INPUT),                              # too few columns
                       ("h1\t100\t0\tx\t+\th2\t102\t0\t102\t95\t104\t60\tcg:Z:100=", cdefs.ERR_INVALID_DATA),          # a number that does not parse
                       ("h1\t100\t0\t100\t*\th2\t102\t0\t102\t95\t104\t60\tcg:Z:100=", cdefs.ERR_INVALID_DATA),       # strand
@@ -345,3 +351,22 @@ def test_paf_reader_keeps_what_process_paf_keeps(tmp_path):
     assert len(back) == len(ents) > 0
     for (a, b, ws, nm, al), (a2, b2, ws2, nm2, al2) in zip(ents, back):
         assert (a, b, nm, al) == (a2, b2, nm2, al2) and np.array_equal(np.asarray(ws, dtype=np.uint32), ws2)
+
+
+def test_distances_bin():
+    """distances.bin (write_divergences, seq/minim_div.rs:112-124): u8 k, u8 w, varint n, the pairs i < j row by row."""
+    def varint(v):
+        out = bytearray()
+        while True:
+            b = v & 0x7F; v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v: return bytes(out)
+    vals = [3, 300, 70000, 0, 5, 129]                                     # (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+    blob = bytes([15, 10]) + varint(4) + b"".join(varint(v) for v in vals)
+    k, w, dist = lio.distances_parse(blob, 4)
+    N = 0xFFFFFFFF
+    assert (k, w) == (15, 10) and dist.tolist() == [[N, 3, 300, 70000], [3, N, 0, 5], [300, 0, N, 129], [70000, 5, 129, N]]
+    for bad, n in ((blob, 5), (blob[:-1], 4), (bytes([15, 10]) + varint(4) + b"\xff" * 6, 4)):
+        with pytest.raises(_lib.LocityperError) as e:
+            lio.distances_parse(bad, n)
+        assert e.value.code == cdefs.ERR_INVALID_DATA
