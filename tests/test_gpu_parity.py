@@ -351,6 +351,10 @@ def test_invalid_inputs_fail_loudly(gpu_ctx):
     aa = api.AllAlignments(loc, 4, 32 * 8, 16, 64)
     with pytest.raises(_lib.LocityperError):
         aa.status()                                   # not scored yet
+    with pytest.raises(_lib.LocityperError):
+        aa.prefilter_truncate(1.0, 1, 1)              # nothing scored, nothing prefiltered
+    with pytest.raises(_lib.LocityperError):
+        api.AllAlignments.load(loc, ReadsChunk.from_pairs([])).prefilter_truncate(1.0, 1, 1)   # scored, but no prefilter scores on the device yet
     with pytest.raises(_lib.LocityperError) as e:
         api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 64, bg, p)      # k > 63: beyond u128 k-mers (kmers.rs:24-26)
     assert e.value.code == cdefs.ERR_INVALID_INPUT
