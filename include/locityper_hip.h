@@ -371,6 +371,9 @@ int32_t lcty_truncate(const double* scores, uint64_t* ixs, uint64_t n, double fi
  * prefix truncate_ixs keeps; only the kept indices come to the host (at 4 096 alleles the scores are 67 MB). ixs = NULL: *n_keep only. */
 int32_t lcty_prefilter_truncate(lcty_reads* reads, double filt_diff, uint64_t min_size, uint64_t threads, uint64_t* ixs, uint64_t cap,
                                 uint64_t* n_keep);
+/* scores[g] = priors[g] + scores[g] on the device (run_filter, solve.rs:114: `--priors`), between lcty_prefilter_async (or the
+ * all-reduce) and lcty_prefilter_truncate; n = the number of genotypes of the last prefilter call. */
+int32_t lcty_prefilter_add_priors(lcty_reads* reads, const double* priors, uint64_t n);
 
 /* generate_genotypes without priors (src/command/genotype.rs:1120-1126) */
 uint64_t lcty_count_genotypes(uint32_t n_alleles, uint32_t ploidy);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lcty_prefilter_scores": (I32, [VP, VP, U64]),
     "lcty_truncate": (I32, [VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_prefilter_truncate": (I32, [VP, D, U64, U64, VP, U64, P(U64)]),
+    "lcty_prefilter_add_priors": (I32, [VP, VP, U64]),
     "lcty_count_genotypes": (U64, [U32, U32]),
     "lcty_generate_genotypes": (I32, [U32, U32, VP, U64]),
     "lcty_locus_window_weights": (I32, [VP, VP]),

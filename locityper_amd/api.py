@@ -350,6 +350,10 @@ class AllAlignments:
         check(lib().lcty_prefilter_scores(self._h, scores.ctypes.data, n))
         return scores
 
+    def prefilter_add_priors(self, priors):
+        priors = np.ascontiguousarray(priors, dtype=np.float64)
+        check(lib().lcty_prefilter_add_priors(self._h, priors.ctypes.data, len(priors)))
+
     def prefilter_truncate(self, filt_diff, min_size, threads):
         """lcty_prefilter_truncate: truncate_ixs on the scores the last prefilter call left on the device; the kept genotype indices
         sorted by (score desc, index asc)."""

@@ -64,6 +64,11 @@ __global__ void select_kernel(const uint64_t* __restrict__ keys, uint64_t n, dou
     out[0] = m;
 }
 
+__global__ void add_priors_kernel(double* __restrict__ scores, const double* __restrict__ priors, uint64_t n) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) scores[i] = priors[i] + scores[i];                                // prior + sum (solve.rs:114)
+}
+
 }  // namespace
 
 }  // namespace lcty
@@ -71,6 +76,27 @@ __global__ void select_kernel(const uint64_t* __restrict__ keys, uint64_t n, dou
 using namespace lcty;
 
 extern "C" {
+
+// scores[g] = priors[g] + scores[g] on the device (run_filter adds the prior of a genotype to its sum, solve.rs:114): the step between
+// lcty_prefilter_async (/ lcty_prefilter_allreduce) and lcty_prefilter_truncate when `--priors` is given
+int32_t lcty_prefilter_add_priors(lcty_reads* reads, const double* priors, uint64_t n) {
+    return guarded([&] {
+        if (!reads || !priors) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (!reads->scored || reads->n_scores == 0 || reads->d_scores.n < reads->n_scores)
+            fail(LCTY_ERR_INVALID_INPUT, "no prefilter scores on the device: lcty_prefilter_async first");
+        if (n != reads->n_scores) fail(LCTY_ERR_INVALID_INPUT, "expected %llu priors", static_cast<unsigned long long>(reads->n_scores));
+        lcty_ctx* ctx = reads->ctx;
+        ctx->activate();
+        hipStream_t s = ctx->stream;
+        auto& B = reads->select;
+        B.k_in.ensure(n);                                                        // staging for the priors (the sort's key buffer: free until the sort)
+        LCTY_HIP(hipMemcpyAsync(B.k_in.p, priors, n * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(add_priors_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s, reads->d_scores.p,
+                           reinterpret_cast<const double*>(B.k_in.p), n);
+        LCTY_HIP(hipGetLastError());
+        LCTY_HIP(hipStreamSynchronize(s));                                       // `priors` is the caller's memory
+    });
+}
 
 int32_t lcty_prefilter_truncate(lcty_reads* reads, double filt_diff, uint64_t min_size, uint64_t threads, uint64_t* ixs, uint64_t cap,
                                 uint64_t* n_keep) {

@@ -2327,9 +2327,10 @@ struct LocusRun {
         // to discard_improbable_genotypes when threads == 1 (solve.rs:797, 853) and data.threads otherwise (1087-1089)
         threads = std::max<uint64_t>(1, prm.threads);
         if (prm.dont_skip || stages[0].in_size < G) {
-            if (!priors && ploidy == 2) {
+            if (ploidy == 2) {
                 // the scores stay on the device: sorted and cut there, only the kept indices come back (lcty_select.hip)
                 ok(lcty_prefilter_async(reads, 2));
+                if (priors) ok(lcty_prefilter_add_priors(reads, priors, G));
                 ok(lcty_prefilter_truncate(reads, prm.filt_diff, stages[0].in_size, threads, ixs.data(), G, &n));
             } else {
                 std::vector<double> scores(G);

@@ -38,6 +38,12 @@ def check_prefilter(aa, Mo, n_alleles, p):
         assert np.array_equal(k3, k1)
     for fd, ms, th in ((0.0, 1, 1), (1.0, 3, 8), (1e300, 7, 1), (5.0, len(sc) + 5, 2), (0.5, 2, len(sc) + 9)):
         assert np.array_equal(aa.prefilter_truncate(fd, ms, th), api.truncate_ixs(sc, np.arange(len(sc)), fd, ms, th)), (fd, ms, th)
+    # priors (`--priors`): added on the device, prior + sum as solve.rs:114 has it
+    pri = -np.random.default_rng(len(sc)).random(len(sc)) * 3.0
+    aa.prefilter_add_priors(pri)
+    assert np.array_equal(aa.prefilter_scores(), pri + sc)
+    assert np.array_equal(aa.prefilter_truncate(1.5, 4, 2), api.truncate_ixs(pri + sc, np.arange(len(sc)), 1.5, 4, 2))
+    assert np.array_equal(aa.run_filter(), sc)                              # the device's scores back as they were
     return sc, so, gts
 
 
