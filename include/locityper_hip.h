@@ -211,7 +211,8 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  *   "solve_chains_per_wave"   1, 2, 4, 5, 6 chains of the greedy loop per wavefront;   "solve_lds_weights"   0: the greedy loop gathers
  *       the window weights, 1 (default where the locus has the weight tables): table indices + tables in LDS;
  *   "anneal_lds_weights"   0 gathered, 1 in LDS as they are, 2 (default where possible) table indices + tables in LDS;
- *   "solve_stats"   1: per-stage iteration counts on stderr;   "queue_trace"   1: wall-clock marks of the phases of every locus of
+ *   "contig_info_slide"   0 / 1: lcty_locus_create counts its neighbourhoods position by position / with sliding windows (default:
+ *       sliding from 1 024 bases on);   "solve_stats"   1: per-stage iteration counts on stderr;   "queue_trace"   1: wall-clock marks of the phases of every locus of
  *       lcty_solve / lcty_solve_queue on stderr;   "gather_chunk_mb"   staging size of lcty_solve_stage_read_sharded;
  *   "prefilter_gram"   0: always the f64 tile kernel, 1: the integer Gram contraction on the matrix cores whenever it applies
  *       (default: from 512 alleles on);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the

@@ -186,6 +186,71 @@ __global__ __launch_bounds__(64) void contig_info_kernel(const uint8_t* __restri
     }
 }
 
+// The same for wide neighbourhoods (long reads: neighb = 2/3 of the read length): a thread takes CI_SEG consecutive positions, counts
+// its first window as above and then SLIDES it — one base, one k-mer count and one ck-mer leave on the left, one of each enters on the
+// right; the ck-mers of the window are counted (u16 per possible ck-mer and thread in LDS, [v * 64 + thread]), `distinct` follows
+// the counts that reach or leave zero. O(neighb + CI_SEG) per thread instead of O(neighb) per position: the direct form took 119 ms
+// for 256 alleles of 50 kb at the neighbourhood of 10-kb reads. Same integers.
+constexpr uint32_t CI_SEG = 256;
+__global__ __launch_bounds__(64) void contig_info_slide_kernel(const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ seq_off,
+                                                               const uint16_t* __restrict__ counts, const uint64_t* __restrict__ cnt_off,
+                                                               const uint32_t* __restrict__ ci_off, uint32_t k, uint32_t neighb, uint32_t ck,
+                                                               uint32_t n_kmers, uint8_t* __restrict__ gc, uint32_t* __restrict__ uniq,
+                                                               uint16_t* __restrict__ compl_cnt) {
+    extern __shared__ uint16_t held[];                       // [n_kmers][64]
+    const uint32_t a = blockIdx.y, tid = threadIdx.x;
+    const uint8_t* seq = seqs + seq_off[a];
+    const uint16_t* cnt = counts + cnt_off[a];
+    const uint32_t len = static_cast<uint32_t>(seq_off[a + 1] - seq_off[a]);
+    const uint32_t n_pos = len - neighb + 1;
+    const uint32_t p0 = (blockIdx.x * 64 + tid) * CI_SEG;
+    if (blockIdx.x * 64 * CI_SEG >= n_pos) return;
+    for (uint32_t v = 0; v < n_kmers; v++) held[v * 64 + tid] = 0;
+    if (p0 >= n_pos) return;                                 // (no barrier below: every thread owns its column of `held`)
+    const uint32_t p1 = min(n_pos, p0 + CI_SEG);
+    const uint32_t mask = (1u << (2 * ck)) - 1u;
+    auto enc_of = [](uint8_t b) -> uint32_t { return b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u; };
+    uint32_t c_gc = 0, v = 0, bad = 0, undef_cnt = 0, distinct = 0;
+    auto enter = [&](uint32_t value, bool is_undef) {
+        if (is_undef) undef_cnt++;
+        else { uint16_t& h = held[value * 64 + tid]; if (h++ == 0) distinct++; }
+    };
+    // the first window
+    for (uint32_t i = 0; i < neighb; i++) {
+        const uint8_t b = seq[p0 + i];
+        c_gc += (b == 'C' || b == 'G');
+        const uint32_t enc = enc_of(b);
+        if (enc == 4) { bad = ck; v = (v << 2) & mask; } else { v = ((v << 2) | enc) & mask; if (bad) bad--; }
+        if (i + 1 >= ck) enter(v, bad != 0);
+    }
+    const uint32_t span = neighb + 1 - k;
+    uint32_t c_u = 0;
+    for (uint32_t i = 0; i < span; i++) c_u += cnt[p0 + i] == 0;
+    const double gc_mult = 100.0 / static_cast<double>(neighb);
+    for (uint32_t p = p0;; p++) {
+        const uint64_t o = static_cast<uint64_t>(ci_off[a]) + p;
+        gc[o] = static_cast<uint8_t>(round(gc_mult * static_cast<double>(c_gc)));
+        uniq[o] = c_u;
+        compl_cnt[o] = static_cast<uint16_t>(distinct + (undef_cnt ? 1u : 0u));
+        if (p + 1 >= p1) break;
+        // slide to p + 1: position p leaves, position p + neighb enters
+        const uint8_t out_b = seq[p], in_b = seq[p + neighb];
+        c_gc += (in_b == 'C' || in_b == 'G');
+        c_gc -= (out_b == 'C' || out_b == 'G');
+        c_u += cnt[p + span] == 0;
+        c_u -= cnt[p] == 0;
+        // the ck-mer that started at p
+        uint32_t lv = 0; bool lbad = false;
+        for (uint32_t j = 0; j < ck; j++) { const uint32_t e = enc_of(seq[p + j]); lbad |= e == 4; lv = (lv << 2) | (e & 3u); }
+        if (lbad) undef_cnt--;
+        else { uint16_t& h = held[(lv & mask) * 64 + tid]; if (--h == 0) distinct--; }
+        // the ck-mer that ends at p + neighb
+        const uint32_t enc = enc_of(in_b);
+        if (enc == 4) { bad = ck; v = (v << 2) & mask; } else { v = ((v << 2) | enc) & mask; if (bad) bad--; }
+        enter(v, bad != 0);
+    }
+}
+
 }  // namespace lcty
 
 using namespace lcty;
@@ -319,9 +384,24 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
                 LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contig_info_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds)));
             const uint32_t max_len0 = *std::max_element(L->allele_len.begin(), L->allele_len.end());
-            const dim3 grid((max_len0 - neighb + 1 + 63) / 64, n_alleles);
-            hipLaunchKernelGGL(contig_info_kernel, grid, dim3(64), lds, s, d_seqs.p, d_seq_off.p, d_counts.p, d_cnt_off.p, L->d_ci_off.p,
-                               k, neighb, ck, words, L->d_gc.p, L->d_uniq_cnt.p, L->d_compl_cnt.p);
+            const uint32_t n_ckmers = 1u << (2 * ck);
+            const size_t lds_slide = static_cast<size_t>(n_ckmers) * 64 * sizeof(uint16_t);
+            // wide neighbourhoods (long reads) slide their window; lcty_ctx_set_knob "contig_info_slide" 0 / 1 forces either form
+            const int64_t want = ctx->knob("contig_info_slide", -1);
+            const bool slide = lds_slide <= 144 * 1024 && neighb <= 65535 && (want >= 0 ? want != 0 : neighb >= 1024);
+            if (slide) {
+                if (lds_slide > 48 * 1024)
+                    LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contig_info_slide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds_slide)));
+                const uint32_t n_pos_max = max_len0 - neighb + 1;
+                const dim3 grid((n_pos_max + 64 * CI_SEG - 1) / (64 * CI_SEG), n_alleles);
+                hipLaunchKernelGGL(contig_info_slide_kernel, grid, dim3(64), lds_slide, s, d_seqs.p, d_seq_off.p, d_counts.p, d_cnt_off.p, L->d_ci_off.p,
+                                   k, neighb, ck, n_ckmers, L->d_gc.p, L->d_uniq_cnt.p, L->d_compl_cnt.p);
+            } else {
+                const dim3 grid((max_len0 - neighb + 1 + 63) / 64, n_alleles);
+                hipLaunchKernelGGL(contig_info_kernel, grid, dim3(64), lds, s, d_seqs.p, d_seq_off.p, d_counts.p, d_cnt_off.p, L->d_ci_off.p,
+                                   k, neighb, ck, words, L->d_gc.p, L->d_uniq_cnt.p, L->d_compl_cnt.p);
+            }
             LCTY_HIP(hipGetLastError());
         }
         L->d_n_windows.alloc(n_alleles); L->d_n_windows.upload(L->n_windows.data(), n_alleles, s);

@@ -71,6 +71,34 @@ def test_locus_products(gpu_ctx, n_alleles, tech, rl):
             assert abs(lut[gc, d] - O.lib().orc_depth_ln_pmf(C.byref(L.bg), C.byref(p), gc, d)) <= 1e-9 * max(1.0, abs(lut[gc, d]))
 
 
+@pytest.mark.parametrize("tech,rl", [(cdefs.TECH_ILLUMINA, 150), (cdefs.TECH_NANOPORE, 10_000)])
+def test_contig_info_direct_and_sliding_forms(gpu_ctx, tech, rl):
+    """K3 twice: one thread per position summing its window, and threads that slide a window over 256 positions (the default for wide
+    neighbourhoods): the same integers, and the oracle's; alleles with bases that are not ACGT."""
+    import time
+    L = synth.SynthLocus(5, 50, technology=tech, read_len=rl, base_len=30_000 if rl > 1000 else 9_000, seed=77)
+    seqs = L.seqs.copy()
+    rng = np.random.default_rng(3)
+    for a in range(5):                                                     # a few N bases, some of them next to each other
+        o, e = int(L.seq_off[a]), int(L.seq_off[a + 1])
+        for q in rng.integers(o + 10, e - 10, size=6): seqs[q] = ord("N")
+        seqs[o + 500:o + 503] = ord("N")
+    p = api.resolve_params(api.default_params(), L.bg)
+    ol = O.OracleLocus(seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    took = {}
+    for form in (0, 1):
+        gpu_ctx.set_knob("contig_info_slide", form)
+        t0 = time.perf_counter()
+        loc = api.Locus(gpu_ctx, seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+        gpu_ctx.synchronize()
+        took[form] = time.perf_counter() - t0
+        for a in range(5):
+            for x, y in zip(loc.contig_info(a), ol.contig_info(a)):
+                assert np.array_equal(np.asarray(x), np.asarray(y)), (form, a)
+    gpu_ctx.set_knob("contig_info_slide", -1)
+    print(f"neighbourhood {L.bg.neighb}: direct {1e3 * took[0]:.1f} ms, sliding {1e3 * took[1]:.1f} ms (locus set-up, 5 alleles)")
+
+
 def test_undef_kmer_quirk(gpu_ctx):
     """An allele window with N and off-target count 0 puts UNDEF into the unique set; read windows
     with N then count as hits (kmers.rs:184-190 + locs.rs:946-947, 984)."""
