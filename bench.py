@@ -669,6 +669,7 @@ def main():
                              "aligner_cells": int(cells), "gcups": cells / (ms_tr * 1e-3) / 1e9 if ms_tr else None,
                              "bases_walked_per_s": n_new * 10_000 / (ms_tr * 1e-3) if ms_tr else None,
                              "second_scoring_pass_ms": ms_sc, "recover_and_rescore_s": t_rec, "first_call_s": t_rec_first, "set_hap_alns_s": t_set,
+                             "set_hap_alns_library_call_s": loco.set_hap_alns_call_s,
                              "good_reads_after": ao.n_good(), "level_pairs": ao.recover_stats()}
         ao.close(); del prim
 

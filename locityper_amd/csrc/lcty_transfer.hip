@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <memory>
 #include <numeric>
+#include <thread>
 
 #include "lcty_objects.hpp"
 #include "lcty_transfer_device.hpp"
@@ -527,6 +528,9 @@ int32_t lcty_locus_set_hap_alns(lcty_locus* loc, uint32_t n_entries, const uint3
         std::vector<std::vector<Best>> best(A);
         auto cq = [](uint32_t op) { return op == 0 || op == 7 || op == 8 || op == 1 || op == 4; };
         auto cr = [](uint32_t op) { return op == 0 || op == 7 || op == 8 || op == 2; };
+        // which entries become cells (serial: the first alignment of a pair wins), then the cells themselves on the host's cores — the
+        // CIGAR walk of 32 640 pairs of 50-kb haplotypes is 0.3 s on one
+        std::vector<uint32_t> taken;
         for (uint32_t t = 0; t < n_entries; t++) {
             const uint32_t q = id1[t], r = id2[t];
             if (q >= A || r >= A) fail(LCTY_ERR_INVALID_INPUT, "haplotype alignment %u refers to a contig out of range", t);
@@ -536,53 +540,85 @@ int32_t lcty_locus_set_hap_alns(lcty_locus* loc, uint32_t n_entries, const uint3
             const double div = aln_len[t] == 0 ? std::numeric_limits<double>::infinity()
                                                : static_cast<double>(aln_len[t] - n_matches[t]) / static_cast<double>(aln_len[t]);     // paf.rs:201-208
             if (div > max_div) continue;
-            Cell c;
-            for (uint64_t k = cigar_off[t]; k < cigar_off[t + 1]; k++) {
-                uint32_t op = cigar[k] & 15u;
-                const uint32_t len = cigar[k] >> 4;
-                if (!(op == 7 || op == 8 || op == 1 || op == 2 || op == 0)) fail(LCTY_ERR_INVALID_DATA, "haplotype alignment %u: unsupported CIGAR operation", t);
-                if (q > r) op = op == 1 ? 2u : (op == 2 ? 1u : op);                             // Cigar::invert: query = lower id
-                c.items.push_back(make_uint2(op, len));
-            }
-            if (c.items.empty()) continue;
-            // the alignment has to cover both haplotypes (full_positive_alignment, paf.rs:211-216)
-            uint32_t qpos = 0, rpos = 0;
-            for (size_t k = 0; k < c.items.size(); k++) {
-                const uint32_t op = c.items[k].x, len = c.items[k].y;
-                c.positions.push_back(make_uint2(qpos, rpos));
-                const uint32_t old_q = qpos;
-                auto upd = [&](std::vector<uint2>& v, uint32_t pos1, uint32_t pos2, bool other) {   // update_sparse_index, cigar.rs:972-986
-                    const uint32_t last = (pos1 + len - 1) >> 8;
-                    for (uint32_t i = static_cast<uint32_t>(v.size()); i <= last; i++)
-                        v.push_back(make_uint2(static_cast<uint32_t>(k), pos2 + (other ? (i << 8) - pos1 : 0u)));
-                };
-                if (cq(op)) { upd(c.sparse[0], qpos, rpos, cr(op)); qpos += len; }
-                if (cr(op)) { upd(c.sparse[1], rpos, old_q, cq(op)); rpos += len; }
-            }
-            c.qlen = qpos; c.rlen = rpos;
-            if (qpos != loc->allele_len[lo] || rpos != loc->allele_len[hi])
-                fail(LCTY_ERR_INVALID_DATA, "haplotype alignment %u does not cover both sequences (%u/%u vs %u/%u)", t, qpos, rpos, loc->allele_len[lo],
-                     loc->allele_len[hi]);
-            c.sparse[0].push_back(make_uint2(static_cast<uint32_t>(c.items.size() - 1), c.rlen));
-            c.sparse[1].push_back(make_uint2(static_cast<uint32_t>(c.items.size() - 1), c.qlen));
-            cell_of[static_cast<size_t>(lo) * A + hi] = static_cast<uint32_t>(cells.size());
-            cells.push_back(std::move(c));
+            if (cigar_off[t + 1] == cigar_off[t]) continue;
+            // (an entry that turns out to be malformed below fails the call, as it did when the cells were built one by one)
+            cell_of[static_cast<size_t>(lo) * A + hi] = static_cast<uint32_t>(taken.size());
+            taken.push_back(t);
             best[q].push_back(Best{r, n_matches[t], static_cast<uint32_t>(best[q].size())});
             best[r].push_back(Best{q, n_matches[t], static_cast<uint32_t>(best[r].size())});
         }
-        for (auto& v : best) std::stable_sort(v.begin(), v.end(), [](const Best& a, const Best& b) { return a.n_matches > b.n_matches; });
-        // flatten
-        std::vector<uint32_t> item_off(cells.size() + 1, 0), sparse_off(2 * cells.size() + 1, 0), best_off(A + 1, 0), best_ids;
-        std::vector<uint2> items, positions, sparse;
-        for (size_t c = 0; c < cells.size(); c++) {
-            items.insert(items.end(), cells[c].items.begin(), cells[c].items.end());
-            positions.insert(positions.end(), cells[c].positions.begin(), cells[c].positions.end());
-            item_off[c + 1] = static_cast<uint32_t>(items.size());
-            for (int d = 0; d < 2; d++) {
-                sparse.insert(sparse.end(), cells[c].sparse[d].begin(), cells[c].sparse[d].end());
-                sparse_off[2 * c + d + 1] = static_cast<uint32_t>(sparse.size());
+        cells.resize(taken.size());
+        const uint32_t n_threads = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>({taken.size() / 64 + 1, 16, std::thread::hardware_concurrency()})));
+        std::vector<uint32_t> bad_entry(n_threads, NONE32T), bad_kind(n_threads, 0);
+        auto build = [&](uint32_t tid) {
+            for (size_t ci = tid; ci < taken.size(); ci += n_threads) {
+                const uint32_t t = taken[ci], q = id1[t], r = id2[t];
+                const uint32_t lo = std::min(q, r), hi = std::max(q, r);
+                Cell& c = cells[ci];
+                bool ok_ops = true;
+                c.items.reserve(cigar_off[t + 1] - cigar_off[t]); c.positions.reserve(cigar_off[t + 1] - cigar_off[t]);
+                for (uint64_t k = cigar_off[t]; k < cigar_off[t + 1]; k++) {
+                    uint32_t op = cigar[k] & 15u;
+                    const uint32_t len = cigar[k] >> 4;
+                    if (!(op == 7 || op == 8 || op == 1 || op == 2 || op == 0)) { ok_ops = false; break; }
+                    if (q > r) op = op == 1 ? 2u : (op == 2 ? 1u : op);                         // Cigar::invert: query = lower id
+                    c.items.push_back(make_uint2(op, len));
+                }
+                if (!ok_ops) { if (t < bad_entry[tid]) { bad_entry[tid] = t; bad_kind[tid] = 1; } continue; }
+                // the alignment has to cover both haplotypes (full_positive_alignment, paf.rs:211-216)
+                uint32_t qpos = 0, rpos = 0;
+                for (size_t k = 0; k < c.items.size(); k++) {
+                    const uint32_t op = c.items[k].x, len = c.items[k].y;
+                    c.positions.push_back(make_uint2(qpos, rpos));
+                    const uint32_t old_q = qpos;
+                    auto upd = [&](std::vector<uint2>& v, uint32_t pos1, uint32_t pos2, bool other) {   // update_sparse_index, cigar.rs:972-986
+                        const uint32_t last = (pos1 + len - 1) >> 8;
+                        for (uint32_t i = static_cast<uint32_t>(v.size()); i <= last; i++)
+                            v.push_back(make_uint2(static_cast<uint32_t>(k), pos2 + (other ? (i << 8) - pos1 : 0u)));
+                    };
+                    if (cq(op)) { upd(c.sparse[0], qpos, rpos, cr(op)); qpos += len; }
+                    if (cr(op)) { upd(c.sparse[1], rpos, old_q, cq(op)); rpos += len; }
+                }
+                c.qlen = qpos; c.rlen = rpos;
+                if (qpos != loc->allele_len[lo] || rpos != loc->allele_len[hi]) { if (t < bad_entry[tid]) { bad_entry[tid] = t; bad_kind[tid] = 2; } continue; }
+                c.sparse[0].push_back(make_uint2(static_cast<uint32_t>(c.items.size() - 1), c.rlen));
+                c.sparse[1].push_back(make_uint2(static_cast<uint32_t>(c.items.size() - 1), c.qlen));
+            }
+        };
+        auto in_parallel = [&](auto&& fn) {
+            std::vector<std::thread> th;
+            for (uint32_t tid = 1; tid < n_threads; tid++) th.emplace_back(fn, tid);
+            fn(0u);
+            for (auto& x : th) x.join();
+        };
+        in_parallel(build);
+        {
+            uint32_t first_bad = NONE32T, kind = 0;
+            for (uint32_t tid = 0; tid < n_threads; tid++) if (bad_entry[tid] < first_bad) { first_bad = bad_entry[tid]; kind = bad_kind[tid]; }
+            if (kind == 1) fail(LCTY_ERR_INVALID_DATA, "haplotype alignment %u: unsupported CIGAR operation", first_bad);
+            if (kind == 2) {
+                const uint32_t t = first_bad, lo = std::min(id1[t], id2[t]), hi = std::max(id1[t], id2[t]);
+                const Cell& c = cells[cell_of[static_cast<size_t>(lo) * A + hi]];
+                fail(LCTY_ERR_INVALID_DATA, "haplotype alignment %u does not cover both sequences (%u/%u vs %u/%u)", t, c.qlen, c.rlen, loc->allele_len[lo],
+                     loc->allele_len[hi]);
             }
         }
+        for (auto& v : best) std::stable_sort(v.begin(), v.end(), [](const Best& a, const Best& b) { return a.n_matches > b.n_matches; });
+        // flatten: offsets serially, the copies on the same threads
+        std::vector<uint32_t> item_off(cells.size() + 1, 0), sparse_off(2 * cells.size() + 1, 0), best_off(A + 1, 0), best_ids;
+        for (size_t c = 0; c < cells.size(); c++) {
+            item_off[c + 1] = item_off[c] + static_cast<uint32_t>(cells[c].items.size());
+            sparse_off[2 * c + 1] = sparse_off[2 * c] + static_cast<uint32_t>(cells[c].sparse[0].size());
+            sparse_off[2 * c + 2] = sparse_off[2 * c + 1] + static_cast<uint32_t>(cells[c].sparse[1].size());
+        }
+        std::vector<uint2> items(item_off[cells.size()]), positions(item_off[cells.size()]), sparse(sparse_off[2 * cells.size()]);
+        in_parallel([&](uint32_t tid) {
+            for (size_t c = tid; c < cells.size(); c += n_threads) {
+                std::copy(cells[c].items.begin(), cells[c].items.end(), items.begin() + item_off[c]);
+                std::copy(cells[c].positions.begin(), cells[c].positions.end(), positions.begin() + item_off[c]);
+                for (int d = 0; d < 2; d++) std::copy(cells[c].sparse[d].begin(), cells[c].sparse[d].end(), sparse.begin() + sparse_off[2 * c + d]);
+            }
+        });
         std::vector<uint4> best_meta;
         for (uint32_t a = 0; a < A; a++) {
             for (const Best& b : best[a]) {
