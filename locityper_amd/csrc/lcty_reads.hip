@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <memory>
 
+#include <string>
+#include <thread>
+
 #include "lcty_objects.hpp"
 
 using namespace lcty;
@@ -195,54 +198,9 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
         if (R->n_pairs + n > R->cap_pairs || raw_pairs + n > R->cap_raw_pairs || R->n_bases + nb > R->cap_bases ||
             R->n_recs + nr > R->cap_recs || R->n_cigar + nc > R->cap_cigar)
             fail(LCTY_ERR_INVALID_INPUT, "chunk exceeds the capacity given to lcty_reads_create%s", R->streaming ? "_streaming" : "");
-        // host-side validation of the CSR structure (cheap, O(pairs + records))
-        uint32_t max_recs = R->max_recs_per_pair;
-        uint64_t max_cig = R->max_cigar_per_pair;
-        uint32_t max_rec_cig = R->max_cigar_per_rec;
-        for (uint64_t m = 0; m < 2 * n; m++) {
-            if (h->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
-            if (h->mate_off[m + 1] < h->mate_off[m] + h->mate_len[m]) fail(LCTY_ERR_INVALID_INPUT, "mate offsets overlap");
-        }
-        std::vector<uint2> meta(n);
-        const bool paired = R->locus->bg.is_paired != 0;
-        for (uint64_t r = 0; r < n; r++) {
-            if (h->aln_off[r + 1] < h->aln_off[r] || (!counted && h->cigar_off[r + 1] < h->cigar_off[r]))
-                fail(LCTY_ERR_INVALID_INPUT, "record / CIGAR offsets must be non-decreasing");
-            const uint64_t cnt = h->aln_off[r + 1] - h->aln_off[r];
-            if (cnt > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "too many records in one read pair");
-            max_recs = std::max<uint32_t>(max_recs, static_cast<uint32_t>(cnt));
-            const uint64_t cw = counted ? 0 : h->cigar_off[r + 1] - h->cigar_off[r];
-            max_cig = std::max(max_cig, cw);
-            // record groups (locs.rs:1119-1131): the second primary starts read end 2, a third one would start
-            // the next read pair
-            uint32_t j2 = static_cast<uint32_t>(cnt), j3 = static_cast<uint32_t>(cnt);
-            if (dev) {                                                        // one primary (or unmapped) record first for every read end that is there
-                if (dev->n_recs_mate[2 * r] + dev->n_recs_mate[2 * r + 1] != cnt) fail(LCTY_ERR_RUNTIME, "record counts of the read ends do not add up");
-                if (dev->n_recs_mate[2 * r + 1]) j2 = dev->n_recs_mate[2 * r];
-                max_rec_cig = std::max(max_rec_cig, dev->max_rec_cigar);
-            }
-            for (uint64_t i = h->aln_off[r]; !dev && i < h->aln_off[r + 1]; i++) {
-                bool is_primary;
-                if (counted) {
-                    if (counted[i].pos_flags >> 31) fail(LCTY_ERR_INVALID_INPUT, "counted alignment %llu: reserved flag bit set", (unsigned long long)i);
-                    is_primary = (counted[i].pos_flags & LCTY_CF_NOT_PRIMARY) == 0;
-                } else {
-                    if (static_cast<uint64_t>(h->recs[i].cigar_rel) + h->recs[i].n_cigar > cw)
-                        fail(LCTY_ERR_INVALID_INPUT, "CIGAR of record %llu leaves its pair's CIGAR range", (unsigned long long)i);
-                    max_rec_cig = std::max(max_rec_cig, h->recs[i].n_cigar);
-                    is_primary = (h->recs[i].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0;
-                }
-                const uint32_t idx = static_cast<uint32_t>(i - h->aln_off[r]);
-                if (idx > 0 && is_primary) {
-                    if (j2 == cnt) j2 = idx; else if (j3 == cnt) j3 = idx;
-                }
-            }
-            meta[r] = make_uint2(j2, paired ? j3 : j2);
-        }
-        R->locus->ensure_edit_thresholds(h->mate_len, 2 * n);
-
+        // The bulk of the chunk is on its way before the host looks at it: from page-locked memory (lcty_host_alloc) the copies run while
+        // the host validates; a chunk that fails validation leaves bytes behind the batch's counters, which nothing reads.
         hipStream_t s = ctx->stream;
-        R->d_mate_len.upload(h->mate_len, 2 * n, s, 2 * raw_pairs);
         static_assert(sizeof(lcty_aln_counted) == sizeof(lcty_aln_rec), "both record forms are 16 bytes");
         if (dev) {
             if (R->n_bases / 16 + nb / 16 > R->d_bases2.n || R->n_recs + nr > R->d_recs.n || R->n_cigar + nc > R->d_cigar.n) fail(LCTY_ERR_RUNTIME, "device buffer overflow");
@@ -251,11 +209,94 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
             if (nr) LCTY_HIP(hipMemcpyAsync(R->d_recs.p + R->n_recs, dev->recs, nr * sizeof(lcty_aln_rec), hipMemcpyDeviceToDevice, s));
             if (nc) LCTY_HIP(hipMemcpyAsync(R->d_cigar.p + R->n_cigar, dev->cigar, nc * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         } else {
-            R->d_bases2.upload(h->bases2, nb / 16, s, R->n_bases / 16);
-            R->d_nmask.upload(h->nmask, nb / 32, s, R->n_bases / 32);
             R->d_recs.upload(counted ? reinterpret_cast<const lcty_aln_rec*>(counted) : h->recs, nr, s, R->n_recs);
             if (!counted) R->d_cigar.upload(h->cigar, nc, s, R->n_cigar);
+            R->d_bases2.upload(h->bases2, nb / 16, s, R->n_bases / 16);
+            R->d_nmask.upload(h->nmask, nb / 32, s, R->n_bases / 32);
         }
+        // host-side validation of the CSR structure, O(pairs + records), on the host's cores (a chunk of 32 768 read pairs x 256 alleles is
+        // 16 M records); the first offending pair decides the error, as a serial walk would
+        uint32_t max_recs = R->max_recs_per_pair;
+        uint64_t max_cig = R->max_cigar_per_pair;
+        uint32_t max_rec_cig = R->max_cigar_per_rec;
+        std::vector<uint2> meta(n);
+        const bool paired = R->locus->bg.is_paired != 0;
+        struct Problem { uint64_t pair = ~0ull; int32_t code = LCTY_OK; std::string text; };
+        const uint32_t n_threads = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>({nr / 500000 + 1, 16, std::thread::hardware_concurrency()})));
+        std::vector<Problem> problems(n_threads);
+        std::vector<uint32_t> t_max_recs(n_threads, 0), t_max_rec_cig(n_threads, 0);
+        std::vector<uint64_t> t_max_cig(n_threads, 0);
+        auto validate = [&](uint32_t tid) {
+            const uint64_t r_lo = n * tid / n_threads, r_hi = n * (tid + 1) / n_threads;
+            Problem& P = problems[tid];
+            auto bad = [&](uint64_t r, int32_t code, const char* fmt, unsigned long long arg) {
+                char buf[160];
+                snprintf(buf, sizeof(buf), fmt, arg);
+                P.pair = r; P.code = code; P.text = buf;
+            };
+            uint32_t mr = 0, mrc = 0; uint64_t mc = 0;
+            for (uint64_t m = 2 * r_lo; m < 2 * r_hi; m++) {
+                if (h->mate_off[m] % 32) { bad(m / 2, LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases%.0llu", 0ull); return; }
+                if (h->mate_off[m + 1] < h->mate_off[m] + h->mate_len[m]) { bad(m / 2, LCTY_ERR_INVALID_INPUT, "mate offsets overlap%.0llu", 0ull); return; }
+            }
+            for (uint64_t r = r_lo; r < r_hi; r++) {
+                if (h->aln_off[r + 1] < h->aln_off[r] || (!counted && h->cigar_off[r + 1] < h->cigar_off[r])) {
+                    bad(r, LCTY_ERR_INVALID_INPUT, "record / CIGAR offsets must be non-decreasing%.0llu", 0ull); return;
+                }
+                const uint64_t cnt = h->aln_off[r + 1] - h->aln_off[r];
+                if (cnt > 0xFFFFFFFFull) { bad(r, LCTY_ERR_UNSUPPORTED, "too many records in one read pair%.0llu", 0ull); return; }
+                mr = std::max<uint32_t>(mr, static_cast<uint32_t>(cnt));
+                const uint64_t cw = counted ? 0 : h->cigar_off[r + 1] - h->cigar_off[r];
+                mc = std::max(mc, cw);
+                // record groups (locs.rs:1119-1131): the second primary starts read end 2, a third one would start
+                // the next read pair
+                uint32_t j2 = static_cast<uint32_t>(cnt), j3 = static_cast<uint32_t>(cnt);
+                if (dev) {                                                        // one primary (or unmapped) record first for every read end that is there
+                    if (dev->n_recs_mate[2 * r] + dev->n_recs_mate[2 * r + 1] != cnt) { bad(r, LCTY_ERR_RUNTIME, "record counts of the read ends do not add up%.0llu", 0ull); return; }
+                    if (dev->n_recs_mate[2 * r + 1]) j2 = dev->n_recs_mate[2 * r];
+                    mrc = std::max(mrc, dev->max_rec_cigar);
+                }
+                for (uint64_t i = h->aln_off[r]; !dev && i < h->aln_off[r + 1]; i++) {
+                    bool is_primary;
+                    if (counted) {
+                        if (counted[i].pos_flags >> 31) { bad(r, LCTY_ERR_INVALID_INPUT, "counted alignment %llu: reserved flag bit set", (unsigned long long)i); return; }
+                        is_primary = (counted[i].pos_flags & LCTY_CF_NOT_PRIMARY) == 0;
+                    } else {
+                        if (static_cast<uint64_t>(h->recs[i].cigar_rel) + h->recs[i].n_cigar > cw) {
+                            bad(r, LCTY_ERR_INVALID_INPUT, "CIGAR of record %llu leaves its pair's CIGAR range", (unsigned long long)i); return;
+                        }
+                        mrc = std::max(mrc, h->recs[i].n_cigar);
+                        is_primary = (h->recs[i].flags & (LCTY_FLAG_SECONDARY | LCTY_FLAG_SUPPL)) == 0;
+                    }
+                    const uint32_t idx = static_cast<uint32_t>(i - h->aln_off[r]);
+                    if (idx > 0 && is_primary) {
+                        if (j2 == cnt) j2 = idx; else if (j3 == cnt) j3 = idx;
+                    }
+                }
+                meta[r] = make_uint2(j2, paired ? j3 : j2);
+            }
+            t_max_recs[tid] = mr; t_max_cig[tid] = mc; t_max_rec_cig[tid] = mrc;
+        };
+        {
+            std::vector<std::thread> th;
+            for (uint32_t tid = 1; tid < n_threads; tid++) th.emplace_back(validate, tid);
+            validate(0);
+            for (auto& x : th) x.join();
+        }
+        {
+            const Problem* first = nullptr;
+            for (const Problem& P : problems) if (P.code != LCTY_OK && (!first || P.pair < first->pair)) first = &P;
+            if (first) {
+                (void)hipStreamSynchronize(s);                                    // the copies read the caller's chunk
+                fail(first->code, "%s", first->text.c_str());
+            }
+        }
+        for (uint32_t tid = 0; tid < n_threads; tid++) {
+            max_recs = std::max(max_recs, t_max_recs[tid]); max_cig = std::max(max_cig, t_max_cig[tid]); max_rec_cig = std::max(max_rec_cig, t_max_rec_cig[tid]);
+        }
+        try { R->locus->ensure_edit_thresholds(h->mate_len, 2 * n); }
+        catch (...) { (void)hipStreamSynchronize(s); throw; }
+        R->d_mate_len.upload(h->mate_len, 2 * n, s, 2 * raw_pairs);
         // rebased offsets
         std::vector<uint64_t> mo(2 * n), ao(n), co(n);
         for (uint64_t m = 0; m < 2 * n; m++) mo[m] = h->mate_off[m + 1] + R->n_bases;
