@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -41,9 +42,59 @@ bool ends_with(const std::string& s, const char* suffix) {
     return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
 }
 
+// BGZF (the blocks of a BAM / .bgz file: gzip members of <= 64 KB whose extra field "BC" holds the member's size): the members are
+// independent, so they inflate on the host's cores straight into their places (htslib does the same with its thread pool). Returns
+// false when the input is not BGZF from end to end (then the serial walk below takes it).
+bool inflate_bgzf(const std::vector<uint8_t>& in, const char* what, std::vector<uint8_t>& out) {
+    struct Block { size_t at, size, out_at; uint32_t isize; };
+    std::vector<Block> blocks;
+    size_t i = 0, total = 0;
+    while (i < in.size()) {
+        if (i + 18 > in.size() || in[i] != 0x1f || in[i + 1] != 0x8b || in[i + 2] != 8 || !(in[i + 3] & 4)) return false;
+        const uint32_t xlen = in[i + 10] | (in[i + 11] << 8);
+        if (i + 12 + xlen > in.size()) return false;
+        uint32_t bsize = 0;
+        for (size_t x = i + 12; x + 4 <= i + 12 + xlen;) {
+            const uint32_t slen = in[x + 2] | (in[x + 3] << 8);
+            if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2 && x + 6 <= i + 12 + xlen) bsize = (in[x + 4] | (in[x + 5] << 8)) + 1u;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || i + bsize > in.size()) return false;
+        const uint32_t isize = in[i + bsize - 4] | (in[i + bsize - 3] << 8) | (in[i + bsize - 2] << 16) | (static_cast<uint32_t>(in[i + bsize - 1]) << 24);
+        if (isize > 65536) return false;
+        blocks.push_back(Block{i, bsize, total, isize});
+        total += isize; i += bsize;
+    }
+    out.resize(total);
+    const uint32_t n_threads = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>({blocks.size() / 64 + 1, 32, std::thread::hardware_concurrency()})));
+    std::vector<int> rc_of(n_threads, Z_OK);
+    auto work = [&](uint32_t tid) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) { rc_of[tid] = Z_MEM_ERROR; return; }
+        for (size_t b = tid; b < blocks.size(); b += n_threads) {
+            const Block& B = blocks[b];
+            zs.next_in = const_cast<Bytef*>(in.data() + B.at); zs.avail_in = static_cast<uInt>(B.size);
+            zs.next_out = out.data() + B.out_at; zs.avail_out = B.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { rc_of[tid] = rc == Z_STREAM_END ? Z_DATA_ERROR : (rc == Z_OK ? Z_BUF_ERROR : rc); break; }
+            if (inflateReset(&zs) != Z_OK) { rc_of[tid] = Z_STREAM_ERROR; break; }
+        }
+        inflateEnd(&zs);
+    };
+    std::vector<std::thread> th;
+    for (uint32_t tid = 1; tid < n_threads; tid++) th.emplace_back(work, tid);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int rc : rc_of) if (rc != Z_OK) fail(LCTY_ERR_INVALID_DATA, "%s: corrupt BGZF block (zlib %d)", what, rc);
+    return true;
+}
+
 // gzip members one after the other (a .gz written in pieces, or the BGZF blocks of a BAM file)
 std::vector<uint8_t> inflate_gzip(const std::vector<uint8_t>& in, const char* what) {
     std::vector<uint8_t> out;
+    if (inflate_bgzf(in, what, out)) return out;
+    out.clear();
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) fail(LCTY_ERR_RUNTIME, "zlib: inflateInit2");

@@ -46,6 +46,44 @@ def test_gzip_round_trip_and_members(tmp_path):
     assert e.value.code == cdefs.ERR_INVALID_INPUT
 
 
+def test_bgzf_blocks_inflate_in_parallel(tmp_path):
+    """BGZF from end to end (every member carries its size in a "BC" extra field): the blocks inflate independently on the host's
+    cores; anything else — a plain member in between, a damaged block — takes the serial walk or fails loudly."""
+    def bgzf(data, block=0xff00):
+        out = bytearray()
+        for i in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if i is None else data[i:i + block]
+            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = comp.compress(chunk) + comp.flush()
+            out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(body) + 25) + body
+            out += struct.pack("<II", zlib.crc32(chunk), len(chunk))
+        return bytes(out)
+    rng = np.random.default_rng(8)
+    data = bytes(rng.integers(0, 7, 6_000_000, dtype=np.uint8)) + os.urandom(200_000)          # ~100 blocks, the last ones incompressible
+    blob = bgzf(data)
+    p = tmp_path / "big.bgz"
+    p.write_bytes(blob)
+    assert lio.read_file(p) == data
+    p2 = tmp_path / "small_blocks.bam"                                      # .bam: the same container
+    p2.write_bytes(bgzf(data[:300_000], block=1000))
+    assert lio.read_file(p2) == data[:300_000]
+    p3 = tmp_path / "mixed.gz"                                              # a plain member first: not BGZF from end to end
+    p3.write_bytes(gzip.compress(b"head ") + bgzf(data[:100_000]))
+    assert lio.read_file(p3) == b"head " + data[:100_000]
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x5A                                              # inside the deflate stream of a block in the middle
+    p4 = tmp_path / "bad.bgz"
+    p4.write_bytes(bytes(bad))
+    with pytest.raises(_lib.LocityperError) as e:
+        lio.read_file(p4)
+    assert e.value.code == cdefs.ERR_INVALID_DATA
+    p5 = tmp_path / "cut.bgz"
+    p5.write_bytes(blob[:len(blob) // 2])                                   # ends inside a block
+    with pytest.raises(_lib.LocityperError) as e:
+        lio.read_file(p5)
+    assert e.value.code == cdefs.ERR_INVALID_DATA
+
+
 def _lz4_frame_by_hand(blocks):
     """An LZ4 frame from (compressed?, bytes) blocks: FLG = version 01, block-independent off (linked blocks), no checksums."""
     out = struct.pack("<I", 0x184D2204) + bytes([0x40, 0x40, 0x00])       # FLG, BD (64 KB), HC (not checked)
