@@ -70,6 +70,7 @@ def parse_args():
                     help="one locus over all ranks, whole path: every rank scores and prefilters all reads of the locus (replicated), the "
                          "(genotype, attempt) chains of both solver stages are dealt to the ranks and their likelihoods all-gathered on the "
                          "devices (RCCL; lcty_solve_stage_sharded, SURVEY 8e level 3); strong scaling. Not the default either")
+    ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (launch-path checks on a one-GPU box; reported in the line)")
     ap.add_argument("--pipeline", type=int, default=0, help="ignored (round 1 option; the queue of loci is the default mode now)")
     ap.add_argument("--recruit-sample", type=int, default=8_000_000,
                     help="read pairs of the extra recruitment measurement (the step before the path, SURVEY 8f rank 1; 0 = skip)")
@@ -120,7 +121,7 @@ def progress(what):
     print(f"[bench {time.time() - _T_START:7.1f} s] {what}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G):
+def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, loc):
     """The reference's CPU path beside the GPU number: the oracle — a C restatement of the reference algorithms —
     with the reference's own thread structure, at threads = 8 (the reference default, genotype.rs:127) and at all physical cores:
       load     AllAlignments::load: single-threaded BAM loop + recover_and_group_alignments on `threads` workers, reads dealt
@@ -209,19 +210,66 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G):
         by["threads_8" if T == 8 else "all_cores"] = entry
     if "all_cores" not in by:
         by["all_cores"] = dict(by["threads_8"])          # an 8-core host: the two coincide
+    # ---- the oracle's chains against the GPU's, on the full batch (stoch.rs:81-120, 195-245): the timed runs above evaluate BayesCalc on
+    # the fly beyond depth 256 as the reference does (own lgamma: a near-tie can flip); for the comparison the oracle gets the device's
+    # tables, so a chain has to follow the same moves and the likelihoods agree to 1e-9 relative
+    chains_check = None
+    if oa_full is not None:
+        ol.inject_tables(loc.depth_lut(), loc.window_weights())
+        ol.inject_depth_table(loc.depth_table(8192))
+        order = np.argsort(-so, kind="stable")
+        nchk = min(8, len(order))
+        sub = gts[order[:nchk]]
+        worst = 0.0
+        for solver, master in ((greedy, 3000), (anneal, 4000)):
+            seeds = api.chain_seeds(master, nchk)
+            _, _, gl = api.solve_stage(aa, sub, solver, 1, seeds)
+            _, _, olk = O.solve_stage(ol, oa_full, sub, solver, 1, seeds, threads=min(8, n_phys))
+            worst = max(worst, float(np.abs(gl - olk).max() / np.abs(olk).max()))
+        chains_check = {"greedy_chains": nchk, "anneal_chains": nchk, "read_pairs": solver_pairs, "max_relative_difference": worst,
+                        "chains_equal_oracle": bool(worst <= 1e-9)}
     best = by["all_cores"]
     return {"value": best["value"], "unit": "read pairs/s", "cores": best["threads"], "kind": "port",
             "sample": f"load + run_filter on the first {ns} read pairs x {A} alleles (all {G} genotypes; {n_good_sample} good pairs); "
                       + (f"solver chains on all {solver_pairs} read pairs (inputs = the batch the GPU scored); " if oa_full is not None else "")
                       + f"whole path composed for {args.pairs} read pairs and the default scheme; median of {reps} (solver chains at all cores: one run)",
             "cpu_model": cpu_model(), "physical_cores": n_phys, "cpu_count": os.cpu_count(),
-            "by_threads": by,
+            "by_threads": by, "chains_check": chains_check,
             "reads_scored_per_s": best["reads_scored_per_s"], "chains_per_s": best.get("chains_per_s"),
             "note": "reference-algorithm CPU restatement (oracle/), never 'locityper': the Rust reference cannot be built here"}
 
 
+def spawn_ranks(args):
+    """`python3 bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): this process becomes the launcher — it starts N
+    fresh children of this very command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, BEFORE it has loaded the
+    HIP library or made any GPU call (a process that has touched the GPU never execs another program), relays rank 0's JSON line and
+    exits non-zero when any child fails. The children are what `torchrun --nproc-per-node N` would have started."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                LCTY_BENCH_LAUNCH="self-spawned children of bench.py")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    line, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        print(f"bench.py: child ranks exited with {codes}", file=sys.stderr)
+        sys.exit(next(c for c in codes if c) or 1)
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    sys.exit(0)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)           # never returns; nothing above this line loads the HIP library
     # stdout carries exactly one JSON line: whatever the libraries underneath print there (gloo announces its connections, RCCL its
     # version) goes to stderr, the line itself to the real stdout at the very end
     sys.stdout.flush()
@@ -235,18 +283,22 @@ def main():
     if world > 1:
         import torch.distributed as dist      # gloo: barrier + max-reduce only, no GPU tensors
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE is {world}: the launcher and the command line disagree about the number of ranks")
 
     ndev = api.device_count()
     if ndev < 1:
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback)")
+    if world > ndev and not args.oversubscribe:
+        raise RuntimeError(f"{world} ranks but {ndev} HIP device(s) visible: one process per GPU (--oversubscribe puts several ranks on a device "
+                           "to exercise the launch path on a small box; the line then says so)")
     ctx = api.Context(local_rank % ndev)
     for kv in args.knob:
         name, _, val = kv.partition("=")
         ctx.set_knob(name, int(val))
 
     comm = None
+    rccl_ranks = None
     first_pair = 0
     total_pairs = args.pairs
     one_locus = args.shard_reads or args.shard_chains
@@ -262,6 +314,7 @@ def main():
             dist.broadcast(t_uid, src=0)
             uid = bytes(t_uid.tolist())
         comm = api.Comm(ctx, world, rank, uid)
+        rccl_ranks = comm.rccl_ranks()[0]
     if args.shard_reads:
         per = (args.pairs + world - 1) // world
         first_pair = min(rank * per, args.pairs)
@@ -459,6 +512,9 @@ def main():
         "value": reads_per_s,
         "unit": "read pairs/s",
         "n_gpus": world,
+        "devices_used": min(world, ndev),
+        "launch": os.environ.get("LCTY_BENCH_LAUNCH", "launcher environment (torchrun)" if world > 1 else "single process"),
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -675,8 +731,11 @@ def main():
 
     if first is not None:
         progress("CPU baseline")
-        out["cpu_baseline"] = cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G)
+        out["cpu_baseline"] = cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, loc)
         out["vs_cpu_baseline"] = {k: reads_per_s / v["value"] for k, v in out["cpu_baseline"]["by_threads"].items()}
+        cc = out["cpu_baseline"].pop("chains_check")
+        out["chains_equal_oracle"] = None if cc is None else cc["chains_equal_oracle"]
+        out["chains_check"] = cc
         from tests import oracle_ffi as O
         if out.get("recruitment") and args.recruit_sample > 0:
             # recruitment on the same core: the oracle's recruit_read_pair on a bounded sample of random pairs

@@ -215,7 +215,8 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  *       sliding from 1 024 bases on);   "solve_stats"   1: per-stage iteration counts on stderr;   "queue_trace"   1: wall-clock marks of the phases of every locus of
  *       lcty_solve / lcty_solve_queue on stderr;   "gather_chunk_mb"   staging size of lcty_solve_stage_read_sharded;
  *   "prefilter_gram"   0: always the f64 tile kernel, 1: the integer Gram contraction on the matrix cores whenever it applies
- *       (default: from 512 alleles on);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the
+ *       (default: from 512 alleles on);   "comm_fail_at"   k: the k-th status agreement of a multi-GPU call fails on this rank (tests of
+ *       the error path of the exchanges);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the
  *       f64 kernel takes the batch);   "prefilter_gram_levels"   levels of a row the contraction takes (<= 16; rows with more go
  *       through the f64 kernel).
  * value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT. None of them changes a result beyond the last bits of
@@ -396,6 +397,14 @@ typedef struct lcty_comm lcty_comm;
 int32_t lcty_comm_unique_id(uint8_t* id);
 int32_t lcty_comm_create(lcty_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* id, lcty_comm** out);
 void    lcty_comm_destroy(lcty_comm* comm);
+/* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank): the launcher's proof of how many ranks an
+ * exchange really spans (bench.py prints it) */
+int32_t lcty_comm_ranks(const lcty_comm* comm, int32_t* n_ranks, int32_t* rank);
+/* Every exchange below: whatever a rank does on its own between two collectives (checks, allocations, launches) runs behind a
+ * status agreement — a three-word MAX all-reduce every rank joins unconditionally — so that a failure on one rank makes ALL ranks
+ * return an error (the failing rank its own status, the others "another rank failed") instead of leaving them inside RCCL; the
+ * same agreement carries the sizes the next collective depends on and refuses ranks that disagree about them.
+ * (Test hook: lcty_ctx_set_knob "comm_fail_at" = k fails the k-th agreement of a call on this rank.) */
 int32_t lcty_prefilter_allreduce(lcty_reads* reads, lcty_comm* comm);
 /* One solver stage with its (genotype, attempt) chains dealt to the ranks of `comm` (SURVEY.md 8e level 3; the reference deals
  * the genotypes of a stage to its worker threads, solve.rs:1052-1062): every rank passes the SAME arguments and holds the same

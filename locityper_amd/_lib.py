@@ -59,6 +59,7 @@ SIGNATURES = {
     "lcty_comm_unique_id": (I32, [VP]),
     "lcty_comm_create": (I32, [VP, I32, I32, VP, P(VP)]),
     "lcty_comm_destroy": (None, [VP]),
+    "lcty_comm_ranks": (I32, [VP, P(I32), P(I32)]),
     "lcty_prefilter_allreduce": (I32, [VP, VP]),
     "lcty_recruit_params_default": (I32, [VP, I32, I32]),
     "lcty_targets_create": (I32, [VP, VP, P(VP)]),

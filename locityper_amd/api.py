@@ -711,6 +711,12 @@ class Comm:
         check(lib().lcty_comm_create(ctx._h, n_ranks, rank, buf, C.byref(self._h)))
         self.n_ranks, self.rank = n_ranks, rank
 
+    def rccl_ranks(self):
+        """(ranks, rank) as RCCL reports them for this communicator (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int32(0), C.c_int32(0)
+        check(lib().lcty_comm_ranks(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
     def prefilter_allreduce(self, aa):
         check(lib().lcty_prefilter_allreduce(aa._h, self._h))
 

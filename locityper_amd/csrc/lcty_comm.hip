@@ -25,31 +25,71 @@ struct lcty_comm {
     lcty_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     int32_t n_ranks = 0, rank = 0;
-    DevBuf<int32_t> d_status;          // one word: the status every rank agrees on before a data collective
+    DevBuf<int64_t> d_status;          // {status, size, ~size}: what every rank agrees on before a data collective (allocated with the communicator)
 };
 
 namespace {
 
-// A rank whose local part failed (a bad read shard, an arena overflow, a chain that lost its hand-shake ...) must not leave the
-// others inside the data collective for ever: every rank joins this one-word MAX all-reduce unconditionally, with its own status,
-// and all of them raise when any of them failed. `local` runs the rank's part and may throw.
-template <typename F>
-void agree_then(lcty_comm* comm, F&& local) {
-    int32_t rc = LCTY_OK;
-    std::string msg;
-    try { local(); }
-    catch (const Error& e) { rc = e.code; msg = e.what(); }
-    catch (const std::exception& e) { rc = LCTY_ERR_RUNTIME; msg = e.what(); }
-    comm->ctx->activate();
+// A rank whose local part failed (a bad read shard, an arena overflow, an allocation, a launch error, a chain that lost its
+// hand-shake ...) must not leave the others inside a data collective for ever: every rank joins this three-word MAX all-reduce
+// unconditionally, with its own status, and all of them raise when any of them failed. `local` runs the rank's part and may throw.
+// EVERYTHING of a rank that can fail between two data collectives belongs in such a lambda. `same` is a number that must be equal
+// on all ranks (a count the next collective is sized with): the words are {status, same, ~same}, so max(same) == ~max(~same) iff
+// every rank brought the same value — a mismatch would otherwise corrupt memory or hang inside RCCL.
+// Test hook: the knob "comm_fail_at" = k makes the k-th agreement (1-based) of the current library call fail on this rank.
+struct AgreeScope {
+    lcty_comm* comm; int64_t fail_at; int64_t step = 0;
+    explicit AgreeScope(lcty_comm* c) : comm(c), fail_at(c->ctx->knob("comm_fail_at", 0)) {}
+    template <typename F>
+    void then(F&& local, uint64_t same = 0) {
+        int32_t rc = LCTY_OK;
+        std::string msg;
+        step++;
+        try {
+            if (fail_at == step) fail(LCTY_ERR_RUNTIME, "rank %d: injected failure at agreement %lld (knob comm_fail_at)", comm->rank, static_cast<long long>(step));
+            local();
+        }
+        catch (const Error& e) { rc = e.code; msg = e.what(); }
+        catch (const std::exception& e) { rc = LCTY_ERR_RUNTIME; msg = e.what(); }
+        comm->ctx->activate();
+        hipStream_t s = comm->ctx->stream;
+        // the status words were allocated with the communicator: nothing here can fail for a reason local to this rank but the
+        // runtime itself
+        const int64_t v = static_cast<int64_t>(same & 0x3FFFFFFFFFFFFFFFull);
+        int64_t words[3] = {rc, v, ~v}, agreed[3] = {rc, v, ~v};
+        comm->d_status.upload(words, 3, s);
+        LCTY_NCCL(ncclAllReduce(comm->d_status.p, comm->d_status.p, 3, ncclInt64, ncclMax, comm->comm, s));
+        comm->d_status.download(agreed, 3, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        if (rc != LCTY_OK) fail(rc, "%s", msg.c_str());
+        if (agreed[0] != LCTY_OK) fail(static_cast<int32_t>(agreed[0]), "rank %d: another rank of the communicator failed with status %d before the exchange", comm->rank, static_cast<int>(agreed[0]));
+        if (agreed[1] != ~agreed[2]) fail(LCTY_ERR_INVALID_INPUT, "rank %d: the ranks of the communicator disagree about a size of the exchange (%lld here)", comm->rank, static_cast<long long>(v));
+    }
+};
+
+// per-chain likelihoods of the blocks of all ranks, gathered on the devices; everything fallible under agreements
+void gather_chain_likelihoods(AgreeScope& A, lcty_comm* comm, const std::vector<double>& local, uint64_t per, uint32_t attempts,
+                              uint64_t n_gt, double* lik_mean, double* lik_var, double* liks_out) {
+    const uint64_t n_ranks = static_cast<uint64_t>(comm->n_ranks);
     hipStream_t s = comm->ctx->stream;
-    comm->d_status.ensure(1);
-    int32_t agreed = rc;
-    comm->d_status.upload(&rc, 1, s);
-    LCTY_NCCL(ncclAllReduce(comm->d_status.p, comm->d_status.p, 1, ncclInt32, ncclMax, comm->comm, s));
-    comm->d_status.download(&agreed, 1, s);
+    DevBuf<double> d_send, d_recv;
+    const uint64_t cnt = per * attempts;
+    A.then([&] {
+        comm->ctx->activate();
+        d_send.alloc(std::max<uint64_t>(cnt, 1));
+        d_recv.alloc(std::max<uint64_t>(cnt, 1) * n_ranks);
+        d_send.upload(local.data(), cnt, s);
+    }, cnt);
+    if (cnt) LCTY_NCCL(ncclAllGather(d_send.p, d_recv.p, cnt, ncclDouble, comm->comm, s));
+    std::vector<double> all(std::max<uint64_t>(cnt, 1) * n_ranks);
+    d_recv.download(all.data(), cnt * n_ranks, s);
     LCTY_HIP(hipStreamSynchronize(s));
-    if (rc != LCTY_OK) fail(rc, "%s", msg.c_str());
-    if (agreed != LCTY_OK) fail(agreed, "rank %d: another rank of the communicator failed with status %d before the exchange", comm->rank, agreed);
+    // rank r's block starts at r * per in the gathered array and at genotype r * per in the list: the same index
+    for (uint64_t g = 0; g < n_gt; g++) {
+        const double* l = all.data() + g * attempts;
+        math::mean_variance_or_nan(l, attempts, &lik_mean[g], &lik_var[g]);
+        if (liks_out) memcpy(liks_out + g * attempts, l, sizeof(double) * attempts);
+    }
 }
 
 }  // namespace
@@ -72,6 +112,7 @@ int32_t lcty_comm_create(lcty_ctx* ctx, int32_t n_ranks, int32_t rank, const uin
         ctx->activate();
         auto c = std::make_unique<lcty_comm>();
         c->ctx = ctx; c->n_ranks = n_ranks; c->rank = rank;
+        c->d_status.alloc(4);
         ncclUniqueId u;
         memcpy(&u, id, sizeof(u));
         LCTY_NCCL(ncclCommInitRank(&c->comm, n_ranks, u, rank));
@@ -85,13 +126,29 @@ void lcty_comm_destroy(lcty_comm* c) {
     delete c;
 }
 
+int32_t lcty_comm_ranks(const lcty_comm* comm, int32_t* n_ranks, int32_t* rank) {
+    return guarded([&] {
+        if (!comm) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        int n = 0, r = 0;
+        LCTY_NCCL(ncclCommCount(comm->comm, &n));
+        LCTY_NCCL(ncclCommUserRank(comm->comm, &r));
+        if (n_ranks) *n_ranks = n;
+        if (rank) *rank = r;
+    });
+}
+
 int32_t lcty_prefilter_allreduce(lcty_reads* reads, lcty_comm* comm) {
     return guarded([&] {
         if (!reads || !comm) fail(LCTY_ERR_INVALID_INPUT, "null argument");
-        if (reads->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
-        if (reads->n_scores == 0) fail(LCTY_ERR_INVALID_INPUT, "lcty_prefilter_async has not been called on this batch");
-        reads->ctx->activate();
-        agree_then(comm, [&] { reads->check_device_error(); });
+        AgreeScope A(comm);
+        // every check that can differ between the ranks sits behind the agreement: a rank whose prefilter never ran, or ran on
+        // another number of genotypes, makes ALL ranks return an error instead of leaving the others in the all-reduce
+        A.then([&] {
+            if (reads->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
+            if (reads->n_scores == 0) fail(LCTY_ERR_INVALID_INPUT, "lcty_prefilter_async has not been called on this batch");
+            reads->ctx->activate();
+            reads->check_device_error();
+        }, reads->n_scores);
         hipStream_t s = reads->ctx->stream;
         // in place, on the stream the prefilter kernels ran on: ordered behind them without a host synchronisation
         LCTY_NCCL(ncclAllReduce(reads->d_scores.p, reads->d_scores.p, reads->n_scores, ncclDouble, ncclSum, comm->comm, s));
@@ -109,35 +166,22 @@ int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint1
                                  double* lik_mean, double* lik_var, double* liks_out) {
     return guarded([&] {
         if (!reads || !comm || !genotypes || !solver || !chain_seeds || !lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
-        if (reads->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
         if (attempts == 0 || ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "attempts and ploidy must be positive");
+        AgreeScope A(comm);
         const uint64_t n_ranks = static_cast<uint64_t>(comm->n_ranks), rank = static_cast<uint64_t>(comm->rank);
         const uint64_t per = (n_gt + n_ranks - 1) / n_ranks;                 // block partition of the stage's genotype list
         const uint64_t lo = std::min(rank * per, n_gt), hi = std::min(lo + per, n_gt);
-        std::vector<double> local(std::max<uint64_t>(per * attempts, 1), std::numeric_limits<double>::quiet_NaN());
-        agree_then(comm, [&] {
+        std::vector<double> local;
+        A.then([&] {
+            if (reads->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
+            local.assign(std::max<uint64_t>(per * attempts, 1), std::numeric_limits<double>::quiet_NaN());
             if (hi <= lo) return;
             std::vector<double> m(hi - lo), v(hi - lo);
             const int32_t rc = lcty_solve_stage(reads, genotypes + lo * ploidy, hi - lo, ploidy, priors ? priors + lo : nullptr, solver,
                                                 attempts, chain_seeds + lo * attempts, m.data(), v.data(), local.data());
             if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
-        });
-        reads->ctx->activate();
-        hipStream_t s = reads->ctx->stream;
-        DevBuf<double> d_send, d_recv;
-        d_send.alloc(std::max<uint64_t>(per * attempts, 1));
-        d_recv.alloc(std::max<uint64_t>(per * attempts, 1) * n_ranks);
-        d_send.upload(local.data(), per * attempts, s);
-        if (per) LCTY_NCCL(ncclAllGather(d_send.p, d_recv.p, per * attempts, ncclDouble, comm->comm, s));
-        std::vector<double> all(std::max<uint64_t>(per * attempts, 1) * n_ranks);
-        d_recv.download(all.data(), per * attempts * n_ranks, s);
-        LCTY_HIP(hipStreamSynchronize(s));
-        // rank r's block starts at r * per in the gathered array and at genotype r * per in the list: the same index
-        for (uint64_t g = 0; g < n_gt; g++) {
-            const double* l = all.data() + g * attempts;
-            math::mean_variance_or_nan(l, attempts, &lik_mean[g], &lik_var[g]);
-            if (liks_out) memcpy(liks_out + g * attempts, l, sizeof(double) * attempts);
-        }
+        }, n_gt * 64 + attempts);
+        gather_chain_likelihoods(A, comm, local, per, attempts, n_gt, lik_mean, lik_var, liks_out);
     });
 }
 
@@ -148,62 +192,61 @@ int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint1
 // further pair-alignments), all-gathered in chunks of rows over RCCL and laid side by side into one table per rank; then the
 // stage's chains are dealt to the ranks in contiguous blocks as in lcty_solve_stage_sharded and their likelihoods all-gathered.
 // The result equals lcty_solve_stage on the unsharded batch bit for bit (the table cells are the same numbers in the same order).
+// Everything a rank does between two collectives — allocations, kernel launches, the plan — runs inside an agreement.
 int32_t lcty_solve_stage_read_sharded(lcty_reads* shard, lcty_comm* comm, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy,
                                       const double* priors, const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                                       double* lik_mean, double* lik_var, double* liks_out) {
     return guarded([&] {
         if (!shard || !comm || !genotypes || !solver || !chain_seeds || !lik_mean || !lik_var) fail(LCTY_ERR_INVALID_INPUT, "null argument");
-        if (shard->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
         if (attempts == 0 || ploidy == 0) fail(LCTY_ERR_INVALID_INPUT, "attempts and ploidy must be positive");
+        AgreeScope A(comm);
         const uint32_t n_ranks = static_cast<uint32_t>(comm->n_ranks), rank = static_cast<uint32_t>(comm->rank);
-        shard->ctx->activate();
-        hipStream_t s = shard->ctx->stream;
+        hipStream_t s = comm->ctx->stream;
         std::unique_ptr<RowGatherer> G;
         uint64_t mine[2] = {0, 0};
-        agree_then(comm, [&] {
+        DevBuf<uint64_t> d_mine, d_all;
+        A.then([&] {
+            if (shard->ctx != comm->ctx) fail(LCTY_ERR_INVALID_INPUT, "the batch and the communicator belong to different contexts");
+            shard->ctx->activate();
             G = std::make_unique<RowGatherer>(shard, genotypes, n_gt, ploidy);
             G->count(shard, rank, &mine[0], &mine[1]);
-        });
+            d_mine.alloc(2); d_all.alloc(2ull * n_ranks);
+            d_mine.upload(mine, 2, s);
+        }, n_gt * 64 + attempts);
         // sizes of every shard
-        DevBuf<uint64_t> d_mine, d_all;
-        d_mine.alloc(2); d_all.alloc(2ull * n_ranks);
-        d_mine.upload(mine, 2, s);
         LCTY_NCCL(ncclAllGather(d_mine.p, d_all.p, 2, ncclUint64, comm->comm, s));
         std::vector<uint64_t> all(2ull * n_ranks), goods(n_ranks), extras(n_ranks);
         d_all.download(all.data(), all.size(), s);
         LCTY_HIP(hipStreamSynchronize(s));
         for (uint32_t r = 0; r < n_ranks; r++) { goods[r] = all[2 * r]; extras[r] = all[2 * r + 1]; }
-        agree_then(comm, [&] { G->plan(goods.data(), extras.data(), n_ranks); });
+        // the plan allocates the staging and the table of this rank; the first chunk is packed under the same agreement, every later
+        // chunk together with the placement of the one before it
+        A.then([&] {
+            G->plan(goods.data(), extras.data(), n_ranks);
+            if (G->n_rows) G->pack_chunk(shard, rank, 0, G->send_cells(), shard->gather.send_pa.p);
+        });
         for (uint32_t row0 = 0; row0 < G->n_rows; row0 += G->rows_per_chunk) {
-            G->pack_chunk(shard, rank, row0, G->send_cells(), shard->gather.send_pa.p);
             LCTY_NCCL(ncclAllGather(G->send_cells(), G->recv_cells(0), G->chunk_cells() * 32, ncclUint8, comm->comm, s));
-            for (uint32_t r = 0; r < n_ranks; r++) G->place_chunk(G->recv_cells(r), r, row0);
+            const uint32_t next = row0 + G->rows_per_chunk;
+            A.then([&] {
+                for (uint32_t r = 0; r < n_ranks; r++) G->place_chunk(G->recv_cells(r), r, row0);
+                if (next < G->n_rows) G->pack_chunk(shard, rank, next, G->send_cells(), shard->gather.send_pa.p);
+            }, G->chunk_cells());
         }
         LCTY_NCCL(ncclAllGather(shard->gather.send_pa.p, shard->gather.pa.p, G->ext_stride * sizeof(PairAlnDev), ncclUint8, comm->comm, s));
-        G->finish();
 
         const uint64_t per = (n_gt + n_ranks - 1) / n_ranks;                 // block partition of the stage's genotype list
-        const uint64_t lo = std::min<uint64_t>(rank * per, n_gt), hi = std::min(lo + per, n_gt);
-        std::vector<double> local(std::max<uint64_t>(per * attempts, 1), std::numeric_limits<double>::quiet_NaN());
-        agree_then(comm, [&] {
+        const uint64_t lo = std::min<uint64_t>(static_cast<uint64_t>(rank) * per, n_gt), hi = std::min(lo + per, n_gt);
+        std::vector<double> local;
+        A.then([&] {
+            G->finish();
+            local.assign(std::max<uint64_t>(per * attempts, 1), std::numeric_limits<double>::quiet_NaN());
             if (hi <= lo) return;
             std::vector<double> m(hi - lo), v(hi - lo);
             solve_stage_gathered(shard, *G, genotypes + lo * ploidy, hi - lo, ploidy, priors ? priors + lo : nullptr, solver, attempts,
                                  chain_seeds + lo * attempts, m.data(), v.data(), local.data());
         });
-        DevBuf<double> d_send, d_recv;
-        d_send.alloc(std::max<uint64_t>(per * attempts, 1));
-        d_recv.alloc(std::max<uint64_t>(per * attempts, 1) * n_ranks);
-        d_send.upload(local.data(), per * attempts, s);
-        if (per) LCTY_NCCL(ncclAllGather(d_send.p, d_recv.p, per * attempts, ncclDouble, comm->comm, s));
-        std::vector<double> liks(std::max<uint64_t>(per * attempts, 1) * n_ranks);
-        d_recv.download(liks.data(), per * attempts * n_ranks, s);
-        LCTY_HIP(hipStreamSynchronize(s));
-        for (uint64_t g = 0; g < n_gt; g++) {
-            const double* l = liks.data() + g * attempts;
-            math::mean_variance_or_nan(l, attempts, &lik_mean[g], &lik_var[g]);
-            if (liks_out) memcpy(liks_out + g * attempts, l, sizeof(double) * attempts);
-        }
+        gather_chain_likelihoods(A, comm, local, per, attempts, n_gt, lik_mean, lik_var, liks_out);
     });
 }
 

@@ -522,19 +522,22 @@ int32_t lcty_bam_read(const char* path, const char* const* names, uint32_t n_all
         if (!path || !names || !out) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         const std::vector<uint8_t> b = inflate_gzip(slurp(path), path);
         size_t i = 0;
-        auto need = [&](size_t n) { if (i + n > b.size()) fail(LCTY_ERR_INVALID_DATA, "%s: truncated BAM", path); };
+        // i <= b.size() always holds; n is compared with what is left, so no sum can wrap (l_text / l_name / block_size are 32-bit
+        // words of the file: 0xFFFFFFFF + 4 must not pass as 3)
+        auto need = [&](uint64_t n) { if (n > b.size() - i) fail(LCTY_ERR_INVALID_DATA, "%s: truncated BAM", path); };
         need(12);
         if (memcmp(&b[0], "BAM\1", 4)) fail(LCTY_ERR_INVALID_DATA, "%s: not a BAM file", path);
         i = 4;
-        const uint32_t l_text = rd32(&b[i]); i += 4; need(l_text + 4); i += l_text;
+        const uint32_t l_text = rd32(&b[i]); i += 4; need(static_cast<uint64_t>(l_text) + 4); i += l_text;
         const uint32_t n_ref = rd32(&b[i]); i += 4;
+        if (n_ref > (b.size() - i) / 8) fail(LCTY_ERR_INVALID_DATA, "%s: truncated BAM (%u references in %llu bytes)", path, n_ref, static_cast<unsigned long long>(b.size() - i));
         std::map<std::string, uint32_t> by_name;
         for (uint32_t a = 0; a < n_alleles; a++) by_name[names[a]] = a;
         std::vector<uint32_t> tid2contig(n_ref);
         for (uint32_t r = 0; r < n_ref; r++) {
-            need(4); const uint32_t l_name = rd32(&b[i]); i += 4; need(l_name + 4);
+            need(4); const uint32_t l_name = rd32(&b[i]); i += 4; need(static_cast<uint64_t>(l_name) + 4);
             const std::string nm(reinterpret_cast<const char*>(&b[i]), l_name ? l_name - 1 : 0);
-            i += l_name + 4;
+            i += static_cast<size_t>(l_name) + 4;
             const auto it = by_name.find(nm);
             if (it == by_name.end()) fail(LCTY_ERR_INVALID_DATA, "Intermediate BAM file contains unexpected contigs (e.g. %s)", nm.c_str());
             tid2contig[r] = it->second;

@@ -590,7 +590,7 @@ void orc_locus_free(orc_locus* l) {
         free(l->infos[a].gc); free(l->infos[a].uniq_cnt); free(l->infos[a].compl_cnt);
     }
     free_explicit(l);
-    free(l->depth_lut); free(l->win_weight_inj); free(l->ci_off_inj); free(l->infos); free(l->seqs); free(l->seq_store); free(l->seq_off); free(l->ins_lut);
+    free(l->depth_lut); free(l->depth_ext_inj); free(l->win_weight_inj); free(l->ci_off_inj); free(l->infos); free(l->seqs); free(l->seq_store); free(l->seq_off); free(l->ins_lut);
     set_free(&l->unique);
     free(l);
 }

@@ -180,6 +180,7 @@ int      orc_locus_set_explicit_weights(orc_locus* l, uint32_t n, const uint32_t
                                         const double* value);
 /* test hook: depth_lut[101*256] and/or win_weight (per position, alleles concatenated) replace the oracle's own tables */
 void     orc_locus_inject_tables(orc_locus* l, const double* depth_lut, const double* win_weight);
+void     orc_locus_inject_depth_table(orc_locus* l, uint32_t width, const double* table);
 /* likelihood of an explicit assignment (recalc_likelihood, assgn.rs:346-354) */
 double   orc_assignment_likelihood(const orc_gt_alns* g, const uint16_t* assgn, double* lik_parts);
 

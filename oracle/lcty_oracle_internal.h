@@ -36,6 +36,7 @@ struct orc_locus {
     double uniq_mult, compl_mult;
     double* depth_lut;      /* [101][256] LinearCache<BayesCalc> values (distr_cache.rs:61-75) */
     double* win_weight_inj; uint64_t* ci_off_inj;   /* test hook: injected per-position window weights */
+    double* depth_ext_inj; uint32_t depth_ext_width; /* test hook: injected BayesCalc::ln_pmf values [101][width] for depths beyond the LinearCache */
     /* ExplicitWeights per allele (model/windows.rs:196-250): len + 1 entries (value, running fixed-point sum) after finish() */
     int has_explicit;
     double** ew_val; uint64_t** ew_cum;

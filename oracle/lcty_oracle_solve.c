@@ -113,6 +113,7 @@ void orc_depth_table(const lcty_bg* bg, const lcty_params* prm, uint32_t lo, uin
 double orc_depth_ln_prob(const orc_locus* l, uint32_t gc, double weight, uint32_t depth) {
     if (weight == 0.0) return 0.0;                 /* WindowDistr::TRIVIAL */
     const double v = depth < LCTY_DEPTH_CACHE ? l->depth_lut[gc * LCTY_DEPTH_CACHE + depth]
+                   : depth < l->depth_ext_width ? l->depth_ext_inj[(size_t)gc * l->depth_ext_width + depth]
                                               : orc_depth_ln_pmf(&l->bg, &l->prm, gc, depth);
     return weight * v;
 }
@@ -777,6 +778,15 @@ void orc_call_checks(const uint16_t* genotypes, uint64_t n, uint32_t ploidy, con
 
 /* Test hook: make the solver consume externally supplied tables (the ones the GPU built), so that oracle and GPU
  * chains see bit-identical inputs and their trajectories can be compared exactly. */
+void orc_locus_inject_depth_table(orc_locus* l, uint32_t width, const double* table) {
+    /* values of BayesCalc::ln_pmf (bayes.rs:27-35) for depths the reference evaluates on the fly: [101][width]; width = 0 removes them */
+    free(l->depth_ext_inj); l->depth_ext_inj = NULL; l->depth_ext_width = 0;
+    if (width && table) {
+        l->depth_ext_inj = (double*)malloc(sizeof(double) * LCTY_GC_BINS * (size_t)width);
+        memcpy(l->depth_ext_inj, table, sizeof(double) * LCTY_GC_BINS * (size_t)width);
+        l->depth_ext_width = width;
+    }
+}
 void orc_locus_inject_tables(orc_locus* l, const double* depth_lut, const double* win_weight) {
     if (depth_lut) memcpy(l->depth_lut, depth_lut, sizeof(double) * LCTY_GC_BINS * LCTY_DEPTH_CACHE);
     if (win_weight) {

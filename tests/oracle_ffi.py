@@ -108,6 +108,7 @@ def lib():
     sig("orc_solver_default", None, C.POINTER(Solver), C.c_int32)
     sig("orc_solve", D, VP, C.POINTER(Solver), U64, VP, VP)
     sig("orc_locus_inject_tables", None, VP, VP, VP)
+    sig("orc_locus_inject_depth_table", None, VP, U32, VP)
     sig("orc_assignment_likelihood", D, VP, VP, VP)
     sig("orc_solve_stage", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP)
     sig("orc_solve_stage_mt", None, VP, VP, VP, U64, U32, VP, C.POINTER(Solver), U32, VP, VP, VP, VP, U32)
@@ -223,6 +224,12 @@ class OracleLocus:
         dl = None if depth_lut is None else np.ascontiguousarray(depth_lut, dtype=np.float64)
         ww = None if win_weight is None else np.ascontiguousarray(win_weight, dtype=np.float64)
         lib().orc_locus_inject_tables(self._h, None if dl is None else dl.ctypes.data, None if ww is None else ww.ctypes.data)
+
+    def inject_depth_table(self, table):
+        """Test hook: BayesCalc::ln_pmf values [101][width] of the GPU's extended depth table for depths beyond the 256 of the LinearCache."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        assert t.ndim == 2 and t.shape[0] == cdefs.GC_BINS
+        lib().orc_locus_inject_depth_table(self._h, t.shape[1], t.ctypes.data)
 
     def load(self, chunk):
         """AllAlignments::load -> OracleAlns (raises ValueError with the error code on invalid data)."""

@@ -471,6 +471,18 @@ def test_full_size_properties(gpu_ctx):
     assert off[-1] == len(counts) and np.all(np.add.reduceat(counts.astype(np.int64), off[:-1].astype(np.int64)) == 3)
     chains, iters, acc = api.solve_stats(full)
     assert chains == 3 and 0 < acc <= iters
+    # the oracle's chains on the very same 1 M read pairs (stoch.rs:81-120, 195-245): it gets the device's tables (the LinearCache, the
+    # values of BayesCalc::ln_pmf beyond it — depths are ~2 000 here —, the window weights) and the scored batch, so that a chain must
+    # follow the same 100 000 iterations / 1 M moves; likelihoods agree to 1e-9 relative (two long sums in another order)
+    off, pa = full.pair_alns()
+    ol.inject_tables(loc.depth_lut(), loc.window_weights())
+    ol.inject_depth_table(loc.depth_table(8192))
+    oa_full = O.alns_from_arrays(A, st, w, unm, off, pa)
+    del pa, off
+    for solver, n_ch in ((greedy, 4), (anneal, 4)):
+        gm, gv, gl = api.solve_stage(full, sub[:n_ch], solver, 1, seeds[:n_ch])
+        om, ov, olk = O.solve_stage(ol, oa_full, sub[:n_ch], solver, 1, seeds[:n_ch], threads=4)
+        assert np.abs(gl - olk).max() <= 1e-9 * np.abs(olk).max(), (solver.kind, gl, olk)
 
 
 # ------------------------------------------------------------------ randomised adversarial pairs
@@ -1061,3 +1073,30 @@ def test_alignment_recovery_of_10kb_reads_against_the_oracle(gpu_ctx):
     # and the recovered table carries the truth: the best genotype of the prefilter is the one the reads were drawn from
     sc = aa.run_filter()
     assert tuple(api.generate_genotypes(n_alleles, 2)[int(np.argmax(sc))]) == L.true_genotype
+
+
+@pytest.mark.gpu
+def test_alignment_recovery_of_10kb_reads_onto_256_alleles(gpu_ctx):
+    """BASELINE.json configs[2] at its allele count: 10-kb single-end ONT reads x 256 alleles, primaries only, so that every read
+    has 255 targets (`best_ixs` is four wavefronts long: the targets of one source go across the lanes in several rounds, the
+    prefix rule of `transfer_fails` = 100 spans rounds; transfer.rs:70-140). Everything after recovery equals the oracle's."""
+    n_alleles, n_reads = 256, 96
+    L = synth.SynthLocus(n_alleles, n_reads, seed=synth.SEED + 9, technology=cdefs.TECH_NANOPORE, read_len=10_000, base_len=30_000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    H = O.HapAlns(n_alleles, transfer_fails=100, max_div=0.1)
+    for q, r, words, nm, ln in L.hap_alns():
+        H.add(q, r, words)
+    H.sort()
+    loc.set_hap_alns(H.entries, transfer_fails=100, max_div=0.1)
+    prim = L.reads(0, n_reads, primaries_only=True)
+    assert int(prim.mate_len.max()) > 9000 and len(prim.recs) <= 2 * n_reads
+    aa = api.AllAlignments.load(loc, prim)
+    n_rec = aa.recover()
+    oa = ol.load_recover(prim, H)
+    compare_gpu_to_oracle(aa, oa, index_fields=())
+    assert n_rec >= 200 * oa.n_good and aa.recover_dp_cells() > 0
+    sc = aa.run_filter()
+    so = O.run_filter(oa.best_aln_matrix(), O.generate_genotypes(n_alleles, 2))
+    assert np.abs(sc - so).max() <= 1e-9 * np.abs(so).max() and int(np.argmax(sc)) == int(np.argmax(so))

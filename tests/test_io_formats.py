@@ -330,6 +330,31 @@ def test_bam_reader_reproduces_the_flat_table(tmp_path):
         assert e.value.code == cdefs.ERR_INVALID_DATA
 
 
+def test_bam_reader_refuses_damaged_headers(tmp_path):
+    """Header words of the file are 32-bit: l_text / l_name / n_ref close to 2^32 must be refused (LCTY_ERR_INVALID_DATA), never
+    wrap past the bounds check."""
+    import struct
+    names = ["a0", "a1"]
+    good = _bam_bytes([("a0", 1000), ("a1", 1000)], [("q", 0, 0, 10, [(20 << 4) | 7], "ACGT" * 5, None)])
+    p = tmp_path / "bad.bam"
+    l_text = struct.unpack_from("<I", good, 4)[0]
+    at_nref = 8 + l_text
+    variants = []
+    for v in (0xFFFFFFFF, 0xFFFFFFFC, 0x7FFFFFFF, len(good)):
+        variants.append(good[:4] + struct.pack("<I", v) + good[8:])                                    # l_text
+        variants.append(good[:at_nref + 4] + struct.pack("<I", v) + good[at_nref + 8:])                # l_name of the first reference
+        variants.append(good[:at_nref] + struct.pack("<I", v) + good[at_nref + 4:])                    # n_ref
+    variants.append(good[:at_nref + 2])                                                                # cut inside n_ref
+    variants.append(good[:10])
+    for raw in variants:
+        p.write_bytes(_bgzf(raw))
+        with pytest.raises(_lib.LocityperError) as e:
+            lio.BamTable(p, names, paired=False)
+        assert e.value.code == cdefs.ERR_INVALID_DATA
+    p.write_bytes(_bgzf(good))
+    assert lio.BamTable(p, names, paired=False).n_pairs == 1
+
+
 def test_paf_reader_keeps_what_process_paf_keeps(tmp_path):
     """haplotypes.paf as command/genotype.rs:1131-1160 + seq/paf.rs read it: which lines become entries (hand-derived), the raw CIGAR
     words, the containers, the errors; a PAF written from the synthetic haplotype alignments comes back as they were."""
