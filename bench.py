@@ -537,7 +537,7 @@ def main():
                    "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
         "reads_scored_per_s": (total_pairs if args.shard_reads else args.pairs if args.shard_chains else args.pairs) * n_break / max(stage_s["score_prefilter"], 1e-9),
         "genotypes_prefiltered_per_s": G * n_break / max(stage_s["score_prefilter"], 1e-9),
-        "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3),
+        "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3) if pref_ms else None,
         "kernel_ms_per_step": {k: r["ms_per_step"] for k, r in roofs.items()} | {"build_loc_table_kernel": ms_tab / kern_steps},
         "solver": None if args.no_solve else {
             "scheme": "greedy:i=5k,a=1 -> anneal:i=20,a=20 -> final comparison",
@@ -551,7 +551,7 @@ def main():
                      "algorithmic_bytes_per_launch": roofs[dominant]["bytes"], "launch_ms": roofs[dominant]["launch_ms"],
                      "what": roofs[dominant]["what"]},
         "roofline_all": roofs,
-        "roofline_score_layout": {"layout_bytes_per_launch": layout_bytes, "achieved_layout_GBs": layout_bytes / (score_ms * 1e-3) / 1e9},
+        "roofline_score_layout": {"layout_bytes_per_launch": layout_bytes, "achieved_layout_GBs": layout_bytes / (score_ms * 1e-3) / 1e9 if score_ms else None},
         "called_genotype": called, "true_genotype": truth, "kept_after_prefilter": kept,
         "setup_s": {"generate_and_upload": gen_s, "locus_create": locus_setup_s},
     }

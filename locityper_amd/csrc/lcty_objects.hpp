@@ -118,7 +118,9 @@ struct lcty_reads {
     bool good_valid = false;
     void ensure_good_index();
     // allele-major location table of the solver stages (lcty_solve.hip), rows of ngp entries
-    lcty::DevBuf<uint8_t> d_loc_table;       // [A][ngp] 32-byte LocEntry cells
+    lcty::DevBuf<uint8_t> d_loc_table;       // [A][ngp] 16-byte LocCell cells
+    lcty::DevBuf<uint32_t> d_loc_ext;        // [A][ngp] arena index of a cell's second pair-alignment
+    lcty::DevBuf<double> d_loc_unm;          // [ngp] "both mates unmapped" probability of every good read pair
     uint64_t ngp = 0;
     bool loc_table_valid = false;
     uint64_t stat_chains = 0, stat_iterations = 0, stat_accepted = 0;   // last lcty_solve_stage
@@ -126,7 +128,8 @@ struct lcty_reads {
     // the location-table rows of a stage's alleles over the reads of EVERY shard of the locus (lcty_solve_stage_read_sharded /
     // lcty_solve_stage_from_shards): kept on the shard that asked, grow-only
     struct RowGatherBufs {
-        lcty::DevBuf<uint8_t> table, send, recv;            // 32-byte cells: [rows][ngp]; one chunk of rows of this shard; of every shard
+        lcty::DevBuf<uint8_t> table, send, recv;            // 16-byte cells [rows][ngp]; 32-byte travelling cells: one chunk of rows of this shard; of every shard
+        lcty::DevBuf<uint32_t> ext; lcty::DevBuf<double> unm; // the side arrays of the gathered table
         lcty::DevBuf<lcty::PairAlnDev> pa, send_pa;         // [shards][ext_stride]; this shard's run
         lcty::DevBuf<uint16_t> alleles, row_of;
         lcty::DevBuf<unsigned long long> counters;          // [shards] extras counted / handed out

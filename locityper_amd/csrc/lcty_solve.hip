@@ -78,6 +78,16 @@ struct __attribute__((aligned(32))) LocEntry {
     uint32_t _pad;
 };
 static_assert(sizeof(LocEntry) == 32, "LocEntry layout");
+// The table the chains stream is LEAN: 16 bytes per (contig, good read) — what every read needs — with the rest in side arrays:
+// `unm` is a property of the read (one f64 per good read, not per cell), `ext` matters only to cells with more than one
+// pair-alignment (a u32 per cell, gathered by the few lanes that need it). solve_init_kernel reads 2 x 16 + 8 B per (chain, read)
+// instead of 2 x 32 B. LocEntry above is the form in which rows TRAVEL between shards (pack_rows_kernel / place_rows_kernel).
+struct __attribute__((aligned(16))) LocCell {
+    double lp;                      // best pair-alignment of the read pair on the contig, -inf = none
+    uint32_t m1n;                   // its first middle (24 bit, MID_NONE24 = unmapped mate) | number of pair-alignments << 24
+    uint32_t m2;                    // its second middle
+};
+static_assert(sizeof(LocCell) == 16, "LocCell layout");
 
 // ChainRec (lcty_common.hpp): one non-trivial read of one chain, all a move can need in one 32-byte gather. Locations in the
 // order of extend_read_gt_alns (windows.rs:793: ln-probability descending, ties in push order); windows after apply_tweak.
@@ -105,7 +115,9 @@ struct SolveView {
     // reads
     uint32_t n_good;
     uint64_t ngp;                   // row stride of the location table (n_good rounded up to 64)
-    const LocEntry* table;          // [A][ngp], or [rows][ngp] with row_of when only the rows of some alleles are held
+    const LocCell* table;           // [A][ngp], or [rows][ngp] with row_of when only the rows of some alleles are held
+    const uint32_t* table_ext;      // same shape: arena index of the second pair-alignment of the cell (cells with more than one)
+    const double* table_unm;        // [ngp] "both mates unmapped" probability of every good read pair
     const uint16_t* row_of;         // allele -> row of `table` (NULL: the allele itself)
     const PairAlnDev* pa;
     // chains
@@ -163,20 +175,26 @@ struct Xoshiro {
 __global__ __launch_bounds__(256) void build_loc_table_kernel(const uint32_t* __restrict__ good_ix, uint32_t n_good, uint64_t ngp,
                                                               uint32_t A, const uint32_t* __restrict__ pa_idx,
                                                               const uint64_t* __restrict__ pa_off, const PairAlnDev* __restrict__ pa,
-                                                              const double* __restrict__ unmapped, LocEntry* __restrict__ table,
+                                                              const double* __restrict__ unmapped, LocCell* __restrict__ table,
+                                                              uint32_t* __restrict__ table_ext, double* __restrict__ table_unm,
                                                               uint32_t* __restrict__ err) {
     // 32 reads x 32 contigs per workgroup: the (pair, contig) index is read along contigs, the table written along reads
-    __shared__ LocEntry tile[32][33];
+    __shared__ LocCell tile[32][33];
+    __shared__ uint32_t tile_ext[32][33];
     const uint32_t g0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
+    if (blockIdx.y == 0 && threadIdx.x < 32) {
+        const uint32_t g = g0 + threadIdx.x;
+        if (g < ngp) table_unm[g] = g < n_good ? unmapped[good_ix[g]] : 0.0;
+    }
     for (uint32_t i = ty; i < 32; i += 8) {
         const uint32_t g = g0 + i, c = c0 + tx;
-        LocEntry e{-INFINITY, MID_NONE24, NONE32S, 0.0, 0u, 0u};
+        LocCell e{-INFINITY, MID_NONE24, NONE32S};
+        uint32_t ext = 0;
         if (g < n_good && c < A) {
             const uint32_t r = good_ix[g];
             const uint32_t idx = pa_idx[static_cast<uint64_t>(r) * A + c];
             const uint32_t cnt = idx >> 24;
-            e.unm = unmapped[r];
             if (cnt) {
                 const uint64_t at = pa_off[r] + (idx & 0xFFFFFFu);
                 const PairAlnDev p = pa[at];
@@ -185,15 +203,15 @@ __global__ __launch_bounds__(256) void build_loc_table_kernel(const uint32_t* __
                 e.lp = p.ln_prob;
                 e.m1n = (p.mid1 == NONE32S ? MID_NONE24 : p.mid1) | (cnt << 24);
                 e.m2 = p.mid2;
-                e.ext = static_cast<uint32_t>(at + 1);
+                ext = static_cast<uint32_t>(at + 1);
             }
         }
-        tile[i][tx] = e;
+        tile[i][tx] = e; tile_ext[i][tx] = ext;
     }
     __syncthreads();
     for (uint32_t j = ty; j < 32; j += 8) {
         const uint32_t c = c0 + j, g = g0 + tx;
-        if (c < A && g < ngp) table[static_cast<uint64_t>(c) * ngp + g] = tile[tx][j];
+        if (c < A && g < ngp) { table[static_cast<uint64_t>(c) * ngp + g] = tile[tx][j]; table_ext[static_cast<uint64_t>(c) * ngp + g] = tile_ext[tx][j]; }
     }
 }
 
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(256) void build_loc_table_kernel(const uint32_t* __
 // per shard the rows are packed — cells of the wanted alleles, the pair-alignments behind the first one of a cell compacted into
 // a run of the shard's own — and then laid side by side, shard after shard, into one table whose cells point into one array of
 // further pair-alignments. `ext` of a packed cell: index into the shard's run.
-__global__ __launch_bounds__(256) void pack_rows_count_kernel(const LocEntry* __restrict__ table, uint64_t ngp, uint32_t n_good,
+__global__ __launch_bounds__(256) void pack_rows_count_kernel(const LocCell* __restrict__ table, uint64_t ngp, uint32_t n_good,
                                                               const uint16_t* __restrict__ alleles, uint32_t n_rows,
                                                               unsigned long long* __restrict__ total) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -214,7 +232,8 @@ __global__ __launch_bounds__(256) void pack_rows_count_kernel(const LocEntry* __
     for (int o = 32; o > 0; o >>= 1) mine += static_cast<uint32_t>(__shfl_xor(static_cast<int>(mine), o));
     if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(total, static_cast<unsigned long long>(mine));
 }
-__global__ __launch_bounds__(256) void pack_rows_kernel(const LocEntry* __restrict__ table, uint64_t ngp, uint32_t n_good,
+__global__ __launch_bounds__(256) void pack_rows_kernel(const LocCell* __restrict__ table, const uint32_t* __restrict__ table_ext,
+                                                        const double* __restrict__ table_unm, uint64_t ngp, uint32_t n_good,
                                                         const uint16_t* __restrict__ alleles, uint32_t n_rows, const PairAlnDev* __restrict__ pa,
                                                         LocEntry* __restrict__ cells, uint64_t out_stride, PairAlnDev* __restrict__ extras,
                                                         unsigned long long* __restrict__ cursor) {
@@ -223,11 +242,14 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const LocEntry* __restri
     const uint32_t u = static_cast<uint32_t>(i / out_stride), g = static_cast<uint32_t>(i % out_stride);
     LocEntry e{-INFINITY, MID_NONE24, NONE32S, 0.0, 0u, 0u};
     if (g < n_good) {
-        e = table[static_cast<uint64_t>(alleles[u]) * ngp + g];
+        const uint64_t at_cell = static_cast<uint64_t>(alleles[u]) * ngp + g;
+        const LocCell c = table[at_cell];
+        e.lp = c.lp; e.m1n = c.m1n; e.m2 = c.m2; e.unm = table_unm[g];
         const uint32_t cnt = e.m1n >> 24;
         if (cnt > 1) {
+            const uint32_t src = table_ext[at_cell];
             const unsigned long long at = atomicAdd(cursor, static_cast<unsigned long long>(cnt - 1));
-            for (uint32_t k = 0; k + 1 < cnt; k++) extras[at + k] = pa[e.ext + k];
+            for (uint32_t k = 0; k + 1 < cnt; k++) extras[at + k] = pa[src + k];
             e.ext = static_cast<uint32_t>(at);
         } else e.ext = 0;
     }
@@ -235,19 +257,26 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const LocEntry* __restri
 }
 // one shard's packed rows into the gathered table: full[u][first + g] = cells[u][g], `ext` moved by where the shard's run starts
 __global__ __launch_bounds__(256) void place_rows_kernel(const LocEntry* __restrict__ cells, uint64_t in_stride, uint32_t n_good, uint32_t n_rows,
-                                                         uint32_t ext_base, LocEntry* __restrict__ full, uint64_t full_stride, uint64_t first) {
+                                                         uint32_t ext_base, LocCell* __restrict__ full, uint32_t* __restrict__ full_ext,
+                                                         double* __restrict__ full_unm, bool write_unm, uint64_t full_stride, uint64_t first) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= static_cast<uint64_t>(n_rows) * n_good) return;
     const uint32_t u = static_cast<uint32_t>(i / n_good), g = static_cast<uint32_t>(i % n_good);
-    LocEntry e = cells[static_cast<uint64_t>(u) * in_stride + g];
-    if ((e.m1n >> 24) > 1) e.ext += ext_base;
-    full[static_cast<uint64_t>(u) * full_stride + first + g] = e;
+    const LocEntry e = cells[static_cast<uint64_t>(u) * in_stride + g];
+    const uint64_t at = static_cast<uint64_t>(u) * full_stride + first + g;
+    full[at] = LocCell{e.lp, e.m1n, e.m2};
+    full_ext[at] = (e.m1n >> 24) > 1 ? e.ext + ext_base : 0u;
+    if (write_unm && u == 0) full_unm[first + g] = e.unm;
 }
-__global__ __launch_bounds__(256) void pad_rows_kernel(LocEntry* __restrict__ full, uint64_t full_stride, uint64_t from, uint32_t n_rows) {
+__global__ __launch_bounds__(256) void pad_rows_kernel(LocCell* __restrict__ full, uint32_t* __restrict__ full_ext, double* __restrict__ full_unm,
+                                                       uint64_t full_stride, uint64_t from, uint32_t n_rows) {
     const uint64_t width = full_stride - from;
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= static_cast<uint64_t>(n_rows) * width) return;
-    full[(i / width) * full_stride + from + i % width] = LocEntry{-INFINITY, MID_NONE24, NONE32S, 0.0, 0u, 0u};
+    const uint64_t at = (i / width) * full_stride + from + i % width;
+    full[at] = LocCell{-INFINITY, MID_NONE24, NONE32S};
+    full_ext[at] = 0u;
+    if (i / width == 0) full_unm[from + i % width] = 0.0;
 }
 
 // BayesCalc::ln_pmf evaluated directly: bayes.rs:27-35 with Ln::map_sum_init (math/mod.rs:80-94)
@@ -318,31 +347,21 @@ struct Locs {
     uint32_t nw;
 };
 
+// from the cells of the genotype's rows (registers), the read's "unmapped" probability and where the cells sit in the table (the
+// `ext` of a cell is fetched only by a lane whose cell holds more than one pair-alignment)
 template <uint32_t P>
-__device__ __forceinline__ void locs_from_cells(Locs<P>& L, const SolveView& V, const LocEntry* cells);
-
-template <uint32_t P>
-__device__ __forceinline__ void locs_init(Locs<P>& L, const SolveView& V, uint32_t g, const Geno<P>& G) {
-    LocEntry cells[P];
-#pragma unroll
-    for (uint32_t p = 0; p < P; p++) cells[p] = V.table[static_cast<uint64_t>(G.row[p]) * V.ngp + g];
-    locs_from_cells<P>(L, V, cells);
-}
-
-// the same from cells that are already at hand (registers or LDS)
-template <uint32_t P>
-__device__ __forceinline__ void locs_from_cells(Locs<P>& L, const SolveView& V, const LocEntry* cells) {
+__device__ __forceinline__ void locs_from_cells(Locs<P>& L, const SolveView& V, const LocCell* cells, double unm, const uint64_t* cell_at) {
     uint32_t raw[P];
     double top = -INFINITY;
+    L.unm = unm;
 #pragma unroll
     for (uint32_t p = 0; p < P; p++) {
-        const LocEntry e = cells[p];
+        const LocCell e = cells[p];
         L.lp[p] = e.lp;
         raw[p] = e.m1n >> 24;
         L.m1[p] = (e.m1n & MID_NONE24) == MID_NONE24 ? NONE32S : (e.m1n & MID_NONE24);
         L.m2[p] = e.m2;
-        L.ext[p] = e.ext;
-        L.unm = e.unm;
+        L.ext[p] = 0;
         top = fmax(top, e.lp);                                              // -inf where the contig has nothing
     }
     top = fmax(top, L.unm);
@@ -351,13 +370,24 @@ __device__ __forceinline__ void locs_from_cells(Locs<P>& L, const SolveView& V, 
 #pragma unroll
     for (uint32_t p = 0; p < P; p++) {
         uint32_t k = (raw[p] && L.lp[p] >= thresh) ? 1u : 0u;
-        if (k && raw[p] > 1)
+        if (k && raw[p] > 1) {
+            L.ext[p] = V.table_ext[cell_at[p]];
             while (k < raw[p] && V.pa[L.ext[p] + k - 1].ln_prob >= thresh) k++;
+        }
         L.n[p] = k;
         L.nw += k;
     }
     L.has_unm = L.unm >= thresh;
     L.nw += L.has_unm;
+}
+
+template <uint32_t P>
+__device__ __forceinline__ void locs_init(Locs<P>& L, const SolveView& V, uint32_t g, const Geno<P>& G) {
+    LocCell cells[P];
+    uint64_t at[P];
+#pragma unroll
+    for (uint32_t p = 0; p < P; p++) { at[p] = static_cast<uint64_t>(G.row[p]) * V.ngp + g; cells[p] = V.table[at[p]]; }
+    locs_from_cells<P>(L, V, cells, V.table_unm[g], at);
 }
 
 struct LocOut {
@@ -459,6 +489,7 @@ __device__ __forceinline__ void block_prefix_excl2(uint32_t va, uint32_t vb, uin
     *ea = ba + ia - va; *eb = bb + ib - vb;
 }
 
+constexpr uint32_t INIT_RPT = 4;              // consecutive reads per thread and block of solve_init_kernel
 template <uint32_t P>
 __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -500,60 +531,100 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     }
     __syncthreads();
 
-    // K13: initial assignment, depth histogram, the records of the non-trivial reads
+    // K13: initial assignment, depth histogram, the records of the non-trivial reads. A thread takes INIT_RPT CONSECUTIVE reads of a
+    // block of 256 * INIT_RPT: its cells of a row are 64 contiguous bytes (a wavefront reads 4 KB of a row at a time), the records it
+    // writes are contiguous too, and the ordered compaction (two barriers) is paid once per 1 024 reads instead of once per 256.
     const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
     double aln_part = 0.0;
     uint32_t nt_total = 0, ex_total = 0;
-    // the table cells of the next 256 reads are requested before this block's are used (the barriers below do not wait for them)
-    LocEntry nxt[P];
-    if (tid < V.n_good) {
+    constexpr uint32_t RPT = INIT_RPT;
+    uint64_t row_at[P];
 #pragma unroll
-        for (uint32_t p = 0; p < P; p++) nxt[p] = V.table[static_cast<uint64_t>(G.row[p]) * V.ngp + tid];
-    }
-    for (uint32_t base = 0; base < V.n_good; base += 256) {
-        const uint32_t rp = base + tid;
-        Locs<P> L; L.nw = 0;
-        uint32_t a0 = 0;
-        LocEntry cur[P];
+    for (uint32_t p = 0; p < P; p++) row_at[p] = static_cast<uint64_t>(G.row[p]) * V.ngp;
+    // the cells of the next block are requested before this block's are used (the barriers below do not wait for them).
+    // ngp is a multiple of 64 and a thread's first read a multiple of RPT: its RPT cells always lie inside the row.
+    LocCell nxt[P][RPT]; double nxt_unm[RPT];
+    auto request = [&](uint32_t base) {
+        const uint32_t r0 = base + tid * RPT;
+        if (r0 < V.n_good) {
 #pragma unroll
-        for (uint32_t p = 0; p < P; p++) cur[p] = nxt[p];
-        if (rp + 256 < V.n_good) {
+            for (uint32_t p = 0; p < P; p++) {
 #pragma unroll
-            for (uint32_t p = 0; p < P; p++) nxt[p] = V.table[static_cast<uint64_t>(G.row[p]) * V.ngp + rp + 256];
+                for (uint32_t k = 0; k < RPT; k++) nxt[p][k] = V.table[row_at[p] + r0 + k];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < RPT; k++) nxt_unm[k] = V.table_unm[r0 + k];
         }
-        if (rp < V.n_good) {
-            locs_from_cells<P>(L, V, cur);
-            if (L.nw > 255) atomicMax(V.overflow, 2u);                           // a record keeps the location in 8 bits
-            if (L.nw > 1 && random_start)
-                a0 = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
+    };
+    request(0);
+    for (uint32_t base = 0; base < V.n_good; base += 256 * RPT) {
+        const uint32_t r0 = base + tid * RPT;
+        LocCell cur[P][RPT]; double cur_unm[RPT];
+#pragma unroll
+        for (uint32_t k = 0; k < RPT; k++) {
+            cur_unm[k] = nxt_unm[k];
+#pragma unroll
+            for (uint32_t p = 0; p < P; p++) cur[p][k] = nxt[p][k];
         }
-        const bool nontrivial = L.nw > 1;
-        const uint32_t n_extra = L.nw > 2 ? min(L.nw, 255u) - 2u : 0u;
+        if (base + 256 * RPT < V.n_good) request(base + 256 * RPT);
+        // pass 1: how many locations, which one first; the thread's share of the two compactions
+        uint32_t nw_k[RPT], a0_k[RPT];
+        uint32_t my_nt = 0, my_ex = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < RPT; k++) {
+            const uint32_t rp = r0 + k;
+            nw_k[k] = 0; a0_k[k] = 0;
+            if (rp < V.n_good) {
+                Locs<P> L;
+                LocCell cells[P]; uint64_t at[P];
+#pragma unroll
+                for (uint32_t p = 0; p < P; p++) { cells[p] = cur[p][k]; at[p] = row_at[p] + rp; }
+                locs_from_cells<P>(L, V, cells, cur_unm[k], at);
+                if (L.nw > 255) atomicMax(V.overflow, 2u);                       // a record keeps the location in 8 bits
+                nw_k[k] = L.nw;
+                if (L.nw > 1 && random_start)
+                    a0_k[k] = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
+                my_nt += L.nw > 1 ? 1u : 0u;
+                my_ex += L.nw > 2 ? min(L.nw, 255u) - 2u : 0u;
+            }
+        }
         // ordered compaction of the non-trivial reads (assgn.rs:61-63) and of their locations beyond the second
         uint32_t chunk_nt, chunk_ex, slot, eix;
-        block_prefix_excl2(nontrivial ? 1u : 0u, n_extra, lane, wave, wave_cnt, &slot, &eix, &chunk_nt, &chunk_ex);
+        block_prefix_excl2(my_nt, my_ex, lane, wave, wave_cnt, &slot, &eix, &chunk_nt, &chunk_ex);
         slot += nt_total; eix += ex_total;
         nt_total += chunk_nt; ex_total += chunk_ex;
-        if (L.nw > 0) {
-            ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = min(L.nw, 255u) | (eix << 8);
-            rec.lp0 = rec.lp1 = 0.0; rec.win0 = rec.win1 = 0;
-            const bool room = eix + n_extra <= V.extra_cap;
-            LocIter<P> it; it.start(L);
-            LocOut o;
-            for (uint32_t t = 0; t < min(L.nw, 255u) && it.next(L, V, o); t++) {
-                uint32_t wa, wb;
-                loc_windows(V, G, o, seed, rp, t, &wa, &wb);
-                const uint32_t win = wa | (wb << 16);
-                if (t == 0) { rec.lp0 = o.lp; rec.win0 = win; }
-                else if (t == 1) { rec.lp1 = o.lp; rec.win1 = win; }
-                else if (room) { ExtraLoc e; e.lp = o.lp; e.win = win; e._pad = 0; extra[eix + t - 2] = e; }
-                if (t == a0) {
-                    atomicAdd(&depth[wa], 1u);
-                    atomicAdd(&depth[wb], 1u);
-                    aln_part += o.lp;
+        // pass 2: the records
+#pragma unroll
+        for (uint32_t k = 0; k < RPT; k++) {
+            const uint32_t rp = r0 + k, nw = nw_k[k], a0 = a0_k[k];
+            if (nw > 0) {
+                Locs<P> L;
+                LocCell cells[P]; uint64_t at[P];
+#pragma unroll
+                for (uint32_t p = 0; p < P; p++) { cells[p] = cur[p][k]; at[p] = row_at[p] + rp; }
+                locs_from_cells<P>(L, V, cells, cur_unm[k], at);
+                const uint32_t n_extra = nw > 2 ? min(nw, 255u) - 2u : 0u;
+                ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = min(nw, 255u) | (eix << 8);
+                rec.lp0 = rec.lp1 = 0.0; rec.win0 = rec.win1 = 0;
+                const bool room = eix + n_extra <= V.extra_cap;
+                LocIter<P> it; it.start(L);
+                LocOut o;
+                for (uint32_t t = 0; t < min(nw, 255u) && it.next(L, V, o); t++) {
+                    uint32_t wa, wb;
+                    loc_windows(V, G, o, seed, rp, t, &wa, &wb);
+                    const uint32_t win = wa | (wb << 16);
+                    if (t == 0) { rec.lp0 = o.lp; rec.win0 = win; }
+                    else if (t == 1) { rec.lp1 = o.lp; rec.win1 = win; }
+                    else if (room) { ExtraLoc e; e.lp = o.lp; e.win = win; e._pad = 0; extra[eix + t - 2] = e; }
+                    if (t == a0) {
+                        atomicAdd(&depth[wa], 1u);
+                        atomicAdd(&depth[wb], 1u);
+                        aln_part += o.lp;
+                    }
                 }
+                if (nw > 1) { recs[slot] = rec; slot++; }
+                eix += n_extra;
             }
-            if (nontrivial) recs[slot] = rec;
         }
     }
     if (ex_total > V.extra_cap) { atomicMax(V.overflow, 4u); atomicMax(V.overflow + 1, ex_total); }
@@ -1543,14 +1614,16 @@ void ensure_solver_tables(lcty_reads* reads) {
     const uint64_t ngp = std::max<uint64_t>(64, (n_good + 63) / 64 * 64);
     const size_t need = static_cast<size_t>(A) * ngp;
     if (n_good >= (1ull << 24)) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles up to 2^24 good read pairs per locus");
-    if (reads->d_loc_table.n < need * sizeof(LocEntry)) reads->d_loc_table.alloc(need * sizeof(LocEntry));
+    if (reads->d_loc_table.n < need * sizeof(LocCell)) reads->d_loc_table.alloc(need * sizeof(LocCell));
+    if (reads->d_loc_ext.n < need) reads->d_loc_ext.alloc(need);
+    if (reads->d_loc_unm.n < ngp) reads->d_loc_unm.alloc(ngp);
     reads->ngp = ngp;
     if (n_good) {
         const dim3 grid(static_cast<uint32_t>(ngp / 32), static_cast<uint32_t>((A + 31) / 32));
         ctx->timed(LCTY_K_SOLVE_TABLE, [&] {
             hipLaunchKernelGGL(build_loc_table_kernel, grid, dim3(256), 0, ctx->stream, reads->d_good_ix.p, static_cast<uint32_t>(n_good), ngp,
                                static_cast<uint32_t>(A), reads->d_pa_idx.p, reads->d_pa_off.p, reads->d_pa.p, reads->d_unmapped.p,
-                               reinterpret_cast<LocEntry*>(reads->d_loc_table.p), reads->d_err.p);
+                               reinterpret_cast<LocCell*>(reads->d_loc_table.p), reads->d_loc_ext.p, reads->d_loc_unm.p, reads->d_err.p);
         });
         LCTY_HIP(hipGetLastError());
         uint32_t flag = 0;
@@ -1691,9 +1764,11 @@ struct StageRunner {
         V.n_wk = tables ? static_cast<uint32_t>(loc->d_wk.n) : 0u; V.n_wc = tables ? static_cast<uint32_t>(loc->d_wc.n) : 0u;
         V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
-        V.table = reinterpret_cast<const LocEntry*>(reads->d_loc_table.p); V.pa = reads->d_pa.p; V.row_of = nullptr;
+        V.table = reinterpret_cast<const LocCell*>(reads->d_loc_table.p); V.table_ext = reads->d_loc_ext.p; V.table_unm = reads->d_loc_unm.p;
+        V.pa = reads->d_pa.p; V.row_of = nullptr;
         if (gathered) {
-            V.table = reinterpret_cast<const LocEntry*>(reads->gather.table.p); V.pa = reads->gather.pa.p; V.row_of = reads->gather.row_of.p;
+            V.table = reinterpret_cast<const LocCell*>(reads->gather.table.p); V.table_ext = reads->gather.ext.p; V.table_unm = reads->gather.unm.p;
+            V.pa = reads->gather.pa.p; V.row_of = reads->gather.row_of.p;
         }
         V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
         V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
@@ -1940,7 +2015,7 @@ void RowGatherer::count(lcty_reads* shard, uint32_t slot, uint64_t* good_out, ui
     const uint64_t n = static_cast<uint64_t>(n_rows) * shard->n_good_cached;
     if (n)
         hipLaunchKernelGGL(pack_rows_count_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<const LocEntry*>(shard->d_loc_table.p), shard->ngp, static_cast<uint32_t>(shard->n_good_cached),
+                           reinterpret_cast<const LocCell*>(shard->d_loc_table.p), shard->ngp, static_cast<uint32_t>(shard->n_good_cached),
                            B.alleles.p, n_rows, B.counters.p + 2 * slot);
     LCTY_HIP(hipGetLastError());
     unsigned long long v = 0;
@@ -1967,11 +2042,11 @@ void RowGatherer::plan(const uint64_t* goods_, const uint64_t* extras, uint32_t 
     auto& B = owner->gather;
     size_t free_b = 0, total_b = 0;
     LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t need = static_cast<uint64_t>(n_rows) * ngp * sizeof(LocEntry);
-    if (B.table.n < need && need > free_b + B.table.n)
+    const uint64_t need = static_cast<uint64_t>(n_rows) * ngp * sizeof(LocCell);
+    if (B.table.n < need && need + need / 4 > free_b + B.table.n)
         fail(LCTY_ERR_RUNTIME, "device memory: the rows of %u alleles over %llu good read pairs (%.1f GB) do not fit", n_rows,
              static_cast<unsigned long long>(n_good), static_cast<double>(need) * 1e-9);
-    B.table.ensure(need);
+    B.table.ensure(need); B.ext.ensure(static_cast<uint64_t>(n_rows) * ngp); B.unm.ensure(ngp);
     B.send.ensure(chunk_cells() * sizeof(LocEntry)); B.recv.ensure(chunk_cells() * n_shards * sizeof(LocEntry));
     B.pa.ensure(ext_stride * n_shards); B.send_pa.ensure(ext_stride);
 }
@@ -1981,8 +2056,8 @@ void RowGatherer::pack_chunk(lcty_reads* shard, uint32_t slot, uint32_t row0, ui
     const uint64_t n = static_cast<uint64_t>(nr) * stride;
     auto& B = owner->gather;
     hipLaunchKernelGGL(pack_rows_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const LocEntry*>(shard->d_loc_table.p), shard->ngp, static_cast<uint32_t>(shard->n_good_cached),
-                       B.alleles.p + row0, nr, shard->d_pa.p, reinterpret_cast<LocEntry*>(cells), stride, run, B.counters.p + 2 * slot + 1);
+                       reinterpret_cast<const LocCell*>(shard->d_loc_table.p), shard->d_loc_ext.p, shard->d_loc_unm.p, shard->ngp,
+                       static_cast<uint32_t>(shard->n_good_cached), B.alleles.p + row0, nr, shard->d_pa.p, reinterpret_cast<LocEntry*>(cells), stride, run, B.counters.p + 2 * slot + 1);
     LCTY_HIP(hipGetLastError());
 }
 
@@ -1992,8 +2067,8 @@ void RowGatherer::place_chunk(const uint8_t* cells, uint32_t shard, uint32_t row
     if (!n) return;
     hipLaunchKernelGGL(place_rows_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const LocEntry*>(cells), stride, static_cast<uint32_t>(goods[shard]), nr,
-                       static_cast<uint32_t>(shard * ext_stride), reinterpret_cast<LocEntry*>(owner->gather.table.p) + static_cast<size_t>(row0) * ngp,
-                       ngp, first[shard]);
+                       static_cast<uint32_t>(shard * ext_stride), reinterpret_cast<LocCell*>(owner->gather.table.p) + static_cast<size_t>(row0) * ngp,
+                       owner->gather.ext.p + static_cast<size_t>(row0) * ngp, owner->gather.unm.p, row0 == 0, ngp, first[shard]);
     LCTY_HIP(hipGetLastError());
 }
 
@@ -2001,7 +2076,7 @@ void RowGatherer::finish() {
     const uint64_t n = static_cast<uint64_t>(n_rows) * (ngp - n_good);
     if (n)
         hipLaunchKernelGGL(pad_rows_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<LocEntry*>(owner->gather.table.p), ngp, n_good, n_rows);
+                           reinterpret_cast<LocCell*>(owner->gather.table.p), owner->gather.ext.p, owner->gather.unm.p, ngp, n_good, n_rows);
     LCTY_HIP(hipGetLastError());
 }
 
