@@ -489,8 +489,41 @@ __device__ __forceinline__ void block_prefix_excl2(uint32_t va, uint32_t vb, uin
     *ea = ba + ia - va; *eb = bb + ib - vb;
 }
 
-constexpr uint32_t INIT_RPT = 4;              // consecutive reads per thread and block of solve_init_kernel
-template <uint32_t P>
+// INIT_RPT (template parameter of solve_init_kernel): reads per thread and block, read base + 256 k + tid for k < INIT_RPT
+// Exclusive prefix sums, in READ order, of two small counts per read over a block of 256 * INIT_RPT reads (sub-block k = the reads
+// base + 256 k + tid): a <= 1 and b <= 253 per read travel in one word (a in 11 bits), one wave scan per sub-block, ONE exchange of
+// the 4 x INIT_RPT wave sums through LDS (two barriers per block). ws: 4 * INIT_RPT words.
+template <uint32_t INIT_RPT>
+__device__ __forceinline__ void block_prefix_multi(const uint32_t (&va)[INIT_RPT], const uint32_t (&vb)[INIT_RPT], uint32_t lane, uint32_t wave,
+                                                   uint32_t* ws, uint32_t (&ea)[INIT_RPT], uint32_t (&eb)[INIT_RPT], uint32_t* total_a, uint32_t* total_b) {
+    uint32_t v[INIT_RPT], inc[INIT_RPT];
+#pragma unroll
+    for (uint32_t k = 0; k < INIT_RPT; k++) {
+        v[k] = va[k] | (vb[k] << 11);
+        uint32_t x = v[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = static_cast<uint32_t>(__shfl_up(static_cast<int>(x), o));
+            if (lane >= static_cast<uint32_t>(o)) x += u;
+        }
+        inc[k] = x;
+        if (lane == 63) ws[k * 4 + wave] = x;
+    }
+    lds_barrier();
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < INIT_RPT; k++) {
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) { const uint32_t w = ws[k * 4 + q]; before = q == wave ? run : before; run += w; }
+        const uint32_t e = before + inc[k] - v[k];
+        ea[k] = e & 0x7FFu; eb[k] = e >> 11;
+    }
+    *total_a = run & 0x7FFu; *total_b = run >> 11;
+    lds_barrier();
+}
+
+template <uint32_t P, uint32_t INIT_RPT>
 __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* depth = reinterpret_cast<uint32_t*>(smem);                          // [wstride]
@@ -531,34 +564,32 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     }
     __syncthreads();
 
-    // K13: initial assignment, depth histogram, the records of the non-trivial reads. A thread takes INIT_RPT CONSECUTIVE reads of a
-    // block of 256 * INIT_RPT: its cells of a row are 64 contiguous bytes (a wavefront reads 4 KB of a row at a time), the records it
-    // writes are contiguous too, and the ordered compaction (two barriers) is paid once per 1 024 reads instead of once per 256.
+    // K13: initial assignment, depth histogram, the records of the non-trivial reads. A block is 256 * INIT_RPT reads; a thread takes
+    // the reads base + 256 k + tid (every load of a wavefront is one contiguous kilobyte of a row), and the ordered compaction (two
+    // barriers) is paid once per 1 024 reads instead of once per 256.
     const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
     double aln_part = 0.0;
     uint32_t nt_total = 0, ex_total = 0;
     constexpr uint32_t RPT = INIT_RPT;
+    uint32_t* wave_sums = reinterpret_cast<uint32_t*>(wave_cnt);                 // [RPT][4]
     uint64_t row_at[P];
 #pragma unroll
     for (uint32_t p = 0; p < P; p++) row_at[p] = static_cast<uint64_t>(G.row[p]) * V.ngp;
-    // the cells of the next block are requested before this block's are used (the barriers below do not wait for them).
-    // ngp is a multiple of 64 and a thread's first read a multiple of RPT: its RPT cells always lie inside the row.
+    // the cells of the next block are requested before this block's are used (the barriers below do not wait for them)
     LocCell nxt[P][RPT]; double nxt_unm[RPT];
     auto request = [&](uint32_t base) {
-        const uint32_t r0 = base + tid * RPT;
-        if (r0 < V.n_good) {
 #pragma unroll
-            for (uint32_t p = 0; p < P; p++) {
+        for (uint32_t k = 0; k < RPT; k++) {
+            const uint32_t rp = base + 256 * k + tid;
+            if (rp < V.n_good) {
 #pragma unroll
-                for (uint32_t k = 0; k < RPT; k++) nxt[p][k] = V.table[row_at[p] + r0 + k];
+                for (uint32_t p = 0; p < P; p++) nxt[p][k] = V.table[row_at[p] + rp];
+                nxt_unm[k] = V.table_unm[rp];
             }
-#pragma unroll
-            for (uint32_t k = 0; k < RPT; k++) nxt_unm[k] = V.table_unm[r0 + k];
         }
     };
     request(0);
     for (uint32_t base = 0; base < V.n_good; base += 256 * RPT) {
-        const uint32_t r0 = base + tid * RPT;
         LocCell cur[P][RPT]; double cur_unm[RPT];
 #pragma unroll
         for (uint32_t k = 0; k < RPT; k++) {
@@ -568,11 +599,10 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
         }
         if (base + 256 * RPT < V.n_good) request(base + 256 * RPT);
         // pass 1: how many locations, which one first; the thread's share of the two compactions
-        uint32_t nw_k[RPT], a0_k[RPT];
-        uint32_t my_nt = 0, my_ex = 0;
+        uint32_t nw_k[RPT], a0_k[RPT], nt_k[RPT], ex_k[RPT];
 #pragma unroll
         for (uint32_t k = 0; k < RPT; k++) {
-            const uint32_t rp = r0 + k;
+            const uint32_t rp = base + 256 * k + tid;
             nw_k[k] = 0; a0_k[k] = 0;
             if (rp < V.n_good) {
                 Locs<P> L;
@@ -584,26 +614,24 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
                 nw_k[k] = L.nw;
                 if (L.nw > 1 && random_start)
                     a0_k[k] = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
-                my_nt += L.nw > 1 ? 1u : 0u;
-                my_ex += L.nw > 2 ? min(L.nw, 255u) - 2u : 0u;
             }
+            nt_k[k] = nw_k[k] > 1 ? 1u : 0u;
+            ex_k[k] = nw_k[k] > 2 ? min(nw_k[k], 255u) - 2u : 0u;
         }
         // ordered compaction of the non-trivial reads (assgn.rs:61-63) and of their locations beyond the second
-        uint32_t chunk_nt, chunk_ex, slot, eix;
-        block_prefix_excl2(my_nt, my_ex, lane, wave, wave_cnt, &slot, &eix, &chunk_nt, &chunk_ex);
-        slot += nt_total; eix += ex_total;
-        nt_total += chunk_nt; ex_total += chunk_ex;
+        uint32_t chunk_nt, chunk_ex, slot_k[RPT], eix_k[RPT];
+        block_prefix_multi<RPT>(nt_k, ex_k, lane, wave, wave_sums, slot_k, eix_k, &chunk_nt, &chunk_ex);
         // pass 2: the records
 #pragma unroll
         for (uint32_t k = 0; k < RPT; k++) {
-            const uint32_t rp = r0 + k, nw = nw_k[k], a0 = a0_k[k];
+            const uint32_t rp = base + 256 * k + tid, nw = nw_k[k], a0 = a0_k[k];
             if (nw > 0) {
                 Locs<P> L;
                 LocCell cells[P]; uint64_t at[P];
 #pragma unroll
                 for (uint32_t p = 0; p < P; p++) { cells[p] = cur[p][k]; at[p] = row_at[p] + rp; }
                 locs_from_cells<P>(L, V, cells, cur_unm[k], at);
-                const uint32_t n_extra = nw > 2 ? min(nw, 255u) - 2u : 0u;
+                const uint32_t n_extra = ex_k[k], slot = nt_total + slot_k[k], eix = ex_total + eix_k[k];
                 ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = min(nw, 255u) | (eix << 8);
                 rec.lp0 = rec.lp1 = 0.0; rec.win0 = rec.win1 = 0;
                 const bool room = eix + n_extra <= V.extra_cap;
@@ -622,10 +650,10 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
                         aln_part += o.lp;
                     }
                 }
-                if (nw > 1) { recs[slot] = rec; slot++; }
-                eix += n_extra;
+                if (nw > 1) recs[slot] = rec;
             }
         }
+        nt_total += chunk_nt; ex_total += chunk_ex;
     }
     if (ex_total > V.extra_cap) { atomicMax(V.overflow, 4u); atomicMax(V.overflow + 1, ex_total); }
     if (ex_total >= (1u << 24)) atomicMax(V.overflow, 2u);
@@ -638,6 +666,15 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     uint32_t* gdepth = V.c_depth + static_cast<uint64_t>(chain) * V.wstride;
     for (uint32_t w = tid; w < G.total_w; w += 256) gdepth[w] = depth[w];
     if (tid == 0) { V.c_aln[chain] = red[0]; V.c_nnt[chain] = nt_total; V.c_totw[chain] = G.total_w; }
+}
+
+// two windows of one location (see Chain::request_pair)
+struct PairGather { int32_t c[2]; uint32_t dmax[2]; double weight[2], vnew[2], vold[2]; };
+// the four terms of depth_lik_diff in its order of summation, ((t1 + t2) + t3) + t4, from the two halves; *deepest: the deepest live window
+__device__ __forceinline__ double pair_term(const PairGather& g, int i, uint32_t* deepest) {
+    const bool live = g.c[i] != 0 && g.weight[i] != 0.0;                     // c == 0: no change; weight 0: WindowDistr::TRIVIAL
+    *deepest = max(*deepest, live ? g.dmax[i] : 0u);
+    return live ? g.weight[i] * g.vnew[i] - g.weight[i] * g.vold[i] : 0.0;
 }
 
 // window state of one chain: depth (25 bit) | GC bin << 25 in LDS, weights in the chain's row of c_ww (L2)
@@ -699,6 +736,28 @@ struct Chain {
         DepthGather g;
         request(w1, w2, w3, w4, g);
         return finish(g);
+    }
+    // depth_lik_diff in two halves of two windows: the current location's pair (w1, w2: depths go down) is the same for every
+    // alternative location of a read, so the greedy loop requests it once and each alternative's pair (w3, w4: depths go up) once.
+    // Inside a pair the coincidence rule of assgn.rs:259-284 is applied as written (w2 == w1: -2 / 0; w4 == w3: +2 / 0); a window
+    // shared BETWEEN the pairs changes both halves — the caller detects that (rare) and takes depth_lik_diff instead.
+    __device__ __forceinline__ void request_pair(uint32_t wa, uint32_t wb, int32_t dir, PairGather& g) const {
+        const int32_t same = wb == wa;
+        g.c[0] = dir * (1 + same); g.c[1] = same ? 0 : dir;
+        const uint32_t w[2] = {wa, wb};
+        uint32_t word[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) word[i] = wd[w[i]];
+        const uint32_t last = V->lut_depth - 1;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t d_old = word[i] & DEPTH_MASK, row = (word[i] >> 25) << V->lut_shift;
+            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
+            g.weight[i] = ww[w[i]];
+            g.vnew[i] = V->lut[row + min(d_new, last)];
+            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.dmax[i] = max(d_new, d_old);
+        }
     }
 };
 
@@ -762,6 +821,26 @@ struct ChainLW {
         DepthGather g;
         request(w1, w2, w3, w4, g);
         return finish(g);
+    }
+    // see Chain::request_pair
+    __device__ __forceinline__ void request_pair(uint32_t wa, uint32_t wb, int32_t dir, PairGather& g) const {
+        const int32_t same = wb == wa;
+        g.c[0] = dir * (1 + same); g.c[1] = same ? 0 : dir;
+        const uint32_t w[2] = {wa, wb};
+        uint32_t word[2], half[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) { word[i] = wd[w[i]]; half[i] = wh[w[i]]; }
+        const uint32_t last = V->lut_depth - 1;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
+            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
+            g.vnew[i] = V->lut[row + min(d_new, last)];
+            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.dmax[i] = max(d_new, d_old);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) g.weight[i] = weight_of(word[i], half[i]);
     }
 };
 
@@ -1040,19 +1119,24 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 asm volatile("" : "+v"(cur_lp), "+v"(cur_w));                     // the wait for this load stays inside the rare branch
             }
             const uint32_t w1 = cur_w & 0xFFFFu, w2 = cur_w >> 16;
-            // up to three alternatives per lane, all requested before any is used
+            // up to three alternatives per lane, all requested before any is used. The pair of the current location is the same
+            // for all of them: requested once; an alternative adds the pair of its own two windows.
             constexpr uint32_t NA = GREEDY_INLINE_LOCS - 1;
             double lp_t[NA]; uint32_t win_t[NA], t_of[NA];
-            typename ChainT::DepthGather g[NA];
+            PairGather gc, ga[NA];
+            bool cross[NA];
+            C.request_pair(w1, w2, -1, gc);
 #pragma unroll
             for (uint32_t u = 0; u < NA; u++) {
                 const bool has = u < n_alt && !(deep && u + (u >= cur ? 1u : 0u) >= GREEDY_INLINE_LOCS);
                 t_of[u] = u + (u >= cur ? 1u : 0u);
-                lp_t[u] = 0.0; win_t[u] = 0;
+                lp_t[u] = 0.0; win_t[u] = 0; cross[u] = false;
                 if (u == 0 || __any(has)) {
                     if (has) cand_loc(b, EA, t_of[u], &lp_t[u], &win_t[u]);
-                    const bool on = has;
-                    C.request(on ? w1 : 0u, on ? w2 : 0u, on ? (win_t[u] & 0xFFFFu) : 0u, on ? (win_t[u] >> 16) : 0u, g[u]);
+                    const uint32_t a3 = has ? (win_t[u] & 0xFFFFu) : 0u, a4 = has ? (win_t[u] >> 16) : 0u;
+                    C.request_pair(a3, a4, 1, ga[u]);
+                    // a window shared between the two pairs (windows 0 and 1 carry no distribution: sharing them changes nothing)
+                    cross[u] = has && ((a3 > 1 && (a3 == w1 || a3 == w2)) || (a4 > 1 && (a4 == w1 || a4 == w2)));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1063,17 +1147,25 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             // best_read_improvement (assgn.rs:287-317): the alternatives in order, a later one only when strictly better
             double best_improv = -INFINITY, lp_new = 0.0, ddiff = 0.0;
             uint32_t new_assgn = 0, w3 = 0, w4 = 0;
+            uint32_t deepest = 0;
+            const double t1 = pair_term(gc, 0, &deepest);
+            const double t12 = t1 + pair_term(gc, 1, &deepest);
 #pragma unroll
             for (uint32_t u = 0; u < NA; u++) {
                 const bool has = u < n_alt && !(deep && t_of[u] >= GREEDY_INLINE_LOCS);
                 if (u == 0 || __any(has)) {
-                    const double dd = C.finish(g[u]);
+                    const double t3 = pair_term(ga[u], 0, &deepest);
+                    double dd = (t12 + t3) + pair_term(ga[u], 1, &deepest);
+                    if (__any(cross[u])) {
+                        if (cross[u]) dd = C.depth_lik_diff(w1, w2, win_t[u] & 0xFFFFu, win_t[u] >> 16);
+                    }
                     const double improv = lp_t[u] + rel_contrib * dd;
                     if (has && (u == 0 || improv > best_improv)) {
                         best_improv = improv; new_assgn = t_of[u]; w3 = win_t[u] & 0xFFFFu; w4 = win_t[u] >> 16; lp_new = lp_t[u]; ddiff = dd;
                     }
                 }
             }
+            if (deepest > V.lut_depth - 1) atomicMax(V.overflow, 1u);            // every chain of the batch is repeated
             if (__any(deep)) {
                 // reads with more than four locations: the ones beyond the fourth from the chain's run, one at a time, in their place
                 // in the order (a read's alternatives are visited by ascending location; those in registers may come after these
@@ -1657,13 +1749,22 @@ __global__ void pause_kernel(uint32_t rounds) {
     for (uint32_t i = 0; i < rounds; i++) __builtin_amdgcn_s_sleep(127);
 }
 
+template <uint32_t P, uint32_t RPT>
+void launch_init_as(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s) {
+    if (lds_init > 48 * 1024)
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P, RPT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds_init)));
+    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL((solve_init_kernel<P, RPT>), dim3(nch), dim3(256), lds_init, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
+}
 template <uint32_t P>
 void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s) {
-    if (lds_init > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds_init)));
-    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); }, s);
-    LCTY_HIP(hipGetLastError());
+    // reads per thread and block (lcty_ctx_set_knob "solve_init_rpt": 1, 2, 4): more reads per exchange mean fewer barriers and more
+    // registers (fewer wavefronts in flight to keep the streams of cells and records going)
+    const int64_t rpt = ctx->knob("solve_init_rpt", 1);      // measured at 1 M x 256: 116 / 119 / 169 ms for 1 / 2 / 4
+    if (rpt >= 4 && P <= 2) launch_init_as<P, 4>(ctx, V, nch, lds_init, s);
+    else if (rpt >= 2 && P <= 2) launch_init_as<P, 2>(ctx, V, nch, lds_init, s);
+    else launch_init_as<P, 1>(ctx, V, nch, lds_init, s);
 }
 
 // LDS of a greedy workgroup: the rows' windows (4 bytes each; 6 with the weights in LDS, plus the two weight tables)

@@ -56,11 +56,11 @@ def test_every_agreement_of_every_exchange_can_fail_with_one_rank(gpu_ctx):
         gpu_ctx.set_knob("comm_fail_at", -1)
         gpu_ctx.set_knob("gather_chunk_mb", -1)
     assert np.array_equal(aa.prefilter_scores(), scores)
-    assert n_agreements["allreduce"] == 1 and n_agreements["chains"] == 2 and n_agreements["reads"] >= 6, n_agreements
+    assert n_agreements["allreduce"] == 1 and n_agreements["chains"] == 2 and n_agreements["reads"] >= 5, n_agreements
     comm.close()
 
 
-@pytest.mark.parametrize("call,n_points", [("allreduce", 1), ("chains", 2), ("reads", 6)])
+@pytest.mark.parametrize("call,n_points", [("allreduce", 1), ("chains", 2), ("reads", 5)])
 def test_a_failing_rank_releases_the_other_rank(tmp_path, call, n_points):
     if api.device_count() < 2:
         pytest.skip("RCCL refuses two ranks on one device: this part needs two GPUs")
