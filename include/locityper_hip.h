@@ -208,7 +208,6 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  *       levels, arenas;
  *   "depth_table_start"   first width of the extended depth table;   "solve_budget_mb"   device memory for the per-chain state of a
  *       solver stage;   "solve_extra_start"   first size of a chain's run of locations beyond the second;
- *   "solve_init_rpt"   1, 2, 4: reads per thread and exchange of the chain initialisation (diploid and haploid genotypes);
  *   "solve_chains_per_wave"   1, 2, 4, 5, 6 chains of the greedy loop per wavefront;   "solve_lds_weights"   0: the greedy loop gathers
  *       the window weights, 1 (default where the locus has the weight tables): table indices + tables in LDS;
  *   "anneal_lds_weights"   0 gathered, 1 in LDS as they are, 2 (default where possible) table indices + tables in LDS;

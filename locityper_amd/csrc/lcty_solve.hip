@@ -126,7 +126,10 @@ struct SolveView {
     const uint64_t* seeds;          // [n_chains]
     const double* priors;           // [n_gt] or null
     lcty_solver solver;
-    ChainRec* recs;                 // [n_chains][ngp] the chain's non-trivial reads in read order; trivial reads never move
+    ChainRec* recs;                 // [n_chains][rstride] the chain's non-trivial reads in read order, in INIT_SEGS segments (RecList)
+    uint32_t seg_reads;             // reads (and record places) per segment; rstride = INIT_SEGS * seg_reads >= n_good
+    uint64_t rstride;
+    uint32_t* c_seg;                // [n_chains][4] non-trivial reads in front of segment 0..3 (c_seg[.][0] = 0)
     ExtraLoc* extra;                // [n_chains][extra_cap] locations 2.. of reads with more than two
     uint32_t extra_cap;
     uint32_t* c_totw;               // [n_chains] windows of the chain's genotype (2 + sum of n_windows)
@@ -169,6 +172,23 @@ struct Xoshiro {
     }
     __device__ __forceinline__ uint64_t below(uint64_t n) { return __umul64hi(next(), n); }
     __device__ __forceinline__ double f64() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+// The ordered list of a chain's non-trivial reads (assgn.rs:61-63), as solve_init_kernel leaves it: the reads of the locus are cut
+// into INIT_SEGS contiguous ranges, one per wavefront of the initialisation, and every wavefront compacts ITS range into ITS part
+// of the chain's record array (part k starts at k * seg_reads) — no exchange between the wavefronts, no barrier per block of
+// reads. The list in read order is the parts one after the other: entry s is record s - cum[k] of part k, where k is the part
+// with cum[k] <= s < cum[k + 1]. cum: four words (cum[0] = 0) in LDS or global memory.
+constexpr uint32_t INIT_SEGS = 4;
+struct RecList {
+    ChainRec* base; const uint32_t* cum; uint32_t seg_reads;
+    __device__ __forceinline__ uint32_t place(uint32_t s) const {
+        const uint32_t c1 = cum[1], c2 = cum[2], c3 = cum[3];
+        const uint32_t k = (s >= c1 ? 1u : 0u) + (s >= c2 ? 1u : 0u) + (s >= c3 ? 1u : 0u);
+        const uint32_t before = s >= c3 ? c3 : s >= c2 ? c2 : s >= c1 ? c1 : 0u;
+        return s - before + k * seg_reads;
+    }
+    __device__ __forceinline__ ChainRec& operator[](uint32_t s) const { return base[place(s)]; }
 };
 
 // ---- K11 input: allele-major location table ----
@@ -489,52 +509,18 @@ __device__ __forceinline__ void block_prefix_excl2(uint32_t va, uint32_t vb, uin
     *ea = ba + ia - va; *eb = bb + ib - vb;
 }
 
-// INIT_RPT (template parameter of solve_init_kernel): reads per thread and block, read base + 256 k + tid for k < INIT_RPT
-// Exclusive prefix sums, in READ order, of two small counts per read over a block of 256 * INIT_RPT reads (sub-block k = the reads
-// base + 256 k + tid): a <= 1 and b <= 253 per read travel in one word (a in 11 bits), one wave scan per sub-block, ONE exchange of
-// the 4 x INIT_RPT wave sums through LDS (two barriers per block). ws: 4 * INIT_RPT words.
-template <uint32_t INIT_RPT>
-__device__ __forceinline__ void block_prefix_multi(const uint32_t (&va)[INIT_RPT], const uint32_t (&vb)[INIT_RPT], uint32_t lane, uint32_t wave,
-                                                   uint32_t* ws, uint32_t (&ea)[INIT_RPT], uint32_t (&eb)[INIT_RPT], uint32_t* total_a, uint32_t* total_b) {
-    uint32_t v[INIT_RPT], inc[INIT_RPT];
-#pragma unroll
-    for (uint32_t k = 0; k < INIT_RPT; k++) {
-        v[k] = va[k] | (vb[k] << 11);
-        uint32_t x = v[k];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = static_cast<uint32_t>(__shfl_up(static_cast<int>(x), o));
-            if (lane >= static_cast<uint32_t>(o)) x += u;
-        }
-        inc[k] = x;
-        if (lane == 63) ws[k * 4 + wave] = x;
-    }
-    lds_barrier();
-    uint32_t run = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < INIT_RPT; k++) {
-        uint32_t before = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) { const uint32_t w = ws[k * 4 + q]; before = q == wave ? run : before; run += w; }
-        const uint32_t e = before + inc[k] - v[k];
-        ea[k] = e & 0x7FFu; eb[k] = e >> 11;
-    }
-    *total_a = run & 0x7FFu; *total_b = run >> 11;
-    lds_barrier();
-}
-
-template <uint32_t P, uint32_t INIT_RPT>
+template <uint32_t P>
 __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* depth = reinterpret_cast<uint32_t*>(smem);                          // [wstride]
     double* red = reinterpret_cast<double*>(smem + ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)));   // [256]
-    uint2* wave_cnt = reinterpret_cast<uint2*>(red + 256);                        // [4]
+    uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(red + 256);                   // [4] records of every segment, [4] = further locations handed out
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = V.seeds[chain];
     Geno<P> G; G.init(V, gi);
-    ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
+    ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.rstride + static_cast<uint64_t>(wave) * V.seg_reads;     // this wavefront's part
     ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
     double* ww = V.c_ww + static_cast<uint64_t>(chain) * V.wstride;
     uint8_t* wgc = V.c_gc + static_cast<uint64_t>(chain) * V.wstride;
@@ -543,6 +529,7 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     // K12: window distributions (apply_tweak, assgn.rs:140-150)
     for (uint32_t w = tid; w < G.total_w; w += 256) {
         depth[w] = 0;
+        if (w == 0) seg_cnt[4] = 0;
         double weight = 0.0; uint32_t g = 0, uc = V.n_wk - 1;                      // windows 0 and 1 (unmapped / out of region): trivial
         if (w >= 2) {
             uint32_t allele = G.id[0], sh = G.shift[0], rs = G.reg_start[0];
@@ -564,108 +551,95 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     }
     __syncthreads();
 
-    // K13: initial assignment, depth histogram, the records of the non-trivial reads. A block is 256 * INIT_RPT reads; a thread takes
-    // the reads base + 256 k + tid (every load of a wavefront is one contiguous kilobyte of a row), and the ordered compaction (two
-    // barriers) is paid once per 1 024 reads instead of once per 256.
+    // K13: initial assignment, depth histogram, the records of the non-trivial reads. The wavefronts of the workgroup do not talk to
+    // each other here: wavefront k takes the k-th contiguous range of the locus' reads (seg_reads of them) and compacts its non-trivial
+    // ones, in read order, into the k-th part of the chain's record array (RecList): a ballot and a population count per 64 reads
+    // instead of a workgroup prefix sum behind two barriers per 256 (those exchanges were 23 of the kernel's 116 ms).
+    // Further locations (beyond a read's second) come out of one run per chain through an LDS counter: where in the run they sit
+    // is nobody's business but the record's.
     const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
     double aln_part = 0.0;
-    uint32_t nt_total = 0, ex_total = 0;
-    constexpr uint32_t RPT = INIT_RPT;
-    uint32_t* wave_sums = reinterpret_cast<uint32_t*>(wave_cnt);                 // [RPT][4]
+    uint32_t n_recs = 0;
     uint64_t row_at[P];
 #pragma unroll
     for (uint32_t p = 0; p < P; p++) row_at[p] = static_cast<uint64_t>(G.row[p]) * V.ngp;
-    // the cells of the next block are requested before this block's are used (the barriers below do not wait for them)
-    LocCell nxt[P][RPT]; double nxt_unm[RPT];
-    auto request = [&](uint32_t base) {
+    const uint32_t seg_lo = min(wave * V.seg_reads, V.n_good), seg_hi = min(seg_lo + V.seg_reads, V.n_good);
+    // the cells of the next 64 reads are requested before this block's are used
+    LocCell nxt[P]; double nxt_unm = 0.0;
+    if (seg_lo + lane < seg_hi) {
 #pragma unroll
-        for (uint32_t k = 0; k < RPT; k++) {
-            const uint32_t rp = base + 256 * k + tid;
-            if (rp < V.n_good) {
-#pragma unroll
-                for (uint32_t p = 0; p < P; p++) nxt[p][k] = V.table[row_at[p] + rp];
-                nxt_unm[k] = V.table_unm[rp];
-            }
-        }
-    };
-    request(0);
-    for (uint32_t base = 0; base < V.n_good; base += 256 * RPT) {
-        LocCell cur[P][RPT]; double cur_unm[RPT];
-#pragma unroll
-        for (uint32_t k = 0; k < RPT; k++) {
-            cur_unm[k] = nxt_unm[k];
-#pragma unroll
-            for (uint32_t p = 0; p < P; p++) cur[p][k] = nxt[p][k];
-        }
-        if (base + 256 * RPT < V.n_good) request(base + 256 * RPT);
-        // pass 1: how many locations, which one first; the thread's share of the two compactions
-        uint32_t nw_k[RPT], a0_k[RPT], nt_k[RPT], ex_k[RPT];
-#pragma unroll
-        for (uint32_t k = 0; k < RPT; k++) {
-            const uint32_t rp = base + 256 * k + tid;
-            nw_k[k] = 0; a0_k[k] = 0;
-            if (rp < V.n_good) {
-                Locs<P> L;
-                LocCell cells[P]; uint64_t at[P];
-#pragma unroll
-                for (uint32_t p = 0; p < P; p++) { cells[p] = cur[p][k]; at[p] = row_at[p] + rp; }
-                locs_from_cells<P>(L, V, cells, cur_unm[k], at);
-                if (L.nw > 255) atomicMax(V.overflow, 2u);                       // a record keeps the location in 8 bits
-                nw_k[k] = L.nw;
-                if (L.nw > 1 && random_start)
-                    a0_k[k] = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
-            }
-            nt_k[k] = nw_k[k] > 1 ? 1u : 0u;
-            ex_k[k] = nw_k[k] > 2 ? min(nw_k[k], 255u) - 2u : 0u;
-        }
-        // ordered compaction of the non-trivial reads (assgn.rs:61-63) and of their locations beyond the second
-        uint32_t chunk_nt, chunk_ex, slot_k[RPT], eix_k[RPT];
-        block_prefix_multi<RPT>(nt_k, ex_k, lane, wave, wave_sums, slot_k, eix_k, &chunk_nt, &chunk_ex);
-        // pass 2: the records
-#pragma unroll
-        for (uint32_t k = 0; k < RPT; k++) {
-            const uint32_t rp = base + 256 * k + tid, nw = nw_k[k], a0 = a0_k[k];
-            if (nw > 0) {
-                Locs<P> L;
-                LocCell cells[P]; uint64_t at[P];
-#pragma unroll
-                for (uint32_t p = 0; p < P; p++) { cells[p] = cur[p][k]; at[p] = row_at[p] + rp; }
-                locs_from_cells<P>(L, V, cells, cur_unm[k], at);
-                const uint32_t n_extra = ex_k[k], slot = nt_total + slot_k[k], eix = ex_total + eix_k[k];
-                ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = min(nw, 255u) | (eix << 8);
-                rec.lp0 = rec.lp1 = 0.0; rec.win0 = rec.win1 = 0;
-                const bool room = eix + n_extra <= V.extra_cap;
-                LocIter<P> it; it.start(L);
-                LocOut o;
-                for (uint32_t t = 0; t < min(nw, 255u) && it.next(L, V, o); t++) {
-                    uint32_t wa, wb;
-                    loc_windows(V, G, o, seed, rp, t, &wa, &wb);
-                    const uint32_t win = wa | (wb << 16);
-                    if (t == 0) { rec.lp0 = o.lp; rec.win0 = win; }
-                    else if (t == 1) { rec.lp1 = o.lp; rec.win1 = win; }
-                    else if (room) { ExtraLoc e; e.lp = o.lp; e.win = win; e._pad = 0; extra[eix + t - 2] = e; }
-                    if (t == a0) {
-                        atomicAdd(&depth[wa], 1u);
-                        atomicAdd(&depth[wb], 1u);
-                        aln_part += o.lp;
-                    }
-                }
-                if (nw > 1) recs[slot] = rec;
-            }
-        }
-        nt_total += chunk_nt; ex_total += chunk_ex;
+        for (uint32_t p = 0; p < P; p++) nxt[p] = V.table[row_at[p] + seg_lo + lane];
+        nxt_unm = V.table_unm[seg_lo + lane];
     }
-    if (ex_total > V.extra_cap) { atomicMax(V.overflow, 4u); atomicMax(V.overflow + 1, ex_total); }
-    if (ex_total >= (1u << 24)) atomicMax(V.overflow, 2u);
+    for (uint32_t base = seg_lo; base < seg_hi; base += 64) {
+        const uint32_t rp = base + lane;
+        LocCell cur[P]; uint64_t at[P];
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) { cur[p] = nxt[p]; at[p] = row_at[p] + rp; }
+        const double cur_unm = nxt_unm;
+        if (rp + 64 < seg_hi) {
+#pragma unroll
+            for (uint32_t p = 0; p < P; p++) nxt[p] = V.table[row_at[p] + rp + 64];
+            nxt_unm = V.table_unm[rp + 64];
+        }
+        Locs<P> L; L.nw = 0;
+        uint32_t a0 = 0;
+        if (rp < seg_hi) {
+            locs_from_cells<P>(L, V, cur, cur_unm, at);
+            if (L.nw > 255) atomicMax(V.overflow, 2u);                           // a record keeps the location in 8 bits
+            if (L.nw > 1 && random_start)
+                a0 = static_cast<uint32_t>(__umul64hi(counter_u64(seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
+        }
+        const bool nontrivial = L.nw > 1;
+        const uint32_t n_extra = L.nw > 2 ? min(L.nw, 255u) - 2u : 0u;
+        // ordered compaction of the non-trivial reads of this range (assgn.rs:61-63)
+        const unsigned long long nt_mask = __ballot(nontrivial);
+        const uint32_t slot = n_recs + static_cast<uint32_t>(__popcll(nt_mask & ((1ull << lane) - 1ull)));
+        n_recs += static_cast<uint32_t>(__popcll(nt_mask));
+        if (L.nw > 0) {
+            uint32_t eix = 0;
+            if (n_extra) eix = atomicAdd(&seg_cnt[4], n_extra);
+            ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = min(L.nw, 255u) | (eix << 8);
+            rec.lp0 = rec.lp1 = 0.0; rec.win0 = rec.win1 = 0;
+            const bool room = static_cast<uint64_t>(eix) + n_extra <= V.extra_cap;
+            LocIter<P> it; it.start(L);
+            LocOut o;
+            for (uint32_t t = 0; t < min(L.nw, 255u) && it.next(L, V, o); t++) {
+                uint32_t wa, wb;
+                loc_windows(V, G, o, seed, rp, t, &wa, &wb);
+                const uint32_t win = wa | (wb << 16);
+                if (t == 0) { rec.lp0 = o.lp; rec.win0 = win; }
+                else if (t == 1) { rec.lp1 = o.lp; rec.win1 = win; }
+                else if (room) { ExtraLoc e; e.lp = o.lp; e.win = win; e._pad = 0; extra[eix + t - 2] = e; }
+                if (t == a0) {
+                    atomicAdd(&depth[wa], 1u);
+                    atomicAdd(&depth[wb], 1u);
+                    aln_part += o.lp;
+                }
+            }
+            if (nontrivial) recs[slot] = rec;
+        }
+    }
+    if (lane == 0) seg_cnt[wave] = n_recs;
     red[tid] = aln_part;
     __syncthreads();
+    const uint32_t ex_total = seg_cnt[4];
+    if (tid == 0) {
+        if (ex_total > V.extra_cap) { atomicMax(V.overflow, 4u); atomicMax(V.overflow + 1, ex_total); }
+        if (ex_total >= (1u << 24)) atomicMax(V.overflow, 2u);
+    }
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
     uint32_t* gdepth = V.c_depth + static_cast<uint64_t>(chain) * V.wstride;
     for (uint32_t w = tid; w < G.total_w; w += 256) gdepth[w] = depth[w];
-    if (tid == 0) { V.c_aln[chain] = red[0]; V.c_nnt[chain] = nt_total; V.c_totw[chain] = G.total_w; }
+    if (tid == 0) {
+        uint32_t* cum = V.c_seg + static_cast<uint64_t>(chain) * 4;
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < INIT_SEGS; k++) { cum[k] = run; run += seg_cnt[k]; }
+        V.c_aln[chain] = red[0]; V.c_nnt[chain] = run; V.c_totw[chain] = G.total_w;
+    }
 }
 
 // two windows of one location (see Chain::request_pair)
@@ -872,7 +846,7 @@ __device__ __forceinline__ void rec_loc(const RecBody& b, const ExtraLoc* extra,
 
 // ReassignmentTarget::random (assgn.rs:451-471) from a generator; uniform over the lanes that share `rng`
 template <typename CHAIN, typename RNG>
-__device__ __forceinline__ void random_move(const CHAIN& C, ChainRec* recs, const ExtraLoc* extra, uint32_t nnt, RNG& rng, Move& m) {
+__device__ __forceinline__ void random_move(const CHAIN& C, const RecList& recs, const ExtraLoc* extra, uint32_t nnt, RNG& rng, Move& m) {
     m.slot = static_cast<uint32_t>(rng.below(nnt));
     const uint32_t packed = load_rp_cur(&recs[m.slot]);
     const RecBody b = load_body(&recs[m.slot]);
@@ -930,6 +904,13 @@ __device__ __forceinline__ double row_sum_f64(double x, uint32_t row_base, uint3
     }
 }
 
+// LDS of a greedy workgroup for its rows' windows: 4 bytes each; 6 with the weights in LDS, plus the two weight tables (16-byte multiple)
+__host__ __device__ inline size_t greedy_lds_windows(uint32_t lpc, uint32_t wstride, uint32_t n_wk, uint32_t n_wc, bool lw) {
+    const size_t rows = static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * wstride;
+    const size_t b = lw ? ((rows * 6 + 7) & ~static_cast<size_t>(7)) + static_cast<size_t>(n_wk + n_wc) * 8 : rows * 4;
+    return (b + 15) & ~static_cast<size_t>(15);
+}
+
 // ---------------- K14 Greedy: 64 / LPC chains per wavefront ----------------
 // A candidate read of an iteration as its lane sees it: the record, and the first two of its locations beyond the second
 struct GreedyCand { uint32_t pick, rpc; RecBody b; };
@@ -962,7 +943,10 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
     const uint32_t chain = live_row ? chain_raw : n_chains - 1;                  // a spare row shadows the last chain, without effects
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(wg_row) * W;
     const uint32_t gi = chain / V.attempts;
-    ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
+    // the parts of the chain's list of non-trivial reads (RecList): four words per row in LDS, behind everything else
+    uint32_t* row_cum = reinterpret_cast<uint32_t*>(smem + greedy_lds_windows(LPC, V.wstride, V.n_wk, V.n_wc, LW)) + static_cast<size_t>(wg_row) * 4;
+    if (jj < 4) row_cum[jj] = V.c_seg[static_cast<uint64_t>(chain) * 4 + jj];
+    const RecList recs{V.recs + static_cast<uint64_t>(chain) * V.rstride, row_cum, V.seg_reads};
     const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
     const uint32_t total_w = V.c_totw[chain];
     const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
@@ -1252,6 +1236,7 @@ struct AnnealRing {
     StagedRead pos[RING];
     uint64_t rng[4];
     uint32_t produced, consumed, stop, go;
+    uint32_t cum[4];            // the parts of the chain's record list (RecList)
 };
 
 // Where the chain's window weights are (MODE): 0 gathered from its row in L2 with the table entries (the same latency chain, the
@@ -1283,7 +1268,8 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     const uint32_t chain = blockIdx.x;
     const uint32_t gi = chain / V.attempts;
     const uint64_t seed = uniform64(V.seeds[chain]);
-    ChainRec* recs = V.recs + static_cast<uint64_t>(chain) * V.ngp;
+    const RecList recs{V.recs + static_cast<uint64_t>(chain) * V.rstride, ring->cum, V.seg_reads};
+    if (threadIdx.x < 4) ring->cum[threadIdx.x] = V.c_seg[static_cast<uint64_t>(chain) * 4 + threadIdx.x];
     const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
     const uint32_t total_w = V.c_totw[chain];
     const double* gww = V.c_ww + static_cast<uint64_t>(chain) * W;
@@ -1631,9 +1617,12 @@ __global__ __launch_bounds__(256) void assignment_counts_kernel(const SolveView 
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < V.n_good && nw[i] == 1) counts[read_off[i]] = static_cast<uint16_t>(V.attempts);
     if (i < V.c_nnt[0]) {
-        const uint32_t rp = V.recs[i].rp_cur & 0xFFFFFFu;
+        // the chains of one genotype have the same non-trivial reads: the parts of chain 0's list are everybody's
+        const RecList first{V.recs, V.c_seg, V.seg_reads};
+        const uint32_t at = first.place(i);
+        const uint32_t rp = V.recs[at].rp_cur & 0xFFFFFFu;
         for (uint32_t a = 0; a < V.attempts; a++) {
-            const uint32_t loc = V.recs[static_cast<uint64_t>(a) * V.ngp + i].rp_cur >> 24;
+            const uint32_t loc = V.recs[static_cast<uint64_t>(a) * V.rstride + at].rp_cur >> 24;
             counts[read_off[rp] + loc] += 1;
         }
     }
@@ -1749,28 +1738,18 @@ __global__ void pause_kernel(uint32_t rounds) {
     for (uint32_t i = 0; i < rounds; i++) __builtin_amdgcn_s_sleep(127);
 }
 
-template <uint32_t P, uint32_t RPT>
-void launch_init_as(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s) {
-    if (lds_init > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P, RPT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds_init)));
-    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL((solve_init_kernel<P, RPT>), dim3(nch), dim3(256), lds_init, s, V); }, s);
-    LCTY_HIP(hipGetLastError());
-}
 template <uint32_t P>
 void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s) {
-    // reads per thread and block (lcty_ctx_set_knob "solve_init_rpt": 1, 2, 4): more reads per exchange mean fewer barriers and more
-    // registers (fewer wavefronts in flight to keep the streams of cells and records going)
-    const int64_t rpt = ctx->knob("solve_init_rpt", 1);      // measured at 1 M x 256: 116 / 119 / 169 ms for 1 / 2 / 4
-    if (rpt >= 4 && P <= 2) launch_init_as<P, 4>(ctx, V, nch, lds_init, s);
-    else if (rpt >= 2 && P <= 2) launch_init_as<P, 2>(ctx, V, nch, lds_init, s);
-    else launch_init_as<P, 1>(ctx, V, nch, lds_init, s);
+    if (lds_init > 48 * 1024)
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds_init)));
+    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
 }
 
-// LDS of a greedy workgroup: the rows' windows (4 bytes each; 6 with the weights in LDS, plus the two weight tables)
+// LDS of a greedy workgroup: the rows' windows (greedy_lds_windows) and four words per row for the parts of its record list
 inline size_t greedy_lds(uint32_t lpc, const SolveView& V, bool lw) {
-    const size_t rows = static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * V.wstride;
-    return lw ? ((rows * 6 + 7) & ~static_cast<size_t>(7)) + static_cast<size_t>(V.n_wk + V.n_wc) * 8 : rows * 4;
+    return greedy_lds_windows(lpc, V.wstride, V.n_wk, V.n_wc, lw) + static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * 16;
 }
 template <uint32_t LPC, bool LW>
 void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
@@ -1865,6 +1844,9 @@ struct StageRunner {
         V.n_wk = tables ? static_cast<uint32_t>(loc->d_wk.n) : 0u; V.n_wc = tables ? static_cast<uint32_t>(loc->d_wc.n) : 0u;
         V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
+        V.seg_reads = static_cast<uint32_t>(((n_good + INIT_SEGS - 1) / INIT_SEGS + 63) / 64 * 64);      // the parts of a chain's record list
+        if (V.seg_reads == 0) V.seg_reads = 64;
+        V.rstride = static_cast<uint64_t>(INIT_SEGS) * V.seg_reads;
         V.table = reinterpret_cast<const LocCell*>(reads->d_loc_table.p); V.table_ext = reads->d_loc_ext.p; V.table_unm = reads->d_loc_unm.p;
         V.pa = reads->d_pa.p; V.row_of = nullptr;
         if (gathered) {
@@ -1900,7 +1882,7 @@ struct StageRunner {
 
     // chains are processed in batches so that the per-chain state (32 B per good read + the run of further locations) fits the device
     void plan_batches() {
-        const uint64_t ngp = V.ngp;
+        const uint64_t ngp = V.rstride;                                     // record places per chain
         const uint64_t per_chain = ngp * sizeof(ChainRec) + static_cast<uint64_t>(ws.extra_cap) * sizeof(ExtraLoc) + static_cast<uint64_t>(V.wstride) * 21 + 64;
         size_t free_b = 0, total_b = 0;
         ctx->release_transfer_scratch();
@@ -1920,12 +1902,12 @@ struct StageRunner {
         }
         ws.cww.ensure(max_chains * V.wstride); ws.cgc.ensure(max_chains * V.wstride); ws.cdepth.ensure(max_chains * V.wstride);
         ws.cuc.ensure(max_chains * V.wstride);
-        ws.cnnt.ensure(max_chains); ws.ctotw.ensure(max_chains); ws.caln.ensure(max_chains);
+        ws.cnnt.ensure(max_chains); ws.cseg.ensure(4 * max_chains); ws.ctotw.ensure(max_chains); ws.caln.ensure(max_chains);
         ws.gt.ensure(gt_per_batch * ploidy); ws.seeds.ensure(max_chains); ws.liks.ensure(max_chains); ws.parts.ensure(4 * max_chains);
         ws.pri.ensure(gt_per_batch);
         V.genotypes = ws.gt.p; V.seeds = ws.seeds.p; V.priors = nullptr;
         V.recs = ws.recs.p; V.extra = ws.extra.p; V.extra_cap = ws.extra_cap; V.liks = ws.liks.p; V.parts = ws.parts.p;
-        V.c_ww = ws.cww.p; V.c_uc = ws.cuc.p; V.c_gc = ws.cgc.p; V.c_depth = ws.cdepth.p; V.c_nnt = ws.cnnt.p; V.c_totw = ws.ctotw.p; V.c_aln = ws.caln.p;
+        V.c_ww = ws.cww.p; V.c_uc = ws.cuc.p; V.c_gc = ws.cgc.p; V.c_depth = ws.cdepth.p; V.c_nnt = ws.cnnt.p; V.c_seg = ws.cseg.p; V.c_totw = ws.ctotw.p; V.c_aln = ws.caln.p;
     }
 
     void upload_genotypes(const uint16_t* genotypes, uint64_t ng) { ws.gt.upload(genotypes, ng * ploidy, stream); }
