@@ -180,13 +180,19 @@ typedef struct lcty_pair_aln {
  * (`-S greedy:x0=..,s=..,p=..` / `-S anneal:n=..,p=..,P=..`, SetParams 128-139, 249-260). */
 #define LCTY_SOLVER_GREEDY 0
 #define LCTY_SOLVER_ANNEAL 1
+/* The exact solver in the place of the reference's ILP back ends (HiGHS: src/solvers/highs.rs:38-134, Gurobi: gurobi.rs:15-83;
+ * registered at solve.rs:152-171, `-S highs` / `-S gurobi`): the same model — one binary per (non-trivial read, location), one-hot
+ * depth variables per window, coupling rows, objective = ReadAssignment::likelihood — built on the device by the stage's
+ * initialisation and solved to proven optimality by branch and bound; `node_limit` nodes without a proof -> LCTY_ERR_SOLVER, as
+ * a non-optimal solver status is upstream (highs.rs:113-116). Every attempt starts from the best location of every read. */
+#define LCTY_SOLVER_EXACT 2
 typedef struct lcty_solver {
     int32_t  kind;          /* LCTY_SOLVER_* */
     int32_t  best_start;    /* greedy: 1 = start from the best location of every read (default), 0 = random */
     uint32_t sample_size;   /* greedy: 10 */
     uint32_t plato_size;    /* greedy: 100; anneal: 10000 */
     uint32_t anneal_steps;  /* anneal: 20000 */
-    uint32_t _pad0;
+    uint32_t node_limit;    /* exact: branch-and-bound nodes per attempt before LCTY_ERR_SOLVER (default 20 000 000) */
     double   init_prob;     /* anneal: 0.5 */
 } lcty_solver;
 

@@ -76,7 +76,7 @@ class Bg(C.Structure):
     ]
 
 
-SOLVER_GREEDY, SOLVER_ANNEAL = 0, 1
+SOLVER_GREEDY, SOLVER_ANNEAL, SOLVER_EXACT = 0, 1, 2
 
 
 class Solver(C.Structure):
@@ -87,7 +87,7 @@ class Solver(C.Structure):
         ("sample_size", C.c_uint32),
         ("plato_size", C.c_uint32),
         ("anneal_steps", C.c_uint32),
-        ("_pad0", C.c_uint32),
+        ("node_limit", C.c_uint32),
         ("init_prob", C.c_double),
     ]
 

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     // instead of a workgroup prefix sum behind two barriers per 256 (those exchanges were 23 of the kernel's 116 ms).
     // Further locations (beyond a read's second) come out of one run per chain through an LDS counter: where in the run they sit
     // is nobody's business but the record's.
-    const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || !V.solver.best_start;
+    const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || (V.solver.kind == LCTY_SOLVER_GREEDY && !V.solver.best_start);
     double aln_part = 0.0;
     uint32_t n_recs = 0;
     uint64_t row_at[P];
@@ -1804,7 +1804,8 @@ struct StageRunner {
         if (!reads->scored) fail(LCTY_ERR_INVALID_INPUT, "lcty_score_reads has not been called on this batch");
         if (ploidy == 0 || ploidy > MAXP) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles ploidy 1..%u", MAXP);
         if (attempts == 0) fail(LCTY_ERR_INVALID_INPUT, "At least one attempt is required for each stage");
-        if (solver->kind != LCTY_SOLVER_GREEDY && solver->kind != LCTY_SOLVER_ANNEAL) fail(LCTY_ERR_INVALID_INPUT, "unknown solver kind");
+        if (solver->kind != LCTY_SOLVER_GREEDY && solver->kind != LCTY_SOLVER_ANNEAL && solver->kind != LCTY_SOLVER_EXACT)
+            fail(LCTY_ERR_INVALID_INPUT, "unknown solver kind");
         if (solver->kind == LCTY_SOLVER_ANNEAL && !(solver->init_prob > 0.0 && solver->init_prob <= 1.0))
             fail(LCTY_ERR_INVALID_INPUT, "Initial probability (%g) must be within (0, 1]", solver->init_prob);
         if (solver->kind == LCTY_SOLVER_ANNEAL && solver->anneal_steps == 0) fail(LCTY_ERR_INVALID_INPUT, "Number of annealing steps must be positive");
@@ -1919,6 +1920,7 @@ struct StageRunner {
             case 3: launch_init<3>(ctx, V, nch, lds_init, stream); break;
             default: launch_init<4>(ctx, V, nch, lds_init, stream); break;
         }
+        if (V.solver.kind == LCTY_SOLVER_EXACT) { solve_exact_batch(nch); return; }
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
             if (lane == 1) wait_for_greedy_of_next_locus();
             launch_anneal(ctx, V, nch, stream);
@@ -1982,6 +1984,228 @@ struct StageRunner {
             hipLaunchKernelGGL(pause_kernel, dim3(1), dim3(64), 0, stream, 8u);
         }
         g.target = 0;
+    }
+
+    // ---- the exact solver (src/solvers/highs.rs:38-134, gurobi.rs:15-83) ----
+    // The reference hands an integer programme to a CPU library: one binary per (non-trivial read, location) with objective
+    // aln_contrib * ln_prob, one-hot depth variables per window with objective depth_contrib * ln_prob(depth), coupling rows; it
+    // asks for the optimum, fails with Error::Solver when the library does not report "optimal", and decodes the assignment by
+    // per-read arg-max. The optimum of that model IS the assignment of largest ReadAssignment::likelihood (assgn.rs:235-237).
+    // Here the model is what solve_init_kernel has just built on the device for the chain (records = the columns of the reads
+    // with their objective and windows after apply_tweak, the window arrays = the depth distributions); it is brought to the host
+    // and solved by branch and bound: depth-first over the non-trivial reads (largest spread of ln-probabilities first, a read's
+    // locations by descending ln-probability), starting from the best of a coordinate ascent, pruned by
+    //     aln_contrib * (fixed ln_prob + sum of the free reads' best) + depth_contrib * sum_w max_{d in [lo_w, lo_w + cap_w]} v_w(d)
+    // where lo_w is the depth the fixed reads give window w and cap_w what the free ones could add. `node_limit` nodes without
+    // a proof of optimality -> LCTY_ERR_SOLVER, as a non-optimal HiGHS status is (highs.rs:113-116). The assignment goes back
+    // into the chain's records, so per-read counts and BAM output see it like any other solver's.
+    void solve_exact_batch(uint32_t nch) {
+        hipStream_t s = stream;
+        uint32_t ovf[2] = {0, 0};
+        ws.ovf.download(ovf, 2, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        if (ovf[0]) return;                                                     // run() repeats the batch (wider table / longer runs)
+        const uint32_t W = V.wstride;
+        std::vector<uint32_t> nnt(nch), totw(nch), seg(4ull * nch);
+        std::vector<double> aln0(nch), liks(nch);
+        ws.cnnt.download(nnt.data(), nch, s); ws.ctotw.download(totw.data(), nch, s); ws.cseg.download(seg.data(), 4ull * nch, s);
+        ws.caln.download(aln0.data(), nch, s);
+        std::vector<double> pri(gt_per_batch, 0.0);
+        if (V.priors) ws.pri.download(pri.data(), (nch + attempts - 1) / attempts, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        std::vector<double> lut;
+        std::vector<ChainRec> recs; std::vector<ExtraLoc> extra; std::vector<double> ww(W); std::vector<uint8_t> gcb(W); std::vector<uint32_t> depth0(W);
+        std::vector<double> parts(4ull * nch, 0.0);
+        for (uint32_t c = 0; c < nch; c++) {
+            const uint32_t n = nnt[c], tw = totw[c];
+            // the chain's model
+            recs.resize(V.rstride); extra.resize(std::max<uint32_t>(V.extra_cap, 1));
+            LCTY_HIP(hipMemcpyAsync(recs.data(), V.recs + static_cast<uint64_t>(c) * V.rstride, V.rstride * sizeof(ChainRec), hipMemcpyDeviceToHost, s));
+            LCTY_HIP(hipMemcpyAsync(extra.data(), V.extra + static_cast<uint64_t>(c) * V.extra_cap, static_cast<size_t>(V.extra_cap) * sizeof(ExtraLoc), hipMemcpyDeviceToHost, s));
+            LCTY_HIP(hipMemcpyAsync(ww.data(), V.c_ww + static_cast<uint64_t>(c) * W, W * sizeof(double), hipMemcpyDeviceToHost, s));
+            LCTY_HIP(hipMemcpyAsync(gcb.data(), V.c_gc + static_cast<uint64_t>(c) * W, W, hipMemcpyDeviceToHost, s));
+            LCTY_HIP(hipMemcpyAsync(depth0.data(), V.c_depth + static_cast<uint64_t>(c) * W, W * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            LCTY_HIP(hipStreamSynchronize(s));
+            struct Loc { double lp; uint32_t wa, wb; };
+            std::vector<uint32_t> first(n + 1, 0), place(n);
+            std::vector<Loc> locs;
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t* cum = &seg[4ull * c];
+                const uint32_t k = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+                place[i] = i - cum[k] + k * V.seg_reads;
+                const ChainRec& r = recs[place[i]];
+                const uint32_t nloc = r.meta & 0xFFu, eix = r.meta >> 8;
+                first[i] = static_cast<uint32_t>(locs.size());
+                for (uint32_t t = 0; t < nloc; t++) {
+                    if (t == 0) locs.push_back({r.lp0, r.win0 & 0xFFFFu, r.win0 >> 16});
+                    else if (t == 1) locs.push_back({r.lp1, r.win1 & 0xFFFFu, r.win1 >> 16});
+                    else { const ExtraLoc& e = extra[eix + t - 2]; locs.push_back({e.lp, e.win & 0xFFFFu, e.win >> 16}); }
+                }
+            }
+            first[n] = static_cast<uint32_t>(locs.size());
+            // depths without the non-trivial reads (they all start at their location 0: best_start), and what they could add
+            std::vector<int64_t> lo(tw, 0);
+            for (uint32_t w = 0; w < tw; w++) lo[w] = depth0[w];
+            double aln_fixed = aln0[c];
+            for (uint32_t i = 0; i < n; i++) { const Loc& l0 = locs[first[i]]; lo[l0.wa]--; lo[l0.wb]--; aln_fixed -= l0.lp; }
+            std::vector<uint32_t> cap(tw, 0);
+            auto mult = [](const Loc& l, uint32_t w) -> uint32_t { return (l.wa == w ? 1u : 0u) + (l.wb == w ? 1u : 0u); };
+            // windows a read can touch, with the largest multiplicity over its locations
+            std::vector<std::vector<std::pair<uint32_t, uint32_t>>> touch(n);
+            for (uint32_t i = 0; i < n; i++) {
+                for (uint32_t t = first[i]; t < first[i + 1]; t++)
+                    for (uint32_t w : {locs[t].wa, locs[t].wb}) {
+                        auto it = std::find_if(touch[i].begin(), touch[i].end(), [&](const std::pair<uint32_t, uint32_t>& x) { return x.first == w; });
+                        const uint32_t m = mult(locs[t], w);
+                        if (it == touch[i].end()) touch[i].push_back({w, m}); else it->second = std::max(it->second, m);
+                    }
+                for (auto& x : touch[i]) cap[x.first] += x.second;
+            }
+            uint64_t need = 0;
+            for (uint32_t w = 0; w < tw; w++) need = std::max<uint64_t>(need, static_cast<uint64_t>(lo[w]) + cap[w] + 1);
+            if (need > loc->lut_ext_depth) { ensure_depth_table(loc, std::min<uint64_t>(need, depth_cap)); V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; lut.clear(); }
+            if (lut.empty()) {
+                lut.resize(static_cast<size_t>(LCTY_GC_BINS) * loc->lut_ext_depth);
+                loc->d_lut_ext.download(lut.data(), lut.size(), s);
+                LCTY_HIP(hipStreamSynchronize(s));
+            }
+            const uint32_t ld = loc->lut_ext_depth;
+            auto v = [&](uint32_t w, int64_t d) -> double {                   // WindowDistr::ln_prob (distr_cache.rs:34-39)
+                return ww[w] == 0.0 ? 0.0 : ww[w] * lut[static_cast<size_t>(gcb[w]) * ld + static_cast<size_t>(d)];
+            };
+            auto range_max = [&](uint32_t w) -> double {
+                if (ww[w] == 0.0) return 0.0;
+                double m = -INFINITY;
+                for (int64_t d = lo[w]; d <= lo[w] + cap[w]; d++) m = std::max(m, v(w, d));
+                return m;
+            };
+            // order of the reads: the widest spread of ln-probabilities first (a wrong choice there is pruned at once)
+            std::vector<uint32_t> order(n);
+            std::iota(order.begin(), order.end(), 0u);
+            auto spread = [&](uint32_t i) { return locs[first[i]].lp - locs[first[i + 1] - 1].lp; };
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return spread(a) > spread(b); });
+            // incumbent: coordinate ascent from the best start (every read at its location 0)
+            std::vector<uint8_t> assign(n, 0), best_assign;
+            std::vector<int64_t> dep(lo);
+            for (uint32_t i = 0; i < n; i++) { dep[locs[first[i]].wa]++; dep[locs[first[i]].wb]++; }
+            const std::vector<int64_t> base_depth(lo);                        // `lo` moves with the search; a leaf is valued from here
+            auto total = [&](const std::vector<uint8_t>& a, double* depth_lik, double* aln_lik) {
+                std::vector<int64_t> d(base_depth);
+                double al = aln_fixed;
+                for (uint32_t i = 0; i < n; i++) { const Loc& l = locs[first[i] + a[i]]; d[l.wa]++; d[l.wb]++; al += l.lp; }
+                double dl = 0.0;
+                for (uint32_t w = 0; w < tw; w++) dl += v(w, d[w]);
+                *depth_lik = dl; *aln_lik = al;
+                return V.depth_contrib * dl + V.aln_contrib * al;
+            };
+            for (bool improved = true; improved;) {
+                improved = false;
+                for (uint32_t i = 0; i < n; i++) {
+                    const Loc& cur = locs[first[i] + assign[i]];
+                    double best_gain = 1e-12; uint32_t best_t = assign[i];
+                    for (uint32_t t = 0; t < first[i + 1] - first[i]; t++) {
+                        if (t == assign[i]) continue;
+                        const Loc& alt = locs[first[i] + t];
+                        std::pair<uint32_t, int> ch[4] = {{cur.wa, -1}, {cur.wb, -1}, {alt.wa, 1}, {alt.wb, 1}};
+                        double gain = V.aln_contrib * (alt.lp - cur.lp), dd = 0.0;
+                        for (int x = 0; x < 4; x++) {
+                            bool seen = false; int delta = 0;
+                            for (int y = 0; y < 4; y++) if (ch[y].first == ch[x].first) { if (y < x) seen = true; delta += ch[y].second; }
+                            if (!seen && delta) dd += v(ch[x].first, dep[ch[x].first] + delta) - v(ch[x].first, dep[ch[x].first]);
+                        }
+                        gain += V.depth_contrib * dd;
+                        if (gain > best_gain) { best_gain = gain; best_t = t; }
+                    }
+                    if (best_t != assign[i]) {
+                        const Loc& alt = locs[first[i] + best_t];
+                        dep[cur.wa]--; dep[cur.wb]--; dep[alt.wa]++; dep[alt.wb]++;
+                        assign[i] = static_cast<uint8_t>(best_t); improved = true;
+                    }
+                }
+            }
+            double dl_best, al_best;
+            double incumbent = total(assign, &dl_best, &al_best);
+            best_assign = assign;
+            // branch and bound
+            const uint64_t node_limit = V.solver.node_limit ? V.solver.node_limit : 20ull * 1000 * 1000;
+            uint64_t nodes = 0;
+            bool out_of_nodes = false;
+            double free_best = 0.0;                                            // sum over the free reads of their best ln-probability
+            for (uint32_t i = 0; i < n; i++) free_best += locs[first[i]].lp;
+            double aln_sum = aln_fixed, win_sum = 0.0;
+            std::vector<double> wmax(tw);
+            for (uint32_t w = 0; w < tw; w++) { wmax[w] = range_max(w); win_sum += wmax[w]; }
+            // depth-first, iterative (a locus can have many thousands of non-trivial reads: no recursion)
+            std::vector<uint8_t> cur_assign(n, 0), entered(n, 0), applied(n, 0);
+            std::vector<uint32_t> next_t(n, 0);
+            std::vector<double> keep_ws(n), keep_al(n);
+            std::vector<std::vector<std::pair<uint32_t, double>>> saved(n);
+            int64_t level = 0;
+            while (level >= 0 && n) {
+                if (static_cast<uint32_t>(level) == n) {                       // a leaf: the value as ReadAssignment::likelihood sums it
+                    if (++nodes > node_limit) out_of_nodes = true;
+                    double dl, al;
+                    const double val = total(cur_assign, &dl, &al);
+                    if (val > incumbent) { incumbent = val; best_assign = cur_assign; dl_best = dl; al_best = al; }
+                    level--;
+                    continue;
+                }
+                const uint32_t i = order[level], nloc = first[i + 1] - first[i];
+                if (!entered[level]) {
+                    // the read leaves the free set: what it could have added to its windows goes, its best ln-probability too
+                    if (++nodes > node_limit) out_of_nodes = true;
+                    entered[level] = 1; applied[level] = 0; next_t[level] = 0;
+                    for (auto& x : touch[i]) cap[x.first] -= x.second;
+                    free_best -= locs[first[i]].lp;
+                }
+                if (applied[level]) {                                           // back from (or past) the location tried last
+                    const Loc& l = locs[first[i] + next_t[level] - 1];
+                    for (auto& sv : saved[level]) wmax[sv.first] = sv.second;
+                    lo[l.wa]--; lo[l.wb]--;
+                    win_sum = keep_ws[level]; aln_sum = keep_al[level];
+                    applied[level] = 0;
+                }
+                if (next_t[level] == nloc || out_of_nodes) {
+                    free_best += locs[first[i]].lp;
+                    for (auto& x : touch[i]) cap[x.first] += x.second;
+                    entered[level] = 0;
+                    level--;
+                    continue;
+                }
+                const uint32_t t = next_t[level]++;
+                const Loc& l = locs[first[i] + t];
+                lo[l.wa]++; lo[l.wb]++;
+                saved[level].clear();
+                double ws_new = win_sum;
+                for (auto& x : touch[i]) {
+                    const double m = range_max(x.first);
+                    saved[level].push_back({x.first, wmax[x.first]});
+                    ws_new += m - wmax[x.first]; wmax[x.first] = m;
+                }
+                applied[level] = 1; keep_ws[level] = win_sum; keep_al[level] = aln_sum;
+                const double bound = V.aln_contrib * (aln_sum + l.lp + free_best) + V.depth_contrib * ws_new;
+                // a subtree is left out when it cannot beat the incumbent by more than the rounding of two long sums
+                if (bound > incumbent + 1e-12 * std::fabs(incumbent) + 1e-10) {
+                    win_sum = ws_new; aln_sum += l.lp; cur_assign[i] = static_cast<uint8_t>(t);
+                    level++;
+                }
+            }
+            if (out_of_nodes)
+                fail(LCTY_ERR_SOLVER, "Exact solver: no proof of optimality within %llu nodes (%u non-trivial reads); Model finished with non-optimal status NodeLimit",
+                     static_cast<unsigned long long>(node_limit), n);
+            // the assignment back into the records; the likelihood as ReadAssignment::likelihood sums it
+            for (uint32_t i = 0; i < n; i++) {
+                ChainRec& r = recs[place[i]];
+                r.rp_cur = (r.rp_cur & 0xFFFFFFu) | (static_cast<uint32_t>(best_assign[i]) << 24);
+            }
+            LCTY_HIP(hipMemcpyAsync(V.recs + static_cast<uint64_t>(c) * V.rstride, recs.data(), V.rstride * sizeof(ChainRec), hipMemcpyHostToDevice, s));
+            LCTY_HIP(hipStreamSynchronize(s));
+            liks[c] = pri[c / attempts] + incumbent;
+            parts[4ull * c] = al_best; parts[4ull * c + 1] = dl_best; parts[4ull * c + 2] = static_cast<double>(nodes); parts[4ull * c + 3] = 0.0;
+        }
+        ws.liks.upload(liks.data(), nch, s);
+        ws.parts.upload(parts.data(), 4ull * nch, s);
+        LCTY_HIP(hipStreamSynchronize(s));
     }
 
     template <typename F>
@@ -2231,10 +2455,11 @@ int32_t lcty_locus_depth_table(lcty_locus* locus, uint32_t* width_io, double* ou
 // Greedy::default / SimAnneal::default (src/solvers/stoch.rs:45-52, 161-168)
 int32_t lcty_solver_default(lcty_solver* s, int32_t kind) {
     return guarded([&] {
-        if (!s || (kind != LCTY_SOLVER_GREEDY && kind != LCTY_SOLVER_ANNEAL)) fail(LCTY_ERR_INVALID_INPUT, "unknown solver kind");
+        if (!s || (kind != LCTY_SOLVER_GREEDY && kind != LCTY_SOLVER_ANNEAL && kind != LCTY_SOLVER_EXACT)) fail(LCTY_ERR_INVALID_INPUT, "unknown solver kind");
         memset(s, 0, sizeof(*s));
         s->kind = kind; s->best_start = 1; s->sample_size = 10;
         s->plato_size = kind == LCTY_SOLVER_GREEDY ? 100 : 10000;
+        s->node_limit = kind == LCTY_SOLVER_EXACT ? 20u * 1000u * 1000u : 0u;
         s->anneal_steps = 20000; s->init_prob = 0.5;
     });
 }

@@ -486,6 +486,50 @@ static void solve_anneal(rassgn* ra, const orc_gt_alns* g, const lcty_solver* s,
     }
 }
 
+/* The optimum of the integer programme the reference hands to HiGHS / Gurobi (src/solvers/highs.rs:38-100, gurobi.rs:15-83): one
+ * binary per (non-trivial read, location) with objective aln_contrib * ln_prob, one-hot depth variables per window with objective
+ * depth_contrib * ln_prob(depth), coupling rows. Its optimum is the assignment of largest ReadAssignment::likelihood
+ * (assgn.rs:235-237); here by EXHAUSTIVE ENUMERATION of the non-trivial reads' locations, every assignment valued from scratch with
+ * recalc_likelihood (assgn.rs:346-354). Test infrastructure for small models: more than max_states assignments -> the likelihood
+ * is NaN. Ties: the first assignment in odometer order (read 0 fastest) of the largest value. */
+static void solve_enumerate(rassgn* ra, const orc_gt_alns* g, uint64_t max_states) {
+    rassgn_init(ra, g, 0, 0);
+    double states = 1.0;
+    for (uint64_t q = 0; q < g->n_nontrivial; q++) {
+        const uint64_t r = g->non_trivial[q];
+        states *= (double)(g->read_ixs[r + 1] - g->read_ixs[r]);
+    }
+    if (states > (double)max_states) { ra->aln_lik = NAN; ra->depth_lik = NAN; return; }
+    uint16_t* best = (uint16_t*)malloc(sizeof(uint16_t) * (g->n_reads ? g->n_reads : 1));
+    memcpy(best, ra->assgn, sizeof(uint16_t) * g->n_reads);
+    double best_lik = rassgn_likelihood(ra);
+    for (;;) {
+        /* odometer over the non-trivial reads */
+        uint64_t q = 0;
+        for (; q < g->n_nontrivial; q++) {
+            const uint64_t r = g->non_trivial[q], i = g->read_ixs[r], m = g->read_ixs[r + 1] - i;
+            const gt_aln* old = &g->alns[i + ra->assgn[r]];
+            ra->depth[old->win[0]]--; ra->depth[old->win[1]]--;
+            ra->assgn[r] = (uint16_t)((uint64_t)ra->assgn[r] + 1 < m ? ra->assgn[r] + 1 : 0);
+            const gt_aln* nw = &g->alns[i + ra->assgn[r]];
+            ra->depth[nw->win[0]]++; ra->depth[nw->win[1]]++;
+            if (ra->assgn[r] != 0) break;
+        }
+        if (q == g->n_nontrivial) break;                 /* wrapped around: every assignment seen */
+        recalc_likelihood(ra);
+        const double lik = rassgn_likelihood(ra);
+        if (lik > best_lik) { best_lik = lik; memcpy(best, ra->assgn, sizeof(uint16_t) * g->n_reads); }
+    }
+    memset(ra->depth, 0, sizeof(uint32_t) * g->total_windows);
+    memcpy(ra->assgn, best, sizeof(uint16_t) * g->n_reads);
+    for (uint64_t r = 0; r < g->n_reads; r++) {
+        const gt_aln* a = &g->alns[g->read_ixs[r] + ra->assgn[r]];
+        ra->depth[a->win[0]]++; ra->depth[a->win[1]]++;
+    }
+    recalc_likelihood(ra);
+    free(best);
+}
+
 void orc_solver_default(lcty_solver* s, int32_t kind) {
     memset(s, 0, sizeof(*s));
     s->kind = kind;
@@ -500,6 +544,7 @@ double orc_solve(const orc_gt_alns* g, const lcty_solver* s, uint64_t seed, uint
     orc_rng rng; orc_rng_seed(&rng, seed);
     if (g->n_nontrivial == 0) rassgn_init(&ra, g, 0, seed);         /* trivial: the only possible assignment */
     else if (s->kind == LCTY_SOLVER_GREEDY) solve_greedy(&ra, g, s, &rng, seed);
+    else if (s->kind == LCTY_SOLVER_EXACT) solve_enumerate(&ra, g, s->node_limit ? s->node_limit : 4000000u);
     else solve_anneal(&ra, g, s, &rng, seed);
     const double lik = rassgn_likelihood(&ra);
     if (assgn_out) memcpy(assgn_out, ra.assgn, sizeof(uint16_t) * g->n_reads);

@@ -1,0 +1,78 @@
+"""The exact solver (the place of the reference's HiGHS / Gurobi back ends, src/solvers/highs.rs:38-134) through the C ABI
+against the oracle's exhaustive enumeration of the same model, on instances small enough to enumerate; on larger ones against the
+chains (an optimum is never below what greedy or annealing find); the node limit; the assignment it leaves behind."""
+import numpy as np
+import pytest
+
+from locityper_amd import _lib, api, cdefs, synth
+from tests import oracle_ffi as O
+from tests.test_gpu_solve import setup
+
+pytestmark = pytest.mark.gpu
+
+
+def test_exact_equals_enumeration_on_small_models(gpu_ctx):
+    exact = api.default_solver(cdefs.SOLVER_EXACT)
+    assert exact.kind == cdefs.SOLVER_EXACT and exact.node_limit == 20_000_000
+    o_exact = O.default_solver(cdefs.SOLVER_EXACT)
+    n_cases = 0
+    for n_alleles, n_pairs, base_len, seed in ((4, 11, 4000, 9), (5, 13, 3000, 21), (3, 12, 2500, 4), (6, 9, 5000, 33)):
+        L, p, loc, aa, ol, oa = setup(gpu_ctx, n_alleles, n_pairs, base_len, seed=seed)
+        gts = api.generate_genotypes(n_alleles, 2)
+        seeds = api.chain_seeds(100 + seed, 2 * len(gts))
+        gm, gv, gl = api.solve_stage(aa, gts, exact, 2, seeds)
+        om, ov, olk = O.solve_stage(ol, oa, gts, o_exact, 2, seeds)
+        assert np.all(np.isfinite(olk)), "the oracle's enumeration must cover these models"
+        assert np.abs(gl - olk).max() <= 1e-9 * np.abs(olk).max()
+        assert np.allclose(gm, om, rtol=1e-9)
+        # never below the chains of the same attempt (same tweak)
+        for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+            _, _, cl = api.solve_stage(aa, gts, api.default_solver(kind), 2, seeds)
+            assert np.all(cl <= gl + 1e-9 * np.abs(gl))
+        n_cases += gl.size
+    assert n_cases >= 90
+    # other ploidies
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 4, 10, 3000, seed=5)
+    for ploidy in (1, 3):
+        g = api.generate_genotypes(4, ploidy)[:4]
+        s = api.chain_seeds(3, len(g))
+        gl = api.solve_stage(aa, g, exact, 1, s)[2]
+        olk = O.solve_stage(ol, oa, g, o_exact, 1, s)[2]
+        assert np.all(np.isfinite(olk)) and np.abs(gl - olk).max() <= 1e-9 * np.abs(olk).max()
+
+
+def test_exact_on_larger_models_node_limit_and_assignment(gpu_ctx):
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 6, 400, 6000, seed=12)
+    gts = api.generate_genotypes(6, 2)[:6]
+    seeds = api.chain_seeds(8, len(gts))
+    exact = api.default_solver(cdefs.SOLVER_EXACT)
+    try:
+        gl = api.solve_stage(aa, gts, exact, 1, seeds)[2]
+    except _lib.LocityperError as e:
+        assert e.code == cdefs.ERR_SOLVER and "non-optimal status" in str(e)          # as HiGHS' non-optimal status (highs.rs:113-116)
+        gl = None
+    if gl is not None:
+        for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+            cl = api.solve_stage(aa, gts, api.default_solver(kind), 1, seeds)[2]
+            assert np.all(cl <= gl + 1e-9 * np.abs(gl))
+        # priors shift the likelihood as for every solver (solve.rs:827)
+        pri = -np.arange(len(gts), dtype=np.float64)
+        assert np.allclose(api.solve_stage(aa, gts, exact, 1, seeds, pri)[2], gl + pri[:, None], rtol=1e-13)
+    # a node limit too small for a proof: Error::Solver, never an unproven answer
+    tight = api.default_solver(cdefs.SOLVER_EXACT)
+    tight.node_limit = 3
+    with pytest.raises(_lib.LocityperError) as e:
+        api.solve_stage(aa, gts[:1], tight, 1, seeds[:1])
+    assert e.value.code == cdefs.ERR_SOLVER
+    # the per-read assignment behind the optimum: counts of one attempt are one location per read, and the likelihood of that
+    # assignment (oracle bookkeeping on the oracle's own model of the genotype) is the optimum
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 4, 12, 3000, seed=17)
+    gt = api.generate_genotypes(4, 2)[int(np.argmax(aa.run_filter()))]
+    s1 = api.chain_seeds(2, 1)
+    lik = api.solve_stage(aa, gt[None, :], exact, 1, s1)[2][0, 0]
+    off, counts = api.assignment_counts(aa, gt, exact, 1, s1)
+    assert np.all(np.add.reduceat(counts.astype(np.int64), off[:-1].astype(np.int64)) == 1)
+    g = O.OracleGtAlns(ol, oa, tuple(int(x) for x in gt))
+    g.apply_tweak(int(s1[0]))
+    assgn = np.array([int(np.argmax(counts[off[r]:off[r + 1]])) for r in range(len(off) - 1)], dtype=np.uint16)
+    assert g.likelihood(assgn)[0] == pytest.approx(lik, rel=1e-9)

@@ -250,3 +250,26 @@ def test_threaded_oracle_equals_the_single_thread_one():
         for threads in (1, 4, 5, 40):
             got = O.solve_stage(ol, oa, gts, O.default_solver(kind), 2, seeds, priors=pri, threads=threads)
             assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+
+
+def test_enumeration_is_the_optimum_of_the_ilp_model():
+    """SURVEY a31: the model of highs.rs:38-100 has the assignment of largest ReadAssignment::likelihood as its optimum; the oracle's
+    exhaustive enumeration (orc_solve with LCTY_SOLVER_EXACT) against an independent enumeration in Python, and against the chains."""
+    L = synth.SynthLocus(4, 40, seed=9, base_len=4000)
+    p = O.resolve_params(O.default_params(), L.bg)
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    oa = ol.load(L.reads(0, 11))
+    exact = O.default_solver(cdefs.SOLVER_EXACT)
+    for gt, seed in (((0, 1), 5), (L.true_genotype, 6), ((2, 2), 7)):
+        g = O.OracleGtAlns(ol, oa, gt)
+        g.apply_tweak(seed)
+        best = brute_force_best(g, g.arrays())
+        lik, assgn, parts = g.solve(exact, seed)
+        assert lik == pytest.approx(best, rel=1e-12)
+        assert g.likelihood(assgn)[0] == pytest.approx(lik, rel=1e-12)
+        for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+            assert g.solve(O.default_solver(kind), seed)[0] <= lik + 1e-9
+    # more assignments than the limit: no answer (NaN), never a wrong one
+    exact.node_limit = 4
+    g = O.OracleGtAlns(ol, oa, L.true_genotype)
+    assert math.isnan(g.solve(exact, 1)[0])
