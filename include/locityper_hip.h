@@ -221,7 +221,8 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  *       sliding from 1 024 bases on);   "solve_stats"   1: per-stage iteration counts on stderr;   "queue_trace"   1: wall-clock marks of the phases of every locus of
  *       lcty_solve / lcty_solve_queue on stderr;   "gather_chunk_mb"   staging size of lcty_solve_stage_read_sharded;
  *   "prefilter_gram"   0: always the f64 tile kernel, 1: the integer Gram contraction on the matrix cores whenever it applies
- *       (default: from 512 alleles on);   "comm_fail_at"   k: the k-th status agreement of a multi-GPU call fails on this rank (tests of
+ *       (default: from 512 alleles on);   "score_lean"   0: counted batches go through the general scoring kernel only (default 1: the lean kernel first, the general
+ *       one on the pairs it leaves);   "comm_fail_at"   k: the k-th status agreement of a multi-GPU call fails on this rank (tests of
  *       the error path of the exchanges);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the
  *       f64 kernel takes the batch);   "prefilter_gram_levels"   levels of a row the contraction takes (<= 16; rows with more go
  *       through the f64 kernel).

@@ -10,6 +10,9 @@
 namespace lcty {
 
 constexpr int WAVE = 64;                       // CDNA4 wavefront
+// the pair-alignment arena of a scored batch: a wavefront of a large scoring launch reserves PA_CHUNK entries at a time
+// (lcty_score.hip); a batch that can hold such a launch gets an eighth more room and a chunk per wavefront (lcty_reads_create)
+constexpr uint32_t PA_CHUNK = 4096, PA_POOL_MIN_PAIRS = 32, PA_MAX_GRID = 256 * 16;
 constexpr uint64_t KSET_EMPTY = ~0ull;         // never a valid canonical k-mer for k <= 31
 
 // Device record of one PairAlignment (src/model/locs.rs:668-676), 24 B.
@@ -80,12 +83,19 @@ struct ReadsView {
     double* matrix;                 // [R][A] read-major; rows of non-GOOD pairs are 0.0
     PairAlnDev* pa;                 // arena
     uint64_t pa_cap;
+    uint32_t pa_chunk;              // entries a wavefront of the scoring kernel reserves at a time (0: every pair reserves its own)
     unsigned long long* pa_count;   // arena cursor
     uint64_t* pa_off;               // [R]
     uint32_t* pa_cnt;               // [R]
     uint32_t* pa_idx;               // [R][A]: offset of the contig's entries inside the pair's arena segment | count << 24
     uint32_t* err_flag;             // first LCTY_ERR_* raised by a kernel
     double* recover_w;              // per pair: read weight if it reaches recover_and_group_alignments (locs.rs:1255), else -1
+    // the lean scoring kernel hands the pairs it does not take (several saved alignments of a read end on one contig, mates
+    // beyond the register path of the k-mer windows) to the general kernel: their indices, appended in any order
+    uint32_t* defer_list;           // [cap_raw_pairs] or null
+    unsigned int* defer_count;      // [1]
+    const uint32_t* only_list;      // general kernel: the pairs to score (null: all n_pairs) ...
+    const unsigned int* only_count; // ... and how many (device memory: no host round trip between the two launches)
     uint8_t* park;                  // scoring kernel, large pairs: per-workgroup scratch of saved alignments (else null)
     uint64_t park_stride;
 };

@@ -89,6 +89,7 @@ struct lcty_reads {
     // of every scored chunk stay. Pairs before raw_first have been scored and their raw data dropped; the per-pair raw arrays
     // (mate_len, mate_off, aln_off, cigar_off, pair_meta) are indexed relative to raw_first. raw_first == 0 otherwise.
     bool streaming = false;
+    bool pa_pooled = false;                  // the arena has room for chunk-wise reservation by the scoring kernel (lcty_device.hpp: PA_CHUNK)
     uint64_t raw_first = 0, cap_raw_pairs = 0;
     uint64_t chunk_cap_recs = 0, chunk_cap_cigar = 0;   // record / CIGAR capacity of a chunk as given at creation (recovery replaces the tables)
     unsigned long long pa_at_raw_first = 0;   // arena cursor when the current chunk started (a chunk can be scored again)
@@ -143,6 +144,8 @@ struct lcty_reads {
         lcty::DevBuf<int> f;
     } gram;
     lcty::DevBuf<uint32_t> d_err;
+    lcty::DevBuf<uint32_t> d_defer_list;     // pairs the lean scoring kernel leaves to the general one (lcty_score.hip), grow-only
+    lcty::DevBuf<unsigned int> d_defer_count;
     lcty::DevBuf<double> d_recover_w;        // per pair: read weight when the pair reaches recover_and_group_alignments, else -1
 
     // prefilter products

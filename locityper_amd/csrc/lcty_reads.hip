@@ -136,7 +136,12 @@ static int32_t create_reads(lcty_locus* locus, uint64_t cap_pairs, uint64_t raw_
         const uint64_t pa_cap = streaming
             ? (cap_pair_alns ? cap_pair_alns : std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS), 3) * cap_pairs * A) + 64
             : std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * cap_pairs * A, 2 * cap_recs + cap_pairs) + 64;
-        R->d_pa.alloc(pa_cap);
+        // large launches hand the arena out in chunks per wavefront (lcty_device.hpp: PA_CHUNK): room for what stays unused
+        // (launches of at least PA_POOL_MIN_PAIRS pairs per wavefront: only batches that can hold that many pairs at a time; a
+        // streaming batch whose caller said how many PairAlignments to make room for keeps exactly that room)
+        R->pa_pooled = raw_pairs >= static_cast<uint64_t>(PA_POOL_MIN_PAIRS) * PA_MAX_GRID / 2 && !(streaming && cap_pair_alns);
+        const uint64_t pa_slack = R->pa_pooled ? pa_cap / 8 + static_cast<uint64_t>(PA_CHUNK) * PA_MAX_GRID : 0;
+        R->d_pa.alloc(pa_cap + pa_slack);
         R->d_pa_count.alloc(1);
         R->d_pa_off.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_pa_cnt.alloc(std::max<uint64_t>(cap_pairs, 1));
@@ -448,7 +453,8 @@ int32_t lcty_reads_get_pair_alns(lcty_reads* reads, uint64_t* off, lcty_pair_aln
         uint64_t run = 0;
         for (uint64_t r = 0; r < n; r++) { if (off) off[r] = run; run += cnt[r]; }
         if (off) off[n] = run;
-        if (run != total) fail(LCTY_ERR_RUNTIME, "pair-alignment arena is inconsistent (%llu vs %llu)", (unsigned long long)run, total);
+        // the cursor counts what was reserved: equal to what is used unless wavefronts took the arena in chunks (lcty_score.hip)
+        if (run > total) fail(LCTY_ERR_RUNTIME, "pair-alignment arena is inconsistent (%llu entries used, %llu reserved)", (unsigned long long)run, total);
         if (!out) return;
         if (cap < run) fail(LCTY_ERR_INVALID_INPUT, "output capacity %llu < %llu pair alignments", (unsigned long long)cap, (unsigned long long)run);
         std::vector<PairAlnDev> arena(total);

@@ -446,13 +446,19 @@ struct Fast3 {
     bool has1, has2;
 };
 
+__device__ __forceinline__ Fast3 fast_from_refs(const InsLut& ins, const AlnRef& a1, const AlnRef& a2, bool has1, bool has2,
+                                                double unm_ins_penalty, bool paired);
 __device__ __forceinline__ Fast3 fast_candidates(const InsLut& ins, const Rec16* rec, uint32_t h1, uint32_t h2, double best0,
                                                  double best1, double unm_ins_penalty, bool paired) {
-    Fast3 f;
-    f.has1 = h1 != NONE16; f.has2 = h2 != NONE16;
     const AlnRef none{0.0, 0, 0, NONE32, false};
-    f.a1 = f.has1 ? load_aln(rec, h1, best0) : none;
-    f.a2 = f.has2 ? load_aln(rec, h2, best1) : none;
+    const bool has1 = h1 != NONE16, has2 = h2 != NONE16;
+    return fast_from_refs(ins, has1 ? load_aln(rec, h1, best0) : none, has2 ? load_aln(rec, h2, best1) : none, has1, has2, unm_ins_penalty, paired);
+}
+__device__ __forceinline__ Fast3 fast_from_refs(const InsLut& ins, const AlnRef& a1, const AlnRef& a2, bool has1, bool has2,
+                                                double unm_ins_penalty, bool paired) {
+    Fast3 f;
+    f.has1 = has1; f.has2 = has2;
+    f.a1 = a1; f.a2 = a2;
     f.present[0] = f.present[1] = f.present[2] = false;
     f.prob[0] = f.prob[1] = f.prob[2] = -INFINITY;
     if (!paired) {                                   // identify_single_end_alignments: one entry (aln, -)
@@ -551,14 +557,23 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
     uint8_t* kk1 = BIG ? reinterpret_cast<uint8_t*>(order + mr2) : reinterpret_cast<uint8_t*>(scratch_cursor + 1);   // [A] general path: kept first-end alns (<= 10)
     uint8_t* kk2 = kk1 + A;                                                   // [A]
     uint8_t* cnt8 = kk2 + A;                                                  // [A] emitted PairAlignments (<= 10); bit 7 = general path
-    const uint32_t* alen = BIG ? L.allele_len : alen_lds;
+    // SPLIT (counted alignments in LDS): the two chain heads of a contig in two words — head(end 0) in head32[c], head(end 1) in
+    // head32[A + c], where the record form keeps the allele lengths (a counted alignment has its clipping applied: pass 1 does not
+    // need them, pass 3 reads them from L2 along the contigs) — so that chaining a saved alignment is ONE LDS exchange instead of a
+    // read and a compare-and-swap loop on a shared word.
+    constexpr bool SPLIT = CNT && !BIG;
+    const uint32_t* alen = (BIG || SPLIT) ? L.allele_len : alen_lds;
     const int lane = threadIdx.x;
     const bool paired = L.is_paired != 0;
     const InsLut ins{L.ins_lut, L.ins_lut_size, L.ins_n, L.ins_lnq, L.ins_lnpmf_const};
-    if constexpr (!BIG) for (uint32_t i = lane; i < A; i += WAVE) alen_lds[i] = L.allele_len[i];
+    if constexpr (!BIG && !SPLIT) for (uint32_t i = lane; i < A; i += WAVE) alen_lds[i] = L.allele_len[i];
     __syncthreads();
 
-    for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
+    unsigned long long pool_at = 0, pool_left = 0;          // this wavefront's share of the pair-alignment arena
+    // all pairs of the batch, or the ones the lean kernel left (their indices and their number are on the device)
+    const uint64_t n_todo = R.only_list ? static_cast<uint64_t>(*R.only_count) : R.n_pairs;
+    for (uint64_t todo = blockIdx.x; todo < n_todo; todo += gridDim.x) {
+        const uint64_t p = R.only_list ? R.only_list[todo] : todo;
         const uint64_t a0 = R.aln_off[p];
         const uint32_t* cig = CNT ? nullptr : R.cigar + R.cigar_off[p];
         const uint2 meta = R.pair_meta[p];                 // {index of the mate-2 primary (or n), records to look at}
@@ -583,7 +598,7 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                 nm1 = (R.nmask + (off1 >> 5))[lane];
             }
         }
-        for (uint32_t i = lane; i < A; i += WAVE) head32[i] = 0xFFFFFFFFu;
+        for (uint32_t i = lane; i < (SPLIT ? 2 * A : A); i += WAVE) head32[i] = 0xFFFFFFFFu;
         if (lane == 0) *scratch_cursor = 0;
         // the records of the first group of pass 1 are requested now, so that they arrive while lanes 0 / 1 work out the
         // thresholds (two more dependent loads each)
@@ -707,14 +722,18 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                             r.end_rev = sc.end | ((bflags & LCTY_FLAG_REVERSE) ? REV_BIT : 0u);
                             rec[idx] = r;
                             // chain per (contig, end): exchange the 16-bit head inside its 32-bit word
-                            uint32_t* word = &head32[contig];
-                            uint32_t old = *word, assumed;
-                            do {
-                                assumed = old;
-                                const uint32_t repl = e ? ((assumed & 0x0000FFFFu) | (idx << 16)) : ((assumed & 0xFFFF0000u) | idx);
-                                old = atomicCAS(word, assumed, repl);
-                            } while (old != assumed);
-                            nxt[idx] = static_cast<uint16_t>(e ? (old >> 16) : (old & 0xFFFFu));
+                            if constexpr (SPLIT) {
+                                nxt[idx] = static_cast<uint16_t>(atomicExch(&head32[e * A + contig], 0xFFFF0000u | idx));
+                            } else {
+                                uint32_t* word = &head32[contig];
+                                uint32_t old = *word, assumed;
+                                do {
+                                    assumed = old;
+                                    const uint32_t repl = e ? ((assumed & 0x0000FFFFu) | (idx << 16)) : ((assumed & 0xFFFF0000u) | idx);
+                                    old = atomicCAS(word, assumed, repl);
+                                } while (old != assumed);
+                                nxt[idx] = static_cast<uint16_t>(e ? (old >> 16) : (old & 0xFFFFu));
+                            }
                         }
                     }
                 }
@@ -772,8 +791,8 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                 uint32_t h1 = NONE16, h2 = NONE16;
                 bool general = false;
                 if (c < A) {
-                    const uint32_t hw = head32[c];
-                    h1 = hw & 0xFFFFu; h2 = hw >> 16;
+                    if constexpr (SPLIT) { h1 = head32[c] & 0xFFFFu; h2 = head32[A + c] & 0xFFFFu; }
+                    else { const uint32_t hw = head32[c]; h1 = hw & 0xFFFFu; h2 = hw >> 16; }
                     general = (h1 != NONE16 && nxt[h1] != NONE16) || (h2 != NONE16 && nxt[h2] != NONE16);
                 }
                 ContigResult res{-INFINITY, 0};
@@ -797,7 +816,9 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                         inb |= ((K1 | K2) & 0x80000000u) != 0;
                         const uint32_t k1 = min(K1 & 0x7FFFFFFFu, max_alns), k2 = min(K2 & 0x7FFFFFFFu, max_alns);   // locs.rs:842-851
                         kk1[c] = static_cast<uint8_t>(k1); kk2[c] = static_cast<uint8_t>(k2);
-                        head32[c] = (o + n1) | (o << 16);     // chains are consumed: {start of list 2, start of list 1} in `order`
+                        // chains are consumed: {start of list 2, start of list 1} in `order`
+                        if constexpr (SPLIT) { head32[c] = o + n1; head32[A + c] = o; }
+                        else head32[c] = (o + n1) | (o << 16);
                         const PairCtx pc{ins, rec, order + o, order + o + n1, k1, k2, bl0, bl1, unm_ins_penalty, paired};
                         res = general_count(pc, max_alns, L.prob_diff);
                         cnt8[c] = static_cast<uint8_t>(res.cnt | 0x80u);
@@ -819,11 +840,24 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
             pair_barrier<BIG>();
 
             if (accepted) {
-                if (lane == 0) {
-                    pa_base = atomicAdd(R.pa_count, static_cast<unsigned long long>(total_cnt));
-                    if (pa_base + total_cnt > R.pa_cap) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
+                // The arena cursor is ONE word in memory: an atomic per read pair from every wavefront of the device queues up at its
+                // L2 channel (2.4 of the kernel's 17.4 ms at 1 M pairs). A wavefront takes PA_CHUNK entries at a time and hands
+                // them to its pairs (launches with at least PA_POOL_MIN_PAIRS pairs per wavefront; ReadsView::pa_chunk); the arena is
+                // addressed through pa_off / pa_cnt only, and lcty_reads_create adds the room (an eighth + a chunk per wavefront).
+                if (R.pa_chunk == 0 || static_cast<uint64_t>(total_cnt) * 8 > R.pa_chunk) {
+                    // small launches and unusually large pairs: their own reservation (nothing of a chunk is left unused for them)
+                    if (lane == 0) pa_base = atomicAdd(R.pa_count, static_cast<unsigned long long>(total_cnt));
+                    pa_base = __shfl(pa_base, 0);
+                } else {
+                    if (total_cnt > pool_left) {                                  // what is left (< an eighth of a chunk) stays unused
+                        if (lane == 0) pool_at = atomicAdd(R.pa_count, static_cast<unsigned long long>(R.pa_chunk));
+                        pool_at = __shfl(pool_at, 0);
+                        pool_left = R.pa_chunk;
+                    }
+                    pa_base = pool_at;
+                    pool_at += total_cnt; pool_left -= total_cnt;
                 }
-                pa_base = __shfl(pa_base, 0);
+                if (lane == 0 && pa_base + total_cnt > R.pa_cap) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
                 const bool room = pa_base + total_cnt <= R.pa_cap;
                 // ---------------- pass 3b: emit PairAlignments, contig-ascending ----------------
                 const double emit_weight = EW ? 1.0 : weight;
@@ -840,13 +874,13 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
                     PairAlnDev* out = R.pa + pa_base + my_off;
                     if (c < A) R.pa_idx[p * A + c] = my_off | (cnt << 24);      // direct (pair, contig) -> entries index
                     if (room && cnt && !general) {
-                        const uint32_t hw = head32[c];
+                        const uint32_t hw = SPLIT ? (head32[c] & 0xFFFFu) | (head32[A + c] << 16) : head32[c];
                         const Fast3 f = fast_candidates(ins, rec, hw & 0xFFFFu, hw >> 16, bl0, bl1, unm_ins_penalty, paired);
                         fast_emit(f, cnt, emit_weight, c, out);
                     }
                     if (__ballot(room && general && cnt)) {
                         if (room && general && cnt) {
-                            const uint32_t hw = head32[c];
+                            const uint32_t hw = SPLIT ? (head32[c] & 0xFFFFu) | (head32[A + c] << 16) : head32[c];
                             const PairCtx pc{ins, rec, order + (hw >> 16), order + (hw & 0xFFFFu), kk1[c], kk2[c], bl0, bl1,
                                              unm_ins_penalty, paired};
                             general_emit(pc, cnt, emit_weight, c, out);
@@ -894,6 +928,243 @@ __device__ __forceinline__ void score_reads_body(const LocusView& L, const Reads
             R.uniq_kmers[2 * p + 1] = accepted ? static_cast<uint16_t>(uk1) : 0;
         }
         pair_barrier<BIG>();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The LEAN form for the common case of counted batches: every (contig, read end) of a pair has at most ONE saved alignment.
+// Then nothing has to be chained, ordered or parked: pass 1 leaves, per (contig, end), the INDEX of the saved record (one LDS
+// exchange; an exchange that finds an index there marks the pair), and pass 3 reads that 16-byte record again — it is in the L2,
+// the pair's records were read microseconds ago — and scores it once more instead of keeping 16 bytes per record in LDS. LDS per
+// wavefront: 8 B per allele + a byte per allele (13 KB -> 2.3 KB at 256 alleles) and half the registers: the kernel is bound by
+// the latency of its dependent steps (67 % of the wavefront cycles waiting), so wavefronts in flight are what it needs.
+// A marked pair — or one whose mates are too long for the register path of the k-mer windows — is left untouched and appended
+// to `defer_list`; the general kernel scores those afterwards. Same arithmetic, same order per pair: the products are the
+// general kernel's bit for bit (tests/test_gpu_counted.py runs both).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ AlnRef ref_from_counted(const LocusView& L, const uint4 raw, uint32_t idx, double best) {
+    const Scored sc = score_counted(L, raw);
+    return AlnRef{sc.ln_prob - best, sc.start, sc.end, idx, ((raw.x >> 28) & 1u) != 0};            // normalize_probs, locs.rs:358-360
+}
+
+__global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const LocusView L, const ReadsView R) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t A = L.n_alleles;
+    uint32_t* head = reinterpret_cast<uint32_t*>(smem);                       // [2A]: saved record of (contig, end 0) | (contig, end 1)
+    uint8_t* cnt8 = reinterpret_cast<uint8_t*>(head + 2 * A);                 // [A] PairAlignments of the contig (<= 3)
+    const int lane = threadIdx.x;
+    const bool paired = L.is_paired != 0;
+    const InsLut ins{L.ins_lut, L.ins_lut_size, L.ins_n, L.ins_lnq, L.ins_lnpmf_const};
+    unsigned long long pool_at = 0, pool_left = 0;
+    for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
+        const uint64_t a0 = R.aln_off[p];
+        const uint2 meta = R.pair_meta[p];
+        const uint32_t j2 = meta.x, n_eff = meta.y;
+        const uint32_t split = min(j2, n_eff);
+        const uint32_t len0 = R.mate_len[2 * p], len1 = paired ? R.mate_len[2 * p + 1] : 0u;
+        double* mrow = R.matrix + p * A;
+        const uint4* recs = reinterpret_cast<const uint4*>(R.recs + a0);
+        const bool regs_ok = len0 <= 2016 && len1 <= 2016;
+        uint64_t bw0 = 0, bw1 = 0;
+        uint32_t nm0 = 0, nm1 = 0;
+        if (regs_ok) {
+            const uint64_t off0 = R.mate_off[2 * p], off1 = R.mate_off[2 * p + 1];
+            if (static_cast<uint32_t>(lane) * 32u < len0) {
+                bw0 = (reinterpret_cast<const uint64_t*>(R.bases2) + (off0 >> 5))[lane];
+                nm0 = (R.nmask + (off0 >> 5))[lane];
+            }
+            if (static_cast<uint32_t>(lane) * 32u < len1) {
+                bw1 = (reinterpret_cast<const uint64_t*>(R.bases2) + (off1 >> 5))[lane];
+                nm1 = (R.nmask + (off1 >> 5))[lane];
+            }
+        }
+        for (uint32_t i = lane; i < 2 * A; i += WAVE) head[i] = 0xFFFFFFFFu;
+        uint4 raw_first[GR];
+#pragma unroll
+        for (int g = 0; g < GR; g++) {
+            const uint32_t idx = g * WAVE + lane;
+            raw_first[g] = idx < n_eff ? recs[idx] : make_uint4(0, 0, 0, 0);
+        }
+        // ---------------- thresholds (lanes 0 / 1 score the primaries): as in the general kernel ----------------
+        uint32_t my_good = 0, my_thr = NONE32, my_pass = NONE32, my_state = 0;
+        if (lane < 2) {
+            const uint32_t e = lane;
+            const uint32_t pidx = e ? j2 : 0u;
+            const bool exists = e == 0 ? n_eff > 0 : (paired && j2 < n_eff);
+            if (e == 1 && !paired) my_state = 3;
+            else if (!exists) my_state = 4;
+            else {
+                const uint4 praw = recs[pidx];
+                const uint32_t read_len = e ? len1 : len0;
+                const uint32_t pcontig = praw.y & 0xFFFFu;
+                const bool is_primary = ((praw.x >> 29) & 1u) == 0;
+                if (read_len == 0 || !is_primary) my_state = 4;
+                else if ((praw.x >> 30) & 1u) my_state = 0;
+                else if (pcontig >= A) my_state = 4;
+                else {
+                    const Scored sc = score_counted(L, praw);
+                    const uint2 gp = L.edit_lut[min(read_len, L.edit_lut_size - 1)];
+                    uint32_t good = gp.x, passable = gp.y, thr = good;
+                    double compl_v = 1.0;
+                    if (L.short_reads) {
+                        const uint32_t mid = (sc.start + sc.end) / 2;
+                        const uint32_t o = L.ci_off[pcontig];
+                        const uint32_t npos = L.ci_off[pcontig + 1] - o;
+                        const uint32_t i = min(mid > L.half_neighb ? mid - L.half_neighb : 0u, npos - 1);
+                        compl_v = static_cast<double>(L.compl_cnt[o + i]) * L.compl_mult;
+                    }
+                    if (compl_v <= L.poor_compl) {
+                        thr = max(good, static_cast<uint32_t>(L.poor_compl_edit * static_cast<double>(read_len)));
+                        passable += thr - good;
+                    }
+                    my_good = good; my_thr = thr; my_pass = passable;
+                    my_state = 1u | (sc.edit <= passable ? 2u : 0u);
+                }
+            }
+        }
+        const uint32_t good0 = __shfl(my_good, 0), thr0 = __shfl(my_thr, 0), pass0 = __shfl(my_pass, 0), st0 = __shfl(my_state, 0);
+        const uint32_t good1 = __shfl(my_good, 1), thr1 = __shfl(my_thr, 1), pass1 = __shfl(my_pass, 1), st1 = __shfl(my_state, 1);
+        __syncthreads();          // head table initialised
+
+        // ---------------- pass 1 ----------------
+        uint32_t be0 = NONE32, be1 = NONE32, bad0 = 0, bad1 = 0;
+        double bl0 = -INFINITY, bl1 = -INFINITY;
+        bool multi = false;
+        const bool look = (st0 & 3u) == 3u;
+        for (uint32_t base = 0; look && base < n_eff; base += WAVE * GR) {
+            uint4 raw[GR];
+#pragma unroll
+            for (int g = 0; g < GR; g++) {
+                const uint32_t idx = base + g * WAVE + lane;
+                if (base == 0) raw[g] = raw_first[g];
+                else raw[g] = idx < n_eff ? recs[idx] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < GR; g++) {
+                const uint32_t idx = base + g * WAVE + lane;
+                const bool unmapped = ((raw[g].x >> 30) & 1u) != 0;
+                const uint32_t contig = raw[g].y & 0xFFFFu;
+                const bool primary = idx == 0 || idx == j2;
+                if (idx < n_eff && !unmapped) {                                 // an unmapped record has no alignment; unmapped primaries end the pair above
+                    const uint32_t e = idx >= split ? 1u : 0u;
+                    if (contig >= A) {
+                        if (!primary) { if (e) bad1 = 1; else bad0 = 1; }
+                    } else {
+                        const Scored sc = score_counted(L, raw[g]);
+                        if (e == 0) { be0 = min(be0, sc.edit); bl0 = fmax(bl0, sc.ln_prob); }
+                        else { be1 = min(be1, sc.edit); bl1 = fmax(bl1, sc.ln_prob); }
+                        if (sc.edit <= (e ? pass1 : pass0))                     // save (locs.rs:314)
+                            multi |= atomicExch(&head[e * A + contig], idx) != 0xFFFFFFFFu;
+                    }
+                }
+            }
+        }
+        be0 = wave_min_u32(be0); be1 = wave_min_u32(be1);
+        bl0 = wave_max_f64(bl0); bl1 = wave_max_f64(bl1);
+        bad0 = wave_sum_u32(bad0); bad1 = wave_sum_u32(bad1);
+        __syncthreads();
+        if (!regs_ok || __ballot(multi) != 0ull) {
+            // not this kernel's pair: untouched, the general kernel takes it
+            if (lane == 0) R.defer_list[atomicAdd(R.defer_count, 1u)] = static_cast<uint32_t>(p);
+            continue;
+        }
+
+        const bool wm0 = look && be0 <= (L.strict_subset ? pass0 : thr0) && !bad0;
+        const bool saved1 = (st1 & 3u) == 3u;
+        const bool err = (st0 & 4u) || (look && bad0) || (wm0 && ((st1 & 4u) || (saved1 && bad1)));
+        if (err && lane == 0) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_INVALID_DATA));
+        const bool wm1 = !paired || (saved1 && be1 <= (L.strict_subset ? pass1 : thr1));
+        bool accepted = wm0 && wm1 && !err;
+        double weight = 1.0;
+        if (accepted) {
+            weight *= be0 <= good0 ? 1.0 : sqrt(static_cast<double>(good0) / static_cast<double>(be0));      // locs.rs:565
+            if (paired) weight *= be1 <= good1 ? 1.0 : sqrt(static_cast<double>(good1) / static_cast<double>(be1));
+        }
+        uint8_t status = LCTY_READ_POORLY_MAPPED;
+        uint32_t total_cnt = 0, uk0 = 0, uk1 = 0;
+        double unmapped_prob = 0.0;
+        uint64_t pa_base = 0;
+        if (!accepted && lane == 0) R.recover_w[p] = -1.0;
+        if (accepted) {
+            pair_unique_kmers_regs(L.kset, L.kset_mask, L.undef_in_set, L.k, len0, len1, bw0, bw1, nm0, nm1, lane, &uk0, &uk1);
+            const uint32_t paired_count = (uk0 + uk1) & 0xFFFFu;
+            double kw = L.weight_interc + static_cast<double>(paired_count) * L.weight_mult;
+            kw = kw < 0.0 ? 0.0 : (kw > 1.0 ? 1.0 : kw);
+            weight *= kw;
+            const uint32_t max_alns = weight >= L.min_weight ? LCTY_MAX_USED_ALNS : LCTY_MAX_UNUSED_ALNS;
+            const double unm_ins_penalty = L.unmapped_penalty + L.insert_penalty;
+            unmapped_prob = paired ? weight * (2.0 * L.unmapped_penalty + L.insert_penalty) : weight * L.unmapped_penalty;
+            const AlnRef none{0.0, 0, 0, NONE32, false};
+            auto candidates = [&](uint32_t c) -> Fast3 {
+                const uint32_t h1 = head[c], h2 = head[A + c];
+                const bool has1 = h1 != 0xFFFFFFFFu, has2 = h2 != 0xFFFFFFFFu;
+                const uint4 r1 = recs[has1 ? h1 : 0u], r2 = recs[has2 ? h2 : 0u];      // L2: read in pass 1 a moment ago
+                return fast_from_refs(ins, has1 ? ref_from_counted(L, r1, h1, bl0) : none, has2 ? ref_from_counted(L, r2, h2, bl1) : none,
+                                      has1, has2, unm_ins_penalty, paired);
+            };
+            // ---------------- pass 3a ----------------
+            bool inb = false;
+            for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
+                const uint32_t c = c0 + lane;
+                ContigResult res{-INFINITY, 0};
+                if (c < A) {
+                    const Fast3 f = candidates(c);
+                    const uint32_t clen = L.allele_len[c];
+                    if (f.has1) { const uint32_t mid = (f.a1.start + f.a1.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                    if (f.has2) { const uint32_t mid = (f.a2.start + f.a2.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                    if (f.has1 || f.has2) res = fast_count(f, max_alns, L.prob_diff);
+                    cnt8[c] = static_cast<uint8_t>(res.cnt);
+                    mrow[c] = res.cnt ? res.best * weight : unmapped_prob;
+                    total_cnt += res.cnt;
+                }
+            }
+            const bool any_inb = __ballot(inb) != 0ull;
+            total_cnt = wave_sum_u32(total_cnt);
+            if (lane == 0) R.recover_w[p] = any_inb ? weight : -1.0;
+            const bool edit_good = be0 <= thr0 && (!paired || be1 <= thr1);
+            if (!any_inb) { status = LCTY_READ_OUT_OF_BOUNDS; accepted = false; }
+            else if (!edit_good) { status = LCTY_READ_POORLY_MAPPED; accepted = false; }
+            else status = weight >= L.min_weight ? LCTY_READ_GOOD : LCTY_READ_FEW_KMERS;
+            if (accepted) {
+                if (R.pa_chunk == 0 || static_cast<uint64_t>(total_cnt) * 8 > R.pa_chunk) {
+                    if (lane == 0) pa_base = atomicAdd(R.pa_count, static_cast<unsigned long long>(total_cnt));
+                    pa_base = __shfl(pa_base, 0);
+                } else {
+                    if (total_cnt > pool_left) {
+                        if (lane == 0) pool_at = atomicAdd(R.pa_count, static_cast<unsigned long long>(R.pa_chunk));
+                        pool_at = __shfl(pool_at, 0);
+                        pool_left = R.pa_chunk;
+                    }
+                    pa_base = pool_at;
+                    pool_at += total_cnt; pool_left -= total_cnt;
+                }
+                if (lane == 0 && pa_base + total_cnt > R.pa_cap) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
+                const bool room = pa_base + total_cnt <= R.pa_cap;
+                // ---------------- pass 3b: every lane wrote its own cnt8 entries: no barrier in between ----------------
+                uint32_t run = 0;
+                for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
+                    const uint32_t c = c0 + lane;
+                    const uint32_t cnt = c < A ? cnt8[c] : 0u;
+                    uint32_t tot;
+                    const uint32_t my_off = run + wave_excl_scan_u32(cnt, lane, &tot);
+                    run += tot;
+                    if (c < A) R.pa_idx[p * A + c] = my_off | (cnt << 24);
+                    if (room && cnt) fast_emit(candidates(c), cnt, weight, c, R.pa + pa_base + my_off);
+                }
+            }
+        }
+        if (status != LCTY_READ_GOOD)
+            for (uint32_t c = lane; c < A; c += WAVE) mrow[c] = 0.0;
+        if (lane == 0) {
+            R.status[p] = status;
+            R.weight[p] = accepted ? weight : 0.0;
+            R.unmapped_prob[p] = accepted ? unmapped_prob : 0.0;
+            R.pa_off[p] = accepted ? pa_base : 0ull;
+            R.pa_cnt[p] = accepted ? total_cnt : 0u;
+            R.uniq_kmers[2 * p] = accepted ? static_cast<uint16_t>(uk0) : 0;
+            R.uniq_kmers[2 * p + 1] = accepted ? static_cast<uint16_t>(uk1) : 0;
+        }
+        __syncthreads();
     }
 }
 
@@ -976,10 +1247,33 @@ void launch_score_reads(lcty_reads* reads) {
         reads->d_park.ensure(stride * grid);
         R.park = reads->d_park.p; R.park_stride = stride;
     }
+    R.pa_chunk = reads->pa_pooled && R.n_pairs / grid >= PA_POOL_MIN_PAIRS ? PA_CHUNK : 0u;
     // the arena cursor goes back to where the pairs on the device start (0 unless a streaming batch has dropped chunks)
     if (reads->raw_first == 0) reads->d_pa_count.zero(ctx->stream);
     else reads->d_pa_count.upload(&reads->pa_at_raw_first, 1, ctx->stream);
+    R.defer_list = nullptr; R.defer_count = nullptr; R.only_list = nullptr; R.only_count = nullptr;
+    // Counted batches: the lean kernel first (at most one saved alignment per contig and read end: the rule), the general kernel
+    // on the pairs it left. lcty_ctx_set_knob "score_lean" 0: the general kernel on everything.
+    const bool lean = reads->counted && !big && !explicit_weights && L.k <= 31 && L.n_alleles <= 16000 && ctx->knob("score_lean", 1) != 0;
+    if (lean) {
+        reads->d_defer_list.ensure(std::max<uint64_t>(R.n_pairs, 1)); reads->d_defer_count.ensure(1);
+        reads->d_defer_count.zero(ctx->stream);
+        R.defer_list = reads->d_defer_list.p; R.defer_count = reads->d_defer_count.p;
+    }
     ctx->timed(LCTY_K_SCORE, [&] {
+        if (lean) {
+            const size_t lean_lds = (static_cast<size_t>(L.n_alleles) * 9 + 15) & ~static_cast<size_t>(15);
+            if (lean_lds > 48 * 1024)
+                LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_counted_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lean_lds)));
+            const uint32_t lean_per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, lds_max / lean_lds)));
+            const uint64_t lean_grid = std::max<uint64_t>(1, std::min<uint64_t>(R.n_pairs, static_cast<uint64_t>(cus) * lean_per_cu));
+            ReadsView RL = R;
+            RL.pa_chunk = reads->pa_pooled && R.n_pairs / lean_grid >= PA_POOL_MIN_PAIRS ? PA_CHUNK : 0u;
+            hipLaunchKernelGGL(score_counted_lean_kernel, dim3(static_cast<uint32_t>(lean_grid)), dim3(WAVE), lean_lds, ctx->stream, L, RL);
+            R.only_list = R.defer_list; R.only_count = R.defer_count;
+            R.pa_chunk = 0;                                                     // the few pairs left reserve their own entries
+        }
         hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs);
     });
     LCTY_HIP(hipGetLastError());

@@ -799,7 +799,8 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         reads->n_recs = m_aln[R]; reads->n_cigar = m_cig[R];
         reads->cap_recs = reads->n_recs; reads->cap_cigar = reads->n_cigar;           // the merged tables are exactly full
         // the pair-alignment arena was sized for the records of lcty_reads_create (same bound as there)
-        const uint64_t pa_cap = std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * reads->cap_pairs * A, 2 * reads->n_recs + reads->cap_pairs) + 64;
+        uint64_t pa_cap = std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * reads->cap_pairs * A, 2 * reads->n_recs + reads->cap_pairs) + 64;
+        if (reads->pa_pooled) pa_cap += pa_cap / 8 + static_cast<uint64_t>(PA_CHUNK) * PA_MAX_GRID;   // lcty_reads_create
         // (a streaming batch keeps the arena it was created with: the PairAlignments of the chunks before this one live in it)
         if (!reads->streaming && reads->d_pa.n < pa_cap) reads->d_pa.alloc(pa_cap);
         reads->max_recs_per_pair = std::max<uint32_t>(reads->streaming ? reads->max_recs_per_pair : 0u, static_cast<uint32_t>(max_recs));

@@ -76,3 +76,44 @@ def test_counted_edge_cases_and_misuse(gpu_ctx):
     with pytest.raises(_lib.LocityperError) as e:
         raw.append(ch, counted=True)
     assert e.value.code == cdefs.ERR_INVALID_INPUT
+
+
+def test_lean_kernel_equals_the_general_kernel(gpu_ctx):
+    """Counted batches go through the lean scoring kernel (at most one saved alignment per contig and read end) and the pairs it
+    leaves through the general one (lcty_score.hip). The same batch with the knob "score_lean" 0 — the general kernel on every
+    pair — must give the same products bit for bit, also when many pairs are left to the general kernel (several secondaries of a
+    read end on one contig), for single-end reads, and against the oracle."""
+    from tests.test_gpu_parity import random_pairs
+    rng = np.random.default_rng(41)
+    alleles = random_alleles(9, 4000, seed=8)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, counts, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, counts, cnt_off, 25, bg, p)
+    ol = O.OracleLocus(seqs, seq_off, counts, cnt_off, 25, bg, p)
+    # (a counted alignment cannot stand for a record with an empty CIGAR: those pairs stay with the record form)
+    pairs = [q for q in random_pairs(rng, alleles, 1500) if all(c != "" or (fl & cdefs.FLAG_UNMAPPED) for _, _, fl, c in q["recs"])]
+    assert len(pairs) > 1000
+    ch = cdefs.ReadsChunk.from_pairs(pairs)
+    cases = [ch]
+    L = synth.SynthLocus(40, 3000, seed=77, base_len=12_000)                 # the benchmark's shape: one record per allele and end
+    p2 = api.resolve_params(api.default_params(), L.bg)
+    loc2 = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p2)
+    try:
+        for locus, chunk in ((loc, ch), (loc2, L.reads(0, 3000))):
+            gpu_ctx.set_knob("score_lean", 1)
+            lean = api.AllAlignments.load(locus, chunk, counted=True)
+            gpu_ctx.set_knob("score_lean", 0)
+            general = api.AllAlignments.load(locus, chunk, counted=True)
+            _same(lean, general)
+            lean.score()                                                    # still with the knob at 0: the same batch through the other kernel
+            _same(lean, general)
+    finally:
+        gpu_ctx.set_knob("score_lean", -1)
+    oa = ol.load(ch)
+    cnt = api.AllAlignments.load(loc, ch, counted=True)
+    st, w, unm, uk = cnt.status()
+    assert np.array_equal(st, oa.status) and np.array_equal(uk, oa.uniq_kmers)
+    assert np.abs(cnt.best_aln_matrix() - oa.best_aln_matrix()).max() < 1e-9
+    off, pa = cnt.pair_alns()
+    assert np.array_equal(off, oa.pa_off) and np.array_equal(pa["mid1"], oa.pair_alns["mid1"]) and np.array_equal(pa["contig"], oa.pair_alns["contig"])
