@@ -70,6 +70,11 @@ def parse_args():
                     help="one locus over all ranks, whole path: every rank scores and prefilters all reads of the locus (replicated), the "
                          "(genotype, attempt) chains of both solver stages are dealt to the ranks and their likelihoods all-gathered on the "
                          "devices (RCCL; lcty_solve_stage_sharded, SURVEY 8e level 3); strong scaling. Not the default either")
+    ap.add_argument("--distinct-loci", type=int, default=3,
+                    help="extra measurement: a queue of loci that are NOT resident — this many distinct loci in page-locked host memory, every "
+                         "position of the queue uploaded (lcty_reads_append_counted on the copy stream, from a loader thread) while the position "
+                         "before it is solved, three batch objects rotating (lcty_solve_queue_fed); 0 = skip")
+    ap.add_argument("--distinct-steps", type=int, default=6, help="positions of the timed queue of the --distinct-loci measurement")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (launch-path checks on a one-GPU box; reported in the line)")
     ap.add_argument("--pipeline", type=int, default=0, help="ignored (round 1 option; the queue of loci is the default mode now)")
     ap.add_argument("--recruit-sample", type=int, default=8_000_000,
@@ -264,6 +269,100 @@ def spawn_ranks(args):
     sys.stdout.write(line)
     sys.stdout.flush()
     sys.exit(0)
+
+
+def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_step):
+    """The queue as `locityper genotype` meets it: every locus arrives from the host. D distinct loci (their counted alignment tables
+    and bases in page-locked memory: 8.3 GB each at 1 M x 256), K positions cycling over them; a loader thread resets one of three batch
+    objects (lcty_reads_reset), uploads the position's chunks (lcty_reads_append_counted: copies on the context's copy stream, the CSR
+    validation on the host's cores next to them) and hands it to lcty_solve_queue_fed, which releases a batch when its last stage is
+    done. Timed: K positions, the first upload included."""
+    import threading
+    D, K, A = args.distinct_loci, args.distinct_steps, args.alleles
+    for b in batches:                                          # the resident loci of the main measurement make room
+        b.close()
+    ctx.trim()
+    t0 = time.time()
+    host = []                                                  # per locus: (SynthLocus, Locus, [(pinned chunk, pinned counted alignments)])
+    n_chunks = (args.pairs + args.chunk - 1) // args.chunk
+    from locityper_amd.cdefs import ReadsChunk, ALN_REC_DTYPE
+    none_recs, none_cig = np.zeros(0, dtype=ALN_REC_DTYPE), np.zeros(0, dtype=np.uint32)
+    caps = None
+    up_bytes = 0
+    for j in range(D):
+        if j < len(loci): L, loc = loci[j]
+        else:
+            L = synth.SynthLocus(A, args.pairs, seed=synth.SEED + 100 + j)
+            loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, api.resolve_params(api.default_params(), L.bg))
+        chunks = []
+        tb = tr = 0
+        for ci in range(n_chunks):
+            lo = ci * args.chunk
+            ch = L.reads(lo, min(args.chunk, args.pairs - lo))
+            alns = ctx.pinned_like(ch.counted(loc.allele_len))
+            pc = ReadsChunk(*(ctx.pinned_like(a) for a in (ch.mate_len, ch.mate_off, ch.bases2, ch.nmask, ch.aln_off)), none_recs,
+                            np.zeros(ch.n_pairs + 1, dtype=np.uint64), none_cig)
+            chunks.append((pc, alns))
+            tb += ch.n_bases; tr += len(ch.recs)
+            if j == 0: up_bytes += alns.nbytes + pc.bases2.nbytes + pc.nmask.nbytes + pc.mate_len.nbytes + pc.mate_off.nbytes + pc.aln_off.nbytes
+            del ch
+        caps = (max(caps[0], tb), max(caps[1], tr)) if caps else (tb, tr)
+        host.append((L, loc, chunks))
+    ctx.set_knob("arena_cap_pct", 35)                         # one PairAlignment per (pair, allele) is the rule here; the bound is two per record
+    cap_bases = (int(caps[0] * 1.01) + 1024) // 32 * 32 + 32
+    rot = [api.AllAlignments(host[0][1], args.pairs, cap_bases, int(caps[1] * 1.01) + 4096, 0) for _ in range(3)]
+    ctx.set_knob("arena_cap_pct", -1)
+    setup_s = time.time() - t0
+
+    def run(k, first_it):
+        ready = [threading.Event() for _ in range(k)]
+        free = [threading.Semaphore(1) for _ in range(3)]
+        problems = []
+        load_s = [0.0] * k
+
+        def loader():
+            try:
+                for i in range(k):
+                    free[i % 3].acquire()
+                    tl = time.perf_counter()
+                    L, loc, chunks = host[(first_it + i) % D]
+                    b = rot[i % 3]
+                    b.reset(loc)
+                    for pc, alns in chunks:
+                        b.append(pc, counted=alns)
+                    load_s[i] = time.perf_counter() - tl
+                    ready[i].set()
+            except BaseException as e:                         # the queue must not wait for ever
+                problems.append(e)
+                for ev in ready: ev.set()
+
+        def acquire(i):
+            ready[i].wait()
+            if problems: raise problems[0]
+            return rot[i % 3]
+
+        th = threading.Thread(target=loader)
+        ctx.synchronize()
+        tq = time.perf_counter()
+        th.start()
+        calls = api.solve_queue_fed(k, acquire, lambda i: free[i % 3].release(), stages, master_seeds=[3000 + first_it + i for i in range(k)])
+        ctx.synchronize()
+        dt = time.perf_counter() - tq
+        th.join()
+        ok = all(tuple(int(x) for x in gts[int(c.ixs[0])]) == tuple(host[(first_it + i) % D][0].true_genotype) for i, c in enumerate(calls))
+        return dt, ok, load_s
+
+    run(3, 0)                                                 # every batch object once: workspaces, page tables
+    dt, ok, load_s = run(K, 1)
+    for b in rot: b.close()
+    ms = 1e3 * dt / K
+    return {"what": f"{K} positions over {D} distinct loci of {args.pairs} read pairs x {A} alleles; every position uploaded from page-locked host memory "
+                    "(lcty_reads_reset + lcty_reads_append_counted from a loader thread, copy stream) while the position before it is solved "
+                    "(lcty_solve_queue_fed, three batch objects); the first upload of the queue is inside the timed region",
+            "ms_per_step": ms, "read_pairs_per_s": args.pairs * K / dt, "resident_ms_per_step": resident_ms_per_step,
+            "ratio_to_resident": ms / resident_ms_per_step, "all_calls_equal_truth": ok,
+            "upload_GB_per_locus": up_bytes / 1e9, "upload_and_validate_s_per_locus": float(np.median(load_s)),
+            "upload_GBs": up_bytes / 1e9 / float(np.median(load_s)), "setup_s": setup_s}
 
 
 def main():
@@ -751,6 +850,9 @@ def main():
             for i in range(nsq):
                 ot.recruit(sq[i, 0].tobytes(), sq[i, 1].tobytes())
             out["cpu_baseline"]["recruitment_read_pairs_per_s"] = nsq / (time.perf_counter() - tc)
+    if args.distinct_loci >= 2 and queue_mode and world == 1 and args.format == "counted":
+        progress("queue of distinct loci, uploads inside the steps")
+        out["distinct_loci_queue"] = distinct_loci_leg(args, ctx, loci, batches, stages, gts, ms_per_step)
     real_stdout.write(json.dumps(out) + "\n")
     real_stdout.flush()
 

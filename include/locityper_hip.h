@@ -221,7 +221,8 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  *       sliding from 1 024 bases on);   "solve_stats"   1: per-stage iteration counts on stderr;   "queue_trace"   1: wall-clock marks of the phases of every locus of
  *       lcty_solve / lcty_solve_queue on stderr;   "gather_chunk_mb"   staging size of lcty_solve_stage_read_sharded;
  *   "prefilter_gram"   0: always the f64 tile kernel, 1: the integer Gram contraction on the matrix cores whenever it applies
- *       (default: from 512 alleles on);   "score_lean"   0: counted batches go through the general scoring kernel only (default 1: the lean kernel first, the general
+ *       (default: from 512 alleles on);   "arena_cap_pct"   p: batches created afterwards (lcty_reads_create) get p % of the bound on their PairAlignment arena (two per
+ *       record; one per (pair, allele) is the rule — an arena that is too small fails loudly);   "score_lean"   0: counted batches go through the general scoring kernel only (default 1: the lean kernel first, the general
  *       one on the pairs it leaves);   "comm_fail_at"   k: the k-th status agreement of a multi-GPU call fails on this rank (tests of
  *       the error path of the exchanges);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the
  *       f64 kernel takes the batch);   "prefilter_gram_levels"   levels of a row the contraction takes (<= 16; rows with more go
@@ -330,6 +331,10 @@ int32_t lcty_reads_append(lcty_reads* reads, const lcty_reads_host* chunk);
  * cigar_off and cigar are not read. A batch holds records or counted alignments, never both. lcty_score_reads, the prefilter and
  * the solver stages see no difference; results equal the record path's bit for bit (tests/test_gpu_counted.py). */
 int32_t lcty_reads_append_counted(lcty_reads* reads, const lcty_reads_host* chunk, const lcty_aln_counted* alns);
+/* An empty batch again, bound to `locus` (same context, not more alleles than the locus it was created for): every buffer stays.
+ * For queues of loci that rotate over a few batch objects — allocating or releasing tens of GB per locus would wait for every
+ * stream of the device. Nothing of the batch may be in use (see lcty_solve_queue_fed's release). */
+int32_t lcty_reads_reset(lcty_reads* reads, lcty_locus* locus);
 void    lcty_reads_destroy(lcty_reads* reads);
 int32_t lcty_reads_n_pairs(const lcty_reads* reads, uint64_t* out);
 
@@ -590,6 +595,17 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
  * again later in the queue: it is scored again). master_seeds[n_batches]; priors NULL or [n_batches] pointers (NULL = no priors). */
 int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages,
                          const uint64_t* master_seeds, const double* const* priors, lcty_call* out);
+/* The same queue fed one batch at a time, for loci that are not all resident: `acquire(user, i)` is called right before position i is
+ * scored and returns its batch (NULL: the queue ends with LCTY_ERR_INVALID_INPUT) — typically filled by another host thread, with
+ * lcty_reads_append* on page-locked chunks (their copies have a stream of their own), while position i - 1 is being solved;
+ * `release(user, i)` (may be NULL) when the last stage of position i is done and nothing of its batch is in use: lcty_reads_reset can
+ * then bind the object to the locus of a later position. Position i is released before position i + 2 is acquired, so three batch
+ * objects carry a queue of any length. The loading of locus i + 1 next to analyze_locus of locus i (genotype.rs:1331-1351). */
+typedef lcty_reads* (*lcty_queue_acquire_fn)(void* user, uint32_t position);
+typedef void (*lcty_queue_release_fn)(void* user, uint32_t position);
+int32_t lcty_solve_queue_fed(uint32_t n_loci, lcty_queue_acquire_fn acquire, lcty_queue_release_fn release, void* user, uint32_t ploidy,
+                             const lcty_stage* stages, uint32_t n_stages, const uint64_t* master_seeds, const double* const* priors,
+                             lcty_call* out);
 
 /* Diagnostics of the last lcty_solve_stage on this batch: chains run, solver iterations (greedy iterations /
  * annealing moves) and accepted moves summed over the chains (stoch.rs has no counterpart; used by bench.py). */

@@ -80,6 +80,8 @@ SIGNATURES = {
     "lcty_stages_default": (I32, [P(Stage), P(U32)]),
     "lcty_solve": (I32, [VP, U32, P(Stage), U32, U64, VP, P(Call), VP, VP, VP]),
     "lcty_solve_queue": (I32, [VP, U32, U32, P(Stage), U32, VP, VP, VP]),
+    "lcty_solve_queue_fed": (I32, [U32, VP, VP, VP, U32, P(Stage), U32, VP, VP, VP]),
+    "lcty_reads_reset": (I32, [VP, VP]),
     "lcty_solve_stats": (I32, [VP, P(U64), P(U64), P(U64)]),
     "lcty_discard_improbable": (I32, [VP, VP, VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),

@@ -240,10 +240,18 @@ class AllAlignments:
         self.score()
         return self
 
+    def reset(self, locus):
+        """lcty_reads_reset: an empty batch again, bound to `locus` (buffers stay)."""
+        check(lib().lcty_reads_reset(self._h, locus._h))
+        self.locus = locus
+        self._scored = False
+
     def append(self, chunk, counted=False):
+        """counted: True (the operations of the chunk's records are counted here, on the host) or the (n_records, 4) u32 array of
+        lcty_aln_counted entries made earlier (ReadsChunk.counted), e.g. in page-locked memory"""
         hs = chunk.host_struct()
-        if counted:
-            alns = np.ascontiguousarray(chunk.counted(self.locus.allele_len), dtype=np.uint32)
+        if counted is not False and counted is not None:
+            alns = np.ascontiguousarray(chunk.counted(self.locus.allele_len) if counted is True else counted, dtype=np.uint32)
             check(lib().lcty_reads_append_counted(self._h, C.byref(hs), alns.ctypes.data))
         else:
             check(lib().lcty_reads_append(self._h, C.byref(hs)))
@@ -594,6 +602,40 @@ def solve_queue(batches, stages=None, master_seeds=None, priors=None, ploidy=2):
         pri_ptr = arr
     calls = (cdefs.Call * n)()
     check(lib().lcty_solve_queue(handles, n, ploidy, stages, len(stages), seeds.ctypes.data, pri_ptr, calls))
+    return list(calls)
+
+
+def solve_queue_fed(n_loci, acquire, release=None, stages=None, master_seeds=None, ploidy=2):
+    """lcty_solve_queue_fed: the queue with its batches handed over one at a time. acquire(i) -> AllAlignments (filled; may block until a
+    loader thread is done with it), release(i) is called when nothing of position i's batch is in use any more. The library call
+    runs without the interpreter lock; the callbacks take it."""
+    stages = default_stages() if stages is None else stages
+    seeds = np.ascontiguousarray(np.arange(1, n_loci + 1) if master_seeds is None else master_seeds, dtype=np.uint64)
+    assert len(seeds) == n_loci
+    failure = []
+
+    @C.CFUNCTYPE(VP, VP, U32)
+    def _acquire(_user, i):
+        try:
+            b = acquire(int(i))
+            return None if b is None else b._h.value
+        except BaseException as e:               # an exception cannot cross the C frames: the queue ends, the exception is raised below
+            failure.append(e)
+            return None
+
+    @C.CFUNCTYPE(None, VP, U32)
+    def _release(_user, i):
+        try:
+            if release is not None:
+                release(int(i))
+        except BaseException as e:
+            failure.append(e)
+
+    calls = (cdefs.Call * n_loci)()
+    rc = lib().lcty_solve_queue_fed(n_loci, C.cast(_acquire, VP), C.cast(_release, VP), None, ploidy, stages, len(stages), seeds.ctypes.data, None, calls)
+    if failure:
+        raise failure[0]
+    check(rc)
     return list(calls)
 
 

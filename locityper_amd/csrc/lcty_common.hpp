@@ -168,6 +168,15 @@ struct lcty_ctx {
         if (!side) LCTY_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
         return side;
     }
+    // The chunks of a batch travel on a stream of their own (lcty_reads_append*): a host thread can fill the batch of the NEXT
+    // locus over PCIe while the kernels of the current one have the other two streams (lcty_solve_queue_fed).
+    hipStream_t copy = nullptr;
+    std::mutex copy_mutex;
+    hipStream_t copy_stream() {
+        std::lock_guard<std::mutex> lock(copy_mutex);
+        if (!copy) LCTY_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+        return copy;
+    }
     // Per-chain device state of the solver stages (lcty_solve.hip), one per stream of the context. Grow-only and kept between
     // stages and loci: at 1 M read pairs the records of 5 000 chains are ~150 GB, and allocating / freeing that per stage costs
     // more than the stage. lcty_ctx_trim releases it.

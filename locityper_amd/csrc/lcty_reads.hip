@@ -139,9 +139,13 @@ static int32_t create_reads(lcty_locus* locus, uint64_t cap_pairs, uint64_t raw_
         // large launches hand the arena out in chunks per wavefront (lcty_device.hpp: PA_CHUNK): room for what stays unused
         // (launches of at least PA_POOL_MIN_PAIRS pairs per wavefront: only batches that can hold that many pairs at a time; a
         // streaming batch whose caller said how many PairAlignments to make room for keeps exactly that room)
+        uint64_t pa_cap_used = pa_cap;
+        // lcty_ctx_set_knob "arena_cap_pct": that share of the bound (a caller that knows its data: one PairAlignment per (pair, allele)
+        // is the rule, the bound is two per record; an arena that turns out too small fails loudly)
+        if (!streaming && ctx->knob("arena_cap_pct", 0) > 0) pa_cap_used = std::max<uint64_t>(64, pa_cap / 100 * static_cast<uint64_t>(ctx->knob("arena_cap_pct", 0)));
         R->pa_pooled = raw_pairs >= static_cast<uint64_t>(PA_POOL_MIN_PAIRS) * PA_MAX_GRID / 2 && !(streaming && cap_pair_alns);
-        const uint64_t pa_slack = R->pa_pooled ? pa_cap / 8 + static_cast<uint64_t>(PA_CHUNK) * PA_MAX_GRID : 0;
-        R->d_pa.alloc(pa_cap + pa_slack);
+        const uint64_t pa_slack = R->pa_pooled ? pa_cap_used / 8 + static_cast<uint64_t>(PA_CHUNK) * PA_MAX_GRID : 0;
+        R->d_pa.alloc(pa_cap_used + pa_slack);
         R->d_pa_count.alloc(1);
         R->d_pa_off.alloc(std::max<uint64_t>(cap_pairs, 1));
         R->d_pa_cnt.alloc(std::max<uint64_t>(cap_pairs, 1));
@@ -205,9 +209,15 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
             fail(LCTY_ERR_INVALID_INPUT, "chunk exceeds the capacity given to lcty_reads_create%s", R->streaming ? "_streaming" : "");
         // The bulk of the chunk is on its way before the host looks at it: from page-locked memory (lcty_host_alloc) the copies run while
         // the host validates; a chunk that fails validation leaves bytes behind the batch's counters, which nothing reads.
-        hipStream_t s = ctx->stream;
+        // The copies run on the context's copy stream, not on the stream of its kernels: the kernels of another batch (the locus
+        // before this one in a queue) do not hold them back, and this call waits for its own copies only. Whatever ends the call
+        // early — a failed validation, an exception of the runtime — waits for the copies first: they read the caller's chunk.
+        hipStream_t s = ctx->copy_stream();
+        struct CopiesDone { hipStream_t s; bool armed = true; ~CopiesDone() { if (armed) (void)hipStreamSynchronize(s); } } copies_done{s};
+        if (!dev && R->scored) LCTY_HIP(hipStreamSynchronize(ctx->stream));   // a scored batch that grows: its kernels have read the old tables
         static_assert(sizeof(lcty_aln_counted) == sizeof(lcty_aln_rec), "both record forms are 16 bytes");
         if (dev) {
+            LCTY_HIP(hipStreamSynchronize(ctx->stream));                          // the mapping kernels that made the records
             if (R->n_bases / 16 + nb / 16 > R->d_bases2.n || R->n_recs + nr > R->d_recs.n || R->n_cigar + nc > R->d_cigar.n) fail(LCTY_ERR_RUNTIME, "device buffer overflow");
             LCTY_HIP(hipMemcpyAsync(R->d_bases2.p + R->n_bases / 16, dev->bases2, nb / 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
             LCTY_HIP(hipMemcpyAsync(R->d_nmask.p + R->n_bases / 32, dev->nmask, nb / 32 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
@@ -283,9 +293,15 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
             t_max_recs[tid] = mr; t_max_cig[tid] = mc; t_max_rec_cig[tid] = mrc;
         };
         {
+            // threads that cannot be started: their share is walked here (a thread that did start is always joined)
             std::vector<std::thread> th;
-            for (uint32_t tid = 1; tid < n_threads; tid++) th.emplace_back(validate, tid);
+            std::vector<uint32_t> here;
+            for (uint32_t tid = 1; tid < n_threads; tid++) {
+                try { th.emplace_back(validate, tid); }
+                catch (const std::system_error&) { here.push_back(tid); }
+            }
             validate(0);
+            for (uint32_t tid : here) validate(tid);
             for (auto& x : th) x.join();
         }
         {
@@ -311,6 +327,7 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
         R->d_cigar_off.upload(co.data(), n, s, raw_pairs + 1);
         R->d_pair_meta.upload(meta.data(), n, s, raw_pairs);
         LCTY_HIP(hipStreamSynchronize(s));
+        copies_done.armed = false;
         R->n_pairs += n; R->n_bases += nb; R->n_recs += nr; R->n_cigar += nc;
         R->max_recs_per_pair = max_recs;
         R->max_cigar_per_pair = static_cast<uint32_t>(std::min<uint64_t>(max_cig, 0xFFFFFFF0ull));
@@ -336,6 +353,29 @@ int32_t lcty_reads_append_counted(lcty_reads* R, const lcty_reads_host* h, const
 }
 
 
+
+// An empty batch again, bound to `locus` (same context, no more alleles than the batch was made for): the buffers stay, so a queue of
+// distinct loci rotates over a few batch objects instead of allocating tens of GB per locus (an allocation or a release waits
+// for every stream of the device). The caller makes sure nothing of the batch is in use any more.
+int32_t lcty_reads_reset(lcty_reads* R, lcty_locus* locus) {
+    return guarded([&] {
+        if (!R || !locus) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        if (locus->ctx != R->ctx) fail(LCTY_ERR_INVALID_INPUT, "the locus belongs to another context");
+        if (static_cast<uint64_t>(locus->n_alleles) * R->cap_pairs > R->d_matrix.n)
+            fail(LCTY_ERR_INVALID_INPUT, "the batch was made for a locus of fewer alleles (%u now)", locus->n_alleles);
+        R->locus = locus;
+        R->n_pairs = R->n_bases = R->n_recs = R->n_cigar = 0;
+        R->max_recs_per_pair = R->max_cigar_per_pair = R->max_cigar_per_rec = 0;
+        R->scored = false; R->counted = false; R->raw_first = 0; R->pa_at_raw_first = 0;
+        R->good_valid = false; R->loc_table_valid = false; R->n_scores = 0; R->n_good_cached = 0;
+        R->ctx->activate();
+        hipStream_t s = R->ctx->copy_stream();
+        R->d_err.zero(s); R->d_pa_count.zero(s);
+        const uint64_t zero = 0;
+        R->d_mate_off.upload(&zero, 1, s); R->d_aln_off.upload(&zero, 1, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+    });
+}
 
 void lcty_reads_destroy(lcty_reads* reads) {
     if (!reads) return;

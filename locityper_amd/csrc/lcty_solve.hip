@@ -2762,6 +2762,67 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
     });
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+// the queue of lcty_solve_queue / lcty_solve_queue_fed: `batch_of(i)` right before position i is scored, `done_with(i)` once its
+// last stage has been joined
+template <typename GET, typename DONE>
+void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages,
+               const uint64_t* master_seeds, const double* const* priors, lcty_call* out) {
+    std::unique_ptr<LocusRun> prev;
+    std::thread tail_thread;
+    int32_t tail_rc = LCTY_OK; std::string tail_msg;
+    lcty_ctx* ctx = nullptr;
+    uint32_t tail_of = 0;
+    auto release_gate = [&] {
+        if (!ctx) return;
+        { std::lock_guard<std::mutex> lock(ctx->gate.m); if (ctx->gate.target > ctx->gate.epoch) ctx->gate.epoch = ctx->gate.target; }
+        ctx->gate.cv.notify_all();
+    };
+    auto join_tail = [&] {
+        const bool had = tail_thread.joinable();
+        if (had) tail_thread.join();
+        prev.reset();
+        if (tail_rc != LCTY_OK) { const int32_t rc = tail_rc; tail_rc = LCTY_OK; fail(rc, "%s", tail_msg.c_str()); }
+        if (had) done_with(tail_of);
+    };
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            auto R = std::make_unique<LocusRun>();
+            R->reads = batch_of(i);
+            ctx = R->reads->ctx;
+            R->ploidy = ploidy; R->stages = stages; R->n_stages = n_stages; R->master_seed = master_seeds[i];
+            R->priors = priors ? priors[i] : nullptr; R->out = &out[i];
+            try { R->head(true); }
+            catch (...) { release_gate(); throw; }
+            release_gate();                                                  // a head that launched no greedy loop must not keep the tail waiting
+            join_tail();
+            prev = std::move(R);
+            LocusRun* run = prev.get();
+            {
+                // the tail of this locus lets the greedy loop of the next locus go first (lcty_ctx::LaunchGate)
+                std::lock_guard<std::mutex> lock(ctx->gate.m);
+                ctx->gate.target = i + 1 < n && n_stages > 1 && stages[0].solver.kind == LCTY_SOLVER_GREEDY ? ctx->gate.epoch + 1 : 0;
+            }
+            tail_of = i;
+            tail_thread = std::thread([run, &tail_rc, &tail_msg] {
+                try { run->tail(1); }
+                catch (const Error& e) { tail_rc = e.code; tail_msg = e.what(); }
+                catch (const std::exception& e) { tail_rc = LCTY_ERR_RUNTIME; tail_msg = e.what(); }
+            });
+        }
+        join_tail();
+    } catch (...) {
+        release_gate();
+        if (tail_thread.joinable()) tail_thread.join();
+        throw;
+    }
+}
+}  // namespace
+
+extern "C" {
+
 // The genotyping loop of `locityper genotype` over its loci (genotype.rs:1331-1351: analyze_locus one after the other) as a queue
 // on one GPU. Each entry is a batch of read pairs of its own locus, appended but not necessarily scored: for every entry
 // lcty_score_reads + lcty_solve. The loci are independent, so the last stage of locus i (the annealing attempts: a few hundred
@@ -2779,48 +2840,29 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
             if (i && (batches[i] == batches[i - 1] || batches[i]->locus == batches[i - 1]->locus))
                 fail(LCTY_ERR_INVALID_INPUT, "neighbours in the queue must be different batches of different loci");
         }
-        std::unique_ptr<LocusRun> prev;
-        std::thread tail_thread;
-        int32_t tail_rc = LCTY_OK; std::string tail_msg;
-        lcty_ctx* ctx = n_batches ? batches[0]->ctx : nullptr;
-        auto release_gate = [&] {
-            if (!ctx) return;
-            { std::lock_guard<std::mutex> lock(ctx->gate.m); if (ctx->gate.target > ctx->gate.epoch) ctx->gate.epoch = ctx->gate.target; }
-            ctx->gate.cv.notify_all();
-        };
-        auto join_tail = [&] {
-            if (tail_thread.joinable()) tail_thread.join();
-            prev.reset();
-            if (tail_rc != LCTY_OK) { const int32_t rc = tail_rc; tail_rc = LCTY_OK; fail(rc, "%s", tail_msg.c_str()); }
-        };
-        try {
-            for (uint32_t i = 0; i < n_batches; i++) {
-                auto R = std::make_unique<LocusRun>();
-                R->reads = batches[i]; R->ploidy = ploidy; R->stages = stages; R->n_stages = n_stages; R->master_seed = master_seeds[i];
-                R->priors = priors ? priors[i] : nullptr; R->out = &out[i];
-                try { R->head(true); }
-                catch (...) { release_gate(); throw; }
-                release_gate();                                                  // a head that launched no greedy loop must not keep the tail waiting
-                join_tail();
-                prev = std::move(R);
-                LocusRun* run = prev.get();
-                {
-                    // the tail of this locus lets the greedy loop of the next locus go first (lcty_ctx::LaunchGate)
-                    std::lock_guard<std::mutex> lock(ctx->gate.m);
-                    ctx->gate.target = i + 1 < n_batches && n_stages > 1 && stages[0].solver.kind == LCTY_SOLVER_GREEDY ? ctx->gate.epoch + 1 : 0;
-                }
-                tail_thread = std::thread([run, &tail_rc, &tail_msg] {
-                    try { run->tail(1); }
-                    catch (const Error& e) { tail_rc = e.code; tail_msg = e.what(); }
-                    catch (const std::exception& e) { tail_rc = LCTY_ERR_RUNTIME; tail_msg = e.what(); }
-                });
-            }
-            join_tail();
-        } catch (...) {
-            release_gate();
-            if (tail_thread.joinable()) tail_thread.join();
-            throw;
-        }
+        run_queue(n_batches, [&](uint32_t i) { return batches[i]; }, [](uint32_t) {}, ploidy, stages, n_stages, master_seeds, priors, out);
+    });
+}
+
+// The same queue with the batches handed over one at a time: `acquire(user, i)` is called right before position i is scored and
+// returns its batch — filled by then, e.g. by a host thread that appends the chunks of locus i while locus i - 1 is being solved
+// (the appends have a stream of their own) —, `release(user, i)` when the last stage of position i has finished and nothing of
+// the batch is in use any more (lcty_reads_reset may then bind it to another locus). Position i is released before position
+// i + 2 is acquired: three batch objects carry a queue of any length. The loop of `locityper genotype` over its loci
+// (genotype.rs:1331-1351) with the loading of locus i + 1 next to the solving of locus i.
+int32_t lcty_solve_queue_fed(uint32_t n_loci, lcty_queue_acquire_fn acquire, lcty_queue_release_fn release, void* user, uint32_t ploidy,
+                             const lcty_stage* stages, uint32_t n_stages, const uint64_t* master_seeds, const double* const* priors, lcty_call* out) {
+    return guarded([&] {
+        if (!acquire || !stages || !master_seeds || !out || n_stages == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        lcty_reads* before = nullptr;
+        run_queue(n_loci, [&](uint32_t i) {
+            lcty_reads* r = acquire(user, i);
+            if (!r) fail(LCTY_ERR_INVALID_INPUT, "the queue's source has no batch for position %u", i);
+            if (before && (r == before || r->locus == before->locus || r->ctx != before->ctx))
+                fail(LCTY_ERR_INVALID_INPUT, "neighbours in the queue must be different batches of different loci in one context");
+            before = r;
+            return r;
+        }, [&](uint32_t i) { if (release) release(user, i); }, ploidy, stages, n_stages, master_seeds, priors, out);
     });
 }
 

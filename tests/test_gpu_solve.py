@@ -396,3 +396,74 @@ def test_queue_of_loci_equals_one_locus_at_a_time(gpu_ctx):
     with pytest.raises(_lib.LocityperError) as e:                       # neighbours must be different loci
         api.solve_queue([batches[0], batches[0]], stages)
     assert e.value.code == cdefs.ERR_INVALID_INPUT
+
+
+def test_fed_queue_of_distinct_loci_equals_the_resident_queue(gpu_ctx):
+    """lcty_solve_queue_fed + lcty_reads_reset: five positions over three loci through THREE rotating batch objects, each position uploaded
+    (counted alignments, from a loader thread, on the copy stream) while the position before it is solved. Every call equals what the
+    locus gets alone; a batch is released before the position two further on is acquired; a source without a batch ends the queue."""
+    import threading
+    stages = (cdefs.Stage * 2)()
+    stages[0].solver = api.default_solver(cdefs.SOLVER_GREEDY); stages[0].in_size = 30; stages[0].attempts = 1
+    stages[1].solver = api.default_solver(cdefs.SOLVER_ANNEAL); stages[1].in_size = 5; stages[1].attempts = 4
+    loci = []
+    for i in range(3):
+        L = synth.SynthLocus(10, 3000 + 500 * i, seed=60 + i, base_len=15000)
+        p = api.resolve_params(api.default_params(), L.bg)
+        loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+        ch = L.reads(0, 3000 + 500 * i)
+        half = ch.n_pairs // 2
+        parts = [ch.slice(0, half), ch.slice(half, ch.n_pairs)]
+        loci.append((L, loc, [(gpu_ctx.pinned_chunk(c), gpu_ctx.pinned_like(c.counted(loc.allele_len))) for c in parts], ch))
+    alone = []
+    for i, (L, loc, parts, ch) in enumerate(loci):
+        aa = api.AllAlignments.load(loc, ch, counted=True)
+        alone.append(api.solve_locus(aa, stages, master_seed=21 + i)[0])
+    cap_b = max(c.n_bases for _, _, _, c in loci) + 64
+    cap_r = max(len(c.recs) for _, _, _, c in loci)
+    rot = [api.AllAlignments(loci[0][1], 4000, cap_b // 32 * 32 + 32, cap_r, 0) for _ in range(3)]
+    order = [0, 1, 2, 0, 1]
+    ready = [threading.Event() for _ in order]
+    free = [threading.Semaphore(1) for _ in range(3)]
+    events = []
+
+    def loader():
+        for q, j in enumerate(order):
+            free[q % 3].acquire()
+            events.append(("load", q))
+            b = rot[q % 3]
+            b.reset(loci[j][1])
+            for pc, alns in loci[j][2]:
+                b.append(pc, counted=alns)
+            ready[q].set()
+
+    def acquire(q):
+        ready[q].wait()
+        events.append(("acquire", q))
+        return rot[q % 3]
+
+    def release(q):
+        events.append(("release", q))
+        free[q % 3].release()
+
+    th = threading.Thread(target=loader)
+    th.start()
+    calls = api.solve_queue_fed(len(order), acquire, release, stages, master_seeds=[21 + j for j in order])
+    th.join()
+    for j, c in zip(order, calls):
+        a = alone[j]
+        n = int(a.n_out)
+        assert int(c.n_out) == n and list(c.ixs[:n]) == list(a.ixs[:n]) and list(c.ln_probs[:n]) == list(a.ln_probs[:n])
+        assert (c.unexpl_reads, c.n_good, c.warnings, c.kept_after_filter) == (a.unexpl_reads, a.n_good, a.warnings, a.kept_after_filter)
+    for q in range(len(order) - 2):
+        assert events.index(("release", q)) < events.index(("acquire", q + 2))
+    assert [e for e in events if e[0] == "release"] == [("release", q) for q in range(len(order))]
+    # a source that has nothing for a position: the queue ends with an error, the positions before it were released
+    with pytest.raises(_lib.LocityperError) as e:
+        api.solve_queue_fed(2, lambda q: rot[0] if q == 0 else None, None, stages)
+    # a batch made for a smaller locus is refused by reset
+    L2 = synth.SynthLocus(12, 100, seed=3, base_len=15000)
+    loc2 = api.Locus(gpu_ctx, L2.seqs, L2.seq_off, L2.counts, L2.cnt_off, L2.k, L2.bg, api.resolve_params(api.default_params(), L2.bg))
+    with pytest.raises(_lib.LocityperError) as e:
+        rot[0].reset(loc2)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
