@@ -1100,3 +1100,48 @@ def test_alignment_recovery_of_10kb_reads_onto_256_alleles(gpu_ctx):
     sc = aa.run_filter()
     so = O.run_filter(oa.best_aln_matrix(), O.generate_genotypes(n_alleles, 2))
     assert np.abs(sc - so).max() <= 1e-9 * np.abs(so).max() and int(np.argmax(sc)) == int(np.argmax(so))
+
+
+@pytest.mark.gpu
+def test_truncate_ixs_on_the_device_against_the_host_form(gpu_ctx):
+    """lcty_prefilter_truncate (lcty_select.hip: threshold count, radix selection of the min_size-th / threads-th score, compaction,
+    ordering of the survivors) against lcty_truncate (the host form of truncate_ixs, solve.rs:52-84) index for index, on score vectors
+    made to hit every branch: ties at the cut, fewer within filt_diff than min_size, fewer than `threads`, everything kept, both
+    zeros, more survivors than one workgroup orders (8 192), scores spread over many binades."""
+    A = 150
+    alleles = random_alleles(A, 400, seed=3)
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, counts, cnt_off, _ = locus_arrays(alleles, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, counts, cnt_off, 25, bg, p)
+    aa = api.AllAlignments.load(loc, ReadsChunk.from_pairs([]))          # no reads: run_filter is 0.0 everywhere, scores = priors exactly
+    G = api.count_genotypes(A, 2)
+    rng = np.random.default_rng(8)
+    vectors = {
+        "continuous": -1000.0 * rng.random(G),
+        "ties": -np.round(50.0 * rng.random(G)),
+        "constant": np.full(G, -3.25),
+        "zeros": np.where(rng.random(G) < 0.5, 0.0, -0.0) - np.where(rng.random(G) < 0.01, 1.0, 0.0),
+        "binades": -np.exp(40.0 * rng.random(G)) * np.where(rng.random(G) < 0.3, -1.0, 1.0),
+        "few_good": np.where(rng.random(G) < 0.001, -1.0 * rng.random(G), -500.0 - np.round(100 * rng.random(G))),
+    }
+    ix_all = np.arange(G, dtype=np.uint64)
+    n_checked = 0
+    for name, sc in vectors.items():
+        aa.prefilter_async()
+        aa.prefilter_add_priors(sc)
+        on_dev = aa.prefilter_scores()
+        assert np.array_equal(on_dev, sc + 0.0)
+        for fd, ms, th in ((10.0, 5000, 8), (0.5, 100, 8), (1e9, 50, 8), (25.0, 3, 9000), (0.0, 1, 1), (3.0, 9000, 16), (5.0, G, 8), (5.0, 20, G + 5),
+                           (200.0, 10, 4), (0.25, 7, 64)):
+            got = aa.prefilter_truncate(fd, ms, th)
+            want = api.truncate_ixs(on_dev, ix_all, fd, ms, th)
+            assert np.array_equal(got, want), (name, fd, ms, th, len(got), len(want))
+            n_checked += 1
+    assert n_checked == 60
+    aa.prefilter_async()
+    bad = vectors["continuous"].copy(); bad[17] = np.nan
+    aa.prefilter_add_priors(bad)
+    with pytest.raises(_lib.LocityperError) as e:
+        aa.prefilter_truncate(1.0, 10, 8)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
