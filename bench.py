@@ -63,9 +63,10 @@ def parse_args():
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
     ap.add_argument("--shard-reads", action="store_true",
-                    help="one locus over all ranks: every rank scores and prefilters a contiguous shard of the read pairs, the run_filter "
-                         "scores are SUM-all-reduced on the devices (RCCL), truncate_ixs runs everywhere; implies --no-solve (the chains "
-                         "need every read) and strong scaling. Not the default: the driver's runs are one locus per rank")
+                    help="one locus over all ranks, whole path (BASELINE configs[4]): every rank scores and prefilters a contiguous shard of the "
+                         "read pairs, the run_filter scores are SUM-all-reduced on the devices (RCCL), truncate_ixs runs everywhere, every solver "
+                         "stage all-gathers the location-table rows of its alleles and deals its chains to the ranks "
+                         "(lcty_solve_stage_read_sharded); strong scaling. Not the default: the driver's runs are one locus per rank")
     ap.add_argument("--shard-chains", action="store_true",
                     help="one locus over all ranks, whole path: every rank scores and prefilters all reads of the locus (replicated), the "
                          "(genotype, attempt) chains of both solver stages are dealt to the ranks and their likelihoods all-gathered on the "
@@ -74,7 +75,7 @@ def parse_args():
                     help="extra measurement: a queue of loci that are NOT resident — this many distinct loci in page-locked host memory, every "
                          "position of the queue uploaded (lcty_reads_append_counted on the copy stream, from a loader thread) while the position "
                          "before it is solved, three batch objects rotating (lcty_solve_queue_fed); 0 = skip")
-    ap.add_argument("--distinct-steps", type=int, default=6, help="positions of the timed queue of the --distinct-loci measurement")
+    ap.add_argument("--distinct-steps", type=int, default=0, help="positions of the timed queue of the --distinct-loci measurement (0: as many as --steps, so that the two queues compare like for like)")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (launch-path checks on a one-GPU box; reported in the line)")
     ap.add_argument("--pipeline", type=int, default=0, help="ignored (round 1 option; the queue of loci is the default mode now)")
     ap.add_argument("--recruit-sample", type=int, default=8_000_000,
@@ -278,7 +279,8 @@ def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_ste
     validation on the host's cores next to them) and hands it to lcty_solve_queue_fed, which releases a batch when its last stage is
     done. Timed: K positions, the first upload included."""
     import threading
-    D, K, A = args.distinct_loci, args.distinct_steps, args.alleles
+    D, K, A = args.distinct_loci, (args.distinct_steps or args.steps), args.alleles
+    trace = any(kv.startswith("queue_trace=") and not kv.endswith("=0") for kv in args.knob)
     for b in batches:                                          # the resident loci of the main measurement make room
         b.close()
     ctx.trim()
@@ -331,21 +333,28 @@ def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_ste
                     for pc, alns in chunks:
                         b.append(pc, counted=alns)
                     load_s[i] = time.perf_counter() - tl
+                    if trace: progress(f"  position {i}: loaded in {load_s[i]:.3f} s")
                     ready[i].set()
             except BaseException as e:                         # the queue must not wait for ever
                 problems.append(e)
                 for ev in ready: ev.set()
 
         def acquire(i):
+            tw = time.perf_counter()
             ready[i].wait()
+            if trace: progress(f"  position {i}: acquired after waiting {time.perf_counter() - tw:.3f} s")
             if problems: raise problems[0]
             return rot[i % 3]
+
+        def release(i):
+            if trace: progress(f"  position {i}: released")
+            free[i % 3].release()
 
         th = threading.Thread(target=loader)
         ctx.synchronize()
         tq = time.perf_counter()
         th.start()
-        calls = api.solve_queue_fed(k, acquire, lambda i: free[i % 3].release(), stages, master_seeds=[3000 + first_it + i for i in range(k)])
+        calls = api.solve_queue_fed(k, acquire, release, stages, master_seeds=[3000 + first_it + i for i in range(k)])
         ctx.synchronize()
         dt = time.perf_counter() - tq
         th.join()
@@ -404,7 +413,6 @@ def main():
     if one_locus:
         os.environ.pop("NCCL_DEBUG", None)         # RCCL logs to stdout, which carries the one JSON line
         os.environ["NCCL_DEBUG_FILE"] = os.devnull
-        args.no_solve = args.shard_reads
         args.recovery_sample = args.recruit_sample = args.ont_sample = 0
         uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
         if dist is not None:
@@ -490,7 +498,9 @@ def main():
         mean, var, att = np.full(n, np.nan), np.full(n, np.nan), np.zeros(n, dtype=np.uint32)
         ixs = keep
         # --shard-chains: the same call on every rank, the chains dealt to the ranks inside the library
-        run_stage = comm.solve_stage if (args.shard_chains and aa is aa_main) else api.solve_stage
+        # --shard-reads: every rank holds its shard of the locus' reads; a stage exchanges the location-table rows of its alleles
+        # (lcty_solve_stage_read_sharded: RCCL all-gathers), then deals its chains to the ranks like --shard-chains
+        run_stage = (comm.solve_stage if args.shard_chains else comm.solve_stage_read_sharded) if (one_locus and aa is aa_main) else api.solve_stage
         ts = time.perf_counter()
         if 20 < len(ixs):
             m, v, _ = run_stage(aa, gts[ixs], greedy, 1, api.chain_seeds(1000 + it, len(ixs)))
@@ -633,7 +643,7 @@ def main():
                    "step": ("one locus through lcty_solve_queue (score + run_filter + default solver scheme + final comparison); the queue "
                             "alternates between two resident loci and overlaps the annealing stage of a locus with the next locus"
                             if queue_mode else "one locus, call by call"),
-                   "parallelism": (f"reads of one locus x{world}, RCCL all-reduce of the run_filter scores" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
+                   "parallelism": (f"reads of one locus x{world}: RCCL all-reduce of the run_filter scores, all-gather of the location-table rows per solver stage, chains dealt to the ranks" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
         "reads_scored_per_s": (total_pairs if args.shard_reads else args.pairs if args.shard_chains else args.pairs) * n_break / max(stage_s["score_prefilter"], 1e-9),
         "genotypes_prefiltered_per_s": G * n_break / max(stage_s["score_prefilter"], 1e-9),
         "prefilter_genotypes_per_s_kernel": G / (pref_ms * 1e-3) if pref_ms else None,
@@ -685,6 +695,18 @@ def main():
         t_targets = time.perf_counter() - tq0
         rngq = np.random.default_rng(11)
         words = rngq.integers(0, 1 << 32, size=nrq * 20, dtype=np.uint64).astype(np.uint32)
+        # 0.2 % of the pairs come from the locus itself (the share of a whole-genome sample a 50-kb locus accounts for is far smaller;
+        # this is what makes the positive path run): their bases over the random ones, at random places of the chunk
+        n_own = max(1, nrq // 500)
+        own = L.reads(0, min(n_own, args.pairs))
+        n_own = own.n_pairs
+        own_at = rngq.choice(nrq, size=n_own, replace=False)
+        mo = own.mate_off.astype(np.int64) // 16
+        short = 0
+        for t in range(n_own):
+            for e in range(2):
+                if int(own.mate_len[2 * t + e]) != 150: short += 1; continue
+                words[(2 * int(own_at[t]) + e) * 10:(2 * int(own_at[t]) + e) * 10 + 10] = own.bases2[mo[2 * t + e]:mo[2 * t + e] + 10]
         from locityper_amd.cdefs import ReadsChunk, ALN_REC_DTYPE
         rq = ReadsChunk(np.full(2 * nrq, 150, dtype=np.uint32), np.arange(2 * nrq + 1, dtype=np.uint64) * 160, words,
                         np.zeros(nrq * 10, dtype=np.uint32), np.zeros(nrq + 1, dtype=np.uint64), np.zeros(0, dtype=ALN_REC_DTYPE),
@@ -694,9 +716,12 @@ def main():
         cntq, _ = T.recruit(rq, paired=True)
         t_call = time.perf_counter() - tq0
         _, ms_q = ctx.timing(api.K_RECRUIT)
-        out["recruitment"] = {"sample": f"{nrq} random 150 + 150-base read pairs against the {A} alleles of the locus ({n_minim} minimizers)",
+        out["recruitment"] = {"sample": f"{nrq} 150 + 150-base read pairs, 99.8 % random and 0.2 % drawn from the locus, against its {A} alleles ({n_minim} minimizers)",
                               "kernel_ms": ms_q, "read_pairs_per_s_kernel": nrq / (ms_q * 1e-3) if ms_q else None,
-                              "read_pairs_per_s_call": nrq / t_call, "targets_build_s": t_targets, "recruited": int(np.count_nonzero(cntq))}
+                              "read_pairs_per_s_call": nrq / t_call, "targets_build_s": t_targets, "recruited": int(np.count_nonzero(cntq)),
+                              "locus_derived_pairs": int(n_own), "locus_derived_recruited": int(np.count_nonzero(cntq[own_at]))}
+        if n_own - short // 2 > 10 and out["recruitment"]["locus_derived_recruited"] == 0:
+            raise RuntimeError("recruitment leg: none of the locus' own read pairs was recruited")
         T.close(); del rq, words
 
     if args.map_sample > 0 and world == 1:

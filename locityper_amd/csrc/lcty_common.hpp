@@ -172,6 +172,7 @@ struct lcty_ctx {
     // locus over PCIe while the kernels of the current one have the other two streams (lcty_solve_queue_fed).
     hipStream_t copy = nullptr;
     std::mutex copy_mutex;
+    std::mutex ws_mutex;              // sizing / (re)allocation of the solver workspaces: the two lanes of a queue look at the free memory one at a time
     hipStream_t copy_stream() {
         std::lock_guard<std::mutex> lock(copy_mutex);
         if (!copy) LCTY_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));

@@ -1883,8 +1883,11 @@ struct StageRunner {
 
     // chains are processed in batches so that the per-chain state (32 B per good read + the run of further locations) fits the device
     void plan_batches() {
+        // one lane at a time: a lane that read the free memory while the other had just released its workspace to enlarge it would
+        // count that memory as its own
+        std::lock_guard<std::mutex> ws_lock(ctx->ws_mutex);
         const uint64_t ngp = V.rstride;                                     // record places per chain
-        const uint64_t per_chain = ngp * sizeof(ChainRec) + static_cast<uint64_t>(ws.extra_cap) * sizeof(ExtraLoc) + static_cast<uint64_t>(V.wstride) * 21 + 64;
+        const uint64_t per_chain = (ngp + ngp / 128) * sizeof(ChainRec) + static_cast<uint64_t>(ws.extra_cap) * sizeof(ExtraLoc) + static_cast<uint64_t>(V.wstride) * 21 + 64;
         size_t free_b = 0, total_b = 0;
         ctx->release_transfer_scratch();
         LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1898,8 +1901,17 @@ struct StageRunner {
         ws.ovf.ensure(2); ws.ovf.zero(s);
         if (ws.recs.n < max_chains * ngp || ws.extra.n < max_chains * ws.extra_cap + 2) {
             // both at once, the old ones released first: the two together are most of the device
+            if (ctx->knob("queue_trace", 0))
+                fprintf(stderr, "[lcty queue] lane %u workspace: %llu chains x %llu places (had %.1f GB of records, %.1f GB of runs; free %.1f GB, budget %.1f GB, %u further locations per chain)\n",
+                        lane, static_cast<unsigned long long>(max_chains), static_cast<unsigned long long>(ngp), ws.recs.n * 32e-9, ws.extra.n * 16e-9,
+                        free_b * 1e-9, budget * 1e-9, ws.extra_cap);
+            // Grow-only, with a little head-room: the loci of a queue differ by a fraction of a per cent in their good read pairs, and a
+            // workspace that followed every locus exactly was released and allocated again (4 s for 150 GB, with every stream of the
+            // device waiting) whenever a slightly larger locus came after a smaller one.
+            const uint64_t want_recs = std::max<uint64_t>(ws.recs.n, max_chains * (ngp + ngp / 128));
+            const uint64_t want_extra = std::max<uint64_t>(ws.extra.n, max_chains * static_cast<uint64_t>(ws.extra_cap) + 2);   // two spare entries: the greedy loop reads a pair per record
             ws.recs.release(); ws.extra.release();
-            ws.recs.alloc(max_chains * ngp); ws.extra.alloc(max_chains * ws.extra_cap + 2);     // two spare entries: the greedy loop reads a pair per record
+            ws.recs.alloc(want_recs); ws.extra.alloc(want_extra);
         }
         ws.cww.ensure(max_chains * V.wstride); ws.cgc.ensure(max_chains * V.wstride); ws.cdepth.ensure(max_chains * V.wstride);
         ws.cuc.ensure(max_chains * V.wstride);
