@@ -179,6 +179,7 @@ __device__ inline bool pos_get(const PairScratch& P, uint32_t read_end, uint32_t
 struct TransferArgs {
     uint32_t cap_alns, hcap, cap_new, cap_words;
     Limits lim; uint32_t last_level;                    // what a lane can hold at this level; 1: nothing behind it
+    uint32_t walk_budget;                               // phases a lane walks before the wavefront looks who needs the aligner (xfer::walk_step)
     const uint64_t* pair_list; uint64_t n_list;         // the pairs of this launch (NULL: all of the batch)
     uint64_t* redo_list; unsigned long long* redo_n;    // pairs handed to the next level
     uint8_t* scratch; size_t scratch_stride;
@@ -324,13 +325,13 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                 // the walks of all lanes, resumed until none of them waits for the aligner any more: one converged call site
                 {
                     Job job;
-                    bool need;
                     do {
-                        need = walking && walk_step(walk, src, Q, out, LS, job);
-                        if (!need) walking = false;
-                        if (need) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);
-                    } while (__any(need));
+                        const uint32_t st = walking ? walk_step(walk, src, Q, out, LS, job, T.walk_budget) : WALK_DONE;
+                        if (st == WALK_JOB) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);
+                        walking = st != WALK_DONE;
+                    } while (__any(walking));
                 }
+                out.flush();
                 if (transferring) {
                     const uint32_t new_start = walk.start_k;
                     const uint32_t diff = out.rlen > out.qlen ? out.rlen - out.qlen : out.qlen - out.rlen;
@@ -733,6 +734,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 TransferArgs T{};
                 T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
                 T.lim = lim; T.last_level = lv + 1 == levels.size();
+                T.walk_budget = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_walk_budget", 1 << 30)));
                 T.pair_list = list; T.n_list = n_list;
                 uint64_t* next = (lv % 2 == 0) ? d_list_a.p : d_list_b.p;
                 T.redo_list = next; T.redo_n = d_cursors.p + 2;

@@ -44,31 +44,37 @@ __device__ __forceinline__ uint32_t op_invert(uint32_t op) {                  //
 // l_base[i * 64 + l]: conflict-free), the rest in the lane's global scratch — a transferred short-read CIGAR rarely has more, and
 // every push looks at the item before it
 constexpr uint32_t CIGAR_LDS_ITEMS = 12;
+// The LAST item of a CIGAR under construction lives in registers (`pend`): a push that extends it — most pushes of a walk do — is
+// an addition, and a push that starts a new item only STORES the finished one. Looking the last item up in the lane's scratch on
+// every push put a dependent global load (the lanes' CIGARs are 48 KB apart: an L2 miss each) into every step of every walk.
+// Readers of the items (get / n) call flush() first.
 struct DCigar {
     uint2* t;              // global part [cap]
     uint2* l;              // LDS part, already offset by the lane (stride 64), or nullptr
     uint32_t lds_n;
     uint32_t n, rlen, qlen, cap;
+    uint2 pend; bool has_pend;                                               // the item behind item n - 1, not stored yet
     bool overflow;                                                           // items were dropped: the lengths are still right
     __device__ void init(uint2* buf, uint32_t capacity, uint2* lds = nullptr) {
         t = buf; cap = capacity; l = lds; lds_n = lds ? CIGAR_LDS_ITEMS : 0u; n = 0; rlen = qlen = 0; overflow = false;
+        pend = make_uint2(0, 0); has_pend = false;
     }
     __device__ __forceinline__ uint2 get(uint32_t i) const { return i < lds_n ? l[i * 64] : t[i]; }
     __device__ __forceinline__ void set(uint32_t i, uint2 v) { if (i < lds_n) l[i * 64] = v; else t[i] = v; }
-    __device__ void clear() { n = 0; rlen = qlen = 0; }
-    __device__ void push_raw(uint2 it) { if (n < cap) set(n++, it); else overflow = true; }                 // lengths untouched
-    __device__ void push_unchecked(uint32_t op, uint32_t len) {              // cigar.rs:343-352
+    __device__ void clear() { n = 0; rlen = qlen = 0; has_pend = false; }
+    __device__ __forceinline__ void flush() {
+        if (has_pend) { if (n < cap) set(n++, pend); else overflow = true; has_pend = false; }
+    }
+    __device__ __forceinline__ void push_raw(uint2 it) { flush(); pend = it; has_pend = true; }          // lengths untouched
+    __device__ __forceinline__ void push_unchecked(uint32_t op, uint32_t len) {   // cigar.rs:343-352
         if (cons_q(op)) qlen += len;
         if (cons_r(op)) rlen += len;
         push_raw(make_uint2(op, len));
     }
-    __device__ void push_checked(uint32_t op, uint32_t len) {                // cigar.rs:355-363
+    __device__ __forceinline__ void push_checked(uint32_t op, uint32_t len) {     // cigar.rs:355-363
         if (cons_q(op)) qlen += len;
         if (cons_r(op)) rlen += len;
-        if (n) {
-            const uint2 last = get(n - 1);
-            if (last.x == op) { set(n - 1, make_uint2(op, last.y + len)); return; }
-        }
+        if (has_pend && pend.x == op) { pend.y += len; return; }
         push_raw(make_uint2(op, len));
     }
 };
@@ -294,6 +300,7 @@ __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_
     uint32_t flag = 0;
     DCigar nc; nc.init(sc.cig_b, sc.lim.cigar_cap);
     bool have = false;
+    self.flush();
     for (uint32_t j = 0; j < self.n; j++) {
         const uint2 item_j = self.get(j);
         const uint32_t op = item_j.x, len = item_j.y;
@@ -325,6 +332,7 @@ __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_
     }
     if (have) {
         for (uint32_t k = i; k < self.n; k++) nc.push_raw(self.get(k));
+        nc.flush();
         for (uint32_t t = 0; t < nc.n; t++) self.set(t, nc.get(t));           // self.tuples = new_cigar.tuples (lengths stay)
         self.n = nc.n;
         self.overflow |= nc.overflow;
@@ -374,6 +382,7 @@ struct Walk {
     uint32_t last1, pos1, last2, pos2, start_k;
     int add;
     uint32_t phase;
+    uint2 nxt1, nxt2;          // the items the two CIGARs continue with (ij item ijx, jk item jk), requested a step before they are needed
 };
 enum : uint32_t { PH_TOP = 0, PH_POST_LEFT, PH_POST, PH_TAIL, PH_POST_RIGHT, PH_FINISH, PH_DONE };
 
@@ -391,23 +400,32 @@ __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, 
     w.start_k = off_rpos + (cons_r(w.op2) ? init_shift : 0);
     if (w.op2 == OP_EQ && init_shift >= FULL_MATCH_PADDING && w.rem2 >= ij.ref_len() + FULL_MATCH_PADDING) {
         for (uint32_t i = 0; i < ij.n; i++) { const uint2 it = ij.item(i); out.push_unchecked(it.x, it.y); }
+        out.flush();
         w.phase = PH_DONE;
         return false;
     }
     const uint2 it1 = ij.item(0);
     w.len1 = it1.y; w.rem1 = w.len1; w.op1 = it1.x;
     w.ijx = 1;
+    w.nxt1 = w.ijx < ij.n ? ij.item(w.ijx) : make_uint2(0, 0);
+    w.nxt2 = w.jk < w.jk_n ? jk_items[w.jk] : make_uint2(0, 0);
     w.last1 = 0; w.pos1 = 0; w.last2 = w.start_k; w.pos2 = w.start_k;
     w.add = -1;
     w.phase = PH_TOP;
     return true;
 }
 
-// walks on until the aligner is needed (returns true, `job` filled) or the transfer is complete (returns false)
-__device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc, Job& job) {
+// walks on until the aligner is needed (WALK_JOB, `job` filled), the transfer is complete (WALK_DONE) or `budget` phases have been
+// walked (WALK_MORE: lcty_ctx_set_knob "transfer_walk_budget"). Measured at 10-kb reads x 256 alleles: letting the lanes that need the
+// aligner wait for ALL others to need it too (no budget) is the fastest form — 231 ms against 350 ms when the wavefront looks after
+// every phase: a call of the aligner costs the wavefront the same whatever the number of lanes in it, so few full calls beat many
+// sparse ones, although the lanes then spend three quarters of the walk waiting (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 16 of 64).
+enum : uint32_t { WALK_DONE = 0, WALK_JOB = 1, WALK_MORE = 2 };
+__device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc, Job& job, uint32_t budget) {
     const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3;
     const uint32_t len_i = S.read_len, len_k = S.target_len;
-    for (;;) {
+    for (;; budget--) {
+        if (budget == 0) return WALK_MORE;
         if (w.phase == PH_TOP) {
             int add = -1;
             const bool e1 = w.op1 == OP_EQ, e2 = w.op2 == OP_EQ;
@@ -422,7 +440,7 @@ __device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCi
                     const uint32_t from = w.last2 > w.pos1 + CLIP_PADDING ? w.last2 - (w.pos1 + CLIP_PADDING) : 0;     // saturating_sub
                     w.phase = PH_POST_LEFT;
                     if (from == w.pos2) out.push_unchecked(OP_I, w.pos1 - w.last1);
-                    else { job = Job{from, w.pos2 - from, w.last1, w.pos1 - w.last1, 1, true}; return true; }
+                    else { job = Job{from, w.pos2 - from, w.last1, w.pos1 - w.last1, 1, true}; return WALK_JOB; }
                 } else {
                     // smart_align (wfa.rs:301-347) without a maximum gap; only the dynamic programme is handed out
                     const uint32_t jump1 = w.pos2 - w.last2, jump2 = w.pos1 - w.last1;
@@ -430,7 +448,7 @@ __device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCi
                         const uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;      // wfa.rs:212
                         if (jump1 == jump2 && jump1 <= safe_mismatch) {
                             for (uint32_t t = 0; t < jump1; t++) out.push_checked(S.r(w.last2 + t) == S.q(w.last1 + t) ? OP_EQ : OP_X, 1);
-                        } else { job = Job{w.last2, jump1, w.last1, jump2, 0, false}; return true; }
+                        } else { job = Job{w.last2, jump1, w.last1, jump2, 0, false}; return WALK_JOB; }
                     } else if (jump1 > 0) out.push_unchecked(OP_D, jump1);
                     else if (jump2 > 0) out.push_unchecked(OP_I, jump2);
                 }
@@ -444,11 +462,17 @@ __device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCi
             w.phase = PH_TOP;
             if (w.rem1 == 0) {
                 if (w.ijx == ij.n) w.phase = PH_TAIL;
-                else { const uint2 it1 = ij.item(w.ijx); w.len1 = it1.y; w.rem1 = w.len1; w.op1 = it1.x; w.ijx++; }
+                else {
+                    const uint2 it1 = w.nxt1; w.len1 = it1.y; w.rem1 = w.len1; w.op1 = it1.x; w.ijx++;
+                    if (w.ijx < ij.n) w.nxt1 = ij.item(w.ijx);                   // used a step from now at the earliest
+                }
             }
             if (w.phase == PH_TOP && w.rem2 == 0) {
                 if (w.jk == w.jk_n) w.phase = PH_TAIL;
-                else { w.len2 = w.jk_items[w.jk].y; w.rem2 = w.len2; w.op2 = w.dir_jk ? op_invert(w.jk_items[w.jk].x) : w.jk_items[w.jk].x; w.jk++; }
+                else {
+                    const uint2 it2 = w.nxt2; w.len2 = it2.y; w.rem2 = w.len2; w.op2 = w.dir_jk ? op_invert(it2.x) : it2.x; w.jk++;
+                    if (w.jk < w.jk_n) w.nxt2 = w.jk_items[w.jk];
+                }
             }
         } else if (w.phase == PH_TAIL) {
             w.phase = PH_FINISH;
@@ -456,10 +480,11 @@ __device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCi
                 // align_ends::<RIGHT>
                 const uint32_t i1 = w.last2, i2 = min(len_k, w.last2 + len_i - w.last1 + CLIP_PADDING);
                 if (i1 == i2) out.push_unchecked(OP_I, len_i - w.last1);
-                else { w.phase = PH_POST_RIGHT; job = Job{i1, i2 - i1, w.last1, len_i - w.last1, 2, false}; return true; }
+                else { w.phase = PH_POST_RIGHT; job = Job{i1, i2 - i1, w.last1, len_i - w.last1, 2, false}; return WALK_JOB; }
             }
         } else if (w.phase == PH_POST_RIGHT) {
             uint32_t soft = 0;
+            out.flush();
             while (out.n && out.get(out.n - 1).x != OP_EQ) {                    // pop_if(op != Equal)
                 const uint2 it = out.get(--out.n);
                 if (cons_q(it.x)) { out.qlen -= it.y; soft += it.y; }
@@ -468,7 +493,7 @@ __device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCi
             if (soft > 0) out.push_unchecked(OP_I, soft);
             w.phase = PH_FINISH;
         } else if (w.phase == PH_FINISH) {
-            cigar_optimize(out, S, 20, 5, sc);                                  // MAX_OPTIMIZATION_GAP, OPTIMIZATION_ANCHOR
+            cigar_optimize(out, S, 20, 5, sc);                                  // MAX_OPTIMIZATION_GAP, OPTIMIZATION_ANCHOR (flushes `out`)
             if (out.n) {                                                        // boundary_ins_to_soft, cigar.rs:554-561
                 const uint2 first = out.get(0);
                 if (first.x == OP_I) out.set(0, make_uint2(OP_S, first.y));
@@ -476,8 +501,8 @@ __device__ inline bool walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCi
                 if (last.x == OP_I) out.set(out.n - 1, make_uint2(OP_S, last.y));
             }
             w.phase = PH_DONE;
-            return false;
-        } else return false;
+            return WALK_DONE;
+        } else return WALK_DONE;
     }
 }
 

@@ -1109,7 +1109,7 @@ def test_truncate_ixs_on_the_device_against_the_host_form(gpu_ctx):
     made to hit every branch: ties at the cut, fewer within filt_diff than min_size, fewer than `threads`, everything kept, both
     zeros, more survivors than one workgroup orders (8 192), scores spread over many binades."""
     A = 150
-    alleles = random_alleles(A, 400, seed=3)
+    alleles = random_alleles(A, 1200, seed=3)
     bg = make_bg()
     p = api.resolve_params(api.default_params(), bg)
     seqs, seq_off, counts, cnt_off, _ = locus_arrays(alleles, 25)
