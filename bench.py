@@ -59,7 +59,7 @@ def parse_args():
                     help="how the alignment table reaches the library: 16-byte counted alignments (lcty_reads_append_counted, SURVEY 8(d)'s "
                          "alignment-table entry; the default) or BAM records with their CIGAR words (lcty_reads_append)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of every CPU-baseline figure (the median is reported)")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r02_v8_pmc_traffic.json"),
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
     ap.add_argument("--shard-reads", action="store_true",
@@ -272,7 +272,7 @@ def spawn_ranks(args):
     sys.exit(0)
 
 
-def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_step):
+def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_step, host_chunks):
     """The queue as `locityper genotype` meets it: every locus arrives from the host. D distinct loci (their counted alignment tables
     and bases in page-locked memory: 8.3 GB each at 1 M x 256), K positions cycling over them; a loader thread resets one of three batch
     objects (lcty_reads_reset), uploads the position's chunks (lcty_reads_append_counted: copies on the context's copy stream, the CSR
@@ -300,13 +300,14 @@ def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_ste
         tb = tr = 0
         for ci in range(n_chunks):
             lo = ci * args.chunk
-            ch = L.reads(lo, min(args.chunk, args.pairs - lo))
+            ch = host_chunks[j][ci] if j < len(host_chunks) and host_chunks[j] else L.reads(lo, min(args.chunk, args.pairs - lo))
             alns = ctx.pinned_like(ch.counted(loc.allele_len))
             pc = ReadsChunk(*(ctx.pinned_like(a) for a in (ch.mate_len, ch.mate_off, ch.bases2, ch.nmask, ch.aln_off)), none_recs,
                             np.zeros(ch.n_pairs + 1, dtype=np.uint64), none_cig)
             chunks.append((pc, alns))
             tb += ch.n_bases; tr += len(ch.recs)
             if j == 0: up_bytes += alns.nbytes + pc.bases2.nbytes + pc.nmask.nbytes + pc.mate_len.nbytes + pc.mate_off.nbytes + pc.aln_off.nbytes
+            if j < len(host_chunks) and host_chunks[j]: host_chunks[j][ci] = None
             del ch
         caps = (max(caps[0], tb), max(caps[1], tr)) if caps else (tb, tr)
         host.append((L, loc, chunks))
@@ -435,7 +436,7 @@ def main():
     t0 = time.time()
     n_loci = 1 if (one_locus or args.no_solve) else 2
     A = args.alleles
-    loci, batches = [], []
+    loci, batches, host_chunks = [], [], []
     locus_setup_s = 0.0
     tot_recs = tot_cigar = tot_bases = 0
     first = None
@@ -455,6 +456,9 @@ def main():
         counted = args.format == "counted"
         aa = api.AllAlignments(loc, args.pairs, cap_bases, int(dens_r * args.pairs * head) + 4096,
                                0 if counted else int(dens_c * args.pairs * head) + 65536)
+        # the chunks of the resident loci are kept on the host when the queue of NON-resident loci is measured afterwards (it uploads them again)
+        keep_host = args.distinct_loci >= 2 and not one_locus and not args.no_solve and world == 1 and counted
+        host_chunks.append([c0] if keep_host else None)
         aa.append(c0, counted=counted)
         if j == 0:
             tot_recs, tot_cigar, tot_bases = len(c0.recs), len(c0.cigar), c0.n_bases
@@ -465,6 +469,7 @@ def main():
             aa.append(ch, counted=counted)
             if j == 0:
                 tot_recs += len(ch.recs); tot_cigar += len(ch.cigar); tot_bases += ch.n_bases
+            if keep_host: host_chunks[j].append(ch)
             del ch
         loci.append((L, loc)); batches.append(aa)
     L, loc = loci[0]
@@ -665,16 +670,23 @@ def main():
         "setup_s": {"generate_and_upload": gen_s, "locus_create": locus_setup_s},
     }
 
-    # HBM traffic from the committed PMC passes (counters cannot be read from inside this process)
+    # HBM traffic from the committed PMC passes (counters cannot be read from inside this process). FETCH_SIZE on gfx950 counts a 128-byte
+    # read request as 64 bytes (MI355X_MICROARCH.md): doubled for the kernels that STREAM wide coalesced reads; kernels that gather 8-32
+    # bytes per lane are outside that calibration and keep the raw figure. Both are in the line.
+    streaming = {"score_reads_kernel", "solve_init_kernel", "prefilter_tile_kernel"}
     try:
         tr = json.load(open(args.traffic))
         if tr.get("read_pairs") == args.pairs and tr.get("alleles") == A:
             for name, r in roofs.items():
-                k = tr["kernels"].get("lcty::" + name) or next((v for n, v in tr["kernels"].items() if n.startswith("lcty::" + name) or n.startswith("void lcty::" + name)), None)
+                cands = [v for n, v in tr["kernels"].items() if name.replace("score_reads_kernel", "score_") in n or name in n]
+                k = max(cands, key=lambda v: v.get("fetch_bytes_raw", 0.0) + v.get("write_bytes", 0.0)) if cands else None
                 if k:
-                    r["traffic"] = k["hbm_bytes"]; r["traffic_fetch_raw"] = k.get("fetch_bytes_raw")
-            out["roofline"]["traffic"] = roofs[dominant].get("traffic")
-            out["roofline"]["traffic_source"] = os.path.relpath(args.traffic, ROOT) + " (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE)"
+                    r["traffic_fetch_raw"] = k.get("fetch_bytes_raw"); r["traffic_fetch_x2"] = 2.0 * k.get("fetch_bytes_raw", 0.0); r["traffic_write"] = k.get("write_bytes")
+                    r["traffic_rule"] = "2 x FETCH_SIZE + WRITE_SIZE (streaming reads)" if name in streaming else "FETCH_SIZE + WRITE_SIZE (narrow gathers: raw)"
+                    r["traffic"] = (2.0 if name in streaming else 1.0) * k.get("fetch_bytes_raw", 0.0) + k.get("write_bytes", 0.0)
+            for key in ("traffic", "traffic_fetch_raw", "traffic_fetch_x2", "traffic_write", "traffic_rule"):
+                out["roofline"][key] = roofs[dominant].get(key)
+            out["roofline"]["traffic_source"] = os.path.relpath(args.traffic, ROOT)
     except (OSError, KeyError, ValueError):
         pass
 
@@ -877,7 +889,7 @@ def main():
             out["cpu_baseline"]["recruitment_read_pairs_per_s"] = nsq / (time.perf_counter() - tc)
     if args.distinct_loci >= 2 and queue_mode and world == 1 and args.format == "counted":
         progress("queue of distinct loci, uploads inside the steps")
-        out["distinct_loci_queue"] = distinct_loci_leg(args, ctx, loci, batches, stages, gts, ms_per_step)
+        out["distinct_loci_queue"] = distinct_loci_leg(args, ctx, loci, batches, stages, gts, ms_per_step, host_chunks)
     real_stdout.write(json.dumps(out) + "\n")
     real_stdout.flush()
 
