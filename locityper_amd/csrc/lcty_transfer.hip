@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
     const bool paired = L.is_paired != 0;
     __shared__ Prelim S;
     __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop, sh_redo;
-    __shared__ uint2 lds_cigar[CIGAR_LDS_ITEMS * 64];              // the first items of every lane's CIGAR under construction
+    __shared__ uint32_t lds_cigar[CIGAR_LDS_ITEMS * 64];           // the first items of every lane's CIGAR under construction
 
     for (uint64_t ii = blockIdx.x; ii < T.n_list; ii += gridDim.x) {
         const uint64_t p = T.pair_list ? T.pair_list[ii] : ii;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     else {
                         kind = 3;
                         // Alignment::new + the scoring of push(): the CIGAR goes through the same counting as a record's
-                        const Scored sc = score_cigar(L, [&out](uint32_t i) { const uint2 it = out.get(i); return (it.y << 4) | it.x; }, out.n, new_start,
+                        const Scored sc = score_cigar(L, [&out](uint32_t i) { return out.word(i); }, out.n, new_start,
                                                       Q.target_len, false);
                         na.ln_prob = sc.ln_prob; na.start = new_start; na.edit = sc.edit;
                         na.contig_end = target | (e << 16) | (s_rev ? (1u << 17) : 0u);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     nn.ln_prob = na.ln_prob; nn.start = na.start; nn.contig_end = na.contig_end; nn.edit = na.edit;
                     nn.n_cigar = out.n; nn.cigar_at = word_at; nn.pushed = 0;
                     P.news[slot] = nn;
-                    for (uint32_t k = 0; k < out.n; k++) { const uint2 it = out.get(k); P.words[word_at + k] = (it.y << 4) | it.x; }
+                    for (uint32_t k = 0; k < out.n; k++) P.words[word_at + k] = out.word(k);
                 }
                 __syncthreads();
                 // PrelimAlignments::push of the chunk's new alignments (locs.rs:298-344), all lanes at once: the targets of one source are

@@ -27,7 +27,7 @@ struct Limits {
     uint32_t dp_cells;         // (n + 1) * (m + 1) direction bytes
 };
 __host__ __device__ inline size_t lane_scratch_bytes(const Limits& m) {
-    size_t b = static_cast<size_t>(m.cigar_cap) * 8 * 2;                       // two CIGARs
+    size_t b = static_cast<size_t>(m.cigar_cap) * 4 * 2;                       // two CIGARs, an item a word (length << 4 | operation)
     b += 3 * (static_cast<size_t>(m.dp_dim) + 1) * 12;                         // two rolling rows + the last column
     b += (2 * static_cast<size_t>(m.dp_dim) + 4 + 15) & ~size_t(15);           // operations of one alignment
     b += m.dp_cells;
@@ -49,18 +49,27 @@ constexpr uint32_t CIGAR_LDS_ITEMS = 12;
 // every push put a dependent global load (the lanes' CIGARs are 48 KB apart: an L2 miss each) into every step of every walk.
 // Readers of the items (get / n) call flush() first.
 struct DCigar {
-    uint2* t;              // global part [cap]
-    uint2* l;              // LDS part, already offset by the lane (stride 64), or nullptr
+    // An item is one word, length << 4 | operation (the BAM form, which is also what leaves the kernel). Item i of lane l lies at
+    // t[i * 64] (t already offset by the lane): the CIGARs of the 64 lanes of a wavefront are INTERLEAVED like the aligner's arrays —
+    // the lanes walk their transfers in step, so their pushes fall into the same few rows of 256 bytes (full lines, written once)
+    // and their sequential passes (optimize, scoring, copy-out) read whole rows. Contiguous per lane (48 KB apart) every 8-byte
+    // store opened a line of its own that was evicted long before the lane had filled it (52 KB written per transfer for 12).
+    uint32_t* t;           // global part [cap] rows of 64 words
+    uint32_t* l;           // LDS part, already offset by the lane (stride 64), or nullptr
     uint32_t lds_n;
     uint32_t n, rlen, qlen, cap;
     uint2 pend; bool has_pend;                                               // the item behind item n - 1, not stored yet
     bool overflow;                                                           // items were dropped: the lengths are still right
-    __device__ void init(uint2* buf, uint32_t capacity, uint2* lds = nullptr) {
+    __device__ void init(uint32_t* buf, uint32_t capacity, uint32_t* lds = nullptr) {
         t = buf; cap = capacity; l = lds; lds_n = lds ? CIGAR_LDS_ITEMS : 0u; n = 0; rlen = qlen = 0; overflow = false;
         pend = make_uint2(0, 0); has_pend = false;
     }
-    __device__ __forceinline__ uint2 get(uint32_t i) const { return i < lds_n ? l[i * 64] : t[i]; }
-    __device__ __forceinline__ void set(uint32_t i, uint2 v) { if (i < lds_n) l[i * 64] = v; else t[i] = v; }
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return i < lds_n ? l[i * 64] : t[static_cast<size_t>(i) * 64]; }
+    __device__ __forceinline__ uint2 get(uint32_t i) const { const uint32_t w = word(i); return make_uint2(w & 15u, w >> 4); }
+    __device__ __forceinline__ void set(uint32_t i, uint2 v) {
+        const uint32_t w = (v.y << 4) | v.x;
+        if (i < lds_n) l[i * 64] = w; else t[static_cast<size_t>(i) * 64] = w;
+    }
     __device__ void clear() { n = 0; rlen = qlen = 0; has_pend = false; }
     __device__ __forceinline__ void flush() {
         if (has_pend) { if (n < cap) set(n++, pend); else overflow = true; has_pend = false; }
@@ -98,8 +107,8 @@ struct Seqs {
 // then touch the same element index at the same time, i.e. one contiguous line instead of 64 scattered ones
 constexpr uint32_t LANE_STRIDE = 64;                                  // lane stride of the interleaved arrays
 struct Scratch {
-    uint2* cig_a;          // [cigar_cap]                      (contiguous per lane)
-    uint2* cig_b;          // [cigar_cap] (optimize)           (contiguous per lane)
+    uint32_t* cig_a;       // [cigar_cap] x LANE_STRIDE words
+    uint32_t* cig_b;       // [cigar_cap] x LANE_STRIDE words (optimize)
     uint8_t* ops;          // [2 * dp_dim + 4] x LANE_STRIDE            aligner output, reversed
     uint8_t* dirs;         // [dp_cells] x LANE_STRIDE
     int32_t* rows;         // [2][dp_dim + 1][3] x LANE_STRIDE
@@ -112,10 +121,10 @@ struct Scratch {
 // `base`: the wavefront's block of 64 * lane_scratch_bytes(lim) bytes
 __device__ inline Scratch scratch_at(uint8_t* base, uint32_t lane, const Limits& lim) {
     Scratch s;
-    const size_t cig = static_cast<size_t>(lim.cigar_cap) * 8, row = (static_cast<size_t>(lim.dp_dim) + 1) * 12;
+    const size_t cig = static_cast<size_t>(lim.cigar_cap) * 4, row = (static_cast<size_t>(lim.dp_dim) + 1) * 12;
     const size_t nops = (2 * static_cast<size_t>(lim.dp_dim) + 4 + 15) & ~size_t(15);
-    s.cig_a = reinterpret_cast<uint2*>(base + lane * cig); base += 64 * cig;
-    s.cig_b = reinterpret_cast<uint2*>(base + lane * cig); base += 64 * cig;
+    s.cig_a = reinterpret_cast<uint32_t*>(base) + lane; base += 64 * cig;
+    s.cig_b = reinterpret_cast<uint32_t*>(base) + lane; base += 64 * cig;
     s.rows = reinterpret_cast<int32_t*>(base) + lane; base += 64 * 2 * row;
     s.lastcol = reinterpret_cast<int32_t*>(base) + lane; base += 64 * row;
     s.ops = base + lane; base += 64 * nops;
@@ -333,7 +342,8 @@ __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_
     if (have) {
         for (uint32_t k = i; k < self.n; k++) nc.push_raw(self.get(k));
         nc.flush();
-        for (uint32_t t = 0; t < nc.n; t++) self.set(t, nc.get(t));           // self.tuples = new_cigar.tuples (lengths stay)
+        // self.tuples = new_cigar.tuples (lengths stay): the new items stay where they are, `self` looks there from now on
+        self.t = nc.t; self.l = nullptr; self.lds_n = 0;
         self.n = nc.n;
         self.overflow |= nc.overflow;
     }
