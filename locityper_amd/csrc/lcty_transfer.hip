@@ -325,9 +325,41 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                 // the walks of all lanes, resumed until none of them waits for the aligner any more: one converged call site
                 {
                     Job job;
+                    LS.cig_free = LS.cig_b;
                     do {
                         const uint32_t st = walking ? walk_step(walk, src, Q, out, LS, job, T.walk_budget) : WALK_DONE;
-                        if (st == WALK_JOB) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);
+                        if (st == WALK_JOB) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);   // the clipped ends
+                        if (__any(st == WALK_ASSEMBLE)) {
+                            // The stretches between anchors the walks left behind, resolved for all lanes together: a lane copies its items
+                            // up to the next marker (a few items), then the lanes that stand at a marker call the aligner at one converged
+                            // site. The first item behind a marker was pushed with push_checked (the anchor that follows a stretch): it is
+                            // pushed that way again, behind the aligner's operations; every other item keeps its boundaries.
+                            DCigar fin; fin.init(LS.cig_b, T.lim.cigar_cap);
+                            bool assembling = st == WALK_ASSEMBLE;
+                            uint32_t ai = 0;
+                            bool after_mark = false;
+                            if (assembling) out.flush();
+                            do {
+                                bool need = false;
+                                uint4 jb = make_uint4(0, 0, 0, 0);
+                                if (assembling) {
+                                    while (ai < out.n) {
+                                        const uint2 it = out.get(ai++);
+                                        if (it.x == JOB_MARK) { jb = LS.jobs[static_cast<size_t>(it.y) * LANE_STRIDE]; need = true; break; }
+                                        if (after_mark) { fin.push_checked(it.x, it.y); after_mark = false; }
+                                        else fin.push_raw(it);
+                                    }
+                                    if (!need) assembling = false;
+                                }
+                                if (need) { aligner_align(Q, jb.x, jb.y, jb.z, jb.w, 0, false, fin, LS); after_mark = true; }
+                            } while (__any(assembling));
+                            if (st == WALK_ASSEMBLE) {
+                                fin.rlen = out.rlen; fin.qlen = out.qlen; fin.overflow |= out.overflow;
+                                out = fin;                                        // the CIGAR lives in cig_b now; cig_a is the free one
+                                LS.cig_free = LS.cig_a;
+                                walk.n_jobs = 0;
+                            }
+                        }
                         walking = st != WALK_DONE;
                     } while (__any(walking));
                 }

@@ -31,6 +31,7 @@ __host__ __device__ inline size_t lane_scratch_bytes(const Limits& m) {
     b += 3 * (static_cast<size_t>(m.dp_dim) + 1) * 12;                         // two rolling rows + the last column
     b += (2 * static_cast<size_t>(m.dp_dim) + 4 + 15) & ~size_t(15);           // operations of one alignment
     b += m.dp_cells;
+    b += (static_cast<size_t>(m.cigar_cap) / 2 + 8) * 16;                      // the stretches a walk leaves for the aligner (Walk::n_jobs)
     return (b + 15) & ~size_t(15);
 }
 
@@ -111,6 +112,8 @@ struct Scratch {
     uint32_t* cig_b;       // [cigar_cap] x LANE_STRIDE words (optimize)
     uint8_t* ops;          // [2 * dp_dim + 4] x LANE_STRIDE            aligner output, reversed
     uint8_t* dirs;         // [dp_cells] x LANE_STRIDE
+    uint4* jobs;           // [cigar_cap / 2 + 8] x LANE_STRIDE: {i1, n, j1, m} of the stretches between anchors a walk left for the aligner
+    uint32_t* cig_free;    // the CIGAR buffer that is not in use (cig_b, or cig_a once the assembled CIGAR lives in cig_b)
     int32_t* rows;         // [2][dp_dim + 1][3] x LANE_STRIDE
     int32_t* lastcol;      // [dp_dim + 1][3] x LANE_STRIDE
     Limits lim;
@@ -128,7 +131,9 @@ __device__ inline Scratch scratch_at(uint8_t* base, uint32_t lane, const Limits&
     s.rows = reinterpret_cast<int32_t*>(base) + lane; base += 64 * 2 * row;
     s.lastcol = reinterpret_cast<int32_t*>(base) + lane; base += 64 * row;
     s.ops = base + lane; base += 64 * nops;
-    s.dirs = base + lane;
+    s.dirs = base + lane; base += 64 * static_cast<size_t>(lim.dp_cells);
+    s.jobs = reinterpret_cast<uint4*>(base) + lane;
+    s.cig_free = s.cig_b;
     s.lim = lim; s.big = 0; s.cells = 0;
     return s;
 }
@@ -307,7 +312,7 @@ __device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint3
 __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_gap, uint32_t anchor_size, Scratch& sc) {
     uint32_t i = 0, qpos1 = 0, rpos1 = 0, qpos2 = 0, rpos2 = 0;
     uint32_t flag = 0;
-    DCigar nc; nc.init(sc.cig_b, sc.lim.cigar_cap);
+    DCigar nc; nc.init(sc.cig_free, sc.lim.cigar_cap);
     bool have = false;
     self.flush();
     for (uint32_t j = 0; j < self.n; j++) {
@@ -392,6 +397,7 @@ struct Walk {
     uint32_t last1, pos1, last2, pos2, start_k;
     int add;
     uint32_t phase;
+    uint32_t n_jobs;           // stretches left for the aligner so far: markers {JOB_MARK, index} in the CIGAR under construction
     uint2 nxt1, nxt2;          // the items the two CIGARs continue with (ij item ijx, jk item jk), requested a step before they are needed
 };
 enum : uint32_t { PH_TOP = 0, PH_POST_LEFT, PH_POST, PH_TAIL, PH_POST_RIGHT, PH_FINISH, PH_DONE };
@@ -421,6 +427,7 @@ __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, 
     w.nxt2 = w.jk < w.jk_n ? jk_items[w.jk] : make_uint2(0, 0);
     w.last1 = 0; w.pos1 = 0; w.last2 = w.start_k; w.pos2 = w.start_k;
     w.add = -1;
+    w.n_jobs = 0;
     w.phase = PH_TOP;
     return true;
 }
@@ -430,7 +437,8 @@ __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, 
 // aligner wait for ALL others to need it too (no budget) is the fastest form — 231 ms against 350 ms when the wavefront looks after
 // every phase: a call of the aligner costs the wavefront the same whatever the number of lanes in it, so few full calls beat many
 // sparse ones, although the lanes then spend three quarters of the walk waiting (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 16 of 64).
-enum : uint32_t { WALK_DONE = 0, WALK_JOB = 1, WALK_MORE = 2 };
+enum : uint32_t { WALK_DONE = 0, WALK_JOB = 1, WALK_MORE = 2, WALK_ASSEMBLE = 3 };
+constexpr uint32_t JOB_MARK = 15;                           // operation code of a marker item: its length is the index of the stretch
 __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc, Job& job, uint32_t budget) {
     const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3;
     const uint32_t len_i = S.read_len, len_k = S.target_len;
@@ -458,7 +466,20 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
                         const uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;      // wfa.rs:212
                         if (jump1 == jump2 && jump1 <= safe_mismatch) {
                             for (uint32_t t = 0; t < jump1; t++) out.push_checked(S.r(w.last2 + t) == S.q(w.last1 + t) ? OP_EQ : OP_X, 1);
-                        } else { job = Job{w.last2, jump1, w.last1, jump2, 0, false}; return WALK_JOB; }
+                        } else {
+                            // A stretch for the aligner between two anchors. Nothing of the walk depends on how it aligns (an end-to-end
+                            // alignment consumes both stretches completely, whatever its operations): the stretch is noted, a marker takes
+                            // its place in the CIGAR and the walk goes on. The aligner runs when the walk has reached the end of the
+                            // read's CIGAR (assemble_jobs, WALK_ASSEMBLE) — for all lanes of the wavefront together, stretch by stretch.
+                            // Calling it from here made every lane wait at every stretch of every other lane: an indel every fifty
+                            // bases of a long read, at another step in every lane (16 of 64 lanes active, profiles/r03_pmc_transfer_*).
+                            if (w.n_jobs < sc.lim.cigar_cap / 2 + 8) {
+                                sc.jobs[static_cast<size_t>(w.n_jobs) * LANE_STRIDE] = make_uint4(w.last2, jump1, w.last1, jump2);
+                                out.push_raw(make_uint2(JOB_MARK, w.n_jobs));
+                                out.rlen += jump1; out.qlen += jump2;
+                                w.n_jobs++;
+                            } else out.overflow = true;
+                        }
                     } else if (jump1 > 0) out.push_unchecked(OP_D, jump1);
                     else if (jump2 > 0) out.push_unchecked(OP_I, jump2);
                 }
@@ -485,6 +506,7 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
                 }
             }
         } else if (w.phase == PH_TAIL) {
+            if (w.n_jobs) return WALK_ASSEMBLE;                                  // the caller resolves the markers (assemble_jobs), then comes back
             w.phase = PH_FINISH;
             if (w.last1 != len_i) {
                 // align_ends::<RIGHT>
