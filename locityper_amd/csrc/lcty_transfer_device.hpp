@@ -35,8 +35,9 @@ __host__ __device__ inline size_t lane_scratch_bytes(const Limits& m) {
     return (b + 15) & ~size_t(15);
 }
 
-__device__ __forceinline__ bool cons_q(uint32_t op) { return op == 0 || op == OP_EQ || op == OP_X || op == OP_I || op == OP_S; }
-__device__ __forceinline__ bool cons_r(uint32_t op) { return op == 0 || op == OP_EQ || op == OP_X || op == OP_D; }
+// consumes the query: M I S = X; consumes the reference: M D = X (bit `op` of a mask; operations are 4-bit codes)
+__device__ __forceinline__ bool cons_q(uint32_t op) { return ((0x193u >> (op & 15u)) & 1u) != 0; }
+__device__ __forceinline__ bool cons_r(uint32_t op) { return ((0x185u >> (op & 15u)) & 1u) != 0; }
 __device__ __forceinline__ uint32_t op_invert(uint32_t op) {                  // Operation::invert, cigar.rs:147-159
     return (op == OP_I || op == OP_S) ? OP_D : (op == OP_D ? OP_I : op);
 }
@@ -358,8 +359,8 @@ __device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_
 __device__ __forceinline__ uint32_t cons_class(uint32_t op) { return cons_q(op) && cons_r(op) ? 0u : (cons_q(op) ? 1u : 2u); }
 __device__ inline uint32_t double_move(uint32_t op1, uint32_t op2, uint32_t& pos1, uint32_t& rem1, uint32_t& pos2, uint32_t& rem2) {
     // bit 0 read moves, 1 read CIGAR shifts, 2 haplotype moves, 3 haplotype CIGAR shifts; index = class(op1) * 3 + class(op2)
-    const uint32_t table[9] = {0xF, 0xB, 0xC, 0x3, 0x3, 0xF, 0xE, 0xA, 0xC};
-    const uint32_t f = table[cons_class(op1) * 3 + cons_class(op2)];
+    // the nine cases as nibbles of one constant, case 0 lowest: {0xF, 0xB, 0xC, 0x3, 0x3, 0xF, 0xE, 0xA, 0xC}
+    const uint32_t f = static_cast<uint32_t>(0xCAEF33CBFull >> (4u * (cons_class(op1) * 3 + cons_class(op2)))) & 0xFu;
     const bool rs = f & 2u, hs = f & 8u;
     const uint32_t shift = (rs && (!hs || rem1 <= rem2)) ? rem1 : rem2;
     pos1 += (f & 1u) ? shift : 0; rem1 -= rs ? shift : 0;
@@ -484,10 +485,12 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
                     else if (jump2 > 0) out.push_unchecked(OP_I, jump2);
                 }
             }
-        } else if (w.phase == PH_POST_LEFT) {
+        }
+        if (w.phase == PH_POST_LEFT) {
             w.start_k = w.start_k + w.pos2 - w.last2 - out.rlen;
             w.phase = PH_POST;
-        } else if (w.phase == PH_POST) {
+        }
+        if (w.phase == PH_POST) {
             const uint32_t shift = double_move(w.op1, w.op2, w.pos1, w.rem1, w.pos2, w.rem2);
             if (w.add >= 0) { out.push_checked(static_cast<uint32_t>(w.add), shift); w.last1 = w.pos1; w.last2 = w.pos2; }
             w.phase = PH_TOP;
@@ -505,7 +508,9 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
                     if (w.jk < w.jk_n) w.nxt2 = w.jk_items[w.jk];
                 }
             }
-        } else if (w.phase == PH_TAIL) {
+        }
+        if (w.phase < PH_TAIL) continue;                                         // the common round: one step of the two CIGARs
+        if (w.phase == PH_TAIL) {
             if (w.n_jobs) return WALK_ASSEMBLE;                                  // the caller resolves the markers (assemble_jobs), then comes back
             w.phase = PH_FINISH;
             if (w.last1 != len_i) {
@@ -514,7 +519,8 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
                 if (i1 == i2) out.push_unchecked(OP_I, len_i - w.last1);
                 else { w.phase = PH_POST_RIGHT; job = Job{i1, i2 - i1, w.last1, len_i - w.last1, 2, false}; return WALK_JOB; }
             }
-        } else if (w.phase == PH_POST_RIGHT) {
+        }
+        if (w.phase == PH_POST_RIGHT) {
             uint32_t soft = 0;
             out.flush();
             while (out.n && out.get(out.n - 1).x != OP_EQ) {                    // pop_if(op != Equal)
@@ -524,7 +530,8 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
             }
             if (soft > 0) out.push_unchecked(OP_I, soft);
             w.phase = PH_FINISH;
-        } else if (w.phase == PH_FINISH) {
+        }
+        if (w.phase == PH_FINISH) {
             cigar_optimize(out, S, 20, 5, sc);                                  // MAX_OPTIMIZATION_GAP, OPTIMIZATION_ANCHOR (flushes `out`)
             if (out.n) {                                                        // boundary_ins_to_soft, cigar.rs:554-561
                 const uint2 first = out.get(0);
@@ -534,7 +541,8 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
             }
             w.phase = PH_DONE;
             return WALK_DONE;
-        } else return WALK_DONE;
+        }
+        if (w.phase == PH_DONE) return WALK_DONE;
     }
 }
 
