@@ -177,13 +177,19 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
     int32_t* prev = sc.rows;
     int32_t* cur = sc.rows + static_cast<size_t>(sc.lim.dp_dim + 1) * 3 * LANE_STRIDE;
     for (uint32_t a = 0; a <= n; a++) {
+        // the cell to the left (this row) and the cell above-left (previous row) travel in registers: reading them back from the
+        // rows in memory made every cell wait for the stores of the cell before it
+        int32_t lm = INF32, ld = INF32, li = INF32;                            // cell (a, b - 1)
+        int32_t gm = INF32, gd = INF32, gi = INF32;                            // cell (a - 1, b - 1)
         for (uint32_t b = 0; b <= m; b++) {
             int32_t cm = INF32, cd = INF32, ci = INF32;
             uint32_t dm = 3, dd = 0, di = 0;
+            int32_t um = INF32, ud = INF32, ui = INF32;                        // cell (a - 1, b)
+            if (a > 0) { um = prev[(b * 3) * LANE_STRIDE]; ud = prev[(b * 3 + 1) * LANE_STRIDE]; ui = prev[(b * 3 + 2) * LANE_STRIDE]; }
             if (a == 0 && b == 0) cm = 0;
             else if (mode == 1 && (a == 0 || b == 0)) cm = 0;                 // a prefix of one sequence is skipped for free
             if (a > 0 && b > 0) {
-                const int32_t pm = prev[((b - 1) * 3) * LANE_STRIDE], pd = prev[((b - 1) * 3 + 1) * LANE_STRIDE], pi = prev[((b - 1) * 3 + 2) * LANE_STRIDE];
+                const int32_t pm = gm, pd = gd, pi = gi;
                 const int32_t best = min(pm, min(pd, pi));
                 if (best < INF32) {
                     const int32_t v = best + (S.r(i1 + a - 1) == S.q(j1 + b - 1) ? -mb : PEN_X);
@@ -191,21 +197,23 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
                 }
             }
             if (a > 0) {
-                const int32_t pm = prev[(b * 3) * LANE_STRIDE], pd = prev[(b * 3 + 1) * LANE_STRIDE], pi = prev[(b * 3 + 2) * LANE_STRIDE];
+                const int32_t pm = um, pd = ud, pi = ui;
                 int32_t v = min(pm, pi) + PEN_O + PEN_E;
                 if (pd + PEN_E < v) v = pd + PEN_E;
                 if (v < INF32) { cd = v; dd = (pd + PEN_E == v) ? 1u : (pm <= pi ? 0u : 2u); }
             }
             if (b > 0) {
-                const int32_t pm = cur[((b - 1) * 3) * LANE_STRIDE], pd = cur[((b - 1) * 3 + 1) * LANE_STRIDE], pi = cur[((b - 1) * 3 + 2) * LANE_STRIDE];
+                const int32_t pm = lm, pd = ld, pi = li;
                 int32_t v = min(pm, pd) + PEN_O + PEN_E;
                 if (pi + PEN_E < v) v = pi + PEN_E;
                 if (v < INF32) { ci = v; di = (pi + PEN_E == v) ? 2u : (pm <= pd ? 0u : 1u); }
             }
             cur[(b * 3) * LANE_STRIDE] = cm; cur[(b * 3 + 1) * LANE_STRIDE] = cd; cur[(b * 3 + 2) * LANE_STRIDE] = ci;
             sc.dirs[static_cast<size_t>(a * W + b) * LANE_STRIDE] = static_cast<uint8_t>(dm | (dd << 2) | (di << 4));
+            lm = cm; ld = cd; li = ci;
+            gm = um; gd = ud; gi = ui;
         }
-        sc.lastcol[(a * 3) * LANE_STRIDE] = cur[(m * 3) * LANE_STRIDE]; sc.lastcol[(a * 3 + 1) * LANE_STRIDE] = cur[(m * 3 + 1) * LANE_STRIDE]; sc.lastcol[(a * 3 + 2) * LANE_STRIDE] = cur[(m * 3 + 2) * LANE_STRIDE];
+        sc.lastcol[(a * 3) * LANE_STRIDE] = lm; sc.lastcol[(a * 3 + 1) * LANE_STRIDE] = ld; sc.lastcol[(a * 3 + 2) * LANE_STRIDE] = li;
         int32_t* t = prev; prev = cur; cur = t;
     }
     const int32_t* lastrow = prev;                                           // row n

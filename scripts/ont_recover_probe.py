@@ -8,6 +8,9 @@ from locityper_amd import api, synth, cdefs
 def main():
     import numpy as np
     args = sys.argv[1:]
+    if "--lib" in args:
+        from locityper_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args[args.index("--lib") + 1]); del args[args.index("--lib"):args.index("--lib") + 2]
     nont = int(args[0]) if args and args[0].isdigit() else 6144
     settings = [a for a in args if "=" in a] or ["default"]
     A = 256
