@@ -176,7 +176,12 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
     sc.cells += static_cast<unsigned long long>(n + 1) * W;
     int32_t* prev = sc.rows;
     int32_t* cur = sc.rows + static_cast<size_t>(sc.lim.dp_dim + 1) * 3 * LANE_STRIDE;
+    // the bases of a short query stretch (the rule: a few bases between two anchors) are taken out of the packed read once, not once per cell
+    uint64_t qpack = 0;
+    const bool q_packed = m <= 8;
+    if (q_packed) for (uint32_t b = 0; b < m; b++) qpack |= static_cast<uint64_t>(S.q(j1 + b)) << (8 * b);
     for (uint32_t a = 0; a <= n; a++) {
+        const uint8_t rbase = a > 0 ? S.r(i1 + a - 1) : 0;
         // the cell to the left (this row) and the cell above-left (previous row) travel in registers: reading them back from the
         // rows in memory made every cell wait for the stores of the cell before it
         int32_t lm = INF32, ld = INF32, li = INF32;                            // cell (a, b - 1)
@@ -192,7 +197,8 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
                 const int32_t pm = gm, pd = gd, pi = gi;
                 const int32_t best = min(pm, min(pd, pi));
                 if (best < INF32) {
-                    const int32_t v = best + (S.r(i1 + a - 1) == S.q(j1 + b - 1) ? -mb : PEN_X);
+                    const uint8_t qbase = q_packed ? static_cast<uint8_t>(qpack >> (8 * (b - 1))) : S.q(j1 + b - 1);
+                    const int32_t v = best + (rbase == qbase ? -mb : PEN_X);
                     if (v < cm) { cm = v; dm = pm == best ? 0u : (pd == best ? 1u : 2u); }
                 }
             }
