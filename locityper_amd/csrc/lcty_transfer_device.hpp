@@ -322,50 +322,86 @@ __device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint3
     return 0;
 }
 
+struct Job { uint32_t i1, n, j1, m; int semiglobal; bool left_clipping; };
 // Cigar::optimize (cigar.rs:1167-1237). As upstream, the reference positions are counted from the start of the CIGAR while the
 // sequence handed in is the whole target haplotype (cigar.rs:1362-1364): kept as written.
-__device__ inline void cigar_optimize(DCigar& self, const Seqs& S, uint32_t max_gap, uint32_t anchor_size, Scratch& sc) {
-    uint32_t i = 0, qpos1 = 0, rpos1 = 0, qpos2 = 0, rpos2 = 0;
-    uint32_t flag = 0;
-    DCigar nc; nc.init(sc.cig_free, sc.lim.cigar_cap);
-    bool have = false;
+// Resumable, like the walk: a pass over the items that copies them into the free CIGAR buffer and, for every stretch between two
+// anchors that holds both an insertion and a deletion, wants smart_align. Called in place, each lane ran its stretches alone while
+// the other 63 waited — 40 of the kernel's 100 ms on 10-kb reads; now opt_step hands the stretch out (true, `job` = reference
+// start / length, query start / length) and the caller runs smart_align for all lanes that hold one, at one call site.
+struct OptState {
+    DCigar nc;
+    uint32_t i, j, qpos1, rpos1, qpos2, rpos2, flag, stage;
+    bool have;
+};
+__device__ inline void opt_init(OptState& o, DCigar& self, Scratch& sc) {
     self.flush();
-    for (uint32_t j = 0; j < self.n; j++) {
-        const uint2 item_j = self.get(j);
-        const uint32_t op = item_j.x, len = item_j.y;
-        const bool cq = cons_q(op), cr = cons_r(op);
-        if (cq && cr && len >= anchor_size) {
-            const uint32_t qshift = qpos2 - qpos1, rshift = rpos2 - rpos1;
-            if (flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
-                if (!have) { have = true; for (uint32_t k = 0; k < i; k++) nc.push_raw(self.get(k)); nc.qlen = qpos1; nc.rlen = rpos1; }
-                smart_align(S, rpos1, rpos2, qpos1, qpos2, 0xFFFFFFFFu, nc, sc);
-                i = j;
+    o.nc.init(sc.cig_free, sc.lim.cigar_cap);
+    o.i = o.j = 0; o.qpos1 = o.rpos1 = o.qpos2 = o.rpos2 = 0; o.flag = 0; o.stage = 0; o.have = false;
+}
+__device__ __forceinline__ void opt_begin_copy(OptState& o, const DCigar& self) {
+    if (!o.have) { o.have = true; for (uint32_t k = 0; k < o.i; k++) o.nc.push_raw(self.get(k)); o.nc.qlen = o.qpos1; o.nc.rlen = o.rpos1; }
+}
+__device__ __forceinline__ void opt_past_anchor(OptState& o, const DCigar& self, uint32_t op, uint32_t len) {
+    o.qpos2 += len; o.rpos2 += len; o.qpos1 = o.qpos2; o.rpos1 = o.rpos2; o.flag = 0;
+    if (o.have) {
+        for (uint32_t k = o.i; k < o.j; k++) o.nc.push_raw(self.get(k));
+        o.nc.push_checked(op, len);
+        o.nc.qlen = o.qpos2; o.nc.rlen = o.rpos2;
+    }
+    o.i = o.j + 1;
+    o.j++;
+}
+// true: align reference [job.i1, +job.n) with query [job.j1, +job.m) into o.nc (smart_align without a maximum gap), then call again
+__device__ inline bool opt_step(OptState& o, DCigar& self, uint32_t max_gap, uint32_t anchor_size, Job& job) {
+    for (;;) {
+        if (o.stage == 0) {                                                   // over the items
+            if (o.j >= self.n) { o.stage = 2; continue; }
+            const uint2 item_j = self.get(o.j);
+            const uint32_t op = item_j.x, len = item_j.y;
+            const bool cq = cons_q(op), cr = cons_r(op);
+            if (cq && cr && len >= anchor_size) {
+                const uint32_t qshift = o.qpos2 - o.qpos1, rshift = o.rpos2 - o.rpos1;
+                if (o.flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
+                    opt_begin_copy(o, self);
+                    job = Job{o.rpos1, o.rpos2 - o.rpos1, o.qpos1, o.qpos2 - o.qpos1, 0, false};
+                    o.stage = 1;
+                    return true;
+                }
+                opt_past_anchor(o, self, op, len);
+            } else {
+                o.qpos2 += cq ? len : 0; o.rpos2 += cr ? len : 0;
+                o.flag |= (cq ? 0u : 1u) | ((cr ? 0u : 1u) << 1);
+                o.j++;
             }
-            qpos2 += len; rpos2 += len; qpos1 = qpos2; rpos1 = rpos2; flag = 0;
-            if (have) {
-                for (uint32_t k = i; k < j; k++) nc.push_raw(self.get(k));
-                nc.push_checked(op, len);
-                nc.qlen = qpos2; nc.rlen = rpos2;
+        } else if (o.stage == 1) {                                            // back from the aligner, in front of the anchor item j
+            o.i = o.j;
+            const uint2 item_j = self.get(o.j);
+            opt_past_anchor(o, self, item_j.x, item_j.y);
+            o.stage = 0;
+        } else if (o.stage == 2) {                                            // what is behind the last anchor
+            const uint32_t qshift = o.qpos2 - o.qpos1, rshift = o.rpos2 - o.rpos1;
+            o.stage = 4;
+            if (o.flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
+                opt_begin_copy(o, self);
+                job = Job{o.rpos1, o.rpos2 - o.rpos1, o.qpos1, o.qpos2 - o.qpos1, 0, false};
+                o.stage = 3;
+                return true;
             }
-            i = j + 1;
+        } else if (o.stage == 3) {
+            o.i = self.n;
+            o.stage = 4;
         } else {
-            qpos2 += cq ? len : 0; rpos2 += cr ? len : 0;
-            flag |= (cq ? 0u : 1u) | ((cr ? 0u : 1u) << 1);
+            if (o.have) {
+                for (uint32_t k = o.i; k < self.n; k++) o.nc.push_raw(self.get(k));
+                o.nc.flush();
+                // self.tuples = new_cigar.tuples (lengths stay): the new items stay where they are, `self` looks there from now on
+                self.t = o.nc.t; self.l = nullptr; self.lds_n = 0;
+                self.n = o.nc.n;
+                self.overflow |= o.nc.overflow;
+            }
+            return false;
         }
-    }
-    const uint32_t qshift = qpos2 - qpos1, rshift = rpos2 - rpos1;
-    if (flag == 3 && !(max_gap < qshift) && !(max_gap < rshift)) {
-        if (!have) { have = true; for (uint32_t k = 0; k < i; k++) nc.push_raw(self.get(k)); nc.qlen = qpos1; nc.rlen = rpos1; }
-        smart_align(S, rpos1, rpos2, qpos1, qpos2, 0xFFFFFFFFu, nc, sc);
-        i = self.n;
-    }
-    if (have) {
-        for (uint32_t k = i; k < self.n; k++) nc.push_raw(self.get(k));
-        nc.flush();
-        // self.tuples = new_cigar.tuples (lengths stay): the new items stay where they are, `self` looks there from now on
-        self.t = nc.t; self.l = nullptr; self.lds_n = 0;
-        self.n = nc.n;
-        self.overflow |= nc.overflow;
     }
 }
 
@@ -404,7 +440,6 @@ struct SrcCigar {
 // at different points of their walks; if the dynamic programme were called from inside the walk, the wavefront would run it once
 // per distinct call point with one lane active. Instead a lane walks until it needs the aligner, hands the stretch out as a `Job`
 // and waits; the caller runs the aligner for all waiting lanes at one converged call site and resumes the walks.
-struct Job { uint32_t i1, n, j1, m; int semiglobal; bool left_clipping; };
 struct Walk {
     const uint2* jk_items; uint32_t jk_n; int dir_jk;
     uint32_t jk, op2, len2, rem2;
@@ -413,9 +448,10 @@ struct Walk {
     int add;
     uint32_t phase;
     uint32_t n_jobs;           // stretches left for the aligner so far: markers {JOB_MARK, index} in the CIGAR under construction
+    OptState opt;              // Cigar::optimize over the finished CIGAR (PH_OPT)
     uint2 nxt1, nxt2;          // the items the two CIGARs continue with (ij item ijx, jk item jk), requested a step before they are needed
 };
-enum : uint32_t { PH_TOP = 0, PH_POST_LEFT, PH_POST, PH_TAIL, PH_POST_RIGHT, PH_FINISH, PH_DONE };
+enum : uint32_t { PH_TOP = 0, PH_POST_LEFT, PH_POST, PH_TAIL, PH_POST_RIGHT, PH_FINISH, PH_OPT, PH_DONE };
 
 // returns false when the whole read alignment is a copy (the read lies inside one long match of the two haplotypes): `out` is final
 __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, int dir_jk, uint32_t start_j, uint32_t off_ix, uint32_t off_qpos,
@@ -452,7 +488,7 @@ __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, 
 // aligner wait for ALL others to need it too (no budget) is the fastest form — 231 ms against 350 ms when the wavefront looks after
 // every phase: a call of the aligner costs the wavefront the same whatever the number of lanes in it, so few full calls beat many
 // sparse ones, although the lanes then spend three quarters of the walk waiting (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 16 of 64).
-enum : uint32_t { WALK_DONE = 0, WALK_JOB = 1, WALK_MORE = 2, WALK_ASSEMBLE = 3 };
+enum : uint32_t { WALK_DONE = 0, WALK_JOB = 1, WALK_MORE = 2, WALK_ASSEMBLE = 3, WALK_OPT_JOB = 4 };
 constexpr uint32_t JOB_MARK = 15;                           // operation code of a marker item: its length is the index of the stretch
 __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc, Job& job, uint32_t budget) {
     const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3;
@@ -546,7 +582,11 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
             w.phase = PH_FINISH;
         }
         if (w.phase == PH_FINISH) {
-            cigar_optimize(out, S, 20, 5, sc);                                  // MAX_OPTIMIZATION_GAP, OPTIMIZATION_ANCHOR (flushes `out`)
+            opt_init(w.opt, out, sc);                                           // MAX_OPTIMIZATION_GAP 20, OPTIMIZATION_ANCHOR 5 (flushes `out`)
+            w.phase = PH_OPT;
+        }
+        if (w.phase == PH_OPT) {
+            if (opt_step(w.opt, out, 20, 5, job)) return WALK_OPT_JOB;         // the caller: smart_align into w.opt.nc, then back here
             if (out.n) {                                                        // boundary_ins_to_soft, cigar.rs:554-561
                 const uint2 first = out.get(0);
                 if (first.x == OP_I) out.set(0, make_uint2(OP_S, first.y));
