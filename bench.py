@@ -76,6 +76,8 @@ def parse_args():
                          "position of the queue uploaded (lcty_reads_append_counted on the copy stream, from a loader thread) while the position "
                          "before it is solved, three batch objects rotating (lcty_solve_queue_fed); 0 = skip")
     ap.add_argument("--distinct-steps", type=int, default=0, help="positions of the timed queue of the --distinct-loci measurement (0: as many as --steps, so that the two queues compare like for like)")
+    ap.add_argument("--distinct-no-upload", action="store_true", help="developer measurement: the rotation of three batch objects through lcty_solve_queue_fed "
+                    "WITHOUT the uploads (every batch keeps the locus the warm-up gave it): what the rotation alone costs")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (launch-path checks on a one-GPU box; reported in the line)")
     ap.add_argument("--pipeline", type=int, default=0, help="ignored (round 1 option; the queue of loci is the default mode now)")
     ap.add_argument("--recruit-sample", type=int, default=8_000_000,
@@ -330,9 +332,10 @@ def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_ste
                     tl = time.perf_counter()
                     L, loc, chunks = host[(first_it + i) % D]
                     b = rot[i % 3]
-                    b.reset(loc)
-                    for pc, alns in chunks:
-                        b.append(pc, counted=alns)
+                    if not (args.distinct_no_upload and first_it == 0 and loaded_once[0]):
+                        b.reset(loc)
+                        for pc, alns in chunks:
+                            b.append(pc, counted=alns)
                     load_s[i] = time.perf_counter() - tl
                     if trace: progress(f"  position {i}: loaded in {load_s[i]:.3f} s")
                     ready[i].set()
@@ -362,9 +365,11 @@ def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_ste
         ok = all(tuple(int(x) for x in gts[int(c.ixs[0])]) == tuple(host[(first_it + i) % D][0].true_genotype) for i, c in enumerate(calls))
         return dt, ok, load_s
 
+    loaded_once = [False]
     run(3, 0)                                                 # every batch object once: workspaces, page tables
+    loaded_once[0] = True
     ctx.timing_reset()
-    dt, ok, load_s = run(K, 1)
+    dt, ok, load_s = run(K, 0 if args.distinct_no_upload else 1)
     kern = {name: ctx.timing(k)[1] / K for name, k in (("score_reads_kernel", api.K_SCORE), ("prefilter_tile_kernel", api.K_PREFILTER),
             ("solve_init_kernel", api.K_SOLVE_INIT), ("greedy_loop_kernel", api.K_SOLVE), ("anneal_loop_kernel", api.K_ANNEAL),
             ("build_loc_table_kernel", api.K_SOLVE_TABLE))}
