@@ -71,11 +71,14 @@ def parse_args():
                     help="one locus over all ranks, whole path: every rank scores and prefilters all reads of the locus (replicated), the "
                          "(genotype, attempt) chains of both solver stages are dealt to the ranks and their likelihoods all-gathered on the "
                          "devices (RCCL; lcty_solve_stage_sharded, SURVEY 8e level 3); strong scaling. Not the default either")
-    ap.add_argument("--distinct-loci", type=int, default=3,
+    ap.add_argument("--distinct-loci", type=int, default=2,
                     help="extra measurement: a queue of loci that are NOT resident — this many distinct loci in page-locked host memory, every "
                          "position of the queue uploaded (lcty_reads_append_counted on the copy stream, from a loader thread) while the position "
-                         "before it is solved, three batch objects rotating (lcty_solve_queue_fed); 0 = skip")
+                         "before it is solved, three batch objects rotating (lcty_solve_queue_fed); 0 = skip. The default, 2, takes the two loci "
+                         "of the main measurement, so that the two queues do the same work (loci differ: with a third locus the resident queue "
+                         "itself goes from 539 to 621 ms per step)")
     ap.add_argument("--distinct-steps", type=int, default=0, help="positions of the timed queue of the --distinct-loci measurement (0: as many as --steps, so that the two queues compare like for like)")
+    ap.add_argument("--loci-seeds", default="", help="developer measurement: seed offsets of the resident loci, comma-separated (default 0,1)")
     ap.add_argument("--distinct-no-upload", action="store_true", help="developer measurement: the rotation of three batch objects through lcty_solve_queue_fed "
                     "WITHOUT the uploads (every batch keeps the locus the warm-up gave it): what the rotation alone costs")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (launch-path checks on a one-GPU box; reported in the line)")
@@ -275,7 +278,8 @@ def spawn_ranks(args):
 
 
 def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_step, host_chunks):
-    """The queue as `locityper genotype` meets it: every locus arrives from the host. D distinct loci (their counted alignment tables
+    """The queue as `locityper genotype` meets it: every locus arrives from the host. D distinct loci — the loci of the main measurement first,
+    so that with the default D = 2 the two queues do the same work — (their counted alignment tables
     and bases in page-locked memory: 8.3 GB each at 1 M x 256), K positions cycling over them; a loader thread resets one of three batch
     objects (lcty_reads_reset), uploads the position's chunks (lcty_reads_append_counted: copies on the context's copy stream, the CSR
     validation on the host's cores next to them) and hands it to lcty_solve_queue_fed, which releases a batch when its last stage is
@@ -451,7 +455,8 @@ def main():
     first = None
     n_chunks = (args.pairs + args.chunk - 1) // args.chunk
     for j in range(n_loci):
-        L = synth.SynthLocus(A, total_pairs, seed=synth.SEED + (0 if one_locus else n_loci * rank + j))
+        seed_off = int(args.loci_seeds.split(",")[j]) if args.loci_seeds else (0 if one_locus else n_loci * rank + j)
+        L = synth.SynthLocus(A, total_pairs, seed=synth.SEED + seed_off)
         params = api.resolve_params(api.default_params(), L.bg)
         t1 = time.time()
         loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
