@@ -329,7 +329,6 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     do {
                         const uint32_t st = walking ? walk_step(walk, src, Q, out, LS, job, T.walk_budget) : WALK_DONE;
                         if (st == WALK_JOB) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);   // the clipped ends
-                        if (st == WALK_OPT_JOB) smart_align(Q, job.i1, job.i1 + job.n, job.j1, job.j1 + job.m, 0xFFFFFFFFu, walk.opt.nc, LS);       // Cigar::optimize
                         if (__any(st == WALK_ASSEMBLE)) {
                             // The stretches between anchors the walks left behind, resolved for all lanes together: a lane copies its items
                             // up to the next marker (a few items), then the lanes that stand at a marker call the aligner at one converged
@@ -361,7 +360,11 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                                 walk.n_jobs = 0;
                             }
                         }
-                        walking = st != WALK_DONE;
+                        if (__any(st == WALK_OPTIMIZE)) {
+                            optimize_and_finish(st == WALK_OPTIMIZE, out, Q, LS);
+                            if (st == WALK_OPTIMIZE) walk.phase = PH_DONE;
+                        }
+                        walking = st != WALK_DONE && st != WALK_OPTIMIZE;
                     } while (__any(walking));
                 }
                 out.flush();

@@ -448,10 +448,9 @@ struct Walk {
     int add;
     uint32_t phase;
     uint32_t n_jobs;           // stretches left for the aligner so far: markers {JOB_MARK, index} in the CIGAR under construction
-    OptState opt;              // Cigar::optimize over the finished CIGAR (PH_OPT)
     uint2 nxt1, nxt2;          // the items the two CIGARs continue with (ij item ijx, jk item jk), requested a step before they are needed
 };
-enum : uint32_t { PH_TOP = 0, PH_POST_LEFT, PH_POST, PH_TAIL, PH_POST_RIGHT, PH_FINISH, PH_OPT, PH_DONE };
+enum : uint32_t { PH_TOP = 0, PH_POST_LEFT, PH_POST, PH_TAIL, PH_POST_RIGHT, PH_FINISH, PH_DONE };
 
 // returns false when the whole read alignment is a copy (the read lies inside one long match of the two haplotypes): `out` is final
 __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, int dir_jk, uint32_t start_j, uint32_t off_ix, uint32_t off_qpos,
@@ -488,7 +487,7 @@ __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, 
 // aligner wait for ALL others to need it too (no budget) is the fastest form — 231 ms against 350 ms when the wavefront looks after
 // every phase: a call of the aligner costs the wavefront the same whatever the number of lanes in it, so few full calls beat many
 // sparse ones, although the lanes then spend three quarters of the walk waiting (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 16 of 64).
-enum : uint32_t { WALK_DONE = 0, WALK_JOB = 1, WALK_MORE = 2, WALK_ASSEMBLE = 3, WALK_OPT_JOB = 4 };
+enum : uint32_t { WALK_DONE = 0, WALK_JOB = 1, WALK_MORE = 2, WALK_ASSEMBLE = 3, WALK_OPTIMIZE = 4 };
 constexpr uint32_t JOB_MARK = 15;                           // operation code of a marker item: its length is the index of the stretch
 __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S, DCigar& out, Scratch& sc, Job& job, uint32_t budget) {
     const uint32_t anchor_size = 5, ANCHOR_MARGIN = 5, CLIP_PADDING = 3;
@@ -581,22 +580,28 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
             if (soft > 0) out.push_unchecked(OP_I, soft);
             w.phase = PH_FINISH;
         }
-        if (w.phase == PH_FINISH) {
-            opt_init(w.opt, out, sc);                                           // MAX_OPTIMIZATION_GAP 20, OPTIMIZATION_ANCHOR 5 (flushes `out`)
-            w.phase = PH_OPT;
-        }
-        if (w.phase == PH_OPT) {
-            if (opt_step(w.opt, out, 20, 5, job)) return WALK_OPT_JOB;         // the caller: smart_align into w.opt.nc, then back here
-            if (out.n) {                                                        // boundary_ins_to_soft, cigar.rs:554-561
-                const uint2 first = out.get(0);
-                if (first.x == OP_I) out.set(0, make_uint2(OP_S, first.y));
-                const uint2 last = out.get(out.n - 1);
-                if (last.x == OP_I) out.set(out.n - 1, make_uint2(OP_S, last.y));
-            }
-            w.phase = PH_DONE;
-            return WALK_DONE;
-        }
+        if (w.phase == PH_FINISH) return WALK_OPTIMIZE;                          // the caller: optimize_and_finish for all lanes together
         if (w.phase == PH_DONE) return WALK_DONE;
+    }
+}
+
+// Cigar::optimize (MAX_OPTIMIZATION_GAP 20, OPTIMIZATION_ANCHOR 5) + boundary_ins_to_soft (cigar.rs:554-561) of the finished transfers
+// of a wavefront: `mine` = this lane has one. The lanes scan their CIGARs; those that stand in front of a stretch call smart_align at one site.
+__device__ inline void optimize_and_finish(bool mine, DCigar& out, const Seqs& S, Scratch& sc) {
+    OptState o;
+    Job job;
+    bool active = mine;
+    if (mine) opt_init(o, out, sc);
+    do {
+        const bool need = active && opt_step(o, out, 20, 5, job);
+        if (active && !need) active = false;
+        if (need) smart_align(S, job.i1, job.i1 + job.n, job.j1, job.j1 + job.m, 0xFFFFFFFFu, o.nc, sc);
+    } while (__any(active));
+    if (mine && out.n) {
+        const uint2 first = out.get(0);
+        if (first.x == OP_I) out.set(0, make_uint2(OP_S, first.y));
+        const uint2 last = out.get(out.n - 1);
+        if (last.x == OP_I) out.set(out.n - 1, make_uint2(OP_S, last.y));
     }
 }
 
