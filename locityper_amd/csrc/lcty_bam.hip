@@ -228,9 +228,13 @@ int32_t lcty_write_bam(const char* path, lcty_reads* reads, const lcty_reads_hos
         };
 
         uint64_t g = 0;                                             // index among the used reads
+        // bam.rs:372-398: the records of ALL used reads first, then those of the unused ones — the stable sort below keeps that order
+        // among records of one position
+        for (int pass = 0; pass < 2; pass++)
         for (uint64_t r = 0; r < R; r++) {
             const bool used = status[r] == LCTY_READ_GOOD, unused = status[r] == LCTY_READ_FEW_KMERS;
             if (!used && !unused) continue;
+            if ((pass == 0) != used) continue;
             // the single alignments of the pair, normalised per read end (normalize_probs, locs.rs:358-360)
             const uint64_t a0 = table->aln_off[r], a1 = table->aln_off[r + 1];
             std::vector<AlnInfo> info(a1 - a0);

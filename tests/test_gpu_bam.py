@@ -78,6 +78,10 @@ def test_bam_of_one_genotype(gpu_ctx, tmp_path, paired):
     # coordinate-sorted, unmapped templates at the end
     keys = [(r["tid"] & 0xFFFFFFFF, r["pos"]) for r in recs]
     assert keys == sorted(keys)
+    # records of one position: those of the used reads before those of the unused ones (bam.rs:372-398 pushes all used reads first, the sort is stable)
+    for x, y in zip(recs, recs[1:]):
+        if (x["tid"], x["pos"]) == (y["tid"], y["pos"]):
+            assert not (x["tags"]["us"] == "F" and y["tags"]["us"] == "T")
     status, weight, unm, uk = aa.status()
     by_read = {}
     for r in recs:
