@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -82,9 +83,15 @@ bool inflate_bgzf(const std::vector<uint8_t>& in, const char* what, std::vector<
         }
         inflateEnd(&zs);
     };
+    // a thread that cannot be started: its share is inflated here (every thread that did start is joined)
     std::vector<std::thread> th;
-    for (uint32_t tid = 1; tid < n_threads; tid++) th.emplace_back(work, tid);
+    std::vector<uint32_t> here;
+    for (uint32_t tid = 1; tid < n_threads; tid++) {
+        try { th.emplace_back(work, tid); }
+        catch (const std::system_error&) { here.push_back(tid); }
+    }
     work(0);
+    for (uint32_t tid : here) work(tid);
     for (auto& x : th) x.join();
     for (int rc : rc_of) if (rc != Z_OK) fail(LCTY_ERR_INVALID_DATA, "%s: corrupt BGZF block (zlib %d)", what, rc);
     return true;

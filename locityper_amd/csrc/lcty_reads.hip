@@ -4,6 +4,7 @@
 #include <memory>
 
 #include <string>
+#include <system_error>
 #include <thread>
 
 #include "lcty_objects.hpp"

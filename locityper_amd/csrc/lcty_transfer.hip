@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <memory>
 #include <numeric>
+#include <system_error>
 #include <thread>
 
 #include "lcty_objects.hpp"
@@ -623,9 +624,15 @@ int32_t lcty_locus_set_hap_alns(lcty_locus* loc, uint32_t n_entries, const uint3
             }
         };
         auto in_parallel = [&](auto&& fn) {
+            // a thread that cannot be started: its share is done here (every thread that did start is joined)
             std::vector<std::thread> th;
-            for (uint32_t tid = 1; tid < n_threads; tid++) th.emplace_back(fn, tid);
+            std::vector<uint32_t> here;
+            for (uint32_t tid = 1; tid < n_threads; tid++) {
+                try { th.emplace_back(fn, tid); }
+                catch (const std::system_error&) { here.push_back(tid); }
+            }
             fn(0u);
+            for (uint32_t tid : here) fn(tid);
             for (auto& x : th) x.join();
         };
         in_parallel(build);
