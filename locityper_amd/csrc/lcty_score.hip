@@ -260,9 +260,15 @@ __device__ __forceinline__ void pair_unique_kmers_regs(const uint64_t* kset, uin
             // 128-base span of this chunk = words 2t, 2t+1, 2t+2 (wave-uniform indices)
             const uint64_t src = m ? bw1 : bw0;
             const uint32_t nsrc = m ? nm1 : nm0;
-            const int wi = static_cast<int>((2 * t) & 63u);
-            const uint64_t wA = __shfl(src, wi), wB = __shfl(src, (wi + 1) & 63), wC = __shfl(src, (wi + 2) & 63);
-            const uint32_t nA = __shfl(nsrc, wi), nB = __shfl(nsrc, (wi + 1) & 63), nC = __shfl(nsrc, (wi + 2) & 63);
+            // the three words of the chunk come from lanes whose index is the same for the whole wavefront: v_readlane (a scalar
+            // operand for what follows), not a trip through the LDS crossbar
+            const int wi = __builtin_amdgcn_readfirstlane(static_cast<int>((2 * t) & 63u));
+            auto lane64 = [](uint64_t v, int l) -> uint64_t {
+                const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), l), hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), l);
+                return (static_cast<uint64_t>(hi) << 32) | lo;
+            };
+            const uint64_t wA = lane64(src, wi), wB = lane64(src, (wi + 1) & 63), wC = lane64(src, (wi + 2) & 63);
+            const uint32_t nA = __builtin_amdgcn_readlane(nsrc, wi), nB = __builtin_amdgcn_readlane(nsrc, (wi + 1) & 63), nC = __builtin_amdgcn_readlane(nsrc, (wi + 2) & 63);
             key[j] = canon_from_words(half ? wB : wA, half ? wC : wB, sh2, k);
             uint32_t nbits = (half ? nB : nA) >> sh1;
             if (sh1 + k > 32u) nbits |= (half ? nC : nB) << (32u - sh1);
