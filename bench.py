@@ -880,6 +880,19 @@ def main():
                              "second_scoring_pass_ms": ms_sc, "recover_and_rescore_s": t_rec, "first_call_s": t_rec_first, "set_hap_alns_s": t_set,
                              "set_hap_alns_library_call_s": loco.set_hap_alns_call_s,
                              "good_reads_after": ao.n_good(), "level_pairs": ao.recover_stats()}
+        # the recovered table carries the truth: run_filter over all genotypes on it must put the genotype the reads were drawn from first
+        sc_o = ao.run_filter()
+        out["long_reads"]["prefilter_best_is_truth"] = bool(tuple(int(x) for x in gts[int(np.argmax(sc_o))]) == tuple(Lo.true_genotype))
+        # per transfer the kernel has to look at the read's CIGAR (4 B per item), the part of the haplotype-to-haplotype CIGAR under the read
+        # (8 B per item), the target's bases under the read, and write the transferred CIGAR (4 B per item): its algorithmic bytes — a small
+        # fraction of the roofline: the walk is bound by instruction issue
+        cig_items = float(sum(len(c.cigar) for c in prim)) / max(sum(c.n_pairs for c in prim), 1)
+        hap_items = float(np.mean([len(h[2]) for h in Ho[:512]])) * 10_000.0 / float(np.mean(np.diff(Lo.seq_off)))
+        per_transfer = 4.0 * cig_items + 8.0 * hap_items + 10_000.0 + 4.0 * cig_items
+        out["long_reads"]["roofline"] = {"bound": "hbm", "kernel": "transfer_kernel", "achieved": per_transfer * n_new / (ms_tr * 1e-3) / 1e9 if ms_tr else None,
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_transfer * n_new / (ms_tr * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_tr else None,
+                                         "traffic": None, "algorithmic_bytes_per_transfer": per_transfer,
+                                         "what": "read CIGAR + haplotype CIGAR under the read + target bases under the read + transferred CIGAR, per transfer"}
         ao.close(); del prim
 
     if first is not None:
