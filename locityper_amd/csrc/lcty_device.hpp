@@ -12,7 +12,7 @@ namespace lcty {
 constexpr int WAVE = 64;                       // CDNA4 wavefront
 // the pair-alignment arena of a scored batch: a wavefront of a large scoring launch reserves PA_CHUNK entries at a time
 // (lcty_score.hip); a batch that can hold such a launch gets an eighth more room and a chunk per wavefront (lcty_reads_create)
-constexpr uint32_t PA_CHUNK = 4096, PA_POOL_MIN_PAIRS = 32, PA_MAX_GRID = 256 * 16;
+constexpr uint32_t PA_CHUNK = 8192, PA_POOL_MIN_PAIRS = 32, PA_MAX_GRID = 256 * 16;
 constexpr uint64_t KSET_EMPTY = ~0ull;         // never a valid canonical k-mer for k <= 31
 
 // Device record of one PairAlignment (src/model/locs.rs:668-676), 24 B.

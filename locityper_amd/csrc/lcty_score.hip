@@ -1108,13 +1108,37 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
                 return fast_from_refs(ins, has1 ? ref_from_counted(L, r1, h1, bl0) : none, has2 ? ref_from_counted(L, r2, h2, bl1) : none,
                                       has1, has2, unm_ins_penalty, paired);
             };
+            // Where the entries go is decided BEFORE the contigs are looked at when the wavefront's share of the arena can hold the
+            // most this pair could write (3 entries per contig that holds a saved alignment): the candidates are then built once,
+            // counted and written in the same pass. Otherwise (no shares in a small launch, or a pair too big for one) the count
+            // comes first and the candidates are built a second time for the writing.
+            uint32_t ub = 0;
+            for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
+                const uint32_t c = c0 + lane;
+                ub += __popcll(__ballot(c < A && (head[c] & head[A + c]) != 0xFFFFFFFFu));
+            }
+            ub *= 3;
+            const bool at_once = R.pa_chunk != 0 && static_cast<uint64_t>(ub) * 8 <= R.pa_chunk;
+            bool room = true;
+            if (at_once) {
+                if (ub > pool_left) {
+                    if (lane == 0) pool_at = atomicAdd(R.pa_count, static_cast<unsigned long long>(R.pa_chunk));
+                    pool_at = __shfl(pool_at, 0);
+                    pool_left = R.pa_chunk;
+                }
+                pa_base = pool_at;
+                room = pa_base + ub <= R.pa_cap;
+            }
             // ---------------- pass 3a ----------------
             bool inb = false;
+            uint32_t run = 0;
             for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
                 const uint32_t c = c0 + lane;
                 ContigResult res{-INFINITY, 0};
+                Fast3 f;
+                f.has1 = f.has2 = false;
                 if (c < A) {
-                    const Fast3 f = candidates(c);
+                    f = candidates(c);
                     const uint32_t clen = L.allele_len[c];
                     if (f.has1) { const uint32_t mid = (f.a1.start + f.a1.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
                     if (f.has2) { const uint32_t mid = (f.a2.start + f.a2.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
@@ -1122,6 +1146,13 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
                     cnt8[c] = static_cast<uint8_t>(res.cnt);
                     mrow[c] = res.cnt ? res.best * weight : unmapped_prob;
                     total_cnt += res.cnt;
+                }
+                if (at_once) {
+                    uint32_t tot;
+                    const uint32_t my_off = run + wave_excl_scan_u32(res.cnt, lane, &tot);
+                    run += tot;
+                    if (c < A) R.pa_idx[p * A + c] = my_off | (res.cnt << 24);
+                    if (room && res.cnt) fast_emit(f, res.cnt, weight, c, R.pa + pa_base + my_off);
                 }
             }
             const bool any_inb = __ballot(inb) != 0ull;
@@ -1131,7 +1162,11 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
             if (!any_inb) { status = LCTY_READ_OUT_OF_BOUNDS; accepted = false; }
             else if (!edit_good) { status = LCTY_READ_POORLY_MAPPED; accepted = false; }
             else status = weight >= L.min_weight ? LCTY_READ_GOOD : LCTY_READ_FEW_KMERS;
-            if (accepted) {
+            if (accepted && at_once) {
+                // what a pair that is not kept wrote stays behind the share's mark and is written over by the next pair
+                if (!room && lane == 0) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
+                pool_at += total_cnt; pool_left -= total_cnt;
+            } else if (accepted) {
                 if (R.pa_chunk == 0 || static_cast<uint64_t>(total_cnt) * 8 > R.pa_chunk) {
                     if (lane == 0) pa_base = atomicAdd(R.pa_count, static_cast<unsigned long long>(total_cnt));
                     pa_base = __shfl(pa_base, 0);
@@ -1145,9 +1180,9 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
                     pool_at += total_cnt; pool_left -= total_cnt;
                 }
                 if (lane == 0 && pa_base + total_cnt > R.pa_cap) atomicMax(R.err_flag, static_cast<uint32_t>(LCTY_ERR_RUNTIME));
-                const bool room = pa_base + total_cnt <= R.pa_cap;
+                room = pa_base + total_cnt <= R.pa_cap;
                 // ---------------- pass 3b: every lane wrote its own cnt8 entries: no barrier in between ----------------
-                uint32_t run = 0;
+                run = 0;
                 for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
                     const uint32_t c = c0 + lane;
                     const uint32_t cnt = c < A ? cnt8[c] : 0u;
