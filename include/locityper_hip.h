@@ -508,8 +508,18 @@ int32_t lcty_recruit(lcty_targets* targets, const lcty_reads_host* chunk, int32_
  * scores higher -> the best candidate of a read end is its primary record, the others with score >= min_score secondary
  * records, a read end without candidates an unmapped record. Record order, flags, =/X/S CIGARs and SEQ orientation are those of
  * the BAM the reference reads, so the result is a chunk for lcty_reads_append; the alleles outside the basis are reached with
- * lcty_recover_alignments. Limits of the slice: read ends of up to 256 bases, up to 32 basis alleles, seed length 8..31, at most
- * 64 seeds per read end and 1 024 votes (the first ones in seed order).
+ * lcty_recover_alignments. Limits of this SHORT route: read ends of up to 256 bases, up to 32 basis alleles, seed length 8..31, at
+ * most 64 seeds per read end and 1 024 votes (the first ones in seed order).
+ * The LONG route (locityper_amd/csrc/lcty_map_long.hip states it, tests/pyref_map_long.py restates it) takes what the short one
+ * refuses — the reference's long-read case, minimap2 -x map-ont / map-hifi --eqx (genotype.rs:990-1002): read ends of up to 2^20 - 1
+ * bases on up to 256 basis alleles. Seeds as above (any number of them) -> every (seed, place) is an anchor (q, t) of its (basis allele,
+ * strand), t on the allele in the read's orientation -> per (allele, strand) one chain: an anchor follows one of the `chain_back`
+ * anchors of its group before it, at most `chain_gap` bases on in both sequences, at most `chain_skew` diagonals apart, gaining
+ * min(dq, dt, k) - (0 if on the same diagonal else 2 + skew) -> the (allele, strand)s whose best chain has >= min_votes anchors and
+ * >= half the score of the read end's best one are aligned along their chain: gap-affine (gaps open from any state) from node to
+ * node, in a band of min(0, d) - band .. max(0, d) + band diagonals between two anchors d diagonals apart, and +- band beyond the first
+ * and last anchor, where the alignment may stop (soft clip; end_bonus when the read end is reached) -> records as above, = / X / I / D / S
+ * CIGARs. route: LCTY_MAP_ROUTE_AUTO takes the short route when the chunk and the index fit it.
  * lcty_locus_build_map_index: the k-mers of the basis alleles (host hash table, once per locus).
  * lcty_map_reads: only the sequence fields of `chunk` are read. aln_off / cigar_off [n_pairs + 1] are always written; with
  *   recs == NULL the call only sizes. bases2_out / nmask_out: the chunk's bases in BAM orientation (same offsets). */
@@ -519,8 +529,16 @@ typedef struct lcty_map_params {
     int32_t  match, mismatch, end_bonus, min_score;
     uint32_t band;               /* diagonals on either side in the alignment with gaps of a clipped candidate (<= 16); 0: none */
     int32_t  gap_open, gap_extend;   /* a gap of n bases costs gap_open + (n - 1) * gap_extend */
+    uint32_t route;              /* LCTY_MAP_ROUTE_* */
+    uint32_t chain_gap;          /* long route: bases between two chained anchors, in either sequence (<= 8 192) */
+    uint32_t chain_skew;         /* long route: diagonals between two chained anchors (<= 1 024) */
+    uint32_t chain_back;         /* long route: anchors of its group an anchor looks back at (1..64) */
 } lcty_map_params;
-int32_t lcty_map_params_default(lcty_map_params* p);
+#define LCTY_MAP_ROUTE_AUTO  0u
+#define LCTY_MAP_ROUTE_SHORT 1u
+#define LCTY_MAP_ROUTE_LONG  2u
+int32_t lcty_map_params_default(lcty_map_params* p);       /* strobealign's scores (short reads) */
+int32_t lcty_map_params_default_long(lcty_map_params* p);  /* minimap2's (map-ont): seeds 16 bases apart, 2 / 4 / gap 4 + 2 n, every record kept */
 int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uint32_t n_basis, uint32_t k);
 int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_params* params, uint64_t* aln_off,
                        lcty_aln_rec* recs, uint64_t cap_recs, uint64_t* cigar_off, uint32_t* cigar, uint64_t cap_cigar,

@@ -643,10 +643,11 @@ K_RECRUIT = 6
 K_MAP = 8
 
 
-def map_params(**over):
-    """lcty_map_params_default (seed length 15, a seed every 5 bases, scores 2 / 8 / end bonus 10, secondary records from score 50)."""
+def map_params(long_reads=False, **over):
+    """lcty_map_params_default (seed length 15, a seed every 5 bases, scores 2 / 8 / end bonus 10, secondary records from score 50) or,
+    with long_reads, lcty_map_params_default_long (a seed every 16 bases, scores 2 / 4 / gaps 4 + 2 n, every record kept)."""
     p = cdefs.MapParams()
-    check(lib().lcty_map_params_default(C.byref(p)))
+    check((lib().lcty_map_params_default_long if long_reads else lib().lcty_map_params_default)(C.byref(p)))
     for k, v in over.items():
         setattr(p, k, v)
     return p

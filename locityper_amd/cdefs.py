@@ -321,7 +321,11 @@ class RecruitParams(C.Structure):      # lcty_recruit_params
 
 class MapParams(C.Structure):          # lcty_map_params
     _fields_ = [("k", C.c_uint32), ("stride", C.c_uint32), ("min_votes", C.c_uint32), ("max_occ", C.c_uint32), ("match", C.c_int32), ("mismatch", C.c_int32),
-                ("end_bonus", C.c_int32), ("min_score", C.c_int32), ("band", C.c_uint32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32)]
+                ("end_bonus", C.c_int32), ("min_score", C.c_int32), ("band", C.c_uint32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32),
+                ("route", C.c_uint32), ("chain_gap", C.c_uint32), ("chain_skew", C.c_uint32), ("chain_back", C.c_uint32)]
+
+
+MAP_ROUTE_AUTO, MAP_ROUTE_SHORT, MAP_ROUTE_LONG = 0, 1, 2
 
 
 WARN_NO_PROBABLE_GENOTYPE, WARN_FEW_READS = 1, 2      # lcty_call_checks

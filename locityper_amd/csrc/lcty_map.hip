@@ -34,31 +34,19 @@
 // listed ones with gaps, one per lane; map_emit_kernel<WRITE> (one wavefront per read end, lane = candidate) runs twice: sizes,
 // then records, with a host prefix sum in between.
 #include <algorithm>
-#include <unordered_map>
 
-#include "lcty_objects.hpp"
+#include "lcty_map_internal.hpp"
 
 namespace lcty {
 
 namespace {
 
-constexpr uint32_t MAP_MAX_LEN = 256;      // bases per read end
 constexpr uint32_t MAP_MAX_HITS = 1024;
-constexpr uint32_t MAP_MAX_BASIS = 32;
 constexpr uint32_t MAP_PER_SEED = 64;      // index entries a seed may vote with (the first ones: by allele, then position)
-constexpr uint32_t MAP_MAX_BAND = 16;      // diagonals on either side of a candidate's own in the alignment with gaps
 constexpr uint32_t MAP_BAND_W = 2 * MAP_MAX_BAND + 1;
 constexpr int32_t MAP_NEG = -(1 << 29);
 constexpr uint32_t MAP_DIR_WORDS = (MAP_BAND_W + 7) / 8;                 // direction nibbles of a row, eight per word
 constexpr uint32_t MAP_REFW = MAP_MAX_LEN + 2 * MAP_MAX_BAND;             // bases of the allele a band alignment can touch
-
-struct MapSlot { uint64_t key; uint32_t start, count; };   // key ~0 = free
-constexpr uint64_t MAP_FREE = ~0ull;
-
-__host__ __device__ inline uint64_t map_hash(uint64_t x) {          // the mix of kmers.rs:93-103
-    x = ~x; x ^= x >> 23; x *= 0x2127599bf4325c37ull; x ^= x >> 47;
-    return x;
-}
 
 // a candidate between the kernels
 struct MapCand {
@@ -94,16 +82,6 @@ struct MapView {
     lcty_aln_rec* recs; uint32_t* cigar;
     uint32_t* out_bases2; uint32_t* out_nmask;
 };
-
-__device__ __forceinline__ uint32_t base_at(const uint32_t* b2, uint64_t off, uint32_t i) {
-    const uint64_t p = off + i;
-    return (b2[p >> 4] >> (2 * (p & 15u))) & 3u;
-}
-__device__ __forceinline__ bool n_at(const uint32_t* nm, uint64_t off, uint32_t i) {
-    const uint64_t p = off + i;
-    return (nm[p >> 5] >> (p & 31u)) & 1u;
-}
-__device__ __forceinline__ uint32_t enc_of(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
 
 // ---- kernel 1: seeds -> votes -> candidates -> extension without gaps; the candidates that stay, in (allele, strand) order
 __device__ void map_seed_one(const MapView& V, const uint64_t m, uint64_t* keys, unsigned long long* best, uint64_t* cand_key) {
@@ -493,11 +471,6 @@ __global__ __launch_bounds__(64) void map_emit_kernel(const MapView V) {
 
 }  // namespace
 
-struct MapIndex {
-    DevBuf<MapSlot> table; DevBuf<uint64_t> entries; DevBuf<uint16_t> basis; DevBuf<uint32_t> scratch;
-    uint64_t mask = 0; uint32_t k = 0, n_basis = 0;
-};
-
 }  // namespace lcty
 
 using namespace lcty;
@@ -515,13 +488,30 @@ int32_t lcty_map_params_default(lcty_map_params* p) {
         p->match = 2; p->mismatch = 8; p->end_bonus = 10;      // strobealign's scores
         p->band = 16; p->gap_open = 12; p->gap_extend = 1;     // a gap of n bases costs gap_open + (n - 1) * gap_extend; band 0: no alignment with gaps
         p->min_score = 50;         // samtools view -e "[AS] >= 50 || flag & 2304 == 0" (genotype.rs:1070)
+        p->route = LCTY_MAP_ROUTE_AUTO;
+        p->chain_gap = 2000; p->chain_skew = 500; p->chain_back = 32;      // long route only
+    });
+}
+
+int32_t lcty_map_params_default_long(lcty_map_params* p) {
+    return guarded([&] {
+        if (!p) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        memset(p, 0, sizeof(*p));
+        p->k = 15; p->stride = 16;                               // minimap2 map-ont / map-hifi seeds are 15..19 bases, one in ~5..10 kept
+        p->min_votes = 3;                                        // minimap2 -n 3: anchors in a chain
+        p->max_occ = 0;
+        p->match = 2; p->mismatch = 4; p->end_bonus = 10;        // minimap2 -A 2 -B 4
+        p->band = 16; p->gap_open = 6; p->gap_extend = 2;        // -O 4 -E 2: a gap of n bases costs 4 + 2 n
+        p->min_score = INT32_MIN;                                // no samtools filter for long reads (genotype.rs:1069-1071)
+        p->route = LCTY_MAP_ROUTE_AUTO;
+        p->chain_gap = 2000; p->chain_skew = 500; p->chain_back = 32;
     });
 }
 
 int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uint32_t n_basis, uint32_t k) {
     return guarded([&] {
         if (!locus || !basis) fail(LCTY_ERR_INVALID_INPUT, "null argument");
-        if (n_basis == 0 || n_basis > MAP_MAX_BASIS) fail(LCTY_ERR_UNSUPPORTED, "1..%u basis alleles", MAP_MAX_BASIS);
+        if (n_basis == 0 || n_basis > MAP_LONG_MAX_BASIS) fail(LCTY_ERR_UNSUPPORTED, "1..%u basis alleles", MAP_LONG_MAX_BASIS);
         if (k < 8 || k > 31) fail(LCTY_ERR_UNSUPPORTED, "seed length %u: 8..31", k);
         lcty_ctx* ctx = locus->ctx;
         ctx->activate();
@@ -531,7 +521,8 @@ int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uin
         std::vector<uint64_t> seq_off(locus->n_alleles + 1);
         locus->d_seq_off.download(seq_off.data(), seq_off.size(), s);
         LCTY_HIP(hipStreamSynchronize(s));
-        std::unordered_map<uint64_t, std::vector<uint64_t>> runs;
+        // (k-mer, place) of every window of the basis alleles, sorted: the run of a k-mer is in (basis allele, position) order
+        std::vector<std::pair<uint64_t, uint64_t>> places;
         std::vector<uint8_t> seq;
         const uint64_t kmask = (1ull << (2 * k)) - 1ull;
         for (uint32_t b = 0; b < n_basis; b++) {
@@ -548,19 +539,25 @@ int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uin
                 rv = (rv >> 2) | (static_cast<uint64_t>(3u - e) << (2 * k - 2));
                 if (++valid >= k) {
                     const bool fwd = fw <= rv;
-                    runs[fwd ? fw : rv].push_back((static_cast<uint64_t>(b) << 33) | ((i + 1 - k) << 1) | (fwd ? 1ull : 0ull));   // by allele, then position
+                    places.emplace_back(fwd ? fw : rv, (static_cast<uint64_t>(b) << 33) | ((i + 1 - k) << 1) | (fwd ? 1ull : 0ull));
                 }
             }
         }
+        if (places.size() > 0xFFFFFFF0ull) fail(LCTY_ERR_UNSUPPORTED, "more than 2^32 k-mer places in the basis alleles");
+        std::sort(places.begin(), places.end());
+        uint64_t distinct = 0;
+        for (size_t i = 0; i < places.size(); i++) distinct += i == 0 || places[i].first != places[i - 1].first;
         uint64_t cap = 1024;
-        while (cap < 2 * runs.size()) cap <<= 1;
+        while (cap < 2 * distinct) cap <<= 1;
         std::vector<MapSlot> table(cap, MapSlot{MAP_FREE, 0u, 0u});
-        std::vector<uint64_t> entries;
-        for (auto& kv : runs) {
-            uint64_t h = map_hash(kv.first) & (cap - 1);
+        std::vector<uint64_t> entries(places.size());
+        for (size_t i = 0; i < places.size();) {
+            size_t j = i;
+            while (j < places.size() && places[j].first == places[i].first) { entries[j] = places[j].second; j++; }
+            uint64_t h = map_hash(places[i].first) & (cap - 1);
             while (table[h].key != MAP_FREE) h = (h + 1) & (cap - 1);
-            table[h] = MapSlot{kv.first, static_cast<uint32_t>(entries.size()), static_cast<uint32_t>(kv.second.size())};
-            entries.insert(entries.end(), kv.second.begin(), kv.second.end());
+            table[h] = MapSlot{places[i].first, static_cast<uint32_t>(i), static_cast<uint32_t>(j - i)};
+            i = j;
         }
         auto ix = std::make_shared<MapIndex>();
         ix->table.alloc(cap); ix->table.upload(table.data(), cap, s);
@@ -573,17 +570,6 @@ int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uin
 }
 
 namespace {
-
-// both passes of the kernel; the records stay on the device (out), the offsets come to the host
-struct MapRun {
-    DevBuf<uint32_t> d_len, d_b2, d_nm, d_nrec, d_ncig, d_ob2, d_onm, d_cigar, d_nhave, d_work, d_counters, d_ops;
-    DevBuf<MapCand> d_cands;
-    uint32_t max_rec_cigar = 0;
-    DevBuf<uint64_t> d_off, d_rec_at, d_cig_at, d_pair_cig;
-    DevBuf<lcty_aln_rec> d_recs;
-    std::vector<uint32_t> nrec, ncig;
-    uint64_t n_recs = 0, n_cigar = 0;
-};
 
 void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_params* params, uint64_t* aln_off, uint64_t* cigar_off, bool sizes_only,
              MapRun& X) {
@@ -604,16 +590,30 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
     uint32_t max_len = 1;
     for (uint64_t m = 0; m < n_mates; m++) {
         max_len = std::max(max_len, chunk->mate_len[m]);
-        if (chunk->mate_len[m] > MAP_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases (this one: %u)", MAP_MAX_LEN, chunk->mate_len[m]);
         if (chunk->mate_off[m] % 32) fail(LCTY_ERR_INVALID_INPUT, "mate offsets must be multiples of 32 bases");
-        if (chunk->mate_len[m] >= params->k && (chunk->mate_len[m] - params->k) / params->stride + 2 > 64)
-            fail(LCTY_ERR_UNSUPPORTED, "more than 64 seeds per read end: raise the stride");
+    }
+    // the route: read ends of up to 256 bases on up to 32 basis alleles vote for diagonals (this file); anything else is chained
+    // and aligned along the chain (lcty_map_long.hip)
+    if (params->route > LCTY_MAP_ROUTE_LONG) fail(LCTY_ERR_INVALID_INPUT, "mapper route %u", params->route);
+    const bool fits_short = max_len <= MAP_MAX_LEN && ix->n_basis <= MAP_MAX_BASIS;
+    const bool long_route = params->route == LCTY_MAP_ROUTE_LONG || (params->route == LCTY_MAP_ROUTE_AUTO && !fits_short);
+    if (!long_route) {
+        if (ix->n_basis > MAP_MAX_BASIS) fail(LCTY_ERR_UNSUPPORTED, "up to %u basis alleles on the short route (the index has %u)", MAP_MAX_BASIS, ix->n_basis);
+        for (uint64_t m = 0; m < n_mates; m++) {
+            if (chunk->mate_len[m] > MAP_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases on the short route (this one: %u)", MAP_MAX_LEN, chunk->mate_len[m]);
+            if (chunk->mate_len[m] >= params->k && (chunk->mate_len[m] - params->k) / params->stride + 2 > 64)
+                fail(LCTY_ERR_UNSUPPORTED, "more than 64 seeds per read end: raise the stride");
+        }
     }
     X.d_len.alloc(n_mates); X.d_len.upload(chunk->mate_len, n_mates, s);
     X.d_off.alloc(n_mates + 1); X.d_off.upload(chunk->mate_off, n_mates + 1, s);
     X.d_b2.alloc(std::max<uint64_t>(nb / 16, 1)); X.d_b2.upload(chunk->bases2, nb / 16, s);
     X.d_nm.alloc(std::max<uint64_t>(nb / 32, 1)); X.d_nm.upload(chunk->nmask, nb / 32, s);
     X.d_nrec.alloc(n_mates); X.d_ncig.alloc(n_mates);
+    if (long_route) {
+        run_map_long(locus, chunk, params, *ix, max_len, aln_off, cigar_off, sizes_only, X);
+        return;
+    }
     MapView V{};
     V.table = ix->table.p; V.mask = ix->mask; V.entries = ix->entries.p; V.basis = ix->basis.p; V.n_basis = ix->n_basis;
     V.k = params->k; V.stride = params->stride; V.min_votes = std::max<uint32_t>(params->min_votes, 1);
@@ -629,9 +629,9 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
     // kernel 1: the candidates that stay, and the list of those to be aligned with gaps
     V.slots = std::min<uint32_t>(64, 2 * ix->n_basis);
     if (n_mates * V.slots > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "chunks of up to %llu read pairs with this basis", (unsigned long long)(0xFFFFFFFFull / V.slots / 2));
-    X.d_cands.alloc(n_mates * V.slots); X.d_nhave.alloc(n_mates); X.d_work.alloc(n_mates * V.slots);
+    X.d_cands.alloc(n_mates * V.slots * sizeof(MapCand)); X.d_nhave.alloc(n_mates); X.d_work.alloc(n_mates * V.slots);
     X.d_counters.alloc(4); X.d_counters.zero(s);
-    V.cands = X.d_cands.p; V.n_have = X.d_nhave.p; V.work = X.d_work.p; V.counters = X.d_counters.p;
+    V.cands = reinterpret_cast<MapCand*>(X.d_cands.p); V.n_have = X.d_nhave.p; V.work = X.d_work.p; V.counters = X.d_counters.p;
     ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_seed_kernel, dim3(n_wg), dim3(64), 0, s, V); }, s);
     LCTY_HIP(hipGetLastError());
     uint32_t counters[4] = {0, 0, 0, 0};

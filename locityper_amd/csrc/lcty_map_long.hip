@@ -1,0 +1,573 @@
+// lcty_map_long.hip — candidate generation inside a locus, the LONG route (second slice): read ends of
+// any length (HiFi / ONT reads of tens of kilobases) on up to 256 basis alleles. The reference hands this to minimap2
+// (-x map-ont | map-hifi -N min(25 000, 4 x alleles) -f 0.05 --eqx, src/command/genotype.rs:990-1002) and reads its `aln.bam`; no
+// source of that mapper is in the reference tree. The algorithm here is this build's own (seed - chain - align, as minimap2-class
+// mappers do), stated below and restated in tests/pyref_map_long.py, against which the kernels are bit-exact.
+//
+// Coordinates of an (allele, strand) group: q = position on the read end AS SEQUENCED, t = position on the allele in the read's
+// orientation (strand 0: the allele itself; strand 1: its reverse complement). Everything up to the record is done in (q, t); the
+// record (position, CIGAR order) is turned into BAM orientation when it is written.
+//
+//   seeds    as on the short route (every `stride`-th k-mer plus the last one, k-mers with a base that is not ACGT or with more than
+//            max_occ places in the index skipped), any number of them.
+//   anchors  every (seed, place) pair is an anchor (q, t) of its group g = basis allele x 2 + strand; a group keeps the first
+//            2 x seeds anchors, in seed order (within a seed: in index order).
+//   chains   an anchor starts a chain (value k) or follows one of the last `chain_back` anchors j of its group: 0 < dq, dt <=
+//            chain_gap, |dq - dt| <= chain_skew, and on another diagonal only k or more bases on in both sequences; value f(j) +
+//            min(dq, dt, k) - (0 on the same diagonal, else 2 + |dq - dt|); the highest value wins, then the most recent anchor.
+//            A group's chain ends at its anchor of the highest value (the first one).
+//   align    the groups whose chain has >= min_votes anchors and >= half the value of the read end's best chain. Walking the chain
+//            from its last anchor to its first: beyond the last anchor an extension (fixed start, free end: it ends on the aligned
+//            base with the best total, end_bonus when the read end is reached, the rest is soft-clipped), between two anchors a piece
+//            (fixed start and end; overlapping anchors of one diagonal are joined as they are), before the first anchor an extension
+//            again (free start). Every segment is a gap-affine alignment over the nodes (i read bases, j allele bases taken) of a band of
+//            diagonals j - i: -band .. +band for the extensions, min(0, d) - band .. max(0, d) + band for a piece whose corners are d
+//            diagonals apart; H = best of (base step, deletion, insertion), gaps open from H at gap_open and go on at gap_extend a
+//            base. Preference on ties: the base step before the deletion before the insertion, to go on before starting afresh,
+//            to open before to extend, the first best end node by (i, diagonal).
+//   records  as on the short route: best score first (the smallest (allele, strand) on ties), the others with score >= min_score
+//            as secondary records, no candidate = an unmapped record; = / X / I / D / S CIGARs, SEQ in BAM orientation.
+//
+// Two kernels. map_long_kernel, one wavefront per read end: lane = seed (index lookups), lane = place of a seed (the chains of all
+// groups grow side by side in a scratch of the workgroup; two places of one group in a batch take turns in index order), then lane =
+// candidate: every lane aligns one group along its chain, the running rows H / F of a band in LDS (wider bands: in scratch), four
+// direction bits per node in scratch, the CIGAR words right to left in a scratch column, copied into the arena at the end.
+// map_long_emit_kernel<WRITE>, one wavefront per read end, runs twice: sizes, then records (host prefix sums in between).
+#include <algorithm>
+
+#include "lcty_map_internal.hpp"
+
+namespace lcty {
+
+namespace {
+
+constexpr int32_t LNEG = -(1 << 29);
+constexpr uint32_t LONG_MAX_GROUPS = 2 * MAP_LONG_MAX_BASIS;
+constexpr uint32_t LONG_WLDS = 64;                 // band widths whose running rows fit the LDS columns
+
+struct LongCand { int32_t score; uint32_t pos, ops_at, n_words, g, pad; };
+
+struct LongView {
+    const MapSlot* table; uint64_t mask;
+    const uint64_t* entries; const uint16_t* basis;
+    uint32_t n_basis, k, stride, min_votes, max_occ, band, chain_gap, chain_skew, chain_back;
+    int32_t match, mismatch, end_bonus, min_score, gap_open, gap_extend;
+    const uint8_t* seqs; const uint64_t* seq_off; const uint32_t* allele_len;
+    uint64_t n_mates;
+    const uint32_t* mate_len; const uint64_t* mate_off; const uint32_t* bases2; const uint32_t* nmask;
+    int paired;
+    // scratch of a workgroup
+    uint4* anchors; uint32_t cap_g;               // [workgroup][group][cap_g]: q, t, value, back | anchors in the chain << 8
+    uint32_t* dirs; uint64_t dirs_words;          // [workgroup][dirs_words][64]
+    int32_t* rows; uint32_t wmax;                 // [workgroup][2][wmax][64]
+    uint32_t* opsbuf; uint32_t ops_lane;          // [workgroup][ops_lane][64]
+    // results of kernel 1
+    LongCand* cands; uint32_t slots; uint32_t* n_have;
+    uint32_t* counters;                           // [1] CIGAR words asked for in `ops`, [2] the widest record
+    uint32_t* ops; uint32_t ops_cap;
+    // kernel 2
+    uint32_t* n_recs; uint32_t* n_cigar;
+    const uint64_t* rec_at; const uint64_t* cig_at; const uint64_t* pair_cig;
+    lcty_aln_rec* recs; uint32_t* cigar; uint32_t* out_bases2; uint32_t* out_nmask;
+};
+
+// one lane's view of its read end and of its group's allele in the read's orientation
+struct Seqs {
+    const uint32_t* b2; const uint32_t* nm; uint64_t off;
+    const uint8_t* ref; uint32_t alen; uint32_t strand;
+    __device__ __forceinline__ uint32_t read_base(uint32_t q) const { return n_at(nm, off, q) ? 4u : base_at(b2, off, q); }
+    __device__ __forceinline__ uint32_t allele_base(uint32_t t) const {
+        const uint32_t e = enc_of(strand ? ref[alen - 1 - t] : ref[t]);
+        return e == 4u ? 4u : (strand ? 3u - e : e);
+    }
+    __device__ __forceinline__ bool eq(uint32_t q, uint32_t t) const {
+        const uint32_t r = read_base(q);
+        return r < 4u && r == allele_base(t);
+    }
+};
+
+// the CIGAR runs of a lane in the order they are met (right to left), one word per run in a column of the workgroup's scratch
+struct LaneEmit {
+    uint32_t* buf; uint32_t n, cur_op, cur_len;
+    __device__ __forceinline__ void put(uint32_t op, uint32_t len) {
+        if (len == 0) return;
+        if (op == cur_op) { cur_len += len; return; }
+        flush();
+        cur_op = op; cur_len = len;
+    }
+    __device__ __forceinline__ void flush() {
+        if (cur_len) { buf[static_cast<size_t>(n) * 64] = (cur_len << 4) | cur_op; n++; }
+        cur_len = 0; cur_op = 0xFu;
+    }
+};
+
+struct SegOut { int32_t score; uint32_t left, t_taken; };
+
+// One segment of an alignment along a chain (the header comment states the recurrence): read bases [q0, q0 + n), allele bases
+// [t0, t0 + m). free_end: the extension beyond the last anchor; free_start: the one before the first anchor; neither: a piece.
+// -> score, read bases left unaligned at the free side, allele bases taken.
+__device__ SegOut segment(const LongView& V, const Seqs& S, const uint32_t q0, const uint32_t n, const uint32_t t0, const uint32_t m,
+                          const bool free_start, const bool free_end, int32_t* lds_h, int32_t* lds_f, int32_t* wide_h, int32_t* wide_f,
+                          uint32_t* dirs, LaneEmit& E) {
+    const int64_t B = V.band;
+    const int64_t d = static_cast<int64_t>(m) - static_cast<int64_t>(n);
+    int64_t dlo, dhi;
+    if (free_start) { dlo = d - B; dhi = d + B; }
+    else if (free_end) { dlo = -B; dhi = B; }
+    else { dlo = (d < 0 ? d : 0) - B; dhi = (d > 0 ? d : 0) + B; }
+    const uint32_t W = static_cast<uint32_t>(dhi - dlo + 1);
+    const uint32_t dw = (W + 7) / 8;
+    int32_t* hp = W <= LONG_WLDS ? lds_h : wide_h;
+    int32_t* fp = W <= LONG_WLDS ? lds_f : wide_f;
+    for (uint32_t kk = 0; kk < W; kk++) { hp[kk * 64] = LNEG; fp[kk * 64] = LNEG; }
+    int32_t best_total = n == 0 ? V.end_bonus : 0; uint32_t best_i = 0, best_kk = static_cast<uint32_t>(-dlo);
+    for (uint32_t i = 0; i <= n; i++) {
+        int32_t e = LNEG, hleft = LNEG;
+        const uint32_t rb = i >= 1 ? S.read_base(q0 + i - 1) : 4u;
+        const int32_t fr = free_start ? (i == 1 ? V.end_bonus : 0) : LNEG;
+        uint32_t packed = 0;
+        int32_t next_h = hp[0], next_f = fp[0];
+        for (uint32_t kk = 0; kk < W; kk++) {
+            const int32_t old_h = next_h;
+            if (kk + 1 < W) { next_h = hp[(kk + 1) * 64]; next_f = fp[(kk + 1) * 64]; } else { next_h = LNEG; next_f = LNEG; }
+            const int64_t j = static_cast<int64_t>(i) + dlo + kk;
+            uint32_t nib = 0;
+            if (j < 0 || j > static_cast<int64_t>(m)) {
+                hp[kk * 64] = LNEG; fp[kk * 64] = LNEG; e = LNEG; hleft = LNEG;
+            } else {
+                int32_t mc = LNEG; uint32_t code = 0;
+                if (i >= 1 && j >= 1) {
+                    int32_t base = old_h;
+                    if (fr > base) { base = fr; code = 3; }
+                    if (base > LNEG / 2) mc = base + (rb < 4u && rb == S.allele_base(t0 + static_cast<uint32_t>(j) - 1) ? V.match : -V.mismatch);
+                }
+                if (i == 0 && j == 0 && !free_start) mc = 0;
+                int32_t f = LNEG; uint32_t fbit = 0;
+                if (i >= 1) {
+                    const int32_t fo = next_h - V.gap_open, fe = next_f - V.gap_extend;
+                    if (fe > fo) { f = fe; fbit = 1; } else f = fo;
+                }
+                uint32_t ebit = 0;
+                if (j >= 1) {
+                    const int32_t eo = hleft - V.gap_open, ee = e - V.gap_extend;
+                    if (ee > eo) { e = ee; ebit = 1; } else e = eo;
+                } else e = LNEG;
+                if (mc < LNEG / 2) mc = LNEG;
+                if (f < LNEG / 2) f = LNEG;
+                if (e < LNEG / 2) e = LNEG;
+                int32_t h = mc;
+                if (e > h) { h = e; code = 1; }
+                if (f > h) { h = f; code = 2; }
+                hp[kk * 64] = h; fp[kk * 64] = f;
+                nib = code | (ebit << 2) | (fbit << 3);
+                hleft = h;
+                if (free_end && mc > LNEG && i >= 1) {
+                    const int32_t total = mc + (i == n ? V.end_bonus : 0);
+                    if (total > best_total) { best_total = total; best_i = i; best_kk = kk; }
+                }
+            }
+            packed |= nib << (4 * (kk & 7));
+            if ((kk & 7) == 7 || kk + 1 == W) { dirs[(static_cast<size_t>(i) * dw + (kk >> 3)) * 64] = packed; packed = 0; }
+        }
+    }
+    uint32_t i, kk; int32_t score; uint32_t state;                      // 0: at H, 1: base step, 2: deletion, 3: insertion
+    if (free_end) { score = best_total; i = best_i; kk = best_kk; state = 1; }
+    else {
+        i = n; kk = static_cast<uint32_t>(d - dlo);
+        score = hp[kk * 64];
+        if (free_start) {
+            const int32_t fresh_all = n == 0 ? V.end_bonus : 0;
+            if (!(score > fresh_all)) return SegOut{fresh_all, n, 0u};   // nothing before the first anchor is aligned
+        }
+        state = 0;
+    }
+    const uint32_t left = free_end ? n - i : 0u;
+    const uint32_t j_end = static_cast<uint32_t>(static_cast<int64_t>(i) + dlo + kk);
+    if (free_end) E.put(4u, left);                                         // the clip lies to the right of the extension
+    for (;;) {
+        const int64_t j = static_cast<int64_t>(i) + dlo + kk;
+        const uint32_t dd = (dirs[(static_cast<size_t>(i) * dw + (kk >> 3)) * 64] >> (4 * (kk & 7))) & 15u;
+        if (state == 0) {
+            if (!free_start && i == 0 && j == 0) break;
+            const uint32_t c = dd & 3u;
+            state = (c == 0 || c == 3) ? 1u : (c == 1 ? 2u : 3u);
+        }
+        if (state == 1) {
+            if (!free_start && i == 0 && j == 0) break;
+            E.put(S.eq(q0 + i - 1, t0 + static_cast<uint32_t>(j) - 1) ? 7u : 8u, 1u);
+            i--;
+            if ((dd & 3u) == 3u) return SegOut{score, i, m - static_cast<uint32_t>(static_cast<int64_t>(i) + dlo + kk)};      // started afresh
+            state = 0;
+        } else if (state == 2) {
+            E.put(2u, 1u);
+            kk--;
+            state = (dd >> 2) & 1u ? 2u : 0u;
+        } else {
+            E.put(1u, 1u);
+            i--; kk++;
+            state = (dd >> 3) & 1u ? 3u : 0u;
+        }
+    }
+    if (free_end) return SegOut{score, left, j_end};
+    return SegOut{score, 0u, m};
+}
+
+__global__ __launch_bounds__(64) void map_long_kernel(const LongView V) {
+    __shared__ uint32_t g_n[LONG_MAX_GROUPS];
+    __shared__ int32_t g_bf[LONG_MAX_GROUPS];
+    __shared__ uint32_t g_bi[LONG_MAX_GROUPS];
+    __shared__ uint32_t owner[LONG_MAX_GROUPS];
+    __shared__ uint16_t cand_g[LONG_MAX_GROUPS];
+    __shared__ uint32_t sd_start[64], sd_count[64], sd_pr[64], sd_fwd[64];
+    __shared__ int32_t lds_h[LONG_WLDS * 64], lds_f[LONG_WLDS * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_groups = 2 * V.n_basis;
+    const uint32_t k = V.k;
+    uint4* wg_anchors = V.anchors + static_cast<size_t>(blockIdx.x) * n_groups * V.cap_g;
+    uint32_t* dirs = V.dirs + static_cast<size_t>(blockIdx.x) * V.dirs_words * 64 + lane;
+    int32_t* wide_h = V.rows + static_cast<size_t>(blockIdx.x) * 2 * V.wmax * 64 + lane;
+    int32_t* wide_f = wide_h + static_cast<size_t>(V.wmax) * 64;
+    uint32_t* opsbuf = V.opsbuf + static_cast<size_t>(blockIdx.x) * V.ops_lane * 64 + lane;
+    for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) {
+        const uint32_t L = V.mate_len[m];
+        if (L == 0) { if (lane == 0) V.n_have[m] = 0; continue; }          // absent read end
+        const uint64_t off = V.mate_off[m];
+        for (uint32_t g = lane; g < n_groups; g += 64) { g_n[g] = 0; g_bf[g] = LNEG; g_bi[g] = 0; owner[g] = 64; }
+        __syncthreads();
+        // ---- seeds -> anchors -> chains
+        uint32_t n_seeds = 0, n0 = 0, span = 0;
+        if (L >= k) { span = L - k; n0 = span / V.stride + 1; n_seeds = n0 + (span % V.stride ? 1u : 0u); }
+        const uint32_t cap = min(2 * n_seeds, V.cap_g);
+        for (uint32_t s0 = 0; s0 < n_seeds; s0 += 64) {
+            const uint32_t sidx = s0 + lane;
+            uint32_t start = 0, count = 0, pr = 0; bool read_fwd = false;
+            if (sidx < n_seeds) {
+                pr = sidx < n0 ? sidx * V.stride : span;
+                uint64_t fw = 0, rv = 0; bool bad = false;
+                for (uint32_t j = 0; j < k; j++) {
+                    const uint32_t e = base_at(V.bases2, off, pr + j);
+                    bad |= n_at(V.nmask, off, pr + j);
+                    fw = (fw << 2) | e;
+                    rv = (rv >> 2) | (static_cast<uint64_t>(3u - e) << (2 * k - 2));
+                }
+                if (!bad) {
+                    read_fwd = fw <= rv;
+                    const uint64_t canon = read_fwd ? fw : rv;
+                    uint64_t h = map_hash(canon) & V.mask;
+                    for (;;) {
+                        const MapSlot sl = V.table[h];
+                        if (sl.key == MAP_FREE) break;
+                        if (sl.key == canon) { start = sl.start; count = sl.count > V.max_occ ? 0u : sl.count; break; }
+                        h = (h + 1) & V.mask;
+                    }
+                }
+            }
+            sd_start[lane] = start; sd_count[lane] = count; sd_pr[lane] = pr; sd_fwd[lane] = read_fwd;
+            __syncthreads();
+            const uint32_t in_batch = min(64u, n_seeds - s0);
+            for (uint32_t si = 0; si < in_batch; si++) {
+                const uint32_t cnt = sd_count[si];
+                if (cnt == 0) continue;
+                const uint32_t st = sd_start[si], q = sd_pr[si]; const bool rfwd = sd_fwd[si] != 0;
+                for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+                    bool pending = e0 + lane < cnt;
+                    uint32_t g = 0, t = 0;
+                    if (pending) {
+                        const uint64_t en = V.entries[st + e0 + lane];
+                        const uint32_t b = static_cast<uint32_t>(en >> 33), pa = static_cast<uint32_t>(en >> 1);
+                        const uint32_t strand = rfwd == ((en & 1ull) != 0) ? 0u : 1u;
+                        g = 2 * b + strand;
+                        t = strand ? V.allele_len[V.basis[b]] - k - pa : pa;
+                    }
+                    // two places of one group take turns, in index order
+                    while (__ballot(pending) != 0ull) {
+                        if (pending) atomicMin(&owner[g], lane);
+                        __syncthreads();
+                        const bool mine = pending && owner[g] == lane;
+                        if (mine) {
+                            const uint32_t have = g_n[g];
+                            if (have < cap) {
+                                uint4* list = wg_anchors + static_cast<size_t>(g) * V.cap_g;
+                                int32_t f = static_cast<int32_t>(k); uint32_t back = 0, cnt_chain = 1;
+                                const uint32_t look = min(V.chain_back, have);
+                                for (uint32_t o = 1; o <= look; o++) {
+                                    const uint4 a = list[have - o];
+                                    const int64_t dq = static_cast<int64_t>(q) - a.x, dt = static_cast<int64_t>(t) - a.y;
+                                    if (dq <= 0 || dt <= 0 || dq > V.chain_gap || dt > V.chain_gap) continue;
+                                    const int64_t sk = dq > dt ? dq - dt : dt - dq;
+                                    if (sk > V.chain_skew || (sk != 0 && (dq < k || dt < k))) continue;
+                                    const int64_t gain = min(min(dq, dt), static_cast<int64_t>(k));
+                                    const int32_t v = static_cast<int32_t>(a.z) + static_cast<int32_t>(gain) - (sk ? 2 + static_cast<int32_t>(sk) : 0);
+                                    if (v > f) { f = v; back = o; cnt_chain = (a.w >> 8) + 1; }
+                                }
+                                list[have] = make_uint4(q, t, static_cast<uint32_t>(f), back | (cnt_chain << 8));
+                                g_n[g] = have + 1;
+                                if (have == 0 || f > g_bf[g]) { g_bf[g] = f; g_bi[g] = have; }
+                            }
+                        }
+                        __syncthreads();
+                        if (mine) { owner[g] = 64; pending = false; }
+                        __syncthreads();
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the groups to be aligned, in (allele, strand) order
+        int32_t top = LNEG;
+        for (uint32_t g = lane; g < n_groups; g += 64) if (g_n[g]) top = max(top, g_bf[g]);
+        for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o));
+        uint32_t n_cand = 0;
+        for (uint32_t g0 = 0; g0 < n_groups; g0 += 64) {
+            const uint32_t g = g0 + lane;
+            bool q = false;
+            if (g < n_groups && g_n[g]) {
+                const uint4 a = wg_anchors[static_cast<size_t>(g) * V.cap_g + g_bi[g]];
+                q = 2 * static_cast<int64_t>(g_bf[g]) >= top && (a.w >> 8) >= V.min_votes;
+            }
+            const unsigned long long qm = __ballot(q);
+            if (q) cand_g[n_cand + static_cast<uint32_t>(__popcll(qm & ((1ull << lane) - 1ull)))] = static_cast<uint16_t>(g);
+            n_cand += static_cast<uint32_t>(__popcll(qm));
+        }
+        __syncthreads();
+        // ---- lane = candidate: the alignment along its chain
+        for (uint32_t c0 = 0; c0 < n_cand; c0 += 64) {
+            if (c0 + lane >= n_cand) continue;                               // the LDS / scratch columns are the lanes' own: no barrier below
+            const uint32_t g = cand_g[c0 + lane];
+            const uint32_t strand = g & 1u, allele = V.basis[g >> 1];
+            Seqs S{V.bases2, V.nmask, off, V.seqs + V.seq_off[allele], V.allele_len[allele], strand};
+            const uint4* list = wg_anchors + static_cast<size_t>(g) * V.cap_g;
+            LaneEmit E{opsbuf, 0u, 0xFu, 0u};
+            uint32_t at = g_bi[g];
+            uint4 a = list[at];
+            SegOut r = segment(V, S, a.x + k, L - (a.x + k), a.y + k, S.alen - (a.y + k), false, true, lds_h + lane, lds_f + lane, wide_h, wide_f, dirs, E);
+            const uint32_t t_end = a.y + k + r.t_taken;
+            int64_t score = static_cast<int64_t>(r.score) + static_cast<int64_t>(k) * V.match;
+            E.put(7u, k);
+            uint32_t cur_q = a.x, cur_t = a.y;
+            while (a.w & 0xFFu) {
+                at -= a.w & 0xFFu;
+                a = list[at];
+                if (a.x + k > cur_q || a.y + k > cur_t) {                       // overlapping seeds of one diagonal
+                    E.put(7u, cur_q - a.x);
+                    score += static_cast<int64_t>(cur_q - a.x) * V.match;
+                } else {
+                    r = segment(V, S, a.x + k, cur_q - (a.x + k), a.y + k, cur_t - (a.y + k), false, false, lds_h + lane, lds_f + lane, wide_h, wide_f, dirs, E);
+                    score += static_cast<int64_t>(r.score) + static_cast<int64_t>(k) * V.match;
+                    E.put(7u, k);
+                }
+                cur_q = a.x; cur_t = a.y;
+            }
+            r = segment(V, S, 0u, cur_q, 0u, cur_t, true, false, lds_h + lane, lds_f + lane, wide_h, wide_f, dirs, E);
+            score += r.score;
+            E.put(4u, r.left);
+            E.flush();
+            const uint32_t t_start = cur_t - r.t_taken;
+            // into the arena: the runs were met right to left in (q, t), which is left to right in BAM orientation on the reverse strand
+            const uint32_t nw = E.n;
+            const uint32_t dst = atomicAdd(&V.counters[1], nw);
+            if (dst + nw <= V.ops_cap && dst + nw >= dst)
+                for (uint32_t w = 0; w < nw; w++) V.ops[dst + w] = opsbuf[static_cast<size_t>(strand ? w : nw - 1 - w) * 64];
+            V.cands[m * V.slots + c0 + lane] = LongCand{static_cast<int32_t>(score), strand ? S.alen - t_end : t_start, dst, nw, g, 0u};
+        }
+        if (lane == 0) V.n_have[m] = n_cand;
+        __syncthreads();
+    }
+}
+
+// ---- kernel 2: the records of a read end from its candidates; sizes (WRITE = false), then the records themselves
+template <bool WRITE>
+__device__ void map_long_emit_one(const LongView& V, const uint64_t m) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t L = V.mate_len[m];
+    if (L == 0) {
+        if (!WRITE && lane == 0) { V.n_recs[m] = 0; V.n_cigar[m] = 0; }
+        return;
+    }
+    const uint64_t off = V.mate_off[m];
+    const uint32_t nh = V.n_have[m];
+    const LongCand* cands = V.cands + m * V.slots;
+    // the primary record: best score, the smallest (allele, strand) on ties (the slots are in that order)
+    int32_t top = INT32_MIN;
+    for (uint32_t s = lane; s < nh; s += 64) top = max(top, cands[s].score);
+    for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o));
+    uint32_t prim = 0xFFFFFFFFu;
+    for (uint32_t s = lane; s < nh; s += 64) if (cands[s].score == top) { prim = s; break; }
+    for (int o = 32; o > 0; o >>= 1) prim = min(prim, static_cast<uint32_t>(__shfl_xor(static_cast<int>(prim), o)));
+    const uint32_t ops_primary = nh ? cands[prim].n_words : 0u;
+    const uint32_t mate2 = V.paired && (m & 1u) ? LCTY_FLAG_MATE2 : 0u;
+    uint64_t rec0 = 0, cig0 = 0, rel0 = 0;
+    if (WRITE) { rec0 = V.rec_at[m]; cig0 = V.cig_at[m]; rel0 = cig0 - V.pair_cig[m >> 1]; }
+    uint32_t n_kept = 0, words = ops_primary, widest = 0;
+    for (uint32_t s0 = 0; s0 < nh; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        LongCand c{};
+        if (s < nh) c = cands[s];
+        const bool keep = s < nh && (s == prim || c.score >= V.min_score);
+        const bool other = keep && s != prim;
+        const unsigned long long om = __ballot(other);
+        uint32_t incl = other ? c.n_words : 0u;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= static_cast<uint32_t>(o)) incl += up; }
+        if (keep) widest = max(widest, c.n_words);
+        if (WRITE) {
+            const uint32_t rank = s == prim ? 0u : 1u + n_kept + static_cast<uint32_t>(__popcll(om & ((1ull << lane) - 1ull)));
+            const uint32_t cig_rel = s == prim ? 0u : words + incl - c.n_words;
+            if (keep) {
+                const uint32_t strand = c.g & 1u;
+                const uint16_t flags = static_cast<uint16_t>((strand ? LCTY_FLAG_REVERSE : 0u) | (s == prim ? 0u : LCTY_FLAG_SECONDARY) | mate2);
+                V.recs[rec0 + rank] = lcty_aln_rec{c.pos, V.basis[c.g >> 1], flags, c.n_words, static_cast<uint32_t>(rel0 + cig_rel)};
+            }
+            // the CIGAR words of the kept candidates of this batch, one candidate at a time over all lanes
+            unsigned long long km = __ballot(keep);
+            while (km) {
+                const int src_lane = __ffsll(static_cast<long long>(km)) - 1;
+                km &= km - 1;
+                const uint32_t from = static_cast<uint32_t>(__shfl(static_cast<int>(c.ops_at), src_lane));
+                const uint32_t nw = static_cast<uint32_t>(__shfl(static_cast<int>(c.n_words), src_lane));
+                const uint32_t to = static_cast<uint32_t>(__shfl(static_cast<int>(cig_rel), src_lane));
+                for (uint32_t w = lane; w < nw; w += 64) V.cigar[cig0 + to + w] = V.ops[from + w];
+            }
+        }
+        n_kept += static_cast<uint32_t>(__popcll(om));
+        words += static_cast<uint32_t>(__shfl(static_cast<int>(incl), 63));
+    }
+    if (!WRITE) {
+        for (int o = 32; o > 0; o >>= 1) widest = max(widest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(widest), o)));
+        if (lane == 0) {
+            V.n_recs[m] = nh ? n_kept + 1 : 1u;                                  // no candidate: one unmapped record
+            V.n_cigar[m] = nh ? words : 0u;
+            if (widest > V.counters[2]) atomicMax(&V.counters[2], widest);
+        }
+        return;
+    }
+    if (nh == 0 && lane == 0) V.recs[rec0] = lcty_aln_rec{0u, 0u, static_cast<uint16_t>(LCTY_FLAG_UNMAPPED | mate2), 0u, static_cast<uint32_t>(rel0)};
+    // SEQ as the BAM has it: reverse-complemented when the primary record is on the reverse strand
+    const bool primary_reverse = nh && (cands[prim].g & 1u);
+    const uint32_t words16 = (L + 15) / 16;
+    for (uint32_t wi = lane; wi < words16; wi += 64) {
+        uint32_t out = 0;
+        for (uint32_t j = 0; j < 16 && wi * 16 + j < L; j++) {
+            const uint32_t i = wi * 16 + j, src = primary_reverse ? L - 1 - i : i;
+            const uint32_t e = base_at(V.bases2, off, src);
+            out |= (primary_reverse ? 3u - e : e) << (2 * j);
+        }
+        V.out_bases2[(off >> 4) + wi] = out;
+    }
+    for (uint32_t wi = lane; wi < (L + 31) / 32; wi += 64) {
+        uint32_t out = 0;
+        for (uint32_t j = 0; j < 32 && wi * 32 + j < L; j++) {
+            const uint32_t i = wi * 32 + j, src = primary_reverse ? L - 1 - i : i;
+            out |= static_cast<uint32_t>(n_at(V.nmask, off, src)) << j;
+        }
+        V.out_nmask[(off >> 5) + wi] = out;
+    }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void map_long_emit_kernel(const LongView V) {
+    for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) map_long_emit_one<WRITE>(V, m);
+}
+
+}  // namespace
+
+void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_params* params, const MapIndex& ix, uint32_t max_len,
+                  uint64_t* aln_off, uint64_t* cigar_off, bool sizes_only, MapRun& X) {
+    lcty_ctx* ctx = locus->ctx;
+    hipStream_t s = ctx->stream;
+    const uint64_t n = chunk->n_pairs, n_mates = 2 * n;
+    const uint64_t nb = chunk->mate_off[n_mates];
+    if (max_len > MAP_LONG_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases (the longest here: %u)", MAP_LONG_MAX_LEN, max_len);
+    if (params->chain_back == 0 || params->chain_back > 64) fail(LCTY_ERR_INVALID_INPUT, "chain_back %u: 1..64", params->chain_back);
+    if (params->chain_gap == 0 || params->chain_gap > 8192) fail(LCTY_ERR_INVALID_INPUT, "chain_gap %u: 1..8192", params->chain_gap);
+    if (params->chain_skew > 1024) fail(LCTY_ERR_INVALID_INPUT, "chain_skew %u: 0..1024", params->chain_skew);
+    if (params->chain_skew > params->chain_gap) fail(LCTY_ERR_INVALID_INPUT, "chain_skew %u > chain_gap %u", params->chain_skew, params->chain_gap);
+    LongView V{};
+    V.table = ix.table.p; V.mask = ix.mask; V.entries = ix.entries.p; V.basis = ix.basis.p; V.n_basis = ix.n_basis;
+    V.k = params->k; V.stride = params->stride; V.min_votes = std::max<uint32_t>(params->min_votes, 1);
+    V.max_occ = params->max_occ ? params->max_occ : 4 * ix.n_basis;
+    V.band = params->band; V.chain_gap = params->chain_gap; V.chain_skew = params->chain_skew; V.chain_back = params->chain_back;
+    V.match = params->match; V.mismatch = params->mismatch; V.end_bonus = params->end_bonus; V.min_score = params->min_score;
+    V.gap_open = params->gap_open; V.gap_extend = params->gap_extend;
+    V.seqs = locus->d_seqs.p; V.seq_off = locus->d_seq_off.p; V.allele_len = locus->d_allele_len.p;
+    V.n_mates = n_mates; V.mate_len = X.d_len.p; V.mate_off = X.d_off.p; V.bases2 = X.d_b2.p; V.nmask = X.d_nm.p;
+    V.paired = locus->bg.is_paired;
+    V.n_recs = X.d_nrec.p; V.n_cigar = X.d_ncig.p;
+    // scratch of a workgroup: the anchors of every group, the direction bits of the largest segment, the rows of the widest band, the
+    // CIGAR runs of a candidate
+    const uint32_t n_groups = 2 * ix.n_basis;
+    const uint32_t max_seeds = max_len >= params->k ? (max_len - params->k) / params->stride + 2 : 0;
+    V.cap_g = std::max<uint32_t>(2 * max_seeds, 1);
+    const uint64_t ext_words = (static_cast<uint64_t>(max_len) + 1) * ((2 * params->band + 1 + 7) / 8);
+    const uint64_t piece_rows = std::min<uint64_t>(params->chain_gap, max_len) + 1;
+    V.wmax = params->chain_skew + 2 * params->band + 1;
+    V.dirs_words = std::max<uint64_t>(ext_words, piece_rows * ((V.wmax + 7) / 8));
+    V.ops_lane = 2 * max_len + 8;
+    const uint64_t per_wg = static_cast<uint64_t>(n_groups) * V.cap_g * sizeof(uint4) + V.dirs_words * 64 * 4 + 2ull * V.wmax * 64 * 4 + static_cast<uint64_t>(V.ops_lane) * 64 * 4;
+    size_t free_b = 0, total_b = 0;
+    LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::min<uint64_t>(free_b / 4, 32ull << 30);
+    const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
+    const uint64_t n_wg64 = std::min<uint64_t>(std::min<uint64_t>(n_mates, 4ull * cus), std::max<uint64_t>(budget / per_wg, 1));
+    if (per_wg > free_b / 2) fail(LCTY_ERR_RUNTIME, "the long route needs %llu MB of scratch per workgroup", (unsigned long long)(per_wg >> 20));
+    const uint32_t n_wg = static_cast<uint32_t>(n_wg64);
+    X.d_anchors.alloc(static_cast<size_t>(n_wg) * n_groups * V.cap_g);
+    X.d_dirs.alloc(static_cast<size_t>(n_wg) * V.dirs_words * 64);
+    X.d_rows.alloc(static_cast<size_t>(n_wg) * 2 * V.wmax * 64);
+    X.d_opsbuf.alloc(static_cast<size_t>(n_wg) * V.ops_lane * 64);
+    V.anchors = X.d_anchors.p; V.dirs = X.d_dirs.p; V.rows = X.d_rows.p; V.opsbuf = X.d_opsbuf.p;
+    V.slots = n_groups;
+    if (n_mates * V.slots > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "chunks of up to %llu read pairs with this basis", (unsigned long long)(0xFFFFFFFFull / V.slots / 2));
+    X.d_cands.alloc(n_mates * V.slots * sizeof(LongCand)); X.d_nhave.alloc(n_mates);
+    X.d_counters.alloc(4);
+    V.cands = reinterpret_cast<LongCand*>(X.d_cands.p); V.n_have = X.d_nhave.p; V.counters = X.d_counters.p;
+    // kernel 1, repeated with more room if the CIGAR words did not fit the arena
+    // room for the words of a chunk of noisy reads on every basis allele (a word per ~4 bases), as far as the memory goes; the kernel
+    // says how many it needed when that was not enough
+    LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+    uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::min<uint64_t>(free_b / 32, nb / 4 * ix.n_basis) + 4096);
+    uint32_t counters[4] = {0, 0, 0, 0};
+    for (;;) {
+        X.d_counters.zero(s);
+        X.d_ops.alloc(cap);
+        V.ops = X.d_ops.p; V.ops_cap = static_cast<uint32_t>(cap);
+        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_kernel, dim3(n_wg), dim3(64), 0, s, V); }, s);
+        LCTY_HIP(hipGetLastError());
+        X.d_counters.download(counters, 4, s);
+        LCTY_HIP(hipStreamSynchronize(s));
+        if (counters[1] <= cap) break;
+        if (counters[1] >= 0xFFFFFFF0u) fail(LCTY_ERR_UNSUPPORTED, "CIGAR words of the chunk's alignments: map it in parts");
+        cap = static_cast<uint64_t>(counters[1]) + 1024;
+    }
+    X.d_anchors.release(); X.d_dirs.release(); X.d_rows.release(); X.d_opsbuf.release();
+    // kernel 2, sizes
+    const uint32_t n_wg2 = static_cast<uint32_t>(std::min<uint64_t>(n_mates, 16ull * cus));
+    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_emit_kernel<false>, dim3(n_wg2), dim3(64), 0, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
+    X.d_counters.download(counters, 4, s);
+    X.nrec.resize(n_mates); X.ncig.resize(n_mates);
+    X.d_nrec.download(X.nrec.data(), n_mates, s); X.d_ncig.download(X.ncig.data(), n_mates, s);
+    LCTY_HIP(hipStreamSynchronize(s));
+    X.max_rec_cigar = counters[2];
+    std::vector<uint64_t> rec_at(n_mates), cig_at(n_mates), pair_cig(n);
+    uint64_t r = 0, c = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        pair_cig[p] = c;
+        for (uint32_t e = 0; e < 2; e++) { rec_at[2 * p + e] = r; cig_at[2 * p + e] = c; r += X.nrec[2 * p + e]; c += X.ncig[2 * p + e]; }
+        aln_off[p + 1] = r; cigar_off[p + 1] = c;
+    }
+    X.n_recs = r; X.n_cigar = c;
+    if (sizes_only) return;
+    X.d_rec_at.alloc(n_mates); X.d_rec_at.upload(rec_at.data(), n_mates, s);
+    X.d_cig_at.alloc(n_mates); X.d_cig_at.upload(cig_at.data(), n_mates, s);
+    X.d_pair_cig.alloc(n); X.d_pair_cig.upload(pair_cig.data(), n, s);
+    X.d_recs.alloc(std::max<uint64_t>(r, 1)); X.d_cigar.alloc(std::max<uint64_t>(c, 1));
+    X.d_ob2.alloc(std::max<uint64_t>(nb / 16, 1)); X.d_onm.alloc(std::max<uint64_t>(nb / 32, 1));
+    X.d_ob2.zero(s); X.d_onm.zero(s);
+    V.rec_at = X.d_rec_at.p; V.cig_at = X.d_cig_at.p; V.pair_cig = X.d_pair_cig.p; V.recs = X.d_recs.p; V.cigar = X.d_cigar.p;
+    V.out_bases2 = X.d_ob2.p; V.out_nmask = X.d_onm.p;
+    ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_emit_kernel<true>, dim3(n_wg2), dim3(64), 0, s, V); }, s);
+    LCTY_HIP(hipGetLastError());
+    LCTY_HIP(hipStreamSynchronize(s));                                          // rec_at & co. are host vectors of this frame
+}
+
+}  // namespace lcty

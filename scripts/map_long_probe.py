@@ -1,0 +1,39 @@
+"""Time the long route of candidate generation (lcty_map_reads on 10-kb ONT reads): reads x basis alleles alignments per second.
+usage: python3 scripts/map_long_probe.py [--reads N] [--alleles A] [--basis B] [--read-len L] [--stride S] [--reps R]"""
+import argparse, json, sys, time
+sys.path.insert(0, ".")
+import numpy as np
+from locityper_amd import api, cdefs, synth
+from tests.test_gpu_map import fastq_orientation
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=1024)
+ap.add_argument("--alleles", type=int, default=16)
+ap.add_argument("--basis", type=int, default=0)
+ap.add_argument("--read-len", type=int, default=10_000)
+ap.add_argument("--base-len", type=int, default=40_000)
+ap.add_argument("--stride", type=int, default=16)
+ap.add_argument("--reps", type=int, default=2)
+a = ap.parse_args()
+ctx = api.Context(0)
+L = synth.SynthLocus(a.alleles, a.reads, seed=synth.SEED + 5, technology=cdefs.TECH_NANOPORE, read_len=a.read_len, base_len=a.base_len)
+p = api.resolve_params(api.default_params(), L.bg)
+loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+truth = L.reads(0, a.reads)
+fq = fastq_orientation(truth)
+mp = api.map_params(long_reads=True, stride=a.stride)
+basis = list(range(a.basis or a.alleles))
+t0 = time.time(); api.build_map_index(loc, basis, k=mp.k); t_index = time.time() - t0
+best = None
+for rep in range(a.reps):
+    ctx.timing_reset()
+    t0 = time.time()
+    got = api.map_reads(loc, fq, mp)
+    dt = time.time() - t0
+    k = ctx.timing(api.K_MAP)
+    best = dt if best is None else min(best, dt)
+n_rec = int(((got.recs["flags"] & cdefs.FLAG_UNMAPPED) == 0).sum())
+bases = int(fq.mate_len.sum())
+print(json.dumps({"reads": a.reads, "basis": len(basis), "read_len": a.read_len, "bases": bases, "index_s": round(t_index, 3), "call_s": round(best, 4),
+                  "kernel": k, "records": n_rec, "cigar_words": int(got.cigar_off[-1]), "alignments_per_s": round(n_rec / best, 1),
+                  "aligned_bases_per_s": round(n_rec * bases / a.reads / best, 1)}))
