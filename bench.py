@@ -85,6 +85,7 @@ def parse_args():
     ap.add_argument("--pipeline", type=int, default=0, help="ignored (round 1 option; the queue of loci is the default mode now)")
     ap.add_argument("--recruit-sample", type=int, default=8_000_000,
                     help="read pairs of the extra recruitment measurement (the step before the path, SURVEY 8f rank 1; 0 = skip)")
+    ap.add_argument("--ont-map-sample", type=int, default=2048, help="of the --ont-sample reads: mapped from their bases alone onto every allele (long route of candidate generation), then scored and prefiltered (0 = skip)")
     ap.add_argument("--map-sample", type=int, default=32768, help="read pairs mapped onto 8 basis alleles by the candidate-generation slice (0 = skip)")
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
@@ -894,6 +895,59 @@ def main():
                                          "traffic": None, "algorithmic_bytes_per_transfer": per_transfer,
                                          "what": "read CIGAR + haplotype CIGAR under the read + target bases under the read + transferred CIGAR, per transfer"}
         ao.close(); del prim
+        if args.ont_map_sample > 0:
+            # ---- the same shape from bases alone (second slice; lcty_map_long.hip): the reads as the sequencer gave
+            # them are mapped onto EVERY allele (seed - chain - gap-affine alignment along the chain; the reference runs minimap2 here,
+            # genotype.rs:990-1002, --basis none), the records go straight into a batch: per-read alignment against every allele on
+            # the device, no external mapper, no recovery needed ----
+            progress("long-read leg from bases alone")
+            nmap = min(args.ont_map_sample, nont)
+            fq = [synth.sequencer_orientation(Lo.reads(lo, min(chunk_o, nmap - lo), primaries_only=True)) for lo in range(0, nmap, chunk_o)]
+            mpl = api.map_params(long_reads=True)
+            basis_l = list(range(A))
+            tm0 = time.perf_counter()
+            api.build_map_index(loco, basis_l, k=mpl.k)
+            t_index = time.perf_counter() - tm0
+            tot_bases = sum(int(c.n_bases) for c in fq); read_bases = sum(int(c.mate_len.sum()) for c in fq)
+            cap_cig = int(read_bases // 3) * len(basis_l) + 4096
+
+            def mapped_batch():
+                b = api.AllAlignments(loco, nmap, (tot_bases + 2048) // 32 * 32, nmap * len(basis_l) * 2 + 1024, cap_cig)
+                for c in fq:
+                    api.map_append(b, c, mpl)
+                return b
+            mapped_batch().close()                                                  # warm-up: scratch allocations, code objects
+            ctx.timing_reset()
+            tm0 = time.perf_counter()
+            am = mapped_batch()
+            t_map = time.perf_counter() - tm0
+            n_launch, ms_map = ctx.timing(api.K_MAP)
+            tm0 = time.perf_counter()
+            am.score()
+            n_mapped = int(am.pair_alns()[0][-1])
+            n_rec2 = am.recover()
+            t_rest = time.perf_counter() - tm0
+            sc_m = am.run_filter()
+            band_w = 2 * mpl.band + 1
+            cells_m = float(n_mapped) * (read_bases / max(nmap, 1)) * band_w
+            per_aln = read_bases / max(nmap, 1) * (0.25 + 1.0 + 1.0)               # packed read bases + allele bases under the read + ~a CIGAR word per 4 bases
+            out["long_reads"]["from_bases"] = {
+                "sample": f"the first {nmap} of those reads as sequenced (no records) onto all {len(basis_l)} alleles: seeds of {mpl.k} every {mpl.stride} bases, "
+                          f"one chain per (allele, strand), gap-affine alignment along the chain in a band of +-{mpl.band}; records straight into a batch "
+                          f"(lcty_reads_map_append, chunks of {chunk_o}), then scoring (+ recovery of the few alignments the mapper left out) + prefilter",
+                "alignments": n_mapped, "map_kernels_ms": ms_map, "launches": int(n_launch), "map_call_s": t_map, "index_build_s": t_index,
+                "alignments_per_s_kernel": n_mapped / (ms_map * 1e-3) if ms_map else None, "reads_per_s_call": nmap / t_map,
+                "aligned_bases_per_s_kernel": n_mapped * (read_bases / max(nmap, 1)) / (ms_map * 1e-3) if ms_map else None,
+                "band_cells": cells_m, "gcups": cells_m / (ms_map * 1e-3) / 1e9 if ms_map else None,
+                "score_recover_rescore_s": t_rest, "alignments_recovered": int(n_rec2), "good_reads": am.n_good(),
+                "prefilter_best_is_truth": bool(tuple(int(x) for x in gts[int(np.argmax(sc_m))]) == tuple(Lo.true_genotype)),
+                "truth_scores_as_the_best": bool(max(float(sc_m[i]) for i, g in enumerate(gts) if tuple(int(x) for x in g) == tuple(Lo.true_genotype)) >= float(sc_m.max()) - 1e-9 * abs(float(sc_m.max()))),
+                "roofline": {"bound": "hbm", "kernel": "map_long_align_kernel", "achieved": per_aln * n_mapped / (ms_map * 1e-3) / 1e9 if ms_map else None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_aln * n_mapped / (ms_map * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_map else None, "traffic": None,
+                             "algorithmic_bytes_per_alignment": per_aln,
+                             "what": "read bases (2 bit) + allele bases under the read + CIGAR words out, per alignment; the kernel is bound by instruction issue "
+                                     "(a row of the band per ~150 instructions of one wavefront), not by these bytes: DESIGN.md section 5"}}
+            am.close(); del fq
 
     if first is not None:
         progress("CPU baseline")

@@ -48,7 +48,7 @@ struct MapRun {
     std::vector<uint32_t> nrec, ncig;
     uint64_t n_recs = 0, n_cigar = 0;
     // scratch of the long route
-    DevBuf<uint4> d_anchors; DevBuf<uint32_t> d_dirs, d_opsbuf; DevBuf<int32_t> d_rows;
+    DevBuf<uint4> d_anchors; DevBuf<uint2> d_chain; DevBuf<uint8_t> d_dirs; DevBuf<uint32_t> d_opsbuf;
 };
 
 // lcty_map_long.hip: the long route over an uploaded chunk (X.d_len .. X.d_nm filled); leaves records, CIGAR words, re-oriented bases

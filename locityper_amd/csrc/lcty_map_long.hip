@@ -28,11 +28,15 @@
 //   records  as on the short route: best score first (the smallest (allele, strand) on ties), the others with score >= min_score
 //            as secondary records, no candidate = an unmapped record; = / X / I / D / S CIGARs, SEQ in BAM orientation.
 //
-// Two kernels. map_long_kernel, one wavefront per read end: lane = seed (index lookups), lane = place of a seed (the chains of all
-// groups grow side by side in a scratch of the workgroup; two places of one group in a batch take turns in index order), then lane =
-// candidate: every lane aligns one group along its chain, the running rows H / F of a band in LDS (wider bands: in scratch), four
-// direction bits per node in scratch, the CIGAR words right to left in a scratch column, copied into the arena at the end.
-// map_long_emit_kernel<WRITE>, one wavefront per read end, runs twice: sizes, then records (host prefix sums in between).
+// Three kernels. map_long_chain_kernel, one wavefront per read end: lane = seed (index lookups), then lane = place of a seed (the
+// chains of all groups grow side by side in a scratch of the workgroup; two places of one group in a batch take turns in index
+// order), then lane = candidate: the chain of every group to be aligned is written out, last anchor first, with a work item.
+// map_long_align_kernel, one wavefront per work item: lane = diagonal of the band. A row of nodes is computed at once — the base step
+// and the insertion come from the row above (LDS), the deletions of the row are a prefix maximum over the lanes (a gap never opens
+// from a deletion at a gain when gap_open >= gap_extend, which the long route asks for, so the openers are the nodes' other two
+// states) — five direction bits per node go to a scratch of the wavefront, the walk back reads them in blocks through LDS and leaves
+// the CIGAR runs right to left in scratch; they are copied into the arena at the end. map_long_emit_kernel<WRITE>, one wavefront per
+// read end, runs twice: sizes, then records (host prefix sums in between).
 #include <algorithm>
 
 #include "lcty_map_internal.hpp"
@@ -43,9 +47,9 @@ namespace {
 
 constexpr int32_t LNEG = -(1 << 29);
 constexpr uint32_t LONG_MAX_GROUPS = 2 * MAP_LONG_MAX_BASIS;
-constexpr uint32_t LONG_WLDS = 64;                 // band widths whose running rows fit the LDS columns
 
 struct LongCand { int32_t score; uint32_t pos, ops_at, n_words, g, pad; };
+struct LongWork { uint32_t mate, g_slot, chain_at, chain_n; };         // g | slot of the read end's candidates << 16
 
 struct LongView {
     const MapSlot* table; uint64_t mask;
@@ -56,185 +60,42 @@ struct LongView {
     uint64_t n_mates;
     const uint32_t* mate_len; const uint64_t* mate_off; const uint32_t* bases2; const uint32_t* nmask;
     int paired;
-    // scratch of a workgroup
+    // kernel 1: scratch of a workgroup, and what it leaves
     uint4* anchors; uint32_t cap_g;               // [workgroup][group][cap_g]: q, t, value, back | anchors in the chain << 8
-    uint32_t* dirs; uint64_t dirs_words;          // [workgroup][dirs_words][64]
-    int32_t* rows; uint32_t wmax;                 // [workgroup][2][wmax][64]
-    uint32_t* opsbuf; uint32_t ops_lane;          // [workgroup][ops_lane][64]
-    // results of kernel 1
-    LongCand* cands; uint32_t slots; uint32_t* n_have;
-    uint32_t* counters;                           // [1] CIGAR words asked for in `ops`, [2] the widest record
+    uint2* chain; uint32_t chain_cap;             // the chains to be aligned: (q, t), last anchor first
+    LongWork* work; uint32_t n_work;
+    uint32_t* n_have;
+    uint32_t* counters;                           // [0] work items, [1] CIGAR words asked for in `ops`, [2] the widest record, [3] chain entries asked for, [4] next work item of kernel 2
+    // kernel 2: scratch of a wavefront, and what it leaves
+    uint8_t* dirs; uint64_t dirs_bytes;           // [wavefront][dirs_bytes]
+    uint32_t* opsbuf; uint32_t ops_wave;          // [wavefront][ops_wave]
+    uint32_t wmax, tb_bytes;
+    LongCand* cands; uint32_t slots;
     uint32_t* ops; uint32_t ops_cap;
-    // kernel 2
+    // kernel 3
     uint32_t* n_recs; uint32_t* n_cigar;
     const uint64_t* rec_at; const uint64_t* cig_at; const uint64_t* pair_cig;
     lcty_aln_rec* recs; uint32_t* cigar; uint32_t* out_bases2; uint32_t* out_nmask;
 };
 
-// one lane's view of its read end and of its group's allele in the read's orientation
-struct Seqs {
-    const uint32_t* b2; const uint32_t* nm; uint64_t off;
-    const uint8_t* ref; uint32_t alen; uint32_t strand;
-    __device__ __forceinline__ uint32_t read_base(uint32_t q) const { return n_at(nm, off, q) ? 4u : base_at(b2, off, q); }
-    __device__ __forceinline__ uint32_t allele_base(uint32_t t) const {
-        const uint32_t e = enc_of(strand ? ref[alen - 1 - t] : ref[t]);
-        return e == 4u ? 4u : (strand ? 3u - e : e);
-    }
-    __device__ __forceinline__ bool eq(uint32_t q, uint32_t t) const {
-        const uint32_t r = read_base(q);
-        return r < 4u && r == allele_base(t);
-    }
-};
-
-// the CIGAR runs of a lane in the order they are met (right to left), one word per run in a column of the workgroup's scratch
-struct LaneEmit {
-    uint32_t* buf; uint32_t n, cur_op, cur_len;
-    __device__ __forceinline__ void put(uint32_t op, uint32_t len) {
-        if (len == 0) return;
-        if (op == cur_op) { cur_len += len; return; }
-        flush();
-        cur_op = op; cur_len = len;
-    }
-    __device__ __forceinline__ void flush() {
-        if (cur_len) { buf[static_cast<size_t>(n) * 64] = (cur_len << 4) | cur_op; n++; }
-        cur_len = 0; cur_op = 0xFu;
-    }
-};
-
-struct SegOut { int32_t score; uint32_t left, t_taken; };
-
-// One segment of an alignment along a chain (the header comment states the recurrence): read bases [q0, q0 + n), allele bases
-// [t0, t0 + m). free_end: the extension beyond the last anchor; free_start: the one before the first anchor; neither: a piece.
-// -> score, read bases left unaligned at the free side, allele bases taken.
-__device__ SegOut segment(const LongView& V, const Seqs& S, const uint32_t q0, const uint32_t n, const uint32_t t0, const uint32_t m,
-                          const bool free_start, const bool free_end, int32_t* lds_h, int32_t* lds_f, int32_t* wide_h, int32_t* wide_f,
-                          uint32_t* dirs, LaneEmit& E) {
-    const int64_t B = V.band;
-    const int64_t d = static_cast<int64_t>(m) - static_cast<int64_t>(n);
-    int64_t dlo, dhi;
-    if (free_start) { dlo = d - B; dhi = d + B; }
-    else if (free_end) { dlo = -B; dhi = B; }
-    else { dlo = (d < 0 ? d : 0) - B; dhi = (d > 0 ? d : 0) + B; }
-    const uint32_t W = static_cast<uint32_t>(dhi - dlo + 1);
-    const uint32_t dw = (W + 7) / 8;
-    int32_t* hp = W <= LONG_WLDS ? lds_h : wide_h;
-    int32_t* fp = W <= LONG_WLDS ? lds_f : wide_f;
-    for (uint32_t kk = 0; kk < W; kk++) { hp[kk * 64] = LNEG; fp[kk * 64] = LNEG; }
-    int32_t best_total = n == 0 ? V.end_bonus : 0; uint32_t best_i = 0, best_kk = static_cast<uint32_t>(-dlo);
-    for (uint32_t i = 0; i <= n; i++) {
-        int32_t e = LNEG, hleft = LNEG;
-        const uint32_t rb = i >= 1 ? S.read_base(q0 + i - 1) : 4u;
-        const int32_t fr = free_start ? (i == 1 ? V.end_bonus : 0) : LNEG;
-        uint32_t packed = 0;
-        int32_t next_h = hp[0], next_f = fp[0];
-        for (uint32_t kk = 0; kk < W; kk++) {
-            const int32_t old_h = next_h;
-            if (kk + 1 < W) { next_h = hp[(kk + 1) * 64]; next_f = fp[(kk + 1) * 64]; } else { next_h = LNEG; next_f = LNEG; }
-            const int64_t j = static_cast<int64_t>(i) + dlo + kk;
-            uint32_t nib = 0;
-            if (j < 0 || j > static_cast<int64_t>(m)) {
-                hp[kk * 64] = LNEG; fp[kk * 64] = LNEG; e = LNEG; hleft = LNEG;
-            } else {
-                int32_t mc = LNEG; uint32_t code = 0;
-                if (i >= 1 && j >= 1) {
-                    int32_t base = old_h;
-                    if (fr > base) { base = fr; code = 3; }
-                    if (base > LNEG / 2) mc = base + (rb < 4u && rb == S.allele_base(t0 + static_cast<uint32_t>(j) - 1) ? V.match : -V.mismatch);
-                }
-                if (i == 0 && j == 0 && !free_start) mc = 0;
-                int32_t f = LNEG; uint32_t fbit = 0;
-                if (i >= 1) {
-                    const int32_t fo = next_h - V.gap_open, fe = next_f - V.gap_extend;
-                    if (fe > fo) { f = fe; fbit = 1; } else f = fo;
-                }
-                uint32_t ebit = 0;
-                if (j >= 1) {
-                    const int32_t eo = hleft - V.gap_open, ee = e - V.gap_extend;
-                    if (ee > eo) { e = ee; ebit = 1; } else e = eo;
-                } else e = LNEG;
-                if (mc < LNEG / 2) mc = LNEG;
-                if (f < LNEG / 2) f = LNEG;
-                if (e < LNEG / 2) e = LNEG;
-                int32_t h = mc;
-                if (e > h) { h = e; code = 1; }
-                if (f > h) { h = f; code = 2; }
-                hp[kk * 64] = h; fp[kk * 64] = f;
-                nib = code | (ebit << 2) | (fbit << 3);
-                hleft = h;
-                if (free_end && mc > LNEG && i >= 1) {
-                    const int32_t total = mc + (i == n ? V.end_bonus : 0);
-                    if (total > best_total) { best_total = total; best_i = i; best_kk = kk; }
-                }
-            }
-            packed |= nib << (4 * (kk & 7));
-            if ((kk & 7) == 7 || kk + 1 == W) { dirs[(static_cast<size_t>(i) * dw + (kk >> 3)) * 64] = packed; packed = 0; }
-        }
-    }
-    uint32_t i, kk; int32_t score; uint32_t state;                      // 0: at H, 1: base step, 2: deletion, 3: insertion
-    if (free_end) { score = best_total; i = best_i; kk = best_kk; state = 1; }
-    else {
-        i = n; kk = static_cast<uint32_t>(d - dlo);
-        score = hp[kk * 64];
-        if (free_start) {
-            const int32_t fresh_all = n == 0 ? V.end_bonus : 0;
-            if (!(score > fresh_all)) return SegOut{fresh_all, n, 0u};   // nothing before the first anchor is aligned
-        }
-        state = 0;
-    }
-    const uint32_t left = free_end ? n - i : 0u;
-    const uint32_t j_end = static_cast<uint32_t>(static_cast<int64_t>(i) + dlo + kk);
-    if (free_end) E.put(4u, left);                                         // the clip lies to the right of the extension
-    for (;;) {
-        const int64_t j = static_cast<int64_t>(i) + dlo + kk;
-        const uint32_t dd = (dirs[(static_cast<size_t>(i) * dw + (kk >> 3)) * 64] >> (4 * (kk & 7))) & 15u;
-        if (state == 0) {
-            if (!free_start && i == 0 && j == 0) break;
-            const uint32_t c = dd & 3u;
-            state = (c == 0 || c == 3) ? 1u : (c == 1 ? 2u : 3u);
-        }
-        if (state == 1) {
-            if (!free_start && i == 0 && j == 0) break;
-            E.put(S.eq(q0 + i - 1, t0 + static_cast<uint32_t>(j) - 1) ? 7u : 8u, 1u);
-            i--;
-            if ((dd & 3u) == 3u) return SegOut{score, i, m - static_cast<uint32_t>(static_cast<int64_t>(i) + dlo + kk)};      // started afresh
-            state = 0;
-        } else if (state == 2) {
-            E.put(2u, 1u);
-            kk--;
-            state = (dd >> 2) & 1u ? 2u : 0u;
-        } else {
-            E.put(1u, 1u);
-            i--; kk++;
-            state = (dd >> 3) & 1u ? 3u : 0u;
-        }
-    }
-    if (free_end) return SegOut{score, left, j_end};
-    return SegOut{score, 0u, m};
-}
-
-__global__ __launch_bounds__(64) void map_long_kernel(const LongView V) {
+// ---- kernel 1: seeds -> anchors -> chains -> the chains to be aligned
+__global__ __launch_bounds__(64) void map_long_chain_kernel(const LongView V) {
     __shared__ uint32_t g_n[LONG_MAX_GROUPS];
     __shared__ int32_t g_bf[LONG_MAX_GROUPS];
     __shared__ uint32_t g_bi[LONG_MAX_GROUPS];
     __shared__ uint32_t owner[LONG_MAX_GROUPS];
     __shared__ uint16_t cand_g[LONG_MAX_GROUPS];
     __shared__ uint32_t sd_start[64], sd_count[64], sd_pr[64], sd_fwd[64];
-    __shared__ int32_t lds_h[LONG_WLDS * 64], lds_f[LONG_WLDS * 64];
     const uint32_t lane = threadIdx.x;
     const uint32_t n_groups = 2 * V.n_basis;
     const uint32_t k = V.k;
     uint4* wg_anchors = V.anchors + static_cast<size_t>(blockIdx.x) * n_groups * V.cap_g;
-    uint32_t* dirs = V.dirs + static_cast<size_t>(blockIdx.x) * V.dirs_words * 64 + lane;
-    int32_t* wide_h = V.rows + static_cast<size_t>(blockIdx.x) * 2 * V.wmax * 64 + lane;
-    int32_t* wide_f = wide_h + static_cast<size_t>(V.wmax) * 64;
-    uint32_t* opsbuf = V.opsbuf + static_cast<size_t>(blockIdx.x) * V.ops_lane * 64 + lane;
     for (uint64_t m = blockIdx.x; m < V.n_mates; m += gridDim.x) {
         const uint32_t L = V.mate_len[m];
         if (L == 0) { if (lane == 0) V.n_have[m] = 0; continue; }          // absent read end
         const uint64_t off = V.mate_off[m];
         for (uint32_t g = lane; g < n_groups; g += 64) { g_n[g] = 0; g_bf[g] = LNEG; g_bi[g] = 0; owner[g] = 64; }
         __syncthreads();
-        // ---- seeds -> anchors -> chains
         uint32_t n_seeds = 0, n0 = 0, span = 0;
         if (L >= k) { span = L - k; n0 = span / V.stride + 1; n_seeds = n0 + (span % V.stride ? 1u : 0u); }
         const uint32_t cap = min(2 * n_seeds, V.cap_g);
@@ -330,47 +191,299 @@ __global__ __launch_bounds__(64) void map_long_kernel(const LongView V) {
             n_cand += static_cast<uint32_t>(__popcll(qm));
         }
         __syncthreads();
-        // ---- lane = candidate: the alignment along its chain
+        // ---- lane = candidate: its chain, last anchor first, and a work item for kernel 2
         for (uint32_t c0 = 0; c0 < n_cand; c0 += 64) {
-            if (c0 + lane >= n_cand) continue;                               // the LDS / scratch columns are the lanes' own: no barrier below
-            const uint32_t g = cand_g[c0 + lane];
-            const uint32_t strand = g & 1u, allele = V.basis[g >> 1];
-            Seqs S{V.bases2, V.nmask, off, V.seqs + V.seq_off[allele], V.allele_len[allele], strand};
+            const bool have = c0 + lane < n_cand;
+            const uint32_t g = have ? cand_g[c0 + lane] : 0u;
             const uint4* list = wg_anchors + static_cast<size_t>(g) * V.cap_g;
-            LaneEmit E{opsbuf, 0u, 0xFu, 0u};
-            uint32_t at = g_bi[g];
-            uint4 a = list[at];
-            SegOut r = segment(V, S, a.x + k, L - (a.x + k), a.y + k, S.alen - (a.y + k), false, true, lds_h + lane, lds_f + lane, wide_h, wide_f, dirs, E);
-            const uint32_t t_end = a.y + k + r.t_taken;
-            int64_t score = static_cast<int64_t>(r.score) + static_cast<int64_t>(k) * V.match;
-            E.put(7u, k);
-            uint32_t cur_q = a.x, cur_t = a.y;
-            while (a.w & 0xFFu) {
-                at -= a.w & 0xFFu;
-                a = list[at];
-                if (a.x + k > cur_q || a.y + k > cur_t) {                       // overlapping seeds of one diagonal
-                    E.put(7u, cur_q - a.x);
-                    score += static_cast<int64_t>(cur_q - a.x) * V.match;
-                } else {
-                    r = segment(V, S, a.x + k, cur_q - (a.x + k), a.y + k, cur_t - (a.y + k), false, false, lds_h + lane, lds_f + lane, wide_h, wide_f, dirs, E);
-                    score += static_cast<int64_t>(r.score) + static_cast<int64_t>(k) * V.match;
-                    E.put(7u, k);
+            uint32_t at = have ? g_bi[g] : 0u;
+            const uint32_t len = have ? list[at].w >> 8 : 0u;
+            uint32_t incl = len;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= static_cast<uint32_t>(o)) incl += up; }
+            const uint32_t total = static_cast<uint32_t>(__shfl(static_cast<int>(incl), 63));
+            const uint32_t in_batch = min(64u, n_cand - c0);
+            uint32_t cbase = 0, wbase = 0;
+            if (lane == 0) { cbase = atomicAdd(&V.counters[3], total); wbase = atomicAdd(&V.counters[0], in_batch); }
+            cbase = static_cast<uint32_t>(__shfl(static_cast<int>(cbase), 0)); wbase = static_cast<uint32_t>(__shfl(static_cast<int>(wbase), 0));
+            const uint32_t mine_at = cbase + incl - len;
+            if (have && cbase + total <= V.chain_cap && cbase + total >= cbase) {
+                for (uint32_t idx = 0; idx < len; idx++) {
+                    const uint4 a = list[at];
+                    V.chain[mine_at + idx] = make_uint2(a.x, a.y);
+                    at -= a.w & 0xFFu;
                 }
-                cur_q = a.x; cur_t = a.y;
+                V.work[wbase + lane] = LongWork{static_cast<uint32_t>(m), g | ((c0 + lane) << 16), mine_at, len};
             }
-            r = segment(V, S, 0u, cur_q, 0u, cur_t, true, false, lds_h + lane, lds_f + lane, wide_h, wide_f, dirs, E);
-            score += r.score;
-            E.put(4u, r.left);
-            E.flush();
-            const uint32_t t_start = cur_t - r.t_taken;
-            // into the arena: the runs were met right to left in (q, t), which is left to right in BAM orientation on the reverse strand
-            const uint32_t nw = E.n;
-            const uint32_t dst = atomicAdd(&V.counters[1], nw);
-            if (dst + nw <= V.ops_cap && dst + nw >= dst)
-                for (uint32_t w = 0; w < nw; w++) V.ops[dst + w] = opsbuf[static_cast<size_t>(strand ? w : nw - 1 - w) * 64];
-            V.cands[m * V.slots + c0 + lane] = LongCand{static_cast<int32_t>(score), strand ? S.alen - t_end : t_start, dst, nw, g, 0u};
         }
         if (lane == 0) V.n_have[m] = n_cand;
+        __syncthreads();
+    }
+}
+
+// ---- kernel 2: one wavefront aligns one group along its chain
+// the read end of the work item and the group's allele in the read's orientation
+struct Seqs {
+    const uint32_t* b2; const uint32_t* nm; uint64_t off;
+    const uint8_t* ref; uint32_t alen; uint32_t strand;
+    __device__ __forceinline__ uint32_t read_base(uint32_t q) const { return n_at(nm, off, q) ? 4u : base_at(b2, off, q); }
+    __device__ __forceinline__ uint32_t allele_base(uint32_t t) const {
+        const uint32_t e = enc_of(strand ? ref[alen - 1 - t] : ref[t]);
+        return e == 4u ? 4u : (strand ? 3u - e : e);
+    }
+};
+
+// the scratch of a wavefront and the CIGAR runs in the order they are met (right to left); every lane holds the same run state,
+// lane 0 writes
+struct WaveState {
+    int32_t* hrow; int32_t* frow; uint8_t* tb;          // LDS: the running rows of a band, a block of direction bytes
+    uint8_t* abuf; uint8_t* rbuf;                        // LDS: the allele bases under 64 rows of the band, the read bases of those rows
+    uint8_t* dirs; uint32_t* ops;                        // scratch of the wavefront
+    uint32_t tb_bytes;
+    uint32_t n, cur_op, cur_len;
+    __device__ __forceinline__ void put(uint32_t op, uint32_t len) {
+        if (len == 0) return;
+        if (op == cur_op) { cur_len += len; return; }
+        flush();
+        cur_op = op; cur_len = len;
+    }
+    __device__ __forceinline__ void flush() {
+        if (cur_len) { if (threadIdx.x == 0) ops[n] = (cur_len << 4) | cur_op; n++; }
+        cur_len = 0; cur_op = 0xFu;
+    }
+};
+
+struct SegOut { int32_t score; uint32_t left, t_taken; };
+
+// lane i takes lane i - 1, lane 0 takes `first` (DPP wave_shr:1)
+__device__ __forceinline__ int32_t from_left(int32_t x, int32_t first) {
+    return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xF, 0xF, false);
+}
+// inclusive prefix maximum over the 64 lanes: inside the rows of 16 (row_shr 1, 2, 4, 8), then across them (row_bcast 15 / 31)
+__device__ __forceinline__ int32_t prefix_max(int32_t v) {
+    constexpr int32_t none = INT32_MIN;
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x111, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x112, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x114, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x118, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(none, v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+
+// One segment of an alignment along a chain (the header comment states the recurrence): read bases [q0, q0 + n), allele bases
+// [t0, t0 + m). free_end: the extension beyond the last anchor; free_start: the one before the first anchor; neither: a piece.
+// -> score, read bases left unaligned at the free side, allele bases taken. All arguments and results are the same in every lane.
+__device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t q0, const uint32_t n, const uint32_t t0, const uint32_t m,
+                               const bool free_start, const bool free_end, WaveState& C) {
+    const uint32_t lane = threadIdx.x;
+    const int32_t B = static_cast<int32_t>(V.band);
+    const int64_t d = static_cast<int64_t>(m) - static_cast<int64_t>(n);
+    int64_t dlo, dhi;
+    if (free_start) { dlo = d - B; dhi = d + B; }
+    else if (free_end) { dlo = -B; dhi = B; }
+    else { dlo = (d < 0 ? d : 0) - B; dhi = (d > 0 ? d : 0) + B; }
+    const uint32_t W = static_cast<uint32_t>(dhi - dlo + 1);
+    const uint32_t n_chunks = (W + 63) / 64;
+    for (uint32_t kk = lane; kk < W; kk += 64) { C.hrow[kk] = LNEG; C.frow[kk] = LNEG; }
+    __syncthreads();
+    int32_t bt = INT32_MIN; uint32_t bi = 0, bkk = 0;                     // this lane's best end node (free end)
+    for (uint32_t i = 0; i <= n; i++) {
+        if ((i & 63u) == 0) {
+            // the bases of the next 64 rows: node (i, j) looks at read base q0 + i - 1 and allele base t0 + j - 1 (5: none)
+            __syncthreads();
+            const uint32_t r = i + lane;
+            C.rbuf[lane] = static_cast<uint8_t>(r >= 1 && r <= n ? S.read_base(q0 + r - 1) : 4u);
+            const int64_t p0 = static_cast<int64_t>(t0) + static_cast<int64_t>(i) + dlo - 1;
+            for (uint32_t x = lane; x < W + 64; x += 64) {
+                const int64_t p = p0 + x;
+                C.abuf[x] = static_cast<uint8_t>(p >= 0 && p < static_cast<int64_t>(S.alen) ? S.allele_base(static_cast<uint32_t>(p)) : 5u);
+            }
+            __syncthreads();
+        }
+        const uint32_t rb = C.rbuf[i & 63u];
+        const int32_t fr = free_start ? (i == 1 ? V.end_bonus : 0) : LNEG;
+        int32_t carry_p = INT32_MIN, carry_h = LNEG, carry_e = LNEG;      // of the lanes to the left: best opener, H and deletion state of the last one
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            const uint32_t kk = c * 64 + lane;
+            const bool in = kk < W;
+            const int64_t j = static_cast<int64_t>(i) + dlo + kk;
+            const bool valid = in && j >= 0 && j <= static_cast<int64_t>(m);
+            const int32_t old_h = in ? C.hrow[kk] : LNEG;
+            const int32_t up_h = kk + 1 < W ? C.hrow[kk + 1] : LNEG, up_f = kk + 1 < W ? C.frow[kk + 1] : LNEG;
+            int32_t mc = LNEG; uint32_t code = 0, mbit = 0;
+            if (valid && i >= 1 && j >= 1) {
+                int32_t base = old_h;
+                if (fr > base) { base = fr; code = 3; }
+                if (base > LNEG / 2) {
+                    mbit = rb < 4u && rb == C.abuf[(i & 63u) + kk] ? 1u : 0u;
+                    mc = base + (mbit ? V.match : -V.mismatch);
+                }
+            }
+            if (valid && i == 0 && j == 0 && !free_start) mc = 0;
+            int32_t f = LNEG; uint32_t fbit = 0;
+            if (valid && i >= 1) {
+                const int32_t fo = up_h - V.gap_open, fe = up_f - V.gap_extend;
+                if (fe > fo) { f = fe; fbit = 1; } else f = fo;
+            }
+            if (mc < LNEG / 2) mc = LNEG;
+            if (f < LNEG / 2) f = LNEG;
+            // the deletions of the row: the best opener to the left, a prefix maximum over the lanes
+            const int32_t ht = mc > f ? mc : f;
+            int32_t pm = valid && ht > LNEG ? ht + V.gap_extend * static_cast<int32_t>(kk) : INT32_MIN;
+            pm = prefix_max(pm);
+            int32_t excl = from_left(pm, INT32_MIN);
+            if (carry_p > excl) excl = carry_p;
+            int32_t e = LNEG;
+            if (valid && j >= 1 && excl != INT32_MIN) {
+                e = excl - V.gap_open - V.gap_extend * (static_cast<int32_t>(kk) - 1);
+                if (e < LNEG / 2) e = LNEG;
+            }
+            int32_t h = mc;
+            if (e > h) { h = e; code = 1; }
+            if (f > h) { h = f; code = 2; }
+            if (!valid) { h = LNEG; e = LNEG; }
+            const int32_t lh = from_left(h, carry_h), le = from_left(e, carry_e);
+            const uint32_t ebit = valid && j >= 1 && le - V.gap_extend > lh - V.gap_open ? 1u : 0u;
+            if (in) { C.hrow[kk] = h; C.frow[kk] = valid ? f : LNEG; }
+            if (valid) C.dirs[static_cast<size_t>(i) * W + kk] = static_cast<uint8_t>(code | (ebit << 2) | (fbit << 3) | (mbit << 4));
+            if (free_end && valid && mc > LNEG && i >= 1) {
+                const int32_t total = mc + (i == n ? V.end_bonus : 0);
+                if (total > bt) { bt = total; bi = i; bkk = kk; }
+            }
+            const int32_t last_p = __builtin_amdgcn_readlane(pm, 63);
+            if (last_p > carry_p) carry_p = last_p;
+            carry_h = __builtin_amdgcn_readlane(h, 63); carry_e = __builtin_amdgcn_readlane(e, 63);
+        }
+        __syncthreads();
+    }
+    uint32_t i, kk; int32_t score; uint32_t state;                      // 0: at H, 1: base step, 2: deletion, 3: insertion
+    if (free_end) {
+        // the first best end node by (i, diagonal) over the lanes; no extension at all unless one is better
+        int32_t rt = bt; uint32_t ri = bi, rk = bkk;
+        for (int o = 32; o > 0; o >>= 1) {
+            const int32_t ot = __shfl_xor(rt, o); const uint32_t oi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(ri), o)), ok = static_cast<uint32_t>(__shfl_xor(static_cast<int>(rk), o));
+            if (ot > rt || (ot == rt && (oi < ri || (oi == ri && ok < rk)))) { rt = ot; ri = oi; rk = ok; }
+        }
+        const int32_t none = n == 0 ? V.end_bonus : 0;
+        if (rt > none) { score = rt; i = ri; kk = rk; } else { score = none; i = 0; kk = static_cast<uint32_t>(-dlo); }
+        state = 1;
+    } else {
+        i = n; kk = static_cast<uint32_t>(d - dlo);
+        score = C.hrow[kk];
+        if (free_start) {
+            const int32_t fresh_all = n == 0 ? V.end_bonus : 0;
+            if (!(score > fresh_all)) return SegOut{fresh_all, n, 0u};   // nothing before the first anchor is aligned
+        }
+        state = 0;
+    }
+    const uint32_t left = free_end ? n - i : 0u;
+    const uint32_t j_end = static_cast<uint32_t>(static_cast<int64_t>(i) + dlo + kk);
+    if (free_end) C.put(4u, left);                                         // the clip lies to the right of the extension
+    const uint32_t rows_blk = C.tb_bytes / W;
+    uint32_t blk_lo = i + 1;                                               // rows [blk_lo, blk_hi] of the direction bytes are in LDS
+    for (;;) {
+        if (i < blk_lo) {
+            __syncthreads();
+            blk_lo = i + 1 > rows_blk ? i + 1 - rows_blk : 0u;
+            const uint32_t nbytes = (i - blk_lo + 1) * W;
+            const uint8_t* src = C.dirs + static_cast<size_t>(blk_lo) * W;
+            for (uint32_t b = lane; b < nbytes; b += 64) C.tb[b] = src[b];
+            __syncthreads();
+        }
+        const int64_t j = static_cast<int64_t>(i) + dlo + kk;
+        const uint32_t dd = C.tb[(i - blk_lo) * W + kk];
+        if (state == 0 && (dd & 3u) == 0 && i >= 1) {
+            // a stretch of base steps that go on from H with the same outcome (= or X): the lanes look up the diagonal, the run is
+            // taken at once (rows of this block, above row 0: what the walk below would do one node at a time)
+            const uint32_t row = i - min(lane, i);
+            const bool ok = lane <= i && row >= 1 && row >= blk_lo;
+            const uint32_t b = ok ? C.tb[(row - blk_lo) * W + kk] : 0xFFu;
+            const unsigned long long stop = __ballot(!(ok && (b & 0x13u) == (dd & 0x13u)));
+            const uint32_t run = stop ? static_cast<uint32_t>(__ffsll(static_cast<long long>(stop))) - 1u : 64u;
+            C.put((dd >> 4) & 1u ? 7u : 8u, run);
+            i -= run;
+            continue;
+        }
+        if (state == 0) {
+            if (!free_start && i == 0 && j == 0) break;
+            const uint32_t c = dd & 3u;
+            state = (c == 0 || c == 3) ? 1u : (c == 1 ? 2u : 3u);
+        }
+        if (state == 1) {
+            if (!free_start && i == 0 && j == 0) break;
+            C.put((dd >> 4) & 1u ? 7u : 8u, 1u);
+            i--;
+            if ((dd & 3u) == 3u) return SegOut{score, i, m - static_cast<uint32_t>(static_cast<int64_t>(i) + dlo + kk)};      // started afresh
+            state = 0;
+        } else if (state == 2) {
+            C.put(2u, 1u);
+            kk--;
+            state = (dd >> 2) & 1u ? 2u : 0u;
+        } else {
+            C.put(1u, 1u);
+            i--; kk++;
+            state = (dd >> 3) & 1u ? 3u : 0u;
+        }
+    }
+    if (free_end) return SegOut{score, left, j_end};
+    return SegOut{score, 0u, m};
+}
+
+__global__ __launch_bounds__(64) void map_long_align_kernel(const LongView V) {
+    extern __shared__ int32_t lds_rows[];                                   // H row, F row [wmax each], then the bytes: direction block, allele bases, read bases
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = V.k;
+    WaveState C{};
+    C.hrow = lds_rows; C.frow = lds_rows + V.wmax; C.tb = reinterpret_cast<uint8_t*>(lds_rows + 2 * V.wmax); C.tb_bytes = V.tb_bytes;
+    C.abuf = C.tb + V.tb_bytes; C.rbuf = C.abuf + V.wmax + 64;
+    C.dirs = V.dirs + static_cast<size_t>(blockIdx.x) * V.dirs_bytes;
+    C.ops = V.opsbuf + static_cast<size_t>(blockIdx.x) * V.ops_wave;
+    for (;;) {
+        // the next work item, whichever wavefront is free: the alignments of a chunk differ in length
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(&V.counters[4], 1u);
+        w = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));
+        if (w >= V.n_work) break;
+        const LongWork item = V.work[w];
+        const uint64_t m = item.mate;
+        const uint32_t g = item.g_slot & 0xFFFFu, slot = item.g_slot >> 16;
+        const uint32_t strand = g & 1u, allele = V.basis[g >> 1];
+        const uint32_t L = V.mate_len[m];
+        const Seqs S{V.bases2, V.nmask, V.mate_off[m], V.seqs + V.seq_off[allele], V.allele_len[allele], strand};
+        const uint2* chain = V.chain + item.chain_at;
+        C.n = 0; C.cur_op = 0xFu; C.cur_len = 0;
+        uint2 a = chain[0];
+        SegOut r = wave_segment(V, S, a.x + k, L - (a.x + k), a.y + k, S.alen - (a.y + k), false, true, C);
+        const uint32_t t_end = a.y + k + r.t_taken;
+        int64_t score = static_cast<int64_t>(r.score) + static_cast<int64_t>(k) * V.match;
+        C.put(7u, k);
+        uint32_t cur_q = a.x, cur_t = a.y;
+        for (uint32_t idx = 1; idx < item.chain_n; idx++) {
+            a = chain[idx];
+            if (a.x + k > cur_q || a.y + k > cur_t) {                           // overlapping seeds of one diagonal
+                C.put(7u, cur_q - a.x);
+                score += static_cast<int64_t>(cur_q - a.x) * V.match;
+            } else {
+                r = wave_segment(V, S, a.x + k, cur_q - (a.x + k), a.y + k, cur_t - (a.y + k), false, false, C);
+                score += static_cast<int64_t>(r.score) + static_cast<int64_t>(k) * V.match;
+                C.put(7u, k);
+            }
+            cur_q = a.x; cur_t = a.y;
+        }
+        r = wave_segment(V, S, 0u, cur_q, 0u, cur_t, true, false, C);
+        score += r.score;
+        C.put(4u, r.left);
+        C.flush();
+        const uint32_t t_start = cur_t - r.t_taken;
+        // into the arena: the runs were met right to left in (q, t), which is left to right in BAM orientation on the reverse strand
+        const uint32_t nw = C.n;
+        uint32_t dst = 0;
+        if (lane == 0) dst = atomicAdd(&V.counters[1], nw);
+        dst = static_cast<uint32_t>(__shfl(static_cast<int>(dst), 0));
+        __syncthreads();
+        if (dst + nw <= V.ops_cap && dst + nw >= dst)
+            for (uint32_t x = lane; x < nw; x += 64) V.ops[dst + x] = C.ops[strand ? x : nw - 1 - x];
+        if (lane == 0) V.cands[m * V.slots + slot] = LongCand{static_cast<int32_t>(score), strand ? S.alen - t_end : t_start, dst, nw, g, 0u};
         __syncthreads();
     }
 }
@@ -492,54 +605,95 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
     V.n_mates = n_mates; V.mate_len = X.d_len.p; V.mate_off = X.d_off.p; V.bases2 = X.d_b2.p; V.nmask = X.d_nm.p;
     V.paired = locus->bg.is_paired;
     V.n_recs = X.d_nrec.p; V.n_cigar = X.d_ncig.p;
-    // scratch of a workgroup: the anchors of every group, the direction bits of the largest segment, the rows of the widest band, the
-    // CIGAR runs of a candidate
+    if (params->gap_open < params->gap_extend) fail(LCTY_ERR_UNSUPPORTED, "the long route needs gap_open >= gap_extend (%d < %d)", params->gap_open, params->gap_extend);
     const uint32_t n_groups = 2 * ix.n_basis;
-    const uint32_t max_seeds = max_len >= params->k ? (max_len - params->k) / params->stride + 2 : 0;
-    V.cap_g = std::max<uint32_t>(2 * max_seeds, 1);
-    const uint64_t ext_words = (static_cast<uint64_t>(max_len) + 1) * ((2 * params->band + 1 + 7) / 8);
-    const uint64_t piece_rows = std::min<uint64_t>(params->chain_gap, max_len) + 1;
-    V.wmax = params->chain_skew + 2 * params->band + 1;
-    V.dirs_words = std::max<uint64_t>(ext_words, piece_rows * ((V.wmax + 7) / 8));
-    V.ops_lane = 2 * max_len + 8;
-    const uint64_t per_wg = static_cast<uint64_t>(n_groups) * V.cap_g * sizeof(uint4) + V.dirs_words * 64 * 4 + 2ull * V.wmax * 64 * 4 + static_cast<uint64_t>(V.ops_lane) * 64 * 4;
-    size_t free_b = 0, total_b = 0;
-    LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = std::min<uint64_t>(free_b / 4, 32ull << 30);
     const uint32_t cus = static_cast<uint32_t>(ctx->props.multiProcessorCount);
-    const uint64_t n_wg64 = std::min<uint64_t>(std::min<uint64_t>(n_mates, 4ull * cus), std::max<uint64_t>(budget / per_wg, 1));
-    if (per_wg > free_b / 2) fail(LCTY_ERR_RUNTIME, "the long route needs %llu MB of scratch per workgroup", (unsigned long long)(per_wg >> 20));
-    const uint32_t n_wg = static_cast<uint32_t>(n_wg64);
-    X.d_anchors.alloc(static_cast<size_t>(n_wg) * n_groups * V.cap_g);
-    X.d_dirs.alloc(static_cast<size_t>(n_wg) * V.dirs_words * 64);
-    X.d_rows.alloc(static_cast<size_t>(n_wg) * 2 * V.wmax * 64);
-    X.d_opsbuf.alloc(static_cast<size_t>(n_wg) * V.ops_lane * 64);
-    V.anchors = X.d_anchors.p; V.dirs = X.d_dirs.p; V.rows = X.d_rows.p; V.opsbuf = X.d_opsbuf.p;
+    size_t free_b = 0, total_b = 0;
     V.slots = n_groups;
     if (n_mates * V.slots > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "chunks of up to %llu read pairs with this basis", (unsigned long long)(0xFFFFFFFFull / V.slots / 2));
     X.d_cands.alloc(n_mates * V.slots * sizeof(LongCand)); X.d_nhave.alloc(n_mates);
-    X.d_counters.alloc(4);
+    X.d_counters.alloc(8);
     V.cands = reinterpret_cast<LongCand*>(X.d_cands.p); V.n_have = X.d_nhave.p; V.counters = X.d_counters.p;
-    // kernel 1, repeated with more room if the CIGAR words did not fit the arena
-    // room for the words of a chunk of noisy reads on every basis allele (a word per ~4 bases), as far as the memory goes; the kernel
-    // says how many it needed when that was not enough
-    LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
-    uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::min<uint64_t>(free_b / 32, nb / 4 * ix.n_basis) + 4096);
-    uint32_t counters[4] = {0, 0, 0, 0};
-    for (;;) {
-        X.d_counters.zero(s);
-        X.d_ops.alloc(cap);
-        V.ops = X.d_ops.p; V.ops_cap = static_cast<uint32_t>(cap);
-        ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_kernel, dim3(n_wg), dim3(64), 0, s, V); }, s);
-        LCTY_HIP(hipGetLastError());
-        X.d_counters.download(counters, 4, s);
-        LCTY_HIP(hipStreamSynchronize(s));
-        if (counters[1] <= cap) break;
-        if (counters[1] >= 0xFFFFFFF0u) fail(LCTY_ERR_UNSUPPORTED, "CIGAR words of the chunk's alignments: map it in parts");
-        cap = static_cast<uint64_t>(counters[1]) + 1024;
+    uint32_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- kernel 1: the chains. Scratch of a workgroup: the anchors of every group; it leaves the chains to be aligned (repeated with
+    // more room if they did not fit) and a work item for each
+    const uint32_t max_seeds = max_len >= params->k ? (max_len - params->k) / params->stride + 2 : 0;
+    V.cap_g = std::max<uint32_t>(2 * max_seeds, 1);
+    {
+        const uint64_t per_wg = static_cast<uint64_t>(n_groups) * V.cap_g * sizeof(uint4);
+        LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (per_wg > free_b / 2) fail(LCTY_ERR_RUNTIME, "the long route needs %llu MB of scratch per workgroup", (unsigned long long)(per_wg >> 20));
+        const uint64_t budget = std::min<uint64_t>(free_b / 4, 16ull << 30);
+        const uint32_t n_wg = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(n_mates, 8ull * cus), std::max<uint64_t>(budget / per_wg, 1)));
+        X.d_anchors.alloc(static_cast<size_t>(n_wg) * n_groups * V.cap_g);
+        V.anchors = X.d_anchors.p;
+        X.d_work.alloc(n_mates * V.slots * (sizeof(LongWork) / sizeof(uint32_t)));
+        V.work = reinterpret_cast<LongWork*>(X.d_work.p);
+        uint64_t seeds_total = 0;
+        for (uint64_t m = 0; m < n_mates; m++)
+            if (chunk->mate_len[m] >= params->k) seeds_total += (chunk->mate_len[m] - params->k) / params->stride + 2;
+        // room for the chains of a chunk of noisy reads on every basis allele (every other seed an anchor), as far as the memory goes; the
+        // kernel says how many entries it needed when that was not enough
+        LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+        uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::min<uint64_t>(free_b / 64, seeds_total * ix.n_basis / 2) + 4096);
+        for (;;) {
+            X.d_counters.zero(s);
+            X.d_chain.alloc(cap);
+            V.chain = X.d_chain.p; V.chain_cap = static_cast<uint32_t>(cap);
+            ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_chain_kernel, dim3(n_wg), dim3(64), 0, s, V); }, s);
+            LCTY_HIP(hipGetLastError());
+            X.d_counters.download(counters, 4, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            if (counters[3] <= cap) break;
+            if (counters[3] >= 0xFFFFFFF0u) fail(LCTY_ERR_UNSUPPORTED, "anchors of the chunk's chains: map it in parts");
+            cap = static_cast<uint64_t>(counters[3]) + 1024;
+        }
+        X.d_anchors.release();
+        V.n_work = counters[0];
     }
-    X.d_anchors.release(); X.d_dirs.release(); X.d_rows.release(); X.d_opsbuf.release();
-    // kernel 2, sizes
+    // ---- kernel 2: the alignments. Scratch of a wavefront: the direction bytes of the largest segment, the CIGAR runs of a candidate;
+    // it leaves the CIGAR words in an arena (repeated with more room if they did not fit)
+    if (V.n_work) {
+        V.wmax = params->chain_skew + 2 * params->band + 1;
+        V.tb_bytes = std::max<uint32_t>(4096, (V.wmax + 3) / 4 * 4);
+        const uint64_t ext_bytes = (static_cast<uint64_t>(max_len) + 1) * (2 * params->band + 1);
+        const uint64_t piece_rows = std::min<uint64_t>(params->chain_gap, max_len) + 1;
+        V.dirs_bytes = (std::max<uint64_t>(ext_bytes, piece_rows * V.wmax) + 15) / 16 * 16;
+        V.ops_wave = 2 * max_len + 8;
+        const uint64_t per_wave = V.dirs_bytes + static_cast<uint64_t>(V.ops_wave) * 4;
+        LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (per_wave > free_b / 2) fail(LCTY_ERR_RUNTIME, "the long route needs %llu MB of scratch per wavefront", (unsigned long long)(per_wave >> 20));
+        const uint64_t budget = std::min<uint64_t>(free_b / 4, 16ull << 30);
+        const uint32_t lds = 2 * V.wmax * 4 + V.tb_bytes + (V.wmax + 64) + 64;
+        const uint32_t n_waves = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(V.n_work, 24ull * cus), std::max<uint64_t>(budget / per_wave, 1)));
+        X.d_dirs.alloc(static_cast<size_t>(n_waves) * V.dirs_bytes);
+        X.d_opsbuf.alloc(static_cast<size_t>(n_waves) * V.ops_wave);
+        V.dirs = X.d_dirs.p; V.opsbuf = X.d_opsbuf.p;
+        // room for the words of a chunk of noisy reads (a word per ~4 bases of every alignment), as far as the memory goes; the kernel
+        // says how many it needed when that was not enough
+        LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
+        uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::min<uint64_t>(free_b / 32, static_cast<uint64_t>(V.n_work) * (nb / std::max<uint64_t>(n, 1) / 4 + 8)) + 4096);
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(map_long_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        for (;;) {
+            const uint32_t zero = 0;
+            X.d_counters.upload(&zero, 1, s, 1); X.d_counters.upload(&zero, 1, s, 4);
+            X.d_ops.alloc(cap);
+            V.ops = X.d_ops.p; V.ops_cap = static_cast<uint32_t>(cap);
+            ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_align_kernel, dim3(n_waves), dim3(64), lds, s, V); }, s);
+            LCTY_HIP(hipGetLastError());
+            X.d_counters.download(counters, 4, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            if (counters[1] <= cap) break;
+            if (counters[1] >= 0xFFFFFFF0u) fail(LCTY_ERR_UNSUPPORTED, "CIGAR words of the chunk's alignments: map it in parts");
+            cap = static_cast<uint64_t>(counters[1]) + 1024;
+        }
+        X.d_dirs.release(); X.d_opsbuf.release();
+    } else {
+        X.d_ops.alloc(1);
+        V.ops = X.d_ops.p; V.ops_cap = 1;
+    }
+    X.d_chain.release();
+    // ---- kernel 3, sizes
     const uint32_t n_wg2 = static_cast<uint32_t>(std::min<uint64_t>(n_mates, 16ull * cus));
     ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_emit_kernel<false>, dim3(n_wg2), dim3(64), 0, s, V); }, s);
     LCTY_HIP(hipGetLastError());

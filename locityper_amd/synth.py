@@ -122,3 +122,31 @@ CONFIGS = {
     4: dict(n_pairs=1_000_000, n_alleles=256, technology=cdefs.TECH_ILLUMINA, read_len=150, n_loci=32),
     5: dict(n_pairs=5_000_000, n_alleles=4096, technology=cdefs.TECH_ILLUMINA, read_len=150),
 }
+
+
+def sequencer_orientation(ch):
+    """The generator's chunk holds SEQ as a BAM does (reverse-complemented where the read end's primary record is on the reverse strand).
+    -> a chunk with the bases as the sequencer gave them and no records: the input of candidate generation (lcty_map_reads)."""
+    from .cdefs import ALN_REC_DTYPE, FLAG_MATE2, FLAG_REVERSE, FLAG_SECONDARY, FLAG_SUPPL, ReadsChunk
+    b2 = ch.bases2.copy(); nm = ch.nmask.copy()
+    flags = ch.recs["flags"].astype(np.int64)
+    sh2 = (2 * np.arange(16)).astype(np.uint32); sh1 = np.arange(32).astype(np.uint32)
+    for pair in range(ch.n_pairs):
+        lo, hi = int(ch.aln_off[pair]), int(ch.aln_off[pair + 1])
+        fl = flags[lo:hi]
+        for e in (0, 1):
+            m = 2 * pair + e
+            ln, off = int(ch.mate_len[m]), int(ch.mate_off[m])
+            own = fl[((fl & FLAG_MATE2) != 0) == bool(e)]
+            own = own[(own & (FLAG_SECONDARY | FLAG_SUPPL)) == 0]
+            if ln == 0 or len(own) == 0 or not int(own[0]) & FLAG_REVERSE:
+                continue
+            idx = off + np.arange(ln, dtype=np.int64)
+            bases = (ch.bases2[idx >> 4] >> (2 * (idx & 15)).astype(np.uint32)) & 3
+            isn = (ch.nmask[idx >> 5] >> (idx & 31).astype(np.uint32)) & 1
+            rb = np.zeros((ln + 15) // 16 * 16, dtype=np.uint32); rb[:ln] = 3 - bases[::-1]
+            rn = np.zeros((ln + 31) // 32 * 32, dtype=np.uint32); rn[:ln] = isn[::-1]
+            b2[off >> 4:(off >> 4) + len(rb) // 16] = np.bitwise_or.reduce(rb.reshape(-1, 16) << sh2, axis=1)
+            nm[off >> 5:(off >> 5) + len(rn) // 32] = np.bitwise_or.reduce(rn.reshape(-1, 32) << sh1, axis=1)
+    z = np.zeros(ch.n_pairs + 1, dtype=np.uint64)
+    return ReadsChunk(ch.mate_len, ch.mate_off, b2, nm, z, np.zeros(0, dtype=ALN_REC_DTYPE), z, np.zeros(0, dtype=np.uint32))
