@@ -902,7 +902,8 @@ def main():
             # the device, no external mapper, no recovery needed ----
             progress("long-read leg from bases alone")
             nmap = min(args.ont_map_sample, nont)
-            fq = [synth.sequencer_orientation(Lo.reads(lo, min(chunk_o, nmap - lo), primaries_only=True)) for lo in range(0, nmap, chunk_o)]
+            chunk_m = 1024                                                          # read ends per mapping call: one wavefront each in the chain kernel
+            fq = [synth.sequencer_orientation(Lo.reads(lo, min(chunk_m, nmap - lo), primaries_only=True)) for lo in range(0, nmap, chunk_m)]
             mpl = api.map_params(long_reads=True)
             basis_l = list(range(A))
             tm0 = time.perf_counter()
@@ -934,7 +935,7 @@ def main():
             out["long_reads"]["from_bases"] = {
                 "sample": f"the first {nmap} of those reads as sequenced (no records) onto all {len(basis_l)} alleles: seeds of {mpl.k} every {mpl.stride} bases, "
                           f"one chain per (allele, strand), gap-affine alignment along the chain in a band of +-{mpl.band}; records straight into a batch "
-                          f"(lcty_reads_map_append, chunks of {chunk_o}), then scoring (+ recovery of the few alignments the mapper left out) + prefilter",
+                          f"(lcty_reads_map_append, chunks of {chunk_m}), then scoring (+ recovery of the few alignments the mapper left out) + prefilter",
                 "alignments": n_mapped, "map_kernels_ms": ms_map, "launches": int(n_launch), "map_call_s": t_map, "index_build_s": t_index,
                 "alignments_per_s_kernel": n_mapped / (ms_map * 1e-3) if ms_map else None, "reads_per_s_call": nmap / t_map,
                 "aligned_bases_per_s_kernel": n_mapped * (read_bases / max(nmap, 1)) / (ms_map * 1e-3) if ms_map else None,

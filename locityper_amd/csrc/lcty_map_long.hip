@@ -151,15 +151,23 @@ __global__ __launch_bounds__(64) void map_long_chain_kernel(const LongView V) {
                                 uint4* list = wg_anchors + static_cast<size_t>(g) * V.cap_g;
                                 int32_t f = static_cast<int32_t>(k); uint32_t back = 0, cnt_chain = 1;
                                 const uint32_t look = min(V.chain_back, have);
-                                for (uint32_t o = 1; o <= look; o++) {
-                                    const uint4 a = list[have - o];
-                                    const int64_t dq = static_cast<int64_t>(q) - a.x, dt = static_cast<int64_t>(t) - a.y;
-                                    if (dq <= 0 || dt <= 0 || dq > V.chain_gap || dt > V.chain_gap) continue;
-                                    const int64_t sk = dq > dt ? dq - dt : dt - dq;
-                                    if (sk > V.chain_skew || (sk != 0 && (dq < k || dt < k))) continue;
-                                    const int64_t gain = min(min(dq, dt), static_cast<int64_t>(k));
-                                    const int32_t v = static_cast<int32_t>(a.z) + static_cast<int32_t>(gain) - (sk ? 2 + static_cast<int32_t>(sk) : 0);
-                                    if (v > f) { f = v; back = o; cnt_chain = (a.w >> 8) + 1; }
+                                // eight anchors back at a time: the loads go out together, the anchors are looked at most recent first
+                                for (uint32_t o0 = 1; o0 <= look; o0 += 8) {
+                                    uint4 prev[8];
+#pragma unroll
+                                    for (uint32_t u = 0; u < 8; u++) prev[u] = list[o0 + u <= look ? have - o0 - u : have - look];
+#pragma unroll
+                                    for (uint32_t u = 0; u < 8; u++) {
+                                        const uint4 a = prev[u];
+                                        const uint32_t o = o0 + u;
+                                        const int64_t dq = static_cast<int64_t>(q) - a.x, dt = static_cast<int64_t>(t) - a.y;
+                                        const int64_t sk = dq > dt ? dq - dt : dt - dq;
+                                        const bool ok = o <= look && dq > 0 && dt > 0 && dq <= V.chain_gap && dt <= V.chain_gap && sk <= V.chain_skew &&
+                                                        (sk == 0 || (dq >= k && dt >= k));
+                                        const int64_t gain = min(min(dq, dt), static_cast<int64_t>(k));
+                                        const int32_t v = static_cast<int32_t>(a.z) + static_cast<int32_t>(gain) - (sk ? 2 + static_cast<int32_t>(sk) : 0);
+                                        if (ok && v > f) { f = v; back = o; cnt_chain = (a.w >> 8) + 1; }
+                                    }
                                 }
                                 list[have] = make_uint4(q, t, static_cast<uint32_t>(f), back | (cnt_chain << 8));
                                 g_n[g] = have + 1;
