@@ -34,6 +34,7 @@
 // listed ones with gaps, one per lane; map_emit_kernel<WRITE> (one wavefront per read end, lane = candidate) runs twice: sizes,
 // then records, with a host prefix sum in between.
 #include <algorithm>
+#include <chrono>
 
 #include "lcty_map_internal.hpp"
 
@@ -720,7 +721,10 @@ int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, c
         lcty_reads_host h = *chunk;
         h.aln_off = aln_off.data(); h.cigar_off = cigar_off.data(); h.recs = nullptr; h.cigar = nullptr;
         DeviceRecords dev{X.d_recs.p, X.d_cigar.p, X.d_ob2.p, X.d_onm.p, X.nrec.data(), X.max_rec_cigar};
+        const auto t0 = std::chrono::steady_clock::now();
         const int32_t rc = reads_append_device(reads, &h, &dev);
+        if (reads->ctx->knob("map_trace", 0))
+            fprintf(stderr, "[lcty map] append of the mapped chunk: %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
     });
 }

@@ -38,6 +38,7 @@
 // the CIGAR runs right to left in scratch; they are copied into the arena at the end. map_long_emit_kernel<WRITE>, one wavefront per
 // read end, runs twice: sizes, then records (host prefix sums in between).
 #include <algorithm>
+#include <chrono>
 
 #include "lcty_map_internal.hpp"
 
@@ -597,6 +598,12 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
     hipStream_t s = ctx->stream;
     const uint64_t n = chunk->n_pairs, n_mates = 2 * n;
     const uint64_t nb = chunk->mate_off[n_mates];
+    // lcty_ctx_set_knob "map_trace" 1: wall-clock marks of the phases of a call on stderr
+    const bool trace = ctx->knob("map_trace", 0) != 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (trace) fprintf(stderr, "[lcty map] %8.3f ms %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), what);
+    };
     if (max_len > MAP_LONG_MAX_LEN) fail(LCTY_ERR_UNSUPPORTED, "read ends of up to %u bases (the longest here: %u)", MAP_LONG_MAX_LEN, max_len);
     if (params->chain_back == 0 || params->chain_back > 64) fail(LCTY_ERR_INVALID_INPUT, "chain_back %u: 1..64", params->chain_back);
     if (params->chain_gap == 0 || params->chain_gap > 8192) fail(LCTY_ERR_INVALID_INPUT, "chain_gap %u: 1..8192", params->chain_gap);
@@ -656,8 +663,10 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
             if (counters[3] >= 0xFFFFFFF0u) fail(LCTY_ERR_UNSUPPORTED, "anchors of the chunk's chains: map it in parts");
             cap = static_cast<uint64_t>(counters[3]) + 1024;
         }
+        mark("chains done");
         X.d_anchors.release();
         V.n_work = counters[0];
+        mark("anchor scratch released");
     }
     // ---- kernel 2: the alignments. Scratch of a wavefront: the direction bytes of the largest segment, the CIGAR runs of a candidate;
     // it leaves the CIGAR words in an arena (repeated with more room if they did not fit)
@@ -681,6 +690,7 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
         // says how many it needed when that was not enough
         LCTY_HIP(hipMemGetInfo(&free_b, &total_b));
         uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::min<uint64_t>(free_b / 32, static_cast<uint64_t>(V.n_work) * (nb / std::max<uint64_t>(n, 1) / 4 + 8)) + 4096);
+        mark("alignment scratch allocated");
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(map_long_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         for (;;) {
             const uint32_t zero = 0;
@@ -695,7 +705,9 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
             if (counters[1] >= 0xFFFFFFF0u) fail(LCTY_ERR_UNSUPPORTED, "CIGAR words of the chunk's alignments: map it in parts");
             cap = static_cast<uint64_t>(counters[1]) + 1024;
         }
+        mark("alignments done");
         X.d_dirs.release(); X.d_opsbuf.release();
+        mark("alignment scratch released");
     } else {
         X.d_ops.alloc(1);
         V.ops = X.d_ops.p; V.ops_cap = 1;
@@ -710,6 +722,7 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
     X.d_nrec.download(X.nrec.data(), n_mates, s); X.d_ncig.download(X.ncig.data(), n_mates, s);
     LCTY_HIP(hipStreamSynchronize(s));
     X.max_rec_cigar = counters[2];
+    mark("sizes done");
     std::vector<uint64_t> rec_at(n_mates), cig_at(n_mates), pair_cig(n);
     uint64_t r = 0, c = 0;
     for (uint64_t p = 0; p < n; p++) {
@@ -730,6 +743,7 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
     ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_emit_kernel<true>, dim3(n_wg2), dim3(64), 0, s, V); }, s);
     LCTY_HIP(hipGetLastError());
     LCTY_HIP(hipStreamSynchronize(s));                                          // rec_at & co. are host vectors of this frame
+    mark("records written");
 }
 
 }  // namespace lcty

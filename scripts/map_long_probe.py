@@ -13,8 +13,11 @@ ap.add_argument("--read-len", type=int, default=10_000)
 ap.add_argument("--base-len", type=int, default=40_000)
 ap.add_argument("--stride", type=int, default=16)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--trace", action="store_true")
 a = ap.parse_args()
 ctx = api.Context(0)
+if a.trace:
+    ctx.set_knob("map_trace", 1)
 L = synth.SynthLocus(a.alleles, a.reads, seed=synth.SEED + 5, technology=cdefs.TECH_NANOPORE, read_len=a.read_len, base_len=a.base_len)
 p = api.resolve_params(api.default_params(), L.bg)
 loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
