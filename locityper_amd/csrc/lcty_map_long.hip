@@ -239,6 +239,10 @@ struct Seqs {
         const uint32_t e = enc_of(strand ? ref[alen - 1 - t] : ref[t]);
         return e == 4u ? 4u : (strand ? 3u - e : e);
     }
+    __device__ __forceinline__ bool eq(uint32_t q, uint32_t t) const {
+        const uint32_t r = read_base(q);
+        return r < 4u && r == allele_base(t);
+    }
 };
 
 // the scratch of a wavefront and the CIGAR runs in the order they are met (right to left); every lane holds the same run state,
@@ -293,7 +297,44 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
     else { dlo = (d < 0 ? d : 0) - B; dhi = (d > 0 ? d : 0) + B; }
     const uint32_t W = static_cast<uint32_t>(dhi - dlo + 1);
     const uint32_t n_chunks = (W + 63) / 64;
+    if (!free_start && !free_end && n == m && n > 0 && n <= C.tb_bytes * 8) {
+        // A piece between corners on one diagonal whose bases differ in h places: any alignment with gaps has an insertion and a
+        // deletion and at most n - 1 base steps, so it scores <= (n - 1) match - 2 gap_open; when the diagonal scores more than that
+        // it is what the rows below would find (and the only one) — the lanes compare 64 bases at a time and the runs are written
+        // from the masks. Nearly half the pieces of a 3 %-error read, nearly all of a HiFi read.
+        uint64_t* masks = reinterpret_cast<uint64_t*>(C.tb);
+        const uint32_t n_masks = (n + 63) / 64;
+        uint32_t h = 0;
+        __syncthreads();
+        for (uint32_t c = 0; c < n_masks; c++) {
+            const uint32_t x = c * 64 + lane;
+            const bool same = x < n && S.eq(q0 + x, t0 + x);
+            const unsigned long long sm = __ballot(same), in = __ballot(x < n);
+            h += static_cast<uint32_t>(__popcll(in & ~sm));
+            if (lane == 0) masks[c] = sm;
+        }
+        __syncthreads();
+        if (static_cast<int64_t>(h) * (V.match + V.mismatch) < static_cast<int64_t>(V.match) + 2 * static_cast<int64_t>(V.gap_open)) {
+            for (uint32_t c = n_masks; c-- > 0;) {
+                const uint64_t bits = masks[c];
+                uint32_t pos = min(64u, n - c * 64);                        // bases of this mask not written yet: [0, pos)
+                while (pos > 0) {
+                    const bool same = (bits >> (pos - 1)) & 1ull;
+                    uint64_t other = same ? ~bits : bits;                   // set where the outcome differs from that of base pos - 1
+                    if (pos < 64) other &= (1ull << pos) - 1ull;
+                    const uint32_t run = other ? pos - (64u - static_cast<uint32_t>(__clzll(static_cast<long long>(other)))) : pos;
+                    C.put(same ? 7u : 8u, run);
+                    pos -= run;
+                }
+            }
+            __syncthreads();
+            return SegOut{static_cast<int32_t>((n - h) * V.match) - static_cast<int32_t>(h * V.mismatch), 0u, m};
+        }
+    }
     for (uint32_t kk = lane; kk < W; kk += 64) { C.hrow[kk] = LNEG; C.frow[kk] = LNEG; }
+    // the direction bytes of a short segment stay in LDS (most pieces: a few dozen rows), those of a long one go through the scratch
+    const bool small = (static_cast<uint64_t>(n) + 1) * W <= C.tb_bytes;
+    uint8_t* dstore = small ? C.tb : C.dirs;
     __syncthreads();
     int32_t bt = INT32_MIN; uint32_t bi = 0, bkk = 0;                     // this lane's best end node (free end)
     for (uint32_t i = 0; i <= n; i++) {
@@ -354,7 +395,7 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
             const int32_t lh = from_left(h, carry_h), le = from_left(e, carry_e);
             const uint32_t ebit = valid && j >= 1 && le - V.gap_extend > lh - V.gap_open ? 1u : 0u;
             if (in) { C.hrow[kk] = h; C.frow[kk] = valid ? f : LNEG; }
-            if (valid) C.dirs[static_cast<size_t>(i) * W + kk] = static_cast<uint8_t>(code | (ebit << 2) | (fbit << 3) | (mbit << 4));
+            if (valid) dstore[static_cast<size_t>(i) * W + kk] = static_cast<uint8_t>(code | (ebit << 2) | (fbit << 3) | (mbit << 4));
             if (free_end && valid && mc > LNEG && i >= 1) {
                 const int32_t total = mc + (i == n ? V.end_bonus : 0);
                 if (total > bt) { bt = total; bi = i; bkk = kk; }
@@ -389,7 +430,7 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
     const uint32_t j_end = static_cast<uint32_t>(static_cast<int64_t>(i) + dlo + kk);
     if (free_end) C.put(4u, left);                                         // the clip lies to the right of the extension
     const uint32_t rows_blk = C.tb_bytes / W;
-    uint32_t blk_lo = i + 1;                                               // rows [blk_lo, blk_hi] of the direction bytes are in LDS
+    uint32_t blk_lo = small ? 0u : i + 1;                                  // rows [blk_lo, ..] of the direction bytes are in LDS (all of them: small)
     for (;;) {
         if (i < blk_lo) {
             __syncthreads();

@@ -1,7 +1,10 @@
 """Time the long route of candidate generation (lcty_map_reads on 10-kb ONT reads): reads x basis alleles alignments per second.
 usage: python3 scripts/map_long_probe.py [--reads N] [--alleles A] [--basis B] [--read-len L] [--stride S] [--reps R]"""
-import argparse, json, sys, time
+import argparse, json, os, sys, time
 sys.path.insert(0, ".")
+if "--lib" in sys.argv:                                  # a library built by scripts/build_experiment.sh
+    from locityper_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1]); del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
 import numpy as np
 from locityper_amd import api, cdefs, synth
 
