@@ -271,6 +271,10 @@ struct SegOut { int32_t score; uint32_t left, t_taken; };
 __device__ __forceinline__ int32_t from_left(int32_t x, int32_t first) {
     return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xF, 0xF, false);
 }
+// lane i takes lane i + 1, lane 63 takes `last` (DPP wave_shl:1)
+__device__ __forceinline__ int32_t from_right(int32_t x, int32_t last) {
+    return __builtin_amdgcn_update_dpp(last, x, 0x130, 0xF, 0xF, false);
+}
 // inclusive prefix maximum over the 64 lanes: inside the rows of 16 (row_shr 1, 2, 4, 8), then across them (row_bcast 15 / 31)
 __device__ __forceinline__ int32_t prefix_max(int32_t v) {
     constexpr int32_t none = INT32_MIN;
@@ -337,6 +341,71 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
     uint8_t* dstore = small ? C.tb : C.dirs;
     __syncthreads();
     int32_t bt = INT32_MIN; uint32_t bi = 0, bkk = 0;                     // this lane's best end node (free end)
+    if (n_chunks == 1) {
+        // a band of up to 64 diagonals (every extension, nearly every piece): the running rows stay in registers — the row above comes
+        // over by a DPP shift — and a row needs no barrier
+        const int32_t jb = static_cast<int32_t>(dlo) + static_cast<int32_t>(lane), mi = static_cast<int32_t>(m);
+        const bool in = lane < W;
+        const int32_t ext_at = V.gap_extend * static_cast<int32_t>(lane);
+        int32_t h_reg = LNEG, f_reg = LNEG;
+        for (uint32_t i = 0; i <= n; i++) {
+            if ((i & 63u) == 0) {
+                __syncthreads();
+                const uint32_t r = i + lane;
+                C.rbuf[lane] = static_cast<uint8_t>(r >= 1 && r <= n ? S.read_base(q0 + r - 1) : 4u);
+                const int64_t p0 = static_cast<int64_t>(t0) + static_cast<int64_t>(i) + dlo - 1;
+                for (uint32_t x = lane; x < W + 64; x += 64) {
+                    const int64_t p = p0 + x;
+                    C.abuf[x] = static_cast<uint8_t>(p >= 0 && p < static_cast<int64_t>(S.alen) ? S.allele_base(static_cast<uint32_t>(p)) : 5u);
+                }
+                __syncthreads();
+            }
+            const uint32_t rb = C.rbuf[i & 63u];
+            const int32_t fr = free_start ? (i == 1 ? V.end_bonus : 0) : LNEG;
+            const int32_t j = static_cast<int32_t>(i) + jb;
+            const bool valid = in && j >= 0 && j <= mi;
+            const int32_t up_h = from_right(h_reg, LNEG), up_f = from_right(f_reg, LNEG);
+            int32_t mc = LNEG; uint32_t code = 0, mbit = 0;
+            if (valid && i >= 1 && j >= 1) {
+                int32_t base = h_reg;
+                if (fr > base) { base = fr; code = 3; }
+                if (base > LNEG / 2) {
+                    mbit = rb < 4u && rb == C.abuf[(i & 63u) + lane] ? 1u : 0u;
+                    mc = base + (mbit ? V.match : -V.mismatch);
+                }
+            }
+            if (valid && i == 0 && j == 0 && !free_start) mc = 0;
+            int32_t f = LNEG; uint32_t fbit = 0;
+            if (valid && i >= 1) {
+                const int32_t fo = up_h - V.gap_open, fe = up_f - V.gap_extend;
+                if (fe > fo) { f = fe; fbit = 1; } else f = fo;
+            }
+            if (mc < LNEG / 2) mc = LNEG;
+            if (f < LNEG / 2) f = LNEG;
+            const int32_t ht = mc > f ? mc : f;
+            const int32_t pm = prefix_max(valid && ht > LNEG ? ht + ext_at : INT32_MIN);
+            const int32_t excl = from_left(pm, INT32_MIN);
+            int32_t e = LNEG;
+            if (valid && j >= 1 && excl != INT32_MIN) {
+                e = excl - V.gap_open - (ext_at - V.gap_extend);
+                if (e < LNEG / 2) e = LNEG;
+            }
+            int32_t h = mc;
+            if (e > h) { h = e; code = 1; }
+            if (f > h) { h = f; code = 2; }
+            if (!valid) { h = LNEG; e = LNEG; f = LNEG; }
+            const int32_t lh = from_left(h, LNEG), le = from_left(e, LNEG);
+            const uint32_t ebit = valid && j >= 1 && le - V.gap_extend > lh - V.gap_open ? 1u : 0u;
+            h_reg = h; f_reg = f;
+            if (valid) dstore[static_cast<size_t>(i) * W + lane] = static_cast<uint8_t>(code | (ebit << 2) | (fbit << 3) | (mbit << 4));
+            if (free_end && valid && mc > LNEG && i >= 1) {
+                const int32_t total = mc + (i == n ? V.end_bonus : 0);
+                if (total > bt) { bt = total; bi = i; bkk = lane; }
+            }
+        }
+        if (in) C.hrow[lane] = h_reg;                                         // where the end node is looked up below
+        __syncthreads();
+    } else
     for (uint32_t i = 0; i <= n; i++) {
         if ((i & 63u) == 0) {
             // the bases of the next 64 rows: node (i, j) looks at read base q0 + i - 1 and allele base t0 + j - 1 (5: none)
