@@ -348,6 +348,7 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
         const bool in = lane < W;
         const int32_t ext_at = V.gap_extend * static_cast<int32_t>(lane);
         int32_t h_reg = LNEG, f_reg = LNEG;
+        uint32_t rb = 4u, ab = 5u;                                            // the bases of this row: read out of LDS a row ahead
         for (uint32_t i = 0; i <= n; i++) {
             if ((i & 63u) == 0) {
                 __syncthreads();
@@ -359,8 +360,10 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
                     C.abuf[x] = static_cast<uint8_t>(p >= 0 && p < static_cast<int64_t>(S.alen) ? S.allele_base(static_cast<uint32_t>(p)) : 5u);
                 }
                 __syncthreads();
+                rb = C.rbuf[0]; ab = C.abuf[lane];
             }
-            const uint32_t rb = C.rbuf[i & 63u];
+            const uint32_t rb_next = C.rbuf[(i + 1) & 63u], ab_next = C.abuf[((i + 1) & 63u) + lane];     // stale at a block's end: read again above
+            const bool same = rb < 4u && rb == ab;
             const int32_t fr = free_start ? (i == 1 ? V.end_bonus : 0) : LNEG;
             const int32_t j = static_cast<int32_t>(i) + jb;
             const bool valid = in && j >= 0 && j <= mi;
@@ -370,8 +373,8 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
                 int32_t base = h_reg;
                 if (fr > base) { base = fr; code = 3; }
                 if (base > LNEG / 2) {
-                    mbit = rb < 4u && rb == C.abuf[(i & 63u) + lane] ? 1u : 0u;
-                    mc = base + (mbit ? V.match : -V.mismatch);
+                    mbit = same ? 1u : 0u;
+                    mc = base + (same ? V.match : -V.mismatch);
                 }
             }
             if (valid && i == 0 && j == 0 && !free_start) mc = 0;
@@ -402,6 +405,7 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
                 const int32_t total = mc + (i == n ? V.end_bonus : 0);
                 if (total > bt) { bt = total; bi = i; bkk = lane; }
             }
+            rb = rb_next; ab = ab_next;
         }
         if (in) C.hrow[lane] = h_reg;                                         // where the end node is looked up below
         __syncthreads();
