@@ -143,6 +143,7 @@ struct SolveView {
     double* liks;                   // [n_chains] prior + likelihood
     double* parts;                  // [n_chains][4] aln_lik, depth_lik, solver iterations, accepted moves (diagnostics)
     uint32_t* overflow;             // set when a window got deeper than the depth table (the host widens it and repeats)
+    uint32_t prio_mode;             // issue priority of the loop kernels: 0 annealing wavefronts first (default), 1 greedy first, 2 none (knob solve_prio_mode)
 };
 
 // a wave-uniform 64-bit value, told to the compiler as such (it then lives in scalar registers)
@@ -933,6 +934,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
     if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (flagged != 0u) return;
+    if (V.prio_mode == 1) __builtin_amdgcn_s_setprio(3);
     const uint32_t W = V.wstride;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // lanes behind the last row (LPC 10, 12: lanes 60..63) ride along with it as lanes without a candidate
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     if (flagged != 0u) return;                     // the batch is repeated by the host (see greedy_loop_kernel)
     // These are few wavefronts with one dependent chain of instructions each; in a queue of loci they share their SIMDs with the
     // greedy wavefronts of the next locus, which always have an instruction ready. The issue arbiter takes the higher priority first.
-    __builtin_amdgcn_s_setprio(3);
+    if (V.prio_mode == 0) __builtin_amdgcn_s_setprio(3);
     const uint32_t W = V.wstride;
     // [W] window weights first (MODE 1) or the two weight tables (MODE 2), then [W] depth words, [W] half-words (MODE 2), then the
     // ring the second wavefront fills
@@ -1856,6 +1858,7 @@ struct StageRunner {
         }
         V.ploidy = ploidy; V.attempts = attempts; V.solver = *solver;
         V.wstride = (2 + ploidy * loc->max_n_windows + 3) & ~3u;
+        V.prio_mode = static_cast<uint32_t>(ctx->knob("solve_prio_mode", 0));
         lds_init = ((static_cast<size_t>(V.wstride) * 4 + 15) & ~static_cast<size_t>(15)) + 256 * 8 + 64;
         if (static_cast<size_t>(V.wstride) * 12 + sizeof(AnnealRing) + 128 > 160 * 1024 || V.wstride > 65535)
             fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype: too many for the device solver", V.wstride);
@@ -1934,7 +1937,7 @@ struct StageRunner {
         }
         if (V.solver.kind == LCTY_SOLVER_EXACT) { solve_exact_batch(nch); return; }
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
-            if (lane == 1) wait_for_greedy_of_next_locus();
+            if (lane == 1 && !ctx->knob("queue_no_gate", 0)) wait_for_greedy_of_next_locus();
             launch_anneal(ctx, V, nch, stream);
             if (ctx->knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p annealing launched (lane %u)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), static_cast<const void*>(reads), lane);
