@@ -17,6 +17,7 @@ ap.add_argument("--base-len", type=int, default=40_000)
 ap.add_argument("--stride", type=int, default=16)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--trace", action="store_true")
+ap.add_argument("--chain-back", type=int, default=0)
 a = ap.parse_args()
 ctx = api.Context(0)
 if a.trace:
@@ -26,6 +27,8 @@ p = api.resolve_params(api.default_params(), L.bg)
 loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
 fq = synth.sequencer_orientation(L.reads(0, a.reads, primaries_only=True))
 mp = api.map_params(long_reads=True, stride=a.stride)
+if a.chain_back:
+    mp.chain_back = a.chain_back
 basis = list(range(a.basis or a.alleles))
 t0 = time.time(); api.build_map_index(loc, basis, k=mp.k); t_index = time.time() - t0
 best = None

@@ -84,3 +84,16 @@ def test_scores_add_up():
         n, c = w >> 4, OP[w & 15]
         want += {"=": 2 * n, "X": -4 * n, "I": -(6 + 2 * (n - 1)), "D": -(6 + 2 * (n - 1)), "S": 0}[c]
     assert score == want + 20 and consumed(cig) == (1600, 1300)
+
+
+def test_sequencer_orientation_of_the_generator_equals_the_plain_loop():
+    """locityper_amd.synth.sequencer_orientation (numpy, used by bench.py and the probes) against the base-by-base loop the GPU tests use."""
+    from locityper_amd import cdefs, synth
+    from tests.test_gpu_map import fastq_orientation
+    for kw in ({"n_alleles": 5, "n_pairs": 120, "seed": 3, "base_len": 5000},
+               {"n_alleles": 3, "n_pairs": 12, "seed": 4, "technology": cdefs.TECH_NANOPORE, "read_len": 6000, "base_len": 20000}):
+        L = synth.SynthLocus(**kw)
+        ch = L.reads(0, kw["n_pairs"], primaries_only="technology" in kw)
+        a, b = fastq_orientation(ch), synth.sequencer_orientation(ch)
+        assert np.array_equal(a.bases2, b.bases2) and np.array_equal(a.nmask, b.nmask) and len(b.recs) == 0
+        assert not np.array_equal(ch.bases2, b.bases2)                                # some read ends were on the reverse strand
