@@ -901,6 +901,7 @@ def main():
             # genotype.rs:990-1002, --basis none), the records go straight into a batch: per-read alignment against every allele on
             # the device, no external mapper, no recovery needed ----
             progress("long-read leg from bases alone")
+            ctx.trim()                                                              # the solver workspaces of the timed region (150 GB) are not this leg's business
             nmap = min(args.ont_map_sample, nont)
             chunk_m = 1024                                                          # read ends per mapping call: one wavefront each in the chain kernel
             fq = [synth.sequencer_orientation(Lo.reads(lo, min(chunk_m, nmap - lo), primaries_only=True)) for lo in range(0, nmap, chunk_m)]

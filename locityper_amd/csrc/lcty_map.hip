@@ -715,9 +715,15 @@ int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, c
         if (!reads || !chunk || !params) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         const uint64_t n = chunk->n_pairs;
         if (n == 0) return;
-        MapRun X;
+        const bool trace = reads->ctx->knob("map_trace", 0) != 0;
+        const auto t_in = std::chrono::steady_clock::now();
+        auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
+        struct Traced { MapRun run; bool on; decltype(since)* clock; ~Traced() { run = MapRun(); if (on) fprintf(stderr, "[lcty map] buffers of the call released at %.3f ms\n", (*clock)()); } };
+        Traced T{MapRun(), trace, &since};
+        MapRun& X = T.run;
         std::vector<uint64_t> aln_off(n + 1), cigar_off(n + 1);
         run_map(reads->locus, chunk, params, aln_off.data(), cigar_off.data(), false, X);
+        if (trace) fprintf(stderr, "[lcty map] mapped at %.3f ms of the call\n", since());
         lcty_reads_host h = *chunk;
         h.aln_off = aln_off.data(); h.cigar_off = cigar_off.data(); h.recs = nullptr; h.cigar = nullptr;
         DeviceRecords dev{X.d_recs.p, X.d_cigar.p, X.d_ob2.p, X.d_onm.p, X.nrec.data(), X.max_rec_cigar};
