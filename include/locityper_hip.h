@@ -184,7 +184,10 @@ typedef struct lcty_pair_aln {
  * registered at solve.rs:152-171, `-S highs` / `-S gurobi`): the same model — one binary per (non-trivial read, location), one-hot
  * depth variables per window, coupling rows, objective = ReadAssignment::likelihood — built on the device by the stage's
  * initialisation and solved to proven optimality by branch and bound; `node_limit` nodes without a proof -> LCTY_ERR_SOLVER, as
- * a non-optimal solver status is upstream (highs.rs:113-116). Every attempt starts from the best location of every read. */
+ * a non-optimal solver status is upstream (highs.rs:113-116). Every attempt starts from the best location of every read.
+ * `init_prob` is this kind's relative gap: 0 (the default) asks for a proof of optimality; g in (0, 1) stops the search when nothing
+ * left can beat the incumbent by more than g x |incumbent| — what HiGHS calls optimal at its default mip_rel_gap of 1e-4, which the
+ * reference does not change (highs.rs:103-110). */
 #define LCTY_SOLVER_EXACT 2
 typedef struct lcty_solver {
     int32_t  kind;          /* LCTY_SOLVER_* */
@@ -193,7 +196,7 @@ typedef struct lcty_solver {
     uint32_t plato_size;    /* greedy: 100; anneal: 10000 */
     uint32_t anneal_steps;  /* anneal: 20000 */
     uint32_t node_limit;    /* exact: branch-and-bound nodes per attempt before LCTY_ERR_SOLVER (default 20 000 000) */
-    double   init_prob;     /* anneal: 0.5 */
+    double   init_prob;     /* anneal: 0.5; exact: relative gap of the proof, 0 */
 } lcty_solver;
 
 typedef struct lcty_ctx   lcty_ctx;

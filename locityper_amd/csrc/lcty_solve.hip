@@ -2202,6 +2202,14 @@ struct StageRunner {
             double aln_sum = aln_fixed, win_sum = 0.0;
             std::vector<double> wmax(tw);
             for (uint32_t w = 0; w < tw; w++) { wmax[w] = range_max(w); win_sum += wmax[w]; }
+            // HiGHS stops a search — and reports "optimal" — when the bound of what is left is within mip_rel_gap (1e-4 by default) of the
+            // incumbent; the reference leaves that option alone (highs.rs:103-110). Here the gap is the caller's (lcty_solver.init_prob
+            // for this kind; 0 = a proof of optimality): subtrees that cannot beat the incumbent by more than it are left out.
+            const double rel_gap = V.solver.init_prob > 0.0 && V.solver.init_prob < 1.0 ? V.solver.init_prob : 0.0;
+            const double root_bound = V.aln_contrib * (aln_sum + free_best) + V.depth_contrib * win_sum;
+            if (ctx->knob("exact_trace", 0))
+                fprintf(stderr, "[lcty exact] chain %u: %u non-trivial reads, %u free; incumbent %.6f, root bound %.6f (gap %.3e relative)\n", c, n, n_free,
+                        incumbent, root_bound, (root_bound - incumbent) / std::fabs(incumbent));
             // depth-first, iterative (a locus can have many thousands of non-trivial reads: no recursion)
             std::vector<uint8_t> cur_assign(n, 0), entered(n, 0), applied(n, 0);
             std::vector<uint32_t> next_t(n, 0);
@@ -2252,7 +2260,7 @@ struct StageRunner {
                 applied[level] = 1; keep_ws[level] = win_sum; keep_al[level] = aln_sum;
                 const double bound = V.aln_contrib * (aln_sum + l.lp + free_best) + V.depth_contrib * ws_new;
                 // a subtree is left out when it cannot beat the incumbent by more than the rounding of two long sums
-                if (bound > incumbent + 1e-12 * std::fabs(incumbent) + 1e-10) {
+                if (bound > incumbent + std::max(rel_gap, 1e-12) * std::fabs(incumbent) + 1e-10) {
                     win_sum = ws_new; aln_sum += l.lp; cur_assign[i] = static_cast<uint8_t>(t);
                     level++;
                 }
@@ -2527,7 +2535,7 @@ int32_t lcty_solver_default(lcty_solver* s, int32_t kind) {
         s->kind = kind; s->best_start = 1; s->sample_size = 10;
         s->plato_size = kind == LCTY_SOLVER_GREEDY ? 100 : 10000;
         s->node_limit = kind == LCTY_SOLVER_EXACT ? 20u * 1000u * 1000u : 0u;
-        s->anneal_steps = 20000; s->init_prob = 0.5;
+        s->anneal_steps = 20000; s->init_prob = kind == LCTY_SOLVER_EXACT ? 0.0 : 0.5;      // exact: the relative gap of the proof (0 = optimal)
     });
 }
 

@@ -7,8 +7,12 @@ from locityper_amd import _lib, api, synth, cdefs
 
 
 def main():
+    gap = 0.0
+    if "--gap" in sys.argv:
+        gap = float(sys.argv[sys.argv.index("--gap") + 1]); del sys.argv[sys.argv.index("--gap"):sys.argv.index("--gap") + 2]
     sizes = [int(a) for a in sys.argv[1:]] or [100, 300, 1000, 3000, 10000]
     ctx = api.Context(0)
+    ctx.set_knob("exact_trace", 1)
     for n in sizes:
         L = synth.SynthLocus(8, n, seed=synth.SEED + 3)
         p = api.resolve_params(api.default_params(), L.bg)
@@ -21,6 +25,7 @@ def main():
         g = api.solve_stage(aa, sub, api.default_solver(cdefs.SOLVER_GREEDY), 1, seeds)[2][:, 0]
         a = api.solve_stage(aa, sub, api.default_solver(cdefs.SOLVER_ANNEAL), 1, seeds)[2][:, 0]
         ex = api.default_solver(cdefs.SOLVER_EXACT)
+        ex.init_prob = gap
         for gi in range(len(sub)):
             t0 = time.perf_counter()
             try:

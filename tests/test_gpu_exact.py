@@ -58,6 +58,15 @@ def test_exact_on_larger_models_node_limit_and_assignment(gpu_ctx):
         # priors shift the likelihood as for every solver (solve.rs:827)
         pri = -np.arange(len(gts), dtype=np.float64)
         assert np.allclose(api.solve_stage(aa, gts, exact, 1, seeds, pri)[2], gl + pri[:, None], rtol=1e-13)
+    # with a relative gap (HiGHS' mip_rel_gap; lcty_solver.init_prob of this kind) the search stops as soon as nothing left can beat the
+    # incumbent by more than the gap: an answer where the proof of optimality runs out of nodes, never above the optimum, within the gap of it
+    assert exact.init_prob == 0.0
+    loose = api.default_solver(cdefs.SOLVER_EXACT)
+    loose.init_prob = 0.25
+    ll = api.solve_stage(aa, gts, loose, 1, seeds)[2]
+    assert np.all(np.isfinite(ll))
+    if gl is not None:
+        assert np.all(ll <= gl + 1e-9 * np.abs(gl)) and np.all(ll >= gl - 0.25 * np.abs(gl))
     # a node limit too small for a proof: Error::Solver, never an unproven answer
     tight = api.default_solver(cdefs.SOLVER_EXACT)
     tight.node_limit = 3
