@@ -2207,6 +2207,29 @@ struct StageRunner {
             // for this kind; 0 = a proof of optimality): subtrees that cannot beat the incumbent by more than it are left out.
             const double rel_gap = V.solver.init_prob > 0.0 && V.solver.init_prob < 1.0 ? V.solver.init_prob : 0.0;
             const double root_bound = V.aln_contrib * (aln_sum + free_best) + V.depth_contrib * win_sum;
+            if (ctx->knob("exact_trace", 0) == 2 && c == 0) {
+                // developer dump of the chain's model (scripts/exact_probe.py --dump): text, one item per line
+                FILE* f = fopen("gpurun_out/exact_model.txt", "w");
+                if (f) {
+                    fprintf(f, "%u %u %u %.17g %.17g %.17g\n", n, tw, ld, V.aln_contrib, V.depth_contrib, aln_fixed);
+                    for (uint32_t w = 0; w < tw; w++) fprintf(f, "W %lld %u %.17g %u\n", static_cast<long long>(base_depth[w]), cap[w], ww[w], static_cast<unsigned>(gcb[w]));
+                    for (uint32_t i = 0; i < n; i++) {
+                        fprintf(f, "R %u %u", static_cast<unsigned>(fixed[i]), first[i + 1] - first[i]);
+                        for (uint32_t t = first[i]; t < first[i + 1]; t++) fprintf(f, " %.17g %u %u", locs[t].lp, locs[t].wa, locs[t].wb);
+                        fprintf(f, "\n");
+                    }
+                    for (uint32_t g = 0; g < LCTY_GC_BINS; g++) {
+                        bool used = false;
+                        for (uint32_t w = 0; w < tw; w++) used |= ww[w] != 0.0 && gcb[w] == g;
+                        if (!used) continue;
+                        fprintf(f, "L %u", g);
+                        for (uint32_t d = 0; d < ld; d++) fprintf(f, " %.17g", lut[static_cast<size_t>(g) * ld + d]);
+                        fprintf(f, "\n");
+                    }
+                    fprintf(f, "I %.17g\n", incumbent);
+                    fclose(f);
+                }
+            }
             if (ctx->knob("exact_trace", 0))
                 fprintf(stderr, "[lcty exact] chain %u: %u non-trivial reads, %u free; incumbent %.6f, root bound %.6f (gap %.3e relative)\n", c, n, n_free,
                         incumbent, root_bound, (root_bound - incumbent) / std::fabs(incumbent));

@@ -10,9 +10,12 @@ def main():
     gap = 0.0
     if "--gap" in sys.argv:
         gap = float(sys.argv[sys.argv.index("--gap") + 1]); del sys.argv[sys.argv.index("--gap"):sys.argv.index("--gap") + 2]
+    dump = "--dump" in sys.argv
+    if dump:
+        sys.argv.remove("--dump")
     sizes = [int(a) for a in sys.argv[1:]] or [100, 300, 1000, 3000, 10000]
     ctx = api.Context(0)
-    ctx.set_knob("exact_trace", 1)
+    ctx.set_knob("exact_trace", 2 if dump else 1)
     for n in sizes:
         L = synth.SynthLocus(8, n, seed=synth.SEED + 3)
         p = api.resolve_params(api.default_params(), L.bg)
