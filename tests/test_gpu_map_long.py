@@ -242,3 +242,29 @@ def test_long_route_misuse_fails_loudly(gpu_ctx):
     for bad in ({"chain_back": 0}, {"chain_back": 70}, {"chain_gap": 0}, {"chain_gap": 10000}, {"chain_skew": 2000}, {"route": 7}, {"band": 20}):
         with pytest.raises(_lib.LocityperError):
             api.map_reads(loc, fq, api.map_params(long_reads=True, route=bad.pop("route", cdefs.MAP_ROUTE_LONG), **bad))
+
+
+def test_long_route_records_straight_into_the_batch(gpu_ctx):
+    """lcty_reads_map_append on the long route (records, CIGAR words and bases copied device to device, chunk after chunk) leaves the batch as
+    lcty_reads_append of the mapped chunks does: the same status, pair alignments and matrix after scoring."""
+    n_alleles, n_reads = 4, 64
+    L = synth.SynthLocus(n_alleles, n_reads, seed=synth.SEED + 8, technology=cdefs.TECH_NANOPORE, read_len=6_000, base_len=30_000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    fq = synth.sequencer_orientation(L.reads(0, n_reads, primaries_only=True))
+    mp = api.map_params(long_reads=True)
+    api.build_map_index(loc, [0, 2, 3], k=mp.k)
+    halves = [fq.slice(0, 24), fq.slice(24, n_reads)]
+    mapped = [api.map_reads(loc, h, mp) for h in halves]
+    assert all(int(m.recs["n_cigar"].max()) > 256 for m in mapped)            # long CIGARs: the records are not the short route's
+    via_host = api.AllAlignments.load(loc, mapped)
+    direct = api.AllAlignments(loc, n_reads, sum(h.n_bases for h in halves), sum(len(m.recs) for m in mapped), sum(len(m.cigar) for m in mapped))
+    for h in halves:
+        api.map_append(direct, h, mp)
+    direct.score()
+    assert direct.n_good() == via_host.n_good() > 0.8 * n_reads
+    for x, y in zip(direct.status(), via_host.status()):
+        assert np.array_equal(x, y)
+    o1, p1 = direct.pair_alns(); o2, p2 = via_host.pair_alns()
+    assert np.array_equal(o1, o2) and np.array_equal(p1, p2)
+    assert np.array_equal(direct.best_aln_matrix(), via_host.best_aln_matrix())
