@@ -915,10 +915,9 @@ def main():
 
             def empty_batch():
                 return api.AllAlignments(loco, nmap, (tot_bases + 2048) // 32 * 32, nmap * len(basis_l) * 2 + 1024, cap_cig)
-            am = empty_batch()                                                      # warm-up: code objects, the first allocations
-            api.map_append(am, fq[0], mpl)
-            am.close()
-            am = empty_batch()
+            am = empty_batch()                                                      # warm-up: code objects, and the buffers of the mapping, which stay
+            api.map_append(am, fq[0], mpl)                                          # with the batch (tens of GB: the first allocation after the solver
+            am.reset(loco)                                                          # workspaces were released takes seconds); then the batch empty again
             ctx.timing_reset()
             tm0 = time.perf_counter()
             for c in fq:
