@@ -2008,12 +2008,11 @@ struct StageRunner {
     // per-read arg-max. The optimum of that model IS the assignment of largest ReadAssignment::likelihood (assgn.rs:235-237).
     // Here the model is what solve_init_kernel has just built on the device for the chain (records = the columns of the reads
     // with their objective and windows after apply_tweak, the window arrays = the depth distributions); it is brought to the host
-    // and solved by branch and bound: depth-first over the non-trivial reads (largest spread of ln-probabilities first, a read's
-    // locations by descending ln-probability), starting from the best of a coordinate ascent, pruned by
-    //     aln_contrib * (fixed ln_prob + sum of the free reads' best) + depth_contrib * sum_w max_{d in [lo_w, lo_w + cap_w]} v_w(d)
-    // where lo_w is the depth the fixed reads give window w and cap_w what the free ones could add. `node_limit` nodes without
-    // a proof of optimality -> LCTY_ERR_SOLVER, as a non-optimal HiGHS status is (highs.rs:113-116). The assignment goes back
-    // into the chain's records, so per-read counts and BAM output see it like any other solver's.
+    // and solved by branch and bound: depth-first over the non-trivial reads (along the alleles; the location the bound's
+    // multipliers prefer first), starting from the best of a coordinate ascent, pruned by a Lagrangian bound over the window counts
+    // (stated where it is set up below: lo_w is the depth the placed reads give window w, cap_w what the free ones could add).
+    // `node_limit` nodes without a proof of optimality -> LCTY_ERR_SOLVER, as a non-optimal HiGHS status is (highs.rs:113-116).
+    // The assignment goes back into the chain's records, so per-read counts and BAM output see it like any other solver's.
     void solve_exact_batch(uint32_t nch) {
         hipStream_t s = stream;
         uint32_t ovf[2] = {0, 0};
