@@ -2272,9 +2272,9 @@ struct StageRunner {
             // for this kind; 0 = a proof of optimality): subtrees that cannot beat the incumbent by more than it are left out.
             const double rel_gap = V.solver.init_prob > 0.0 && V.solver.init_prob < 1.0 ? V.solver.init_prob : 0.0;
             const double root_bound = V.aln_contrib * aln_sum + free_best + win_sum;
-            if (ctx->knob("exact_trace", 0) == 2 && c == 0) {
-                // developer dump of the chain's model (scripts/exact_probe.py --dump): text, one item per line
-                FILE* f = fopen("gpurun_out/exact_model.txt", "w");
+            if (ctx->knob("exact_trace", 0) == 2 && c == 0 && getenv("LCTY_EXACT_DUMP")) {
+                // developer dump of the chain's model into the file the environment names (scripts/exact_probe.py --dump): text, one item per line
+                FILE* f = fopen(getenv("LCTY_EXACT_DUMP"), "w");
                 if (f) {
                     fprintf(f, "%u %u %u %.17g %.17g %.17g\n", n, tw, ld, V.aln_contrib, V.depth_contrib, aln_fixed);
                     for (uint32_t w = 0; w < tw; w++) fprintf(f, "W %lld %u %.17g %u\n", static_cast<long long>(base_depth[w]), cap[w], ww[w], static_cast<unsigned>(gcb[w]));

@@ -13,6 +13,8 @@ def main():
     dump = "--dump" in sys.argv
     if dump:
         sys.argv.remove("--dump")
+        os.makedirs("gpurun_out", exist_ok=True)
+        os.environ["LCTY_EXACT_DUMP"] = "gpurun_out/exact_model.txt"
     sizes = [int(a) for a in sys.argv[1:]] or [100, 300, 1000, 3000, 10000]
     ctx = api.Context(0)
     ctx.set_knob("exact_trace", 2 if dump else 1)
