@@ -83,7 +83,7 @@ def noisy_read(rng, haps, lo, hi):
     return (s.translate(comp)[::-1] if rng.integers(0, 2) else s).decode()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_long_route_on_random_inputs_equals_its_restatement(gpu_ctx, seed):
     """Random alleles some SNVs and indels of up to 60 bases apart; read ends of 20..900 bases from either strand with substitutions,
     indels and bases that are not ACGT, read ends shorter than a seed, foreign ones, absent second ends; random parameters (narrow
@@ -103,7 +103,7 @@ def test_long_route_on_random_inputs_equals_its_restatement(gpu_ctx, seed):
     basis = sorted(rng.choice(5, size=int(rng.integers(1, 6)), replace=False).tolist())
     mp = api.map_params(long_reads=True, route=cdefs.MAP_ROUTE_LONG, k=int(rng.integers(9, 20)), stride=int(rng.integers(3, 20)),
                         min_votes=int(rng.integers(1, 4)), min_score=int(rng.choice([-(1 << 31), 0, 60])), max_occ=int(rng.integers(0, 3)) * 7,
-                        band=int(rng.choice([2, 5, 16])), gap_open=int(rng.integers(2, 14)), gap_extend=int(rng.integers(0, 3)),
+                        band=int(rng.choice([2, 5, 16]) if seed <= 4 else rng.choice([0, 1, 3, 11])), gap_open=int(rng.integers(2, 14)), gap_extend=int(rng.integers(0, 3)),
                         mismatch=int(rng.integers(1, 9)), end_bonus=int(rng.integers(0, 12)),
                         chain_back=int(rng.choice([1, 3, 16, 64])), chain_gap=int(rng.choice([60, 300, 2000])), chain_skew=int(rng.choice([0, 20, 60])))
     api.build_map_index(loc, basis, k=mp.k)
