@@ -268,3 +268,20 @@ def test_long_route_records_straight_into_the_batch(gpu_ctx):
     o1, p1 = direct.pair_alns(); o2, p2 = via_host.pair_alns()
     assert np.array_equal(o1, o2) and np.array_equal(p1, p2)
     assert np.array_equal(direct.best_aln_matrix(), via_host.best_aln_matrix())
+
+
+@pytest.mark.parametrize("stride,skew", [(16, 500), (96, 500), (200, 40)])
+def test_kilobase_reads_equal_the_restatement(gpu_ctx, stride, skew):
+    """3-kb ONT reads (3 % errors) on three alleles against the restatement, record for record: with seeds 96 or 200 bases apart the pieces
+    between anchors are hundreds of rows long — direction bytes through the scratch of the wavefront, the walk back over several blocks,
+    the bases of a segment staged more than once — which the short random inputs above do not reach."""
+    L = synth.SynthLocus(3, 10, seed=synth.SEED + 21, technology=cdefs.TECH_NANOPORE, read_len=3_000, base_len=12_000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    fq = synth.sequencer_orientation(L.reads(0, 10, primaries_only=True))
+    mp = api.map_params(long_reads=True, stride=stride, chain_skew=skew, min_votes=2)
+    basis = [0, 1, 2]
+    api.build_map_index(loc, basis, k=mp.k)
+    got = api.map_reads(loc, fq, mp)
+    recs, cigar, cig_off = assert_equals_restatement(got, fq, L.seqs, L.seq_off, basis, mp, paired=False)
+    assert sum(1 for r in recs if not r[2] & cdefs.FLAG_UNMAPPED) >= 20 and max(r[3] for r in recs) > 100
