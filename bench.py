@@ -278,6 +278,16 @@ def spawn_ranks(args):
     sys.exit(0)
 
 
+def long_route_traffic(n_alignments):
+    """HBM bytes of the long route's align kernel for that many alignments of 10-kb reads, from the committed counter passes (None without the file)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_map_long_2048_ont_reads_x16.json")) as f:
+            t = json.load(f)["traffic"]["align_kernel_bytes_per_alignment"]
+        return (t["fetch_raw"] + t["write"]) * n_alignments
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_step, host_chunks):
     """The queue as `locityper genotype` meets it: every locus arrives from the host. D distinct loci — the loci of the main measurement first,
     so that with the default D = 2 the two queues do the same work — (their counted alignment tables
@@ -945,7 +955,8 @@ def main():
                 "prefilter_best_is_truth": bool(tuple(int(x) for x in gts[int(np.argmax(sc_m))]) == tuple(Lo.true_genotype)),
                 "truth_scores_as_the_best": bool(max(float(sc_m[i]) for i, g in enumerate(gts) if tuple(int(x) for x in g) == tuple(Lo.true_genotype)) >= float(sc_m.max()) - 1e-9 * abs(float(sc_m.max()))),
                 "roofline": {"bound": "hbm", "kernel": "map_long_align_kernel", "achieved": per_aln * n_mapped / (ms_map * 1e-3) / 1e9 if ms_map else None,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_aln * n_mapped / (ms_map * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_map else None, "traffic": None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_aln * n_mapped / (ms_map * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_map else None,
+                             "traffic": long_route_traffic(n_mapped), "traffic_source": "profiles/r03_pmc_map_long_2048_ont_reads_x16.json (FETCH_SIZE raw + WRITE_SIZE per alignment of the align kernel, 10-kb reads)",
                              "algorithmic_bytes_per_alignment": per_aln,
                              "what": "read bases (2 bit) + allele bases under the read + CIGAR words out, per alignment; the kernel is bound by instruction issue "
                                      "(a row of the band per ~150 instructions of one wavefront), not by these bytes: DESIGN.md section 5"}}
