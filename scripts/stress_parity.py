@@ -1,5 +1,5 @@
 """Developer stress run: the parity checks of tests/ over many random shapes and seeds (scoring, prefilter + both truncates, solver
-stages on injected tables, candidate generation against its restatement). Prints one line per case; exits non-zero at the first mismatch."""
+stages on injected tables, candidate generation — both routes — against its restatements). Prints one line per case; exits non-zero at the first mismatch."""
 import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,6 +7,7 @@ from locityper_amd import api, cdefs, synth
 from tests import oracle_ffi as O
 from tests.helpers import compare_gpu_to_oracle
 from tests.test_gpu_map import test_mapper_on_random_inputs_equals_its_restatement as mapper_case
+from tests.test_gpu_map_long import test_long_route_on_random_inputs_equals_its_restatement as long_mapper_case
 
 
 def one_case(ctx, rng, i):
@@ -118,6 +119,13 @@ def main():
         except Exception:
             print(f"mapper seed {seed}: FAILED", flush=True); traceback.print_exc(); sys.exit(1)
     print(f"mapper: {n} random inputs ok  [{time.time() - t0:.0f} s]", flush=True)
+    base = int(sys.argv[2]) * 1000 if len(sys.argv) > 2 else 100
+    for seed in range(base, base + n):
+        try:
+            long_mapper_case(ctx, seed)
+        except Exception:
+            print(f"long-route mapper seed {seed}: FAILED", flush=True); traceback.print_exc(); sys.exit(1)
+    print(f"long-route mapper: {n} random inputs ok  [{time.time() - t0:.0f} s]", flush=True)
     print("all ok")
 
 main()
