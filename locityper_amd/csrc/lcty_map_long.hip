@@ -335,6 +335,33 @@ __device__ SegOut wave_segment(const LongView& V, const Seqs& S, const uint32_t 
             return SegOut{static_cast<int32_t>((n - h) * V.match) - static_cast<int32_t>(h * V.mismatch), 0u, m};
         }
     }
+    if (!free_start && !free_end && n != m && V.gap_open > V.gap_extend) {
+        // A piece whose two sides differ by one gap only — the shorter side equals the longer one with |d| bases taken out: a common
+        // prefix of p bases (on the corner's diagonal) and a common suffix of x bases (on the other corner's) with p + x >= the shorter
+        // length. "prefix, one gap of |d|, suffix" then scores (shorter length) x match - (gap_open + (|d| - 1) gap_extend), which no
+        // alignment of the two sides can beat; of the places the gap can take, the rows below leave it at the leftmost (their walk back
+        // prefers the base step, which stays optimal as long as a place to its left is left) — opened once and extended, since opening
+        // costs more than extending. Written straight away.
+        const uint32_t lo = n < m ? n : m;
+        uint32_t pre = lo, suf = lo;
+        for (uint32_t c0 = 0; c0 < lo; c0 += 64) {
+            const uint32_t x = c0 + lane;
+            const unsigned long long bad = __ballot(x < lo && !S.eq(q0 + x, t0 + x));
+            if (bad) { pre = c0 + static_cast<uint32_t>(__ffsll(static_cast<long long>(bad))) - 1u; break; }
+        }
+        for (uint32_t c0 = 0; c0 < lo; c0 += 64) {
+            const uint32_t x = c0 + lane;
+            const unsigned long long bad = __ballot(x < lo && !S.eq(q0 + n - 1 - x, t0 + m - 1 - x));
+            if (bad) { suf = c0 + static_cast<uint32_t>(__ffsll(static_cast<long long>(bad))) - 1u; break; }
+        }
+        if (lo - suf <= pre) {
+            const uint32_t at = lo - suf, gap = n < m ? m - n : n - m;
+            C.put(7u, lo - at);
+            C.put(n < m ? 2u : 1u, gap);
+            C.put(7u, at);
+            return SegOut{static_cast<int32_t>(lo) * V.match - (V.gap_open + static_cast<int32_t>(gap - 1) * V.gap_extend), 0u, m};
+        }
+    }
     for (uint32_t kk = lane; kk < W; kk += 64) { C.hrow[kk] = LNEG; C.frow[kk] = LNEG; }
     // the direction bytes of a short segment stay in LDS (most pieces: a few dozen rows), those of a long one go through the scratch
     const bool small = (static_cast<uint64_t>(n) + 1) * W <= C.tb_bytes;
