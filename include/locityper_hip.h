@@ -548,8 +548,8 @@ int32_t lcty_map_reads(lcty_locus* locus, const lcty_reads_host* chunk, const lc
                        uint32_t* bases2_out, uint32_t* nmask_out);
 /* The same with the records going straight into a batch of the locus (as lcty_reads_append of the mapped chunk would put them):
  * records, CIGAR words and re-oriented bases are copied device to device, only the offsets visit the host. The device buffers of the
- * mapping (arenas and kernel scratch: tens of GB for long reads on many alleles) stay with the batch from chunk to chunk and are
- * released by lcty_score_reads (or with the batch). */
+ * mapping (arenas and kernel scratch: tens of GB for long reads on many alleles) stay with the context from chunk to chunk; the solver
+ * stages release them before they size their workspace, and so does lcty_ctx_trim. One mapping call at a time per context. */
 int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, const lcty_map_params* params);
 
 /* ---- solver stages (src/solvers/solve.rs:789-850, src/solvers/stoch.rs, src/model/assgn.rs) ----------------

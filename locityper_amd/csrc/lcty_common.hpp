@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <condition_variable>
 #include <mutex>
 #include <stdexcept>
@@ -196,9 +197,15 @@ struct lcty_ctx {
     // releases it.
     lcty::DevBuf<uint8_t> transfer_scratch;
     lcty::DevBuf<uint8_t> transfer_recs; lcty::DevBuf<uint32_t> transfer_words;      // arenas of the transferred alignments (records as bytes: lcty_aln_rec is declared later)
+    // Device buffers of candidate generation (lcty_map.hip: arenas of CIGAR words and chains, kernel scratch — tens of GB for long reads on
+    // many alleles), kept from chunk to chunk of a streaming loop { lcty_reads_map_append; lcty_score_reads } and released with the lane
+    // scratch above: before the solver stages size their workspace, and by lcty_ctx_trim.
+    std::shared_ptr<void> map_scratch;
+    std::mutex map_mutex;             // one lcty_reads_map_append at a time per context: its buffers are the context's
     std::mutex scratch_mutex;
     void release_transfer_scratch() {
         std::lock_guard<std::mutex> g(scratch_mutex);
+        map_scratch.reset();
         if (transfer_scratch.n) transfer_scratch.release();
         if (transfer_recs.n) transfer_recs.release();
         if (transfer_words.n) transfer_words.release();

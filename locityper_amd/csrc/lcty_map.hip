@@ -719,10 +719,15 @@ int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, c
         const auto t_in = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
         // the device buffers of the mapping (arenas of CIGAR words and chains, scratch of the kernels: tens of GB for long reads on many
-        // alleles) stay with the batch from its first chunk until it is scored (lcty_score_reads releases them): a streaming loop
-        // does not allocate and release them per chunk
-        auto held = std::static_pointer_cast<MapRun>(reads->map_scratch);
-        if (!held) { held = std::make_shared<MapRun>(); reads->map_scratch = held; }
+        // alleles) stay with the context from chunk to chunk — a streaming loop does not allocate and release them per chunk — until the
+        // solver stages take the memory back (lcty_ctx::release_transfer_scratch) or lcty_ctx_trim is called
+        std::lock_guard<std::mutex> one_at_a_time(reads->ctx->map_mutex);
+        std::shared_ptr<MapRun> held;
+        {
+            std::lock_guard<std::mutex> lock(reads->ctx->scratch_mutex);
+            held = std::static_pointer_cast<MapRun>(reads->ctx->map_scratch);
+            if (!held) { held = std::make_shared<MapRun>(); reads->ctx->map_scratch = held; }
+        }
         MapRun& X = *held;
         std::vector<uint64_t> aln_off(n + 1), cigar_off(n + 1);
         run_map(reads->locus, chunk, params, aln_off.data(), cigar_off.data(), false, X);

@@ -113,7 +113,6 @@ struct lcty_reads {
     lcty::DevBuf<uint64_t> d_pa_off;
     lcty::DevBuf<uint32_t> d_pa_cnt;
     lcty::DevBuf<uint32_t> d_pa_idx;         // [R][A]
-    std::shared_ptr<void> map_scratch;       // device buffers of lcty_reads_map_append, kept from chunk to chunk (lcty_map.hip); released by lcty_score_reads
     // solver stages: compact list of GOOD pairs (AllAlignments::reads order), built lazily after scoring
     lcty::DevBuf<uint32_t> d_good_ix;
     uint64_t n_good_cached = 0;

@@ -395,7 +395,6 @@ int32_t lcty_score_reads(lcty_reads* reads) {
     return guarded([&] {
         if (!reads) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         reads->ctx->activate();
-        reads->map_scratch.reset();                                            // what lcty_reads_map_append kept between its chunks
         if (reads->n_pairs > reads->raw_first) launch_score_reads(reads);      // streaming: the chunk on the device
         reads->scored = true;
         reads->good_valid = false; reads->loc_table_valid = false;
