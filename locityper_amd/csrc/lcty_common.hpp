@@ -89,6 +89,9 @@ struct DevBuf {
     void ensure(size_t count) {                      // grow-only: a workspace that survives the call
         if (n < count) alloc(count);
     }
+    void ensure_slack(size_t count) {                // the same with a quarter of head-room: what comes next is about as large, seldom larger
+        if (n < count) alloc(count + count / 4 + 64);
+    }
     void upload(const T* host, size_t count, hipStream_t s, size_t dst_off = 0) {
         if (dst_off + count > n) fail(LCTY_ERR_RUNTIME, "device buffer overflow (%zu + %zu > %zu)", dst_off, count, n);
         if (count) LCTY_HIP(hipMemcpyAsync(p + dst_off, host, count * sizeof(T), hipMemcpyHostToDevice, s));

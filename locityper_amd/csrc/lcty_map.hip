@@ -606,11 +606,11 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
                 fail(LCTY_ERR_UNSUPPORTED, "more than 64 seeds per read end: raise the stride");
         }
     }
-    X.d_len.ensure(n_mates); X.d_len.upload(chunk->mate_len, n_mates, s);
-    X.d_off.ensure(n_mates + 1); X.d_off.upload(chunk->mate_off, n_mates + 1, s);
-    X.d_b2.ensure(std::max<uint64_t>(nb / 16, 1)); X.d_b2.upload(chunk->bases2, nb / 16, s);
-    X.d_nm.ensure(std::max<uint64_t>(nb / 32, 1)); X.d_nm.upload(chunk->nmask, nb / 32, s);
-    X.d_nrec.ensure(n_mates); X.d_ncig.ensure(n_mates);
+    X.d_len.ensure_slack(n_mates); X.d_len.upload(chunk->mate_len, n_mates, s);
+    X.d_off.ensure_slack(n_mates + 1); X.d_off.upload(chunk->mate_off, n_mates + 1, s);
+    X.d_b2.ensure_slack(std::max<uint64_t>(nb / 16, 1)); X.d_b2.upload(chunk->bases2, nb / 16, s);
+    X.d_nm.ensure_slack(std::max<uint64_t>(nb / 32, 1)); X.d_nm.upload(chunk->nmask, nb / 32, s);
+    X.d_nrec.ensure_slack(n_mates); X.d_ncig.ensure_slack(n_mates);
     if (long_route) {
         run_map_long(locus, chunk, params, *ix, max_len, aln_off, cigar_off, sizes_only, X);
         return;
@@ -630,8 +630,8 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
     // kernel 1: the candidates that stay, and the list of those to be aligned with gaps
     V.slots = std::min<uint32_t>(64, 2 * ix->n_basis);
     if (n_mates * V.slots > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "chunks of up to %llu read pairs with this basis", (unsigned long long)(0xFFFFFFFFull / V.slots / 2));
-    X.d_cands.ensure(n_mates * V.slots * sizeof(MapCand)); X.d_nhave.ensure(n_mates); X.d_work.ensure(n_mates * V.slots);
-    X.d_counters.ensure(4); X.d_counters.zero(s);
+    X.d_cands.ensure_slack(n_mates * V.slots * sizeof(MapCand)); X.d_nhave.ensure_slack(n_mates); X.d_work.ensure_slack(n_mates * V.slots);
+    X.d_counters.ensure_slack(4); X.d_counters.zero(s);
     V.cands = reinterpret_cast<MapCand*>(X.d_cands.p); V.n_have = X.d_nhave.p; V.work = X.d_work.p; V.counters = X.d_counters.p;
     ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_seed_kernel, dim3(n_wg), dim3(64), 0, s, V); }, s);
     LCTY_HIP(hipGetLastError());
@@ -648,7 +648,7 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
         uint64_t cap = 6ull * V.n_work + 1024;
         for (;;) {
             if (cap > 0xFFFFFFF0ull) fail(LCTY_ERR_UNSUPPORTED, "CIGAR words of the alignments with gaps: map the chunk in parts");
-            X.d_ops.ensure(cap);
+            X.d_ops.ensure_slack(cap);
             V.ops = X.d_ops.p; V.ops_cap = static_cast<uint32_t>(cap);
             ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_gap_kernel, dim3(n_wg2), dim3(64), 0, s, V); }, s);
             LCTY_HIP(hipGetLastError());
@@ -677,11 +677,11 @@ void run_map(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_map_par
     }
     X.n_recs = r; X.n_cigar = c;
     if (sizes_only) return;
-    X.d_rec_at.ensure(n_mates); X.d_rec_at.upload(rec_at.data(), n_mates, s);
-    X.d_cig_at.ensure(n_mates); X.d_cig_at.upload(cig_at.data(), n_mates, s);
-    X.d_pair_cig.ensure(n); X.d_pair_cig.upload(pair_cig.data(), n, s);
-    X.d_recs.ensure(std::max<uint64_t>(r, 1)); X.d_cigar.ensure(std::max<uint64_t>(c, 1));
-    X.d_ob2.ensure(std::max<uint64_t>(nb / 16, 1)); X.d_onm.ensure(std::max<uint64_t>(nb / 32, 1));
+    X.d_rec_at.ensure_slack(n_mates); X.d_rec_at.upload(rec_at.data(), n_mates, s);
+    X.d_cig_at.ensure_slack(n_mates); X.d_cig_at.upload(cig_at.data(), n_mates, s);
+    X.d_pair_cig.ensure_slack(n); X.d_pair_cig.upload(pair_cig.data(), n, s);
+    X.d_recs.ensure_slack(std::max<uint64_t>(r, 1)); X.d_cigar.ensure_slack(std::max<uint64_t>(c, 1));
+    X.d_ob2.ensure_slack(std::max<uint64_t>(nb / 16, 1)); X.d_onm.ensure_slack(std::max<uint64_t>(nb / 32, 1));
     X.d_ob2.zero(s); X.d_onm.zero(s);
     V.rec_at = X.d_rec_at.p; V.cig_at = X.d_cig_at.p; V.pair_cig = X.d_pair_cig.p; V.recs = X.d_recs.p; V.cigar = X.d_cigar.p;
     V.out_bases2 = X.d_ob2.p; V.out_nmask = X.d_onm.p;

@@ -767,8 +767,8 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
     size_t free_b = 0, total_b = 0;
     V.slots = n_groups;
     if (n_mates * V.slots > 0xFFFFFFFFull) fail(LCTY_ERR_UNSUPPORTED, "chunks of up to %llu read pairs with this basis", (unsigned long long)(0xFFFFFFFFull / V.slots / 2));
-    X.d_cands.ensure(n_mates * V.slots * sizeof(LongCand)); X.d_nhave.ensure(n_mates);
-    X.d_counters.ensure(8);
+    X.d_cands.ensure_slack(n_mates * V.slots * sizeof(LongCand)); X.d_nhave.ensure_slack(n_mates);
+    X.d_counters.ensure_slack(8);
     V.cands = reinterpret_cast<LongCand*>(X.d_cands.p); V.n_have = X.d_nhave.p; V.counters = X.d_counters.p;
     uint32_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // ---- kernel 1: the chains. Scratch of a workgroup: the anchors of every group; it leaves the chains to be aligned (repeated with
@@ -781,9 +781,9 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
         if (per_wg > free_b / 2) fail(LCTY_ERR_RUNTIME, "the long route needs %llu MB of scratch per workgroup", (unsigned long long)(per_wg >> 20));
         const uint64_t budget = std::min<uint64_t>(free_b / 4, 16ull << 30);
         const uint32_t n_wg = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(n_mates, 8ull * cus), std::max<uint64_t>(budget / per_wg, 1)));
-        X.d_anchors.ensure(static_cast<size_t>(n_wg) * n_groups * V.cap_g);
+        X.d_anchors.ensure_slack(static_cast<size_t>(n_wg) * n_groups * V.cap_g);
         V.anchors = X.d_anchors.p;
-        X.d_work.ensure(n_mates * V.slots * (sizeof(LongWork) / sizeof(uint32_t)));
+        X.d_work.ensure_slack(n_mates * V.slots * (sizeof(LongWork) / sizeof(uint32_t)));
         V.work = reinterpret_cast<LongWork*>(X.d_work.p);
         uint64_t seeds_total = 0;
         for (uint64_t m = 0; m < n_mates; m++)
@@ -794,7 +794,7 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
         uint64_t cap = std::min<uint64_t>(0xFFFFFFF0ull, std::min<uint64_t>(free_b / 64, seeds_total * ix.n_basis / 2) + 4096);
         for (;;) {
             X.d_counters.zero(s);
-            X.d_chain.ensure(cap);
+            X.d_chain.ensure_slack(cap);
             V.chain = X.d_chain.p; V.chain_cap = static_cast<uint32_t>(cap);
             ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_chain_kernel, dim3(n_wg), dim3(64), 0, s, V); }, s);
             LCTY_HIP(hipGetLastError());
@@ -822,8 +822,8 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
         const uint64_t budget = std::min<uint64_t>(free_b / 4, 16ull << 30);
         const uint32_t lds = 2 * V.wmax * 4 + V.tb_bytes + (V.wmax + 64) + 64;
         const uint32_t n_waves = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint64_t>(V.n_work, 24ull * cus), std::max<uint64_t>(budget / per_wave, 1)));
-        X.d_dirs.ensure(static_cast<size_t>(n_waves) * V.dirs_bytes);
-        X.d_opsbuf.ensure(static_cast<size_t>(n_waves) * V.ops_wave);
+        X.d_dirs.ensure_slack(static_cast<size_t>(n_waves) * V.dirs_bytes);
+        X.d_opsbuf.ensure_slack(static_cast<size_t>(n_waves) * V.ops_wave);
         V.dirs = X.d_dirs.p; V.opsbuf = X.d_opsbuf.p;
         // room for the words of a chunk of noisy reads (a word per ~4 bases of every alignment), as far as the memory goes; the kernel
         // says how many it needed when that was not enough
@@ -834,7 +834,7 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
         for (;;) {
             const uint32_t zero = 0;
             X.d_counters.upload(&zero, 1, s, 1); X.d_counters.upload(&zero, 1, s, 4);
-            X.d_ops.ensure(cap);
+            X.d_ops.ensure_slack(cap);
             V.ops = X.d_ops.p; V.ops_cap = static_cast<uint32_t>(cap);
             ctx->timed(LCTY_K_MAP, [&] { hipLaunchKernelGGL(map_long_align_kernel, dim3(n_waves), dim3(64), lds, s, V); }, s);
             LCTY_HIP(hipGetLastError());
@@ -846,7 +846,7 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
         }
         mark("alignments done");
     } else {
-        X.d_ops.ensure(1);
+        X.d_ops.ensure_slack(1);
         V.ops = X.d_ops.p; V.ops_cap = 1;
     }
     // ---- kernel 3, sizes
@@ -868,11 +868,11 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
     }
     X.n_recs = r; X.n_cigar = c;
     if (sizes_only) return;
-    X.d_rec_at.ensure(n_mates); X.d_rec_at.upload(rec_at.data(), n_mates, s);
-    X.d_cig_at.ensure(n_mates); X.d_cig_at.upload(cig_at.data(), n_mates, s);
-    X.d_pair_cig.ensure(n); X.d_pair_cig.upload(pair_cig.data(), n, s);
-    X.d_recs.ensure(std::max<uint64_t>(r, 1)); X.d_cigar.ensure(std::max<uint64_t>(c, 1));
-    X.d_ob2.ensure(std::max<uint64_t>(nb / 16, 1)); X.d_onm.ensure(std::max<uint64_t>(nb / 32, 1));
+    X.d_rec_at.ensure_slack(n_mates); X.d_rec_at.upload(rec_at.data(), n_mates, s);
+    X.d_cig_at.ensure_slack(n_mates); X.d_cig_at.upload(cig_at.data(), n_mates, s);
+    X.d_pair_cig.ensure_slack(n); X.d_pair_cig.upload(pair_cig.data(), n, s);
+    X.d_recs.ensure_slack(std::max<uint64_t>(r, 1)); X.d_cigar.ensure_slack(std::max<uint64_t>(c, 1));
+    X.d_ob2.ensure_slack(std::max<uint64_t>(nb / 16, 1)); X.d_onm.ensure_slack(std::max<uint64_t>(nb / 32, 1));
     X.d_ob2.zero(s); X.d_onm.zero(s);
     V.rec_at = X.d_rec_at.p; V.cig_at = X.d_cig_at.p; V.pair_cig = X.d_pair_cig.p; V.recs = X.d_recs.p; V.cigar = X.d_cigar.p;
     V.out_bases2 = X.d_ob2.p; V.out_nmask = X.d_onm.p;
