@@ -2143,12 +2143,12 @@ struct StageRunner {
             for (uint32_t i : order) { const uint32_t w = place_of(i); key[i] = w == 0xFFFFFFFFu ? 0u : along(w); }
             auto spread = [&](uint32_t i) { return locs[first[i]].lp - locs[first[i + 1] - 1].lp; };
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : spread(a) > spread(b); });
-            const uint32_t n_free = static_cast<uint32_t>(order.size());
+            uint32_t n_free = static_cast<uint32_t>(order.size());
             // incumbent: coordinate ascent from the best start (every read at its location 0)
             std::vector<uint8_t> assign(n, 0), best_assign;
             std::vector<int64_t> dep(lo);
             for (uint32_t i : order) { dep[locs[first[i]].wa]++; dep[locs[first[i]].wb]++; }
-            const std::vector<int64_t> base_depth(lo);                        // `lo` moves with the search; a leaf is valued from here
+            std::vector<int64_t> base_depth(lo);                              // `lo` moves with the search; a leaf is valued from here
             auto total = [&](const std::vector<uint8_t>& a, double* depth_lik, double* aln_lik) {
                 std::vector<int64_t> d(base_depth);
                 double al = aln_fixed;
@@ -2215,9 +2215,13 @@ struct StageRunner {
                 }
                 return m;
             };
-            if (n_free > 12) {
+            // ... and reads are fixed by their reduced costs: with the bound UB at the multipliers found, a solution that has read i at location t
+            // scores at most UB - (the read's best term - its term at t); when that is below the incumbent for every location but the
+            // incumbent's own, the read stays there in every better solution. Fixed reads make the windows' ranges narrower, the bound
+            // tighter, and the next round fixes more: at 10 000 read pairs all but a few hundred of the 7 800 free reads.
+            for (uint32_t round = 0; round < 12 && n_free > 12; round++) {
                 std::vector<double> best_lam(lam), g(tw), cnt(tw);
-                std::vector<uint8_t> pick(n, 0);
+                std::vector<uint8_t> pick(best_assign);
                 double best_ub = INFINITY, theta = 1.0; uint32_t stall = 0;
                 const uint32_t iters = static_cast<uint32_t>(std::min<uint64_t>(3000, 400 + n_free / 2));
                 for (uint32_t it = 0; it < iters; it++) {
@@ -2258,6 +2262,34 @@ struct StageRunner {
                     for (uint32_t w = 0; w < tw; w++) lam[w] -= step * g[w];
                 }
                 lam = best_lam;
+                // reduced-cost fixing at these multipliers
+                double ub = V.aln_contrib * aln_fixed;
+                std::vector<double> rbest(n, 0.0);
+                for (uint32_t i : order) { rbest[i] = rterm(i, nullptr); ub += rbest[i]; }
+                for (uint32_t w = 0; w < tw; w++) ub += wterm(w);
+                const double floor_val = incumbent - (1e-9 * std::fabs(incumbent) + 1e-9);
+                std::vector<uint32_t> still;
+                uint32_t newly = 0;
+                for (uint32_t i : order) {
+                    const uint32_t b = best_assign[i];
+                    bool only = true;
+                    for (uint32_t t = first[i]; t < first[i + 1] && only; t++) {
+                        if (t - first[i] == b) continue;
+                        const double x = V.aln_contrib * locs[t].lp + lam[locs[t].wa] + lam[locs[t].wb];
+                        if (!(ub - (rbest[i] - x) < floor_val)) only = false;
+                    }
+                    if (!only) { still.push_back(i); continue; }
+                    const Loc& l = locs[first[i] + b];
+                    fixed[i] = 2; newly++;
+                    for (auto& x : touch[i]) cap[x.first] -= x.second;
+                    lo[l.wa]++; lo[l.wb]++; base_depth[l.wa]++; base_depth[l.wb]++;
+                    aln_fixed += l.lp;
+                }
+                order.swap(still);
+                n_free = static_cast<uint32_t>(order.size());
+                if (ctx->knob("exact_trace", 0))
+                    fprintf(stderr, "[lcty exact] chain %u round %u: bound %.6f, incumbent %.6f, %u reads fixed by reduced costs, %u free\n", c, round, ub, incumbent, newly, n_free);
+                if (newly == 0) break;
             }
             std::vector<double> rmax(n, 0.0);
             std::vector<uint8_t> first_try(n, 0);                              // the location the multipliers prefer is explored first
@@ -2299,7 +2331,7 @@ struct StageRunner {
                 fprintf(stderr, "[lcty exact] chain %u: %u non-trivial reads, %u free; incumbent %.6f, root bound %.6f (gap %.3e relative)\n", c, n, n_free,
                         incumbent, root_bound, (root_bound - incumbent) / std::fabs(incumbent));
             // depth-first, iterative (a locus can have many thousands of non-trivial reads: no recursion)
-            std::vector<uint8_t> cur_assign(n, 0), entered(n, 0), applied(n, 0);
+            std::vector<uint8_t> cur_assign(best_assign), entered(n, 0), applied(n, 0);      // the reads fixed above keep their locations
             std::vector<uint32_t> next_t(n, 0);
             std::vector<double> keep_ws(n), keep_al(n);
             std::vector<std::vector<std::pair<uint32_t, double>>> saved(n);
