@@ -31,12 +31,15 @@
 // Three kernels. map_long_chain_kernel, one wavefront per read end: lane = seed (index lookups), then lane = place of a seed (the
 // chains of all groups grow side by side in a scratch of the workgroup; two places of one group in a batch take turns in index
 // order), then lane = candidate: the chain of every group to be aligned is written out, last anchor first, with a work item.
-// map_long_align_kernel, one wavefront per work item: lane = diagonal of the band. A row of nodes is computed at once — the base step
-// and the insertion come from the row above (LDS), the deletions of the row are a prefix maximum over the lanes (a gap never opens
-// from a deletion at a gain when gap_open >= gap_extend, which the long route asks for, so the openers are the nodes' other two
-// states) — five direction bits per node go to a scratch of the wavefront, the walk back reads them in blocks through LDS and leaves
-// the CIGAR runs right to left in scratch; they are copied into the arena at the end. map_long_emit_kernel<WRITE>, one wavefront per
-// read end, runs twice: sizes, then records (host prefix sums in between).
+// map_long_align_kernel, one wavefront per work item (taken from a cursor): lane = diagonal of the band. A row of nodes is computed
+// at once — the base step and the insertion come from the row above (registers and a DPP shift for bands of up to 64 diagonals, two LDS
+// rows in chunks of 64 lanes beyond), the deletions of the row are a prefix maximum over the lanes (a gap never opens from a deletion
+// at a gain when gap_open >= gap_extend, which the long route asks for, so the openers are the nodes' other two states) — five
+// direction bits per node stay in LDS (short segments) or go to a scratch of the wavefront, the walk back reads them in blocks through
+// LDS, takes runs of equal base steps at once, and leaves the CIGAR runs right to left in scratch; they are copied into the arena at
+// the end. Two kinds of piece never reach the rows: equal lengths with so few mismatches that the diagonal provably beats any gap, and
+// sides that differ by one gap only. map_long_emit_kernel<WRITE>, one wavefront per read end, runs twice: sizes, then records (host
+// prefix sums in between).
 #include <algorithm>
 #include <chrono>
 
