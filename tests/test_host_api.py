@@ -231,3 +231,19 @@ def test_truncate_keeps_at_least_threads_genotypes():
 def test_knobs_are_named_and_checked():
     L = _lib.lib()
     assert L.lcty_ctx_set_knob(None, b"solve_budget_mb", 1) == cdefs.ERR_INVALID_INPUT
+
+
+def test_mapper_and_solver_defaults():
+    """lcty_map_params_default / _default_long (host only): strobealign's and minimap2's scores, the long route's chaining limits; the struct is
+    the header's (15 four-byte fields). lcty_solver_default for the exact solver: a proof of optimality unless a gap is asked for."""
+    assert C.sizeof(cdefs.MapParams) == 15 * 4
+    short, long_ = api.map_params(), api.map_params(long_reads=True)
+    assert (short.k, short.stride, short.match, short.mismatch, short.gap_open, short.gap_extend, short.min_score, short.band) == (15, 5, 2, 8, 12, 1, 50, 16)
+    assert (long_.k, long_.stride, long_.match, long_.mismatch, long_.gap_open, long_.gap_extend, long_.min_votes) == (15, 16, 2, 4, 6, 2, 3)
+    assert long_.min_score == -(1 << 31) and long_.gap_open > long_.gap_extend
+    for mp in (short, long_):
+        assert (mp.route, mp.chain_gap, mp.chain_skew, mp.chain_back) == (cdefs.MAP_ROUTE_AUTO, 2000, 500, 32)
+    assert _lib.lib().lcty_map_params_default_long(None) == cdefs.ERR_INVALID_INPUT
+    ex = api.default_solver(cdefs.SOLVER_EXACT)
+    assert ex.kind == cdefs.SOLVER_EXACT and ex.init_prob == 0.0 and ex.node_limit == 20_000_000
+    assert api.default_solver(cdefs.SOLVER_ANNEAL).init_prob == 0.5
