@@ -2215,9 +2215,9 @@ struct StageRunner {
                 }
                 return m;
             };
-            // ... and reads are fixed by their reduced costs: with the bound UB at the multipliers found, a solution that has read i at location t
-            // scores at most UB - (the read's best term - its term at t); when that is below the incumbent for every location but the
-            // incumbent's own, the read stays there in every better solution. Fixed reads make the windows' ranges narrower, the bound
+            // ... and reads are fixed by probing: with the bound UB at the multipliers found, a solution that has read i at location t scores at
+            // most UB - (the read's best term) + (the bound's terms with the read placed at t); when that is below the incumbent for every
+            // location but the incumbent's own, the read stays there in every better solution. Fixed reads make the windows' ranges narrower, the bound
             // tighter, and the next round fixes more: at 10 000 read pairs all but a few hundred of the 7 800 free reads.
             for (uint32_t round = 0; round < 12 && n_free > 12; round++) {
                 std::vector<double> best_lam(lam), g(tw), cnt(tw);
@@ -2275,8 +2275,19 @@ struct StageRunner {
                     bool only = true;
                     for (uint32_t t = first[i]; t < first[i + 1] && only; t++) {
                         if (t - first[i] == b) continue;
-                        const double x = V.aln_contrib * locs[t].lp + lam[locs[t].wa] + lam[locs[t].wb];
-                        if (!(ub - (rbest[i] - x) < floor_val)) only = false;
+                        // the bound with the read AT t (what the search computes one level down): its ln-probability, and the windows it can
+                        // touch with the read counted where t puts it and no longer among what the free reads could add — never above
+                        // the reduced-cost form "the read's term at t" (a window's term falls by at least lam x what the read adds)
+                        double x = V.aln_contrib * locs[t].lp;
+                        for (auto& tw_ : touch[i]) {
+                            const uint32_t w = tw_.first;
+                            if (ww[w] == 0.0) continue;
+                            const int64_t add = static_cast<int64_t>(mult(locs[t], w)), room = static_cast<int64_t>(cap[w]) - tw_.second;
+                            double m = -INFINITY; const double lw = lam[w];
+                            for (int64_t k = 0; k <= room; k++) m = std::max(m, V.depth_contrib * v(w, lo[w] + add + k) - lw * static_cast<double>(k));
+                            x += m - wterm(w);
+                        }
+                        if (!(ub - rbest[i] + x < floor_val)) only = false;
                     }
                     if (!only) { still.push_back(i); continue; }
                     const Loc& l = locs[first[i] + b];
