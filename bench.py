@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--alleles", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
     ap.add_argument("--knob", action="append", default=[], help="developer experiments: name=value for lcty_ctx_set_knob (repeatable)")
-    ap.add_argument("--cpu-sample", type=int, default=16384, help="pairs given to the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="pairs given to the CPU baseline (0 = skip)")
     ap.add_argument("--ont-sample", type=int, default=6144,
                     help="reads of the extra long-read measurement (BASELINE.json configs[2] shape: 10 kb ONT reads x the locus' alleles, "
                          "the mapper reports the primaries, the other alleles are reached by alignment recovery); 0 = skip")
@@ -137,34 +137,50 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
     """The reference's CPU path beside the GPU number: the oracle — a C restatement of the reference algorithms —
     with the reference's own thread structure, at threads = 8 (the reference default, genotype.rs:127) and at all physical cores:
       load     AllAlignments::load: single-threaded BAM loop + recover_and_group_alignments on `threads` workers, reads dealt
-               round-robin (locs.rs:1116-1174) -> orc_load_mt on the first --cpu-sample read pairs of the same workload;
-      filter   run_filter, single-threaded as solve.rs:87-122, on the sample's matrix, all G genotypes;
+               round-robin (locs.rs:1116-1174) -> orc_load_mt on --cpu-sample read pairs of the same workload, taken as four equal
+               slices spread over the batch (pairs 0.., P/4.., P/2.., 3P/4..); linear in the read pairs: scaled to the workload;
+      filter   run_filter, single-threaded as solve.rs:87-122, MEASURED AT FULL SIZE: all G genotypes over the matrix of all good read
+               pairs of the workload (the matrix the GPU scored: bit-identical to the oracle's by the parity tests) — unless the
+               sample says that takes more than a minute, then scaled from the sample;
       solver   the stages of MainWorker::run (solve.rs:1047-1062: genotypes in contiguous runs over the workers) -> orc_solve_stage_mt
-               on ALL read pairs of the workload (the oracle gets the batch the GPU scored: bit-identical inputs by the parity tests),
-               one genotype per worker and stage: `threads` greedy chains, then `threads` annealing chains.
-    Every stage is linear in the number of read pairs (and the solver stages in the number of chains), so the whole path on the
-    workload — load + run_filter + 5 000 greedy chains + 20 x 20 annealing chains, the default scheme — is composed from the measured
-    rates; median of --cpu-reps runs per figure."""
+               on ALL read pairs of the workload (the oracle gets the batch the GPU scored), one genotype per worker and stage:
+               `threads` greedy chains, then `threads` annealing chains, every worker refilling ONE GenotypeAlignments object
+               (oracle/lcty_oracle_solve.c: orc_gt_alns_fill); chains per second and per thread are both in the entry.
+    The whole path on the workload = load (scaled) + run_filter (measured) + 5 000 greedy + 20 x 20 annealing chains (the default
+    scheme, from the measured chain rates); median of --cpu-reps runs where a figure is repeated."""
     from tests import oracle_ffi as O
     A = args.alleles
-    ns = min(args.cpu_sample, first.n_pairs)
-    sample = first.slice(0, ns)
+    ns = min(args.cpu_sample, first.n_pairs * 4, args.pairs) // 4 * 4
+    per = max(ns // 4, 1)
+    slices = [first.slice(0, min(per, first.n_pairs))]
+    for q in (1, 2, 3):
+        lo = (args.pairs * q // 4) // 32 * 32
+        if ns >= 4 and lo + per <= args.pairs: slices.append(L.reads(lo, per))
+    ns = sum(c.n_pairs for c in slices)
     ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, params)
     reps = max(1, args.cpu_reps)
     med = lambda xs: float(np.median(xs))
     n_phys = physical_cores()
-    thread_sets = [8] if n_phys == 8 else [8, n_phys]
-    # ---- run_filter: single thread whatever `threads` is ----
-    oa = ol.load(sample)
+    thread_sets = [8] if n_phys <= 8 else [8, n_phys]
+    # ---- run_filter: single thread whatever `threads` is; first on the first slice (for the estimate), then at full size ----
+    oa = ol.load(slices[0])
     Mo = oa.best_aln_matrix()
-    tf = []
-    for _ in range(reps):
-        tc = time.perf_counter()
-        so = O.run_filter(Mo, gts)
-        O.truncate(so, all_ixs, params.filt_diff, 5000, 8)
-        tf.append(time.perf_counter() - tc)
-    t_filter = med(tf)
+    tc = time.perf_counter()
+    so = O.run_filter(Mo, gts)
+    O.truncate(so, all_ixs, params.filt_diff, 5000, 8)
+    t_filter_sample = time.perf_counter() - tc
     n_good_sample = oa.n_good
+    filter_pairs = slices[0].n_pairs
+    t_filter_full = t_filter_sample * args.pairs / filter_pairs
+    filter_measured = False
+    if t_filter_full <= 60.0:
+        Mfull = aa.best_aln_matrix()                                        # [A][n_good] as locs.rs:1203-1212 lays it out
+        tc = time.perf_counter()
+        so = O.run_filter(Mfull, gts)
+        O.truncate(so, all_ixs, params.filt_diff, 5000, 8)
+        t_filter_full = time.perf_counter() - tc
+        filter_measured = True
+        del Mfull
     # ---- solver inputs at full size: the scored batch of the GPU ----
     solver_pairs, oa_full = 0, None
     if not args.no_solve:
@@ -185,27 +201,29 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
     for T in thread_sets:
         tl, ts_, tg_ = [], [], []
         for _ in range(reps):
-            tc = time.perf_counter()
-            ob, secs = ol.load_mt(sample, T)
-            ob.best_aln_matrix()
-            tl.append(time.perf_counter() - tc); ts_.append(secs[0]); tg_.append(secs[1])
-            del ob
+            t_all = s_all = g_all = 0.0
+            for c in slices:
+                tc = time.perf_counter()
+                ob, secs = ol.load_mt(c, T)
+                ob.best_aln_matrix()
+                t_all += time.perf_counter() - tc; s_all += secs[0]; g_all += secs[1]
+                del ob
+            tl.append(t_all); ts_.append(s_all); tg_.append(g_all)
         t_load = med(tl)
-        entry = {"threads": T, "load_s": t_load, "load_serial_s": med(ts_), "load_group_s": med(tg_),
-                 "run_filter_s": t_filter, "reads_scored_per_s": ns / (t_load + t_filter)}
-        # whole path on the workload, composed from rates that are linear in the number of read pairs
         scale = args.pairs / ns
-        total = (t_load + t_filter) * scale
+        entry = {"threads": T, "load_s": t_load, "load_serial_s": med(ts_), "load_group_s": med(tg_), "load_read_pairs": ns,
+                 "run_filter_s": t_filter_full, "run_filter_measured_at_full_size": filter_measured,
+                 "reads_scored_per_s": args.pairs / (t_load * scale + t_filter_full)}
+        total = t_load * scale + t_filter_full
         if oa_full is not None:
-            # the best genotypes of the sample's prefilter: what the stages would work on
+            # the best genotypes of the prefilter: what the stages would work on
             order = np.argsort(-so, kind="stable")
             ng = min(max(T, 8), len(order))
             sub_g = gts[order[:ng]]
             na = min(max(T, 4), len(order))
             sub_a = gts[order[:na]]
             tgreedy, tanneal = [], []
-            # at all cores one worker per core runs a full-size chain (4 s each, twice): once is 1.5 min of the run, so no repeats there
-            for rep in range(reps if T == 8 else 1):
+            for rep in range(reps if T == 8 else 1):                         # at all cores one worker per core runs a full-size chain: once
                 tc = time.perf_counter()
                 O.solve_stage(ol, oa_full, sub_g, greedy, 1, api.chain_seeds(1000 + rep, ng), threads=T)
                 tgreedy.append(time.perf_counter() - tc)
@@ -215,6 +233,7 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
             g_cps, a_cps = ng / med(tgreedy), na / med(tanneal)
             entry.update({"greedy_chains_per_s@R": g_cps, "anneal_chains_per_s@R": a_cps, "solver_read_pairs": solver_pairs,
                           "greedy_chains_timed": ng, "anneal_chains_timed": na,
+                          "greedy_chains_per_s_per_thread": g_cps / min(T, ng), "anneal_chains_per_s_per_thread": a_cps / min(T, na),
                           "chains_per_s": 5400.0 / (5000.0 / g_cps + 400.0 / a_cps)})
             total += (5000.0 / g_cps + 400.0 / a_cps) * (args.pairs / solver_pairs)
         entry["seconds_per_locus"] = total
@@ -222,6 +241,10 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
         by["threads_8" if T == 8 else "all_cores"] = entry
     if "all_cores" not in by:
         by["all_cores"] = dict(by["threads_8"])          # an 8-core host: the two coincide
+    if oa_full is not None and "greedy_chains_per_s_per_thread" in by["threads_8"]:
+        # how the stage loop scales from the reference's default of 8 threads to every core (1.0 = linear in the threads)
+        t8, ta = by["threads_8"], by["all_cores"]
+        by["all_cores"]["chain_scaling_vs_8_threads"] = (ta["chains_per_s"] / t8["chains_per_s"]) / max(ta["threads"] / 8.0, 1.0)
     # ---- the oracle's chains against the GPU's, on the full batch (stoch.rs:81-120, 195-245): the timed runs above evaluate BayesCalc on
     # the fly beyond depth 256 as the reference does (own lgamma: a near-tie can flip); for the comparison the oracle gets the device's
     # tables, so a chain has to follow the same moves and the likelihoods agree to 1e-9 relative
@@ -242,9 +265,10 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
                         "chains_equal_oracle": bool(worst <= 1e-9)}
     best = by["all_cores"]
     return {"value": best["value"], "unit": "read pairs/s", "cores": best["threads"], "kind": "port",
-            "sample": f"load + run_filter on the first {ns} read pairs x {A} alleles (all {G} genotypes; {n_good_sample} good pairs); "
+            "sample": f"load on {ns} read pairs x {A} alleles (four slices spread over the batch), scaled to {args.pairs}; run_filter "
+                      + (f"measured on all {args.pairs} read pairs, all {G} genotypes, one thread as upstream; " if filter_measured else f"on {filter_pairs} read pairs ({n_good_sample} good), scaled; ")
                       + (f"solver chains on all {solver_pairs} read pairs (inputs = the batch the GPU scored); " if oa_full is not None else "")
-                      + f"whole path composed for {args.pairs} read pairs and the default scheme; median of {reps} (solver chains at all cores: one run)",
+                      + f"whole path = load + run_filter + 5 000 greedy + 400 annealing chains at the measured rates; median of {reps} (at all cores: one run)",
             "cpu_model": cpu_model(), "physical_cores": n_phys, "cpu_count": os.cpu_count(),
             "by_threads": by, "chains_check": chains_check,
             "reads_scored_per_s": best["reads_scored_per_s"], "chains_per_s": best.get("chains_per_s"),
@@ -263,17 +287,43 @@ def spawn_ranks(args):
         port = sk.getsockname()[1]
     base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                 LCTY_BENCH_LAUNCH="self-spawned children of bench.py")
+    # every rank's OpenMP teams (synthetic data, CSR validation), loader and validation threads get their share of the host's cores:
+    # N ranks with the default "all cores" each would oversubscribe the host N-fold during set-up and inside the loader threads
+    share = max(1, physical_cores() // max(args.gpus, 1))
+    if "OMP_NUM_THREADS" not in os.environ: base["OMP_NUM_THREADS"] = str(share)
+    base["LCTY_BENCH_HOST_THREADS"] = str(share)
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(args.gpus):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    line, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's line is read by a thread; the launcher polls ALL children: one that dies before the rendezvous would leave the others
+    # waiting for it for ever — the rest is ended and the launcher exits non-zero as soon as any child fails
+    import threading
+    import time as _time
+    got = {}
+    reader = threading.Thread(target=lambda: got.setdefault("line", procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None: codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            _time.sleep(2.0)                                       # the others may be on their way out with the same error
+            for i, p in enumerate(procs):
+                if codes[i] is None and p.poll() is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try: codes[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired: p.kill(); codes[i] = p.wait()
+            break
+        _time.sleep(0.2)
     if any(codes):
         print(f"bench.py: child ranks exited with {codes}", file=sys.stderr)
         sys.exit(next(c for c in codes if c) or 1)
-    sys.stdout.write(line)
+    reader.join(timeout=30)
+    sys.stdout.write(got.get("line", ""))
     sys.stdout.flush()
     sys.exit(0)
 
@@ -369,11 +419,15 @@ def distinct_loci_leg(args, ctx, loci, batches, stages, gts, resident_ms_per_ste
             if trace: progress(f"  position {i}: released")
             free[i % 3].release()
 
-        th = threading.Thread(target=loader)
+        th = threading.Thread(target=loader, daemon=True)      # a queue that raised must not leave the process waiting for its loader
         ctx.synchronize()
         tq = time.perf_counter()
         th.start()
-        calls = api.solve_queue_fed(k, acquire, release, stages, master_seeds=[3000 + first_it + i for i in range(k)])
+        try:
+            calls = api.solve_queue_fed(k, acquire, release, stages, master_seeds=[3000 + first_it + i for i in range(k)])
+        except BaseException:
+            for f in free: f.release()                          # the loader may sit in an acquire: let it run out
+            raise
         ctx.synchronize()
         dt = time.perf_counter() - tq
         th.join()
@@ -426,6 +480,8 @@ def main():
         raise RuntimeError(f"{world} ranks but {ndev} HIP device(s) visible: one process per GPU (--oversubscribe puts several ranks on a device "
                            "to exercise the launch path on a small box; the line then says so)")
     ctx = api.Context(local_rank % ndev)
+    if world > 1:                                  # this rank's share of the host's cores (spawn_ranks sets it; under torchrun: cores / ranks)
+        ctx.set_knob("host_threads", max(1, min(16, int(os.environ.get("LCTY_BENCH_HOST_THREADS", physical_cores() // world)))))
     for kv in args.knob:
         name, _, val = kv.partition("=")
         ctx.set_knob(name, int(val))
@@ -575,10 +631,15 @@ def main():
     ctx.synchronize()
     elapsed = time.perf_counter() - t_start
     barrier()
+    rank_ms = None
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
+        lo = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        # the step of the line is the slowest rank's; the fastest beside it shows how evenly the ranks ran
+        rank_ms = {"min": 1e3 * float(lo[0]) / args.steps, "max": 1e3 * float(t[0]) / args.steps}
         elapsed = float(t[0])
     n_score, ms_score = ctx.timing(api.K_SCORE)
     n_pref, ms_pref = ctx.timing(api.K_PREFILTER)
@@ -660,6 +721,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_ranks": rank_ms,
         "higher_is_better": True,
         "scaling": "strong" if one_locus else "weak",
         "vs_baseline": None,

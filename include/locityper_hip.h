@@ -183,11 +183,15 @@ typedef struct lcty_pair_aln {
 /* The exact solver in the place of the reference's ILP back ends (HiGHS: src/solvers/highs.rs:38-134, Gurobi: gurobi.rs:15-83;
  * registered at solve.rs:152-171, `-S highs` / `-S gurobi`): the same model — one binary per (non-trivial read, location), one-hot
  * depth variables per window, coupling rows, objective = ReadAssignment::likelihood — built on the device by the stage's
- * initialisation and solved to proven optimality by branch and bound; `node_limit` nodes without a proof -> LCTY_ERR_SOLVER, as
- * a non-optimal solver status is upstream (highs.rs:113-116). Every attempt starts from the best location of every read.
- * `init_prob` is this kind's relative gap: 0 (the default) asks for a proof of optimality; g in (0, 1) stops the search when nothing
- * left can beat the incumbent by more than g x |incumbent| — what HiGHS calls optimal at its default mip_rel_gap of 1e-4, which the
- * reference does not change (highs.rs:103-110). */
+ * initialisation and solved by branch and bound ON THE HOST: the models of a stage's chains are copied to the host, solved by a pool
+ * of host threads, one model per thread at a time (as the reference runs one model per worker, solve.rs:1052-1062;
+ * lcty_ctx_set_knob "exact_threads", default: the machine's hardware threads, at most 64), and the assignments are written back
+ * into the chains' device records. `node_limit` nodes without an answer -> LCTY_ERR_SOLVER, as a non-optimal solver status is
+ * upstream (highs.rs:113-116). Every attempt starts from the best location of every read; with tweak = 0 the attempts of a genotype
+ * share one model, which is solved once.
+ * `init_prob` is this kind's relative gap g: the search stops when nothing left can beat the incumbent by more than g x |incumbent|.
+ * Default 1e-4 = HiGHS' default mip_rel_gap, at which the reference's runs report "optimal" (highs.rs:103-110 changes no option);
+ * 0 asks for a proof of optimality (reaches ~1 000 read pairs; larger loci end in LCTY_ERR_SOLVER). */
 #define LCTY_SOLVER_EXACT 2
 typedef struct lcty_solver {
     int32_t  kind;          /* LCTY_SOLVER_* */
@@ -196,7 +200,8 @@ typedef struct lcty_solver {
     uint32_t plato_size;    /* greedy: 100; anneal: 10000 */
     uint32_t anneal_steps;  /* anneal: 20000 */
     uint32_t node_limit;    /* exact: branch-and-bound nodes per attempt before LCTY_ERR_SOLVER (default 20 000 000) */
-    double   init_prob;     /* anneal: 0.5; exact: relative gap of the proof, 0 */
+    double   init_prob;     /* anneal: 0.5; exact: relative gap at which the search stops and the answer counts as optimal = HiGHS'
+                             * mip_rel_gap, default 1e-4 as the reference's runs (highs.rs:103-110 leaves the option alone); 0 = a proof */
 } lcty_solver;
 
 typedef struct lcty_ctx   lcty_ctx;
@@ -234,6 +239,10 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  * value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT. None of them changes a result beyond the last bits of
  * an f64 sum (the order in which a chain's likelihood or a genotype's score is added up). */
 int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value);
+/* Files a developer asks the library to write (no environment variable is read anywhere in the library): name "exact_dump" = the
+ * model of the first chain of an exact-solver stage as text, written when that stage runs; path NULL or "" switches it off.
+ * No counterpart upstream (HiGHS' own `write_model` is not called by highs.rs). */
+int32_t lcty_ctx_set_path(lcty_ctx* ctx, const char* name, const char* path);
 /* The solver stages keep their per-chain device state (32 B per chain and good read pair: ~150 GB for the 5 000 greedy chains of
  * the default scheme at 1 M read pairs; batches of chains when the device has less) with the context between stages and loci;
  * this releases it (the next stage allocates again). So does alignment recovery with its lane scratch and the arenas of the

@@ -86,6 +86,7 @@ SIGNATURES = {
     "lcty_discard_improbable": (I32, [VP, VP, VP, VP, U64, D, U64, U64, P(U64)]),
     "lcty_produce_result": (I32, [VP, VP, VP, VP, U64, D, U64, VP, VP, P(U64), P(D)]),
     "lcty_ctx_set_knob": (I32, [VP, C.c_char_p, C.c_int64]),
+    "lcty_ctx_set_path": (I32, [VP, C.c_char_p, C.c_char_p]),
     "lcty_map_params_default": (I32, [VP]),
     "lcty_map_params_default_long": (I32, [VP]),
     "lcty_locus_build_map_index": (I32, [VP, VP, U32, U32]),

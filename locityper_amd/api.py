@@ -53,6 +53,10 @@ class Context:
         """lcty_ctx_set_knob: a limit of the retry / batching machinery (tests lower them); value < 0 = default."""
         check(lib().lcty_ctx_set_knob(self._h, name.encode(), int(value)))
 
+    def set_path(self, name, path):
+        """lcty_ctx_set_path: a file the library is asked to write ("exact_dump"); None switches it off."""
+        check(lib().lcty_ctx_set_path(self._h, name.encode(), None if path is None else str(path).encode()))
+
     def trim(self):
         """lcty_ctx_trim: release the solver workspaces kept between stages."""
         check(lib().lcty_ctx_trim(self._h))

@@ -67,6 +67,16 @@ struct AgreeScope {
     }
 };
 
+// the sizes of a stage as one word the ranks must agree on: n_gt (< 2^31 chains per stage) in the high part, attempts below — no two
+// (n_gt, attempts) pairs share a word
+inline uint64_t stage_word(uint64_t n_gt, uint32_t attempts) { return ((n_gt & 0x3FFFFFFFull) << 32) | attempts; }
+// a 62-bit mix of several sizes (what AgreeScope::then compares): ranks that differ in any of them differ in the word
+inline uint64_t sizes_word(std::initializer_list<uint64_t> v) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (uint64_t x : v) { h ^= x + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 31; }
+    return h & 0x3FFFFFFFFFFFFFFFull;
+}
+
 // per-chain likelihoods of the blocks of all ranks, gathered on the devices; everything fallible under agreements
 void gather_chain_likelihoods(AgreeScope& A, lcty_comm* comm, const std::vector<double>& local, uint64_t per, uint32_t attempts,
                               uint64_t n_gt, double* lik_mean, double* lik_var, double* liks_out) {
@@ -180,7 +190,7 @@ int32_t lcty_solve_stage_sharded(lcty_reads* reads, lcty_comm* comm, const uint1
             const int32_t rc = lcty_solve_stage(reads, genotypes + lo * ploidy, hi - lo, ploidy, priors ? priors + lo : nullptr, solver,
                                                 attempts, chain_seeds + lo * attempts, m.data(), v.data(), local.data());
             if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
-        }, n_gt * 64 + attempts);
+        }, stage_word(n_gt, attempts));
         gather_chain_likelihoods(A, comm, local, per, attempts, n_gt, lik_mean, lik_var, liks_out);
     });
 }
@@ -212,7 +222,7 @@ int32_t lcty_solve_stage_read_sharded(lcty_reads* shard, lcty_comm* comm, const 
             G->count(shard, rank, &mine[0], &mine[1]);
             d_mine.alloc(2); d_all.alloc(2ull * n_ranks);
             d_mine.upload(mine, 2, s);
-        }, n_gt * 64 + attempts);
+        }, stage_word(n_gt, attempts));
         // sizes of every shard
         LCTY_NCCL(ncclAllGather(d_mine.p, d_all.p, 2, ncclUint64, comm->comm, s));
         std::vector<uint64_t> all(2ull * n_ranks), goods(n_ranks), extras(n_ranks);
@@ -225,6 +235,9 @@ int32_t lcty_solve_stage_read_sharded(lcty_reads* shard, lcty_comm* comm, const 
             G->plan(goods.data(), extras.data(), n_ranks);
             if (G->n_rows) G->pack_chunk(shard, rank, 0, G->send_cells(), shard->gather.send_pa.p);
         });
+        // the plan's sizes come from a per-context knob (gather_chunk_mb) and from every rank's own genotype list: ranks that differ in
+        // any of them would enter the first all-gather with different sizes or loop a different number of times — agreed BEFORE it
+        A.then([] {}, sizes_word({G->n_rows, G->rows_per_chunk, G->chunk_cells(), G->ext_stride}));
         for (uint32_t row0 = 0; row0 < G->n_rows; row0 += G->rows_per_chunk) {
             LCTY_NCCL(ncclAllGather(G->send_cells(), G->recv_cells(0), G->chunk_cells() * 32, ncclUint8, comm->comm, s));
             const uint32_t next = row0 + G->rows_per_chunk;

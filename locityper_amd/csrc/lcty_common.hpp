@@ -134,6 +134,7 @@ struct lcty_ctx {
     std::mutex timing_mutex;
     bool timing_on = false;                           // lcty_timing_reset switches the event timing on; a run that never asks pays nothing
     std::map<std::string, int64_t> knobs;             // lcty_ctx_set_knob: limits that tests lower to exercise retry / batching paths
+    std::string exact_dump_path;                      // lcty_ctx_set_path "exact_dump": where the exact solver leaves the model of a stage's first chain ("" = nowhere)
 
     hipEvent_t get_event();
     void fold_oldest(lcty::KernelTimer& t, size_t count);

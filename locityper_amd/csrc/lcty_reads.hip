@@ -238,7 +238,9 @@ static int32_t append_impl(lcty_reads* R, const lcty_reads_host* h, const lcty_a
         std::vector<uint2> meta(n);
         const bool paired = R->locus->bg.is_paired != 0;
         struct Problem { uint64_t pair = ~0ull; int32_t code = LCTY_OK; std::string text; };
-        const uint32_t n_threads = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>({nr / 500000 + 1, 16, std::thread::hardware_concurrency()})));
+        // lcty_ctx_set_knob "host_threads": the most host threads one call of the library starts (default 16; several ranks on one host share its cores)
+        const uint64_t host_cap = static_cast<uint64_t>(std::max<int64_t>(1, ctx->knob("host_threads", 16)));
+        const uint32_t n_threads = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>({nr / 500000 + 1, host_cap, std::thread::hardware_concurrency()})));
         std::vector<Problem> problems(n_threads);
         std::vector<uint32_t> t_max_recs(n_threads, 0), t_max_rec_cig(n_threads, 0);
         std::vector<uint64_t> t_max_cig(n_threads, 0);

@@ -1288,7 +1288,10 @@ void launch_score_reads(lcty_reads* reads) {
         reads->d_park.ensure(stride * grid);
         R.park = reads->d_park.p; R.park_stride = stride;
     }
-    R.pa_chunk = reads->pa_pooled && R.n_pairs / grid >= PA_POOL_MIN_PAIRS ? PA_CHUNK : 0u;
+    // chunk-wise reservation abandons up to one partly used chunk per wavefront and LAUNCH: the arena's slack (lcty_reads_create) covers
+    // PA_MAX_GRID wavefronts of one launch, so larger grids (parts with more CUs) and the many launches of a streaming batch reserve per pair
+    const bool pooled = reads->pa_pooled && !reads->streaming;
+    R.pa_chunk = pooled && grid <= PA_MAX_GRID && R.n_pairs / grid >= PA_POOL_MIN_PAIRS ? PA_CHUNK : 0u;
     // the arena cursor goes back to where the pairs on the device start (0 unless a streaming batch has dropped chunks)
     if (reads->raw_first == 0) reads->d_pa_count.zero(ctx->stream);
     else reads->d_pa_count.upload(&reads->pa_at_raw_first, 1, ctx->stream);
@@ -1310,7 +1313,7 @@ void launch_score_reads(lcty_reads* reads) {
             const uint32_t lean_per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, lds_max / lean_lds)));
             const uint64_t lean_grid = std::max<uint64_t>(1, std::min<uint64_t>(R.n_pairs, static_cast<uint64_t>(cus) * lean_per_cu));
             ReadsView RL = R;
-            RL.pa_chunk = reads->pa_pooled && R.n_pairs / lean_grid >= PA_POOL_MIN_PAIRS ? PA_CHUNK : 0u;
+            RL.pa_chunk = pooled && lean_grid <= PA_MAX_GRID && R.n_pairs / lean_grid >= PA_POOL_MIN_PAIRS ? PA_CHUNK : 0u;
             hipLaunchKernelGGL(score_counted_lean_kernel, dim3(static_cast<uint32_t>(lean_grid)), dim3(WAVE), lean_lds, ctx->stream, L, RL);
             R.only_list = R.defer_list; R.only_count = R.defer_count;
             R.pa_chunk = 0;                                                     // the few pairs left reserve their own entries

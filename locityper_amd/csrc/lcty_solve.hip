@@ -33,6 +33,7 @@
 // Randomness is the injected per-chain seed described in oracle/lcty_oracle.h (the reference's rand adaptors
 // are not in its tree): counter-based draws for tweaks / random starts, xoshiro256++ for the solver loop.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <memory>
@@ -40,9 +41,18 @@
 #include <thread>
 #include <type_traits>
 
+#include "lcty_exact.hpp"
 #include "lcty_objects.hpp"
 
 namespace lcty {
+
+// Forms of the greedy loop under measurement, a bit mask:
+//   1  the parts of a chain's record list in registers instead of four LDS words per row
+//   2  duplicate check of a sample through an LDS array of the row's picks (one write + three 16-byte reads) instead of eleven lane exchanges
+//   4  the row's best candidate through one 64-bit LDS maximum per lane instead of four rounds of lane exchanges
+//   8  depth-table entries as pairs {v[d], v[d + 1]}: one 16-byte gather per window instead of two 8-byte ones
+//  16  a candidate's record as two 16-byte loads instead of six field loads
+// (a template parameter of the kernel; lcty_ctx_set_knob "solve_greedy_form" picks among the compiled ones)
 
 constexpr uint32_t MAXP = 4;                  // ploidy handled by the device solver
 constexpr uint32_t NONE32S = 0xFFFFFFFFu;
@@ -109,6 +119,7 @@ struct SolveView {
     const double* wk; const double* wc;
     uint32_t n_wk, n_wc;            // 0: no tables (the greedy loop then gathers the weights)
     const double* lut;              // [LCTY_GC_BINS][lut_depth]
+    const double2* lut2;            // the same as pairs: lut2[g][d] = {lut[g][d], lut[g][d + 1]} (the last entry of a row repeats itself)
     uint32_t lut_depth, lut_shift;  // lut_depth = 1 << lut_shift
     const DepthNB* depth_nb;
     uint32_t n_alt;
@@ -183,8 +194,9 @@ struct Xoshiro {
 constexpr uint32_t INIT_SEGS = 4;
 struct RecList {
     ChainRec* base; const uint32_t* cum; uint32_t seg_reads;
+    uint32_t r1 = 0, r2 = 0, r3 = 0; bool in_regs = false;                  // the three bounds held by the lane itself (greedy loop)
     __device__ __forceinline__ uint32_t place(uint32_t s) const {
-        const uint32_t c1 = cum[1], c2 = cum[2], c3 = cum[3];
+        const uint32_t c1 = in_regs ? r1 : cum[1], c2 = in_regs ? r2 : cum[2], c3 = in_regs ? r3 : cum[3];
         const uint32_t k = (s >= c1 ? 1u : 0u) + (s >= c2 ? 1u : 0u) + (s >= c3 ? 1u : 0u);
         const uint32_t before = s >= c3 ? c3 : s >= c2 ? c2 : s >= c1 ? c1 : 0u;
         return s - before + k * seg_reads;
@@ -334,6 +346,13 @@ __global__ __launch_bounds__(256) void build_depth_table_kernel(const double* __
     if (i >= LCTY_GC_BINS * lut_depth) return;
     const uint32_t g = i / lut_depth, d = i % lut_depth;
     lut[i] = d < LCTY_DEPTH_CACHE ? cache[g * LCTY_DEPTH_CACHE + d] : bayes_ln_pmf_direct(nb + g, n_alt, d);
+}
+
+__global__ __launch_bounds__(256) void build_depth_pairs_kernel(const double* __restrict__ lut, uint32_t lut_depth, double2* __restrict__ pairs) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= LCTY_GC_BINS * lut_depth) return;
+    const uint32_t d = i % lut_depth;
+    pairs[i] = make_double2(lut[i], lut[d + 1 < lut_depth ? i + 1 : i]);
 }
 
 // ---- the genotype of a chain: GenotypeWindows (windows.rs:709-739) ----
@@ -644,11 +663,20 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
 }
 
 // two windows of one location (see Chain::request_pair)
-struct PairGather { int32_t c[2]; uint32_t dmax[2]; double weight[2], vnew[2], vold[2]; };
+// With the table as pairs (GREEDY_FORM & 8) the entries arrive as pr[i] = {v[lo], v[lo + 1]} at the lower of a window's two depths, and
+// `far` = v[lo + 2] for a window that both ends of the location share (a step of two); which of them is the entry before and after the
+// move is sorted out in pair_term, i.e. behind the wait for the whole group — a select right behind a load waits for that load
+struct PairGather { int32_t c[2]; uint32_t dmax[2]; double weight[2], vnew[2], vold[2]; double2 pr[2]; double far; };
 // the four terms of depth_lik_diff in its order of summation, ((t1 + t2) + t3) + t4, from the two halves; *deepest: the deepest live window
+template <uint32_t GREEDY_FORM = 0>
 __device__ __forceinline__ double pair_term(const PairGather& g, int i, uint32_t* deepest) {
     const bool live = g.c[i] != 0 && g.weight[i] != 0.0;                     // c == 0: no change; weight 0: WindowDistr::TRIVIAL
     *deepest = max(*deepest, live ? g.dmax[i] : 0u);
+    if constexpr ((GREEDY_FORM & 8u) != 0) {
+        const double hi = (g.c[i] == 2 || g.c[i] == -2) ? g.far : g.pr[i].y;  // the entry at the higher of the two depths
+        const double vnew = g.c[i] > 0 ? hi : g.pr[i].x, vold = g.c[i] > 0 ? g.pr[i].x : hi;
+        return live ? g.weight[i] * vnew - g.weight[i] * vold : 0.0;
+    }
     return live ? g.weight[i] * g.vnew[i] - g.weight[i] * g.vold[i] : 0.0;
 }
 
@@ -741,6 +769,7 @@ struct Chain {
 // entries, which is how window_weight_kernel made it. Every 8-byte weight gather moved a 128-byte line out of the L2;
 // at 5 000 chains those lines were a quarter of the loop's time.
 constexpr uint32_t LW_DEPTH_BITS = 23, LW_DEPTH_MASK = (1u << LW_DEPTH_BITS) - 1u;      // nine bits for a table index
+template <uint32_t GREEDY_FORM = 0>
 struct ChainLW {
     const SolveView* V;
     uint32_t* wd;               // LDS: depth | wk index << 23
@@ -806,13 +835,36 @@ struct ChainLW {
 #pragma unroll
         for (int i = 0; i < 2; i++) { word[i] = wd[w[i]]; half[i] = wh[w[i]]; }
         const uint32_t last = V->lut_depth - 1;
+        if constexpr ((GREEDY_FORM & 8u) != 0) {
+            // one 16-byte gather per window: the pair at the lower of the two depths holds the entry before and the entry after a
+            // step of one; a step of two (both windows of the pair coincide) takes its far entry from a second pair (rare)
+            uint32_t lo[2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
-            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
-            g.vnew[i] = V->lut[row + min(d_new, last)];
-            g.vold[i] = V->lut[row + min(d_old, last)];
-            g.dmax[i] = max(d_new, d_old);
+            for (int i = 0; i < 2; i++) {
+                const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
+                const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
+                lo[i] = min(d_old, d_new);
+                g.pr[i] = V->lut2[row + min(lo[i], last)];
+                g.dmax[i] = max(d_new, d_old);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) g.weight[i] = weight_of(word[i], half[i]);
+            g.far = 0.0;
+            // |c[0]| == 2: v[lo + 2] = the second half of the pair at lo + 1 (lanes without a candidate sit on window 0 twice: no weight)
+            if (__any(same && g.weight[0] != 0.0)) {
+                const uint32_t row = (half[0] & 0x7Fu) << V->lut_shift;
+                g.far = V->lut2[row + min(lo[0] + 1u, last)].y;
+            }
+            return;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
+                const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
+                g.vnew[i] = V->lut[row + min(d_new, last)];
+                g.vold[i] = V->lut[row + min(d_old, last)];
+                g.dmax[i] = max(d_new, d_old);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; i++) g.weight[i] = weight_of(word[i], half[i]);
@@ -905,6 +957,7 @@ __device__ __forceinline__ double row_sum_f64(double x, uint32_t row_base, uint3
     }
 }
 
+constexpr uint32_t GREEDY_ROW_TAIL = 24;      // words per row behind the windows (see the kernel)
 // LDS of a greedy workgroup for its rows' windows: 4 bytes each; 6 with the weights in LDS, plus the two weight tables (16-byte multiple)
 __host__ __device__ inline size_t greedy_lds_windows(uint32_t lpc, uint32_t wstride, uint32_t n_wk, uint32_t n_wc, bool lw) {
     const size_t rows = static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * wstride;
@@ -914,7 +967,7 @@ __host__ __device__ inline size_t greedy_lds_windows(uint32_t lpc, uint32_t wstr
 
 // ---------------- K14 Greedy: 64 / LPC chains per wavefront ----------------
 // A candidate read of an iteration as its lane sees it: the record, and the first two of its locations beyond the second
-struct GreedyCand { uint32_t pick, rpc; RecBody b; };
+struct GreedyCand { uint32_t pick, rpc; RecBody b; uint32_t spare; };     // spare: the first word of a 16-byte record load, kept until the record is used
 struct GreedyExt { double lp2, lp3; uint32_t win2, win3; };
 constexpr uint32_t GREEDY_INLINE_LOCS = 4;     // locations of a read the pipelined path holds in registers; reads with more take loads
 __device__ __forceinline__ void cand_loc(const RecBody& b, const GreedyExt& e, uint32_t t, double* lp, uint32_t* win) {
@@ -923,12 +976,12 @@ __device__ __forceinline__ void cand_loc(const RecBody& b, const GreedyExt& e, u
 }
 
 // With the weights in LDS a workgroup is two wavefronts that share the two tables (nothing else: after one barrier they run apart)
-template <uint32_t LPC, bool LW>
+template <uint32_t LPC, bool LW, uint32_t GREEDY_FORM = 0>
 __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveView V, const uint32_t n_chains) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint32_t flagged;
     constexpr uint32_t CPW = 64 / LPC, WAVES = LW ? 2u : 1u, ROWS = CPW * WAVES;
-    using ChainT = typename std::conditional<LW, ChainLW, Chain>::type;
+    using ChainT = typename std::conditional<LW, ChainLW<GREEDY_FORM>, Chain>::type;
     // a batch whose initialisation raised a flag (a chain's run of further locations was too short, ...) is repeated by the host:
     // its records are incomplete and must not be followed
     if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -946,9 +999,17 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(wg_row) * W;
     const uint32_t gi = chain / V.attempts;
     // the parts of the chain's list of non-trivial reads (RecList): four words per row in LDS, behind everything else
-    uint32_t* row_cum = reinterpret_cast<uint32_t*>(smem + greedy_lds_windows(LPC, V.wstride, V.n_wk, V.n_wc, LW)) + static_cast<size_t>(wg_row) * 4;
+    // per row, behind the windows: [0..3] the parts of the record list, [4..15] the picks of the current sample (duplicate check), [16..21] three
+    // 64-bit slots for the row's best improvement (taken in turn by consecutive iterations)
+    uint32_t* row_cum = reinterpret_cast<uint32_t*>(smem + greedy_lds_windows(LPC, V.wstride, V.n_wk, V.n_wc, LW)) + static_cast<size_t>(wg_row) * GREEDY_ROW_TAIL;
     if (jj < 4) row_cum[jj] = V.c_seg[static_cast<uint64_t>(chain) * 4 + jj];
-    const RecList recs{V.recs + static_cast<uint64_t>(chain) * V.rstride, row_cum, V.seg_reads};
+    if (jj < 6) row_cum[16 + jj] = 0;
+    unsigned long long* row_best = reinterpret_cast<unsigned long long*>(row_cum + 16);
+    RecList recs{V.recs + static_cast<uint64_t>(chain) * V.rstride, row_cum, V.seg_reads};
+    if constexpr ((GREEDY_FORM & 1u) != 0) {
+        const uint32_t* cg = V.c_seg + static_cast<uint64_t>(chain) * 4;
+        recs.r1 = cg[1]; recs.r2 = cg[2]; recs.r3 = cg[3]; recs.in_regs = true;
+    }
     const ExtraLoc* extra = V.extra + static_cast<uint64_t>(chain) * V.extra_cap;
     const uint32_t total_w = V.c_totw[chain];
     const uint8_t* ggc = V.c_gc + static_cast<uint64_t>(chain) * W;
@@ -967,7 +1028,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         }
         for (uint32_t i = threadIdx.x; i < V.n_wk; i += 64 * WAVES) lwk[i] = V.wk[i];
         for (uint32_t i = threadIdx.x; i < V.n_wc; i += 64 * WAVES) lwc[i] = V.wc[i];
-        C = ChainLW{&V, wd, wh, lwk, lwc};
+        C = ChainLW<GREEDY_FORM>{&V, wd, wh, lwk, lwc};
         __syncthreads();                                                         // the tables; from here on the wavefronts run apart
     } else {
         for (uint32_t w = jj; w < total_w && jj < LPC; w += LPC) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
@@ -1032,6 +1093,18 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x126, 0xF, 0xF, false) == v;
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x127, 0xF, 0xF, false) == v;
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false) == v;
+            } else if constexpr ((GREEDY_FORM & 2u) != 0 && LPC <= 12) {
+                // the row's picks through LDS: one write, three 16-byte reads every lane of the row shares, instead of LPC - 1 lane exchanges
+                if (jj < LPC) row_cum[4 + jj] = idx;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4* pk = reinterpret_cast<const uint4*>(row_cum + 4);
+                const uint4 p0 = pk[0], p1 = pk[1], p2 = pk[2];
+                const uint32_t all[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+                uint32_t same = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < LPC; q++) same += all[q] == idx ? 1u : 0u;
+                dup = same > 1u;                                              // the lane's own pick is one of the matches
             } else {
                 for (uint32_t d = 1; d < LPC; d++) {
                     const uint32_t other = static_cast<uint32_t>(__shfl(static_cast<int>(idx), static_cast<int>(row_base + ((jj + d) % LPC))));
@@ -1073,8 +1146,21 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         auto request_record = [&](GreedyCand& c) {
             c.pick = sample();
             const ChainRec* r = &recs[cand ? c.pick : 0u];
-            c.rpc = load_rp_cur(r);
-            c.b.meta = field32(r, 4); c.b.lp0 = field64(r, 8); c.b.lp1 = field64(r, 16); c.b.win0 = field32(r, 24); c.b.win1 = field32(r, 28);
+            if constexpr ((GREEDY_FORM & 16u) != 0) {
+                // the `cur` word from L2 as before (agent scope: this wavefront's own stores arrive there in order), the rest of the record as
+                // two 16-byte loads: three tag look-ups per candidate instead of six
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                c.rpc = load_rp_cur(r);
+                const u32x4 qa = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r));
+                const u32x4 qb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r) + 1);
+                c.spare = qa.x; c.b.meta = qa.y;               // all four words stay live: a dead one is handed out again at once, behind a wait for the load
+                c.b.lp0 = __hiloint2double(static_cast<int>(qa.w), static_cast<int>(qa.z));
+                c.b.lp1 = __hiloint2double(static_cast<int>(qb.y), static_cast<int>(qb.x));
+                c.b.win0 = qb.z; c.b.win1 = qb.w;
+            } else {
+                c.rpc = load_rp_cur(r);
+                c.b.meta = field32(r, 4); c.b.lp0 = field64(r, 8); c.b.lp1 = field64(r, 16); c.b.win0 = field32(r, 24); c.b.win1 = field32(r, 28);
+            }
         };
         // the first two further locations of a record that has arrived (reads with two locations: the chain's first entry, unused)
         auto request_ext = [&](const GreedyCand& c, GreedyExt& e) {
@@ -1089,8 +1175,10 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
 
         // one iteration: A = its candidates (arrived), EA their further locations (arrived); N = the candidates of the next
         // iteration (arrived), EN receives their further locations; F = the slot the sample three iterations ahead goes to (= A's)
-        auto iteration = [&](GreedyCand& A, const GreedyExt& EA, const GreedyCand& N, GreedyExt& EN) {
+        auto iteration = [&](auto slot_tag, GreedyCand& A, const GreedyExt& EA, const GreedyCand& N, GreedyExt& EN) {
+            constexpr uint32_t SLOT = decltype(slot_tag)::value;
             const RecBody b = A.b;
+            if constexpr ((GREEDY_FORM & 16u) != 0) asm volatile("" :: "v"(A.spare));
             const uint32_t pick = A.pick, rpc0 = A.rpc;
             const uint32_t nloc = b.meta & 0xFFu;
             uint32_t cur = rpc0 >> 24;
@@ -1134,14 +1222,14 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             double best_improv = -INFINITY, lp_new = 0.0, ddiff = 0.0;
             uint32_t new_assgn = 0, w3 = 0, w4 = 0;
             uint32_t deepest = 0;
-            const double t1 = pair_term(gc, 0, &deepest);
-            const double t12 = t1 + pair_term(gc, 1, &deepest);
+            const double t1 = pair_term<GREEDY_FORM>(gc, 0, &deepest);
+            const double t12 = t1 + pair_term<GREEDY_FORM>(gc, 1, &deepest);
 #pragma unroll
             for (uint32_t u = 0; u < NA; u++) {
                 const bool has = u < n_alt && !(deep && t_of[u] >= GREEDY_INLINE_LOCS);
                 if (u == 0 || __any(has)) {
-                    const double t3 = pair_term(ga[u], 0, &deepest);
-                    double dd = (t12 + t3) + pair_term(ga[u], 1, &deepest);
+                    const double t3 = pair_term<GREEDY_FORM>(ga[u], 0, &deepest);
+                    double dd = (t12 + t3) + pair_term<GREEDY_FORM>(ga[u], 1, &deepest);
                     if (__any(cross[u])) {
                         if (cross[u]) dd = C.depth_lik_diff(w1, w2, win_t[u] & 0xFFFFu, win_t[u] >> 16);
                     }
@@ -1171,8 +1259,21 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             }
             const double my_improv = n_alt ? V.aln_contrib * (best_improv - cur_lp) : -INFINITY;
             // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
-            const double best = row_max_f64<LPC>(my_improv, row_base, jj);
-            const unsigned long long who = __ballot(n_alt && my_improv == best);
+            double best;
+            if constexpr ((GREEDY_FORM & 4u) != 0 && LPC != 16) {
+                // one 64-bit LDS maximum per lane over an order-preserving image of the improvement (-0.0 folded into +0.0 first, so that
+                // equal doubles have equal images), one read; the slot two iterations ahead is cleared by the row's first lane
+                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(my_improv + 0.0));
+                const unsigned long long key = bits ^ ((bits >> 63) ? ~0ull : 0x8000000000000000ull);
+                atomicMax(&row_best[SLOT], key);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long top = row_best[SLOT];
+                if (jj == 0) row_best[(SLOT + 2) % 3] = 0ull;
+                const unsigned long long tb = top ^ ((top >> 63) ? 0x8000000000000000ull : ~0ull);
+                best = __longlong_as_double(static_cast<long long>(tb));
+            } else best = row_max_f64<LPC>(my_improv, row_base, jj);
+            const unsigned long long who = __ballot(n_alt && (my_improv + 0.0) == best);
             const unsigned long long who_row = (who >> row_base) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63u)) - 1ull));
             const uint32_t src = who_row ? static_cast<uint32_t>(__ffsll(static_cast<long long>(who_row))) - 1u : 0u;
             const bool moved = !done && who_row != 0ull && best > min_diff;
@@ -1206,11 +1307,11 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         request_record(R0); request_record(R1); request_record(R2);
         request_ext(R0, E0);
         while (__any(!done)) {
-            iteration(R0, E0, R1, E1);
+            iteration(std::integral_constant<uint32_t, 0>{}, R0, E0, R1, E1);
             if (!__any(!done)) break;
-            iteration(R1, E1, R2, E2);
+            iteration(std::integral_constant<uint32_t, 1>{}, R1, E1, R2, E2);
             if (!__any(!done)) break;
-            iteration(R2, E2, R0, E0);
+            iteration(std::integral_constant<uint32_t, 2>{}, R2, E2, R0, E0);
         }
     }
     depth_mine = row_sum_f64<LPC>(depth_mine, row_base, jj); aln_mine = row_sum_f64<LPC>(aln_mine, row_base, jj);
@@ -1248,7 +1349,7 @@ struct AnnealRing {
 template <int MODE>
 __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) {
     constexpr bool WWL = MODE == 1, LW = MODE == 2;
-    using ChainT = typename std::conditional<LW, ChainLW, Chain>::type;
+    using ChainT = typename std::conditional<LW, ChainLW<0>, Chain>::type;
     extern __shared__ __align__(32) uint8_t smem[];
     __shared__ uint32_t flagged;
     if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1340,7 +1441,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         return;
     }
     ChainT C;
-    if constexpr (LW) C = ChainLW{&V, wd, wh, lww, lww + V.n_wk};
+    if constexpr (LW) C = ChainLW<0>{&V, wd, wh, lww, lww + V.n_wk};
     else C = Chain{&V, wd, WWL ? lww : gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
@@ -1583,6 +1684,12 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
 }
 
 // count_unexplained_reads (solve.rs:718-729): best_at_contig (locs.rs:605-611) is the likelihood-matrix entry
+// the exact solver's assignment into a chain's records: only the word a move changes (StageRunner::solve_exact_batch)
+__global__ __launch_bounds__(256) void store_cur_kernel(ChainRec* __restrict__ recs, const uint32_t* __restrict__ words, uint64_t n) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) recs[i].rp_cur = words[i];
+}
+
 __global__ __launch_bounds__(256) void count_unexplained_kernel(const uint8_t* __restrict__ status, const double* __restrict__ unmapped,
                                                                 const double* __restrict__ matrix, uint64_t n_pairs, uint32_t A,
                                                                 const uint16_t* __restrict__ ids, uint32_t ploidy,
@@ -1732,6 +1839,10 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
     hipLaunchKernelGGL(build_depth_table_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, loc->d_depth_lut.p, loc->d_depth_nb.p,
                        static_cast<uint32_t>(loc->prm.n_alt_cn), depth, loc->d_lut_ext.p);
     LCTY_HIP(hipGetLastError());
+    loc->d_lut_pair.alloc(2 * static_cast<size_t>(LCTY_GC_BINS) * depth);
+    hipLaunchKernelGGL(build_depth_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, loc->d_lut_ext.p, depth,
+                       reinterpret_cast<double2*>(loc->d_lut_pair.p));
+    LCTY_HIP(hipGetLastError());
     loc->lut_ext_depth = depth;
 }
 
@@ -1751,19 +1862,36 @@ void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_ini
 
 // LDS of a greedy workgroup: the rows' windows (greedy_lds_windows) and four words per row for the parts of its record list
 inline size_t greedy_lds(uint32_t lpc, const SolveView& V, bool lw) {
-    return greedy_lds_windows(lpc, V.wstride, V.n_wk, V.n_wc, lw) + static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * 16;
+    return greedy_lds_windows(lpc, V.wstride, V.n_wk, V.n_wc, lw) + static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * GREEDY_ROW_TAIL * 4;
 }
-template <uint32_t LPC, bool LW>
-void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
+template <uint32_t LPC, bool LW, uint32_t FORM = 0>
+void launch_greedy_form(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
     constexpr uint32_t ROWS = (64 / LPC) * (LW ? 2 : 1);
     const size_t lds = greedy_lds(LPC, V, LW);
     if (lds > 48 * 1024)
-        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC, LW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_loop_kernel<LPC, LW, FORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds)));
     ctx->timed(LCTY_K_SOLVE, [&] {
-        hipLaunchKernelGGL((greedy_loop_kernel<LPC, LW>), dim3((nch + ROWS - 1) / ROWS), dim3(LW ? 128 : 64), lds, s, V, nch);
+        hipLaunchKernelGGL((greedy_loop_kernel<LPC, LW, FORM>), dim3((nch + ROWS - 1) / ROWS), dim3(LW ? 128 : 64), lds, s, V, nch);
     }, s);
     LCTY_HIP(hipGetLastError());
+}
+template <uint32_t LPC, bool LW>
+void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
+    if constexpr (LPC == 12 && LW) {
+        // the forms under measurement exist for the stage shape of the default scheme only
+        switch (ctx->knob("solve_greedy_form", 0)) {
+            case 1: return launch_greedy_form<LPC, LW, 1>(ctx, V, nch, s);
+            case 2: return launch_greedy_form<LPC, LW, 2>(ctx, V, nch, s);
+            case 4: return launch_greedy_form<LPC, LW, 4>(ctx, V, nch, s);
+            case 8: return launch_greedy_form<LPC, LW, 8>(ctx, V, nch, s);
+            case 16: return launch_greedy_form<LPC, LW, 16>(ctx, V, nch, s);
+            case 24: return launch_greedy_form<LPC, LW, 24>(ctx, V, nch, s);
+            case 31: return launch_greedy_form<LPC, LW, 31>(ctx, V, nch, s);
+            default: break;
+        }
+    }
+    launch_greedy_form<LPC, LW, 0>(ctx, V, nch, s);
 }
 
 template <int MODE>
@@ -1845,7 +1973,7 @@ struct StageRunner {
         const bool tables = loc->weight_tables_valid && !loc->has_explicit;
         V.wk = tables ? loc->d_wk.p : nullptr; V.wc = tables ? loc->d_wc.p : nullptr;
         V.n_wk = tables ? static_cast<uint32_t>(loc->d_wk.n) : 0u; V.n_wc = tables ? static_cast<uint32_t>(loc->d_wc.n) : 0u;
-        V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
+        V.lut = loc->d_lut_ext.p; V.lut2 = reinterpret_cast<const double2*>(loc->d_lut_pair.p); V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
         V.seg_reads = static_cast<uint32_t>(((n_good + INIT_SEGS - 1) / INIT_SEGS + 63) / 64 * 64);      // the parts of a chain's record list
         if (V.seg_reads == 0) V.seg_reads = 64;
@@ -2002,17 +2130,13 @@ struct StageRunner {
     }
 
     // ---- the exact solver (src/solvers/highs.rs:38-134, gurobi.rs:15-83) ----
-    // The reference hands an integer programme to a CPU library: one binary per (non-trivial read, location) with objective
-    // aln_contrib * ln_prob, one-hot depth variables per window with objective depth_contrib * ln_prob(depth), coupling rows; it
-    // asks for the optimum, fails with Error::Solver when the library does not report "optimal", and decodes the assignment by
-    // per-read arg-max. The optimum of that model IS the assignment of largest ReadAssignment::likelihood (assgn.rs:235-237).
-    // Here the model is what solve_init_kernel has just built on the device for the chain (records = the columns of the reads
-    // with their objective and windows after apply_tweak, the window arrays = the depth distributions); it is brought to the host
-    // and solved by branch and bound: depth-first over the non-trivial reads (along the alleles; the location the bound's
-    // multipliers prefer first), starting from the best of a coordinate ascent, pruned by a Lagrangian bound over the window counts
-    // (stated where it is set up below: lo_w is the depth the placed reads give window w, cap_w what the free ones could add).
-    // `node_limit` nodes without a proof of optimality -> LCTY_ERR_SOLVER, as a non-optimal HiGHS status is (highs.rs:113-116).
-    // The assignment goes back into the chain's records, so per-read counts and BAM output see it like any other solver's.
+    // SOLVED ON THE HOST (lcty_exact.cpp: branch and bound under a Lagrangian bound). The model of a chain is what solve_init_kernel has
+    // just built on the device (records = the columns of the reads with their objective and windows after apply_tweak, the window arrays
+    // = the depth distributions); the models of a group of chains are brought to the host, solved by a pool of host threads — one model
+    // per thread at a time, as the reference runs one model per worker (solve.rs:1052-1062) — and the assignments go back into the
+    // chains' records, so per-read counts and BAM output see them like any other solver's. With tweak = 0 apply_tweak draws nothing and
+    // the attempts of a genotype share one model: it is solved once. `node_limit` nodes without a proof of optimality (within the
+    // relative gap the caller allows, HiGHS' mip_rel_gap) -> LCTY_ERR_SOLVER, as a non-optimal HiGHS status is (highs.rs:113-116).
     void solve_exact_batch(uint32_t nch) {
         hipStream_t s = stream;
         uint32_t ovf[2] = {0, 0};
@@ -2020,394 +2144,120 @@ struct StageRunner {
         LCTY_HIP(hipStreamSynchronize(s));
         if (ovf[0]) return;                                                     // run() repeats the batch (wider table / longer runs)
         const uint32_t W = V.wstride;
+        const uint32_t ng = (nch + attempts - 1) / attempts;
         std::vector<uint32_t> nnt(nch), totw(nch), seg(4ull * nch);
-        std::vector<double> aln0(nch), liks(nch);
+        std::vector<double> aln0(nch), liks(nch), parts(4ull * nch, 0.0);
+        std::vector<uint16_t> gids(static_cast<size_t>(ng) * ploidy);
         ws.cnnt.download(nnt.data(), nch, s); ws.ctotw.download(totw.data(), nch, s); ws.cseg.download(seg.data(), 4ull * nch, s);
-        ws.caln.download(aln0.data(), nch, s);
+        ws.caln.download(aln0.data(), nch, s); ws.gt.download(gids.data(), gids.size(), s);
         std::vector<double> pri(gt_per_batch, 0.0);
-        if (V.priors) ws.pri.download(pri.data(), (nch + attempts - 1) / attempts, s);
+        if (V.priors) ws.pri.download(pri.data(), ng, s);
         LCTY_HIP(hipStreamSynchronize(s));
+        const bool shared_model = V.tweak == 0 && attempts > 1;                 // one model per genotype
+        std::vector<uint32_t> todo;                                              // the chains whose model is solved
+        for (uint32_t c = 0; c < nch; c++) if (!shared_model || c % attempts == 0) todo.push_back(c);
+        // a group of models at a time: what the host holds of them (records, runs, window arrays) stays below ~2 GB
+        const size_t model_bytes = static_cast<size_t>(V.rstride) * sizeof(ChainRec) + static_cast<size_t>(V.extra_cap) * sizeof(ExtraLoc) + static_cast<size_t>(W) * 13 + 4096;
+        const size_t group = std::max<size_t>(1, std::min<size_t>(todo.size(), (2ull << 30) / model_bytes));
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t n_threads = static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(ctx->knob("exact_threads", std::min(hw, 64u)), 256)));
+        const int trace = static_cast<int>(ctx->knob("exact_trace", 0));
         std::vector<double> lut;
-        std::vector<ChainRec> recs; std::vector<ExtraLoc> extra; std::vector<double> ww(W); std::vector<uint8_t> gcb(W); std::vector<uint32_t> depth0(W);
-        std::vector<double> parts(4ull * nch, 0.0);
-        for (uint32_t c = 0; c < nch; c++) {
-            const uint32_t n = nnt[c], tw = totw[c];
-            // the chain's model
-            recs.resize(V.rstride); extra.resize(std::max<uint32_t>(V.extra_cap, 1));
-            LCTY_HIP(hipMemcpyAsync(recs.data(), V.recs + static_cast<uint64_t>(c) * V.rstride, V.rstride * sizeof(ChainRec), hipMemcpyDeviceToHost, s));
-            LCTY_HIP(hipMemcpyAsync(extra.data(), V.extra + static_cast<uint64_t>(c) * V.extra_cap, static_cast<size_t>(V.extra_cap) * sizeof(ExtraLoc), hipMemcpyDeviceToHost, s));
-            LCTY_HIP(hipMemcpyAsync(ww.data(), V.c_ww + static_cast<uint64_t>(c) * W, W * sizeof(double), hipMemcpyDeviceToHost, s));
-            LCTY_HIP(hipMemcpyAsync(gcb.data(), V.c_gc + static_cast<uint64_t>(c) * W, W, hipMemcpyDeviceToHost, s));
-            LCTY_HIP(hipMemcpyAsync(depth0.data(), V.c_depth + static_cast<uint64_t>(c) * W, W * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            LCTY_HIP(hipStreamSynchronize(s));
-            struct Loc { double lp; uint32_t wa, wb; };
-            std::vector<uint32_t> first(n + 1, 0), place(n);
-            std::vector<Loc> locs;
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t* cum = &seg[4ull * c];
-                const uint32_t k = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
-                place[i] = i - cum[k] + k * V.seg_reads;
-                const ChainRec& r = recs[place[i]];
-                const uint32_t nloc = r.meta & 0xFFu, eix = r.meta >> 8;
-                first[i] = static_cast<uint32_t>(locs.size());
-                for (uint32_t t = 0; t < nloc; t++) {
-                    if (t == 0) locs.push_back({r.lp0, r.win0 & 0xFFFFu, r.win0 >> 16});
-                    else if (t == 1) locs.push_back({r.lp1, r.win1 & 0xFFFFu, r.win1 >> 16});
-                    else { const ExtraLoc& e = extra[eix + t - 2]; locs.push_back({e.lp, e.win & 0xFFFFu, e.win >> 16}); }
-                }
-            }
-            first[n] = static_cast<uint32_t>(locs.size());
-            // depths without the non-trivial reads (they all start at their location 0: best_start), and what they could add
-            std::vector<int64_t> lo(tw, 0);
-            for (uint32_t w = 0; w < tw; w++) lo[w] = depth0[w];
-            double aln_fixed = aln0[c];
-            for (uint32_t i = 0; i < n; i++) { const Loc& l0 = locs[first[i]]; lo[l0.wa]--; lo[l0.wb]--; aln_fixed -= l0.lp; }
-            std::vector<uint32_t> cap(tw, 0);
-            auto mult = [](const Loc& l, uint32_t w) -> uint32_t { return (l.wa == w ? 1u : 0u) + (l.wb == w ? 1u : 0u); };
-            // windows a read can touch, with the largest multiplicity over its locations
-            std::vector<std::vector<std::pair<uint32_t, uint32_t>>> touch(n);
-            for (uint32_t i = 0; i < n; i++) {
-                for (uint32_t t = first[i]; t < first[i + 1]; t++)
-                    for (uint32_t w : {locs[t].wa, locs[t].wb}) {
-                        auto it = std::find_if(touch[i].begin(), touch[i].end(), [&](const std::pair<uint32_t, uint32_t>& x) { return x.first == w; });
-                        const uint32_t m = mult(locs[t], w);
-                        if (it == touch[i].end()) touch[i].push_back({w, m}); else it->second = std::max(it->second, m);
-                    }
-                for (auto& x : touch[i]) cap[x.first] += x.second;
-            }
+        struct Held { std::vector<ChainRec> recs; std::vector<uint32_t> place; exact::Model model; exact::Result res; };
+        for (size_t g0 = 0; g0 < todo.size(); g0 += group) {
+            const size_t gn = std::min(group, todo.size() - g0);
+            std::vector<Held> held(gn);
+            std::vector<ExtraLoc> extra(std::max<uint32_t>(V.extra_cap, 1));
+            std::vector<uint32_t> depth0(W);
             uint64_t need = 0;
-            for (uint32_t w = 0; w < tw; w++) need = std::max<uint64_t>(need, static_cast<uint64_t>(lo[w]) + cap[w] + 1);
-            if (need > loc->lut_ext_depth) { ensure_depth_table(loc, std::min<uint64_t>(need, depth_cap)); V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; lut.clear(); }
+            for (size_t k = 0; k < gn; k++) {
+                const uint32_t c = todo[g0 + k], n = nnt[c], tw = totw[c];
+                Held& h = held[k];
+                exact::Model& m = h.model;
+                h.recs.resize(V.rstride); m.ww.resize(W); m.gcb.resize(W);
+                LCTY_HIP(hipMemcpyAsync(h.recs.data(), V.recs + static_cast<uint64_t>(c) * V.rstride, V.rstride * sizeof(ChainRec), hipMemcpyDeviceToHost, s));
+                LCTY_HIP(hipMemcpyAsync(extra.data(), V.extra + static_cast<uint64_t>(c) * V.extra_cap, static_cast<size_t>(V.extra_cap) * sizeof(ExtraLoc), hipMemcpyDeviceToHost, s));
+                LCTY_HIP(hipMemcpyAsync(m.ww.data(), V.c_ww + static_cast<uint64_t>(c) * W, W * sizeof(double), hipMemcpyDeviceToHost, s));
+                LCTY_HIP(hipMemcpyAsync(m.gcb.data(), V.c_gc + static_cast<uint64_t>(c) * W, W, hipMemcpyDeviceToHost, s));
+                LCTY_HIP(hipMemcpyAsync(depth0.data(), V.c_depth + static_cast<uint64_t>(c) * W, W * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                LCTY_HIP(hipStreamSynchronize(s));
+                m.n = n; m.tw = tw; m.aln0 = aln0[c];
+                m.ww.resize(tw); m.gcb.resize(tw); m.depth0.assign(depth0.begin(), depth0.begin() + tw);
+                m.first.assign(n + 1, 0); h.place.resize(n);
+                const uint32_t* cum = &seg[4ull * c];
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t q = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+                    h.place[i] = i - cum[q] + q * V.seg_reads;
+                    const ChainRec& r = h.recs[h.place[i]];
+                    const uint32_t nloc = r.meta & 0xFFu, eix = r.meta >> 8;
+                    m.first[i] = static_cast<uint32_t>(m.locs.size());
+                    for (uint32_t t = 0; t < nloc; t++) {
+                        if (t == 0) m.locs.push_back({r.lp0, r.win0 & 0xFFFFu, r.win0 >> 16});
+                        else if (t == 1) m.locs.push_back({r.lp1, r.win1 & 0xFFFFu, r.win1 >> 16});
+                        else { const ExtraLoc& e = extra[eix + t - 2]; m.locs.push_back({e.lp, e.win & 0xFFFFu, e.win >> 16}); }
+                    }
+                }
+                m.first[n] = static_cast<uint32_t>(m.locs.size());
+                m.allele_first_w.assign(1, 2u);
+                for (uint32_t q = 0; q < ploidy; q++)
+                    m.allele_first_w.push_back(m.allele_first_w.back() + loc->n_windows[gids[static_cast<size_t>(c / attempts) * ploidy + q]]);
+                m.aln_contrib = V.aln_contrib; m.depth_contrib = V.depth_contrib;
+                m.node_limit = V.solver.node_limit ? V.solver.node_limit : 20ull * 1000 * 1000;
+                m.rel_gap = V.solver.init_prob > 0.0 && V.solver.init_prob < 1.0 ? V.solver.init_prob : 0.0;
+                m.chain = c; m.trace = trace; m.gc_bins = LCTY_GC_BINS;
+                if (c == 0) m.dump_path = ctx->exact_dump_path;
+                need = std::max(need, exact::depth_needed(m));
+            }
+            if (need > loc->lut_ext_depth) {
+                std::lock_guard<std::mutex> ws_lock(ctx->ws_mutex);             // the other lane of a queue may be sizing its own stage
+                ensure_depth_table(loc, std::min<uint64_t>(need, depth_cap));
+                V.lut = loc->d_lut_ext.p; V.lut2 = reinterpret_cast<const double2*>(loc->d_lut_pair.p); V.lut_depth = loc->lut_ext_depth; lut.clear();
+            }
             if (lut.empty()) {
                 lut.resize(static_cast<size_t>(LCTY_GC_BINS) * loc->lut_ext_depth);
                 loc->d_lut_ext.download(lut.data(), lut.size(), s);
                 LCTY_HIP(hipStreamSynchronize(s));
             }
             const uint32_t ld = loc->lut_ext_depth;
-            auto v = [&](uint32_t w, int64_t d) -> double {                   // WindowDistr::ln_prob (distr_cache.rs:34-39)
-                return ww[w] == 0.0 ? 0.0 : ww[w] * lut[static_cast<size_t>(gcb[w]) * ld + static_cast<size_t>(d)];
-            };
-            // Reads that cannot be anywhere but at their best location in an optimum: moving read i from its best location to another one
-            // gains at most depth_contrib * (the largest rise any feasible depth allows the windows it leaves and the windows it enters)
-            // and loses aln_contrib * (lp_best - lp_other); when the loss is larger for every other location, any assignment with the
-            // read elsewhere is improved by moving it back. Such reads are fixed (they count as depth the others see), which narrows the
-            // depth ranges and may fix more: repeated until nothing changes. At 1 % divergence between two alleles 19 of 20 read pairs
-            // cover a difference and have a clear best location; what stays free are the pairs that match both alleles alike.
-            std::vector<uint8_t> fixed(n, 0);
-            auto rise = [&](uint32_t w, int dir) -> double {                   // max over feasible depths of v(d + dir) - v(d)
-                if (ww[w] == 0.0) return 0.0;
-                double m = -INFINITY;
-                const int64_t d_lo = lo[w] + (dir < 0 ? 1 : 0), d_hi = lo[w] + cap[w] - (dir > 0 ? 1 : 0);
-                for (int64_t d = d_lo; d <= d_hi; d++) m = std::max(m, v(w, d + dir) - v(w, d));
-                return m == -INFINITY ? 0.0 : m;
-            };
-            for (bool again = true; again;) {
-                again = false;
-                for (uint32_t i = 0; i < n; i++) {
-                    if (fixed[i]) continue;
-                    const Loc& b0 = locs[first[i]];
-                    bool dominated = true;
-                    for (uint32_t t = first[i] + 1; t < first[i + 1] && dominated; t++) {
-                        const Loc& o = locs[t];
-                        // leaving b0's windows (their depth with the read there is >= lo + its share), entering o's; windows shared by
-                        // both locations cancel in the worst case as well: bounding them separately only loosens the bound
-                        double gain = rise(b0.wa, -1) + rise(b0.wb, -1) + rise(o.wa, 1) + rise(o.wb, 1);
-                        if (b0.wa == b0.wb) gain = std::max(gain, 2.0 * rise(b0.wa, -1) + rise(o.wa, 1) + rise(o.wb, 1));
-                        if (o.wa == o.wb) gain = std::max(gain, rise(b0.wa, -1) + rise(b0.wb, -1) + 2.0 * rise(o.wa, 1));
-                        if (!(V.aln_contrib * (b0.lp - o.lp) > V.depth_contrib * gain + 1e-9)) dominated = false;
-                    }
-                    if (dominated) {
-                        fixed[i] = 1; again = true;
-                        for (auto& x : touch[i]) cap[x.first] -= x.second;
-                        lo[b0.wa]++; lo[b0.wb]++;
-                        aln_fixed += b0.lp;
-                    }
-                }
+            // the pool: a worker takes the next model of the group (the largest first would balance better; the models of a stage are alike)
+            std::atomic<size_t> next{0};
+            auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < gn;) exact::solve(held[k].model, lut.data(), ld, held[k].res); };
+            const uint32_t nt = static_cast<uint32_t>(std::min<size_t>(n_threads, gn));
+            if (nt <= 1) work();
+            else {
+                std::vector<std::thread> pool;
+                for (uint32_t t = 0; t < nt; t++) pool.emplace_back(work);
+                for (auto& th : pool) th.join();
             }
-            // order of the free reads: along the alleles (a window all of whose reads are placed has its exact term in the bound: a
-            // wrong choice shows a few reads later, not at the end), reads of one place by the spread of their ln-probabilities
-            std::vector<uint32_t> order;
-            for (uint32_t i = 0; i < n; i++) if (!fixed[i]) order.push_back(i);
-            auto place_of = [&](uint32_t i) { uint32_t m = 0xFFFFFFFFu; for (uint32_t t = first[i]; t < first[i + 1]; t++) for (uint32_t w : {locs[t].wa, locs[t].wb}) if (w >= 2) m = std::min(m, w); return m; };
-            // windows of the alleles of a genotype lie one allele after the other: the place along the locus is the window index inside its allele
-            std::vector<uint32_t> allele_first_w(1, 2u);
-            {
-                const uint32_t gi = c / attempts;
-                std::vector<uint16_t> ids(ploidy);
-                ws.gt.download(ids.data(), ploidy, s, static_cast<uint64_t>(gi) * ploidy);
-                LCTY_HIP(hipStreamSynchronize(s));
-                for (uint32_t q = 0; q < ploidy; q++) allele_first_w.push_back(allele_first_w.back() + loc->n_windows[ids[q]]);
+            for (size_t k = 0; k < gn; k++) {
+                const Held& h = held[k];
+                if (h.res.out_of_nodes)
+                    fail(LCTY_ERR_SOLVER, "Exact solver: no proof of optimality within %llu nodes (%u non-trivial reads, %u of them free after fixing the dominated ones); Model finished with non-optimal status NodeLimit",
+                         static_cast<unsigned long long>(h.model.node_limit), h.model.n, h.res.n_free);
             }
-            auto along = [&](uint32_t w) { uint32_t q = 0; while (q + 1 < allele_first_w.size() && w >= allele_first_w[q + 1]) q++; return w - allele_first_w[q]; };
-            std::vector<uint32_t> key(n, 0);
-            for (uint32_t i : order) { const uint32_t w = place_of(i); key[i] = w == 0xFFFFFFFFu ? 0u : along(w); }
-            auto spread = [&](uint32_t i) { return locs[first[i]].lp - locs[first[i + 1] - 1].lp; };
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : spread(a) > spread(b); });
-            uint32_t n_free = static_cast<uint32_t>(order.size());
-            // incumbent: coordinate ascent from the best start (every read at its location 0)
-            std::vector<uint8_t> assign(n, 0), best_assign;
-            std::vector<int64_t> dep(lo);
-            for (uint32_t i : order) { dep[locs[first[i]].wa]++; dep[locs[first[i]].wb]++; }
-            std::vector<int64_t> base_depth(lo);                              // `lo` moves with the search; a leaf is valued from here
-            auto total = [&](const std::vector<uint8_t>& a, double* depth_lik, double* aln_lik) {
-                std::vector<int64_t> d(base_depth);
-                double al = aln_fixed;
-                for (uint32_t i : order) { const Loc& l = locs[first[i] + a[i]]; d[l.wa]++; d[l.wb]++; al += l.lp; }
-                double dl = 0.0;
-                for (uint32_t w = 0; w < tw; w++) dl += v(w, d[w]);
-                *depth_lik = dl; *aln_lik = al;
-                return V.depth_contrib * dl + V.aln_contrib * al;
-            };
-            auto ascend = [&](std::vector<uint8_t>& assign, std::vector<int64_t>& dep) {
-            for (bool improved = true; improved;) {
-                improved = false;
-                for (uint32_t i : order) {
-                    const Loc& cur = locs[first[i] + assign[i]];
-                    double best_gain = 1e-12; uint32_t best_t = assign[i];
-                    for (uint32_t t = 0; t < first[i + 1] - first[i]; t++) {
-                        if (t == assign[i]) continue;
-                        const Loc& alt = locs[first[i] + t];
-                        std::pair<uint32_t, int> ch[4] = {{cur.wa, -1}, {cur.wb, -1}, {alt.wa, 1}, {alt.wb, 1}};
-                        double gain = V.aln_contrib * (alt.lp - cur.lp), dd = 0.0;
-                        for (int x = 0; x < 4; x++) {
-                            bool seen = false; int delta = 0;
-                            for (int y = 0; y < 4; y++) if (ch[y].first == ch[x].first) { if (y < x) seen = true; delta += ch[y].second; }
-                            if (!seen && delta) dd += v(ch[x].first, dep[ch[x].first] + delta) - v(ch[x].first, dep[ch[x].first]);
-                        }
-                        gain += V.depth_contrib * dd;
-                        if (gain > best_gain) { best_gain = gain; best_t = t; }
-                    }
-                    if (best_t != assign[i]) {
-                        const Loc& alt = locs[first[i] + best_t];
-                        dep[cur.wa]--; dep[cur.wb]--; dep[alt.wa]++; dep[alt.wb]++;
-                        assign[i] = static_cast<uint8_t>(best_t); improved = true;
-                    }
+            // the assignments back into the records (of every attempt that shares the model: same reads at the same places, only the
+            // runs of further locations are laid out per chain, so only the `cur` words travel); the likelihood as ReadAssignment::likelihood sums it
+            DevBuf<uint32_t> d_words;
+            d_words.alloc(V.rstride);
+            std::vector<uint32_t> words(V.rstride);
+            for (size_t k = 0; k < gn; k++) {
+                Held& h = held[k];
+                const uint32_t c0 = todo[g0 + k];
+                for (uint64_t j = 0; j < V.rstride; j++) words[j] = h.recs[j].rp_cur;
+                for (uint32_t i = 0; i < h.model.n; i++) words[h.place[i]] = (words[h.place[i]] & 0xFFFFFFu) | (static_cast<uint32_t>(h.res.assign[i]) << 24);
+                d_words.upload(words.data(), V.rstride, s);
+                const uint32_t c1 = shared_model ? std::min(c0 + attempts, nch) : c0 + 1;
+                for (uint32_t c = c0; c < c1; c++) {
+                    if (nnt[c] != h.model.n) fail(LCTY_ERR_RUNTIME, "exact solver: the attempts of a genotype without a tweak differ in their models");
+                    hipLaunchKernelGGL(store_cur_kernel, dim3(static_cast<uint32_t>((V.rstride + 255) / 256)), dim3(256), 0, s,
+                                       V.recs + static_cast<uint64_t>(c) * V.rstride, d_words.p, V.rstride);
+                    LCTY_HIP(hipGetLastError());
+                    liks[c] = pri[c / attempts] + h.res.value;
+                    parts[4ull * c] = h.res.aln_lik; parts[4ull * c + 1] = h.res.depth_lik; parts[4ull * c + 2] = static_cast<double>(h.res.nodes); parts[4ull * c + 3] = 0.0;
                 }
+                LCTY_HIP(hipStreamSynchronize(s));                              // `words` is filled again for the next model
             }
-            };
-            ascend(assign, dep);
-            double dl_best, al_best;
-            double incumbent = total(assign, &dl_best, &al_best);
-            best_assign = assign;
-            // branch and bound
-            const uint64_t node_limit = V.solver.node_limit ? V.solver.node_limit : 20ull * 1000 * 1000;
-            uint64_t nodes = 0;
-            bool out_of_nodes = false;
-            // The bound. With a multiplier lam_w per window the objective of any completion of the free reads is at most
-            //     aln_contrib * (ln_prob placed so far) + sum over the free reads of max_t [aln_contrib * lp_t + lam over t's windows]
-            //       + sum over the windows of max_{k in [0, cap_w]} [depth_contrib * v_w(lo_w + k) - lam_w * k]
-            // (add and subtract lam_w x what the free reads put into window w); lam = 0 is "every free read at its best location, every window
-            // at the best depth its reads could give it". The multipliers are set once, at the root, by subgradient steps that lower the
-            // bound (Polyak steps towards the incumbent), and every node is bounded with them: at 10 000 read pairs the root gap falls
-            // from 1.6e-2 to 6e-4 (scripts/exact_lagrangian_probe.py). The rounded multiplier solutions also feed the incumbent.
-            std::vector<double> lam(tw, 0.0);
-            auto wterm = [&](uint32_t w) -> double {
-                if (ww[w] == 0.0) return 0.0;                                  // a window without a distribution keeps lam_w = 0
-                double m = -INFINITY; const double lw = lam[w];
-                for (int64_t k = 0; k <= static_cast<int64_t>(cap[w]); k++) m = std::max(m, V.depth_contrib * v(w, lo[w] + k) - lw * static_cast<double>(k));
-                return m;
-            };
-            auto rterm = [&](uint32_t i, uint32_t* arg) -> double {
-                double m = -INFINITY;
-                for (uint32_t t = first[i]; t < first[i + 1]; t++) {
-                    const double x = V.aln_contrib * locs[t].lp + lam[locs[t].wa] + lam[locs[t].wb];
-                    if (x > m) { m = x; if (arg) *arg = t - first[i]; }
-                }
-                return m;
-            };
-            // ... and reads are fixed by probing: with the bound UB at the multipliers found, a solution that has read i at location t scores at
-            // most UB - (the read's best term) + (the bound's terms with the read placed at t); when that is below the incumbent for every
-            // location but the incumbent's own, the read stays there in every better solution. Fixed reads make the windows' ranges narrower, the bound
-            // tighter, and the next round fixes more: at 10 000 read pairs all but a few hundred of the 7 800 free reads.
-            for (uint32_t round = 0; round < 12 && n_free > 12; round++) {
-                std::vector<double> best_lam(lam), g(tw), cnt(tw);
-                std::vector<uint8_t> pick(best_assign);
-                double best_ub = INFINITY, theta = 1.0; uint32_t stall = 0;
-                const uint32_t iters = static_cast<uint32_t>(std::min<uint64_t>(3000, 400 + n_free / 2));
-                for (uint32_t it = 0; it < iters; it++) {
-                    std::fill(cnt.begin(), cnt.end(), 0.0);
-                    double ub = V.aln_contrib * aln_fixed;
-                    for (uint32_t i : order) {
-                        uint32_t t = 0;
-                        ub += rterm(i, &t);
-                        pick[i] = static_cast<uint8_t>(t);
-                        const Loc& l = locs[first[i] + t]; cnt[l.wa] += 1.0; cnt[l.wb] += 1.0;
-                    }
-                    double norm = 0.0;
-                    for (uint32_t w = 0; w < tw; w++) {
-                        g[w] = 0.0;
-                        if (ww[w] == 0.0) continue;
-                        double m = -INFINITY; int64_t kbest = 0;
-                        for (int64_t k = 0; k <= static_cast<int64_t>(cap[w]); k++) {
-                            const double x = V.depth_contrib * v(w, lo[w] + k) - lam[w] * static_cast<double>(k);
-                            if (x > m) { m = x; kbest = k; }
-                        }
-                        ub += m;
-                        g[w] = cnt[w] - static_cast<double>(kbest);
-                        norm += g[w] * g[w];
-                    }
-                    if (ub < best_ub - 1e-9) { best_ub = ub; best_lam = lam; stall = 0; }
-                    else if (++stall >= 20) { theta *= 0.7; stall = 0; }
-                    if (it % 25 == 0) {                                         // the multipliers' own choice of locations as a start of the ascent
-                        std::vector<uint8_t> from(pick);
-                        std::vector<int64_t> d2(base_depth);
-                        for (uint32_t i : order) { const Loc& l = locs[first[i] + from[i]]; d2[l.wa]++; d2[l.wb]++; }
-                        ascend(from, d2);
-                        double dl, al;
-                        const double val = total(from, &dl, &al);
-                        if (val > incumbent) { incumbent = val; best_assign = from; dl_best = dl; al_best = al; }
-                    }
-                    if (norm == 0.0 || theta < 1e-6) break;
-                    const double step = theta * (ub - incumbent) / norm;
-                    for (uint32_t w = 0; w < tw; w++) lam[w] -= step * g[w];
-                }
-                lam = best_lam;
-                // reduced-cost fixing at these multipliers
-                double ub = V.aln_contrib * aln_fixed;
-                std::vector<double> rbest(n, 0.0);
-                for (uint32_t i : order) { rbest[i] = rterm(i, nullptr); ub += rbest[i]; }
-                for (uint32_t w = 0; w < tw; w++) ub += wterm(w);
-                const double floor_val = incumbent - (1e-9 * std::fabs(incumbent) + 1e-9);
-                std::vector<uint32_t> still;
-                uint32_t newly = 0;
-                for (uint32_t i : order) {
-                    const uint32_t b = best_assign[i];
-                    bool only = true;
-                    for (uint32_t t = first[i]; t < first[i + 1] && only; t++) {
-                        if (t - first[i] == b) continue;
-                        // the bound with the read AT t (what the search computes one level down): its ln-probability, and the windows it can
-                        // touch with the read counted where t puts it and no longer among what the free reads could add — never above
-                        // the reduced-cost form "the read's term at t" (a window's term falls by at least lam x what the read adds)
-                        double x = V.aln_contrib * locs[t].lp;
-                        for (auto& tw_ : touch[i]) {
-                            const uint32_t w = tw_.first;
-                            if (ww[w] == 0.0) continue;
-                            const int64_t add = static_cast<int64_t>(mult(locs[t], w)), room = static_cast<int64_t>(cap[w]) - tw_.second;
-                            double m = -INFINITY; const double lw = lam[w];
-                            for (int64_t k = 0; k <= room; k++) m = std::max(m, V.depth_contrib * v(w, lo[w] + add + k) - lw * static_cast<double>(k));
-                            x += m - wterm(w);
-                        }
-                        if (!(ub - rbest[i] + x < floor_val)) only = false;
-                    }
-                    if (!only) { still.push_back(i); continue; }
-                    const Loc& l = locs[first[i] + b];
-                    fixed[i] = 2; newly++;
-                    for (auto& x : touch[i]) cap[x.first] -= x.second;
-                    lo[l.wa]++; lo[l.wb]++; base_depth[l.wa]++; base_depth[l.wb]++;
-                    aln_fixed += l.lp;
-                }
-                order.swap(still);
-                n_free = static_cast<uint32_t>(order.size());
-                if (ctx->knob("exact_trace", 0))
-                    fprintf(stderr, "[lcty exact] chain %u round %u: bound %.6f, incumbent %.6f, %u reads fixed by reduced costs, %u free\n", c, round, ub, incumbent, newly, n_free);
-                if (newly == 0) break;
-            }
-            std::vector<double> rmax(n, 0.0);
-            std::vector<uint8_t> first_try(n, 0);                              // the location the multipliers prefer is explored first
-            double free_best = 0.0;                                            // sum over the free reads of their terms of the bound
-            for (uint32_t i : order) { uint32_t t = 0; rmax[i] = rterm(i, &t); first_try[i] = static_cast<uint8_t>(t); free_best += rmax[i]; }
-            auto explored = [&](uint32_t i, uint32_t e) -> uint32_t { return e == 0 ? first_try[i] : (e - 1 < first_try[i] ? e - 1 : e); };
-            double aln_sum = aln_fixed, win_sum = 0.0;
-            std::vector<double> wmax(tw);
-            for (uint32_t w = 0; w < tw; w++) { wmax[w] = wterm(w); win_sum += wmax[w]; }
-            // HiGHS stops a search — and reports "optimal" — when the bound of what is left is within mip_rel_gap (1e-4 by default) of the
-            // incumbent; the reference leaves that option alone (highs.rs:103-110). Here the gap is the caller's (lcty_solver.init_prob
-            // for this kind; 0 = a proof of optimality): subtrees that cannot beat the incumbent by more than it are left out.
-            const double rel_gap = V.solver.init_prob > 0.0 && V.solver.init_prob < 1.0 ? V.solver.init_prob : 0.0;
-            const double root_bound = V.aln_contrib * aln_sum + free_best + win_sum;
-            if (ctx->knob("exact_trace", 0) == 2 && c == 0 && getenv("LCTY_EXACT_DUMP")) {
-                // developer dump of the chain's model into the file the environment names (scripts/exact_probe.py --dump): text, one item per line
-                FILE* f = fopen(getenv("LCTY_EXACT_DUMP"), "w");
-                if (f) {
-                    fprintf(f, "%u %u %u %.17g %.17g %.17g\n", n, tw, ld, V.aln_contrib, V.depth_contrib, aln_fixed);
-                    for (uint32_t w = 0; w < tw; w++) fprintf(f, "W %lld %u %.17g %u\n", static_cast<long long>(base_depth[w]), cap[w], ww[w], static_cast<unsigned>(gcb[w]));
-                    for (uint32_t i = 0; i < n; i++) {
-                        fprintf(f, "R %u %u", static_cast<unsigned>(fixed[i]), first[i + 1] - first[i]);
-                        for (uint32_t t = first[i]; t < first[i + 1]; t++) fprintf(f, " %.17g %u %u", locs[t].lp, locs[t].wa, locs[t].wb);
-                        fprintf(f, "\n");
-                    }
-                    for (uint32_t g = 0; g < LCTY_GC_BINS; g++) {
-                        bool used = false;
-                        for (uint32_t w = 0; w < tw; w++) used |= ww[w] != 0.0 && gcb[w] == g;
-                        if (!used) continue;
-                        fprintf(f, "L %u", g);
-                        for (uint32_t d = 0; d < ld; d++) fprintf(f, " %.17g", lut[static_cast<size_t>(g) * ld + d]);
-                        fprintf(f, "\n");
-                    }
-                    fprintf(f, "I %.17g\n", incumbent);
-                    fclose(f);
-                }
-            }
-            if (ctx->knob("exact_trace", 0))
-                fprintf(stderr, "[lcty exact] chain %u: %u non-trivial reads, %u free; incumbent %.6f, root bound %.6f (gap %.3e relative)\n", c, n, n_free,
-                        incumbent, root_bound, (root_bound - incumbent) / std::fabs(incumbent));
-            // depth-first, iterative (a locus can have many thousands of non-trivial reads: no recursion)
-            std::vector<uint8_t> cur_assign(best_assign), entered(n, 0), applied(n, 0);      // the reads fixed above keep their locations
-            std::vector<uint32_t> next_t(n, 0);
-            std::vector<double> keep_ws(n), keep_al(n);
-            std::vector<std::vector<std::pair<uint32_t, double>>> saved(n);
-            int64_t level = 0;
-            while (level >= 0 && n_free) {
-                if (static_cast<uint32_t>(level) == n_free) {                  // a leaf: the value as ReadAssignment::likelihood sums it
-                    if (++nodes > node_limit) out_of_nodes = true;
-                    double dl, al;
-                    const double val = total(cur_assign, &dl, &al);
-                    if (val > incumbent) { incumbent = val; best_assign = cur_assign; dl_best = dl; al_best = al; }
-                    level--;
-                    continue;
-                }
-                const uint32_t i = order[level], nloc = first[i + 1] - first[i];
-                if (!entered[level]) {
-                    // the read leaves the free set: what it could have added to its windows goes, its best ln-probability too
-                    if (++nodes > node_limit) out_of_nodes = true;
-                    entered[level] = 1; applied[level] = 0; next_t[level] = 0;
-                    for (auto& x : touch[i]) cap[x.first] -= x.second;
-                    free_best -= rmax[i];
-                }
-                if (applied[level]) {                                           // back from (or past) the location tried last
-                    const Loc& l = locs[first[i] + explored(i, next_t[level] - 1)];
-                    for (auto& sv : saved[level]) wmax[sv.first] = sv.second;
-                    lo[l.wa]--; lo[l.wb]--;
-                    win_sum = keep_ws[level]; aln_sum = keep_al[level];
-                    applied[level] = 0;
-                }
-                if (next_t[level] == nloc || out_of_nodes) {
-                    free_best += rmax[i];
-                    for (auto& x : touch[i]) cap[x.first] += x.second;
-                    entered[level] = 0;
-                    level--;
-                    continue;
-                }
-                const uint32_t t = explored(i, next_t[level]++);
-                const Loc& l = locs[first[i] + t];
-                lo[l.wa]++; lo[l.wb]++;
-                saved[level].clear();
-                double ws_new = win_sum;
-                for (auto& x : touch[i]) {
-                    const double m = wterm(x.first);
-                    saved[level].push_back({x.first, wmax[x.first]});
-                    ws_new += m - wmax[x.first]; wmax[x.first] = m;
-                }
-                applied[level] = 1; keep_ws[level] = win_sum; keep_al[level] = aln_sum;
-                const double bound = V.aln_contrib * (aln_sum + l.lp) + free_best + ws_new;
-                // a subtree is left out when it cannot beat the incumbent by more than the rounding of two long sums
-                if (bound > incumbent + std::max(rel_gap, 1e-12) * std::fabs(incumbent) + 1e-10) {
-                    win_sum = ws_new; aln_sum += l.lp; cur_assign[i] = static_cast<uint8_t>(t);
-                    level++;
-                }
-            }
-            if (out_of_nodes)
-                fail(LCTY_ERR_SOLVER, "Exact solver: no proof of optimality within %llu nodes (%u non-trivial reads, %u of them free after fixing the dominated ones); Model finished with non-optimal status NodeLimit",
-                     static_cast<unsigned long long>(node_limit), n, n_free);
-            // the assignment back into the records; the likelihood as ReadAssignment::likelihood sums it
-            for (uint32_t i = 0; i < n; i++) {
-                ChainRec& r = recs[place[i]];
-                r.rp_cur = (r.rp_cur & 0xFFFFFFu) | (static_cast<uint32_t>(best_assign[i]) << 24);
-            }
-            LCTY_HIP(hipMemcpyAsync(V.recs + static_cast<uint64_t>(c) * V.rstride, recs.data(), V.rstride * sizeof(ChainRec), hipMemcpyHostToDevice, s));
-            LCTY_HIP(hipStreamSynchronize(s));
-            liks[c] = pri[c / attempts] + incumbent;
-            parts[4ull * c] = al_best; parts[4ull * c + 1] = dl_best; parts[4ull * c + 2] = static_cast<double>(nodes); parts[4ull * c + 3] = 0.0;
+            LCTY_HIP(hipStreamSynchronize(s));                                  // the records leave `held` with the group
         }
         ws.liks.upload(liks.data(), nch, s);
         ws.parts.upload(parts.data(), 4ull * nch, s);
@@ -2425,7 +2275,7 @@ struct StageRunner {
             if (priors) ws.pri.upload(priors + g0, ng, s);
             V.priors = priors ? ws.pri.p : nullptr;
             for (;;) {
-                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth));
+                V.lut = loc->d_lut_ext.p; V.lut2 = reinterpret_cast<const double2*>(loc->d_lut_pair.p); V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth));
                 launch(static_cast<uint32_t>(nch));
                 uint32_t ovf[2] = {0, 0};
                 ws.ovf.download(ovf, 2, s);
@@ -2666,7 +2516,7 @@ int32_t lcty_solver_default(lcty_solver* s, int32_t kind) {
         s->kind = kind; s->best_start = 1; s->sample_size = 10;
         s->plato_size = kind == LCTY_SOLVER_GREEDY ? 100 : 10000;
         s->node_limit = kind == LCTY_SOLVER_EXACT ? 20u * 1000u * 1000u : 0u;
-        s->anneal_steps = 20000; s->init_prob = kind == LCTY_SOLVER_EXACT ? 0.0 : 0.5;      // exact: the relative gap of the proof (0 = optimal)
+        s->anneal_steps = 20000; s->init_prob = kind == LCTY_SOLVER_EXACT ? 1e-4 : 0.5;      // exact: the relative gap at which the search stops = HiGHS' default mip_rel_gap, which the reference leaves alone (highs.rs:103-110); 0 = a proof of optimality
     });
 }
 

@@ -138,6 +138,9 @@ struct orc_gt_alns {
     uint32_t total_windows;
     uint8_t* w_gc; double* w_weight;          /* depth_distrs after apply_tweak */
     double depth_contrib, aln_contrib;
+    /* capacities of the arrays above: a worker of orc_solve_stage refills ONE object for the genotypes of its run (orc_gt_alns_fill)
+     * instead of allocating ~100 B per read pair and genotype anew — 128 workers doing that at once spend their time in page faults */
+    uint64_t cap_alns, cap_reads; uint32_t cap_windows;
 };
 
 typedef struct { gt_aln a; uint32_t order; } tmp_loc;
@@ -147,10 +150,10 @@ static int cmp_loc(const void* x, const void* y) {
     return a->order < b->order ? -1 : (a->order > b->order ? 1 : 0);
 }
 
-orc_gt_alns* orc_gt_alns_new(const orc_locus* l, const orc_alns* A, const uint16_t* ids, uint32_t ploidy) {
-    if (ploidy == 0 || ploidy > 16) return NULL;
-    orc_gt_alns* g = (orc_gt_alns*)calloc(1, sizeof(*g));
+/* GenotypeAlignments::new (assgn.rs:41-84) into `g`, whose arrays are kept and grown as needed */
+static void orc_gt_alns_fill(orc_gt_alns* g, const orc_locus* l, const orc_alns* A, const uint16_t* ids, uint32_t ploidy) {
     g->l = l; g->ploidy = ploidy;
+    g->n_alns = 0; g->n_nontrivial = 0;
     /* GenotypeWindows::new — windows.rs:721-739 */
     uint32_t shift = 2;                                     /* REG_WINDOW_SHIFT */
     g->wshifts[0] = shift;
@@ -160,15 +163,28 @@ orc_gt_alns* orc_gt_alns_new(const orc_locus* l, const orc_alns* A, const uint16
         g->wshifts[i + 1] = shift;
     }
     g->total_windows = shift;
-    g->w_gc = (uint8_t*)calloc(shift, 1);
-    g->w_weight = (double*)calloc(shift, sizeof(double));
+    if (shift > g->cap_windows) {
+        free(g->w_gc); free(g->w_weight);
+        g->w_gc = (uint8_t*)malloc(shift); g->w_weight = (double*)malloc(sizeof(double) * shift);
+        g->cap_windows = shift;
+    }
+    memset(g->w_gc, 0, shift); memset(g->w_weight, 0, sizeof(double) * shift);
     g->aln_contrib = 1.0 - l->prm.lik_skew;                 /* assgn.rs:80-81 */
     g->depth_contrib = 1.0 + l->prm.lik_skew;
     g->n_reads = A->n_good;
-    g->read_ixs = (uint64_t*)calloc(A->n_good + 1, sizeof(uint64_t));
-    g->non_trivial = (uint64_t*)malloc(sizeof(uint64_t) * (A->n_good ? A->n_good : 1));
-    uint64_t cap = A->n_good * (ploidy + 1) + 16;
-    g->alns = (gt_aln*)malloc(sizeof(gt_aln) * cap);
+    if (A->n_good + 1 > g->cap_reads) {
+        free(g->read_ixs); free(g->non_trivial);
+        g->read_ixs = (uint64_t*)malloc(sizeof(uint64_t) * (A->n_good + 1));
+        g->non_trivial = (uint64_t*)malloc(sizeof(uint64_t) * (A->n_good ? A->n_good : 1));
+        g->cap_reads = A->n_good + 1;
+    }
+    g->read_ixs[0] = 0;
+    uint64_t cap = g->cap_alns;
+    if (cap < A->n_good * (ploidy + 1) + 16) {
+        cap = A->n_good * (ploidy + 1) + 16;
+        free(g->alns);
+        g->alns = (gt_aln*)malloc(sizeof(gt_aln) * cap);
+    }
     tmp_loc* tmp = NULL; size_t tmp_cap = 0;
     const double prob_diff = l->prm.prob_diff;
     uint64_t rp = 0;
@@ -212,6 +228,13 @@ orc_gt_alns* orc_gt_alns_new(const orc_locus* l, const orc_alns* A, const uint16
         rp++;
     }
     free(tmp);
+    g->cap_alns = cap;
+}
+
+orc_gt_alns* orc_gt_alns_new(const orc_locus* l, const orc_alns* A, const uint16_t* ids, uint32_t ploidy) {
+    if (ploidy == 0 || ploidy > 16) return NULL;
+    orc_gt_alns* g = (orc_gt_alns*)calloc(1, sizeof(*g));
+    orc_gt_alns_fill(g, l, A, ids, ploidy);
     return g;
 }
 
@@ -574,8 +597,10 @@ void orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* geno
                      const double* priors, const lcty_solver* s, uint32_t attempts, const uint64_t* chain_seeds,
                      double* lik_mean, double* lik_var, double* liks_out) {
     double* liks = (double*)malloc(sizeof(double) * (attempts ? attempts : 1));
+    if (ploidy == 0 || ploidy > 16) { for (uint64_t gi = 0; gi < n_gt; gi++) lik_mean[gi] = lik_var[gi] = NAN; free(liks); return; }
+    orc_gt_alns* g = (orc_gt_alns*)calloc(1, sizeof(*g));       /* this worker's GenotypeAlignments, refilled per genotype */
     for (uint64_t gi = 0; gi < n_gt; gi++) {
-        orc_gt_alns* g = orc_gt_alns_new(l, a, genotypes + gi * ploidy, ploidy);
+        orc_gt_alns_fill(g, l, a, genotypes + gi * ploidy, ploidy);
         const double prior = priors ? priors[gi] : 0.0;
         for (uint32_t at = 0; at < attempts; at++) {
             const uint64_t seed = chain_seeds[gi * attempts + at];
@@ -594,8 +619,8 @@ void orc_solve_stage(const orc_locus* l, const orc_alns* a, const uint16_t* geno
             var = acc / (double)(attempts - 1);
         }
         lik_mean[gi] = mean; lik_var[gi] = var;
-        orc_gt_alns_free(g);
     }
+    orc_gt_alns_free(g);
     free(liks);
 }
 

@@ -7,17 +7,17 @@ from locityper_amd import _lib, api, synth, cdefs
 
 
 def main():
-    gap = 0.0
+    gap = None                                   # the library's default: 1e-4, HiGHS' mip_rel_gap
     if "--gap" in sys.argv:
         gap = float(sys.argv[sys.argv.index("--gap") + 1]); del sys.argv[sys.argv.index("--gap"):sys.argv.index("--gap") + 2]
     dump = "--dump" in sys.argv
     if dump:
         sys.argv.remove("--dump")
         os.makedirs("gpurun_out", exist_ok=True)
-        os.environ["LCTY_EXACT_DUMP"] = "gpurun_out/exact_model.txt"
     sizes = [int(a) for a in sys.argv[1:]] or [100, 300, 1000, 3000, 10000]
     ctx = api.Context(0)
-    ctx.set_knob("exact_trace", 2 if dump else 1)
+    ctx.set_knob("exact_trace", 1)
+    if dump: ctx.set_path("exact_dump", "gpurun_out/exact_model.txt")
     for n in sizes:
         L = synth.SynthLocus(8, n, seed=synth.SEED + 3)
         p = api.resolve_params(api.default_params(), L.bg)
@@ -30,7 +30,7 @@ def main():
         g = api.solve_stage(aa, sub, api.default_solver(cdefs.SOLVER_GREEDY), 1, seeds)[2][:, 0]
         a = api.solve_stage(aa, sub, api.default_solver(cdefs.SOLVER_ANNEAL), 1, seeds)[2][:, 0]
         ex = api.default_solver(cdefs.SOLVER_EXACT)
-        ex.init_prob = gap
+        if gap is not None: ex.init_prob = gap
         for gi in range(len(sub)):
             t0 = time.perf_counter()
             try:

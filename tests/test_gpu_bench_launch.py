@@ -47,3 +47,20 @@ def test_self_launch_reports_the_ranks_it_started():
     assert r1.returncode == 0, r1.stderr[-3000:]
     o1 = json.loads(r1.stdout.strip().splitlines()[-1])
     assert o1["n_gpus"] == 1 and o1["launch"] == "single process" and o1["rccl_ranks"] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["--shard-reads", "--shard-chains"])
+def test_one_locus_sharded_over_the_ranks_through_the_whole_path(mode):
+    """BASELINE configs[4]'s form (`--shard-reads`: the reads of ONE locus over the ranks — run_filter scores all-reduced, location-table
+    rows all-gathered per solver stage, chains dealt to the ranks) and the chain-sharded form, solver on, through the launch path of the
+    driver. RCCL refuses two ranks on one device, so a one-GPU box runs the communicator with one rank; two devices run two."""
+    from locityper_amd import api
+    n = 2 if api.device_count() >= 2 else 1
+    r = run_bench(["--gpus", str(n), mode])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == n and out["rccl_ranks"] == n and out["scaling"] == "strong"
+    assert out["solver"] is not None and tuple(out["called_genotype"]) == tuple(out["true_genotype"])
+    if n > 1:
+        assert out["ms_per_step_ranks"]["min"] <= out["ms_per_step_ranks"]["max"] == pytest.approx(out["ms_per_step"])

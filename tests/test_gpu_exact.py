@@ -11,8 +11,16 @@ from tests.test_gpu_solve import setup
 pytestmark = pytest.mark.gpu
 
 
+def proof():
+    """the exact solver asked for a proof of optimality (relative gap 0) instead of the default gap of 1e-4"""
+    s = api.default_solver(cdefs.SOLVER_EXACT)
+    assert s.init_prob == 1e-4                   # HiGHS' default mip_rel_gap, which the reference leaves alone (highs.rs:103-110)
+    s.init_prob = 0.0
+    return s
+
+
 def test_exact_equals_enumeration_on_small_models(gpu_ctx):
-    exact = api.default_solver(cdefs.SOLVER_EXACT)
+    exact = proof()
     assert exact.kind == cdefs.SOLVER_EXACT and exact.node_limit == 20_000_000
     o_exact = O.default_solver(cdefs.SOLVER_EXACT)
     n_cases = 0
@@ -45,7 +53,7 @@ def test_exact_on_larger_models_node_limit_and_assignment(gpu_ctx):
     L, p, loc, aa, ol, oa = setup(gpu_ctx, 6, 400, 6000, seed=12)
     gts = api.generate_genotypes(6, 2)[:6]
     seeds = api.chain_seeds(8, len(gts))
-    exact = api.default_solver(cdefs.SOLVER_EXACT)
+    exact = proof()
     try:
         gl = api.solve_stage(aa, gts, exact, 1, seeds)[2]
     except _lib.LocityperError as e:
@@ -60,7 +68,6 @@ def test_exact_on_larger_models_node_limit_and_assignment(gpu_ctx):
         assert np.allclose(api.solve_stage(aa, gts, exact, 1, seeds, pri)[2], gl + pri[:, None], rtol=1e-13)
     # with a relative gap (HiGHS' mip_rel_gap; lcty_solver.init_prob of this kind) the search stops as soon as nothing left can beat the
     # incumbent by more than the gap: an answer where the proof of optimality runs out of nodes, never above the optimum, within the gap of it
-    assert exact.init_prob == 0.0
     loose = api.default_solver(cdefs.SOLVER_EXACT)
     loose.init_prob = 0.25
     ll = api.solve_stage(aa, gts, loose, 1, seeds)[2]
@@ -68,7 +75,7 @@ def test_exact_on_larger_models_node_limit_and_assignment(gpu_ctx):
     if gl is not None:
         assert np.all(ll <= gl + 1e-9 * np.abs(gl)) and np.all(ll >= gl - 0.25 * np.abs(gl))
     # a node limit too small for a proof: Error::Solver, never an unproven answer
-    tight = api.default_solver(cdefs.SOLVER_EXACT)
+    tight = proof()
     tight.node_limit = 3
     with pytest.raises(_lib.LocityperError) as e:
         api.solve_stage(aa, gts[:1], tight, 1, seeds[:1])
@@ -89,24 +96,57 @@ def test_exact_on_larger_models_node_limit_and_assignment(gpu_ctx):
 
 def test_exact_at_configs0_size_within_the_reference_solvers_gap(gpu_ctx):
     """BASELINE.json configs[0]: 10 000 read pairs x 8 alleles. The reference's HiGHS run stops — and reports "optimal" — at its default relative
-    gap of 1e-4 (highs.rs:103-116 changes no option); with that gap (lcty_solver.init_prob of this kind) the exact solver answers for the two
-    best genotypes of the prefilter, and its likelihood is not below what the greedy and the annealing chains of the same attempt reach. The
-    bound behind it: the window counts dualised, multipliers set by subgradient steps at the root (1.6e-2 -> ~1e-4 relative at this size)."""
+    gap of 1e-4 (highs.rs:103-116 changes no option); that gap is lcty_solver_default's for this kind, and with it the exact solver answers for
+    the genotypes of a stage (20 here, one attempt each, solved by the pool of host threads), and its likelihood is not below what the greedy and
+    the annealing chains of the same attempt reach. The bound behind it: the window counts dualised, multipliers set by subgradient steps at the
+    root (1.6e-2 -> ~1e-4 relative at this size)."""
+    import time
     L = synth.SynthLocus(8, 10_000, seed=synth.SEED + 3)
     p = api.resolve_params(api.default_params(), L.bg)
     loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
     aa = api.AllAlignments.load(loc, L.reads(0, 10_000))
     gts = api.generate_genotypes(8, 2)
-    sub = np.ascontiguousarray(gts[np.argsort(-aa.run_filter(), kind="stable")[:2]])
+    sub = np.ascontiguousarray(gts[np.argsort(-aa.run_filter(), kind="stable")[:20]])
     seeds = api.chain_seeds(5, len(sub))
     ex = api.default_solver(cdefs.SOLVER_EXACT)
-    ex.init_prob = 1e-4
+    api.solve_stage(aa, sub[:1], ex, 1, seeds[:1])                      # first use: workspace, depth table
+    t0 = time.perf_counter()
     el = api.solve_stage(aa, sub, ex, 1, seeds)[2][:, 0]
+    wall = time.perf_counter() - t0
     assert np.all(np.isfinite(el))
     for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
         cl = api.solve_stage(aa, sub, api.default_solver(kind), 1, seeds)[2][:, 0]
         assert np.all(cl <= el + 1e-9 * np.abs(el)), (kind, cl, el)
+    # the pool: one thread gives the same answers (every model is solved on its own), and takes longer when the machine has cores to spare
+    gpu_ctx.set_knob("exact_threads", 1)
+    t0 = time.perf_counter()
+    e1 = api.solve_stage(aa, sub, ex, 1, seeds)[2][:, 0]
+    wall1 = time.perf_counter() - t0
+    gpu_ctx.set_knob("exact_threads", -1)
+    assert np.array_equal(e1, el)
+    print(f"exact, 20 genotypes x 10 000 read pairs: {wall:.2f} s with the pool, {wall1:.2f} s on one thread")
+    import os
+    if (os.cpu_count() or 1) >= 16: assert wall <= 1.5 and wall < 0.5 * wall1, (wall, wall1)
     # the proof of optimality itself (gap 0) still runs out of nodes at this size: Error::Solver, as a HiGHS run that is not "optimal"
     with pytest.raises(_lib.LocityperError) as e:
-        api.solve_stage(aa, sub[:1], api.default_solver(cdefs.SOLVER_EXACT), 1, seeds[:1])
+        api.solve_stage(aa, sub[:1], proof(), 1, seeds[:1])
     assert e.value.code == cdefs.ERR_SOLVER
+
+
+def test_attempts_without_a_tweak_share_one_model(gpu_ctx):
+    """tweak = 0: apply_tweak draws nothing (assgn.rs:127-151), the attempts of a genotype see one model; it is solved once and every attempt's
+    records carry the assignment (the per-read counts of `attempts` attempts are `attempts` x one attempt's)."""
+    L = synth.SynthLocus(4, 60, seed=synth.SEED + 11)
+    prm = api.default_params(); prm.tweak = 0
+    p = api.resolve_params(prm, L.bg)
+    assert p.tweak == 0
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    aa = api.AllAlignments.load(loc, L.reads(0, 60))
+    gts = api.generate_genotypes(4, 2)[:5]
+    ex = api.default_solver(cdefs.SOLVER_EXACT)
+    l3 = api.solve_stage(aa, gts, ex, 3, api.chain_seeds(1, 15))[2]
+    l1 = api.solve_stage(aa, gts, ex, 1, api.chain_seeds(2, 5))[2]
+    assert np.array_equal(l3, np.repeat(l1, 3, axis=1))
+    off, c3 = api.assignment_counts(aa, gts[0], ex, 3, api.chain_seeds(1, 3))
+    _, c1 = api.assignment_counts(aa, gts[0], ex, 1, api.chain_seeds(1, 1))
+    assert np.array_equal(c3, 3 * c1)

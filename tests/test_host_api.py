@@ -235,7 +235,8 @@ def test_knobs_are_named_and_checked():
 
 def test_mapper_and_solver_defaults():
     """lcty_map_params_default / _default_long (host only): strobealign's and minimap2's scores, the long route's chaining limits; the struct is
-    the header's (15 four-byte fields). lcty_solver_default for the exact solver: a proof of optimality unless a gap is asked for."""
+    the header's (15 four-byte fields). lcty_solver_default for the exact solver: HiGHS' default relative gap of 1e-4, which the reference
+    leaves alone (highs.rs:103-110); a proof of optimality is gap 0. lcty_ctx_set_path knows its names."""
     assert C.sizeof(cdefs.MapParams) == 15 * 4
     short, long_ = api.map_params(), api.map_params(long_reads=True)
     assert (short.k, short.stride, short.match, short.mismatch, short.gap_open, short.gap_extend, short.min_score, short.band) == (15, 5, 2, 8, 12, 1, 50, 16)
@@ -245,5 +246,6 @@ def test_mapper_and_solver_defaults():
         assert (mp.route, mp.chain_gap, mp.chain_skew, mp.chain_back) == (cdefs.MAP_ROUTE_AUTO, 2000, 500, 32)
     assert _lib.lib().lcty_map_params_default_long(None) == cdefs.ERR_INVALID_INPUT
     ex = api.default_solver(cdefs.SOLVER_EXACT)
-    assert ex.kind == cdefs.SOLVER_EXACT and ex.init_prob == 0.0 and ex.node_limit == 20_000_000
+    assert ex.kind == cdefs.SOLVER_EXACT and ex.init_prob == 1e-4 and ex.node_limit == 20_000_000
+    assert _lib.lib().lcty_ctx_set_path(None, b"exact_dump", b"/tmp/x") == cdefs.ERR_INVALID_INPUT
     assert api.default_solver(cdefs.SOLVER_ANNEAL).init_prob == 0.5
