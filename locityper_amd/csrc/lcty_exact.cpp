@@ -195,8 +195,13 @@ void solve(const Model& m, const double* lut, uint32_t ld, Result& out) {
     // most UB - (the read's best term) + (the bound's terms with the read placed at t); when that is below the incumbent for every
     // location but the incumbent's own, the read stays there in every better solution. Fixed reads make the windows' ranges narrower, the bound
     // tighter, and the next round fixes more: at 10 000 read pairs all but a few hundred of the 7 800 free reads.
-    for (uint32_t round = 0; round < 12 && n_free > 12; round++) {
-        std::vector<double> best_lam(lam), g(tw), cnt(tw);
+    // the gap the search may leave (HiGHS' mip_rel_gap): once the bound is within it of the incumbent the search below ends at its root,
+    // so neither more subgradient steps nor more fixing rounds are of any use
+    const double stop_gap = m.rel_gap > 0.0 && m.rel_gap < 1.0 ? m.rel_gap : 0.0;
+    auto within_gap = [&](double ub) { return stop_gap > 0.0 && ub - incumbent <= 0.98 * stop_gap * std::fabs(incumbent); };
+    double prev_round_ub = INFINITY;
+    for (uint32_t round = 0; round < 16 && n_free > 12; round++) {
+        std::vector<double> best_lam(lam), g(tw), cnt(tw), dir(tw, 0.0);
         std::vector<uint8_t> pick(best_assign);
         double best_ub = INFINITY, theta = 1.0; uint32_t stall = 0;
         const uint32_t iters = static_cast<uint32_t>(std::min<uint64_t>(3000, 400 + n_free / 2));
@@ -224,6 +229,7 @@ void solve(const Model& m, const double* lut, uint32_t ld, Result& out) {
             }
             if (ub < best_ub - 1e-9) { best_ub = ub; best_lam = lam; stall = 0; }
             else if (++stall >= 20) { theta *= 0.7; stall = 0; }
+            if (within_gap(best_ub)) break;
             if (it % 25 == 0) {                                         // the multipliers' own choice of locations as a start of the ascent
                 std::vector<uint8_t> from(pick);
                 std::vector<int64_t> d2(base_depth);
@@ -234,8 +240,16 @@ void solve(const Model& m, const double* lut, uint32_t ld, Result& out) {
                 if (val > incumbent) { incumbent = val; best_assign = from; dl_best = dl; al_best = al; }
             }
             if (norm == 0.0 || theta < 1e-6) break;
-            const double step = theta * (ub - incumbent) / norm;
-            for (uint32_t w = 0; w < tw; w++) lam[w] -= step * g[w];
+            // deflected subgradient (Camerini, Fratta, Maffioli 1975): the direction keeps a share of the previous one whenever the two
+            // point apart — the zig-zag of plain subgradient steps across the kinks of the bound is what made it creep
+            double dot = 0.0, dn = 0.0;
+            for (uint32_t w = 0; w < tw; w++) { dot += dir[w] * g[w]; dn += dir[w] * dir[w]; }
+            const double beta = (dot < 0.0 && dn > 0.0) ? -1.5 * dot / dn : 0.0;
+            double dnorm = 0.0;
+            for (uint32_t w = 0; w < tw; w++) { dir[w] = g[w] + beta * dir[w]; dnorm += dir[w] * dir[w]; }
+            if (dnorm == 0.0) break;
+            const double step = theta * (ub - incumbent) / dnorm;
+            for (uint32_t w = 0; w < tw; w++) lam[w] -= step * dir[w];
         }
         lam = best_lam;
         // reduced-cost fixing at these multipliers
@@ -276,7 +290,10 @@ void solve(const Model& m, const double* lut, uint32_t ld, Result& out) {
         n_free = static_cast<uint32_t>(order.size());
         if (m.trace)
             fprintf(stderr, "[lcty exact] chain %u round %u: bound %.6f, incumbent %.6f, %u reads fixed by reduced costs, %u free\n", m.chain, round, ub, incumbent, newly, n_free);
-        if (newly == 0) break;
+        if (within_gap(ub)) break;
+        // another round starts from these multipliers with full steps again: worth it while reads get fixed or the bound still moves
+        if (newly == 0 && !(ub < prev_round_ub - 2e-6 * std::fabs(incumbent))) break;
+        prev_round_ub = ub;
     }
     std::vector<double> rmax(n, 0.0);
     std::vector<uint8_t> first_try(n, 0);                              // the location the multipliers prefer is explored first
