@@ -190,7 +190,7 @@ struct lcty_ctx {
         lcty::DevBuf<lcty::ChainRec> recs; lcty::DevBuf<lcty::ExtraLoc> extra;
         uint32_t extra_cap = 0, extra_for_ploidy = 0;
         lcty::DevBuf<uint16_t> gt; lcty::DevBuf<uint8_t> cgc; lcty::DevBuf<uint32_t> cdepth, cnnt, cseg, ctotw, ovf, cuc; lcty::DevBuf<uint64_t> seeds;
-        lcty::DevBuf<double> pri, liks, parts, cww, caln;
+        lcty::DevBuf<double> pri, liks, parts, cww, caln, dbg;
         void release_all() {
             recs.release(); extra.release(); gt.release(); cgc.release(); cdepth.release(); cuc.release(); cnnt.release(); cseg.release(); ctotw.release(); ovf.release();
             seeds.release(); pri.release(); liks.release(); parts.release(); cww.release(); caln.release(); extra_cap = 0;

@@ -52,6 +52,7 @@ namespace lcty {
 //   4  the row's best candidate through one 64-bit LDS maximum per lane instead of four rounds of lane exchanges
 //   8  depth-table entries as pairs {v[d], v[d + 1]}: one 16-byte gather per window instead of two 8-byte ones
 //  16  a candidate's record as two 16-byte loads instead of six field loads
+//  32  (diagnostic) the phases of an iteration timed with the shader clock, summed per wavefront into SolveView::dbg
 // (a template parameter of the kernel; lcty_ctx_set_knob "solve_greedy_form" picks among the compiled ones)
 
 constexpr uint32_t MAXP = 4;                  // ploidy handled by the device solver
@@ -154,6 +155,7 @@ struct SolveView {
     double* liks;                   // [n_chains] prior + likelihood
     double* parts;                  // [n_chains][4] aln_lik, depth_lik, solver iterations, accepted moves (diagnostics)
     uint32_t* overflow;             // set when a window got deeper than the depth table (the host widens it and repeats)
+    double* dbg;                    // [wavefronts][8] clock cycles per phase of the greedy iteration (form 32 only)
     uint32_t prio_mode;             // issue priority of the loop kernels: 0 annealing wavefronts first (default), 1 greedy first, 2 none (knob solve_prio_mode)
 };
 
@@ -1048,6 +1050,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
     double depth_mine = 0.0, aln_mine = 0.0;                                     // likelihood changes of the moves this lane applied
 
     bool done = nnt == 0 || !live_row;
+    uint64_t phase[5] = {0, 0, 0, 0, 0}, sub[4] = {0, 0, 0, 0}, t_loop0 = 0;
     if (__any(!done)) {
         const uint32_t nnt1 = max(nnt, 1u);
         const uint64_t max_iter = max(static_cast<uint64_t>(100000), static_cast<uint64_t>(V.solver.plato_size) * 100);
@@ -1177,6 +1180,15 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         // iteration (arrived), EN receives their further locations; F = the slot the sample three iterations ahead goes to (= A's)
         auto iteration = [&](auto slot_tag, GreedyCand& A, const GreedyExt& EA, const GreedyCand& N, GreedyExt& EN) {
             constexpr uint32_t SLOT = decltype(slot_tag)::value;
+            constexpr bool TIMED = (GREEDY_FORM & 32u) != 0;
+            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, ts[3] = {0, 0, 0}, tw0 = 0;
+            auto subtick = [&](int k) { if constexpr (TIMED) { __builtin_amdgcn_sched_barrier(0); ts[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } };
+            auto tick = [&](int k) { if constexpr (TIMED) { __builtin_amdgcn_sched_barrier(0); tk[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } };
+            tick(0);
+            if constexpr (TIMED) {                     // how long the further locations requested an iteration ago are still on their way
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0); tw0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+            }
             const RecBody b = A.b;
             if constexpr ((GREEDY_FORM & 16u) != 0) asm volatile("" :: "v"(A.spare));
             const uint32_t pick = A.pick, rpc0 = A.rpc;
@@ -1193,6 +1205,8 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 asm volatile("" : "+v"(cur_lp), "+v"(cur_w));                     // the wait for this load stays inside the rare branch
             }
             const uint32_t w1 = cur_w & 0xFFFFu, w2 = cur_w >> 16;
+            if constexpr (TIMED) asm volatile("" :: "v"(w1), "v"(w2), "v"(cur_lp));
+            subtick(0);
             // up to three alternatives per lane, all requested before any is used. The pair of the current location is the same
             // for all of them: requested once; an alternative adds the pair of its own two windows.
             constexpr uint32_t NA = GREEDY_INLINE_LOCS - 1;
@@ -1200,8 +1214,10 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             PairGather gc, ga[NA];
             bool cross[NA];
             C.request_pair(w1, w2, -1, gc);
+            subtick(1);
 #pragma unroll
             for (uint32_t u = 0; u < NA; u++) {
+                if (u == 1) subtick(2);
                 const bool has = u < n_alt && !(deep && u + (u >= cur ? 1u : 0u) >= GREEDY_INLINE_LOCS);
                 t_of[u] = u + (u >= cur ? 1u : 0u);
                 lp_t[u] = 0.0; win_t[u] = 0; cross[u] = false;
@@ -1214,10 +1230,12 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            tick(1);
             request_ext(N, EN);
             __builtin_amdgcn_sched_barrier(0);
             request_record(A);                                                  // A's registers have been read: the slot takes the sample of i + 3
             __builtin_amdgcn_sched_barrier(0);
+            tick(2);
             // best_read_improvement (assgn.rs:287-317): the alternatives in order, a later one only when strictly better
             double best_improv = -INFINITY, lp_new = 0.0, ddiff = 0.0;
             uint32_t new_assgn = 0, w3 = 0, w4 = 0;
@@ -1258,6 +1276,8 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 }
             }
             const double my_improv = n_alt ? V.aln_contrib * (best_improv - cur_lp) : -INFINITY;
+            if constexpr (TIMED) asm volatile("" :: "v"(my_improv));
+            tick(3);
             // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
             double best;
             if constexpr ((GREEDY_FORM & 4u) != 0 && LPC != 16) {
@@ -1277,6 +1297,8 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             const unsigned long long who_row = (who >> row_base) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63u)) - 1ull));
             const uint32_t src = who_row ? static_cast<uint32_t>(__ffsll(static_cast<long long>(who_row))) - 1u : 0u;
             const bool moved = !done && who_row != 0ull && best > min_diff;
+            if constexpr (TIMED) asm volatile("" :: "s"(who));
+            tick(4);
             // reassign (assgn.rs:331-343) by the lane that holds the move; the others only learn which list slot changed.
             // The lane's share of the likelihood is added up at the end.
             if (moved && jj == src) {
@@ -1292,6 +1314,12 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             const uint32_t moved_to = static_cast<uint32_t>(__shfl(static_cast<int>(new_assgn), static_cast<int>(row_base + src)));
             h3s = h2s; h3t = h2t; h2s = h1s; h2t = h1t;
             h1s = moved ? moved_slot : 0xFFFFFFFFu; h1t = moved_to;
+            if constexpr (TIMED) {
+                asm volatile("" :: "v"(h1s), "v"(h1t));
+                tick(5);
+                for (int k = 0; k < 5; k++) phase[k] += tk[k + 1] - tk[k];
+                sub[0] += ts[0] - tw0; sub[1] += ts[1] - ts[0]; sub[2] += ts[2] - ts[1]; sub[3] += tw0 - tk[0];
+            }
             if (!done) {
                 n_iter++; iter++;
                 if (moved) { n_acc++; curr_plato = 0; }
@@ -1304,6 +1332,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         };
         GreedyCand R0, R1, R2;
         GreedyExt E0, E1, E2;
+        if constexpr ((GREEDY_FORM & 32u) != 0) t_loop0 = __builtin_amdgcn_s_memtime();
         request_record(R0); request_record(R1); request_record(R2);
         request_ext(R0, E0);
         while (__any(!done)) {
@@ -1312,6 +1341,14 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             iteration(std::integral_constant<uint32_t, 1>{}, R1, E1, R2, E2);
             if (!__any(!done)) break;
             iteration(std::integral_constant<uint32_t, 2>{}, R2, E2, R0, E0);
+        }
+    }
+    if constexpr ((GREEDY_FORM & 32u) != 0) {
+        if (lane == 0 && V.dbg) {
+            double* d = V.dbg + (static_cast<size_t>(blockIdx.x) * WAVES + wave) * 12;
+            for (int k = 0; k < 5; k++) d[k] = static_cast<double>(phase[k]);
+            d[5] = static_cast<double>(__builtin_amdgcn_s_memtime() - t_loop0); d[6] = static_cast<double>(n_iter); d[7] = 0.0;
+            for (int k = 0; k < 4; k++) d[8 + k] = static_cast<double>(sub[k]);
         }
     }
     depth_mine = row_sum_f64<LPC>(depth_mine, row_base, jj); aln_mine = row_sum_f64<LPC>(aln_mine, row_base, jj);
@@ -1888,6 +1925,7 @@ void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t 
             case 16: return launch_greedy_form<LPC, LW, 16>(ctx, V, nch, s);
             case 24: return launch_greedy_form<LPC, LW, 24>(ctx, V, nch, s);
             case 31: return launch_greedy_form<LPC, LW, 31>(ctx, V, nch, s);
+            case 32: return launch_greedy_form<LPC, LW, 32>(ctx, V, nch, s);
             default: break;
         }
     }
@@ -2099,11 +2137,25 @@ struct StageRunner {
             constexpr uint32_t L = decltype(tag)::value;
             if (lw) launch_greedy<L, true>(ctx, V, nch, stream); else launch_greedy<L, false>(ctx, V, nch, stream);
         };
+        const bool timed_form = lpc == 12 && lw && ctx->knob("solve_greedy_form", 0) == 32;
+        const size_t n_waves = (static_cast<size_t>(nch) + 4) / 5 + 2;
+        V.dbg = nullptr;
+        if (timed_form) { ws.dbg.ensure(12 * n_waves); ws.dbg.zero(stream); V.dbg = ws.dbg.p; }
         if (lpc == 10) go(std::integral_constant<uint32_t, 10>{});
         else if (lpc == 12) go(std::integral_constant<uint32_t, 12>{});
         else if (lpc == 16) go(std::integral_constant<uint32_t, 16>{});
         else if (lpc == 32) go(std::integral_constant<uint32_t, 32>{});
         else go(std::integral_constant<uint32_t, 64>{});
+        if (timed_form) {
+            // diagnostic: mean shader-clock cycles per iteration and phase over the wavefronts of the launch
+            std::vector<double> d(12 * n_waves);
+            ws.dbg.download(d.data(), d.size(), stream);
+            LCTY_HIP(hipStreamSynchronize(stream));
+            double sum[12] = {0}; size_t used = 0;
+            for (size_t w = 0; w < n_waves; w++) if (d[12 * w + 6] > 0) { used++; for (int k = 0; k < 12; k++) sum[k] += d[12 * w + k] / d[12 * w + 6]; }
+            if (used) fprintf(stderr, "[lcty greedy phases] %zu wavefronts; clock ticks per iteration: candidates+requests %.0f (waiting for the further locations %.0f, current location %.0f, its pair %.0f, first alternative %.0f), ext+sample+record request %.0f, wait+score %.0f, row best %.0f, move %.0f; loop total %.0f\n",
+                              used, sum[0] / used, sum[11] / used, sum[8] / used, sum[9] / used, sum[10] / used, sum[1] / used, sum[2] / used, sum[3] / used, sum[4] / used, sum[5] / used);
+        }
     }
 
     // lcty_ctx::LaunchGate: the main stream's greedy loop of the next locus goes first, the side stream's annealing loop right behind
