@@ -65,7 +65,6 @@ struct lcty_locus {
     bool has_hap_alns = false;
     lcty::DevBuf<double> d_lut_ext;          // [101][lut_ext_depth] depth table of the solver stages (lcty_solve.hip)
     uint32_t lut_ext_depth = 0;
-    lcty::DevBuf<double> d_lut_pair;         // the same table as pairs {v[d], v[d + 1]} (16 B per entry): one gather gives a window's entry before and after a move
     uint32_t max_n_windows = 0;
 
     lcty::LocusView view() const;

@@ -46,14 +46,12 @@
 
 namespace lcty {
 
-// Forms of the greedy loop under measurement, a bit mask:
-//   1  the parts of a chain's record list in registers instead of four LDS words per row
-//   2  duplicate check of a sample through an LDS array of the row's picks (one write + three 16-byte reads) instead of eleven lane exchanges
-//   4  the row's best candidate through one 64-bit LDS maximum per lane instead of four rounds of lane exchanges
-//   8  depth-table entries as pairs {v[d], v[d + 1]}: one 16-byte gather per window instead of two 8-byte ones
-//  16  a candidate's record as two 16-byte loads instead of six field loads
-//  32  (diagnostic) the phases of an iteration timed with the shader clock, summed per wavefront into SolveView::dbg
-// (a template parameter of the kernel; lcty_ctx_set_knob "solve_greedy_form" picks among the compiled ones)
+// Forms of the greedy loop (template parameter of the kernel; lcty_ctx_set_knob "solve_greedy_form" picks among the compiled ones):
+//   32  (diagnostic) the phases of an iteration timed with the shader clock, summed per wavefront into SolveView::dbg
+// Tried in round 4 and dropped (profiles/r04_greedy_forms_and_phases.txt): duplicate check / row maximum through LDS, the depth table
+// as pairs, 16-byte record loads, a lane per alternative (further alternatives of a read on spare lanes of its row) — none moved the
+// loop. What an iteration costs is the cache lines it has to bring into the CU — one record line from HBM and four table lines from
+// the L2 per candidate, ~250 per wavefront-iteration, ~165 in flight per CU — whatever the instructions around them look like.
 
 constexpr uint32_t MAXP = 4;                  // ploidy handled by the device solver
 constexpr uint32_t NONE32S = 0xFFFFFFFFu;
@@ -120,7 +118,6 @@ struct SolveView {
     const double* wk; const double* wc;
     uint32_t n_wk, n_wc;            // 0: no tables (the greedy loop then gathers the weights)
     const double* lut;              // [LCTY_GC_BINS][lut_depth]
-    const double2* lut2;            // the same as pairs: lut2[g][d] = {lut[g][d], lut[g][d + 1]} (the last entry of a row repeats itself)
     uint32_t lut_depth, lut_shift;  // lut_depth = 1 << lut_shift
     const DepthNB* depth_nb;
     uint32_t n_alt;
@@ -348,13 +345,6 @@ __global__ __launch_bounds__(256) void build_depth_table_kernel(const double* __
     if (i >= LCTY_GC_BINS * lut_depth) return;
     const uint32_t g = i / lut_depth, d = i % lut_depth;
     lut[i] = d < LCTY_DEPTH_CACHE ? cache[g * LCTY_DEPTH_CACHE + d] : bayes_ln_pmf_direct(nb + g, n_alt, d);
-}
-
-__global__ __launch_bounds__(256) void build_depth_pairs_kernel(const double* __restrict__ lut, uint32_t lut_depth, double2* __restrict__ pairs) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= LCTY_GC_BINS * lut_depth) return;
-    const uint32_t d = i % lut_depth;
-    pairs[i] = make_double2(lut[i], lut[d + 1 < lut_depth ? i + 1 : i]);
 }
 
 // ---- the genotype of a chain: GenotypeWindows (windows.rs:709-739) ----
@@ -665,20 +655,11 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
 }
 
 // two windows of one location (see Chain::request_pair)
-// With the table as pairs (GREEDY_FORM & 8) the entries arrive as pr[i] = {v[lo], v[lo + 1]} at the lower of a window's two depths, and
-// `far` = v[lo + 2] for a window that both ends of the location share (a step of two); which of them is the entry before and after the
-// move is sorted out in pair_term, i.e. behind the wait for the whole group — a select right behind a load waits for that load
-struct PairGather { int32_t c[2]; uint32_t dmax[2]; double weight[2], vnew[2], vold[2]; double2 pr[2]; double far; };
+struct PairGather { int32_t c[2]; uint32_t dmax[2]; double weight[2], vnew[2], vold[2]; };
 // the four terms of depth_lik_diff in its order of summation, ((t1 + t2) + t3) + t4, from the two halves; *deepest: the deepest live window
-template <uint32_t GREEDY_FORM = 0>
 __device__ __forceinline__ double pair_term(const PairGather& g, int i, uint32_t* deepest) {
     const bool live = g.c[i] != 0 && g.weight[i] != 0.0;                     // c == 0: no change; weight 0: WindowDistr::TRIVIAL
     *deepest = max(*deepest, live ? g.dmax[i] : 0u);
-    if constexpr ((GREEDY_FORM & 8u) != 0) {
-        const double hi = (g.c[i] == 2 || g.c[i] == -2) ? g.far : g.pr[i].y;  // the entry at the higher of the two depths
-        const double vnew = g.c[i] > 0 ? hi : g.pr[i].x, vold = g.c[i] > 0 ? g.pr[i].x : hi;
-        return live ? g.weight[i] * vnew - g.weight[i] * vold : 0.0;
-    }
     return live ? g.weight[i] * g.vnew[i] - g.weight[i] * g.vold[i] : 0.0;
 }
 
@@ -771,7 +752,6 @@ struct Chain {
 // entries, which is how window_weight_kernel made it. Every 8-byte weight gather moved a 128-byte line out of the L2;
 // at 5 000 chains those lines were a quarter of the loop's time.
 constexpr uint32_t LW_DEPTH_BITS = 23, LW_DEPTH_MASK = (1u << LW_DEPTH_BITS) - 1u;      // nine bits for a table index
-template <uint32_t GREEDY_FORM = 0>
 struct ChainLW {
     const SolveView* V;
     uint32_t* wd;               // LDS: depth | wk index << 23
@@ -837,36 +817,13 @@ struct ChainLW {
 #pragma unroll
         for (int i = 0; i < 2; i++) { word[i] = wd[w[i]]; half[i] = wh[w[i]]; }
         const uint32_t last = V->lut_depth - 1;
-        if constexpr ((GREEDY_FORM & 8u) != 0) {
-            // one 16-byte gather per window: the pair at the lower of the two depths holds the entry before and the entry after a
-            // step of one; a step of two (both windows of the pair coincide) takes its far entry from a second pair (rare)
-            uint32_t lo[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
-                const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
-                lo[i] = min(d_old, d_new);
-                g.pr[i] = V->lut2[row + min(lo[i], last)];
-                g.dmax[i] = max(d_new, d_old);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++) g.weight[i] = weight_of(word[i], half[i]);
-            g.far = 0.0;
-            // |c[0]| == 2: v[lo + 2] = the second half of the pair at lo + 1 (lanes without a candidate sit on window 0 twice: no weight)
-            if (__any(same && g.weight[0] != 0.0)) {
-                const uint32_t row = (half[0] & 0x7Fu) << V->lut_shift;
-                g.far = V->lut2[row + min(lo[0] + 1u, last)].y;
-            }
-            return;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
-                const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
-                g.vnew[i] = V->lut[row + min(d_new, last)];
-                g.vold[i] = V->lut[row + min(d_old, last)];
-                g.dmax[i] = max(d_new, d_old);
-            }
+        for (int i = 0; i < 2; i++) {
+            const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
+            const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
+            g.vnew[i] = V->lut[row + min(d_new, last)];
+            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.dmax[i] = max(d_new, d_old);
         }
 #pragma unroll
         for (int i = 0; i < 2; i++) g.weight[i] = weight_of(word[i], half[i]);
@@ -959,7 +916,7 @@ __device__ __forceinline__ double row_sum_f64(double x, uint32_t row_base, uint3
     }
 }
 
-constexpr uint32_t GREEDY_ROW_TAIL = 24;      // words per row behind the windows (see the kernel)
+constexpr uint32_t GREEDY_ROW_TAIL = 4;       // words per row behind the windows (see the kernel)
 // LDS of a greedy workgroup for its rows' windows: 4 bytes each; 6 with the weights in LDS, plus the two weight tables (16-byte multiple)
 __host__ __device__ inline size_t greedy_lds_windows(uint32_t lpc, uint32_t wstride, uint32_t n_wk, uint32_t n_wc, bool lw) {
     const size_t rows = static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * wstride;
@@ -969,12 +926,16 @@ __host__ __device__ inline size_t greedy_lds_windows(uint32_t lpc, uint32_t wstr
 
 // ---------------- K14 Greedy: 64 / LPC chains per wavefront ----------------
 // A candidate read of an iteration as its lane sees it: the record, and the first two of its locations beyond the second
-struct GreedyCand { uint32_t pick, rpc; RecBody b; uint32_t spare; };     // spare: the first word of a 16-byte record load, kept until the record is used
+struct GreedyCand { uint32_t pick, rpc; RecBody b; };
 struct GreedyExt { double lp2, lp3; uint32_t win2, win3; };
 constexpr uint32_t GREEDY_INLINE_LOCS = 4;     // locations of a read the pipelined path holds in registers; reads with more take loads
+// selects, not branches: as nested conditionals this became a tree of divergent branches (600 clock ticks per iteration)
 __device__ __forceinline__ void cand_loc(const RecBody& b, const GreedyExt& e, uint32_t t, double* lp, uint32_t* win) {
-    *lp = t == 0 ? b.lp0 : t == 1 ? b.lp1 : t == 2 ? e.lp2 : e.lp3;
-    *win = t == 0 ? b.win0 : t == 1 ? b.win1 : t == 2 ? e.win2 : e.win3;
+    double l = b.lp0; uint32_t w = b.win0;
+    l = t == 1 ? b.lp1 : l; w = t == 1 ? b.win1 : w;
+    l = t == 2 ? e.lp2 : l; w = t == 2 ? e.win2 : w;
+    l = t >= 3 ? e.lp3 : l; w = t >= 3 ? e.win3 : w;
+    *lp = l; *win = w;
 }
 
 // With the weights in LDS a workgroup is two wavefronts that share the two tables (nothing else: after one barrier they run apart)
@@ -983,7 +944,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ uint32_t flagged;
     constexpr uint32_t CPW = 64 / LPC, WAVES = LW ? 2u : 1u, ROWS = CPW * WAVES;
-    using ChainT = typename std::conditional<LW, ChainLW<GREEDY_FORM>, Chain>::type;
+    using ChainT = typename std::conditional<LW, ChainLW, Chain>::type;
     // a batch whose initialisation raised a flag (a chain's run of further locations was too short, ...) is repeated by the host:
     // its records are incomplete and must not be followed
     if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1001,14 +962,12 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(wg_row) * W;
     const uint32_t gi = chain / V.attempts;
     // the parts of the chain's list of non-trivial reads (RecList): four words per row in LDS, behind everything else
-    // per row, behind the windows: [0..3] the parts of the record list, [4..15] the picks of the current sample (duplicate check), [16..21] three
-    // 64-bit slots for the row's best improvement (taken in turn by consecutive iterations)
+    // per row, behind the windows: [0..3] the parts of the record list
     uint32_t* row_cum = reinterpret_cast<uint32_t*>(smem + greedy_lds_windows(LPC, V.wstride, V.n_wk, V.n_wc, LW)) + static_cast<size_t>(wg_row) * GREEDY_ROW_TAIL;
     if (jj < 4) row_cum[jj] = V.c_seg[static_cast<uint64_t>(chain) * 4 + jj];
-    if (jj < 6) row_cum[16 + jj] = 0;
-    unsigned long long* row_best = reinterpret_cast<unsigned long long*>(row_cum + 16);
     RecList recs{V.recs + static_cast<uint64_t>(chain) * V.rstride, row_cum, V.seg_reads};
-    if constexpr ((GREEDY_FORM & 1u) != 0) {
+    {
+        // the bounds of the list's parts in registers of the lane (three LDS reads per pick less: 312 -> 309 ms)
         const uint32_t* cg = V.c_seg + static_cast<uint64_t>(chain) * 4;
         recs.r1 = cg[1]; recs.r2 = cg[2]; recs.r3 = cg[3]; recs.in_regs = true;
     }
@@ -1030,7 +989,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         }
         for (uint32_t i = threadIdx.x; i < V.n_wk; i += 64 * WAVES) lwk[i] = V.wk[i];
         for (uint32_t i = threadIdx.x; i < V.n_wc; i += 64 * WAVES) lwc[i] = V.wc[i];
-        C = ChainLW<GREEDY_FORM>{&V, wd, wh, lwk, lwc};
+        C = ChainLW{&V, wd, wh, lwk, lwc};
         __syncthreads();                                                         // the tables; from here on the wavefronts run apart
     } else {
         for (uint32_t w = jj; w < total_w && jj < LPC; w += LPC) wd[w] = gd[w] | (static_cast<uint32_t>(ggc[w]) << 25);
@@ -1096,18 +1055,6 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x126, 0xF, 0xF, false) == v;
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x127, 0xF, 0xF, false) == v;
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false) == v;
-            } else if constexpr ((GREEDY_FORM & 2u) != 0 && LPC <= 12) {
-                // the row's picks through LDS: one write, three 16-byte reads every lane of the row shares, instead of LPC - 1 lane exchanges
-                if (jj < LPC) row_cum[4 + jj] = idx;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint4* pk = reinterpret_cast<const uint4*>(row_cum + 4);
-                const uint4 p0 = pk[0], p1 = pk[1], p2 = pk[2];
-                const uint32_t all[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-                uint32_t same = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < LPC; q++) same += all[q] == idx ? 1u : 0u;
-                dup = same > 1u;                                              // the lane's own pick is one of the matches
             } else {
                 for (uint32_t d = 1; d < LPC; d++) {
                     const uint32_t other = static_cast<uint32_t>(__shfl(static_cast<int>(idx), static_cast<int>(row_base + ((jj + d) % LPC))));
@@ -1149,21 +1096,8 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         auto request_record = [&](GreedyCand& c) {
             c.pick = sample();
             const ChainRec* r = &recs[cand ? c.pick : 0u];
-            if constexpr ((GREEDY_FORM & 16u) != 0) {
-                // the `cur` word from L2 as before (agent scope: this wavefront's own stores arrive there in order), the rest of the record as
-                // two 16-byte loads: three tag look-ups per candidate instead of six
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                c.rpc = load_rp_cur(r);
-                const u32x4 qa = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r));
-                const u32x4 qb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r) + 1);
-                c.spare = qa.x; c.b.meta = qa.y;               // all four words stay live: a dead one is handed out again at once, behind a wait for the load
-                c.b.lp0 = __hiloint2double(static_cast<int>(qa.w), static_cast<int>(qa.z));
-                c.b.lp1 = __hiloint2double(static_cast<int>(qb.y), static_cast<int>(qb.x));
-                c.b.win0 = qb.z; c.b.win1 = qb.w;
-            } else {
-                c.rpc = load_rp_cur(r);
-                c.b.meta = field32(r, 4); c.b.lp0 = field64(r, 8); c.b.lp1 = field64(r, 16); c.b.win0 = field32(r, 24); c.b.win1 = field32(r, 28);
-            }
+            c.rpc = load_rp_cur(r);
+            c.b.meta = field32(r, 4); c.b.lp0 = field64(r, 8); c.b.lp1 = field64(r, 16); c.b.win0 = field32(r, 24); c.b.win1 = field32(r, 28);
         };
         // the first two further locations of a record that has arrived (reads with two locations: the chain's first entry, unused)
         auto request_ext = [&](const GreedyCand& c, GreedyExt& e) {
@@ -1190,7 +1124,6 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 __builtin_amdgcn_sched_barrier(0); tw0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
             }
             const RecBody b = A.b;
-            if constexpr ((GREEDY_FORM & 16u) != 0) asm volatile("" :: "v"(A.spare));
             const uint32_t pick = A.pick, rpc0 = A.rpc;
             const uint32_t nloc = b.meta & 0xFFu;
             uint32_t cur = rpc0 >> 24;
@@ -1240,14 +1173,14 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             double best_improv = -INFINITY, lp_new = 0.0, ddiff = 0.0;
             uint32_t new_assgn = 0, w3 = 0, w4 = 0;
             uint32_t deepest = 0;
-            const double t1 = pair_term<GREEDY_FORM>(gc, 0, &deepest);
-            const double t12 = t1 + pair_term<GREEDY_FORM>(gc, 1, &deepest);
+            const double t1 = pair_term(gc, 0, &deepest);
+            const double t12 = t1 + pair_term(gc, 1, &deepest);
 #pragma unroll
             for (uint32_t u = 0; u < NA; u++) {
                 const bool has = u < n_alt && !(deep && t_of[u] >= GREEDY_INLINE_LOCS);
                 if (u == 0 || __any(has)) {
-                    const double t3 = pair_term<GREEDY_FORM>(ga[u], 0, &deepest);
-                    double dd = (t12 + t3) + pair_term<GREEDY_FORM>(ga[u], 1, &deepest);
+                    const double t3 = pair_term(ga[u], 0, &deepest);
+                    double dd = (t12 + t3) + pair_term(ga[u], 1, &deepest);
                     if (__any(cross[u])) {
                         if (cross[u]) dd = C.depth_lik_diff(w1, w2, win_t[u] & 0xFFFFu, win_t[u] >> 16);
                     }
@@ -1279,21 +1212,8 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             if constexpr (TIMED) asm volatile("" :: "v"(my_improv));
             tick(3);
             // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
-            double best;
-            if constexpr ((GREEDY_FORM & 4u) != 0 && LPC != 16) {
-                // one 64-bit LDS maximum per lane over an order-preserving image of the improvement (-0.0 folded into +0.0 first, so that
-                // equal doubles have equal images), one read; the slot two iterations ahead is cleared by the row's first lane
-                const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(my_improv + 0.0));
-                const unsigned long long key = bits ^ ((bits >> 63) ? ~0ull : 0x8000000000000000ull);
-                atomicMax(&row_best[SLOT], key);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const unsigned long long top = row_best[SLOT];
-                if (jj == 0) row_best[(SLOT + 2) % 3] = 0ull;
-                const unsigned long long tb = top ^ ((top >> 63) ? 0x8000000000000000ull : ~0ull);
-                best = __longlong_as_double(static_cast<long long>(tb));
-            } else best = row_max_f64<LPC>(my_improv, row_base, jj);
-            const unsigned long long who = __ballot(n_alt && (my_improv + 0.0) == best);
+            const double best = row_max_f64<LPC>(my_improv, row_base, jj);
+            const unsigned long long who = __ballot(n_alt && my_improv == best);
             const unsigned long long who_row = (who >> row_base) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63u)) - 1ull));
             const uint32_t src = who_row ? static_cast<uint32_t>(__ffsll(static_cast<long long>(who_row))) - 1u : 0u;
             const bool moved = !done && who_row != 0ull && best > min_diff;
@@ -1386,7 +1306,7 @@ struct AnnealRing {
 template <int MODE>
 __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) {
     constexpr bool WWL = MODE == 1, LW = MODE == 2;
-    using ChainT = typename std::conditional<LW, ChainLW<0>, Chain>::type;
+    using ChainT = typename std::conditional<LW, ChainLW, Chain>::type;
     extern __shared__ __align__(32) uint8_t smem[];
     __shared__ uint32_t flagged;
     if (threadIdx.x == 0) flagged = __hip_atomic_load(V.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1478,7 +1398,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         return;
     }
     ChainT C;
-    if constexpr (LW) C = ChainLW<0>{&V, wd, wh, lww, lww + V.n_wk};
+    if constexpr (LW) C = ChainLW{&V, wd, wh, lww, lww + V.n_wk};
     else C = Chain{&V, wd, WWL ? lww : gww};
     // depth_lik = sum over windows (recalc_likelihood, assgn.rs:347-350)
     double depth_lik = 0.0;
@@ -1876,10 +1796,6 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
     hipLaunchKernelGGL(build_depth_table_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, loc->d_depth_lut.p, loc->d_depth_nb.p,
                        static_cast<uint32_t>(loc->prm.n_alt_cn), depth, loc->d_lut_ext.p);
     LCTY_HIP(hipGetLastError());
-    loc->d_lut_pair.alloc(2 * static_cast<size_t>(LCTY_GC_BINS) * depth);
-    hipLaunchKernelGGL(build_depth_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, loc->d_lut_ext.p, depth,
-                       reinterpret_cast<double2*>(loc->d_lut_pair.p));
-    LCTY_HIP(hipGetLastError());
     loc->lut_ext_depth = depth;
 }
 
@@ -1918,13 +1834,6 @@ void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t 
     if constexpr (LPC == 12 && LW) {
         // the forms under measurement exist for the stage shape of the default scheme only
         switch (ctx->knob("solve_greedy_form", 0)) {
-            case 1: return launch_greedy_form<LPC, LW, 1>(ctx, V, nch, s);
-            case 2: return launch_greedy_form<LPC, LW, 2>(ctx, V, nch, s);
-            case 4: return launch_greedy_form<LPC, LW, 4>(ctx, V, nch, s);
-            case 8: return launch_greedy_form<LPC, LW, 8>(ctx, V, nch, s);
-            case 16: return launch_greedy_form<LPC, LW, 16>(ctx, V, nch, s);
-            case 24: return launch_greedy_form<LPC, LW, 24>(ctx, V, nch, s);
-            case 31: return launch_greedy_form<LPC, LW, 31>(ctx, V, nch, s);
             case 32: return launch_greedy_form<LPC, LW, 32>(ctx, V, nch, s);
             default: break;
         }
@@ -2011,7 +1920,7 @@ struct StageRunner {
         const bool tables = loc->weight_tables_valid && !loc->has_explicit;
         V.wk = tables ? loc->d_wk.p : nullptr; V.wc = tables ? loc->d_wc.p : nullptr;
         V.n_wk = tables ? static_cast<uint32_t>(loc->d_wk.n) : 0u; V.n_wc = tables ? static_cast<uint32_t>(loc->d_wc.n) : 0u;
-        V.lut = loc->d_lut_ext.p; V.lut2 = reinterpret_cast<const double2*>(loc->d_lut_pair.p); V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
+        V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth)); V.depth_nb = loc->d_depth_nb.p; V.n_alt = loc->prm.n_alt_cn;
         V.n_good = static_cast<uint32_t>(n_good); V.ngp = ngp;
         V.seg_reads = static_cast<uint32_t>(((n_good + INIT_SEGS - 1) / INIT_SEGS + 63) / 64 * 64);      // the parts of a chain's record list
         if (V.seg_reads == 0) V.seg_reads = 64;
@@ -2137,7 +2046,7 @@ struct StageRunner {
             constexpr uint32_t L = decltype(tag)::value;
             if (lw) launch_greedy<L, true>(ctx, V, nch, stream); else launch_greedy<L, false>(ctx, V, nch, stream);
         };
-        const bool timed_form = lpc == 12 && lw && ctx->knob("solve_greedy_form", 0) == 32;
+        const bool timed_form = lpc == 12 && lw && (ctx->knob("solve_greedy_form", 0) & 32) != 0;
         const size_t n_waves = (static_cast<size_t>(nch) + 4) / 5 + 2;
         V.dbg = nullptr;
         if (timed_form) { ws.dbg.ensure(12 * n_waves); ws.dbg.zero(stream); V.dbg = ws.dbg.p; }
@@ -2263,7 +2172,7 @@ struct StageRunner {
             if (need > loc->lut_ext_depth) {
                 std::lock_guard<std::mutex> ws_lock(ctx->ws_mutex);             // the other lane of a queue may be sizing its own stage
                 ensure_depth_table(loc, std::min<uint64_t>(need, depth_cap));
-                V.lut = loc->d_lut_ext.p; V.lut2 = reinterpret_cast<const double2*>(loc->d_lut_pair.p); V.lut_depth = loc->lut_ext_depth; lut.clear();
+                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; lut.clear();
             }
             if (lut.empty()) {
                 lut.resize(static_cast<size_t>(LCTY_GC_BINS) * loc->lut_ext_depth);
@@ -2327,7 +2236,7 @@ struct StageRunner {
             if (priors) ws.pri.upload(priors + g0, ng, s);
             V.priors = priors ? ws.pri.p : nullptr;
             for (;;) {
-                V.lut = loc->d_lut_ext.p; V.lut2 = reinterpret_cast<const double2*>(loc->d_lut_pair.p); V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth));
+                V.lut = loc->d_lut_ext.p; V.lut_depth = loc->lut_ext_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(loc->lut_ext_depth));
                 launch(static_cast<uint32_t>(nch));
                 uint32_t ovf[2] = {0, 0};
                 ws.ovf.download(ovf, 2, s);
