@@ -87,6 +87,8 @@ def parse_args():
                     help="read pairs of the extra recruitment measurement (the step before the path, SURVEY 8f rank 1; 0 = skip)")
     ap.add_argument("--ont-map-sample", type=int, default=2048, help="of the --ont-sample reads: mapped from their bases alone onto every allele (long route of candidate generation), then scored and prefiltered (0 = skip)")
     ap.add_argument("--map-sample", type=int, default=32768, help="read pairs mapped onto 8 basis alleles by the candidate-generation slice (0 = skip)")
+    ap.add_argument("--ont-stream-sample", type=int, default=65536,
+                    help="10-kb ONT reads of the configs[2] leg from bases alone, streamed (mapped onto all alleles on the device, scored, prefiltered; 0 = skip)")
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
@@ -494,7 +496,7 @@ def main():
     if one_locus:
         os.environ.pop("NCCL_DEBUG", None)         # RCCL logs to stdout, which carries the one JSON line
         os.environ["NCCL_DEBUG_FILE"] = os.devnull
-        args.recovery_sample = args.recruit_sample = args.ont_sample = 0
+        args.recovery_sample = args.recruit_sample = args.ont_sample = args.ont_stream_sample = 0
         uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
         if dist is not None:
             import torch
@@ -996,12 +998,22 @@ def main():
                 api.map_append(am, c, mpl)
             t_map = time.perf_counter() - tm0
             n_launch, ms_map = ctx.timing(api.K_MAP)
+            # scoring, recovery with its second scoring pass (a first pass looks where a transfer would start at all: the mapper has reached
+            # every allele, so there is next to nothing) and run_filter, each on its own clock
             tm0 = time.perf_counter()
             am.score()
+            ctx.synchronize()
+            t_score1 = time.perf_counter() - tm0
             n_mapped = int(am.pair_alns()[0][-1])
+            tm0 = time.perf_counter()
             n_rec2 = am.recover()
-            t_rest = time.perf_counter() - tm0
+            ctx.synchronize()
+            t_recover = time.perf_counter() - tm0
+            tm0 = time.perf_counter()
             sc_m = am.run_filter()
+            ctx.synchronize()
+            t_filter = time.perf_counter() - tm0
+            t_rest = t_score1 + t_recover + t_filter
             band_w = 2 * mpl.band + 1
             cells_m = float(n_mapped) * (read_bases / max(nmap, 1)) * band_w
             per_aln = read_bases / max(nmap, 1) * (0.25 + 1.0 + 1.0)               # packed read bases + allele bases under the read + ~a CIGAR word per 4 bases
@@ -1013,7 +1025,9 @@ def main():
                 "alignments_per_s_kernel": n_mapped / (ms_map * 1e-3) if ms_map else None, "reads_per_s_call": nmap / t_map,
                 "aligned_bases_per_s_kernel": n_mapped * (read_bases / max(nmap, 1)) / (ms_map * 1e-3) if ms_map else None,
                 "band_cells": cells_m, "gcups": cells_m / (ms_map * 1e-3) / 1e9 if ms_map else None,
-                "score_recover_rescore_s": t_rest, "alignments_recovered": int(n_rec2), "good_reads": am.n_good(),
+                "score_recover_rescore_s": t_rest, "score_s": t_score1, "recover_s": t_recover, "run_filter_s": t_filter,
+                "reads_per_s_bases_to_prefilter": nmap / (t_map + t_rest),
+                "alignments_recovered": int(n_rec2), "good_reads": am.n_good(),
                 "prefilter_best_is_truth": bool(tuple(int(x) for x in gts[int(np.argmax(sc_m))]) == tuple(Lo.true_genotype)),
                 "truth_scores_as_the_best": bool(max(float(sc_m[i]) for i, g in enumerate(gts) if tuple(int(x) for x in g) == tuple(Lo.true_genotype)) >= float(sc_m.max()) - 1e-9 * abs(float(sc_m.max()))),
                 "roofline": {"bound": "hbm", "kernel": "map_long_align_kernel", "achieved": per_aln * n_mapped / (ms_map * 1e-3) / 1e9 if ms_map else None,
@@ -1023,6 +1037,12 @@ def main():
                              "what": "read bases (2 bit) + allele bases under the read + CIGAR words out, per alignment; the kernel is bound by instruction issue "
                                      "(a row of the band per ~150 instructions of one wavefront), not by these bytes: DESIGN.md section 5"}}
             am.close(); del fq
+
+    if args.ont_stream_sample > 0 and world == 1:
+        progress("configs[2] from bases, streamed")
+        from locityper_amd import legs
+        ctx.trim()
+        out["long_reads_stream"] = legs.ont_from_bases_stream(ctx, args.ont_stream_sample, A, progress=progress)
 
     if first is not None:
         progress("CPU baseline")

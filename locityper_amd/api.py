@@ -269,7 +269,7 @@ class AllAlignments:
         """Alignment recovery (transfer.rs:70-140) between two scoring passes; returns the number of transferred alignments."""
         n = U64()
         check(lib().lcty_recover_alignments(self._h, C.byref(n)))
-        self.score()
+        if n.value: self.score()                 # nothing transferred: the batch is as it was scored
         return int(n.value)
 
     def recover_dp_cells(self):

@@ -194,6 +194,8 @@ struct TransferArgs {
     uint32_t* flag;                // 1 = arena overflow (retry larger), LCTY_ERR_* >= 2 otherwise
     unsigned long long* dp_cells;  // cells of the aligner's matrices, all lanes
     double min_weight;
+    uint32_t dry_run;              // 1: only look where a transfer WOULD start (no similar position on the target yet): pairs with any go to
+                                   // redo_list, their number of such (source, target) combinations is added to rec_cursor; nothing is walked
 };
 
 __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     const uint2 s1 = sp[si], s2 = sp[si + 1];
                     const uint32_t approx = s1.y + (((sa.start & 255u) * (s2.y - s1.y)) >> 8);
                     if (pos_get(P, e, target, approx, &hit)) kind = 1;
+                    else if (T.dry_run) kind = 4;
                     else {
                         // find_cigar_offset (cigar.rs:1143-1162)
                         const uint2* pos = H.positions + bm.y;
@@ -322,6 +325,15 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                         walking = walk_init(walk, H.items + bm.y, bm.z, dir, sa.start, ci, qpos_at, rpos_at,
                                             src, out);
                     }
+                }
+                if (T.dry_run) {
+                    // an upper bound: the real run also finds the alignments it has transferred itself, and stops at its failures
+                    const unsigned long long would = __ballot(kind == 4);
+                    if (kind == 1 && hit < n0) P.seen[hit] = 1;
+                    __syncthreads();
+                    if (lane == 0) sh_n_new += static_cast<uint32_t>(__popcll(would));
+                    __syncthreads();
+                    continue;
                 }
                 // the walks of all lanes, resumed until none of them waits for the aligner any more: one converged call site
                 {
@@ -476,6 +488,14 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
         }
         __syncthreads();
 
+        if (T.dry_run) {
+            if (lane == 0 && sh_n_new) {
+                T.redo_list[atomicAdd(T.redo_n, 1ull)] = p;
+                atomicAdd(T.rec_cursor, static_cast<unsigned long long>(sh_n_new));
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- hand the transferred alignments over: per pair a contiguous run, read end 0 first, push order inside an end ----
         const uint32_t n_new = sh_redo ? 0u : sh_n_new, n_words = sh_words;
         if (n_new) {
@@ -755,6 +775,53 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         DevBuf<uint8_t>& d_xrecs_bytes = ctx->transfer_recs; DevBuf<uint32_t>& d_xwords = ctx->transfer_words;     // kept between calls, as the scratch
         lcty_aln_rec* xrecs = nullptr;
         unsigned long long cursors[3] = {0, 0, 0};
+        // First a look at where transfers would start at all: the position estimate on every target and the probe of the pair's position
+        // set, nothing walked (a few KB of scratch per wavefront). A batch whose mapper has already reached every allele — candidate
+        // generation on the device, lcty_map_long.hip — has nothing to recover, and a call that sized its lane scratch and arenas for
+        // "every record onto every other contig" paid seconds of allocation for it (1.5 s at 2 048 10-kb reads x 256 alleles). The
+        // walk then takes the pairs that have something to do, with arenas for at most what this pass counted.
+        DevBuf<uint64_t> d_list_0;
+        uint64_t n_first = 0, would = 0;
+        {
+            const uint32_t cap_alns = reads->max_recs_per_pair + 1;
+            uint32_t hcap = 64;
+            while (hcap < 2 * cap_alns + 2) hcap <<= 1;
+            Limits none; none.cigar_cap = 1; none.dp_dim = 0; none.dp_cells = 0;
+            const size_t stride = pair_scratch_bytes(cap_alns, hcap, 1, 1, none);
+            const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>({R, max_blocks, scratch_budget / stride})));
+            if (d_scratch.n < stride * blocks) d_scratch.alloc(stride * blocks);
+            d_list_0.alloc(R);
+            d_flag.zero(s); LCTY_HIP(hipMemsetAsync(d_cursors.p, 0, 3 * sizeof(unsigned long long), s));
+            TransferArgs T{};
+            T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = 1; T.cap_words = 1; T.lim = none; T.last_level = 1; T.walk_budget = 1;
+            T.pair_list = nullptr; T.n_list = R; T.redo_list = d_list_0.p; T.redo_n = d_cursors.p + 2;
+            T.scratch = d_scratch.p; T.scratch_stride = stride;
+            T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
+            T.out_recs = nullptr; T.out_recs_cap = 0; T.out_words = nullptr; T.out_words_cap = 0;
+            T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.dp_cells = d_cursors.p + 3; T.min_weight = loc->prm.min_weight;
+            T.dry_run = 1;
+            ctx->timed(LCTY_K_TRANSFER, [&] {
+                hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
+            });
+            LCTY_HIP(hipGetLastError());
+            uint32_t flag = 0;
+            d_flag.download(&flag, 1, s);
+            d_cursors.download(cursors, 3, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            if (flag > 1) fail(static_cast<int32_t>(flag), "alignment recovery failed on the device");
+            would = cursors[0]; n_first = cursors[2];
+            reads->recover_level_pairs[0] = reads->recover_level_pairs[1] = reads->recover_level_pairs[2] = 0;
+            if (n_first == 0) { reads->recover_dp_cells = 0; return; }                 // every target of every alignment is there already
+            // the pairs in batch order again (the pass appended them as its wavefronts got to them): the walk's arenas then fill in the
+            // order they always did
+            std::vector<uint64_t> lst(n_first);
+            d_list_0.download(lst.data(), n_first, s);
+            LCTY_HIP(hipStreamSynchronize(s));
+            std::sort(lst.begin(), lst.end());
+            d_list_0.upload(lst.data(), n_first, s);
+            arena_recs = std::min<uint64_t>(arena_recs, would + 1024);
+            arena_words = std::min<uint64_t>(arena_words, arena_recs * std::max<uint32_t>(4, rec_cigar + 8));
+        }
         for (int attempt = 0;; attempt++) {
             if (attempt > 12) fail(LCTY_ERR_RUNTIME, "alignment recovery: arenas keep overflowing");
             const uint32_t cap_alns = reads->max_recs_per_pair + cap_new;
@@ -767,8 +834,8 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             d_flag.zero(s); LCTY_HIP(hipMemsetAsync(d_cursors.p, 0, 3 * sizeof(unsigned long long), s));      // the aligner's cell count runs on
             uint32_t flag = 0;
             reads->recover_level_pairs[0] = reads->recover_level_pairs[1] = reads->recover_level_pairs[2] = 0;
-            const uint64_t* list = nullptr;
-            uint64_t n_list = R;
+            const uint64_t* list = d_list_0.p;
+            uint64_t n_list = n_first;
             for (size_t lv = 0; lv < levels.size() && n_list; lv++) {
                 const Limits lim = levels[lv];
                 const size_t stride = pair_scratch_bytes(cap_alns, hcap, cap_new, cap_words, lim);
@@ -778,6 +845,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
                 T.lim = lim; T.last_level = lv + 1 == levels.size();
                 T.walk_budget = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_walk_budget", 1 << 30)));
+                T.dry_run = 0;
                 T.pair_list = list; T.n_list = n_list;
                 uint64_t* next = (lv % 2 == 0) ? d_list_a.p : d_list_b.p;
                 T.redo_list = next; T.redo_n = d_cursors.p + 2;

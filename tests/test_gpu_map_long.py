@@ -285,3 +285,21 @@ def test_kilobase_reads_equal_the_restatement(gpu_ctx, stride, skew):
     got = api.map_reads(loc, fq, mp)
     recs, cigar, cig_off = assert_equals_restatement(got, fq, L.seqs, L.seq_off, basis, mp, paired=False)
     assert sum(1 for r in recs if not r[2] & cdefs.FLAG_UNMAPPED) >= 20 and max(r[3] for r in recs) > 100
+
+
+def test_long_route_on_256_basis_alleles_equals_the_restatement(gpu_ctx):
+    """The widest form of the long route — 256 basis alleles: 512 (allele, strand) groups per read end, the widest group tables and chain
+    scratch — record for record against the restatement: eight 2-3-kb ONT reads (3 % errors) onto every allele of a 256-allele locus
+    (the shape BASELINE.json configs[2] maps; the Python side takes a minute or two)."""
+    L = synth.SynthLocus(256, 8, seed=synth.SEED + 23, technology=cdefs.TECH_NANOPORE, read_len=2_500, base_len=8_000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    fq = synth.sequencer_orientation(L.reads(0, 8, primaries_only=True))
+    assert int(fq.mate_len[::2].min()) >= 2000
+    mp = api.map_params(long_reads=True)
+    basis = list(range(256))
+    api.build_map_index(loc, basis, k=mp.k)
+    got = api.map_reads(loc, fq, mp)
+    recs, cigar, cig_off = assert_equals_restatement(got, fq, L.seqs, L.seq_off, basis, mp, paired=False)
+    mapped = [r for r in recs if not r[2] & cdefs.FLAG_UNMAPPED]
+    assert len(mapped) >= 8 * 250 and len({r[1] for r in mapped}) == 256          # every allele reached, by (nearly) every read
