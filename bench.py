@@ -1042,7 +1042,27 @@ def main():
         progress("configs[2] from bases, streamed")
         from locityper_amd import legs
         ctx.trim()
-        out["long_reads_stream"] = legs.ont_from_bases_stream(ctx, args.ont_stream_sample, A, progress=progress)
+        out["long_reads_stream"], (Ls, ps) = legs.ont_from_bases_stream(ctx, args.ont_stream_sample, A, progress=progress)
+        if args.cpu_sample > 0:
+            # the CPU beside it: the oracle has no restatement of the mapper in C (tests/pyref_map_long.py is Python: 16 alignments/s); what
+            # it has for long reads is the reference's own route once a mapper has placed a read — AllAlignments::load with alignment recovery
+            # onto the other alleles (locs.rs:1085-1185, transfer.rs:70-140) — timed on one core
+            from tests import oracle_ffi as O
+            ns = min(8, args.ont_stream_sample)
+            ols = O.OracleLocus(Ls.seqs, Ls.seq_off, Ls.counts, Ls.cnt_off, Ls.k, Ls.bg, ps)
+            Hos = O.HapAlns(A, transfer_fails=100, max_div=0.1)
+            for q, r, w, _, _ in Ls.hap_alns(): Hos.add(q, r, w)
+            Hos.sort()
+            prim_s = Ls.reads(0, ns, primaries_only=True)
+            tc = time.perf_counter()
+            oas = ols.load_recover(prim_s, Hos)
+            dtc = time.perf_counter() - tc
+            out["long_reads_stream"]["cpu_baseline"] = {
+                "value": ns / dtc, "unit": "reads/s", "cores": 1, "kind": "port",
+                "sample": f"{ns} of those reads with the generator's primary record: oracle AllAlignments::load with alignment recovery onto the other "
+                          f"{A - 1} alleles (the reference's route behind its mapper; the mapper itself has no C restatement)",
+                "alignments_per_s": ns * A / dtc, "good_reads": oas.n_good}
+            del ols, Hos, oas
 
     if first is not None:
         progress("CPU baseline")

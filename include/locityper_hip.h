@@ -219,8 +219,7 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
 /* Limits of the retry / batching machinery of this context and choices between equivalent kernel forms, for tests that must reach
  * those paths with small inputs (no environment variable changes what the library computes):
  *   "transfer_levels", "transfer_scratch_mb", "transfer_waves", "transfer_cap_new", "transfer_arena"   lcty_recover_alignments: scratch
- *       levels, arenas;   "transfer_walk_budget"   phases of the two-CIGAR walk between two looks of a wavefront at which of its lanes need
- *       the aligner (default: none in between — measured at 10-kb reads x 256 alleles: 231 ms without, 238 / 265 / 322 / 350 ms at 16 / 8 / 4 / 1);
+ *       levels, arenas;
  *   "depth_table_start"   first width of the extended depth table;   "solve_budget_mb"   device memory for the per-chain state of a
  *       solver stage;   "solve_extra_start"   first size of a chain's run of locations beyond the second;
  *   "solve_chains_per_wave"   1, 2, 4, 5, 6 chains of the greedy loop per wavefront;   "solve_lds_weights"   0: the greedy loop gathers

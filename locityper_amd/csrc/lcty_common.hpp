@@ -105,7 +105,7 @@ struct DevBuf {
     }
 };
 
-// One non-trivial read of one solver chain / a location beyond its second (lcty_solve.hip)
+// One non-trivial read of one solver chain / a location beyond its second (lcty_solve_kernels.hip)
 struct __attribute__((aligned(32))) ChainRec {
     uint32_t rp_cur;                // good-read index (24 bit) | current location << 24 (the only field a move changes)
     uint32_t meta;                  // number of locations (8 bit) | index of location 2 in the chain's ExtraLoc run << 8
@@ -183,7 +183,7 @@ struct lcty_ctx {
         if (!copy) LCTY_HIP(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
         return copy;
     }
-    // Per-chain device state of the solver stages (lcty_solve.hip), one per stream of the context. Grow-only and kept between
+    // Per-chain device state of the solver stages (lcty_solve_kernels.hip), one per stream of the context. Grow-only and kept between
     // stages and loci: at 1 M read pairs the records of 5 000 chains are ~150 GB, and allocating / freeing that per stage costs
     // more than the stage. lcty_ctx_trim releases it.
     struct SolveWorkspace {

@@ -63,7 +63,7 @@ struct lcty_locus {
     lcty::DevBuf<uint2> d_hap_items, d_hap_positions, d_hap_sparse;
     uint32_t hap_transfer_fails = 0, hap_cells = 0;
     bool has_hap_alns = false;
-    lcty::DevBuf<double> d_lut_ext;          // [101][lut_ext_depth] depth table of the solver stages (lcty_solve.hip)
+    lcty::DevBuf<double> d_lut_ext;          // [101][lut_ext_depth] depth table of the solver stages (lcty_solve_kernels.hip)
     uint32_t lut_ext_depth = 0;
     uint32_t max_n_windows = 0;
 
@@ -118,7 +118,7 @@ struct lcty_reads {
     uint64_t n_good_cached = 0;
     bool good_valid = false;
     void ensure_good_index();
-    // allele-major location table of the solver stages (lcty_solve.hip), rows of ngp entries
+    // allele-major location table of the solver stages (lcty_solve_kernels.hip), rows of ngp entries
     lcty::DevBuf<uint8_t> d_loc_table;       // [A][ngp] 16-byte LocCell cells
     lcty::DevBuf<uint32_t> d_loc_ext;        // [A][ngp] arena index of a cell's second pair-alignment
     lcty::DevBuf<double> d_loc_unm;          // [ngp] "both mates unmapped" probability of every good read pair
@@ -178,7 +178,7 @@ struct DeviceRecords {
 int32_t reads_append_device(lcty_reads* R, const lcty_reads_host* h, const DeviceRecords* dev);
 
 // The rows of a stage's alleles of the location tables of several batches (shards of one locus' reads, in read order), laid
-// side by side into one table the solver kernels run on (lcty_solve.hip). The caller moves the packed rows between devices
+// side by side into one table the solver kernels run on (lcty_solve_kernels.hip). The caller moves the packed rows between devices
 // (lcty_comm.hip) or hands every shard over itself (lcty_solve_stage_from_shards).
 struct RowGatherer {
     lcty_reads* owner; lcty_ctx* ctx; hipStream_t stream;

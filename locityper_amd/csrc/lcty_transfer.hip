@@ -844,7 +844,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 TransferArgs T{};
                 T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
                 T.lim = lim; T.last_level = lv + 1 == levels.size();
-                T.walk_budget = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_walk_budget", 1 << 30)));
+                T.walk_budget = 1u << 30;                             // the walk never stops to look who needs the aligner (round 3: any budget was slower)
                 T.dry_run = 0;
                 T.pair_list = list; T.n_list = n_list;
                 uint64_t* next = (lv % 2 == 0) ? d_list_a.p : d_list_b.p;

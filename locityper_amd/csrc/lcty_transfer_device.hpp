@@ -483,7 +483,7 @@ __device__ inline bool walk_init(Walk& w, const uint2* jk_items, uint32_t jk_n, 
 }
 
 // walks on until the aligner is needed (WALK_JOB, `job` filled), the transfer is complete (WALK_DONE) or `budget` phases have been
-// walked (WALK_MORE: lcty_ctx_set_knob "transfer_walk_budget"). Measured at 10-kb reads x 256 alleles: letting the lanes that need the
+// walked (WALK_MORE; a knob in round 3, a constant now: no budget). Measured at 10-kb reads x 256 alleles: letting the lanes that need the
 // aligner wait for ALL others to need it too (no budget) is the fastest form — 231 ms against 350 ms when the wavefront looks after
 // every phase: a call of the aligner costs the wavefront the same whatever the number of lanes in it, so few full calls beat many
 // sparse ones, although the lanes then spend three quarters of the walk waiting (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 16 of 64).

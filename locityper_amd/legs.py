@@ -121,13 +121,14 @@ def ont_from_bases_on_a_basis(ctx, n_reads, n_alleles=256, n_basis=16, chunk=204
     return out, (L, loc, chunks)
 
 
-def ont_from_bases_stream(ctx, n_reads, n_alleles=256, chunk=1024, read_len=10_000, seed_off=77, cpu_sample=8, progress=None):
+def ont_from_bases_stream(ctx, n_reads, n_alleles=256, chunk=1024, read_len=10_000, seed_off=77, progress=None):
     """BASELINE.json configs[2] as named — 10-kb ONT reads x 256 alleles, the long-read DP path — from the bases alone to the prefilter call,
     through a streaming batch: every chunk of reads as sequenced is mapped onto EVERY allele on the device (long route: seeds -> one chain
     per (allele, strand) -> banded gap-affine alignment; the reference runs minimap2 -N min(25 000, 4 x alleles) here, genotype.rs:990-1002),
     its records go straight into the batch and are scored (AllAlignments::load), then dropped; run_filter over all genotypes at the end.
     (Mapping onto a basis of 16 alleles and reaching the others by alignment transfer is three times as fast and calls the wrong genotype
-    on these reads: ont_from_bases_on_a_basis and DESIGN.md say why.)"""
+    on these reads: ont_from_bases_on_a_basis and DESIGN.md say why.) Returns the leg's figures and (locus generator, resolved parameters)
+    for the caller's CPU baseline (the oracle is test infrastructure: nothing in this package touches it)."""
     say = progress or (lambda *_: None)
     A = n_alleles
     L = synth.SynthLocus(A, n_reads, seed=synth.SEED + seed_off, technology=cdefs.TECH_NANOPORE, read_len=read_len)
@@ -195,23 +196,4 @@ def ont_from_bases_stream(ctx, n_reads, n_alleles=256, chunk=1024, read_len=10_0
                              "~120 KB per alignment, small beside it"},
     }
     aa.close()
-    if cpu_sample:
-        # the CPU beside it: the oracle has no restatement of the mapper in C (tests/pyref_map_long.py is Python: 16 alignments/s); what
-        # it has for long reads is the reference's own route once a mapper has placed a read — AllAlignments::load with alignment recovery
-        # onto the other alleles (locs.rs:1085-1185, transfer.rs:70-140) — timed on one core
-        from tests import oracle_ffi as O
-        ns = min(cpu_sample, n_reads)
-        ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
-        Hs = L.hap_alns()
-        Ho = O.HapAlns(A, transfer_fails=100, max_div=0.1)
-        for q, r, w, _, _ in Hs: Ho.add(q, r, w)
-        Ho.sort()
-        prim = L.reads(0, ns, primaries_only=True)
-        t0 = time.perf_counter()
-        oa = ol.load_recover(prim, Ho)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-                               "sample": f"{ns} of those reads with the generator's primary record: oracle AllAlignments::load with alignment recovery onto the "
-                                         f"other {A - 1} alleles (the reference's route behind its mapper; the mapper itself has no C restatement)",
-                               "alignments_per_s": ns * A / dt, "good_reads": oa.n_good}
-    return out
+    return out, (L, p)

@@ -5,4 +5,4 @@ from locityper_amd import api, legs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 ctx = api.Context(0)
-print(json.dumps(legs.ont_from_bases_stream(ctx, n, 256, chunk=chunk, progress=lambda s: print(s, file=sys.stderr, flush=True))))
+print(json.dumps(legs.ont_from_bases_stream(ctx, n, 256, chunk=chunk, progress=lambda s: print(s, file=sys.stderr, flush=True))[0]))

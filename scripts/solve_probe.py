@@ -18,7 +18,7 @@ def main():
         if args[i] == "--chains": n = int(args[i + 1]); i += 2
         elif args[i] == "--lib":
             from locityper_amd import _lib
-            _lib.LIB_PATH = os.path.abspath(args[i + 1]); i += 2          # a variant built by scripts/build_solve_experiments.sh
+            _lib.LIB_PATH = os.path.abspath(args[i + 1]); i += 2          # a variant library built by hand (hipcc over a patched copy of a source)
         elif args[i] == "--short": short = True; i += 1
         else: settings.append(args[i]); i += 1
     if not settings: settings = ["default"]

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from locityper_amd import api, synth, cdefs, _lib
-if os.environ.get("LCTY_EXPERIMENT_LIB"):              # developer experiments only (scripts/build_solve_experiments.sh)
+if os.environ.get("LCTY_EXPERIMENT_LIB"):              # developer experiments only (a variant library built by hand)
     _lib.LIB_PATH = os.environ["LCTY_EXPERIMENT_LIB"]
 
 def main():
