@@ -163,7 +163,11 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
     reps = max(1, args.cpu_reps)
     med = lambda xs: float(np.median(xs))
     n_phys = physical_cores()
-    thread_sets = [8] if n_phys <= 8 else [8, n_phys]
+    # the second setting stops at 32 threads: beyond that the oracle's stage loop does not scale (run r4_v1, 128 cores: 2.72 chains/s against
+    # 2.01 at 8 threads — every worker streams the locus' 6 GB of pair-alignments per genotype, GenotypeAlignments::new — and 128 full-size
+    # chains at once are 95 s of the run)
+    n_max = min(n_phys, 32)
+    thread_sets = [8] if n_max <= 8 else [8, n_max]
     # ---- run_filter: single thread whatever `threads` is; first on the first slice (for the estimate), then at full size ----
     oa = ol.load(slices[0])
     Mo = oa.best_aln_matrix()
@@ -225,7 +229,7 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
             na = min(max(T, 4), len(order))
             sub_a = gts[order[:na]]
             tgreedy, tanneal = [], []
-            for rep in range(reps if T == 8 else 1):                         # at all cores one worker per core runs a full-size chain: once
+            for rep in range(1):                                              # a full-size chain per worker is seconds: once
                 tc = time.perf_counter()
                 O.solve_stage(ol, oa_full, sub_g, greedy, 1, api.chain_seeds(1000 + rep, ng), threads=T)
                 tgreedy.append(time.perf_counter() - tc)
@@ -243,6 +247,7 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
         by["threads_8" if T == 8 else "all_cores"] = entry
     if "all_cores" not in by:
         by["all_cores"] = dict(by["threads_8"])          # an 8-core host: the two coincide
+    by["all_cores"]["note"] = f"{by['all_cores']['threads']} threads of {n_phys} physical cores (capped at 32: see bench.py)"
     if oa_full is not None and "greedy_chains_per_s_per_thread" in by["threads_8"]:
         # how the stage loop scales from the reference's default of 8 threads to every core (1.0 = linear in the threads)
         t8, ta = by["threads_8"], by["all_cores"]
