@@ -59,7 +59,7 @@ def parse_args():
                     help="how the alignment table reaches the library: 16-byte counted alignments (lcty_reads_append_counted, SURVEY 8(d)'s "
                          "alignment-table entry; the default) or BAM records with their CIGAR words (lcty_reads_append)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of every CPU-baseline figure (the median is reported)")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"),
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
     ap.add_argument("--shard-reads", action="store_true",

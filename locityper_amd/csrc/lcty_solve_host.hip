@@ -213,7 +213,21 @@ struct StageRunner {
         if (V.solver.kind == LCTY_SOLVER_EXACT) { solve_exact_batch(nch); return; }
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
             if (lane == 1) wait_for_greedy_of_next_locus();
+            const bool timed_anneal = ctx->knob("solve_anneal_timing", 0) != 0;
+            V.dbg = nullptr;
+            if (timed_anneal) { ws.dbg.ensure(12 * static_cast<size_t>(nch)); ws.dbg.zero(stream); V.dbg = ws.dbg.p; }
             launch_anneal(ctx, V, nch, stream);
+            if (timed_anneal) {
+                // diagnostic: the second loop of the annealing chains (stoch.rs:228-241), shader-clock ticks per ROUND and phase, means over the chains
+                std::vector<double> d(12 * static_cast<size_t>(nch));
+                ws.dbg.download(d.data(), d.size(), stream);
+                LCTY_HIP(hipStreamSynchronize(stream));
+                double sum[10] = {0}; size_t used = 0;
+                for (size_t c = 0; c < nch; c++) if (d[12 * c + 6] > 0) { used++; for (int k = 0; k < 6; k++) sum[k] += d[12 * c + k] / d[12 * c + 6]; for (int k = 6; k < 10; k++) sum[k] += d[12 * c + k]; }
+                if (used) fprintf(stderr, "[lcty anneal phases] %zu chains; second loop: %.0f rounds, %.1f moves per round, accepted %.0f of %.0f moves in all; ticks per round: wait for the ring + words %.0f, "
+                                          "moves from the ring %.0f, depths + gathers + score %.0f, ballots + chain walk %.0f, apply + retire %.0f; loop total per round %.0f\n",
+                                  used, sum[6] / used, sum[7] / std::max(sum[6], 1.0), sum[8] / used, sum[9] / used, sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used, sum[4] / used, sum[5] / used);
+            }
             if (ctx->knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p annealing launched (lane %u)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), static_cast<const void*>(reads), lane);
             return;

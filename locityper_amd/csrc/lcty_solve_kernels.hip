@@ -1344,13 +1344,18 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         // draws earlier; next to the greedy chains of the following locus the line has left the L2 by then), and it was a round
         // trip of its own in front of the table gathers. pf of lane l is the word of position pf_base + l; the step that applied a
         // move after the words were requested patches the one it changed (lm_*).
-        uint32_t pf = 0, pf_slot = 0xFFFFFFFFu, pf_base = 0, pf_n = 0, lm_slot = 0xFFFFFFFFu, lm_to = 0;
+        constexpr uint32_t MAXA = 8;                                          // accepted moves one round of the second loop applies at most
+        uint32_t pf = 0, pf_slot = 0xFFFFFFFFu, pf_base = 0, pf_n = 0;
+        uint32_t lm_slot[MAXA], lm_to[MAXA];                                  // the moves applied since the words were requested (uniform)
+#pragma unroll
+        for (uint32_t k = 0; k < MAXA; k++) { lm_slot[k] = 0xFFFFFFFFu; lm_to[k] = 0; }
         auto pf_issue = [&]() {                                               // one load per lane, no branch around it
             const uint32_t avail = __hip_atomic_load(&ring->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - consumed;
             pf_base = consumed; pf_n = min(avail, 64u);
             pf_slot = lane < pf_n ? slot_at(lane) : 0u;
             pf = load_rp_cur(&recs[pf_slot]);
-            lm_slot = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t k = 0; k < MAXA; k++) lm_slot[k] = 0xFFFFFFFFu;
         };
         auto pf_covered = [&]() -> uint32_t {                                 // positions from `consumed` on whose words are here
             const uint32_t end = pf_base + pf_n;
@@ -1360,7 +1365,10 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
             const int src = static_cast<int>((consumed + off - pf_base) & 63u);
             const uint32_t v = static_cast<uint32_t>(__shfl(static_cast<int>(pf), src));
             const uint32_t vs = static_cast<uint32_t>(__shfl(static_cast<int>(pf_slot), src));
-            return vs == lm_slot ? (v & 0xFFFFFFu) | (lm_to << 24) : v;
+            uint32_t out = v;
+#pragma unroll
+            for (uint32_t k = 0; k < MAXA; k++) out = vs == lm_slot[k] ? (v & 0xFFFFFFu) | (lm_to[k] << 24) : out;
+            return out;
         };
         auto retire = [&](uint32_t q) {                                    // the producer may reuse the ring entries of q draws
             consumed += q;
@@ -1399,7 +1407,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
             const double diff = improvement(m) - min_diff;
             bool accept = diff >= 0.0;
             if (!accept) { accept = ring_f64(c) <= exp(diff / (temp_step * static_cast<double>(i))); c++; }
-            if (accept) { reassign(m); curr_plato = 0; lm_slot = m.slot; lm_to = m.new_assgn; }
+            if (accept) { reassign(m); curr_plato = 0; lm_slot[0] = m.slot; lm_to[0] = m.new_assgn; }
             else { curr_plato++; }
             retire(c);
             if (!accept && curr_plato >= V.solver.plato_size) break;
@@ -1411,15 +1419,23 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         // the stream continues right behind it. Same moves, same order, same result as the serial loop.
         uint64_t iter = 0;
         uint32_t width = 16;                                               // lanes that speculate: about twice the recent run length
+        // (diagnostic, lcty_ctx_set_knob "solve_anneal_timing": SolveView::dbg set) shader-clock ticks of the phases of a round, rounds, moves
+        const bool timed = V.dbg != nullptr;
+        uint64_t tph[5] = {0, 0, 0, 0, 0}, n_rounds = 0, n_walked = 0, t_first = timed ? __builtin_amdgcn_s_memtime() : 0;
+        auto stamp = [&]() -> uint64_t { return timed ? __builtin_amdgcn_s_memtime() : 0ull; };
         while (!lost && iter < max_iter && curr_plato < V.solver.plato_size) {
+            const uint64_t ta = stamp();
             const uint32_t avail = ring_wait(2);                           // a move may take the draw after its own
             if (!avail) break;
             if (pf_covered() < 2) pf_issue();
             const uint32_t w = min(min(width, avail - 1), pf_covered());       // only positions whose `cur` words are here
             Move m; blank(m);
             bool accepted = false, wide = false;
+            const uint64_t tb = stamp();
             const uint32_t packed = pf_take(lane);
             if (lane < w) wide = move_pre(lane, packed, m) == 2;                // lanes beyond: windows 0, no effect
+            if (timed) asm volatile("" :: "v"(m.w1), "v"(m.w3), "v"(m.lp_new));
+            const uint64_t tc = stamp();
             {
                 typename ChainT::DepthGather g;
                 C.request(m.w1, m.w2, m.w3, m.w4, g);
@@ -1427,6 +1443,8 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 m.ddiff = C.finish(g);
             }
             accepted = lane < w && improvement(m) > min_diff;
+            if (timed) asm volatile("" :: "v"(m.ddiff));
+            const uint64_t td = stamp();
             const unsigned long long acc = __ballot(accepted);
             const unsigned long long two = __ballot(wide);
             uint32_t q = 0, walked = 0;
@@ -1439,18 +1457,69 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
             const uint32_t after = ones ? 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(ones))) : 0u;      // r + 1
             const unsigned long long chain_mask = __ballot(lane < w && ((lane - after) & 1u) == 0u);
             const unsigned long long hits = acc & chain_mask;
-            const uint32_t stop = hits ? static_cast<uint32_t>(__ffsll(static_cast<long long>(hits))) - 1u : w;   // first accepted move on the chain
-            const uint32_t moves = static_cast<uint32_t>(__popcll(chain_mask & (stop >= 63u ? ~0ull : ((2ull << stop) - 1ull))));   // evaluated in order, the hit included
-            const uint32_t rejected = moves - (hits ? 1u : 0u);
-            if (iter + moves <= max_iter && curr_plato + rejected < V.solver.plato_size) {
-                // neither cap is reached inside this step: the serial loop would have gone exactly this far
-                iter += moves; n_iter += moves; walked = moves; curr_plato += rejected;
-                if (hits) { hit = static_cast<int>(stop); q = stop + 1u + static_cast<uint32_t>((two >> stop) & 1ull); }
-                else {
-                    // everything evaluated was rejected: the draws used are those of the chain's moves among the first w positions
-                    const uint32_t last = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(chain_mask)));
-                    q = last + 1u + static_cast<uint32_t>((two >> last) & 1ull);
+            // SEVERAL ACCEPTED MOVES PER ROUND (round 4). One move in eight is accepted (configs[1]: 126 665 of 1.02 M), so a round that stops at its
+            // first accepted move walks eight positions of the sixty it has evaluated. But a move that follows an accepted one sees another
+            // state only where the two meet: its evaluation — the depths of its four windows, the current location of its read — is the one
+            // the serial loop would make as long as none of its windows and not its read belong to a move accepted before it in this round.
+            // So the walk goes on behind an accepted move, up to the first position that meets an earlier accepted move (it starts the next
+            // round, evaluated afresh), and every accepted move on the way is applied: same moves, same order, same sums as the serial loop.
+            unsigned long long applied = 0ull, rest = hits;
+            uint32_t n_app = 0, stop_excl = w;                                  // positions from stop_excl on belong to the next round
+            uint32_t a_slot[MAXA], a_to[MAXA];
+            double a_dd[MAXA], a_dl[MAXA];
+            const double my_dl = m.lp_new - m.lp_old;
+            auto lane64 = [](double x, int l) -> double {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+            };
+#pragma unroll
+            for (uint32_t k = 0; k < MAXA; k++) {
+                a_slot[k] = 0xFFFFFFFFu; a_to[k] = 0; a_dd[k] = 0.0; a_dl[k] = 0.0;
+                const uint32_t a = rest ? static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u : 64u;
+                if (a < stop_excl) {                                            // uniform
+                    const int al = __builtin_amdgcn_readfirstlane(static_cast<int>(a));
+                    const uint32_t aw1 = __builtin_amdgcn_readlane(m.w1, al), aw2 = __builtin_amdgcn_readlane(m.w2, al);
+                    const uint32_t aw3 = __builtin_amdgcn_readlane(m.w3, al), aw4 = __builtin_amdgcn_readlane(m.w4, al);
+                    a_slot[k] = __builtin_amdgcn_readlane(m.slot, al); a_to[k] = __builtin_amdgcn_readlane(m.new_assgn, al);
+                    a_dd[k] = lane64(m.ddiff, al); a_dl[k] = lane64(my_dl, al);
+                    applied |= 1ull << a; n_app = k + 1;
+                    // windows 0 and 1 (unmapped, out of the region) carry no distribution: their depths enter no evaluation
+                    auto meets = [&](uint32_t x) { return x >= 2u && (x == aw1 || x == aw2 || x == aw3 || x == aw4); };
+                    const bool conflict = lane > a && ((chain_mask >> lane) & 1ull) != 0ull &&
+                                          (m.slot == a_slot[k] || meets(m.w1) || meets(m.w2) || meets(m.w3) || meets(m.w4));
+                    const unsigned long long cm = __ballot(conflict);
+                    if (cm) stop_excl = min(stop_excl, static_cast<uint32_t>(__ffsll(static_cast<long long>(cm))) - 1u);
+                    rest &= ~((2ull << a) - 1ull);                              // a <= 62: w <= RING - 1
                 }
+            }
+            if (rest) stop_excl = min(stop_excl, static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u);   // an accepted move this round does not take
+            const unsigned long long upto = stop_excl >= 64u ? ~0ull : ((1ull << stop_excl) - 1ull);
+            const unsigned long long P = chain_mask & upto;                    // the positions the serial loop walks on this state
+            const uint32_t moves = static_cast<uint32_t>(__popcll(P));
+            const uint32_t first_a = applied ? static_cast<uint32_t>(__ffsll(static_cast<long long>(applied))) - 1u : 64u;
+            const uint32_t last_a = applied ? 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(applied))) : 0u;
+            const uint32_t rej_first = applied ? static_cast<uint32_t>(__popcll(P & ((1ull << first_a) - 1ull))) : moves;
+            const uint32_t rej_last = applied ? static_cast<uint32_t>(__popcll(P & ~((2ull << last_a) - 1ull))) : 0u;
+            bool many = false;
+            if (V.solver.plato_size > 64u && iter + moves <= max_iter && curr_plato + rej_first < V.solver.plato_size) {
+                // neither cap is reached inside this round (a run of rejections inside it is shorter than 64 < plato_size): the serial loop
+                // would have gone exactly this far
+                many = true;
+                iter += moves; n_iter += moves; walked = moves;
+                curr_plato = applied ? rej_last : curr_plato + moves;
+                const uint32_t lastp = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(P)));
+                q = lastp + 1u + static_cast<uint32_t>((two >> lastp) & 1ull);
+#pragma unroll
+                for (uint32_t k = 0; k < MAXA; k++) {
+                    if (k < n_app) { n_acc++; depth_lik += a_dd[k]; aln_lik += a_dl[k]; }       // in the order of the moves
+                    lm_slot[k] = k < n_app ? a_slot[k] : 0xFFFFFFFFu; lm_to[k] = a_to[k];          // the words requested above were read before these stores
+                }
+                if ((applied >> lane) & 1ull) {
+                    atomicAdd(&wd[m.w3], 1u); atomicAdd(&wd[m.w4], 1u);        // the depth field never borrows from the GC bits
+                    atomicSub(&wd[m.w1], 1u); atomicSub(&wd[m.w2], 1u);
+                    store_rp_cur(&recs[m.slot], m.rp | (m.new_assgn << 24));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             } else {
                 while (q < w) {                                               // the last steps of a chain: one move at a time
                     if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
@@ -1461,6 +1530,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                     q += cons;
                 }
             }
+            const uint64_t te = stamp();
             if (hit >= 0) {
                 Move a;
                 a.rp = __shfl(m.rp, hit); a.new_assgn = __shfl(m.new_assgn, hit); a.slot = __shfl(m.slot, hit);
@@ -1468,10 +1538,22 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 a.lp_old = __shfl(m.lp_old, hit); a.lp_new = __shfl(m.lp_new, hit); a.ddiff = __shfl(m.ddiff, hit);
                 reassign(a);
                 curr_plato = 0;
-                lm_slot = a.slot; lm_to = a.new_assgn;                          // the words requested above were read before this store
+                lm_slot[0] = a.slot; lm_to[0] = a.new_assgn;                    // the words requested above were read before this store
             }
+            if (many) hit = applied ? 0 : -1;                                   // for the width below: something was accepted
             width = min(RING - 1, max(8u, hit >= 0 ? (width + 2 * walked + 4) / 2 : 2 * width));
             retire(q);
+            if (timed) {
+                const uint64_t tf = stamp();
+                tph[0] += tb - ta; tph[1] += tc - tb; tph[2] += td - tc; tph[3] += te - td; tph[4] += tf - te;
+                n_rounds++; n_walked += walked;
+            }
+        }
+        if (timed && lane == 0) {
+            double* d = V.dbg + static_cast<size_t>(chain) * 12;
+            for (int k = 0; k < 5; k++) d[k] = static_cast<double>(tph[k]);
+            d[5] = static_cast<double>(__builtin_amdgcn_s_memtime() - t_first); d[6] = static_cast<double>(n_rounds); d[7] = static_cast<double>(n_walked);
+            d[8] = static_cast<double>(n_acc); d[9] = static_cast<double>(n_iter);
         }
     }
     if (!handed_over) __syncthreads();                                   // the producer waits for exactly one hand-over

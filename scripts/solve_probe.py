@@ -12,6 +12,7 @@ def main():
     args = [a for a in sys.argv[1:]]
     n = 5000
     short = False
+    anneal = False                                    # --anneal: the annealing stage of the default scheme instead (20 genotypes x 20 attempts)
     settings = []
     i = 0
     while i < len(args):
@@ -20,6 +21,7 @@ def main():
             from locityper_amd import _lib
             _lib.LIB_PATH = os.path.abspath(args[i + 1]); i += 2          # a variant library built by hand (hipcc over a patched copy of a source)
         elif args[i] == "--short": short = True; i += 1
+        elif args[i] == "--anneal": anneal = True; i += 1
         else: settings.append(args[i]); i += 1
     if not settings: settings = ["default"]
     A, pairs = 256, 1_000_000
@@ -39,21 +41,23 @@ def main():
     gts = api.generate_genotypes(A, 2)
     order = np.argsort(-sc, kind="stable")
     top = np.ascontiguousarray(gts[order[:n]])
-    sv = api.default_solver(cdefs.SOLVER_GREEDY)
+    sv = api.default_solver(cdefs.SOLVER_ANNEAL if anneal else cdefs.SOLVER_GREEDY)
     if short: sv.plato_size = 1
+    att = 1
+    if anneal: top, att, n = np.ascontiguousarray(top[:20]), 20, 400
     seeds = api.chain_seeds(7, n)
-    api.solve_stage(aa, top[:64], sv, 1, seeds[:64])          # allocations
+    api.solve_stage(aa, top[:min(64, len(top))], sv, att, seeds[:min(64, len(top)) * att])          # allocations
     first = None
     for st in settings:
         knobs = [] if st == "default" else [kv.split("=") for kv in st.split(",")]
         for k, v in knobs: ctx.set_knob(k, int(v))
-        api.solve_stage(aa, top, sv, 1, seeds)                # warm (workspace growth)
+        api.solve_stage(aa, top, sv, att, seeds)              # warm (workspace growth)
         ctx.timing_reset()
         t0 = time.perf_counter()
-        m, v_, l = api.solve_stage(aa, top, sv, 1, seeds)
+        m, v_, l = api.solve_stage(aa, top, sv, att, seeds)
         wall = time.perf_counter() - t0
         if first is None: first = l
-        print(f"{st}: init {ctx.timing(api.K_SOLVE_INIT)[1]:.1f} ms, loop {ctx.timing(api.K_SOLVE)[1]:.1f} ms, wall {1e3 * wall:.1f} ms, "
+        print(f"{st}: init {ctx.timing(api.K_SOLVE_INIT)[1]:.1f} ms, loop {ctx.timing(api.K_ANNEAL if anneal else api.K_SOLVE)[1]:.1f} ms, wall {1e3 * wall:.1f} ms, "
               f"likelihoods equal the first setting's: {bool(np.array_equal(l, first))}", flush=True)
         for k, _ in knobs: ctx.set_knob(k, -1)
 
