@@ -1344,9 +1344,11 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         // draws earlier; next to the greedy chains of the following locus the line has left the L2 by then), and it was a round
         // trip of its own in front of the table gathers. pf of lane l is the word of position pf_base + l; the step that applied a
         // move after the words were requested patches the one it changed (lm_*).
-        constexpr uint32_t MAXA = 8;                                          // accepted moves one round of the second loop applies at most
+        constexpr uint32_t MAXA = 6;                                          // accepted moves one round of the second loop applies at most
         uint32_t pf = 0, pf_slot = 0xFFFFFFFFu, pf_base = 0, pf_n = 0;
-        uint32_t lm_slot[MAXA], lm_to[MAXA];                                  // the moves applied since the words were requested (uniform)
+        // the moves applied since the `cur` words were requested (uniform): the words were read before those stores and are patched when
+        // they are taken — not where the moves are applied: that would wait for the words, which come from HBM
+        uint32_t lm_slot[MAXA], lm_to[MAXA];
 #pragma unroll
         for (uint32_t k = 0; k < MAXA; k++) { lm_slot[k] = 0xFFFFFFFFu; lm_to[k] = 0; }
         auto pf_issue = [&]() {                                               // one load per lane, no branch around it
@@ -1463,56 +1465,54 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
             // the serial loop would make as long as none of its windows and not its read belong to a move accepted before it in this round.
             // So the walk goes on behind an accepted move, up to the first position that meets an earlier accepted move (it starts the next
             // round, evaluated afresh), and every accepted move on the way is applied: same moves, same order, same sums as the serial loop.
-            unsigned long long applied = 0ull, rest = hits;
-            uint32_t n_app = 0, stop_excl = w;                                  // positions from stop_excl on belong to the next round
-            uint32_t a_slot[MAXA], a_to[MAXA];
-            double a_dd[MAXA], a_dl[MAXA];
-            const double my_dl = m.lp_new - m.lp_old;
-            auto lane64 = [](double x, int l) -> double {
-                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-            };
+            bool many = false;
+            unsigned long long applied = 0ull;
+            if (V.solver.plato_size > 64u && iter + 64u <= max_iter && curr_plato + 64u < V.solver.plato_size) {
+                // neither cap can be reached inside this round (it walks at most 63 positions; a run of rejections inside it is shorter
+                // than plato_size): the accepted moves are taken one after the other, each with its sums in the order of the moves
+                many = true;
+                // (everything that steers this loop is the same in all lanes and told to the compiler as such: left as lane values it
+                // becomes a divergent loop of nested branches — 3 700 clock ticks a round instead of a few hundred)
+                unsigned long long rest = uniform64(hits);
+                uint32_t n_app = 0, stop_excl = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));   // positions from stop_excl on belong to the next round
+                const double my_dl = m.lp_new - m.lp_old;
+                const uint32_t my_w12 = m.w1 | (m.w2 << 16), my_w34 = m.w3 | (m.w4 << 16);
+                const uint32_t on_chain = static_cast<uint32_t>((chain_mask >> lane) & 1ull);
+                while (rest) {
+                    const uint32_t a = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(rest)) - 1));
+                    if (a >= stop_excl || n_app == MAXA) break;
+                    const int al = static_cast<int>(a);
+                    const uint32_t a12 = __builtin_amdgcn_readlane(my_w12, al), a34 = __builtin_amdgcn_readlane(my_w34, al);
+                    const uint32_t aslot = __builtin_amdgcn_readlane(m.slot, al), ato = __builtin_amdgcn_readlane(m.new_assgn, al);
+                    const uint32_t aw1 = a12 & 0xFFFFu, aw2 = a12 >> 16, aw3 = a34 & 0xFFFFu, aw4 = a34 >> 16;
+                    n_acc++; n_app++;
+                    depth_lik += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m.ddiff), al), __builtin_amdgcn_readlane(__double2loint(m.ddiff), al));
+                    aln_lik += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_dl), al), __builtin_amdgcn_readlane(__double2loint(my_dl), al));
+                    applied |= 1ull << a;
 #pragma unroll
-            for (uint32_t k = 0; k < MAXA; k++) {
-                a_slot[k] = 0xFFFFFFFFu; a_to[k] = 0; a_dd[k] = 0.0; a_dl[k] = 0.0;
-                const uint32_t a = rest ? static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u : 64u;
-                if (a < stop_excl) {                                            // uniform
-                    const int al = __builtin_amdgcn_readfirstlane(static_cast<int>(a));
-                    const uint32_t aw1 = __builtin_amdgcn_readlane(m.w1, al), aw2 = __builtin_amdgcn_readlane(m.w2, al);
-                    const uint32_t aw3 = __builtin_amdgcn_readlane(m.w3, al), aw4 = __builtin_amdgcn_readlane(m.w4, al);
-                    a_slot[k] = __builtin_amdgcn_readlane(m.slot, al); a_to[k] = __builtin_amdgcn_readlane(m.new_assgn, al);
-                    a_dd[k] = lane64(m.ddiff, al); a_dl[k] = lane64(my_dl, al);
-                    applied |= 1ull << a; n_app = k + 1;
-                    // windows 0 and 1 (unmapped, out of the region) carry no distribution: their depths enter no evaluation
-                    auto meets = [&](uint32_t x) { return x >= 2u && (x == aw1 || x == aw2 || x == aw3 || x == aw4); };
-                    const bool conflict = lane > a && ((chain_mask >> lane) & 1ull) != 0ull &&
-                                          (m.slot == a_slot[k] || meets(m.w1) || meets(m.w2) || meets(m.w3) || meets(m.w4));
-                    const unsigned long long cm = __ballot(conflict);
-                    if (cm) stop_excl = min(stop_excl, static_cast<uint32_t>(__ffsll(static_cast<long long>(cm))) - 1u);
+                    for (uint32_t k = 0; k < MAXA; k++) if (n_app == k + 1) { lm_slot[k] = aslot; lm_to[k] = ato; }
+                    // windows 0 and 1 (unmapped, out of the region) carry no distribution: their depths enter no evaluation.
+                    // Bit operations, no short cuts: a chain of || is a chain of branches
+                    auto meets = [&](uint32_t x) -> uint32_t {
+                        return static_cast<uint32_t>(x >= 2u) & (static_cast<uint32_t>(x == aw1) | static_cast<uint32_t>(x == aw2) | static_cast<uint32_t>(x == aw3) | static_cast<uint32_t>(x == aw4));
+                    };
+                    const uint32_t conflict = static_cast<uint32_t>(lane > a) & on_chain &
+                                              (static_cast<uint32_t>(m.slot == aslot) | meets(m.w1) | meets(m.w2) | meets(m.w3) | meets(m.w4));
+                    const unsigned long long cm = __ballot(conflict != 0u);
+                    if (cm) stop_excl = min(stop_excl, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(cm)) - 1)));
                     rest &= ~((2ull << a) - 1ull);                              // a <= 62: w <= RING - 1
                 }
-            }
-            if (rest) stop_excl = min(stop_excl, static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u);   // an accepted move this round does not take
-            const unsigned long long upto = stop_excl >= 64u ? ~0ull : ((1ull << stop_excl) - 1ull);
-            const unsigned long long P = chain_mask & upto;                    // the positions the serial loop walks on this state
-            const uint32_t moves = static_cast<uint32_t>(__popcll(P));
-            const uint32_t first_a = applied ? static_cast<uint32_t>(__ffsll(static_cast<long long>(applied))) - 1u : 64u;
-            const uint32_t last_a = applied ? 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(applied))) : 0u;
-            const uint32_t rej_first = applied ? static_cast<uint32_t>(__popcll(P & ((1ull << first_a) - 1ull))) : moves;
-            const uint32_t rej_last = applied ? static_cast<uint32_t>(__popcll(P & ~((2ull << last_a) - 1ull))) : 0u;
-            bool many = false;
-            if (V.solver.plato_size > 64u && iter + moves <= max_iter && curr_plato + rej_first < V.solver.plato_size) {
-                // neither cap is reached inside this round (a run of rejections inside it is shorter than 64 < plato_size): the serial loop
-                // would have gone exactly this far
-                many = true;
+                if (rest) stop_excl = min(stop_excl, static_cast<uint32_t>(__ffsll(static_cast<long long>(rest))) - 1u);   // an accepted move this round does not take
+                const unsigned long long upto = stop_excl >= 64u ? ~0ull : ((1ull << stop_excl) - 1ull);
+                const unsigned long long P = chain_mask & upto;                // the positions the serial loop walks on this state
+                const uint32_t moves = static_cast<uint32_t>(__popcll(P));
                 iter += moves; n_iter += moves; walked = moves;
-                curr_plato = applied ? rej_last : curr_plato + moves;
+                if (applied) {
+                    const uint32_t last_a = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(applied)));
+                    curr_plato = static_cast<uint32_t>(__popcll(P & ~((2ull << last_a) - 1ull)));
+                } else curr_plato += moves;
                 const uint32_t lastp = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(P)));
                 q = lastp + 1u + static_cast<uint32_t>((two >> lastp) & 1ull);
-#pragma unroll
-                for (uint32_t k = 0; k < MAXA; k++) {
-                    if (k < n_app) { n_acc++; depth_lik += a_dd[k]; aln_lik += a_dl[k]; }       // in the order of the moves
-                    lm_slot[k] = k < n_app ? a_slot[k] : 0xFFFFFFFFu; lm_to[k] = a_to[k];          // the words requested above were read before these stores
-                }
                 if ((applied >> lane) & 1ull) {
                     atomicAdd(&wd[m.w3], 1u); atomicAdd(&wd[m.w4], 1u);        // the depth field never borrows from the GC bits
                     atomicSub(&wd[m.w1], 1u); atomicSub(&wd[m.w2], 1u);
