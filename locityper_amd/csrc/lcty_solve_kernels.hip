@@ -1158,7 +1158,9 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
     if (flagged != 0u) return;                     // the batch is repeated by the host (see greedy_loop_kernel)
     // These are few wavefronts with one dependent chain of instructions each; in a queue of loci they share their SIMDs with the
     // greedy wavefronts of the next locus, which always have an instruction ready. The issue arbiter takes the higher priority first.
-    __builtin_amdgcn_s_setprio(3);            // the annealing wavefronts issue first next to the greedy chains of the following locus (537 ms per step; greedy first 567, no priorities 579: round 3)
+    // the annealing wavefronts issue first next to the greedy chains of the following locus (round 3: 537 ms per step; greedy first 567, no
+    // priorities 579; round 4, with the annealing stage the shorter of the two: 466.7 ms, greedy first 468.3 with the annealing stage 36 ms longer)
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t W = V.wstride;
     // [W] window weights first (MODE 1) or the two weight tables (MODE 2), then [W] depth words, [W] half-words (MODE 2), then the
     // ring the second wavefront fills
