@@ -1097,8 +1097,12 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         GreedyCand R0, R1, R2;
         GreedyExt E0, E1, E2;
         if constexpr ((GREEDY_FORM & 32u) != 0) t_loop0 = __builtin_amdgcn_s_memtime();
-        request_record(R0); request_record(R1); request_record(R2);
+        // in the order the loop leaves its requests behind — the further locations of the coming iteration, THEN the record of the one
+        // after the next: the first copy of the unrolled loop is entered from here and from the loop's end, and the wait in front of
+        // its further locations must fit both (with the records requested first it waited for everything in flight, one iteration in three)
+        request_record(R0); request_record(R1);
         request_ext(R0, E0);
+        request_record(R2);
         while (__any(!done)) {
             iteration(std::integral_constant<uint32_t, 0>{}, R0, E0, R1, E1);
             if (!__any(!done)) break;
