@@ -10,6 +10,7 @@ using namespace lcty;
 
 namespace lcty {
 static thread_local std::string g_last_error;
+thread_local hipStream_t tl_stream = nullptr;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 }  // namespace lcty
 
@@ -81,7 +82,7 @@ int32_t lcty_ctx_create(int32_t device_id, lcty_ctx** out) {
         c->device = device_id;
         LCTY_HIP(hipSetDevice(device_id));
         LCTY_HIP(hipGetDeviceProperties(&c->props, device_id));
-        LCTY_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        LCTY_HIP(hipStreamCreateWithFlags(&c->stream.main, hipStreamNonBlocking));
         *out = c.release();
     });
 }
@@ -94,7 +95,7 @@ void lcty_ctx_destroy(lcty_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->gate.ev) (void)hipEventDestroy(ctx->gate.ev);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
-    (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream.main);
     delete ctx;
 }
 

@@ -122,12 +122,26 @@ struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// The stream a context's calls are issued on: its main stream, unless the calling host thread has been bound to another one
+// (the tail thread of lcty_solve_queue works on the side stream: whatever it calls — the error flag of the batch, a wider depth
+// table — must neither be issued on nor wait for the main stream, where the next locus is running).
+extern thread_local hipStream_t tl_stream;
+struct StreamRef {
+    hipStream_t main = nullptr;
+    operator hipStream_t() const { return tl_stream ? tl_stream : main; }
+};
+struct StreamScope {                                    // binds the calling thread to a stream for the lifetime of the object
+    explicit StreamScope(hipStream_t s) { tl_stream = s; }
+    ~StreamScope() { tl_stream = nullptr; }
+    StreamScope(const StreamScope&) = delete; StreamScope& operator=(const StreamScope&) = delete;
+};
+
 }  // namespace lcty
 
-// One GPU, one stream. All work of a context is issued on `stream`.
+// One GPU. The work of a context is issued on `stream` (see lcty::StreamRef); the queue of loci adds the streams further down.
 struct lcty_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    lcty::StreamRef stream;
     hipDeviceProp_t props{};
     lcty::KernelTimer timers[LCTY_K_COUNT];
     std::vector<hipEvent_t> event_pool;

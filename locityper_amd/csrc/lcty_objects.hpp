@@ -157,7 +157,7 @@ struct lcty_reads {
     uint64_t n_scores = 0;
 
     lcty::ReadsView view() const;
-    void check_device_error();               // throws when a kernel raised LCTY_ERR_*
+    void check_device_error(hipStream_t on = nullptr);   // throws when a kernel raised LCTY_ERR_* (looked up on `on`, or the calling thread's stream)
 };
 
 namespace lcty {

@@ -87,10 +87,11 @@ void lcty_reads::ensure_good_index() {
     good_valid = true;
 }
 
-void lcty_reads::check_device_error() {
+void lcty_reads::check_device_error(hipStream_t on) {
     uint32_t flag = 0;
-    d_err.download(&flag, 1, ctx->stream);
-    LCTY_HIP(hipStreamSynchronize(ctx->stream));
+    if (!on) on = ctx->stream;
+    d_err.download(&flag, 1, on);
+    LCTY_HIP(hipStreamSynchronize(on));
     if (flag == LCTY_ERR_INVALID_DATA)
         fail(LCTY_ERR_INVALID_DATA,
              "alignment table violates the input contract (unsupported CIGAR operation, hard-clipped or empty primary, "

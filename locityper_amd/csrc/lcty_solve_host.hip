@@ -97,7 +97,7 @@ struct StageRunner {
         ctx = reads->ctx; loc = reads->locus;
         ctx->activate();
         stream = lane ? ctx->side_stream() : ctx->stream;
-        reads->check_device_error();
+        reads->check_device_error(stream);
         const uint32_t A = loc->n_alleles;
         for (uint64_t i = 0; i < n_gt * ploidy; i++)
             if (genotypes[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotypes[i], A);
@@ -585,7 +585,7 @@ namespace {
 uint32_t count_unexplained_on(hipStream_t s, lcty_reads* reads, const uint16_t* genotype, uint32_t ploidy) {
     lcty_ctx* ctx = reads->ctx;
     ctx->activate();
-    reads->check_device_error();
+    reads->check_device_error(s);
     const uint32_t A = reads->locus->n_alleles;
     for (uint32_t i = 0; i < ploidy; i++)
         if (genotype[i] >= A) fail(LCTY_ERR_INVALID_INPUT, "genotype refers to allele %u >= %u", genotype[i], A);
@@ -856,7 +856,8 @@ struct LocusRun {
         mark(lane ? "tail stage: discarded" : "head stage: discarded");
     }
 
-    void head(bool score) {
+    // everything before the chains: scores, run_filter, the batch's location table. Issued on the calling thread's stream.
+    void pre(bool score) {
         if (!reads || !stages || !out || n_stages == 0) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         mark("head: start");
         if (score) ok(lcty_score_reads(reads));
@@ -893,12 +894,18 @@ struct LocusRun {
         mark("head: prefiltered and truncated");
         mean.assign(G, std::numeric_limits<double>::quiet_NaN()); var.assign(G, std::numeric_limits<double>::quiet_NaN());
         att.assign(G, 0);
-        for (uint32_t si = 0; si + 1 < n_stages; si++) stage(si, 0);
+        ensure_solver_tables(reads);
+        mark("head: location table built");
     }
+    void chains() { for (uint32_t si = 0; si + 1 < n_stages; si++) stage(si, 0); }
+    void head(bool score) { pre(score); chains(); }
 
     void tail(uint32_t lane) {
         lcty_ctx* ctx = reads->ctx;
         ctx->activate();
+        // on the side lane every call of this thread that says "the context's stream" means the side stream (a wider depth table, the error flag)
+        std::unique_ptr<StreamScope> on_side;
+        if (lane) on_side = std::make_unique<StreamScope>(ctx->side_stream());
         const lcty_params& prm = reads->locus->prm;
         mark("tail: start");
         stage(n_stages - 1, lane);
