@@ -96,6 +96,7 @@ struct ReadsView {
     unsigned int* defer_count;      // [1]
     const uint32_t* only_list;      // general kernel: the pairs to score (null: all n_pairs) ...
     const unsigned int* only_count; // ... and how many (device memory: no host round trip between the two launches)
+    unsigned long long* dbg;        // lcty_ctx_set_knob "score_timing": shader-clock sums of the lean kernel's phases (else null)
     uint8_t* park;                  // scoring kernel, large pairs: per-workgroup scratch of saved alignments (else null)
     uint64_t park_stride;
 };

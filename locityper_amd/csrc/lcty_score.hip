@@ -247,7 +247,7 @@ __device__ __forceinline__ void pair_unique_kmers_regs(const uint64_t* kset, uin
     const uint32_t half = static_cast<uint32_t>(lane) >> 5;
     const uint32_t sh2 = (lane & 31u) * 2u, sh1 = lane & 31u;
     for (uint32_t it0 = 0; it0 < items; it0 += 4) {
-        uint64_t key[4], val[4], slot[4];
+        uint64_t key[4], slot[4];
         bool live[4], undef[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -275,22 +275,38 @@ __device__ __forceinline__ void pair_unique_kmers_regs(const uint64_t* kset, uin
             undef[j] = (nbits & ((1u << k) - 1u)) != 0u;  // window contains a non-ACGT base -> UNDEF (kmers.rs:184-190)
             slot[j] = mix64(key[j]) & kset_mask;
         }
+        // The probes of all four items advance together, two slots of the table per step: a step costs one trip to the L2 whatever
+        // the number of lanes and items still searching (one item after the other, one slot at a time, the four chains add up:
+        // at a load of 1/4 the longest chain of 64 lanes is 4 or 5 slots).
+        uint32_t pend = 0, hits = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) val[j] = (live[j] && !undef[j]) ? kset[slot[j]] : KSET_EMPTY;
+        for (int j = 0; j < 4; j++) {
+            if (live[j] && !undef[j]) pend |= 1u << j;
+            if (live[j] && undef[j] && undef_in_set != 0) hits |= 1u << j;
+        }
+        while (__any(pend != 0)) {
+            uint64_t v0[4], v1[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool go = (pend >> j) & 1u;
+                v0[j] = go ? kset[slot[j]] : KSET_EMPTY;
+                v1[j] = go ? kset[(slot[j] + 1) & kset_mask] : KSET_EMPTY;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!((pend >> j) & 1u)) continue;
+                const bool found = v0[j] == key[j] || (v0[j] != KSET_EMPTY && v1[j] == key[j]);
+                const bool ended = v0[j] == KSET_EMPTY || v1[j] == KSET_EMPTY;
+                if (found) hits |= 1u << j;
+                if (found || ended) pend &= ~(1u << j);
+                else slot[j] = (slot[j] + 2) & kset_mask;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t it = it0 + j;
             if (it < items) {                             // wave-uniform
-                bool hit = false;
-                if (live[j]) {
-                    if (undef[j]) hit = undef_in_set != 0;
-                    else {
-                        uint64_t v = val[j], s = slot[j];
-                        while (v != key[j] && v != KSET_EMPTY) { s = (s + 1) & kset_mask; v = kset[s]; }
-                        hit = v == key[j];
-                    }
-                }
-                const unsigned long long mask = __ballot(hit);
+                const unsigned long long mask = __ballot((hits >> j) & 1u);
                 const bool m = it >= nch0;
                 const uint32_t t = m ? it - nch0 : it;
                 if (m) walk1.feed(mask, t * WAVE, k); else walk0.feed(mask, t * WAVE, k);
@@ -953,11 +969,29 @@ __device__ __forceinline__ AlnRef ref_from_counted(const LocusView& L, const uin
     return AlnRef{sc.ln_prob - best, sc.start, sc.end, idx, ((raw.x >> 28) & 1u) != 0};            // normalize_probs, locs.rs:358-360
 }
 
-__global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const LocusView L, const ReadsView R) {
+template <bool TIMED, bool KEEP>
+__device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsView& R) {
     extern __shared__ __align__(16) uint8_t smem[];
+    // TIMED (a diagnostic build of the same code, lcty_ctx_set_knob "score_timing"): where a wavefront's time goes, phase by phase
+    uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    auto stamp = [&](int k) {
+        if constexpr (TIMED) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            tph[k] += t - t_prev; t_prev = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (TIMED) t_prev = __builtin_amdgcn_s_memtime();
     const uint32_t A = L.n_alleles;
+    // KEEP (few alleles: 33 B of LDS per allele): what pass 1 computed of the saved alignment — its place, strand and index packed
+    // into 64 bits, its ln-probability — stays in LDS and pass 3 has it from there; otherwise (9 B per allele) pass 1 leaves the
+    // record's index and pass 3 reads and scores the record again.
     uint32_t* head = reinterpret_cast<uint32_t*>(smem);                       // [2A]: saved record of (contig, end 0) | (contig, end 1)
-    uint8_t* cnt8 = reinterpret_cast<uint8_t*>(head + 2 * A);                 // [A] PairAlignments of the contig (<= 3)
+    unsigned long long* kept = reinterpret_cast<unsigned long long*>(smem);   // KEEP [2A]: start | rev << 28 | (end - start) << 29 | index << 47
+    double* kept_lp = reinterpret_cast<double*>(kept + 2 * A);                // KEEP [2A]
+    uint8_t* cnt8 = KEEP ? reinterpret_cast<uint8_t*>(kept_lp + 2 * A) : reinterpret_cast<uint8_t*>(head + 2 * A);   // [A] PairAlignments of the contig (<= 3)
+    constexpr unsigned long long NOT_KEPT = ~0ull;
     const int lane = threadIdx.x;
     const bool paired = L.is_paired != 0;
     const InsLut ins{L.ins_lut, L.ins_lut_size, L.ins_n, L.ins_lnq, L.ins_lnpmf_const};
@@ -984,7 +1018,8 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
                 nm1 = (R.nmask + (off1 >> 5))[lane];
             }
         }
-        for (uint32_t i = lane; i < 2 * A; i += WAVE) head[i] = 0xFFFFFFFFu;
+        if constexpr (KEEP) { for (uint32_t i = lane; i < 2 * A; i += WAVE) kept[i] = NOT_KEPT; }
+        else { for (uint32_t i = lane; i < 2 * A; i += WAVE) head[i] = 0xFFFFFFFFu; }
         uint4 raw_first[GR];
 #pragma unroll
         for (int g = 0; g < GR; g++) {
@@ -1031,6 +1066,7 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
         const uint32_t good0 = __shfl(my_good, 0), thr0 = __shfl(my_thr, 0), pass0 = __shfl(my_pass, 0), st0 = __shfl(my_state, 0);
         const uint32_t good1 = __shfl(my_good, 1), thr1 = __shfl(my_thr, 1), pass1 = __shfl(my_pass, 1), st1 = __shfl(my_state, 1);
         __syncthreads();          // head table initialised
+        stamp(0);
 
         // ---------------- pass 1 ----------------
         uint32_t be0 = NONE32, be1 = NONE32, bad0 = 0, bad1 = 0;
@@ -1059,8 +1095,15 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
                         const Scored sc = score_counted(L, raw[g]);
                         if (e == 0) { be0 = min(be0, sc.edit); bl0 = fmax(bl0, sc.ln_prob); }
                         else { be1 = min(be1, sc.edit); bl1 = fmax(bl1, sc.ln_prob); }
-                        if (sc.edit <= (e ? pass1 : pass0))                     // save (locs.rs:314)
-                            multi |= atomicExch(&head[e * A + contig], idx) != 0xFFFFFFFFu;
+                        if (sc.edit <= (e ? pass1 : pass0)) {                   // save (locs.rs:314)
+                            if constexpr (KEEP) {
+                                // 28 + 1 + 18 (three 16-bit counts) + 16 bits (the kernel is not launched on pairs of 65535 records or more)
+                                const unsigned long long packed = static_cast<unsigned long long>(sc.start) | static_cast<unsigned long long>((raw[g].x >> 28) & 1u) << 28 |
+                                    static_cast<unsigned long long>(sc.end - sc.start) << 29 | static_cast<unsigned long long>(idx) << 47;
+                                multi |= atomicExch(&kept[e * A + contig], packed) != NOT_KEPT;
+                                kept_lp[e * A + contig] = sc.ln_prob;
+                            } else multi |= atomicExch(&head[e * A + contig], idx) != 0xFFFFFFFFu;
+                        }
                     }
                 }
             }
@@ -1069,6 +1112,7 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
         bl0 = wave_max_f64(bl0); bl1 = wave_max_f64(bl1);
         bad0 = wave_sum_u32(bad0); bad1 = wave_sum_u32(bad1);
         __syncthreads();
+        stamp(1);
         if (!regs_ok || __ballot(multi) != 0ull) {
             // not this kernel's pair: untouched, the general kernel takes it
             if (lane == 0) R.defer_list[atomicAdd(R.defer_count, 1u)] = static_cast<uint32_t>(p);
@@ -1093,6 +1137,7 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
         if (!accepted && lane == 0) R.recover_w[p] = -1.0;
         if (accepted) {
             pair_unique_kmers_regs(L.kset, L.kset_mask, L.undef_in_set, L.k, len0, len1, bw0, bw1, nm0, nm1, lane, &uk0, &uk1);
+            stamp(2);
             const uint32_t paired_count = (uk0 + uk1) & 0xFFFFu;
             double kw = L.weight_interc + static_cast<double>(paired_count) * L.weight_mult;
             kw = kw < 0.0 ? 0.0 : (kw > 1.0 ? 1.0 : kw);
@@ -1102,11 +1147,22 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
             unmapped_prob = paired ? weight * (2.0 * L.unmapped_penalty + L.insert_penalty) : weight * L.unmapped_penalty;
             const AlnRef none{0.0, 0, 0, NONE32, false};
             auto candidates = [&](uint32_t c) -> Fast3 {
-                const uint32_t h1 = head[c], h2 = head[A + c];
-                const bool has1 = h1 != 0xFFFFFFFFu, has2 = h2 != 0xFFFFFFFFu;
-                const uint4 r1 = recs[has1 ? h1 : 0u], r2 = recs[has2 ? h2 : 0u];      // L2: read in pass 1 a moment ago
-                return fast_from_refs(ins, has1 ? ref_from_counted(L, r1, h1, bl0) : none, has2 ? ref_from_counted(L, r2, h2, bl1) : none,
-                                      has1, has2, unm_ins_penalty, paired);
+                if constexpr (KEEP) {
+                    const unsigned long long k1 = kept[c], k2 = kept[A + c];
+                    const bool has1 = k1 != NOT_KEPT, has2 = k2 != NOT_KEPT;
+                    auto ref = [](unsigned long long v, double lp) {
+                        const uint32_t start = static_cast<uint32_t>(v) & 0x0FFFFFFFu;
+                        return AlnRef{lp, start, start + (static_cast<uint32_t>(v >> 29) & 0x3FFFFu), static_cast<uint32_t>(v >> 47), ((v >> 28) & 1ull) != 0};
+                    };
+                    return fast_from_refs(ins, has1 ? ref(k1, kept_lp[c] - bl0) : none, has2 ? ref(k2, kept_lp[A + c] - bl1) : none,
+                                          has1, has2, unm_ins_penalty, paired);
+                } else {
+                    const uint32_t h1 = head[c], h2 = head[A + c];
+                    const bool has1 = h1 != 0xFFFFFFFFu, has2 = h2 != 0xFFFFFFFFu;
+                    const uint4 r1 = recs[has1 ? h1 : 0u], r2 = recs[has2 ? h2 : 0u];      // L2: read in pass 1 a moment ago
+                    return fast_from_refs(ins, has1 ? ref_from_counted(L, r1, h1, bl0) : none, has2 ? ref_from_counted(L, r2, h2, bl1) : none,
+                                          has1, has2, unm_ins_penalty, paired);
+                }
             };
             // Where the entries go is decided BEFORE the contigs are looked at when the wavefront's share of the arena can hold the
             // most this pair could write (3 entries per contig that holds a saved alignment): the candidates are then built once,
@@ -1115,7 +1171,8 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
             uint32_t ub = 0;
             for (uint32_t c0 = 0; c0 < A; c0 += WAVE) {
                 const uint32_t c = c0 + lane;
-                ub += __popcll(__ballot(c < A && (head[c] & head[A + c]) != 0xFFFFFFFFu));
+                if constexpr (KEEP) ub += __popcll(__ballot(c < A && (kept[c] & kept[A + c]) != NOT_KEPT));
+                else ub += __popcll(__ballot(c < A && (head[c] & head[A + c]) != 0xFFFFFFFFu));
             }
             ub *= 3;
             const bool at_once = R.pa_chunk != 0 && static_cast<uint64_t>(ub) * 8 <= R.pa_chunk;
@@ -1129,6 +1186,7 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
                 pa_base = pool_at;
                 room = pa_base + ub <= R.pa_cap;
             }
+            stamp(3);
             // ---------------- pass 3a ----------------
             bool inb = false;
             uint32_t run = 0;
@@ -1155,6 +1213,7 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
                     if (room && res.cnt) fast_emit(f, res.cnt, weight, c, R.pa + pa_base + my_off);
                 }
             }
+            stamp(4);
             const bool any_inb = __ballot(inb) != 0ull;
             total_cnt = wave_sum_u32(total_cnt);
             if (lane == 0) R.recover_w[p] = any_inb ? weight : -1.0;
@@ -1206,8 +1265,19 @@ __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const Locus
             R.uniq_kmers[2 * p + 1] = accepted ? static_cast<uint16_t>(uk1) : 0;
         }
         __syncthreads();
+        stamp(5);
+        if constexpr (TIMED) tph[7] += 1;
+    }
+    if constexpr (TIMED) {
+        if (lane == 0)
+            for (int k = 0; k < 8; k++) atomicAdd(R.dbg + k, static_cast<unsigned long long>(tph[k]));
     }
 }
+
+__global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const LocusView L, const ReadsView R) { score_lean_body<false, false>(L, R); }
+__global__ __launch_bounds__(WAVE, 4) void score_counted_lean_keep_kernel(const LocusView L, const ReadsView R) { score_lean_body<false, true>(L, R); }
+__global__ __launch_bounds__(WAVE, 4) void score_counted_lean_timed_kernel(const LocusView L, const ReadsView R) { score_lean_body<true, false>(L, R); }
+__global__ __launch_bounds__(WAVE, 4) void score_counted_lean_keep_timed_kernel(const LocusView L, const ReadsView R) { score_lean_body<true, true>(L, R); }
 
 __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
     score_reads_body<false, false>(L, R, max_recs);
@@ -1306,15 +1376,32 @@ void launch_score_reads(lcty_reads* reads) {
     }
     ctx->timed(LCTY_K_SCORE, [&] {
         if (lean) {
-            const size_t lean_lds = (static_cast<size_t>(L.n_alleles) * 9 + 15) & ~static_cast<size_t>(15);
+            // sixteen wavefronts per CU either way: with the saved alignments' products kept in LDS (33 B per allele) while that many fit
+            const bool keep = static_cast<size_t>(L.n_alleles) * 33 + 16 <= lds_max / 16 && ctx->knob("score_lean_keep", 1) != 0;
+            const size_t lean_lds = (static_cast<size_t>(L.n_alleles) * (keep ? 33 : 9) + 15) & ~static_cast<size_t>(15);
+            const bool timing = ctx->knob("score_timing", 0) != 0;
+            auto lean_kernel = timing ? (keep ? score_counted_lean_keep_timed_kernel : score_counted_lean_timed_kernel)
+                                      : (keep ? score_counted_lean_keep_kernel : score_counted_lean_kernel);
             if (lean_lds > 48 * 1024)
-                LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_counted_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lean_lds)));
             const uint32_t lean_per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, lds_max / lean_lds)));
             const uint64_t lean_grid = std::max<uint64_t>(1, std::min<uint64_t>(R.n_pairs, static_cast<uint64_t>(cus) * lean_per_cu));
             ReadsView RL = R;
             RL.pa_chunk = pooled && lean_grid <= PA_MAX_GRID && R.n_pairs / lean_grid >= PA_POOL_MIN_PAIRS ? PA_CHUNK : 0u;
-            hipLaunchKernelGGL(score_counted_lean_kernel, dim3(static_cast<uint32_t>(lean_grid)), dim3(WAVE), lean_lds, ctx->stream, L, RL);
+            if (timing) {
+                // diagnostic: the timed build of the lean kernel; ticks (10 ns) per pair of a wavefront, phase by phase, on stderr
+                reads->d_score_dbg.ensure(8); reads->d_score_dbg.zero(ctx->stream);
+                RL.dbg = reads->d_score_dbg.p;
+                hipLaunchKernelGGL(lean_kernel, dim3(static_cast<uint32_t>(lean_grid)), dim3(WAVE), lean_lds, ctx->stream, L, RL);
+                unsigned long long t[8];
+                reads->d_score_dbg.download(t, 8, ctx->stream);
+                LCTY_HIP(hipStreamSynchronize(ctx->stream));
+                const double n = static_cast<double>(std::max<unsigned long long>(t[7], 1));
+                fprintf(stderr, "[lcty score] lean kernel, ticks per pair of a wavefront (%llu pairs, %llu wavefronts): records + thresholds %.0f, pass 1 %.0f, "
+                        "k-mers %.0f, arena share %.0f, pass 3 %.0f, tail %.0f\n", t[7], static_cast<unsigned long long>(lean_grid),
+                        t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n);
+            } else hipLaunchKernelGGL(lean_kernel, dim3(static_cast<uint32_t>(lean_grid)), dim3(WAVE), lean_lds, ctx->stream, L, RL);
             R.only_list = R.defer_list; R.only_count = R.defer_count;
             R.pa_chunk = 0;                                                     // the few pairs left reserve their own entries
         }

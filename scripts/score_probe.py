@@ -1,5 +1,5 @@
 """Developer measurement: the scoring kernel of BASELINE configs[1] (1 M read pairs x 256 alleles) alone.
-   python3 scripts/score_probe.py [--lib variant.so] [--format counted|records] [--pairs N]
+   python3 scripts/score_probe.py [--lib variant.so] [--format counted|records] [--pairs N] [knob=value ...]
 Prints the kernel time of lcty_score_reads (mean of 5 launches) and a checksum of its products (statuses, matrix sum, arena size)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ import numpy as np
 
 def main():
     args = sys.argv[1:]
-    fmt, pairs = "counted", 1_000_000
+    fmt, pairs, knobs = "counted", 1_000_000, []
     i = 0
     while i < len(args):
         if args[i] == "--lib":
@@ -16,12 +16,14 @@ def main():
             _lib.LIB_PATH = os.path.abspath(args[i + 1]); i += 2
         elif args[i] == "--format": fmt = args[i + 1]; i += 2
         elif args[i] == "--pairs": pairs = int(args[i + 1]); i += 2
+        elif "=" in args[i]: knobs.append(args[i].split("=")); i += 1
         else: raise SystemExit("unknown argument " + args[i])
     from locityper_amd import api, synth, cdefs
     A = 256
     L = synth.SynthLocus(A, pairs, seed=synth.SEED)
     p = api.resolve_params(api.default_params(), L.bg)
     ctx = api.Context(0)
+    for name, val in knobs: ctx.set_knob(name, int(val))
     loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
     aa = None
     counted = fmt == "counted"
