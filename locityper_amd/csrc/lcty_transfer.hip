@@ -839,7 +839,10 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             for (size_t lv = 0; lv < levels.size() && n_list; lv++) {
                 const Limits lim = levels[lv];
                 const size_t stride = pair_scratch_bytes(cap_alns, hcap, cap_new, cap_words, lim);
-                const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>({n_list, max_blocks, scratch_budget / stride})));
+                uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>({n_list, max_blocks, scratch_budget / stride})));
+                // whole rounds: a wavefront takes the pairs blockIdx, blockIdx + gridDim, ... and a pair costs tens of milliseconds here, so
+                // 1.5 rounds (6 144 long reads on 4 096 wavefronts) take as long as two — the same two rounds on 3 072 wavefronts run faster each
+                blocks = static_cast<uint32_t>((n_list + (n_list + blocks - 1) / blocks - 1) / ((n_list + blocks - 1) / blocks));
                 if (d_scratch.n < stride * blocks) d_scratch.alloc(stride * blocks);
                 TransferArgs T{};
                 T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
