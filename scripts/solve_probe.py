@@ -1,5 +1,5 @@
 """Developer measurement: the solver stages of BASELINE configs[1] (1 M read pairs x 256 alleles) ALONE, once per knob setting:
-   python3 scripts/solve_probe.py [--chains 5000] [--short] name=value[,name=value...] ...
+   python3 scripts/solve_probe.py [--chains 5000] [--short] [--base-len 50000] name=value[,name=value...] ...
 For every setting: solve_init_kernel and greedy_loop_kernel times of the default greedy stage (5 000 chains, 100 000 iterations;
 --short: plateau 1, the stage is its initialisation) and whether the per-chain likelihoods equal those of the first setting bit for bit."""
 import os, sys, time
@@ -14,6 +14,7 @@ def main():
     short = False
     anneal = False                                    # --anneal: the annealing stage of the default scheme instead (20 genotypes x 20 attempts)
     settings = []
+    base_len = 50_000                                 # --base-len: shorter alleles = fewer windows per chain = more greedy wavefronts per CU
     i = 0
     while i < len(args):
         if args[i] == "--chains": n = int(args[i + 1]); i += 2
@@ -21,11 +22,12 @@ def main():
             from locityper_amd import _lib
             _lib.LIB_PATH = os.path.abspath(args[i + 1]); i += 2          # a variant library built by hand (hipcc over a patched copy of a source)
         elif args[i] == "--short": short = True; i += 1
+        elif args[i] == "--base-len": base_len = int(args[i + 1]); i += 2
         elif args[i] == "--anneal": anneal = True; i += 1
         else: settings.append(args[i]); i += 1
     if not settings: settings = ["default"]
     A, pairs = 256, 1_000_000
-    L = synth.SynthLocus(A, pairs, seed=synth.SEED)
+    L = synth.SynthLocus(A, pairs, seed=synth.SEED, base_len=base_len)
     p = api.resolve_params(api.default_params(), L.bg)
     ctx = api.Context(0)
     loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
@@ -57,8 +59,9 @@ def main():
         m, v_, l = api.solve_stage(aa, top, sv, att, seeds)
         wall = time.perf_counter() - t0
         if first is None: first = l
-        print(f"{st}: init {ctx.timing(api.K_SOLVE_INIT)[1]:.1f} ms, loop {ctx.timing(api.K_ANNEAL if anneal else api.K_SOLVE)[1]:.1f} ms, wall {1e3 * wall:.1f} ms, "
-              f"likelihoods equal the first setting's: {bool(np.array_equal(l, first))}", flush=True)
+        ch_, it_, acc_ = api.solve_stats(aa)
+        print(f"{st}: {ch_} chains, {it_} iterations, {acc_} accepted; init {ctx.timing(api.K_SOLVE_INIT)[1]:.1f} ms, loop {ctx.timing(api.K_ANNEAL if anneal else api.K_SOLVE)[1]:.1f} ms, wall {1e3 * wall:.1f} ms, "
+              f"likelihoods equal the first setting's: {bool(np.array_equal(l, first))} (largest relative difference {float(np.max(np.abs(l - first) / np.abs(first))):.3g})", flush=True)
         for k, _ in knobs: ctx.set_knob(k, -1)
 
 
