@@ -14,6 +14,7 @@ def main():
     short = False
     anneal = False                                    # --anneal: the annealing stage of the default scheme instead (20 genotypes x 20 attempts)
     settings = []
+    sort_gts = False
     base_len = 50_000                                 # --base-len: shorter alleles = fewer windows per chain = more greedy wavefronts per CU
     i = 0
     while i < len(args):
@@ -23,6 +24,7 @@ def main():
             _lib.LIB_PATH = os.path.abspath(args[i + 1]); i += 2          # a variant library built by hand (hipcc over a patched copy of a source)
         elif args[i] == "--short": short = True; i += 1
         elif args[i] == "--base-len": base_len = int(args[i + 1]); i += 2
+        elif args[i] == "--sort-genotypes": sort_gts = True; i += 1      # the stage's genotypes in lexicographic order instead of by prefilter score
         elif args[i] == "--anneal": anneal = True; i += 1
         else: settings.append(args[i]); i += 1
     if not settings: settings = ["default"]
@@ -43,6 +45,7 @@ def main():
     gts = api.generate_genotypes(A, 2)
     order = np.argsort(-sc, kind="stable")
     top = np.ascontiguousarray(gts[order[:n]])
+    if sort_gts: top = np.ascontiguousarray(top[np.lexsort((top[:, 1], top[:, 0]))])
     sv = api.default_solver(cdefs.SOLVER_ANNEAL if anneal else cdefs.SOLVER_GREEDY)
     if short: sv.plato_size = 1
     att = 1
