@@ -231,7 +231,9 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  *   "prefilter_gram"   0: always the f64 tile kernel, 1: the integer Gram contraction on the matrix cores whenever it applies
  *       (default: from 512 alleles on);   "arena_cap_pct"   p: batches created afterwards (lcty_reads_create) get p % of the bound on their PairAlignment arena (two per
  *       record; one per (pair, allele) is the rule — an arena that is too small fails loudly);   "score_lean"   0: counted batches go through the general scoring kernel only (default 1: the lean kernel first, the general
- *       one on the pairs it leaves);   "comm_fail_at"   k: the k-th status agreement of a multi-GPU call fails on this rank (tests of
+ *       one on the pairs it leaves);   "score_lean_keep"   0: the lean kernel scores a saved record again in its last pass instead of
+ *       keeping the first pass' products in LDS (what loci of more than 310 alleles get anyway);   "score_timing"   1: the lean kernel's
+ *       timed build, shader-clock ticks per phase on stderr;   "comm_fail_at"   k: the k-th status agreement of a multi-GPU call fails on this rank (tests of
  *       the error path of the exchanges);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the
  *       f64 kernel takes the batch);   "prefilter_gram_levels"   levels of a row the contraction takes (<= 16; rows with more go
  *       through the f64 kernel).

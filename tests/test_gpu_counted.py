@@ -108,8 +108,14 @@ def test_lean_kernel_equals_the_general_kernel(gpu_ctx):
             _same(lean, general)
             lean.score()                                                    # still with the knob at 0: the same batch through the other kernel
             _same(lean, general)
+            # the lean kernel's other form: pass 1 leaves the record's index and pass 3 scores the record again (what loci of more
+            # than 310 alleles get) instead of keeping pass 1's products in LDS
+            gpu_ctx.set_knob("score_lean", 1); gpu_ctx.set_knob("score_lean_keep", 0)
+            again = api.AllAlignments.load(locus, chunk, counted=True)
+            _same(again, general)
+            gpu_ctx.set_knob("score_lean_keep", -1)
     finally:
-        gpu_ctx.set_knob("score_lean", -1)
+        gpu_ctx.set_knob("score_lean", -1); gpu_ctx.set_knob("score_lean_keep", -1)
     oa = ol.load(ch)
     cnt = api.AllAlignments.load(loc, ch, counted=True)
     st, w, unm, uk = cnt.status()
