@@ -114,7 +114,7 @@ struct lcty_reads {
     lcty::DevBuf<uint32_t> d_pa_cnt;
     lcty::DevBuf<uint32_t> d_pa_idx;         // [R][A]
     // solver stages: compact list of GOOD pairs (AllAlignments::reads order), built lazily after scoring
-    lcty::DevBuf<uint32_t> d_good_ix;
+    lcty::DevBuf<uint32_t> d_good_ix, d_good_cnt;
     uint64_t n_good_cached = 0;
     bool good_valid = false;
     void ensure_good_index();

@@ -52,6 +52,63 @@ void compact_matrix(lcty_reads* reads, double* d_out, uint64_t n_good) {
     LCTY_HIP(hipStreamSynchronize(ctx->stream));
 }
 
+
+// ---- the indices of the GOOD pairs of a batch, in batch order (lcty_reads::ensure_good_index) ----
+constexpr uint32_t GOOD_BLOCK = 1024;
+__global__ __launch_bounds__(256) void good_count_kernel(const uint8_t* __restrict__ status, uint32_t n, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t part[4];
+    const uint32_t base = blockIdx.x * GOOD_BLOCK;
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < GOOD_BLOCK; i += 256) c += base + i < n && status[base + i] == LCTY_READ_GOOD;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// cnt[0..blocks) -> exclusive prefix sums, cnt[blocks] = total (one workgroup of 1 024 threads, any number of blocks)
+__global__ __launch_bounds__(1024) void good_scan_kernel(uint32_t* __restrict__ cnt, uint32_t blocks) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < blocks; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < blocks ? cnt[i] : 0u;
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if ((threadIdx.x & 63u) >= static_cast<uint32_t>(o)) incl += up; }
+        if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
+        if (i < blocks) cnt[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[blocks] = carry;
+}
+__global__ __launch_bounds__(256) void good_scatter_kernel(const uint8_t* __restrict__ status, uint32_t n, const uint32_t* __restrict__ cnt,
+                                                           uint32_t* __restrict__ good_ix) {
+    __shared__ uint32_t run;
+    const uint32_t base = blockIdx.x * GOOD_BLOCK, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) run = cnt[blockIdx.x];
+    __syncthreads();
+    // the block's 1 024 pairs in order: wavefront w takes pairs [256 w, 256 w + 256) in four steps of 64, the wavefronts one after the other
+    for (uint32_t w = 0; w < 4; w++) {
+        if (wave == w) {
+            uint32_t at = run;
+            for (uint32_t step = 0; step < 4; step++) {
+                const uint32_t i = base + w * 256 + step * 64 + lane;
+                const bool good = i < n && status[i] == LCTY_READ_GOOD;
+                const unsigned long long m = __ballot(good);
+                if (good) good_ix[at + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)))] = i;
+                at += static_cast<uint32_t>(__popcll(m));
+            }
+            if (lane == 0) run = at;
+        }
+        __syncthreads();
+    }
+}
 }  // namespace lcty
 
 // The pairs whose records are on the device: all of them, or the current chunk of a streaming batch — then the per-pair
@@ -75,15 +132,23 @@ ReadsView lcty_reads::view() const {
 void lcty_reads::ensure_good_index() {
     if (good_valid) return;
     if (n_pairs >= 0xFFFFFFFFull) lcty::fail(LCTY_ERR_UNSUPPORTED, "more than 2^32 read pairs in one batch");
-    std::vector<uint8_t> status(n_pairs);
-    d_status.download(status.data(), n_pairs, ctx->stream);
-    LCTY_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> good;
-    for (uint64_t r = 0; r < n_pairs; r++) if (status[r] == LCTY_READ_GOOD) good.push_back(static_cast<uint32_t>(r));
-    d_good_ix.ensure(std::max<size_t>(good.size(), 1));       // grow-only: a hipFree waits for every stream of the device
-    d_good_ix.upload(good.data(), good.size(), ctx->stream);
-    LCTY_HIP(hipStreamSynchronize(ctx->stream));
-    n_good_cached = good.size();
+    // The indices of the GOOD pairs in batch order, made on the device (blocks of 1 024 pairs: count, scan of the counts by one workgroup,
+    // ordered scatter): only their number comes back. The host loop over the status bytes (a megabyte down, four up, the loop itself) was
+    // 3 ms on the critical path of every locus of a queue.
+    hipStream_t s = ctx->stream;
+    const uint32_t n = static_cast<uint32_t>(n_pairs), blocks = (n + lcty::GOOD_BLOCK - 1) / lcty::GOOD_BLOCK;
+    d_good_ix.ensure(std::max<size_t>(n_pairs, 1));           // grow-only: a hipFree waits for every stream of the device
+    d_good_cnt.ensure(static_cast<size_t>(blocks) + 1);
+    uint32_t total = 0;
+    if (n) {
+        hipLaunchKernelGGL(lcty::good_count_kernel, dim3(blocks), dim3(256), 0, s, d_status.p, n, d_good_cnt.p);
+        hipLaunchKernelGGL(lcty::good_scan_kernel, dim3(1), dim3(1024), 0, s, d_good_cnt.p, blocks);
+        hipLaunchKernelGGL(lcty::good_scatter_kernel, dim3(blocks), dim3(256), 0, s, d_status.p, n, d_good_cnt.p, d_good_ix.p);
+        LCTY_HIP(hipGetLastError());
+        d_good_cnt.download(&total, 1, s, blocks);
+        LCTY_HIP(hipStreamSynchronize(s));
+    }
+    n_good_cached = total;
     good_valid = true;
 }
 

@@ -957,7 +957,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         // one iteration: A = its candidates (arrived), EA their further locations (arrived); N = the candidates of the next
         // iteration (arrived), EN receives their further locations; F = the slot the sample three iterations ahead goes to (= A's)
         auto iteration = [&](auto slot_tag, GreedyCand& A, const GreedyExt& EA, const GreedyCand& N, GreedyExt& EN) {
-            constexpr uint32_t SLOT = decltype(slot_tag)::value;
+            [[maybe_unused]] constexpr uint32_t SLOT = decltype(slot_tag)::value;
             constexpr bool TIMED = (GREEDY_FORM & 32u) != 0;
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, ts[3] = {0, 0, 0}, tw0 = 0;
             auto subtick = [&](int k) { if constexpr (TIMED) { __builtin_amdgcn_sched_barrier(0); ts[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } };
