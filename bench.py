@@ -786,6 +786,20 @@ def main():
             out["roofline"]["traffic_source"] = os.path.relpath(args.traffic, ROOT)
     except (OSError, KeyError, ValueError):
         pass
+    # what the wavefronts of each kernel were doing (committed SQ counter pass, scripts/pmc_sq_summary.py): the fraction of their cycles with
+    # an instruction in flight / waiting. issuing x wavefronts per SIMD near or above 1 = the kernel is bound by its instruction stream.
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq.json")))["kernels"]
+        per_simd = {"greedy_loop_kernel": 1.0, "solve_init_kernel": 5.0, "score_reads_kernel": 4.0, "anneal_loop_kernel": 0.8, "prefilter_tile_kernel": None}
+        for name, r in roofs.items():
+            cands = [v for n, v in sq.items() if name.replace("score_reads_kernel", "score_counted_lean") in n]
+            if cands:
+                k = max(cands, key=lambda v: v.get("SQ_WAVE_CYCLES", 0.0))
+                r["sq"] = {"issuing_frac": round(k.get("active_inst_frac", 0.0), 3), "waiting_frac": round(k.get("wait_any_frac", 0.0), 3),
+                           "wavefronts_per_simd": per_simd.get(name), "source": "profiles/r04_pmc_sq.json"}
+        out["roofline"]["sq"] = roofs[dominant].get("sq")
+    except (OSError, KeyError, ValueError):
+        pass
 
     if world == 1:
         progress("timed region done")
