@@ -533,7 +533,7 @@ int32_t lcty_recruit(lcty_targets* targets, const lcty_reads_host* chunk, int32_
  * node, in a band of min(0, d) - band .. max(0, d) + band diagonals between two anchors d diagonals apart, and +- band beyond the first
  * and last anchor, where the alignment may stop (soft clip; end_bonus when the read end is reached) -> records as above, = / X / I / D / S
  * CIGARs. route: LCTY_MAP_ROUTE_AUTO takes the short route when the chunk and the index fit it.
- * lcty_locus_build_map_index: the k-mers of the basis alleles (host hash table, once per locus).
+ * lcty_locus_build_map_index: the k-mers of the basis alleles (hash table built on the device, once per locus).
  * lcty_map_reads: only the sequence fields of `chunk` are read. aln_off / cigar_off [n_pairs + 1] are always written; with
  *   recs == NULL the call only sizes. bases2_out / nmask_out: the chunk's bases in BAM orientation (same offsets). */
 typedef struct lcty_map_params {

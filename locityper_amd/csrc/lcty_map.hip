@@ -516,56 +516,9 @@ int32_t lcty_locus_build_map_index(lcty_locus* locus, const uint16_t* basis, uin
         if (k < 8 || k > 31) fail(LCTY_ERR_UNSUPPORTED, "seed length %u: 8..31", k);
         lcty_ctx* ctx = locus->ctx;
         ctx->activate();
-        hipStream_t s = ctx->stream;
         for (uint32_t b = 0; b < n_basis; b++)
             if (basis[b] >= locus->n_alleles) fail(LCTY_ERR_INVALID_INPUT, "basis allele %u >= %u", basis[b], locus->n_alleles);
-        std::vector<uint64_t> seq_off(locus->n_alleles + 1);
-        locus->d_seq_off.download(seq_off.data(), seq_off.size(), s);
-        LCTY_HIP(hipStreamSynchronize(s));
-        // (k-mer, place) of every window of the basis alleles, sorted: the run of a k-mer is in (basis allele, position) order
-        std::vector<std::pair<uint64_t, uint64_t>> places;
-        std::vector<uint8_t> seq;
-        const uint64_t kmask = (1ull << (2 * k)) - 1ull;
-        for (uint32_t b = 0; b < n_basis; b++) {
-            const uint64_t o = seq_off[basis[b]], len = seq_off[basis[b] + 1] - o;
-            seq.resize(len);
-            locus->d_seqs.download(seq.data(), len, s, o);
-            LCTY_HIP(hipStreamSynchronize(s));
-            uint64_t fw = 0, rv = 0, valid = 0;
-            for (uint64_t i = 0; i < len; i++) {
-                const uint8_t c = seq[i];
-                const uint32_t e = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
-                if (e == 4) { valid = 0; fw = rv = 0; continue; }
-                fw = ((fw << 2) | e) & kmask;
-                rv = (rv >> 2) | (static_cast<uint64_t>(3u - e) << (2 * k - 2));
-                if (++valid >= k) {
-                    const bool fwd = fw <= rv;
-                    places.emplace_back(fwd ? fw : rv, (static_cast<uint64_t>(b) << 33) | ((i + 1 - k) << 1) | (fwd ? 1ull : 0ull));
-                }
-            }
-        }
-        if (places.size() > 0xFFFFFFF0ull) fail(LCTY_ERR_UNSUPPORTED, "more than 2^32 k-mer places in the basis alleles");
-        std::sort(places.begin(), places.end());
-        uint64_t distinct = 0;
-        for (size_t i = 0; i < places.size(); i++) distinct += i == 0 || places[i].first != places[i - 1].first;
-        uint64_t cap = 1024;
-        while (cap < 2 * distinct) cap <<= 1;
-        std::vector<MapSlot> table(cap, MapSlot{MAP_FREE, 0u, 0u});
-        std::vector<uint64_t> entries(places.size());
-        for (size_t i = 0; i < places.size();) {
-            size_t j = i;
-            while (j < places.size() && places[j].first == places[i].first) { entries[j] = places[j].second; j++; }
-            uint64_t h = map_hash(places[i].first) & (cap - 1);
-            while (table[h].key != MAP_FREE) h = (h + 1) & (cap - 1);
-            table[h] = MapSlot{places[i].first, static_cast<uint32_t>(i), static_cast<uint32_t>(j - i)};
-            i = j;
-        }
-        auto ix = std::make_shared<MapIndex>();
-        ix->table.alloc(cap); ix->table.upload(table.data(), cap, s);
-        ix->entries.alloc(std::max<size_t>(entries.size(), 1)); ix->entries.upload(entries.data(), entries.size(), s);
-        ix->basis.alloc(n_basis); ix->basis.upload(basis, n_basis, s);
-        LCTY_HIP(hipStreamSynchronize(s));
-        ix->mask = cap - 1; ix->k = k; ix->n_basis = n_basis;
+        auto ix = build_map_index_device(locus, basis, n_basis, k);             // lcty_map_index.hip
         locus->map_index = ix;
     });
 }

@@ -38,6 +38,9 @@ struct MapIndex {
     uint64_t mask = 0; uint32_t k = 0, n_basis = 0;
 };
 
+// lcty_map_index.hip: the index of the given basis alleles, made on the device
+std::shared_ptr<MapIndex> build_map_index_device(lcty_locus* locus, const uint16_t* basis, uint32_t n_basis, uint32_t k);
+
 // both passes of a route; the records stay on the device, the offsets come to the host
 struct MapRun {
     DevBuf<uint32_t> d_len, d_b2, d_nm, d_nrec, d_ncig, d_ob2, d_onm, d_cigar, d_nhave, d_work, d_counters, d_ops;
