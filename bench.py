@@ -664,9 +664,15 @@ def main():
         quality = float(calls[-1].quality)
         greedy_chains_per_step = float(np.mean([int(c.kept_after_filter) for c in calls]))
         # per-stage wall times and iteration counts: one more locus call by call, outside the timed region
+        alone_ms = {}
         if rank == 0:
+            ctx.timing_reset()                                  # the queue's timers have been read: what follows are the kernels with nothing beside them
             step(7)
             ctx.synchronize()
+            for name, kid in (("score_reads_kernel", api.K_SCORE), ("prefilter_tile_kernel", api.K_PREFILTER), ("solve_init_kernel", api.K_SOLVE_INIT),
+                              ("greedy_loop_kernel", api.K_SOLVE), ("anneal_loop_kernel", api.K_ANNEAL)):
+                nk, msk = ctx.timing(kid)
+                if nk: alone_ms[name] = msk / nk
         res = None
     else:
         scores, keep, res = result
@@ -767,6 +773,12 @@ def main():
         "setup_s": {"generate_and_upload": gen_s, "locus_create": locus_setup_s},
     }
 
+    # the same kernels of one more locus solved call by call, nothing else on the device (in the queue the last stage of the locus before runs beside them)
+    if queue_mode:
+        for name, r in roofs.items():
+            if name in alone_ms and alone_ms[name] > 0:
+                r["launch_ms_alone"] = alone_ms[name]
+                if "bytes" in r: r["frac_alone"] = r["bytes"] / (alone_ms[name] * 1e-3) / 1e9 / 8000.0
     # HBM traffic from the committed PMC passes (counters cannot be read from inside this process). FETCH_SIZE on gfx950 counts a 128-byte
     # read request as 64 bytes (MI355X_MICROARCH.md): doubled for the kernels that STREAM wide coalesced reads; kernels that gather 8-32
     # bytes per lane are outside that calibration and keep the raw figure. Both are in the line.
