@@ -55,6 +55,7 @@ struct PairScratch {
     PAln* alns; uint32_t cap_alns;
     uint64_t* hkey; uint2* hval; uint32_t hcap;         // position set: key -> {index, pos}; key 0 = free (real keys have bits 48+ set)
     uint8_t* seen;
+    uint4* pre;                                          // [cap_alns] scores of the input records with long CIGARs, made by the whole wavefront
     NewAln* news; uint32_t cap_new;
     uint32_t* words; uint32_t cap_words;
     uint8_t* lanes;                                      // 64 x lane_scratch_bytes
@@ -65,6 +66,7 @@ __host__ __device__ inline size_t pair_scratch_bytes(uint32_t cap_alns, uint32_t
     b += sizeof(PAln) * cap_alns; b = (b + 15) & ~size_t(15);
     b += 8 * hcap + 8 * hcap;
     b += (cap_alns + 15) & ~15u;
+    b += sizeof(uint4) * static_cast<size_t>(cap_alns);
     b += sizeof(NewAln) * cap_new; b = (b + 15) & ~size_t(15);
     b += 4 * static_cast<size_t>(cap_words); b = (b + 15) & ~size_t(15);
     b += 64 * lane_scratch_bytes(lim);
@@ -78,6 +80,7 @@ __device__ inline PairScratch carve(uint8_t* base, uint32_t cap_alns, uint32_t h
     s.hkey = reinterpret_cast<uint64_t*>(base + b); b += 8 * hcap;
     s.hval = reinterpret_cast<uint2*>(base + b); b += 8 * hcap; s.hcap = hcap;
     s.seen = base + b; b += (cap_alns + 15) & ~15u;
+    s.pre = reinterpret_cast<uint4*>(base + b); b += sizeof(uint4) * static_cast<size_t>(cap_alns);
     s.news = reinterpret_cast<NewAln*>(base + b); s.cap_new = cap_new; b += sizeof(NewAln) * cap_new; b = (b + 15) & ~size_t(15);
     s.words = reinterpret_cast<uint32_t*>(base + b); s.cap_words = cap_words; b += 4 * static_cast<size_t>(cap_words); b = (b + 15) & ~size_t(15);
     s.lanes = base + b;
@@ -113,6 +116,36 @@ __device__ inline Scored score_cigar(const LocusView& L, WordAt word, uint32_t n
 }
 __device__ inline Scored score_words(const LocusView& L, const uint32_t* raw, uint32_t n, uint32_t pos, uint32_t contig_len, bool primary) {
     return score_cigar(L, [raw](uint32_t i) { return raw[i]; }, n, pos, contig_len, primary);
+}
+// The same by all 64 lanes (a 10-kb read's CIGAR is ~3 000 words): lane l counts the words l, l + 64, ..., the counts are summed across
+// the lanes (integers: the order does not matter) and every lane ends with the result score_words gives.
+constexpr uint32_t WAVE_SCORE_FROM = 32;          // words from which a record's CIGAR is counted by the wavefront
+__device__ inline Scored score_words_wave(const LocusView& L, const uint32_t* raw, uint32_t n, uint32_t pos, uint32_t contig_len, bool primary, uint32_t lane) {
+    uint32_t c[6] = {0, 0, 0, 0, 0, 0};                  // matches, mismatches, insertions, deletions, left clip, right clip
+    bool bad = false;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t w = raw[i];
+        uint32_t op = w & 15u;
+        const uint32_t len = w >> 4;
+        const bool edge = i == 0 || i + 1 == n;
+        if (op == OP_H) { if (edge && !primary) op = OP_S; else bad = true; }
+        if (op == OP_EQ) c[0] += len; else if (op == OP_X) c[1] += len; else if (op == OP_I) c[2] += len; else if (op == OP_D) c[3] += len;
+        else if (op == OP_S) { if (i == 0) c[4] = len; if (i + 1 == n) c[5] = len; }
+        else bad = true;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        for (int o = 32; o > 0; o >>= 1) c[k] += static_cast<uint32_t>(__shfl_xor(static_cast<int>(c[k]), o));
+    Scored s;
+    const uint32_t ref_len = c[0] + c[1] + c[3];
+    s.start = pos; s.end = pos + ref_len;
+    const uint32_t clip = min(c[4], pos) + min(c[5], contig_len > s.end ? contig_len - s.end : 0u);
+    const uint32_t common = c[1] + c[2] + clip;
+    s.edit = common + c[3];
+    s.ln_prob = L.lp[0] * static_cast<double>(c[0]) + L.lp[1] * static_cast<double>(c[1]) + L.lp[2] * static_cast<double>(c[2])
+              + L.lp[3] * static_cast<double>(c[3]) + L.lp[4] * static_cast<double>(clip);
+    s.bad = __any(bad);
+    return s;
 }
 
 __device__ __forceinline__ uint64_t pos_key(uint32_t read_end, uint32_t contig, uint32_t pos) {       // encode, locs.rs:181-184
@@ -194,6 +227,7 @@ struct TransferArgs {
     uint32_t* flag;                // 1 = arena overflow (retry larger), LCTY_ERR_* >= 2 otherwise
     unsigned long long* dp_cells;  // cells of the aligner's matrices, all lanes
     double min_weight;
+    uint32_t wave_scores;          // 1: the batch has records whose CIGARs are long enough to be counted by the whole wavefront (WAVE_SCORE_FROM words)
     uint32_t dry_run;              // 1: only look where a transfer WOULD start (no similar position on the target yet): pairs with any go to
                                    // redo_list, their number of such (source, target) combinations is added to rec_cursor; nothing is walked
 };
@@ -222,6 +256,19 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
         for (uint32_t i = lane; i < P.cap_alns; i += 64) P.seen[i] = 0;
         __syncthreads();
 
+        // the records with long CIGARs are scored by the whole wavefront first (the lane that builds the PrelimAlignments below used to
+        // read every word of every record itself: 770 k words for a 10-kb read with a record on each of 256 alleles)
+        if (T.wave_scores) {
+            for (uint32_t idx = 0; idx < n_eff; idx++) {
+                const lcty_aln_rec rc = recs[idx];
+                if (rc.n_cigar < WAVE_SCORE_FROM) continue;
+                const bool primary = idx == 0 || (paired && idx == j2);
+                const Scored sc = score_words_wave(L, cig + rc.cigar_rel, rc.n_cigar, rc.pos, L.allele_len[rc.contig], primary, lane);
+                if (lane == 0) P.pre[idx] = make_uint4(static_cast<uint32_t>(__double2loint(sc.ln_prob)), static_cast<uint32_t>(__double2hiint(sc.ln_prob)), sc.end,
+                                                       sc.edit | (sc.bad ? 0x80000000u : 0u));
+            }
+            __syncthreads();
+        }
         // ---- PrelimAlignments of the pair, as read_next_alns builds them (locs.rs:502-567), one lane: the order matters ----
         if (lane == 0) {
             S.n_alns = 0;
@@ -234,7 +281,12 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     const lcty_aln_rec rc = recs[idx];
                     const bool primary = idx == first;
                     if (rc.n_cigar == 0) continue;                           // skipped with a warning, locs.rs:550-554
-                    const Scored sc = score_words(L, cig + rc.cigar_rel, rc.n_cigar, rc.pos, L.allele_len[rc.contig], primary);
+                    Scored sc;
+                    if (T.wave_scores && rc.n_cigar >= WAVE_SCORE_FROM) {
+                        const uint4 pv = P.pre[idx];
+                        sc.ln_prob = __hiloint2double(static_cast<int>(pv.y), static_cast<int>(pv.x)); sc.start = rc.pos; sc.end = pv.z;
+                        sc.edit = pv.w & 0x7FFFFFFFu; sc.bad = (pv.w >> 31) != 0;
+                    } else sc = score_words(L, cig + rc.cigar_rel, rc.n_cigar, rc.pos, L.allele_len[rc.contig], primary);
                     if (primary) {                                           // thresholds, locs.rs:529-537
                         const uint2 gp = L.edit_lut[min(read_len, L.edit_lut_size - 1)];
                         uint32_t good = gp.x, passable = gp.y, thr = good;
@@ -799,7 +851,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
             T.out_recs = nullptr; T.out_recs_cap = 0; T.out_words = nullptr; T.out_words_cap = 0;
             T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.dp_cells = d_cursors.p + 3; T.min_weight = loc->prm.min_weight;
-            T.dry_run = 1;
+            T.dry_run = 1; T.wave_scores = reads->max_cigar_per_rec >= WAVE_SCORE_FROM ? 1u : 0u;
             ctx->timed(LCTY_K_TRANSFER, [&] {
                 hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
             });
@@ -848,7 +900,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 T.cap_alns = cap_alns; T.hcap = hcap; T.cap_new = cap_new; T.cap_words = cap_words;
                 T.lim = lim; T.last_level = lv + 1 == levels.size();
                 T.walk_budget = 1u << 30;                             // the walk never stops to look who needs the aligner (round 3: any budget was slower)
-                T.dry_run = 0;
+                T.dry_run = 0; T.wave_scores = reads->max_cigar_per_rec >= WAVE_SCORE_FROM ? 1u : 0u;
                 T.pair_list = list; T.n_list = n_list;
                 uint64_t* next = (lv % 2 == 0) ? d_list_a.p : d_list_b.p;
                 T.redo_list = next; T.redo_n = d_cursors.p + 2;
