@@ -940,7 +940,9 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         auto request_record = [&](GreedyCand& c) {
             c.pick = sample();
             const ChainRec* r = &recs[cand ? c.pick : 0u];
-            c.rpc = load_rp_cur(r);
+            // at wavefront scope like the other fields: the word comes in with the record's line. The only writer of a chain's records is this
+            // wavefront (a wavefront sees its own stores); what it stored after this request is in the last three moves kept below
+            c.rpc = field32(r, 0);
             c.b.meta = field32(r, 4); c.b.lp0 = field64(r, 8); c.b.lp1 = field64(r, 16); c.b.win0 = field32(r, 24); c.b.win1 = field32(r, 28);
         };
         // the first two further locations of a record that has arrived (reads with two locations: the chain's first entry, unused)
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             if (moved && jj == src) {
                 atomicAdd(&wd[w3], 1u); atomicAdd(&wd[w4], 1u);                   // the depth field never borrows from the GC bits
                 atomicSub(&wd[w1], 1u); atomicSub(&wd[w2], 1u);
-                store_rp_cur(&recs[pick], (rpc0 & 0xFFFFFFu) | (new_assgn << 24));
+                __hip_atomic_store(&recs[pick].rp_cur, (rpc0 & 0xFFFFFFu) | (new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 depth_mine += ddiff;
                 aln_mine += lp_new - cur_lp;
             }
