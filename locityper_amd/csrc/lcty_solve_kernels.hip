@@ -675,12 +675,14 @@ struct ChainLW {
     }
 };
 
-// the `cur` word of a record: served by L2 (agent scope), where a wavefront's own stores arrive in program order
+// the `cur` word of a record. Wavefront scope: a chain's records are written by the one wavefront that runs the chain and read back by that
+// wavefront (a wavefront sees its own stores: the CU's L1 is written through and kept current); other kernels see them at the kernel's end.
+// (At agent scope, as in rounds 1-3, every look at the word was a request of its own to the L2 next to the record's line.)
 __device__ __forceinline__ uint32_t load_rp_cur(const ChainRec* r) {
-    return __hip_atomic_load(&r->rp_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(&r->rp_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 __device__ __forceinline__ void store_rp_cur(ChainRec* r, uint32_t v) {
-    __hip_atomic_store(&r->rp_cur, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&r->rp_cur, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 // the immutable part of a record: two 16-byte loads
 struct RecBody { uint32_t meta; double lp0, lp1; uint32_t win0, win1; };
@@ -1070,7 +1072,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             if (moved && jj == src) {
                 atomicAdd(&wd[w3], 1u); atomicAdd(&wd[w4], 1u);                   // the depth field never borrows from the GC bits
                 atomicSub(&wd[w1], 1u); atomicSub(&wd[w2], 1u);
-                __hip_atomic_store(&recs[pick].rp_cur, (rpc0 & 0xFFFFFFu) | (new_assgn << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                store_rp_cur(&recs[pick], (rpc0 & 0xFFFFFFu) | (new_assgn << 24));
                 depth_mine += ddiff;
                 aln_mine += lp_new - cur_lp;
             }
