@@ -773,7 +773,10 @@ __host__ __device__ inline size_t greedy_lds_windows(uint32_t lpc, uint32_t wstr
 
 // ---------------- K14 Greedy: 64 / LPC chains per wavefront ----------------
 // A candidate read of an iteration as its lane sees it: the record, and the first two of its locations beyond the second
-struct GreedyCand { uint32_t pick, rpc; RecBody b; };
+// as they were loaded: the two 16-byte halves of a ChainRec, two ExtraLoc entries. They are taken apart where an iteration uses them (a
+// 16-byte load taken apart right behind itself makes the compiler wait for it there)
+struct GreedyCand { uint32_t pick; uint4 q0, q1; };
+struct GreedyExtRaw { uint4 x0, x1; };
 struct GreedyExt { double lp2, lp3; uint32_t win2, win3; };
 constexpr uint32_t GREEDY_INLINE_LOCS = 4;     // locations of a read the pipelined path holds in registers; reads with more take loads
 // selects, not branches: as nested conditionals this became a tree of divergent branches (600 clock ticks per iteration)
@@ -929,29 +932,19 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             }
             return idx;
         };
-        // Loads that stay in flight across iterations are issued field by field (relaxed atomic loads: the compiler neither
-        // merges nor splits them). A merged 12- or 16-byte load comes back as a register tuple, and a tuple whose parts live
-        // on for different lengths gets copied apart by the register allocator right after the load — which waits for it.
-        auto field32 = [](const void* p, uint32_t byte_off) -> uint32_t {
-            return __hip_atomic_load(reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(p) + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        };
-        auto field64 = [](const void* p, uint32_t byte_off) -> double {
-            return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
-                reinterpret_cast<const unsigned long long*>(static_cast<const uint8_t*>(p) + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)));
-        };
+        // A record is requested as its two 16-byte halves, its further locations as two 16-byte entries. Every load that misses the L1 is a
+        // request of its own to the L2, also when the line is already on its way: as six field loads (rounds 2-3) a record cost six requests,
+        // and its current-location word, read at agent scope, a seventh (round 4: 303 -> 276 ms for the stage alone).
         auto request_record = [&](GreedyCand& c) {
             c.pick = sample();
-            const ChainRec* r = &recs[cand ? c.pick : 0u];
-            // at wavefront scope like the other fields: the word comes in with the record's line. The only writer of a chain's records is this
-            // wavefront (a wavefront sees its own stores); what it stored after this request is in the last three moves kept below
-            c.rpc = field32(r, 0);
-            c.b.meta = field32(r, 4); c.b.lp0 = field64(r, 8); c.b.lp1 = field64(r, 16); c.b.win0 = field32(r, 24); c.b.win1 = field32(r, 28);
+            const uint4* r = reinterpret_cast<const uint4*>(&recs[cand ? c.pick : 0u]);
+            c.q0 = r[0]; c.q1 = r[1];
         };
         // the first two further locations of a record that has arrived (reads with two locations: the chain's first entry, unused)
-        auto request_ext = [&](const GreedyCand& c, GreedyExt& e) {
-            const uint32_t nloc = c.b.meta & 0xFFu;
-            const ExtraLoc* p = extra + (cand && nloc > 2 ? (c.b.meta >> 8) : 0u);   // the run has spare entries behind it
-            e.lp2 = field64(p, 0); e.win2 = field32(p, 8); e.lp3 = field64(p, 16); e.win3 = field32(p, 24);
+        auto request_ext = [&](const GreedyCand& c, GreedyExtRaw& e) {
+            const uint32_t meta = c.q0.y, nloc = meta & 0xFFu;
+            const uint4* p = reinterpret_cast<const uint4*>(extra + (cand && nloc > 2 ? (meta >> 8) : 0u));   // the run has spare entries behind it
+            e.x0 = p[0]; e.x1 = p[1];
         };
         uint32_t curr_plato = 0;
         uint64_t iter = 0;
@@ -960,7 +953,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
 
         // one iteration: A = its candidates (arrived), EA their further locations (arrived); N = the candidates of the next
         // iteration (arrived), EN receives their further locations; F = the slot the sample three iterations ahead goes to (= A's)
-        auto iteration = [&](auto slot_tag, GreedyCand& A, const GreedyExt& EA, const GreedyCand& N, GreedyExt& EN) {
+        auto iteration = [&](auto slot_tag, GreedyCand& A, const GreedyExtRaw& EA, const GreedyCand& N, GreedyExtRaw& EN) {
             [[maybe_unused]] constexpr uint32_t SLOT = decltype(slot_tag)::value;
             constexpr bool TIMED = (GREEDY_FORM & 32u) != 0;
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, ts[3] = {0, 0, 0}, tw0 = 0;
@@ -971,8 +964,15 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0); tw0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
             }
-            const RecBody b = A.b;
-            const uint32_t pick = A.pick, rpc0 = A.rpc;
+            RecBody b; GreedyExt EAu;
+            const uint32_t pick = A.pick, rpc0 = A.q0.x;
+            {
+                const uint4 q0 = A.q0, q1 = A.q1, x0 = EA.x0, x1 = EA.x1;
+                b.meta = q0.y; b.lp0 = __hiloint2double(static_cast<int>(q0.w), static_cast<int>(q0.z));
+                b.lp1 = __hiloint2double(static_cast<int>(q1.y), static_cast<int>(q1.x)); b.win0 = q1.z; b.win1 = q1.w;
+                EAu.lp2 = __hiloint2double(static_cast<int>(x0.y), static_cast<int>(x0.x)); EAu.win2 = x0.z;
+                EAu.lp3 = __hiloint2double(static_cast<int>(x1.y), static_cast<int>(x1.x)); EAu.win3 = x1.z;
+            }
             const uint32_t nloc = b.meta & 0xFFu;
             uint32_t cur = rpc0 >> 24;
             cur = pick == h3s ? h3t : cur; cur = pick == h2s ? h2t : cur; cur = pick == h1s ? h1t : cur;
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             const uint32_t n_alt = (cand && !done) ? nloc - 1 : 0u;
             const bool deep = n_alt != 0 && nloc > GREEDY_INLINE_LOCS;           // some locations of this read are not in registers
             double cur_lp = 0.0; uint32_t cur_w = 0;
-            if (n_alt) cand_loc(b, EA, min(cur, GREEDY_INLINE_LOCS - 1), &cur_lp, &cur_w);
+            if (n_alt) cand_loc(b, EAu, min(cur, GREEDY_INLINE_LOCS - 1), &cur_lp, &cur_w);
             if (__any(deep && cur >= GREEDY_INLINE_LOCS)) {                      // rare: the current location itself is beyond the fourth
                 if (deep && cur >= GREEDY_INLINE_LOCS) rec_loc(b, extra, cur, &cur_lp, &cur_w);
                 asm volatile("" : "+v"(cur_lp), "+v"(cur_w));                     // the wait for this load stays inside the rare branch
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 t_of[u] = u + (u >= cur ? 1u : 0u);
                 lp_t[u] = 0.0; win_t[u] = 0; cross[u] = false;
                 if (u == 0 || __any(has)) {
-                    if (has) cand_loc(b, EA, t_of[u], &lp_t[u], &win_t[u]);
+                    if (has) cand_loc(b, EAu, t_of[u], &lp_t[u], &win_t[u]);
                     const uint32_t a3 = has ? (win_t[u] & 0xFFFFu) : 0u, a4 = has ? (win_t[u] >> 16) : 0u;
                     C.request_pair(a3, a4, 1, ga[u]);
                     // a window shared between the two pairs (windows 0 and 1 carry no distribution: sharing them changes nothing)
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             }
         };
         GreedyCand R0, R1, R2;
-        GreedyExt E0, E1, E2;
+        GreedyExtRaw E0, E1, E2;
         if constexpr ((GREEDY_FORM & 32u) != 0) t_loop0 = __builtin_amdgcn_s_memtime();
         // in the order the loop leaves its requests behind — the further locations of the coming iteration, THEN the record of the one
         // after the next: the first copy of the unrolled loop is entered from here and from the loop's end, and the wait in front of
