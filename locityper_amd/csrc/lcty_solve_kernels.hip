@@ -686,9 +686,10 @@ __device__ __forceinline__ void store_rp_cur(ChainRec* r, uint32_t v) {
 }
 // the immutable part of a record: two 16-byte loads
 struct RecBody { uint32_t meta; double lp0, lp1; uint32_t win0, win1; };
-__device__ __forceinline__ RecBody load_body(const ChainRec* r) {
+__device__ __forceinline__ RecBody load_body(const ChainRec* r, uint32_t* rp_cur = nullptr) {
     const uint4 a = *reinterpret_cast<const uint4*>(r);
     const uint4 b = *(reinterpret_cast<const uint4*>(r) + 1);
+    if (rp_cur) *rp_cur = a.x;                                              // the word in front of the body: no load of its own
     RecBody o;
     o.meta = a.y;
     o.lp0 = __hiloint2double(static_cast<int>(a.w), static_cast<int>(a.z));
@@ -707,8 +708,8 @@ __device__ __forceinline__ void rec_loc(const RecBody& b, const ExtraLoc* extra,
 template <typename CHAIN, typename RNG>
 __device__ __forceinline__ void random_move(const CHAIN& C, const RecList& recs, const ExtraLoc* extra, uint32_t nnt, RNG& rng, Move& m) {
     m.slot = static_cast<uint32_t>(rng.below(nnt));
-    const uint32_t packed = load_rp_cur(&recs[m.slot]);
-    const RecBody b = load_body(&recs[m.slot]);
+    uint32_t packed;
+    const RecBody b = load_body(&recs[m.slot], &packed);                    // (the chain's own stores are in it: wavefront scope, see load_rp_cur)
     const uint32_t rp = packed & 0xFFFFFFu, old_assgn = packed >> 24, total = b.meta & 0xFFu;
     uint32_t new_assgn;
     if (total == 2) new_assgn = 1 - old_assgn;
@@ -1235,8 +1236,9 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 }
                 if (lane < n) {
                     const uint32_t slot = static_cast<uint32_t>(__umul64hi(mine, static_cast<uint64_t>(nnt)));
-                    const uint32_t rp = recs[slot].rp_cur & 0xFFFFFFu;
-                    const RecBody b = load_body(&recs[slot]);
+                    uint32_t rp;
+                    const RecBody b = load_body(&recs[slot], &rp);
+                    rp &= 0xFFFFFFu;
                     StagedRead* e = &ring->pos[(produced + lane) & (RING - 1)];
                     const uint32_t nloc = b.meta & 0xFFu;
                     e->draw = mine; e->rp = rp; e->nloc = nloc;
