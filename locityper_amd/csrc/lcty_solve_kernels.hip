@@ -677,7 +677,8 @@ struct ChainLW {
 
 // the `cur` word of a record. Wavefront scope: a chain's records are written by the one wavefront that runs the chain and read back by that
 // wavefront (a wavefront sees its own stores: the CU's L1 is written through and kept current); other kernels see them at the kernel's end.
-// (At agent scope, as in rounds 1-3, every look at the word was a request of its own to the L2 next to the record's line.)
+// (At agent scope, as in rounds 1-3, every look at the word was a request of its own to the L2 next to the record's line: 50 of the greedy
+// loop's 304 L1 -> L2 requests per wavefront-iteration.)
 __device__ __forceinline__ uint32_t load_rp_cur(const ChainRec* r) {
     return __hip_atomic_load(&r->rp_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -933,9 +934,10 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             }
             return idx;
         };
-        // A record is requested as its two 16-byte halves, its further locations as two 16-byte entries. Every load that misses the L1 is a
-        // request of its own to the L2, also when the line is already on its way: as six field loads (rounds 2-3) a record cost six requests,
-        // and its current-location word, read at agent scope, a seventh (round 4: 303 -> 276 ms for the stage alone).
+        // A record is requested as its two 16-byte halves, its further locations as two 16-byte entries: as six + four field loads (rounds
+        // 2-3) they were ten look-ups in the CU's L1 per candidate for two lines, and the current-location word, read at agent scope, a request
+        // of its own to the L2. Round 4: 957 -> 671 L1 look-ups and 304 -> 247 L1 -> L2 requests per wavefront-iteration, 303 -> 276 ms for the
+        // stage alone. (What the loop waits for is the CU's L1 path, not its own instructions: profiles/r04_greedy_forms_and_phases.txt.)
         auto request_record = [&](GreedyCand& c) {
             c.pick = sample();
             const uint4* r = reinterpret_cast<const uint4*>(&recs[cand ? c.pick : 0u]);
