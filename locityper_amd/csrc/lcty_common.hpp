@@ -205,9 +205,10 @@ struct lcty_ctx {
         uint32_t extra_cap = 0, extra_for_ploidy = 0;
         lcty::DevBuf<uint16_t> gt; lcty::DevBuf<uint8_t> cgc; lcty::DevBuf<uint32_t> cdepth, cnnt, cseg, ctotw, ovf, cuc; lcty::DevBuf<uint64_t> seeds;
         lcty::DevBuf<double> pri, liks, parts, cww, caln, dbg;
+        lcty::DevBuf<uint8_t> init_plan;      // the groups of a diploid stage's initialisation and their chains (lcty_solve_device.hpp: InitGroup, InitChainP)
         void release_all() {
             recs.release(); extra.release(); gt.release(); cgc.release(); cdepth.release(); cuc.release(); cnnt.release(); cseg.release(); ctotw.release(); ovf.release();
-            seeds.release(); pri.release(); liks.release(); parts.release(); cww.release(); caln.release(); extra_cap = 0;
+            seeds.release(); pri.release(); liks.release(); parts.release(); cww.release(); caln.release(); dbg.release(); init_plan.release(); extra_cap = 0;
         }
     } solve_ws[2];
     // Lane scratch of alignment recovery (lcty_transfer.hip): tens of GB for long reads, kept between the chunks of a streaming batch

@@ -158,11 +158,40 @@ struct RecList {
     __device__ __forceinline__ ChainRec& operator[](uint32_t s) const { return base[place(s)]; }
 };
 
+// ---- the initialisation of a diploid stage in GROUPS of chains (solve_init_tile_kernel) ----
+// The 5 000 chains of a stage are pairs out of a few hundred alleles: a workgroup that builds the records of several chains whose
+// genotypes share alleles reads every shared row of the location table once. The host cuts the stage into groups (plan_init_groups):
+// at most INIT_TILE_T chains on at most INIT_TILE_R distinct rows; the attempts of a genotype share both rows.
+constexpr uint32_t INIT_TILE_T = 8, INIT_TILE_R = 6;
+constexpr uint32_t INIT_TILE_Q = 1024;      // places in a wavefront's list of deferred reads (a ring; a block adds at most 64 per chain to < 64)
+static_assert(INIT_TILE_Q >= 64 * (INIT_TILE_T + 1) && (INIT_TILE_Q & (INIT_TILE_Q - 1)) == 0, "the list holds a block's entries");
+struct __attribute__((aligned(16))) InitChainP {     // one chain of a group: GenotypeWindows (windows.rs:709-739) of its two contigs, made on the host
+    uint64_t seed;
+    uint32_t chain;                 // index of the chain in the batch (genotype * attempts + attempt)
+    uint32_t ia, ib;                // which of the group's rows hold its two contigs
+    uint32_t row0, row1;            // the same as rows of the location table
+    uint32_t id0, id1;              // the alleles
+    uint32_t shift0, rs0, re0, shift1, rs1, re1;     // first window, region start, region end of either contig
+    uint32_t total_w;
+};
+static_assert(sizeof(InitChainP) == 64, "InitChainP layout");
+struct __attribute__((aligned(16))) InitGroup { uint32_t first, n_chains, n_rows, _pad; uint32_t row[8]; };
+static_assert(sizeof(InitGroup) == 48 && INIT_TILE_R <= 8, "InitGroup layout");
+struct InitPlan {
+    std::vector<InitGroup> groups; std::vector<InitChainP> chains;
+    uint32_t T = 0, R = 0;          // the launch's largest group
+    size_t lds = 0;
+};
+
 // ---- launchers of lcty_solve_kernels.hip (the only way the host side starts a solver kernel) ----
 void ensure_solver_tables(lcty_reads* reads);                              // location table + compact "unmapped" column of a scored batch
 void ensure_depth_table(lcty_locus* loc, uint64_t want);                   // extended depth table of the locus, at least `want` wide
 bool solver_lds_fits(uint32_t wstride);                                    // the window arrays of one chain next to the annealing ring in 160 KB of LDS
-void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s);
+// the batch of a stage as the host has it: what plan_init_groups makes the groups of a diploid stage from (row_of: NULL = the allele itself)
+struct InitHost { const uint16_t* genotypes; const uint64_t* seeds; const uint16_t* row_of; const lcty_locus* loc; uint32_t n_cus; };
+void plan_init_groups(const SolveView& V, const InitHost& H, uint32_t nch, InitPlan& plan);
+void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s, const InitHost* host, lcty_ctx::SolveWorkspace& ws,
+                 InitPlan& plan);
 void launch_greedy_chains(lcty_ctx* ctx, SolveView& V, uint32_t nch, hipStream_t stream, lcty_ctx::SolveWorkspace& ws);
 void launch_anneal(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s);
 void launch_pause(hipStream_t s);

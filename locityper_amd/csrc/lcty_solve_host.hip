@@ -80,6 +80,9 @@ struct StageRunner {
     uint32_t lane;                      // 0: the context's stream; 1: its side stream (the last stage of a locus while the next locus starts)
     hipStream_t stream;
     lcty_ctx::SolveWorkspace& ws;       // device state of the chains: grow-only, lives as long as the context
+    InitPlan init_plan;                 // the groups of the batch being initialised (host copy: its upload is asynchronous)
+    InitHost init_host{nullptr, nullptr, nullptr, nullptr, 0};
+    const RowGatherer* gathered_rows = nullptr;
 
     StageRunner(lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver, uint32_t attempts_,
                 const uint64_t* chain_seeds, uint32_t lane_ = 0, const RowGatherer* gathered = nullptr)
@@ -94,7 +97,7 @@ struct StageRunner {
         if (solver->kind == LCTY_SOLVER_ANNEAL && solver->anneal_steps == 0) fail(LCTY_ERR_INVALID_INPUT, "Number of annealing steps must be positive");
         if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size == 0) fail(LCTY_ERR_INVALID_INPUT, "Sample size must be positive");
         if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size > 64) fail(LCTY_ERR_UNSUPPORTED, "greedy sample size above 64");
-        ctx = reads->ctx; loc = reads->locus;
+        ctx = reads->ctx; loc = reads->locus; gathered_rows = gathered;
         ctx->activate();
         stream = lane ? ctx->side_stream() : ctx->stream;
         reads->check_device_error(stream);
@@ -209,7 +212,7 @@ struct StageRunner {
     void upload_genotypes(const uint16_t* genotypes, uint64_t ng) { ws.gt.upload(genotypes, ng * ploidy, stream); }
 
     void launch(uint32_t nch) {
-        launch_init(ctx, V, nch, lds_init, stream);
+        launch_init(ctx, V, nch, lds_init, stream, init_host.genotypes ? &init_host : nullptr, ws, init_plan);
         if (V.solver.kind == LCTY_SOLVER_EXACT) { solve_exact_batch(nch); return; }
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
             if (lane == 1) wait_for_greedy_of_next_locus();
@@ -402,6 +405,8 @@ struct StageRunner {
             const uint64_t ng = std::min(gt_per_batch, n_gt - g0), nch = ng * attempts;
             upload_genotypes(genotypes + g0 * ploidy, ng);
             ws.seeds.upload(chain_seeds + g0 * attempts, nch, s);
+            init_host = InitHost{genotypes + g0 * ploidy, chain_seeds + g0 * attempts, gathered_rows ? gathered_rows->row_of.data() : nullptr, loc,
+                                 static_cast<uint32_t>(ctx->props.multiProcessorCount)};
             if (priors) ws.pri.upload(priors + g0, ng, s);
             V.priors = priors ? ws.pri.p : nullptr;
             for (;;) {

@@ -499,6 +499,299 @@ __global__ __launch_bounds__(256) void solve_init_kernel(const SolveView V) {
     }
 }
 
+// ---------------- K12 + K13 of a diploid stage: one 256-thread workgroup per GROUP of chains (InitGroup) ----------------
+// solve_init_kernel streams two rows of the location table per chain: 40 B read + 32 B written per (chain, read), and with 5 000
+// chains out of a few hundred alleles every row is read forty times over. Here a workgroup builds the records of up to INIT_TILE_T
+// chains whose genotypes lie on at most INIT_TILE_R rows: wavefront k takes the k-th range of the locus' reads as before, loads the
+// rows' cells of a block of 64 reads ONCE (next block's in flight), parks them in its own LDS strip (a lane reads back only what it
+// wrote: the strip is a register file indexed by a uniform number) and walks the group's chains over them. Per (chain, read):
+// 32 B written, 16 B x rows / chains + 8 B / chains read.
+// The body per chain is straight-line for what nearly every read is — at most one pair-alignment within the threshold on either
+// contig, so its locations are a subset of {contig 0, contig 1, both unmapped}: order by three comparisons, the tweak hash of a
+// location from a per-read base shared by the group's chains, no loop. A read with several pair-alignments on a contig in reach
+// (~1 %) gets its place in the record list like the others (whether it is non-trivial is looked up at once in the rare case it is
+// not evident) and is put on the wavefront's list of deferred reads; the list is worked off 64 entries at a time by the general
+// code (locs_from_cells + LocIter, one entry per lane, chain parameters per lane) between two blocks.
+__device__ __forceinline__ uint64_t counter_fin(uint64_t z) {                 // the finaliser of counter_u64
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+constexpr uint64_t GOLDEN64 = 0x9e3779b97f4a7c15ull;
+__host__ __device__ inline size_t init_tile_lds(uint32_t T, uint32_t R, uint32_t wstride) {
+    const size_t depth = (static_cast<size_t>(T) * wstride * 4 + 15) & ~static_cast<size_t>(15);
+    return depth + static_cast<size_t>(T) * 256 * 8 + 4ull * R * 64 * 16 + static_cast<size_t>(T) * 4 * 8 + static_cast<size_t>(T) * 4 * 5 + 64;
+}
+
+// the general code for the deferred reads of a wavefront: lane i takes the i-th of the first n entries of its list (a ring in global
+// memory, written and read by this wavefront only: wavefront scope). What the reads add to the chains' alignment likelihood is summed
+// per chain in the order the reads were listed — increasing read number — whatever else shares the list: c_aln must not depend on
+// how the stage was cut into groups.
+__device__ __forceinline__ void init_tile_deferred(const SolveView& V, const InitChainP* __restrict__ cp, uint32_t T, uint32_t* depth, double* aln_def,
+                                                   uint32_t* ex_cnt, unsigned long long* queue, uint32_t head, uint32_t n, uint32_t wave, uint32_t lane, bool random_start) {
+    double add = 0.0;
+    uint32_t my_c = 0xFFFFFFFFu;
+    if (lane < n) {
+        const unsigned long long packed = __hip_atomic_load(&queue[(head + lane) & (INIT_TILE_Q - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint2 item = make_uint2(static_cast<uint32_t>(packed), static_cast<uint32_t>(packed >> 32));
+        const uint32_t c = item.x >> 24, rp = item.x & 0xFFFFFFu, slot = item.y;
+        const InitChainP P = cp[c];
+        Geno<2> G;
+        G.id[0] = P.id0; G.id[1] = P.id1; G.row[0] = P.row0; G.row[1] = P.row1; G.shift[0] = P.shift0; G.shift[1] = P.shift1;
+        G.reg_start[0] = P.rs0; G.reg_start[1] = P.rs1; G.reg_end[0] = P.re0; G.reg_end[1] = P.re1; G.total_w = P.total_w;
+        Locs<2> L;
+        locs_init<2>(L, V, rp, G);
+        if (L.nw > 255) atomicMax(V.overflow, 2u);                               // a record keeps the location in 8 bits
+        uint32_t a0 = 0;
+        if (L.nw > 1 && random_start)
+            a0 = static_cast<uint32_t>(__umul64hi(counter_u64(P.seed ^ INIT_KEY_XOR, rp), static_cast<uint64_t>(L.nw)));
+        const uint32_t nloc = min(L.nw, 255u), n_extra = nloc > 2 ? nloc - 2u : 0u;
+        uint32_t eix = 0;
+        if (n_extra) eix = atomicAdd(&ex_cnt[c], n_extra);
+        const bool room = static_cast<uint64_t>(eix) + n_extra <= V.extra_cap;
+        ExtraLoc* extra = V.extra + static_cast<uint64_t>(P.chain) * V.extra_cap;
+        ChainRec rec; rec.rp_cur = rp | (a0 << 24); rec.meta = nloc | (eix << 8);
+        rec.lp0 = rec.lp1 = 0.0; rec.win0 = rec.win1 = 0;
+        LocIter<2> it; it.start(L);
+        LocOut o;
+        for (uint32_t t = 0; t < nloc && it.next(L, V, o); t++) {
+            uint32_t wa, wb;
+            loc_windows(V, G, o, P.seed, rp, t, &wa, &wb);
+            const uint32_t win = wa | (wb << 16);
+            if (t == 0) { rec.lp0 = o.lp; rec.win0 = win; }
+            else if (t == 1) { rec.lp1 = o.lp; rec.win1 = win; }
+            else if (room) { ExtraLoc e; e.lp = o.lp; e.win = win; e._pad = 0; extra[eix + t - 2] = e; }
+            if (t == a0) {
+                atomicAdd(&depth[static_cast<size_t>(c) * V.wstride + wa], 1u);
+                atomicAdd(&depth[static_cast<size_t>(c) * V.wstride + wb], 1u);
+                add = o.lp;
+                my_c = c;
+            }
+        }
+        if (L.nw > 1) V.recs[static_cast<uint64_t>(P.chain) * V.rstride + static_cast<uint64_t>(wave) * V.seg_reads + slot] = rec;
+    }
+    for (uint32_t c = 0; c < T; c++) {
+        unsigned long long m = __ballot(my_c == c);
+        if (!m) continue;
+        double acc = aln_def[c * 4 + wave];
+        while (m) {
+            const int l = __ffsll(static_cast<long long>(m)) - 1;
+            acc += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(add), l), __builtin_amdgcn_readlane(__double2loint(add), l));
+            m &= m - 1;
+        }
+        if (lane == 0) aln_def[c * 4 + wave] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void solve_init_tile_kernel(const SolveView V, const InitGroup* __restrict__ groups, const InitChainP* __restrict__ chains,
+                                                             unsigned long long* lists, const uint32_t T_max, const uint32_t R_max) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const InitGroup& grp = groups[blockIdx.x];
+    const uint32_t T = grp.n_chains, R = grp.n_rows;
+    const InitChainP* __restrict__ cp = chains + grp.first;
+    const uint32_t W = V.wstride;
+    uint32_t* depth = reinterpret_cast<uint32_t*>(smem);                            // [T_max][W]
+    size_t at = (static_cast<size_t>(T_max) * W * 4 + 15) & ~static_cast<size_t>(15);
+    double* aln = reinterpret_cast<double*>(smem + at); at += static_cast<size_t>(T_max) * 256 * 8;      // [T_max][256] every thread's share of c_aln
+    uint4* stage = reinterpret_cast<uint4*>(smem + at) + static_cast<size_t>(wave) * R_max * 64; at += 4ull * R_max * 64 * 16;   // [4][R_max][64]
+    unsigned long long* queue = lists + (static_cast<size_t>(blockIdx.x) * 4 + wave) * INIT_TILE_Q;     // this wavefront's list of deferred reads
+    double* aln_def = reinterpret_cast<double*>(smem + at); at += static_cast<size_t>(T_max) * 4 * 8;      // [T_max][4] the deferred reads' share of c_aln, per wavefront
+    uint32_t* ex_cnt = reinterpret_cast<uint32_t*>(smem + at); at += static_cast<size_t>(T_max) * 4;    // further locations handed out per chain
+    uint32_t* seg_cnt = reinterpret_cast<uint32_t*>(smem + at);                     // [T_max][4] records of every segment
+
+    // K12: window distributions of every chain of the group (apply_tweak, assgn.rs:140-150)
+    for (uint32_t c = 0; c < T; c++) {
+        const InitChainP P = cp[c];
+        double* ww = V.c_ww + static_cast<uint64_t>(P.chain) * W;
+        uint8_t* wgc = V.c_gc + static_cast<uint64_t>(P.chain) * W;
+        uint32_t* wuc = V.n_wk ? V.c_uc + static_cast<uint64_t>(P.chain) * W : nullptr;
+        for (uint32_t w = tid; w < P.total_w; w += 256) {
+            depth[c * W + w] = 0;
+            double weight = 0.0; uint32_t g = 0, uc = V.n_wk - 1;                  // windows 0 and 1 (unmapped / out of region): trivial
+            if (w >= 2) {
+                const bool second = w >= P.shift1;
+                const uint32_t allele = second ? P.id1 : P.id0, sh = second ? P.shift1 : P.shift0, rs = second ? P.rs1 : P.rs0;
+                const uint32_t start = rs + (w - sh) * V.window, end = start + V.window;
+                const uint32_t left = min(V.tweak, start), right = min(V.tweak, V.allele_len[allele] - end);
+                const uint64_t r = counter_u64(P.seed ^ WINDOW_KEY_XOR, w);               // rng.random_range(-left..=right)
+                const int64_t off = -static_cast<int64_t>(left) + static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(left + right + 1)));
+                const uint32_t wstart = static_cast<uint32_t>(static_cast<int64_t>(start) + off);
+                const uint32_t i = V.ci_off[allele] + (wstart > V.left_padding ? wstart - V.left_padding : 0u);
+                weight = V.win_weight[i];
+                g = V.gc[i];
+                if (wuc) uc = V.uniq_cnt[i] | (static_cast<uint32_t>(V.compl_cnt[i]) << 16);
+                if (weight < V.min_weight || weight < 1e-7) { weight = 0.0; g = 0; uc = V.n_wk - 1; }      // assgn.rs:144-148, distr_cache.rs:84
+            }
+            ww[w] = weight; wgc[w] = static_cast<uint8_t>(g);
+            if (wuc) wuc[w] = uc;
+        }
+        aln[c * 256 + tid] = 0.0;
+        if (tid < 4) aln_def[c * 4 + tid] = 0.0;
+        if (tid == 0) ex_cnt[c] = 0;
+    }
+    __syncthreads();
+
+    // K13: initial assignment, depth histograms, the records of the non-trivial reads. The wavefronts do not talk to each other.
+    const bool random_start = V.solver.kind == LCTY_SOLVER_ANNEAL || (V.solver.kind == LCTY_SOLVER_GREEDY && !V.solver.best_start);
+    const uint32_t seg_lo = min(wave * V.seg_reads, V.n_good), seg_hi = min(seg_lo + V.seg_reads, V.n_good);
+    uint64_t row_at[INIT_TILE_R];
+#pragma unroll
+    for (uint32_t r = 0; r < INIT_TILE_R; r++) row_at[r] = static_cast<uint64_t>(grp.row[r < R ? r : 0]) * V.ngp;
+    const uint4* __restrict__ table = reinterpret_cast<const uint4*>(V.table);      // LocCell: {lp lo, lp hi, m1n, m2}
+    uint4 nxt[INIT_TILE_R]; double nxt_unm = 0.0;
+#pragma unroll
+    for (uint32_t r = 0; r < INIT_TILE_R; r++) nxt[r] = make_uint4(0, 0, 0, 0);
+    if (seg_lo + lane < seg_hi) {
+#pragma unroll
+        for (uint32_t r = 0; r < INIT_TILE_R; r++) if (r < R) nxt[r] = table[row_at[r] + seg_lo + lane];
+        nxt_unm = V.table_unm[seg_lo + lane];
+    }
+    uint32_t n_recs_all = 0;                   // lane c: the records of chain c so far (read and written with a uniform lane number)
+    uint32_t qn = 0, qhead = 0;                // entries on the list of deferred reads (a ring), its first
+    for (uint32_t base = seg_lo; base < seg_hi; base += 64) {
+        const uint32_t rp = base + lane;
+        const bool in = rp < seg_hi;
+#pragma unroll
+        for (uint32_t r = 0; r < INIT_TILE_R; r++) if (r < R) stage[r * 64 + lane] = nxt[r];
+        const double unm = nxt_unm;
+        if (rp + 64 < seg_hi) {                // the cells of the next 64 reads: in flight while the group's chains go over this block
+#pragma unroll
+            for (uint32_t r = 0; r < INIT_TILE_R; r++) if (r < R) nxt[r] = table[row_at[r] + rp + 64];
+            nxt_unm = V.table_unm[rp + 64];
+        }
+        // per read, shared by the chains: the multiples of the golden ratio inside counter_u64(seed, rp << 16 | t) and counter_u64(seed', rp)
+        const uint64_t zbase = ((static_cast<uint64_t>(rp) << 16) + 1ull) * GOLDEN64;
+        const uint64_t abase = (static_cast<uint64_t>(rp) + 1ull) * GOLDEN64;
+        for (uint32_t c = 0; c < T; c++) {
+            const InitChainP P = cp[c];
+            const uint4 qa = stage[P.ia * 64 + lane], qb = stage[P.ib * 64 + lane];
+            const double lpA = __hiloint2double(static_cast<int>(qa.y), static_cast<int>(qa.x));
+            const double lpB = __hiloint2double(static_cast<int>(qb.y), static_cast<int>(qb.x));
+            const uint32_t rawA = qa.z >> 24, rawB = qb.z >> 24;
+            const double thresh = fmax(fmax(lpA, lpB), unm) - V.prob_diff;           // max(unm - d, best_i - d, ...) == max(...) - d
+            const bool kA = in && rawA != 0 && lpA >= thresh, kB = in && rawB != 0 && lpB >= thresh, kU = in && unm >= thresh;
+            const bool multi = (kA && rawA > 1) || (kB && rawB > 1);                 // several pair-alignments on a contig in reach: deferred
+            const uint32_t nw = (kA ? 1u : 0u) + (kB ? 1u : 0u) + (kU ? 1u : 0u);
+            bool nontrivial = nw > 1;
+            if (__any(multi && nw == 1)) {
+                // the contig's second pair-alignment decides whether the read is non-trivial (locs_from_cells: pa[ext + k - 1] at k = 1)
+                if (multi && nw == 1) {
+                    const uint32_t ext = V.table_ext[static_cast<uint64_t>(kA ? P.row0 : P.row1) * V.ngp + rp];
+                    nontrivial = V.pa[ext].ln_prob >= thresh;
+                }
+            }
+            // ordered compaction of the non-trivial reads of this range (assgn.rs:61-63)
+            const unsigned long long nt_mask = __ballot(nontrivial);
+            const uint32_t before = __builtin_amdgcn_readlane(n_recs_all, c);
+            const uint32_t slot = before + static_cast<uint32_t>(__popcll(nt_mask & ((1ull << lane) - 1ull)));
+            {
+                const uint32_t after = __builtin_amdgcn_readfirstlane(before + static_cast<uint32_t>(__popcll(nt_mask)));
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(n_recs_all) : "s"(after), "s"(c) : "m0");   // (one scalar register per VOP3 on gfx9: the lane number goes through m0)
+            }
+            const unsigned long long mm = __ballot(multi);
+            if (mm) {
+                if (multi)
+                    __hip_atomic_store(&queue[(qhead + qn + static_cast<uint32_t>(__popcll(mm & ((1ull << lane) - 1ull)))) & (INIT_TILE_Q - 1)],
+                                       static_cast<unsigned long long>(rp | (c << 24)) | (static_cast<unsigned long long>(slot) << 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+                qn += static_cast<uint32_t>(__popcll(mm));
+            }
+            // the read's locations in decreasing ln_prob, ties in push order (contig 0, contig 1, then "unmapped") — windows.rs:793
+            const bool BgtA = lpB > lpA, UgtA = unm > lpA, UgtB = unm > lpB;
+            const uint32_t posA = ((kB && BgtA) ? 1u : 0u) + ((kU && UgtA) ? 1u : 0u);
+            const uint32_t posB = ((kA && !BgtA) ? 1u : 0u) + ((kU && UgtB) ? 1u : 0u);
+            // get_shifted_window_ix + middle_window (windows.rs:62-68, 465-470) with define_windows_random (123-136)
+            uint32_t tA1 = 0, tA2 = 0, tB1 = 0, tB2 = 0;
+            if (V.tweak) {
+                const uint64_t z0 = P.seed + zbase;
+                const uint64_t rA = counter_fin(z0 + (posA == 0 ? 0ull : posA == 1 ? GOLDEN64 : 2ull * GOLDEN64));
+                const uint64_t rB = counter_fin(z0 + (posB == 0 ? 0ull : posB == 1 ? GOLDEN64 : 2ull * GOLDEN64));
+                tA1 = V.by_tweak.mod(static_cast<uint32_t>(rA >> 32)); tA2 = V.by_tweak.mod(static_cast<uint32_t>(rA));
+                tB1 = V.by_tweak.mod(static_cast<uint32_t>(rB >> 32)); tB2 = V.by_tweak.mod(static_cast<uint32_t>(rB));
+            }
+            auto window_ix = [&](uint32_t mid, bool none, uint32_t tw, uint32_t rs, uint32_t re, uint32_t sh) -> uint32_t {
+                const uint32_t m = mid + tw;
+                const uint32_t inside = (rs <= m && m < re) ? V.by_window.div(m - rs) + sh : 1u;      // BOUNDARY_WINDOW
+                return none ? 0u : inside;                                                             // UNMAPPED_WINDOW
+            };
+            const uint32_t midA1 = qa.z & MID_NONE24, midB1 = qb.z & MID_NONE24;
+            const uint32_t winA = window_ix(midA1, midA1 == MID_NONE24, tA1, P.rs0, P.re0, P.shift0) |
+                                  (window_ix(qa.w, qa.w == NONE32S, tA2, P.rs0, P.re0, P.shift0) << 16);
+            const uint32_t winB = window_ix(midB1, midB1 == MID_NONE24, tB1, P.rs1, P.re1, P.shift1) |
+                                  (window_ix(qb.w, qb.w == NONE32S, tB2, P.rs1, P.re1, P.shift1) << 16);
+            // the location at place q of the order (q < nw): contig 0, contig 1, or — neither — "both unmapped" (values, selects)
+            const bool a_0 = kA && posA == 0, b_0 = kB && posB == 0, a_1 = kA && posA == 1, b_1 = kB && posB == 1, a_2 = kA && posA == 2, b_2 = kB && posB == 2;
+            const double lp0 = a_0 ? lpA : (b_0 ? lpB : unm), lp1 = a_1 ? lpA : (b_1 ? lpB : unm), lp2 = a_2 ? lpA : (b_2 ? lpB : unm);
+            const uint32_t win0 = a_0 ? winA : (b_0 ? winB : 0u), win1 = a_1 ? winA : (b_1 ? winB : 0u), win2 = a_2 ? winA : (b_2 ? winB : 0u);
+            uint32_t a0 = 0;
+            double lps = lp0; uint32_t wins = win0;                                // where the read starts: its best location, or a drawn one
+            if (random_start) {
+                const uint64_t r = counter_fin((P.seed ^ INIT_KEY_XOR) + abase);
+                a0 = nw > 1 ? static_cast<uint32_t>(__umul64hi(r, static_cast<uint64_t>(nw))) : 0u;
+                lps = a0 == 0 ? lp0 : (a0 == 1 ? lp1 : lp2); wins = a0 == 0 ? win0 : (a0 == 1 ? win1 : win2);
+            }
+            const bool fast = !multi && nw != 0;
+            if (fast) {
+                atomicAdd(&depth[c * W + (wins & 0xFFFFu)], 1u);
+                atomicAdd(&depth[c * W + (wins >> 16)], 1u);
+                aln[c * 256 + tid] += lps;
+            }
+            uint32_t eix = 0;
+            if (fast && nw == 3) {
+                eix = atomicAdd(&ex_cnt[c], 1u);
+                if (eix < V.extra_cap) {
+                    ExtraLoc e; e.lp = lp2; e.win = win2; e._pad = 0;
+                    V.extra[static_cast<uint64_t>(P.chain) * V.extra_cap + eix] = e;
+                }
+            }
+            if (fast && nw > 1) {
+                uint4* dst = reinterpret_cast<uint4*>(V.recs + static_cast<uint64_t>(P.chain) * V.rstride + static_cast<uint64_t>(wave) * V.seg_reads + slot);
+                dst[0] = make_uint4(rp | (a0 << 24), nw | (eix << 8), static_cast<uint32_t>(__double2loint(lp0)), static_cast<uint32_t>(__double2hiint(lp0)));
+                dst[1] = make_uint4(static_cast<uint32_t>(__double2loint(lp1)), static_cast<uint32_t>(__double2hiint(lp1)), win0, win1);
+            }
+        }
+        // The list of deferred reads is worked off between blocks, 64 entries at a time, all of it behind the wavefront's last block: a
+        // block adds at most 64 entries per chain to the fewer than 64 left over. (Inside the chain loop the general code's loads made
+        // every chain wait for the record stores of the chain before it: the loop holds stores only.)
+        const bool last = base + 64 >= seg_hi;
+        if (qn >= 64 || (last && qn)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            while (qn >= 64 || (last && qn)) {
+                const uint32_t n = min(qn, 64u);
+                init_tile_deferred(V, cp, T, depth, aln_def, ex_cnt, queue, qhead, n, wave, lane, random_start);
+                qhead = (qhead + n) & (INIT_TILE_Q - 1); qn -= n;
+            }
+        }
+    }
+    if (lane < T) seg_cnt[lane * 4 + wave] = n_recs_all;
+    __syncthreads();
+    for (uint32_t c = 0; c < T; c++) {
+        const InitChainP P = cp[c];
+        const uint32_t ex_total = ex_cnt[c];
+        if (tid == 0) {
+            if (ex_total > V.extra_cap) { atomicMax(V.overflow, 4u); atomicMax(V.overflow + 1, ex_total); }
+            if (ex_total >= (1u << 24)) atomicMax(V.overflow, 2u);
+        }
+        uint32_t* gdepth = V.c_depth + static_cast<uint64_t>(P.chain) * W;
+        for (uint32_t w = tid; w < P.total_w; w += 256) gdepth[w] = depth[c * W + w];
+        // c_aln: the threads' shares, added up by the first wavefront
+        if (wave == 0) {
+            double v = (aln[c * 256 + lane] + aln[c * 256 + 64 + lane]) + (aln[c * 256 + 128 + lane] + aln[c * 256 + 192 + lane]);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            v += (aln_def[c * 4] + aln_def[c * 4 + 1]) + (aln_def[c * 4 + 2] + aln_def[c * 4 + 3]);
+            if (lane == 0) {
+                uint32_t* cum = V.c_seg + static_cast<uint64_t>(P.chain) * 4;
+                uint32_t run = 0;
+                for (uint32_t k = 0; k < INIT_SEGS; k++) { cum[k] = run; run += seg_cnt[c * 4 + k]; }
+                V.c_aln[P.chain] = v; V.c_nnt[P.chain] = run; V.c_totw[P.chain] = P.total_w;
+            }
+        }
+    }
+}
+
 // two windows of one location (see Chain::request_pair)
 struct PairGather { int32_t c[2]; uint32_t dmax[2]; double weight[2], vnew[2], vold[2]; };
 // the four terms of depth_lik_diff in its order of summation, ((t1 + t2) + t3) + t4, from the two halves; *deepest: the deepest live window
@@ -1798,7 +2091,152 @@ void launch_greedy_chains(lcty_ctx* ctx, SolveView& V, uint32_t nch, hipStream_t
 bool solver_lds_fits(uint32_t wstride) {
     return !(static_cast<size_t>(wstride) * 12 + sizeof(AnnealRing) + 128 > 160 * 1024 || wstride > 65535);
 }
-void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s) {
+// The groups of a diploid stage (solve_init_tile_kernel). Alleles are ranked by how many of the stage's genotypes hold them; a genotype
+// whose better-ranked allele has rank u and whose other allele has rank v belongs to tile (u / 2, v / 4): two alleles by four, eight
+// genotypes on six rows when the tile is full — the top of a prefilter is a few alleles paired with nearly everything plus a dense
+// core, and both fill their tiles. Genotypes are taken in tile order and a group is closed when the next genotype's chains or rows
+// no longer fit; the attempts of a genotype stay together (they share both rows) unless there are more of them than a group holds.
+//
+// How long the launch lasts is a matter of how its workgroups fill the device, not only of what they read: a workgroup lasts as
+// long as its chains are many (the kernel is bound by its instruction stream), S of them are resident, and 1 091 groups of five on
+// 512 places are three rounds where 1 024 would have been two. So: the groups are as large as "every place gets one" allows
+// (ceil(chains / S), at most INIT_TILE_T), the largest go first, and what is left behind the first S groups is cut into pieces small
+// enough that every place gets three or more of them — the places that finish their large group take small ones until none is left,
+// and the launch ends within one small piece of the ideal.
+void plan_init_groups(const SolveView& V, const InitHost& H, uint32_t nch, InitPlan& plan) {
+    plan.groups.clear(); plan.chains.clear(); plan.T = plan.R = 0; plan.lds = 0;
+    const uint32_t attempts = V.attempts, ng = (nch + attempts - 1) / attempts, A = V.A;
+    uint32_t T_cap = INIT_TILE_T;                                            // what the LDS holds with two workgroups per CU
+    while (T_cap > 1 && init_tile_lds(T_cap, std::min(INIT_TILE_R, T_cap + 1), V.wstride) > 80 * 1024) T_cap--;
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(160 * 1024 / init_tile_lds(T_cap, std::min(INIT_TILE_R, T_cap + 1), V.wstride), 4));
+    const uint64_t places = per_cu * std::max(1u, H.n_cus);
+    T_cap = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(T_cap, (nch + places - 1) / places)));
+    const uint32_t R_cap = std::min(INIT_TILE_R, T_cap + 1);
+    std::vector<uint32_t> deg(A, 0), rank(A, 0), order(A);
+    for (uint32_t g = 0; g < ng; g++) { deg[H.genotypes[2 * g]]++; deg[H.genotypes[2 * g + 1]]++; }
+    for (uint32_t a = 0; a < A; a++) order[a] = a;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return deg[x] > deg[y]; });
+    for (uint32_t r = 0; r < A; r++) rank[order[r]] = r;
+    std::vector<uint32_t> gts(ng);
+    std::vector<uint64_t> key(ng);
+    for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t ra = rank[H.genotypes[2 * g]], rb = rank[H.genotypes[2 * g + 1]];
+        const uint64_t u = std::min(ra, rb), v = std::max(ra, rb);
+        key[g] = ((u / 2) << 48) | ((v / 4) << 32) | (u << 16) | v;
+        gts[g] = g;
+    }
+    std::sort(gts.begin(), gts.end(), [&](uint32_t x, uint32_t y) { return key[x] != key[y] ? key[x] < key[y] : x < y; });
+    auto row_of = [&](uint32_t allele) -> uint32_t { return H.row_of ? H.row_of[allele] : allele; };
+    // first the groups as lists of (genotype, first attempt, attempts) ...
+    struct Unit { uint32_t gi, a0, n; };
+    struct Proto { std::vector<Unit> units; uint32_t n_chains = 0, n_rows = 0; uint32_t row[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+    std::vector<Proto> protos;
+    Proto cur;
+    auto close = [&] { if (cur.n_chains) protos.push_back(cur); cur = Proto{}; };
+    auto fresh_rows = [&](const Proto& p, uint32_t r0, uint32_t r1) -> uint32_t {
+        bool h0 = false, h1 = false;
+        for (uint32_t r = 0; r < p.n_rows; r++) { h0 |= p.row[r] == r0; h1 |= p.row[r] == r1; }
+        return (h0 ? 0u : 1u) + ((h1 || r1 == r0) ? 0u : 1u);
+    };
+    auto add_rows = [&](Proto& p, uint32_t r0, uint32_t r1) {
+        for (uint32_t x : {r0, r1}) {
+            bool have = false;
+            for (uint32_t r = 0; r < p.n_rows; r++) have |= p.row[r] == x;
+            if (!have) p.row[p.n_rows++] = x;
+        }
+    };
+    for (uint32_t gi : gts) {
+        const uint32_t r0 = row_of(H.genotypes[2 * gi]), r1 = row_of(H.genotypes[2 * gi + 1]);
+        for (uint32_t a0 = 0; a0 < attempts;) {
+            const uint32_t want = std::min(attempts - a0, T_cap);
+            if (cur.n_chains + want > T_cap || cur.n_rows + fresh_rows(cur, r0, r1) > R_cap) close();
+            add_rows(cur, r0, r1);
+            cur.units.push_back(Unit{gi, a0, want}); cur.n_chains += want;
+            a0 += want;
+        }
+    }
+    close();
+    // ... the largest first, the tail behind the first `places` of them in small pieces ...
+    std::stable_sort(protos.begin(), protos.end(), [](const Proto& a, const Proto& b) { return a.n_chains > b.n_chains; });
+    if (protos.size() > places) {
+        uint64_t tail_chains = 0;
+        for (size_t i = places; i < protos.size(); i++) tail_chains += protos[i].n_chains;
+        const uint32_t piece = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(T_cap, tail_chains / (3 * places))));
+        std::vector<Proto> tail;
+        for (size_t i = places; i < protos.size(); i++) {
+            Proto part;
+            for (const Unit& u : protos[i].units)
+                for (uint32_t done = 0; done < u.n;) {
+                    const uint32_t take = std::min(u.n - done, piece - part.n_chains);
+                    add_rows(part, row_of(H.genotypes[2 * u.gi]), row_of(H.genotypes[2 * u.gi + 1]));
+                    part.units.push_back(Unit{u.gi, u.a0 + done, take}); part.n_chains += take;
+                    done += take;
+                    if (part.n_chains == piece) { tail.push_back(part); part = Proto{}; }
+                }
+            if (part.n_chains) tail.push_back(part);
+        }
+        protos.resize(places);
+        protos.insert(protos.end(), tail.begin(), tail.end());
+    }
+    // ... then the groups and their chains as the kernel reads them
+    for (const Proto& p : protos) {
+        InitGroup g{};
+        g.first = static_cast<uint32_t>(plan.chains.size()); g.n_rows = p.n_rows;
+        for (uint32_t r = 0; r < 8; r++) g.row[r] = p.row[r];
+        for (const Unit& u : p.units) {
+            const uint32_t id0 = H.genotypes[2 * u.gi], id1 = H.genotypes[2 * u.gi + 1];
+            const uint32_t row0 = row_of(id0), row1 = row_of(id1);
+            uint32_t ia = 0, ib = 0;
+            for (uint32_t r = 0; r < p.n_rows; r++) { if (p.row[r] == row0) ia = r; if (p.row[r] == row1) ib = r; }
+            const uint32_t nw0 = H.loc->n_windows[id0], nw1 = H.loc->n_windows[id1];
+            for (uint32_t k = 0; k < u.n; k++) {
+                const uint32_t chain = u.gi * attempts + u.a0 + k;
+                if (chain >= nch) break;
+                InitChainP P{};
+                P.seed = H.seeds[chain]; P.chain = chain; P.ia = ia; P.ib = ib; P.row0 = row0; P.row1 = row1; P.id0 = id0; P.id1 = id1;
+                P.shift0 = 2; P.rs0 = H.loc->reg_start[id0]; P.re0 = P.rs0 + nw0 * V.window;           // GenotypeWindows: REG_WINDOW_SHIFT = 2
+                P.shift1 = 2 + nw0; P.rs1 = H.loc->reg_start[id1]; P.re1 = P.rs1 + nw1 * V.window;
+                P.total_w = 2 + nw0 + nw1;
+                plan.chains.push_back(P);
+                g.n_chains++;
+            }
+        }
+        if (!g.n_chains) continue;
+        plan.T = std::max(plan.T, g.n_chains); plan.R = std::max(plan.R, g.n_rows);
+        plan.groups.push_back(g);
+    }
+    plan.lds = init_tile_lds(plan.T, plan.R, V.wstride);
+}
+
+void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s, const InitHost* host, lcty_ctx::SolveWorkspace& ws,
+                 InitPlan& plan) {
+    if (V.ploidy == 2 && host && nch && ctx->knob("solve_init_tiles", 1) != 0) {
+        plan_init_groups(V, *host, nch, plan);
+        const size_t gb = plan.groups.size() * sizeof(InitGroup), cb = plan.chains.size() * sizeof(InitChainP);
+        if (ctx->knob("solve_stats", 0)) {
+            uint64_t rows = 0; uint32_t hist[INIT_TILE_T + 1] = {0};
+            for (const InitGroup& g : plan.groups) { rows += g.n_rows; hist[g.n_chains]++; }
+            fprintf(stderr, "[lcty solve] initialisation: %u chains in %zu groups (largest %u chains, %u rows; %.2f rows per chain; LDS %zu B); groups of 1..%u chains:",
+                    nch, plan.groups.size(), plan.T, plan.R, static_cast<double>(rows) / nch, plan.lds, INIT_TILE_T);
+            for (uint32_t t = 1; t <= INIT_TILE_T; t++) fprintf(stderr, " %u", hist[t]);
+            fprintf(stderr, "\n");
+        }
+        const size_t lb = plan.groups.size() * 4 * INIT_TILE_Q * sizeof(unsigned long long);   // a list of deferred reads per wavefront
+        ws.init_plan.ensure_slack(gb + cb + lb);
+        LCTY_HIP(hipMemcpyAsync(ws.init_plan.p, plan.groups.data(), gb, hipMemcpyHostToDevice, s));
+        LCTY_HIP(hipMemcpyAsync(ws.init_plan.p + gb, plan.chains.data(), cb, hipMemcpyHostToDevice, s));
+        if (plan.lds > 48 * 1024)
+            LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(plan.lds)));
+        const InitGroup* d_groups = reinterpret_cast<const InitGroup*>(ws.init_plan.p);
+        const InitChainP* d_chains = reinterpret_cast<const InitChainP*>(ws.init_plan.p + gb);
+        ctx->timed(LCTY_K_SOLVE_INIT, [&] {
+            hipLaunchKernelGGL(solve_init_tile_kernel, dim3(static_cast<uint32_t>(plan.groups.size())), dim3(256), plan.lds, s, V, d_groups, d_chains,
+                               reinterpret_cast<unsigned long long*>(ws.init_plan.p + gb + cb), plan.T, plan.R);
+        }, s);
+        LCTY_HIP(hipGetLastError());
+        return;
+    }
     switch (V.ploidy) {
         case 1: launch_init_p<1>(ctx, V, nch, lds_init, s); break;
         case 2: launch_init_p<2>(ctx, V, nch, lds_init, s); break;
