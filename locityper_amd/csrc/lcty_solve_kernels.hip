@@ -518,6 +518,11 @@ __device__ __forceinline__ uint64_t counter_fin(uint64_t z) {                 //
     return z ^ (z >> 31);
 }
 constexpr uint64_t GOLDEN64 = 0x9e3779b97f4a7c15ull;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_16(uint4* p, uint4 v) {              // one 16-byte store that stays one
+    u32x4_t x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t*>(p));
+}
 __host__ __device__ inline size_t init_tile_lds(uint32_t T, uint32_t R, uint32_t wstride) {
     const size_t depth = (static_cast<size_t>(T) * wstride * 4 + 15) & ~static_cast<size_t>(15);
     return depth + static_cast<size_t>(T) * 256 * 8 + 4ull * R * 64 * 16 + static_cast<size_t>(T) * 4 * 8 + static_cast<size_t>(T) * 4 * 5 + 64;
@@ -666,6 +671,7 @@ __global__ __launch_bounds__(256) void solve_init_tile_kernel(const SolveView V,
         for (uint32_t c = 0; c < T; c++) {
             const InitChainP P = cp[c];
             const uint4 qa = stage[P.ia * 64 + lane], qb = stage[P.ib * 64 + lane];
+            const double aln_before = aln[c * 256 + tid];
             const double lpA = __hiloint2double(static_cast<int>(qa.y), static_cast<int>(qa.x));
             const double lpB = __hiloint2double(static_cast<int>(qb.y), static_cast<int>(qb.x));
             const uint32_t rawA = qa.z >> 24, rawB = qb.z >> 24;
@@ -712,8 +718,10 @@ __global__ __launch_bounds__(256) void solve_init_tile_kernel(const SolveView V,
             }
             auto window_ix = [&](uint32_t mid, bool none, uint32_t tw, uint32_t rs, uint32_t re, uint32_t sh) -> uint32_t {
                 const uint32_t m = mid + tw;
-                const uint32_t inside = (rs <= m && m < re) ? V.by_window.div(m - rs) + sh : 1u;      // BOUNDARY_WINDOW
-                return none ? 0u : inside;                                                             // UNMAPPED_WINDOW
+                uint32_t q = V.by_window.div(m - rs) + sh;
+                asm volatile("" : "+v"(q));                                         // a value, then selects: no branch around the division
+                const uint32_t inside = (rs <= m && m < re) ? q : 1u;              // BOUNDARY_WINDOW
+                return none ? 0u : inside;                                          // UNMAPPED_WINDOW
             };
             const uint32_t midA1 = qa.z & MID_NONE24, midB1 = qb.z & MID_NONE24;
             const uint32_t winA = window_ix(midA1, midA1 == MID_NONE24, tA1, P.rs0, P.re0, P.shift0) |
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(256) void solve_init_tile_kernel(const SolveView V,
             if (fast) {
                 atomicAdd(&depth[c * W + (wins & 0xFFFFu)], 1u);
                 atomicAdd(&depth[c * W + (wins >> 16)], 1u);
-                aln[c * 256 + tid] += lps;
+                aln[c * 256 + tid] = aln_before + lps;
             }
             uint32_t eix = 0;
             if (fast && nw == 3) {
@@ -747,8 +755,9 @@ __global__ __launch_bounds__(256) void solve_init_tile_kernel(const SolveView V,
             }
             if (fast && nw > 1) {
                 uint4* dst = reinterpret_cast<uint4*>(V.recs + static_cast<uint64_t>(P.chain) * V.rstride + static_cast<uint64_t>(wave) * V.seg_reads + slot);
-                dst[0] = make_uint4(rp | (a0 << 24), nw | (eix << 8), static_cast<uint32_t>(__double2loint(lp0)), static_cast<uint32_t>(__double2hiint(lp0)));
-                dst[1] = make_uint4(static_cast<uint32_t>(__double2loint(lp1)), static_cast<uint32_t>(__double2hiint(lp1)), win0, win1);
+                // the record as its two 16-byte halves (left to itself the compiler stores 8 + 16 + 8 bytes, the middle piece unaligned)
+                store_16(dst, make_uint4(rp | (a0 << 24), nw | (eix << 8), static_cast<uint32_t>(__double2loint(lp0)), static_cast<uint32_t>(__double2hiint(lp0))));
+                store_16(dst + 1, make_uint4(static_cast<uint32_t>(__double2loint(lp1)), static_cast<uint32_t>(__double2hiint(lp1)), win0, win1));
             }
         }
         // The list of deferred reads is worked off between blocks, 64 entries at a time, all of it behind the wavefront's last block: a
