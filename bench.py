@@ -244,14 +244,16 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
             total += (5000.0 / g_cps + 400.0 / a_cps) * (args.pairs / solver_pairs)
         entry["seconds_per_locus"] = total
         entry["value"] = args.pairs / total
-        by["threads_8" if T == 8 else "all_cores"] = entry
-    if "all_cores" not in by:
-        by["all_cores"] = dict(by["threads_8"])          # an 8-core host: the two coincide
-    by["all_cores"]["note"] = f"{by['all_cores']['threads']} threads of {n_phys} physical cores (capped at 32: see bench.py)"
-    if oa_full is not None and "greedy_chains_per_s_per_thread" in by["threads_8"]:
-        # how the stage loop scales from the reference's default of 8 threads to every core (1.0 = linear in the threads)
-        t8, ta = by["threads_8"], by["all_cores"]
-        by["all_cores"]["chain_scaling_vs_8_threads"] = (ta["chains_per_s"] / t8["chains_per_s"]) / max(ta["threads"] / 8.0, 1.0)
+        by[f"threads_{T}"] = entry
+    # the reported baseline is the FASTER of the thread settings tried (8 = the reference's default; min(physical cores, 32): beyond that the
+    # restatement's stage loop stops scaling, see above) — named by its thread count, not "all cores"
+    best_key = max(by, key=lambda k_: by[k_]["value"])
+    for k_ in by: by[k_]["note"] = f"{by[k_]['threads']} threads of {n_phys} physical cores"
+    widest = by[f"threads_{thread_sets[-1]}"]
+    if oa_full is not None and len(thread_sets) > 1 and "chains_per_s" in widest:
+        # how the stage loop scales from the reference's default of 8 threads to the widest setting (1.0 = linear in the threads)
+        t8 = by["threads_8"]
+        widest["chain_scaling_vs_8_threads"] = (widest["chains_per_s"] / t8["chains_per_s"]) / max(widest["threads"] / 8.0, 1.0)
     # ---- the oracle's chains against the GPU's, on the full batch (stoch.rs:81-120, 195-245): the timed runs above evaluate BayesCalc on
     # the fly beyond depth 256 as the reference does (own lgamma: a near-tie can flip); for the comparison the oracle gets the device's
     # tables, so a chain has to follow the same moves and the likelihoods agree to 1e-9 relative
@@ -270,14 +272,14 @@ def cpu_baseline(args, L, params, first, aa, gts, all_ixs, greedy, anneal, G, lo
             worst = max(worst, float(np.abs(gl - olk).max() / np.abs(olk).max()))
         chains_check = {"greedy_chains": nchk, "anneal_chains": nchk, "read_pairs": solver_pairs, "max_relative_difference": worst,
                         "chains_equal_oracle": bool(worst <= 1e-9)}
-    best = by["all_cores"]
+    best = by[best_key]
     return {"value": best["value"], "unit": "read pairs/s", "cores": best["threads"], "kind": "port",
             "sample": f"load on {ns} read pairs x {A} alleles (four slices spread over the batch), scaled to {args.pairs}; run_filter "
                       + (f"measured on all {args.pairs} read pairs, all {G} genotypes, one thread as upstream; " if filter_measured else f"on {filter_pairs} read pairs ({n_good_sample} good), scaled; ")
                       + (f"solver chains on all {solver_pairs} read pairs (inputs = the batch the GPU scored); " if oa_full is not None else "")
-                      + f"whole path = load + run_filter + 5 000 greedy + 400 annealing chains at the measured rates; median of {reps} (at all cores: one run)",
+                      + f"whole path = load + run_filter + 5 000 greedy + 400 annealing chains at the measured rates; median of {reps}; the faster of the thread settings in by_threads",
             "cpu_model": cpu_model(), "physical_cores": n_phys, "cpu_count": os.cpu_count(),
-            "by_threads": by, "chains_check": chains_check,
+            "by_threads": by, "reported_setting": best_key, "chains_check": chains_check,
             "reads_scored_per_s": best["reads_scored_per_s"], "chains_per_s": best.get("chains_per_s"),
             "note": "reference-algorithm CPU restatement (oracle/), never 'locityper': the Rust reference cannot be built here"}
 

@@ -658,13 +658,14 @@ int32_t lcty_produce_result(const double* lik_mean, const double* lik_var, const
 #define LCTY_K_SCORE     0
 #define LCTY_K_PREFILTER 1
 #define LCTY_K_SOLVE     2   /* greedy_loop_kernel: the Greedy chains */
-#define LCTY_K_SOLVE_INIT  3 /* solve_init_kernel: apply_tweak + ReadAssignment::try_new of every chain, its records */
+#define LCTY_K_SOLVE_INIT  3 /* solve_init_tile_kernel / solve_init_kernel: apply_tweak + ReadAssignment::try_new of every chain of a greedy (or exact) stage, its records */
 #define LCTY_K_SOLVE_TABLE 4 /* build_loc_table_kernel: allele-major location table of a scored batch */
 #define LCTY_K_TRANSFER  5   /* transfer_kernel: alignment recovery */
 #define LCTY_K_RECRUIT   6   /* recruit_kernel: minimizer read recruitment */
 #define LCTY_K_ANNEAL    7   /* anneal_loop_kernel: the SimAnneal chains */
 #define LCTY_K_MAP       8   /* map_kernel: candidate generation on the basis alleles */
-#define LCTY_K_COUNT     9
+#define LCTY_K_SOLVE_INIT_ANNEAL 9 /* the same for the chains of an annealing stage (a few hundred: a launch of its own size, timed apart) */
+#define LCTY_K_COUNT     10
 /* Timing is opt-in: nothing is recorded before the first lcty_timing_reset on a context (a production run that never reads
  * timings creates no events); afterwards every launch is bracketed by two events, at most 256 pairs per kernel id kept. */
 int32_t lcty_timing_reset(lcty_ctx* ctx);

@@ -103,6 +103,7 @@ class Context:
 
 K_SCORE, K_PREFILTER, K_SOLVE, K_SOLVE_INIT, K_SOLVE_TABLE = 0, 1, 2, 3, 4
 K_TRANSFER, K_ANNEAL = 5, 7
+K_SOLVE_INIT_ANNEAL = 9          # the initialisation of an annealing stage's chains (K_SOLVE_INIT: a greedy or exact stage's)
 
 
 class Locus:

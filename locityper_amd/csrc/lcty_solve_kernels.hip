@@ -810,6 +810,12 @@ __device__ __forceinline__ double pair_term(const PairGather& g, int i, uint32_t
     return live ? g.weight[i] * g.vnew[i] - g.weight[i] * g.vold[i] : 0.0;
 }
 
+// An entry of the depth table by its 32-bit BYTE offset: the load then takes the table's address from scalar registers and the offset
+// from one vector register (as an index it took a 64-bit shift-and-add per gather: ~40 of the greedy iteration's vector instructions).
+// ensure_depth_table keeps the table below 4 GB.
+__device__ __forceinline__ double lut_at(const double* lut, uint32_t index) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lut) + (index << 3));
+}
 // window state of one chain: depth (25 bit) | GC bin << 25 in LDS, weights in the chain's row of c_ww (L2)
 constexpr uint32_t DEPTH_MASK = 0x1FFFFFFu;
 struct Chain {
@@ -821,7 +827,7 @@ struct Chain {
         const double weight = ww[w];
         if (weight == 0.0) return 0.0;                                      // WindowDistr::TRIVIAL
         if (d >= V->lut_depth) { atomicMax(V->overflow, 1u); return 0.0; }  // every chain of the batch is repeated
-        return weight * V->lut[g * V->lut_depth + d];
+        return weight * lut_at(V->lut, g * V->lut_depth + d);
     }
     __device__ __forceinline__ double wlp_at(uint32_t w) const { return wlp(w, wd[w] >> 25, wd[w] & DEPTH_MASK); }
     // depth_lik_diff (assgn.rs:259-284) = sum of atomic_depth_lik_diff (244-254) over the four windows, in two halves: `request`
@@ -847,8 +853,8 @@ struct Chain {
             const uint32_t d_old = word[i] & DEPTH_MASK, row = (word[i] >> 25) << V->lut_shift;
             const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
             g.weight[i] = ww[w[i]];
-            g.vnew[i] = V->lut[row + min(d_new, last)];
-            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.vnew[i] = lut_at(V->lut, row + min(d_new, last));
+            g.vold[i] = lut_at(V->lut, row + min(d_old, last));
             g.dmax[i] = max(d_new, d_old);
         }
     }
@@ -887,8 +893,8 @@ struct Chain {
             const uint32_t d_old = word[i] & DEPTH_MASK, row = (word[i] >> 25) << V->lut_shift;
             const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
             g.weight[i] = ww[w[i]];
-            g.vnew[i] = V->lut[row + min(d_new, last)];
-            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.vnew[i] = lut_at(V->lut, row + min(d_new, last));
+            g.vold[i] = lut_at(V->lut, row + min(d_old, last));
             g.dmax[i] = max(d_new, d_old);
         }
     }
@@ -912,7 +918,7 @@ struct ChainLW {
         const uint32_t d = word & LW_DEPTH_MASK;
         if (weight == 0.0) return 0.0;
         if (d >= V->lut_depth) { atomicMax(V->overflow, 1u); return 0.0; }
-        return weight * V->lut[(half & 0x7Fu) * V->lut_depth + d];
+        return weight * lut_at(V->lut, (half & 0x7Fu) * V->lut_depth + d);
     }
     __device__ __forceinline__ void request(uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, DepthGather& g) const {
         const int32_t e21 = w2 == w1, e31 = w3 == w1, e41 = w4 == w1;
@@ -930,8 +936,8 @@ struct ChainLW {
         for (int i = 0; i < 4; i++) {
             const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
             const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
-            g.vnew[i] = V->lut[row + min(d_new, last)];
-            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.vnew[i] = lut_at(V->lut, row + min(d_new, last));
+            g.vold[i] = lut_at(V->lut, row + min(d_old, last));
             g.dmax[i] = max(d_new, d_old);
         }
 #pragma unroll
@@ -968,8 +974,8 @@ struct ChainLW {
         for (int i = 0; i < 2; i++) {
             const uint32_t d_old = word[i] & LW_DEPTH_MASK, row = (half[i] & 0x7Fu) << V->lut_shift;
             const uint32_t d_new = static_cast<uint32_t>(static_cast<int32_t>(d_old) + g.c[i]);
-            g.vnew[i] = V->lut[row + min(d_new, last)];
-            g.vold[i] = V->lut[row + min(d_old, last)];
+            g.vnew[i] = lut_at(V->lut, row + min(d_new, last));
+            g.vold[i] = lut_at(V->lut, row + min(d_old, last));
             g.dmax[i] = max(d_new, d_old);
         }
 #pragma unroll
@@ -1975,6 +1981,7 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
     uint32_t depth = LCTY_DEPTH_CACHE;
     while (depth < want) depth *= 2;
     if (loc->lut_ext_depth >= depth) return;
+    if (depth > (1u << 22)) fail(LCTY_ERR_UNSUPPORTED, "a window more than 4 M read ends deep (the depth table is addressed by 32-bit byte offsets)");
     lcty_ctx* ctx = loc->ctx;
     loc->d_lut_ext.alloc(static_cast<size_t>(LCTY_GC_BINS) * depth);
     const uint32_t n = LCTY_GC_BINS * depth;
@@ -1994,7 +2001,8 @@ void launch_init_p(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_i
     if (lds_init > 48 * 1024)
         LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(solve_init_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_init)));
-    ctx->timed(LCTY_K_SOLVE_INIT, [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); }, s);
+    ctx->timed(V.solver.kind == LCTY_SOLVER_ANNEAL ? LCTY_K_SOLVE_INIT_ANNEAL : LCTY_K_SOLVE_INIT,
+               [&] { hipLaunchKernelGGL(solve_init_kernel<P>, dim3(nch), dim3(256), lds_init, s, V); }, s);
     LCTY_HIP(hipGetLastError());
 }
 
@@ -2239,7 +2247,7 @@ void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_ini
                                          static_cast<int>(plan.lds)));
         const InitGroup* d_groups = reinterpret_cast<const InitGroup*>(ws.init_plan.p);
         const InitChainP* d_chains = reinterpret_cast<const InitChainP*>(ws.init_plan.p + gb);
-        ctx->timed(LCTY_K_SOLVE_INIT, [&] {
+        ctx->timed(V.solver.kind == LCTY_SOLVER_ANNEAL ? LCTY_K_SOLVE_INIT_ANNEAL : LCTY_K_SOLVE_INIT, [&] {
             hipLaunchKernelGGL(solve_init_tile_kernel, dim3(static_cast<uint32_t>(plan.groups.size())), dim3(256), plan.lds, s, V, d_groups, d_chains,
                                reinterpret_cast<unsigned long long*>(ws.init_plan.p + gb + cb), plan.T, plan.R);
         }, s);
