@@ -32,6 +32,9 @@ from locityper_amd import _lib, api, synth, cdefs  # noqa: E402
 ALG_BYTES_FIXED = 75 + 2016
 
 
+from scripts.sources_sha import sources_sha16
+
+
 def survey_bytes_per_pair(n_alleles):
     return ALG_BYTES_FIXED + 2 * n_alleles * 16 + n_alleles * 8
 
@@ -48,6 +51,7 @@ def parse_args():
     ap.add_argument("--alleles", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=32768, help="pairs per generated/uploaded chunk")
     ap.add_argument("--knob", action="append", default=[], help="developer experiments: name=value for lcty_ctx_set_knob (repeatable)")
+    ap.add_argument("--diag", action="store_true", help="load the developer build of the library (make -C locityper_amd/csrc DIAG=1): trace and timing knobs exist there only")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="pairs given to the CPU baseline (0 = skip)")
     ap.add_argument("--ont-sample", type=int, default=6144,
                     help="reads of the extra long-read measurement (BASELINE.json configs[2] shape: 10 kb ONT reads x the locus' alleles, "
@@ -59,7 +63,7 @@ def parse_args():
                     help="how the alignment table reaches the library: 16-byte counted alignments (lcty_reads_append_counted, SURVEY 8(d)'s "
                          "alignment-table entry; the default) or BAM records with their CIGAR words (lcty_reads_append)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of every CPU-baseline figure (the median is reported)")
-    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"),
+    ap.add_argument("--traffic", default=os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"),
                     help="per-launch HBM bytes from the PMC passes (scripts/pmc_summary.py); used when it matches the workload")
     ap.add_argument("--no-solve", action="store_true", help="leave the solver stages out of the step (score + prefilter only)")
     ap.add_argument("--shard-reads", action="store_true",
@@ -471,6 +475,7 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    if args.diag: _lib.use_diag_build()
     _lib.lib()      # load the HIP library before anything else can bring another HIP runtime into scope
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -655,6 +660,7 @@ def main():
     n_solve, ms_solve = ctx.timing(api.K_SOLVE)
     n_ann, ms_ann = ctx.timing(api.K_ANNEAL)
     n_init, ms_init = ctx.timing(api.K_SOLVE_INIT)
+    n_init_a, ms_init_a = ctx.timing(api.K_SOLVE_INIT_ANNEAL)
     n_tab, ms_tab = ctx.timing(api.K_SOLVE_TABLE)
     calls_ok = None
     if queue_mode:
@@ -672,7 +678,7 @@ def main():
             step(7)
             ctx.synchronize()
             for name, kid in (("score_reads_kernel", api.K_SCORE), ("prefilter_tile_kernel", api.K_PREFILTER), ("solve_init_kernel", api.K_SOLVE_INIT),
-                              ("greedy_loop_kernel", api.K_SOLVE), ("anneal_loop_kernel", api.K_ANNEAL)):
+                              ("solve_init_kernel_annealing_stage", api.K_SOLVE_INIT_ANNEAL), ("greedy_loop_kernel", api.K_SOLVE), ("anneal_loop_kernel", api.K_ANNEAL)):
                 nk, msk = ctx.timing(kid)
                 if nk: alone_ms[name] = msk / nk
         res = None
@@ -704,15 +710,32 @@ def main():
                                "bytes": alg_bytes, "what": "SURVEY 8(d): 75 + 2*A*16 + 2016 + A*8 B per read pair"},
         "prefilter_tile_kernel": {"ms_per_step": ms_pref / kern_steps, "launch_ms": pref_ms, "bound": "valu_f64",
                                   "ops": 2.0 * G * args.pairs, "what": "2 * G * R max-add"},
+        # the two initialisations of a step apart: the greedy stage's chains (~5 000, main stream) and the annealing stage's (400, side stream)
         "solve_init_kernel": {"ms_per_step": ms_init / kern_steps, "launch_ms": ms_init / max(n_init, 1), "bound": "hbm",
-                              "bytes": (34.0 * n_good + 207e3) * chains_step / 2 if chains_step else 0.0,
-                              "what": "SURVEY 8(d): the reads CSR once per genotype x attempt, 34 B * R + 207 KB LUT, per launch (two launches per step)"},
+                              "bytes": (34.0 * n_good + 207e3) * per_step["greedy_chains"] if chains_step else 0.0,
+                              "chains_per_launch": per_step["greedy_chains"],
+                              "what": "solve_init_tile_kernel on the chains of the greedy stage; SURVEY 8(d): the reads CSR once per genotype x attempt, "
+                                      "34 B * R + 207 KB LUT per chain (the layout: 32 B written + 16 B x rows / chains read per chain and read)"},
+        "solve_init_kernel_annealing_stage": {"ms_per_step": ms_init_a / kern_steps, "launch_ms": ms_init_a / max(n_init_a, 1), "bound": "hbm",
+                              "bytes": (34.0 * n_good + 207e3) * per_step["anneal_chains"] if chains_step else 0.0,
+                              "chains_per_launch": per_step["anneal_chains"],
+                              "what": "the same kernel on the chains of the annealing stage (side stream, beside the next locus)"},
         "greedy_loop_kernel": {"ms_per_step": ms_solve / kern_steps, "launch_ms": ms_solve / max(n_solve, 1), "bound": "hbm",
                                "bytes": 32.0 * 10 * per_step["greedy_iterations"],
                                "what": "one 32 B record per candidate read, 10 candidates per iteration"},
         "anneal_loop_kernel": {"ms_per_step": ms_ann / kern_steps, "launch_ms": ms_ann / max(n_ann, 1), "bound": "hbm",
                                "bytes": 32.0 * per_step["anneal_moves"], "what": "one 32 B record per evaluated move (latency-bound serial chains)"},
     }
+    # the loop kernels are random 32-byte gathers out of the chains' 148 GB of records: what the device does of THOSE at best (a lane keeps
+    # one to four in flight, 1 250 - 10 000 wavefronts: 37.9 G gathers/s, profiles/r05_gather_probe.txt) is the ceiling their record
+    # gathers are held against; SURVEY 8(d) itself calls K14 latency-bound
+    GATHER_CEILING = 37.9e9
+    for name, gathers in (("greedy_loop_kernel", 10.0 * per_step["greedy_iterations"]), ("anneal_loop_kernel", per_step["anneal_moves"])):
+        r = roofs[name]
+        if r["launch_ms"] > 0:
+            r["record_gathers_per_s"] = gathers / (r["launch_ms"] * 1e-3)
+            r["gather_ceiling_frac"] = r["record_gathers_per_s"] / GATHER_CEILING
+            r["gather_ceiling"] = {"gathers_per_s": GATHER_CEILING, "source": "profiles/r05_gather_probe.txt (scripts/gather_probe.hip: 148 GB footprint)"}
     for k, r in roofs.items():
         if r["bound"] == "hbm":
             r["achieved"] = r["bytes"] / max(r["launch_ms"], 1e-9) / 1e6; r["peak"] = HBM_PEAK_GBS; r["unit"] = "GB/s"
@@ -771,6 +794,7 @@ def main():
                      "what": roofs[dominant]["what"]},
         "roofline_all": roofs,
         "roofline_score_layout": {"layout_bytes_per_launch": layout_bytes, "achieved_layout_GBs": layout_bytes / (score_ms * 1e-3) / 1e9 if score_ms else None},
+        "kernel_sources_sha16": sources_sha16(ROOT),
         "called_genotype": called, "true_genotype": truth, "kept_after_prefilter": kept,
         "setup_s": {"generate_and_upload": gen_s, "locus_create": locus_setup_s},
     }
@@ -789,7 +813,7 @@ def main():
         tr = json.load(open(args.traffic))
         if tr.get("read_pairs") == args.pairs and tr.get("alleles") == A:
             for name, r in roofs.items():
-                cands = [v for n, v in tr["kernels"].items() if name.replace("score_reads_kernel", "score_") in n or name in n]
+                cands = [v for n, v in tr["kernels"].items() if name.replace("score_reads_kernel", "score_") in n or name.replace("solve_init_kernel", "solve_init_tile_kernel") in n]
                 k = max(cands, key=lambda v: v.get("fetch_bytes_raw", 0.0) + v.get("write_bytes", 0.0)) if cands else None
                 if k:
                     r["traffic_fetch_raw"] = k.get("fetch_bytes_raw"); r["traffic_fetch_x2"] = 2.0 * k.get("fetch_bytes_raw", 0.0); r["traffic_write"] = k.get("write_bytes")
@@ -798,19 +822,30 @@ def main():
             for key in ("traffic", "traffic_fetch_raw", "traffic_fetch_x2", "traffic_write", "traffic_rule"):
                 out["roofline"][key] = roofs[dominant].get(key)
             out["roofline"]["traffic_source"] = os.path.relpath(args.traffic, ROOT)
+            # a counter file from other kernels than the ones timed here must show: the library's sources are hashed next to every pass
+            out["roofline"]["traffic_taken_at_commit"] = tr.get("taken_at_commit")
+            out["roofline"]["traffic_sources_sha16"] = tr.get("sources_sha16")
+            out["roofline"]["traffic_is_current"] = tr.get("sources_sha16") == out["kernel_sources_sha16"]
     except (OSError, KeyError, ValueError):
         pass
     # what the wavefronts of each kernel were doing (committed SQ counter pass, scripts/pmc_sq_summary.py): the fraction of their cycles with
     # an instruction in flight / waiting. issuing x wavefronts per SIMD near or above 1 = the kernel is bound by its instruction stream.
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq.json")))["kernels"]
-        per_simd = {"greedy_loop_kernel": 1.0, "solve_init_kernel": 5.0, "score_reads_kernel": 4.0, "anneal_loop_kernel": 0.8, "prefilter_tile_kernel": None}
+        sq_doc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_sq.json")))
+        sq = sq_doc["kernels"]
+        per_simd = {"greedy_loop_kernel": 1.0, "solve_init_kernel": 2.0, "score_reads_kernel": 4.0, "anneal_loop_kernel": 0.8, "prefilter_tile_kernel": None}
         for name, r in roofs.items():
-            cands = [v for n, v in sq.items() if name.replace("score_reads_kernel", "score_counted_lean") in n]
+            cands = [v for n, v in sq.items() if name.replace("score_reads_kernel", "score_counted_lean").replace("solve_init_kernel", "solve_init_tile_kernel") in n]
             if cands:
                 k = max(cands, key=lambda v: v.get("SQ_WAVE_CYCLES", 0.0))
                 r["sq"] = {"issuing_frac": round(k.get("active_inst_frac", 0.0), 3), "waiting_frac": round(k.get("wait_any_frac", 0.0), 3),
-                           "wavefronts_per_simd": per_simd.get(name), "source": "profiles/r04_pmc_sq.json"}
+                           "wavefronts_per_simd": per_simd.get(name), "source": "profiles/r05_pmc_sq.json",
+                           "is_current": sq_doc.get("sources_sha16") == out["kernel_sources_sha16"]}
+                # vector instructions issued per launch against what the SIMDs could issue in the launch's time (one per 4 cycles each: quarter-
+                # and half-rate instructions take longer, so a kernel is bound by its vector stream well below 1)
+                launches = max(k.get("launches", 0.0), 1.0)
+                if k.get("SQ_INSTS_VALU") and r.get("launch_ms"):
+                    r["sq"]["valu_issue_frac"] = (k["SQ_INSTS_VALU"] / launches) / (1024 * 2.4e9 / 4.0 * r["launch_ms"] * 1e-3)
         out["roofline"]["sq"] = roofs[dominant].get("sq")
     except (OSError, KeyError, ValueError):
         pass

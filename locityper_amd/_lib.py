@@ -6,7 +6,18 @@ from .cdefs import Bg, Params, ReadsHost, PairAln, Solver, Stage, Call
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocityper_hip.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "liblocityper_hip_diag.so")     # the developer build (make -C locityper_amd/csrc DIAG=1): traces, in-kernel timing
 _lib = None
+
+
+def use_diag_build():
+    """Developer probes (scripts/): load the -DLCTY_DIAG build instead of the product library; before the first call into it."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is loaded already")
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise RuntimeError("no developer build: make -C locityper_amd/csrc DIAG=1")
+    LIB_PATH = DIAG_LIB_PATH
 
 I32, U32, U64, D, VP = C.c_int32, C.c_uint32, C.c_uint64, C.c_double, C.c_void_p
 P = C.POINTER

@@ -42,7 +42,16 @@ int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value) {
     return guarded([&] {
         if (!ctx || !name) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         static const char* const known[] = {"transfer_levels", "transfer_scratch_mb", "transfer_waves", "transfer_cap_new", "transfer_arena",
-                                            "depth_table_start", "solve_budget_mb", "solve_stats", "solve_chains_per_wave", "solve_extra_start", "solve_lds_weights", "anneal_lds_weights", "queue_trace", "contig_info_slide", "gather_chunk_mb", "prefilter_gram", "prefilter_gram_cols", "prefilter_gram_levels", "comm_fail_at", "score_lean", "arena_cap_pct", "map_trace", "exact_trace", "exact_threads", "host_threads", "solve_greedy_form", "solve_anneal_timing", "score_timing", "score_lean_keep", "solve_init_tiles", nullptr};
+                                            "depth_table_start", "solve_budget_mb", "solve_chains_per_wave", "solve_extra_start", "solve_lds_weights",
+                                            "anneal_lds_weights", "contig_info_slide", "gather_chunk_mb", "prefilter_gram", "prefilter_gram_cols",
+                                            "prefilter_gram_levels", "comm_fail_at", "score_lean", "arena_cap_pct", "exact_threads", "host_threads",
+                                            "score_lean_keep",
+#ifdef LCTY_DIAG
+                                            // the developer build (make DIAG=1): traces, in-kernel timing, kernel forms under measurement
+                                            "solve_stats", "queue_trace", "map_trace", "exact_trace", "solve_greedy_form", "solve_anneal_timing", "score_timing",
+                                            "solve_init_tiles",
+#endif
+                                            nullptr};
         bool ok = false;
         for (const char* const* k = known; *k; k++) ok |= strcmp(*k, name) == 0;
         if (!ok) fail(LCTY_ERR_INVALID_INPUT, "unknown knob '%s'", name);

@@ -20,6 +20,12 @@
 
 namespace lcty {
 
+#ifdef LCTY_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
+
 // Thread-local message of the last failure (lcty_last_error()).
 void set_last_error(const std::string& msg);
 
@@ -130,9 +136,10 @@ struct StreamRef {
     hipStream_t main = nullptr;
     operator hipStream_t() const { return tl_stream ? tl_stream : main; }
 };
-struct StreamScope {                                    // binds the calling thread to a stream for the lifetime of the object
-    explicit StreamScope(hipStream_t s) { tl_stream = s; }
-    ~StreamScope() { tl_stream = nullptr; }
+struct StreamScope {                                    // binds the calling thread to a stream for the lifetime of the object (scopes nest)
+    hipStream_t before;
+    explicit StreamScope(hipStream_t s) : before(tl_stream) { tl_stream = s; }
+    ~StreamScope() { tl_stream = before; }
     StreamScope(const StreamScope&) = delete; StreamScope& operator=(const StreamScope&) = delete;
 };
 
@@ -233,5 +240,9 @@ struct lcty_ctx {
         auto it = knobs.find(name);
         return it == knobs.end() ? dflt : it->second;
     }
+    // Switches of the developer build only (make DIAG=1 -> -DLCTY_DIAG, liblocityper_hip_diag.so): traces on stderr, shader-clock stamps
+    // inside kernels, alternative kernel forms under measurement. The product library knows none of these names and carries none of
+    // their code: the branches below are dead there and the timed kernel instantiations are never referenced.
+    int64_t diag_knob(const char* name, int64_t dflt) const { return lcty::kDiag ? knob(name, dflt) : dflt; }
     void activate() const { LCTY_HIP(hipSetDevice(device)); }
 };

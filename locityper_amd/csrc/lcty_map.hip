@@ -668,7 +668,7 @@ int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, c
         if (!reads || !chunk || !params) fail(LCTY_ERR_INVALID_INPUT, "null argument");
         const uint64_t n = chunk->n_pairs;
         if (n == 0) return;
-        const bool trace = reads->ctx->knob("map_trace", 0) != 0;
+        const bool trace = reads->ctx->diag_knob("map_trace", 0) != 0;
         const auto t_in = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
         // the device buffers of the mapping (arenas of CIGAR words and chains, scratch of the kernels: tens of GB for long reads on many
@@ -690,7 +690,7 @@ int32_t lcty_reads_map_append(lcty_reads* reads, const lcty_reads_host* chunk, c
         DeviceRecords dev{X.d_recs.p, X.d_cigar.p, X.d_ob2.p, X.d_onm.p, X.nrec.data(), X.max_rec_cigar};
         const auto t0 = std::chrono::steady_clock::now();
         const int32_t rc = reads_append_device(reads, &h, &dev);
-        if (reads->ctx->knob("map_trace", 0))
+        if (reads->ctx->diag_knob("map_trace", 0))
             fprintf(stderr, "[lcty map] append of the mapped chunk: %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (rc != LCTY_OK) fail(rc, "%s", lcty_last_error());
     });

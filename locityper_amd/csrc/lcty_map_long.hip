@@ -743,7 +743,7 @@ void run_map_long(lcty_locus* locus, const lcty_reads_host* chunk, const lcty_ma
     const uint64_t n = chunk->n_pairs, n_mates = 2 * n;
     const uint64_t nb = chunk->mate_off[n_mates];
     // lcty_ctx_set_knob "map_trace" 1: wall-clock marks of the phases of a call on stderr
-    const bool trace = ctx->knob("map_trace", 0) != 0;
+    const bool trace = ctx->diag_knob("map_trace", 0) != 0;
     const auto t_begin = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
         if (trace) fprintf(stderr, "[lcty map] %8.3f ms %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), what);

@@ -1276,8 +1276,10 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
 
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const LocusView L, const ReadsView R) { score_lean_body<false, false>(L, R); }
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_keep_kernel(const LocusView L, const ReadsView R) { score_lean_body<false, true>(L, R); }
+#ifdef LCTY_DIAG     // the developer build: the same kernels with shader-clock stamps between their phases (knob "score_timing")
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_timed_kernel(const LocusView L, const ReadsView R) { score_lean_body<true, false>(L, R); }
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_keep_timed_kernel(const LocusView L, const ReadsView R) { score_lean_body<true, true>(L, R); }
+#endif
 
 __global__ __launch_bounds__(WAVE, 3) void score_reads_kernel(const LocusView L, const ReadsView R, const uint32_t max_recs) {
     score_reads_body<false, false>(L, R, max_recs);
@@ -1379,9 +1381,13 @@ void launch_score_reads(lcty_reads* reads) {
             // sixteen wavefronts per CU either way: with the saved alignments' products kept in LDS (33 B per allele) while that many fit
             const bool keep = static_cast<size_t>(L.n_alleles) * 33 + 16 <= lds_max / 16 && ctx->knob("score_lean_keep", 1) != 0;
             const size_t lean_lds = (static_cast<size_t>(L.n_alleles) * (keep ? 33 : 9) + 15) & ~static_cast<size_t>(15);
-            const bool timing = ctx->knob("score_timing", 0) != 0;
-            auto lean_kernel = timing ? (keep ? score_counted_lean_keep_timed_kernel : score_counted_lean_timed_kernel)
-                                      : (keep ? score_counted_lean_keep_kernel : score_counted_lean_kernel);
+            auto lean_kernel = keep ? score_counted_lean_keep_kernel : score_counted_lean_kernel;
+#ifdef LCTY_DIAG
+            const bool timing = ctx->diag_knob("score_timing", 0) != 0;
+            if (timing) lean_kernel = keep ? score_counted_lean_keep_timed_kernel : score_counted_lean_timed_kernel;
+#else
+            constexpr bool timing = false;
+#endif
             if (lean_lds > 48 * 1024)
                 LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lean_lds)));

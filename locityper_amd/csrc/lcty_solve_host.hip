@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <exception>
 #include <memory>
 #include <numeric>
 #include <thread>
@@ -187,7 +188,7 @@ struct StageRunner {
         ws.ovf.ensure(2); ws.ovf.zero(s);
         if (ws.recs.n < max_chains * ngp || ws.extra.n < max_chains * ws.extra_cap + 2) {
             // both at once, the old ones released first: the two together are most of the device
-            if (ctx->knob("queue_trace", 0))
+            if (ctx->diag_knob("queue_trace", 0))
                 fprintf(stderr, "[lcty queue] lane %u workspace: %llu chains x %llu places (had %.1f GB of records, %.1f GB of runs; free %.1f GB, budget %.1f GB, %u further locations per chain)\n",
                         lane, static_cast<unsigned long long>(max_chains), static_cast<unsigned long long>(ngp), ws.recs.n * 32e-9, ws.extra.n * 16e-9,
                         free_b * 1e-9, budget * 1e-9, ws.extra_cap);
@@ -216,7 +217,7 @@ struct StageRunner {
         if (V.solver.kind == LCTY_SOLVER_EXACT) { solve_exact_batch(nch); return; }
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
             if (lane == 1) wait_for_greedy_of_next_locus();
-            const bool timed_anneal = ctx->knob("solve_anneal_timing", 0) != 0;
+            const bool timed_anneal = ctx->diag_knob("solve_anneal_timing", 0) != 0;
             V.dbg = nullptr;
             if (timed_anneal) { ws.dbg.ensure(12 * static_cast<size_t>(nch)); ws.dbg.zero(stream); V.dbg = ws.dbg.p; }
             launch_anneal(ctx, V, nch, stream);
@@ -231,12 +232,12 @@ struct StageRunner {
                                           "moves from the ring %.0f, depths + gathers + score %.0f, ballots + chain walk %.0f, apply + retire %.0f; loop total per round %.0f\n",
                                   used, sum[6] / used, sum[7] / std::max(sum[6], 1.0), sum[8] / used, sum[9] / used, sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used, sum[4] / used, sum[5] / used);
             }
-            if (ctx->knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p annealing launched (lane %u)\n",
+            if (ctx->diag_knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p annealing launched (lane %u)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), static_cast<const void*>(reads), lane);
             return;
         }
         if (lane == 0) announce_greedy();
-        if (ctx->knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p greedy about to launch (lane %u)\n",
+        if (ctx->diag_knob("queue_trace", 0)) fprintf(stderr, "[lcty queue] %.3f ms batch %p greedy about to launch (lane %u)\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), static_cast<const void*>(reads), lane);
         launch_greedy_chains(ctx, V, nch, stream, ws);
     }
@@ -295,8 +296,11 @@ struct StageRunner {
         const size_t model_bytes = static_cast<size_t>(V.rstride) * sizeof(ChainRec) + static_cast<size_t>(V.extra_cap) * sizeof(ExtraLoc) + static_cast<size_t>(W) * 13 + 4096;
         const size_t group = std::max<size_t>(1, std::min<size_t>(todo.size(), (2ull << 30) / model_bytes));
         const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-        const uint32_t n_threads = static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(ctx->knob("exact_threads", std::min(hw, 64u)), 256)));
-        const int trace = static_cast<int>(ctx->knob("exact_trace", 0));
+        // the pool: `exact_threads`, by default what `host_threads` gives this context (bench.py --gpus N: cores / N per rank), at most 64; the head
+        // lane and the tail thread of a queue each have their pool, so two exact stages at once share the host's cores
+        const int64_t host_share = ctx->knob("host_threads", 0) > 0 ? ctx->knob("host_threads", 0) : static_cast<int64_t>(hw);
+        const uint32_t n_threads = static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(ctx->knob("exact_threads", std::min<int64_t>(host_share, 64)), 256)));
+        const int trace = static_cast<int>(ctx->diag_knob("exact_trace", 0));
         std::vector<double> lut;
         struct Held { std::vector<ChainRec> recs; std::vector<uint32_t> place; exact::Model model; exact::Result res; };
         for (size_t g0 = 0; g0 < todo.size(); g0 += group) {
@@ -356,7 +360,19 @@ struct StageRunner {
             const uint32_t ld = loc->lut_ext_depth;
             // the pool: a worker takes the next model of the group (the largest first would balance better; the models of a stage are alike)
             std::atomic<size_t> next{0};
-            auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < gn;) exact::solve(held[k].model, lut.data(), ld, held[k].res); };
+            // an exception on a worker (std::bad_alloc on a large model) must not reach std::terminate: the first one is kept, the workers
+            // stop taking models, and it is thrown again on the calling thread once they have joined
+            std::exception_ptr failed;
+            std::mutex failed_mutex;
+            auto work = [&] {
+                try {
+                    for (size_t k; (k = next.fetch_add(1)) < gn;) exact::solve(held[k].model, lut.data(), ld, held[k].res);
+                } catch (...) {
+                    std::lock_guard<std::mutex> g(failed_mutex);
+                    if (!failed) failed = std::current_exception();
+                    next.store(gn);
+                }
+            };
             const uint32_t nt = static_cast<uint32_t>(std::min<size_t>(n_threads, gn));
             if (nt <= 1) work();
             else {
@@ -364,6 +380,7 @@ struct StageRunner {
                 for (uint32_t t = 0; t < nt; t++) pool.emplace_back(work);
                 for (auto& th : pool) th.join();
             }
+            if (failed) std::rethrow_exception(failed);
             for (size_t k = 0; k < gn; k++) {
                 const Held& h = held[k];
                 if (h.res.out_of_nodes)
@@ -427,7 +444,7 @@ struct StageRunner {
                     }
                     reads->stat_chains += nch; reads->stat_iterations += static_cast<uint64_t>(sum);
                     reads->stat_accepted += static_cast<uint64_t>(acc);
-                    if (ctx->knob("solve_stats", 0))
+                    if (ctx->diag_knob("solve_stats", 0))
                         fprintf(stderr, "[lcty solve] chains=%llu iterations mean=%.0f min=%.0f max=%.0f accepted mean=%.0f lut_depth=%u\n",
                                 static_cast<unsigned long long>(nch), sum / nch, mn, mx, acc / nch, loc->lut_ext_depth);
                     break;
@@ -836,7 +853,7 @@ struct LocusRun {
     static void ok(int32_t rc) { if (rc != LCTY_OK) throw Error(rc, std::string(lcty_last_error())); }
     // lcty_ctx_set_knob "queue_trace" 1: wall-clock marks of the phases of a locus on stderr (where does a step of the queue go?)
     void mark(const char* what) const {
-        if (!reads || reads->ctx->knob("queue_trace", 0) == 0) return;
+        if (!reads || reads->ctx->diag_knob("queue_trace", 0) == 0) return;
         const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         fprintf(stderr, "[lcty queue] %.3f ms batch %p %s\n", t, static_cast<const void*>(reads), what);
     }

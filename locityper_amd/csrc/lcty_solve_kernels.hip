@@ -693,7 +693,9 @@ __global__ __launch_bounds__(256) void solve_init_tile_kernel(const SolveView V,
             const uint32_t slot = before + static_cast<uint32_t>(__popcll(nt_mask & ((1ull << lane) - 1ull)));
             {
                 const uint32_t after = __builtin_amdgcn_readfirstlane(before + static_cast<uint32_t>(__popcll(nt_mask)));
-                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(n_recs_all) : "s"(after), "s"(c) : "m0");   // (one scalar register per VOP3 on gfx9: the lane number goes through m0)
+                uint32_t m0_was;                                                   // (one scalar register per VOP3 on gfx9: the lane number goes through m0, which is put back)
+                asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                             : "+v"(n_recs_all), "=&s"(m0_was) : "s"(after), "s"(c));
             }
             const unsigned long long mm = __ballot(multi);
             if (mm) {
@@ -1387,7 +1389,9 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 depth_mine += ddiff;
                 aln_mine += lp_new - cur_lp;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // release AND acquire: the record loads of the coming iterations (request_record, plain 16-byte loads of other lanes) must not be
+            // moved above this store of the current-location word — the three-move history covers the loads issued BEFORE it only
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint32_t moved_slot = static_cast<uint32_t>(__shfl(static_cast<int>(pick), static_cast<int>(row_base + src)));
             const uint32_t moved_to = static_cast<uint32_t>(__shfl(static_cast<int>(new_assgn), static_cast<int>(row_base + src)));
@@ -1589,8 +1593,9 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
             store_rp_cur(&recs[m.slot], m.rp | (m.new_assgn << 24));
         }
         // one wavefront owns the chain: LDS and vector-memory operations of a wavefront execute in program order, so the
-        // following reads see these updates without waiting for the store to complete (no s_waitcnt vmcnt(0) here)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // following reads see these updates without waiting for the store to complete (no s_waitcnt vmcnt(0) here); acquire as well:
+        // no later load of a record (pf_issue, load_body) may be moved above the store
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -1840,7 +1845,7 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                     atomicSub(&wd[m.w1], 1u); atomicSub(&wd[m.w2], 1u);
                     store_rp_cur(&recs[m.slot], m.rp | (m.new_assgn << 24));
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             } else {
                 while (q < w) {                                               // the last steps of a chain: one move at a time
@@ -2024,13 +2029,16 @@ void launch_greedy_form(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStre
 }
 template <uint32_t LPC, bool LW>
 void launch_greedy(lcty_ctx* ctx, const SolveView& V, uint32_t nch, hipStream_t s) {
+#ifdef LCTY_DIAG
     if constexpr (LPC == 12 && LW) {
-        // the forms under measurement exist for the stage shape of the default scheme only
-        switch (ctx->knob("solve_greedy_form", 0)) {
+        // the developer build: the loop with shader-clock stamps between its phases (knob "solve_greedy_form" 32), for the stage shape of
+        // the default scheme only
+        switch (ctx->diag_knob("solve_greedy_form", 0)) {
             case 32: return launch_greedy_form<LPC, LW, 32>(ctx, V, nch, s);
             default: break;
         }
     }
+#endif
     launch_greedy_form<LPC, LW, 0>(ctx, V, nch, s);
 }
 
@@ -2083,7 +2091,7 @@ void launch_greedy_chains(lcty_ctx* ctx, SolveView& V, uint32_t nch, hipStream_t
         constexpr uint32_t L = decltype(tag)::value;
         if (lw) launch_greedy<L, true>(ctx, V, nch, stream); else launch_greedy<L, false>(ctx, V, nch, stream);
     };
-    const bool timed_form = lpc == 12 && lw && (ctx->knob("solve_greedy_form", 0) & 32) != 0;
+    const bool timed_form = lpc == 12 && lw && (ctx->diag_knob("solve_greedy_form", 0) & 32) != 0;
     const size_t n_waves = (static_cast<size_t>(nch) + 4) / 5 + 2;
     V.dbg = nullptr;
     if (timed_form) { ws.dbg.ensure(12 * n_waves); ws.dbg.zero(stream); V.dbg = ws.dbg.p; }
@@ -2227,10 +2235,10 @@ void plan_init_groups(const SolveView& V, const InitHost& H, uint32_t nch, InitP
 
 void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s, const InitHost* host, lcty_ctx::SolveWorkspace& ws,
                  InitPlan& plan) {
-    if (V.ploidy == 2 && host && nch && ctx->knob("solve_init_tiles", 1) != 0) {
+    if (V.ploidy == 2 && host && nch && ctx->diag_knob("solve_init_tiles", 1) != 0) {
         plan_init_groups(V, *host, nch, plan);
         const size_t gb = plan.groups.size() * sizeof(InitGroup), cb = plan.chains.size() * sizeof(InitChainP);
-        if (ctx->knob("solve_stats", 0)) {
+        if (ctx->diag_knob("solve_stats", 0)) {
             uint64_t rows = 0; uint32_t hist[INIT_TILE_T + 1] = {0};
             for (const InitGroup& g : plan.groups) { rows += g.n_rows; hist[g.n_chains]++; }
             fprintf(stderr, "[lcty solve] initialisation: %u chains in %zu groups (largest %u chains, %u rows; %.2f rows per chain; LDS %zu B); groups of 1..%u chains:",

@@ -831,7 +831,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         // set, nothing walked (a few KB of scratch per wavefront). A batch whose mapper has already reached every allele — candidate
         // generation on the device, lcty_map_long.hip — has nothing to recover, and a call that sized its lane scratch and arenas for
         // "every record onto every other contig" paid seconds of allocation for it (1.5 s at 2 048 10-kb reads x 256 alleles). The
-        // walk then takes the pairs that have something to do, with arenas for at most what this pass counted.
+        // walk then takes the pairs that have something to do, with arenas for about what this pass counted.
         DevBuf<uint64_t> d_list_0;
         uint64_t n_first = 0, would = 0;
         {
@@ -863,6 +863,16 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             if (flag > 1) fail(static_cast<int32_t>(flag), "alignment recovery failed on the device");
             would = cursors[0]; n_first = cursors[2];
             reads->recover_level_pairs[0] = reads->recover_level_pairs[1] = reads->recover_level_pairs[2] = 0;
+            // flag 1: a pair's alignments or positions did not fit the small scratch of this pass, so the pass may have left pairs off its
+            // list: the walk then takes every pair, with the arenas sized as before the pass existed
+            const bool look_incomplete = flag == 1;
+            if (look_incomplete) {
+                std::vector<uint64_t> all(R);
+                for (uint64_t i = 0; i < R; i++) all[i] = i;
+                d_list_0.upload(all.data(), R, s);
+                LCTY_HIP(hipStreamSynchronize(s));
+                n_first = R; would = arena_recs;
+            }
             if (n_first == 0) { reads->recover_dp_cells = 0; return; }                 // every target of every alignment is there already
             // the pairs in batch order again (the pass appended them as its wavefronts got to them): the walk's arenas then fill in the
             // order they always did
@@ -871,6 +881,8 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             LCTY_HIP(hipStreamSynchronize(s));
             std::sort(lst.begin(), lst.end());
             d_list_0.upload(lst.data(), n_first, s);
+            // `would` is an estimate, not a bound: the walk stops a source at transfer_fails failures, marks fewer targets as seen than this
+            // pass did and can then try sources this pass skipped. An arena that turns out too small is what the retry loop below is for.
             arena_recs = std::min<uint64_t>(arena_recs, would + 1024);
             arena_words = std::min<uint64_t>(arena_words, arena_recs * std::max<uint32_t>(4, rec_cigar + 8));
         }

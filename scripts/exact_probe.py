@@ -3,7 +3,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from locityper_amd import _lib, api, synth, cdefs
+from locityper_amd import _lib
+_lib.use_diag_build()                                        # exact_trace is a knob of the developer build (make -C locityper_amd/csrc DIAG=1)
+from locityper_amd import api, synth, cdefs
 
 
 def main():
@@ -16,7 +18,7 @@ def main():
         os.makedirs("gpurun_out", exist_ok=True)
     sizes = [int(a) for a in sys.argv[1:]] or [100, 300, 1000, 3000, 10000]
     ctx = api.Context(0)
-    ctx.set_knob("exact_trace", 1)
+    ctx.set_knob("exact_trace", 1)                            # (the developer build: _lib.use_diag_build() above)
     if dump: ctx.set_path("exact_dump", "gpurun_out/exact_model.txt")
     for n in sizes:
         L = synth.SynthLocus(8, n, seed=synth.SEED + 3)

@@ -2,7 +2,10 @@
 usage: python3 scripts/map_long_probe.py [--reads N] [--alleles A] [--basis B] [--read-len L] [--stride S] [--reps R]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, ".")
-if "--lib" in sys.argv:                                  # a library built by scripts/build_experiment.sh
+if "--trace" in sys.argv:                                # the mapper's trace exists in the developer build only (make DIAG=1)
+    from locityper_amd import _lib
+    _lib.use_diag_build()
+if "--lib" in sys.argv:                                  # a library built by hand
     from locityper_amd import _lib
     _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1]); del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
 import numpy as np

@@ -15,6 +15,7 @@ loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
 H = L.hap_alns()
 loc.set_hap_alns(H, transfer_fails=100, max_div=0.1)
 mp = api.map_params(long_reads=True)
+if os.environ.get('LCTY_WFA_SCORES'): mp.match, mp.mismatch, mp.gap_open, mp.gap_extend = 2, 6, 13, 1
 fq = synth.sequencer_orientation(L.reads(0, n, primaries_only=True))
 rb = int(fq.mate_len.sum())
 

@@ -32,6 +32,23 @@ def per_kernel(path, counter):
     return out
 
 
+def stamp(doc, counter_file):
+    """Which sources the pass saw (sources.sha16 that scripts/gpu_round.sh left in the pass's directory tree) and the commit this summary is
+    made at (the pass is run on a snapshot of the committed tree)."""
+    import os, subprocess
+    d = os.path.dirname(os.path.abspath(counter_file))
+    for _ in range(6):
+        f = os.path.join(d, "sources.sha16")
+        if os.path.exists(f):
+            doc["sources_sha16"] = open(f).read().strip()
+            break
+        d = os.path.dirname(d)
+    try:
+        doc["taken_at_commit"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:
+        pass
+
+
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
@@ -47,6 +64,7 @@ def main():
         wb = 1024.0 * w / max(nw, 1)
         out["kernels"][k] = {"launches": max(nf, nw), "fetch_bytes_raw": fb, "fetch_bytes_corrected": 2.0 * fb, "write_bytes": wb,
                              "hbm_bytes": 2.0 * fb + wb}
+    stamp(out, sys.argv[1])
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out["kernels"].items():
         print(f"{k:45s} x{v['launches']:<3d} fetch {v['fetch_bytes_corrected'] / 1e9:9.3f} GB (raw {v['fetch_bytes_raw'] / 1e9:8.3f})  "

@@ -1,5 +1,5 @@
 """Developer measurement: the solver stages of BASELINE configs[1] (1 M read pairs x 256 alleles) ALONE, once per knob setting:
-   python3 scripts/solve_probe.py [--chains 5000] [--short] [--base-len 50000] name=value[,name=value...] ...
+   python3 scripts/solve_probe.py [--diag] [--chains 5000] [--short] [--base-len 50000] name=value[,name=value...] ...
 For every setting: solve_init_kernel and greedy_loop_kernel times of the default greedy stage (5 000 chains, 100 000 iterations;
 --short: plateau 1, the stage is its initialisation) and whether the per-chain likelihoods equal those of the first setting bit for bit."""
 import os, sys, time
@@ -22,6 +22,9 @@ def main():
         elif args[i] == "--lib":
             from locityper_amd import _lib
             _lib.LIB_PATH = os.path.abspath(args[i + 1]); i += 2          # a variant library built by hand (hipcc over a patched copy of a source)
+        elif args[i] == "--diag":                                 # the developer build: knobs such as solve_stats, solve_greedy_form, solve_init_tiles exist there only
+            from locityper_amd import _lib
+            _lib.use_diag_build(); i += 1
         elif args[i] == "--short": short = True; i += 1
         elif args[i] == "--base-len": base_len = int(args[i + 1]); i += 2
         elif args[i] == "--sort-genotypes": sort_gts = True; i += 1      # the stage's genotypes in lexicographic order instead of by prefilter score
