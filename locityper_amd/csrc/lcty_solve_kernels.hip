@@ -1721,43 +1721,37 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
         const double start_temp = fmax(-max_abs / log(V.solver.init_prob), 1e-5);
         const double temp_step = start_temp / static_cast<double>(V.solver.anneal_steps);
         uint32_t curr_plato = 0;
-        for (uint32_t i = V.solver.anneal_steps; i >= 1 && !lost; i--) {
-            if (!ring_wait(3)) break;
-            n_iter++;
-            Move m; blank(m);
-            if (pf_covered() < 1) pf_issue();                                  // the first step (or a ring that ran dry): wait for the words
-            uint32_t c = move_pre(0, pf_take(0), m);
-            {
-                typename ChainT::DepthGather g;
-                C.request(m.w1, m.w2, m.w3, m.w4, g);
-                pf_issue();                                                     // the words of the next step travel with this step's gathers
-                m.ddiff = C.finish(g);
-            }
-            const double diff = improvement(m) - min_diff;
-            bool accept = diff >= 0.0;
-            if (!accept) { accept = ring_f64(c) <= exp(diff / (temp_step * static_cast<double>(i))); c++; }
-            if (accept) { reassign(m); curr_plato = 0; lm_slot[0] = m.slot; lm_to[0] = m.new_assgn; }
-            else { curr_plato++; }
-            retire(c);
-            if (!accept && curr_plato >= V.solver.plato_size) break;
-        }
-        // Second loop of stoch.rs:228-241: a move changes the state only when it is accepted, so the moves that
-        // follow a rejection see the same state. Lane q evaluates the move that starts at draw q of the random
-        // stream (a move takes one draw, two when the read has more than two locations); the lanes that lie on
-        // the true chain of moves are then walked in order up to the first accepted one, which is applied, and
-        // the stream continues right behind it. Same moves, same order, same result as the serial loop.
+        // Both loops of stoch.rs:214-241 as ROUNDS over the staged positions of the random stream. A move changes the state only when it
+        // is accepted, so the moves that follow a rejection see the same state: lane q evaluates the move that starts at draw q of the
+        // stream, the lanes that lie on the true chain of moves are walked in order, and every accepted move is applied up to the first
+        // position that meets an earlier accepted move of the round (it starts the next round, evaluated afresh). Same moves, same order,
+        // same sums as the serial loops.
+        //   second loop (228-241): a move takes one draw, two when its read has more than two locations; accepted iff improvement > min_diff.
+        //   first loop (214-226, round 5): the Metropolis test takes one more draw when the move does not pay (diff < 0), so where the
+        //     chain goes on depends on the evaluations — known for every position once the lanes have evaluated theirs: a scalar walk over
+        //     three ballots; a position's step number i (its temperature) is `steps_left` minus the positions on the chain before it.
+        uint32_t steps_left = V.solver.anneal_steps;                       // first loop: the step about to be taken (i of stoch.rs:214)
+        bool phase1 = true;
         uint64_t iter = 0;
         uint32_t width = 16;                                               // lanes that speculate: about twice the recent run length
-        // (diagnostic, lcty_ctx_set_knob "solve_anneal_timing": SolveView::dbg set) shader-clock ticks of the phases of a round, rounds, moves
+        // (developer build, knob "solve_anneal_timing": SolveView::dbg set) shader-clock ticks of the phases of a round, rounds, moves
         const bool timed = V.dbg != nullptr;
         uint64_t tph[5] = {0, 0, 0, 0, 0}, n_rounds = 0, n_walked = 0, t_first = timed ? __builtin_amdgcn_s_memtime() : 0;
         auto stamp = [&]() -> uint64_t { return timed ? __builtin_amdgcn_s_memtime() : 0ull; };
-        while (!lost && iter < max_iter && curr_plato < V.solver.plato_size) {
+        while (!lost) {
+            if (phase1 && steps_left == 0) phase1 = false;
+            if (!phase1 && !(iter < max_iter && curr_plato < V.solver.plato_size)) break;
             const uint64_t ta = stamp();
-            const uint32_t avail = ring_wait(2);                           // a move may take the draw after its own
+            const uint32_t need = phase1 ? 3u : 2u;                        // a move may take the draw after its own, the Metropolis test one more
+            const uint32_t avail = ring_wait(need);
             if (!avail) break;
             if (pf_covered() < 2) pf_issue();
-            const uint32_t w = min(min(width, avail - 1), pf_covered());       // only positions whose `cur` words are here
+            // a round may take several moves when neither the loop's count nor the plateau can end inside it (it walks at most 63 positions)
+            const bool many_ok = V.solver.plato_size > 64u && curr_plato + 64u < V.solver.plato_size &&
+                                 (phase1 ? steps_left > 64u : iter + 64u <= max_iter);
+            uint32_t w = min(min(width, avail - (need - 1u)), pf_covered());   // only positions whose `cur` words are here
+            if (phase1 && !many_ok) w = min(w, 1u);                         // the schedule's last steps: one position a round
+            const bool many = phase1 || many_ok;
             Move m; blank(m);
             bool accepted = false, wide = false;
             const uint64_t tb = stamp();
@@ -1771,33 +1765,46 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 pf_issue();                                                     // the words of the next round travel with this round's gathers
                 m.ddiff = C.finish(g);
             }
-            accepted = lane < w && improvement(m) > min_diff;
+            const double impr = improvement(m);
+            const double diff = impr - min_diff;                               // first loop (stoch.rs:216)
+            const bool needu = phase1 && lane < w && !(diff >= 0.0);            // the Metropolis draw is taken (217: `||` evaluates its right side)
+            if (!phase1) accepted = lane < w && impr > min_diff;
             if (timed) asm volatile("" :: "v"(m.ddiff));
             const uint64_t td = stamp();
-            const unsigned long long acc = __ballot(accepted);
             const unsigned long long two = __ballot(wide);
+            const unsigned long long nu = __ballot(needu);
             uint32_t q = 0, walked = 0;
             int hit = -1;
-            // Which lanes lie on the true chain of moves: position 0 does; position p > 0 does unless p - 1 does and its move takes two
-            // draws. Behind the nearest position r < p whose move takes one draw (or the start) the chain alternates, so p is on it
-            // iff p - (r + 1) is even: one count-leading-zeros per lane instead of a serial walk over the draws.
             const unsigned long long below = lane ? ((1ull << lane) - 1ull) : 0ull;
-            const unsigned long long ones = ~two & below;
-            const uint32_t after = ones ? 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(ones))) : 0u;      // r + 1
-            const unsigned long long chain_mask = __ballot(lane < w && ((lane - after) & 1u) == 0u);
+            unsigned long long chain_mask;
+            if (phase1) {
+                // position p on the chain is followed by p + 1 + (two draws for the move) + (the Metropolis draw)
+                const unsigned long long two_u = uniform64(two), nu_u = uniform64(nu);
+                const uint32_t w_u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));
+                unsigned long long cm = 0ull;
+                for (uint32_t pos = 0; pos < w_u; pos += 1u + static_cast<uint32_t>((two_u >> pos) & 1ull) + static_cast<uint32_t>((nu_u >> pos) & 1ull)) cm |= 1ull << pos;
+                chain_mask = cm;
+                const bool on = ((chain_mask >> lane) & 1ull) != 0ull;
+                accepted = on && !needu;
+                if (on && needu) {
+                    const uint32_t i_q = steps_left - static_cast<uint32_t>(__popcll(chain_mask & below));       // >= 1: steps_left > 64 or w == 1
+                    accepted = ring_f64(lane + (wide ? 2u : 1u)) <= exp(diff / (temp_step * static_cast<double>(i_q)));
+                }
+            } else {
+                // position 0 is on the chain; position p > 0 is unless p - 1 is and its move takes two draws. Behind the nearest position
+                // r < p whose move takes one draw (or the start) the chain alternates, so p is on it iff p - (r + 1) is even: one
+                // count-leading-zeros per lane instead of a serial walk over the draws.
+                const unsigned long long ones = ~two & below;
+                const uint32_t after = ones ? 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(ones))) : 0u;      // r + 1
+                chain_mask = __ballot(lane < w && ((lane - after) & 1u) == 0u);
+            }
+            const unsigned long long acc = __ballot(accepted);
             const unsigned long long hits = acc & chain_mask;
-            // SEVERAL ACCEPTED MOVES PER ROUND (round 4). One move in eight is accepted (configs[1]: 126 665 of 1.02 M), so a round that stops at its
-            // first accepted move walks eight positions of the sixty it has evaluated. But a move that follows an accepted one sees another
-            // state only where the two meet: its evaluation — the depths of its four windows, the current location of its read — is the one
-            // the serial loop would make as long as none of its windows and not its read belong to a move accepted before it in this round.
-            // So the walk goes on behind an accepted move, up to the first position that meets an earlier accepted move (it starts the next
-            // round, evaluated afresh), and every accepted move on the way is applied: same moves, same order, same sums as the serial loop.
-            bool many = false;
+            // SEVERAL ACCEPTED MOVES PER ROUND. A move that follows an accepted one sees another state only where the two meet: its
+            // evaluation — the depths of its four windows, the current location of its read — is the one the serial loop would make as
+            // long as none of its windows and not its read belong to a move accepted before it in this round.
             unsigned long long applied = 0ull;
-            if (V.solver.plato_size > 64u && iter + 64u <= max_iter && curr_plato + 64u < V.solver.plato_size) {
-                // neither cap can be reached inside this round (it walks at most 63 positions; a run of rejections inside it is shorter
-                // than plato_size): the accepted moves are taken one after the other, each with its sums in the order of the moves
-                many = true;
+            if (many) {
                 // (everything that steers this loop is the same in all lanes and told to the compiler as such: left as lane values it
                 // becomes a divergent loop of nested branches — 3 700 clock ticks a round instead of a few hundred)
                 unsigned long long rest = uniform64(hits);
@@ -1833,13 +1840,14 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 const unsigned long long upto = stop_excl >= 64u ? ~0ull : ((1ull << stop_excl) - 1ull);
                 const unsigned long long P = chain_mask & upto;                // the positions the serial loop walks on this state
                 const uint32_t moves = static_cast<uint32_t>(__popcll(P));
-                iter += moves; n_iter += moves; walked = moves;
+                n_iter += moves; walked = moves;
+                if (phase1) steps_left -= moves; else iter += moves;
                 if (applied) {
                     const uint32_t last_a = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(applied)));
                     curr_plato = static_cast<uint32_t>(__popcll(P & ~((2ull << last_a) - 1ull)));
                 } else curr_plato += moves;
                 const uint32_t lastp = 63u - static_cast<uint32_t>(__clzll(static_cast<long long>(P)));
-                q = lastp + 1u + static_cast<uint32_t>((two >> lastp) & 1ull);
+                q = lastp + 1u + static_cast<uint32_t>((two >> lastp) & 1ull) + static_cast<uint32_t>((nu >> lastp) & 1ull);
                 if ((applied >> lane) & 1ull) {
                     atomicAdd(&wd[m.w3], 1u); atomicAdd(&wd[m.w4], 1u);        // the depth field never borrows from the GC bits
                     atomicSub(&wd[m.w1], 1u); atomicSub(&wd[m.w2], 1u);
@@ -1847,6 +1855,8 @@ __global__ __launch_bounds__(128, 4) void anneal_loop_kernel(const SolveView V) 
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                // stoch.rs:222-224: the schedule ends at a rejection that fills the plateau (only a round of one position can get here)
+                if (phase1 && curr_plato >= V.solver.plato_size) phase1 = false;
             } else {
                 while (q < w) {                                               // the last steps of a chain: one move at a time
                     if (iter >= max_iter || curr_plato >= V.solver.plato_size) break;
