@@ -146,6 +146,8 @@ struct lcty_reads {
     lcty::DevBuf<uint32_t> d_err;
     lcty::DevBuf<uint32_t> d_defer_list;     // pairs the lean scoring kernel leaves to the general one (lcty_score.hip), grow-only
     lcty::DevBuf<unsigned int> d_defer_count;
+    lcty::DevBuf<uint32_t> d_defer_list2;    // pairs the two-slot form of the lean kernel leaves to the general one
+    lcty::DevBuf<unsigned int> d_defer_count2;
     lcty::DevBuf<unsigned long long> d_score_dbg;            // lcty_ctx_set_knob "score_timing"
     lcty::DevBuf<double> d_recover_w;        // per pair: read weight when the pair reaches recover_and_group_alignments, else -1
 

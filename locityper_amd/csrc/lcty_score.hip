@@ -331,6 +331,8 @@ __device__ __forceinline__ AlnRef load_aln(const Rec16* rec, uint32_t idx, doubl
     return AlnRef{r.ln_prob - best_lik, r.start, r.end_rev & ~REV_BIT, idx, (r.end_rev & REV_BIT) != 0};   // normalize_probs, locs.rs:358-360
 }
 
+template <typename C, typename F> __device__ inline void enumerate_pairs(const C& c, F&& f);
+
 struct PairCtx {
     InsLut ins;
     const Rec16* rec;
@@ -350,38 +352,58 @@ struct PairCtx {
     }
     // f(prob, order, aln1 | idx NONE32, aln2 | idx NONE32) for every PairAlignment pushed, in push order
     template <typename F>
-    __device__ inline void enumerate(F&& f) const {
-        const AlnRef none{0.0, 0, 0, NONE32, false};
-        if (!paired) {
-            for (uint32_t i = 0; i < k1; i++) { const AlnRef a = get1(i); f(a.lp, i, a, none); }
-            return;
-        }
-        for (uint32_t i = 0; i < k1; i++) {
-            const AlnRef a1 = get1(i);
-            double m1 = -INFINITY;
-            for (uint32_t j = 0; j < k2; j++) {
-                const AlnRef a2 = get2(j);
-                if (a1.rev != a2.rev) {
-                    const double prob = pair_prob(a1, a2);
-                    if (isfinite(prob)) { m1 = fmax(m1, prob); f(prob, i * (k2 + 1) + j, a1, a2); }
-                }
+    __device__ inline void enumerate(F&& f) const { enumerate_pairs(*this, f); }
+};
+
+// identify_contig_pair_alns (locs.rs:746-799) over any context that has k1, k2, paired, unm_ins_penalty, get1, get2, pair_prob
+template <typename C, typename F>
+__device__ inline void enumerate_pairs(const C& c, F&& f) {
+    const AlnRef none{0.0, 0, 0, NONE32, false};
+    if (!c.paired) {
+        for (uint32_t i = 0; i < c.k1; i++) { const AlnRef a = c.get1(i); f(a.lp, i, a, none); }
+        return;
+    }
+    for (uint32_t i = 0; i < c.k1; i++) {
+        const AlnRef a1 = c.get1(i);
+        double m1 = -INFINITY;
+        for (uint32_t j = 0; j < c.k2; j++) {
+            const AlnRef a2 = c.get2(j);
+            if (a1.rev != a2.rev) {
+                const double prob = c.pair_prob(a1, a2);
+                if (isfinite(prob)) { m1 = fmax(m1, prob); f(prob, i * (c.k2 + 1) + j, a1, a2); }
             }
-            const double alone = a1.lp + unm_ins_penalty;
-            if (alone >= m1) f(alone, i * (k2 + 1) + k2, a1, none);
         }
-        for (uint32_t j = 0; j < k2; j++) {
-            const AlnRef a2 = get2(j);
-            double m2 = -INFINITY;
-            for (uint32_t i = 0; i < k1; i++) {
-                const AlnRef a1 = get1(i);
-                if (a1.rev != a2.rev) {
-                    const double prob = pair_prob(a1, a2);
-                    if (isfinite(prob)) m2 = fmax(m2, prob);
-                }
+        const double alone = a1.lp + c.unm_ins_penalty;
+        if (alone >= m1) f(alone, i * (c.k2 + 1) + c.k2, a1, none);
+    }
+    for (uint32_t j = 0; j < c.k2; j++) {
+        const AlnRef a2 = c.get2(j);
+        double m2 = -INFINITY;
+        for (uint32_t i = 0; i < c.k1; i++) {
+            const AlnRef a1 = c.get1(i);
+            if (a1.rev != a2.rev) {
+                const double prob = c.pair_prob(a1, a2);
+                if (isfinite(prob)) m2 = fmax(m2, prob);
             }
-            const double alone = a2.lp + unm_ins_penalty;
-            if (alone >= m2) f(alone, k1 * (k2 + 1) + j, none, a2);
         }
+        const double alone = a2.lp + c.unm_ins_penalty;
+        if (alone >= m2) f(alone, c.k1 * (c.k2 + 1) + j, none, a2);
+    }
+}
+
+// the same pairing over at most two saved alignments per read end, held in registers (the lean kernel's second pass over the pairs it
+// had left: score_lean_body<.., TWO>)
+struct SmallCtx {
+    InsLut ins;
+    AlnRef a10, a11, a20, a21;          // named members, selects: an array whose address is taken lives in scratch memory
+    uint32_t k1, k2;
+    double unm_ins_penalty;
+    bool paired;
+    __device__ inline AlnRef get1(uint32_t i) const { return i ? a11 : a10; }
+    __device__ inline AlnRef get2(uint32_t j) const { return j ? a21 : a20; }
+    __device__ inline double pair_prob(const AlnRef& x1, const AlnRef& x2) const {
+        const uint32_t insert = max(x1.end, x2.end) - min(x1.start, x2.start);
+        return x1.lp + x2.lp + ins.ln_prob(insert);
     }
 };
 
@@ -425,24 +447,27 @@ struct ContigResult {
 };
 
 // general path: best + kept count of one contig
-__device__ __noinline__ ContigResult general_count(const PairCtx pc, uint32_t max_alns, double prob_diff) {
+template <typename C>
+__device__ __forceinline__ ContigResult count_pairs(const C& pc, uint32_t max_alns, double prob_diff) {
     double best = -INFINITY;
-    pc.enumerate([&](double prob, uint32_t, const AlnRef&, const AlnRef&) { best = fmax(best, prob); });
+    enumerate_pairs(pc, [&](double prob, uint32_t, const AlnRef&, const AlnRef&) { best = fmax(best, prob); });
     const double thresh = best - prob_diff;                                  // locs.rs:796
     uint32_t ge = 0;
-    pc.enumerate([&](double prob, uint32_t, const AlnRef&, const AlnRef&) { ge += prob >= thresh; });
+    enumerate_pairs(pc, [&](double prob, uint32_t, const AlnRef&, const AlnRef&) { ge += prob >= thresh; });
     return ContigResult{best, min(ge, max_alns)};                            // locs.rs:797
 }
+__device__ __noinline__ ContigResult general_count(const PairCtx pc, uint32_t max_alns, double prob_diff) { return count_pairs(pc, max_alns, prob_diff); }
 
 // general path: selection-emit of the kept PairAlignments (decreasing ln_prob, ties in push order, locs.rs:795)
-__device__ __noinline__ void general_emit(const PairCtx pc, uint32_t cnt, double weight, uint32_t contig, PairAlnDev* out) {
+template <typename C>
+__device__ __forceinline__ void emit_pairs(const C& pc, uint32_t cnt, double weight, uint32_t contig, PairAlnDev* out) {
     double prev_prob = INFINITY;
     uint32_t prev_ord = 0;
     bool first = true;
     for (uint32_t e = 0; e < cnt; e++) {
         double bp = -INFINITY; uint32_t bo = NONE32;
         AlnRef b1{0.0, 0, 0, NONE32, false}, b2 = b1;
-        pc.enumerate([&](double prob, uint32_t ord, const AlnRef& x1, const AlnRef& x2) {
+        enumerate_pairs(pc, [&](double prob, uint32_t ord, const AlnRef& x1, const AlnRef& x2) {
             const bool after = first || prob < prev_prob || (prob == prev_prob && ord > prev_ord);
             if (after && (prob > bp || (prob == bp && ord < bo))) { bp = prob; bo = ord; b1 = x1; b2 = x2; }
         });
@@ -458,6 +483,7 @@ __device__ __noinline__ void general_emit(const PairCtx pc, uint32_t cnt, double
         prev_prob = bp; prev_ord = bo; first = false;
     }
 }
+__device__ __noinline__ void general_emit(const PairCtx pc, uint32_t cnt, double weight, uint32_t contig, PairAlnDev* out) { emit_pairs(pc, cnt, weight, contig, out); }
 
 // Fast path: at most one saved alignment per read end on this contig. Candidates in push order:
 // 0 = (aln1, aln2), 1 = (aln1, unmapped), 2 = (unmapped, aln2).
@@ -969,8 +995,10 @@ __device__ __forceinline__ AlnRef ref_from_counted(const LocusView& L, const uin
     return AlnRef{sc.ln_prob - best, sc.start, sc.end, idx, ((raw.x >> 28) & 1u) != 0};            // normalize_probs, locs.rs:358-360
 }
 
-template <bool TIMED, bool KEEP>
+constexpr uint32_t LEAN_OVF = 64;             // second saved alignments of (contig, read end) groups a pair of the TWO form can hold
+template <bool TIMED, bool KEEP, bool TWO = false>
 __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsView& R) {
+    static_assert(!TWO || KEEP, "the two-slot form keeps the saved alignments' products in LDS");
     extern __shared__ __align__(16) uint8_t smem[];
     // TIMED (a diagnostic build of the same code, lcty_ctx_set_knob "score_timing"): where a wavefront's time goes, phase by phase
     uint64_t tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
@@ -991,12 +1019,21 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
     unsigned long long* kept = reinterpret_cast<unsigned long long*>(smem);   // KEEP [2A]: start | rev << 28 | (end - start) << 29 | index << 47
     double* kept_lp = reinterpret_cast<double*>(kept + 2 * A);                // KEEP [2A]
     uint8_t* cnt8 = KEEP ? reinterpret_cast<uint8_t*>(kept_lp + 2 * A) : reinterpret_cast<uint8_t*>(head + 2 * A);   // [A] PairAlignments of the contig (<= 3)
+    // TWO: the second saved alignment of a (contig, read end) group, where there is one: a list of [LEAN_OVF] packed values with its count,
+    // and per group the place of its second on that list ([2A], LEAN_NONE: none) — an exchange on it tells a third alignment of a group
+    unsigned long long* ovf_val = reinterpret_cast<unsigned long long*>(smem + ((static_cast<size_t>(A) * 33 + 7) & ~static_cast<size_t>(7)));
+    uint32_t* ovf_n = reinterpret_cast<uint32_t*>(ovf_val + LEAN_OVF);
+    uint32_t* ovf_at = ovf_n + 2;
+    constexpr uint32_t LEAN_NONE = 0xFFFFFFFFu;
     constexpr unsigned long long NOT_KEPT = ~0ull;
     const int lane = threadIdx.x;
     const bool paired = L.is_paired != 0;
     const InsLut ins{L.ins_lut, L.ins_lut_size, L.ins_n, L.ins_lnq, L.ins_lnpmf_const};
     unsigned long long pool_at = 0, pool_left = 0;
-    for (uint64_t p = blockIdx.x; p < R.n_pairs; p += gridDim.x) {
+    // TWO: the pairs the first lean launch left (only_list); what this form cannot take either goes on to defer_list
+    const uint64_t n_todo = TWO ? static_cast<uint64_t>(*R.only_count) : R.n_pairs;
+    for (uint64_t todo = blockIdx.x; todo < n_todo; todo += gridDim.x) {
+        const uint64_t p = TWO ? R.only_list[todo] : todo;
         const uint64_t a0 = R.aln_off[p];
         const uint2 meta = R.pair_meta[p];
         const uint32_t j2 = meta.x, n_eff = meta.y;
@@ -1018,7 +1055,7 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
                 nm1 = (R.nmask + (off1 >> 5))[lane];
             }
         }
-        if constexpr (KEEP) { for (uint32_t i = lane; i < 2 * A; i += WAVE) kept[i] = NOT_KEPT; }
+        if constexpr (KEEP) { for (uint32_t i = lane; i < 2 * A; i += WAVE) { kept[i] = NOT_KEPT; if (TWO) ovf_at[i] = LEAN_NONE; } if (TWO && lane == 0) *ovf_n = 0; }
         else { for (uint32_t i = lane; i < 2 * A; i += WAVE) head[i] = 0xFFFFFFFFu; }
         uint4 raw_first[GR];
 #pragma unroll
@@ -1100,7 +1137,18 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
                                 // 28 + 1 + 18 (three 16-bit counts) + 16 bits (the kernel is not launched on pairs of 65535 records or more)
                                 const unsigned long long packed = static_cast<unsigned long long>(sc.start) | static_cast<unsigned long long>((raw[g].x >> 28) & 1u) << 28 |
                                     static_cast<unsigned long long>(sc.end - sc.start) << 29 | static_cast<unsigned long long>(idx) << 47;
-                                multi |= atomicExch(&kept[e * A + contig], packed) != NOT_KEPT;
+                                const unsigned long long before = atomicExch(&kept[e * A + contig], packed);
+                                if (before != NOT_KEPT) {
+                                    if constexpr (TWO) {
+                                        // the group's second saved alignment goes on the pair's list (which of the two stays in the slot is
+                                        // all one: pass 3 orders them; their ln-probabilities are computed again there — kept_lp holds either)
+                                        const uint32_t at = atomicAdd(ovf_n, 1u);
+                                        if (at < LEAN_OVF) {
+                                            ovf_val[at] = before;
+                                            multi |= atomicExch(&ovf_at[e * A + contig], at) != LEAN_NONE;      // a third one: the general kernel's
+                                        } else multi = true;
+                                    } else multi = true;
+                                }
                                 kept_lp[e * A + contig] = sc.ln_prob;
                             } else multi |= atomicExch(&head[e * A + contig], idx) != 0xFFFFFFFFu;
                         }
@@ -1164,6 +1212,45 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
                                           has1, has2, unm_ins_penalty, paired);
                 }
             };
+            // TWO: a (contig, read end) group may hold a second saved alignment (the pair's list); such a contig takes the general pairing
+            // over at most 2 x 2 alignments in registers (SmallCtx), every other contig the three candidates of the fast path
+            SmallCtx sc;
+            sc.ins = ins; sc.unm_ins_penalty = unm_ins_penalty; sc.paired = paired; sc.k1 = sc.k2 = 0;
+            sc.a10 = sc.a11 = sc.a20 = sc.a21 = none;
+            auto packed_ref = [](unsigned long long v, double lp) {
+                const uint32_t start = static_cast<uint32_t>(v) & 0x0FFFFFFFu;
+                return AlnRef{lp, start, start + (static_cast<uint32_t>(v >> 29) & 0x3FFFFu), static_cast<uint32_t>(v >> 47), ((v >> 28) & 1ull) != 0};
+            };
+            // the saved alignments of one group in the order of gather_sort_dedupe: ln_prob descending, record index ascending, the later
+            // member of a 128-bp bin dropped (locs.rs:321-342); with two of them their ln-probabilities come from the records again
+            struct Group { AlnRef r0, r1; uint32_t k; };
+            auto group_refs = [&](uint32_t key, double best) -> Group {
+                Group g{none, none, 0u};
+                if constexpr (KEEP) {
+                    const unsigned long long m = kept[key];
+                    if (m == NOT_KEPT) return g;
+                    unsigned long long x = NOT_KEPT;
+                    if constexpr (TWO) { const uint32_t at = ovf_at[key]; if (at != LEAN_NONE) x = ovf_val[at]; }
+                    if (x == NOT_KEPT) { g.r0 = packed_ref(m, kept_lp[key] - best); g.k = 1u; return g; }
+                    const uint32_t i0 = static_cast<uint32_t>(m >> 47), i1 = static_cast<uint32_t>(x >> 47);
+                    const double l0 = score_counted(L, recs[i0]).ln_prob, l1 = score_counted(L, recs[i1]).ln_prob;
+                    const bool m_first = l0 > l1 || (l0 == l1 && i0 < i1);
+                    g.r0 = packed_ref(m_first ? m : x, (m_first ? l0 : l1) - best);
+                    g.r1 = packed_ref(m_first ? x : m, (m_first ? l1 : l0) - best);
+                    g.k = (g.r0.start >> 7) == (g.r1.start >> 7) ? 1u : 2u;
+                }
+                return g;
+            };
+            // the candidates of contig c: true = through `sc` (some group holds two), false = through the fast path's three
+            auto build = [&](uint32_t c, Fast3& f) -> bool {
+                if constexpr (TWO) {
+                    const Group g1 = group_refs(c, bl0), g2 = group_refs(A + c, bl1);
+                    sc.a10 = g1.r0; sc.a11 = g1.r1; sc.k1 = g1.k; sc.a20 = g2.r0; sc.a21 = g2.r1; sc.k2 = g2.k;
+                    if (sc.k1 > 1 || sc.k2 > 1) return true;
+                    f = fast_from_refs(ins, g1.r0, g2.r0, sc.k1 != 0, sc.k2 != 0, unm_ins_penalty, paired);
+                    return false;
+                } else { f = candidates(c); return false; }
+            };
             // Where the entries go is decided BEFORE the contigs are looked at when the wavefront's share of the arena can hold the
             // most this pair could write (3 entries per contig that holds a saved alignment): the candidates are then built once,
             // counted and written in the same pass. Otherwise (no shares in a small launch, or a pair too big for one) the count
@@ -1175,7 +1262,7 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
                 else ub += __popcll(__ballot(c < A && (head[c] & head[A + c]) != 0xFFFFFFFFu));
             }
             ub *= 3;
-            const bool at_once = R.pa_chunk != 0 && static_cast<uint64_t>(ub) * 8 <= R.pa_chunk;
+            const bool at_once = !TWO && R.pa_chunk != 0 && static_cast<uint64_t>(ub) * 8 <= R.pa_chunk;
             bool room = true;
             if (at_once) {
                 if (ub > pool_left) {
@@ -1196,11 +1283,17 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
                 Fast3 f;
                 f.has1 = f.has2 = false;
                 if (c < A) {
-                    f = candidates(c);
+                    const bool small = build(c, f);
                     const uint32_t clen = L.allele_len[c];
-                    if (f.has1) { const uint32_t mid = (f.a1.start + f.a1.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
-                    if (f.has2) { const uint32_t mid = (f.a2.start + f.a2.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
-                    if (f.has1 || f.has2) res = fast_count(f, max_alns, L.prob_diff);
+                    if (small) {
+                        for (uint32_t i = 0; i < sc.k1; i++) { const AlnRef a = sc.get1(i); const uint32_t mid = (a.start + a.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                        for (uint32_t j = 0; j < sc.k2; j++) { const AlnRef a = sc.get2(j); const uint32_t mid = (a.start + a.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                        res = count_pairs(sc, max_alns, L.prob_diff);
+                    } else {
+                        if (f.has1) { const uint32_t mid = (f.a1.start + f.a1.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                        if (f.has2) { const uint32_t mid = (f.a2.start + f.a2.end) / 2; inb |= L.boundary <= mid && mid < clen - L.boundary; }
+                        if (f.has1 || f.has2) res = fast_count(f, max_alns, L.prob_diff);
+                    }
                     cnt8[c] = static_cast<uint8_t>(res.cnt);
                     mrow[c] = res.cnt ? res.best * weight : unmapped_prob;
                     total_cnt += res.cnt;
@@ -1249,7 +1342,12 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
                     const uint32_t my_off = run + wave_excl_scan_u32(cnt, lane, &tot);
                     run += tot;
                     if (c < A) R.pa_idx[p * A + c] = my_off | (cnt << 24);
-                    if (room && cnt) fast_emit(candidates(c), cnt, weight, c, R.pa + pa_base + my_off);
+                    if (room && cnt) {
+                        Fast3 f2;
+                        f2.has1 = f2.has2 = false;
+                        if (build(c, f2)) emit_pairs(sc, cnt, weight, c, R.pa + pa_base + my_off);
+                        else fast_emit(f2, cnt, weight, c, R.pa + pa_base + my_off);
+                    }
                 }
             }
         }
@@ -1276,6 +1374,9 @@ __device__ __forceinline__ void score_lean_body(const LocusView& L, const ReadsV
 
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_kernel(const LocusView L, const ReadsView R) { score_lean_body<false, false>(L, R); }
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_keep_kernel(const LocusView L, const ReadsView R) { score_lean_body<false, true>(L, R); }
+// the pairs the kernel above left, with a second saved alignment per (contig, read end) allowed (13 % of the pairs at config 2; what it
+// leaves in turn — a group of three or more, or more than LEAN_OVF such groups — is the general kernel's)
+__global__ __launch_bounds__(WAVE, 2) void score_counted_lean_two_kernel(const LocusView L, const ReadsView R) { score_lean_body<false, true, true>(L, R); }
 #ifdef LCTY_DIAG     // the developer build: the same kernels with shader-clock stamps between their phases (knob "score_timing")
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_timed_kernel(const LocusView L, const ReadsView R) { score_lean_body<true, false>(L, R); }
 __global__ __launch_bounds__(WAVE, 4) void score_counted_lean_keep_timed_kernel(const LocusView L, const ReadsView R) { score_lean_body<true, true>(L, R); }
@@ -1410,6 +1511,22 @@ void launch_score_reads(lcty_reads* reads) {
             } else hipLaunchKernelGGL(lean_kernel, dim3(static_cast<uint32_t>(lean_grid)), dim3(WAVE), lean_lds, ctx->stream, L, RL);
             R.only_list = R.defer_list; R.only_count = R.defer_count;
             R.pa_chunk = 0;                                                     // the few pairs left reserve their own entries
+            if (keep && ctx->knob("score_lean_two", 1) != 0) {
+                // the pairs the lean kernel left go through its two-slot form first (a second saved alignment per (contig, read end):
+                // most of them); the general kernel takes what that leaves. The counts stay on the device.
+                reads->d_defer_list2.ensure(std::max<uint64_t>(R.n_pairs, 1)); reads->d_defer_count2.ensure(1);
+                reads->d_defer_count2.zero(ctx->stream);
+                ReadsView R2 = R;
+                R2.defer_list = reads->d_defer_list2.p; R2.defer_count = reads->d_defer_count2.p;
+                const size_t two_lds = ((((static_cast<size_t>(L.n_alleles) * 33 + 7) & ~static_cast<size_t>(7)) + LEAN_OVF * 8 + 8 + static_cast<size_t>(L.n_alleles) * 8) + 15) & ~static_cast<size_t>(15);
+                if (two_lds > 48 * 1024)
+                    LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(score_counted_lean_two_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(two_lds)));
+                const uint32_t two_per_cu = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(8, lds_max / two_lds)));    // two wavefronts per SIMD: 2 x 2 alignments per contig in registers
+                const uint64_t two_grid = std::max<uint64_t>(1, std::min<uint64_t>(R.n_pairs, static_cast<uint64_t>(cus) * two_per_cu));
+                hipLaunchKernelGGL(score_counted_lean_two_kernel, dim3(static_cast<uint32_t>(two_grid)), dim3(WAVE), two_lds, ctx->stream, L, R2);
+                R.only_list = R2.defer_list; R.only_count = R2.defer_count;
+            }
         }
         hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(WAVE), lds, ctx->stream, L, R, max_recs);
     });

@@ -79,8 +79,8 @@ def test_counted_edge_cases_and_misuse(gpu_ctx):
 
 
 def test_lean_kernel_equals_the_general_kernel(gpu_ctx):
-    """Counted batches go through the lean scoring kernel (at most one saved alignment per contig and read end) and the pairs it
-    leaves through the general one (lcty_score.hip). The same batch with the knob "score_lean" 0 — the general kernel on every
+    """Counted batches go through the lean scoring kernel (at most one saved alignment per contig and read end), the pairs it leaves
+    through its two-slot form (a second saved alignment per contig and read end) and what that leaves through the general one (lcty_score.hip). The same batch with the knob "score_lean" 0 — the general kernel on every
     pair — must give the same products bit for bit, also when many pairs are left to the general kernel (several secondaries of a
     read end on one contig), for single-end reads, and against the oracle."""
     from tests.test_gpu_parity import random_pairs
@@ -114,8 +114,13 @@ def test_lean_kernel_equals_the_general_kernel(gpu_ctx):
             again = api.AllAlignments.load(locus, chunk, counted=True)
             _same(again, general)
             gpu_ctx.set_knob("score_lean_keep", -1)
+            # without the two-slot form in between (round 4's flow: the lean kernel, then the general one on everything it leaves)
+            gpu_ctx.set_knob("score_lean_two", 0)
+            again = api.AllAlignments.load(locus, chunk, counted=True)
+            _same(again, general)
+            gpu_ctx.set_knob("score_lean_two", -1)
     finally:
-        gpu_ctx.set_knob("score_lean", -1); gpu_ctx.set_knob("score_lean_keep", -1)
+        gpu_ctx.set_knob("score_lean", -1); gpu_ctx.set_knob("score_lean_keep", -1); gpu_ctx.set_knob("score_lean_two", -1)
     oa = ol.load(ch)
     cnt = api.AllAlignments.load(loc, ch, counted=True)
     st, w, unm, uk = cnt.status()
