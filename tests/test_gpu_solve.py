@@ -285,6 +285,35 @@ def test_chain_batches_do_not_change_results(gpu_ctx):
     assert api.solve_stats(aa)[0] == 3 * len(gts)
 
 
+def test_the_grouping_of_a_stage_does_not_change_a_chain(gpu_ctx):
+    """The initialisation of a diploid stage builds the records of several chains at once (groups of chains on shared rows of the location
+    table, solve_init_tile_kernel): what a chain starts from — and therefore where it ends — must not depend on which other genotypes are in
+    the stage, on their order, or on how many attempts share a group. Stages of every kind of group: all 136 genotypes of 16 alleles (full
+    tiles and their edges, homozygous genotypes, a tail of single chains), the same genotypes one by one, in reverse order, and with more
+    attempts than a group holds; reads with several pair-alignments on a contig (the deferred path) are in the batch."""
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 16, 4000, 12000)
+    gts = api.generate_genotypes(16, 2)
+    for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+        sv = api.default_solver(kind)
+        if kind == cdefs.SOLVER_GREEDY: sv.plato_size = 20
+        else: sv.anneal_steps, sv.plato_size = 300, 200
+        seeds = api.chain_seeds(5, len(gts))
+        whole = api.solve_stage(aa, gts, sv, 1, seeds)[2][:, 0]
+        alone = np.array([api.solve_stage(aa, gts[i:i + 1], sv, 1, seeds[i:i + 1])[2][0, 0] for i in range(0, len(gts), 7)])
+        assert np.array_equal(whole[::7], alone)
+        back = api.solve_stage(aa, np.ascontiguousarray(gts[::-1]), sv, 1, np.ascontiguousarray(seeds[::-1]))[2][:, 0]
+        assert np.array_equal(back[::-1], whole)
+        # eleven attempts of three genotypes: groups of eight and of three chains of one genotype; attempt 0 carries the seed it had above
+        sub = np.ascontiguousarray(gts[[3, 40, 135]])
+        s11 = api.chain_seeds(6, 33)
+        many = api.solve_stage(aa, sub, sv, 11, s11)[2]
+        for g in range(3):
+            for a in (0, 7, 10):
+                one = api.solve_stage(aa, sub[g:g + 1], sv, 1, s11[g * 11 + a:g * 11 + a + 1])[2][0, 0]
+                assert one == many[g, a]
+    compare_stage(aa, ol, oa, gts[:24], api.default_solver(cdefs.SOLVER_GREEDY), 2, api.chain_seeds(9, 48))
+
+
 def test_library_scheme_driver_equals_the_composed_calls(gpu_ctx):
     """lcty_solve (solve::solve in C++ inside the library) against the same sequence of C-ABI calls made from Python."""
     L, p, loc, aa, ol, oa = setup(gpu_ctx, 12, 6000, 20000)
