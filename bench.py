@@ -1036,6 +1036,16 @@ def main():
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_transfer * n_new / (ms_tr * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_tr else None,
                                          "traffic": None, "algorithmic_bytes_per_transfer": per_transfer,
                                          "what": "read CIGAR + haplotype CIGAR under the read + target bases under the read + transferred CIGAR, per transfer"}
+        try:
+            # HBM bytes per transfer from the committed counter passes over the same kernel (scripts/run_transfer_traffic.sh), times this leg's transfers
+            with open(os.path.join(ROOT, "profiles", "r05_pmc_transfer_kernel.json")) as f:
+                tt = json.load(f)
+            bpt = tt["bytes_per_transfer"]
+            out["long_reads"]["roofline"].update({"traffic": (bpt["fetch_raw"] + bpt["write"]) * n_new, "traffic_bytes_per_transfer": bpt,
+                                                   "traffic_rule": "FETCH_SIZE + WRITE_SIZE (narrow gathers: raw)", "traffic_source": "profiles/r05_pmc_transfer_kernel.json",
+                                                   "traffic_is_current": tt.get("sources_sha16") == out["kernel_sources_sha16"]})
+        except (OSError, KeyError, ValueError):
+            pass
         ao.close(); del prim
         if args.ont_map_sample > 0:
             # ---- the same shape from bases alone (second slice; lcty_map_long.hip): the reads as the sequencer gave

@@ -529,7 +529,7 @@ __host__ __device__ inline size_t init_tile_lds(uint32_t T, uint32_t R, uint32_t
 }
 
 // the general code for the deferred reads of a wavefront: lane i takes the i-th of the first n entries of its list (a ring in global
-// memory, written and read by this wavefront only; read at agent scope behind a release fence). What the reads add to the chains' alignment likelihood is summed
+// memory, written and read by this wavefront only; read behind a workgroup-scope release fence). What the reads add to the chains' alignment likelihood is summed
 // per chain in the order the reads were listed — increasing read number — whatever else shares the list: c_aln must not depend on
 // how the stage was cut into groups.
 __device__ __forceinline__ void init_tile_deferred(const SolveView& V, const InitChainP* __restrict__ cp, uint32_t T, uint32_t* depth, double* aln_def,
@@ -537,7 +537,7 @@ __device__ __forceinline__ void init_tile_deferred(const SolveView& V, const Ini
     double add = 0.0;
     uint32_t my_c = 0xFFFFFFFFu;
     if (lane < n) {
-        const unsigned long long packed = __hip_atomic_load(&queue[(head + lane) & (INIT_TILE_Q - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long packed = __hip_atomic_load(&queue[(head + lane) & (INIT_TILE_Q - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint2 item = make_uint2(static_cast<uint32_t>(packed), static_cast<uint32_t>(packed >> 32));
         const uint32_t c = item.x >> 24, rp = item.x & 0xFFFFFFu, slot = item.y;
         const InitChainP P = cp[c];
@@ -767,11 +767,12 @@ __global__ __launch_bounds__(256) void solve_init_tile_kernel(const SolveView V,
         // every chain wait for the record stores of the chain before it: the loop holds stores only.)
         const bool last = base + 64 >= seg_hi;
         if (qn >= 64 || (last && qn)) {
-            // the list's entries were stored by other lanes of this wavefront: their stores complete (agent-scope release: rare, between
-            // blocks), the entries are then read past the L1 (agent-scope loads)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // the list's entries were stored by other lanes of this wavefront: workgroup scope — the stores have completed before the
+            // entries are read (same CU, same L1). NOT agent scope: on this multi-XCD device an agent-scope release writes the XCD's L2
+            // back (buffer_wbl2) and the acquire invalidates it — with the records streaming through, 57 -> 205 ms for the launch.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             while (qn >= 64 || (last && qn)) {
                 const uint32_t n = min(qn, 64u);
                 init_tile_deferred(V, cp, T, depth, aln_def, ex_cnt, queue, qhead, n, wave, lane, random_start);
