@@ -209,6 +209,49 @@ def test_mapper_on_random_inputs_equals_its_restatement(gpu_ctx, seed):
         assert R.mate_bases(got, m) == (bases, isn)
 
 
+@pytest.mark.parametrize("k", [8, 16, 23, 31])
+def test_index_of_short_and_long_seeds_and_alleles_with_other_bases(gpu_ctx, k):
+    """The k-mer index of the basis alleles is ordered by the library's own radix sort (lcty_map_index.hip): one pass per byte of the key a
+    k-mer of this k can differ in plus the top byte — 3 passes at k = 8, 8 at k = 31, an even or odd number of buffer swaps — and windows
+    with a base that is not ACGT (runs of N inside the alleles) sort behind every k-mer. The mapper on such an index must give the
+    restatement's records."""
+    from tests.helpers import locus_arrays, make_bg
+    rng = np.random.default_rng(500 + k)
+    base = rng.choice(list(b"ACGT"), size=3000).astype(np.uint8)
+    haps = []
+    for a in range(4):
+        h = base.copy()
+        for q in rng.integers(50, 2950, size=8):
+            h[q] = ord("ACGT"[(("ACGT".index(chr(h[q]))) + 1 + int(rng.integers(0, 3))) % 4])
+        for _ in range(3):                                                           # runs of N, and single ones
+            at = int(rng.integers(100, 2800)); h[at:at + int(rng.integers(1, 40))] = ord("N")
+        haps.append(bytearray(h.tolist()))
+    bg = make_bg()
+    p = api.resolve_params(api.default_params(), bg)
+    seqs, seq_off, cflat, cnt_off, _ = locus_arrays(haps, 25)
+    loc = api.Locus(gpu_ctx, seqs, seq_off, cflat, cnt_off, 25, bg, p)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def read_end():
+        h = haps[int(rng.integers(0, 4))]
+        ln = int(rng.integers(60, 251))
+        at = int(rng.integers(0, len(h) - ln))
+        s = bytes(c if c != ord("N") else ord("A") for c in h[at:at + ln])
+        return (s.translate(comp)[::-1] if rng.integers(0, 2) else s).decode()
+    pairs = [{"seq1": read_end(), "seq2": read_end(), "recs": []} for _ in range(60)]
+    ch = cdefs.ReadsChunk.from_pairs(pairs)
+    basis = [0, 2, 3]
+    mp = api.map_params(k=k, stride=5, min_votes=2, band=16)
+    api.build_map_index(loc, basis, k=mp.k)
+    got = api.map_reads(loc, ch, mp)
+    aln_off, recs, cig_off, cigar, strands = R.map_chunk(ch, seqs, seq_off, basis, mp)
+    assert np.array_equal(got.aln_off, aln_off) and np.array_equal(got.cigar_off, cig_off) and np.array_equal(got.cigar, cigar)
+    want = np.array(recs, dtype=[("pos", "<u4"), ("contig", "<u2"), ("flags", "<u2"), ("n_cigar", "<u4"), ("cigar_rel", "<u4")])
+    for f in ("pos", "contig", "flags", "n_cigar", "cigar_rel"):
+        assert np.array_equal(got.recs[f], want[f]), f
+    assert int((got.recs["flags"] & cdefs.FLAG_UNMAPPED == 0).sum()) > 60              # the reads do map
+
+
 def test_mapper_aligns_clipped_candidates_with_gaps(gpu_ctx):
     """Read ends across a 4-base deletion / a 3-base insertion relative to the allele: end to end with one D / I run on the device
     as in the restatement (tests/test_pyref_map.py derives these records by hand); without a band they stay clipped."""
