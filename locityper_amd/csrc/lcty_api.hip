@@ -49,7 +49,7 @@ int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value) {
 #ifdef LCTY_DIAG
                                             // the developer build (make DIAG=1): traces, in-kernel timing, kernel forms under measurement
                                             "solve_stats", "queue_trace", "map_trace", "exact_trace", "solve_greedy_form", "solve_anneal_timing", "score_timing",
-                                            "solve_init_tiles",
+                                            "solve_init_tiles", "transfer_phases",
 #endif
                                             nullptr};
         bool ok = false;

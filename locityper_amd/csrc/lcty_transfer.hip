@@ -68,7 +68,7 @@ __host__ __device__ inline size_t pair_scratch_bytes(uint32_t cap_alns, uint32_t
     b += (cap_alns + 15) & ~15u;
     b += sizeof(uint4) * static_cast<size_t>(cap_alns);
     b += sizeof(NewAln) * cap_new; b = (b + 15) & ~size_t(15);
-    b += 4 * static_cast<size_t>(cap_words); b = (b + 15) & ~size_t(15);
+    b += 4 * static_cast<size_t>(cap_words); b = (b + 127) & ~size_t(127);            // the lanes' chunks of 64 bytes lie inside cache lines
     b += 64 * lane_scratch_bytes(lim);
     return (b + 255) & ~size_t(255);
 }
@@ -82,7 +82,7 @@ __device__ inline PairScratch carve(uint8_t* base, uint32_t cap_alns, uint32_t h
     s.seen = base + b; b += (cap_alns + 15) & ~15u;
     s.pre = reinterpret_cast<uint4*>(base + b); b += sizeof(uint4) * static_cast<size_t>(cap_alns);
     s.news = reinterpret_cast<NewAln*>(base + b); s.cap_new = cap_new; b += sizeof(NewAln) * cap_new; b = (b + 15) & ~size_t(15);
-    s.words = reinterpret_cast<uint32_t*>(base + b); s.cap_words = cap_words; b += 4 * static_cast<size_t>(cap_words); b = (b + 15) & ~size_t(15);
+    s.words = reinterpret_cast<uint32_t*>(base + b); s.cap_words = cap_words; b += 4 * static_cast<size_t>(cap_words); b = (b + 127) & ~size_t(127);
     s.lanes = base + b;
     return s;
 }
@@ -226,13 +226,14 @@ struct TransferArgs {
     uint64_t* out_rec_at; uint64_t* out_word_at;        // [R]
     uint32_t* flag;                // 1 = arena overflow (retry larger), LCTY_ERR_* >= 2 otherwise
     unsigned long long* dp_cells;  // cells of the aligner's matrices, all lanes
+    unsigned long long* phases;    // developer build (knob transfer_phases): shader-clock ticks of the kernel's parts, summed over the wavefronts; else NULL
     double min_weight;
     uint32_t wave_scores;          // 1: the batch has records whose CIGARs are long enough to be counted by the whole wavefront (WAVE_SCORE_FROM words)
     uint32_t dry_run;              // 1: only look where a transfer WOULD start (no similar position on the target yet): pairs with any go to
                                    // redo_list, their number of such (source, target) combinations is added to rec_cursor; nothing is walked
 };
 
-__global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
+__global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
     const uint32_t lane = threadIdx.x;
     uint8_t* base = T.scratch + static_cast<size_t>(blockIdx.x) * T.scratch_stride;
     const PairScratch P = carve(base, T.cap_alns, T.hcap, T.cap_new, T.cap_words);
@@ -240,7 +241,23 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
     const bool paired = L.is_paired != 0;
     __shared__ Prelim S;
     __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop, sh_redo;
-    __shared__ uint32_t lds_cigar[CIGAR_LDS_ITEMS * 64];           // the first items of every lane's CIGAR under construction
+    __shared__ uint32_t lds_wb[CIGAR_CHUNK * 64];                  // the chunk of every lane's CIGAR under construction (DCigar::wb)
+    __shared__ uint32_t lds_win[ITEM_WIN * 64];                    // the items a lane's pass over a finished CIGAR reads ahead (ItemWindow)
+    __shared__ uint32_t lds_src[SRC_LDS_WORDS];                    // the source alignment's CIGAR: every lane of every chunk walks it
+    // developer build: where a wavefront's time goes (0 set-up + wave scoring, 1 PrelimAlignments, 2 estimate / probe / offset / walk_init,
+    // 3 walk, 4 aligner for clipped ends, 5 assemble, 6 optimize, 7 scoring of the result, 8 push, 9 hand-over)
+    [[maybe_unused]] unsigned long long tph[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto mark = [&](int k) {
+        if constexpr (kDiag) {
+            if (T.phases) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+                tph[k] += now - tlast; tlast = now;
+            }
+        }
+    };
+    if constexpr (kDiag) tlast = __builtin_amdgcn_s_memtime();
 
     for (uint64_t ii = blockIdx.x; ii < T.n_list; ii += gridDim.x) {
         const uint64_t p = T.pair_list ? T.pair_list[ii] : ii;
@@ -269,6 +286,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
             }
             __syncthreads();
         }
+        mark(0);
         // ---- PrelimAlignments of the pair, as read_next_alns builds them (locs.rs:502-567), one lane: the order matters ----
         if (lane == 0) {
             S.n_alns = 0;
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
             }
         }
         __syncthreads();
+        mark(1);
         const uint32_t n0 = S.n_alns;
 
         // ---- HapAlns::transfer_alignments (transfer.rs:70-140): sources in order, targets of a source across lanes ----
@@ -325,6 +344,10 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
             SrcCigar src;
             if (sa.src & 0x80000000u) { const NewAln na = P.news[sa.src & 0x7FFFFFFFu]; src.raw = P.words + na.cigar_at; src.n = na.n_cigar; src.hard_to_soft = false; }
             else { src.raw = cig + recs[sa.src].cigar_rel; src.n = recs[sa.src].n_cigar; src.hard_to_soft = true; }
+            // its first SRC_LDS_WORDS words go to LDS (a 10-kb ONT read: ~900): the lanes of all chunks walk this one CIGAR, each at its own item
+            src.lds = lds_src; src.lds_n = T.dry_run ? 0u : min(src.n, SRC_LDS_WORDS);
+            for (uint32_t k = lane; k < src.lds_n; k += 64) lds_src[k] = src.raw[k];
+            __syncthreads();
             // the read in the orientation of the source alignment: the stored bases are the primary record's (MateData::new)
             const uint32_t prim = e ? j2 : 0u;
             const bool prim_rev = (recs[prim].flags & LCTY_FLAG_REVERSE) != 0;
@@ -339,7 +362,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                 // 0 nothing, 1 similar position exists (index in `hit`), 2 failed transfer, 3 new alignment
                 uint32_t kind = 0, hit = NONE32T, target = 0;
                 PAln na; na.ln_prob = 0.0; na.start = 0; na.contig_end = 0; na.edit = 0; na.src = 0;
-                DCigar out; out.init(LS.cig_a, T.lim.cigar_cap, lds_cigar + lane);
+                DCigar out; out.init(LS.cig_a, T.lim.cigar_cap, lds_wb + lane);
                 bool beyond = false;                                         // this transfer needs a lane with more scratch
                 bool transferring = false, walking = false;
                 Walk walk; walk.start_k = 0; walk.phase = PH_DONE;
@@ -378,6 +401,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                                             src, out);
                     }
                 }
+                mark(2);
                 if (T.dry_run) {
                     // an upper bound: the real run also finds the alignments it has transferred itself, and stops at its failures
                     const unsigned long long would = __ballot(kind == 4);
@@ -393,30 +417,50 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     LS.cig_free = LS.cig_b;
                     do {
                         const uint32_t st = walking ? walk_step(walk, src, Q, out, LS, job, T.walk_budget) : WALK_DONE;
+                        mark(3);
                         if (st == WALK_JOB) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);   // the clipped ends
+                        mark(4);
                         if (__any(st == WALK_ASSEMBLE)) {
                             // The stretches between anchors the walks left behind, resolved for all lanes together: a lane copies its items
                             // up to the next marker (a few items), then the lanes that stand at a marker call the aligner at one converged
                             // site. The first item behind a marker was pushed with push_checked (the anchor that follows a stretch): it is
                             // pushed that way again, behind the aligner's operations; every other item keeps its boundaries.
-                            DCigar fin; fin.init(LS.cig_b, T.lim.cigar_cap);
+                            DCigar fin; fin.init(LS.cig_b, T.lim.cigar_cap, lds_wb + lane);
                             bool assembling = st == WALK_ASSEMBLE;
                             uint32_t ai = 0;
                             bool after_mark = false;
-                            if (assembling) out.flush();
+                            if (assembling) out.finish();                         // `fin` takes the lane's LDS buffer
+                            ItemWindow win; win.init(lds_win + lane);
                             do {
+                                // a round: every lane that is copying reads its next ITEM_WIN items (all lanes' loads in flight together), copies
+                                // them up to a marker, and the lanes that stand at one call the aligner — the lanes drift apart instead of
+                                // waiting for each other at every marker (waiting there: 82.6 ms for the launch instead of 74.4)
                                 bool need = false;
                                 uint4 jb = make_uint4(0, 0, 0, 0);
                                 if (assembling) {
-                                    while (ai < out.n) {
-                                        const uint2 it = out.get(ai++);
+                                    while (win.has(ai)) {
+                                        const uint2 it = win.get(ai++);
                                         if (it.x == JOB_MARK) { jb = LS.jobs[static_cast<size_t>(it.y) * LANE_STRIDE]; need = true; break; }
                                         if (after_mark) { fin.push_checked(it.x, it.y); after_mark = false; }
                                         else fin.push_raw(it);
                                     }
-                                    if (!need) assembling = false;
+                                    if (!need && ai >= out.n) assembling = false;
                                 }
+                                if (assembling && !need) win.fill(out, ai);     // at the end of its window (the first round: of the empty one)
+                                [[maybe_unused]] unsigned long long t0 = 0;
+                                if constexpr (kDiag) { if (T.phases) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } }
                                 if (need) { aligner_align(Q, jb.x, jb.y, jb.z, jb.w, 0, false, fin, LS); after_mark = true; }
+                                if constexpr (kDiag) {
+                                    if (T.phases) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        tph[10] += __builtin_amdgcn_s_memtime() - t0; tph[11]++;
+                                        tph[16] += static_cast<unsigned long long>(__popcll(__ballot(need)));
+                                        uint32_t mx = need ? (jb.y + 1) * (jb.w + 1) : 0u;
+                                        for (int o = 32; o > 0; o >>= 1) mx = max(mx, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mx), o)));
+                                        tph[17] += mx;
+                                        tph[18] += __any(need && (jb.y > xfer::DP_SMALL || jb.w > xfer::DP_SMALL)) ? 1u : 0u;
+                                    }
+                                }
                             } while (__any(assembling));
                             if (st == WALK_ASSEMBLE) {
                                 fin.rlen = out.rlen; fin.qlen = out.qlen; fin.overflow |= out.overflow;
@@ -424,15 +468,17 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                                 LS.cig_free = LS.cig_a;
                                 walk.n_jobs = 0;
                             }
+                            mark(5);
                         }
                         if (__any(st == WALK_OPTIMIZE)) {
-                            optimize_and_finish(st == WALK_OPTIMIZE, out, Q, LS);
+                            optimize_and_finish(st == WALK_OPTIMIZE, out, Q, LS, lds_win + lane, lds_wb + lane, kDiag && T.phases ? tph + 12 : nullptr);
                             if (st == WALK_OPTIMIZE) walk.phase = PH_DONE;
+                            mark(6);
                         }
                         walking = st != WALK_DONE && st != WALK_OPTIMIZE;
                     } while (__any(walking));
                 }
-                out.flush();
+                out.finish();
                 if (transferring) {
                     const uint32_t new_start = walk.start_k;
                     const uint32_t diff = out.rlen > out.qlen ? out.rlen - out.qlen : out.qlen - out.rlen;
@@ -449,6 +495,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                         na.contig_end = target | (e << 16) | (s_rev ? (1u << 17) : 0u);
                     }
                 }
+                mark(7);
                 // the loop of transfer.rs:90-136 stops at the (transfer_fails + 1)-th failure: everything behind it did not happen
                 const unsigned long long fail_mask = __ballot(kind == 2);
                 const uint32_t fails_before = sh_fails + static_cast<uint32_t>(__popcll(fail_mask & ((1ull << lane) - 1ull)));
@@ -485,7 +532,13 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     nn.ln_prob = na.ln_prob; nn.start = na.start; nn.contig_end = na.contig_end; nn.edit = na.edit;
                     nn.n_cigar = out.n; nn.cigar_at = word_at; nn.pushed = 0;
                     P.news[slot] = nn;
-                    for (uint32_t k = 0; k < out.n; k++) P.words[word_at + k] = out.word(k);
+                    for (uint32_t k = 0; k < out.n; k += 8) {                   // eight loads in flight (one by one each waited for the store before it)
+                        uint32_t v[8];
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; u++) v[u] = k + u < out.n ? out.word(k + u) : 0u;
+#pragma unroll
+                        for (uint32_t u = 0; u < 8; u++) if (k + u < out.n) P.words[word_at + k + u] = v[u];
+                    }
                 }
                 __syncthreads();
                 // PrelimAlignments::push of the chunk's new alignments (locs.rs:298-344), all lanes at once: the targets of one source are
@@ -536,6 +589,7 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
                     if (sh_fails > H.transfer_fails || !room) sh_stop = 1;
                 }
                 __syncthreads();
+                mark(8);
             }
         }
         __syncthreads();
@@ -581,6 +635,10 @@ __global__ __launch_bounds__(64, 4) void transfer_kernel(const LocusView L, cons
             }
         }
         __syncthreads();
+        mark(9);
+    }
+    if constexpr (kDiag) {
+        if (T.phases && lane == 0) for (int k = 0; k < 20; k++) atomicAdd(&T.phases[k], tph[k]);
     }
     // aligner work of this wavefront (launches that are repeated with larger arenas count again: it is what the device did)
     unsigned long long cells = LS.cells;
@@ -786,8 +844,9 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         DevBuf<uint32_t> d_new_cnt, d_new_words, d_flag;
         DevBuf<uint64_t> d_rec_at, d_word_at, d_list_a, d_list_b;
         DevBuf<unsigned long long> d_cursors;                                      // records, words, pairs for the next level, aligner cells
-        d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(4);
-        LCTY_HIP(hipMemsetAsync(d_cursors.p + 3, 0, sizeof(unsigned long long), s));
+        d_new_cnt.alloc(2 * R); d_new_words.alloc(R); d_rec_at.alloc(R); d_word_at.alloc(R); d_flag.alloc(1); d_cursors.alloc(4 + 20);
+        LCTY_HIP(hipMemsetAsync(d_cursors.p + 3, 0, 21 * sizeof(unsigned long long), s));
+        const bool phases = ctx->diag_knob("transfer_phases", 0) != 0;             // developer build only
         d_list_a.alloc(R); d_list_b.alloc(R);
         // Levels of lane scratch. Level 0 is sized for the reads of the batch (short reads: transferred CIGARs of <= 192 items,
         // stretches between anchors of <= 255 bases) and takes every pair at full occupancy; a pair with a transfer that needs more
@@ -795,7 +854,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         const uint32_t rec_cigar = std::max<uint32_t>(reads->max_cigar_per_rec, 1);
         std::vector<Limits> levels;
         {
-            Limits l0; l0.cigar_cap = std::max<uint32_t>(192, 2 * rec_cigar + 128); l0.dp_dim = 255; l0.dp_cells = 32768;
+            Limits l0; l0.cigar_cap = (std::max<uint32_t>(192, 2 * rec_cigar + 128) + 15u) & ~15u; l0.dp_dim = 255; l0.dp_cells = 32768;      // whole chunks (DCigar)
             Limits l1; l1.cigar_cap = std::max<uint32_t>(2048, 4 * l0.cigar_cap); l1.dp_dim = 2047; l1.dp_cells = 1u << 20;
             Limits l2; l2.cigar_cap = 4 * l1.cigar_cap; l2.dp_dim = 16383; l2.dp_cells = 1u << 26;
             levels = {l0, l1, l2};
@@ -811,7 +870,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
         }
         if (ctx->knob("transfer_scratch_mb", 0) > 0) scratch_budget = std::max<uint64_t>(64, static_cast<uint64_t>(ctx->knob("transfer_scratch_mb", 0))) << 20;
         // one wavefront per workgroup, 128 VGPRs (launch bounds; a few spills are cheaper than the fourth wavefront per SIMD is worth)
-        uint32_t waves = 16;
+        uint32_t waves = 12;
         waves = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_waves", waves)));
         const uint32_t max_blocks = static_cast<uint32_t>(ctx->props.multiProcessorCount) * waves;
 
@@ -851,6 +910,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
             T.out_recs = nullptr; T.out_recs_cap = 0; T.out_words = nullptr; T.out_words_cap = 0;
             T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.dp_cells = d_cursors.p + 3; T.min_weight = loc->prm.min_weight;
+            T.phases = nullptr;
             T.dry_run = 1; T.wave_scores = reads->max_cigar_per_rec >= WAVE_SCORE_FROM ? 1u : 0u;
             ctx->timed(LCTY_K_TRANSFER, [&] {
                 hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
@@ -920,6 +980,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 T.new_cnt = d_new_cnt.p; T.new_words = d_new_words.p; T.rec_cursor = d_cursors.p; T.word_cursor = d_cursors.p + 1;
                 T.out_recs = xrecs; T.out_recs_cap = arena_recs; T.out_words = d_xwords.p; T.out_words_cap = arena_words;
                 T.out_rec_at = d_rec_at.p; T.out_word_at = d_word_at.p; T.flag = d_flag.p; T.dp_cells = d_cursors.p + 3; T.min_weight = loc->prm.min_weight;
+                T.phases = phases ? d_cursors.p + 4 : nullptr;
                 LCTY_HIP(hipMemsetAsync(d_cursors.p + 2, 0, sizeof(unsigned long long), s));
                 ctx->timed(LCTY_K_TRANSFER, [&] {
                     hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
@@ -946,6 +1007,26 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             d_cursors.download(&cells, 1, s, 3);
             LCTY_HIP(hipStreamSynchronize(s));
             reads->recover_dp_cells = cells;
+        }
+        if (phases) {
+            unsigned long long t[20];
+            d_cursors.download(t, 20, s, 4);
+            LCTY_HIP(hipStreamSynchronize(s));
+            unsigned long long sum = 0;
+            for (int k = 0; k < 10; k++) sum += t[k];
+            static const char* names[10] = {"set-up + wave scoring", "PrelimAlignments", "estimate / probe / offset / walk_init", "walk", "aligner (clipped ends)",
+                                            "assemble", "optimize", "scoring of the result", "push", "hand-over"};
+            for (int k = 0; k < 10; k++)
+                std::fprintf(stderr, "[transfer phases] %-40s %6.2f %%\n", names[k], sum ? 100.0 * static_cast<double>(t[k]) / static_cast<double>(sum) : 0.0);
+            auto rounds = [&](const char* what, unsigned long long ticks, unsigned long long n, unsigned long long lanes, unsigned long long cells) {
+                const double r = static_cast<double>(std::max<unsigned long long>(n, 1));
+                std::fprintf(stderr, "[transfer phases] %s: %.2f %% of all inside the aligner; %llu rounds, %.1f lanes with a stretch per round, largest matrix of a "
+                             "round %.1f cells on average, %.0f ticks per round\n", what, 100.0 * static_cast<double>(ticks) / static_cast<double>(sum), n,
+                             static_cast<double>(lanes) / r, static_cast<double>(cells) / r, static_cast<double>(ticks) / r);
+            };
+            rounds("assemble", t[10], t[11], t[16], t[17]);
+            rounds("optimize", t[12], t[13], t[14], t[15]);
+            std::fprintf(stderr, "[transfer phases] assemble rounds with a stretch beyond %u bases in some lane: %llu; ticks in all: %llu\n", xfer::DP_SMALL, t[18], sum);
         }
         if (n_recovered) *n_recovered = total_new;
         if (total_new == 0) return;

@@ -42,39 +42,67 @@ __device__ __forceinline__ uint32_t op_invert(uint32_t op) {                  //
     return (op == OP_I || op == OP_S) ? OP_D : (op == OP_D ? OP_I : op);
 }
 
-// Cigar under construction (cigar.rs:203-208): items {op, len}. The first `lds_n` items of a lane live in LDS (item i of lane l at
-// l_base[i * 64 + l]: conflict-free), the rest in the lane's global scratch — a transferred short-read CIGAR rarely has more, and
-// every push looks at the item before it
-constexpr uint32_t CIGAR_LDS_ITEMS = 12;
-// The LAST item of a CIGAR under construction lives in registers (`pend`): a push that extends it — most pushes of a walk do — is
-// an addition, and a push that starts a new item only STORES the finished one. Looking the last item up in the lane's scratch on
-// every push put a dependent global load (the lanes' CIGARs are 48 KB apart: an L2 miss each) into every step of every walk.
-// Readers of the items (get / n) call flush() first.
+// Cigar under construction (cigar.rs:203-208): items {op, len}, an item one word, length << 4 | operation (the BAM form, which is also
+// what leaves the kernel).
+// The LAST item lives in registers (`pend`): a push that extends it — most pushes of a walk do — is an addition, and a push that starts a
+// new item only hands the finished one on. Readers of the items (get / word / n) call flush() first.
+// Layout in the lane's scratch: CHUNKS of 16 items, 64 bytes, chunk c of lane l at t[c * 1024 + l * 16] — and a chunk is written at once:
+// the items of the chunk under construction are collected in LDS (`wb`, word k of lane l at wb[k * 64 + l]) and leave as four 16-byte
+// stores when the 16th arrives. (Rounds 3-4 had item i of lane l at t[i * 64 + l], stored one by one: the lanes of a wavefront walk
+// their transfers at their own pace, so every item was a 4-byte store into a 256-byte row of its own — 3 passes x 900 items x 64
+// lanes of partial-line writes per chunk of targets, 28 KB written per transfer for 11, and every pass waited on them.)
+// Only one CIGAR of a lane is under construction at a time (the walk's, then the assembled one, then the optimized one): they hand the
+// LDS buffer on — finish() writes the last, partial chunk out and lets go of it; from then on the CIGAR is read from global memory.
+constexpr uint32_t CIGAR_CHUNK = 16;
 struct DCigar {
-    // An item is one word, length << 4 | operation (the BAM form, which is also what leaves the kernel). Item i of lane l lies at
-    // t[i * 64] (t already offset by the lane): the CIGARs of the 64 lanes of a wavefront are INTERLEAVED like the aligner's arrays —
-    // the lanes walk their transfers in step, so their pushes fall into the same few rows of 256 bytes (full lines, written once)
-    // and their sequential passes (optimize, scoring, copy-out) read whole rows. Contiguous per lane (48 KB apart) every 8-byte
-    // store opened a line of its own that was evicted long before the lane had filled it (52 KB written per transfer for 12).
-    uint32_t* t;           // global part [cap] rows of 64 words
-    uint32_t* l;           // LDS part, already offset by the lane (stride 64), or nullptr
-    uint32_t lds_n;
+    uint32_t* t;           // global part: [cap / 16] chunks x 64 lanes x 16 words, already offset by the lane (lane * 16 words)
+    uint32_t* wb;          // LDS: the chunk under construction, already offset by the lane (stride 64); nullptr once finished
     uint32_t n, rlen, qlen, cap;
     uint2 pend; bool has_pend;                                               // the item behind item n - 1, not stored yet
     bool overflow;                                                           // items were dropped: the lengths are still right
-    __device__ void init(uint32_t* buf, uint32_t capacity, uint32_t* lds = nullptr) {
-        t = buf; cap = capacity; l = lds; lds_n = lds ? CIGAR_LDS_ITEMS : 0u; n = 0; rlen = qlen = 0; overflow = false;
+    __device__ void init(uint32_t* buf, uint32_t capacity, uint32_t* write_buffer) {
+        t = buf; cap = capacity; wb = write_buffer; n = 0; rlen = qlen = 0; overflow = false;
         pend = make_uint2(0, 0); has_pend = false;
     }
-    __device__ __forceinline__ uint32_t word(uint32_t i) const { return i < lds_n ? l[i * 64] : t[static_cast<size_t>(i) * 64]; }
+    __device__ __forceinline__ uint32_t* at(uint32_t i) const { return t + static_cast<size_t>(i >> 4) * (CIGAR_CHUNK * 64) + (i & 15u); }
+    __device__ __forceinline__ bool in_wb(uint32_t i) const { return wb != nullptr && i >= (n & ~15u); }
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return in_wb(i) ? wb[(i & 15u) * 64] : *at(i); }
     __device__ __forceinline__ uint2 get(uint32_t i) const { const uint32_t w = word(i); return make_uint2(w & 15u, w >> 4); }
     __device__ __forceinline__ void set(uint32_t i, uint2 v) {
         const uint32_t w = (v.y << 4) | v.x;
-        if (i < lds_n) l[i * 64] = w; else t[static_cast<size_t>(i) * 64] = w;
+        if (in_wb(i)) wb[(i & 15u) * 64] = w; else *at(i) = w;
+    }
+    __device__ __forceinline__ void store_chunk(uint32_t first) {                // the 16 words of the LDS buffer -> chunk first / 16
+        uint4* dst = reinterpret_cast<uint4*>(at(first));
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) dst[q] = make_uint4(wb[(4 * q) * 64], wb[(4 * q + 1) * 64], wb[(4 * q + 2) * 64], wb[(4 * q + 3) * 64]);
+    }
+    __device__ __forceinline__ void append(uint32_t w) {                         // n < cap
+        wb[(n & 15u) * 64] = w; n++;
+        if ((n & 15u) == 0) store_chunk(n - CIGAR_CHUNK);
+    }
+    // the last item taken off again (align_ends::<RIGHT>); stepping back over a chunk boundary brings that chunk back into the buffer
+    __device__ __forceinline__ uint2 pop_back() {
+        n--;
+        if ((n & 15u) == 15u) {
+            const uint4* src = reinterpret_cast<const uint4*>(at(n & ~15u));
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint4 v = src[q];
+                wb[(4 * q) * 64] = v.x; wb[(4 * q + 1) * 64] = v.y; wb[(4 * q + 2) * 64] = v.z; wb[(4 * q + 3) * 64] = v.w;
+            }
+        }
+        const uint32_t w = wb[(n & 15u) * 64];
+        return make_uint2(w & 15u, w >> 4);
     }
     __device__ void clear() { n = 0; rlen = qlen = 0; has_pend = false; }
     __device__ __forceinline__ void flush() {
-        if (has_pend) { if (n < cap) set(n++, pend); else overflow = true; has_pend = false; }
+        if (has_pend) { if (n < cap) append((pend.y << 4) | pend.x); else overflow = true; has_pend = false; }
+    }
+    // nothing more will be pushed: everything to global memory, the LDS buffer is free for the lane's next CIGAR
+    __device__ __forceinline__ void finish() {
+        flush();
+        if (wb) { if (n & 15u) store_chunk(n & ~15u); wb = nullptr; }
     }
     __device__ __forceinline__ void push_raw(uint2 it) { flush(); pend = it; has_pend = true; }          // lengths untouched
     __device__ __forceinline__ void push_unchecked(uint32_t op, uint32_t len) {   // cigar.rs:343-352
@@ -89,6 +117,40 @@ struct DCigar {
         push_raw(make_uint2(op, len));
     }
 };
+
+// The next items of a lane's finished CIGAR, read ahead into LDS. A pass over a CIGAR in the lane's scratch (assemble, optimize) paid one
+// trip to the L2 per item — every lane of the wavefront at its own item, nothing else to do meanwhile, 1.5-2.5 us each next to the
+// stores of the 3 000 other wavefronts; a window is filled by ITEM_WIN loads that are in flight together. Filled by all lanes of a
+// wavefront at the same point of the code (their positions differ, their pace does not): word k of lane l at w[k * 64 + l].
+constexpr uint32_t ITEM_WIN = 16;
+struct ItemWindow {
+    uint32_t* w;           // LDS, already offset by the lane
+    uint32_t base, end;    // the window holds the items [base, end)
+    __device__ __forceinline__ void init(uint32_t* lds_lane) { w = lds_lane; base = end = 0; }
+    __device__ __forceinline__ bool has(uint32_t i) const { return i - base < end - base; }
+    __device__ __forceinline__ void fill(const DCigar& c, uint32_t from) {
+        base = from; end = min(from + ITEM_WIN, c.n);
+        uint32_t v[ITEM_WIN];
+#pragma unroll
+        for (uint32_t k = 0; k < ITEM_WIN; k++) v[k] = from + k < c.n ? c.word(from + k) : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < ITEM_WIN; k++) w[k * 64] = v[k];
+    }
+    __device__ __forceinline__ uint2 get(uint32_t i) const { const uint32_t x = w[(i - base) * 64]; return make_uint2(x & 15u, x >> 4); }
+    // item i of `c`: out of the window where it holds it
+    __device__ __forceinline__ uint2 item(const DCigar& c, uint32_t i) const { return has(i) ? get(i) : c.get(i); }
+};
+// items [from, to) of `src` appended to `dst` as they are (push_raw), eight loads in flight at a time (one by one every load waited for
+// the store in front of it)
+__device__ inline void copy_items(const DCigar& src, uint32_t from, uint32_t to, DCigar& dst) {
+    for (uint32_t k = from; k < to; k += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) v[u] = k + u < to ? src.word(k + u) : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) if (k + u < to) dst.push_raw(make_uint2(v[u] & 15u, v[u] >> 4));
+    }
+}
 
 // the read in the orientation of the alignment (MateData::get_seq, locs.rs:87-93) and the target haplotype, as ASCII
 struct Seqs {
@@ -109,8 +171,8 @@ struct Seqs {
 // then touch the same element index at the same time, i.e. one contiguous line instead of 64 scattered ones
 constexpr uint32_t LANE_STRIDE = 64;                                  // lane stride of the interleaved arrays
 struct Scratch {
-    uint32_t* cig_a;       // [cigar_cap] x LANE_STRIDE words
-    uint32_t* cig_b;       // [cigar_cap] x LANE_STRIDE words (optimize)
+    uint32_t* cig_a;       // [cigar_cap / 16] chunks x LANE_STRIDE x 16 words (DCigar)
+    uint32_t* cig_b;       // the same (assemble, optimize)
     uint8_t* ops;          // [2 * dp_dim + 4] x LANE_STRIDE            aligner output, reversed
     uint8_t* dirs;         // [dp_cells] x LANE_STRIDE
     uint4* jobs;           // [cigar_cap / 2 + 8] x LANE_STRIDE: {i1, n, j1, m} of the stretches between anchors a walk left for the aligner
@@ -127,8 +189,8 @@ __device__ inline Scratch scratch_at(uint8_t* base, uint32_t lane, const Limits&
     Scratch s;
     const size_t cig = static_cast<size_t>(lim.cigar_cap) * 4, row = (static_cast<size_t>(lim.dp_dim) + 1) * 12;
     const size_t nops = (2 * static_cast<size_t>(lim.dp_dim) + 4 + 15) & ~size_t(15);
-    s.cig_a = reinterpret_cast<uint32_t*>(base) + lane; base += 64 * cig;
-    s.cig_b = reinterpret_cast<uint32_t*>(base) + lane; base += 64 * cig;
+    s.cig_a = reinterpret_cast<uint32_t*>(base) + lane * CIGAR_CHUNK; base += 64 * cig;        // cigar_cap is a multiple of the chunk
+    s.cig_b = reinterpret_cast<uint32_t*>(base) + lane * CIGAR_CHUNK; base += 64 * cig;
     s.rows = reinterpret_cast<int32_t*>(base) + lane; base += 64 * 2 * row;
     s.lastcol = reinterpret_cast<int32_t*>(base) + lane; base += 64 * row;
     s.ops = base + lane; base += 64 * nops;
@@ -274,10 +336,114 @@ __device__ inline int dp_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t 
 
 __device__ __forceinline__ uint32_t op_from_char(uint8_t ch) { return ch == '=' ? OP_EQ : ch == 'X' ? OP_X : ch == 'I' ? OP_I : OP_D; }
 
+// dp_align for the stretches the rule leaves between two anchors of a long read — a handful of bases on either side — end to end and
+// without a match bonus (the global aligner). Same recurrence, same tie rules, same walk back as dp_align above, but nothing goes
+// through memory: the previous row of the three matrices lives in registers (the column loop is unrolled, a lane's columns beyond its m
+// are skipped), a row of direction bytes is one 64-bit word, the rows are kept in eight of them (insert / extract by select), the bases
+// of both stretches are packed into a register each (all their loads in flight together), and the operations leave as 2-bit codes
+// (0 '=', 1 'X', 2 'I', 3 'D'; operation t of the REVERSED alignment in bits 2t..2t+1 of *ops2). dp_align keeps rows, directions and
+// operations in the lane's scratch: seven memory operations per cell, each cell behind the stores of the one before it.
+// (Tried: values times four + rank so that "smallest of three, ties in order, and which" is one v_min3_u32 — half the vector
+// instructions per cell, 2.5 ms MORE for the launch: the kernel does not wait for this arithmetic.)
+constexpr uint32_t DP_SMALL = 7;                                             // both stretches at most this long (and at least one base)
+__device__ inline int dp_align_small(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, Scratch& sc, uint32_t* n_ops, uint32_t* ops2) {
+    constexpr uint32_t W8 = DP_SMALL + 1;
+    sc.cells += static_cast<unsigned long long>(n + 1) * (m + 1);
+    // an index beyond the stretch reads the stretch's last base again, unused
+    uint64_t qpack = 0, rpack = 0;
+    for (uint32_t b = 0; b < m; b++) qpack |= static_cast<uint64_t>(S.q(j1 + b)) << (8 * b);
+    for (uint32_t a = 0; a < n; a++) rpack |= static_cast<uint64_t>(S.r(i1 + a)) << (8 * a);
+    int32_t pm[W8], pd[W8], pi[W8];                                          // row a - 1 (then row a, column by column)
+    uint64_t drow[W8];
+#pragma unroll
+    for (uint32_t b = 0; b < W8; b++) { pm[b] = pd[b] = pi[b] = INF32; drow[b] = 0; }
+    for (uint32_t a = 0; a <= n; a++) {
+        const uint32_t rbase = a > 0 ? static_cast<uint32_t>(rpack >> (8 * (a - 1))) & 0xFFu : 0u;
+        int32_t lm = INF32, ld = INF32, li = INF32;                            // cell (a, b - 1)
+        int32_t gm = INF32, gd = INF32, gi = INF32;                            // cell (a - 1, b - 1)
+        uint64_t row = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < W8; b++) {
+            if (b <= m) {
+                int32_t cm = INF32, cd = INF32, ci = INF32;
+                uint32_t dm = 3, dd = 0, di = 0;
+                const int32_t um = a > 0 ? pm[b] : INF32, ud = a > 0 ? pd[b] : INF32, ui = a > 0 ? pi[b] : INF32;      // cell (a - 1, b)
+                if (a == 0 && b == 0) cm = 0;
+                if (a > 0 && b > 0) {
+                    const int32_t best = min(gm, min(gd, gi));
+                    if (best < INF32) {
+                        const uint32_t qbase = static_cast<uint32_t>(qpack >> (8 * (b - 1))) & 0xFFu;
+                        const int32_t v = best + (rbase == qbase ? 0 : PEN_X);
+                        if (v < cm) { cm = v; dm = gm == best ? 0u : (gd == best ? 1u : 2u); }
+                    }
+                }
+                if (a > 0) {
+                    int32_t v = min(um, ui) + PEN_O + PEN_E;
+                    if (ud + PEN_E < v) v = ud + PEN_E;
+                    if (v < INF32) { cd = v; dd = (ud + PEN_E == v) ? 1u : (um <= ui ? 0u : 2u); }
+                }
+                if (b > 0) {
+                    int32_t v = min(lm, ld) + PEN_O + PEN_E;
+                    if (li + PEN_E < v) v = li + PEN_E;
+                    if (v < INF32) { ci = v; di = (li + PEN_E == v) ? 2u : (lm <= ld ? 0u : 1u); }
+                }
+                pm[b] = cm; pd[b] = cd; pi[b] = ci;
+                row |= static_cast<uint64_t>(dm | (dd << 2) | (di << 4)) << (8 * b);
+                lm = cm; ld = cd; li = ci;
+                gm = um; gd = ud; gi = ui;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < W8; k++) drow[k] = a == k ? row : drow[k];
+    }
+    int32_t em = INF32, ed = INF32, ei = INF32;
+#pragma unroll
+    for (uint32_t b = 0; b < W8; b++) if (b == m) { em = pm[b]; ed = pd[b]; ei = pi[b]; }
+    const int32_t best = min(em, min(ed, ei));
+    if (best >= INF32 || best > MAX_STEPS) return DP_DROPPED;
+    uint32_t k = 0, ops = 0;
+    uint32_t a = n, b = m;
+    uint32_t st = (em <= ed && em <= ei) ? 0u : (ed <= ei ? 1u : 2u);
+    while (a > 0 || b > 0) {
+        uint64_t row = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < W8; r++) row = a == r ? drow[r] : row;
+        const uint32_t d = static_cast<uint32_t>(row >> (8 * b)) & 0xFFu;
+        if (st == 0) {
+            const bool eq = (static_cast<uint32_t>(rpack >> (8 * (a - 1))) & 0xFFu) == (static_cast<uint32_t>(qpack >> (8 * (b - 1))) & 0xFFu);
+            ops |= (eq ? 0u : 1u) << (2 * k); k++;
+            st = d & 3u; a--; b--;
+        } else if (st == 1) {
+            ops |= 3u << (2 * k); k++;
+            const uint32_t dd = (d >> 2) & 3u;
+            st = dd == 1 ? 1u : (dd == 0 ? 0u : 2u);
+            a--;
+        } else {
+            ops |= 2u << (2 * k); k++;
+            const uint32_t di = (d >> 4) & 3u;
+            st = di == 2 ? 2u : (di == 0 ? 0u : 1u);
+            b--;
+        }
+    }
+    *n_ops = k; *ops2 = ops;
+    return best;
+}
+
 // Aligner::align::<LEFT_CLIPPING> (wfa.rs:254-299). semiglobal: 0 global aligner, 1 LEFT, 2 RIGHT free ends
 __device__ inline int aligner_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, int semiglobal, bool left_clipping, DCigar& cg,
                                     Scratch& sc) {
     uint32_t n_ops = 0;
+    // (the same acceptance as dp_align's: a level whose scratch would refuse the stretch refuses it here too)
+    if (semiglobal == 0 && !left_clipping && n >= 1 && m >= 1 && n <= DP_SMALL && m <= DP_SMALL && n <= sc.lim.dp_dim && m <= sc.lim.dp_dim && (n + 1) * (m + 1) <= sc.lim.dp_cells) {
+        uint32_t ops2 = 0;
+        const int pen = dp_align_small(S, i1, n, j1, m, sc, &n_ops, &ops2);
+        if (pen == DP_DROPPED) return align_simple(S, i1, n, j1, m, cg);
+        for (uint32_t t = n_ops; t-- > 0;) {
+            const uint32_t c = (ops2 >> (2 * t)) & 3u;
+            cg.push_checked(c == 0 ? OP_EQ : c == 1 ? OP_X : c == 2 ? OP_I : OP_D, 1);
+        }
+        return -pen;
+    }
     const int pen = dp_align(S, i1, n, j1, m, semiglobal ? max(1, PEN_X / 2) : 0, semiglobal, sc, &n_ops);
     // DP_TOO_BIG: a stand-in that consumes both stretches completely, as any end-to-end alignment does — the caller looks at sc.big
     if (pen == DP_DROPPED || pen == DP_TOO_BIG) return align_simple(S, i1, n, j1, m, cg);
@@ -331,33 +497,42 @@ struct Job { uint32_t i1, n, j1, m; int semiglobal; bool left_clipping; };
 // start / length, query start / length) and the caller runs smart_align for all lanes that hold one, at one call site.
 struct OptState {
     DCigar nc;
+    ItemWindow win;        // items of `self` from the last anchor on
     uint32_t i, j, qpos1, rpos1, qpos2, rpos2, flag, stage;
     bool have;
 };
-__device__ inline void opt_init(OptState& o, DCigar& self, Scratch& sc) {
-    self.flush();
-    o.nc.init(sc.cig_free, sc.lim.cigar_cap);
+__device__ inline void opt_init(OptState& o, DCigar& self, Scratch& sc, uint32_t* lds_win, uint32_t* lds_wb) {
+    self.finish();                                                            // read from global memory from here on; the new CIGAR takes the buffer
+    o.win.init(lds_win);
+    o.nc.init(sc.cig_free, sc.lim.cigar_cap, lds_wb);
     o.i = o.j = 0; o.qpos1 = o.rpos1 = o.qpos2 = o.rpos2 = 0; o.flag = 0; o.stage = 0; o.have = false;
 }
 __device__ __forceinline__ void opt_begin_copy(OptState& o, const DCigar& self) {
-    if (!o.have) { o.have = true; for (uint32_t k = 0; k < o.i; k++) o.nc.push_raw(self.get(k)); o.nc.qlen = o.qpos1; o.nc.rlen = o.rpos1; }
+    if (!o.have) { o.have = true; copy_items(self, 0, o.i, o.nc); o.nc.qlen = o.qpos1; o.nc.rlen = o.rpos1; }
 }
 __device__ __forceinline__ void opt_past_anchor(OptState& o, const DCigar& self, uint32_t op, uint32_t len) {
     o.qpos2 += len; o.rpos2 += len; o.qpos1 = o.qpos2; o.rpos1 = o.rpos2; o.flag = 0;
     if (o.have) {
-        for (uint32_t k = o.i; k < o.j; k++) o.nc.push_raw(self.get(k));
+        for (uint32_t k = o.i; k < o.j; k++) o.nc.push_raw(o.win.item(self, k));
         o.nc.push_checked(op, len);
         o.nc.qlen = o.qpos2; o.nc.rlen = o.rpos2;
     }
     o.i = o.j + 1;
     o.j++;
 }
-// true: align reference [job.i1, +job.n) with query [job.j1, +job.m) into o.nc (smart_align without a maximum gap), then call again
+// true: align reference [job.i1, +job.n) with query [job.j1, +job.m) into o.nc (smart_align without a maximum gap), then call again;
+// false: the pass is complete, or (opt_wants_items) it stands at an item its window does not hold — fill, then call again
+__device__ __forceinline__ bool opt_wants_items(const OptState& o, const DCigar& self) { return o.stage == 0 && o.j < self.n && !o.win.has(o.j); }
+__device__ __forceinline__ void opt_fill(OptState& o, const DCigar& self) {
+    // from the last anchor, so that the items a stretch copies are in the window too — unless the stretch is as long as the window
+    o.win.fill(self, o.j - o.i < ITEM_WIN - 4 ? o.i : o.j);
+}
 __device__ inline bool opt_step(OptState& o, DCigar& self, uint32_t max_gap, uint32_t anchor_size, Job& job) {
     for (;;) {
         if (o.stage == 0) {                                                   // over the items
             if (o.j >= self.n) { o.stage = 2; continue; }
-            const uint2 item_j = self.get(o.j);
+            if (!o.win.has(o.j)) return false;                                // the caller fills the windows of all lanes (opt_wants_items)
+            const uint2 item_j = o.win.get(o.j);
             const uint32_t op = item_j.x, len = item_j.y;
             const bool cq = cons_q(op), cr = cons_r(op);
             if (cq && cr && len >= anchor_size) {
@@ -376,7 +551,7 @@ __device__ inline bool opt_step(OptState& o, DCigar& self, uint32_t max_gap, uin
             }
         } else if (o.stage == 1) {                                            // back from the aligner, in front of the anchor item j
             o.i = o.j;
-            const uint2 item_j = self.get(o.j);
+            const uint2 item_j = o.win.item(self, o.j);
             opt_past_anchor(o, self, item_j.x, item_j.y);
             o.stage = 0;
         } else if (o.stage == 2) {                                            // what is behind the last anchor
@@ -393,10 +568,10 @@ __device__ inline bool opt_step(OptState& o, DCigar& self, uint32_t max_gap, uin
             o.stage = 4;
         } else {
             if (o.have) {
-                for (uint32_t k = o.i; k < self.n; k++) o.nc.push_raw(self.get(k));
-                o.nc.flush();
+                copy_items(self, o.i, self.n, o.nc);
+                o.nc.finish();
                 // self.tuples = new_cigar.tuples (lengths stay): the new items stay where they are, `self` looks there from now on
-                self.t = o.nc.t; self.l = nullptr; self.lds_n = 0;
+                self.t = o.nc.t; self.wb = nullptr;
                 self.n = o.nc.n;
                 self.overflow |= o.nc.overflow;
             }
@@ -419,12 +594,15 @@ __device__ inline uint32_t double_move(uint32_t op1, uint32_t op2, uint32_t& pos
 }
 
 // the read's own CIGAR as it is stored: raw BAM words, hard clips at the ends count as soft ones (cigar.rs:309-320)
+constexpr uint32_t SRC_LDS_WORDS = 1024;
 struct SrcCigar {
     const uint32_t* raw; uint32_t n; bool hard_to_soft;
+    const uint32_t* lds; uint32_t lds_n;                   // the first lds_n words once more, in LDS (shared by the lanes)
     __device__ __forceinline__ uint2 item(uint32_t i) const {
-        uint32_t op = raw[i] & 15u;
+        const uint32_t w = i < lds_n ? lds[i] : raw[i];
+        uint32_t op = w & 15u;
         if (hard_to_soft && op == OP_H && (i == 0 || i + 1 == n)) op = OP_S;
-        return make_uint2(op, raw[i] >> 4);
+        return make_uint2(op, w >> 4);
     }
     __device__ uint32_t ref_len() const {
         uint32_t r = 0;
@@ -513,9 +691,14 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
                     // smart_align (wfa.rs:301-347) without a maximum gap; only the dynamic programme is handed out
                     const uint32_t jump1 = w.pos2 - w.last2, jump2 = w.pos1 - w.last1;
                     if (jump1 > 0 && jump2 > 0) {
-                        const uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;      // wfa.rs:212
+                        constexpr uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;  // wfa.rs:212
                         if (jump1 == jump2 && jump1 <= safe_mismatch) {
-                            for (uint32_t t = 0; t < jump1; t++) out.push_checked(S.r(w.last2 + t) == S.q(w.last1 + t) ? OP_EQ : OP_X, 1);
+                            // (the bases of the whole stretch first — at most three of each — then the pushes: their stores would hold the loads up)
+                            bool eq[safe_mismatch];
+#pragma unroll
+                            for (uint32_t t = 0; t < safe_mismatch; t++) eq[t] = S.r(w.last2 + min(t, jump1 - 1)) == S.q(w.last1 + min(t, jump1 - 1));
+#pragma unroll
+                            for (uint32_t t = 0; t < safe_mismatch; t++) if (t < jump1) out.push_checked(eq[t] ? OP_EQ : OP_X, 1);
                         } else {
                             // A stretch for the aligner between two anchors. Nothing of the walk depends on how it aligns (an end-to-end
                             // alignment consumes both stretches completely, whatever its operations): the stretch is noted, a marker takes
@@ -573,7 +756,7 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
             uint32_t soft = 0;
             out.flush();
             while (out.n && out.get(out.n - 1).x != OP_EQ) {                    // pop_if(op != Equal)
-                const uint2 it = out.get(--out.n);
+                const uint2 it = out.pop_back();
                 if (cons_q(it.x)) { out.qlen -= it.y; soft += it.y; }
                 if (cons_r(it.x)) out.rlen -= it.y;
             }
@@ -587,15 +770,33 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
 
 // Cigar::optimize (MAX_OPTIMIZATION_GAP 20, OPTIMIZATION_ANCHOR 5) + boundary_ins_to_soft (cigar.rs:554-561) of the finished transfers
 // of a wavefront: `mine` = this lane has one. The lanes scan their CIGARs; those that stand in front of a stretch call smart_align at one site.
-__device__ inline void optimize_and_finish(bool mine, DCigar& out, const Seqs& S, Scratch& sc) {
+// (diag: developer build, four counters — ticks inside smart_align, rounds, lanes with a stretch, largest matrix of a round)
+__device__ inline void optimize_and_finish(bool mine, DCigar& out, const Seqs& S, Scratch& sc, uint32_t* lds_win, uint32_t* lds_wb,
+                                           unsigned long long* diag = nullptr) {
     OptState o;
     Job job;
     bool active = mine;
-    if (mine) opt_init(o, out, sc);
+    if (mine) opt_init(o, out, sc, lds_win, lds_wb);
     do {
-        const bool need = active && opt_step(o, out, 20, 5, job);
-        if (active && !need) active = false;
+        // a round: every lane that is scanning reads its next items (all lanes' loads in flight together) and scans on to a stretch, the end
+        // of its window or the end of the CIGAR; the lanes that stand in front of a stretch call smart_align (see the assemble loop)
+        bool need = false;
+        if (active) {
+            need = opt_step(o, out, 20, 5, job);
+            if (!need && !opt_wants_items(o, out)) active = false;
+        }
+        if (active && !need) opt_fill(o, out);                                // at the end of its window (the first round: of the empty one)
+        unsigned long long t0 = 0;
+        if (diag) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         if (need) smart_align(S, job.i1, job.i1 + job.n, job.j1, job.j1 + job.m, 0xFFFFFFFFu, o.nc, sc);
+        if (diag) {
+            __builtin_amdgcn_sched_barrier(0);
+            diag[0] += __builtin_amdgcn_s_memtime() - t0; diag[1]++;
+            diag[2] += static_cast<unsigned long long>(__popcll(__ballot(need)));
+            uint32_t mx = need ? (job.n + 1) * (job.m + 1) : 0u;
+            for (int k = 32; k > 0; k >>= 1) mx = max(mx, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mx), k)));
+            diag[3] += mx;
+        }
     } while (__any(active));
     if (mine && out.n) {
         const uint2 first = out.get(0);

@@ -1,5 +1,5 @@
 """Developer measurement: lcty_recover_alignments on a batch of synthetic 10-kb ONT reads x 256 alleles (wall vs kernel time), once per
-knob setting:  python3 scripts/ont_recover_probe.py [reads] [name=value[,name=value] ...]; the products of every setting must equal
+knob setting:  python3 scripts/ont_recover_probe.py [--diag] [reads] [name=value[,name=value] ...]; the products of every setting must equal
 those of the first (statuses, matrix)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,9 @@ def main():
     if "--lib" in args:
         from locityper_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args[args.index("--lib") + 1]); del args[args.index("--lib"):args.index("--lib") + 2]
+    if "--diag" in args:                                          # the developer build: knob transfer_phases exists there only
+        from locityper_amd import _lib
+        _lib.use_diag_build(); args.remove("--diag")
     nont = int(args[0]) if args and args[0].isdigit() else 6144
     settings = [a for a in args if "=" in a] or ["default"]
     A = 256
