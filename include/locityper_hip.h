@@ -235,7 +235,8 @@ int32_t lcty_ctx_synchronize(lcty_ctx* ctx);
  *       keeping the first pass' products in LDS (what loci of more than 310 alleles get anyway);   "score_timing"   1: the lean kernel's
  *       timed build, shader-clock ticks per phase on stderr;   "comm_fail_at"   k: the k-th status agreement of a multi-GPU call fails on this rank (tests of
  *       the error path of the exchanges);   "prefilter_gram_cols"   room for that many level columns per read (default 6; too few: the
- *       f64 kernel takes the batch);   "prefilter_gram_levels"   levels of a row the contraction takes (<= 16; rows with more go
+ *       f64 kernel takes the batch);   "queue_early_head"   0: lcty_solve_queue makes the head of a locus after the chains of the locus before (default 1:
+ *       beside them);   "prefilter_gram_levels"   levels of a row the contraction takes (<= 16; rows with more go
  *       through the f64 kernel).
  * value < 0 restores the default; an unknown name is LCTY_ERR_INVALID_INPUT. None of them changes a result beyond the last bits of
  * an f64 sum (the order in which a chain's likelihood or a genotype's score is added up). */
@@ -624,7 +625,10 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
 /* The loop of `locityper genotype` over its loci (analyze_locus one after the other, command/genotype.rs:1331-1351) as a queue on one
  * GPU: for every entry lcty_score_reads + lcty_solve. Loci are independent, so the last stage of entry i (by default the annealing
  * attempts: a few hundred long serial chains on a few per cent of the device) runs on a second stream of the context, from a second
- * host thread, while entry i + 1 is scored, prefiltered and greedily solved. out[i] equals what lcty_solve gives for entry i alone.
+ * host thread, while entry i + 1 is greedily solved — and what comes before the chains of entry i + 2 (its scores, run_filter, the cut,
+ * the location table) is issued on a third stream, by a third host thread, as soon as the last stage of entry i has ended, beside the
+ * greedy chains of entry i + 1 (knob "queue_early_head" 0: on the main stream after those chains, as lcty_solve_queue_fed does).
+ * out[i] equals what lcty_solve gives for entry i alone.
  * All batches share one context; neighbours in the queue are different batches of different lcty_locus objects (a batch may come
  * again later in the queue: it is scored again). master_seeds[n_batches]; priors NULL or [n_batches] pointers (NULL = no priors). */
 int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages,

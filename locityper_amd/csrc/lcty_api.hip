@@ -45,7 +45,7 @@ int32_t lcty_ctx_set_knob(lcty_ctx* ctx, const char* name, int64_t value) {
                                             "depth_table_start", "solve_budget_mb", "solve_chains_per_wave", "solve_extra_start", "solve_lds_weights",
                                             "anneal_lds_weights", "contig_info_slide", "gather_chunk_mb", "prefilter_gram", "prefilter_gram_cols",
                                             "prefilter_gram_levels", "comm_fail_at", "score_lean", "arena_cap_pct", "exact_threads", "host_threads",
-                                            "score_lean_keep", "score_lean_two",
+                                            "score_lean_keep", "score_lean_two", "queue_early_head",
 #ifdef LCTY_DIAG
                                             // the developer build (make DIAG=1): traces, in-kernel timing, kernel forms under measurement
                                             "solve_stats", "queue_trace", "map_trace", "exact_trace", "solve_greedy_form", "solve_anneal_timing", "score_timing",
@@ -103,7 +103,9 @@ void lcty_ctx_destroy(lcty_ctx* ctx) {
     for (auto& t : ctx->timers) for (auto& pr : t.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->gate.ev) (void)hipEventDestroy(ctx->gate.ev);
+    if (ctx->gate.init_ev) (void)hipEventDestroy(ctx->gate.init_ev);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->fore) { (void)hipStreamSynchronize(ctx->fore); (void)hipStreamDestroy(ctx->fore); }
     (void)hipStreamDestroy(ctx->stream.main);
     delete ctx;
 }

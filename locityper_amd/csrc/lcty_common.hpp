@@ -189,10 +189,23 @@ struct lcty_ctx {
         uint64_t epoch = 0;             // greedy launches announced so far (or released by the queue)
         uint64_t target = 0;            // what the running tail waits for (0: nothing)
         hipEvent_t ev = nullptr;        // recorded on the main stream just before the greedy loop is launched
+        // ... and the other way round for the two INITIALISATIONS: the one of the last stage of locus i (400 chains, 8 ms) goes first, the one
+        // of locus i + 1's greedy chains (5 000, 57 ms, on the critical path) behind it. Side by side the long one took 73 ms; beside the
+        // greedy LOOP the short one took 216 ms (the CU's L1 path is full of the loop's gathers).
+        uint64_t tails_started = 0;     // last stages handed to the side stream so far
+        uint64_t tail_inits = 0;        // ... whose initialisation has been issued (or which have ended)
+        hipEvent_t init_ev = nullptr;   // recorded on the side stream behind that initialisation
     } gate;
     hipStream_t side_stream() {
         if (!side) LCTY_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
         return side;
+    }
+    // Third stream: everything of the NEXT locus that comes before its chains — scores, run_filter, the cut, the location table — while the
+    // greedy chains of the current locus have the main stream (one wavefront per SIMD and most of the LDS, but idle issue slots and 35 KB).
+    hipStream_t fore = nullptr;
+    hipStream_t fore_stream() {
+        if (!fore) LCTY_HIP(hipStreamCreateWithFlags(&fore, hipStreamNonBlocking));
+        return fore;
     }
     // The chunks of a batch travel on a stream of their own (lcty_reads_append*): a host thread can fill the batch of the NEXT
     // locus over PCIe while the kernels of the current one have the other two streams (lcty_solve_queue_fed).

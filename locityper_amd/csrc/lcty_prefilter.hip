@@ -14,7 +14,9 @@
 namespace lcty {
 
 constexpr uint32_t PT = 128;        // alleles per tile side
-constexpr uint32_t RC = 32;         // reads per LDS stage
+constexpr uint32_t RC = 32;         // reads per LDS stage (and the unit the read range is split in)
+constexpr uint32_t RC_BESIDE = 8;   // the same kernel with a quarter of the LDS (17 KB): the head of the NEXT locus of a queue runs beside the greedy
+                                    // chains of the current one, whose two workgroups per CU leave 35 KB (lcty_solve_queue); same sums in the same order
 constexpr uint32_t ROWD = PT + 8;   // doubles per LDS row: +16 B after every 32 doubles (bank spread for ds_read_b128)
 constexpr uint32_t DIAG_BLOCKS = 136;   // 8x8 blocks (bi <= bj) of a diagonal tile: 16*17/2
 
@@ -31,12 +33,13 @@ __device__ __forceinline__ double vmax(double a, double b) {
 // genotype index of the multiset {i <= j} among all C(A+1, 2) (lexicographic; ext/vec.rs:298-339)
 __host__ __device__ inline uint64_t gt_index(uint64_t i, uint64_t j, uint64_t A) { return i * A - i * (i - 1) / 2 + (j - i); }
 
+template <uint32_t RCT>
 __global__ __launch_bounds__(256) void prefilter_tile_kernel(const double* __restrict__ M, uint64_t n_reads, uint32_t A,
                                                              uint32_t n_tiles, uint64_t reads_per_split,
                                                              double* __restrict__ partials, uint64_t G) {
     extern __shared__ __align__(16) double lds[];
     double* lds_a = lds;
-    double* lds_b = lds + RC * ROWD;
+    double* lds_b = lds + RCT * ROWD;
     const uint32_t tid = threadIdx.x;
     // tile pair (I <= J) from the linear index
     uint32_t tp = blockIdx.x, I = 0;
@@ -64,10 +67,10 @@ __global__ __launch_bounds__(256) void prefilter_tile_kernel(const double* __res
     const uint32_t colI = I * PT, colJ = J * PT;
     if (diag) lds_b = lds_a;
 
-    for (uint64_t r0 = r_begin; r0 < r_end; r0 += RC) {
+    for (uint64_t r0 = r_begin; r0 < r_end; r0 += RCT) {
         // stage RC rows x 128 columns of both tiles (zero fill outside the matrix: max(0,0)+acc == acc); every load of
         // the stage is issued before the first LDS write
-        constexpr uint32_t NT = RC * PT / 256, HALF = NT / 2;
+        constexpr uint32_t NT = RCT * PT / 256, HALF = NT / 2;
 #pragma unroll
         for (uint32_t h = 0; h < 2; h++) {
             double va[HALF], vb[HALF];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void prefilter_tile_kernel(const double* __res
             const double* pa = lds_a + swz(bi * 8);
             const double* pb = lds_b + swz(bj * 8);
 #pragma unroll 2
-            for (uint32_t rr = 0; rr < RC; rr++) {
+            for (uint32_t rr = 0; rr < RCT; rr++) {
                 double a[8], b[8];
 #pragma unroll
                 for (int x = 0; x < 8; x++) { a[x] = pa[rr * ROWD + x]; b[x] = pb[rr * ROWD + x]; }
@@ -179,13 +182,19 @@ void launch_prefilter_tile(lcty_reads* reads, const double* M, uint64_t R, doubl
     if (per == 0) per = RC;
     splits = std::max<uint64_t>(1, (R + per - 1) / per);
     if (reads->d_partials.n < splits * G) reads->d_partials.alloc(splits * G);
-    const size_t lds = 2 * RC * ROWD * sizeof(double);
+    // the calling thread works on the context's fore stream: beside the greedy chains of another locus (RC_BESIDE)
+    const bool beside = ctx->fore != nullptr && static_cast<hipStream_t>(ctx->stream) == ctx->fore;
+    const size_t lds = 2 * (beside ? RC_BESIDE : RC) * ROWD * sizeof(double);
     // per device and cheap: no process-wide "already done" flag (contexts on several GPUs, several host threads)
-    LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_tile_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    LCTY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prefilter_tile_kernel<RC>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(2 * RC * ROWD * sizeof(double))));
     ctx->timed(LCTY_K_PREFILTER, [&] {
-        hipLaunchKernelGGL(prefilter_tile_kernel, dim3(n_tp, static_cast<uint32_t>(splits)), dim3(256), lds, ctx->stream,
-                           M, R, A, n_tiles, per, reads->d_partials.p, G);
+        if (beside)
+            hipLaunchKernelGGL(prefilter_tile_kernel<RC_BESIDE>, dim3(n_tp, static_cast<uint32_t>(splits)), dim3(256), lds, ctx->stream,
+                               M, R, A, n_tiles, per, reads->d_partials.p, G);
+        else
+            hipLaunchKernelGGL(prefilter_tile_kernel<RC>, dim3(n_tp, static_cast<uint32_t>(splits)), dim3(256), lds, ctx->stream,
+                               M, R, A, n_tiles, per, reads->d_partials.p, G);
         hipLaunchKernelGGL(prefilter_reduce_kernel, dim3(static_cast<uint32_t>((G + 255) / 256)), dim3(256), 0, ctx->stream,
                            reads->d_partials.p, static_cast<uint32_t>(splits), G, static_cast<const double*>(nullptr),
                            d_scores_out);

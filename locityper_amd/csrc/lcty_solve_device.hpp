@@ -188,7 +188,11 @@ void ensure_solver_tables(lcty_reads* reads);                              // lo
 void ensure_depth_table(lcty_locus* loc, uint64_t want);                   // extended depth table of the locus, at least `want` wide
 bool solver_lds_fits(uint32_t wstride);                                    // the window arrays of one chain next to the annealing ring in 160 KB of LDS
 // the batch of a stage as the host has it: what plan_init_groups makes the groups of a diploid stage from (row_of: NULL = the allele itself)
-struct InitHost { const uint16_t* genotypes; const uint64_t* seeds; const uint16_t* row_of; const lcty_locus* loc; uint32_t n_cus; };
+struct InitHost {
+    const uint16_t* genotypes; const uint64_t* seeds; const uint16_t* row_of; const lcty_locus* loc; uint32_t n_cus;
+    uint32_t lds_budget;       // bytes of LDS a group may take (0: half a CU's); the last stage of a locus in a queue starts beside the greedy
+                               // chains of the next locus, whose two workgroups per CU leave 35 KB
+};
 void plan_init_groups(const SolveView& V, const InitHost& H, uint32_t nch, InitPlan& plan);
 void launch_init(lcty_ctx* ctx, const SolveView& V, uint32_t nch, size_t lds_init, hipStream_t s, const InitHost* host, lcty_ctx::SolveWorkspace& ws,
                  InitPlan& plan);

@@ -9,6 +9,7 @@
 #include <exception>
 #include <memory>
 #include <numeric>
+#include <future>
 #include <thread>
 #include <type_traits>
 
@@ -82,7 +83,7 @@ struct StageRunner {
     hipStream_t stream;
     lcty_ctx::SolveWorkspace& ws;       // device state of the chains: grow-only, lives as long as the context
     InitPlan init_plan;                 // the groups of the batch being initialised (host copy: its upload is asynchronous)
-    InitHost init_host{nullptr, nullptr, nullptr, nullptr, 0};
+    InitHost init_host{nullptr, nullptr, nullptr, nullptr, 0, 0};
     const RowGatherer* gathered_rows = nullptr;
 
     StageRunner(lcty_reads* r, const uint16_t* genotypes, uint64_t n_gt_, uint32_t ploidy_, const lcty_solver* solver, uint32_t attempts_,
@@ -213,9 +214,13 @@ struct StageRunner {
     void upload_genotypes(const uint16_t* genotypes, uint64_t ng) { ws.gt.upload(genotypes, ng * ploidy, stream); }
 
     void launch(uint32_t nch) {
+        if (lane == 0) wait_for_tail_init();
         launch_init(ctx, V, nch, lds_init, stream, init_host.genotypes ? &init_host : nullptr, ws, init_plan);
+        if (lane == 1) announce_tail_init();
         if (V.solver.kind == LCTY_SOLVER_EXACT) { solve_exact_batch(nch); return; }
         if (V.solver.kind == LCTY_SOLVER_ANNEAL) {
+            // (the stage's initialisation above does NOT wait: beside the greedy loop — the CU's L1 path full of its gathers — it took 216 ms
+            // instead of 8; it runs beside the next locus' initialisation, in groups small enough to fit next to that one's: InitHost::lds_budget)
             if (lane == 1) wait_for_greedy_of_next_locus();
             const bool timed_anneal = ctx->diag_knob("solve_anneal_timing", 0) != 0;
             V.dbg = nullptr;
@@ -242,6 +247,23 @@ struct StageRunner {
         launch_greedy_chains(ctx, V, nch, stream, ws);
     }
 
+    // lcty_ctx::LaunchGate: the side stream's initialisation (the last stage of the locus before) goes first, the main stream's behind it
+    void announce_tail_init() {
+        auto& g = ctx->gate;
+        {
+            std::lock_guard<std::mutex> lock(g.m);
+            if (!g.init_ev) LCTY_HIP(hipEventCreateWithFlags(&g.init_ev, hipEventDisableTiming));
+            LCTY_HIP(hipEventRecord(g.init_ev, stream));
+            g.tail_inits = g.tails_started;
+        }
+        g.cv.notify_all();
+    }
+    void wait_for_tail_init() {
+        auto& g = ctx->gate;
+        std::unique_lock<std::mutex> lock(g.m);
+        g.cv.wait(lock, [&] { return g.tail_inits >= g.tails_started; });      // a tail that has just been started: until it has issued its initialisation
+        if (g.init_ev) LCTY_HIP(hipStreamWaitEvent(stream, g.init_ev, 0));      // (an older one's event has long been reached)
+    }
     // lcty_ctx::LaunchGate: the main stream's greedy loop of the next locus goes first, the side stream's annealing loop right behind
     void announce_greedy() {
         auto& g = ctx->gate;
@@ -423,7 +445,7 @@ struct StageRunner {
             upload_genotypes(genotypes + g0 * ploidy, ng);
             ws.seeds.upload(chain_seeds + g0 * attempts, nch, s);
             init_host = InitHost{genotypes + g0 * ploidy, chain_seeds + g0 * attempts, gathered_rows ? gathered_rows->row_of.data() : nullptr, loc,
-                                 static_cast<uint32_t>(ctx->props.multiProcessorCount)};
+                                 static_cast<uint32_t>(ctx->props.multiProcessorCount), lane == 1 ? 32u * 1024u : 0u};
             if (priors) ws.pri.upload(priors + g0, ng, s);
             V.priors = priors ? ws.pri.p : nullptr;
             for (;;) {
@@ -963,13 +985,21 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
 
 namespace {
 // the queue of lcty_solve_queue / lcty_solve_queue_fed: `batch_of(i)` right before position i is scored, `done_with(i)` once its
-// last stage has been joined
+// last stage has been joined.
+// `early`: what comes before the chains of locus i + 1 (LocusRun::pre: scores, run_filter, the cut, the location table — 19 + 2.5 ms of
+// a 380-ms step at 1 M read pairs x 256 alleles) is issued by a third host thread on the context's fore stream as soon as the last
+// stage of locus i - 1 has ended, i.e. beside the greedy chains of locus i, which leave the device's issue slots and a fifth of its
+// LDS free. Batch i + 1 is then touched while locus i is in its chains — never before the tail of i - 1 has ended, so "an entry may
+// appear again, not next to itself" still holds — and `batch_of` / `done_with` would be called from that thread and earlier: only the
+// array form (lcty_solve_queue), where they are look-ups, takes this path.
 template <typename GET, typename DONE>
 void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages,
-               const uint64_t* master_seeds, const double* const* priors, lcty_call* out) {
-    std::unique_ptr<LocusRun> prev;
-    std::thread tail_thread;
+               const uint64_t* master_seeds, const double* const* priors, lcty_call* out, bool early) {
+    std::unique_ptr<LocusRun> prev, next;
+    std::thread tail_thread, fore_thread;
     int32_t tail_rc = LCTY_OK; std::string tail_msg;
+    int32_t fore_rc = LCTY_OK; std::string fore_msg;
+    std::shared_future<void> tail_ended;                                     // of the tail that is running (or the last one that ran)
     lcty_ctx* ctx = nullptr;
     uint32_t tail_of = 0;
     auto release_gate = [&] {
@@ -984,14 +1014,42 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
         if (tail_rc != LCTY_OK) { const int32_t rc = tail_rc; tail_rc = LCTY_OK; fail(rc, "%s", tail_msg.c_str()); }
         if (had) done_with(tail_of);
     };
+    auto join_fore = [&] {
+        if (fore_thread.joinable()) fore_thread.join();
+        if (fore_rc != LCTY_OK) { const int32_t rc = fore_rc; fore_rc = LCTY_OK; next.reset(); fail(rc, "%s", fore_msg.c_str()); }
+    };
+    auto make_run = [&](uint32_t i) {
+        auto R = std::make_unique<LocusRun>();
+        R->reads = batch_of(i);
+        R->ploidy = ploidy; R->stages = stages; R->n_stages = n_stages; R->master_seed = master_seeds[i];
+        R->priors = priors ? priors[i] : nullptr; R->out = &out[i];
+        return R;
+    };
     try {
         for (uint32_t i = 0; i < n; i++) {
-            auto R = std::make_unique<LocusRun>();
-            R->reads = batch_of(i);
+            std::unique_ptr<LocusRun> R;
+            if (next) { join_fore(); R = std::move(next); }                   // its scores, cut and tables were made beside the chains of locus i - 1
+            else { R = make_run(i); R->pre(true); }
             ctx = R->reads->ctx;
-            R->ploidy = ploidy; R->stages = stages; R->n_stages = n_stages; R->master_seed = master_seeds[i];
-            R->priors = priors ? priors[i] : nullptr; R->out = &out[i];
-            try { R->head(true); }
+            if (early && i + 1 < n) {
+                next = make_run(i + 1);
+                if (next->reads->ctx != ctx) fail(LCTY_ERR_INVALID_INPUT, "the batches of a queue share one context");
+                LocusRun* nx = next.get();
+                std::shared_future<void> before = tail_ended;               // the tail of locus i - 1: batch i + 1 may be the batch it works on
+                lcty_ctx* c = ctx;
+                fore_thread = std::thread([nx, before, c, &fore_rc, &fore_msg] {
+                    try {
+                        if (before.valid()) before.wait();
+                        c->activate();
+                        StreamScope on_fore(c->fore_stream());
+                        nx->pre(true);
+                        LCTY_HIP(hipStreamSynchronize(c->fore_stream()));       // the chains of this locus are issued on the main stream
+                    }
+                    catch (const Error& e) { fore_rc = e.code; fore_msg = e.what(); }
+                    catch (const std::exception& e) { fore_rc = LCTY_ERR_RUNTIME; fore_msg = e.what(); }
+                });
+            }
+            try { R->chains(); }
             catch (...) { release_gate(); throw; }
             release_gate();                                                  // a head that launched no greedy loop must not keep the tail waiting
             join_tail();
@@ -1003,15 +1061,24 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
                 ctx->gate.target = i + 1 < n && n_stages > 1 && stages[0].solver.kind == LCTY_SOLVER_GREEDY ? ctx->gate.epoch + 1 : 0;
             }
             tail_of = i;
-            tail_thread = std::thread([run, &tail_rc, &tail_msg] {
+            auto ended = std::make_shared<std::promise<void>>();
+            tail_ended = ended->get_future().share();
+            { std::lock_guard<std::mutex> lock(ctx->gate.m); ctx->gate.tails_started++; }
+            lcty_ctx* c = ctx;
+            tail_thread = std::thread([run, ended, c, &tail_rc, &tail_msg] {
                 try { run->tail(1); }
                 catch (const Error& e) { tail_rc = e.code; tail_msg = e.what(); }
                 catch (const std::exception& e) { tail_rc = LCTY_ERR_RUNTIME; tail_msg = e.what(); }
+                // (a tail that ended without an initialisation of its own — an error, a skipped stage — must not keep the next locus waiting)
+                { std::lock_guard<std::mutex> lock(c->gate.m); if (c->gate.tail_inits < c->gate.tails_started) c->gate.tail_inits = c->gate.tails_started; }
+                c->gate.cv.notify_all();
+                ended->set_value();
             });
         }
         join_tail();
     } catch (...) {
         release_gate();
+        if (fore_thread.joinable()) fore_thread.join();
         if (tail_thread.joinable()) tail_thread.join();
         throw;
     }
@@ -1037,7 +1104,8 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
             if (i && (batches[i] == batches[i - 1] || batches[i]->locus == batches[i - 1]->locus))
                 fail(LCTY_ERR_INVALID_INPUT, "neighbours in the queue must be different batches of different loci");
         }
-        run_queue(n_batches, [&](uint32_t i) { return batches[i]; }, [](uint32_t) {}, ploidy, stages, n_stages, master_seeds, priors, out);
+        run_queue(n_batches, [&](uint32_t i) { return batches[i]; }, [](uint32_t) {}, ploidy, stages, n_stages, master_seeds, priors, out,
+                  batches[0]->ctx->knob("queue_early_head", 1) != 0);
     });
 }
 
@@ -1059,7 +1127,7 @@ int32_t lcty_solve_queue_fed(uint32_t n_loci, lcty_queue_acquire_fn acquire, lct
                 fail(LCTY_ERR_INVALID_INPUT, "neighbours in the queue must be different batches of different loci in one context");
             before = r;
             return r;
-        }, [&](uint32_t i) { if (release) release(user, i); }, ploidy, stages, n_stages, master_seeds, priors, out);
+        }, [&](uint32_t i) { if (release) release(user, i); }, ploidy, stages, n_stages, master_seeds, priors, out, false);
     });
 }
 

@@ -2145,7 +2145,8 @@ void plan_init_groups(const SolveView& V, const InitHost& H, uint32_t nch, InitP
     plan.groups.clear(); plan.chains.clear(); plan.T = plan.R = 0; plan.lds = 0;
     const uint32_t attempts = V.attempts, ng = (nch + attempts - 1) / attempts, A = V.A;
     uint32_t T_cap = INIT_TILE_T;                                            // what the LDS holds with two workgroups per CU
-    while (T_cap > 1 && init_tile_lds(T_cap, std::min(INIT_TILE_R, T_cap + 1), V.wstride) > 80 * 1024) T_cap--;
+    const size_t lds_budget = H.lds_budget ? H.lds_budget : 80 * 1024;
+    while (T_cap > 1 && init_tile_lds(T_cap, std::min(INIT_TILE_R, T_cap + 1), V.wstride) > lds_budget) T_cap--;
     const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(160 * 1024 / init_tile_lds(T_cap, std::min(INIT_TILE_R, T_cap + 1), V.wstride), 4));
     const uint64_t places = per_cu * std::max(1u, H.n_cus);
     T_cap = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(T_cap, (nch + places - 1) / places)));

@@ -422,6 +422,22 @@ def test_queue_of_loci_equals_one_locus_at_a_time(gpu_ctx):
         assert list(c.ln_probs[:n]) == list(a.ln_probs[:n]) and c.quality == a.quality
         assert (c.unexpl_reads, c.n_good, c.warnings, c.kept_after_filter) == (a.unexpl_reads, a.n_good, a.warnings, a.kept_after_filter)
         assert tuple(api.generate_genotypes(10, 2)[int(c.ixs[0])]) == cases[i][0].true_genotype
+    # the same queue with the head of a locus (scores, cut, location table) made on the main stream after the chains of the locus before,
+    # instead of beside them on the fore stream: nothing but the order of issue differs
+    gpu_ctx.set_knob("queue_early_head", 0)
+    try:
+        late = api.solve_queue([batches[i] for i in order], stages, master_seeds=[11 + i for i in order])
+    finally:
+        gpu_ctx.set_knob("queue_early_head", -1)
+    for c, l in zip(calls, late):
+        n = int(c.n_out)
+        assert int(l.n_out) == n and list(l.ixs[:n]) == list(c.ixs[:n]) and list(l.ln_probs[:n]) == list(c.ln_probs[:n])
+        assert (l.unexpl_reads, l.n_good, l.warnings, l.kept_after_filter) == (c.unexpl_reads, c.n_good, c.warnings, c.kept_after_filter)
+    # a queue of two positions (one head beside chains, no tail before it) and of one
+    two = api.solve_queue([batches[2], batches[0]], stages, master_seeds=[13, 11])
+    assert [list(t.ixs[:int(t.n_out)]) for t in two] == [list(alone[2].ixs[:int(alone[2].n_out)]), list(alone[0].ixs[:int(alone[0].n_out)])]
+    one = api.solve_queue([batches[1]], stages, master_seeds=[12])
+    assert list(one[0].ln_probs[:int(one[0].n_out)]) == list(alone[1].ln_probs[:int(alone[1].n_out)])
     with pytest.raises(_lib.LocityperError) as e:                       # neighbours must be different loci
         api.solve_queue([batches[0], batches[0]], stages)
     assert e.value.code == cdefs.ERR_INVALID_INPUT
