@@ -496,9 +496,11 @@ def main():
     ctx = api.Context(local_rank % ndev)
     if world > 1:                                  # this rank's share of the host's cores (spawn_ranks sets it; under torchrun: cores / ranks)
         ctx.set_knob("host_threads", max(1, min(16, int(os.environ.get("LCTY_BENCH_HOST_THREADS", physical_cores() // world)))))
+    early_head = True                              # lcty_solve_queue's default (knob queue_early_head)
     for kv in args.knob:
         name, _, val = kv.partition("=")
         ctx.set_knob(name, int(val))
+        if name == "queue_early_head": early_head = int(val) != 0
 
     comm = None
     rccl_ranks = None
@@ -726,6 +728,12 @@ def main():
         "anneal_loop_kernel": {"ms_per_step": ms_ann / kern_steps, "launch_ms": ms_ann / max(n_ann, 1), "bound": "hbm",
                                "bytes": 32.0 * per_step["anneal_moves"], "what": "one 32 B record per evaluated move (latency-bound serial chains)"},
     }
+    if queue_mode and early_head:
+        # lcty_solve_queue issues everything before the chains of a locus on a third stream, beside the greedy chains of the locus before
+        # (one wavefront per SIMD, 125 of 160 KB of LDS): launch_ms of these two is the kernel in THAT place — off the critical path of a step —
+        # and launch_ms_alone / frac_alone the kernel with the device to itself
+        for name in ("score_reads_kernel", "prefilter_tile_kernel"):
+            roofs[name]["in_the_queue"] = "fore stream, beside the greedy chains of the locus before; not on the critical path of a step"
     # the loop kernels are random 32-byte gathers out of the chains' 148 GB of records: what the device does of THOSE at best (a lane keeps
     # one to four in flight, 1 250 - 10 000 wavefronts: 37.9 G gathers/s, profiles/r05_gather_probe.txt) is the ceiling their record
     # gathers are held against; SURVEY 8(d) itself calls K14 latency-bound
@@ -774,7 +782,8 @@ def main():
                    "alignment_table": ("16-byte counted alignments (lcty_reads_append_counted): the caller counts the CIGAR operations"
                                        if args.format == "counted" else "16-byte BAM records + CIGAR words (lcty_reads_append)"),
                    "step": ("one locus through lcty_solve_queue (score + run_filter + default solver scheme + final comparison); the queue "
-                            "alternates between two resident loci and overlaps the annealing stage of a locus with the next locus"
+                            "alternates between two resident loci; beside the greedy chains of a locus run the annealing stage of the locus "
+                            "before (side stream) and" + (" the scores, run_filter and location table of the locus after (fore stream)" if early_head else " nothing else")
                             if queue_mode else "one locus, call by call"),
                    "parallelism": (f"reads of one locus x{world}: RCCL all-reduce of the run_filter scores, all-gather of the location-table rows per solver stage, chains dealt to the ranks" if args.shard_reads else f"solver chains of one locus x{world} (reads replicated), RCCL all-gather of the chain likelihoods" if args.shard_chains else f"loci x{world}")},
         "reads_scored_per_s": (total_pairs if args.shard_reads else args.pairs if args.shard_chains else args.pairs) * n_break / max(stage_s["score_prefilter"], 1e-9),
