@@ -869,7 +869,9 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 scratch_budget = std::max<uint64_t>(scratch_budget, std::min<uint64_t>((free_b + ctx->transfer_scratch.n) / 2, 128ull << 30));      // what the context already holds counts as free
         }
         if (ctx->knob("transfer_scratch_mb", 0) > 0) scratch_budget = std::max<uint64_t>(64, static_cast<uint64_t>(ctx->knob("transfer_scratch_mb", 0))) << 20;
-        // one wavefront per workgroup, 128 VGPRs (launch bounds; a few spills are cheaper than the fourth wavefront per SIMD is worth)
+        // one wavefront per workgroup, three per SIMD (launch bounds: 168 VGPRs, 12 KB of LDS): the walk and its in-register aligner spill at
+        // 128, and a fourth wavefront bought nothing (6 144 ONT reads x 256 alleles: 87.8 ms with 12 per CU, 88.7 with 16; six or eight per
+        // SIMD at 80 / 64 VGPRs: 155-169 ms)
         uint32_t waves = 12;
         waves = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_waves", waves)));
         const uint32_t max_blocks = static_cast<uint32_t>(ctx->props.multiProcessorCount) * waves;
