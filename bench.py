@@ -853,8 +853,10 @@ def main():
                 # vector instructions issued per launch against what the SIMDs could issue in the launch's time (one per 4 cycles each: quarter-
                 # and half-rate instructions take longer, so a kernel is bound by its vector stream well below 1)
                 launches = max(k.get("launches", 0.0), 1.0)
-                if k.get("SQ_INSTS_VALU") and r.get("launch_ms"):
-                    r["sq"]["valu_issue_frac"] = (k["SQ_INSTS_VALU"] / launches) / (1024 * 2.4e9 / 4.0 * r["launch_ms"] * 1e-3)
+                # (a kernel that runs beside the greedy chains in the queue: against its time with the device to itself)
+                ms_for_issue = r.get("launch_ms_alone") if r.get("in_the_queue") and r.get("launch_ms_alone") else r.get("launch_ms")
+                if k.get("SQ_INSTS_VALU") and ms_for_issue:
+                    r["sq"]["valu_issue_frac"] = (k["SQ_INSTS_VALU"] / launches) / (1024 * 2.4e9 / 4.0 * ms_for_issue * 1e-3)
         out["roofline"]["sq"] = roofs[dominant].get("sq")
     except (OSError, KeyError, ValueError):
         pass
