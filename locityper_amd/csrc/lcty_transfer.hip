@@ -233,7 +233,10 @@ struct TransferArgs {
                                    // redo_list, their number of such (source, target) combinations is added to rec_cursor; nothing is walked
 };
 
-__global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
+// WPS wavefronts per SIMD: 3 (168 VGPRs) for batches with long CIGARs, whose lanes live in the walk and the in-register aligner (they spill
+// at 128); 4 (128 VGPRs) for short reads, whose transfers are a handful of items each and gain from the fourth wavefront
+template <int WPS>
+__global__ __launch_bounds__(64, WPS) void transfer_kernel(const LocusView L, const ReadsView R, const HapView H, const TransferArgs T) {
     const uint32_t lane = threadIdx.x;
     uint8_t* base = T.scratch + static_cast<size_t>(blockIdx.x) * T.scratch_stride;
     const PairScratch P = carve(base, T.cap_alns, T.hcap, T.cap_new, T.cap_words);
@@ -241,9 +244,10 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
     const bool paired = L.is_paired != 0;
     __shared__ Prelim S;
     __shared__ uint32_t sh_n_new, sh_words, sh_fails, sh_stop, sh_redo;
-    __shared__ uint32_t lds_wb[CIGAR_CHUNK * 64];                  // the chunk of every lane's CIGAR under construction (DCigar::wb)
-    __shared__ uint32_t lds_win[ITEM_WIN * 64];                    // the items a lane's pass over a finished CIGAR reads ahead (ItemWindow)
-    __shared__ uint32_t lds_src[SRC_LDS_WORDS];                    // the source alignment's CIGAR: every lane of every chunk walks it
+    __shared__ uint32_t lds_a[CIGAR_CHUNK * 64], lds_b[CIGAR_CHUNK * 64];   // two slices of 16 words per lane: the chunk of its CIGAR under construction, and
+                                                                             // the finished CIGAR that is read meanwhile (whole, or the window read ahead): DCigar
+    constexpr uint32_t SRC_WORDS = WPS == 3 ? SRC_LDS_WORDS : 64u;   // (short reads: a few words — and 16 wavefronts per CU must fit the LDS)
+    __shared__ uint32_t lds_src[SRC_WORDS];                        // the source alignment's CIGAR: every lane of every chunk walks it
     // developer build: where a wavefront's time goes (0 set-up + wave scoring, 1 PrelimAlignments, 2 estimate / probe / offset / walk_init,
     // 3 walk, 4 aligner for clipped ends, 5 assemble, 6 optimize, 7 scoring of the result, 8 push, 9 hand-over)
     [[maybe_unused]] unsigned long long tph[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
             if (sa.src & 0x80000000u) { const NewAln na = P.news[sa.src & 0x7FFFFFFFu]; src.raw = P.words + na.cigar_at; src.n = na.n_cigar; src.hard_to_soft = false; }
             else { src.raw = cig + recs[sa.src].cigar_rel; src.n = recs[sa.src].n_cigar; src.hard_to_soft = true; }
             // its first SRC_LDS_WORDS words go to LDS (a 10-kb ONT read: ~900): the lanes of all chunks walk this one CIGAR, each at its own item
-            src.lds = lds_src; src.lds_n = T.dry_run ? 0u : min(src.n, SRC_LDS_WORDS);
+            src.lds = lds_src; src.lds_n = T.dry_run ? 0u : min(src.n, SRC_WORDS);
             for (uint32_t k = lane; k < src.lds_n; k += 64) lds_src[k] = src.raw[k];
             __syncthreads();
             // the read in the orientation of the source alignment: the stored bases are the primary record's (MateData::new)
@@ -362,7 +366,8 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
                 // 0 nothing, 1 similar position exists (index in `hit`), 2 failed transfer, 3 new alignment
                 uint32_t kind = 0, hit = NONE32T, target = 0;
                 PAln na; na.ln_prob = 0.0; na.start = 0; na.contig_end = 0; na.edit = 0; na.src = 0;
-                DCigar out; out.init(LS.cig_a, T.lim.cigar_cap, lds_wb + lane);
+                uint32_t* const slice_a = lds_a + lane; uint32_t* const slice_b = lds_b + lane;
+                DCigar out; out.init(LS.cig_a, T.lim.cigar_cap, slice_a);
                 bool beyond = false;                                         // this transfer needs a lane with more scratch
                 bool transferring = false, walking = false;
                 Walk walk; walk.start_k = 0; walk.phase = PH_DONE;
@@ -418,19 +423,19 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
                     do {
                         const uint32_t st = walking ? walk_step(walk, src, Q, out, LS, job, T.walk_budget) : WALK_DONE;
                         mark(3);
-                        if (st == WALK_JOB) aligner_align(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);   // the clipped ends
+                        if (st == WALK_JOB) aligner_align<false>(Q, job.i1, job.n, job.j1, job.m, job.semiglobal, job.left_clipping, out, LS);   // the clipped ends
                         mark(4);
                         if (__any(st == WALK_ASSEMBLE)) {
                             // The stretches between anchors the walks left behind, resolved for all lanes together: a lane copies its items
                             // up to the next marker (a few items), then the lanes that stand at a marker call the aligner at one converged
                             // site. The first item behind a marker was pushed with push_checked (the anchor that follows a stretch): it is
                             // pushed that way again, behind the aligner's operations; every other item keeps its boundaries.
-                            DCigar fin; fin.init(LS.cig_b, T.lim.cigar_cap, lds_wb + lane);
+                            DCigar fin; fin.init(LS.cig_b, T.lim.cigar_cap, out.slice == slice_a ? slice_b : slice_a);
                             bool assembling = st == WALK_ASSEMBLE;
                             uint32_t ai = 0;
                             bool after_mark = false;
-                            if (assembling) out.finish();                         // `fin` takes the lane's LDS buffer
-                            ItemWindow win; win.init(lds_win + lane);
+                            if (assembling) out.finish();                         // `fin` collects in the lane's other slice
+                            ItemWindow win; win.init(out);
                             do {
                                 // a round: every lane that is copying reads its next ITEM_WIN items (all lanes' loads in flight together), copies
                                 // them up to a marker, and the lanes that stand at one call the aligner — the lanes drift apart instead of
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
                                 if (assembling && !need) win.fill(out, ai);     // at the end of its window (the first round: of the empty one)
                                 [[maybe_unused]] unsigned long long t0 = 0;
                                 if constexpr (kDiag) { if (T.phases) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } }
-                                if (need) { aligner_align(Q, jb.x, jb.y, jb.z, jb.w, 0, false, fin, LS); after_mark = true; }
+                                if (need) { aligner_align<WPS == 3>(Q, jb.x, jb.y, jb.z, jb.w, 0, false, fin, LS); after_mark = true; }
                                 if constexpr (kDiag) {
                                     if (T.phases) {
                                         __builtin_amdgcn_sched_barrier(0);
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
                             mark(5);
                         }
                         if (__any(st == WALK_OPTIMIZE)) {
-                            optimize_and_finish(st == WALK_OPTIMIZE, out, Q, LS, lds_win + lane, lds_wb + lane, kDiag && T.phases ? tph + 12 : nullptr);
+                            optimize_and_finish<WPS == 3>(st == WALK_OPTIMIZE, out, Q, LS, slice_a, slice_b, kDiag && T.phases ? tph + 12 : nullptr);
                             if (st == WALK_OPTIMIZE) walk.phase = PH_DONE;
                             mark(6);
                         }
@@ -489,8 +494,10 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
                     else {
                         kind = 3;
                         // Alignment::new + the scoring of push(): the CIGAR goes through the same counting as a record's
-                        const Scored sc = score_cigar(L, [&out](uint32_t i) { return out.word(i); }, out.n, new_start,
-                                                      Q.target_len, false);
+                        // (a CIGAR of one chunk is still in its LDS slice: DCigar::keep)
+                        const uint32_t* kept = out.keep;
+                        const Scored sc = kept ? score_cigar(L, [kept](uint32_t i) { return kept[i * 64]; }, out.n, new_start, Q.target_len, false)
+                                               : score_cigar(L, [&out](uint32_t i) { return *out.at(i); }, out.n, new_start, Q.target_len, false);
                         na.ln_prob = sc.ln_prob; na.start = new_start; na.edit = sc.edit;
                         na.contig_end = target | (e << 16) | (s_rev ? (1u << 17) : 0u);
                     }
@@ -532,10 +539,11 @@ __global__ __launch_bounds__(64, 3) void transfer_kernel(const LocusView L, cons
                     nn.ln_prob = na.ln_prob; nn.start = na.start; nn.contig_end = na.contig_end; nn.edit = na.edit;
                     nn.n_cigar = out.n; nn.cigar_at = word_at; nn.pushed = 0;
                     P.news[slot] = nn;
-                    for (uint32_t k = 0; k < out.n; k += 8) {                   // eight loads in flight (one by one each waited for the store before it)
+                    if (out.keep) for (uint32_t k = 0; k < out.n; k++) P.words[word_at + k] = out.keep[k * 64];
+                    else for (uint32_t k = 0; k < out.n; k += 8) {              // eight loads in flight (one by one each waited for the store before it)
                         uint32_t v[8];
 #pragma unroll
-                        for (uint32_t u = 0; u < 8; u++) v[u] = k + u < out.n ? out.word(k + u) : 0u;
+                        for (uint32_t u = 0; u < 8; u++) v[u] = k + u < out.n ? *out.at(k + u) : 0u;
 #pragma unroll
                         for (uint32_t u = 0; u < 8; u++) if (k + u < out.n) P.words[word_at + k + u] = v[u];
                     }
@@ -869,10 +877,11 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 scratch_budget = std::max<uint64_t>(scratch_budget, std::min<uint64_t>((free_b + ctx->transfer_scratch.n) / 2, 128ull << 30));      // what the context already holds counts as free
         }
         if (ctx->knob("transfer_scratch_mb", 0) > 0) scratch_budget = std::max<uint64_t>(64, static_cast<uint64_t>(ctx->knob("transfer_scratch_mb", 0))) << 20;
-        // one wavefront per workgroup, three per SIMD (launch bounds: 168 VGPRs, 12 KB of LDS): the walk and its in-register aligner spill at
-        // 128, and a fourth wavefront bought nothing (6 144 ONT reads x 256 alleles: 87.8 ms with 12 per CU, 88.7 with 16; six or eight per
-        // SIMD at 80 / 64 VGPRs: 155-169 ms)
-        uint32_t waves = 12;
+        // one wavefront per workgroup; three per SIMD for long CIGARs (launch bounds: 168 VGPRs; the walk and its in-register aligner spill at
+        // 128, and a fourth wavefront bought nothing there — 6 144 ONT reads x 256 alleles: 87.8 ms with 12 per CU, 88.7 with 16; six or eight
+        // per SIMD at 80 / 64 VGPRs: 155-169 ms), four for short reads (262 144 Illumina pairs x 256 alleles: 50 ms at three, 40 at four)
+        const bool long_cigars = rec_cigar > 256;                             // (the longest CIGAR of a record: 150-base reads stay below, a 10-kb ONT read has ~900 words)
+        uint32_t waves = long_cigars ? 12 : 16;
         waves = static_cast<uint32_t>(std::max<int64_t>(1, ctx->knob("transfer_waves", waves)));
         const uint32_t max_blocks = static_cast<uint32_t>(ctx->props.multiProcessorCount) * waves;
 
@@ -915,7 +924,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             T.phases = nullptr;
             T.dry_run = 1; T.wave_scores = reads->max_cigar_per_rec >= WAVE_SCORE_FROM ? 1u : 0u;
             ctx->timed(LCTY_K_TRANSFER, [&] {
-                hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
+                hipLaunchKernelGGL(transfer_kernel<4>, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
             });
             LCTY_HIP(hipGetLastError());
             uint32_t flag = 0;
@@ -985,7 +994,8 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
                 T.phases = phases ? d_cursors.p + 4 : nullptr;
                 LCTY_HIP(hipMemsetAsync(d_cursors.p + 2, 0, sizeof(unsigned long long), s));
                 ctx->timed(LCTY_K_TRANSFER, [&] {
-                    hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
+                    if (long_cigars) hipLaunchKernelGGL(transfer_kernel<3>, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
+                    else hipLaunchKernelGGL(transfer_kernel<4>, dim3(blocks), dim3(64), 0, s, loc->view(), reads->view(), H, T);
                 });
                 LCTY_HIP(hipGetLastError());
                 d_flag.download(&flag, 1, s);
@@ -1019,7 +1029,7 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             static const char* names[10] = {"set-up + wave scoring", "PrelimAlignments", "estimate / probe / offset / walk_init", "walk", "aligner (clipped ends)",
                                             "assemble", "optimize", "scoring of the result", "push", "hand-over"};
             for (int k = 0; k < 10; k++)
-                std::fprintf(stderr, "[transfer phases] %-40s %6.2f %%\n", names[k], sum ? 100.0 * static_cast<double>(t[k]) / static_cast<double>(sum) : 0.0);
+                std::fprintf(stderr, "[transfer phases] %-40s %6.2f %%  %llu\n", names[k], sum ? 100.0 * static_cast<double>(t[k]) / static_cast<double>(sum) : 0.0, t[k]);
             auto rounds = [&](const char* what, unsigned long long ticks, unsigned long long n, unsigned long long lanes, unsigned long long cells) {
                 const double r = static_cast<double>(std::max<unsigned long long>(n, 1));
                 std::fprintf(stderr, "[transfer phases] %s: %.2f %% of all inside the aligner; %llu rounds, %.1f lanes with a stretch per round, largest matrix of a "

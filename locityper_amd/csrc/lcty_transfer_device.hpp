@@ -51,26 +51,31 @@ __device__ __forceinline__ uint32_t op_invert(uint32_t op) {                  //
 // stores when the 16th arrives. (Rounds 3-4 had item i of lane l at t[i * 64 + l], stored one by one: the lanes of a wavefront walk
 // their transfers at their own pace, so every item was a 4-byte store into a 256-byte row of its own — 3 passes x 900 items x 64
 // lanes of partial-line writes per chunk of targets, 28 KB written per transfer for 11, and every pass waited on them.)
-// Only one CIGAR of a lane is under construction at a time (the walk's, then the assembled one, then the optimized one): they hand the
-// LDS buffer on — finish() writes the last, partial chunk out and lets go of it; from then on the CIGAR is read from global memory.
+// A lane has TWO such LDS slices of 16 words. Only one CIGAR of a lane is under construction at a time (the walk's, then the assembled one,
+// then the optimized one) and at most one finished CIGAR is being read meanwhile: the new CIGAR collects its chunk in the slice the
+// finished one does not own. finish(): a CIGAR of at most 16 items — every transferred short read — simply STAYS in its slice (`keep`) and
+// never sees global memory until it is copied out; a longer one writes its last, partial chunk out, is read from global memory from then
+// on, and its slice serves the reader as the window its items are read ahead into (ItemWindow).
 constexpr uint32_t CIGAR_CHUNK = 16;
 struct DCigar {
     uint32_t* t;           // global part: [cap / 16] chunks x 64 lanes x 16 words, already offset by the lane (lane * 16 words)
     uint32_t* wb;          // LDS: the chunk under construction, already offset by the lane (stride 64); nullptr once finished
+    uint32_t* keep;        // LDS: ALL items of a finished CIGAR of at most 16 (then nothing of it is in global memory); else nullptr
+    uint32_t* slice;       // the LDS slice this CIGAR was given (wb while under construction; `keep` or free for the reader's window afterwards)
     uint32_t n, rlen, qlen, cap;
     uint2 pend; bool has_pend;                                               // the item behind item n - 1, not stored yet
     bool overflow;                                                           // items were dropped: the lengths are still right
-    __device__ void init(uint32_t* buf, uint32_t capacity, uint32_t* write_buffer) {
-        t = buf; cap = capacity; wb = write_buffer; n = 0; rlen = qlen = 0; overflow = false;
+    __device__ void init(uint32_t* buf, uint32_t capacity, uint32_t* lds_slice) {
+        t = buf; cap = capacity; wb = slice = lds_slice; keep = nullptr; n = 0; rlen = qlen = 0; overflow = false;
         pend = make_uint2(0, 0); has_pend = false;
     }
     __device__ __forceinline__ uint32_t* at(uint32_t i) const { return t + static_cast<size_t>(i >> 4) * (CIGAR_CHUNK * 64) + (i & 15u); }
     __device__ __forceinline__ bool in_wb(uint32_t i) const { return wb != nullptr && i >= (n & ~15u); }
-    __device__ __forceinline__ uint32_t word(uint32_t i) const { return in_wb(i) ? wb[(i & 15u) * 64] : *at(i); }
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return in_wb(i) ? wb[(i & 15u) * 64] : keep ? keep[(i & 15u) * 64] : *at(i); }
     __device__ __forceinline__ uint2 get(uint32_t i) const { const uint32_t w = word(i); return make_uint2(w & 15u, w >> 4); }
     __device__ __forceinline__ void set(uint32_t i, uint2 v) {
         const uint32_t w = (v.y << 4) | v.x;
-        if (in_wb(i)) wb[(i & 15u) * 64] = w; else *at(i) = w;
+        if (in_wb(i)) wb[(i & 15u) * 64] = w; else if (keep) keep[(i & 15u) * 64] = w; else *at(i) = w;
     }
     __device__ __forceinline__ void store_chunk(uint32_t first) {                // the 16 words of the LDS buffer -> chunk first / 16
         uint4* dst = reinterpret_cast<uint4*>(at(first));
@@ -99,10 +104,14 @@ struct DCigar {
     __device__ __forceinline__ void flush() {
         if (has_pend) { if (n < cap) append((pend.y << 4) | pend.x); else overflow = true; has_pend = false; }
     }
-    // nothing more will be pushed: everything to global memory, the LDS buffer is free for the lane's next CIGAR
+    // nothing more will be pushed: a CIGAR of one chunk stays where it is, a longer one goes to global memory completely
     __device__ __forceinline__ void finish() {
         flush();
-        if (wb) { if (n & 15u) store_chunk(n & ~15u); wb = nullptr; }
+        if (wb) {
+            if (n <= CIGAR_CHUNK) keep = wb;
+            else if (n & 15u) store_chunk(n & ~15u);
+            wb = nullptr;
+        }
     }
     __device__ __forceinline__ void push_raw(uint2 it) { flush(); pend = it; has_pend = true; }          // lengths untouched
     __device__ __forceinline__ void push_unchecked(uint32_t op, uint32_t len) {   // cigar.rs:343-352
@@ -124,11 +133,12 @@ struct DCigar {
 // wavefront at the same point of the code (their positions differ, their pace does not): word k of lane l at w[k * 64 + l].
 constexpr uint32_t ITEM_WIN = 16;
 struct ItemWindow {
-    uint32_t* w;           // LDS, already offset by the lane
+    uint32_t* w;           // LDS, already offset by the lane: the slice of the CIGAR that is read (free once that CIGAR is in global memory)
     uint32_t base, end;    // the window holds the items [base, end)
-    __device__ __forceinline__ void init(uint32_t* lds_lane) { w = lds_lane; base = end = 0; }
+    __device__ __forceinline__ void init(const DCigar& c) { w = c.slice; base = end = 0; }
     __device__ __forceinline__ bool has(uint32_t i) const { return i - base < end - base; }
     __device__ __forceinline__ void fill(const DCigar& c, uint32_t from) {
+        if (c.keep) { base = 0; end = c.n; return; }                          // the whole CIGAR is in this very slice: nothing to load
         base = from; end = min(from + ITEM_WIN, c.n);
         uint32_t v[ITEM_WIN];
 #pragma unroll
@@ -430,11 +440,14 @@ __device__ inline int dp_align_small(const Seqs& S, uint32_t i1, uint32_t n, uin
 }
 
 // Aligner::align::<LEFT_CLIPPING> (wfa.rs:254-299). semiglobal: 0 global aligner, 1 LEFT, 2 RIGHT free ends
+// SMALL: short end-to-end stretches take dp_align_small (the kernel's build for long CIGARs; in the one for short reads, which has a
+// quarter fewer registers per lane, its arrays would spill)
+template <bool SMALL>
 __device__ inline int aligner_align(const Seqs& S, uint32_t i1, uint32_t n, uint32_t j1, uint32_t m, int semiglobal, bool left_clipping, DCigar& cg,
                                     Scratch& sc) {
     uint32_t n_ops = 0;
     // (the same acceptance as dp_align's: a level whose scratch would refuse the stretch refuses it here too)
-    if (semiglobal == 0 && !left_clipping && n >= 1 && m >= 1 && n <= DP_SMALL && m <= DP_SMALL && n <= sc.lim.dp_dim && m <= sc.lim.dp_dim && (n + 1) * (m + 1) <= sc.lim.dp_cells) {
+    if (SMALL && semiglobal == 0 && !left_clipping && n >= 1 && m >= 1 && n <= DP_SMALL && m <= DP_SMALL && n <= sc.lim.dp_dim && m <= sc.lim.dp_dim && (n + 1) * (m + 1) <= sc.lim.dp_cells) {
         uint32_t ops2 = 0;
         const int pen = dp_align_small(S, i1, n, j1, m, sc, &n_ops, &ops2);
         if (pen == DP_DROPPED) return align_simple(S, i1, n, j1, m, cg);
@@ -467,6 +480,7 @@ __device__ inline int aligner_align(const Seqs& S, uint32_t i1, uint32_t n, uint
 }
 
 // smart_align (wfa.rs:301-347); max_gap 0xFFFFFFFF = the `()` threshold
+template <bool SMALL>
 __device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint32_t j1, uint32_t j2, uint32_t max_gap, DCigar& cg, Scratch& sc) {
     const uint32_t jump1 = i2 - i1, jump2 = j2 - j1;
     if (jump1 > 0 && jump2 > 0) {
@@ -481,7 +495,7 @@ __device__ inline int smart_align(const Seqs& S, uint32_t i1, uint32_t i2, uint3
             }
             return ndiff * PEN_X;
         }
-        return aligner_align(S, i1, jump1, j1, jump2, 0, false, cg, sc);
+        return aligner_align<SMALL>(S, i1, jump1, j1, jump2, 0, false, cg, sc);
     }
     if (jump1 > 0) { cg.push_unchecked(OP_D, jump1); return -PEN_O - static_cast<int>(jump1) * PEN_E; }
     if (jump2 > 0) { cg.push_unchecked(OP_I, jump2); return -PEN_O - static_cast<int>(jump2) * PEN_E; }
@@ -501,10 +515,11 @@ struct OptState {
     uint32_t i, j, qpos1, rpos1, qpos2, rpos2, flag, stage;
     bool have;
 };
-__device__ inline void opt_init(OptState& o, DCigar& self, Scratch& sc, uint32_t* lds_win, uint32_t* lds_wb) {
-    self.finish();                                                            // read from global memory from here on; the new CIGAR takes the buffer
-    o.win.init(lds_win);
-    o.nc.init(sc.cig_free, sc.lim.cigar_cap, lds_wb);
+__device__ inline void opt_init(OptState& o, DCigar& self, Scratch& sc, uint32_t* slice_a, uint32_t* slice_b) {
+    self.finish();
+    o.win.init(self);
+    if (self.keep) o.win.fill(self, 0);                                       // (a CIGAR of one chunk: the window is its slice, nothing is loaded)
+    o.nc.init(sc.cig_free, sc.lim.cigar_cap, self.slice == slice_a ? slice_b : slice_a);      // the new CIGAR collects in the other slice
     o.i = o.j = 0; o.qpos1 = o.rpos1 = o.qpos2 = o.rpos2 = 0; o.flag = 0; o.stage = 0; o.have = false;
 }
 __device__ __forceinline__ void opt_begin_copy(OptState& o, const DCigar& self) {
@@ -571,7 +586,7 @@ __device__ inline bool opt_step(OptState& o, DCigar& self, uint32_t max_gap, uin
                 copy_items(self, o.i, self.n, o.nc);
                 o.nc.finish();
                 // self.tuples = new_cigar.tuples (lengths stay): the new items stay where they are, `self` looks there from now on
-                self.t = o.nc.t; self.wb = nullptr;
+                self.t = o.nc.t; self.wb = nullptr; self.keep = o.nc.keep; self.slice = o.nc.slice;
                 self.n = o.nc.n;
                 self.overflow |= o.nc.overflow;
             }
@@ -693,12 +708,16 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
                     if (jump1 > 0 && jump2 > 0) {
                         constexpr uint32_t safe_mismatch = (2 * PEN_O + 2 * PEN_E) / PEN_X;  // wfa.rs:212
                         if (jump1 == jump2 && jump1 <= safe_mismatch) {
-                            // (the bases of the whole stretch first — at most three of each — then the pushes: their stores would hold the loads up)
+                            // (one base: the short-read case. Else the bases of the whole stretch first — at most three of each — then the
+                            // pushes: their stores would hold the loads up)
+                            if (jump1 == 1) out.push_checked(S.r(w.last2) == S.q(w.last1) ? OP_EQ : OP_X, 1);
+                            else {
                             bool eq[safe_mismatch];
 #pragma unroll
                             for (uint32_t t = 0; t < safe_mismatch; t++) eq[t] = S.r(w.last2 + min(t, jump1 - 1)) == S.q(w.last1 + min(t, jump1 - 1));
 #pragma unroll
                             for (uint32_t t = 0; t < safe_mismatch; t++) if (t < jump1) out.push_checked(eq[t] ? OP_EQ : OP_X, 1);
+                            }
                         } else {
                             // A stretch for the aligner between two anchors. Nothing of the walk depends on how it aligns (an end-to-end
                             // alignment consumes both stretches completely, whatever its operations): the stretch is noted, a marker takes
@@ -771,12 +790,13 @@ __device__ inline uint32_t walk_step(Walk& w, const SrcCigar& ij, const Seqs& S,
 // Cigar::optimize (MAX_OPTIMIZATION_GAP 20, OPTIMIZATION_ANCHOR 5) + boundary_ins_to_soft (cigar.rs:554-561) of the finished transfers
 // of a wavefront: `mine` = this lane has one. The lanes scan their CIGARs; those that stand in front of a stretch call smart_align at one site.
 // (diag: developer build, four counters — ticks inside smart_align, rounds, lanes with a stretch, largest matrix of a round)
-__device__ inline void optimize_and_finish(bool mine, DCigar& out, const Seqs& S, Scratch& sc, uint32_t* lds_win, uint32_t* lds_wb,
+template <bool SMALL>
+__device__ inline void optimize_and_finish(bool mine, DCigar& out, const Seqs& S, Scratch& sc, uint32_t* slice_a, uint32_t* slice_b,
                                            unsigned long long* diag = nullptr) {
     OptState o;
     Job job;
     bool active = mine;
-    if (mine) opt_init(o, out, sc, lds_win, lds_wb);
+    if (mine) opt_init(o, out, sc, slice_a, slice_b);
     do {
         // a round: every lane that is scanning reads its next items (all lanes' loads in flight together) and scans on to a stretch, the end
         // of its window or the end of the CIGAR; the lanes that stand in front of a stretch call smart_align (see the assemble loop)
@@ -788,7 +808,7 @@ __device__ inline void optimize_and_finish(bool mine, DCigar& out, const Seqs& S
         if (active && !need) opt_fill(o, out);                                // at the end of its window (the first round: of the empty one)
         unsigned long long t0 = 0;
         if (diag) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-        if (need) smart_align(S, job.i1, job.i1 + job.n, job.j1, job.j1 + job.m, 0xFFFFFFFFu, o.nc, sc);
+        if (need) smart_align<SMALL>(S, job.i1, job.i1 + job.n, job.j1, job.j1 + job.m, 0xFFFFFFFFu, o.nc, sc);
         if (diag) {
             __builtin_amdgcn_sched_barrier(0);
             diag[0] += __builtin_amdgcn_s_memtime() - t0; diag[1]++;
