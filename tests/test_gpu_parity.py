@@ -1050,12 +1050,15 @@ def test_alignment_recovery_neighbour_bin_quirk(gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_alignment_recovery_of_10kb_reads_against_the_oracle(gpu_ctx):
+@pytest.mark.parametrize("read_len,longest", [(10_000, 7000), (500, 600)])
+def test_alignment_recovery_of_10kb_reads_against_the_oracle(gpu_ctx, read_len, longest):
     """BASELINE.json configs[2] in its stated form, at test size: 10-kb single-end ONT reads (3 % errors, CIGARs of ~670 operations),
     the mapper reports the primary alignment only, every other allele is reached by HapAlns::transfer_alignments. Statuses, k-mer
-    counts, weights, the likelihood matrix and the pair alignments after recovery equal the oracle's."""
+    counts, weights, the likelihood matrix and the pair alignments after recovery equal the oracle's.
+    500-base reads (CIGARs of up to ~200 operations) take the other build of the kernel: four wavefronts per SIMD, the general aligner only,
+    transferred CIGARs of several 16-item chunks in global memory read back through the windows."""
     n_alleles, n_reads = 6, 48
-    L = synth.SynthLocus(n_alleles, n_reads, seed=synth.SEED + 5, technology=cdefs.TECH_NANOPORE, read_len=10_000, base_len=40_000)
+    L = synth.SynthLocus(n_alleles, n_reads, seed=synth.SEED + 5, technology=cdefs.TECH_NANOPORE, read_len=read_len, base_len=40_000)
     p = api.resolve_params(api.default_params(), L.bg)
     loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
     ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
@@ -1065,7 +1068,9 @@ def test_alignment_recovery_of_10kb_reads_against_the_oracle(gpu_ctx):
     H.sort()
     loc.set_hap_alns(H.entries, transfer_fails=100, max_div=0.1)
     prim = L.reads(0, n_reads, primaries_only=True)
-    assert int(prim.mate_len.max()) > 7000 and len(prim.recs) <= 2 * n_reads
+    assert int(prim.mate_len.max()) > longest and len(prim.recs) <= 2 * n_reads
+    n_words = max(int(r["n_cigar"]) for r in prim.recs) if len(prim.recs) else 0
+    assert (n_words > 256) == (read_len == 10_000) and n_words > 16                 # which build of the kernel the batch gets (lcty_transfer.hip: long_cigars)
     aa = api.AllAlignments.load(loc, prim)
     n_rec = aa.recover()
     oa = ol.load_recover(prim, H)
