@@ -1065,6 +1065,16 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
             tail_ended = ended->get_future().share();
             { std::lock_guard<std::mutex> lock(ctx->gate.m); ctx->gate.tails_started++; }
             lcty_ctx* c = ctx;
+            // (a tail that cannot be started has no initialisation to wait for: the count must not stay ahead, or the next stage of this
+            // context — this queue's or a later call's — would wait for it for ever)
+            struct StartGuard {
+                lcty_ctx* c; bool armed = true;
+                ~StartGuard() {
+                    if (!armed) return;
+                    { std::lock_guard<std::mutex> lock(c->gate.m); c->gate.tail_inits = c->gate.tails_started; }
+                    c->gate.cv.notify_all();
+                }
+            } start_guard{c};
             tail_thread = std::thread([run, ended, c, &tail_rc, &tail_msg] {
                 try { run->tail(1); }
                 catch (const Error& e) { tail_rc = e.code; tail_msg = e.what(); }
@@ -1074,6 +1084,7 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
                 c->gate.cv.notify_all();
                 ended->set_value();
             });
+            start_guard.armed = false;
         }
         join_tail();
     } catch (...) {
