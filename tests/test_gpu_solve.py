@@ -443,6 +443,28 @@ def test_queue_of_loci_equals_one_locus_at_a_time(gpu_ctx):
     assert e.value.code == cdefs.ERR_INVALID_INPUT
 
 
+@pytest.mark.parametrize("scheme", ["greedy-greedy-anneal", "anneal only", "greedy only"])
+def test_queue_with_other_schemes_equals_one_locus_at_a_time(gpu_ctx, scheme):
+    """The queue's three lanes (head of the next locus on the fore stream, chains on the main stream, last stage on the side stream) and the
+    two launch gates with schemes of three stages (two of them in the head's chains) and of ONE stage (no chains in the head at all: the
+    only stage is the tail's): every entry gets what lcty_solve gives it alone."""
+    kinds = {"greedy-greedy-anneal": [(cdefs.SOLVER_GREEDY, 30, 1), (cdefs.SOLVER_GREEDY, 10, 2), (cdefs.SOLVER_ANNEAL, 4, 3)],
+             "anneal only": [(cdefs.SOLVER_ANNEAL, 12, 2)], "greedy only": [(cdefs.SOLVER_GREEDY, 20, 2)]}[scheme]
+    stages = (cdefs.Stage * len(kinds))()
+    for st, (kind, in_size, attempts) in zip(stages, kinds):
+        st.solver = api.default_solver(kind); st.in_size = in_size; st.attempts = attempts
+    cases = [setup(gpu_ctx, 8, 2500 + 600 * i, 12000, seed=140 + i) for i in range(3)]
+    batches = [c[3] for c in cases]
+    alone = [api.solve_locus(b, stages, master_seed=31 + i)[0] for i, b in enumerate(batches)]
+    order = [0, 1, 2, 1]
+    calls = api.solve_queue([batches[i] for i in order], stages, master_seeds=[31 + i for i in order])
+    for i, c in zip(order, calls):
+        a = alone[i]
+        n = int(a.n_out)
+        assert int(c.n_out) == n and list(c.ixs[:n]) == list(a.ixs[:n]) and list(c.ln_probs[:n]) == list(a.ln_probs[:n])
+        assert (c.unexpl_reads, c.n_good, c.warnings, c.kept_after_filter, c.quality) == (a.unexpl_reads, a.n_good, a.warnings, a.kept_after_filter, a.quality)
+
+
 def test_fed_queue_of_distinct_loci_equals_the_resident_queue(gpu_ctx):
     """lcty_solve_queue_fed + lcty_reads_reset: five positions over three loci through THREE rotating batch objects, each position uploaded
     (counted alignments, from a loader thread, on the copy stream) while the position before it is solved. Every call equals what the
