@@ -627,7 +627,7 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
  * attempts: a few hundred long serial chains on a few per cent of the device) runs on a second stream of the context, from a second
  * host thread, while entry i + 1 is greedily solved — and what comes before the chains of entry i + 2 (its scores, run_filter, the cut,
  * the location table) is issued on a third stream, by a third host thread, as soon as the last stage of entry i has ended, beside the
- * greedy chains of entry i + 1 (knob "queue_early_head" 0: on the main stream after those chains, as lcty_solve_queue_fed does).
+ * greedy chains of entry i + 1 (knob "queue_early_head" 0: on the main stream after those chains).
  * out[i] equals what lcty_solve gives for entry i alone.
  * All batches share one context; neighbours in the queue are different batches of different lcty_locus objects (a batch may come
  * again later in the queue: it is scored again). master_seeds[n_batches]; priors NULL or [n_batches] pointers (NULL = no priors). */
@@ -637,8 +637,11 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
  * scored and returns its batch (NULL: the queue ends with LCTY_ERR_INVALID_INPUT) — typically filled by another host thread, with
  * lcty_reads_append* on page-locked chunks (their copies have a stream of their own), while position i - 1 is being solved;
  * `release(user, i)` (may be NULL) when the last stage of position i is done and nothing of its batch is in use: lcty_reads_reset can
- * then bind the object to the locus of a later position. Position i is released before position i + 2 is acquired, so three batch
- * objects carry a queue of any length. The loading of locus i + 1 next to analyze_locus of locus i (genotype.rs:1331-1351). */
+ * then bind the object to the locus of a later position. Position i is released before position i + 3 is acquired, so three batch
+ * objects carry a queue of any length. `acquire(user, i)` for i > 0 comes from a thread of the library, while position i - 1 is in its
+ * chains and once the last stage of position i - 2 has ended (the head of position i is made there: lcty_solve_queue), and may run at
+ * the same time as a `release` on the caller's thread; with knob "queue_early_head" 0 both come from the caller's thread, `acquire(i)`
+ * after the chains of position i - 1 and after `release(i - 2)`. The loading of locus i + 1 next to analyze_locus of locus i (genotype.rs:1331-1351). */
 typedef lcty_reads* (*lcty_queue_acquire_fn)(void* user, uint32_t position);
 typedef void (*lcty_queue_release_fn)(void* user, uint32_t position);
 int32_t lcty_solve_queue_fed(uint32_t n_loci, lcty_queue_acquire_fn acquire, lcty_queue_release_fn release, void* user, uint32_t ploidy,

@@ -986,15 +986,16 @@ int32_t lcty_solve(lcty_reads* reads, uint32_t ploidy, const lcty_stage* stages,
 namespace {
 // the queue of lcty_solve_queue / lcty_solve_queue_fed: `batch_of(i)` right before position i is scored, `done_with(i)` once its
 // last stage has been joined.
-// `early`: what comes before the chains of locus i + 1 (LocusRun::pre: scores, run_filter, the cut, the location table — 19 + 2.5 ms of
-// a 380-ms step at 1 M read pairs x 256 alleles) is issued by a third host thread on the context's fore stream as soon as the last
-// stage of locus i - 1 has ended, i.e. beside the greedy chains of locus i, which leave the device's issue slots and a fifth of its
-// LDS free. Batch i + 1 is then touched while locus i is in its chains — never before the tail of i - 1 has ended, so "an entry may
-// appear again, not next to itself" still holds — and `batch_of` / `done_with` would be called from that thread and earlier: only the
-// array form (lcty_solve_queue), where they are look-ups, takes this path.
+// What comes before the chains of locus i + 1 (LocusRun::pre: scores, run_filter, the cut, the location table — 19 + 2.5 ms of a 380-ms
+// step at 1 M read pairs x 256 alleles) is issued by a third host thread on the context's fore stream as soon as the last stage of locus
+// i - 1 has ended, i.e. beside the greedy chains of locus i, which leave the device's issue slots and a fifth of its LDS free (knob
+// "queue_early_head" 0: on the main stream after those chains). Batch i + 1 is then touched while locus i is in its chains — never
+// before the tail of i - 1 has ended, so "an entry may appear again, not next to itself" still holds. `batch_of(i + 1)` is called from
+// that thread (a fed queue's loader needs the time until then), `done_with` from the caller's: a fed queue's callbacks may run at the
+// same time, and position i + 1 is acquired BEFORE position i - 1 is released (three batch objects still carry any length).
 template <typename GET, typename DONE>
 void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, const lcty_stage* stages, uint32_t n_stages,
-               const uint64_t* master_seeds, const double* const* priors, lcty_call* out, bool early) {
+               const uint64_t* master_seeds, const double* const* priors, lcty_call* out) {
     std::unique_ptr<LocusRun> prev, next;
     std::thread tail_thread, fore_thread;
     int32_t tail_rc = LCTY_OK; std::string tail_msg;
@@ -1028,19 +1029,20 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
     try {
         for (uint32_t i = 0; i < n; i++) {
             std::unique_ptr<LocusRun> R;
-            if (next) { join_fore(); R = std::move(next); }                   // its scores, cut and tables were made beside the chains of locus i - 1
+            if (fore_thread.joinable()) { join_fore(); R = std::move(next); } // its scores, cut and tables were made beside the chains of locus i - 1
             else { R = make_run(i); R->pre(true); }
             ctx = R->reads->ctx;
-            if (early && i + 1 < n) {
-                next = make_run(i + 1);
-                if (next->reads->ctx != ctx) fail(LCTY_ERR_INVALID_INPUT, "the batches of a queue share one context");
-                LocusRun* nx = next.get();
+            if (i + 1 < n && ctx->knob("queue_early_head", 1) != 0) {
                 std::shared_future<void> before = tail_ended;               // the tail of locus i - 1: batch i + 1 may be the batch it works on
                 lcty_ctx* c = ctx;
-                fore_thread = std::thread([nx, before, c, &fore_rc, &fore_msg] {
+                // (`batch_of(i + 1)` from that thread too, once the tail has ended: a fed queue's loader is filling that batch meanwhile)
+                fore_thread = std::thread([&next, &make_run, i, before, c, &fore_rc, &fore_msg] {
                     try {
                         if (before.valid()) before.wait();
                         c->activate();
+                        next = make_run(i + 1);
+                        if (next->reads->ctx != c) fail(LCTY_ERR_INVALID_INPUT, "the batches of a queue share one context");
+                        LocusRun* nx = next.get();
                         StreamScope on_fore(c->fore_stream());
                         nx->pre(true);
                         LCTY_HIP(hipStreamSynchronize(c->fore_stream()));       // the chains of this locus are issued on the main stream
@@ -1115,8 +1117,7 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
             if (i && (batches[i] == batches[i - 1] || batches[i]->locus == batches[i - 1]->locus))
                 fail(LCTY_ERR_INVALID_INPUT, "neighbours in the queue must be different batches of different loci");
         }
-        run_queue(n_batches, [&](uint32_t i) { return batches[i]; }, [](uint32_t) {}, ploidy, stages, n_stages, master_seeds, priors, out,
-                  batches[0]->ctx->knob("queue_early_head", 1) != 0);
+        run_queue(n_batches, [&](uint32_t i) { return batches[i]; }, [](uint32_t) {}, ploidy, stages, n_stages, master_seeds, priors, out);
     });
 }
 
@@ -1138,7 +1139,7 @@ int32_t lcty_solve_queue_fed(uint32_t n_loci, lcty_queue_acquire_fn acquire, lct
                 fail(LCTY_ERR_INVALID_INPUT, "neighbours in the queue must be different batches of different loci in one context");
             before = r;
             return r;
-        }, [&](uint32_t i) { if (release) release(user, i); }, ploidy, stages, n_stages, master_seeds, priors, out, false);
+        }, [&](uint32_t i) { if (release) release(user, i); }, ploidy, stages, n_stages, master_seeds, priors, out);
     });
 }
 

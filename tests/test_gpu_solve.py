@@ -468,7 +468,7 @@ def test_queue_with_other_schemes_equals_one_locus_at_a_time(gpu_ctx, scheme):
 def test_fed_queue_of_distinct_loci_equals_the_resident_queue(gpu_ctx):
     """lcty_solve_queue_fed + lcty_reads_reset: five positions over three loci through THREE rotating batch objects, each position uploaded
     (counted alignments, from a loader thread, on the copy stream) while the position before it is solved. Every call equals what the
-    locus gets alone; a batch is released before the position two further on is acquired; a source without a batch ends the queue."""
+    locus gets alone; a batch is released before the position three further on is acquired; a source without a batch ends the queue."""
     import threading
     stages = (cdefs.Stage * 2)()
     stages[0].solver = api.default_solver(cdefs.SOLVER_GREEDY); stages[0].in_size = 30; stages[0].attempts = 1
@@ -522,9 +522,32 @@ def test_fed_queue_of_distinct_loci_equals_the_resident_queue(gpu_ctx):
         n = int(a.n_out)
         assert int(c.n_out) == n and list(c.ixs[:n]) == list(a.ixs[:n]) and list(c.ln_probs[:n]) == list(a.ln_probs[:n])
         assert (c.unexpl_reads, c.n_good, c.warnings, c.kept_after_filter) == (a.unexpl_reads, a.n_good, a.warnings, a.kept_after_filter)
+    # three objects carry the queue: a position is released before the position three further on is acquired (the head of position q + 2 is
+    # made beside the chains of position q + 1, i.e. it is acquired before position q — whose last stage has ended by then — is released)
+    for q in range(len(order) - 3):
+        assert events.index(("release", q)) < events.index(("acquire", q + 3))
+    assert [e for e in events if e[0] == "release"] == [("release", q) for q in range(len(order))]
+    assert [e for e in events if e[0] == "acquire"] == [("acquire", q) for q in range(len(order))]
+    # and with the head of a position made after the chains of the position before it (the order of round 4): two further on
+    gpu_ctx.set_knob("queue_early_head", 0)
+    try:
+        events.clear()
+        ready2 = [threading.Event() for _ in order]
+        ready[:] = ready2
+        for f in free:
+            while f.acquire(blocking=False): pass
+            f.release()
+        th = threading.Thread(target=loader)
+        th.start()
+        late = api.solve_queue_fed(len(order), acquire, release, stages, master_seeds=[21 + j for j in order])
+        th.join()
+    finally:
+        gpu_ctx.set_knob("queue_early_head", -1)
+    for c, l in zip(calls, late):
+        n = int(c.n_out)
+        assert int(l.n_out) == n and list(l.ixs[:n]) == list(c.ixs[:n]) and list(l.ln_probs[:n]) == list(c.ln_probs[:n])
     for q in range(len(order) - 2):
         assert events.index(("release", q)) < events.index(("acquire", q + 2))
-    assert [e for e in events if e[0] == "release"] == [("release", q) for q in range(len(order))]
     # a source that has nothing for a position: the queue ends with an error, the positions before it were released
     with pytest.raises(_lib.LocityperError) as e:
         api.solve_queue_fed(2, lambda q: rot[0] if q == 0 else None, None, stages)
