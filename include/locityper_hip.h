@@ -575,6 +575,50 @@ int32_t lcty_chain_seeds(uint64_t master_seed, uint64_t n, uint64_t* out);
 int32_t lcty_solve_stage(lcty_reads* reads, const uint16_t* genotypes, uint64_t n_gt, uint32_t ploidy, const double* priors,
                          const lcty_solver* solver, uint32_t attempts, const uint64_t* chain_seeds,
                          double* lik_mean, double* lik_var, double* liks_out);
+
+/* ---- `trait Solver` on the caller's own object (src/solvers/mod.rs:49-75) ------------------------------------------------
+ * The reference calls a solver as `gt_alns.apply_tweak(rng, ..); stage.solver.solve(&gt_alns, rng)` (solve.rs:824-826): the
+ * solver is handed a GenotypeAlignments (model/assgn.rs:16-36) the CALLER built and tweaked, and returns a ReadAssignment
+ * (assgn.rs:171-186) borrowing it. lcty_gt_alns_view is that object as plain arrays, lcty_solve_given is `Solver::solve` on it:
+ * ONE chain of `solver` (Greedy, stoch.rs:81-120; SimAnneal, 195-245; the exact model of highs.rs:38-134) on the device, over
+ * exactly the locations, windows and window distributions given — nothing is re-derived from a read batch and no tweak is drawn.
+ *   read_ixs[n_reads + 1]   assgn.rs:29-33; read pair i has the locations read_ixs[i] .. read_ixs[i + 1] (at least one, best first)
+ *   ln_prob[n_alns]         ReadGtAlns::ln_prob (windows.rs:83-92)
+ *   windows[2 * n_alns]     ReadGtAlns::windows after define_windows_determ / _random (windows.rs:112-136)
+ *   window_gc / _weight[n_windows]   depth_distrs (assgn.rs:21, 140-150): WindowDistr::weight, 0 = WindowDistr::TRIVIAL
+ *                           (distr_cache.rs:28-31); the GC bin selects the cached distribution of `locus` (DistrCache,
+ *                           distr_cache.rs:61-92); windows 0 and 1 are the two trivial ones (assgn.rs:72-77)
+ *   depth_contrib, aln_contrib   assgn.rs:24-25, 80-81
+ *   wshifts[n_contigs + 1]  GenotypeWindows::wshifts (windows.rs:709-739), optional (n_contigs 0): only the exact solver looks
+ *                           at it, for the order of its search
+ * rng_state: the four words of the caller's XoshiroRng (xoshiro256++, ext/rand.rs:3). With non-trivial reads the call draws ONE
+ * next_u64 from it — the chain's seed, as lcty_solve_stage takes one seed per chain; the chain is then that of lcty_solve_stage for
+ * this seed (DESIGN.md §2 lists the adaptors) — and leaves the state advanced by that draw. A genotype without non-trivial reads has
+ * one assignment (Solver::solve, mod.rs:64-66): the generator is not touched (rng_state may be NULL).
+ * Outputs: read_assgn[n_reads] (ReadAssignment::read_assgn), lik_parts = {aln_lik, depth_lik} (optional), *likelihood =
+ * depth_contrib * depth_lik + aln_contrib * aln_lik (ReadAssignment::likelihood, assgn.rs:235-237; optional).
+ * Re-entrant: any number of host threads may call it at once on one locus (the Solver contract: `&self` shared by the worker
+ * threads, solve.rs:254-257, 1010-1017); every call in flight has its own stream and chain state. Limits of the device solver:
+ * < 2^24 read pairs, <= 255 locations per read pair (LCTY_ERR_UNSUPPORTED beyond; the reference asserts <= 65 535, assgn.rs:58).
+ * LCTY_ERR_SOLVER as `Error::Solver` (err.rs:14): the exact solver without a proof inside its node limit (highs.rs:113-116). */
+typedef struct lcty_gt_alns_view {
+    uint64_t n_reads;
+    const uint64_t* read_ixs;
+    const double*   ln_prob;
+    const uint32_t* windows;
+    uint32_t n_windows;
+    uint32_t n_contigs;
+    const uint8_t*  window_gc;
+    const double*   window_weight;
+    const uint32_t* wshifts;
+    double depth_contrib, aln_contrib;
+} lcty_gt_alns_view;
+int32_t lcty_solve_given(lcty_locus* locus, const lcty_gt_alns_view* gt_alns, const lcty_solver* solver, uint64_t* rng_state,
+                         uint16_t* read_assgn, double* lik_parts, double* likelihood);
+/* XoshiroRng::seed_from_u64 (ext/rand.rs:3-22) into four words / next_u64 on them: for a caller whose generator keeps its state
+ * private (rand_xoshiro without serde): `lcty_rng_seed_from_u64(rng.next_u64(), state)` starts a stream for the solver calls */
+int32_t lcty_rng_seed_from_u64(uint64_t seed, uint64_t* state);
+int32_t lcty_rng_next_u64(uint64_t* state, uint64_t* out);
 /* Per-read assignment counts of ONE genotype over `attempts` chains — the "per-read posteriors" behind the output BAMs
  * (GenotypeAlignments::create_counts + ReadAssignment::update_counts, assgn.rs:94-96, 374-378; solve.rs:821-836;
  * model/bam.rs divides by `attempts`). read_off[n_good + 1]: first count of every good read pair, its possible

@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 
-from .cdefs import Bg, Params, ReadsHost, PairAln, Solver, Stage, Call
+from .cdefs import Bg, Params, ReadsHost, PairAln, Solver, Stage, Call, GtAlnsView
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocityper_hip.so")
@@ -82,6 +82,9 @@ SIGNATURES = {
     "lcty_solver_default": (I32, [P(Solver), I32]),
     "lcty_chain_seeds": (I32, [U64, U64, VP]),
     "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
+    "lcty_solve_given": (I32, [VP, P(GtAlnsView), P(Solver), VP, VP, VP, P(D)]),
+    "lcty_rng_seed_from_u64": (I32, [U64, VP]),
+    "lcty_rng_next_u64": (I32, [VP, P(U64)]),
     "lcty_solve_stage_sharded": (I32, [VP, VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
     "lcty_solve_stage_read_sharded": (I32, [VP, VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
     "lcty_solve_stage_from_shards": (I32, [VP, U32, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),

@@ -405,6 +405,48 @@ def solve_stage(aa, genotypes, solver, attempts, seeds, priors=None):
     return mean, var, liks
 
 
+def rng_seed_from_u64(seed):
+    """The four words of XoshiroRng::seed_from_u64(seed) (ext/rand.rs:3-22)."""
+    st = np.zeros(4, dtype=np.uint64)
+    check(lib().lcty_rng_seed_from_u64(seed, st.ctypes.data))
+    return st
+
+
+def rng_next_u64(state):
+    """next_u64 of the xoshiro256++ generator whose four words `state` holds (advanced in place)."""
+    out = U64(0)
+    check(lib().lcty_rng_next_u64(state.ctypes.data, C.byref(out)))
+    return int(out.value)
+
+
+def solve_given(locus, read_ixs, ln_prob, windows, window_gc, window_weight, depth_contrib, aln_contrib, solver, rng_state, wshifts=None):
+    """`Solver::solve` (solvers/mod.rs:59-72) on a GenotypeAlignments handed over as arrays (lcty_solve_given): one chain on the device
+    over exactly these locations and window distributions. Returns (likelihood, read_assgn u16[n_reads], (aln_lik, depth_lik));
+    `rng_state` (four uint64 words, xoshiro256++) is advanced in place by the one draw the call takes."""
+    read_ixs = np.ascontiguousarray(read_ixs, dtype=np.uint64)
+    ln_prob = np.ascontiguousarray(ln_prob, dtype=np.float64)
+    windows = np.ascontiguousarray(windows, dtype=np.uint32).reshape(-1)
+    window_gc = np.ascontiguousarray(window_gc, dtype=np.uint8)
+    window_weight = np.ascontiguousarray(window_weight, dtype=np.float64)
+    n_reads = len(read_ixs) - 1
+    v = cdefs.GtAlnsView()
+    v.n_reads = n_reads
+    v.read_ixs, v.ln_prob, v.windows = read_ixs.ctypes.data, ln_prob.ctypes.data, windows.ctypes.data
+    v.n_windows = len(window_weight)
+    v.window_gc, v.window_weight = window_gc.ctypes.data, window_weight.ctypes.data
+    ws = None
+    if wshifts is not None:
+        ws = np.ascontiguousarray(wshifts, dtype=np.uint32)
+        v.n_contigs, v.wshifts = len(ws) - 1, ws.ctypes.data
+    v.depth_contrib, v.aln_contrib = depth_contrib, aln_contrib
+    assgn = np.zeros(max(n_reads, 1), dtype=np.uint16)
+    parts = np.zeros(2, dtype=np.float64)
+    lik = D(0.0)
+    check(lib().lcty_solve_given(locus._h, C.byref(v), C.byref(solver), None if rng_state is None else rng_state.ctypes.data,
+                                 assgn.ctypes.data, parts.ctypes.data, C.byref(lik)))
+    return float(lik.value), assgn[:n_reads], parts
+
+
 def solve_stage_from_shards(shards, genotypes, solver, attempts, seeds, priors=None):
     """One solver stage over the reads of several batches of one locus on one device (lcty_solve_stage_from_shards): `shards` in
     read order; equals solve_stage on the unsharded batch."""

@@ -92,6 +92,23 @@ class Solver(C.Structure):
     ]
 
 
+class GtAlnsView(C.Structure):
+    """lcty_gt_alns_view: a GenotypeAlignments after apply_tweak as plain arrays (model/assgn.rs:16-36)."""
+    _fields_ = [
+        ("n_reads", C.c_uint64),
+        ("read_ixs", C.c_void_p),
+        ("ln_prob", C.c_void_p),
+        ("windows", C.c_void_p),
+        ("n_windows", C.c_uint32),
+        ("n_contigs", C.c_uint32),
+        ("window_gc", C.c_void_p),
+        ("window_weight", C.c_void_p),
+        ("wshifts", C.c_void_p),
+        ("depth_contrib", C.c_double),
+        ("aln_contrib", C.c_double),
+    ]
+
+
 class AlnRec(C.Structure):
     _fields_ = [
         ("pos", C.c_uint32),

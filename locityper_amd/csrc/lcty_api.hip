@@ -106,6 +106,7 @@ void lcty_ctx_destroy(lcty_ctx* ctx) {
     if (ctx->gate.init_ev) (void)hipEventDestroy(ctx->gate.init_ev);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->fore) { (void)hipStreamSynchronize(ctx->fore); (void)hipStreamDestroy(ctx->fore); }
+    for (auto& slot : ctx->given_slots) if (slot->stream) { (void)hipStreamSynchronize(slot->stream); (void)hipStreamDestroy(slot->stream); }
     (void)hipStreamDestroy(ctx->stream.main);
     delete ctx;
 }
@@ -140,6 +141,14 @@ int32_t lcty_ctx_trim(lcty_ctx* ctx) {
         LCTY_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->side) LCTY_HIP(hipStreamSynchronize(ctx->side));
         for (auto& w : ctx->solve_ws) w.release_all();
+        {
+            std::lock_guard<std::mutex> g(ctx->given_mutex);
+            for (auto& slot : ctx->given_slots) {
+                if (slot->busy) continue;                                     // a call of another thread is using it
+                slot->ws.release_all(); slot->lut.release(); slot->lut_depth = 0; slot->lut_of = 0;
+                slot->read_ixs.release(); slot->lp.release(); slot->weight.release(); slot->win.release(); slot->gc.release(); slot->assgn.release();
+            }
+        }
         ctx->release_transfer_scratch();
     });
 }

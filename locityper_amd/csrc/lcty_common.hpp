@@ -231,6 +231,18 @@ struct lcty_ctx {
             seeds.release(); pri.release(); liks.release(); parts.release(); cww.release(); caln.release(); dbg.release(); init_plan.release(); extra_cap = 0;
         }
     } solve_ws[2];
+    // lcty_solve_given (lcty_solve_given.hip): `Solver::solve` is called from the reference's worker threads at once; every call in flight
+    // has a slot — a stream, the state of one chain, the caller's arrays on the device, a depth table of its own. Grow-only, kept between
+    // calls; lcty_ctx_trim releases the slots that are free.
+    struct GivenSlot {
+        hipStream_t stream = nullptr;
+        bool busy = false;
+        SolveWorkspace ws;
+        lcty::DevBuf<double> lut; uint32_t lut_depth = 0; uint64_t lut_of = 0;          // serial of the locus the table was made for
+        lcty::DevBuf<uint64_t> read_ixs; lcty::DevBuf<double> lp, weight; lcty::DevBuf<uint32_t> win; lcty::DevBuf<uint8_t> gc; lcty::DevBuf<uint16_t> assgn;
+    };
+    std::vector<std::unique_ptr<GivenSlot>> given_slots;
+    std::mutex given_mutex;
     // Lane scratch of alignment recovery (lcty_transfer.hip): tens of GB for long reads, kept between the chunks of a streaming batch
     // (allocating it costs more than the kernel). The solver stages take it back before they size their own workspace; lcty_ctx_trim
     // releases it.

@@ -5,6 +5,7 @@
 //   LUTs: InsertDistr (bg/insertsz.rs:195-208), DistrCache (model/distr_cache.rs:61-75),
 //         EditDistCache (bg/err_prof.rs:415-448)
 #include <algorithm>
+#include <atomic>
 #include <memory>
 
 #include "lcty_objects.hpp"
@@ -328,6 +329,8 @@ int32_t lcty_locus_create(lcty_ctx* ctx, uint32_t n_alleles, const uint8_t* seqs
         ctx->activate();
 
         auto L = std::unique_ptr<lcty_locus>(new lcty_locus());
+        static std::atomic<uint64_t> next_serial{1};
+        L->serial = next_serial.fetch_add(1);
         L->ctx = ctx; L->n_alleles = n_alleles; L->k = k; L->bg = *bg; L->prm = *params;
         const uint32_t neighb = bg->neighb, window = bg->window, ck = params->complexity_k;
         if (window == 0 || neighb < window) fail(LCTY_ERR_INVALID_DATA, "bg_depth: neighbourhood (%u) < window (%u)", neighb, window);

@@ -12,6 +12,7 @@
 // ContigSet + KmerCounts + ContigInfos + UniqueKmers + InsertDistr + EditDistCache + DistrCache
 struct lcty_locus {
     lcty_ctx* ctx = nullptr;
+    uint64_t serial = 0;                     // unique per created locus (a later locus can sit at the address of a destroyed one)
     uint32_t n_alleles = 0, k = 0;
     lcty_bg bg{};
     lcty_params prm{};

@@ -186,6 +186,7 @@ struct InitPlan {
 // ---- launchers of lcty_solve_kernels.hip (the only way the host side starts a solver kernel) ----
 void ensure_solver_tables(lcty_reads* reads);                              // location table + compact "unmapped" column of a scored batch
 void ensure_depth_table(lcty_locus* loc, uint64_t want);                   // extended depth table of the locus, at least `want` wide
+void build_depth_table_into(const lcty_locus* loc, uint32_t depth, DevBuf<double>& out, hipStream_t s);   // the same table into a buffer of the caller's
 bool solver_lds_fits(uint32_t wstride);                                    // the window arrays of one chain next to the annealing ring in 160 KB of LDS
 // the batch of a stage as the host has it: what plan_init_groups makes the groups of a diploid stage from (row_of: NULL = the allele itself)
 struct InitHost {

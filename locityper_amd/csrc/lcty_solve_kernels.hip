@@ -2009,6 +2009,17 @@ void ensure_depth_table(lcty_locus* loc, uint64_t want) {
     loc->lut_ext_depth = depth;
 }
 
+// the same table of `loc` into a buffer of the caller's, on the caller's stream: lcty_solve_given keeps one per slot,
+// so that calls from several threads never share a table that one of them is widening
+void build_depth_table_into(const lcty_locus* loc, uint32_t depth, DevBuf<double>& out, hipStream_t s) {
+    if (depth > (1u << 22)) fail(LCTY_ERR_UNSUPPORTED, "a window more than 4 M read ends deep (the depth table is addressed by 32-bit byte offsets)");
+    out.alloc(static_cast<size_t>(LCTY_GC_BINS) * depth);
+    const uint32_t n = LCTY_GC_BINS * depth;
+    hipLaunchKernelGGL(build_depth_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, loc->d_depth_lut.p, loc->d_depth_nb.p,
+                       static_cast<uint32_t>(loc->prm.n_alt_cn), depth, out.p);
+    LCTY_HIP(hipGetLastError());
+}
+
 // a few microseconds of nothing (one wavefront): lets the workgroups of a kernel launched just before on another stream get resident
 __global__ void pause_kernel(uint32_t rounds) {
     for (uint32_t i = 0; i < rounds; i++) __builtin_amdgcn_s_sleep(127);

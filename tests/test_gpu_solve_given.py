@@ -1,0 +1,226 @@
+"""lcty_solve_given — `Solver::solve` on the GenotypeAlignments the CALLER holds (src/solvers/mod.rs:49-75, called as
+`gt_alns.apply_tweak(rng, ..); stage.solver.solve(&gt_alns, rng)` at src/solvers/solve.rs:824-826) — against the oracle.
+
+The oracle builds a GenotypeAlignments (orc_gt_alns_new = assgn.rs:41-84), tweaks it with a key of the TEST's choosing
+(orc_gt_alns_apply_tweak = assgn.rs:127-151) and hands its arrays over; the device must then run the chain orc_solve runs on that
+very object: same assignment read for read, same likelihood parts. The oracle is given the device's depth table, so both sides see
+bit-identical numbers and a chain cannot leave the other's trajectory."""
+import itertools
+import threading
+
+import numpy as np
+import pytest
+
+from locityper_amd import _lib, api, cdefs, synth
+from tests import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make(ctx, n_alleles, n_pairs, base_len, seed=31, tech=cdefs.TECH_ILLUMINA, read_len=150, **prm):
+    L = synth.SynthLocus(n_alleles, n_pairs, seed=seed, base_len=base_len, technology=tech, read_len=read_len)
+    p = api.default_params()
+    for k, v in prm.items():
+        setattr(p, k, v)
+    api.resolve_params(p, L.bg)
+    loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    oa = ol.load(L.reads(0, n_pairs))                                    # the oracle's own AllAlignments: no read batch on the device at all
+    width = 1
+    while width < 4 * n_pairs + 4:
+        width *= 2
+    ol.inject_tables(loc.depth_lut(), None)
+    ol.inject_depth_table(loc.depth_table(min(width, 1 << 16)))
+    return L, p, loc, ol, oa
+
+
+def view_of(g, p, tweak_key):
+    g.apply_tweak(tweak_key)
+    a = g.arrays()
+    gc, w = g.window_distr()
+    return dict(read_ixs=a["read_ixs"], ln_prob=a["ln_prob"], windows=a["windows"], window_gc=gc, window_weight=w,
+                depth_contrib=1.0 + p.lik_skew, aln_contrib=1.0 - p.lik_skew)
+
+
+def solvers():
+    g0 = api.default_solver(cdefs.SOLVER_GREEDY)
+    g1 = api.default_solver(cdefs.SOLVER_GREEDY)
+    g1.best_start, g1.sample_size, g1.plato_size = 0, 4, 40
+    a0 = api.default_solver(cdefs.SOLVER_ANNEAL)
+    a0.anneal_steps, a0.plato_size = 3000, 1500
+    return [g0, g1, a0]
+
+
+def check_one(loc, g, p, solver, tweak_key, master):
+    v = view_of(g, p, tweak_key)
+    state = api.rng_seed_from_u64(master)
+    ahead = state.copy()
+    seed = api.rng_next_u64(ahead)                                       # the one draw the call takes from the caller's generator
+    lik, assgn, parts = api.solve_given(loc, solver=solver, rng_state=state, **v)
+    olik, oassgn, oparts = g.solve(solver, seed)
+    assert np.array_equal(assgn, oassgn), f"{int((assgn != oassgn).sum())} of {len(assgn)} reads assigned differently"
+    assert abs(lik - olik) <= 1e-9 * abs(olik) and np.allclose(parts, oparts, rtol=1e-9, atol=1e-9)
+    if g.n_nontrivial:
+        assert np.array_equal(state, ahead), "the caller's generator is advanced by exactly one draw"
+    else:
+        assert np.array_equal(state, api.rng_seed_from_u64(master)), "a trivial genotype does not touch the generator"
+    return lik
+
+
+def test_fifty_given_genotype_alignments_equal_the_oracle_chain(gpu_ctx):
+    """PE diploid (heterozygous and homozygous), ploidy 3, single-end long reads; greedy (best start), greedy (random start, small sample),
+    annealing. The tweak key is NOT the chain's seed: the windows are the caller's, whatever they came from."""
+    n = 0
+    rnd = np.random.default_rng(5)
+    L, p, loc, ol, oa = make(gpu_ctx, 8, 3000, 20000)
+    cases = [(0, 1), (2, 5), (3, 3), (7, 7), (1, 6), (4, 4), tuple(int(x) for x in L.true_genotype)]
+    for ids, solver in itertools.product(cases, solvers()):
+        g = O.OracleGtAlns(ol, oa, ids)
+        check_one(loc, g, p, solver, int(rnd.integers(1, 2**63)), int(rnd.integers(1, 2**63)))
+        n += 1
+    for ids, solver in itertools.product([(0, 1, 2), (3, 3, 5), (6, 6, 6), (1, 4, 7)], solvers()):       # ploidy 3: further locations
+        g = O.OracleGtAlns(ol, oa, ids)
+        check_one(loc, g, p, solver, int(rnd.integers(1, 2**63)), int(rnd.integers(1, 2**63)))
+        n += 1
+    L, p, loc, ol, oa = make(gpu_ctx, 6, 300, 40000, tech=cdefs.TECH_NANOPORE, read_len=4000)
+    for ids, solver in itertools.product([(0, 1), (2, 2), (3, 5), (4,), (0, 3, 4)], solvers()):
+        g = O.OracleGtAlns(ol, oa, ids)
+        check_one(loc, g, p, solver, int(rnd.integers(1, 2**63)), int(rnd.integers(1, 2**63)))
+        n += 1
+    L, p, loc, ol, oa = make(gpu_ctx, 4, 1500, 9000, tweak=0)           # define_windows_determ
+    for ids in [(0, 1), (2, 3)]:
+        g = O.OracleGtAlns(ol, oa, ids)
+        check_one(loc, g, p, solvers()[0], 0, 99 + ids[0])
+        n += 1
+    assert n >= 50
+
+
+def test_given_chain_is_the_stage_chain_of_that_seed(gpu_ctx):
+    """With the windows of apply_tweak(seed) the call is the batch of one of lcty_solve_stage (same adaptors)."""
+    L = synth.SynthLocus(8, 4000, seed=31, base_len=20000)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(gpu_ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    aa = api.AllAlignments.load(loc, L.reads(0, 4000))
+    st, w, unm, uk = aa.status()
+    off, pa = aa.pair_alns()
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ol.inject_tables(loc.depth_lut(), loc.window_weights())
+    ol.inject_depth_table(loc.depth_table(1 << 14))
+    oa = O.alns_from_arrays(8, st, w, unm, off, pa)
+    for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+        solver = api.default_solver(kind)
+        for k, ids in enumerate([(0, 3), (5, 5), tuple(int(x) for x in L.true_genotype)]):
+            state = api.rng_seed_from_u64(1000 + k)
+            seed = api.rng_next_u64(state.copy())
+            g = O.OracleGtAlns(ol, oa, ids)
+            lik, assgn, parts = api.solve_given(loc, solver=solver, rng_state=state, **view_of(g, p, seed))
+            _, _, liks = api.solve_stage(aa, np.array([ids], dtype=np.uint16), solver, 1, np.array([seed], dtype=np.uint64))
+            assert abs(lik - liks[0, 0]) <= 1e-10 * abs(lik)
+
+
+def recompute(v, assgn, table):
+    """ReadAssignment::recalc_likelihood + likelihood (assgn.rs:235-237, 346-354) of an assignment, in numpy."""
+    ix = v["read_ixs"][:-1].astype(np.int64) + assgn.astype(np.int64)
+    aln = float(np.sum(v["ln_prob"][ix]))
+    depth = np.bincount(np.asarray(v["windows"]).reshape(-1, 2)[ix].reshape(-1), minlength=len(v["window_weight"]))
+    w = v["window_weight"]
+    dl = float(np.sum(np.where(w != 0.0, w * table[v["window_gc"].astype(np.int64), depth], 0.0)))
+    return v["depth_contrib"] * dl + v["aln_contrib"] * aln, aln, dl
+
+
+def test_the_call_honours_what_it_is_given(gpu_ctx):
+    """Arrays no read batch could have produced: windows permuted, weights and contributions changed, ln-probabilities perturbed. The
+    returned likelihood is that of the returned assignment ON THESE ARRAYS, a greedy chain from the best start does not end below its
+    start, and the exact solver equals enumeration."""
+    L, p, loc, ol, oa = make(gpu_ctx, 6, 1200, 9000)
+    table = loc.depth_table(1 << 13)
+    rnd = np.random.default_rng(11)
+    g = O.OracleGtAlns(ol, oa, (1, 4))
+    v = view_of(g, p, 77)
+    W = len(v["window_weight"])
+    perm = np.concatenate([[0, 1], 2 + rnd.permutation(W - 2)]).astype(np.uint32)
+    v["windows"] = perm[v["windows"]]
+    v["window_weight"] = np.where(rnd.random(W) < 0.2, 0.0, rnd.random(W)); v["window_weight"][:2] = 0.0
+    v["window_gc"] = rnd.integers(30, 70, W).astype(np.uint8)
+    v["ln_prob"] = v["ln_prob"] - rnd.random(len(v["ln_prob"]))
+    v["depth_contrib"], v["aln_contrib"] = 1.3, 0.7
+    for solver in solvers():
+        state = api.rng_seed_from_u64(3)
+        lik, assgn, parts = api.solve_given(loc, solver=solver, rng_state=state, **v)
+        n_loc = np.diff(v["read_ixs"]).astype(np.int64)
+        assert np.all(assgn < n_loc)
+        want, aln, dl = recompute(v, assgn, table)
+        assert abs(lik - want) <= 1e-9 * abs(want) and abs(parts[0] - aln) <= 1e-9 * abs(aln) and abs(parts[1] - dl) <= 1e-9 * max(1.0, abs(dl))
+        start, _, _ = recompute(v, np.zeros_like(assgn), table)
+        if solver.kind == cdefs.SOLVER_GREEDY and solver.best_start:
+            assert lik >= start - 1e-9 * abs(start)
+    # the exact solver on a model small enough to enumerate: twelve reads, six of them with two or three locations
+    rix = np.array([0, 1, 3, 4, 7, 8, 10, 11, 13, 14, 15, 18, 19], dtype=np.uint64)
+    n_alns = int(rix[-1])
+    small = dict(read_ixs=rix, ln_prob=-rnd.random(n_alns) * 8, windows=rnd.integers(2, 8, (n_alns, 2)).astype(np.uint32),
+                 window_gc=np.full(8, 50, dtype=np.uint8), window_weight=np.array([0, 0, 1, 0.5, 0.9, 1, 0.3, 0.8]), depth_contrib=1.85, aln_contrib=0.15)
+    for r in range(12):                                                  # best first, as extend_read_gt_alns leaves them
+        small["ln_prob"][int(rix[r]):int(rix[r + 1])] = -np.sort(-small["ln_prob"][int(rix[r]):int(rix[r + 1])])
+    ex = api.default_solver(cdefs.SOLVER_EXACT)
+    ex.init_prob = 0.0                                                   # a proof
+    lik, assgn, parts = api.solve_given(loc, solver=ex, rng_state=api.rng_seed_from_u64(1), wshifts=[2, 5, 8], **small)
+    best = -np.inf
+    for choice in itertools.product(*[range(int(rix[r + 1] - rix[r])) for r in range(12)]):
+        best = max(best, recompute(small, np.array(choice, dtype=np.uint16), table)[0])
+    assert abs(lik - best) <= 1e-9 * abs(best)
+    assert abs(recompute(small, assgn, table)[0] - lik) <= 1e-9 * abs(lik)
+
+
+def test_trivial_genotype_and_errors(gpu_ctx):
+    L, p, loc, ol, oa = make(gpu_ctx, 4, 300, 6000)
+    table = loc.depth_table(1 << 10)
+    # every read pair with ONE location: Solver::solve returns the only assignment and never looks at the generator (mod.rs:64-66)
+    v = dict(read_ixs=np.arange(6, dtype=np.uint64), ln_prob=-np.arange(5, dtype=np.float64), windows=np.array([[2, 3]] * 5, dtype=np.uint32),
+             window_gc=np.full(5, 40, dtype=np.uint8), window_weight=np.array([0, 0, 1.0, 0.5, 1.0]), depth_contrib=1.85, aln_contrib=0.15)
+    for solver in solvers():
+        lik, assgn, parts = api.solve_given(loc, solver=solver, rng_state=None, **v)
+        assert not assgn.any() and abs(lik - recompute(v, assgn, table)[0]) <= 1e-12 * abs(lik)
+    state = api.rng_seed_from_u64(8)
+    api.solve_given(loc, solver=solvers()[0], rng_state=state, **v)
+    assert np.array_equal(state, api.rng_seed_from_u64(8))
+    bad = dict(v); bad["read_ixs"] = np.array([0, 1, 1, 3, 4, 5], dtype=np.uint64)
+    with pytest.raises(_lib.LocityperError) as e:
+        api.solve_given(loc, solver=solvers()[0], rng_state=state, **bad)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT and "zero possible alignment locations" in str(e.value)
+    bad = dict(v); bad["windows"] = np.array([[2, 9]] * 5, dtype=np.uint32)
+    with pytest.raises(_lib.LocityperError) as e:
+        api.solve_given(loc, solver=solvers()[0], rng_state=state, **bad)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
+    many = dict(read_ixs=np.array([0, 300], dtype=np.uint64), ln_prob=-np.arange(300, dtype=np.float64), windows=np.full((300, 2), 2, dtype=np.uint32),
+                window_gc=np.full(3, 40, dtype=np.uint8), window_weight=np.array([0, 0, 1.0]), depth_contrib=1.85, aln_contrib=0.15)
+    with pytest.raises(_lib.LocityperError) as e:
+        api.solve_given(loc, solver=solvers()[0], rng_state=state, **many)
+    assert e.value.code == cdefs.ERR_UNSUPPORTED
+    two = dict(v); two["read_ixs"] = np.array([0, 2, 3, 4, 5], dtype=np.uint64)
+    with pytest.raises(_lib.LocityperError) as e:                        # non-trivial reads need the caller's generator
+        api.solve_given(loc, solver=solvers()[0], rng_state=None, **two)
+    assert e.value.code == cdefs.ERR_INVALID_INPUT
+
+
+def test_concurrent_calls_from_worker_threads(gpu_ctx):
+    """The Solver contract: `&self` shared by the worker threads, one call per (genotype, attempt) at once (solve.rs:1010-1017)."""
+    L, p, loc, ol, oa = make(gpu_ctx, 8, 2500, 16000)
+    jobs = []
+    for k, ids in enumerate([(0, 1), (2, 3), (4, 5), (6, 7), (0, 7), (3, 3), (1, 2), (5, 6)]):
+        g = O.OracleGtAlns(ol, oa, ids)
+        solver = solvers()[k % 3]
+        v = view_of(g, p, 500 + k)
+        seed = api.rng_next_u64(api.rng_seed_from_u64(40 + k))
+        jobs.append((v, solver, 40 + k, g.solve(solver, seed)))
+    out = [None] * len(jobs)
+
+    def work(i):
+        v, solver, master, _ = jobs[i]
+        out[i] = api.solve_given(loc, solver=solver, rng_state=api.rng_seed_from_u64(master), **v)
+
+    for _ in range(3):
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        for (v, solver, master, (olik, oassgn, oparts)), (lik, assgn, parts) in zip(jobs, out):
+            assert np.array_equal(assgn, oassgn) and abs(lik - olik) <= 1e-9 * abs(olik)
