@@ -615,6 +615,21 @@ typedef struct lcty_gt_alns_view {
 } lcty_gt_alns_view;
 int32_t lcty_solve_given(lcty_locus* locus, const lcty_gt_alns_view* gt_alns, const lcty_solver* solver, uint64_t* rng_state,
                          uint16_t* read_assgn, double* lik_parts, double* likelihood);
+/* The same call for a caller that holds the window distributions itself and no lcty_locus — which is what `Solver::solve` is
+ * handed: the WindowDistr of every window carries its cached distribution (Arc<LinearCache<BayesCalc<..>>>, distr_cache.rs:17-25), at
+ * most one per GC bin. `tables`: values[n_rows][width] = DiscretePmf::ln_pmf(depth) of row's distribution for depth 0 .. width - 1
+ * (LinearCache::ln_pmf, lincache.rs:41-48: cached below 256, evaluated beyond); window_gc[w] then names the ROW of window w. width
+ * must exceed what lcty_gt_alns_deepest reports for the object: the number of locations that name the fullest window with a
+ * distribution (no assignment can make a window deeper). id != 0: a table the slot already holds under this id, width and row count
+ * is not uploaded again (the rows of a locus do not change between the attempts of its genotypes). n_rows <= 128. */
+typedef struct lcty_depth_tables {
+    uint32_t n_rows, width;
+    const double* values;
+    uint64_t id;
+} lcty_depth_tables;
+int32_t lcty_gt_alns_deepest(const lcty_gt_alns_view* gt_alns, uint32_t* deepest);
+int32_t lcty_solve_given_tables(lcty_ctx* ctx, const lcty_gt_alns_view* gt_alns, const lcty_depth_tables* tables, const lcty_solver* solver,
+                                uint64_t* rng_state, uint16_t* read_assgn, double* lik_parts, double* likelihood);
 /* XoshiroRng::seed_from_u64 (ext/rand.rs:3-22) into four words / next_u64 on them: for a caller whose generator keeps its state
  * private (rand_xoshiro without serde): `lcty_rng_seed_from_u64(rng.next_u64(), state)` starts a stream for the solver calls */
 int32_t lcty_rng_seed_from_u64(uint64_t seed, uint64_t* state);

@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 
-from .cdefs import Bg, Params, ReadsHost, PairAln, Solver, Stage, Call, GtAlnsView
+from .cdefs import Bg, Params, ReadsHost, PairAln, Solver, Stage, Call, GtAlnsView, DepthTables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblocityper_hip.so")
@@ -83,6 +83,8 @@ SIGNATURES = {
     "lcty_chain_seeds": (I32, [U64, U64, VP]),
     "lcty_solve_stage": (I32, [VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),
     "lcty_solve_given": (I32, [VP, P(GtAlnsView), P(Solver), VP, VP, VP, P(D)]),
+    "lcty_solve_given_tables": (I32, [VP, P(GtAlnsView), P(DepthTables), P(Solver), VP, VP, VP, P(D)]),
+    "lcty_gt_alns_deepest": (I32, [P(GtAlnsView), P(U32)]),
     "lcty_rng_seed_from_u64": (I32, [U64, VP]),
     "lcty_rng_next_u64": (I32, [VP, P(U64)]),
     "lcty_solve_stage_sharded": (I32, [VP, VP, VP, U64, U32, VP, P(Solver), U32, VP, VP, VP, VP]),

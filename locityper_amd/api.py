@@ -419,10 +419,12 @@ def rng_next_u64(state):
     return int(out.value)
 
 
-def solve_given(locus, read_ixs, ln_prob, windows, window_gc, window_weight, depth_contrib, aln_contrib, solver, rng_state, wshifts=None):
+def solve_given(locus, read_ixs, ln_prob, windows, window_gc, window_weight, depth_contrib, aln_contrib, solver, rng_state, wshifts=None,
+                tables=None, tables_id=0, deepest_only=False):
     """`Solver::solve` (solvers/mod.rs:59-72) on a GenotypeAlignments handed over as arrays (lcty_solve_given): one chain on the device
     over exactly these locations and window distributions. Returns (likelihood, read_assgn u16[n_reads], (aln_lik, depth_lik));
-    `rng_state` (four uint64 words, xoshiro256++) is advanced in place by the one draw the call takes."""
+    `rng_state` (four uint64 words, xoshiro256++) is advanced in place by the one draw the call takes. With `tables` (f64[n_rows][width])
+    `locus` is a Context and window_gc names rows of the caller's own distributions (lcty_solve_given_tables)."""
     read_ixs = np.ascontiguousarray(read_ixs, dtype=np.uint64)
     ln_prob = np.ascontiguousarray(ln_prob, dtype=np.float64)
     windows = np.ascontiguousarray(windows, dtype=np.uint32).reshape(-1)
@@ -442,8 +444,18 @@ def solve_given(locus, read_ixs, ln_prob, windows, window_gc, window_weight, dep
     assgn = np.zeros(max(n_reads, 1), dtype=np.uint16)
     parts = np.zeros(2, dtype=np.float64)
     lik = D(0.0)
-    check(lib().lcty_solve_given(locus._h, C.byref(v), C.byref(solver), None if rng_state is None else rng_state.ctypes.data,
-                                 assgn.ctypes.data, parts.ctypes.data, C.byref(lik)))
+    if deepest_only:
+        d = U32(0)
+        check(lib().lcty_gt_alns_deepest(C.byref(v), C.byref(d)))
+        return int(d.value)
+    rs = None if rng_state is None else rng_state.ctypes.data
+    if tables is None:
+        check(lib().lcty_solve_given(locus._h, C.byref(v), C.byref(solver), rs, assgn.ctypes.data, parts.ctypes.data, C.byref(lik)))
+    else:
+        tables = np.ascontiguousarray(tables, dtype=np.float64)
+        t = cdefs.DepthTables(tables.shape[0], tables.shape[1], tables.ctypes.data, tables_id)
+        check(lib().lcty_solve_given_tables(locus._h, C.byref(v), C.byref(t), C.byref(solver), rs, assgn.ctypes.data, parts.ctypes.data,
+                                            C.byref(lik)))
     return float(lik.value), assgn[:n_reads], parts
 
 

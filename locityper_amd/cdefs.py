@@ -109,6 +109,11 @@ class GtAlnsView(C.Structure):
     ]
 
 
+class DepthTables(C.Structure):
+    """lcty_depth_tables: the caller's own window distributions as rows of ln-probabilities over the depth."""
+    _fields_ = [("n_rows", C.c_uint32), ("width", C.c_uint32), ("values", C.c_void_p), ("id", C.c_uint64)]
+
+
 class AlnRec(C.Structure):
     _fields_ = [
         ("pos", C.c_uint32),

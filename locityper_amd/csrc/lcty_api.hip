@@ -145,7 +145,7 @@ int32_t lcty_ctx_trim(lcty_ctx* ctx) {
             std::lock_guard<std::mutex> g(ctx->given_mutex);
             for (auto& slot : ctx->given_slots) {
                 if (slot->busy) continue;                                     // a call of another thread is using it
-                slot->ws.release_all(); slot->lut.release(); slot->lut_depth = 0; slot->lut_of = 0;
+                slot->ws.release_all(); slot->lut.release(); slot->lut_depth = 0; slot->lut_of = 0; slot->lut_is_given = false;
                 slot->read_ixs.release(); slot->lp.release(); slot->weight.release(); slot->win.release(); slot->gc.release(); slot->assgn.release();
             }
         }

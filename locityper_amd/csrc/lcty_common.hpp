@@ -238,7 +238,8 @@ struct lcty_ctx {
         hipStream_t stream = nullptr;
         bool busy = false;
         SolveWorkspace ws;
-        lcty::DevBuf<double> lut; uint32_t lut_depth = 0; uint64_t lut_of = 0;          // serial of the locus the table was made for
+        lcty::DevBuf<double> lut; uint32_t lut_depth = 0; uint64_t lut_of = 0;          // serial of the locus the table was made for, or the id of the caller's tables
+        bool lut_is_given = false; uint32_t lut_given_width = 0, lut_given_rows = 0;
         lcty::DevBuf<uint64_t> read_ixs; lcty::DevBuf<double> lp, weight; lcty::DevBuf<uint32_t> win; lcty::DevBuf<uint8_t> gc; lcty::DevBuf<uint16_t> assgn;
     };
     std::vector<std::unique_ptr<GivenSlot>> given_slots;

@@ -155,44 +155,66 @@ void check_solver(const lcty_solver* solver) {
     if (solver->kind == LCTY_SOLVER_GREEDY && solver->sample_size > 64) fail(LCTY_ERR_UNSUPPORTED, "greedy sample size above 64");
 }
 
-void solve_given(lcty_locus* loc, const lcty_gt_alns_view* g, const lcty_solver* solver, uint64_t* rng_state, uint16_t* read_assgn,
-                 double* lik_parts, double* likelihood) {
-    if (!loc || !g || !solver || !read_assgn) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+// what every location that names a window adds up to: no assignment can make the window deeper (a pair in one window counts twice)
+uint64_t deepest_window(const lcty_gt_alns_view* g, std::vector<uint32_t>& reach) {
+    const uint32_t W = g->n_windows;
+    const uint64_t n_alns = g->read_ixs[g->n_reads];
+    reach.assign(W, 0);
+    for (uint64_t i = 0; i < n_alns; i++) {
+        const uint32_t wa = g->windows[2 * i], wb = g->windows[2 * i + 1];
+        if (wa >= W || wb >= W) fail(LCTY_ERR_INVALID_INPUT, "location %llu lies in window %u of %u", static_cast<unsigned long long>(i), std::max(wa, wb), W);
+        reach[wa]++; reach[wb]++;
+    }
+    uint64_t deepest = 0;
+    for (uint32_t w = 0; w < W; w++) if (g->window_weight[w] != 0.0) deepest = std::max<uint64_t>(deepest, reach[w]);
+    return deepest;
+}
+
+void check_view(const lcty_gt_alns_view* g) {
+    if (!g) fail(LCTY_ERR_INVALID_INPUT, "null argument");
     if (!g->read_ixs || (g->n_windows && (!g->window_gc || !g->window_weight))) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    if (g->n_windows < 2) fail(LCTY_ERR_INVALID_INPUT, "a genotype has at least the two windows of unmapped and out-of-region reads (windows.rs:70-76)");
+    if (g->n_reads >= (1ull << 24)) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles up to 2^24 read pairs per locus");
+    if (g->read_ixs[0] != 0) fail(LCTY_ERR_INVALID_INPUT, "read_ixs[0] must be 0 (assgn.rs:29-31)");
+    if (g->read_ixs[g->n_reads] && (!g->ln_prob || !g->windows)) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    for (uint64_t r = 0; r < g->n_reads; r++)
+        if (g->read_ixs[r + 1] <= g->read_ixs[r])
+            fail(LCTY_ERR_INVALID_INPUT, "Read pair %llu has zero possible alignment locations", static_cast<unsigned long long>(r));
+}
+
+// `loc`: the window distributions are the locus' DistrCache rows, window_gc = GC bin. `T`: they are rows of the caller's table.
+void solve_given(lcty_ctx* ctx, lcty_locus* loc, const lcty_depth_tables* T, const lcty_gt_alns_view* g, const lcty_solver* solver,
+                 uint64_t* rng_state, uint16_t* read_assgn, double* lik_parts, double* likelihood) {
+    if (!ctx || (!loc && !T) || !g || !solver || !read_assgn) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+    if (T && (!T->values || T->n_rows == 0 || T->n_rows > 128 || T->width < 2)) fail(LCTY_ERR_INVALID_INPUT, "depth tables: 1..128 rows of at least two depths");
+    check_view(g);
     check_solver(solver);
     const uint64_t R = g->n_reads;
     const uint32_t W = g->n_windows;
-    if (W < 2) fail(LCTY_ERR_INVALID_INPUT, "a genotype has at least the two windows of unmapped and out-of-region reads (windows.rs:70-76)");
-    if (R >= (1ull << 24)) fail(LCTY_ERR_UNSUPPORTED, "the device solver handles up to 2^24 read pairs per locus");
-    if (g->read_ixs[0] != 0) fail(LCTY_ERR_INVALID_INPUT, "read_ixs[0] must be 0 (assgn.rs:29-31)");
     const uint64_t n_alns = g->read_ixs[R];
-    if (n_alns && (!g->ln_prob || !g->windows)) fail(LCTY_ERR_INVALID_INPUT, "null argument");
     if (g->n_contigs > 16 || (g->n_contigs && !g->wshifts)) fail(LCTY_ERR_INVALID_INPUT, "wshifts: n_contigs + 1 entries for at most 16 contigs");
     // what the reference asserts while it builds the object (assgn.rs:55-58), and what the records hold
     uint64_t nnt = 0, n_extra = 0;
     for (uint64_t r = 0; r < R; r++) {
-        if (g->read_ixs[r + 1] <= g->read_ixs[r])
-            fail(LCTY_ERR_INVALID_INPUT, "Read pair %llu has zero possible alignment locations", static_cast<unsigned long long>(r));
         const uint64_t m = g->read_ixs[r + 1] - g->read_ixs[r];
         if (m > 255) fail(LCTY_ERR_UNSUPPORTED, "Read pair %llu has too many alignment locations (%llu): the device solver keeps a location in 8 bits",
                           static_cast<unsigned long long>(r), static_cast<unsigned long long>(m));
         if (m > 1) { nnt++; n_extra += m - 2; }
     }
     if (n_extra >= (1ull << 24)) fail(LCTY_ERR_UNSUPPORTED, "2^24 or more further locations in one chain");
-    // deepest a window can get: every location that names it taken at once (a pair in one window counts twice)
-    std::vector<uint32_t> reach(W, 0);
-    for (uint64_t i = 0; i < n_alns; i++) {
-        const uint32_t wa = g->windows[2 * i], wb = g->windows[2 * i + 1];
-        if (wa >= W || wb >= W) fail(LCTY_ERR_INVALID_INPUT, "location %llu lies in window %u of %u", static_cast<unsigned long long>(i), std::max(wa, wb), W);
+    for (uint64_t i = 0; i < n_alns; i++)
         if (std::isnan(g->ln_prob[i])) fail(LCTY_ERR_INVALID_INPUT, "location %llu has no ln-probability", static_cast<unsigned long long>(i));
-        reach[wa]++; reach[wb]++;
-    }
+    const uint32_t n_rows = T ? T->n_rows : LCTY_GC_BINS;
     for (uint32_t w = 0; w < W; w++) {
         if (!(g->window_weight[w] >= 0.0)) fail(LCTY_ERR_INVALID_INPUT, "window %u has weight %g", w, g->window_weight[w]);
-        if (g->window_weight[w] != 0.0 && g->window_gc[w] >= LCTY_GC_BINS) fail(LCTY_ERR_INVALID_INPUT, "window %u has GC bin %u", w, g->window_gc[w]);
+        if (g->window_weight[w] != 0.0 && g->window_gc[w] >= n_rows)
+            fail(LCTY_ERR_INVALID_INPUT, "window %u names distribution %u of %u", w, g->window_gc[w], n_rows);
     }
-    uint64_t deepest = 0;
-    for (uint32_t w = 0; w < W; w++) if (g->window_weight[w] != 0.0) deepest = std::max<uint64_t>(deepest, reach[w]);
+    std::vector<uint32_t> reach;
+    const uint64_t deepest = deepest_window(g, reach);
+    if (T && deepest + 1 > T->width)
+        fail(LCTY_ERR_INVALID_INPUT, "depth tables of %u depths: a window of this genotype can get %llu deep (lcty_gt_alns_deepest)", T->width,
+             static_cast<unsigned long long>(deepest));
 
     // Solver::solve (mod.rs:59-72): without non-trivial reads there is one assignment and the generator is not touched
     uint64_t seed = 0;
@@ -201,7 +223,6 @@ void solve_given(lcty_locus* loc, const lcty_gt_alns_view* g, const lcty_solver*
         seed = xoshiro_next(rng_state);                          // the chain's seed: one draw of the caller's generator, as a stage takes one per chain
     }
 
-    lcty_ctx* ctx = loc->ctx;
     ctx->activate();
     SlotLease lease(ctx);
     lcty_ctx::GivenSlot& S = *lease.slot;
@@ -218,16 +239,25 @@ void solve_given(lcty_locus* loc, const lcty_gt_alns_view* g, const lcty_solver*
     V.ploidy = g->n_contigs ? g->n_contigs : 1; V.attempts = 1; V.solver = *solver; V.priors = nullptr;
     V.wstride = (W + 3) & ~3u;
     if (!solver_lds_fits(V.wstride)) fail(LCTY_ERR_UNSUPPORTED, "%u windows per genotype: too many for the device solver", W);
-    // the slot's depth table: DistrCache (distr_cache.rs:61-75) of this locus, wide enough for the deepest window
-    {
+    // the slot's depth table, wide enough for the deepest window: DistrCache (distr_cache.rs:61-75) of the locus, made on the device —
+    // or the caller's rows (a power-of-two row stride; what lies behind a row's `width` is never read: deepest < width)
+    if (loc) {
         uint32_t depth = LCTY_DEPTH_CACHE;
         while (depth < deepest + 2) depth *= 2;
-        if (S.lut_of != loc->serial || S.lut_depth < depth) {
+        if (S.lut_of != loc->serial || S.lut_is_given || S.lut_depth < depth) {
             build_depth_table_into(loc, depth, S.lut, s);
-            S.lut_of = loc->serial; S.lut_depth = depth;
+            S.lut_of = loc->serial; S.lut_is_given = false; S.lut_depth = depth;
         }
-        V.lut = S.lut.p; V.lut_depth = S.lut_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(S.lut_depth));
+    } else if (!(S.lut_is_given && T->id != 0 && S.lut_of == T->id && S.lut_given_width == T->width && S.lut_given_rows == T->n_rows)) {
+        uint32_t depth = 2;
+        while (depth < T->width) depth *= 2;
+        if (depth > (1u << 22)) fail(LCTY_ERR_UNSUPPORTED, "depth tables more than 4 M depths wide");
+        S.lut.ensure(static_cast<size_t>(128) * depth);
+        LCTY_HIP(hipMemcpy2DAsync(S.lut.p, static_cast<size_t>(depth) * 8, T->values, static_cast<size_t>(T->width) * 8, static_cast<size_t>(T->width) * 8,
+                                  T->n_rows, hipMemcpyHostToDevice, s));
+        S.lut_of = T->id; S.lut_is_given = true; S.lut_depth = depth; S.lut_given_width = T->width; S.lut_given_rows = T->n_rows;
     }
+    V.lut = S.lut.p; V.lut_depth = S.lut_depth; V.lut_shift = static_cast<uint32_t>(__builtin_ctz(S.lut_depth));
     const uint32_t extra_cap = static_cast<uint32_t>(n_extra) + 2;     // two spare entries: the greedy loop reads a pair per record
     ws.recs.ensure_slack(V.rstride); ws.extra.ensure_slack(extra_cap);
     ws.cww.ensure_slack(V.wstride); ws.cgc.ensure_slack(V.wstride); ws.cdepth.ensure_slack(V.wstride);
@@ -277,11 +307,11 @@ void solve_given(lcty_locus* loc, const lcty_gt_alns_view* g, const lcty_solver*
         m.aln_contrib = g->aln_contrib; m.depth_contrib = g->depth_contrib;
         m.node_limit = solver->node_limit ? solver->node_limit : 20ull * 1000 * 1000;
         m.rel_gap = solver->init_prob > 0.0 && solver->init_prob < 1.0 ? solver->init_prob : 0.0;
-        m.gc_bins = LCTY_GC_BINS;
-        std::vector<double> lut(static_cast<size_t>(LCTY_GC_BINS) * S.lut_depth);
+        m.gc_bins = n_rows;
+        std::vector<double> lut(static_cast<size_t>(n_rows) * S.lut_depth);
         S.lut.download(lut.data(), lut.size(), s);
         LCTY_HIP(hipStreamSynchronize(s));
-        if (exact::depth_needed(m) > S.lut_depth) fail(LCTY_ERR_RUNTIME, "exact solver: a window deeper than the reads that can reach it");
+        // (no window with a distribution gets deeper than `deepest` < the table's width: the search indexes the table for those only)
         exact::Result res;
         exact::solve(m, lut.data(), S.lut_depth, res);
         if (res.out_of_nodes)
@@ -317,7 +347,27 @@ extern "C" {
 
 int32_t lcty_solve_given(lcty_locus* locus, const lcty_gt_alns_view* gt_alns, const lcty_solver* solver, uint64_t* rng_state,
                          uint16_t* read_assgn, double* lik_parts, double* likelihood) {
-    return guarded([&] { solve_given(locus, gt_alns, solver, rng_state, read_assgn, lik_parts, likelihood); });
+    return guarded([&] {
+        if (!locus) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        solve_given(locus->ctx, locus, nullptr, gt_alns, solver, rng_state, read_assgn, lik_parts, likelihood);
+    });
+}
+
+int32_t lcty_solve_given_tables(lcty_ctx* ctx, const lcty_gt_alns_view* gt_alns, const lcty_depth_tables* tables, const lcty_solver* solver,
+                                uint64_t* rng_state, uint16_t* read_assgn, double* lik_parts, double* likelihood) {
+    return guarded([&] {
+        if (!tables) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        solve_given(ctx, nullptr, tables, gt_alns, solver, rng_state, read_assgn, lik_parts, likelihood);
+    });
+}
+
+int32_t lcty_gt_alns_deepest(const lcty_gt_alns_view* gt_alns, uint32_t* deepest) {
+    return guarded([&] {
+        if (!deepest) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        check_view(gt_alns);
+        std::vector<uint32_t> reach;
+        *deepest = static_cast<uint32_t>(deepest_window(gt_alns, reach));
+    });
 }
 
 // XoshiroRng::seed_from_u64 (ext/rand.rs:3-22: SplitMix64 fill) / next_u64 for callers that keep the generator's four words themselves

@@ -124,7 +124,8 @@ def recompute(v, assgn, table):
     aln = float(np.sum(v["ln_prob"][ix]))
     depth = np.bincount(np.asarray(v["windows"]).reshape(-1, 2)[ix].reshape(-1), minlength=len(v["window_weight"]))
     w = v["window_weight"]
-    dl = float(np.sum(np.where(w != 0.0, w * table[v["window_gc"].astype(np.int64), depth], 0.0)))
+    live = w != 0.0                                                      # WindowDistr::TRIVIAL contributes 0 whatever its depth
+    dl = float(np.sum(w[live] * table[v["window_gc"].astype(np.int64)[live], depth[live]]))
     return v["depth_contrib"] * dl + v["aln_contrib"] * aln, aln, dl
 
 
@@ -224,3 +225,36 @@ def test_concurrent_calls_from_worker_threads(gpu_ctx):
         for t in threads: t.join()
         for (v, solver, master, (olik, oassgn, oparts)), (lik, assgn, parts) in zip(jobs, out):
             assert np.array_equal(assgn, oassgn) and abs(lik - olik) <= 1e-9 * abs(olik)
+
+
+def test_the_callers_own_distributions(gpu_ctx):
+    """lcty_solve_given_tables: no lcty_locus at all — the window distributions come as rows of ln-probabilities, which is what the
+    WindowDistr objects of a GenotypeAlignments hold (distr_cache.rs:17-39). With the locus' own rows the chain is the chain of
+    lcty_solve_given; with other rows the likelihood is the returned assignment's on THOSE rows."""
+    L, p, loc, ol, oa = make(gpu_ctx, 8, 2500, 16000)
+    rnd = np.random.default_rng(23)
+    for k, ids in enumerate([(0, 5), (2, 2), (1, 3, 6)]):
+        g = O.OracleGtAlns(ol, oa, ids)
+        v = view_of(g, p, 900 + k)
+        deepest = api.solve_given(gpu_ctx, solver=None, rng_state=None, deepest_only=True, **v)
+        reach = np.bincount(np.asarray(v["windows"]).reshape(-1), minlength=len(v["window_weight"]))
+        assert deepest == int(reach[v["window_weight"] != 0.0].max())
+        rows = loc.depth_table(deepest + 1)[:, :deepest + 1]                # the locus' DistrCache as the caller would evaluate it
+        for solver in solvers():
+            a = api.solve_given(loc, solver=solver, rng_state=api.rng_seed_from_u64(70 + k), **v)
+            b = api.solve_given(gpu_ctx, solver=solver, rng_state=api.rng_seed_from_u64(70 + k), tables=rows, tables_id=1 + k, **v)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        # other rows: three distributions of the caller's own making, windows dealt to them at random
+        own = -np.abs(rnd.normal(size=(3, deepest + 1))).cumsum(axis=1) * 0.01
+        v2 = dict(v); v2["window_gc"] = rnd.integers(0, 3, len(v["window_gc"])).astype(np.uint8)
+        for solver in solvers()[:2]:
+            lik, assgn, parts = api.solve_given(gpu_ctx, solver=solver, rng_state=api.rng_seed_from_u64(5), tables=own, **v2)
+            want, aln, dl = recompute(v2, assgn, own)
+            assert abs(lik - want) <= 1e-9 * abs(want)
+        with pytest.raises(_lib.LocityperError) as e:                     # rows that end before the deepest window can
+            api.solve_given(gpu_ctx, solver=solvers()[0], rng_state=api.rng_seed_from_u64(5), tables=own[:, :deepest], **v2)
+        assert e.value.code == cdefs.ERR_INVALID_INPUT and "lcty_gt_alns_deepest" in str(e.value)
+        v3 = dict(v2); v3["window_gc"] = np.full(len(v["window_gc"]), 3, dtype=np.uint8)
+        with pytest.raises(_lib.LocityperError) as e:
+            api.solve_given(gpu_ctx, solver=solvers()[0], rng_state=api.rng_seed_from_u64(5), tables=own, **v3)
+        assert e.value.code == cdefs.ERR_INVALID_INPUT

@@ -249,3 +249,33 @@ def test_mapper_and_solver_defaults():
     assert ex.kind == cdefs.SOLVER_EXACT and ex.init_prob == 1e-4 and ex.node_limit == 20_000_000
     assert _lib.lib().lcty_ctx_set_path(None, b"exact_dump", b"/tmp/x") == cdefs.ERR_INVALID_INPUT
     assert api.default_solver(cdefs.SOLVER_ANNEAL).init_prob == 0.5
+
+
+def test_rust_shim_declares_what_the_header_declares():
+    """shim/src/hip/sys.rs is hand-written (no bindgen, no rustc in this image): every function it declares must be a symbol of the
+    header with the same number of arguments, and its #[repr(C)] structs must list the header's fields in the header's order."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "locityper_hip.h")).read(), flags=re.S)
+    rust = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "shim", "src", "hip", "sys.rs")).read())
+    L = _lib.lib()
+    fns = re.findall(r"pub fn (lcty_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", rust, flags=re.S)
+    assert len(fns) >= 10
+    for name, args in fns:
+        assert hasattr(L, name), f"{name} is not exported"
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", header, flags=re.S)
+        assert m, f"{name} is not declared in the header"
+        c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        r_args = [a for a in args.split(",") if a.strip()]
+        assert len(c_args) == len(r_args), f"{name}: {len(c_args)} arguments in the header, {len(r_args)} in sys.rs"
+        assert len(_lib.SIGNATURES[name][1]) == len(c_args)
+    for struct in ("lcty_solver", "lcty_gt_alns_view", "lcty_depth_tables"):
+        m = re.search(r"typedef struct " + struct + r"\s*\{(.*?)\}\s*" + struct + r"\s*;", header, flags=re.S)
+        c_fields = []
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if decl:
+                c_fields += [re.sub(r"[\s\*]", "", f).split("[")[0] for f in re.sub(r"^(const\s+)?\w+\s*\**", "", decl, count=1).split(",")]
+        r = re.search(r"pub struct " + struct + r"\s*\{(.*?)\}", rust, flags=re.S)
+        r_fields = re.findall(r"pub (\w+)\s*:", r.group(1))
+        assert c_fields == r_fields, (struct, c_fields, r_fields)
+    # the C sizes the Rust structs must have (natural alignment on both sides)
+    assert C.sizeof(cdefs.Solver) == 32 and C.sizeof(cdefs.GtAlnsView) == 80 and C.sizeof(cdefs.DepthTables) == 24
