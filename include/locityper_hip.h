@@ -700,7 +700,9 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
  * objects carry a queue of any length. `acquire(user, i)` for i > 0 comes from a thread of the library, while position i - 1 is in its
  * chains and once the last stage of position i - 2 has ended (the head of position i is made there: lcty_solve_queue), and may run at
  * the same time as a `release` on the caller's thread; with knob "queue_early_head" 0 both come from the caller's thread, `acquire(i)`
- * after the chains of position i - 1 and after `release(i - 2)`. The loading of locus i + 1 next to analyze_locus of locus i (genotype.rs:1331-1351). */
+ * after the chains of position i - 1 and after `release(i - 2)`. On an error every position that was acquired and not yet released is
+ * released before the call returns, with nothing of the queue left in flight on the device. The loading of locus i + 1 next to
+ * analyze_locus of locus i (genotype.rs:1331-1351). */
 typedef lcty_reads* (*lcty_queue_acquire_fn)(void* user, uint32_t position);
 typedef void (*lcty_queue_release_fn)(void* user, uint32_t position);
 int32_t lcty_solve_queue_fed(uint32_t n_loci, lcty_queue_acquire_fn acquire, lcty_queue_release_fn release, void* user, uint32_t ploidy,

@@ -1008,12 +1008,20 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
         { std::lock_guard<std::mutex> lock(ctx->gate.m); if (ctx->gate.target > ctx->gate.epoch) ctx->gate.epoch = ctx->gate.target; }
         ctx->gate.cv.notify_all();
     };
+    // positions whose batch has been asked for and not yet given back: on an error every one of them is given back once nothing of the
+    // queue is in flight any more (the fore thread acquires position i + 1 while i is in its chains and i - 1 in its tail)
+    std::mutex held_mutex;
+    std::vector<uint32_t> held;
+    auto give_back = [&](uint32_t i) {
+        { std::lock_guard<std::mutex> lock(held_mutex); held.erase(std::remove(held.begin(), held.end(), i), held.end()); }
+        done_with(i);
+    };
     auto join_tail = [&] {
         const bool had = tail_thread.joinable();
         if (had) tail_thread.join();
         prev.reset();
         if (tail_rc != LCTY_OK) { const int32_t rc = tail_rc; tail_rc = LCTY_OK; fail(rc, "%s", tail_msg.c_str()); }
-        if (had) done_with(tail_of);
+        if (had) give_back(tail_of);
     };
     auto join_fore = [&] {
         if (fore_thread.joinable()) fore_thread.join();
@@ -1022,6 +1030,7 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
     auto make_run = [&](uint32_t i) {
         auto R = std::make_unique<LocusRun>();
         R->reads = batch_of(i);
+        { std::lock_guard<std::mutex> lock(held_mutex); held.push_back(i); }
         R->ploidy = ploidy; R->stages = stages; R->n_stages = n_stages; R->master_seed = master_seeds[i];
         R->priors = priors ? priors[i] : nullptr; R->out = &out[i];
         return R;
@@ -1093,6 +1102,19 @@ void run_queue(uint32_t n, GET&& batch_of, DONE&& done_with, uint32_t ploidy, co
         release_gate();
         if (fore_thread.joinable()) fore_thread.join();
         if (tail_thread.joinable()) tail_thread.join();
+        // Nothing of the queue may still be running when the caller gets its batches back (it may reset or destroy them): what the
+        // three threads issued is waited for, then every position that was acquired and not released is released — the one whose
+        // tail was joined here, the one in its chains, and the one the fore thread had taken ahead.
+        if (ctx) {
+            (void)hipStreamSynchronize(ctx->stream.main);
+            if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+            if (ctx->fore) (void)hipStreamSynchronize(ctx->fore);
+        }
+        std::vector<uint32_t> left;
+        { std::lock_guard<std::mutex> lock(held_mutex); left.swap(held); }
+        for (uint32_t i : left) {
+            try { done_with(i); } catch (...) {}                              // the first error is the one reported
+        }
         throw;
     }
 }
@@ -1121,12 +1143,17 @@ int32_t lcty_solve_queue(lcty_reads* const* batches, uint32_t n_batches, uint32_
     });
 }
 
-// The same queue with the batches handed over one at a time: `acquire(user, i)` is called right before position i is scored and
-// returns its batch — filled by then, e.g. by a host thread that appends the chunks of locus i while locus i - 1 is being solved
-// (the appends have a stream of their own) —, `release(user, i)` when the last stage of position i has finished and nothing of
-// the batch is in use any more (lcty_reads_reset may then bind it to another locus). Position i is released before position
-// i + 2 is acquired: three batch objects carry a queue of any length. The loop of `locityper genotype` over its loci
-// (genotype.rs:1331-1351) with the loading of locus i + 1 next to the solving of locus i.
+// The same queue with the batches handed over one at a time: `acquire(user, i)` returns the batch of position i — filled by then,
+// e.g. by a host thread that appends the chunks of locus i while locus i - 1 is being solved (the appends have a stream of their
+// own) —, `release(user, i)` is called when the last stage of position i has finished and nothing of the batch is in use any more
+// (lcty_reads_reset may then bind it to another locus). WHICH THREAD CALLS WHAT (round 5 on): acquire(0) comes from the caller's
+// thread; acquire(i > 0) from a thread of the library, as soon as the last stage of position i - 2 has ended, i.e. while position
+// i - 1 is in its chains — so acquire(i) can run AT THE SAME TIME as release(i - 2) and comes BEFORE release(i - 1); release(i)
+// precedes acquire(i + 3): three batch objects carry a queue of any length. Callbacks that share state guard it (or set the knob
+// "queue_early_head" to 0: every callback then comes from the caller's thread, acquire(i) after release(i - 2)). On an error every
+// position that was acquired and not yet released is released before the call returns, with nothing of the queue left in flight.
+// The loop of `locityper genotype` over its loci (genotype.rs:1331-1351) with the loading of locus i + 1 next to the solving of
+// locus i.
 int32_t lcty_solve_queue_fed(uint32_t n_loci, lcty_queue_acquire_fn acquire, lcty_queue_release_fn release, void* user, uint32_t ploidy,
                              const lcty_stage* stages, uint32_t n_stages, const uint64_t* master_seeds, const double* const* priors, lcty_call* out) {
     return guarded([&] {

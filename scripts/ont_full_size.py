@@ -1,12 +1,25 @@
-"""BASELINE.json configs[2] at its stated size — 1 M synthetic 10-kb ONT reads x 256 alleles, from the bases alone to the prefilter call — through
-the bench's `long_reads_stream` leg (locityper_amd/legs.py::ont_from_bases_stream): python3 scripts/ont_full_size.py [reads] > line.json"""
+"""BASELINE.json configs[2] at its stated size — 1 000 000 10-kb ONT reads x 256 alleles — one line of JSON on stdout:
+    python3 scripts/ont_full_size.py [reads]                    from the bases alone (the build's own mapper, (f)2), streamed, to the prefilter call
+    python3 scripts/ont_full_size.py [reads] --whole-path       the path the reference runs on GIVEN alignments, records + CIGARs streamed
+    python3 scripts/ont_full_size.py [reads] --whole-path --counted   the same with counted alignments, resident (4 GB at full size)
+(bench_legs/long_reads.py holds the legs; --check compares eight chains of each solver with the oracle on the scored batch)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from locityper_amd import api, legs
+from locityper_amd import api
+from bench_legs import long_reads as LR
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-t0 = time.time()
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+flags = {a for a in sys.argv[1:] if a.startswith("--")}
+n = int(args[0]) if args else 1_000_000
 ctx = api.Context(0)
-out, _ = legs.ont_from_bases_stream(ctx, n, progress=lambda m: print(f"[{time.time() - t0:7.1f} s] {m}", file=sys.stderr, flush=True))
-out["wall_s_with_generation"] = time.time() - t0
+t0 = time.time()
+say = lambda m: print(f"[{time.time() - t0:7.1f} s] {m}", file=sys.stderr, flush=True)
+if "--whole-path" in flags:
+    checker = None
+    if "--check" in flags:
+        from bench_legs.cpu import whole_path_chains_check as checker
+    out = LR.ont_whole_path(ctx, n, progress=say, checker=checker, counted="--counted" in flags, chunk=8192)
+else:
+    out, _ = LR.ont_from_bases_stream(ctx, n, progress=say)
+out["wall_s_incl_generation"] = time.time() - t0
 print(json.dumps(out))

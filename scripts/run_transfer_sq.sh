@@ -1,3 +1,4 @@
+#!/bin/bash
 # SQ and instruction-cache counters of alignment recovery's transfer_kernel (scripts/ont_recover_probe.py under rocprofv3, two passes);
 # -> <out>/transfer_sq.json (copy to profiles/r05_pmc_sq_transfer_kernel.json)
 cd /tmp && export TMPDIR=/tmp

@@ -1,3 +1,4 @@
+#!/bin/bash
 # HBM traffic of alignment recovery's transfer_kernel: FETCH_SIZE and WRITE_SIZE, each pass alone (scripts/ont_recover_probe.py under rocprofv3);
 # bytes per transferred alignment of 10-kb ONT reads on 256 alleles -> <out>/transfer_traffic.json (copy to profiles/r05_pmc_transfer_kernel.json)
 cd /tmp && export TMPDIR=/tmp

@@ -83,3 +83,30 @@ def test_a_failing_rank_releases_the_other_rank(tmp_path, call, n_points):
             assert "rank 0: ok" in outs[0] and "rank 1: ok" in outs[1]
         else:
             assert "injected failure" in outs[1] and "another rank" in outs[0], outs
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("call", ["allreduce", "chains", "reads"])
+def test_the_exchanges_across_real_ranks(tmp_path, call, world):
+    """The RCCL exchanges with more than one rank, nothing failing: the two-rank (four-, eight-rank) forms of
+    test_gpu_parity.py::test_read_sharded_prefilter_allreduce, ::test_chain_sharded_stage and ::test_read_sharded_stage. One FRESH
+    process per rank (tests/comm_fail_worker.py; no process that has touched the GPU starts another program); every rank checks
+    inside the worker that what the exchange gave it equals the single-device call on the whole batch — the all-reduced run_filter
+    scores to 1e-11, the chain likelihoods of both sharded stages bit for bit. Skipped below `world` devices: RCCL refuses two ranks
+    on one device, and every box of rounds 1-6 had one GPU — until a multi-GPU box runs this, nothing is claimed for RCCL beyond one rank."""
+    if api.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (RCCL refuses several ranks on one device)")
+    id_file = str(tmp_path / f"id_{call}_{world}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "comm_fail_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), id_file, call, "0", "0"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    for r, pr in enumerate(procs):
+        try:
+            out, err = pr.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail(f"{call} over {world} ranks: rank {r} did not come back")
+        assert pr.returncode == 0, err[-2000:]
+        assert f"rank {r}: ok" in out, (out, err[-1500:])

@@ -191,7 +191,7 @@ def test_config1_whole_path_against_the_oracle_pipeline(gpu_ctx):
         seeds = api.chain_seeds(100 + si, len(kg) * attempts)
         m, v, _ = api.solve_stage(aa, gts[kg], solver, attempts, seeds)
         m2, v2, _ = O.solve_stage(ol, oa, gts[ko], solver, attempts, seeds)
-        # measured over four loci x both solvers (scripts/own_tables_probe.py, profiles/r02_own_tables_probe.txt): 49-97 % of the chains
+        # measured over four loci x both solvers (profiles/r02_own_tables_probe.txt; the probe script of round 2 is gone): 49-97 % of the chains
         # identical to 1e-9, the others within 5.4e-4 relative; stage means within 0.21 standard deviations between attempts
         assert np.allclose(m, m2, rtol=1e-3, atol=0) and np.mean(np.abs(m - m2) <= 1e-9 * np.abs(m2)) >= 0.40
         assert kg[int(np.argmax(m))] == ko[int(np.argmax(m2))]
