@@ -745,6 +745,10 @@ int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, doubl
  *   libbrotlidec.so.1, LCTY_ERR_UNSUPPORTED without it), anything else as it is. *data is released with lcty_io_free.
  *   `kmers.bin.br` / `.lz4` (command/paths.rs:4-5) -> lcty_io_read_file -> lcty_kmer_counts_parse.
  * lcty_io_write_gz: ext::sys::create_gzip + write.
+ * lcty_io_write_br: the brotli writer behind `sol.csv.br`, `reads.csv.br` and the other --debug tables (solvers/solve.rs:937-938,
+ *   model/locs.rs:1062-1065): a brotli stream (RFC 7932) of `data` — compressed at `quality` 0..11 by the system's libbrotlienc.so.1
+ *   (looked up at run time), or, without that library or with quality < 0, STORED in uncompressed meta-blocks (a valid stream any
+ *   brotli reader takes, the reference's included; *stored = 1 then).
  * lcty_bg_from_json: BgDistr::load (src/bg/mod.rs:159-177) on the text of PREPROC/distr.gz: seq_info (349-364), insert_distr
  *   ({} = single-end, bg/insertsz.rs:195-208), error_profile (bg/err_prof.rs:321-329), bg_depth (bg/depth.rs:400-412; required, as
  *   `locityper genotype` requires it); edit thresholds = EditThresh::default_for (err_prof.rs:394-399). Missing keys / wrong types
@@ -756,6 +760,7 @@ int32_t lcty_timing_get(lcty_ctx* ctx, int32_t kernel, uint64_t* launches, doubl
 int32_t lcty_io_read_file(const char* path, uint8_t** data, uint64_t* len);
 void    lcty_io_free(void* p);
 int32_t lcty_io_write_gz(const char* path, const uint8_t* data, uint64_t len);
+int32_t lcty_io_write_br(const char* path, const uint8_t* data, uint64_t len, int32_t quality, int32_t* stored);
 int32_t lcty_bg_from_json(const char* json, uint64_t len, lcty_bg* bg, double* read_len);
 int32_t lcty_res_to_json(const lcty_call* call, const uint16_t* genotypes, uint32_t ploidy, const char* const* names, uint32_t n_alleles,
                          const double* lik_mean, const double* lik_var, const uint32_t* distances, int32_t true_edit_distances,

@@ -114,6 +114,7 @@ SIGNATURES = {
     "lcty_io_read_file": (I32, [C.c_char_p, P(VP), P(U64)]),
     "lcty_io_free": (None, [VP]),
     "lcty_io_write_gz": (I32, [C.c_char_p, VP, U64]),
+    "lcty_io_write_br": (I32, [C.c_char_p, VP, U64, I32, P(I32)]),
     "lcty_bg_from_json": (I32, [C.c_char_p, U64, VP, P(D)]),
     "lcty_res_to_json": (I32, [VP, VP, U32, VP, U32, VP, VP, VP, I32, D, VP, U64, P(U64)]),
     "lcty_write_bam": (I32, [C.c_char_p, VP, VP, VP, VP, VP, VP, VP, VP, U32, C.c_uint16, VP, VP, P(U64)]),

@@ -365,6 +365,59 @@ struct lcty_bam_table {
     lcty_reads_host view{};
 };
 
+namespace {
+
+// A brotli stream (RFC 7932) for the files the reference writes through its brotli writer — `sol.csv.br`, `reads.csv.br` and the other
+// --debug tables (ext/sys.rs create_brotli; solvers/solve.rs:937-938, model/locs.rs:1062-1065). With the system's libbrotlienc.so.1
+// (looked up at run time, like the decoder) the stream is compressed at `quality` (0..11; the reference's writer uses its crate's
+// default); without it — or with quality < 0 — the bytes go into UNCOMPRESSED meta-blocks (RFC 7932 §9.2: ISLAST 0, MNIBBLES, MLEN - 1,
+// ISUNCOMPRESSED 1, padding, the bytes; at most 65 536 bytes each so that MLEN - 1 takes four nibbles; a last empty meta-block): a
+// valid stream every brotli reader takes, the reference's multi-stream reader included — stored, not compressed.
+std::vector<uint8_t> brotli_stored(const uint8_t* data, uint64_t len) {
+    std::vector<uint8_t> out;
+    out.reserve(len + 3 * (len / 65536 + 1) + 2);
+    bool first = true;
+    for (uint64_t at = 0; at < len;) {
+        const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(len - at, 65536));
+        // the stream starts with WBITS = 22 (the four bits 1011, least significant first); a meta-block header is ISLAST (0), MNIBBLES
+        // (00: four nibbles), MLEN - 1 (16 bits), ISUNCOMPRESSED (1): 20 bits — 24 with WBITS in front, or with four bits of padding
+        uint32_t bits = 0, nb = 0;
+        auto put = [&](uint32_t v, uint32_t k) { bits |= v << nb; nb += k; };
+        if (first) put(0xBu, 4);
+        put(0, 1); put(0, 2); put(n - 1, 16); put(1, 1);
+        out.push_back(static_cast<uint8_t>(bits)); out.push_back(static_cast<uint8_t>(bits >> 8)); out.push_back(static_cast<uint8_t>(bits >> 16));
+        out.insert(out.end(), data + at, data + at + n);
+        at += n; first = false;
+    }
+    out.push_back(first ? 0x3Bu : 0x03u);        // ISLAST 1, ISLASTEMPTY 1 (behind WBITS when the stream is empty), padding
+    return out;
+}
+
+std::vector<uint8_t> brotli_encode(const uint8_t* data, uint64_t len, int32_t quality, bool* stored) {
+    *stored = true;
+    if (quality >= 0) {
+        using compress_fn = int (*)(int, int, int, size_t, const uint8_t*, size_t*, uint8_t*);
+        using bound_fn = size_t (*)(size_t);
+        static void* lib = dlopen("libbrotlienc.so.1", RTLD_NOW | RTLD_LOCAL);
+        static compress_fn compress = lib ? reinterpret_cast<compress_fn>(dlsym(lib, "BrotliEncoderCompress")) : nullptr;
+        static bound_fn bound = lib ? reinterpret_cast<bound_fn>(dlsym(lib, "BrotliEncoderMaxCompressedSize")) : nullptr;
+        if (compress && bound) {
+            size_t cap = bound(static_cast<size_t>(len));
+            if (cap == 0) cap = static_cast<size_t>(len) + (len >> 2) + 1024;
+            std::vector<uint8_t> out(cap);
+            size_t n = cap;
+            if (compress(std::min(quality, 11), 22, 0, static_cast<size_t>(len), data, &n, out.data()) == 1) {
+                out.resize(n);
+                *stored = false;
+                return out;
+            }
+        }
+    }
+    return brotli_stored(data, len);
+}
+
+}  // namespace
+
 extern "C" {
 
 int32_t lcty_io_read_file(const char* path, uint8_t** data, uint64_t* len) {
@@ -398,6 +451,19 @@ int32_t lcty_io_write_gz(const char* path, const uint8_t* data, uint64_t len) {
             at += n;
         }
         if (gzclose(f) != Z_OK) fail(LCTY_ERR_RUNTIME, "write error on %s", path);
+    });
+}
+
+int32_t lcty_io_write_br(const char* path, const uint8_t* data, uint64_t len, int32_t quality, int32_t* stored) {
+    return guarded([&] {
+        if (!path || (len && !data)) fail(LCTY_ERR_INVALID_INPUT, "null argument");
+        bool st = true;
+        const std::vector<uint8_t> out = brotli_encode(data, len, quality, &st);
+        FILE* f = fopen(path, "wb");
+        if (!f) fail(LCTY_ERR_INVALID_INPUT, "cannot create %s", path);
+        const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+        if (fclose(f) != 0 || !ok) fail(LCTY_ERR_RUNTIME, "write error on %s", path);
+        if (stored) *stored = st ? 1 : 0;
     });
 }
 

@@ -22,6 +22,15 @@ def write_gz(path, data):
     check(lib().lcty_io_write_gz(str(path).encode(), buf, len(buf)))
 
 
+def write_br(path, data, quality=5):
+    """lcty_io_write_br: a brotli stream of `data` (the reference's `.csv.br` debug tables); returns True when the stream is STORED in
+    uncompressed meta-blocks (no libbrotlienc on this system, or quality < 0)."""
+    buf = bytes(data)
+    stored = C.c_int32(0)
+    check(lib().lcty_io_write_br(str(path).encode(), buf, len(buf), quality, C.byref(stored)))
+    return bool(stored.value)
+
+
 def distances_parse(data, n_alleles):
     """lcty_distances_parse: distances.bin -> (k, w, symmetric u32 matrix, NONE_U32 on the diagonal)."""
     buf = bytes(data)

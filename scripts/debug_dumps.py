@@ -141,6 +141,11 @@ def main():
         os.makedirs(os.path.join(a.outdir, side), exist_ok=True)
         for name, text in files.items():
             open(os.path.join(a.outdir, side, name), "w").write(text)
+            if side == "hip":
+                # ... and as the reference leaves them in OUT/loci/<locus>/: brotli streams (`sol.csv.br`, `read_pairs.csv.br`, ...:
+                # solvers/solve.rs:937-938, model/locs.rs:1062-1065) through the library's writer
+                from locityper_amd import io as lio
+                lio.write_br(os.path.join(a.outdir, side, name + ".br"), text.encode())
     for name in res["hip"]:
         ok, why = same_but_last_digit(res["hip"][name], res["oracle"][name], 2e-4 if name != "read_kmers.csv" else 0.011)
         print(f"{name}: {'same' if ok else 'DIFFERENT ' + why} ({res['hip'][name].count(chr(10))} lines)")

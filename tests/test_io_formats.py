@@ -148,6 +148,59 @@ def test_brotli_streams_through_the_system_decoder(tmp_path):
     assert e.value.code == cdefs.ERR_INVALID_DATA
 
 
+def _stored_brotli_payload(raw):
+    """The payload of a brotli stream that consists of UNCOMPRESSED meta-blocks only (RFC 7932 sections 9.1-9.2), decoded by hand: WBITS,
+    then per meta-block ISLAST, MNIBBLES, MLEN - 1, ISUNCOMPRESSED, zero padding to the byte, MLEN bytes; the last one ISLAST + ISLASTEMPTY."""
+    bit = 0
+
+    def take(k):
+        nonlocal bit
+        v = 0
+        for i in range(k):
+            v |= ((raw[(bit + i) >> 3] >> ((bit + i) & 7)) & 1) << i
+        bit += k
+        return v
+    if take(1):                                                          # WBITS: 0 = 16; else three more bits (0 there: a 7-bit form)
+        assert take(3) != 0
+    out = bytearray()
+    while True:
+        if take(1):                                                      # ISLAST
+            assert take(1) == 1                                          # ISLASTEMPTY
+            while bit & 7:
+                assert take(1) == 0
+            assert bit // 8 == len(raw)
+            return bytes(out)
+        nib = take(2)
+        assert nib != 3
+        mlen = take(4 * (nib + 4)) + 1
+        assert take(1) == 1                                              # ISUNCOMPRESSED
+        while bit & 7:
+            assert take(1) == 0
+        out += raw[bit // 8:bit // 8 + mlen]
+        bit += 8 * mlen
+
+
+def test_brotli_writer_stored_and_compressed(tmp_path):
+    """lcty_io_write_br: the writer behind the reference's `.csv.br` tables. Stored form (quality < 0): decoded here by hand from the
+    RFC's bit layout AND by the system decoder through lcty_io_read_file; compressed form: where libbrotlienc is present."""
+    for data in (b"", b"x", b"stage\tgenotype\tlik\n" * 5000, os.urandom(200_001), bytes(65536), bytes(65537)):
+        p = tmp_path / "sol.csv.br"
+        assert lio.write_br(p, data, quality=-1) is True
+        raw = p.read_bytes()
+        assert _stored_brotli_payload(raw) == data
+        assert len(raw) <= len(data) + 3 * (len(data) // 65536 + 1) + 1
+        if _cdll("libbrotlidec.so.1") is not None:
+            assert lio.read_file(p) == data
+            two = tmp_path / "two.csv.br"
+            two.write_bytes(raw + raw)                                   # streams one after the other, as the reference's reader takes them
+            assert lio.read_file(two) == data + data
+    if _cdll("libbrotlienc.so.1") is not None and _cdll("libbrotlidec.so.1") is not None:
+        data = b"1\ta0,a1\t-123.4567\n" * 20000
+        p = tmp_path / "reads.csv.br"
+        assert lio.write_br(p, data, quality=5) is False
+        assert p.stat().st_size < len(data) // 20 and lio.read_file(p) == data
+
+
 def test_kmer_counts_from_compressed_files(tmp_path):
     """kmers.bin.lz4 / .gz -> lcty_io_read_file -> lcty_kmer_counts_parse (counts.rs:108-150: u8 k, u8 bytes, varint contigs, counts)."""
     def varint(v):
