@@ -324,11 +324,19 @@ def ont_whole_path(ctx, n_reads, n_alleles=256, chunk=4096, read_len=10_000, see
         ctx.synchronize()
         t_score = time.perf_counter() - t0
     stages = api.default_stages()
+    # the first lcty_solve of a context allocates the chains' workspace (150 GB at this size: seconds, once per context — the main
+    # measurement's warm-up steps pay it there); the second call, on the workspace the library keeps, is the one on the clock
+    t0 = time.perf_counter()
+    api.solve_locus(aa, stages, master_seed)
+    ctx.synchronize()
+    t_solve_first = time.perf_counter() - t0
+    before = {kid: ctx.timing(kid)[1] for kid in (api.K_PREFILTER, api.K_SOLVE_TABLE, api.K_SOLVE_INIT, api.K_SOLVE_INIT_ANNEAL, api.K_SOLVE,
+                                                  api.K_ANNEAL)}
     t0 = time.perf_counter()
     call, mean, var, att = api.solve_locus(aa, stages, master_seed)
     ctx.synchronize()
     t_solve = time.perf_counter() - t0
-    kern = {name: ctx.timing(kid)[1] for name, kid in (
+    kern = {name: ctx.timing(kid)[1] - before.get(kid, 0.0) for name, kid in (
         ("score_reads_kernel", api.K_SCORE), ("transfer_kernel", api.K_TRANSFER), ("prefilter_tile_kernel", api.K_PREFILTER),
         ("build_loc_table_kernel", api.K_SOLVE_TABLE), ("solve_init_kernel", api.K_SOLVE_INIT),
         ("solve_init_kernel_annealing_stage", api.K_SOLVE_INIT_ANNEAL), ("greedy_loop_kernel", api.K_SOLVE),
@@ -383,6 +391,7 @@ def ont_whole_path(ctx, n_reads, n_alleles=256, chunk=4096, read_len=10_000, see
         "reads_per_s_without_the_uploads": n_reads / (total - t_app),
         "append_s": t_app, "upload_GBs": up_bytes / 1e9 / t_app if t_app else None, "score_call_s": t_score,
         "recover_call_s": t_rec, "alignments_transferred": int(n_new), "solve_call_s": t_solve,
+        "solve_first_call_s_with_the_workspace_allocation": t_solve_first,
         "kernel_ms": kern, "kept_after_filter": kept,
         "called_genotype": list(called), "true_genotype": list(truth), "all_calls_equal_truth": called == truth,
         "quality": float(call.quality), "unexpl_reads": int(call.unexpl_reads),
