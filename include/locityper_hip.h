@@ -511,6 +511,31 @@ int32_t lcty_targets_finalize(lcty_targets* targets, uint64_t* n_minimizers);
 int32_t lcty_recruit(lcty_targets* targets, const lcty_reads_host* chunk, int32_t paired, uint32_t max_out, uint32_t* out_cnt,
                      uint32_t* out_loci);
 
+/* ---- the readers and writers around recruitment (host; src/seq/fastx.rs, src/seq/recruit.rs:1000-1030) -------------------------
+ * lcty_fastx_open: Reader::from_path (fastx.rs:296-312) on one FASTA / FASTQ file (plain or gzip), PairedEndInterleaved (444-466)
+ *   with `interleaved`, PairedEndReaders (473-511) with a second file. lcty_fastx_next: up to max_records records (read pairs when
+ *   paired) as the sequence fields of a chunk — what lcty_recruit reads; every byte but A, C, G, T is "not ACGT" (seq/kmers.rs:178-190)
+ *   —; the arrays belong to the handle until the next call; *n = 0 at the end of the input. A record's name is its header up to the
+ *   first blank (fastx.rs:417-419). Errors as upstream, LCTY_ERR_INVALID_DATA with the reference's messages: "Fastq record .. is
+ *   incomplete" / "has incorrect format" / "has non-matching sequence and qualities", "Fasta record .. has an empty sequence.", "Odd
+ *   number of records in an interleaved input file(s)", "non matching first and second mate(s)", "Different number of records in
+ *   paired-end input files".
+ * lcty_fastx_writers_open / lcty_fastx_write_recruited / _close: the per-locus read files of recruit_single_thread's loop
+ *   (recruit.rs:1017-1021: `record.write_to(writers.get(locus_ix))` for every locus of the answer): record i of the LAST chunk goes
+ *   to the writers out_loci[i * max_out .. + out_cnt[i]] as lcty_recruit filled them, as write_fastq / write_fasta leave it
+ *   (fastx.rs:46-75) and both mates of a pair one after the other (141-150) — the `reads.fq` the mapper is given WITHOUT
+ *   --interleaved. A path that ends in .gz is gzip-compressed. */
+typedef struct lcty_fastx lcty_fastx;
+typedef struct lcty_fastx_writers lcty_fastx_writers;
+int32_t lcty_fastx_open(const char* path1, const char* path2, int32_t interleaved, lcty_fastx** out);
+void    lcty_fastx_close(lcty_fastx* f);
+int32_t lcty_fastx_is_paired(const lcty_fastx* f, int32_t* paired);
+int32_t lcty_fastx_next(lcty_fastx* f, uint64_t max_records, lcty_reads_host* view, uint64_t* n);
+int32_t lcty_fastx_writers_open(const char* const* paths, uint32_t n, lcty_fastx_writers** out);
+int32_t lcty_fastx_write_recruited(lcty_fastx* f, lcty_fastx_writers* writers, uint32_t max_out, const uint32_t* out_cnt, const uint32_t* out_loci,
+                                   uint64_t* n_written);
+int32_t lcty_fastx_writers_close(lcty_fastx_writers* writers);
+
 /* ---- candidate generation inside a locus (first slice) ----------------------------------------------------
  * The reference runs an external mapper per locus — strobealign -k 15 -N/-M min(25000, 4 x alleles) -S 0.5 --eqx for short
  * reads (src/command/genotype.rs:962-1005), piped through samtools view -e "[AS] >= 50 || flag & 2304 == 0" (1055-1094), on the

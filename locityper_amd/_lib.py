@@ -78,6 +78,13 @@ SIGNATURES = {
     "lcty_targets_add_locus": (I32, [VP, U32, VP, VP, VP, VP, U32, P(U32)]),
     "lcty_targets_finalize": (I32, [VP, P(U64)]),
     "lcty_recruit": (I32, [VP, VP, I32, U32, VP, VP]),
+    "lcty_fastx_open": (I32, [C.c_char_p, C.c_char_p, I32, P(VP)]),
+    "lcty_fastx_close": (None, [VP]),
+    "lcty_fastx_is_paired": (I32, [VP, P(I32)]),
+    "lcty_fastx_next": (I32, [VP, U64, P(ReadsHost), P(U64)]),
+    "lcty_fastx_writers_open": (I32, [P(C.c_char_p), U32, P(VP)]),
+    "lcty_fastx_write_recruited": (I32, [VP, VP, U32, VP, VP, P(U64)]),
+    "lcty_fastx_writers_close": (I32, [VP]),
     "lcty_locus_depth_table": (I32, [VP, P(U32), VP]),
     "lcty_solver_default": (I32, [P(Solver), I32]),
     "lcty_chain_seeds": (I32, [U64, U64, VP]),

@@ -140,3 +140,61 @@ class BamTable:
 
     def __del__(self):
         self.close()
+
+
+class Fastx:
+    """lcty_fastx_*: FASTA / FASTQ input for recruitment (src/seq/fastx.rs readers) and the per-locus writers behind it."""
+
+    def __init__(self, path1, path2=None, interleaved=False):
+        self._h = VP()
+        check(lib().lcty_fastx_open(str(path1).encode(), None if path2 is None else str(path2).encode(), int(interleaved), C.byref(self._h)))
+        p = C.c_int32(0)
+        check(lib().lcty_fastx_is_paired(self._h, C.byref(p)))
+        self.paired = bool(p.value)
+
+    def next(self, max_records):
+        """The next chunk as a cdefs.ReadsChunk of sequence fields (views into the handle: valid until the next call), or None."""
+        hs = cdefs.ReadsHost()
+        n = U64(0)
+        check(lib().lcty_fastx_next(self._h, max_records, C.byref(hs), C.byref(n)))
+        n = int(n.value)
+        if n == 0:
+            return None
+        def arr(ptr, count, dt):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(count,))
+        mate_off = arr(hs.mate_off, 2 * n + 1, C.c_uint64)
+        nb = int(mate_off[-1])
+        z = np.zeros(n + 1, dtype=np.uint64)
+        return cdefs.ReadsChunk(arr(hs.mate_len, 2 * n, C.c_uint32), mate_off, arr(hs.bases2, nb // 16 + 1, C.c_uint32),
+                                arr(hs.nmask, nb // 32 + 1, C.c_uint32), z, np.zeros(0, dtype=cdefs.ALN_REC_DTYPE), z, np.zeros(0, dtype=np.uint32))
+
+    def write_recruited(self, writers, cnt, loci):
+        cnt = np.ascontiguousarray(cnt, dtype=np.uint32)
+        loci = np.ascontiguousarray(loci, dtype=np.uint32)
+        n = U64(0)
+        check(lib().lcty_fastx_write_recruited(self._h, writers._h, loci.shape[1], cnt.ctypes.data, loci.ctypes.data, C.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if self._h:
+            lib().lcty_fastx_close(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FastxWriters:
+    def __init__(self, paths):
+        self._keep = [str(p).encode() for p in paths]
+        arr = (C.c_char_p * len(self._keep))(*self._keep)
+        self._h = VP()
+        check(lib().lcty_fastx_writers_open(arr, len(self._keep), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, VP()
+            check(lib().lcty_fastx_writers_close(h))

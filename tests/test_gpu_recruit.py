@@ -131,3 +131,42 @@ def test_single_reads_of_every_length_match_oracle(gpu_ctx, over):
         assert list(out[i, :cnt[i]]) == exp, (i, len(rd["seq1"]), over)
         n_rec += bool(exp); n_long_rec += bool(exp) and len(rd["seq1"]) > 500
     assert n_rec > 60 and n_long_rec > 30, (n_rec, n_long_rec)
+
+
+def test_fastq_files_through_the_readers_the_kernel_and_the_per_locus_writers(gpu_ctx, tmp_path):
+    """recruit_single_thread's loop (src/seq/recruit.rs:1010-1024) with the library's own readers and writers (lcty_fastx.hip): two gzip
+    FASTQ files -> chunks of 64 read pairs -> lcty_recruit -> `reads.fq` of every locus. Every locus' file must hold exactly the
+    pairs the oracle's recruit_read_pair recruits to it, in input order, both mates one after the other, as write_fastq leaves them."""
+    import gzip
+    from locityper_amd import io as lio
+    rng = np.random.default_rng(21)
+    loci = _loci(rng, n_loci=3)
+    gt, ot = _both(gpu_ctx, loci)
+    pairs = _reads(rng, loci, 300)
+    qual = lambda n: "".join(chr(33 + int(q)) for q in rng.integers(2, 40, n))
+    recs = [(f"pair{i}/1 some description", p["seq1"], qual(len(p["seq1"])), f"pair{i}/2", p["seq2"], qual(len(p["seq2"]))) for i, p in enumerate(pairs)]
+    with gzip.open(tmp_path / "r1.fq.gz", "wt") as a, gzip.open(tmp_path / "r2.fq.gz", "wt") as b:
+        for n1, s1, q1, n2, s2, q2 in recs:
+            a.write(f"@{n1}\n{s1}\n+\n{q1}\n")
+            b.write(f"@{n2}\n{s2}\n+\n{q2}\n")
+    want = [""] * len(loci)
+    for n1, s1, q1, n2, s2, q2 in recs:
+        for l in ot.recruit(s1.encode(), s2.encode()):
+            want[l] += f"@{n1.split(' ')[0]}\n{s1}\n+\n{q1}\n@{n2}\n{s2}\n+\n{q2}\n"
+    assert sum(1 for w in want if w) >= 2                                   # the sample recruits to several loci
+    out = [tmp_path / f"locus{l}.fq" for l in range(len(loci))]
+    writers = lio.FastxWriters(out)
+    f = lio.Fastx(tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz")
+    n_pairs = n_recruited = 0
+    while True:
+        ch = f.next(64)
+        if ch is None:
+            break
+        cnt, lc = gt.recruit(ch, paired=True)
+        n_recruited += f.write_recruited(writers, cnt, lc)
+        n_pairs += ch.n_pairs
+    writers.close()
+    assert n_pairs == 300 and n_recruited == sum(1 for r in recs if ot.recruit(r[1].encode(), r[4].encode()))
+    for l in range(len(loci)):
+        assert out[l].read_text() == want[l]
+    gt.close()
