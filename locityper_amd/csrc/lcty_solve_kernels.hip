@@ -1078,7 +1078,7 @@ __device__ __forceinline__ double row_sum_f64(double x, uint32_t row_base, uint3
     }
 }
 
-constexpr uint32_t GREEDY_ROW_TAIL = 4;       // words per row behind the windows (see the kernel)
+constexpr uint32_t GREEDY_ROW_TAIL = 8;       // words per row behind the windows (see the kernel)
 // LDS of a greedy workgroup for its rows' windows: 4 bytes each; 6 with the weights in LDS, plus the two weight tables (16-byte multiple)
 __host__ __device__ inline size_t greedy_lds_windows(uint32_t lpc, uint32_t wstride, uint32_t n_wk, uint32_t n_wc, bool lw) {
     const size_t rows = static_cast<size_t>(64 / lpc) * (lw ? 2 : 1) * wstride;
@@ -1126,9 +1126,11 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
     uint32_t* wd = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(wg_row) * W;
     const uint32_t gi = chain / V.attempts;
     // the parts of the chain's list of non-trivial reads (RecList): four words per row in LDS, behind everything else
-    // per row, behind the windows: [0..3] the parts of the record list
+    // per row, behind the windows: [0..3] the parts of the record list, [4..5] row_best
     uint32_t* row_cum = reinterpret_cast<uint32_t*>(smem + greedy_lds_windows(LPC, V.wstride, V.n_wk, V.n_wc, LW)) + static_cast<size_t>(wg_row) * GREEDY_ROW_TAIL;
     if (jj < 4) row_cum[jj] = V.c_seg[static_cast<uint64_t>(chain) * 4 + jj];
+    [[maybe_unused]] double* row_best = reinterpret_cast<double*>(row_cum + 4);          // [4..5] the row's largest improvement of an iteration
+    if (jj == 0) *row_best = -INFINITY;
     RecList recs{V.recs + static_cast<uint64_t>(chain) * V.rstride, row_cum, V.seg_reads};
     {
         // the bounds of the list's parts in registers of the lane (three LDS reads per pick less: 312 -> 309 ms)
@@ -1220,7 +1222,8 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x127, 0xF, 0xF, false) == v;
                 dup |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false) == v;
             } else {
-                for (uint32_t d = 1; d < LPC; d++) {
+                // two lanes at ring distance k meet at rotation k or LPC - k, one of which is at most LPC / 2 (all LPC - 1 rotations: + 4 ms)
+                for (uint32_t d = 1; d <= LPC / 2; d++) {
                     const uint32_t other = static_cast<uint32_t>(__shfl(static_cast<int>(idx), static_cast<int>(row_base + ((jj + d) % LPC))));
                     dup |= other == idx;
                 }
@@ -1260,6 +1263,8 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
         auto request_ext = [&](const GreedyCand& c, GreedyExtRaw& e) {
             const uint32_t meta = c.q0.y, nloc = meta & 0xFFu;
             const uint4* p = reinterpret_cast<const uint4*>(extra + (cand && nloc > 2 ? (meta >> 8) : 0u));   // the run has spare entries behind it
+            // (unconditional: under `if (__any(nloc > 2))` the loop took 306 ms instead of 274, under a per-lane `if` 292 — the wait counts
+            // in front of the gathers' use must then fit both paths; profiles/r06_solver_notes.txt section 5)
             e.x0 = p[0]; e.x1 = p[1];
         };
         uint32_t curr_plato = 0;
@@ -1376,7 +1381,17 @@ __global__ __launch_bounds__(LW ? 128 : 64) void greedy_loop_kernel(const SolveV
             if constexpr (TIMED) asm volatile("" :: "v"(my_improv));
             tick(3);
             // first candidate (sample order) with the largest improvement above min_diff (stoch.rs:103-109)
-            const double best = row_max_f64<LPC>(my_improv, row_base, jj);
+            double best;
+            if constexpr ((LPC & (LPC - 1)) != 0) {
+                // rows of 10 or 12 lanes: the LDS works a wavefront's operations off in order — the row's lanes meet in ONE atomic maximum,
+                // the read behind it sees all of them, the reset behind that is seen by the next iteration's (four rounds of two
+                // ds_bpermute each on the ring: + 7 ms)
+                if (n_alt) __hip_atomic_fetch_max(row_best, my_improv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                best = __hip_atomic_load(row_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (jj == 0) __hip_atomic_store(row_best, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else best = row_max_f64<LPC>(my_improv, row_base, jj);
             const unsigned long long who = __ballot(n_alt && my_improv == best);
             const unsigned long long who_row = (who >> row_base) & (LPC == 64 ? ~0ull : ((1ull << (LPC & 63u)) - 1ull));
             const uint32_t src = who_row ? static_cast<uint32_t>(__ffsll(static_cast<long long>(who_row))) - 1u : 0u;
