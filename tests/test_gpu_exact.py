@@ -97,9 +97,10 @@ def test_exact_on_larger_models_node_limit_and_assignment(gpu_ctx):
 def test_exact_at_configs0_size_within_the_reference_solvers_gap(gpu_ctx):
     """BASELINE.json configs[0]: 10 000 read pairs x 8 alleles. The reference's HiGHS run stops — and reports "optimal" — at its default relative
     gap of 1e-4 (highs.rs:103-116 changes no option); that gap is lcty_solver_default's for this kind, and with it the exact solver answers for
-    the genotypes of a stage (the best 16 of the prefilter here, one attempt each, solved by the pool of host threads; of the best 20 one is
-    still refused: scripts/exact_probe.py), and its likelihood is not below what the greedy and
-    the annealing chains of the same attempt reach. The bound behind it: the window counts dualised, multipliers set by subgradient steps at the
+    the genotypes of a stage (the best 16 of the prefilter here, one attempt each, solved by the pool of host threads — and, below, all 36
+    genotypes of the locus: until round 6 twelve of them were refused, their single-move incumbents 1-2e-4 below the bound), and its
+    likelihood is not below what the greedy and the annealing chains of the same attempt reach. Against HiGHS itself on the reference's
+    programme: tests/test_exact_highs.py (CPU). The bound behind it: the window counts dualised, multipliers set by subgradient steps at the
     root (1.6e-2 -> ~1e-4 relative at this size)."""
     import time
     L = synth.SynthLocus(8, 10_000, seed=synth.SEED + 3)
@@ -131,6 +132,14 @@ def test_exact_at_configs0_size_within_the_reference_solvers_gap(gpu_ctx):
     import os
     if (os.cpu_count() or 1) >= 16 and wall1 > 0.2:
         assert wall < 1.2 * wall1, f"the exact solver's pool took {wall:.2f} s, one thread {wall1:.2f} s"
+    # every genotype of the locus is answered (moves of two reads that meet in a window lift the incumbent into the gap), none below its chains
+    every = np.ascontiguousarray(gts[np.argsort(-aa.run_filter(), kind="stable")])
+    s36 = api.chain_seeds(6, len(every))
+    e36 = api.solve_stage(aa, every, ex, 1, s36)[2][:, 0]
+    assert len(e36) == 36 and np.all(np.isfinite(e36))
+    for kind in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL):
+        c36 = api.solve_stage(aa, every, api.default_solver(kind), 1, s36)[2][:, 0]
+        assert np.all(c36 <= e36 + 1e-9 * np.abs(e36)), (kind, c36 - e36)
     # the proof of optimality itself (gap 0) still runs out of nodes at this size: Error::Solver, as a HiGHS run that is not "optimal"
     with pytest.raises(_lib.LocityperError) as e:
         api.solve_stage(aa, sub[:1], proof(), 1, seeds[:1])
