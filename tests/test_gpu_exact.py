@@ -163,3 +163,33 @@ def test_attempts_without_a_tweak_share_one_model(gpu_ctx):
     off, c3 = api.assignment_counts(aa, gts[0], ex, 3, api.chain_seeds(1, 3))
     _, c1 = api.assignment_counts(aa, gts[0], ex, 1, api.chain_seeds(1, 1))
     assert np.array_equal(c3, 3 * c1)
+
+
+def test_exact_through_the_c_abi_against_highs_on_the_references_programme(gpu_ctx):
+    """BASELINE configs[0] through the library (the model built on the device from the scored batch, solved by the pool of host threads)
+    against HiGHS (scipy.optimize.milp) on `HighsSolver::define_model`'s programme (highs.rs:38-134) built from the oracle's
+    GenotypeAlignments with the same tweak: the best genotype of the prefilter and the one of rank 18 (refused until round 6). Both solvers
+    stop inside the default relative gap of 1e-4; HiGHS ends at its root node, at the optimum."""
+    import ctypes as C
+    from tests import pyref_highs as H
+    L, p, loc, aa, ol, oa = setup(gpu_ctx, 8, 10_000, 50_000, seed=synth.SEED + 3)
+    gts = api.generate_genotypes(8, 2)
+    order = np.argsort(-aa.run_filter(), kind="stable")
+    ex = api.default_solver(cdefs.SOLVER_EXACT)
+    lib = O.lib()
+    lib.orc_depth_ln_prob.restype = C.c_double
+    for rank in (0, 18):
+        gt = np.ascontiguousarray(gts[order[rank]][None, :])
+        seed = api.chain_seeds(40 + rank, 1)
+        lik = api.solve_stage(aa, gt, ex, 1, seed)[2][0, 0]
+        g = O.OracleGtAlns(ol, oa, tuple(int(x) for x in gt[0]))
+        g.apply_tweak(int(seed[0]))
+        a = g.arrays()
+        gc, w = g.window_distr()
+        ok, h_assgn, _, info = H.solve(a["read_ixs"], a["ln_prob"], a["windows"], gc, w,
+                                       lambda ww, d: lib.orc_depth_ln_prob(ol._h, int(gc[ww]), float(w[ww]), int(d)),
+                                       1.0 - p.lik_skew, 1.0 + p.lik_skew, time_limit=300.0)
+        assert ok, info
+        h_lik = g.likelihood(h_assgn)[0]
+        gap = 1e-4 * abs(h_lik)
+        assert h_lik - 0.5 * gap <= lik <= h_lik + gap, (rank, lik, h_lik, info)
