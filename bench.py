@@ -95,6 +95,9 @@ def parse_args():
     ap.add_argument("--ont-stream-sample", type=int, default=16384,
                     help="10-kb ONT reads of the configs[2] leg from bases alone, streamed (mapped onto all alleles on the device, scored, "
                          "prefiltered; 0 = skip)")
+    ap.add_argument("--exact-sample", type=int, default=1,
+                    help="extra measurement: the exact solver on BASELINE configs[0] (10 000 read pairs x 8 alleles, all 36 genotypes), and "
+                         "HiGHS (scipy) on the reference's programme for this many of the best genotypes beside it (0 = skip the leg)")
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
@@ -133,7 +136,7 @@ def set_up_comm(args, ctx, rank, world, dist):
     """--shard-reads / --shard-chains: one RCCL communicator over the ranks (rank 0's id goes round through gloo)."""
     os.environ.pop("NCCL_DEBUG", None)         # RCCL logs to stdout, which carries the one JSON line
     os.environ["NCCL_DEBUG_FILE"] = os.devnull
-    args.recovery_sample = args.recruit_sample = args.ont_sample = args.ont_stream_sample = args.ont_whole_path_sample = 0
+    args.recovery_sample = args.recruit_sample = args.ont_sample = args.ont_stream_sample = args.ont_whole_path_sample = args.exact_sample = 0
     uid = api.comm_unique_id() if rank == 0 else bytes(api.COMM_ID_BYTES)
     if dist is not None:
         import torch
@@ -472,6 +475,7 @@ def main():
         progress("timed region done")
         ctx.trim()          # the solver workspaces of the timed steps (160 GB) make room for the extra measurements below
     rprm = None
+    exact_state = None
     if extra and args.format == "counted" and host_chunks and host_chunks[0] and not args.no_solve:
         progress("scoring on the records form of the same batch")
         out["roofline_all"]["score_reads_kernel"]["records_format"] = records_format_figure(args, ctx, loc, host_chunks[0], totals)
@@ -488,6 +492,10 @@ def main():
         progress("alignment-recovery leg")
         from bench_legs.short_reads import recovery_leg
         out["recovery"] = recovery_leg(args, ctx, L, loc)
+    if extra and args.exact_sample > 0:
+        progress("exact-solver leg")
+        from bench_legs.short_reads import exact_solver_leg
+        out["exact_solver"], exact_state = exact_solver_leg(args, ctx)
     if extra and args.many_alleles_sample > 0:
         progress("many-alleles leg")
         from bench_legs.short_reads import many_alleles_leg
@@ -535,6 +543,13 @@ def main():
         out["chains_check"] = cc
         if rprm is not None:
             out["cpu_baseline"]["recruitment_read_pairs_per_s"] = CPU.recruitment_baseline(L, rprm)
+        if exact_state is not None:
+            progress("HiGHS on the reference's programme beside the exact-solver leg")
+            try:
+                out["exact_solver"]["against_highs"] = CPU.exact_against_highs(exact_state, args.exact_sample)
+            except Exception as e:                     # an extra beside an extra: the line stands without it
+                out["exact_solver"]["against_highs"] = {"error": str(e)}
+    exact_state = None
     if args.distinct_loci >= 2 and queue_mode and extra and args.format == "counted":
         progress("queue of distinct loci, uploads inside the steps")
         from bench_legs.loci_queue import distinct_loci_leg

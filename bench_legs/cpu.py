@@ -237,3 +237,37 @@ def whole_path_chains_check(L, p, loc, aa, gts, scores, greedy, anneal, n_chains
         worst = max(worst, float(np.abs(gl - olk).max() / np.abs(olk).max()))
     return {"greedy_chains": len(sub), "anneal_chains": len(sub), "reads": int(aa.n_pairs), "max_relative_difference": worst,
             "chains_equal_oracle": bool(worst <= 1e-9)}
+
+
+def exact_against_highs(state, n_genotypes):
+    """Beside the exact-solver leg (bench_legs/short_reads.py::exact_solver_leg), on the host: HiGHS itself (scipy.optimize.milp) on the
+    reference's integer programme (HighsSolver::define_model, highs.rs:38-100) built from the ORACLE's GenotypeAlignments with the same
+    tweak (tests/pyref_highs.py) — what the reference's back end takes for the same model, one thread as the reference runs a model, and
+    how far below its optimum the library's answer is. For the best `n_genotypes` of the prefilter."""
+    import ctypes as C
+    import time
+    from tests import oracle_ffi as O, pyref_highs as H
+    L, p, loc, aa, every, seeds, lik = state
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    ol.inject_tables(loc.depth_lut(), loc.window_weights())
+    st, w8, unm, _ = aa.status()
+    off, pa = aa.pair_alns()
+    oa = O.alns_from_arrays(8, st, w8, unm, off, pa)
+    lib = O.lib()
+    lib.orc_depth_ln_prob.restype = C.c_double
+    rows = []
+    for r in range(min(n_genotypes, len(every))):
+        g = O.OracleGtAlns(ol, oa, tuple(int(x) for x in every[r]))
+        g.apply_tweak(int(seeds[r]))
+        a = g.arrays()
+        gc, ww = g.window_distr()
+        t1 = time.perf_counter()
+        ok, h_assgn, _, info = H.solve(a["read_ixs"], a["ln_prob"], a["windows"], gc, ww,
+                                       lambda x, d: lib.orc_depth_ln_prob(ol._h, int(gc[x]), float(ww[x]), int(d)),
+                                       1.0 - p.lik_skew, 1.0 + p.lik_skew, time_limit=120.0)
+        h_lik = g.likelihood(h_assgn)[0] if ok else None
+        rows.append({"genotype": [int(x) for x in every[r]], "highs_seconds": time.perf_counter() - t1, "highs_status_optimal": bool(ok),
+                     "highs_nodes": info.get("mip_node_count"), "highs_likelihood": h_lik, "library_likelihood": float(lik[r]),
+                     "library_below_highs_relative": (None if h_lik is None else float((h_lik - lik[r]) / abs(h_lik)))})
+    return {"what": "scipy.optimize.milp (HiGHS) on HighsSolver::define_model's programme from the oracle's GenotypeAlignments, the reference's "
+                    "options, one host thread", "rows": rows}

@@ -159,3 +159,35 @@ def many_alleles_leg(args, ctx):
     leg["true_genotype"] = list(Lm.true_genotype)
     am.close()
     return leg
+
+
+def exact_solver_leg(args, ctx):
+    """The exact solver (the place of HighsSolver, solvers/highs.rs:38-134) on BASELINE.json configs[0] — 10 000 read pairs x 8
+    alleles: every one of the locus' 36 genotypes, one attempt each, through lcty_solve_stage (models built on the device, solved by the
+    pool of host threads). Returns the leg and what bench_legs/cpu.py::exact_against_highs needs to hold HiGHS beside it."""
+    from locityper_amd import cdefs
+    L = synth.SynthLocus(8, 10_000, seed=synth.SEED + 3)
+    p = api.resolve_params(api.default_params(), L.bg)
+    loc = api.Locus(ctx, L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    aa = api.AllAlignments.load(loc, L.reads(0, 10_000))
+    gts = api.generate_genotypes(8, 2)
+    order = np.argsort(-aa.run_filter(), kind="stable")
+    every = np.ascontiguousarray(gts[order])
+    seeds = api.chain_seeds(77, len(every))
+    ex = api.default_solver(cdefs.SOLVER_EXACT)
+    api.solve_stage(aa, every[:1], ex, 1, seeds[:1])                          # first use: workspace, depth table
+    t0 = time.perf_counter()
+    try:
+        lik = api.solve_stage(aa, every, ex, 1, seeds)[2][:, 0]
+    except Exception as e:                                                     # LCTY_ERR_SOLVER: a genotype without an answer inside the node limit
+        return {"workload": "10000 read pairs x 8 alleles (BASELINE.json configs[0]), 36 genotypes x 1 attempt", "error": str(e)}, None
+    wall = time.perf_counter() - t0
+    chains = {}
+    for name, kind in (("greedy", cdefs.SOLVER_GREEDY), ("annealing", cdefs.SOLVER_ANNEAL)):
+        cl = api.solve_stage(aa, every, api.default_solver(kind), 1, seeds)[2][:, 0]
+        chains[name + "_chain_below_exact_max"] = float(np.max(lik - cl))
+        chains[name + "_chains_above_exact"] = int(np.count_nonzero(cl > lik + 1e-9 * np.abs(lik)))
+    leg = {"workload": "10000 read pairs x 8 alleles (BASELINE.json configs[0]): all 36 genotypes x 1 attempt, relative gap 1e-4 (HiGHS' default)",
+           "genotypes": int(len(every)), "answered": int(np.count_nonzero(np.isfinite(lik))), "seconds": wall, "genotypes_per_s": len(every) / wall,
+           "host_threads": "the pool of the library (exact_threads: the machine's hardware threads, at most 64)", **chains}
+    return leg, (L, p, loc, aa, every, seeds, lik)

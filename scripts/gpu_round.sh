@@ -11,7 +11,7 @@ TAG=${1:-round}; STEPS=${2:-tb}; shift; shift
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 python3 scripts/sources_sha.py > "$OUT/sources.sha16"        # which kernels these passes saw (bench.py compares)
-LEAN="--cpu-sample 0 --ont-whole-path-sample 0 --ont-stream-sample 0 --recovery-sample 0 --recruit-sample 0 --map-sample 0 --many-alleles-sample 0 --ont-sample 0 --ont-map-sample 0"
+LEAN="--cpu-sample 0 --exact-sample 0 --ont-whole-path-sample 0 --ont-stream-sample 0 --recovery-sample 0 --recruit-sample 0 --map-sample 0 --many-alleles-sample 0 --ont-sample 0 --ont-map-sample 0"
 case "$STEPS" in *t*) timeout 1500 python3 -m pytest tests -m gpu -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" "$OUT/pytest.log" | tail -15;; esac
 case "$STEPS" in *b*) timeout 1200 python3 bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cut -c1-600 "$OUT/bench.json";; esac
 case "$STEPS" in *l*) timeout 900 python3 bench.py $LEAN "$@" > "$OUT/bench_lean.json" 2> "$OUT/bench_lean.err"; echo "lean bench rc=$?"; cut -c1-600 "$OUT/bench_lean.json";; esac
