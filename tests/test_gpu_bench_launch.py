@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--pairs", "20000", "--alleles", "16", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--ont-sample", "0",
-         "--many-alleles-sample", "0", "--recruit-sample", "0", "--map-sample", "0", "--recovery-sample", "0", "--ont-stream-sample", "0", "--ont-whole-path-sample", "0"]
+         "--many-alleles-sample", "0", "--recruit-sample", "0", "--map-sample", "0", "--recovery-sample", "0", "--ont-stream-sample", "0", "--ont-whole-path-sample", "0", "--exact-sample", "0"]
 
 
 def run_bench(extra, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
