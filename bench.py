@@ -546,9 +546,10 @@ def main():
         if exact_state is not None:
             progress("HiGHS on the reference's programme beside the exact-solver leg")
             try:
-                out["exact_solver"]["against_highs"] = CPU.exact_against_highs(exact_state, args.exact_sample)
+                out["cpu_baseline"]["exact_against_highs"] = CPU.exact_against_highs(exact_state, args.exact_sample)
             except Exception as e:                     # an extra beside an extra: the line stands without it
-                out["exact_solver"]["against_highs"] = {"error": str(e)}
+                out["cpu_baseline"]["exact_against_highs"] = {"error": str(e)}
+            out["exact_solver"]["against_highs"] = "cpu_baseline.exact_against_highs (the CPU block: HiGHS on the reference's programme)"
     exact_state = None
     if args.distinct_loci >= 2 and queue_mode and extra and args.format == "counted":
         progress("queue of distinct loci, uploads inside the steps")
