@@ -96,8 +96,11 @@ def parse_args():
                     help="10-kb ONT reads of the configs[2] leg from bases alone, streamed (mapped onto all alleles on the device, scored, "
                          "prefiltered; 0 = skip)")
     ap.add_argument("--exact-sample", type=int, default=1,
-                    help="extra measurement: the exact solver on BASELINE configs[0] (10 000 read pairs x 8 alleles, all 36 genotypes), and "
-                         "HiGHS (scipy) on the reference's programme for this many of the best genotypes beside it (0 = skip the leg)")
+                    help="extra measurement: the exact solver on BASELINE configs[0] (10 000 read pairs x 8 alleles, all 36 genotypes); 0 = skip")
+    ap.add_argument("--exact-highs", type=int, default=0,
+                    help="beside that leg, in the CPU block: HiGHS (scipy.optimize.milp) on the reference's programme for this many of the best "
+                         "genotypes (half a minute to a minute and a half each on a busy host; tests/test_exact_highs.py holds the two "
+                         "solvers against each other in any case)")
     ap.add_argument("--recovery-sample", type=int, default=262144,
                     help="read pairs of the extra alignment-recovery measurement (K6, outside the timed region; 0 = skip)")
     return ap.parse_args()
@@ -543,10 +546,10 @@ def main():
         out["chains_check"] = cc
         if rprm is not None:
             out["cpu_baseline"]["recruitment_read_pairs_per_s"] = CPU.recruitment_baseline(L, rprm)
-        if exact_state is not None:
+        if exact_state is not None and args.exact_highs > 0:
             progress("HiGHS on the reference's programme beside the exact-solver leg")
             try:
-                out["cpu_baseline"]["exact_against_highs"] = CPU.exact_against_highs(exact_state, args.exact_sample)
+                out["cpu_baseline"]["exact_against_highs"] = CPU.exact_against_highs(exact_state, args.exact_highs)
             except Exception as e:                     # an extra beside an extra: the line stands without it
                 out["cpu_baseline"]["exact_against_highs"] = {"error": str(e)}
             out["exact_solver"]["against_highs"] = "cpu_baseline.exact_against_highs (the CPU block: HiGHS on the reference's programme)"
