@@ -5,7 +5,7 @@
 // asks for the optimum, fails with Error::Solver when the library does not report "optimal" (highs.rs:113-116), and decodes the
 // assignment by per-read arg-max. The optimum of that model IS the assignment of largest ReadAssignment::likelihood (assgn.rs:235-237).
 // Here: depth-first over the non-trivial reads (along the alleles; the location the bound's multipliers prefer first), starting from
-// the best of a coordinate ascent, pruned by a Lagrangian bound over the window counts (stated where it is set up below: lo_w is the
+// the best of a coordinate ascent over moves of one read and of two reads that meet in a window, pruned by a Lagrangian bound over the window counts (stated where it is set up below: lo_w is the
 // depth the placed reads give window w, cap_w what the free ones could add). `node_limit` nodes without a proof -> out_of_nodes.
 // Host code only: runs on the caller's pool of threads, one model per thread, like the reference's workers (solve.rs:1052-1062).
 #include "lcty_exact.hpp"
@@ -236,7 +236,8 @@ void solve(const Model& m, const double* lut, uint32_t ld, Result& out) {
     // (add and subtract lam_w x what the free reads put into window w); lam = 0 is "every free read at its best location, every window
     // at the best depth its reads could give it". The multipliers are set once, at the root, by subgradient steps that lower the
     // bound (Polyak steps towards the incumbent), and every node is bounded with them: at 10 000 read pairs the root gap falls
-    // from 1.6e-2 to 6e-4 (scripts/exact_lagrangian_probe.py). The rounded multiplier solutions also feed the incumbent.
+    // from 1.6e-2 to 6e-4 and ends ~0.45 above the optimum HiGHS proves for the reference's programme (tests/test_exact_highs.py): the
+    // relaxation's own slack. The rounded multiplier solutions also feed the incumbent.
     std::vector<double> lam(tw, 0.0);
     auto wterm = [&](uint32_t w) -> double {
         if (ww[w] == 0.0) return 0.0;                                  // a window without a distribution keeps lam_w = 0
@@ -410,7 +411,7 @@ void solve(const Model& m, const double* lut, uint32_t ld, Result& out) {
     const double rel_gap = m.rel_gap > 0.0 && m.rel_gap < 1.0 ? m.rel_gap : 0.0;
     const double root_bound = m.aln_contrib * aln_sum + free_best + win_sum;
     if (!m.dump_path.empty()) {
-        // the model as the search sees it (scripts/exact_probe.py --dump, scripts/exact_lagrangian_probe.py): text, one item per line
+        // the model as the search sees it (scripts/exact_probe.py --dump): text, one item per line
         FILE* f = fopen(m.dump_path.c_str(), "w");
         if (f) {
             fprintf(f, "%u %u %u %.17g %.17g %.17g\n", n, tw, ld, m.aln_contrib, m.depth_contrib, aln_fixed);

@@ -196,8 +196,12 @@ struct StageRunner {
             // Grow-only, with a little head-room: the loci of a queue differ by a fraction of a per cent in their good read pairs, and a
             // workspace that followed every locus exactly was released and allocated again (4 s for 150 GB, with every stream of the
             // device waiting) whenever a slightly larger locus came after a smaller one.
-            const uint64_t want_recs = std::max<uint64_t>(ws.recs.n, max_chains * (ngp + ngp / 128));
-            const uint64_t want_extra = std::max<uint64_t>(ws.extra.n, max_chains * static_cast<uint64_t>(ws.extra_cap) + 2);   // two spare entries: the greedy loop reads a pair per record
+            uint64_t want_recs = std::max<uint64_t>(ws.recs.n, max_chains * (ngp + ngp / 128));
+            uint64_t want_extra = std::max<uint64_t>(ws.extra.n, max_chains * static_cast<uint64_t>(ws.extra_cap) + 2);   // two spare entries: the greedy loop reads a pair per record
+            if (want_recs * sizeof(ChainRec) + want_extra * sizeof(ExtraLoc) > budget) {
+                // ... unless what is kept does not fit beside what is needed (longer runs of further locations for fewer chains): exactly then
+                want_recs = max_chains * (ngp + ngp / 128); want_extra = max_chains * static_cast<uint64_t>(ws.extra_cap) + 2;
+            }
             ws.recs.release(); ws.extra.release();
             ws.recs.alloc(want_recs); ws.extra.alloc(want_extra);
         }
@@ -440,8 +444,9 @@ struct StageRunner {
     void run(const uint16_t* genotypes, const double* priors, const uint64_t* chain_seeds, F&& after_batch) {
         hipStream_t s = stream;
         std::vector<double> liks(gt_per_batch * attempts);
-        for (uint64_t g0 = 0; g0 < n_gt; g0 += gt_per_batch) {
+        for (uint64_t g0 = 0; g0 < n_gt;) {
             const uint64_t ng = std::min(gt_per_batch, n_gt - g0), nch = ng * attempts;
+            bool smaller_batches = false;
             upload_genotypes(genotypes + g0 * ploidy, ng);
             ws.seeds.upload(chain_seeds + g0 * attempts, nch, s);
             init_host = InitHost{genotypes + g0 * ploidy, chain_seeds + g0 * attempts, gathered_rows ? gathered_rows->row_of.data() : nullptr, loc,
@@ -482,14 +487,20 @@ struct StageRunner {
                     plan_batches();
                     V.overflow = ws.ovf.p;
                     V.priors = priors ? ws.pri.p : nullptr;                    // plan_batches starts from "no priors"; this batch's are uploaded
-                    if (gt_per_batch < ng) fail(LCTY_ERR_RUNTIME, "device memory: %llu chains of this stage do not fit with %u further locations each (had %llu)",
-                                                static_cast<unsigned long long>(ng * attempts), ws.extra_cap, static_cast<unsigned long long>(before));
+                    if (ctx->diag_knob("queue_trace", 0))
+                        fprintf(stderr, "[lcty queue] lane %u: %u further locations per chain, room for %llu genotypes a batch (had %llu)\n", lane, ws.extra_cap,
+                                static_cast<unsigned long long>(gt_per_batch), static_cast<unsigned long long>(before));
+                    // the longer runs leave room for fewer chains than this batch holds: the batch again from its first genotype, in
+                    // smaller batches (it used to end the call: a 1 M-read ONT locus whose batch shared the device with 22 GB of records)
+                    if (gt_per_batch < ng) { smaller_batches = true; break; }
                     continue;
                 }
                 if (loc->lut_ext_depth >= depth_cap) fail(LCTY_ERR_RUNTIME, "window depth beyond 2 * reads + 2");
                 ensure_depth_table(loc, std::min<uint64_t>(4ull * loc->lut_ext_depth, depth_cap));
             }
+            if (smaller_batches) continue;
             after_batch(g0, ng, liks.data());
+            g0 += ng;
         }
     }
 };

@@ -400,6 +400,18 @@ def test_reads_with_many_locations_and_the_growth_of_their_runs(gpu_ctx):
         gpu_ctx.set_knob("solve_extra_start", -1)
         gpu_ctx.trim()
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    # ... and when the grown runs leave room for fewer chains than the batch holds, the batch starts again in smaller batches (it used to
+    # end the call with "device memory"): a budget in which the nine genotypes fit with runs of 7 entries and no longer with ~2 600
+    gpu_ctx.set_knob("solve_extra_start", 7)
+    gpu_ctx.set_knob("solve_budget_mb", 2)
+    try:
+        gpu_ctx.trim()
+        tight = [api.solve_stage(aa, g3, api.default_solver(k), 2, seeds)[2] for k in (cdefs.SOLVER_GREEDY, cdefs.SOLVER_ANNEAL)]
+    finally:
+        gpu_ctx.set_knob("solve_extra_start", -1)
+        gpu_ctx.set_knob("solve_budget_mb", -1)
+        gpu_ctx.trim()
+    assert np.array_equal(tight[0], ref[0]) and np.array_equal(tight[1], ref[1])
     g4 = api.generate_genotypes(6, 4)[:4]
     compare_stage(aa, ol, oa, g4, api.default_solver(cdefs.SOLVER_ANNEAL), 2, api.chain_seeds(6, 8))
 
