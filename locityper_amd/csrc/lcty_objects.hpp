@@ -94,6 +94,13 @@ struct lcty_reads {
     uint64_t raw_first = 0, cap_raw_pairs = 0;
     uint64_t chunk_cap_recs = 0, chunk_cap_cigar = 0;   // record / CIGAR capacity of a chunk as given at creation (recovery replaces the tables)
     unsigned long long pa_at_raw_first = 0;   // arena cursor when the current chunk started (a chunk can be scored again)
+    // a streaming batch keeps a second set of record tables: alignment recovery merges a chunk's records with the transferred ones INTO
+    // the spare set and swaps the two, instead of allocating (and freeing) a chunk's worth of device memory per chunk — 22 GB at
+    // 32 768 10-kb reads x 256 alleles, a third of a second a time
+    lcty::DevBuf<uint64_t> spare_aln_off, spare_cigar_off;
+    lcty::DevBuf<lcty_aln_rec> spare_recs;
+    lcty::DevBuf<uint32_t> spare_cigar;
+    lcty::DevBuf<uint2> spare_pair_meta;
 
     lcty::DevBuf<uint32_t> d_mate_len;
     lcty::DevBuf<uint64_t> d_mate_off;

@@ -1978,6 +1978,10 @@ __global__ __launch_bounds__(256) void assignment_counts_kernel(const SolveView 
 // location table + compact "unmapped" column of a scored batch (rebuilt after every lcty_score_reads)
 void ensure_solver_tables(lcty_reads* reads) {
     reads->ensure_good_index();
+    // a streaming batch that goes on to the solver is past its chunks: the spare record tables of alignment recovery (lcty_objects.hpp) are
+    // device memory the stage's workspace wants (a later recovery allocates them again)
+    reads->spare_aln_off.release(); reads->spare_cigar_off.release(); reads->spare_recs.release(); reads->spare_cigar.release();
+    reads->spare_pair_meta.release();
     if (reads->loc_table_valid) return;
     lcty_ctx* ctx = reads->ctx;
     lcty_locus* loc = reads->locus;

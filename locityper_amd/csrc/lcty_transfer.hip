@@ -1058,19 +1058,38 @@ int32_t lcty_recover_alignments(lcty_reads* reads, uint64_t* n_recovered) {
             max_recs = std::max(max_recs, nr); max_cig = std::max(max_cig, nw);
         }
         if (max_recs > 65535) fail(LCTY_ERR_UNSUPPORTED, "more than 65535 alignments of one read pair after recovery");
-        DevBuf<uint64_t> d_m_aln, d_m_cig; DevBuf<lcty_aln_rec> d_m_recs; DevBuf<uint32_t> d_m_cigar; DevBuf<uint2> d_m_meta;
+        // the merged tables: a resident batch gets new ones, exactly as large as they are full (the old ones are freed below); a streaming
+        // batch merges into its spare set and swaps (lcty_objects.hpp), both sets at least a chunk's capacity, so that neither this call
+        // nor the next chunk's append allocates
+        const bool keep = reads->streaming;
+        DevBuf<uint64_t> l_aln, l_cig; DevBuf<lcty_aln_rec> l_recs; DevBuf<uint32_t> l_cigar; DevBuf<uint2> l_meta;
+        DevBuf<uint64_t>& d_m_aln = keep ? reads->spare_aln_off : l_aln; DevBuf<uint64_t>& d_m_cig = keep ? reads->spare_cigar_off : l_cig;
+        DevBuf<lcty_aln_rec>& d_m_recs = keep ? reads->spare_recs : l_recs; DevBuf<uint32_t>& d_m_cigar = keep ? reads->spare_cigar : l_cigar;
+        DevBuf<uint2>& d_m_meta = keep ? reads->spare_pair_meta : l_meta;
         const uint64_t raw_pairs_cap = std::max<uint64_t>(reads->streaming ? reads->cap_raw_pairs : reads->cap_pairs, R);
-        d_m_aln.alloc(raw_pairs_cap + 1); d_m_cig.alloc(raw_pairs_cap + 1);
+        if (keep) {
+            d_m_aln.ensure(raw_pairs_cap + 1); d_m_cig.ensure(raw_pairs_cap + 1); d_m_meta.ensure(raw_pairs_cap);
+            // (grow-only, by a sixteenth at a time: the merged chunks of a batch differ by a per cent or two, and without head-room every
+            // chunk a little larger than all before it was a fresh 22-GB allocation — eight of them in 31 chunks, a third of a second each)
+            auto grown = [](uint64_t need) { return need + need / 16; };
+            const uint64_t need_recs = std::max<uint64_t>(m_aln[R] + 1, reads->chunk_cap_recs + 1);
+            const uint64_t need_cigar = std::max<uint64_t>(m_cig[R] + 16, reads->chunk_cap_cigar + 16);
+            if (d_m_recs.n < need_recs) d_m_recs.alloc(grown(need_recs));
+            if (d_m_cigar.n < need_cigar) d_m_cigar.alloc(grown(need_cigar));
+        } else {
+            d_m_aln.alloc(raw_pairs_cap + 1); d_m_cig.alloc(raw_pairs_cap + 1);
+            d_m_recs.alloc(m_aln[R] + 1); d_m_cigar.alloc(m_cig[R] + 8); d_m_meta.alloc(raw_pairs_cap);
+        }
         d_m_aln.upload(m_aln.data(), R + 1, s); d_m_cig.upload(m_cig.data(), R + 1, s);
-        d_m_recs.alloc(m_aln[R] + 1); d_m_cigar.alloc(m_cig[R] + 8); d_m_meta.alloc(raw_pairs_cap);
         hipLaunchKernelGGL(merge_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(R, 65535))), dim3(64), 0, s, reads->view(), d_new_cnt.p, d_new_words.p,
                            d_rec_at.p, d_word_at.p, xrecs, d_xwords.p, d_m_aln.p, d_m_cig.p, d_m_recs.p, d_m_cigar.p, d_m_meta.p);
         LCTY_HIP(hipGetLastError());
         LCTY_HIP(hipStreamSynchronize(s));
-        reads->d_aln_off = std::move(d_m_aln); reads->d_cigar_off = std::move(d_m_cig);
-        reads->d_recs = std::move(d_m_recs); reads->d_cigar = std::move(d_m_cigar); reads->d_pair_meta = std::move(d_m_meta);
+        std::swap(reads->d_aln_off, d_m_aln); std::swap(reads->d_cigar_off, d_m_cig);
+        std::swap(reads->d_recs, d_m_recs); std::swap(reads->d_cigar, d_m_cigar); std::swap(reads->d_pair_meta, d_m_meta);
         reads->n_recs = m_aln[R]; reads->n_cigar = m_cig[R];
-        reads->cap_recs = reads->n_recs; reads->cap_cigar = reads->n_cigar;           // the merged tables are exactly full
+        if (keep) { reads->cap_recs = reads->d_recs.n - 1; reads->cap_cigar = reads->d_cigar.n - 16; }
+        else { reads->cap_recs = reads->n_recs; reads->cap_cigar = reads->n_cigar; }           // the merged tables are exactly full
         // the pair-alignment arena was sized for the records of lcty_reads_create (same bound as there)
         uint64_t pa_cap = std::min<uint64_t>(static_cast<uint64_t>(LCTY_MAX_USED_ALNS) * reads->cap_pairs * A, 2 * reads->n_recs + reads->cap_pairs) + 64;
         if (reads->pa_pooled) pa_cap += pa_cap / 8 + static_cast<uint64_t>(PA_CHUNK) * PA_MAX_GRID;   // lcty_reads_create

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from locityper_amd import api
 from bench_legs import long_reads as LR
 
-chunk = 8192                                        # reads per streamed chunk of the records form (--chunk N)
+chunk = 32768                                       # reads per streamed chunk (--chunk N): 22 GB of records + CIGARs a chunk at 256 alleles
 if "--chunk" in sys.argv:
     i = sys.argv.index("--chunk"); chunk = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
