@@ -68,3 +68,41 @@ def test_exact_solver_proves_small_models_that_highs_solves_to_optimality():
         ok, h_assgn, h_obj, info = H.solve(a["read_ixs"], a["ln_prob"], a["windows"], gc, w, depth_ln_prob, ac, dc, mip_rel_gap=0.0)
         assert ok, info
         assert g.likelihood(h_assgn)[0] == pytest.approx(value, rel=1e-9, abs=1e-7)
+
+
+def test_single_end_long_reads_against_highs():
+    """Single-end long reads (ONT, 3 000 bases): a location's two windows are one window twice for part of the locations — the `inc = 2`
+    branch of define_model (highs.rs:63-72) — and reads have locations on both alleles plus "both unmapped". The library's solver at the
+    default gap against HiGHS; where it also proves its answer (gap 0), the two optima are one number."""
+    from locityper_amd import cdefs
+    A, n = 6, 400
+    L = synth.SynthLocus(A, n, seed=synth.SEED + 11, technology=cdefs.TECH_NANOPORE, read_len=3000, base_len=40000)
+    p = O.resolve_params(O.default_params(), L.bg)
+    ol = O.OracleLocus(L.seqs, L.seq_off, L.counts, L.cnt_off, L.k, L.bg, p)
+    oa = ol.load(L.reads(0, n))
+    gts = O.generate_genotypes(A, 2)
+    order = np.argsort(-O.run_filter(oa.best_aln_matrix(), gts), kind="stable")
+    lib = O.lib()
+    lib.orc_depth_ln_prob.restype = C.c_double
+    ac, dc = 1.0 - p.lik_skew, 1.0 + p.lik_skew
+    proven = 0
+    for rank in (0, 5, len(gts) - 1):
+        g = O.OracleGtAlns(ol, oa, tuple(int(x) for x in gts[order[rank]]))
+        g.apply_tweak(99 + rank)
+        a = g.arrays()
+        gc, w = g.window_distr()
+        assert np.any(a["windows"][:, 0] == a["windows"][:, 1])
+        m = X.Model(a, gc, w)
+        lut = np.array([[lib.orc_depth_ln_prob(ol._h, gcb, 1.0, d) for d in range(max(m.depth_needed(), 64))] for gcb in range(101)])
+        f = lambda x, d, gc=gc, w=w: lib.orc_depth_ln_prob(ol._h, int(gc[x]), float(w[x]), int(d))
+        ok, h_assgn, _, info = H.solve(a["read_ixs"], a["ln_prob"], a["windows"], gc, w, f, ac, dc, mip_rel_gap=0.0)
+        assert ok, info
+        h_lik = g.likelihood(h_assgn)[0]
+        answered, assgn, value, parts, nodes, n_free = m.solve(lut, ac, dc, rel_gap=1e-4)
+        assert answered and g.likelihood(assgn)[0] == pytest.approx(value, rel=1e-12)
+        assert h_lik - 1e-4 * abs(h_lik) <= value <= h_lik + 1e-9 * abs(h_lik)
+        answered0, _, value0, _, _, _ = m.solve(lut, ac, dc, rel_gap=0.0, node_limit=2_000_000)
+        if answered0:
+            proven += 1
+            assert value0 == pytest.approx(h_lik, rel=1e-9)
+    assert proven >= 2
